@@ -1,0 +1,295 @@
+/*
+ * hppfcl_amd.h -- C ABI of the MI355X batched narrow-phase engine.
+ *
+ * This is the drop-in boundary for hpp-fcl's narrow phase.  hpp-fcl has no FFI
+ * layer of its own; its seam is the C++ pair of free functions
+ *     hpp::fcl::collide (o1, tf1, o2, tf2, CollisionRequest, CollisionResult&)
+ *         -- /root/reference/include/hpp/fcl/collision.h:58-70, src/collision.cpp:69-130
+ *     hpp::fcl::distance(o1, tf1, o2, tf2, DistanceRequest,  DistanceResult&)
+ *         -- include/hpp/fcl/distance.h:53-65,  src/distance.cpp:60-109
+ * and below them the uniform function-pointer signature of the dispatch tables
+ * (include/hpp/fcl/collision_func_matrix.h:61-67).  The entry points declared here
+ * are the *batched* form of exactly those two calls: N independent
+ * (geometry, pose, geometry, pose) queries under one request, N result records.
+ * The header-only shim include/hppfcl_amd_compat.hpp re-exposes them under the
+ * reference's own names (hpp::fcl::collide / distance / CollisionRequest / ...).
+ *
+ * Plain C: pointers and sizes only.  No torch / Eigen / STL types.
+ * All floating point at this boundary is fp64 unless a name ends in _f32.
+ */
+#ifndef HPPFCL_AMD_H
+#define HPPFCL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HFCL_ABI_VERSION 1
+
+/* ---- geometry kinds: numeric values are hpp-fcl's NODE_TYPE
+ *      (include/hpp/fcl/collision_object.h:65-89) so a caller can pass
+ *      CollisionGeometry::getNodeType() straight through. ------------------------ */
+enum {
+  HFCL_BV_OBBRSS     = 5,  /* BVHModel<OBBRSS>                                   */
+  HFCL_GEOM_BOX      = 9,  /* params = halfSide[3]      (geometric_shapes.h:164) */
+  HFCL_GEOM_SPHERE   = 10, /* params[0] = radius        (geometric_shapes.h:238) */
+  HFCL_GEOM_CAPSULE  = 11, /* params[0] = radius, [1] = halfLength (:381-400)    */
+  HFCL_GEOM_CONVEX   = 14, /* num_points vertices at vertex_offset (:638-872)    */
+  HFCL_GEOM_TRIANGLE = 17, /* 3 vertices at vertex_offset (TriangleP, :109)      */
+  HFCL_GEOM_ELLIPSOID= 19  /* params = radii[3]         (geometric_shapes.h:303) */
+};
+
+/* One entry of the shape library.  Mirrors the data members of ShapeBase and its
+ * subclasses that the narrow phase reads (include/hpp/fcl/shape/geometric_shapes.h). */
+typedef struct hfcl_shape {
+  int32_t  type;                /* one of HFCL_GEOM_* / HFCL_BV_OBBRSS                  */
+  uint32_t num_points;          /* CONVEX: #vertices; TRIANGLE: 3; BVH: #vertices        */
+  uint32_t vertex_offset;       /* first vertex in the library vertex array (units: vertices) */
+  uint32_t bvh_index;           /* BVH only: index into the mesh table (hfcl_lib_add_bvh) */
+  double   params[3];
+  double   swept_sphere_radius; /* ShapeBase::getSweptSphereRadius(), geometric_shapes.h:59-102 */
+} hfcl_shape;
+
+/* Pose = memory image of hpp::fcl::Transform3f (include/hpp/fcl/math/transform.h:56-61):
+ * Matrix3f R stored column-major (Eigen default) followed by Vec3f T -> 12 doubles.
+ *   pose[0..8]  = R(0,0) R(1,0) R(2,0) R(0,1) R(1,1) R(2,1) R(0,2) R(1,2) R(2,2)
+ *   pose[9..11] = T
+ * so `reinterpret_cast<const double*>(&tf)` of a std::vector<Transform3f> is valid input. */
+#define HFCL_POSE_DOUBLES 12
+
+/* Compact fp32 pose for the fp32 device-resident path: unit quaternion (w,x,y,z) +
+ * translation = 7 floats = 28 B (SURVEY.md 8d byte accounting). */
+#define HFCL_POSE_F32_FLOATS 7
+
+/* ---- enums of include/hpp/fcl/data_types.h:85-98 (same numeric values) ---------- */
+enum { HFCL_GUESS_DEFAULT = 0, HFCL_GUESS_CACHED = 1, HFCL_GUESS_BOUNDING_VOLUME = 2 };
+enum { HFCL_GJK_DEFAULT = 0, HFCL_GJK_POLYAK = 1, HFCL_GJK_NESTEROV = 2 };
+enum { HFCL_CRIT_DEFAULT = 0, HFCL_CRIT_DUALITY_GAP = 1, HFCL_CRIT_HYBRID = 2 };
+enum { HFCL_CRIT_RELATIVE = 0, HFCL_CRIT_ABSOLUTE = 1 };
+
+/* GJK::Status, include/hpp/fcl/narrowphase/gjk.h:95-102 */
+enum {
+  HFCL_GJK_DID_NOT_RUN = 0, HFCL_GJK_FAILED = 1, HFCL_GJK_NO_COLLISION_EARLY_STOPPED = 2,
+  HFCL_GJK_NO_COLLISION = 3, HFCL_GJK_COLLISION_WITH_PENETRATION_INFORMATION = 4,
+  HFCL_GJK_COLLISION = 5
+};
+/* EPA::Status, gjk.h:330-341 (DidNotRun is -1 there; stored here as 15 in 4 bits) */
+enum {
+  HFCL_EPA_FAILED = 0, HFCL_EPA_VALID = 1, HFCL_EPA_ACCURACY_REACHED = 3,
+  HFCL_EPA_DEGENERATED = 2, HFCL_EPA_NON_CONVEX = 4, HFCL_EPA_INVALID_HULL = 6,
+  HFCL_EPA_OUT_OF_FACES = 8, HFCL_EPA_OUT_OF_VERTICES = 10, HFCL_EPA_FALLBACK = 12,
+  HFCL_EPA_DID_NOT_RUN = 15
+};
+
+/* QueryRequest, include/hpp/fcl/collision_data.h:171-273 (same names, same defaults;
+ * defaults are filled by hfcl_*_request_init). */
+typedef struct hfcl_query_request {
+  int32_t  gjk_initial_guess;               /* DefaultGuess                           */
+  int32_t  gjk_variant;                     /* DefaultGJK                             */
+  int32_t  gjk_convergence_criterion;       /* Default (VDB)                          */
+  int32_t  gjk_convergence_criterion_type;  /* Relative                               */
+  uint32_t gjk_max_iterations;              /* 128  narrowphase_defaults.h:47         */
+  uint32_t epa_max_iterations;              /* 64   narrowphase_defaults.h:60 (device limit: <= 64) */
+  double   gjk_tolerance;                   /* 1e-6                                   */
+  double   epa_tolerance;                   /* 1e-6                                   */
+  double   collision_distance_threshold;    /* Eigen dummy_precision<double> = 1e-12, collision_data.h:236 */
+  double   cached_gjk_guess[3];             /* (1,0,0)                                */
+  int32_t  cached_support_func_guess[2];    /* (0,0)                                  */
+} hfcl_query_request;
+
+/* CollisionRequest, collision_data.h:312-383 */
+typedef struct hfcl_collision_request {
+  hfcl_query_request q;
+  uint32_t num_max_contacts;    /* 1 ; 0 is an error (src/collision.cpp:82-85)          */
+  int32_t  enable_contact;      /* true                                                 */
+  double   security_margin;     /* 0 ; -inf => no test, cleared result (collision.cpp:73) */
+  double   break_distance;      /* 1e-3                                                 */
+  double   distance_upper_bound;/* DBL_MAX                                              */
+} hfcl_collision_request;
+
+/* DistanceRequest, collision_data.h:987-1050 */
+typedef struct hfcl_distance_request {
+  hfcl_query_request q;
+  int32_t  enable_nearest_points;  /* deprecated in the reference; always computed      */
+  int32_t  enable_signed_distance; /* true => EPA on penetration                        */
+  double   rel_err;                /* 0 (BVH distance pruning)                          */
+  double   abs_err;                /* 0                                                 */
+} hfcl_distance_request;
+
+/* Packed per-pair status word (both result formats):
+ *   bits  0..2  gjk status        bits  3..6  epa status (HFCL_EPA_*, 15 = did not run)
+ *   bit   7     contact flag (collide: a Contact was added; distance: min_distance <= 0)
+ *   bits  8..15 gjk iterations    bits 16..22 epa iterations
+ *   bit  23     operands were swapped internally and swapped back
+ *   bit  31     record not computed (unsupported pair / -inf margin)                    */
+#define HFCL_STATUS_GJK(s)       ((s) & 7u)
+#define HFCL_STATUS_EPA(s)       (((s) >> 3) & 15u)
+#define HFCL_STATUS_CONTACT(s)   (((s) >> 7) & 1u)
+#define HFCL_STATUS_GJK_ITERS(s) (((s) >> 8) & 255u)
+#define HFCL_STATUS_EPA_ITERS(s) (((s) >> 16) & 127u)
+#define HFCL_STATUS_SKIPPED(s)   (((s) >> 31) & 1u)
+
+/* One fp64 result record = the fields of DistanceResult (collision_data.h:1053-1174)
+ * or, for collide, of CollisionResult + its (at most one, for shape-shape) Contact
+ * (collision_data.h:59-166, 391-494):
+ *   distance():  min_distance = distance, normal, nearest_points = p1,p2, b1,b2
+ *   collide():   Contact.penetration_depth = distance (NOT margin-adjusted,
+ *                shape_shape_func.h:155), Contact.normal/nearest_points = normal,p1,p2,
+ *                Contact.pos = (p1+p2)/2, CollisionResult.distance_lower_bound =
+ *                distance - security_margin, numContacts() = num_contacts.
+ * World frame; normal points from o1 to o2.  NaN where the reference yields NaN. */
+typedef struct hfcl_result {
+  double   distance;
+  double   normal[3];
+  double   p1[3];
+  double   p2[3];
+  int32_t  b1, b2;          /* Contact::NONE = -1 for primitives; triangle ids for BVH */
+  uint32_t status;          /* packed, see above                                       */
+  int32_t  num_contacts;    /* collide only                                            */
+} hfcl_result;              /* 96 bytes                                                */
+
+/* Compact fp32 record for the fp32 device-resident path: 44 bytes. */
+typedef struct hfcl_result_f32 {
+  float    distance;
+  float    p1[3];
+  float    p2[3];
+  float    normal[3];
+  uint32_t status;
+} hfcl_result_f32;
+
+/* Warm-start cache (QueryRequest::cached_gjk_guess / cached_support_func_guess flowing
+ * request -> solver -> result -> request, src/collision.cpp:125-127). Optional arrays. */
+typedef struct hfcl_guess {
+  double  gjk_guess[3];
+  int32_t support_guess[2];
+} hfcl_guess;
+
+/* A contact of a mesh-mesh collide query (num_max_contacts > 1). */
+typedef struct hfcl_contact {
+  uint32_t pair;            /* index of the query in the batch */
+  int32_t  b1, b2;
+  uint32_t _pad;
+  double   penetration_depth;
+  double   normal[3];
+  double   p1[3];
+  double   p2[3];
+} hfcl_contact;
+
+typedef struct hfcl_lib hfcl_lib;   /* opaque: shape library resident on one GPU */
+
+/* Error codes (the C++ shim maps them back to the exceptions the reference throws). */
+enum {
+  HFCL_OK = 0,
+  HFCL_ERR_INVALID_ARGUMENT = 1,   /* std::invalid_argument in the reference            */
+  HFCL_ERR_UNSUPPORTED_PAIR = 2,   /* "Collision function between node type ... not yet supported" */
+  HFCL_ERR_NO_DEVICE = 3,          /* no HIP device / HIP runtime error: fail loudly     */
+  HFCL_ERR_HIP = 4,
+  HFCL_ERR_LIMIT = 5               /* epa_max_iterations > 64, convex > 64 vertices, ... */
+};
+
+/* ---- library lifetime --------------------------------------------------------------- */
+int  hfcl_abi_version(void);
+/* number of visible HIP devices (0 => every compute entry point returns HFCL_ERR_NO_DEVICE) */
+int  hfcl_device_count(void);
+const char* hfcl_last_error(void);
+
+void hfcl_collision_request_init(hfcl_collision_request* r);
+void hfcl_distance_request_init(hfcl_distance_request* r);
+
+/* Copy the shape table and vertex array (n_vertices x 3 doubles) to `device`.
+ * Returns NULL (and sets hfcl_last_error) on failure -- never a CPU fallback. */
+hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes,
+                          const double* vertices, size_t n_vertices, int device);
+void      hfcl_lib_destroy(hfcl_lib* lib);
+size_t    hfcl_lib_num_shapes(const hfcl_lib* lib);
+int       hfcl_lib_device(const hfcl_lib* lib);
+
+/* Register a BVHModel<OBBRSS> (include/hpp/fcl/BVH/BVH_model.h:66-360, BV_node.h:52-148):
+ * nodes: n_nodes records of 32 doubles in the reference's field order
+ *   [first_child, first_primitive, num_primitives, 0,
+ *    obb.axes(col-major 9), obb.To(3), obb.extent(3),
+ *    rss.axes(col-major 9) -- ignored, shared with obb --, rss.Tr(3), rss.length[2], rss.radius]
+ * (see hfcl_bvh_node below), vertices n_vertices x 3, triangles n_tris x 3 (uint32).
+ * Returns the bvh_index to store in hfcl_shape.bvh_index, or -1. */
+typedef struct hfcl_bvh_node {
+  int32_t first_child;      /* >0: children at first_child, first_child+1; <0: leaf, primitive = -(first_child+1)  (BV_node.h:57-101) */
+  int32_t first_primitive;
+  int32_t num_primitives;
+  int32_t _pad;
+  double  obb_axes[9];      /* column-major, OBB.h:52-126 */
+  double  obb_To[3];
+  double  obb_extent[3];
+  double  rss_axes[9];      /* column-major, RSS.h:54-150 */
+  double  rss_Tr[3];
+  double  rss_length[2];
+  double  rss_radius;
+} hfcl_bvh_node;
+
+int hfcl_lib_add_bvh(hfcl_lib* lib, const hfcl_bvh_node* nodes, size_t n_nodes,
+                     const double* vertices, size_t n_vertices,
+                     const uint32_t* triangles, size_t n_tris);
+
+/* ---- batched queries, host buffers (H2D + kernels + D2H inside the call) ------------
+ * shape1/shape2: n indices into the library; tf1/tf2: n poses (12 doubles each).
+ * guess_in / guess_out: NULL or n records (used when q.gjk_initial_guess == CachedGuess).
+ * Replaces: collide() src/collision.cpp:69-130 ; distance() src/distance.cpp:60-109. */
+int hfcl_collide_batch(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2,
+                       const double* tf1, const double* tf2, size_t n,
+                       const hfcl_collision_request* req, hfcl_result* out,
+                       const hfcl_guess* guess_in, hfcl_guess* guess_out);
+
+int hfcl_distance_batch(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2,
+                        const double* tf1, const double* tf2, size_t n,
+                        const hfcl_distance_request* req, hfcl_result* out,
+                        const hfcl_guess* guess_in, hfcl_guess* guess_out);
+
+/* ---- batched queries, device-resident buffers (no copies; asynchronous on `stream`,
+ * a hipStream_t passed as void*; NULL = the null stream).  All pointers are device
+ * pointers on the library's device.  Same semantics as above. */
+int hfcl_collide_batch_device(hfcl_lib* lib, const uint32_t* d_shape1, const uint32_t* d_shape2,
+                              const double* d_tf1, const double* d_tf2, size_t n,
+                              const hfcl_collision_request* req, hfcl_result* d_out,
+                              const hfcl_guess* d_guess_in, hfcl_guess* d_guess_out,
+                              void* stream);
+
+int hfcl_distance_batch_device(hfcl_lib* lib, const uint32_t* d_shape1, const uint32_t* d_shape2,
+                               const double* d_tf1, const double* d_tf2, size_t n,
+                               const hfcl_distance_request* req, hfcl_result* d_out,
+                               const hfcl_guess* d_guess_in, hfcl_guess* d_guess_out,
+                               void* stream);
+
+/* fp32 compute path (the reference has no fp32; parity = fp32 result vs fp64 oracle within
+ * the tolerance stated in tests/).  Poses are 7-float (quat wxyz + translation) records,
+ * results are 44-byte hfcl_result_f32 records.  Device-resident only. */
+int hfcl_distance_batch_device_f32(hfcl_lib* lib, const uint32_t* d_shape1, const uint32_t* d_shape2,
+                                   const float* d_pose1, const float* d_pose2, size_t n,
+                                   const hfcl_distance_request* req, hfcl_result_f32* d_out,
+                                   void* stream);
+int hfcl_collide_batch_device_f32(hfcl_lib* lib, const uint32_t* d_shape1, const uint32_t* d_shape2,
+                                  const float* d_pose1, const float* d_pose2, size_t n,
+                                  const hfcl_collision_request* req, hfcl_result_f32* d_out,
+                                  void* stream);
+
+/* Mesh-mesh collide with more than one contact: per-pair records as above plus a
+ * compacted contact list (capacity max_contacts_total; *n_contacts_out receives the
+ * number produced; contacts beyond capacity are counted but dropped). Host buffers. */
+int hfcl_collide_batch_contacts(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2,
+                                const double* tf1, const double* tf2, size_t n,
+                                const hfcl_collision_request* req, hfcl_result* out,
+                                hfcl_contact* contacts, size_t max_contacts_total,
+                                size_t* n_contacts_out);
+
+/* ---- instrumentation ---------------------------------------------------------------
+ * Milliseconds the GPU spent in the kernels of the most recent *_device call on this
+ * library (HIP events on the launch stream); synchronises that stream. */
+double hfcl_last_kernel_ms(hfcl_lib* lib);
+/* Name of the dominant kernel of the last call (for matching rocprofv3 output). */
+const char* hfcl_last_kernel_name(hfcl_lib* lib);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPPFCL_AMD_H */

@@ -1,0 +1,153 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path (see vec3.hpp).
+// C entry points (ctypes-friendly) over the fp64 CPU restatement.  Used by tests/, by
+// __graft_entry__.smoke() as the checker, and by bench.py's cpu_baseline leg.
+#include <cstring>
+#include <thread>
+#include <vector>
+#include "bvh.hpp"
+#include "narrowphase.hpp"
+
+using namespace orc;
+
+static Shape make_shape(const hfcl_shape& s, const double* vertices) {
+  Shape r;
+  r.kind = s.type;
+  r.p[0] = s.params[0];
+  r.p[1] = s.params[1];
+  r.p[2] = s.params[2];
+  r.ssr = s.swept_sphere_radius;
+  if (s.type == HFCL_GEOM_CONVEX || s.type == HFCL_GEOM_TRIANGLE) {
+    r.verts = vertices + 3 * size_t(s.vertex_offset);
+    r.nverts = int(s.num_points);
+  }
+  return r;
+}
+
+template <class F>
+static void parallel_for(size_t n, int n_threads, F f) {
+  if (n_threads <= 1 || n < 2) {
+    f(size_t(0), n);
+    return;
+  }
+  std::vector<std::thread> th;
+  size_t chunk = (n + n_threads - 1) / n_threads;
+  for (int t = 0; t < n_threads; ++t) {
+    size_t b = t * chunk, e = std::min(n, b + chunk);
+    if (b >= e) break;
+    th.emplace_back([=] { f(b, e); });
+  }
+  for (auto& t : th) t.join();
+}
+
+extern "C" {
+
+void orc_distance_request_init(hfcl_distance_request* r) { distance_request_defaults(r); }
+void orc_collision_request_init(hfcl_collision_request* r) { collision_request_defaults(r); }
+
+int orc_distance_batch(const hfcl_shape* shapes, size_t n_shapes, const double* vertices, const uint32_t* s1,
+                       const uint32_t* s2, const double* tf1, const double* tf2, size_t n,
+                       const hfcl_distance_request* req, hfcl_result* out, const hfcl_guess* gin, hfcl_guess* gout,
+                       int n_threads) {
+  std::vector<Shape> lib(n_shapes);
+  for (size_t i = 0; i < n_shapes; ++i) lib[i] = make_shape(shapes[i], vertices);
+  int err = 0;
+  parallel_for(n, n_threads, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      int rc = distance_pair(lib[s1[i]], tf_from_abi(tf1 + 12 * i), lib[s2[i]], tf_from_abi(tf2 + 12 * i), *req,
+                             gin ? gin + i : nullptr, out[i], gout ? gout + i : nullptr);
+      if (rc) err = rc;
+    }
+  });
+  return err;
+}
+
+int orc_collide_batch(const hfcl_shape* shapes, size_t n_shapes, const double* vertices, const uint32_t* s1,
+                      const uint32_t* s2, const double* tf1, const double* tf2, size_t n,
+                      const hfcl_collision_request* req, hfcl_result* out, const hfcl_guess* gin, hfcl_guess* gout,
+                      int n_threads) {
+  std::vector<Shape> lib(n_shapes);
+  for (size_t i = 0; i < n_shapes; ++i) lib[i] = make_shape(shapes[i], vertices);
+  int err = 0;
+  parallel_for(n, n_threads, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      int rc = collide_pair(lib[s1[i]], tf_from_abi(tf1 + 12 * i), lib[s2[i]], tf_from_abi(tf2 + 12 * i), *req,
+                            gin ? gin + i : nullptr, out[i], gout ? gout + i : nullptr);
+      if (rc) err = rc;
+    }
+  });
+  return err;
+}
+
+// Raw GJK (+ optional EPA) on a MinkowskiDiff, the level test/gjk.cpp:337-490 exercises.
+//   out[0..2]=w0, [3..5]=w1, [6..8]=normal (shape-0 frame), [9]=gjk.distance, [10..12]=ray,
+//   [13]=epa.depth ; istat[0]=gjk status, [1]=gjk iterations, [2]=epa status (-1 n/a), [3]=epa iterations,
+//   [4]=final simplex rank, [5]=iterations_momentum_stop
+int orc_gjk_raw(const hfcl_shape* s0, const double* v0, const hfcl_shape* s1, const double* v1, const double* tf0,
+                const double* tf1, unsigned gjk_max_it, double gjk_tol, int variant, int criterion, int criterion_type,
+                double distance_upper_bound, const double* guess, int run_epa, unsigned epa_max_it, double epa_tol,
+                const double* epa_guess, double* out, int* istat) {
+  Shape a = make_shape(*s0, v0), b = make_shape(*s1, v1);
+  if (a.verts) a.verts = v0 + 3 * size_t(s0->vertex_offset);
+  if (b.verts) b.verts = v1 + 3 * size_t(s1->vertex_offset);
+  MinkowskiDiff md;
+  md.set(&a, &b, tf_from_abi(tf0), tf_from_abi(tf1));
+  GJK gjk(gjk_max_it, gjk_tol);
+  gjk.gjk_variant = variant;
+  gjk.convergence_criterion = criterion;
+  gjk.convergence_criterion_type = criterion_type;
+  gjk.distance_upper_bound = distance_upper_bound;
+  int hint[2] = {0, 0};
+  GJK::Status st = gjk.evaluate(md, V3(guess[0], guess[1], guess[2]), hint);
+  istat[0] = st;
+  istat[1] = int(gjk.iterations);
+  istat[2] = -1;
+  istat[3] = 0;
+  istat[4] = gjk.simplex.rank;
+  istat[5] = int(gjk.iterations_momentum_stop);
+  V3 w0, w1, n;
+  out[13] = 0;
+  bool use_epa = run_epa && st == GJK::Collision;
+  if (!use_epa) {
+    gjk.get_witness_points_and_normal(md, w0, w1, n);
+  } else {
+    EPA epa(epa_max_it, epa_tol);
+    EPA::Status es = epa.evaluate(gjk, V3(epa_guess[0], epa_guess[1], epa_guess[2]));
+    istat[2] = es;
+    istat[3] = int(epa.iterations);
+    epa.get_witness_points_and_normal(md, w0, w1, n);
+    out[13] = epa.depth;
+  }
+  for (int k = 0; k < 3; ++k) {
+    out[k] = w0[k];
+    out[3 + k] = w1[k];
+    out[6 + k] = n[k];
+    out[10 + k] = gjk.ray[k];
+  }
+  out[9] = gjk.distance;
+  return 0;
+}
+
+// Project::project{Line,Triangle,Tetrahedra}Origin (test/simple.cpp KATs). pts: rank x 3.
+// out: param[4], sqr_distance ; returns encode.
+unsigned orc_project_origin(int rank, const double* pts, double* out) {
+  V3 p[4];
+  for (int i = 0; i < rank; ++i) p[i] = V3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+  ProjectResult r;
+  if (rank == 2) r = project_line_origin(p[0], p[1]);
+  if (rank == 3) r = project_triangle_origin(p[0], p[1], p[2]);
+  if (rank == 4) r = project_tetrahedra_origin(p[0], p[1], p[2], p[3]);
+  for (int i = 0; i < 4; ++i) out[i] = r.param[i];
+  out[4] = r.sqr_distance;
+  return r.encode;
+}
+
+// Support function of one shape (shape frame), for supports KATs.
+void orc_shape_support(const hfcl_shape* s, const double* verts, const double* dir, double* out, int* hint) {
+  Shape a = make_shape(*s, verts);
+  V3 r = shape_support(a, V3(dir[0], dir[1], dir[2]), *hint);
+  out[0] = r.x;
+  out[1] = r.y;
+  out[2] = r.z;
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+"""ctypes binding of oracle/liboracle.so -- the fp64 CPU restatement of the reference.
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product (hpp-fcl_amd/) never imports this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.orc_project_origin.restype = C.c_uint
+    return _LIB
+
+
+def _pkg():
+    import importlib.util
+    import sys
+    if "hppfcl_amd" in sys.modules:
+        return sys.modules["hppfcl_amd"]
+    spec = importlib.util.spec_from_file_location(
+        "hppfcl_amd", os.path.join(_ROOT, "hpp-fcl_amd", "__init__.py"),
+        submodule_search_locations=[os.path.join(_ROOT, "hpp-fcl_amd")])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["hppfcl_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _batch(fn, shapes, verts, s1, s2, tf1, tf2, req, guess_in, want_guess, n_threads):
+    abi = _pkg().abi
+    shapes = np.ascontiguousarray(shapes)
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    s1 = np.ascontiguousarray(s1, dtype=np.uint32)
+    s2 = np.ascontiguousarray(s2, dtype=np.uint32)
+    tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
+    tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
+    n = len(s1)
+    assert len(s2) == n and len(tf1) == n and len(tf2) == n
+    out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    gout = np.zeros(n, dtype=abi.GUESS_DTYPE) if want_guess else None
+    if guess_in is not None:
+        guess_in = np.ascontiguousarray(guess_in, dtype=abi.GUESS_DTYPE)
+    rc = fn(abi.ptr(shapes), C.c_size_t(len(shapes)), abi.ptr(verts), abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1),
+            abi.ptr(tf2), C.c_size_t(n), C.byref(req), abi.ptr(out), abi.ptr(guess_in), abi.ptr(gout),
+            C.c_int(n_threads))
+    return rc, out, gout
+
+
+def distance_batch(shapes, verts, s1, s2, tf1, tf2, req=None, guess_in=None, want_guess=False, n_threads=1):
+    abi = _pkg().abi
+    req = req or abi.default_distance_request()
+    rc, out, gout = _batch(lib().orc_distance_batch, shapes, verts, s1, s2, tf1, tf2, req, guess_in, want_guess,
+                           n_threads)
+    if rc:
+        raise ValueError("oracle distance: error %d" % rc)
+    return (out, gout) if want_guess else out
+
+
+def collide_batch(shapes, verts, s1, s2, tf1, tf2, req=None, guess_in=None, want_guess=False, n_threads=1):
+    abi = _pkg().abi
+    req = req or abi.default_collision_request()
+    rc, out, gout = _batch(lib().orc_collide_batch, shapes, verts, s1, s2, tf1, tf2, req, guess_in, want_guess,
+                           n_threads)
+    if rc:
+        raise ValueError("oracle collide: error %d" % rc)
+    return (out, gout) if want_guess else out
+
+
+def gjk_raw(shape0, verts0, shape1, verts1, tf0, tf1, max_it=128, tol=1e-6, variant=0, criterion=0,
+            criterion_type=0, upper_bound=np.finfo(np.float64).max, guess=(1, 0, 0), run_epa=False,
+            epa_max_it=64, epa_tol=1e-6, epa_guess=(1, 0, 0)):
+    """Raw GJK (+EPA) on one MinkowskiDiff: the level test/gjk.cpp exercises.  shapeN: 1-element SHAPE arrays."""
+    abi = _pkg().abi
+    s0 = np.ascontiguousarray(shape0)
+    s1 = np.ascontiguousarray(shape1)
+    v0 = np.ascontiguousarray(verts0 if verts0 is not None else np.zeros((1, 3)), dtype=np.float64)
+    v1 = np.ascontiguousarray(verts1 if verts1 is not None else np.zeros((1, 3)), dtype=np.float64)
+    tf0 = np.ascontiguousarray(tf0, dtype=np.float64)
+    tf1 = np.ascontiguousarray(tf1, dtype=np.float64)
+    g = np.array(guess, dtype=np.float64)
+    eg = np.array(epa_guess, dtype=np.float64)
+    out = np.zeros(14)
+    istat = np.zeros(6, dtype=np.int32)
+    lib().orc_gjk_raw(abi.ptr(s0), abi.ptr(v0), abi.ptr(s1), abi.ptr(v1), abi.ptr(tf0), abi.ptr(tf1),
+                      C.c_uint(max_it), C.c_double(tol), C.c_int(variant), C.c_int(criterion),
+                      C.c_int(criterion_type), C.c_double(upper_bound), abi.ptr(g), C.c_int(1 if run_epa else 0),
+                      C.c_uint(epa_max_it), C.c_double(epa_tol), abi.ptr(eg), abi.ptr(out), abi.ptr(istat))
+    return dict(w0=out[0:3].copy(), w1=out[3:6].copy(), normal=out[6:9].copy(), distance=out[9],
+                ray=out[10:13].copy(), epa_depth=out[13], gjk_status=int(istat[0]), gjk_iterations=int(istat[1]),
+                epa_status=int(istat[2]), epa_iterations=int(istat[3]), rank=int(istat[4]),
+                momentum_stop=int(istat[5]))
+
+
+def project_origin(points):
+    abi = _pkg().abi
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros(5)
+    enc = lib().orc_project_origin(C.c_int(len(pts)), abi.ptr(pts), abi.ptr(out))
+    return dict(param=out[:4].copy(), sqr_distance=out[4], encode=int(enc))
+
+
+def shape_support(shape, verts, direction):
+    abi = _pkg().abi
+    s = np.ascontiguousarray(shape)
+    v = np.ascontiguousarray(verts if verts is not None else np.zeros((1, 3)), dtype=np.float64)
+    d = np.array(direction, dtype=np.float64)
+    out = np.zeros(3)
+    hint = C.c_int(0)
+    lib().orc_shape_support(abi.ptr(s), abi.ptr(v), abi.ptr(d), abi.ptr(out), C.byref(hint))
+    return out, hint.value
