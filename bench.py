@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py -- queries/second of the batched narrow phase on N MI355X (one process per GPU).
+
+A "step" is one pass of the hot path over one batch of synthetic pairs that is already resident
+in HBM: classify -> GJK kernels -> EPA kernel, through the C ABI's device-resident entry point.
+Default workload = BASELINE.json configs[2] (the configuration north_star's target is quoted on):
+1M Convex-Convex (32-vertex hulls, shared 4096-hull library) distance() queries, signed
+distance (GJK+EPA), Nesterov acceleration, fp32.  `--workload cfg2` runs configs[1]
+(1M Box-Capsule collide(), fp64) instead.
+
+N > 1 (launched by torch.distributed.run): every rank owns its own 1M-pair shard (weak scaling,
+different seed per rank) and the per-shard result records are all-gathered over RCCL/xGMI
+(north_star), overlapped with the next step's kernels on a separate stream.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_pkg  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+# ALGORITHMIC bytes per query (DESIGN.md "Measurement"): compulsory traffic only
+BYTES_PER_QUERY = {
+    "cfg3": 8 + 2 * 28 + 44,   # 2 shape ids + 2 (quat+T) fp32 poses + 44-B fp32 record = 108 B
+    "cfg2": 8 + 2 * 96 + 96,   # 2 shape ids + 2 Transform3f images (fp64) + 96-B fp64 record = 296 B
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
+    ap.add_argument("--pairs", type=int, default=1_000_000, help="pairs per GPU per step")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of result records (N>1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" %
+                             (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = load_pkg()
+    abi, wl = pkg.abi, pkg.workloads
+    n = args.pairs
+    if args.workload == "cfg3":
+        batch = wl.cfg3_convex_convex(n=n, seed=1 + rank)
+        dtype = "f32"
+    else:
+        batch = wl.cfg2_box_capsule(n=n, seed=1 + rank)
+        dtype = "f64"
+    req = wl.make_request(batch, abi)
+    lib = pkg.Library(batch.lib, device=local_rank)
+
+    d_s1 = torch.from_numpy(batch.s1.astype(np.int32)).to(dev)
+    d_s2 = torch.from_numpy(batch.s2.astype(np.int32)).to(dev)
+    if dtype == "f32":
+        d_p1 = torch.from_numpy(batch.pose1_f32).to(dev)
+        d_p2 = torch.from_numpy(batch.pose2_f32).to(dev)
+        rec_words = 11
+        launch = lib.distance_device_f32 if batch.kind == "distance" else lib.collide_device_f32
+    else:
+        d_p1 = torch.from_numpy(batch.tf1).to(dev)
+        d_p2 = torch.from_numpy(batch.tf2).to(dev)
+        rec_words = 24
+        launch = lib.distance_device if batch.kind == "distance" else lib.collide_device
+    outs = [torch.zeros(n * rec_words, dtype=torch.int32, device=dev) for _ in range(2)]
+    gather = world > 1 and not args.no_gather
+    gathered = [torch.empty(world * n * rec_words, dtype=torch.int32, device=dev) for _ in range(2)] if gather else None
+    stream = torch.cuda.current_stream()
+
+    kernel_ms = {}
+
+    def one_step(i, record_times):
+        buf = i & 1
+        launch(d_s1, d_s2, d_p1, d_p2, n, req, outs[buf], stream=stream.cuda_stream)
+        work = None
+        if gather:
+            # results of this step travel over xGMI while the next step's kernels run
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            work = (buf, ev)
+        if record_times:
+            for name, ms in lib.last_kernel_breakdown():  # HIP events on the launch stream
+                kernel_ms.setdefault(name, []).append(ms)
+        return work
+
+    comm_stream = torch.cuda.Stream(device=dev) if gather else None
+    pending = []
+
+    def flush_gather(work):
+        buf, ev = work
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ev)
+            h = dist.all_gather_into_tensor(gathered[buf], outs[buf], async_op=True)
+        return h
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        w = one_step(i, False)
+        if w:
+            flush_gather(w).wait()
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        w = one_step(i, False)
+        if w:
+            if len(pending) >= 2:
+                pending.pop(0).wait()
+            pending.append(flush_gather(w))
+    for h in pending:
+        h.wait()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations (HIP events inside the library, on the launch stream), separate pass so
+    # the event reads do not serialise the timed region
+    for i in range(min(args.steps, 10)):
+        one_step(i, True)
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        res = outs[(args.steps - 1) & 1].cpu().numpy()
+        status = res.view(abi.RESULT_F32_DTYPE if dtype == "f32" else abi.RESULT_DTYPE)["status"]
+        contact_frac = float(abi.status_contact(status).mean())
+        buckets = lib.last_bucket_counts()
+        total_q = args.steps * n * world
+        qps = total_q / elapsed
+        ms_per_step = 1e3 * elapsed / args.steps
+        avg = {k: float(np.mean(v)) for k, v in kernel_ms.items() if np.mean(v) > 0}
+        dominant = max(avg, key=avg.get) if avg else ""
+        bpq = BYTES_PER_QUERY[args.workload]
+        # units the dominant kernel processes in one launch
+        if dominant == "k_epa":
+            units = buckets["epa_queue"]
+        else:
+            units = n
+        dom_ms = avg.get(dominant, float("nan"))
+        achieved = (units * bpq) / (dom_ms * 1e-3) / 1e9 if dom_ms == dom_ms and dom_ms > 0 else None
+        pipeline_ms = float(sum(avg.values()))
+        roofline = {
+            "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+            "bytes_per_query": bpq, "units_per_launch": units, "kernel_ms": dom_ms,
+            "pipeline_ms": pipeline_ms, "pipeline_achieved": (n * bpq) / (pipeline_ms * 1e-3) / 1e9 if pipeline_ms else None,
+            "kernels_ms": avg,
+        }
+        cpu = None
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_binding as ob  # checker/baseline only -- never on the product path
+            ns = min(args.cpu_sample, n)
+            sb = batch.slice(0, ns)
+            fn = ob.distance_batch if sb.kind == "distance" else ob.collide_batch
+            tf1, tf2 = sb.tf1, sb.tf2
+            fn(sb.shapes, sb.verts, sb.s1[:1000], sb.s2[:1000], tf1[:1000], tf2[:1000], req)  # warm-up
+            reps, t_cpu = 0, 0.0
+            while t_cpu < 10.0 and reps < 5:
+                t1 = time.perf_counter()
+                fn(sb.shapes, sb.verts, sb.s1, sb.s2, tf1, tf2, req, n_threads=1)
+                t_cpu += time.perf_counter() - t1
+                reps += 1
+            cores_all = os.cpu_count() or 1
+            t1 = time.perf_counter()
+            fn(sb.shapes, sb.verts, sb.s1, sb.s2, tf1, tf2, req, n_threads=cores_all)
+            t_all = time.perf_counter() - t1
+            cpu = {"value": reps * ns / t_cpu, "unit": "queries/s", "cores": 1, "kind": "port",
+                   "sample": "%d pairs of the same workload x %d repeats, fp64 CPU oracle (oracle/), 1 thread" % (ns, reps),
+                   "all_cores": {"value": ns / t_all, "cores": cores_all}}
+        line = {
+            "metric": "narrow-phase queries/s (collision+distance)", "value": qps, "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": batch.name, "baseline_config": "configs[2]" if args.workload == "cfg3" else "configs[1]",
+                       "pairs_per_gpu_per_step": n, "contact_fraction": contact_frac, "buckets": buckets,
+                       "request": batch.kind, "all_gather_results": bool(gather),
+                       "lane_group_width": int(os.environ.get("HFCL_CVX_W", "8"))},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    lib.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,437 @@
+// hfcl_epa.hpp -- Expanding Polytope Algorithm core for the batched MI355X narrow phase.
+//
+// Behavioural contract: hpp-fcl's details::EPA (/root/reference/src/narrowphase/gjk.cpp:
+// reset :1014-1037, newFace :1068-1138, findClosestFace :1141-1154, evaluate :1156-1316,
+// expand :1361-1449, getWitnessPointsAndNormal :1451-1466) and GJK::encloseOrigin (:437-492).
+//
+// Re-designed for the GPU:
+//   * the polytope (<= 68 vertices, <= 132 faces) lives in a caller-provided scratch block
+//     (LDS on the device), structure-of-arrays, 8-bit indices instead of pointers;
+//   * the hull/stock doubly linked lists of the reference are replaced by an in-hull flag
+//     plus an append stamp: the reference's list order (most recently appended first) only
+//     matters as the tie-break of findClosestFace, which becomes a lane-parallel
+//     arg-min over (d^2 ascending, stamp descending);
+//   * the recursive expand() is an explicit frame stack; encloseOrigin() is an explicit
+//     state machine (both recursions have bounded depth).
+// One polytope is driven by one lane group; all lanes of the group execute the scalar
+// control flow redundantly (uniform LDS addresses broadcast), face scans are split over lanes.
+#pragma once
+#include "hfcl_gjk.hpp"
+
+namespace hfcl {
+
+enum {
+  EPA_FAILED = 0, EPA_VALID = 1, EPA_ACCURACY_REACHED = 3, EPA_DEGENERATED = 2, EPA_NON_CONVEX = 4,
+  EPA_INVALID_HULL = 6, EPA_OUT_OF_FACES = 8, EPA_OUT_OF_VERTICES = 10, EPA_FALLBACK = 12, EPA_DID_NOT_RUN = 15
+};
+
+constexpr int EPA_MAX_ITER = 64;                 // device limit (reference default, narrowphase_defaults.h:60)
+constexpr int EPA_MAX_VERTS = EPA_MAX_ITER + 4;  // gjk.cpp:1020
+constexpr int EPA_MAX_FACES = 2 * EPA_MAX_ITER + 4;  // gjk.cpp:1021
+constexpr int EPA_NULL = 255;
+
+template <typename T>
+struct PW0 {  // simplex-vertex payload: support point on shape 0 (w1 = w0 - w)
+  V3<T> w0;
+};
+
+// Scratch layout (SoA).  sizeof = 68*2*3*T + 132*4*T + 132*10 + 132*2 + 132 + pad
+template <typename T>
+struct EpaScratch {
+  T vw[3][EPA_MAX_VERTS];   // vertex w
+  T v0[3][EPA_MAX_VERTS];   // vertex w0
+  T fn[3][EPA_MAX_FACES];   // face normal
+  T fd[EPA_MAX_FACES];      // face distance
+  uint16_t fstamp[EPA_MAX_FACES];
+  uint8_t fvid[3][EPA_MAX_FACES];
+  uint8_t fadj[3][EPA_MAX_FACES];
+  uint8_t fadje[EPA_MAX_FACES];   // 3 x 2 bits
+  uint8_t fflag[EPA_MAX_FACES];   // bit0 in hull, bit1 ignore
+  uint8_t fpass[EPA_MAX_FACES];
+  uint8_t stock[EPA_MAX_FACES];   // free-face stack
+  uint16_t stack[EPA_MAX_FACES];  // expand() frames: face | edge<<8 | stage<<10
+};
+
+// Lane-group operations.  W = 1 on the host validation build.
+template <int W_>
+struct SerialGroup {
+  static constexpr int W = 1;
+  static HFCL_HD int lane() { return 0; }
+  template <class X> static HFCL_HD X shfl_xor(X v, int) { return v; }
+  static HFCL_HD void sync() {}
+};
+
+template <typename T>
+struct EpaResult {
+  int status;
+  int iterations;
+  V3<T> normal;
+  T depth;
+  // result face (reference order) or single vertex for FallBack
+  V3<T> rw[3], rw0[3];
+};
+
+template <typename T, class Grp>
+struct Epa {
+  EpaScratch<T>* m;
+  T tolerance;
+  int max_iterations;
+  int status;
+  int num_vertices;
+  int hull_count;
+  int stock_top;
+  int stamp;
+
+  HFCL_HD V3<T> vw(int i) const { return mk<T>(m->vw[0][i], m->vw[1][i], m->vw[2][i]); }
+  HFCL_HD V3<T> v0(int i) const { return mk<T>(m->v0[0][i], m->v0[1][i], m->v0[2][i]); }
+  HFCL_HD void set_vert(int i, const V3<T>& w, const V3<T>& w0) {
+    m->vw[0][i] = w.x; m->vw[1][i] = w.y; m->vw[2][i] = w.z;
+    m->v0[0][i] = w0.x; m->v0[1][i] = w0.y; m->v0[2][i] = w0.z;
+  }
+  HFCL_HD V3<T> fn(int f) const { return mk<T>(m->fn[0][f], m->fn[1][f], m->fn[2][f]); }
+  HFCL_HD int adj_edge(int f, int e) const { return (m->fadje[f] >> (2 * e)) & 3; }
+  HFCL_HD void bind(int fa, int ea, int fb, int eb) {  // gjk.h:312-320
+    m->fadje[fa] = uint8_t((m->fadje[fa] & ~(3 << (2 * ea))) | (eb << (2 * ea)));
+    m->fadj[ea][fa] = uint8_t(fb);
+    m->fadje[fb] = uint8_t((m->fadje[fb] & ~(3 << (2 * eb))) | (ea << (2 * eb)));
+    m->fadj[eb][fb] = uint8_t(fa);
+  }
+  HFCL_HD void hull_remove(int f) {
+    m->fflag[f] &= uint8_t(~1);
+    --hull_count;
+    m->stock[stock_top++] = uint8_t(f);
+  }
+
+  HFCL_HD void reset(EpaScratch<T>* mem, int max_it, T tol) {  // :1014-1037
+    m = mem;
+    tolerance = tol;
+    max_iterations = max_it;
+    status = EPA_DID_NOT_RUN;
+    num_vertices = 0;
+    hull_count = 0;
+    stamp = 0;
+    const int nf = 2 * max_it + 4;
+    // face 0 on top of the stock, as in the reference (stock filled in reverse order)
+    for (int i = Grp::lane(); i < nf; i += Grp::W) {
+      m->stock[i] = uint8_t(nf - 1 - i);
+      m->fflag[i] = 0;
+    }
+    stock_top = nf;
+    Grp::sync();
+  }
+
+  // newFace :1068-1138.  Returns face index or EPA_NULL.
+  HFCL_HD int new_face(int ia, int ib, int ic, bool force) {
+    if (stock_top == 0) {
+      status = EPA_OUT_OF_FACES;
+      return EPA_NULL;
+    }
+    const int f = m->stock[--stock_top];
+    ++hull_count;
+    m->fflag[f] = 1;
+    m->fstamp[f] = uint16_t(stamp++);
+    m->fpass[f] = 0;
+    m->fvid[0][f] = uint8_t(ia);
+    m->fvid[1][f] = uint8_t(ib);
+    m->fvid[2][f] = uint8_t(ic);
+    const V3<T> a = vw(ia), b = vw(ib), c = vw(ic);
+    V3<T> n = cross(b - a, c - a);
+    bool keep = false;
+    if (norm(n) > Lim<T>::eps()) {
+      n = normalized(n);
+      const T a_dot_nab = dot(a, cross(b - a, n));
+      const T b_dot_nbc = dot(b, cross(c - b, n));
+      const T c_dot_nca = dot(c, cross(a - c, n));
+      T d;
+      if (a_dot_nab >= -tolerance && b_dot_nbc >= -tolerance && c_dot_nca >= -tolerance) {
+        d = dot(a, n);
+      } else {
+        d = Lim<T>::max();
+        m->fflag[f] = 3;  // in hull + ignore
+      }
+      m->fn[0][f] = n.x; m->fn[1][f] = n.y; m->fn[2][f] = n.z;
+      m->fd[f] = d;
+      if (d >= -tolerance || force)
+        keep = true;
+      else
+        status = EPA_NON_CONVEX;
+    } else {
+      m->fn[0][f] = n.x; m->fn[1][f] = n.y; m->fn[2][f] = n.z;
+      status = EPA_DEGENERATED;
+    }
+    if (keep) return f;
+    hull_remove(f);
+    return EPA_NULL;
+  }
+
+  // findClosestFace :1141-1154: min d^2 over non-ignored hull faces, first in list order
+  // (= largest append stamp) on ties; if every face is ignored: the list head.
+  HFCL_HD int find_closest_face() {
+    Grp::sync();
+    const int nf = 2 * max_iterations + 4;
+    T best = Lim<T>::max();
+    int best_stamp = -1, best_f = EPA_NULL;
+    int head_stamp = -1, head_f = EPA_NULL;
+    for (int f = Grp::lane(); f < nf; f += Grp::W) {
+      const int fl = m->fflag[f];
+      if (!(fl & 1)) continue;
+      const int st = m->fstamp[f];
+      if (st > head_stamp) {
+        head_stamp = st;
+        head_f = f;
+      }
+      if (fl & 2) continue;
+      const T d = m->fd[f];
+      const T sq = d * d;
+      if (sq < best || (sq == best && st > best_stamp && best_f != EPA_NULL)) {
+        best = sq;
+        best_stamp = st;
+        best_f = f;
+      }
+    }
+    for (int msk = 1; msk < Grp::W; msk <<= 1) {
+      const T ob = Grp::shfl_xor(best, msk);
+      const int os = Grp::shfl_xor(best_stamp, msk), of = Grp::shfl_xor(best_f, msk);
+      const int ohs = Grp::shfl_xor(head_stamp, msk), ohf = Grp::shfl_xor(head_f, msk);
+      const bool take = (of != EPA_NULL) && (best_f == EPA_NULL || ob < best || (ob == best && os > best_stamp));
+      if (take) {
+        best = ob;
+        best_stamp = os;
+        best_f = of;
+      }
+      if (ohs > head_stamp) {
+        head_stamp = ohs;
+        head_f = ohf;
+      }
+    }
+    return best_f != EPA_NULL ? best_f : head_f;
+  }
+
+  // expand :1361-1449, explicit stack.  Returns `valid`.
+  HFCL_HD bool expand(int pass, int f0, int e0, int& hz_current, int& hz_first, int& hz_count) {
+    // gjk.cpp:1410-1411: 3*sqrt(DBL_EPSILON) = 4.47e-8 in fp64.  In fp32 the literal formula
+    // would give 1e-3 (three orders above the solver tolerance: expand() then keeps faces the new
+    // vertex is clearly above), while 4.47e-8 is below fp32 round-off for coplanar supports of
+    // flat-faced shapes (degenerate faces).  2e-7 (~1.7 ulp) minimises the mismatch against the
+    // fp64 oracle on the cfg2/cfg3/cfg5 sets.
+const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
+    const int id_w = num_vertices - 1;
+    const V3<T> ww = vw(id_w);
+    int sp = 0;
+    m->stack[sp++] = uint16_t(f0 | (e0 << 8));
+    while (sp > 0) {
+      const unsigned fr = m->stack[sp - 1];
+      const int f = fr & 255, e = (fr >> 8) & 3, stage = (fr >> 10) & 3;
+      const int e1 = (e + 1) % 3, e2 = (e + 2) % 3;
+      if (stage == 0) {
+        if (m->fpass[f] == pass) {
+          status = EPA_INVALID_HULL;
+          return false;
+        }
+        if (dot(fn(f), ww - vw(m->fvid[e][f])) < dummy_precision) {
+          // case 1: the support point is "below" f: new face (f[e1], f[e], w)
+          const int nf = new_face(m->fvid[e1][f], m->fvid[e][f], id_w, false);
+          if (nf == EPA_NULL) return false;
+          bind(nf, 0, f, e);
+          if (hz_current != EPA_NULL)
+            bind(nf, 2, hz_current, 1);
+          else
+            hz_first = nf;
+          hz_current = nf;
+          ++hz_count;
+          --sp;  // return true
+          continue;
+        }
+        // case 2: above f
+        m->fpass[f] = uint8_t(pass);
+        m->stack[sp - 1] = uint16_t(f | (e << 8) | (1 << 10));
+        m->stack[sp++] = uint16_t(m->fadj[e1][f] | (adj_edge(f, e1) << 8));
+      } else if (stage == 1) {
+        m->stack[sp - 1] = uint16_t(f | (e << 8) | (2 << 10));
+        m->stack[sp++] = uint16_t(m->fadj[e2][f] | (adj_edge(f, e2) << 8));
+      } else {
+        hull_remove(f);
+        --sp;
+      }
+    }
+    return true;
+  }
+
+  // GJK::encloseOrigin :437-492 on verts[0..rank) (reference order).  sup(dir) -> (w, w0).
+  template <class Sup>
+  HFCL_HD bool enclose_origin(int& rank, Sup& sup) {
+    const int base = rank;
+    int cnt[4] = {0, 0, 0, 0};
+    bool entering = true;
+    for (;;) {
+      if (entering) {
+        if (rank == 4) {
+          if (habs(triple(vw(0) - vw(3), vw(1) - vw(3), vw(2) - vw(3))) > T(0)) return true;
+          if (base == 4) return false;
+          --rank;  // parent removes the vertex
+          entering = false;
+          continue;
+        }
+        cnt[rank] = 0;
+      }
+      // try the next candidate direction at this level
+      V3<T> dir = mk<T>(T(0), T(0), T(0));
+      bool have = false;
+      while (!have) {
+        const int c = cnt[rank];
+        if (rank == 1) {
+          if (c >= 6) break;
+          const int i = c >> 1;  // both the "+" and the "-" attempt use +e_i (reference quirk :443-448)
+          dir = mk<T>(i == 0 ? T(1) : T(0), i == 1 ? T(1) : T(0), i == 2 ? T(1) : T(0));
+          have = true;
+        } else if (rank == 2) {
+          if (c >= 6) break;
+          const int i = c >> 1;
+          const V3<T> d = vw(1) - vw(0);
+          const V3<T> axis = mk<T>(i == 0 ? T(1) : T(0), i == 1 ? T(1) : T(0), i == 2 ? T(1) : T(0));
+          const V3<T> p = cross(d, axis);
+          if (is_zero(p)) {
+            cnt[rank] = (i + 1) * 2;
+            continue;
+          }
+          dir = (c & 1) ? -p : p;
+          have = true;
+        } else {  // rank 3
+          if (c >= 2) break;
+          const V3<T> axis = cross(vw(1) - vw(0), vw(2) - vw(0));
+          if (is_zero(axis)) {
+            cnt[rank] = 2;
+            continue;
+          }
+          dir = (c & 1) ? -axis : axis;
+          have = true;
+        }
+      }
+      if (!have) {
+        if (rank == base) return false;
+        --rank;
+        entering = false;
+        continue;
+      }
+      ++cnt[rank];
+      V3<T> w, w0;
+      sup(dir, w, w0);
+      Grp::sync();
+      set_vert(rank, w, w0);
+      Grp::sync();
+      ++rank;
+      entering = true;
+    }
+  }
+
+  // EPA::evaluate :1156-1316.  verts[0..rank) must already hold GJK's final simplex in the
+  // reference's order (oldest first).  guess = the vector passed as `guess` to evaluate().
+  template <class Sup>
+  HFCL_HD void evaluate(int rank, const V3<T>& guess, T ssr_sum, Sup& sup, EpaResult<T>& out) {
+    const bool enclosed = enclose_origin(rank, sup);
+    out.iterations = 0;
+    if (rank > 1 && enclosed) {
+      status = EPA_VALID;
+      num_vertices = 4;
+      if (dot(vw(0) - vw(3), cross(vw(1) - vw(3), vw(2) - vw(3))) < T(0)) {
+        const V3<T> a = vw(0), a0 = v0(0), b = vw(1), b0 = v0(1);
+        Grp::sync();
+        set_vert(0, b, b0);
+        set_vert(1, a, a0);
+        Grp::sync();
+      }
+      int t0 = new_face(0, 1, 2, true);
+      int t1 = new_face(1, 0, 3, true);
+      int t2 = new_face(2, 1, 3, true);
+      int t3 = new_face(0, 2, 3, true);
+      if (hull_count == 4) {
+        bind(t0, 0, t1, 0);
+        bind(t0, 1, t2, 0);
+        bind(t0, 2, t3, 0);
+        bind(t1, 1, t3, 2);
+        bind(t1, 2, t2, 1);
+        bind(t2, 2, t3, 1);
+        int closest = find_closest_face();
+        V3<T> outer_n = fn(closest);
+        T outer_d = m->fd[closest];
+        int o0 = m->fvid[0][closest], o1 = m->fvid[1][closest], o2 = m->fvid[2][closest];
+        status = EPA_VALID;
+        int iterations = 0;
+        int pass = 0;
+        for (; iterations < max_iterations; ++iterations) {
+          if (num_vertices >= max_iterations + 4) {
+            status = EPA_OUT_OF_VERTICES;
+            break;
+          }
+          int hz_current = EPA_NULL, hz_first = EPA_NULL, hz_count = 0;
+          const int iw = num_vertices++;
+          m->fpass[closest] = uint8_t(++pass);
+          const V3<T> cn = fn(closest);
+          V3<T> w, w0;
+          sup(cn, w, w0);
+          Grp::sync();
+          set_vert(iw, w, w0);
+          Grp::sync();
+          const V3<T> vf1 = vw(m->fvid[0][closest]), vf2 = vw(m->fvid[1][closest]), vf3 = vw(m->fvid[2][closest]);
+          const T fdist = dot(cn, w - vf1);
+          const T wnorm = norm(w);
+          const T thr = tolerance + tolerance * wnorm;
+          if (fdist <= thr) {
+            status = EPA_ACCURACY_REACHED;
+            break;
+          }
+          if (norm(w - vf1) <= thr || norm(w - vf2) <= thr || norm(w - vf3) <= thr) {
+            status = EPA_ACCURACY_REACHED;
+            break;
+          }
+          bool valid = true;
+          for (int j = 0; j < 3 && valid; ++j)
+            valid = valid && expand(pass, m->fadj[j][closest], adj_edge(closest, j), hz_current, hz_first, hz_count);
+          if (!valid || hz_count < 3) break;
+          bind(hz_first, 2, hz_current, 1);
+          hull_remove(closest);
+          closest = find_closest_face();
+          outer_n = fn(closest);
+          outer_d = m->fd[closest];
+          o0 = m->fvid[0][closest];
+          o1 = m->fvid[1][closest];
+          o2 = m->fvid[2][closest];
+        }
+        status = (iterations < max_iterations) ? status : EPA_FAILED;
+        out.status = status;
+        out.iterations = iterations;
+        out.normal = outer_n;
+        out.depth = outer_d + ssr_sum;
+        out.rw[0] = vw(o0); out.rw[1] = vw(o1); out.rw[2] = vw(o2);
+        out.rw0[0] = v0(o0); out.rw0[1] = v0(o1); out.rw0[2] = v0(o2);
+        return;
+      }
+    }
+    // FallBack :1299-1315
+    status = EPA_FALLBACK;
+    out.status = status;
+    V3<T> n = -guess;
+    const T nl = norm(n);
+    out.normal = (nl > T(0)) ? (n / nl) : mk<T>(T(1), T(0), T(0));
+    out.depth = T(0);
+    out.rw[0] = vw(0);
+    out.rw0[0] = v0(0);
+  }
+};
+
+// EPA::getWitnessPointsAndNormal (:1451-1466) + inflate, shape-0 frame
+template <typename T>
+HFCL_HD void epa_witness_normal(const EpaResult<T>& r, T r0, T r1, V3<T>& w0, V3<T>& w1, V3<T>& normal) {
+  V3<T> w1v[3];
+  for (int i = 0; i < 3; ++i) w1v[i] = r.rw0[i] - r.rw[i];
+  closest_points(3, r.rw, r.rw0, w1v, w0, w1);
+  if (norm(w0 - w1) > Lim<T>::dummy()) {
+    normal = (r.depth >= T(0)) ? normalized(w0 - w1) : normalized(w1 - w0);
+  } else {
+    normal = r.normal;
+  }
+  if (r0 > T(0)) w0 = w0 + r0 * normal;
+  if (r1 > T(0)) w1 = w1 - r1 * normal;
+}
+
+}  // namespace hfcl

@@ -1,0 +1,1066 @@
+// hfcl_kernels.hip -- HIP kernels (gfx950 / CDNA4, wave64) and the C-ABI implementation of
+// include/hppfcl_amd.h.  No CPU fallback anywhere in this file: every compute entry point
+// needs a HIP device and fails loudly without one.
+//
+// Kernel map (pair buckets follow the reference's dispatch table,
+// include/hpp/fcl/internal/shape_shape_func.h:185-211):
+//   k_classify      pair -> bucket lists (wave-aggregated atomics), one pass over the shape ids
+//   k_closed<T>     sphere-sphere / sphere-capsule / capsule-capsule / box-sphere, one pair per lane
+//   k_gjk_prim<T>   GJK for Box/Capsule/Ellipsoid/Sphere pairs, one pair per lane (no vertices to share)
+//   k_gjk_cvx<T,W,M> GJK with convex hulls: one pair per W-lane group, hull vertices distributed
+//                   over the group's registers, support = per-lane dots + xor-butterfly arg-max
+//   k_epa<T>        EPA on the pairs GJK left in `Collision`: one pair per wavefront, polytope in LDS
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/hppfcl_amd.h"
+#include "hfcl_pair.hpp"
+
+using namespace hfcl;
+
+// ---------------------------------------------------------------------------------------
+// bucket ids (finer than hfcl_shapes.hpp's pair_class: the convex bucket is split by which
+// side carries vertices so the kernel is specialised at compile time)
+// ---------------------------------------------------------------------------------------
+enum { B_CLOSED = 0, B_PRIM = 1, B_CC = 2, B_PC = 3, B_CP = 4, B_BVH = 5, B_UNSUPPORTED = 6, B_COUNT = 7 };
+
+__host__ __device__ inline int bucket_of(int k1, int k2) {
+  const int c = pair_class(k1, k2);
+  if (c == CLS_CLOSED) return B_CLOSED;
+  if (c == CLS_PRIM_GJK) return B_PRIM;
+  if (c == CLS_BVH) return B_BVH;
+  if (c == CLS_CONVEX) {
+    if (k1 == K_CONVEX && k2 == K_CONVEX) return B_CC;
+    return (k1 == K_CONVEX) ? B_CP : B_PC;
+  }
+  return B_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel parameter blocks
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct LibView {
+  const DShape<T>* shapes;
+  const T* verts;
+  const uint8_t* kinds;
+  uint32_t n_shapes;
+};
+
+template <typename T> struct IO;
+template <> struct IO<double> {
+  const double* tf1;
+  const double* tf2;
+  hfcl_result* out;
+  const hfcl_guess* gin;
+  hfcl_guess* gout;
+};
+template <> struct IO<float> {
+  const float* tf1;
+  const float* tf2;
+  hfcl_result_f32* out;
+  const hfcl_guess* gin;  // unused
+  hfcl_guess* gout;       // unused
+};
+
+template <typename T> using EpaItem = EpaSeed<T>;
+
+struct Work {
+  const uint32_t* shape1;
+  const uint32_t* shape2;
+  uint32_t n;
+  uint32_t* lists;   // B_COUNT lists of capacity n each
+  uint32_t* counts;  // B_COUNT counters + [B_COUNT] = epa queue length
+  void* epa_queue;
+};
+
+__device__ __forceinline__ Pose<double> load_pose(const double* base, uint32_t i) { return pose_from_abi<double>(base + 12 * size_t(i)); }
+__device__ __forceinline__ Pose<float> load_pose(const float* base, uint32_t i) { return pose_from_quat<float>(base + 7 * size_t(i)); }
+
+// One finished query -> result record (tail of ShapeShapeDistancer::run / ShapeShapeCollider::run).
+__device__ __forceinline__ void store_record(const IO<double>& io, uint32_t pair, const PairOut<double>& o, bool contact,
+                                             int nc) {
+  hfcl_result r;
+  r.distance = o.distance;
+  r.normal[0] = o.normal.x; r.normal[1] = o.normal.y; r.normal[2] = o.normal.z;
+  r.p1[0] = o.p1.x; r.p1[1] = o.p1.y; r.p1[2] = o.p1.z;
+  r.p2[0] = o.p2.x; r.p2[1] = o.p2.y; r.p2[2] = o.p2.z;
+  r.b1 = -1;
+  r.b2 = -1;
+  r.status = pack_status(o.gjk_status, o.epa_status, contact, o.gjk_iters, o.epa_iters);
+  r.num_contacts = nc;
+  io.out[pair] = r;
+}
+__device__ __forceinline__ void store_record(const IO<float>& io, uint32_t pair, const PairOut<float>& o, bool contact,
+                                             int) {
+  hfcl_result_f32 r;
+  r.distance = o.distance;
+  r.p1[0] = o.p1.x; r.p1[1] = o.p1.y; r.p1[2] = o.p1.z;
+  r.p2[0] = o.p2.x; r.p2[1] = o.p2.y; r.p2[2] = o.p2.z;
+  r.normal[0] = o.normal.x; r.normal[1] = o.normal.y; r.normal[2] = o.normal.z;
+  r.status = pack_status(o.gjk_status, o.epa_status, contact, o.gjk_iters, o.epa_iters);
+  io.out[pair] = r;
+}
+template <typename T>
+__device__ __forceinline__ void write_out(const IO<T>& io, const QParams<T>& q, uint32_t pair, PairOut<T> o) {
+  int nc;
+  const bool contact = apply_query_semantics(q, o, nc);
+  store_record(io, pair, o, contact, nc);
+}
+
+template <typename T>
+__device__ __forceinline__ void write_guess(const IO<T>&, uint32_t, const V3<T>&, int, int) {}
+template <>
+__device__ __forceinline__ void write_guess<double>(const IO<double>& io, uint32_t pair, const V3<double>& g, int h0, int h1) {
+  if (io.gout) {
+    hfcl_guess r;
+    r.gjk_guess[0] = g.x; r.gjk_guess[1] = g.y; r.gjk_guess[2] = g.z;
+    r.support_guess[0] = h0;
+    r.support_guess[1] = h1;
+    io.gout[pair] = r;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ V3<T> initial_guess(const IO<T>& io, const QParams<T>& q, uint32_t pair) {
+  if (q.guess_mode == HFCL_GUESS_CACHED) return mk<T>(q.guess[0], q.guess[1], q.guess[2]);
+  return mk<T>(T(1), T(0), T(0));
+}
+template <>
+__device__ __forceinline__ V3<double> initial_guess<double>(const IO<double>& io, const QParams<double>& q, uint32_t pair) {
+  if (q.guess_mode == HFCL_GUESS_CACHED) {
+    if (io.gin) return mk<double>(io.gin[pair].gjk_guess[0], io.gin[pair].gjk_guess[1], io.gin[pair].gjk_guess[2]);
+    return mk<double>(q.guess[0], q.guess[1], q.guess[2]);
+  }
+  return mk<double>(1.0, 0.0, 0.0);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_classify: bucket every pair by (kind1, kind2).  Wave-aggregated list append.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_classify(Work wk, const uint8_t* kinds, uint32_t n_shapes) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t n_round = (wk.n + 63u) & ~63u;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    int b = -1;
+    if (i < wk.n) {
+      const uint32_t s1 = wk.shape1[i], s2 = wk.shape2[i];
+      b = (s1 < n_shapes && s2 < n_shapes) ? bucket_of(kinds[s1], kinds[s2]) : B_UNSUPPORTED;
+    }
+    for (int c = 0; c < B_COUNT; ++c) {
+      const unsigned long long m = __ballot(b == c);
+      if (m == 0ull) continue;
+      uint32_t base = 0;
+      const int leader = __ffsll((long long)m) - 1;
+      const int lane = threadIdx.x & 63;
+      if (lane == leader) base = atomicAdd(&wk.counts[c], (uint32_t)__popcll(m));
+      base = __shfl(base, leader, 64);
+      if (b == c) {
+        const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+        wk.lists[size_t(c) * wk.n + base + rank] = i;
+      }
+    }
+  }
+}
+
+// pairs the engine cannot evaluate: flagged, never silently computed elsewhere
+template <typename T>
+__global__ void __launch_bounds__(256) k_unsupported(Work wk, IO<T> io) {
+  const uint32_t cnt = wk.counts[B_UNSUPPORTED];
+  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
+    const uint32_t pair = wk.lists[size_t(B_UNSUPPORTED) * wk.n + it];
+    auto r = io.out[pair];
+    memset(&r, 0, sizeof(r));
+    r.status = 0x80000000u;
+    io.out[pair] = r;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_closed: closed-form pairs, one pair per lane.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_closed(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  const uint32_t cnt = wk.counts[B_CLOSED];
+  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
+    const uint32_t pair = wk.lists[size_t(B_CLOSED) * wk.n + it];
+    const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    PairOut<T> o;
+    o.distance = closed_form_distance(a, tf1, b, tf2, o.p1, o.p2, o.normal);
+    o.gjk_status = GJK_DID_NOT_RUN;
+    o.epa_status = EPA_DID_NOT_RUN;
+    o.gjk_iters = o.epa_iters = 0;
+    write_out<T>(io, q, pair, o);
+    // the closed forms never touch the solver's cached guess: it stays at its initial value
+    write_guess<T>(io, pair, initial_guess<T>(io, q, pair), 0, 0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Shared GJK epilogue: final record, or hand-off to k_epa through the device queue.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void finish_gjk(const Gjk<T, PW0<T>>& g, const Work& wk, const IO<T>& io, const QParams<T>& q,
+                                           uint32_t pair, const Pose<T>& tf1, T r0, T r1, const V3<T>& guess0,
+                                           bool writer) {
+  PairOut<T> o;
+  EpaSeed<T> seed;
+  const bool to_epa = gjk_finish(g, q, tf1, r0, r1, guess0, o, seed);
+  if (!writer) return;
+  if (to_epa) {
+    const uint32_t slot = atomicAdd(&wk.counts[B_COUNT], 1u);
+    seed.pair = pair;
+    reinterpret_cast<EpaSeed<T>*>(wk.epa_queue)[slot] = seed;
+  } else {
+    write_out<T>(io, q, pair, o);
+    write_guess<T>(io, pair, o.cached_guess, 0, 0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_gjk_prim: primitive x primitive GJK, one pair per lane.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_gjk_prim(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  const uint32_t cnt = wk.counts[B_PRIM];
+  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
+    const uint32_t pair = wk.lists[size_t(B_PRIM) * wk.n + it];
+    const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    SerialSupport<T> sup;
+    sup.a = a;
+    sup.b = b;
+    sup.va = sup.vb = nullptr;
+    sup.md = make_mdiff(tf1, tf2);
+    const T r0 = swept_radius(a), r1 = swept_radius(b);
+    const V3<T> guess0 = initial_guess<T>(io, q, pair);
+    Gjk<T, PW0<T>> g;
+    gjk_run(g, q.gjk, guess0, r0 + r1, false, sup);
+    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, true);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Convex hull held by a W-lane group: lane l owns vertices [l*VPL, (l+1)*VPL).
+// getShapeSupportLinear (support_functions.cpp:400-421): first index of the maximum dot.
+// ---------------------------------------------------------------------------------------
+constexpr int HULL_MAX = 32;  // ConvexBase::num_vertices_large_convex_threshold (geometric_shapes.h:709)
+
+template <typename T, int W>
+struct HullRegs {
+  static constexpr int VPL = (HULL_MAX + W - 1) / W;
+  V3<T> v[VPL];
+
+  __device__ __forceinline__ void load(const T* verts, uint32_t n, int lig) {
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      uint32_t idx = uint32_t(lig * VPL + k);
+      idx = idx < n ? idx : 0u;  // padding duplicates vertex 0 (never wins the first-index tie-break)
+      const T* p = verts + 3 * size_t(idx);
+      v[k] = mk<T>(p[0], p[1], p[2]);
+    }
+  }
+  __device__ __forceinline__ V3<T> support(const V3<T>& dir, int lig) const {
+    T best = dot(v[0], dir);
+    int bi = lig * VPL;
+#pragma unroll
+    for (int k = 1; k < VPL; ++k) {
+      const T d = dot(v[k], dir);
+      if (d > best) {
+        best = d;
+        bi = lig * VPL + k;
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < W; m <<= 1) {
+      const T od = __shfl_xor(best, m, W);
+      const int oi = __shfl_xor(bi, m, W);
+      if (od > best || (od == best && oi < bi)) {
+        best = od;
+        bi = oi;
+      }
+    }
+    const int owner = bi / VPL, slot = bi % VPL;
+    V3<T> c = v[0];
+#pragma unroll
+    for (int k = 1; k < VPL; ++k)
+      if (slot == k) c = v[k];
+    return mk<T>(__shfl(c.x, owner, W), __shfl(c.y, owner, W), __shfl(c.z, owner, W));
+  }
+};
+
+// M: 0 = convex-convex, 1 = prim-convex, 2 = convex-prim
+template <typename T, int W, int M>
+struct CvxSupport {
+  DShape<T> a, b;
+  HullRegs<T, W> h0, h1;
+  MDiff<T> md;
+  int lig;
+  __device__ __forceinline__ void eval(const V3<T>& dir, V3<T>& w, V3<T>& w0) const {
+    if (M == 1)
+      w0 = prim_support(a, dir);
+    else
+      w0 = h0.support(dir, lig);
+    const V3<T> d1 = md.identity ? -dir : -tmul(md.oR1, dir);
+    V3<T> s1;
+    if (M == 2)
+      s1 = prim_support(b, d1);
+    else
+      s1 = h1.support(d1, lig);
+    s1 = md.identity ? s1 : (mul(md.oR1, s1) + md.ot1);
+    w = w0 - s1;
+  }
+  __device__ __forceinline__ void operator()(const V3<T>& dir, V3<T>& w, V3<T>& w0) const { eval(dir, w, w0); }
+};
+
+template <typename T, int W, int M>
+__global__ void __launch_bounds__(256) k_gjk_cvx(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  constexpr int BUCKET = (M == 0) ? B_CC : (M == 1 ? B_PC : B_CP);
+  const uint32_t cnt = wk.counts[BUCKET];
+  const int lig = threadIdx.x & (W - 1);
+  const uint32_t groups = (gridDim.x * blockDim.x) / W;
+  for (uint32_t it = (blockIdx.x * blockDim.x + threadIdx.x) / W; it < cnt; it += groups) {
+    const uint32_t pair = wk.lists[size_t(BUCKET) * wk.n + it];
+    CvxSupport<T, W, M> sup;
+    sup.a = lib.shapes[wk.shape1[pair]];
+    sup.b = lib.shapes[wk.shape2[pair]];
+    sup.lig = lig;
+    if (M != 1) sup.h0.load(lib.verts + 3 * size_t(sup.a.vertex_offset), sup.a.num_points, lig);
+    if (M != 2) sup.h1.load(lib.verts + 3 * size_t(sup.b.vertex_offset), sup.b.num_points, lig);
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    sup.md = make_mdiff(tf1, tf2);
+    const T r0 = swept_radius(sup.a), r1 = swept_radius(sup.b);
+    const V3<T> guess0 = initial_guess<T>(io, q, pair);
+    Gjk<T, PW0<T>> g;
+    // normalize_support_direction only when both are ConvexBase (minkowski_difference.cpp:261-266)
+    gjk_run(g, q.gjk, guess0, r0 + r1, M == 0, sup);
+    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_epa: one queued pair per wavefront, polytope in LDS.
+// ---------------------------------------------------------------------------------------
+struct WaveGroup {
+  static constexpr int W = 64;
+  static __device__ __forceinline__ int lane() { return threadIdx.x & 63; }
+  template <class X> static __device__ __forceinline__ X shfl_xor(X v, int m) { return __shfl_xor(v, m, 64); }
+  static __device__ __forceinline__ void sync() { __builtin_amdgcn_wave_barrier(); }
+};
+
+template <typename T>
+struct EpaSupport {  // any pair kind, evaluated by a whole wave
+  DShape<T> a, b;
+  HullRegs<T, 64> h0, h1;
+  MDiff<T> md;
+  int lane;
+  __device__ __forceinline__ void operator()(const V3<T>& dir, V3<T>& w, V3<T>& w0) const {
+    if (a.kind == K_CONVEX)
+      w0 = h0.support(dir, lane);
+    else
+      w0 = prim_support(a, dir);
+    const V3<T> d1 = md.identity ? -dir : -tmul(md.oR1, dir);
+    V3<T> s1;
+    if (b.kind == K_CONVEX)
+      s1 = h1.support(d1, lane);
+    else
+      s1 = prim_support(b, d1);
+    s1 = md.identity ? s1 : (mul(md.oR1, s1) + md.ot1);
+    w = w0 - s1;
+  }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  __shared__ EpaScratch<T> scratch[4];
+  const uint32_t cnt = wk.counts[B_COUNT];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t waves = gridDim.x * 4;
+  const EpaItem<T>* queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
+  for (uint32_t it = blockIdx.x * 4 + wave; it < cnt; it += waves) {
+    const EpaItem<T> item = queue[it];
+    const uint32_t pair = item.pair;
+    EpaSupport<T> sup;
+    sup.a = lib.shapes[wk.shape1[pair]];
+    sup.b = lib.shapes[wk.shape2[pair]];
+    sup.lane = lane;
+    if (sup.a.kind == K_CONVEX) sup.h0.load(lib.verts + 3 * size_t(sup.a.vertex_offset), sup.a.num_points, lane);
+    if (sup.b.kind == K_CONVEX) sup.h1.load(lib.verts + 3 * size_t(sup.b.vertex_offset), sup.b.num_points, lane);
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    sup.md = make_mdiff(tf1, tf2);
+    const T r0 = swept_radius(sup.a), r1 = swept_radius(sup.b);
+
+    PairOut<T> o;
+    epa_run<T, WaveGroup>(&scratch[wave], item, q, tf1, r0, r1, sup, o);
+    if (lane == 0) {
+      write_out<T>(io, q, pair, o);
+      write_guess<T>(io, pair, o.cached_guess, 0, 0);
+    }
+    WaveGroup::sync();
+  }
+}
+
+// =======================================================================================
+// Host side: library object + C ABI
+// =======================================================================================
+static thread_local std::string g_last_error;
+static void set_error(const std::string& s) { g_last_error = s; }
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                           \
+      return HFCL_ERR_HIP;                                                                    \
+    }                                                                                         \
+  } while (0)
+
+struct KernelTime {
+  const char* name;
+  hipEvent_t e0, e1;
+  bool used;
+};
+
+struct hfcl_lib {
+  int device = 0;
+  size_t n_shapes = 0;
+  std::vector<hfcl_shape> h_shapes;
+  DShape<double>* d_shapes64 = nullptr;
+  DShape<float>* d_shapes32 = nullptr;
+  double* d_verts64 = nullptr;
+  float* d_verts32 = nullptr;
+  uint8_t* d_kinds = nullptr;
+  // workspace (grown on demand)
+  size_t ws_capacity = 0;  // pairs
+  uint32_t* d_lists = nullptr;
+  uint32_t* d_counts = nullptr;
+  void* d_epa_queue = nullptr;
+  // host-call staging buffers
+  size_t st_capacity = 0;
+  uint32_t *d_s1 = nullptr, *d_s2 = nullptr;
+  double *d_tf1 = nullptr, *d_tf2 = nullptr;
+  hfcl_result* d_out = nullptr;
+  hfcl_guess *d_gin = nullptr, *d_gout = nullptr;
+  // instrumentation
+  std::vector<KernelTime> timers;
+  int cvx_w = 8;
+  int n_cus = 256;
+  std::string dominant;
+  uint32_t h_counts[B_COUNT + 1] = {0};
+};
+
+static int ensure_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    set_error("no HIP device available (hipGetDeviceCount): the engine has no CPU fallback");
+    return HFCL_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    set_error("device index out of range");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(device));
+  return HFCL_OK;
+}
+
+extern "C" {
+
+int hfcl_abi_version(void) { return HFCL_ABI_VERSION; }
+int hfcl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+const char* hfcl_last_error(void) { return g_last_error.c_str(); }
+
+static void query_defaults(hfcl_query_request* q) {
+  q->gjk_initial_guess = HFCL_GUESS_DEFAULT;
+  q->gjk_variant = HFCL_GJK_DEFAULT;
+  q->gjk_convergence_criterion = HFCL_CRIT_DEFAULT;
+  q->gjk_convergence_criterion_type = HFCL_CRIT_RELATIVE;
+  q->gjk_max_iterations = 128;
+  q->epa_max_iterations = 64;
+  q->gjk_tolerance = 1e-6;
+  q->epa_tolerance = 1e-6;
+  q->collision_distance_threshold = 1e-12;
+  q->cached_gjk_guess[0] = 1.0;
+  q->cached_gjk_guess[1] = 0.0;
+  q->cached_gjk_guess[2] = 0.0;
+  q->cached_support_func_guess[0] = 0;
+  q->cached_support_func_guess[1] = 0;
+}
+void hfcl_collision_request_init(hfcl_collision_request* r) {
+  memset(r, 0, sizeof(*r));
+  query_defaults(&r->q);
+  r->num_max_contacts = 1;
+  r->enable_contact = 1;
+  r->security_margin = 0.0;
+  r->break_distance = 1e-3;
+  r->distance_upper_bound = 1.7976931348623157e+308;
+}
+void hfcl_distance_request_init(hfcl_distance_request* r) {
+  memset(r, 0, sizeof(*r));
+  query_defaults(&r->q);
+  r->enable_nearest_points = 1;
+  r->enable_signed_distance = 1;
+  r->rel_err = 0.0;
+  r->abs_err = 0.0;
+}
+
+hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const double* vertices, size_t n_vertices,
+                          int device) {
+  if (ensure_device(device) != HFCL_OK) return nullptr;
+  if (!shapes || n_shapes == 0) {
+    set_error("hfcl_lib_create: empty shape table");
+    return nullptr;
+  }
+  for (size_t i = 0; i < n_shapes; ++i) {
+    const hfcl_shape& s = shapes[i];
+    const bool ok_kind = s.type == HFCL_GEOM_BOX || s.type == HFCL_GEOM_SPHERE || s.type == HFCL_GEOM_CAPSULE ||
+                         s.type == HFCL_GEOM_ELLIPSOID || s.type == HFCL_GEOM_CONVEX || s.type == HFCL_BV_OBBRSS ||
+                         s.type == HFCL_GEOM_TRIANGLE;
+    if (!ok_kind) {
+      set_error("hfcl_lib_create: unsupported shape type " + std::to_string(s.type));
+      return nullptr;
+    }
+    if (s.type == HFCL_GEOM_CONVEX) {
+      if (s.num_points == 0 || s.num_points > (uint32_t)HULL_MAX) {
+        set_error("hfcl_lib_create: convex shapes must have 1.." + std::to_string(HULL_MAX) +
+                  " vertices (linear-support path, support_functions.cpp:400-421); got " +
+                  std::to_string(s.num_points));
+        return nullptr;
+      }
+      if (size_t(s.vertex_offset) + s.num_points > n_vertices) {
+        set_error("hfcl_lib_create: convex vertex range out of bounds");
+        return nullptr;
+      }
+    }
+  }
+  hfcl_lib* lib = new hfcl_lib();
+  lib->device = device;
+  lib->n_shapes = n_shapes;
+  lib->h_shapes.assign(shapes, shapes + n_shapes);
+  std::vector<DShape<double>> s64(n_shapes);
+  std::vector<DShape<float>> s32(n_shapes);
+  std::vector<uint8_t> kinds(n_shapes);
+  for (size_t i = 0; i < n_shapes; ++i) {
+    const hfcl_shape& s = shapes[i];
+    s64[i].kind = s.type;
+    s64[i].num_points = s.num_points;
+    s64[i].vertex_offset = s.vertex_offset;
+    s64[i].bvh_index = s.bvh_index;
+    s64[i].p0 = s.params[0];
+    s64[i].p1 = s.params[1];
+    s64[i].p2 = s.params[2];
+    s64[i].ssr = s.swept_sphere_radius;
+    s32[i].kind = s.type;
+    s32[i].num_points = s.num_points;
+    s32[i].vertex_offset = s.vertex_offset;
+    s32[i].bvh_index = s.bvh_index;
+    s32[i].p0 = float(s.params[0]);
+    s32[i].p1 = float(s.params[1]);
+    s32[i].p2 = float(s.params[2]);
+    s32[i].ssr = float(s.swept_sphere_radius);
+    kinds[i] = uint8_t(s.type);
+  }
+  std::vector<float> v32(3 * n_vertices + 3);
+  for (size_t i = 0; i < 3 * n_vertices; ++i) v32[i] = float(vertices[i]);
+  bool ok = true;
+  ok = ok && hipMalloc(&lib->d_shapes64, n_shapes * sizeof(DShape<double>)) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_shapes32, n_shapes * sizeof(DShape<float>)) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_kinds, n_shapes) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_verts64, (3 * n_vertices + 3) * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_verts32, (3 * n_vertices + 3) * sizeof(float)) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_counts, (B_COUNT + 1) * sizeof(uint32_t)) == hipSuccess;
+  if (ok) {
+    ok = ok && hipMemcpy(lib->d_shapes64, s64.data(), n_shapes * sizeof(DShape<double>), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(lib->d_shapes32, s32.data(), n_shapes * sizeof(DShape<float>), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(lib->d_kinds, kinds.data(), n_shapes, hipMemcpyHostToDevice) == hipSuccess;
+    if (n_vertices) {
+      ok = ok && hipMemcpy(lib->d_verts64, vertices, 3 * n_vertices * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+      ok = ok && hipMemcpy(lib->d_verts32, v32.data(), 3 * n_vertices * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    }
+  }
+  if (!ok) {
+    set_error("hfcl_lib_create: HIP allocation/copy failed");
+    hfcl_lib_destroy(lib);
+    return nullptr;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) lib->n_cus = prop.multiProcessorCount;
+  if (const char* w = getenv("HFCL_CVX_W")) {
+    int v = atoi(w);
+    if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) lib->cvx_w = v;
+  }
+  return lib;
+}
+
+void hfcl_lib_destroy(hfcl_lib* lib) {
+  if (!lib) return;
+  hipSetDevice(lib->device);
+  hipFree(lib->d_shapes64);
+  hipFree(lib->d_shapes32);
+  hipFree(lib->d_kinds);
+  hipFree(lib->d_verts64);
+  hipFree(lib->d_verts32);
+  hipFree(lib->d_counts);
+  hipFree(lib->d_lists);
+  hipFree(lib->d_epa_queue);
+  hipFree(lib->d_s1);
+  hipFree(lib->d_s2);
+  hipFree(lib->d_tf1);
+  hipFree(lib->d_tf2);
+  hipFree(lib->d_out);
+  hipFree(lib->d_gin);
+  hipFree(lib->d_gout);
+  for (auto& t : lib->timers) {
+    hipEventDestroy(t.e0);
+    hipEventDestroy(t.e1);
+  }
+  delete lib;
+}
+size_t hfcl_lib_num_shapes(const hfcl_lib* lib) { return lib ? lib->n_shapes : 0; }
+int hfcl_lib_device(const hfcl_lib* lib) { return lib ? lib->device : -1; }
+
+int hfcl_lib_add_bvh(hfcl_lib*, const hfcl_bvh_node*, size_t, const double*, size_t, const uint32_t*, size_t) {
+  set_error("hfcl_lib_add_bvh: BVHModel<OBBRSS> traversal is not built yet (SURVEY.md 8a rows a15-a19)");
+  return -1;
+}
+
+}  // extern "C"
+
+static int ensure_workspace(hfcl_lib* lib, size_t n) {
+  if (n <= lib->ws_capacity) return HFCL_OK;
+  size_t cap = n + n / 8 + 1024;
+  hipFree(lib->d_lists);
+  hipFree(lib->d_epa_queue);
+  lib->d_lists = nullptr;
+  lib->d_epa_queue = nullptr;
+  lib->ws_capacity = 0;
+  HIP_TRY(hipMalloc(&lib->d_lists, size_t(B_COUNT) * cap * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&lib->d_epa_queue, cap * sizeof(EpaItem<double>)));
+  lib->ws_capacity = cap;
+  return HFCL_OK;
+}
+
+static KernelTime* timer_slot(hfcl_lib* lib, size_t i, const char* name) {
+  while (lib->timers.size() <= i) {
+    KernelTime t;
+    t.name = "";
+    t.used = false;
+    hipEventCreate(&t.e0);
+    hipEventCreate(&t.e1);
+    lib->timers.push_back(t);
+  }
+  lib->timers[i].name = name;
+  lib->timers[i].used = true;
+  return &lib->timers[i];
+}
+
+template <typename T>
+static void fill_qparams(QParams<T>& q, const hfcl_query_request& r) {
+  q.gjk.tolerance = T(r.gjk_tolerance);
+  q.gjk.max_iterations = r.gjk_max_iterations;
+  q.gjk.variant = r.gjk_variant;
+  q.gjk.crit = r.gjk_convergence_criterion;
+  q.gjk.crit_type = r.gjk_convergence_criterion_type;
+  q.epa_tolerance = T(r.epa_tolerance);
+  q.epa_max_iterations = int(r.epa_max_iterations);
+  q.collision_distance_threshold = T(r.collision_distance_threshold);
+  q.guess_mode = r.gjk_initial_guess;
+  q.guess[0] = T(r.cached_gjk_guess[0]);
+  q.guess[1] = T(r.cached_gjk_guess[1]);
+  q.guess[2] = T(r.cached_gjk_guess[2]);
+}
+
+static int validate_query(const hfcl_query_request& q) {
+  if (!(q.gjk_tolerance > 0) || !(q.epa_tolerance > 0)) {
+    set_error("tolerance must be positive (gjk.cpp:62)");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  if (q.epa_max_iterations > (uint32_t)EPA_MAX_ITER) {
+    set_error("epa_max_iterations > 64 exceeds the device polytope capacity");
+    return HFCL_ERR_LIMIT;
+  }
+  if (q.gjk_variant < 0 || q.gjk_variant > 2 || q.gjk_convergence_criterion < 0 || q.gjk_convergence_criterion > 2 ||
+      q.gjk_convergence_criterion_type < 0 || q.gjk_convergence_criterion_type > 1) {
+    set_error("invalid GJK variant / convergence criterion");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  if (q.gjk_initial_guess == HFCL_GUESS_BOUNDING_VOLUME) {
+    set_error("GJKInitialGuess::BoundingVolumeGuess is not supported by the batched engine yet");
+    return HFCL_ERR_LIMIT;
+  }
+  return HFCL_OK;
+}
+
+template <typename T, int W>
+static void launch_cvx(hfcl_lib* lib, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q,
+                       hipStream_t st, size_t& ti, int grid) {
+  KernelTime* t;
+  t = timer_slot(lib, ti++, "k_gjk_cvx<cc>");
+  hipEventRecord(t->e0, st);
+  hipLaunchKernelGGL((k_gjk_cvx<T, W, 0>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+  hipEventRecord(t->e1, st);
+  t = timer_slot(lib, ti++, "k_gjk_cvx<pc>");
+  hipEventRecord(t->e0, st);
+  hipLaunchKernelGGL((k_gjk_cvx<T, W, 1>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+  hipEventRecord(t->e1, st);
+  t = timer_slot(lib, ti++, "k_gjk_cvx<cp>");
+  hipEventRecord(t->e0, st);
+  hipLaunchKernelGGL((k_gjk_cvx<T, W, 2>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+  hipEventRecord(t->e1, st);
+}
+
+// The whole pipeline for one batch, asynchronous on `st`.
+template <typename T>
+static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, IO<T> io, size_t n, QParams<T> q,
+                     hipStream_t st) {
+  if (n == 0) return HFCL_OK;
+  if (n > 0xFFFFFFF0ull) {
+    set_error("batch too large (max 2^32-16 pairs per call)");
+    return HFCL_ERR_LIMIT;
+  }
+  HIP_TRY(hipSetDevice(lib->device));
+  int rc = ensure_workspace(lib, n);
+  if (rc) return rc;
+  Work wk;
+  wk.shape1 = d_s1;
+  wk.shape2 = d_s2;
+  wk.n = uint32_t(n);
+  wk.lists = lib->d_lists;
+  wk.counts = lib->d_counts;
+  wk.epa_queue = lib->d_epa_queue;
+  LibView<T> lv;
+  lv.shapes = std::is_same<T, double>::value ? (const DShape<T>*)lib->d_shapes64 : (const DShape<T>*)lib->d_shapes32;
+  lv.verts = std::is_same<T, double>::value ? (const T*)lib->d_verts64 : (const T*)lib->d_verts32;
+  lv.kinds = lib->d_kinds;
+  lv.n_shapes = uint32_t(lib->n_shapes);
+
+  for (auto& t : lib->timers) t.used = false;
+  size_t ti = 0;
+  const int max_blocks = lib->n_cus * 8;
+  auto blocks_for = [&](size_t items, size_t per_block) {
+    size_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > (size_t)max_blocks) b = max_blocks;
+    return int(b);
+  };
+  HIP_TRY(hipMemsetAsync(lib->d_counts, 0, (B_COUNT + 1) * sizeof(uint32_t), st));
+  KernelTime* t = timer_slot(lib, ti++, "k_classify");
+  hipEventRecord(t->e0, st);
+  hipLaunchKernelGGL(k_classify, dim3(blocks_for(n, 256 * 4)), dim3(256), 0, st, wk, lib->d_kinds, uint32_t(lib->n_shapes));
+  hipEventRecord(t->e1, st);
+
+  t = timer_slot(lib, ti++, "k_closed");
+  hipEventRecord(t->e0, st);
+  hipLaunchKernelGGL((k_closed<T>), dim3(blocks_for(n, 256)), dim3(256), 0, st, wk, lv, io, q);
+  hipEventRecord(t->e1, st);
+
+  t = timer_slot(lib, ti++, "k_gjk_prim");
+  hipEventRecord(t->e0, st);
+  hipLaunchKernelGGL((k_gjk_prim<T>), dim3(blocks_for(n, 256)), dim3(256), 0, st, wk, lv, io, q);
+  hipEventRecord(t->e1, st);
+
+  const int w = lib->cvx_w;
+  const int cgrid = blocks_for(n, 256 / w);
+  if (w == 4) launch_cvx<T, 4>(lib, wk, lv, io, q, st, ti, cgrid);
+  else if (w == 16) launch_cvx<T, 16>(lib, wk, lv, io, q, st, ti, cgrid);
+  else if (w == 32) launch_cvx<T, 32>(lib, wk, lv, io, q, st, ti, cgrid);
+  else if (w == 64) launch_cvx<T, 64>(lib, wk, lv, io, q, st, ti, cgrid);
+  else launch_cvx<T, 8>(lib, wk, lv, io, q, st, ti, cgrid);
+
+  t = timer_slot(lib, ti++, "k_unsupported");
+  hipEventRecord(t->e0, st);
+  hipLaunchKernelGGL((k_unsupported<T>), dim3(blocks_for(n, 256 * 64)), dim3(256), 0, st, wk, io);
+  hipEventRecord(t->e1, st);
+
+  if (q.compute_penetration) {
+    t = timer_slot(lib, ti++, "k_epa");
+    hipEventRecord(t->e0, st);
+    hipLaunchKernelGGL((k_epa<T>), dim3(blocks_for(n, 4)), dim3(256), 0, st, wk, lv, io, q);
+    hipEventRecord(t->e1, st);
+  }
+  HIP_TRY(hipMemcpyAsync(lib->h_counts, lib->d_counts, (B_COUNT + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipGetLastError());
+  return HFCL_OK;
+}
+
+template <typename T>
+static int setup_collide(const hfcl_collision_request* req, QParams<T>& q, bool& skip_all) {
+  skip_all = false;
+  if (!req) {
+    set_error("null request");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  if (req->num_max_contacts == 0) {  // src/collision.cpp:82-85
+    set_error("Invalid number of max contacts (current value is 0).");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  int rc = validate_query(req->q);
+  if (rc) return rc;
+  fill_qparams(q, req->q);
+  q.mode = 1;
+  q.compute_penetration = (req->enable_contact || req->security_margin < 0) ? 1 : 0;  // shape_shape_func.h:141-142
+  q.security_margin = T(req->security_margin);
+  // narrowphase.h:228-229
+  double ub = req->distance_upper_bound > req->security_margin ? req->distance_upper_bound : req->security_margin;
+  if (ub < 0) ub = 0;
+  q.gjk.distance_upper_bound = (ub >= double(Lim<T>::max())) ? Lim<T>::max() : T(ub);
+  if (req->security_margin == -__builtin_inf()) skip_all = true;  // src/collision.cpp:73-76
+  return HFCL_OK;
+}
+template <typename T>
+static int setup_distance(const hfcl_distance_request* req, QParams<T>& q) {
+  if (!req) {
+    set_error("null request");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  int rc = validate_query(req->q);
+  if (rc) return rc;
+  fill_qparams(q, req->q);
+  q.mode = 0;
+  q.compute_penetration = req->enable_signed_distance ? 1 : 0;
+  q.security_margin = T(0);
+  q.gjk.distance_upper_bound = Lim<T>::max();  // narrowphase.h:175
+  return HFCL_OK;
+}
+
+// -inf security margin: cleared results, nothing computed (src/collision.cpp:73-76)
+template <typename R>
+__global__ void k_fill_skipped(R* out, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    R r;
+    memset(&r, 0, sizeof(r));
+    r.distance = 3.402823466e+38f;
+    r.status = 0x80000000u;
+    out[i] = r;
+  }
+}
+template <>
+__global__ void k_fill_skipped<hfcl_result>(hfcl_result* out, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    hfcl_result r;
+    const double x = __builtin_nan("");
+    r.distance = 1.7976931348623157e+308;
+    for (int k = 0; k < 3; ++k) r.normal[k] = r.p1[k] = r.p2[k] = x;
+    r.b1 = r.b2 = -1;
+    r.status = 0x80000000u;
+    r.num_contacts = 0;
+    out[i] = r;
+  }
+}
+
+extern "C" {
+
+int hfcl_collide_batch_device(hfcl_lib* lib, const uint32_t* d_shape1, const uint32_t* d_shape2, const double* d_tf1,
+                              const double* d_tf2, size_t n, const hfcl_collision_request* req, hfcl_result* d_out,
+                              const hfcl_guess* d_guess_in, hfcl_guess* d_guess_out, void* stream) {
+  if (!lib) {
+    set_error("null library");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  QParams<double> q;
+  bool skip;
+  int rc = setup_collide<double>(req, q, skip);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (skip) {
+    HIP_TRY(hipSetDevice(lib->device));
+    if (n) hipLaunchKernelGGL((k_fill_skipped<hfcl_result>), dim3(1024), dim3(256), 0, st, d_out, uint32_t(n));
+    return HFCL_OK;
+  }
+  IO<double> io{d_tf1, d_tf2, d_out, d_guess_in, d_guess_out};
+  return run_batch<double>(lib, d_shape1, d_shape2, io, n, q, st);
+}
+
+int hfcl_distance_batch_device(hfcl_lib* lib, const uint32_t* d_shape1, const uint32_t* d_shape2, const double* d_tf1,
+                               const double* d_tf2, size_t n, const hfcl_distance_request* req, hfcl_result* d_out,
+                               const hfcl_guess* d_guess_in, hfcl_guess* d_guess_out, void* stream) {
+  if (!lib) {
+    set_error("null library");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  QParams<double> q;
+  int rc = setup_distance<double>(req, q);
+  if (rc) return rc;
+  IO<double> io{d_tf1, d_tf2, d_out, d_guess_in, d_guess_out};
+  return run_batch<double>(lib, d_shape1, d_shape2, io, n, q, (hipStream_t)stream);
+}
+
+int hfcl_distance_batch_device_f32(hfcl_lib* lib, const uint32_t* d_shape1, const uint32_t* d_shape2,
+                                   const float* d_pose1, const float* d_pose2, size_t n,
+                                   const hfcl_distance_request* req, hfcl_result_f32* d_out, void* stream) {
+  if (!lib) {
+    set_error("null library");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  QParams<float> q;
+  int rc = setup_distance<float>(req, q);
+  if (rc) return rc;
+  IO<float> io{d_pose1, d_pose2, d_out, nullptr, nullptr};
+  return run_batch<float>(lib, d_shape1, d_shape2, io, n, q, (hipStream_t)stream);
+}
+
+int hfcl_collide_batch_device_f32(hfcl_lib* lib, const uint32_t* d_shape1, const uint32_t* d_shape2,
+                                  const float* d_pose1, const float* d_pose2, size_t n,
+                                  const hfcl_collision_request* req, hfcl_result_f32* d_out, void* stream) {
+  if (!lib) {
+    set_error("null library");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  QParams<float> q;
+  bool skip;
+  int rc = setup_collide<float>(req, q, skip);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (skip) {
+    HIP_TRY(hipSetDevice(lib->device));
+    if (n) hipLaunchKernelGGL((k_fill_skipped<hfcl_result_f32>), dim3(1024), dim3(256), 0, st, d_out, uint32_t(n));
+    return HFCL_OK;
+  }
+  IO<float> io{d_pose1, d_pose2, d_out, nullptr, nullptr};
+  return run_batch<float>(lib, d_shape1, d_shape2, io, n, q, st);
+}
+
+static int ensure_staging(hfcl_lib* lib, size_t n, bool gin, bool gout) {
+  if (n > lib->st_capacity) {
+    hipFree(lib->d_s1); hipFree(lib->d_s2); hipFree(lib->d_tf1); hipFree(lib->d_tf2); hipFree(lib->d_out);
+    hipFree(lib->d_gin); hipFree(lib->d_gout);
+    lib->d_s1 = lib->d_s2 = nullptr;
+    lib->d_tf1 = lib->d_tf2 = nullptr;
+    lib->d_out = nullptr;
+    lib->d_gin = lib->d_gout = nullptr;
+    lib->st_capacity = 0;
+    size_t cap = n + n / 8 + 256;
+    HIP_TRY(hipMalloc(&lib->d_s1, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&lib->d_s2, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&lib->d_tf1, cap * 12 * sizeof(double)));
+    HIP_TRY(hipMalloc(&lib->d_tf2, cap * 12 * sizeof(double)));
+    HIP_TRY(hipMalloc(&lib->d_out, cap * sizeof(hfcl_result)));
+    lib->st_capacity = cap;
+  }
+  if (gin && !lib->d_gin) HIP_TRY(hipMalloc(&lib->d_gin, lib->st_capacity * sizeof(hfcl_guess)));
+  if (gout && !lib->d_gout) HIP_TRY(hipMalloc(&lib->d_gout, lib->st_capacity * sizeof(hfcl_guess)));
+  return HFCL_OK;
+}
+
+static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, const double* tf1, const double* tf2,
+                      size_t n, const hfcl_collision_request* creq, const hfcl_distance_request* dreq, hfcl_result* out,
+                      const hfcl_guess* gin, hfcl_guess* gout) {
+  if (!lib) {
+    set_error("null library");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  if (n == 0) return HFCL_OK;
+  if (!s1 || !s2 || !tf1 || !tf2 || !out) {
+    set_error("null buffer");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(lib->device));
+  int rc = ensure_staging(lib, n, gin != nullptr, gout != nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(lib->d_s1, s1, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_s2, s2, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_tf1, tf1, n * 12 * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_tf2, tf2, n * 12 * sizeof(double), hipMemcpyHostToDevice));
+  if (gin) HIP_TRY(hipMemcpy(lib->d_gin, gin, n * sizeof(hfcl_guess), hipMemcpyHostToDevice));
+  if (creq)
+    rc = hfcl_collide_batch_device(lib, lib->d_s1, lib->d_s2, lib->d_tf1, lib->d_tf2, n, creq, lib->d_out,
+                                   gin ? lib->d_gin : nullptr, gout ? lib->d_gout : nullptr, nullptr);
+  else
+    rc = hfcl_distance_batch_device(lib, lib->d_s1, lib->d_s2, lib->d_tf1, lib->d_tf2, n, dreq, lib->d_out,
+                                    gin ? lib->d_gin : nullptr, gout ? lib->d_gout : nullptr, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, lib->d_out, n * sizeof(hfcl_result), hipMemcpyDeviceToHost));
+  if (gout) HIP_TRY(hipMemcpy(gout, lib->d_gout, n * sizeof(hfcl_guess), hipMemcpyDeviceToHost));
+  const bool skipped = creq && creq->security_margin == -__builtin_inf();
+  if (!skipped && lib->h_counts[B_UNSUPPORTED] > 0) {
+    set_error("Collision/distance function between some node types of the batch is not yet supported (" +
+              std::to_string(lib->h_counts[B_UNSUPPORTED]) + " pairs; their records carry status bit 31)");
+    return HFCL_ERR_UNSUPPORTED_PAIR;
+  }
+  if (!skipped && lib->h_counts[B_BVH] > 0) {
+    set_error("BVHModel<OBBRSS> pairs in batch: traversal kernel not built yet");
+    return HFCL_ERR_UNSUPPORTED_PAIR;
+  }
+  return HFCL_OK;
+}
+
+int hfcl_collide_batch(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2, const double* tf1,
+                       const double* tf2, size_t n, const hfcl_collision_request* req, hfcl_result* out,
+                       const hfcl_guess* guess_in, hfcl_guess* guess_out) {
+  if (!req) {
+    set_error("null request");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  return host_batch(lib, shape1, shape2, tf1, tf2, n, req, nullptr, out, guess_in, guess_out);
+}
+int hfcl_distance_batch(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2, const double* tf1,
+                        const double* tf2, size_t n, const hfcl_distance_request* req, hfcl_result* out,
+                        const hfcl_guess* guess_in, hfcl_guess* guess_out) {
+  if (!req) {
+    set_error("null request");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  return host_batch(lib, shape1, shape2, tf1, tf2, n, nullptr, req, out, guess_in, guess_out);
+}
+
+int hfcl_collide_batch_contacts(hfcl_lib*, const uint32_t*, const uint32_t*, const double*, const double*, size_t,
+                                const hfcl_collision_request*, hfcl_result*, hfcl_contact*, size_t, size_t*) {
+  set_error("hfcl_collide_batch_contacts: mesh-mesh traversal is not built yet");
+  return HFCL_ERR_UNSUPPORTED_PAIR;
+}
+
+double hfcl_last_kernel_ms(hfcl_lib* lib) {
+  if (!lib) return 0.0;
+  hipSetDevice(lib->device);
+  double total = 0, best = -1;
+  lib->dominant = "";
+  for (auto& t : lib->timers) {
+    if (!t.used) continue;
+    if (hipEventSynchronize(t.e1) != hipSuccess) continue;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, t.e0, t.e1) != hipSuccess) continue;
+    total += ms;
+    if (ms > best) {
+      best = ms;
+      lib->dominant = t.name;
+    }
+  }
+  return total;
+}
+const char* hfcl_last_kernel_name(hfcl_lib* lib) { return lib ? lib->dominant.c_str() : ""; }
+
+// breakdown: up to `cap` (name, ms) entries of the last call; returns the number written
+int hfcl_last_kernel_breakdown(hfcl_lib* lib, const char** names, double* ms, int cap) {
+  if (!lib) return 0;
+  hipSetDevice(lib->device);
+  int k = 0;
+  for (auto& t : lib->timers) {
+    if (!t.used || k >= cap) continue;
+    float m = 0;
+    if (hipEventSynchronize(t.e1) != hipSuccess) continue;
+    if (hipEventElapsedTime(&m, t.e0, t.e1) != hipSuccess) continue;
+    names[k] = t.name;
+    ms[k] = m;
+    ++k;
+  }
+  return k;
+}
+
+// bucket populations of the last call (after a stream sync): closed, prim, cc, pc, cp, bvh, unsupported, epa-queue
+void hfcl_last_bucket_counts(hfcl_lib* lib, uint32_t* out8) {
+  for (int i = 0; i <= B_COUNT; ++i) out8[i] = lib ? lib->h_counts[i] : 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,256 @@
+// hfcl_shapes.hpp -- device shape records, primitive support functions, closed-form pairs.
+//
+// Behavioural contract (reference file:line):
+//   supports      src/narrowphase/support_functions.cpp:140-222 (Box, Sphere, Ellipsoid, Capsule;
+//                 NoSweptSphere option: sphere/capsule radii are added back after GJK/EPA,
+//                 src/narrowphase/minkowski_difference.cpp:103-125,183-201)
+//   closed forms  src/narrowphase/details.h:52-101 (sphere-capsule), :215-232 (sphere-sphere),
+//                 :435-495 (box-sphere), src/distance/capsule_capsule.cpp:52-167
+#pragma once
+#include "hfcl_math.hpp"
+
+namespace hfcl {
+
+enum { K_BOX = 9, K_SPHERE = 10, K_CAPSULE = 11, K_CONVEX = 14, K_TRIANGLE = 17, K_ELLIPSOID = 19, K_BVH = 5 };
+
+// Device image of one shape-library entry (both an fp64 and an fp32 table are resident).
+template <typename T>
+struct DShape {
+  int32_t kind;
+  uint32_t num_points;
+  uint32_t vertex_offset;  // in vertices, into the library vertex array of the same precision
+  uint32_t bvh_index;
+  T p0, p1, p2;            // Box halfSide / Sphere r / Capsule r,halfLength / Ellipsoid radii
+  T ssr;                   // swept sphere radius
+};
+
+// pair classes (kernel buckets), from the reference's dispatch table
+// (include/hpp/fcl/internal/shape_shape_func.h:185-211)
+enum { CLS_CLOSED = 0, CLS_PRIM_GJK = 1, CLS_CONVEX = 2, CLS_BVH = 3, CLS_UNSUPPORTED = 4, CLS_COUNT = 5 };
+
+HFCL_HD bool kind_is_prim(int k) { return k == K_BOX || k == K_SPHERE || k == K_CAPSULE || k == K_ELLIPSOID; }
+HFCL_HD int pair_class(int k1, int k2) {
+  if (k1 == K_BVH && k2 == K_BVH) return CLS_BVH;
+  const bool p1 = kind_is_prim(k1), p2 = kind_is_prim(k2);
+  if (p1 && p2) {
+    const bool sc1 = (k1 == K_SPHERE || k1 == K_CAPSULE), sc2 = (k2 == K_SPHERE || k2 == K_CAPSULE);
+    if (sc1 && sc2) return CLS_CLOSED;                                              // sph-sph, sph-cap, cap-cap
+    if ((k1 == K_BOX && k2 == K_SPHERE) || (k1 == K_SPHERE && k2 == K_BOX)) return CLS_CLOSED;  // box-sphere
+    return CLS_PRIM_GJK;
+  }
+  if ((p1 || k1 == K_CONVEX) && (p2 || k2 == K_CONVEX)) return CLS_CONVEX;
+  return CLS_UNSUPPORTED;
+}
+
+// The Box support's `inflate` is a function-local static evaluated on the first call of the
+// process in the reference (support_functions.cpp:146); pinned to 1+1e-10.
+template <typename T> HFCL_HD T box_inflate() { return T(1) + T(1e-10); }
+
+// getShapeSupport<NoSweptSphere> for the primitive kinds, in the shape's own frame.
+template <typename T>
+HFCL_HD V3<T> prim_support(const DShape<T>& s, const V3<T>& dir) {
+  const T tiny = Lim<T>::tiny();
+  if (s.kind == K_BOX) {
+    const T inf = box_inflate<T>();
+    V3<T> r;
+    r.x = ((dir.x > tiny) ? s.p0 : T(0)) + ((dir.x < -tiny) ? (-inf * s.p0) : T(0));
+    r.y = ((dir.y > tiny) ? s.p1 : T(0)) + ((dir.y < -tiny) ? (-inf * s.p1) : T(0));
+    r.z = ((dir.z > tiny) ? s.p2 : T(0)) + ((dir.z < -tiny) ? (-inf * s.p2) : T(0));
+    return r;
+  }
+  if (s.kind == K_ELLIPSOID) {
+    const T a2 = s.p0 * s.p0, b2 = s.p1 * s.p1, c2 = s.p2 * s.p2;
+    const V3<T> v = mk<T>(a2 * dir.x, b2 * dir.y, c2 * dir.z);
+    const T d = hsqrt(dot(v, dir));
+    return v / d;
+  }
+  if (s.kind == K_CAPSULE) {
+    T z = T(0);
+    if (dir.z > tiny)
+      z = s.p1;
+    else if (dir.z < -tiny)
+      z = -s.p1;
+    return mk<T>(T(0), T(0), z);
+  }
+  return mk<T>(T(0), T(0), T(0));  // sphere: a point, radius is swept
+}
+
+// radius folded into MinkowskiDiff::swept_sphere_radius[i]
+template <typename T> HFCL_HD T swept_radius(const DShape<T>& s) {
+  return s.ssr + ((s.kind == K_SPHERE || s.kind == K_CAPSULE) ? s.p0 : T(0));
+}
+
+// ---------------------------------------------------------------------------------------
+// Closed forms.  All return the signed distance and fill world-frame p1, p2, normal (o1->o2).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+HFCL_HD T sphere_sphere(const DShape<T>& s1, const Pose<T>& tf1, const DShape<T>& s2, const Pose<T>& tf2, V3<T>& p1,
+                        V3<T>& p2, V3<T>& normal) {
+  const T r1 = s1.p0 + s1.ssr, r2 = s2.p0 + s2.ssr;
+  const V3<T> c1c2 = tf2.t - tf1.t;
+  const T cdist = norm(c1c2);
+  V3<T> unit = mk<T>(T(1), T(0), T(0));
+  if (cdist > Lim<T>::eps()) unit = c1c2 / cdist;
+  normal = unit;
+  p1 = tf1.t + r1 * unit;
+  p2 = tf2.t - r2 * unit;
+  return cdist - r1 - r2;
+}
+
+template <typename T>
+HFCL_HD T sphere_capsule(const DShape<T>& s1, const Pose<T>& tf1, const DShape<T>& s2, const Pose<T>& tf2, V3<T>& p1,
+                         V3<T>& p2, V3<T>& normal) {
+  const V3<T> pos1 = xform(tf2, mk<T>(T(0), T(0), s2.p1));
+  const V3<T> pos2 = xform(tf2, mk<T>(T(0), T(0), -s2.p1));
+  const V3<T> s_c = tf1.t;
+  V3<T> seg;
+  {
+    const V3<T> v = pos2 - pos1, w = s_c - pos1;
+    const T c1 = dot(w, v), c2 = dot(v, v);
+    if (c1 <= T(0))
+      seg = pos1;
+    else if (c2 <= c1)
+      seg = pos2;
+    else
+      seg = pos1 + v * (c1 / c2);
+  }
+  normal = seg - s_c;
+  const T nrm = norm(normal);
+  const T r1 = s1.p0 + s1.ssr, r2 = s2.p0 + s2.ssr;
+  if (nrm > Lim<T>::eps())
+    normal = normalized(normal);
+  else
+    normal = mk<T>(T(1), T(0), T(0));
+  p1 = s_c + normal * r1;
+  p2 = seg - normal * r2;
+  return nrm - r1 - r2;
+}
+
+template <typename T>
+HFCL_HD V3<T> clamped_linear(const V3<T>& a, T s_n, T s_d, const V3<T>& d) {
+  if (s_n <= T(0)) return a;
+  if (s_n >= s_d) return a + d;
+  return a + (s_n / s_d) * d;
+}
+
+template <typename T>
+HFCL_HD T capsule_capsule(const DShape<T>& c1s, const Pose<T>& tf1, const DShape<T>& c2s, const Pose<T>& tf2, V3<T>& wp1,
+                          V3<T>& wp2, V3<T>& normal) {
+  const T EPSILON = Lim<T>::eps() * T(100);
+  const V3<T> c1 = tf1.t, c2 = tf2.t;
+  const T radius1 = c1s.p0 + c1s.ssr, radius2 = c2s.p0 + c2s.ssr;
+  const V3<T> d1 = (T(2) * c1s.p1) * col(tf1.R, 2);
+  const V3<T> d2 = (T(2) * c2s.p1) * col(tf2.R, 2);
+  const V3<T> p1 = c1 - d1 / T(2);
+  const V3<T> p2 = c2 - d2 / T(2);
+  const V3<T> r = p1 - p2;
+  const T a = dot(d1, d1), b = dot(d1, d2), c = dot(d1, r), e = dot(d2, d2), f = dot(d2, r);
+  V3<T> w1, w2;
+  if (a <= EPSILON) {
+    w1 = p1;
+    if (e <= EPSILON)
+      w2 = p2;
+    else
+      w2 = clamped_linear(p2, f, e, d2);
+  } else if (e <= EPSILON) {
+    w1 = clamped_linear(p1, -c, a, d1);
+    w2 = p2;
+  } else {
+    const T denom = hmax(a * e - b * b, T(0));
+    T s, t;
+    if (denom > EPSILON) {
+      const T num = b * f - c * e;
+      s = (num <= T(0)) ? T(0) : ((num >= denom) ? T(1) : num / denom);
+      t = b * s + f;
+    } else {
+      s = T(0);
+      t = f;
+    }
+    if (t <= T(0)) {
+      w2 = p2;
+      w1 = clamped_linear(p1, -c, a, d1);
+    } else if (t >= e) {
+      w1 = clamped_linear(p1, b - c, a, d1);
+      w2 = p2 + d2;
+    } else {
+      w1 = p1 + s * d1;
+      w2 = p2 + (t / e) * d2;
+    }
+  }
+  const T distance = norm(w1 - w2) - (radius1 + radius2);
+  normal = normalized(w2 - w1);
+  wp1 = w1 + radius1 * normal;
+  wp2 = w2 - radius2 * normal;
+  return distance;
+}
+
+template <typename T>
+HFCL_HD T box_sphere(const DShape<T>& b, const Pose<T>& tfb, const DShape<T>& s, const Pose<T>& tfs, V3<T>& pb,
+                     V3<T>& ps, V3<T>& normal) {
+  const V3<T> os = tfs.t, ob = tfb.t;
+  pb = ob;
+  bool outside = false;
+  const V3<T> o = tmul(tfb.R, os - ob);
+  int axis = -1;
+  T min_d = Lim<T>::max();
+  const T hs[3] = {b.p0, b.p1, b.p2};
+  const T oo[3] = {o.x, o.y, o.z};
+  for (int i = 0; i < 3; ++i) {
+    const V3<T> ci = col(tfb.R, i);
+    if (oo[i] < -hs[i]) {
+      pb = pb - hs[i] * ci;
+      outside = true;
+    } else if (oo[i] > hs[i]) {
+      pb = pb + hs[i] * ci;
+      outside = true;
+    } else {
+      pb = pb + oo[i] * ci;
+      const T facedist = hs[i] - habs(oo[i]);
+      if (!outside && facedist < min_d) {
+        axis = i;
+        min_d = facedist;
+      }
+    }
+  }
+  normal = pb - os;
+  const T pdist = norm(normal);
+  T dist;
+  if (outside) {
+    dist = pdist - s.p0;
+    normal = normal / (-pdist);
+  } else {
+    const V3<T> ca = col(tfb.R, axis);
+    normal = (comp(o, axis) >= T(0)) ? ca : -ca;
+    dist = -min_d - s.p0;
+  }
+  ps = os - s.p0 * normal;
+  if (!outside || dist <= T(0)) pb = ps - dist * normal;
+  if (b.ssr > T(0) || s.ssr > T(0)) {
+    pb = pb + b.ssr * normal;
+    ps = ps - s.ssr * normal;
+    dist -= (b.ssr + s.ssr);
+  }
+  return dist;
+}
+
+// Dispatch of the CLS_CLOSED bucket incl. the operand swaps of sphere_capsule.cpp:60-71 and
+// box_sphere.cpp:62-75.
+template <typename T>
+HFCL_HD T closed_form_distance(const DShape<T>& s1, const Pose<T>& tf1, const DShape<T>& s2, const Pose<T>& tf2,
+                               V3<T>& p1, V3<T>& p2, V3<T>& n) {
+  if (s1.kind == K_SPHERE && s2.kind == K_SPHERE) return sphere_sphere(s1, tf1, s2, tf2, p1, p2, n);
+  if (s1.kind == K_SPHERE && s2.kind == K_CAPSULE) return sphere_capsule(s1, tf1, s2, tf2, p1, p2, n);
+  if (s1.kind == K_CAPSULE && s2.kind == K_SPHERE) {
+    const T d = sphere_capsule(s2, tf2, s1, tf1, p2, p1, n);
+    n = -n;
+    return d;
+  }
+  if (s1.kind == K_CAPSULE && s2.kind == K_CAPSULE) return capsule_capsule(s1, tf1, s2, tf2, p1, p2, n);
+  if (s1.kind == K_BOX && s2.kind == K_SPHERE) return box_sphere(s1, tf1, s2, tf2, p1, p2, n);
+  // sphere - box
+  const T d = box_sphere(s2, tf2, s1, tf1, p2, p1, n);
+  n = -n;
+  return d;
+}
+
+}  // namespace hfcl

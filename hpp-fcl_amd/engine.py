@@ -1,0 +1,173 @@
+"""ctypes front-end of csrc/libhppfcl_amd.so (the C ABI of include/hppfcl_amd.h).
+
+Plumbing only: argument marshalling and device-pointer hand-off.  All compute is in the HIP
+library.  There is NO fallback: a missing library or a missing GPU raises."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_CSRC, "libhppfcl_amd.so")
+
+EXPORTED_SYMBOLS = [
+    "hfcl_abi_version", "hfcl_device_count", "hfcl_last_error", "hfcl_collision_request_init",
+    "hfcl_distance_request_init", "hfcl_lib_create", "hfcl_lib_destroy", "hfcl_lib_num_shapes", "hfcl_lib_device",
+    "hfcl_lib_add_bvh", "hfcl_collide_batch", "hfcl_distance_batch", "hfcl_collide_batch_device",
+    "hfcl_distance_batch_device", "hfcl_distance_batch_device_f32", "hfcl_collide_batch_device_f32",
+    "hfcl_collide_batch_contacts", "hfcl_last_kernel_ms", "hfcl_last_kernel_name",
+]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("hfcl error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build_native(verbose=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _CSRC]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_DLL = None
+
+
+def dll():
+    """Load the native library; raises if it has not been built (no fallback)."""
+    global _DLL
+    if _DLL is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(abi.ERR_NO_DEVICE, "native library %s is missing: run __graft_entry__.build()" % LIB_PATH)
+        d = C.CDLL(LIB_PATH)
+        d.hfcl_last_error.restype = C.c_char_p
+        d.hfcl_lib_create.restype = C.c_void_p
+        d.hfcl_lib_num_shapes.restype = C.c_size_t
+        d.hfcl_last_kernel_ms.restype = C.c_double
+        d.hfcl_last_kernel_name.restype = C.c_char_p
+        _DLL = d
+    return _DLL
+
+
+def last_error():
+    return dll().hfcl_last_error().decode()
+
+
+def device_count():
+    return int(dll().hfcl_device_count())
+
+
+def _check(rc):
+    if rc != 0:
+        raise EngineError(rc, last_error())
+
+
+def _dptr(x):
+    """Device pointer of a torch tensor / int / None."""
+    if x is None:
+        return C.c_void_p(0)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    return C.c_void_p(x.data_ptr())
+
+
+class Library:
+    """hfcl_lib: a shape library resident on one GPU."""
+
+    def __init__(self, shape_library, device=0):
+        d = dll()
+        self._shapes = np.ascontiguousarray(shape_library.shapes_array())
+        self._verts = np.ascontiguousarray(shape_library.vertices_array(), dtype=np.float64)
+        self.device = device
+        h = d.hfcl_lib_create(abi.ptr(self._shapes), C.c_size_t(len(self._shapes)), abi.ptr(self._verts),
+                              C.c_size_t(len(self._verts)), C.c_int(device))
+        if not h:
+            raise EngineError(abi.ERR_NO_DEVICE, last_error())
+        self._h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            dll().hfcl_lib_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-buffer entry points (H2D + kernels + D2H inside the call) ----
+    def _host(self, fn, s1, s2, tf1, tf2, req, guess_in, want_guess):
+        s1 = np.ascontiguousarray(s1, dtype=np.uint32)
+        s2 = np.ascontiguousarray(s2, dtype=np.uint32)
+        tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
+        tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
+        n = len(s1)
+        if not (len(s2) == n and len(tf1) == n and len(tf2) == n):
+            raise ValueError("batch arrays must have equal length")
+        out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+        if guess_in is not None:
+            guess_in = np.ascontiguousarray(guess_in, dtype=abi.GUESS_DTYPE)
+        gout = np.zeros(n, dtype=abi.GUESS_DTYPE) if want_guess else None
+        rc = fn(self._h, abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1), abi.ptr(tf2), C.c_size_t(n), C.byref(req),
+                abi.ptr(out), abi.ptr(guess_in), abi.ptr(gout))
+        _check(rc)
+        return (out, gout) if want_guess else out
+
+    def collide(self, s1, s2, tf1, tf2, req=None, guess_in=None, want_guess=False):
+        """Batched hpp::fcl::collide (src/collision.cpp:69-130)."""
+        return self._host(dll().hfcl_collide_batch, s1, s2, tf1, tf2, req or abi.default_collision_request(),
+                          guess_in, want_guess)
+
+    def distance(self, s1, s2, tf1, tf2, req=None, guess_in=None, want_guess=False):
+        """Batched hpp::fcl::distance (src/distance.cpp:60-109)."""
+        return self._host(dll().hfcl_distance_batch, s1, s2, tf1, tf2, req or abi.default_distance_request(),
+                          guess_in, want_guess)
+
+    # ---- device-resident entry points (torch tensors or raw device pointers) ----
+    def collide_device(self, d_s1, d_s2, d_tf1, d_tf2, n, req, d_out, d_gin=None, d_gout=None, stream=0):
+        _check(dll().hfcl_collide_batch_device(self._h, _dptr(d_s1), _dptr(d_s2), _dptr(d_tf1), _dptr(d_tf2),
+                                                C.c_size_t(n), C.byref(req), _dptr(d_out), _dptr(d_gin),
+                                                _dptr(d_gout), C.c_void_p(stream)))
+
+    def distance_device(self, d_s1, d_s2, d_tf1, d_tf2, n, req, d_out, d_gin=None, d_gout=None, stream=0):
+        _check(dll().hfcl_distance_batch_device(self._h, _dptr(d_s1), _dptr(d_s2), _dptr(d_tf1), _dptr(d_tf2),
+                                                 C.c_size_t(n), C.byref(req), _dptr(d_out), _dptr(d_gin),
+                                                 _dptr(d_gout), C.c_void_p(stream)))
+
+    def distance_device_f32(self, d_s1, d_s2, d_pose1, d_pose2, n, req, d_out, stream=0):
+        _check(dll().hfcl_distance_batch_device_f32(self._h, _dptr(d_s1), _dptr(d_s2), _dptr(d_pose1),
+                                                     _dptr(d_pose2), C.c_size_t(n), C.byref(req), _dptr(d_out),
+                                                     C.c_void_p(stream)))
+
+    def collide_device_f32(self, d_s1, d_s2, d_pose1, d_pose2, n, req, d_out, stream=0):
+        _check(dll().hfcl_collide_batch_device_f32(self._h, _dptr(d_s1), _dptr(d_s2), _dptr(d_pose1),
+                                                    _dptr(d_pose2), C.c_size_t(n), C.byref(req), _dptr(d_out),
+                                                    C.c_void_p(stream)))
+
+    # ---- instrumentation ----
+    def last_kernel_ms(self):
+        return float(dll().hfcl_last_kernel_ms(self._h))
+
+    def last_kernel_name(self):
+        return dll().hfcl_last_kernel_name(self._h).decode()
+
+    def last_kernel_breakdown(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_double * 16)()
+        k = dll().hfcl_last_kernel_breakdown(self._h, names, ms, 16)
+        return [(names[i].decode(), float(ms[i])) for i in range(k)]
+
+    def last_bucket_counts(self):
+        out = (C.c_uint32 * 8)()
+        dll().hfcl_last_bucket_counts(self._h, out)
+        keys = ["closed", "prim", "cc", "pc", "cp", "bvh", "unsupported", "epa_queue"]
+        return dict(zip(keys, [int(v) for v in out]))

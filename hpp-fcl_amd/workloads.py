@@ -1,0 +1,172 @@
+"""Synthetic workloads of BASELINE.json's configs.  Plumbing: numpy only.
+
+All randomness comes from a counter-based generator (Philox) keyed by (seed, stream) so the
+same batch can be regenerated anywhere (host, GPU box, any rank) without shipping data.
+Default seed = 1, echoing the reference's unseeded rand() (test/utility.cpp:93-96)."""
+import numpy as np
+
+from . import geometry
+
+
+def _rng(seed, stream):
+    return np.random.Generator(np.random.Philox(key=[int(seed), int(stream)]))
+
+
+def uniform_quaternions(rng, n):
+    """uniformRandomQuaternion, include/hpp/fcl/math/transform.h:228-249 -> (w,x,y,z)."""
+    u1, u2, u3 = rng.random(n), rng.random(n), rng.random(n)
+    m1, m2 = np.sqrt(1.0 - u1), np.sqrt(u1)
+    q = np.empty((n, 4))
+    q[:, 0] = m1 * np.sin(2 * np.pi * u2)
+    q[:, 1] = m1 * np.cos(2 * np.pi * u2)
+    q[:, 2] = m2 * np.sin(2 * np.pi * u3)
+    q[:, 3] = m2 * np.cos(2 * np.pi * u3)
+    return q
+
+
+def fibonacci_sphere(n):
+    i = np.arange(n) + 0.5
+    phi = np.arccos(1 - 2 * i / n)
+    theta = np.pi * (1 + 5 ** 0.5) * i
+    return np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], axis=1)
+
+
+class Batch:
+    """One batch of queries: shape library + pair list + poses (both precisions)."""
+
+    def __init__(self, name, lib, s1, s2, quat1, T1, quat2, T2, kind, request_overrides=None):
+        self.name = name
+        self.lib = lib
+        self.shapes = lib.shapes_array()
+        self.verts = lib.vertices_array()
+        self.s1 = np.ascontiguousarray(s1, dtype=np.uint32)
+        self.s2 = np.ascontiguousarray(s2, dtype=np.uint32)
+        self.quat1, self.T1, self.quat2, self.T2 = quat1, T1, quat2, T2
+        self.kind = kind  # "distance" | "collide"
+        self.request_overrides = request_overrides or {}
+
+    def __len__(self):
+        return len(self.s1)
+
+    @property
+    def tf1(self):
+        return geometry.make_pose(quat=self.quat1, T=self.T1)
+
+    @property
+    def tf2(self):
+        return geometry.make_pose(quat=self.quat2, T=self.T2)
+
+    @property
+    def pose1_f32(self):
+        return geometry.pose_f32_from_quat(self.quat1, self.T1)
+
+    @property
+    def pose2_f32(self):
+        return geometry.pose_f32_from_quat(self.quat2, self.T2)
+
+    def tf_from_f32(self):
+        """fp64 poses built from the *rounded* fp32 quaternion/translation (what the fp32 path sees)."""
+        p1, p2 = self.pose1_f32.astype(np.float64), self.pose2_f32.astype(np.float64)
+
+        def mk(p):
+            q = p[:, :4] / np.linalg.norm(p[:, :4], axis=1, keepdims=True)
+            return geometry.make_pose(quat=q, T=p[:, 4:7])
+
+        return mk(p1), mk(p2)
+
+    def slice(self, lo, hi):
+        b = Batch.__new__(Batch)
+        b.__dict__.update(self.__dict__)
+        b.s1, b.s2 = self.s1[lo:hi], self.s2[lo:hi]
+        b.quat1, b.T1, b.quat2, b.T2 = self.quat1[lo:hi], self.T1[lo:hi], self.quat2[lo:hi], self.T2[lo:hi]
+        return b
+
+
+def _poses(rng, n, half_width):
+    q1, q2 = uniform_quaternions(rng, n), uniform_quaternions(rng, n)
+    T1 = rng.uniform(-half_width, half_width, (n, 3))
+    T2 = rng.uniform(-half_width, half_width, (n, 3))
+    return q1, T1, q2, T2
+
+
+def cfg1_sphere_sphere(n=1000, seed=1):
+    """cfg1: Sphere-Sphere distance(), radii U[0.1,1] (test/utility.cpp:565-567)."""
+    rng = _rng(seed, 1)
+    lib = geometry.ShapeLibrary()
+    nlib = 256
+    for r in rng.uniform(0.1, 1.0, nlib):
+        lib.add_sphere(float(r))
+    s1, s2 = rng.integers(0, nlib, n), rng.integers(0, nlib, n)
+    q1, T1, q2, T2 = _poses(rng, n, 0.9)
+    return Batch("cfg1_sphere_sphere_distance", lib, s1, s2, q1, T1, q2, T2, "distance")
+
+
+def cfg2_box_capsule(n=1_000_000, seed=1, nlib=1024, half_width=0.92):
+    """cfg2: Box-Capsule collide(), default request.  Box side U[0.1,1]^3 (makeRandomBox,
+    test/utility.cpp:559-563), Capsule r U[0.1,0.8], lz U[0.2,1.0] (:575-579).  The translation cube is
+    sized so ~30 % of the pairs penetrate (the reference's GJK benchmark had 28 % colliding,
+    test/benchmark/test_fcl_gjk.output:3)."""
+    rng = _rng(seed, 2)
+    lib = geometry.ShapeLibrary()
+    for s in rng.uniform(0.1, 1.0, (nlib, 3)):
+        lib.add_box(*map(float, s))
+    for r, lz in zip(rng.uniform(0.1, 0.8, nlib), rng.uniform(0.2, 1.0, nlib)):
+        lib.add_capsule(float(r), float(lz))
+    s1 = rng.integers(0, nlib, n)
+    s2 = nlib + rng.integers(0, nlib, n)
+    q1, T1, q2, T2 = _poses(rng, n, half_width)
+    return Batch("cfg2_box_capsule_collide", lib, s1, s2, q1, T1, q2, T2, "collide")
+
+
+def convex_hull_library(rng, nlib, nverts=32):
+    lib = geometry.ShapeLibrary()
+    base = fibonacci_sphere(nverts)
+    for radii in rng.uniform(0.1, 1.0, (nlib, 3)):
+        lib.add_convex(base * radii)
+    return lib
+
+
+def cfg3_convex_convex(n=1_000_000, seed=1, nlib=4096, half_width=1.0, nverts=32):
+    """cfg3: Convex-Convex distance(), signed, NesterovAcceleration.  Hulls: 32 Fibonacci-sphere
+    directions scaled by ellipsoid radii U[0.1,1]^3 (every point is a hull vertex, linear
+    support path; no qhull needed).  Shared library of `nlib` hulls."""
+    rng = _rng(seed, 3)
+    lib = convex_hull_library(rng, nlib, nverts)
+    s1, s2 = rng.integers(0, nlib, n), rng.integers(0, nlib, n)
+    q1, T1, q2, T2 = _poses(rng, n, half_width)
+    from . import abi
+    return Batch("cfg3_convex32_distance_nesterov", lib, s1, s2, q1, T1, q2, T2, "distance",
+                 {"gjk_variant": abi.NesterovAcceleration})
+
+
+def cfg5_mixed(n=100_000, seed=1, nper=256, half_width=0.8):
+    """cfg5-style mixed primitive+convex pairs (type mix 20 % each of Box/Sphere/Capsule/
+    Ellipsoid/Convex32), synthetic pair list (the host broadphase is a later row)."""
+    rng = _rng(seed, 5)
+    lib = geometry.ShapeLibrary()
+    for s in rng.uniform(0.1, 1.0, (nper, 3)):
+        lib.add_box(*map(float, s))
+    for r in rng.uniform(0.1, 1.0, nper):
+        lib.add_sphere(float(r))
+    for r, lz in zip(rng.uniform(0.1, 0.8, nper), rng.uniform(0.2, 1.0, nper)):
+        lib.add_capsule(float(r), float(lz))
+    for r in rng.uniform(0.1, 1.0, (nper, 3)):
+        lib.add_ellipsoid(*map(float, r))
+    base = fibonacci_sphere(32)
+    for radii in rng.uniform(0.1, 1.0, (nper, 3)):
+        lib.add_convex(base * radii)
+    s1, s2 = rng.integers(0, 5 * nper, n), rng.integers(0, 5 * nper, n)
+    q1, T1, q2, T2 = _poses(rng, n, half_width)
+    return Batch("cfg5_mixed_collide", lib, s1, s2, q1, T1, q2, T2, "collide")
+
+
+def make_request(batch, abi, **kw):
+    req = abi.default_distance_request() if batch.kind == "distance" else abi.default_collision_request()
+    over = dict(batch.request_overrides)
+    over.update(kw)
+    for k, v in over.items():
+        if hasattr(req, k):
+            setattr(req, k, v)
+        else:
+            setattr(req.q, k, v)
+    return req

@@ -1,0 +1,51 @@
+"""ctypes binding of tests/hostsim/libhostsim.so: the device per-pair headers compiled for the
+host (TEST INFRASTRUCTURE, see tests/hostsim/hostsim.cpp).  Never used by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        subprocess.check_call(["make", "-s", "-C", _DIR])
+        _LIB = C.CDLL(os.path.join(_DIR, "libhostsim.so"))
+    return _LIB
+
+
+def batch_f64(abi, shapes, verts, s1, s2, tf1, tf2, req, guess_in=None, want_guess=False):
+    shapes = np.ascontiguousarray(shapes)
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    s1 = np.ascontiguousarray(s1, dtype=np.uint32)
+    s2 = np.ascontiguousarray(s2, dtype=np.uint32)
+    tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
+    tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
+    n = len(s1)
+    out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    gout = np.zeros(n, dtype=abi.GUESS_DTYPE) if want_guess else None
+    is_coll = isinstance(req, abi.CollisionRequest)
+    lib().sim_batch_f64(abi.ptr(shapes), C.c_size_t(len(shapes)), abi.ptr(verts), abi.ptr(s1), abi.ptr(s2),
+                        abi.ptr(tf1), abi.ptr(tf2), C.c_size_t(n), C.byref(req) if is_coll else None,
+                        None if is_coll else C.byref(req), abi.ptr(out), abi.ptr(guess_in), abi.ptr(gout))
+    return (out, gout) if want_guess else out
+
+
+def batch_f32(abi, shapes, verts, s1, s2, pose1, pose2, req):
+    shapes = np.ascontiguousarray(shapes)
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    s1 = np.ascontiguousarray(s1, dtype=np.uint32)
+    s2 = np.ascontiguousarray(s2, dtype=np.uint32)
+    pose1 = np.ascontiguousarray(pose1, dtype=np.float32).reshape(-1, 7)
+    pose2 = np.ascontiguousarray(pose2, dtype=np.float32).reshape(-1, 7)
+    n = len(s1)
+    out = np.zeros(n, dtype=abi.RESULT_F32_DTYPE)
+    is_coll = isinstance(req, abi.CollisionRequest)
+    lib().sim_batch_f32(abi.ptr(shapes), C.c_size_t(len(shapes)), abi.ptr(verts), C.c_size_t(len(verts)),
+                        abi.ptr(s1), abi.ptr(s2), abi.ptr(pose1), abi.ptr(pose2), C.c_size_t(n),
+                        C.byref(req) if is_coll else None, None if is_coll else C.byref(req), abi.ptr(out))
+    return out

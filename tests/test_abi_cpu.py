@@ -1,0 +1,61 @@
+"""CPU checks of the C-ABI library: it loads, exports every symbol include/hppfcl_amd.h declares,
+and refuses to compute without a GPU (no fallback)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    pkg.engine.build_native()
+    lib = pkg.engine.dll()
+    hdr = open(os.path.join(ROOT, "include", "hppfcl_amd.h")).read()
+    declared = set(re.findall(r"\b(hfcl_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"hfcl_lib"}  # type name
+    assert len(declared) >= 19
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), "missing export: " + sym
+    assert lib.hfcl_abi_version() == 1
+    assert set(pkg.engine.EXPORTED_SYMBOLS) <= declared
+
+
+def test_struct_layouts_match_header(pkg):
+    import ctypes as C
+    abi = pkg.abi
+    assert C.sizeof(abi.Shape) == 48
+    assert C.sizeof(abi.QueryRequest) == 80
+    assert C.sizeof(abi.CollisionRequest) == 80 + 32
+    assert C.sizeof(abi.DistanceRequest) == 80 + 24
+    # defaults filled by the C library equal the Python-side defaults (= the reference's)
+    lib = pkg.engine.dll()
+    c = abi.CollisionRequest()
+    lib.hfcl_collision_request_init(C.byref(c))
+    d = abi.default_collision_request()
+    assert bytes(c) == bytes(d)
+    c = abi.DistanceRequest()
+    lib.hfcl_distance_request_init(C.byref(c))
+    assert bytes(c) == bytes(abi.default_distance_request())
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    if pkg.engine.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    L = pkg.ShapeLibrary()
+    L.add_sphere(1.0)
+    with pytest.raises(pkg.EngineError) as e:
+        pkg.Library(L)
+    assert e.value.code == pkg.abi.ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_never_references_the_oracle():
+    """The shipped package must not import, link or mention anything under oracle/ or tests/."""
+    pkg_dir = os.path.join(ROOT, "hpp-fcl_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".cpp", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_binding" not in txt and "liboracle" not in txt and "hostsim_binding" not in txt, f
+                assert not re.search(r'#include\s+"[^"]*oracle/', txt), f

