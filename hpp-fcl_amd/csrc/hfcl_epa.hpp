@@ -34,6 +34,12 @@ template <typename T>
 struct PW0 {  // simplex-vertex payload: support point on shape 0 (w1 = w0 - w)
   V3<T> w0;
 };
+template <typename T>
+HFCL_HD PW0<T> psel(bool c, const PW0<T>& a, const PW0<T>& b) {
+  PW0<T> r;
+  r.w0 = sel(c, a.w0, b.w0);
+  return r;
+}
 
 // Scratch layout (SoA).  sizeof = 68*2*3*T + 132*4*T + 132*10 + 132*2 + 132 + pad
 template <typename T>

@@ -126,6 +126,16 @@ struct Gjk {
   bool done, normalize;
 };
 
+// Component-wise select of a simplex vertex.  (A `c ? a : b` on the structs themselves turns
+// into a select of *addresses*, which keeps the whole simplex in scratch memory.)
+template <typename T, class P>
+HFCL_HD SimplexV<T, P> svsel(bool c, const SimplexV<T, P>& a, const SimplexV<T, P>& b) {
+  SimplexV<T, P> r;
+  r.w = sel(c, a.w, b.w);
+  r.p = psel(c, a.p, b.p);
+  return r;
+}
+
 template <typename T, class P>
 HFCL_HD void gjk_init(Gjk<T, P>& g, const GjkParams<T>& prm, const V3<T>& guess, T ssr_sum, bool normalize_dir) {
   g.alpha = T(0);
@@ -208,7 +218,7 @@ HFCL_HD bool gjk_check_convergence(Gjk<T, P>& g, const GjkParams<T>& prm, T omeg
 
 // originToSegment (gjk.cpp:502-515) for A and X; leaves [A, X]
 template <typename T, class P>
-HFCL_HD void gjk_to_segment(Gjk<T, P>& g, const SimplexV<T, P>& X, const V3<T>& AX, T AXdotAO) {
+HFCL_HD void gjk_to_segment(Gjk<T, P>& g, const SimplexV<T, P> X, const V3<T> AX, T AXdotAO) {
   const V3<T> A = g.s0.w;
   V3<T> r = dot(AX, X.w) * A + AXdotAO * X.w;
   g.ray = r / sqnorm(AX);
@@ -217,11 +227,11 @@ HFCL_HD void gjk_to_segment(Gjk<T, P>& g, const SimplexV<T, P>& X, const V3<T>& 
 }
 // originToTriangle (gjk.cpp:517-541) for (A, X, Y) with normal N and N.AO
 template <typename T, class P>
-HFCL_HD bool gjk_to_triangle(Gjk<T, P>& g, const SimplexV<T, P>& X, const SimplexV<T, P>& Y, const V3<T>& N, T NdotAO) {
+HFCL_HD bool gjk_to_triangle(Gjk<T, P>& g, const SimplexV<T, P> X, const SimplexV<T, P> Y, const V3<T> N, T NdotAO) {
   g.rank = 3;
   const bool keep = (NdotAO >= T(0));  // ==0 and >0: next = [y, x, A]  -> newest-first [A, x, y]
-  const SimplexV<T, P> n1 = keep ? X : Y;
-  const SimplexV<T, P> n2 = keep ? Y : X;
+  const SimplexV<T, P> n1 = svsel(keep, X, Y);
+  const SimplexV<T, P> n2 = svsel(keep, Y, X);
   g.s1 = n1;
   g.s2 = n2;
   if (NdotAO == T(0)) {
@@ -321,15 +331,15 @@ HFCL_HD bool gjk_project_tetra(Gjk<T, P>& g) {  // :613-1010
   }
   if (reg <= REG_AD) {  // segment A-X
     const bool xb = (reg == REG_AB), xc = (reg == REG_AC);
-    const SimplexV<T, P> X = xb ? g.s1 : (xc ? g.s2 : g.s3);
+    const SimplexV<T, P> X = svsel(xb, g.s1, svsel(xc, g.s2, g.s3));
     const T xa_aa = xb ? ba_aa : (xc ? ca_aa : da_aa);
     gjk_to_segment(g, X, X.w - A, -xa_aa);
     return false;
   }
   // triangle A-X-Y: ABC -> (B,C), ACD -> (C,D), ADB -> (D,B)
   const bool tb = (reg == REG_ABC), tc = (reg == REG_ACD);
-  const SimplexV<T, P> X = tb ? g.s1 : (tc ? g.s2 : g.s3);
-  const SimplexV<T, P> Y = tb ? g.s2 : (tc ? g.s3 : g.s1);
+  const SimplexV<T, P> X = svsel(tb, g.s1, svsel(tc, g.s2, g.s3));
+  const SimplexV<T, P> Y = svsel(tb, g.s2, svsel(tc, g.s3, g.s1));
   const T ndotao = tb ? -c_axb : (tc ? -d_axc : d_axb);
   gjk_to_triangle(g, X, Y, cross(X.w - A, Y.w - A), ndotao);
   return false;

@@ -77,14 +77,6 @@ HFCL_HD void gjk_run(Gjk<T, PW0<T>>& g, const GjkParams<T>& prm, const V3<T>& gu
   }
 }
 
-template <typename T>
-HFCL_HD SimplexV<T, PW0<T>> sv_sel(bool c, const SimplexV<T, PW0<T>>& a, const SimplexV<T, PW0<T>>& b) {
-  SimplexV<T, PW0<T>> r;
-  r.w = sel(c, a.w, b.w);
-  r.p.w0 = sel(c, a.p.w0, b.p.w0);
-  return r;
-}
-
 // Returns true when the pair must go through EPA (seed filled); otherwise `out` is final.
 template <typename T>
 HFCL_HD bool gjk_finish(const Gjk<T, PW0<T>>& g, const QParams<T>& q, const Pose<T>& tf1, T r0, T r1,
@@ -100,9 +92,9 @@ HFCL_HD bool gjk_finish(const Gjk<T, PW0<T>>& g, const QParams<T>& q, const Pose
   out.epa_iters = 0;
   if (st == GJK_COLLISION && q.compute_penetration) {
     // newest-first registers -> reference order: ref[i] = s[rank-1-i]
-    const SV ref0 = (r == 1) ? g.s0 : ((r == 2) ? g.s1 : ((r == 3) ? g.s2 : g.s3));
-    const SV ref1 = (r == 2) ? g.s0 : ((r == 3) ? g.s1 : g.s2);
-    const SV ref2 = (r == 3) ? g.s0 : g.s1;
+    const SV ref0 = svsel(r == 1, g.s0, svsel(r == 2, g.s1, svsel(r == 3, g.s2, g.s3)));
+    const SV ref1 = svsel(r == 2, g.s0, svsel(r == 3, g.s1, g.s2));
+    const SV ref2 = svsel(r == 3, g.s0, g.s1);
     seed.rank = r;
     seed.w[0] = ref0.w; seed.w0[0] = ref0.p.w0;
     seed.w[1] = ref1.w; seed.w0[1] = ref1.p.w0;
@@ -120,8 +112,8 @@ HFCL_HD bool gjk_finish(const Gjk<T, PW0<T>>& g, const QParams<T>& q, const Pose
     return false;
   }
   // NoCollision / CollisionWithPenetrationInformation / Failed: GJKExtractWitnessPointsAndNormal :610-636
-  const SV ref0 = (r == 1) ? g.s0 : ((r == 2) ? g.s1 : g.s2);
-  const SV ref1 = (r == 2) ? g.s0 : g.s1;
+  const SV ref0 = svsel(r == 1, g.s0, svsel(r == 2, g.s1, g.s2));
+  const SV ref1 = svsel(r == 2, g.s0, g.s1);
   V3<T> wv[3] = {ref0.w, ref1.w, g.s0.w};
   V3<T> w0v[3] = {ref0.p.w0, ref1.p.w0, g.s0.p.w0};
   V3<T> w1v[3] = {ref0.p.w0 - ref0.w, ref1.p.w0 - ref1.w, g.s0.p.w0 - g.s0.w};

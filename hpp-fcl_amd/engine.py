@@ -12,7 +12,7 @@ from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_CSRC, "libhppfcl_amd.so")
+LIB_PATH = os.environ.get("HFCL_LIB_PATH", os.path.join(_CSRC, "libhppfcl_amd.so"))  # override: A/B builds
 
 EXPORTED_SYMBOLS = [
     "hfcl_abi_version", "hfcl_device_count", "hfcl_last_error", "hfcl_collision_request_init",

@@ -24,6 +24,11 @@ def check_parity(abi, got, ref, *, dist_tol, point_tol, flag_band, name="", allo
     dd = np.where(finite, np.abs(d_got - d_ref), 0.0)
     same_inf = np.where(~finite, (d_got == d_ref) | (fp32 & (np.abs(d_got) > 1e37)), True)
     bad_d = (dd > dist_tol * (1 + np.abs(np.where(finite, d_ref, 0)))) | ~same_inf
+    # GJK early stop (status 2): the reported distance is only a lower bound above
+    # distance_upper_bound (narrowphase.h:589-608); its value depends on the iteration at which the
+    # bound was crossed, so only require both to be early-stopped lower bounds of the same sign.
+    early = (abi.status_gjk(st_r) == 2) & (abi.status_gjk(st_g) == 2)
+    bad_d &= ~(early & (d_got > 0) & (d_ref > 0))
     nan_r = np.isnan(ref["p1"]).any(axis=1)
     nan_g = np.isnan(got["p1"]).any(axis=1)
     bad_nan = (nan_r != nan_g) & ~near
