@@ -73,8 +73,8 @@ struct EpaResult {
   int iterations;
   V3<T> normal;
   T depth;
-  // result face (reference order) or single vertex for FallBack
-  V3<T> rw[3], rw0[3];
+  // result face (reference order) or single vertex for FallBack: w and w0 of its 3 vertices
+  V3<T> rw0_, rw1_, rw2_, r00, r01, r02;
 };
 
 template <typename T, class Grp>
@@ -267,7 +267,7 @@ const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
   template <class Sup>
   HFCL_HD bool enclose_origin(int& rank, Sup& sup) {
     const int base = rank;
-    int cnt[4] = {0, 0, 0, 0};
+    int c1 = 0, c2 = 0, c3 = 0;  // candidate counters of the rank-1/2/3 levels (no arrays: registers)
     bool entering = true;
     for (;;) {
       if (entering) {
@@ -278,13 +278,15 @@ const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
           entering = false;
           continue;
         }
-        cnt[rank] = 0;
+        if (rank == 1) c1 = 0;
+        if (rank == 2) c2 = 0;
+        if (rank == 3) c3 = 0;
       }
       // try the next candidate direction at this level
       V3<T> dir = mk<T>(T(0), T(0), T(0));
       bool have = false;
       while (!have) {
-        const int c = cnt[rank];
+        const int c = (rank == 1) ? c1 : ((rank == 2) ? c2 : c3);
         if (rank == 1) {
           if (c >= 6) break;
           const int i = c >> 1;  // both the "+" and the "-" attempt use +e_i (reference quirk :443-448)
@@ -297,7 +299,7 @@ const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
           const V3<T> axis = mk<T>(i == 0 ? T(1) : T(0), i == 1 ? T(1) : T(0), i == 2 ? T(1) : T(0));
           const V3<T> p = cross(d, axis);
           if (is_zero(p)) {
-            cnt[rank] = (i + 1) * 2;
+            c2 = (i + 1) * 2;
             continue;
           }
           dir = (c & 1) ? -p : p;
@@ -306,7 +308,7 @@ const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
           if (c >= 2) break;
           const V3<T> axis = cross(vw(1) - vw(0), vw(2) - vw(0));
           if (is_zero(axis)) {
-            cnt[rank] = 2;
+            c3 = 2;
             continue;
           }
           dir = (c & 1) ? -axis : axis;
@@ -319,7 +321,9 @@ const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
         entering = false;
         continue;
       }
-      ++cnt[rank];
+      if (rank == 1) ++c1;
+      if (rank == 2) ++c2;
+      if (rank == 3) ++c3;
       V3<T> w, w0;
       sup(dir, w, w0);
       Grp::sync();
@@ -408,8 +412,8 @@ const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
         out.iterations = iterations;
         out.normal = outer_n;
         out.depth = outer_d + ssr_sum;
-        out.rw[0] = vw(o0); out.rw[1] = vw(o1); out.rw[2] = vw(o2);
-        out.rw0[0] = v0(o0); out.rw0[1] = v0(o1); out.rw0[2] = v0(o2);
+        out.rw0_ = vw(o0); out.rw1_ = vw(o1); out.rw2_ = vw(o2);
+        out.r00 = v0(o0); out.r01 = v0(o1); out.r02 = v0(o2);
         return;
       }
     }
@@ -420,17 +424,15 @@ const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
     const T nl = norm(n);
     out.normal = (nl > T(0)) ? (n / nl) : mk<T>(T(1), T(0), T(0));
     out.depth = T(0);
-    out.rw[0] = vw(0);
-    out.rw0[0] = v0(0);
+    out.rw0_ = vw(0);
+    out.r00 = v0(0);
   }
 };
 
 // EPA::getWitnessPointsAndNormal (:1451-1466) + inflate, shape-0 frame
 template <typename T>
 HFCL_HD void epa_witness_normal(const EpaResult<T>& r, T r0, T r1, V3<T>& w0, V3<T>& w1, V3<T>& normal) {
-  V3<T> w1v[3];
-  for (int i = 0; i < 3; ++i) w1v[i] = r.rw0[i] - r.rw[i];
-  closest_points(3, r.rw, r.rw0, w1v, w0, w1);
+  closest_points(3, r.rw0_, r.rw1_, r.rw2_, r.r00, r.r01, r.r02, r.r00 - r.rw0_, r.r01 - r.rw1_, r.r02 - r.rw2_, w0, w1);
   if (norm(w0 - w1) > Lim<T>::dummy()) {
     normal = (r.depth >= T(0)) ? normalized(w0 - w1) : normalized(w1 - w0);
   } else {

@@ -544,43 +544,41 @@ HFCL_HD void project_tetra_origin(const V3<T>& a, const V3<T>& b, const V3<T>& c
   }
 }
 
-// getClosestPoints for rank 1..3: wv/w0/w1 hold the simplex vertices oldest-first.
+// getClosestPoints for rank 1..3.  (va,vb,vc) = simplex.vertex[0..2] (oldest first), each given
+// as w / w0 / w1.  Plain V3 arguments (no arrays) so everything stays in registers.
 template <typename T>
-HFCL_HD void closest_points(int rank, const V3<T> wv[3], const V3<T> w0v[3], const V3<T> w1v[3], V3<T>& w0, V3<T>& w1) {
+HFCL_HD void closest_points(int rank, const V3<T>& aw, const V3<T>& bw, const V3<T>& cw, const V3<T>& a0, const V3<T>& b0,
+                            const V3<T>& c0, const V3<T>& a1, const V3<T>& b1, const V3<T>& c1, V3<T>& w0, V3<T>& w1) {
   if (rank == 1) {
-    w0 = w0v[0];
-    w1 = w1v[0];
+    w0 = a0;
+    w1 = a1;
     return;
   }
   if (rank == 2) {
-    const V3<T> a = wv[0], b = wv[1];
-    const V3<T> N = b - a;
-    T la = dot(N, -a);
+    const V3<T> N = bw - aw;
+    T la = dot(N, -aw);
     if (la <= T(0)) {
-      w0 = w0v[0];
-      w1 = w1v[0];
+      w0 = a0;
+      w1 = a1;
     } else {
       T lb = sqnorm(N);
       if (la > lb) {
-        w0 = w0v[1];
-        w1 = w1v[1];
+        w0 = b0;
+        w1 = b1;
       } else {
         lb = la / lb;
         la = T(1) - lb;
-        w0 = la * w0v[0] + lb * w0v[1];
-        w1 = la * w1v[0] + lb * w1v[1];
+        w0 = la * a0 + lb * b0;
+        w1 = la * a1 + lb * b1;
       }
     }
     return;
   }
   T prm[3];
-  project_triangle_origin(wv[0], wv[1], wv[2], prm);
-  w0 = mk<T>(T(0), T(0), T(0));
-  w1 = w0;
-  for (int i = 0; i < 3; ++i) {
-    w0 = w0 + prm[i] * w0v[i];
-    w1 = w1 + prm[i] * w1v[i];
-  }
+  project_triangle_origin(aw, bw, cw, prm);
+  const V3<T> z = mk<T>(T(0), T(0), T(0));
+  w0 = ((z + prm[0] * a0) + prm[1] * b0) + prm[2] * c0;
+  w1 = ((z + prm[0] * a1) + prm[1] * b1) + prm[2] * c1;
 }
 
 // GJK::getWitnessPointsAndNormal (gjk.cpp:177-186) + details::inflate (:158-173), shape-0 frame

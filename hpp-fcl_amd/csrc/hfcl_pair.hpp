@@ -114,11 +114,9 @@ HFCL_HD bool gjk_finish(const Gjk<T, PW0<T>>& g, const QParams<T>& q, const Pose
   // NoCollision / CollisionWithPenetrationInformation / Failed: GJKExtractWitnessPointsAndNormal :610-636
   const SV ref0 = svsel(r == 1, g.s0, svsel(r == 2, g.s1, g.s2));
   const SV ref1 = svsel(r == 2, g.s0, g.s1);
-  V3<T> wv[3] = {ref0.w, ref1.w, g.s0.w};
-  V3<T> w0v[3] = {ref0.p.w0, ref1.p.w0, g.s0.p.w0};
-  V3<T> w1v[3] = {ref0.p.w0 - ref0.w, ref1.p.w0 - ref1.w, g.s0.p.w0 - g.s0.w};
   V3<T> p1, p2, n;
-  closest_points(r, wv, w0v, w1v, p1, p2);
+  closest_points(r, ref0.w, ref1.w, g.s0.w, ref0.p.w0, ref1.p.w0, g.s0.p.w0, ref0.p.w0 - ref0.w, ref1.p.w0 - ref1.w,
+                 g.s0.p.w0 - g.s0.w, p1, p2);
   gjk_witness_normal(g.ray, r0, r1, p1, p2, n);
   to_world(tf1, g.distance, p1, p2, n);
   out.distance = g.distance;
@@ -135,7 +133,12 @@ HFCL_HD void epa_run(EpaScratch<T>* scratch, const EpaSeed<T>& seed, const QPara
                      Sup& sup, PairOut<T>& out) {
   Epa<T, Grp> epa;
   epa.reset(scratch, q.epa_max_iterations, q.epa_tolerance);
-  for (int i = 0; i < seed.rank; ++i) epa.set_vert(i, seed.w[i], seed.w0[i]);
+  // all four slots are written (slots >= rank are scratch that encloseOrigin overwrites): constant
+  // indices keep the seed in registers
+  epa.set_vert(0, seed.w[0], seed.w0[0]);
+  epa.set_vert(1, seed.w[1], seed.w0[1]);
+  epa.set_vert(2, seed.w[2], seed.w0[2]);
+  epa.set_vert(3, seed.w[3], seed.w0[3]);
   Grp::sync();
   EpaResult<T> res;
   epa.evaluate(seed.rank, -seed.guess, r0 + r1, sup, res);
