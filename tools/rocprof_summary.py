@@ -12,7 +12,7 @@ import sys
 def kernel_stats(db):
     con = sqlite3.connect(db)
     rows = list(con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    out = ["# kernel-trace stats: %s" % db, "%-90s %8s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct")]
+    out = ["# kernel-trace stats: %s" % db, "%-90s %8s %14s %12s %7s" % ("kernel", "calls", "total_ms", "avg_ms", "pct")]
     for name, calls, tot, avg, pct in rows:
         out.append("%-90s %8d %14.1f %12.2f %7.2f" % (name[:90], calls, tot / 1e3, avg / 1e3, pct))
     return "\n".join(out)
