@@ -502,6 +502,8 @@ HFCL_HD T project_triangle_origin(const V3<T>& a, const V3<T>& b, const V3<T>& c
 }
 
 // Project::projectTetrahedraOrigin (src/intersect.cpp:648-705); only the parameterisation.
+// The loop over the three faces (a,b,d), (b,c,d), (c,a,d) is written out so that no array is
+// indexed dynamically (registers only).
 template <typename T>
 HFCL_HD void project_tetra_origin(const V3<T>& a, const V3<T>& b, const V3<T>& c, const V3<T>& d, T prm[4]) {
   prm[0] = prm[1] = prm[2] = prm[3] = T(0);
@@ -510,22 +512,28 @@ HFCL_HD void project_tetra_origin(const V3<T>& a, const V3<T>& b, const V3<T>& c
   const bool ng = (vl * dot(a, cross(b - c, a - b))) <= T(0);
   if (ng && habs(vl) > T(0)) {
     T mindist = T(-1);
-    // faces (vt[i], vt[j], d) for (i,j) = (0,1), (1,2), (2,0)
-    const V3<T> vi[3] = {a, b, c};
-    const V3<T> di[3] = {dl0, dl1, dl2};
-    for (int i = 0; i < 3; ++i) {
-      const int j = (i + 1) % 3;
-      const T s = vl * dot(d, cross(di[i], di[j]));
-      if (s > T(0)) {
-        T q[3];
-        const T sq = project_triangle_origin(vi[i], vi[j], d, q);
-        if (mindist < T(0) || sq < mindist) {
-          mindist = sq;
-          prm[i] = q[0];
-          prm[j] = q[1];
-          prm[(j + 1) % 3] = T(0);
-          prm[3] = q[2];
-        }
+    if (vl * dot(d, cross(dl0, dl1)) > T(0)) {  // i = 0, j = 1
+      T q[3];
+      const T sq = project_triangle_origin(a, b, d, q);
+      if (mindist < T(0) || sq < mindist) {
+        mindist = sq;
+        prm[0] = q[0]; prm[1] = q[1]; prm[2] = T(0); prm[3] = q[2];
+      }
+    }
+    if (vl * dot(d, cross(dl1, dl2)) > T(0)) {  // i = 1, j = 2
+      T q[3];
+      const T sq = project_triangle_origin(b, c, d, q);
+      if (mindist < T(0) || sq < mindist) {
+        mindist = sq;
+        prm[1] = q[0]; prm[2] = q[1]; prm[0] = T(0); prm[3] = q[2];
+      }
+    }
+    if (vl * dot(d, cross(dl2, dl0)) > T(0)) {  // i = 2, j = 0
+      T q[3];
+      const T sq = project_triangle_origin(c, a, d, q);
+      if (mindist < T(0) || sq < mindist) {
+        mindist = sq;
+        prm[2] = q[0]; prm[0] = q[1]; prm[1] = T(0); prm[3] = q[2];
       }
     }
     if (mindist < T(0)) {

@@ -10,6 +10,9 @@
 //   k_gjk_cvx<T,W,M> GJK with convex hulls: one pair per W-lane group, hull vertices distributed
 //                   over the group's registers, support = per-lane dots + xor-butterfly arg-max
 //   k_epa<T>        EPA on the pairs GJK left in `Collision`: one pair per wavefront, polytope in LDS
+//   k_bvh_collide<T> BVHModel<OBBRSS> x BVHModel<OBBRSS> collide(): one mesh pair per lane, explicit DFS
+//                   stack in LDS (reference order, so the first contact is the reference's), OBB SAT per
+//                   node pair, triangle-triangle GJK at the leaves (batched per wave to limit divergence)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -20,6 +23,7 @@
 #include <vector>
 
 #include "../../include/hppfcl_amd.h"
+#include "hfcl_bvh.hpp"
 #include "hfcl_pair.hpp"
 
 using namespace hfcl;
@@ -112,6 +116,32 @@ __device__ __forceinline__ void write_out(const IO<T>& io, const QParams<T>& q, 
   int nc;
   const bool contact = apply_query_semantics(q, o, nc);
   store_record(io, pair, o, contact, nc);
+}
+
+// BVH pair record: distance = distance_lower_bound + margin (= the first contact's penetration depth
+// when num_max_contacts == 1), p1/p2/normal = CollisionResult::nearest_points/normal, b1/b2 = first contact.
+__device__ __forceinline__ void store_bvh_record(const IO<double>& io, uint32_t pair, const PairOut<double>& o, uint32_t nc,
+                                                 int b1, int b2, bool overflow) {
+  hfcl_result r;
+  r.distance = o.distance;
+  r.normal[0] = o.normal.x; r.normal[1] = o.normal.y; r.normal[2] = o.normal.z;
+  r.p1[0] = o.p1.x; r.p1[1] = o.p1.y; r.p1[2] = o.p1.z;
+  r.p2[0] = o.p2.x; r.p2[1] = o.p2.y; r.p2[2] = o.p2.z;
+  r.b1 = b1;
+  r.b2 = b2;
+  r.status = (nc ? 128u : 0u) | (overflow ? 0xC0000000u : 0u);
+  r.num_contacts = int(nc);
+  io.out[pair] = r;
+}
+__device__ __forceinline__ void store_bvh_record(const IO<float>& io, uint32_t pair, const PairOut<float>& o, uint32_t nc,
+                                                 int, int, bool overflow) {
+  hfcl_result_f32 r;
+  r.distance = o.distance;
+  r.p1[0] = o.p1.x; r.p1[1] = o.p1.y; r.p1[2] = o.p1.z;
+  r.p2[0] = o.p2.x; r.p2[1] = o.p2.y; r.p2[2] = o.p2.z;
+  r.normal[0] = o.normal.x; r.normal[1] = o.normal.y; r.normal[2] = o.normal.z;
+  r.status = (nc ? 128u : 0u) | (overflow ? 0xC0000000u : 0u);
+  io.out[pair] = r;
 }
 
 template <typename T>
@@ -407,6 +437,191 @@ __global__ void __launch_bounds__(256) k_epa(Work wk, LibView<T> lib, IO<T> io, 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// k_bvh_collide: BVHModel<OBBRSS> x BVHModel<OBBRSS> collide().
+// Traversal = collisionRecurse (src/traversal/traversal_recurse.cpp:44-85) with the recursion
+// flattened into a per-lane LDS stack; children are pushed right-then-left so they pop in the
+// reference's order, and the walk ends as soon as num_max_contacts contacts exist (canStop()).
+// ---------------------------------------------------------------------------------------
+struct DMesh {
+  uint32_t node_off, vert_off, tri_off, n_nodes;
+};
+template <typename T>
+struct BvhView {
+  const DNode<T>* nodes;
+  const T* verts;        // xyz
+  const uint32_t* tris;  // 3 local vertex ids per triangle
+  const DMesh* meshes;
+  uint32_t n_meshes;
+};
+struct BvhParams {
+  uint32_t num_max_contacts;
+  hfcl_contact* contacts;   // optional device contact list
+  uint32_t contacts_cap;
+  uint32_t* contacts_count;
+};
+
+constexpr int BVH_STACK = 96;
+constexpr int BVH_BLOCK = 128;
+
+template <typename T>
+__global__ void __launch_bounds__(BVH_BLOCK) k_bvh_collide(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
+                                                          BvhParams bp, T break_distance2) {
+  __shared__ uint32_t stack[BVH_STACK][BVH_BLOCK];
+  const uint32_t cnt = wk.counts[B_BVH];
+  const int tid = threadIdx.x;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const T nanv = Lim<T>::nan();
+  for (uint32_t base = blockIdx.x * blockDim.x; base < cnt; base += stride) {
+    const uint32_t it = base + tid;
+    const bool valid = it < cnt;
+    uint32_t pair = 0;
+    DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
+    Pose<T> tf1, tf2;
+    M3<T> RT_R;
+    V3<T> RT_T;
+    int sp = 0;
+    bool overflow = false;
+    if (valid) {
+      pair = wk.lists[size_t(B_BVH) * wk.n + it];
+      const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+      m1 = bv.meshes[a.bvh_index];
+      m2 = bv.meshes[b.bvh_index];
+      tf1 = load_pose(io.tf1, pair);
+      tf2 = load_pose(io.tf2, pair);
+      RT_R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
+      RT_T = tmul(tf1.R, tf2.t - tf1.t);
+      stack[0][tid] = 0u;  // (b1 = 0, b2 = 0)
+      sp = 1;
+    }
+    uint32_t ncontacts = 0;
+    T dlb = Lim<T>::max(), rec_dist = Lim<T>::max();
+    V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1, nn = np1;
+    int fb1 = -1, fb2 = -1;
+    bool have_leaf = false;
+    uint32_t lb1 = 0, lb2 = 0;
+    for (;;) {
+      // ---- BV phase: advance every lane that has no leaf test pending
+      for (;;) {
+        const bool can_bv = !have_leaf && sp > 0;
+        if (!__any(can_bv)) break;
+        if (__popcll(__ballot(have_leaf)) >= 32) break;
+        if (can_bv) {
+          const uint32_t e = stack[--sp][tid];
+          const uint32_t b1 = e & 0xFFFFu, b2 = e >> 16;
+          const DNode<T> n1 = bv.nodes[m1.node_off + b1];
+          const DNode<T> n2 = bv.nodes[m2.node_off + b2];
+          const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
+          if (l1 && l2) {
+            have_leaf = true;
+            lb1 = uint32_t(-(n1.first_child + 1));
+            lb2 = uint32_t(-(n2.first_child + 1));
+          } else {
+            T sq;
+            // argument order of the reference: overlap(RT.R, RT.T, model2.bv(b2), model1.bv(b1))
+            const bool disjoint = obb_disjoint(RT_R, RT_T, n2, n1, q.security_margin, break_distance2, sq);
+            if (disjoint) {  // updateDistanceLowerBoundFromBV
+              if (!(dlb <= T(0))) {
+                const T nd = hsqrt(sq);
+                if (nd < dlb) {
+                  dlb = nd;
+                  rec_dist = nd + q.security_margin;
+                }
+              }
+            } else {
+              const T sz1 = sqnorm(n1.extent), sz2 = sqnorm(n2.extent);
+              const bool first = l2 || (!l1 && (sz1 > sz2));  // firstOverSecond
+              uint32_t ea, eb;
+              if (first) {
+                const uint32_t c1 = uint32_t(n1.first_child);
+                ea = c1 | (b2 << 16);
+                eb = (c1 + 1) | (b2 << 16);
+              } else {
+                const uint32_t c1 = uint32_t(n2.first_child);
+                ea = b1 | (c1 << 16);
+                eb = b1 | ((c1 + 1) << 16);
+              }
+              if (sp + 2 > BVH_STACK) {
+                overflow = true;
+                sp = 0;
+              } else {
+                stack[sp++][tid] = eb;  // second child below
+                stack[sp++][tid] = ea;  // first child on top
+              }
+            }
+          }
+        }
+      }
+      if (!__any(have_leaf)) break;
+      // ---- leaf phase (leafCollides, traversal_node_bvhs.h:184-233)
+      if (have_leaf) {
+        have_leaf = false;
+        const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + lb1);
+        const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + lb2);
+        const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
+        const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
+        auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
+        TriSupport<T> tri;
+        tri.p1 = xform(tf1, vtx(v1, t1[0]));
+        tri.p2 = xform(tf1, vtx(v1, t1[1]));
+        tri.p3 = xform(tf1, vtx(v1, t1[2]));
+        tri.q1 = xform(tf2, vtx(v2, t2[0]));
+        tri.q2 = xform(tf2, vtx(v2, t2[1]));
+        tri.q3 = xform(tf2, vtx(v2, t2[2]));
+        V3<T> p1, p2, n;
+        int gst, git;
+        const T distance = tri_tri_distance(tri, q.gjk, q.guess_mode == HFCL_GUESS_CACHED,
+                                            mk<T>(q.guess[0], q.guess[1], q.guess[2]), p1, p2, n, gst, git);
+        const T dtc = distance - q.security_margin;
+        if (dtc < dlb) {  // updateDistanceLowerBoundFromLeaf
+          dlb = dtc;
+          rec_dist = distance;
+          np1 = p1;
+          np2 = p2;
+          nn = n;
+        }
+        if (dtc <= q.collision_distance_threshold) {
+          if (ncontacts < bp.num_max_contacts) {
+            if (ncontacts == 0) {
+              fb1 = int(lb1);
+              fb2 = int(lb2);
+            }
+            ++ncontacts;
+            if (bp.contacts) {
+              const uint32_t slot = atomicAdd(bp.contacts_count, 1u);
+              if (slot < bp.contacts_cap) {
+                hfcl_contact c;
+                c.pair = pair;
+                c.b1 = int(lb1);
+                c.b2 = int(lb2);
+                c._pad = 0;
+                c.penetration_depth = double(distance);
+                c.normal[0] = n.x; c.normal[1] = n.y; c.normal[2] = n.z;
+                c.p1[0] = p1.x; c.p1[1] = p1.y; c.p1[2] = p1.z;
+                c.p2[0] = p2.x; c.p2[1] = p2.y; c.p2[2] = p2.z;
+                bp.contacts[slot] = c;
+              }
+            }
+          }
+          if (ncontacts >= bp.num_max_contacts) sp = 0;  // canStop(): nothing else is visited
+        }
+      }
+    }
+    if (valid) {
+      PairOut<T> o;
+      o.distance = rec_dist;
+      o.normal = nn;
+      o.p1 = np1;
+      o.p2 = np2;
+      o.gjk_status = GJK_DID_NOT_RUN;
+      o.epa_status = EPA_DID_NOT_RUN;
+      o.gjk_iters = o.epa_iters = 0;
+      store_bvh_record(io, pair, o, ncontacts, fb1, fb2, overflow);
+    }
+  }
+}
+
 // =======================================================================================
 // Host side: library object + C ABI
 // =======================================================================================
@@ -454,6 +669,24 @@ struct hfcl_lib {
   int n_cus = 256;
   std::string dominant;
   uint32_t h_counts[B_COUNT + 1] = {0};
+  // BVH models (host staging + device images in both precisions; uploaded lazily)
+  std::vector<hfcl_bvh_node> h_bvh_nodes;
+  std::vector<double> h_bvh_verts;
+  std::vector<uint32_t> h_bvh_tris;
+  std::vector<DMesh> h_meshes;
+  bool bvh_dirty = false;
+  DNode<double>* d_nodes64 = nullptr;
+  DNode<float>* d_nodes32 = nullptr;
+  double* d_bverts64 = nullptr;
+  float* d_bverts32 = nullptr;
+  uint32_t* d_btris = nullptr;
+  DMesh* d_meshes = nullptr;
+  // contact list of the last hfcl_collide_batch_contacts call
+  hfcl_contact* d_contacts = nullptr;
+  size_t contacts_cap = 0;
+  uint32_t* d_contacts_count = nullptr;
+  BvhParams bvh_params = {1u, nullptr, 0u, nullptr};
+  double break_distance = 1e-3;
 };
 
 static int ensure_device(int device) {
@@ -621,6 +854,14 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_out);
   hipFree(lib->d_gin);
   hipFree(lib->d_gout);
+  hipFree(lib->d_nodes64);
+  hipFree(lib->d_nodes32);
+  hipFree(lib->d_bverts64);
+  hipFree(lib->d_bverts32);
+  hipFree(lib->d_btris);
+  hipFree(lib->d_meshes);
+  hipFree(lib->d_contacts);
+  hipFree(lib->d_contacts_count);
   for (auto& t : lib->timers) {
     hipEventDestroy(t.e0);
     hipEventDestroy(t.e1);
@@ -630,9 +871,43 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
 size_t hfcl_lib_num_shapes(const hfcl_lib* lib) { return lib ? lib->n_shapes : 0; }
 int hfcl_lib_device(const hfcl_lib* lib) { return lib ? lib->device : -1; }
 
-int hfcl_lib_add_bvh(hfcl_lib*, const hfcl_bvh_node*, size_t, const double*, size_t, const uint32_t*, size_t) {
-  set_error("hfcl_lib_add_bvh: BVHModel<OBBRSS> traversal is not built yet (SURVEY.md 8a rows a15-a19)");
-  return -1;
+int hfcl_lib_add_bvh(hfcl_lib* lib, const hfcl_bvh_node* nodes, size_t n_nodes, const double* vertices,
+                     size_t n_vertices, const uint32_t* triangles, size_t n_tris) {
+  if (!lib || !nodes || !vertices || !triangles || n_tris == 0) {
+    set_error("hfcl_lib_add_bvh: null/empty input");
+    return -1;
+  }
+  if (n_nodes != 2 * n_tris - 1) {  // BVH_model.cpp:821-825
+    set_error("hfcl_lib_add_bvh: a BVHModel with T triangles has exactly 2T-1 nodes");
+    return -1;
+  }
+  if (n_nodes > 65535) {
+    set_error("hfcl_lib_add_bvh: more than 65535 BV nodes per model (16-bit node ids on the device stack)");
+    return -1;
+  }
+  for (size_t i = 0; i < n_nodes; ++i) {
+    const int fc = nodes[i].first_child;
+    if (fc == 0 || (fc > 0 && size_t(fc) + 1 > n_nodes - 1) || (fc < 0 && size_t(-(fc + 1)) >= n_tris)) {
+      set_error("hfcl_lib_add_bvh: malformed node array (first_child out of range)");
+      return -1;
+    }
+  }
+  for (size_t i = 0; i < 3 * n_tris; ++i)
+    if (triangles[i] >= n_vertices) {
+      set_error("hfcl_lib_add_bvh: triangle vertex index out of range");
+      return -1;
+    }
+  DMesh m;
+  m.node_off = uint32_t(lib->h_bvh_nodes.size());
+  m.vert_off = uint32_t(lib->h_bvh_verts.size() / 3);
+  m.tri_off = uint32_t(lib->h_bvh_tris.size() / 3);
+  m.n_nodes = uint32_t(n_nodes);
+  lib->h_bvh_nodes.insert(lib->h_bvh_nodes.end(), nodes, nodes + n_nodes);
+  lib->h_bvh_verts.insert(lib->h_bvh_verts.end(), vertices, vertices + 3 * n_vertices);
+  lib->h_bvh_tris.insert(lib->h_bvh_tris.end(), triangles, triangles + 3 * n_tris);
+  lib->h_meshes.push_back(m);
+  lib->bvh_dirty = true;
+  return int(lib->h_meshes.size() - 1);
 }
 
 }  // extern "C"
@@ -648,6 +923,51 @@ static int ensure_workspace(hfcl_lib* lib, size_t n) {
   HIP_TRY(hipMalloc(&lib->d_lists, size_t(B_COUNT) * cap * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&lib->d_epa_queue, cap * sizeof(EpaItem<double>)));
   lib->ws_capacity = cap;
+  return HFCL_OK;
+}
+
+template <typename T>
+static DNode<T> pack_node(const hfcl_bvh_node& n) {
+  DNode<T> d;
+  d.first_child = n.first_child;
+  d.pad_ = 0;
+  const double* a = n.obb_axes;  // column-major
+  d.axes.r0 = mk<T>(T(a[0]), T(a[3]), T(a[6]));
+  d.axes.r1 = mk<T>(T(a[1]), T(a[4]), T(a[7]));
+  d.axes.r2 = mk<T>(T(a[2]), T(a[5]), T(a[8]));
+  d.To = mk<T>(T(n.obb_To[0]), T(n.obb_To[1]), T(n.obb_To[2]));
+  d.extent = mk<T>(T(n.obb_extent[0]), T(n.obb_extent[1]), T(n.obb_extent[2]));
+  return d;
+}
+
+static int upload_bvh(hfcl_lib* lib) {
+  if (!lib->bvh_dirty) return HFCL_OK;
+  hipFree(lib->d_nodes64); hipFree(lib->d_nodes32); hipFree(lib->d_bverts64); hipFree(lib->d_bverts32);
+  hipFree(lib->d_btris); hipFree(lib->d_meshes);
+  lib->d_nodes64 = nullptr; lib->d_nodes32 = nullptr; lib->d_bverts64 = nullptr; lib->d_bverts32 = nullptr;
+  lib->d_btris = nullptr; lib->d_meshes = nullptr;
+  const size_t nn = lib->h_bvh_nodes.size(), nv = lib->h_bvh_verts.size(), nt = lib->h_bvh_tris.size();
+  std::vector<DNode<double>> n64(nn);
+  std::vector<DNode<float>> n32(nn);
+  for (size_t i = 0; i < nn; ++i) {
+    n64[i] = pack_node<double>(lib->h_bvh_nodes[i]);
+    n32[i] = pack_node<float>(lib->h_bvh_nodes[i]);
+  }
+  std::vector<float> v32(nv);
+  for (size_t i = 0; i < nv; ++i) v32[i] = float(lib->h_bvh_verts[i]);
+  HIP_TRY(hipMalloc(&lib->d_nodes64, nn * sizeof(DNode<double>)));
+  HIP_TRY(hipMalloc(&lib->d_nodes32, nn * sizeof(DNode<float>)));
+  HIP_TRY(hipMalloc(&lib->d_bverts64, nv * sizeof(double)));
+  HIP_TRY(hipMalloc(&lib->d_bverts32, nv * sizeof(float)));
+  HIP_TRY(hipMalloc(&lib->d_btris, nt * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&lib->d_meshes, lib->h_meshes.size() * sizeof(DMesh)));
+  HIP_TRY(hipMemcpy(lib->d_nodes64, n64.data(), nn * sizeof(DNode<double>), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_nodes32, n32.data(), nn * sizeof(DNode<float>), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_bverts64, lib->h_bvh_verts.data(), nv * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_bverts32, v32.data(), nv * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_btris, lib->h_bvh_tris.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_meshes, lib->h_meshes.data(), lib->h_meshes.size() * sizeof(DMesh), hipMemcpyHostToDevice));
+  lib->bvh_dirty = false;
   return HFCL_OK;
 }
 
@@ -778,6 +1098,22 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   else if (w == 64) launch_cvx<T, 64>(lib, wk, lv, io, q, st, ti, cgrid);
   else launch_cvx<T, 8>(lib, wk, lv, io, q, st, ti, cgrid);
 
+  if (!lib->h_meshes.empty() && q.mode == 1) {
+    rc = upload_bvh(lib);
+    if (rc) return rc;
+    BvhView<T> bv;
+    bv.nodes = std::is_same<T, double>::value ? (const DNode<T>*)lib->d_nodes64 : (const DNode<T>*)lib->d_nodes32;
+    bv.verts = std::is_same<T, double>::value ? (const T*)lib->d_bverts64 : (const T*)lib->d_bverts32;
+    bv.tris = lib->d_btris;
+    bv.meshes = lib->d_meshes;
+    bv.n_meshes = uint32_t(lib->h_meshes.size());
+    t = timer_slot(lib, ti++, "k_bvh_collide");
+    hipEventRecord(t->e0, st);
+    hipLaunchKernelGGL((k_bvh_collide<T>), dim3(blocks_for(n, BVH_BLOCK)), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q,
+                       lib->bvh_params, T(lib->break_distance * lib->break_distance));
+    hipEventRecord(t->e1, st);
+  }
+
   t = timer_slot(lib, ti++, "k_unsupported");
   hipEventRecord(t->e0, st);
   hipLaunchKernelGGL((k_unsupported<T>), dim3(blocks_for(n, 256 * 64)), dim3(256), 0, st, wk, io);
@@ -879,6 +1215,8 @@ int hfcl_collide_batch_device(hfcl_lib* lib, const uint32_t* d_shape1, const uin
     return HFCL_OK;
   }
   IO<double> io{d_tf1, d_tf2, d_out, d_guess_in, d_guess_out};
+  lib->bvh_params.num_max_contacts = req->num_max_contacts;
+  lib->break_distance = req->break_distance;
   return run_batch<double>(lib, d_shape1, d_shape2, io, n, q, st);
 }
 
@@ -928,6 +1266,8 @@ int hfcl_collide_batch_device_f32(hfcl_lib* lib, const uint32_t* d_shape1, const
     return HFCL_OK;
   }
   IO<float> io{d_pose1, d_pose2, d_out, nullptr, nullptr};
+  lib->bvh_params.num_max_contacts = req->num_max_contacts;
+  lib->break_distance = req->break_distance;
   return run_batch<float>(lib, d_shape1, d_shape2, io, n, q, st);
 }
 
@@ -989,8 +1329,8 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
               std::to_string(lib->h_counts[B_UNSUPPORTED]) + " pairs; their records carry status bit 31)");
     return HFCL_ERR_UNSUPPORTED_PAIR;
   }
-  if (!skipped && lib->h_counts[B_BVH] > 0) {
-    set_error("BVHModel<OBBRSS> pairs in batch: traversal kernel not built yet");
+  if (!skipped && lib->h_counts[B_BVH] > 0 && !creq) {
+    set_error("distance() between BVHModel<OBBRSS> pairs is not built yet (collide() is)");
     return HFCL_ERR_UNSUPPORTED_PAIR;
   }
   return HFCL_OK;
@@ -1015,10 +1355,37 @@ int hfcl_distance_batch(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* s
   return host_batch(lib, shape1, shape2, tf1, tf2, n, nullptr, req, out, guess_in, guess_out);
 }
 
-int hfcl_collide_batch_contacts(hfcl_lib*, const uint32_t*, const uint32_t*, const double*, const double*, size_t,
-                                const hfcl_collision_request*, hfcl_result*, hfcl_contact*, size_t, size_t*) {
-  set_error("hfcl_collide_batch_contacts: mesh-mesh traversal is not built yet");
-  return HFCL_ERR_UNSUPPORTED_PAIR;
+int hfcl_collide_batch_contacts(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2, const double* tf1,
+                                const double* tf2, size_t n, const hfcl_collision_request* req, hfcl_result* out,
+                                hfcl_contact* contacts, size_t max_contacts_total, size_t* n_contacts_out) {
+  if (!lib || !req || !contacts || !n_contacts_out) {
+    set_error("null argument");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(lib->device));
+  if (max_contacts_total > lib->contacts_cap) {
+    hipFree(lib->d_contacts);
+    lib->d_contacts = nullptr;
+    lib->contacts_cap = 0;
+    HIP_TRY(hipMalloc(&lib->d_contacts, max_contacts_total * sizeof(hfcl_contact)));
+    lib->contacts_cap = max_contacts_total;
+  }
+  if (!lib->d_contacts_count) HIP_TRY(hipMalloc(&lib->d_contacts_count, sizeof(uint32_t)));
+  HIP_TRY(hipMemset(lib->d_contacts_count, 0, sizeof(uint32_t)));
+  lib->bvh_params.contacts = lib->d_contacts;
+  lib->bvh_params.contacts_cap = uint32_t(max_contacts_total > 0xFFFFFFFFull ? 0xFFFFFFFFull : max_contacts_total);
+  lib->bvh_params.contacts_count = lib->d_contacts_count;
+  int rc = host_batch(lib, shape1, shape2, tf1, tf2, n, req, nullptr, out, nullptr, nullptr);
+  lib->bvh_params.contacts = nullptr;
+  lib->bvh_params.contacts_cap = 0;
+  lib->bvh_params.contacts_count = nullptr;
+  if (rc) return rc;
+  uint32_t cnt = 0;
+  HIP_TRY(hipMemcpy(&cnt, lib->d_contacts_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  const size_t stored = cnt < max_contacts_total ? cnt : max_contacts_total;
+  if (stored) HIP_TRY(hipMemcpy(contacts, lib->d_contacts, stored * sizeof(hfcl_contact), hipMemcpyDeviceToHost));
+  *n_contacts_out = cnt;  // number produced (may exceed the capacity; the excess was dropped)
+  return HFCL_OK;
 }
 
 double hfcl_last_kernel_ms(hfcl_lib* lib) {

@@ -104,6 +104,32 @@ class Library:
         except Exception:
             pass
 
+    def add_bvh(self, mesh):
+        """Register a BVHModel<OBBRSS> (bvh_builder.Mesh); returns its bvh_index."""
+        nodes = np.ascontiguousarray(mesh.nodes)
+        verts = np.ascontiguousarray(mesh.vertices, dtype=np.float64)
+        tris = np.ascontiguousarray(mesh.triangles, dtype=np.uint32)
+        idx = dll().hfcl_lib_add_bvh(self._h, abi.ptr(nodes), C.c_size_t(len(nodes)), abi.ptr(verts),
+                                     C.c_size_t(len(verts)), abi.ptr(tris), C.c_size_t(len(tris)))
+        if idx < 0:
+            raise EngineError(abi.ERR_INVALID_ARGUMENT, last_error())
+        return idx
+
+    def collide_contacts(self, s1, s2, tf1, tf2, req, max_contacts):
+        """Batched collide() returning (records, contacts[CONTACT_DTYPE], n_produced)."""
+        s1 = np.ascontiguousarray(s1, dtype=np.uint32)
+        s2 = np.ascontiguousarray(s2, dtype=np.uint32)
+        tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
+        tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
+        n = len(s1)
+        out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+        contacts = np.zeros(max_contacts, dtype=abi.CONTACT_DTYPE)
+        nc = C.c_size_t(0)
+        _check(dll().hfcl_collide_batch_contacts(self._h, abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1), abi.ptr(tf2),
+                                                 C.c_size_t(n), C.byref(req), abi.ptr(out), abi.ptr(contacts),
+                                                 C.c_size_t(max_contacts), C.byref(nc)))
+        return out, contacts[:min(nc.value, max_contacts)], int(nc.value)
+
     # ---- host-buffer entry points (H2D + kernels + D2H inside the call) ----
     def _host(self, fn, s1, s2, tf1, tf2, req, guess_in, want_guess):
         s1 = np.ascontiguousarray(s1, dtype=np.uint32)

@@ -44,6 +44,7 @@ class Batch:
         self.quat1, self.T1, self.quat2, self.T2 = quat1, T1, quat2, T2
         self.kind = kind  # "distance" | "collide"
         self.request_overrides = request_overrides or {}
+        self.meshes = None
 
     def __len__(self):
         return len(self.s1)
@@ -158,6 +159,42 @@ def cfg5_mixed(n=100_000, seed=1, nper=256, half_width=0.8):
     s1, s2 = rng.integers(0, 5 * nper, n), rng.integers(0, 5 * nper, n)
     q1, T1, q2, T2 = _poses(rng, n, half_width)
     return Batch("cfg5_mixed_collide", lib, s1, s2, q1, T1, q2, T2, "collide")
+
+
+_MESH_CACHE = {}
+
+
+def mesh_variants(n_variants=8, seg=50, ring=50):
+    """cfg4 mesh library: perturbed UV spheres (seg=ring=50 -> 5000 triangles, 2502 vertices, 9999 nodes)."""
+    from . import bvh_builder
+    key = (n_variants, seg, ring)
+    if key not in _MESH_CACHE:
+        _MESH_CACHE[key] = [bvh_builder.Mesh(*bvh_builder.bumpy_sphere(seg, ring, r=1.0, amp=0.12 + 0.01 * k,
+                                                                       freq=2 + (k % 3), phase=0.7 * k))
+                            for k in range(n_variants)]
+    return _MESH_CACHE[key]
+
+
+def cfg4_mesh_mesh(n=100_000, seed=1, n_variants=8, seg=50, ring=50, half_width=1.25):
+    """cfg4: BVHModel<OBBRSS> x BVHModel<OBBRSS> collide(), default request (first contact)."""
+    rng = _rng(seed, 4)
+    meshes = mesh_variants(n_variants, seg, ring)
+    lib = geometry.ShapeLibrary()
+    for k, m in enumerate(meshes):
+        lib.add_bvh(k, len(m.vertices))
+    s1, s2 = rng.integers(0, n_variants, n), rng.integers(0, n_variants, n)
+    q1, T1, q2, T2 = _poses(rng, n, half_width)
+    b = Batch("cfg4_mesh_mesh_collide_%dtri" % (2 * seg * ring), lib, s1, s2, q1, T1, q2, T2, "collide")
+    b.meshes = meshes
+    return b
+
+
+def make_library(pkg, batch, device=0):
+    """engine.Library for a batch (registers the batch's meshes, if any)."""
+    lib = pkg.Library(batch.lib, device=device)
+    for m in getattr(batch, "meshes", []) or []:
+        lib.add_bvh(m)
+    return lib
 
 
 def make_request(batch, abi, **kw):

@@ -1,3 +1,37 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path (see vec3.hpp).
-// BVHModel<OBBRSS> traversal restatement -- filled in below.
+//
+// fp64 CPU restatement of BVHModel<OBBRSS> x BVHModel<OBBRSS> collide():
+//   OBB overlap test      src/BV/OBB.cpp:290-393 (obbDisjointAndLowerBoundDistance), :475-483 (overlap)
+//   traversal             src/traversal/traversal_recurse.cpp:44-85 (collisionRecurse)
+//   traversal node        include/hpp/fcl/internal/traversal_node_bvhs.h:89-98 (firstOverSecond),
+//                         :152-168 (BVDisjoints), :184-233 (leafCollides)
+//   setup                 include/hpp/fcl/internal/traversal_node_setup.h:532-566, src/collision_func_matrix.cpp:187-204
+//   lower-bound updates   include/hpp/fcl/collision_data.h:1177-1197
 #pragma once
+#include <vector>
+#include "narrowphase.hpp"
+
+namespace orc {
+
+struct MeshView {
+  const hfcl_bvh_node* nodes = nullptr;
+  size_t n_nodes = 0;
+  const double* verts = nullptr;
+  const uint32_t* tris = nullptr;
+};
+
+struct BvhStats {
+  unsigned num_bv_tests = 0, num_leaf_tests = 0;
+};
+
+// Returns HFCL_OK.  `out` = per-pair record (see DESIGN.md "BVH records"); contacts (may be null)
+// receives every Contact added (up to num_max_contacts), in the reference's DFS order.
+int bvh_collide_pair(const MeshView& m1, const Tf& tf1, const MeshView& m2, const Tf& tf2,
+                     const hfcl_collision_request& req, hfcl_result& out, std::vector<hfcl_contact>* contacts,
+                     uint32_t pair_index, BvhStats* stats);
+
+// OBB overlap (exposed for unit tests): returns true when NOT disjoint.
+bool obb_overlap(const M3& R0, const V3& T0, const hfcl_bvh_node& b1, const hfcl_bvh_node& b2, double security_margin,
+                 double break_distance, double& sqrDistLowerBound);
+
+}  // namespace orc

@@ -2,6 +2,7 @@
 // C entry points (ctypes-friendly) over the fp64 CPU restatement.  Used by tests/, by
 // __graft_entry__.smoke() as the checker, and by bench.py's cpu_baseline leg.
 #include <cstring>
+#include <algorithm>
 #include <thread>
 #include <vector>
 #include "bvh.hpp"
@@ -148,6 +149,48 @@ void orc_shape_support(const hfcl_shape* s, const double* verts, const double* d
   out[0] = r.x;
   out[1] = r.y;
   out[2] = r.z;
+}
+
+// BVHModel<OBBRSS> x BVHModel<OBBRSS> collide().  Mesh table: per mesh (node_off, n_nodes, vert_off, tri_off)
+// into the concatenated node / vertex (xyz doubles) / triangle (3 x uint32, local vertex ids) arrays.
+// out_stats (nullable): 2 x uint32 per pair (num_bv_tests, num_leaf_tests).
+// contacts (nullable): capacity max_contacts; *n_contacts receives the number stored.
+int orc_bvh_collide_batch(const hfcl_bvh_node* nodes, const double* verts, const uint32_t* tris,
+                          const uint64_t* mesh_table, size_t n_meshes, const uint32_t* m1, const uint32_t* m2,
+                          const double* tf1, const double* tf2, size_t n, const hfcl_collision_request* req,
+                          hfcl_result* out, uint32_t* out_stats, hfcl_contact* contacts, size_t max_contacts,
+                          size_t* n_contacts, int n_threads) {
+  std::vector<MeshView> meshes(n_meshes);
+  for (size_t i = 0; i < n_meshes; ++i) {
+    meshes[i].nodes = nodes + mesh_table[4 * i];
+    meshes[i].n_nodes = mesh_table[4 * i + 1];
+    meshes[i].verts = verts + 3 * mesh_table[4 * i + 2];
+    meshes[i].tris = tris + 3 * mesh_table[4 * i + 3];
+  }
+  int err = 0;
+  std::vector<std::vector<hfcl_contact>> per_thread(std::max(1, n_threads));
+  size_t chunk = (n + std::max(1, n_threads) - 1) / std::max(1, n_threads);
+  parallel_for(n, n_threads, [&](size_t b, size_t e) {
+    std::vector<hfcl_contact>& cl = per_thread[chunk ? b / chunk : 0];
+    for (size_t i = b; i < e; ++i) {
+      BvhStats st;
+      int rc = bvh_collide_pair(meshes[m1[i]], tf_from_abi(tf1 + 12 * i), meshes[m2[i]], tf_from_abi(tf2 + 12 * i), *req,
+                                out[i], contacts ? &cl : nullptr, uint32_t(i), &st);
+      if (rc) err = rc;
+      if (out_stats) {
+        out_stats[2 * i] = st.num_bv_tests;
+        out_stats[2 * i + 1] = st.num_leaf_tests;
+      }
+    }
+  });
+  if (contacts) {
+    size_t k = 0;
+    for (auto& cl : per_thread)
+      for (auto& c : cl)
+        if (k < max_contacts) contacts[k++] = c;
+    if (n_contacts) *n_contacts = k;
+  }
+  return err;
 }
 
 }  // extern "C"

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/hppfcl_amd.h"
+#include "../../hpp-fcl_amd/csrc/hfcl_bvh.hpp"
 #include "../../hpp-fcl_amd/csrc/hfcl_pair.hpp"
 
 using namespace hfcl;
@@ -174,6 +175,126 @@ int sim_batch_f32(const hfcl_shape* shapes, size_t n_shapes, const double* verti
     r.p2[0] = o.p2.x; r.p2[1] = o.p2.y; r.p2[2] = o.p2.z;
     r.normal[0] = o.normal.x; r.normal[1] = o.normal.y; r.normal[2] = o.normal.z;
     r.status = pack_status(o.gjk_status, o.epa_status, contact, o.gjk_iters, o.epa_iters);
+  }
+  return 0;
+}
+
+}  // extern "C"
+
+// BVHModel<OBBRSS> collide through the device headers' BV test / leaf test with a serial DFS
+// (same push order and stop rule as k_bvh_collide).  mesh_table: (node_off, n_nodes, vert_off, tri_off).
+template <typename T>
+static void bvh_pair(const std::vector<DNode<T>>& nodes, const std::vector<T>& verts, const uint32_t* tris,
+                     const uint64_t* m1, const uint64_t* m2, const Pose<T>& tf1, const Pose<T>& tf2, const QParams<T>& q,
+                     uint32_t num_max_contacts, T break_distance2, hfcl_result& r, std::vector<hfcl_contact>* contacts,
+                     uint32_t pair) {
+  const M3<T> RT_R = tmul(tf1.R, tf2.R);
+  const V3<T> RT_T = tmul(tf1.R, tf2.t - tf1.t);
+  std::vector<uint32_t> stack;
+  stack.push_back(0);
+  uint32_t nc = 0;
+  T dlb = Lim<T>::max(), rec = Lim<T>::max();
+  const T nanv = Lim<T>::nan();
+  V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1, nn = np1;
+  int fb1 = -1, fb2 = -1;
+  while (!stack.empty()) {
+    const uint32_t e = stack.back();
+    stack.pop_back();
+    const uint32_t b1 = e & 0xFFFFu, b2 = e >> 16;
+    const DNode<T>& n1 = nodes[m1[0] + b1];
+    const DNode<T>& n2 = nodes[m2[0] + b2];
+    const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
+    if (l1 && l2) {
+      const uint32_t p1i = uint32_t(-(n1.first_child + 1)), p2i = uint32_t(-(n2.first_child + 1));
+      const uint32_t* t1 = tris + 3 * (m1[3] + p1i);
+      const uint32_t* t2 = tris + 3 * (m2[3] + p2i);
+      auto vtx = [&](uint64_t off, uint32_t i) { return mk<T>(verts[3 * (off + i)], verts[3 * (off + i) + 1], verts[3 * (off + i) + 2]); };
+      TriSupport<T> tri;
+      tri.p1 = xform(tf1, vtx(m1[2], t1[0])); tri.p2 = xform(tf1, vtx(m1[2], t1[1])); tri.p3 = xform(tf1, vtx(m1[2], t1[2]));
+      tri.q1 = xform(tf2, vtx(m2[2], t2[0])); tri.q2 = xform(tf2, vtx(m2[2], t2[1])); tri.q3 = xform(tf2, vtx(m2[2], t2[2]));
+      V3<T> p1, p2, n;
+      int gst, git;
+      const T d = tri_tri_distance(tri, q.gjk, q.guess_mode == HFCL_GUESS_CACHED, mk<T>(q.guess[0], q.guess[1], q.guess[2]),
+                                   p1, p2, n, gst, git);
+      const T dtc = d - q.security_margin;
+      if (dtc < dlb) { dlb = dtc; rec = d; np1 = p1; np2 = p2; nn = n; }
+      if (dtc <= q.collision_distance_threshold) {
+        if (nc < num_max_contacts) {
+          if (nc == 0) { fb1 = int(p1i); fb2 = int(p2i); }
+          ++nc;
+          if (contacts) {
+            hfcl_contact c;
+            c.pair = pair; c.b1 = int(p1i); c.b2 = int(p2i); c._pad = 0; c.penetration_depth = d;
+            c.normal[0] = n.x; c.normal[1] = n.y; c.normal[2] = n.z;
+            c.p1[0] = p1.x; c.p1[1] = p1.y; c.p1[2] = p1.z; c.p2[0] = p2.x; c.p2[1] = p2.y; c.p2[2] = p2.z;
+            contacts->push_back(c);
+          }
+        }
+        if (nc >= num_max_contacts) break;
+      }
+      continue;
+    }
+    T sq;
+    if (obb_disjoint(RT_R, RT_T, n2, n1, q.security_margin, break_distance2, sq)) {
+      if (!(dlb <= T(0))) {
+        const T nd = hsqrt(sq);
+        if (nd < dlb) { dlb = nd; rec = nd + q.security_margin; }
+      }
+      continue;
+    }
+    const bool first = l2 || (!l1 && (sqnorm(n1.extent) > sqnorm(n2.extent)));
+    if (first) {
+      const uint32_t c1 = uint32_t(n1.first_child);
+      stack.push_back((c1 + 1) | (b2 << 16));
+      stack.push_back(c1 | (b2 << 16));
+    } else {
+      const uint32_t c1 = uint32_t(n2.first_child);
+      stack.push_back(b1 | ((c1 + 1) << 16));
+      stack.push_back(b1 | (c1 << 16));
+    }
+  }
+  r.distance = rec;
+  r.normal[0] = nn.x; r.normal[1] = nn.y; r.normal[2] = nn.z;
+  r.p1[0] = np1.x; r.p1[1] = np1.y; r.p1[2] = np1.z;
+  r.p2[0] = np2.x; r.p2[1] = np2.y; r.p2[2] = np2.z;
+  r.b1 = fb1; r.b2 = fb2;
+  r.status = nc ? 128u : 0u;
+  r.num_contacts = int(nc);
+}
+
+extern "C" {
+
+int sim_bvh_collide_f64(const hfcl_bvh_node* nodes, size_t n_nodes, const double* verts, size_t n_verts,
+                        const uint32_t* tris, const uint64_t* mesh_table, const uint32_t* m1, const uint32_t* m2,
+                        const double* tf1, const double* tf2, size_t n, const hfcl_collision_request* creq, hfcl_result* out,
+                        hfcl_contact* contacts, size_t max_contacts, size_t* n_contacts) {
+  std::vector<DNode<double>> dn(n_nodes);
+  for (size_t i = 0; i < n_nodes; ++i) {
+    const double* a = nodes[i].obb_axes;
+    dn[i].first_child = nodes[i].first_child;
+    dn[i].axes.r0 = mk<double>(a[0], a[3], a[6]);
+    dn[i].axes.r1 = mk<double>(a[1], a[4], a[7]);
+    dn[i].axes.r2 = mk<double>(a[2], a[5], a[8]);
+    dn[i].To = mk<double>(nodes[i].obb_To[0], nodes[i].obb_To[1], nodes[i].obb_To[2]);
+    dn[i].extent = mk<double>(nodes[i].obb_extent[0], nodes[i].obb_extent[1], nodes[i].obb_extent[2]);
+  }
+  std::vector<double> v(verts, verts + 3 * n_verts);
+  QParams<double> q;
+  fill_q(q, creq->q);
+  q.mode = 1;
+  q.compute_penetration = (creq->enable_contact || creq->security_margin < 0) ? 1 : 0;
+  q.security_margin = creq->security_margin;
+  q.gjk.distance_upper_bound = Lim<double>::max();
+  std::vector<hfcl_contact> cl;
+  for (size_t i = 0; i < n; ++i)
+    bvh_pair<double>(dn, v, tris, mesh_table + 4 * m1[i], mesh_table + 4 * m2[i], pose_from_abi<double>(tf1 + 12 * i),
+                     pose_from_abi<double>(tf2 + 12 * i), q, creq->num_max_contacts,
+                     creq->break_distance * creq->break_distance, out[i], contacts ? &cl : nullptr, uint32_t(i));
+  if (contacts) {
+    size_t k = 0;
+    for (auto& c : cl)
+      if (k < max_contacts) contacts[k++] = c;
+    *n_contacts = cl.size();
   }
   return 0;
 }

@@ -49,3 +49,23 @@ def batch_f32(abi, shapes, verts, s1, s2, pose1, pose2, req):
                         abi.ptr(s1), abi.ptr(s2), abi.ptr(pose1), abi.ptr(pose2), C.c_size_t(n),
                         C.byref(req) if is_coll else None, None if is_coll else C.byref(req), abi.ptr(out))
     return out
+
+
+def bvh_collide_f64(abi, meshlib, m1, m2, tf1, tf2, req, max_contacts=0):
+    m1 = np.ascontiguousarray(m1, dtype=np.uint32)
+    m2 = np.ascontiguousarray(m2, dtype=np.uint32)
+    tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
+    tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
+    n = len(m1)
+    out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    contacts = np.zeros(max(1, max_contacts), dtype=abi.CONTACT_DTYPE)
+    nc = C.c_size_t(0)
+    nodes = np.ascontiguousarray(meshlib.nodes)
+    lib().sim_bvh_collide_f64(abi.ptr(nodes), C.c_size_t(len(nodes)), abi.ptr(meshlib.verts),
+                              C.c_size_t(len(meshlib.verts)), abi.ptr(meshlib.tris), abi.ptr(meshlib.table),
+                              abi.ptr(m1), abi.ptr(m2), abi.ptr(tf1), abi.ptr(tf2), C.c_size_t(n), C.byref(req),
+                              abi.ptr(out), abi.ptr(contacts) if max_contacts else None, C.c_size_t(max_contacts),
+                              C.byref(nc))
+    if max_contacts:
+        return out, contacts[:min(nc.value, max_contacts)]
+    return out

@@ -124,3 +124,32 @@ def shape_support(shape, verts, direction):
     hint = C.c_int(0)
     lib().orc_shape_support(abi.ptr(s), abi.ptr(v), abi.ptr(d), abi.ptr(out), C.byref(hint))
     return out, hint.value
+
+
+def bvh_collide_batch(meshlib, m1, m2, tf1, tf2, req=None, max_contacts=0, n_threads=1, want_stats=False):
+    """BVHModel<OBBRSS> x BVHModel<OBBRSS> collide() through the oracle.  meshlib: bvh_builder.MeshLibrary."""
+    abi = _pkg().abi
+    req = req or abi.default_collision_request()
+    m1 = np.ascontiguousarray(m1, dtype=np.uint32)
+    m2 = np.ascontiguousarray(m2, dtype=np.uint32)
+    tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
+    tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
+    n = len(m1)
+    out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    stats = np.zeros((n, 2), dtype=np.uint32)
+    contacts = np.zeros(max(1, max_contacts), dtype=abi.CONTACT_DTYPE)
+    nc = C.c_size_t(0)
+    nodes = np.ascontiguousarray(meshlib.nodes)
+    rc = lib().orc_bvh_collide_batch(abi.ptr(nodes), abi.ptr(meshlib.verts), abi.ptr(meshlib.tris),
+                                     abi.ptr(meshlib.table), C.c_size_t(len(meshlib.table)), abi.ptr(m1), abi.ptr(m2),
+                                     abi.ptr(tf1), abi.ptr(tf2), C.c_size_t(n), C.byref(req), abi.ptr(out),
+                                     abi.ptr(stats), abi.ptr(contacts) if max_contacts else None,
+                                     C.c_size_t(max_contacts), C.byref(nc), C.c_int(n_threads))
+    if rc:
+        raise ValueError("oracle bvh collide: error %d" % rc)
+    res = [out]
+    if max_contacts:
+        res.append(contacts[:nc.value])
+    if want_stats:
+        res.append(stats)
+    return res[0] if len(res) == 1 else tuple(res)

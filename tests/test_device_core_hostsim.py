@@ -111,3 +111,88 @@ def test_tetra_region_table_matches_oracle_tree(pkg, oracle):
     assert (ref["distance"] < 0).mean() > 0.8
     assert np.array_equal(got["status"], ref["status"])
     assert np.abs(got["distance"] - ref["distance"]).max() < 1e-12
+
+
+# ------------------------------------------------------------------------------------- BVH (cfg4)
+@pytest.fixture(scope="module")
+def small_meshes(pkg):
+    bb = pkg.bvh_builder
+    return bb.MeshLibrary([bb.Mesh(*bb.bumpy_sphere(12, 12)), bb.Mesh(*bb.bumpy_sphere(10, 14, phase=1.0)),
+                           bb.Mesh(*bb.bumpy_sphere(16, 16, phase=2.0))])
+
+
+def _mesh_queries(pkg, n, seed, nm=3, hw=1.2):
+    g = pkg.geometry
+    rng = np.random.default_rng(seed)
+
+    def rq():
+        q = rng.normal(size=(n, 4))
+        return q / np.linalg.norm(q, axis=1, keepdims=True)
+
+    return (rng.integers(0, nm, n), rng.integers(0, nm, n), g.make_pose(quat=rq(), T=rng.uniform(-hw, hw, (n, 3))),
+            g.make_pose(quat=rq(), T=rng.uniform(-hw, hw, (n, 3))))
+
+
+def test_bvh_builder_tree_is_well_formed(pkg, small_meshes):
+    for m in small_meshes.meshes:
+        nodes = m.nodes
+        assert len(nodes) == 2 * m.num_tris - 1  # BVH_model.cpp:821-825
+        leaves = nodes["first_child"][nodes["first_child"] < 0]
+        assert sorted((-(leaves + 1)).tolist()) == list(range(m.num_tris))
+        inner = nodes["first_child"][nodes["first_child"] > 0]
+        assert sorted(np.concatenate([inner, inner + 1]).tolist()) == list(range(1, len(nodes)))
+        # every OBB contains the vertices of its triangles
+        for i in (0, 1, len(nodes) // 2):
+            nd = nodes[i]
+            axes = nd["obb_axes"].reshape(3, 3).T
+            prims = m.primitive_indices[nd["first_primitive"]:nd["first_primitive"] + nd["num_primitives"]]
+            P = m.vertices[m.triangles[prims].reshape(-1)]
+            loc = (P - nd["obb_To"]) @ axes
+            assert np.all(np.abs(loc) <= nd["obb_extent"] + 1e-9)
+
+
+def test_oracle_bvh_contact_set_equals_brute_force(pkg, oracle, small_meshes):
+    """test/collision.cpp:625-654 style: with num_max_contacts = inf the sorted contact set (b1,b2) is
+    traversal independent -- compare the BVH traversal against all triangle pairs."""
+    abi, g = pkg.abi, pkg.geometry
+    m1, m2 = small_meshes.meshes[0], small_meshes.meshes[1]
+    i1, i2, tf1, tf2 = _mesh_queries(pkg, 12, 1)
+    i1[:], i2[:] = 0, 1
+    req = abi.default_collision_request()
+    req.num_max_contacts = 10 ** 6
+    out, contacts = oracle.bvh_collide_batch(small_meshes, i1, i2, tf1, tf2, req, max_contacts=10 ** 6)
+    L = g.ShapeLibrary()
+    for mm in (m1, m2):
+        for t3 in mm.triangles:
+            L.add_triangle(*mm.vertices[t3])
+    a = np.repeat(np.arange(m1.num_tris), m2.num_tris)
+    b = m1.num_tris + np.tile(np.arange(m2.num_tris), m1.num_tris)
+    for k in range(len(i1)):
+        r = oracle.collide_batch(L.shapes_array(), L.vertices_array(), a, b, np.tile(tf1[k], (len(a), 1)),
+                                 np.tile(tf2[k], (len(a), 1)), req)
+        hit = r["num_contacts"] > 0
+        brute = set(zip(a[hit].tolist(), (b[hit] - m1.num_tris).tolist()))
+        ck = contacts[contacts["pair"] == k]
+        assert brute == set(zip(ck["b1"].tolist(), ck["b2"].tolist()))
+        assert out["num_contacts"][k] == len(brute)
+
+
+@pytest.mark.parametrize("nmax,margin", [(1, 0.0), (10 ** 6, 0.0), (3, 0.02), (1, -0.01)])
+def test_bvh_device_code_matches_oracle(pkg, oracle, hostsim, small_meshes, nmax, margin):
+    """OBB SAT + triangle-triangle leaf + DFS order of the device headers (host build) vs the oracle:
+    identical contact counts, first-contact primitive ids, contact lists (order included)."""
+    abi = pkg.abi
+    i1, i2, tf1, tf2 = _mesh_queries(pkg, 1500, 2)
+    req = abi.default_collision_request()
+    req.num_max_contacts, req.security_margin = nmax, margin
+    ref, cref = oracle.bvh_collide_batch(small_meshes, i1, i2, tf1, tf2, req, max_contacts=2 * 10 ** 6, n_threads=1)
+    got, cgot = hostsim.bvh_collide_f64(abi, small_meshes, i1, i2, tf1, tf2, req, max_contacts=2 * 10 ** 6)
+    assert (ref["num_contacts"] > 0).mean() > 0.3
+    assert np.array_equal(ref["num_contacts"], got["num_contacts"])
+    assert np.array_equal(ref["b1"], got["b1"]) and np.array_equal(ref["b2"], got["b2"])
+    fin = np.abs(ref["distance"]) < 1e300
+    assert np.abs(ref["distance"][fin] - got["distance"][fin]).max() < 1e-12
+    assert np.array_equal(np.isnan(ref["p1"]), np.isnan(got["p1"]))
+    assert len(cref) == len(cgot)
+    assert np.array_equal(cref["pair"], cgot["pair"]) and np.array_equal(cref["b1"], cgot["b1"])
+    assert np.allclose(cref["penetration_depth"], cgot["penetration_depth"], atol=1e-12)

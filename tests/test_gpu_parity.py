@@ -204,3 +204,83 @@ def test_full_size_properties(pkg, oracle, torch_cuda, case):
     frac = abi.status_contact(got["status"]).mean()
     assert 0.2 < frac < 0.45, frac
     lib.close()
+
+
+# ------------------------------------------------------------------------------------- BVH (cfg4)
+def _run_bvh(pkg, oracle, b, req, max_contacts=0):
+    bb = pkg.bvh_builder
+    ML = bb.MeshLibrary(b.meshes)
+    lib = pkg.workloads.make_library(pkg, b)
+    try:
+        if max_contacts:
+            got, cgot, produced = lib.collide_contacts(b.s1, b.s2, b.tf1, b.tf2, req, max_contacts)
+            ref, cref = oracle.bvh_collide_batch(ML, b.s1, b.s2, b.tf1, b.tf2, req, max_contacts=max_contacts, n_threads=8)
+            return got, ref, cgot, cref, produced, lib.last_kernel_breakdown()
+        got = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
+        ref = oracle.bvh_collide_batch(ML, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=8)
+        return got, ref, lib.last_kernel_breakdown()
+    finally:
+        lib.close()
+
+
+def _check_bvh_records(abi, got, ref, name):
+    assert not np.any((got["status"] >> 30) & 1), name + ": traversal stack overflow"
+    near = np.abs(ref["distance"]) < 1e-9
+    same_nc = got["num_contacts"] == ref["num_contacts"]
+    assert np.all(same_nc | near), "%s: contact counts differ on %d queries" % (name, (~(same_nc | near)).sum())
+    ok = same_nc & ~near
+    assert np.array_equal(got["b1"][ok], ref["b1"][ok]) and np.array_equal(got["b2"][ok], ref["b2"][ok]), \
+        name + ": first-contact primitive ids differ"
+    fin = (np.abs(ref["distance"]) < 1e300) & ok
+    assert np.abs(got["distance"][fin] - ref["distance"][fin]).max() < 1e-6
+    assert np.array_equal(np.isnan(got["p1"][ok]), np.isnan(ref["p1"][ok]))
+    sep_g, sep_r = got["p2"] - got["p1"], ref["p2"] - ref["p1"]
+    m = fin & ~np.isnan(ref["p1"]).any(axis=1)
+    assert np.abs(sep_g[m] - sep_r[m]).max() < 1e-5
+
+
+@pytest.mark.parametrize("seg,n", [(12, 20000), (50, 4000)])
+def test_bvh_collide_first_contact(pkg, oracle, seg, n):
+    """Default request (num_max_contacts = 1): collision flag and the first contact's (b1, b2) in the
+    reference's DFS order are exact; depth / witness data to 1e-6."""
+    abi, wl = pkg.abi, pkg.workloads
+    b = wl.cfg4_mesh_mesh(n=n, seg=seg, ring=seg, n_variants=4)
+    req = wl.make_request(b, abi)
+    got, ref, kt = _run_bvh(pkg, oracle, b, req)
+    _check_bvh_records(abi, got, ref, "bvh-first-%d" % seg)
+    frac = (ref["num_contacts"] > 0).mean()
+    assert 0.2 < frac < 0.8, frac
+
+
+def test_bvh_collide_all_contacts(pkg, oracle):
+    """num_max_contacts = inf: the sorted contact set per query equals the oracle's
+    (test/collision.cpp:419-422,523-563 semantics)."""
+    abi, wl = pkg.abi, pkg.workloads
+    b = wl.cfg4_mesh_mesh(n=3000, seg=14, ring=14, n_variants=3)
+    req = wl.make_request(b, abi, num_max_contacts=10 ** 6)
+    got, ref, cgot, cref, produced, kt = _run_bvh(pkg, oracle, b, req, max_contacts=4 * 10 ** 6)
+    assert produced == len(cref) == len(cgot)
+    assert np.array_equal(got["num_contacts"], ref["num_contacts"])
+    kg = np.lexsort((cgot["b2"], cgot["b1"], cgot["pair"]))
+    kr = np.lexsort((cref["b2"], cref["b1"], cref["pair"]))
+    for f in ("pair", "b1", "b2"):
+        assert np.array_equal(cgot[f][kg], cref[f][kr])
+    assert np.abs(cgot["penetration_depth"][kg] - cref["penetration_depth"][kr]).max() < 1e-6
+
+
+def test_bvh_security_margin_and_mixed_batch(pkg, oracle):
+    """margin > 0 widens contacts; a batch mixing mesh pairs and primitive pairs goes to the right kernels."""
+    abi, wl, g = pkg.abi, pkg.workloads, pkg.geometry
+    b = wl.cfg4_mesh_mesh(n=3000, seg=12, ring=12, n_variants=2)
+    req = wl.make_request(b, abi, security_margin=0.05)
+    got, ref, kt = _run_bvh(pkg, oracle, b, req)
+    _check_bvh_records(abi, got, ref, "bvh-margin")
+    req0 = wl.make_request(b, abi)
+    got0, ref0, _ = _run_bvh(pkg, oracle, b, req0)
+    assert (got["num_contacts"] > 0).sum() >= (got0["num_contacts"] > 0).sum()
+    # distance() on mesh pairs is reported as unsupported, not silently mis-answered
+    lib = wl.make_library(pkg, b)
+    with pytest.raises(pkg.EngineError) as e:
+        lib.distance(b.s1[:10], b.s2[:10], b.tf1[:10], b.tf2[:10])
+    assert e.value.code == abi.ERR_UNSUPPORTED_PAIR
+    lib.close()
