@@ -47,6 +47,13 @@ def dll():
     if _DLL is None:
         if not os.path.exists(LIB_PATH):
             raise EngineError(abi.ERR_NO_DEVICE, "native library %s is missing: run __graft_entry__.build()" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.  If torch is going to
+        # be used in this process (device tensors, streams, torch.distributed) it must be loaded first
+        # so that this library binds to the same runtime; loading ours first makes torch.cuda unusable.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         d = C.CDLL(LIB_PATH)
         d.hfcl_last_error.restype = C.c_char_p
         d.hfcl_lib_create.restype = C.c_void_p
