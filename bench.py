@@ -32,7 +32,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 BYTES_PER_QUERY = {
     "cfg3": 8 + 2 * 28 + 44,   # 2 shape ids + 2 (quat+T) fp32 poses + 44-B fp32 record = 108 B
     "cfg2": 8 + 2 * 96 + 96,   # 2 shape ids + 2 Transform3f images (fp64) + 96-B fp64 record = 296 B
+    # cfg4: ids + poses + record, plus the BV nodes / triangles the *reference DFS* visits
+    # (SURVEY.md 8d): 2 x 128 B (fp64 device node) per BV test, 2 x (3 x 24 B vertices + 12 B indices)
+    # per leaf test; N_bv, N_leaf are measured with the oracle on a sample and reported.
+    "cfg4": 8 + 2 * 96 + 96,
 }
+CFG4_BYTES_PER_BV_TEST = 2 * 128
+CFG4_BYTES_PER_LEAF_TEST = 2 * (3 * 24 + 12)
 
 
 def parse():
@@ -40,8 +46,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
-    ap.add_argument("--pairs", type=int, default=1_000_000, help="pairs per GPU per step")
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4"])
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default 1M; cfg4: 100k)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of result records (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
@@ -69,15 +75,18 @@ def main():
 
     pkg = load_pkg()
     abi, wl = pkg.abi, pkg.workloads
-    n = args.pairs
+    n = args.pairs or (100_000 if args.workload == "cfg4" else 1_000_000)
     if args.workload == "cfg3":
         batch = wl.cfg3_convex_convex(n=n, seed=1 + rank)
         dtype = "f32"
-    else:
+    elif args.workload == "cfg2":
         batch = wl.cfg2_box_capsule(n=n, seed=1 + rank)
         dtype = "f64"
+    else:
+        batch = wl.cfg4_mesh_mesh(n=n, seed=1 + rank)
+        dtype = "f64"
     req = wl.make_request(batch, abi)
-    lib = pkg.Library(batch.lib, device=local_rank)
+    lib = wl.make_library(pkg, batch, device=local_rank)
 
     d_s1 = torch.from_numpy(batch.s1.astype(np.int32)).to(dev)
     d_s2 = torch.from_numpy(batch.s2.astype(np.int32)).to(dev)
@@ -166,9 +175,22 @@ def main():
         avg = {k: float(np.mean(v)) for k, v in kernel_ms.items() if np.mean(v) > 0}
         dominant = max(avg, key=avg.get) if avg else ""
         bpq = BYTES_PER_QUERY[args.workload]
+        extra_cfg = {}
+        if args.workload == "cfg4":
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_binding as ob0  # measures N_bv / N_leaf of the reference DFS on a sample
+            ns0 = min(2000, n)
+            ML = pkg.bvh_builder.MeshLibrary(batch.meshes)
+            _, st0 = ob0.bvh_collide_batch(ML, batch.s1[:ns0], batch.s2[:ns0], batch.tf1[:ns0], batch.tf2[:ns0], req,
+                                           n_threads=os.cpu_count() or 1, want_stats=True)
+            nbv, nleaf = float(st0[:, 0].mean()), float(st0[:, 1].mean())
+            bpq = bpq + CFG4_BYTES_PER_BV_TEST * nbv + CFG4_BYTES_PER_LEAF_TEST * nleaf
+            extra_cfg = {"mean_bv_tests": nbv, "mean_leaf_tests": nleaf, "stats_sample": ns0}
         # units the dominant kernel processes in one launch
-        if dominant == "k_epa":
+        if dominant.startswith("k_epa<fast"):
             units = buckets["epa_queue"]
+        elif dominant.startswith("k_epa<full"):
+            units = buckets["epa_overflow"]
         else:
             units = n
         dom_ms = avg.get(dominant, float("nan"))
@@ -187,18 +209,27 @@ def main():
             import oracle_binding as ob  # checker/baseline only -- never on the product path
             ns = min(args.cpu_sample, n)
             sb = batch.slice(0, ns)
-            fn = ob.distance_batch if sb.kind == "distance" else ob.collide_batch
             tf1, tf2 = sb.tf1, sb.tf2
-            fn(sb.shapes, sb.verts, sb.s1[:1000], sb.s2[:1000], tf1[:1000], tf2[:1000], req)  # warm-up
+            if args.workload == "cfg4":
+                MLc = pkg.bvh_builder.MeshLibrary(batch.meshes)
+
+                def run_cpu(lo, hi, threads):
+                    ob.bvh_collide_batch(MLc, sb.s1[lo:hi], sb.s2[lo:hi], tf1[lo:hi], tf2[lo:hi], req, n_threads=threads)
+            else:
+                fn = ob.distance_batch if sb.kind == "distance" else ob.collide_batch
+
+                def run_cpu(lo, hi, threads):
+                    fn(sb.shapes, sb.verts, sb.s1[lo:hi], sb.s2[lo:hi], tf1[lo:hi], tf2[lo:hi], req, n_threads=threads)
+            run_cpu(0, min(1000, ns), 1)  # warm-up
             reps, t_cpu = 0, 0.0
             while t_cpu < 10.0 and reps < 5:
                 t1 = time.perf_counter()
-                fn(sb.shapes, sb.verts, sb.s1, sb.s2, tf1, tf2, req, n_threads=1)
+                run_cpu(0, ns, 1)
                 t_cpu += time.perf_counter() - t1
                 reps += 1
             cores_all = os.cpu_count() or 1
             t1 = time.perf_counter()
-            fn(sb.shapes, sb.verts, sb.s1, sb.s2, tf1, tf2, req, n_threads=cores_all)
+            run_cpu(0, ns, cores_all)
             t_all = time.perf_counter() - t1
             cpu = {"value": reps * ns / t_cpu, "unit": "queries/s", "cores": 1, "kind": "port",
                    "sample": "%d pairs of the same workload x %d repeats, fp64 CPU oracle (oracle/), 1 thread" % (ns, reps),
@@ -207,7 +238,8 @@ def main():
             "metric": "narrow-phase queries/s (collision+distance)", "value": qps, "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": batch.name, "baseline_config": "configs[2]" if args.workload == "cfg3" else "configs[1]",
+            "config": {"workload": batch.name, **extra_cfg,
+                       "baseline_config": {"cfg3": "configs[2]", "cfg2": "configs[1]", "cfg4": "configs[3]"}[args.workload],
                        "pairs_per_gpu_per_step": n, "contact_fraction": contact_frac, "buckets": buckets,
                        "request": batch.kind, "all_gather_results": bool(gather),
                        "lane_group_width": int(os.environ.get("HFCL_CVX_W", "8"))},

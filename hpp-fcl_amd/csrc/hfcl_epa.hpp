@@ -41,21 +41,25 @@ HFCL_HD PW0<T> psel(bool c, const PW0<T>& a, const PW0<T>& b) {
   return r;
 }
 
-// Scratch layout (SoA).  sizeof = 68*2*3*T + 132*4*T + 132*10 + 132*2 + 132 + pad
-template <typename T>
+// Scratch layout (SoA), sized for CAP iterations: CAP+4 vertices, 2*CAP+4 faces (gjk.cpp:1020-1021).
+// CAP = 64 is the reference capacity; the fast kernel uses a smaller CAP (several polytopes per
+// wave fit in LDS) and hands polytopes that outgrow it to the full-capacity kernel.
+template <typename T, int CAP>
 struct EpaScratch {
-  T vw[3][EPA_MAX_VERTS];   // vertex w
-  T v0[3][EPA_MAX_VERTS];   // vertex w0
-  T fn[3][EPA_MAX_FACES];   // face normal
-  T fd[EPA_MAX_FACES];      // face distance
-  uint16_t fstamp[EPA_MAX_FACES];
-  uint8_t fvid[3][EPA_MAX_FACES];
-  uint8_t fadj[3][EPA_MAX_FACES];
-  uint8_t fadje[EPA_MAX_FACES];   // 3 x 2 bits
-  uint8_t fflag[EPA_MAX_FACES];   // bit0 in hull, bit1 ignore
-  uint8_t fpass[EPA_MAX_FACES];
-  uint8_t stock[EPA_MAX_FACES];   // free-face stack
-  uint16_t stack[EPA_MAX_FACES];  // expand() frames: face | edge<<8 | stage<<10
+  static constexpr int NV = CAP + 4;
+  static constexpr int NF = 2 * CAP + 4;
+  T vw[3][NV];   // vertex w
+  T v0[3][NV];   // vertex w0
+  T fn[3][NF];   // face normal
+  T fd[NF];      // face distance
+  uint16_t fstamp[NF];
+  uint16_t stack[NF];  // expand() frames: face | edge<<8 | stage<<10
+  uint8_t fvid[3][NF];
+  uint8_t fadj[3][NF];
+  uint8_t fadje[NF];   // 3 x 2 bits
+  uint8_t fflag[NF];   // bit0 in hull, bit1 ignore
+  uint8_t fpass[NF];
+  uint8_t stock[NF];   // free-face stack
 };
 
 // Lane-group operations.  W = 1 on the host validation build.
@@ -77,11 +81,13 @@ struct EpaResult {
   V3<T> rw0_, rw1_, rw2_, r00, r01, r02;
 };
 
-template <typename T, class Grp>
+template <typename T, class Grp, int CAP = EPA_MAX_ITER>
 struct Epa {
-  EpaScratch<T>* m;
+  EpaScratch<T, CAP>* m;
   T tolerance;
-  int max_iterations;
+  int max_iterations;  // the request's (reference) limit
+  int cap_iterations;  // min(max_iterations, CAP): what this scratch block can hold
+  bool overflow;       // the polytope outgrew CAP although the reference's capacity would not be exhausted
   int status;
   int num_vertices;
   int hull_count;
@@ -108,15 +114,17 @@ struct Epa {
     m->stock[stock_top++] = uint8_t(f);
   }
 
-  HFCL_HD void reset(EpaScratch<T>* mem, int max_it, T tol) {  // :1014-1037
+  HFCL_HD void reset(EpaScratch<T, CAP>* mem, int max_it, T tol) {  // :1014-1037
     m = mem;
     tolerance = tol;
     max_iterations = max_it;
+    cap_iterations = max_it < CAP ? max_it : CAP;
+    overflow = false;
     status = EPA_DID_NOT_RUN;
     num_vertices = 0;
     hull_count = 0;
     stamp = 0;
-    const int nf = 2 * max_it + 4;
+    const int nf = 2 * cap_iterations + 4;
     // face 0 on top of the stock, as in the reference (stock filled in reverse order)
     for (int i = Grp::lane(); i < nf; i += Grp::W) {
       m->stock[i] = uint8_t(nf - 1 - i);
@@ -129,6 +137,7 @@ struct Epa {
   // newFace :1068-1138.  Returns face index or EPA_NULL.
   HFCL_HD int new_face(int ia, int ib, int ic, bool force) {
     if (stock_top == 0) {
+      if (cap_iterations < max_iterations) overflow = true;  // the reference still has faces in stock
       status = EPA_OUT_OF_FACES;
       return EPA_NULL;
     }
@@ -174,7 +183,7 @@ struct Epa {
   // (= largest append stamp) on ties; if every face is ignored: the list head.
   HFCL_HD int find_closest_face() {
     Grp::sync();
-    const int nf = 2 * max_iterations + 4;
+    const int nf = 2 * cap_iterations + 4;
     T best = Lim<T>::max();
     int best_stamp = -1, best_f = EPA_NULL;
     int head_stamp = -1, head_f = EPA_NULL;
@@ -369,6 +378,10 @@ const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
         int iterations = 0;
         int pass = 0;
         for (; iterations < max_iterations; ++iterations) {
+          if (iterations >= cap_iterations && cap_iterations < max_iterations) {
+            overflow = true;  // capacity of this scratch block reached before the reference's limit
+            break;
+          }
           if (num_vertices >= max_iterations + 4) {
             status = EPA_OUT_OF_VERTICES;
             break;
@@ -397,6 +410,7 @@ const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
           bool valid = true;
           for (int j = 0; j < 3 && valid; ++j)
             valid = valid && expand(pass, m->fadj[j][closest], adj_edge(closest, j), hz_current, hz_first, hz_count);
+          if (overflow) break;
           if (!valid || hz_count < 3) break;
           bind(hz_first, 2, hz_current, 1);
           hull_remove(closest);

@@ -80,8 +80,9 @@ struct Work {
   const uint32_t* shape2;
   uint32_t n;
   uint32_t* lists;   // B_COUNT lists of capacity n each
-  uint32_t* counts;  // B_COUNT counters + [B_COUNT] = epa queue length
+  uint32_t* counts;  // B_COUNT counters + [B_COUNT] = epa queue length + [B_COUNT+1] = overflow queue length
   void* epa_queue;
+  void* epa_queue2;  // polytopes that outgrew the fast EPA kernel's scratch block
 };
 
 __device__ __forceinline__ Pose<double> load_pose(const double* base, uint32_t i) { return pose_from_abi<double>(base + 12 * size_t(i)); }
@@ -376,30 +377,37 @@ __global__ void __launch_bounds__(256) k_gjk_cvx(Work wk, LibView<T> lib, IO<T> 
 }
 
 // ---------------------------------------------------------------------------------------
-// k_epa: one queued pair per wavefront, polytope in LDS.
+// k_epa: EPA on the pairs GJK left in `Collision`.  One polytope per WE-lane group, 64/WE polytopes
+// per wavefront, scratch blocks in LDS.  Two tiers:
+//   tier 1  WE = 8, CAP = EPA_FAST_CAP iterations: 8 polytopes per wave share one instruction stream;
+//           a polytope that outgrows the small block is re-queued (seed unchanged)
+//   tier 2  WE = 64, CAP = 64 (the reference capacity): one polytope per wave for the re-queued rest
 // ---------------------------------------------------------------------------------------
-struct WaveGroup {
-  static constexpr int W = 64;
-  static __device__ __forceinline__ int lane() { return threadIdx.x & 63; }
-  template <class X> static __device__ __forceinline__ X shfl_xor(X v, int m) { return __shfl_xor(v, m, 64); }
+template <int W_>
+struct LaneGroup {
+  static constexpr int W = W_;
+  static __device__ __forceinline__ int lane() { return threadIdx.x & (W_ - 1); }
+  template <class X> static __device__ __forceinline__ X shfl_xor(X v, int m) { return __shfl_xor(v, m, W_); }
   static __device__ __forceinline__ void sync() { __builtin_amdgcn_wave_barrier(); }
 };
 
-template <typename T>
-struct EpaSupport {  // any pair kind, evaluated by a whole wave
+constexpr int EPA_FAST_CAP = 28;
+
+template <typename T, int WE>
+struct EpaSupport {  // any pair kind, evaluated by one lane group
   DShape<T> a, b;
-  HullRegs<T, 64> h0, h1;
+  HullRegs<T, WE> h0, h1;
   MDiff<T> md;
-  int lane;
+  int lig;
   __device__ __forceinline__ void operator()(const V3<T>& dir, V3<T>& w, V3<T>& w0) const {
     if (a.kind == K_CONVEX)
-      w0 = h0.support(dir, lane);
+      w0 = h0.support(dir, lig);
     else
       w0 = prim_support(a, dir);
     const V3<T> d1 = md.identity ? -dir : -tmul(md.oR1, dir);
     V3<T> s1;
     if (b.kind == K_CONVEX)
-      s1 = h1.support(d1, lane);
+      s1 = h1.support(d1, lig);
     else
       s1 = prim_support(b, d1);
     s1 = md.identity ? s1 : (mul(md.oR1, s1) + md.ot1);
@@ -407,36 +415,41 @@ struct EpaSupport {  // any pair kind, evaluated by a whole wave
   }
 };
 
-template <typename T>
-__global__ void __launch_bounds__(256) k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
-  __shared__ EpaScratch<T> scratch[4];
-  const uint32_t cnt = wk.counts[B_COUNT];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t waves = gridDim.x * 4;
-  const EpaItem<T>* queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
-  for (uint32_t it = blockIdx.x * 4 + wave; it < cnt; it += waves) {
+// TIER: 1 reads queue 1 and may push to queue 2; 2 reads queue 2 (never overflows: CAP = 64)
+template <typename T, int WE, int CAP, int TIER>
+__global__ void __launch_bounds__(64) k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  constexpr int G = 64 / WE;
+  __shared__ EpaScratch<T, CAP> scratch[G];
+  const uint32_t cnt = wk.counts[TIER == 1 ? B_COUNT : B_COUNT + 1];
+  const int lane = threadIdx.x & 63, grp = lane / WE, lig = lane & (WE - 1);
+  const uint32_t groups = gridDim.x * G;
+  const EpaItem<T>* queue = reinterpret_cast<const EpaItem<T>*>(TIER == 1 ? wk.epa_queue : wk.epa_queue2);
+  for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += groups) {
     const EpaItem<T> item = queue[it];
     const uint32_t pair = item.pair;
-    EpaSupport<T> sup;
+    EpaSupport<T, WE> sup;
     sup.a = lib.shapes[wk.shape1[pair]];
     sup.b = lib.shapes[wk.shape2[pair]];
-    sup.lane = lane;
-    if (sup.a.kind == K_CONVEX) sup.h0.load(lib.verts + 3 * size_t(sup.a.vertex_offset), sup.a.num_points, lane);
-    if (sup.b.kind == K_CONVEX) sup.h1.load(lib.verts + 3 * size_t(sup.b.vertex_offset), sup.b.num_points, lane);
+    sup.lig = lig;
+    if (sup.a.kind == K_CONVEX) sup.h0.load(lib.verts + 3 * size_t(sup.a.vertex_offset), sup.a.num_points, lig);
+    if (sup.b.kind == K_CONVEX) sup.h1.load(lib.verts + 3 * size_t(sup.b.vertex_offset), sup.b.num_points, lig);
     const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
     sup.md = make_mdiff(tf1, tf2);
     const T r0 = swept_radius(sup.a), r1 = swept_radius(sup.b);
-
     PairOut<T> o;
-    epa_run<T, WaveGroup>(&scratch[wave], item, q, tf1, r0, r1, sup, o);
-    if (lane == 0) {
-      write_out<T>(io, q, pair, o);
-      write_guess<T>(io, pair, o.cached_guess, 0, 0);
+    const bool done = epa_run<T, LaneGroup<WE>, CAP>(&scratch[grp], item, q, tf1, r0, r1, sup, o);
+    if (lig == 0) {
+      if (done) {
+        write_out<T>(io, q, pair, o);
+        write_guess<T>(io, pair, o.cached_guess, 0, 0);
+      } else if (TIER == 1) {
+        const uint32_t slot = atomicAdd(&wk.counts[B_COUNT + 1], 1u);
+        reinterpret_cast<EpaItem<T>*>(wk.epa_queue2)[slot] = item;
+      }
     }
-    WaveGroup::sync();
+    LaneGroup<WE>::sync();
   }
 }
-
 
 // ---------------------------------------------------------------------------------------
 // k_bvh_collide: BVHModel<OBBRSS> x BVHModel<OBBRSS> collide().
@@ -657,6 +670,7 @@ struct hfcl_lib {
   uint32_t* d_lists = nullptr;
   uint32_t* d_counts = nullptr;
   void* d_epa_queue = nullptr;
+  void* d_epa_queue2 = nullptr;
   // host-call staging buffers
   size_t st_capacity = 0;
   uint32_t *d_s1 = nullptr, *d_s2 = nullptr;
@@ -668,7 +682,7 @@ struct hfcl_lib {
   int cvx_w = 8;
   int n_cus = 256;
   std::string dominant;
-  uint32_t h_counts[B_COUNT + 1] = {0};
+  uint32_t h_counts[B_COUNT + 2] = {0};
   // BVH models (host staging + device images in both precisions; uploaded lazily)
   std::vector<hfcl_bvh_node> h_bvh_nodes;
   std::vector<double> h_bvh_verts;
@@ -812,7 +826,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   ok = ok && hipMalloc(&lib->d_kinds, n_shapes) == hipSuccess;
   ok = ok && hipMalloc(&lib->d_verts64, (3 * n_vertices + 3) * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc(&lib->d_verts32, (3 * n_vertices + 3) * sizeof(float)) == hipSuccess;
-  ok = ok && hipMalloc(&lib->d_counts, (B_COUNT + 1) * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_counts, (B_COUNT + 2) * sizeof(uint32_t)) == hipSuccess;
   if (ok) {
     ok = ok && hipMemcpy(lib->d_shapes64, s64.data(), n_shapes * sizeof(DShape<double>), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(lib->d_shapes32, s32.data(), n_shapes * sizeof(DShape<float>), hipMemcpyHostToDevice) == hipSuccess;
@@ -847,6 +861,7 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_counts);
   hipFree(lib->d_lists);
   hipFree(lib->d_epa_queue);
+  hipFree(lib->d_epa_queue2);
   hipFree(lib->d_s1);
   hipFree(lib->d_s2);
   hipFree(lib->d_tf1);
@@ -917,11 +932,14 @@ static int ensure_workspace(hfcl_lib* lib, size_t n) {
   size_t cap = n + n / 8 + 1024;
   hipFree(lib->d_lists);
   hipFree(lib->d_epa_queue);
+  hipFree(lib->d_epa_queue2);
   lib->d_lists = nullptr;
   lib->d_epa_queue = nullptr;
+  lib->d_epa_queue2 = nullptr;
   lib->ws_capacity = 0;
   HIP_TRY(hipMalloc(&lib->d_lists, size_t(B_COUNT) * cap * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&lib->d_epa_queue, cap * sizeof(EpaItem<double>)));
+  HIP_TRY(hipMalloc(&lib->d_epa_queue2, cap * sizeof(EpaItem<double>)));
   lib->ws_capacity = cap;
   return HFCL_OK;
 }
@@ -1059,6 +1077,7 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   wk.lists = lib->d_lists;
   wk.counts = lib->d_counts;
   wk.epa_queue = lib->d_epa_queue;
+  wk.epa_queue2 = lib->d_epa_queue2;
   LibView<T> lv;
   lv.shapes = std::is_same<T, double>::value ? (const DShape<T>*)lib->d_shapes64 : (const DShape<T>*)lib->d_shapes32;
   lv.verts = std::is_same<T, double>::value ? (const T*)lib->d_verts64 : (const T*)lib->d_verts32;
@@ -1067,14 +1086,14 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
 
   for (auto& t : lib->timers) t.used = false;
   size_t ti = 0;
-  const int max_blocks = lib->n_cus * 8;
+  const int max_blocks = lib->n_cus * 16;
   auto blocks_for = [&](size_t items, size_t per_block) {
     size_t b = (items + per_block - 1) / per_block;
     if (b < 1) b = 1;
     if (b > (size_t)max_blocks) b = max_blocks;
     return int(b);
   };
-  HIP_TRY(hipMemsetAsync(lib->d_counts, 0, (B_COUNT + 1) * sizeof(uint32_t), st));
+  HIP_TRY(hipMemsetAsync(lib->d_counts, 0, (B_COUNT + 2) * sizeof(uint32_t), st));
   KernelTime* t = timer_slot(lib, ti++, "k_classify");
   hipEventRecord(t->e0, st);
   hipLaunchKernelGGL(k_classify, dim3(blocks_for(n, 256 * 4)), dim3(256), 0, st, wk, lib->d_kinds, uint32_t(lib->n_shapes));
@@ -1120,12 +1139,16 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   hipEventRecord(t->e1, st);
 
   if (q.compute_penetration) {
-    t = timer_slot(lib, ti++, "k_epa");
+    t = timer_slot(lib, ti++, "k_epa<fast>");
     hipEventRecord(t->e0, st);
-    hipLaunchKernelGGL((k_epa<T>), dim3(blocks_for(n, 4)), dim3(256), 0, st, wk, lv, io, q);
+    hipLaunchKernelGGL((k_epa<T, 8, EPA_FAST_CAP, 1>), dim3(blocks_for(n, 8)), dim3(64), 0, st, wk, lv, io, q);
+    hipEventRecord(t->e1, st);
+    t = timer_slot(lib, ti++, "k_epa<full>");
+    hipEventRecord(t->e0, st);
+    hipLaunchKernelGGL((k_epa<T, 64, EPA_MAX_ITER, 2>), dim3(blocks_for(n, 1)), dim3(64), 0, st, wk, lv, io, q);
     hipEventRecord(t->e1, st);
   }
-  HIP_TRY(hipMemcpyAsync(lib->h_counts, lib->d_counts, (B_COUNT + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(lib->h_counts, lib->d_counts, (B_COUNT + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipGetLastError());
   return HFCL_OK;
 }
@@ -1425,9 +1448,10 @@ int hfcl_last_kernel_breakdown(hfcl_lib* lib, const char** names, double* ms, in
   return k;
 }
 
-// bucket populations of the last call (after a stream sync): closed, prim, cc, pc, cp, bvh, unsupported, epa-queue
-void hfcl_last_bucket_counts(hfcl_lib* lib, uint32_t* out8) {
-  for (int i = 0; i <= B_COUNT; ++i) out8[i] = lib ? lib->h_counts[i] : 0;
+// bucket populations of the last call (after a stream sync): closed, prim, cc, pc, cp, bvh, unsupported,
+// epa queue, epa overflow queue
+void hfcl_last_bucket_counts(hfcl_lib* lib, uint32_t* out9) {
+  for (int i = 0; i <= B_COUNT + 1; ++i) out9[i] = lib ? lib->h_counts[i] : 0;
 }
 
 }  // extern "C"

@@ -127,11 +127,13 @@ HFCL_HD bool gjk_finish(const Gjk<T, PW0<T>>& g, const QParams<T>& q, const Pose
   return false;
 }
 
-// EPA branch of runGJKAndEPA (narrowphase.h:505-584) for one seed.
-template <typename T, class Grp, class Sup>
-HFCL_HD void epa_run(EpaScratch<T>* scratch, const EpaSeed<T>& seed, const QParams<T>& q, const Pose<T>& tf1, T r0, T r1,
-                     Sup& sup, PairOut<T>& out) {
-  Epa<T, Grp> epa;
+// EPA branch of runGJKAndEPA (narrowphase.h:505-584) for one seed.  Returns false when the
+// polytope outgrew the CAP-sized scratch block (the caller re-queues the seed for the
+// full-capacity kernel; `out` is then meaningless).
+template <typename T, class Grp, int CAP, class Sup>
+HFCL_HD bool epa_run(EpaScratch<T, CAP>* scratch, const EpaSeed<T>& seed, const QParams<T>& q, const Pose<T>& tf1, T r0,
+                     T r1, Sup& sup, PairOut<T>& out) {
+  Epa<T, Grp, CAP> epa;
   epa.reset(scratch, q.epa_max_iterations, q.epa_tolerance);
   // all four slots are written (slots >= rank are scratch that encloseOrigin overwrites): constant
   // indices keep the seed in registers
@@ -142,6 +144,7 @@ HFCL_HD void epa_run(EpaScratch<T>* scratch, const EpaSeed<T>& seed, const QPara
   Grp::sync();
   EpaResult<T> res;
   epa.evaluate(seed.rank, -seed.guess, r0 + r1, sup, res);
+  if (epa.overflow) return false;
   out.gjk_status = GJK_COLLISION;
   out.gjk_iters = int(seed.gjk_iters);
   out.epa_status = res.status;
@@ -151,7 +154,7 @@ HFCL_HD void epa_run(EpaScratch<T>* scratch, const EpaSeed<T>& seed, const QPara
     out.distance = -Lim<T>::max();
     out.normal = out.p1 = out.p2 = mk<T>(nanv, nanv, nanv);
     out.cached_guess = mk<T>(T(1), T(0), T(0));
-    return;
+    return true;
   }
   // EPAExtractWitnessPointsAndNormal :658-711
   out.cached_guess = -(res.depth * res.normal);
@@ -163,6 +166,7 @@ HFCL_HD void epa_run(EpaScratch<T>* scratch, const EpaSeed<T>& seed, const QPara
   out.normal = n;
   out.p1 = p1;
   out.p2 = p2;
+  return true;
 }
 
 // Record semantics on a fresh result object.  Returns the contact flag; for collide() the

@@ -200,7 +200,7 @@ class Library:
         return [(names[i].decode(), float(ms[i])) for i in range(k)]
 
     def last_bucket_counts(self):
-        out = (C.c_uint32 * 8)()
+        out = (C.c_uint32 * 9)()
         dll().hfcl_last_bucket_counts(self._h, out)
-        keys = ["closed", "prim", "cc", "pc", "cp", "bvh", "unsupported", "epa_queue"]
+        keys = ["closed", "prim", "cc", "pc", "cp", "bvh", "unsupported", "epa_queue", "epa_overflow"]
         return dict(zip(keys, [int(v) for v in out]))

@@ -66,8 +66,11 @@ static void one_pair(const DShape<T>& a, const DShape<T>& b, const T* verts, con
     gjk_run(g, q.gjk, guess0, r0 + r1, a.kind == K_CONVEX && b.kind == K_CONVEX, sup);
     EpaSeed<T> seed;
     if (gjk_finish(g, q, tf1, r0, r1, guess0, o, seed)) {
-      static thread_local EpaScratch<T> scratch;
-      epa_run<T, SerialGroup<1>>(&scratch, seed, q, tf1, r0, r1, sup, o);
+      // same two-tier scheme as the kernels: small-capacity block first, full capacity on overflow
+      static thread_local EpaScratch<T, 24> small;
+      static thread_local EpaScratch<T, EPA_MAX_ITER> full;
+      if (!epa_run<T, SerialGroup<1>, 24>(&small, seed, q, tf1, r0, r1, sup, o))
+        epa_run<T, SerialGroup<1>, EPA_MAX_ITER>(&full, seed, q, tf1, r0, r1, sup, o);
     }
   } else {
     skipped = true;
