@@ -242,7 +242,7 @@ def main():
                        "baseline_config": {"cfg3": "configs[2]", "cfg2": "configs[1]", "cfg4": "configs[3]"}[args.workload],
                        "pairs_per_gpu_per_step": n, "contact_fraction": contact_frac, "buckets": buckets,
                        "request": batch.kind, "all_gather_results": bool(gather),
-                       "lane_group_width": int(os.environ.get("HFCL_CVX_W", "8"))},
+                       "lane_group_width": int(os.environ.get("HFCL_CVX_W", "4"))},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

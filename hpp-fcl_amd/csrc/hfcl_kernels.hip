@@ -176,27 +176,49 @@ __device__ __forceinline__ V3<double> initial_guess<double>(const IO<double>& io
 // k_classify: bucket every pair by (kind1, kind2).  Wave-aggregated list append.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_classify(Work wk, const uint8_t* kinds, uint32_t n_shapes) {
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t n_round = (wk.n + 63u) & ~63u;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-    int b = -1;
-    if (i < wk.n) {
-      const uint32_t s1 = wk.shape1[i], s2 = wk.shape2[i];
-      b = (s1 < n_shapes && s2 < n_shapes) ? bucket_of(kinds[s1], kinds[s2]) : B_UNSUPPORTED;
-    }
-    for (int c = 0; c < B_COUNT; ++c) {
-      const unsigned long long m = __ballot(b == c);
-      if (m == 0ull) continue;
-      uint32_t base = 0;
-      const int leader = __ffsll((long long)m) - 1;
-      const int lane = threadIdx.x & 63;
-      if (lane == leader) base = atomicAdd(&wk.counts[c], (uint32_t)__popcll(m));
-      base = __shfl(base, leader, 64);
-      if (b == c) {
-        const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
-        wk.lists[size_t(c) * wk.n + base + rank] = i;
+  // Each block handles CHUNK consecutive pairs per trip: per-bucket counts are built in LDS, one
+  // global atomic per (block, bucket) reserves a range, then every lane writes its pair index.
+  constexpr int PER_THREAD = 8;
+  constexpr uint32_t CHUNK = 256 * PER_THREAD;
+  __shared__ uint32_t s_count[B_COUNT];
+  __shared__ uint32_t s_base[B_COUNT];
+  for (uint32_t start = blockIdx.x * CHUNK; start < wk.n; start += gridDim.x * CHUNK) {
+    if (threadIdx.x < B_COUNT) s_count[threadIdx.x] = 0;
+    __syncthreads();
+    int bk[PER_THREAD];
+    uint32_t rk[PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+      const uint32_t i = start + k * 256 + threadIdx.x;
+      bk[k] = -1;
+      rk[k] = 0;
+      if (i < wk.n) {
+        const uint32_t s1 = wk.shape1[i], s2 = wk.shape2[i];
+        bk[k] = (s1 < n_shapes && s2 < n_shapes) ? bucket_of(kinds[s1], kinds[s2]) : B_UNSUPPORTED;
+      }
+      // wave-aggregated LDS counter update
+      for (int c = 0; c < B_COUNT; ++c) {
+        const unsigned long long m = __ballot(bk[k] == c);
+        if (m == 0ull) continue;
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&s_count[c], (uint32_t)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (bk[k] == c) rk[k] = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       }
     }
+    __syncthreads();
+    if (threadIdx.x < B_COUNT) {
+      const uint32_t c = s_count[threadIdx.x];
+      s_base[threadIdx.x] = c ? atomicAdd(&wk.counts[threadIdx.x], c) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+      if (bk[k] >= 0) wk.lists[size_t(bk[k]) * wk.n + s_base[bk[k]] + rk[k]] = start + k * 256 + threadIdx.x;
+    }
+    __syncthreads();
   }
 }
 
@@ -391,7 +413,14 @@ struct LaneGroup {
   static __device__ __forceinline__ void sync() { __builtin_amdgcn_wave_barrier(); }
 };
 
-constexpr int EPA_FAST_CAP = 28;
+#ifndef HFCL_EPA_FAST_CAP
+#define HFCL_EPA_FAST_CAP 20
+#endif
+constexpr int EPA_FAST_CAP = HFCL_EPA_FAST_CAP;
+#ifndef HFCL_EPA_WE
+#define HFCL_EPA_WE 8
+#endif
+constexpr int EPA_WE = HFCL_EPA_WE;
 
 template <typename T, int WE>
 struct EpaSupport {  // any pair kind, evaluated by one lane group
@@ -679,7 +708,7 @@ struct hfcl_lib {
   hfcl_guess *d_gin = nullptr, *d_gout = nullptr;
   // instrumentation
   std::vector<KernelTime> timers;
-  int cvx_w = 8;
+  int cvx_w = 4;
   int n_cus = 256;
   std::string dominant;
   uint32_t h_counts[B_COUNT + 2] = {0};
@@ -1096,7 +1125,7 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   HIP_TRY(hipMemsetAsync(lib->d_counts, 0, (B_COUNT + 2) * sizeof(uint32_t), st));
   KernelTime* t = timer_slot(lib, ti++, "k_classify");
   hipEventRecord(t->e0, st);
-  hipLaunchKernelGGL(k_classify, dim3(blocks_for(n, 256 * 4)), dim3(256), 0, st, wk, lib->d_kinds, uint32_t(lib->n_shapes));
+  hipLaunchKernelGGL(k_classify, dim3(blocks_for(n, 256 * 8)), dim3(256), 0, st, wk, lib->d_kinds, uint32_t(lib->n_shapes));
   hipEventRecord(t->e1, st);
 
   t = timer_slot(lib, ti++, "k_closed");
@@ -1111,11 +1140,11 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
 
   const int w = lib->cvx_w;
   const int cgrid = blocks_for(n, 256 / w);
-  if (w == 4) launch_cvx<T, 4>(lib, wk, lv, io, q, st, ti, cgrid);
-  else if (w == 16) launch_cvx<T, 16>(lib, wk, lv, io, q, st, ti, cgrid);
+  if (w == 16) launch_cvx<T, 16>(lib, wk, lv, io, q, st, ti, cgrid);
   else if (w == 32) launch_cvx<T, 32>(lib, wk, lv, io, q, st, ti, cgrid);
   else if (w == 64) launch_cvx<T, 64>(lib, wk, lv, io, q, st, ti, cgrid);
-  else launch_cvx<T, 8>(lib, wk, lv, io, q, st, ti, cgrid);
+  else if (w == 8) launch_cvx<T, 8>(lib, wk, lv, io, q, st, ti, cgrid);
+  else launch_cvx<T, 4>(lib, wk, lv, io, q, st, ti, cgrid);
 
   if (!lib->h_meshes.empty() && q.mode == 1) {
     rc = upload_bvh(lib);
@@ -1141,11 +1170,11 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   if (q.compute_penetration) {
     t = timer_slot(lib, ti++, "k_epa<fast>");
     hipEventRecord(t->e0, st);
-    hipLaunchKernelGGL((k_epa<T, 8, EPA_FAST_CAP, 1>), dim3(blocks_for(n, 8)), dim3(64), 0, st, wk, lv, io, q);
+    hipLaunchKernelGGL((k_epa<T, EPA_WE, EPA_FAST_CAP, 1>), dim3(blocks_for(n, 64 / EPA_WE)), dim3(64), 0, st, wk, lv, io, q);
     hipEventRecord(t->e1, st);
     t = timer_slot(lib, ti++, "k_epa<full>");
     hipEventRecord(t->e0, st);
-    hipLaunchKernelGGL((k_epa<T, 64, EPA_MAX_ITER, 2>), dim3(blocks_for(n, 1)), dim3(64), 0, st, wk, lv, io, q);
+    hipLaunchKernelGGL((k_epa<T, 8, EPA_MAX_ITER, 2>), dim3(blocks_for(n / 64 + 1, 8)), dim3(64), 0, st, wk, lv, io, q);
     hipEventRecord(t->e1, st);
   }
   HIP_TRY(hipMemcpyAsync(lib->h_counts, lib->d_counts, (B_COUNT + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

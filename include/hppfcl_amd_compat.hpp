@@ -1,0 +1,467 @@
+// hppfcl_amd_compat.hpp -- header-only C++ shim exposing the C ABI (hppfcl_amd.h) under the
+// reference's own names so hpp-fcl user code for the narrow-phase path recompiles against it.
+//
+// Mirrors (same names, argument meaning, defaults and error behaviour):
+//   Transform3f                 include/hpp/fcl/math/transform.h:56-218
+//   CollisionGeometry/ShapeBase include/hpp/fcl/collision_object.h:94-190, shape/geometric_shapes.h:59-102
+//   Box, Sphere, Capsule, Ellipsoid, ConvexBase   shape/geometric_shapes.h:164-187,238-251,381-400,303-320,638-872
+//   QueryRequest, CollisionRequest, DistanceRequest, Contact, CollisionResult, DistanceResult
+//                               include/hpp/fcl/collision_data.h:59-166,171-273,312-383,391-494,987-1174
+//   collide(), distance()       include/hpp/fcl/collision.h:58-70, distance.h:53-65 (src/collision.cpp:69-130,
+//                               src/distance.cpp:60-109); std::invalid_argument for num_max_contacts == 0 and for
+//                               unsupported node-type pairs, exactly where the reference throws.
+//   CollisionCallBackCollect-style batching: amd::BatchQueries (default_broadphase_callbacks.h:224-252)
+//
+// No Eigen: Vec3f / Matrix3f are minimal PODs with the same memory image as the Eigen types the
+// reference uses (Matrix3f column-major), so `Transform3f` is bit-compatible with the ABI pose.
+// There is no CPU fallback: every query runs on the GPU through libhppfcl_amd.so.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstddef>
+#include <limits>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "hppfcl_amd.h"
+
+namespace hpp {
+namespace fcl {
+
+typedef double FCL_REAL;
+
+struct Vec3f {
+  FCL_REAL v[3];
+  Vec3f() : v{0, 0, 0} {}
+  Vec3f(FCL_REAL x, FCL_REAL y, FCL_REAL z) : v{x, y, z} {}
+  FCL_REAL& operator[](int i) { return v[i]; }
+  const FCL_REAL& operator[](int i) const { return v[i]; }
+  const FCL_REAL* data() const { return v; }
+  static Vec3f Constant(FCL_REAL c) { return Vec3f(c, c, c); }
+  static Vec3f Zero() { return Vec3f(0, 0, 0); }
+  Vec3f operator+(const Vec3f& o) const { return Vec3f(v[0] + o.v[0], v[1] + o.v[1], v[2] + o.v[2]); }
+  Vec3f operator-(const Vec3f& o) const { return Vec3f(v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]); }
+  Vec3f operator*(FCL_REAL s) const { return Vec3f(v[0] * s, v[1] * s, v[2] * s); }
+  Vec3f operator/(FCL_REAL s) const { return Vec3f(v[0] / s, v[1] / s, v[2] / s); }
+  Vec3f operator-() const { return Vec3f(-v[0], -v[1], -v[2]); }
+  FCL_REAL dot(const Vec3f& o) const { return v[0] * o.v[0] + v[1] * o.v[1] + v[2] * o.v[2]; }
+  FCL_REAL norm() const { return std::sqrt(dot(*this)); }
+};
+
+struct Matrix3f {  // column-major, like Eigen::Matrix<double,3,3>
+  FCL_REAL m[9];
+  Matrix3f() { setIdentity(); }
+  void setIdentity() {
+    for (int i = 0; i < 9; ++i) m[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  }
+  static Matrix3f Identity() { return Matrix3f(); }
+  FCL_REAL& operator()(int r, int c) { return m[c * 3 + r]; }
+  const FCL_REAL& operator()(int r, int c) const { return m[c * 3 + r]; }
+  Vec3f operator*(const Vec3f& x) const {
+    return Vec3f((*this)(0, 0) * x[0] + (*this)(0, 1) * x[1] + (*this)(0, 2) * x[2],
+                 (*this)(1, 0) * x[0] + (*this)(1, 1) * x[1] + (*this)(1, 2) * x[2],
+                 (*this)(2, 0) * x[0] + (*this)(2, 1) * x[1] + (*this)(2, 2) * x[2]);
+  }
+  Matrix3f operator*(const Matrix3f& o) const {
+    Matrix3f r;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) r(i, j) = (*this)(i, 0) * o(0, j) + (*this)(i, 1) * o(1, j) + (*this)(i, 2) * o(2, j);
+    return r;
+  }
+};
+
+struct Quatf {  // makeQuat(w, x, y, z)
+  FCL_REAL w, x, y, z;
+  Matrix3f toRotationMatrix() const {  // Eigen::Quaternion::toRotationMatrix
+    Matrix3f R;
+    const FCL_REAL tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x,
+                   txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R(0, 0) = 1 - (tyy + tzz); R(0, 1) = txy - twz; R(0, 2) = txz + twy;
+    R(1, 0) = txy + twz; R(1, 1) = 1 - (txx + tzz); R(1, 2) = tyz - twx;
+    R(2, 0) = txz - twy; R(2, 1) = tyz + twx; R(2, 2) = 1 - (txx + tyy);
+    return R;
+  }
+};
+inline Quatf makeQuat(FCL_REAL w, FCL_REAL x, FCL_REAL y, FCL_REAL z) { return Quatf{w, x, y, z}; }
+
+class Transform3f {
+  Matrix3f R;
+  Vec3f T;
+
+ public:
+  Transform3f() {}
+  Transform3f(const Matrix3f& R_, const Vec3f& T_) : R(R_), T(T_) {}
+  Transform3f(const Quatf& q, const Vec3f& T_) : R(q.toRotationMatrix()), T(T_) {}
+  explicit Transform3f(const Matrix3f& R_) : R(R_) {}
+  explicit Transform3f(const Quatf& q) : R(q.toRotationMatrix()) {}
+  explicit Transform3f(const Vec3f& T_) : T(T_) {}
+  static Transform3f Identity() { return Transform3f(); }
+  const Vec3f& getTranslation() const { return T; }
+  const Matrix3f& getRotation() const { return R; }
+  void setTranslation(const Vec3f& t) { T = t; }
+  void setRotation(const Matrix3f& r) { R = r; }
+  void setQuatRotation(const Quatf& q) { R = q.toRotationMatrix(); }
+  Vec3f transform(const Vec3f& x) const { return R * x + T; }
+  Transform3f operator*(const Transform3f& o) const { return Transform3f(R * o.R, R * o.T + T); }
+};
+static_assert(sizeof(Transform3f) == HFCL_POSE_DOUBLES * sizeof(double), "Transform3f must be the ABI pose image");
+
+enum NODE_TYPE {  // include/hpp/fcl/collision_object.h:65-89 (subset in scope)
+  BV_OBBRSS = HFCL_BV_OBBRSS, GEOM_BOX = HFCL_GEOM_BOX, GEOM_SPHERE = HFCL_GEOM_SPHERE, GEOM_CAPSULE = HFCL_GEOM_CAPSULE,
+  GEOM_CONVEX = HFCL_GEOM_CONVEX, GEOM_TRIANGLE = HFCL_GEOM_TRIANGLE, GEOM_ELLIPSOID = HFCL_GEOM_ELLIPSOID
+};
+enum GJKInitialGuess { DefaultGuess, CachedGuess, BoundingVolumeGuess };
+enum GJKVariant { DefaultGJK, PolyakAcceleration, NesterovAcceleration };
+enum GJKConvergenceCriterion { Default, DualityGap, Hybrid };
+enum GJKConvergenceCriterionType { Relative, Absolute };
+typedef std::array<int, 2> support_func_guess_t;
+
+class CollisionGeometry {
+ public:
+  virtual ~CollisionGeometry() {}
+  virtual NODE_TYPE getNodeType() const = 0;
+};
+class ShapeBase : public CollisionGeometry {
+ public:
+  void setSweptSphereRadius(FCL_REAL r) {
+    if (r < 0) throw std::invalid_argument("Swept-sphere radius must be positive.");
+    m_swept_sphere_radius = r;
+  }
+  FCL_REAL getSweptSphereRadius() const { return m_swept_sphere_radius; }
+
+ protected:
+  FCL_REAL m_swept_sphere_radius = 0;
+};
+class Box : public ShapeBase {
+ public:
+  Box(FCL_REAL x, FCL_REAL y, FCL_REAL z) : halfSide(x / 2, y / 2, z / 2) {}
+  explicit Box(const Vec3f& side) : halfSide(side * 0.5) {}
+  Vec3f halfSide;
+  NODE_TYPE getNodeType() const override { return GEOM_BOX; }
+};
+class Sphere : public ShapeBase {
+ public:
+  explicit Sphere(FCL_REAL r) : radius(r) {}
+  FCL_REAL radius;
+  NODE_TYPE getNodeType() const override { return GEOM_SPHERE; }
+};
+class Capsule : public ShapeBase {
+ public:
+  Capsule(FCL_REAL r, FCL_REAL lz) : radius(r), halfLength(lz / 2) {}
+  FCL_REAL radius, halfLength;
+  NODE_TYPE getNodeType() const override { return GEOM_CAPSULE; }
+};
+class Ellipsoid : public ShapeBase {
+ public:
+  Ellipsoid(FCL_REAL rx, FCL_REAL ry, FCL_REAL rz) : radii(rx, ry, rz) {}
+  Vec3f radii;
+  NODE_TYPE getNodeType() const override { return GEOM_ELLIPSOID; }
+};
+class ConvexBase : public ShapeBase {
+ public:
+  explicit ConvexBase(std::shared_ptr<std::vector<Vec3f>> pts) : points(std::move(pts)) {
+    num_points = static_cast<unsigned int>(points->size());
+  }
+  std::shared_ptr<std::vector<Vec3f>> points;
+  unsigned int num_points;
+  NODE_TYPE getNodeType() const override { return GEOM_CONVEX; }
+};
+
+struct QueryRequest {
+  GJKInitialGuess gjk_initial_guess = DefaultGuess;
+  mutable Vec3f cached_gjk_guess = Vec3f(1, 0, 0);
+  mutable support_func_guess_t cached_support_func_guess = {{0, 0}};
+  size_t gjk_max_iterations = 128;
+  FCL_REAL gjk_tolerance = 1e-6;
+  GJKVariant gjk_variant = DefaultGJK;
+  GJKConvergenceCriterion gjk_convergence_criterion = Default;
+  GJKConvergenceCriterionType gjk_convergence_criterion_type = Relative;
+  size_t epa_max_iterations = 64;
+  FCL_REAL epa_tolerance = 1e-6;
+  bool enable_timings = false;
+  FCL_REAL collision_distance_threshold = 1e-12;
+};
+struct CollisionRequest : QueryRequest {
+  size_t num_max_contacts = 1;
+  bool enable_contact = true;
+  FCL_REAL security_margin = 0;
+  FCL_REAL break_distance = 1e-3;
+  FCL_REAL distance_upper_bound = (std::numeric_limits<FCL_REAL>::max)();
+};
+struct DistanceRequest : QueryRequest {
+  bool enable_nearest_points = true;
+  bool enable_signed_distance = true;
+  FCL_REAL rel_err = 0, abs_err = 0;
+  DistanceRequest(bool enable_nearest_points_ = true, bool enable_signed_distance_ = true, FCL_REAL rel_err_ = 0,
+                  FCL_REAL abs_err_ = 0)
+      : enable_nearest_points(enable_nearest_points_), enable_signed_distance(enable_signed_distance_),
+        rel_err(rel_err_), abs_err(abs_err_) {}
+};
+
+struct Contact {
+  const CollisionGeometry* o1 = nullptr;
+  const CollisionGeometry* o2 = nullptr;
+  int b1 = -1, b2 = -1;
+  Vec3f normal;
+  std::array<Vec3f, 2> nearest_points;
+  Vec3f pos;
+  FCL_REAL penetration_depth = (std::numeric_limits<FCL_REAL>::max)();
+  static const int NONE = -1;
+};
+
+struct QueryResult {
+  Vec3f cached_gjk_guess;
+  support_func_guess_t cached_support_func_guess = {{-1, -1}};
+};
+struct CollisionResult : QueryResult {
+  FCL_REAL distance_lower_bound = (std::numeric_limits<FCL_REAL>::max)();
+  Vec3f normal = Vec3f::Constant(std::numeric_limits<FCL_REAL>::quiet_NaN());
+  std::array<Vec3f, 2> nearest_points = {{normal, normal}};
+  bool isCollision() const { return !contacts.empty(); }
+  size_t numContacts() const { return contacts.size(); }
+  const Contact& getContact(size_t i) const {
+    if (contacts.empty()) throw std::invalid_argument("The number of contacts is zero. No Contact can be returned.");
+    return contacts[i < contacts.size() ? i : contacts.size() - 1];
+  }
+  void addContact(const Contact& c) { contacts.push_back(c); }
+  void clear() { *this = CollisionResult(); }
+
+ private:
+  std::vector<Contact> contacts;
+};
+struct DistanceResult : QueryResult {
+  FCL_REAL min_distance = (std::numeric_limits<FCL_REAL>::max)();
+  Vec3f normal = Vec3f::Constant(std::numeric_limits<FCL_REAL>::quiet_NaN());
+  std::array<Vec3f, 2> nearest_points = {{normal, normal}};
+  const CollisionGeometry* o1 = nullptr;
+  const CollisionGeometry* o2 = nullptr;
+  int b1 = -1, b2 = -1;
+  static const int NONE = -1;
+  void clear() { *this = DistanceResult(); }
+};
+
+namespace amd {
+
+inline void fill_query(hfcl_query_request& q, const QueryRequest& r) {
+  q.gjk_initial_guess = r.gjk_initial_guess;
+  q.gjk_variant = r.gjk_variant;
+  q.gjk_convergence_criterion = r.gjk_convergence_criterion;
+  q.gjk_convergence_criterion_type = r.gjk_convergence_criterion_type;
+  q.gjk_max_iterations = static_cast<uint32_t>(r.gjk_max_iterations);
+  q.epa_max_iterations = static_cast<uint32_t>(r.epa_max_iterations);
+  q.gjk_tolerance = r.gjk_tolerance;
+  q.epa_tolerance = r.epa_tolerance;
+  q.collision_distance_threshold = r.collision_distance_threshold;
+  for (int k = 0; k < 3; ++k) q.cached_gjk_guess[k] = r.cached_gjk_guess[k];
+  q.cached_support_func_guess[0] = r.cached_support_func_guess[0];
+  q.cached_support_func_guess[1] = r.cached_support_func_guess[1];
+}
+inline hfcl_collision_request to_abi(const CollisionRequest& r) {
+  hfcl_collision_request a;
+  hfcl_collision_request_init(&a);
+  fill_query(a.q, r);
+  a.num_max_contacts = static_cast<uint32_t>(r.num_max_contacts);
+  a.enable_contact = r.enable_contact;
+  a.security_margin = r.security_margin;
+  a.break_distance = r.break_distance;
+  a.distance_upper_bound = r.distance_upper_bound;
+  return a;
+}
+inline hfcl_distance_request to_abi(const DistanceRequest& r) {
+  hfcl_distance_request a;
+  hfcl_distance_request_init(&a);
+  fill_query(a.q, r);
+  a.enable_nearest_points = r.enable_nearest_points;
+  a.enable_signed_distance = r.enable_signed_distance;
+  a.rel_err = r.rel_err;
+  a.abs_err = r.abs_err;
+  return a;
+}
+[[noreturn]] inline void throw_for(int rc) {
+  const std::string msg = hfcl_last_error();
+  if (rc == HFCL_ERR_INVALID_ARGUMENT || rc == HFCL_ERR_UNSUPPORTED_PAIR) throw std::invalid_argument(msg);
+  throw std::runtime_error(msg);
+}
+
+// A set of geometries registered once (the device shape library) + batched queries on it:
+// the CollisionCallBackCollect hand-off (collect pairs on the host, evaluate them in one call).
+class BatchQueries {
+ public:
+  explicit BatchQueries(int device = 0) : device_(device) {}
+  ~BatchQueries() { hfcl_lib_destroy(lib_); }
+  BatchQueries(const BatchQueries&) = delete;
+  BatchQueries& operator=(const BatchQueries&) = delete;
+
+  uint32_t add(const CollisionGeometry* g) {
+    auto it = ids_.find(g);
+    if (it != ids_.end()) return it->second;
+    hfcl_shape s{};
+    s.type = g->getNodeType();
+    const ShapeBase* sb = dynamic_cast<const ShapeBase*>(g);
+    s.swept_sphere_radius = sb ? sb->getSweptSphereRadius() : 0.0;
+    switch (g->getNodeType()) {
+      case GEOM_BOX: { auto* b = static_cast<const Box*>(g); for (int i = 0; i < 3; ++i) s.params[i] = b->halfSide[i]; break; }
+      case GEOM_SPHERE: s.params[0] = static_cast<const Sphere*>(g)->radius; break;
+      case GEOM_CAPSULE: { auto* c = static_cast<const Capsule*>(g); s.params[0] = c->radius; s.params[1] = c->halfLength; break; }
+      case GEOM_ELLIPSOID: { auto* e = static_cast<const Ellipsoid*>(g); for (int i = 0; i < 3; ++i) s.params[i] = e->radii[i]; break; }
+      case GEOM_CONVEX: {
+        auto* c = static_cast<const ConvexBase*>(g);
+        s.num_points = c->num_points;
+        s.vertex_offset = static_cast<uint32_t>(verts_.size() / 3);
+        for (const Vec3f& p : *c->points) verts_.insert(verts_.end(), p.data(), p.data() + 3);
+        break;
+      }
+      default: throw std::invalid_argument("unsupported node type");
+    }
+    shapes_.push_back(s);
+    geoms_.push_back(g);
+    hfcl_lib_destroy(lib_);
+    lib_ = nullptr;
+    const uint32_t id = static_cast<uint32_t>(shapes_.size() - 1);
+    ids_[g] = id;
+    return id;
+  }
+
+  void collide(const std::vector<std::pair<uint32_t, uint32_t>>& pairs, const std::vector<Transform3f>& tf1,
+               const std::vector<Transform3f>& tf2, const CollisionRequest& request, std::vector<CollisionResult>& results) {
+    run(pairs, tf1, tf2, &request, nullptr);
+    results.assign(pairs.size(), CollisionResult());
+    for (size_t i = 0; i < pairs.size(); ++i) fill(results[i], pairs[i], request, rec_[i], guess_[i]);
+  }
+  void distance(const std::vector<std::pair<uint32_t, uint32_t>>& pairs, const std::vector<Transform3f>& tf1,
+                const std::vector<Transform3f>& tf2, const DistanceRequest& request, std::vector<DistanceResult>& results) {
+    run(pairs, tf1, tf2, nullptr, &request);
+    results.assign(pairs.size(), DistanceResult());
+    for (size_t i = 0; i < pairs.size(); ++i) fill(results[i], pairs[i], rec_[i], guess_[i]);
+  }
+
+  void fill(CollisionResult& res, const std::pair<uint32_t, uint32_t>& p, const CollisionRequest& request,
+            const hfcl_result& r, const hfcl_guess& g) const {
+    if (!HFCL_STATUS_SKIPPED(r.status)) {
+      const Vec3f n(r.normal[0], r.normal[1], r.normal[2]), p1(r.p1[0], r.p1[1], r.p1[2]), p2(r.p2[0], r.p2[1], r.p2[2]);
+      const FCL_REAL dtc = r.distance - request.security_margin;  // updateDistanceLowerBoundFromLeaf
+      if (dtc < res.distance_lower_bound) {
+        res.distance_lower_bound = dtc;
+        res.nearest_points = {{p1, p2}};
+        res.normal = n;
+      }
+      if (r.num_contacts > 0 && res.numContacts() < request.num_max_contacts) {
+        Contact c;
+        c.o1 = geoms_[p.first];
+        c.o2 = geoms_[p.second];
+        c.b1 = r.b1;
+        c.b2 = r.b2;
+        c.normal = n;
+        c.nearest_points = {{p1, p2}};
+        c.pos = (p1 + p2) / 2;
+        c.penetration_depth = r.distance;
+        res.addContact(c);
+      }
+    }
+    res.cached_gjk_guess = Vec3f(g.gjk_guess[0], g.gjk_guess[1], g.gjk_guess[2]);
+    res.cached_support_func_guess = {{g.support_guess[0], g.support_guess[1]}};
+  }
+  void fill(DistanceResult& res, const std::pair<uint32_t, uint32_t>& p, const hfcl_result& r, const hfcl_guess& g) const {
+    if (res.min_distance > r.distance) {  // DistanceResult::update
+      res.min_distance = r.distance;
+      res.o1 = geoms_[p.first];
+      res.o2 = geoms_[p.second];
+      res.b1 = r.b1;
+      res.b2 = r.b2;
+      res.nearest_points = {{Vec3f(r.p1[0], r.p1[1], r.p1[2]), Vec3f(r.p2[0], r.p2[1], r.p2[2])}};
+      res.normal = Vec3f(r.normal[0], r.normal[1], r.normal[2]);
+    }
+    res.cached_gjk_guess = Vec3f(g.gjk_guess[0], g.gjk_guess[1], g.gjk_guess[2]);
+    res.cached_support_func_guess = {{g.support_guess[0], g.support_guess[1]}};
+  }
+  const std::vector<hfcl_result>& records() const { return rec_; }
+  const std::vector<hfcl_guess>& guesses() const { return guess_; }
+
+  void run(const std::vector<std::pair<uint32_t, uint32_t>>& pairs, const std::vector<Transform3f>& tf1,
+           const std::vector<Transform3f>& tf2, const CollisionRequest* creq, const DistanceRequest* dreq) {
+    if (tf1.size() != pairs.size() || tf2.size() != pairs.size()) throw std::invalid_argument("pairs/poses size mismatch");
+    if (!lib_) {
+      lib_ = hfcl_lib_create(shapes_.data(), shapes_.size(), verts_.data(), verts_.size() / 3, device_);
+      if (!lib_) throw std::runtime_error(hfcl_last_error());
+    }
+    std::vector<uint32_t> s1(pairs.size()), s2(pairs.size());
+    for (size_t i = 0; i < pairs.size(); ++i) {
+      s1[i] = pairs[i].first;
+      s2[i] = pairs[i].second;
+    }
+    rec_.resize(pairs.size());
+    guess_.resize(pairs.size());
+    int rc;
+    if (creq) {
+      const hfcl_collision_request a = to_abi(*creq);
+      rc = hfcl_collide_batch(lib_, s1.data(), s2.data(), reinterpret_cast<const double*>(tf1.data()),
+                              reinterpret_cast<const double*>(tf2.data()), pairs.size(), &a, rec_.data(), nullptr, guess_.data());
+    } else {
+      const hfcl_distance_request a = to_abi(*dreq);
+      rc = hfcl_distance_batch(lib_, s1.data(), s2.data(), reinterpret_cast<const double*>(tf1.data()),
+                               reinterpret_cast<const double*>(tf2.data()), pairs.size(), &a, rec_.data(), nullptr, guess_.data());
+    }
+    if (rc) throw_for(rc);
+  }
+
+ private:
+  int device_;
+  hfcl_lib* lib_ = nullptr;
+  std::vector<hfcl_shape> shapes_;
+  std::vector<double> verts_;
+  std::vector<const CollisionGeometry*> geoms_;
+  std::map<const CollisionGeometry*, uint32_t> ids_;
+  std::vector<hfcl_result> rec_;
+  std::vector<hfcl_guess> guess_;
+};
+
+inline BatchQueries& default_context() {
+  static thread_local BatchQueries ctx(0);
+  return ctx;
+}
+
+}  // namespace amd
+
+/// hpp::fcl::collide (src/collision.cpp:69-130) as a batch of one.  Results accumulate in
+/// `result` like in the reference (the caller clears between queries).
+inline std::size_t collide(const CollisionGeometry* o1, const Transform3f& tf1, const CollisionGeometry* o2,
+                           const Transform3f& tf2, const CollisionRequest& request, CollisionResult& result) {
+  if (request.security_margin == -std::numeric_limits<FCL_REAL>::infinity()) {
+    result.clear();
+    return 0;
+  }
+  if (request.num_max_contacts == 0)
+    throw std::invalid_argument("Invalid number of max contacts (current value is 0).");
+  if (result.isCollision() && request.num_max_contacts <= result.numContacts()) return result.numContacts();
+  amd::BatchQueries& ctx = amd::default_context();
+  const std::pair<uint32_t, uint32_t> p(ctx.add(o1), ctx.add(o2));
+  ctx.run({p}, {tf1}, {tf2}, &request, nullptr);
+  ctx.fill(result, p, request, ctx.records()[0], ctx.guesses()[0]);
+  if (request.gjk_initial_guess == CachedGuess) {  // QueryRequest::updateGuess
+    request.cached_gjk_guess = result.cached_gjk_guess;
+    request.cached_support_func_guess = result.cached_support_func_guess;
+  }
+  return result.numContacts();
+}
+
+/// hpp::fcl::distance (src/distance.cpp:60-109) as a batch of one.
+inline FCL_REAL distance(const CollisionGeometry* o1, const Transform3f& tf1, const CollisionGeometry* o2,
+                         const Transform3f& tf2, const DistanceRequest& request, DistanceResult& result) {
+  if (result.min_distance <= 0) return result.min_distance;  // DistanceRequest::isSatisfied
+  amd::BatchQueries& ctx = amd::default_context();
+  const std::pair<uint32_t, uint32_t> p(ctx.add(o1), ctx.add(o2));
+  ctx.run({p}, {tf1}, {tf2}, nullptr, &request);
+  ctx.fill(result, p, ctx.records()[0], ctx.guesses()[0]);
+  if (request.gjk_initial_guess == CachedGuess) {
+    request.cached_gjk_guess = result.cached_gjk_guess;
+    request.cached_support_func_guess = result.cached_support_func_guess;
+  }
+  return ctx.records()[0].distance;
+}
+
+}  // namespace fcl
+}  // namespace hpp

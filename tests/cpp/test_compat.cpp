@@ -1,0 +1,97 @@
+// Reads like the reference's own tests, against include/hppfcl_amd_compat.hpp:
+//   test/capsule_box_1.cpp:51-116, test/box_box_distance.cpp:62-110, test/geometric_shapes.cpp:238-333 (subset),
+//   src/collision.cpp:82-85 (num_max_contacts == 0 throws).
+// Exit code 0 = all checks passed; 3 = no GPU (the shim has no CPU fallback).
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+
+#include "hppfcl_amd_compat.hpp"
+
+static int failures = 0;
+#define CHECK(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); ++failures; } } while (0)
+#define CHECK_CLOSE(x, ref, pct) CHECK(std::fabs((x) - (ref)) <= std::fabs(ref) * (pct) / 100.0)
+#define CHECK_CLOSE_TO_0(x, eps) CHECK(std::fabs(x) < (eps))
+
+int main() {
+  using namespace hpp::fcl;
+  if (hfcl_device_count() < 1) {
+    Sphere s(1.0);
+    try {
+      DistanceRequest rq; DistanceResult rs;
+      distance(&s, Transform3f(), &s, Transform3f(Vec3f(3, 0, 0)), rq, rs);
+    } catch (const std::runtime_error& e) {
+      std::printf("no GPU: %s\n", e.what());
+      return 3;
+    }
+    return 4;
+  }
+  {  // distance_capsule_box (capsule_box_1.cpp)
+    Capsule capsule(2., 4.);
+    Box box(1., 2., 4.);
+    DistanceRequest distanceRequest(true, true, 0, 0);
+    DistanceResult distanceResult;
+    Transform3f tf1(Vec3f(3., 0, 0)), tf2;
+    distance(&capsule, tf1, &box, tf2, distanceRequest, distanceResult);
+    Vec3f o1 = distanceResult.nearest_points[0], o2 = distanceResult.nearest_points[1];
+    CHECK_CLOSE(distanceResult.min_distance, 0.5, 1e-1);
+    CHECK_CLOSE(o1[0], 1.0, 1e-1); CHECK_CLOSE_TO_0(o1[1], 1e-1);
+    CHECK_CLOSE(o2[0], 0.5, 1e-1); CHECK_CLOSE_TO_0(o2[1], 1e-1);
+    tf1 = Transform3f(Vec3f(0., 0., 8.));
+    distanceResult.clear();
+    distance(&capsule, tf1, &box, tf2, distanceRequest, distanceResult);
+    o1 = distanceResult.nearest_points[0]; o2 = distanceResult.nearest_points[1];
+    CHECK_CLOSE(distanceResult.min_distance, 2.0, 1e-1);
+    CHECK_CLOSE(o1[2], 4.0, 1e-1); CHECK_CLOSE(o2[2], 2.0, 1e-1);
+    tf1.setTranslation(Vec3f(-10., 0., 0.));
+    tf1.setQuatRotation(makeQuat(std::sqrt(2) / 2, 0, std::sqrt(2) / 2, 0));
+    distanceResult.clear();
+    distance(&capsule, tf1, &box, tf2, distanceRequest, distanceResult);
+    o1 = distanceResult.nearest_points[0]; o2 = distanceResult.nearest_points[1];
+    CHECK_CLOSE(distanceResult.min_distance, 5.5, 1e-1);
+    CHECK_CLOSE(o1[0], -6, 1e-2); CHECK_CLOSE(o2[0], -0.5, 1e-2);
+  }
+  {  // distance_box_box_1 (box_box_distance.cpp:62-103)
+    Box s1(6, 10, 2), s2(2, 2, 2);
+    DistanceRequest rq(true, true, 0, 0);
+    DistanceResult rs;
+    distance(&s1, Transform3f(), &s2, Transform3f(Vec3f(25, 20, 5)), rq, rs);
+    CHECK_CLOSE(rs.min_distance, std::sqrt(21. * 21 + 14 * 14 + 3 * 3), 1e-4);
+    CHECK_CLOSE(rs.nearest_points[0][0], 3, 1e-6); CHECK_CLOSE(rs.nearest_points[0][1], 5, 1e-6);
+    CHECK_CLOSE(rs.nearest_points[1][0], 24, 1e-6); CHECK_CLOSE(rs.nearest_points[1][2], 4, 1e-6);
+  }
+  {  // collide_spheresphere (geometric_shapes.cpp:238-333, subset) + Contact fields
+    Sphere s1(20), s2(10);
+    CollisionRequest rq; CollisionResult rs;
+    CHECK(collide(&s1, Transform3f(), &s2, Transform3f(Vec3f(40, 0, 0)), rq, rs) == 0);
+    CHECK(!rs.isCollision() && std::fabs(rs.distance_lower_bound - 10) < 1e-9);
+    rs.clear();
+    CHECK(collide(&s1, Transform3f(), &s2, Transform3f(Vec3f(29.9, 0, 0)), rq, rs) == 1);
+    const Contact& c = rs.getContact(0);
+    CHECK(std::fabs(c.normal[0] - 1) < 1e-12 && std::fabs(c.penetration_depth + 0.1) < 1e-9);
+    CHECK(c.o1 == &s1 && c.o2 == &s2 && c.b1 == Contact::NONE);
+    CHECK(std::fabs(c.pos[0] - (c.nearest_points[0][0] + c.nearest_points[1][0]) / 2) < 1e-12);
+    rq.num_max_contacts = 0;
+    bool threw = false;
+    try { rs.clear(); collide(&s1, Transform3f(), &s2, Transform3f(), rq, rs); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    CollisionRequest rq2; rq2.security_margin = -std::numeric_limits<double>::infinity();
+    CHECK(collide(&s1, Transform3f(), &s2, Transform3f(), rq2, rs) == 0 && !rs.isCollision());
+  }
+  {  // batched hand-off (CollisionCallBackCollect style) on convex hulls + warm start round trip
+    auto pts = std::make_shared<std::vector<Vec3f>>();
+    for (int i = 0; i < 8; ++i) pts->push_back(Vec3f((i & 1) ? 1 : -1, (i & 2) ? 1 : -1, (i & 4) ? 1 : -1));
+    ConvexBase cube(pts);
+    Box box(2, 2, 2);
+    amd::BatchQueries batch;
+    const uint32_t a = batch.add(&cube), b = batch.add(&box);
+    std::vector<std::pair<uint32_t, uint32_t>> pairs;
+    std::vector<Transform3f> tf1, tf2;
+    for (int k = 0; k < 100; ++k) { pairs.push_back({a, b}); tf1.push_back(Transform3f()); tf2.push_back(Transform3f(Vec3f(1.5 + 0.02 * k, 0.1, 0))); }
+    DistanceRequest rq; std::vector<DistanceResult> res;
+    batch.distance(pairs, tf1, tf2, rq, res);
+    for (int k = 0; k < 100; ++k) CHECK(std::fabs(res[k].min_distance - (1.5 + 0.02 * k - 2.0)) < 1e-6);
+  }
+  std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
+  return failures ? 1 : 0;
+}

@@ -59,3 +59,15 @@ def test_product_never_references_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_binding" not in txt and "liboracle" not in txt and "hostsim_binding" not in txt, f
                 assert not re.search(r'#include\s+"[^"]*oracle/', txt), f
+
+
+def test_cpp_shim_compiles_and_fails_loudly_without_gpu(pkg):
+    """include/hppfcl_amd_compat.hpp: the hpp::fcl-named shim compiles with plain g++ against the C ABI."""
+    import subprocess
+    pkg.engine.build_native()
+    d = os.path.join(ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-s", "-C", d])
+    if pkg.engine.device_count() > 0:
+        pytest.skip("a GPU is visible (the GPU suite runs the binary)")
+    r = subprocess.run([os.path.join(d, "test_compat")], capture_output=True, text=True)
+    assert r.returncode == 3 and "no CPU fallback" in r.stdout

@@ -284,3 +284,13 @@ def test_bvh_security_margin_and_mixed_batch(pkg, oracle):
         lib.distance(b.s1[:10], b.s2[:10], b.tf1[:10], b.tf2[:10])
     assert e.value.code == abi.ERR_UNSUPPORTED_PAIR
     lib.close()
+
+
+def test_cpp_shim_runs_reference_style_tests(pkg):
+    """tests/cpp/test_compat.cpp: hpp-fcl-named C++ (collide/distance/CollisionRequest/...) on the GPU."""
+    import os
+    import subprocess
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    subprocess.check_call(["make", "-s", "-C", d])
+    r = subprocess.run([os.path.join(d, "test_compat")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
