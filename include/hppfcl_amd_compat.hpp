@@ -297,9 +297,8 @@ class BatchQueries {
   BatchQueries& operator=(const BatchQueries&) = delete;
 
   uint32_t add(const CollisionGeometry* g) {
-    auto it = ids_.find(g);
-    if (it != ids_.end()) return it->second;
     hfcl_shape s{};
+    std::vector<double> v;
     s.type = g->getNodeType();
     const ShapeBase* sb = dynamic_cast<const ShapeBase*>(g);
     s.swept_sphere_radius = sb ? sb->getSweptSphereRadius() : 0.0;
@@ -311,12 +310,24 @@ class BatchQueries {
       case GEOM_CONVEX: {
         auto* c = static_cast<const ConvexBase*>(g);
         s.num_points = c->num_points;
-        s.vertex_offset = static_cast<uint32_t>(verts_.size() / 3);
-        for (const Vec3f& p : *c->points) verts_.insert(verts_.end(), p.data(), p.data() + 3);
+        for (const Vec3f& p : *c->points) v.insert(v.end(), p.data(), p.data() + 3);
         break;
       }
       default: throw std::invalid_argument("unsupported node type");
     }
+    // The cache is keyed by address; a hit is only trusted if the geometry's *content* is still
+    // what was registered (addresses get reused once a geometry is destroyed).
+    auto it = ids_.find(g);
+    if (it != ids_.end()) {
+      const hfcl_shape& o = shapes_[it->second];
+      bool same = o.type == s.type && o.num_points == s.num_points && o.swept_sphere_radius == s.swept_sphere_radius &&
+                  o.params[0] == s.params[0] && o.params[1] == s.params[1] && o.params[2] == s.params[2];
+      if (same && s.type == GEOM_CONVEX)
+        for (size_t k = 0; k < v.size() && same; ++k) same = verts_[3 * size_t(o.vertex_offset) + k] == v[k];
+      if (same) return it->second;
+    }
+    s.vertex_offset = static_cast<uint32_t>(verts_.size() / 3);
+    verts_.insert(verts_.end(), v.begin(), v.end());
     shapes_.push_back(s);
     geoms_.push_back(g);
     hfcl_lib_destroy(lib_);
