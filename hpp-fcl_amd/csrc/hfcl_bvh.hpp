@@ -11,6 +11,14 @@
 
 namespace hfcl {
 
+// RSS part of a node (RSS.h:54-150); its axes are the OBB's (BVFitter<OBBRSS>::fit sets
+// rss.axes = obb.axes, BV_fitter.cpp:513).  fp32: 24 B, fp64: 48 B; read by the distance traversal only.
+template <typename T>
+struct DRss {
+  V3<T> Tr;
+  T l0, l1, r;
+};
+
 // Device node: what the collide traversal reads of BVNode<OBBRSS> (BV_node.h:52-148, OBB.h:52-126).
 // fp32: 64 B, fp64: 128 B.
 template <typename T>
@@ -148,6 +156,279 @@ HFCL_HD T tri_tri_distance(const TriSupport<T>& tri, const GjkParams<T>& prm_in,
     distance = -hmax(d1, hmax(d2, d3));
   }
   return distance;
+}
+
+// ---------------------------------------------------------------------------------------
+// distance(): RSS lower bound and triangle-triangle distance
+//   rectDistance / segCoords / inVoronoi   src/BV/RSS.cpp:49-713
+//   distance(R0,T0,rss1,rss2)              src/BV/RSS.cpp:995-1005
+//   segPoints / sqrTriDistance             src/intersect.cpp:60-368
+// ---------------------------------------------------------------------------------------
+template <typename T> HFCL_HD T clipr(T v, T a, T b) { return v < a ? a : (v > b ? b : v); }
+
+template <typename T>
+HFCL_HD void seg_coords(T& t, T& u, T a, T b, T A_dot_B, T A_dot_T, T B_dot_T) {
+  const T denom = T(1) - A_dot_B * A_dot_B;
+  t = (denom == T(0)) ? T(0) : clipr((A_dot_T - B_dot_T * A_dot_B) / denom, T(0), a);
+  u = t * A_dot_B - B_dot_T;
+  if (u < T(0)) {
+    u = T(0);
+    t = clipr(A_dot_T, T(0), a);
+  } else if (u > b) {
+    u = b;
+    t = clipr(u * A_dot_B + A_dot_T, T(0), a);
+  }
+}
+template <typename T>
+HFCL_HD bool in_voronoi(T a, T b, T Anorm_dot_B, T Anorm_dot_T, T A_dot_B, T A_dot_T, T B_dot_T) {
+  if (habs(Anorm_dot_B) < T(1e-7)) return false;
+  const T u = clipr(-Anorm_dot_T / Anorm_dot_B, T(0), b);
+  const T t = clipr(u * A_dot_B + A_dot_T, T(0), a);
+  const T v = t * A_dot_B - B_dot_T;
+  return (Anorm_dot_B > T(0)) ? (v > (u + T(1e-7))) : (v < (u - T(1e-7)));
+}
+
+// rectDistance: distance between rectangle A = [0,a0]x[0,a1]x{0} and rectangle B with origin Tab,
+// axes = columns 0,1 of Rab, side lengths b0,b1.  The reference enumerates 16 edge pairs as
+// straight-line code; here the same tests are generated from the edge-pair geometry:
+//   A edge: runs along axis ea at coordinate ua*a[oa] on the other axis oa = 1-ea,
+//   B edge: runs along B's axis eb at B-coordinate ub*b[ob], ob = 1-eb,
+// in the reference's order (ea,eb) = (1,1),(1,0),(0,1),(0,0), each with (U,U),(U,L),(L,U),(L,L).
+template <typename T>
+HFCL_HD T rect_distance(const M3<T>& Rab, const V3<T>& Tab, T a0, T a1, T b0, T b1) {
+  const T R[3][3] = {{Rab.r0.x, Rab.r0.y, Rab.r0.z}, {Rab.r1.x, Rab.r1.y, Rab.r1.z}, {Rab.r2.x, Rab.r2.y, Rab.r2.z}};
+  const T av[2] = {a0, a1}, bv[2] = {b0, b1};
+  const V3<T> Tba_v = tmul(Rab, Tab);
+  const T Tabv[3] = {Tab.x, Tab.y, Tab.z}, Tba[3] = {Tba_v.x, Tba_v.y, Tba_v.z};
+#pragma unroll
+  for (int ea = 1; ea >= 0; --ea) {
+    const int oa = 1 - ea;
+#pragma unroll
+    for (int eb = 1; eb >= 0; --eb) {
+      const int ob = 1 - eb;
+      // B-frame coordinate (along B axis ob) of A's corners: (0,0), (a[ea] along ea), (a[oa] along oa)
+      const T A_ll = -Tba[ob];
+      const T A_e = av[ea] * R[ea][ob];  // step along the A edge direction
+      const T A_o = av[oa] * R[oa][ob];  // step to the "upper" A edge
+      // A-frame coordinate (along A axis oa) of B's corners
+      const T B_ll = Tabv[oa];
+      const T B_e = bv[eb] * R[oa][eb];
+      const T B_o = bv[ob] * R[oa][ob];
+#pragma unroll
+      for (int ua = 1; ua >= 0; --ua) {
+#pragma unroll
+        for (int ub = 1; ub >= 0; --ub) {
+          const T ea0 = A_ll + (ua ? A_o : T(0)), ea1 = ea0 + A_e;  // A edge end points in B's ob coordinate
+          const T A_l = hmin(ea0, ea1), A_u = hmax(ea0, ea1);
+          const T eb0 = B_ll + (ub ? B_o : T(0)), eb1 = eb0 + B_e;  // B edge end points in A's oa coordinate
+          const T B_l = hmin(eb0, eb1), B_u = hmax(eb0, eb1);
+          const bool pre1 = ub ? (A_u > bv[ob]) : (A_l < T(0));
+          const bool pre2 = ua ? (B_u > av[oa]) : (B_l < T(0));
+          if (!(pre1 && pre2)) continue;
+          const T pa = ua ? av[oa] : T(0), pb = ub ? bv[ob] : T(0);
+          const T A_dot_B = R[ea][eb];
+          const T A_dot_T = Tabv[ea] + pb * R[ea][ob];  // e_ea . (Pb - Pa)
+          const T B_dot_T = Tba[eb] - pa * R[oa][eb];    // B_eb . (Pb - Pa)
+          const bool skip1 = ub ? (A_l > bv[ob]) : (A_u < T(0));
+          const T sgn_b = ub ? T(1) : T(-1);
+          const bool v1 = skip1 || in_voronoi(bv[eb], av[ea], sgn_b * R[ea][ob], sgn_b * (pa * R[oa][ob] - Tba[ob] - pb),
+                                              A_dot_B, pa * R[oa][eb] - Tba[eb], -Tabv[ea] - pb * R[ea][ob]);
+          if (!v1) continue;
+          const bool skip2 = ua ? (B_l > av[oa]) : (B_u < T(0));
+          const T sgn_a = ua ? T(1) : T(-1);
+          const bool v2 = skip2 || in_voronoi(av[ea], bv[eb], sgn_a * R[oa][eb], sgn_a * (Tabv[oa] + pb * R[oa][ob] - pa),
+                                              A_dot_B, A_dot_T, B_dot_T);
+          if (!v2) continue;
+          T t, u;
+          seg_coords(t, u, av[ea], bv[eb], A_dot_B, A_dot_T, B_dot_T);
+          // S = (Pb + u B_eb) - (Pa + t A_ea)
+          T S[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) S[k] = Tabv[k] + R[k][ob] * pb + R[k][eb] * u;
+          S[oa] -= pa;
+          S[ea] -= t;
+          return hsqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
+        }
+      }
+    }
+  }
+  T sep1, sep2;
+  if (Tabv[2] > T(0)) {
+    sep1 = Tabv[2];
+    if (R[2][0] < T(0)) sep1 += b0 * R[2][0];
+    if (R[2][1] < T(0)) sep1 += b1 * R[2][1];
+  } else {
+    sep1 = -Tabv[2];
+    if (R[2][0] > T(0)) sep1 -= b0 * R[2][0];
+    if (R[2][1] > T(0)) sep1 -= b1 * R[2][1];
+  }
+  if (Tba[2] < T(0)) {
+    sep2 = -Tba[2];
+    if (R[0][2] < T(0)) sep2 += a0 * R[0][2];
+    if (R[1][2] < T(0)) sep2 += a1 * R[1][2];
+  } else {
+    sep2 = Tba[2];
+    if (R[0][2] > T(0)) sep2 -= a0 * R[0][2];
+    if (R[1][2] > T(0)) sep2 -= a1 * R[1][2];
+  }
+  const T sep = sep1 > sep2 ? sep1 : sep2;
+  return sep > T(0) ? sep : T(0);
+}
+
+// distance(R0, T0, b1.rss, b2.rss): lower bound of the distance between the two node volumes
+template <typename T>
+HFCL_HD T rss_lower_bound(const M3<T>& R0, const V3<T>& T0, const DNode<T>& n1, const DRss<T>& r1, const DNode<T>& n2,
+                          const DRss<T>& r2) {
+  const M3<T> R = tmul(n1.axes, mmul(R0, n2.axes));
+  const V3<T> Ttemp = mul(R0, r2.Tr) + T0 - r1.Tr;
+  const V3<T> Tv = tmul(n1.axes, Ttemp);
+  const T d = rect_distance(R, Tv, r1.l0, r1.l1, r2.l0, r2.l1) - (r1.r + r2.r);
+  return d < T(0) ? T(0) : d;
+}
+
+HFCL_HD bool hisnan(float x) { return !(x == x); }
+HFCL_HD bool hisnan(double x) { return !(x == x); }
+
+template <typename T>
+HFCL_HD void seg_points(const V3<T>& P, const V3<T>& A, const V3<T>& Q, const V3<T>& B, V3<T>& VEC, V3<T>& X, V3<T>& Y) {
+  V3<T> Tv = Q - P;
+  const T A_dot_A = dot(A, A), B_dot_B = dot(B, B), A_dot_B = dot(A, B), A_dot_T = dot(A, Tv), B_dot_T = dot(B, Tv);
+  const T denom = A_dot_A * B_dot_B - A_dot_B * A_dot_B;
+  T t = (A_dot_T * B_dot_B - B_dot_T * A_dot_B) / denom;
+  if ((t < T(0)) || hisnan(t))
+    t = T(0);
+  else if (t > T(1))
+    t = T(1);
+  const T u = (t * A_dot_B - B_dot_T) / B_dot_B;
+  if ((u <= T(0)) || hisnan(u)) {
+    Y = Q;
+    t = A_dot_T / A_dot_A;
+    if ((t <= T(0)) || hisnan(t)) {
+      X = P;
+      VEC = Q - P;
+    } else if (t >= T(1)) {
+      X = P + A;
+      VEC = Q - X;
+    } else {
+      X = P + A * t;
+      VEC = cross(A, cross(Tv, A));
+    }
+  } else if (u >= T(1)) {
+    Y = Q + B;
+    t = (A_dot_B + A_dot_T) / A_dot_A;
+    if ((t <= T(0)) || hisnan(t)) {
+      X = P;
+      VEC = Y - P;
+    } else if (t >= T(1)) {
+      X = P + A;
+      VEC = Y - X;
+    } else {
+      X = P + A * t;
+      Tv = Y - P;
+      VEC = cross(A, cross(Tv, A));
+    }
+  } else {
+    Y = Q + B * u;
+    if ((t <= T(0)) || hisnan(t)) {
+      X = P;
+      VEC = cross(B, cross(Tv, B));
+    } else if (t >= T(1)) {
+      X = P + A;
+      Tv = Q - X;
+      VEC = cross(B, cross(Tv, B));
+    } else {
+      X = P + A * t;
+      VEC = cross(A, B);
+      if (dot(VEC, Tv) < T(0)) VEC = -VEC;
+    }
+  }
+}
+
+// sqrTriDistance(S, T, P, Q): squared distance between triangles (0 when they overlap)
+template <typename T>
+HFCL_HD T sqr_tri_distance(const V3<T>& s0, const V3<T>& s1, const V3<T>& s2, const V3<T>& t0, const V3<T>& t1,
+                           const V3<T>& t2, V3<T>& P, V3<T>& Q) {
+  const V3<T> S[3] = {s0, s1, s2}, Tt[3] = {t0, t1, t2};
+  const V3<T> Sv[3] = {s1 - s0, s2 - s1, s0 - s2}, Tv[3] = {t1 - t0, t2 - t1, t0 - t2};
+  V3<T> minP = s0, minQ = t0;
+  bool shown_disjoint = false;
+  T mindd = sqnorm(s0 - t0) + T(1);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      V3<T> VEC;
+      seg_points(S[i], Sv[i], Tt[j], Tv[j], VEC, P, Q);
+      const V3<T> V = Q - P;
+      const T dd = dot(V, V);
+      if (dd <= mindd) {
+        minP = P;
+        minQ = Q;
+        mindd = dd;
+        T a = dot(S[(i + 2) % 3] - P, VEC);
+        T b = dot(Tt[(j + 2) % 3] - Q, VEC);
+        if ((a <= T(0)) && (b >= T(0))) return dd;
+        const T p = dot(V, VEC);
+        if (a < T(0)) a = T(0);
+        if (b > T(0)) b = T(0);
+        if ((p - a + b) > T(0)) shown_disjoint = true;
+      }
+    }
+  }
+  const V3<T> Sn = cross(Sv[0], Sv[1]);
+  const T Snl = dot(Sn, Sn);
+  if (Snl > T(1e-15)) {
+    const T p0 = dot(s0 - t0, Sn), p1 = dot(s0 - t1, Sn), p2 = dot(s0 - t2, Sn);
+    int point = -1;
+    if ((p0 > T(0)) && (p1 > T(0)) && (p2 > T(0))) {
+      point = (p0 < p1) ? 0 : 1;
+      if (p2 < (point == 0 ? p0 : p1)) point = 2;
+    } else if ((p0 < T(0)) && (p1 < T(0)) && (p2 < T(0))) {
+      point = (p0 > p1) ? 0 : 1;
+      if (p2 > (point == 0 ? p0 : p1)) point = 2;
+    }
+    if (point >= 0) {
+      shown_disjoint = true;
+      const V3<T> tp = point == 0 ? t0 : (point == 1 ? t1 : t2);
+      const T pp = point == 0 ? p0 : (point == 1 ? p1 : p2);
+      if (dot(tp - s0, cross(Sn, Sv[0])) > T(0) && dot(tp - s1, cross(Sn, Sv[1])) > T(0) &&
+          dot(tp - s2, cross(Sn, Sv[2])) > T(0)) {
+        P = tp + Sn * (pp / Snl);
+        Q = tp;
+        return sqnorm(P - Q);
+      }
+    }
+  }
+  const V3<T> Tn = cross(Tv[0], Tv[1]);
+  const T Tnl = dot(Tn, Tn);
+  if (Tnl > T(1e-15)) {
+    const T p0 = dot(t0 - s0, Tn), p1 = dot(t0 - s1, Tn), p2 = dot(t0 - s2, Tn);
+    int point = -1;
+    if ((p0 > T(0)) && (p1 > T(0)) && (p2 > T(0))) {
+      point = (p0 < p1) ? 0 : 1;
+      if (p2 < (point == 0 ? p0 : p1)) point = 2;
+    } else if ((p0 < T(0)) && (p1 < T(0)) && (p2 < T(0))) {
+      point = (p0 > p1) ? 0 : 1;
+      if (p2 > (point == 0 ? p0 : p1)) point = 2;
+    }
+    if (point >= 0) {
+      shown_disjoint = true;
+      const V3<T> sp = point == 0 ? s0 : (point == 1 ? s1 : s2);
+      const T pp = point == 0 ? p0 : (point == 1 ? p1 : p2);
+      if (dot(sp - t0, cross(Tn, Tv[0])) > T(0) && dot(sp - t1, cross(Tn, Tv[1])) > T(0) &&
+          dot(sp - t2, cross(Tn, Tv[2])) > T(0)) {
+        P = sp;
+        Q = sp + Tn * (pp / Tnl);
+        return sqnorm(P - Q);
+      }
+    }
+  }
+  if (shown_disjoint) {
+    P = minP;
+    Q = minQ;
+    return mindd;
+  }
+  return T(0);
 }
 
 }  // namespace hfcl

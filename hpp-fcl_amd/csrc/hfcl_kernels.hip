@@ -130,8 +130,9 @@ __device__ __forceinline__ void store_bvh_record(const IO<double>& io, uint32_t 
   r.p2[0] = o.p2.x; r.p2[1] = o.p2.y; r.p2[2] = o.p2.z;
   r.b1 = b1;
   r.b2 = b2;
+  // nc: number of contacts (collide) ; bit 31 set = "distance(): contact flag only, no Contact object"
   r.status = (nc ? 128u : 0u) | (overflow ? 0xC0000000u : 0u);
-  r.num_contacts = int(nc);
+  r.num_contacts = int(nc & 0x7FFFFFFFu);
   io.out[pair] = r;
 }
 __device__ __forceinline__ void store_bvh_record(const IO<float>& io, uint32_t pair, const PairOut<float>& o, uint32_t nc,
@@ -492,6 +493,7 @@ struct DMesh {
 template <typename T>
 struct BvhView {
   const DNode<T>* nodes;
+  const DRss<T>* rss;
   const T* verts;        // xyz
   const uint32_t* tris;  // 3 local vertex ids per triangle
   const DMesh* meshes;
@@ -664,6 +666,112 @@ __global__ void __launch_bounds__(BVH_BLOCK) k_bvh_collide(Work wk, LibView<T> l
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// k_bvh_distance: BVHModel<OBBRSS> x BVHModel<OBBRSS> distance().  distanceRecurse
+// (src/traversal/traversal_recurse.cpp:153-203) flattened: both child pairs get their RSS lower
+// bound, the farther one is pushed first (with its bound), the nearer one on top; a popped entry is
+// skipped when its bound can no longer beat the current minimum (canStop, rel_err = abs_err = 0 as
+// latched by the reference's traversal node, traversal_node_bvhs.h:409-410).  Leaves =
+// sqrTriDistance in model 1's frame; the result is seeded with triangle 0 x triangle 0 (preprocess).
+// ---------------------------------------------------------------------------------------
+constexpr int BVHD_STACK = 64;
+constexpr int BVHD_BLOCK = 64;
+
+template <typename T>
+__global__ void __launch_bounds__(BVHD_BLOCK) k_bvh_distance(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q) {
+  __shared__ uint32_t stack_e[BVHD_STACK][BVHD_BLOCK];
+  __shared__ T stack_d[BVHD_STACK][BVHD_BLOCK];
+  const uint32_t cnt = wk.counts[B_BVH];
+  const int tid = threadIdx.x;
+  const T nanv = Lim<T>::nan();
+  for (uint32_t it = blockIdx.x * blockDim.x + tid; it < cnt; it += gridDim.x * blockDim.x) {
+    const uint32_t pair = wk.lists[size_t(B_BVH) * wk.n + it];
+    const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+    const DMesh m1 = bv.meshes[a.bvh_index], m2 = bv.meshes[b.bvh_index];
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    const M3<T> RT_R = tmul(tf1.R, tf2.R);
+    const V3<T> RT_T = tmul(tf1.R, tf2.t - tf1.t);
+    const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
+    const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
+    T mind = Lim<T>::max();
+    int fb1 = -1, fb2 = -1;
+    V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1;
+    bool overflow = false;
+    auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
+    auto leaf = [&](uint32_t p1i, uint32_t p2i) {
+      const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + p1i);
+      const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + p2i);
+      V3<T> P, Q;
+      const T d2 = sqr_tri_distance(vtx(v1, t1[0]), vtx(v1, t1[1]), vtx(v1, t1[2]), mul(RT_R, vtx(v2, t2[0])) + RT_T,
+                                    mul(RT_R, vtx(v2, t2[1])) + RT_T, mul(RT_R, vtx(v2, t2[2])) + RT_T, P, Q);
+      const T d = hsqrt(d2);
+      if (mind > d) {  // DistanceResult::update
+        mind = d;
+        fb1 = int(p1i);
+        fb2 = int(p2i);
+        np1 = P;
+        np2 = Q;
+      }
+    };
+    leaf(0u, 0u);  // preprocess()
+    int sp = 1;
+    stack_e[0][tid] = 0u;
+    stack_d[0][tid] = T(-1);
+    while (sp > 0) {
+      --sp;
+      const uint32_t e = stack_e[sp][tid];
+      const T de = stack_d[sp][tid];
+      if (de >= T(0) && de >= mind) continue;  // canStop(d)
+      const uint32_t b1 = e & 0xFFFFu, b2 = e >> 16;
+      const DNode<T> n1 = bv.nodes[m1.node_off + b1];
+      const DNode<T> n2 = bv.nodes[m2.node_off + b2];
+      const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
+      if (l1 && l2) {
+        leaf(uint32_t(-(n1.first_child + 1)), uint32_t(-(n2.first_child + 1)));
+        continue;
+      }
+      uint32_t a1, a2, c1, c2;
+      if (l2 || (!l1 && (sqnorm(n1.extent) > sqnorm(n2.extent)))) {
+        a1 = uint32_t(n1.first_child);
+        a2 = b2;
+        c1 = a1 + 1;
+        c2 = b2;
+      } else {
+        a1 = b1;
+        a2 = uint32_t(n2.first_child);
+        c1 = b1;
+        c2 = a2 + 1;
+      }
+      const T d1 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + a1], bv.rss[m1.node_off + a1],
+                                   bv.nodes[m2.node_off + a2], bv.rss[m2.node_off + a2]);
+      const T d2 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + c1], bv.rss[m1.node_off + c1],
+                                   bv.nodes[m2.node_off + c2], bv.rss[m2.node_off + c2]);
+      if (sp + 2 > BVHD_STACK) {
+        overflow = true;
+        break;
+      }
+      const uint32_t ea = a1 | (a2 << 16), ec = c1 | (c2 << 16);
+      const bool c_first = d2 < d1;  // visit (c1,c2) first when it is strictly nearer
+      stack_e[sp][tid] = c_first ? ea : ec;
+      stack_d[sp][tid] = c_first ? d1 : d2;
+      ++sp;
+      stack_e[sp][tid] = c_first ? ec : ea;
+      stack_d[sp][tid] = c_first ? d2 : d1;
+      ++sp;
+    }
+    PairOut<T> o;
+    o.distance = mind;
+    o.normal = mk<T>(nanv, nanv, nanv);  // not set by the reference on this path (traversal_node_bvhs.h:454,465)
+    o.p1 = xform(tf1, np1);              // postprocess(): model-1 frame -> world
+    o.p2 = xform(tf1, np2);
+    o.gjk_status = GJK_DID_NOT_RUN;
+    o.epa_status = EPA_DID_NOT_RUN;
+    o.gjk_iters = o.epa_iters = 0;
+    store_bvh_record(io, pair, o, mind <= T(0) ? 0x80000000u : 0u, fb1, fb2, overflow);
+  }
+}
+
 // =======================================================================================
 // Host side: library object + C ABI
 // =======================================================================================
@@ -720,6 +828,8 @@ struct hfcl_lib {
   bool bvh_dirty = false;
   DNode<double>* d_nodes64 = nullptr;
   DNode<float>* d_nodes32 = nullptr;
+  DRss<double>* d_rss64 = nullptr;
+  DRss<float>* d_rss32 = nullptr;
   double* d_bverts64 = nullptr;
   float* d_bverts32 = nullptr;
   uint32_t* d_btris = nullptr;
@@ -900,6 +1010,8 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_gout);
   hipFree(lib->d_nodes64);
   hipFree(lib->d_nodes32);
+  hipFree(lib->d_rss64);
+  hipFree(lib->d_rss32);
   hipFree(lib->d_bverts64);
   hipFree(lib->d_bverts32);
   hipFree(lib->d_btris);
@@ -990,15 +1102,28 @@ static DNode<T> pack_node(const hfcl_bvh_node& n) {
 static int upload_bvh(hfcl_lib* lib) {
   if (!lib->bvh_dirty) return HFCL_OK;
   hipFree(lib->d_nodes64); hipFree(lib->d_nodes32); hipFree(lib->d_bverts64); hipFree(lib->d_bverts32);
-  hipFree(lib->d_btris); hipFree(lib->d_meshes);
+  hipFree(lib->d_btris); hipFree(lib->d_meshes); hipFree(lib->d_rss64); hipFree(lib->d_rss32);
+  lib->d_rss64 = nullptr; lib->d_rss32 = nullptr;
   lib->d_nodes64 = nullptr; lib->d_nodes32 = nullptr; lib->d_bverts64 = nullptr; lib->d_bverts32 = nullptr;
   lib->d_btris = nullptr; lib->d_meshes = nullptr;
   const size_t nn = lib->h_bvh_nodes.size(), nv = lib->h_bvh_verts.size(), nt = lib->h_bvh_tris.size();
   std::vector<DNode<double>> n64(nn);
   std::vector<DNode<float>> n32(nn);
+  std::vector<DRss<double>> r64(nn);
+  std::vector<DRss<float>> r32(nn);
   for (size_t i = 0; i < nn; ++i) {
-    n64[i] = pack_node<double>(lib->h_bvh_nodes[i]);
-    n32[i] = pack_node<float>(lib->h_bvh_nodes[i]);
+    const hfcl_bvh_node& hn = lib->h_bvh_nodes[i];
+    n64[i] = pack_node<double>(hn);
+    n32[i] = pack_node<float>(hn);
+    r64[i].Tr = mk<double>(hn.rss_Tr[0], hn.rss_Tr[1], hn.rss_Tr[2]);
+    r64[i].l0 = hn.rss_length[0];
+    r64[i].l1 = hn.rss_length[1];
+    r64[i].r = hn.rss_radius;
+    r32[i].Tr = mk<float>(float(hn.rss_Tr[0]), float(hn.rss_Tr[1]), float(hn.rss_Tr[2]));
+    // fp32 image of the RSS must still contain the fp64 one: round the radius up a little
+    r32[i].l0 = float(hn.rss_length[0]);
+    r32[i].l1 = float(hn.rss_length[1]);
+    r32[i].r = float(hn.rss_radius) * (1.0f + 4e-7f) + 1e-7f;
   }
   std::vector<float> v32(nv);
   for (size_t i = 0; i < nv; ++i) v32[i] = float(lib->h_bvh_verts[i]);
@@ -1010,6 +1135,10 @@ static int upload_bvh(hfcl_lib* lib) {
   HIP_TRY(hipMalloc(&lib->d_meshes, lib->h_meshes.size() * sizeof(DMesh)));
   HIP_TRY(hipMemcpy(lib->d_nodes64, n64.data(), nn * sizeof(DNode<double>), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(lib->d_nodes32, n32.data(), nn * sizeof(DNode<float>), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&lib->d_rss64, nn * sizeof(DRss<double>)));
+  HIP_TRY(hipMalloc(&lib->d_rss32, nn * sizeof(DRss<float>)));
+  HIP_TRY(hipMemcpy(lib->d_rss64, r64.data(), nn * sizeof(DRss<double>), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_rss32, r32.data(), nn * sizeof(DRss<float>), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(lib->d_bverts64, lib->h_bvh_verts.data(), nv * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(lib->d_bverts32, v32.data(), nv * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(lib->d_btris, lib->h_bvh_tris.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1146,20 +1275,28 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   else if (w == 8) launch_cvx<T, 8>(lib, wk, lv, io, q, st, ti, cgrid);
   else launch_cvx<T, 4>(lib, wk, lv, io, q, st, ti, cgrid);
 
-  if (!lib->h_meshes.empty() && q.mode == 1) {
+  if (!lib->h_meshes.empty()) {
     rc = upload_bvh(lib);
     if (rc) return rc;
     BvhView<T> bv;
     bv.nodes = std::is_same<T, double>::value ? (const DNode<T>*)lib->d_nodes64 : (const DNode<T>*)lib->d_nodes32;
+    bv.rss = std::is_same<T, double>::value ? (const DRss<T>*)lib->d_rss64 : (const DRss<T>*)lib->d_rss32;
     bv.verts = std::is_same<T, double>::value ? (const T*)lib->d_bverts64 : (const T*)lib->d_bverts32;
     bv.tris = lib->d_btris;
     bv.meshes = lib->d_meshes;
     bv.n_meshes = uint32_t(lib->h_meshes.size());
-    t = timer_slot(lib, ti++, "k_bvh_collide");
-    hipEventRecord(t->e0, st);
-    hipLaunchKernelGGL((k_bvh_collide<T>), dim3(blocks_for(n, BVH_BLOCK)), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q,
-                       lib->bvh_params, T(lib->break_distance * lib->break_distance));
-    hipEventRecord(t->e1, st);
+    if (q.mode == 1) {
+      t = timer_slot(lib, ti++, "k_bvh_collide");
+      hipEventRecord(t->e0, st);
+      hipLaunchKernelGGL((k_bvh_collide<T>), dim3(blocks_for(n, BVH_BLOCK)), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q,
+                         lib->bvh_params, T(lib->break_distance * lib->break_distance));
+      hipEventRecord(t->e1, st);
+    } else {
+      t = timer_slot(lib, ti++, "k_bvh_distance");
+      hipEventRecord(t->e0, st);
+      hipLaunchKernelGGL((k_bvh_distance<T>), dim3(blocks_for(n, BVHD_BLOCK)), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q);
+      hipEventRecord(t->e1, st);
+    }
   }
 
   t = timer_slot(lib, ti++, "k_unsupported");
@@ -1381,9 +1518,9 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
               std::to_string(lib->h_counts[B_UNSUPPORTED]) + " pairs; their records carry status bit 31)");
     return HFCL_ERR_UNSUPPORTED_PAIR;
   }
-  if (!skipped && lib->h_counts[B_BVH] > 0 && !creq) {
-    set_error("distance() between BVHModel<OBBRSS> pairs is not built yet (collide() is)");
-    return HFCL_ERR_UNSUPPORTED_PAIR;
+  if (!skipped && lib->h_counts[B_BVH] > 0 && lib->h_meshes.empty()) {
+    set_error("BVH shapes in the batch but no BVHModel registered (hfcl_lib_add_bvh)");
+    return HFCL_ERR_INVALID_ARGUMENT;
   }
   return HFCL_OK;
 }

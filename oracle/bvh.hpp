@@ -35,3 +35,17 @@ bool obb_overlap(const M3& R0, const V3& T0, const hfcl_bvh_node& b1, const hfcl
                  double break_distance, double& sqrDistLowerBound);
 
 }  // namespace orc
+
+namespace orc {
+// ---- BVHModel<OBBRSS> distance() ------------------------------------------------------------
+//   rectDistance / segCoords / inVoronoi   src/BV/RSS.cpp:49-713
+//   distance(R0,T0,rss1,rss2)              src/BV/RSS.cpp:995-1005 (OBBRSS forwards to RSS, OBBRSS.h:151-154)
+//   segPoints / sqrTriDistance             src/intersect.cpp:60-384
+//   distanceRecurse                        src/traversal/traversal_recurse.cpp:153-203
+//   MeshDistanceTraversalNode<OBBRSS,0>    include/hpp/fcl/internal/traversal_node_bvhs.h:386-531
+double rect_distance(const M3& Rab, const V3& Tab, const double a[2], const double b[2]);
+double rss_distance(const M3& R0, const V3& T0, const hfcl_bvh_node& b1, const hfcl_bvh_node& b2);
+double sqr_tri_distance(const V3 S[3], const V3 T[3], V3& P, V3& Q);
+int bvh_distance_pair(const MeshView& m1, const Tf& tf1, const MeshView& m2, const Tf& tf2, hfcl_result& out,
+                      BvhStats* stats);
+}  // namespace orc

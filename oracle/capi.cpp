@@ -193,4 +193,51 @@ int orc_bvh_collide_batch(const hfcl_bvh_node* nodes, const double* verts, const
   return err;
 }
 
+// BVHModel<OBBRSS> x BVHModel<OBBRSS> distance(); same mesh table as orc_bvh_collide_batch.
+int orc_bvh_distance_batch(const hfcl_bvh_node* nodes, const double* verts, const uint32_t* tris,
+                           const uint64_t* mesh_table, size_t n_meshes, const uint32_t* m1, const uint32_t* m2,
+                           const double* tf1, const double* tf2, size_t n, hfcl_result* out, uint32_t* out_stats,
+                           int n_threads) {
+  std::vector<MeshView> meshes(n_meshes);
+  for (size_t i = 0; i < n_meshes; ++i) {
+    meshes[i].nodes = nodes + mesh_table[4 * i];
+    meshes[i].n_nodes = mesh_table[4 * i + 1];
+    meshes[i].verts = verts + 3 * mesh_table[4 * i + 2];
+    meshes[i].tris = tris + 3 * mesh_table[4 * i + 3];
+  }
+  parallel_for(n, n_threads, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      BvhStats st;
+      bvh_distance_pair(meshes[m1[i]], tf_from_abi(tf1 + 12 * i), meshes[m2[i]], tf_from_abi(tf2 + 12 * i), out[i], &st);
+      if (out_stats) {
+        out_stats[2 * i] = st.num_bv_tests;
+        out_stats[2 * i + 1] = st.num_leaf_tests;
+      }
+    }
+  });
+  return 0;
+}
+
+// rectDistance on raw inputs (unit tests): Rab row-major 9, Tab 3, a 2, b 2
+double orc_rect_distance(const double* Rab, const double* Tab, const double* a, const double* b) {
+  M3 R;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R.m[i][j] = Rab[3 * i + j];
+  return rect_distance(R, V3(Tab[0], Tab[1], Tab[2]), a, b);
+}
+// sqrTriDistance on raw inputs: S, T = 3x3 each; out = P(3), Q(3); returns d^2
+double orc_sqr_tri_distance(const double* S, const double* T, double* out) {
+  V3 s[3], t[3], P, Q;
+  for (int k = 0; k < 3; ++k) {
+    s[k] = V3(S[3 * k], S[3 * k + 1], S[3 * k + 2]);
+    t[k] = V3(T[3 * k], T[3 * k + 1], T[3 * k + 2]);
+  }
+  const double d2 = sqr_tri_distance(s, t, P, Q);
+  for (int k = 0; k < 3; ++k) {
+    out[k] = P[k];
+    out[3 + k] = Q[k];
+  }
+  return d2;
+}
+
 }  // extern "C"

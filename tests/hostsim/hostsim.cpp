@@ -265,7 +265,99 @@ static void bvh_pair(const std::vector<DNode<T>>& nodes, const std::vector<T>& v
   r.num_contacts = int(nc);
 }
 
+// BVHModel<OBBRSS> distance(): distanceRecurse order (nearer child first, prune on the RSS bound)
+template <typename T>
+static void bvh_distance_pair(const std::vector<DNode<T>>& nodes, const std::vector<DRss<T>>& rss, const std::vector<T>& verts,
+                              const uint32_t* tris, const uint64_t* m1, const uint64_t* m2, const Pose<T>& tf1,
+                              const Pose<T>& tf2, hfcl_result& r) {
+  const M3<T> RT_R = tmul(tf1.R, tf2.R);
+  const V3<T> RT_T = tmul(tf1.R, tf2.t - tf1.t);
+  T mind = Lim<T>::max();
+  int fb1 = -1, fb2 = -1;
+  const T nanv = Lim<T>::nan();
+  V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1;
+  auto vtx = [&](uint64_t off, uint32_t i) { return mk<T>(verts[3 * (off + i)], verts[3 * (off + i) + 1], verts[3 * (off + i) + 2]); };
+  auto leaf = [&](uint32_t p1i, uint32_t p2i) {
+    const uint32_t* t1 = tris + 3 * (m1[3] + p1i);
+    const uint32_t* t2 = tris + 3 * (m2[3] + p2i);
+    V3<T> P, Q;
+    const T d2 = sqr_tri_distance(vtx(m1[2], t1[0]), vtx(m1[2], t1[1]), vtx(m1[2], t1[2]),
+                                  mul(RT_R, vtx(m2[2], t2[0])) + RT_T, mul(RT_R, vtx(m2[2], t2[1])) + RT_T,
+                                  mul(RT_R, vtx(m2[2], t2[2])) + RT_T, P, Q);
+    const T d = hsqrt(d2);
+    if (mind > d) { mind = d; fb1 = int(p1i); fb2 = int(p2i); np1 = P; np2 = Q; }
+  };
+  leaf(0, 0);
+  struct E { uint32_t b1, b2; T d; };
+  std::vector<E> stack;
+  stack.push_back({0, 0, T(-1)});
+  while (!stack.empty()) {
+    const E e = stack.back();
+    stack.pop_back();
+    if (e.d >= T(0) && e.d >= mind) continue;  // canStop(d) evaluated when the child is about to be visited
+    const DNode<T>& n1 = nodes[m1[0] + e.b1];
+    const DNode<T>& n2 = nodes[m2[0] + e.b2];
+    const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
+    if (l1 && l2) { leaf(uint32_t(-(n1.first_child + 1)), uint32_t(-(n2.first_child + 1))); continue; }
+    uint32_t a1, a2, c1, c2;
+    if (l2 || (!l1 && (sqnorm(n1.extent) > sqnorm(n2.extent)))) { a1 = uint32_t(n1.first_child); a2 = e.b2; c1 = a1 + 1; c2 = e.b2; }
+    else { a1 = e.b1; a2 = uint32_t(n2.first_child); c1 = e.b1; c2 = a2 + 1; }
+    const T d1 = rss_lower_bound(RT_R, RT_T, nodes[m1[0] + a1], rss[m1[0] + a1], nodes[m2[0] + a2], rss[m2[0] + a2]);
+    const T d2 = rss_lower_bound(RT_R, RT_T, nodes[m1[0] + c1], rss[m1[0] + c1], nodes[m2[0] + c2], rss[m2[0] + c2]);
+    if (d2 < d1) { stack.push_back({a1, a2, d1}); stack.push_back({c1, c2, d2}); }
+    else { stack.push_back({c1, c2, d2}); stack.push_back({a1, a2, d1}); }
+  }
+  const V3<T> w1 = xform(tf1, np1), w2 = xform(tf1, np2);
+  r.distance = mind;
+  r.normal[0] = r.normal[1] = r.normal[2] = nanv;
+  r.p1[0] = w1.x; r.p1[1] = w1.y; r.p1[2] = w1.z;
+  r.p2[0] = w2.x; r.p2[1] = w2.y; r.p2[2] = w2.z;
+  r.b1 = fb1; r.b2 = fb2;
+  r.status = (mind <= T(0)) ? 128u : 0u;
+  r.num_contacts = 0;
+}
+
 extern "C" {
+
+double sim_rect_distance(const double* Rab, const double* Tab, const double* a, const double* b) {
+  M3<double> R;
+  R.r0 = mk<double>(Rab[0], Rab[1], Rab[2]);
+  R.r1 = mk<double>(Rab[3], Rab[4], Rab[5]);
+  R.r2 = mk<double>(Rab[6], Rab[7], Rab[8]);
+  return rect_distance(R, mk<double>(Tab[0], Tab[1], Tab[2]), a[0], a[1], b[0], b[1]);
+}
+double sim_sqr_tri_distance(const double* S, const double* T, double* out) {
+  V3<double> P, Q;
+  const double d2 = sqr_tri_distance(mk<double>(S[0], S[1], S[2]), mk<double>(S[3], S[4], S[5]), mk<double>(S[6], S[7], S[8]),
+                                     mk<double>(T[0], T[1], T[2]), mk<double>(T[3], T[4], T[5]), mk<double>(T[6], T[7], T[8]), P, Q);
+  out[0] = P.x; out[1] = P.y; out[2] = P.z; out[3] = Q.x; out[4] = Q.y; out[5] = Q.z;
+  return d2;
+}
+
+int sim_bvh_distance_f64(const hfcl_bvh_node* nodes, size_t n_nodes, const double* verts, size_t n_verts,
+                         const uint32_t* tris, const uint64_t* mesh_table, const uint32_t* m1, const uint32_t* m2,
+                         const double* tf1, const double* tf2, size_t n, hfcl_result* out) {
+  std::vector<DNode<double>> dn(n_nodes);
+  std::vector<DRss<double>> dr(n_nodes);
+  for (size_t i = 0; i < n_nodes; ++i) {
+    const double* a = nodes[i].obb_axes;
+    dn[i].first_child = nodes[i].first_child;
+    dn[i].axes.r0 = mk<double>(a[0], a[3], a[6]);
+    dn[i].axes.r1 = mk<double>(a[1], a[4], a[7]);
+    dn[i].axes.r2 = mk<double>(a[2], a[5], a[8]);
+    dn[i].To = mk<double>(nodes[i].obb_To[0], nodes[i].obb_To[1], nodes[i].obb_To[2]);
+    dn[i].extent = mk<double>(nodes[i].obb_extent[0], nodes[i].obb_extent[1], nodes[i].obb_extent[2]);
+    dr[i].Tr = mk<double>(nodes[i].rss_Tr[0], nodes[i].rss_Tr[1], nodes[i].rss_Tr[2]);
+    dr[i].l0 = nodes[i].rss_length[0];
+    dr[i].l1 = nodes[i].rss_length[1];
+    dr[i].r = nodes[i].rss_radius;
+  }
+  std::vector<double> v(verts, verts + 3 * n_verts);
+  for (size_t i = 0; i < n; ++i)
+    bvh_distance_pair<double>(dn, dr, v, tris, mesh_table + 4 * m1[i], mesh_table + 4 * m2[i], pose_from_abi<double>(tf1 + 12 * i),
+                              pose_from_abi<double>(tf2 + 12 * i), out[i]);
+  return 0;
+}
 
 int sim_bvh_collide_f64(const hfcl_bvh_node* nodes, size_t n_nodes, const double* verts, size_t n_verts,
                         const uint32_t* tris, const uint64_t* mesh_table, const uint32_t* m1, const uint32_t* m2,

@@ -69,3 +69,36 @@ def bvh_collide_f64(abi, meshlib, m1, m2, tf1, tf2, req, max_contacts=0):
     if max_contacts:
         return out, contacts[:min(nc.value, max_contacts)]
     return out
+
+
+def bvh_distance_f64(abi, meshlib, m1, m2, tf1, tf2):
+    m1 = np.ascontiguousarray(m1, dtype=np.uint32)
+    m2 = np.ascontiguousarray(m2, dtype=np.uint32)
+    tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
+    tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
+    n = len(m1)
+    out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    nodes = np.ascontiguousarray(meshlib.nodes)
+    lib().sim_bvh_distance_f64(abi.ptr(nodes), C.c_size_t(len(nodes)), abi.ptr(meshlib.verts),
+                               C.c_size_t(len(meshlib.verts)), abi.ptr(meshlib.tris), abi.ptr(meshlib.table),
+                               abi.ptr(m1), abi.ptr(m2), abi.ptr(tf1), abi.ptr(tf2), C.c_size_t(n), abi.ptr(out))
+    return out
+
+
+def rect_distance(abi, Rab, Tab, a, b):
+    L = lib()
+    L.sim_rect_distance.restype = C.c_double
+    R = np.ascontiguousarray(Rab, dtype=np.float64)
+    T = np.ascontiguousarray(Tab, dtype=np.float64)
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return L.sim_rect_distance(abi.ptr(R), abi.ptr(T), abi.ptr(a), abi.ptr(b))
+
+
+def sqr_tri_distance(abi, S, T):
+    L = lib()
+    L.sim_sqr_tri_distance.restype = C.c_double
+    S = np.ascontiguousarray(S, dtype=np.float64)
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    out = np.zeros(6)
+    return L.sim_sqr_tri_distance(abi.ptr(S), abi.ptr(T), abi.ptr(out)), out[:3].copy(), out[3:].copy()

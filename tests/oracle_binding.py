@@ -153,3 +153,42 @@ def bvh_collide_batch(meshlib, m1, m2, tf1, tf2, req=None, max_contacts=0, n_thr
     if want_stats:
         res.append(stats)
     return res[0] if len(res) == 1 else tuple(res)
+
+
+def bvh_distance_batch(meshlib, m1, m2, tf1, tf2, n_threads=1, want_stats=False):
+    """BVHModel<OBBRSS> x BVHModel<OBBRSS> distance() through the oracle."""
+    abi = _pkg().abi
+    m1 = np.ascontiguousarray(m1, dtype=np.uint32)
+    m2 = np.ascontiguousarray(m2, dtype=np.uint32)
+    tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
+    tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
+    n = len(m1)
+    out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    stats = np.zeros((n, 2), dtype=np.uint32)
+    nodes = np.ascontiguousarray(meshlib.nodes)
+    lib().orc_bvh_distance_batch(abi.ptr(nodes), abi.ptr(meshlib.verts), abi.ptr(meshlib.tris), abi.ptr(meshlib.table),
+                                 C.c_size_t(len(meshlib.table)), abi.ptr(m1), abi.ptr(m2), abi.ptr(tf1), abi.ptr(tf2),
+                                 C.c_size_t(n), abi.ptr(out), abi.ptr(stats), C.c_int(n_threads))
+    return (out, stats) if want_stats else out
+
+
+def rect_distance(Rab, Tab, a, b):
+    abi = _pkg().abi
+    L = lib()
+    L.orc_rect_distance.restype = C.c_double
+    R = np.ascontiguousarray(Rab, dtype=np.float64)
+    T = np.ascontiguousarray(Tab, dtype=np.float64)
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return L.orc_rect_distance(abi.ptr(R), abi.ptr(T), abi.ptr(a), abi.ptr(b))
+
+
+def sqr_tri_distance(S, T):
+    abi = _pkg().abi
+    L = lib()
+    L.orc_sqr_tri_distance.restype = C.c_double
+    S = np.ascontiguousarray(S, dtype=np.float64)
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    out = np.zeros(6)
+    d2 = L.orc_sqr_tri_distance(abi.ptr(S), abi.ptr(T), abi.ptr(out))
+    return d2, out[:3].copy(), out[3:].copy()

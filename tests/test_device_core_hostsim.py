@@ -196,3 +196,68 @@ def test_bvh_device_code_matches_oracle(pkg, oracle, hostsim, small_meshes, nmax
     assert len(cref) == len(cgot)
     assert np.array_equal(cref["pair"], cgot["pair"]) and np.array_equal(cref["b1"], cgot["b1"])
     assert np.allclose(cref["penetration_depth"], cgot["penetration_depth"], atol=1e-12)
+
+
+def test_rect_distance_two_formulations_and_brute_force(pkg, oracle, hostsim):
+    """rectDistance (RSS.cpp:121-713): the oracle's block-by-block transcription, the device's
+    edge-pair-parametric formulation and a bounded QP agree."""
+    from scipy.optimize import minimize
+    g, abi = pkg.geometry, pkg.abi
+    rng = np.random.default_rng(3)
+    for k in range(3000):
+        q = rng.normal(size=4)
+        R = g.quat_to_matrix(q / np.linalg.norm(q))
+        T, a, b = rng.uniform(-3, 3, 3), rng.uniform(0.05, 1.5, 2), rng.uniform(0.05, 1.5, 2)
+        d_or = oracle.rect_distance(R, T, a, b)
+        assert abs(d_or - hostsim.rect_distance(abi, R, T, a, b)) < 1e-12
+        if k < 60:
+            def f(x):
+                d = T + R[:, 0] * x[2] + R[:, 1] * x[3] - np.array([x[0], x[1], 0.0])
+                return d @ d
+            best = min(minimize(f, x0, bounds=[(0, a[0]), (0, a[1]), (0, b[0]), (0, b[1])], method="L-BFGS-B",
+                                options=dict(ftol=1e-15, gtol=1e-12)).fun
+                       for x0 in [(0, 0, 0, 0), (a[0], a[1], b[0], b[1]), (a[0] / 2, a[1] / 2, b[0] / 2, b[1] / 2)])
+            assert d_or <= np.sqrt(best) + 1e-6  # a valid lower bound (exact in practice)
+            assert abs(d_or - np.sqrt(best)) < 1e-4
+
+
+def test_sqr_tri_distance_vs_gjk(pkg, oracle, hostsim):
+    """sqrTriDistance (intersect.cpp:156-368) against the (independently pinned) GJK triangle distance."""
+    g, abi = pkg.geometry, pkg.abi
+    rng = np.random.default_rng(4)
+    n = 1500
+    S = rng.uniform(-1, 1, (n, 3, 3))
+    T = rng.uniform(-1, 1, (n, 3, 3)) + rng.uniform(-1.5, 1.5, (n, 1, 3))
+    L = g.ShapeLibrary()
+    for i in range(n):
+        L.add_triangle(*S[i])
+    for i in range(n):
+        L.add_triangle(*T[i])
+    I = np.tile(g.make_pose(), (n, 1))
+    r = oracle.distance_batch(L.shapes_array(), L.vertices_array(), np.arange(n), n + np.arange(n), I, I)
+    for i in range(n):
+        d2, P, Q = oracle.sqr_tri_distance(S[i], T[i])
+        d2s, Ps, Qs = hostsim.sqr_tri_distance(abi, S[i], T[i])
+        assert d2 == d2s
+        if abi.status_gjk(r["status"][i]) == abi.GJK_Collision:
+            assert d2 < 1e-10
+        else:
+            assert abs(np.sqrt(d2) - r["distance"][i]) < 1e-9
+            assert np.allclose(P, Ps, atol=1e-12) and np.allclose(Q, Qs, atol=1e-12)
+
+
+def test_bvh_distance_device_code_matches_oracle_and_brute_force(pkg, oracle, hostsim, small_meshes):
+    abi, g = pkg.abi, pkg.geometry
+    i1, i2, tf1, tf2 = _mesh_queries(pkg, 600, 5, hw=2.5)
+    ref = oracle.bvh_distance_batch(small_meshes, i1, i2, tf1, tf2)
+    got = hostsim.bvh_distance_f64(abi, small_meshes, i1, i2, tf1, tf2)
+    assert 0.05 < (ref["distance"] == 0).mean() < 0.6
+    assert np.abs(ref["distance"] - got["distance"]).max() < 1e-12
+    assert np.array_equal(ref["b1"], got["b1"]) and np.array_equal(ref["b2"], got["b2"])
+    assert np.nanmax(np.abs(ref["p1"] - got["p1"])) < 1e-12 and np.isnan(got["normal"]).all()
+    for k in range(4):  # all triangle pairs
+        A, B = small_meshes.meshes[i1[k]], small_meshes.meshes[i2[k]]
+        VA = A.vertices @ g.pose_R(tf1[k]).T + g.pose_T(tf1[k])
+        VB = B.vertices @ g.pose_R(tf2[k]).T + g.pose_T(tf2[k])
+        best = min(oracle.sqr_tri_distance(VA[ta], VB[tb])[0] for ta in A.triangles[::1] for tb in B.triangles[::1])
+        assert abs(np.sqrt(best) - ref["distance"][k]) < 1e-9

@@ -278,12 +278,29 @@ def test_bvh_security_margin_and_mixed_batch(pkg, oracle):
     req0 = wl.make_request(b, abi)
     got0, ref0, _ = _run_bvh(pkg, oracle, b, req0)
     assert (got["num_contacts"] > 0).sum() >= (got0["num_contacts"] > 0).sum()
-    # distance() on mesh pairs is reported as unsupported, not silently mis-answered
+
+
+@pytest.mark.parametrize("seg,n,hw", [(12, 20000, 2.5), (50, 3000, 2.2)])
+def test_bvh_distance(pkg, oracle, seg, n, hw):
+    """BVHModel<OBBRSS> distance(): min distance, nearest triangle ids and nearest points vs the oracle."""
+    abi, wl, bb = pkg.abi, pkg.workloads, pkg.bvh_builder
+    b = wl.cfg4_mesh_mesh(n=n, seg=seg, ring=seg, n_variants=4, half_width=hw)
+    ML = bb.MeshLibrary(b.meshes)
     lib = wl.make_library(pkg, b)
-    with pytest.raises(pkg.EngineError) as e:
-        lib.distance(b.s1[:10], b.s2[:10], b.tf1[:10], b.tf2[:10])
-    assert e.value.code == abi.ERR_UNSUPPORTED_PAIR
+    got = lib.distance(b.s1, b.s2, b.tf1, b.tf2)
     lib.close()
+    ref = oracle.bvh_distance_batch(ML, b.s1, b.s2, b.tf1, b.tf2, n_threads=8)
+    assert not np.any((got["status"] >> 30) & 1), "traversal stack overflow"
+    assert np.abs(got["distance"] - ref["distance"]).max() < 1e-9
+    pos = ref["distance"] > 1e-9
+    same = (got["b1"] == ref["b1"]) & (got["b2"] == ref["b2"])
+    assert same[pos].mean() > 0.999  # ties between equidistant triangle pairs may resolve differently (FMA)
+    m = pos & same
+    assert np.abs(got["p1"][m] - ref["p1"][m]).max() < 1e-7 and np.abs(got["p2"][m] - ref["p2"][m]).max() < 1e-7
+    assert np.isnan(got["normal"]).all()
+    assert 0.05 < (ref["distance"] == 0).mean() < 0.9
+    # |p2 - p1| = d for separated meshes
+    assert np.abs(np.linalg.norm(got["p2"][pos] - got["p1"][pos], axis=1) - got["distance"][pos]).max() < 1e-7
 
 
 def test_cpp_shim_runs_reference_style_tests(pkg):
