@@ -28,6 +28,17 @@
 
 using namespace hfcl;
 
+// minimum waves per SIMD the register allocator must allow for (A/B-tuned, see profiles/)
+#ifndef HFCL_WPE_GJK
+#define HFCL_WPE_GJK 3
+#endif
+#ifndef HFCL_WPE_EPA
+#define HFCL_WPE_EPA 2
+#endif
+#ifndef HFCL_WPE_PRIM
+#define HFCL_WPE_PRIM 2
+#endif
+
 // ---------------------------------------------------------------------------------------
 // bucket ids (finer than hfcl_shapes.hpp's pair_class: the convex bucket is split by which
 // side carries vertices so the kernel is specialised at compile time)
@@ -282,7 +293,7 @@ __device__ __forceinline__ void finish_gjk(const Gjk<T, PW0<T>>& g, const Work& 
 // k_gjk_prim: primitive x primitive GJK, one pair per lane.
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) k_gjk_prim(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_PRIM, 8))) k_gjk_prim(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   const uint32_t cnt = wk.counts[B_PRIM];
   for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
     const uint32_t pair = wk.lists[size_t(B_PRIM) * wk.n + it];
@@ -375,7 +386,7 @@ struct CvxSupport {
 };
 
 template <typename T, int W, int M>
-__global__ void __launch_bounds__(256) k_gjk_cvx(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_GJK, 8))) k_gjk_cvx(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   constexpr int BUCKET = (M == 0) ? B_CC : (M == 1 ? B_PC : B_CP);
   const uint32_t cnt = wk.counts[BUCKET];
   const int lig = threadIdx.x & (W - 1);
@@ -447,7 +458,7 @@ struct EpaSupport {  // any pair kind, evaluated by one lane group
 
 // TIER: 1 reads queue 1 and may push to queue 2; 2 reads queue 2 (never overflows: CAP = 64)
 template <typename T, int WE, int CAP, int TIER>
-__global__ void __launch_bounds__(64) k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_EPA, 8))) k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   constexpr int G = 64 / WE;
   __shared__ EpaScratch<T, CAP> scratch[G];
   const uint32_t cnt = wk.counts[TIER == 1 ? B_COUNT : B_COUNT + 1];
