@@ -54,6 +54,29 @@ def parse():
     return ap.parse_args()
 
 
+def load_traffic(workload, dominant, n):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass
+    (tools/measure_traffic.py -> profiles/traffic_<workload>.json; FETCH_SIZE / WRITE_SIZE in KB).
+    gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-B requests at
+    64 B, exact x2 for wide streaming reads and uncalibrated otherwise -> we report
+    2 x FETCH + WRITE (upper bound) and keep the raw figures in the note."""
+    import re
+    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    if not os.path.exists(path):
+        return None, "no PMC pass committed for this workload"
+    t = json.load(open(path))
+    if t.get("pairs") not in (None, n):
+        return None, "PMC pass was taken at a different batch size"
+    m = re.match(r"(k_\w+)(?:<(\w+)>)?", dominant)
+    base, tag = m.group(1), m.group(2)
+    sel = {"fast": ", 1>(", "full": ", 2>(", "cc": ", 0>(", "pc": ", 1>(", "cp": ", 2>("}.get(tag, "")
+    for name, v in t["kernels"].items():
+        if base in name and sel in name and "FETCH_SIZE_KB_per_dispatch" in v and "WRITE_SIZE_KB_per_dispatch" in v:
+            f, w = v["FETCH_SIZE_KB_per_dispatch"] * 1024, v["WRITE_SIZE_KB_per_dispatch"] * 1024
+            return 2 * f + w, "PMC per launch: FETCH_SIZE raw %.3g B (x2 gfx950 correction applied), WRITE_SIZE %.3g B; %s" % (f, w, os.path.relpath(path, ROOT))
+    return None, "kernel not found in " + os.path.relpath(path, ROOT)
+
+
 def main():
     args = parse()
     import torch
@@ -196,9 +219,10 @@ def main():
         dom_ms = avg.get(dominant, float("nan"))
         achieved = (units * bpq) / (dom_ms * 1e-3) / 1e9 if dom_ms == dom_ms and dom_ms > 0 else None
         pipeline_ms = float(sum(avg.values()))
+        traffic, traffic_note = load_traffic(args.workload, dominant, n)
         roofline = {
             "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_note": traffic_note,
             "bytes_per_query": bpq, "units_per_launch": units, "kernel_ms": dom_ms,
             "pipeline_ms": pipeline_ms, "pipeline_achieved": (n * bpq) / (pipeline_ms * 1e-3) / 1e9 if pipeline_ms else None,
             "kernels_ms": avg,

@@ -1,26 +1,17 @@
-"""Host-side construction of BVHModel<OBBRSS> inputs (plumbing; numpy only).
+"""BVHModel<OBBRSS> inputs on the host (plumbing; the construction itself is native:
+csrc/hfcl_bvh_build.cpp behind `hfcl_bvh_build`).
 
 The device traverses node arrays in the reference's encoding (include/hpp/fcl/BV/BV_node.h:52-101:
 `first_child > 0`: children at first_child, first_child+1; `< 0`: leaf, primitive = -(first_child+1);
-node 0 = root; 2*T-1 nodes).  This module produces such arrays:
+node 0 = root; 2*T-1 nodes).  This module offers
 
-  * `uv_sphere(seg, ring, r)`            generateBVHModel(Sphere), shape/geometric_shape_to_BVH_model.h:92-150
-  * `build_obbrss(vertices, triangles)`  the recipe of BVHModel::recursiveBuildTree
-    (src/BVH/BVH_model.cpp:892-960): fit (covariance of the triangle vertices
-    src/BVH/BVH_utility.cpp:183-259 -> eigenvectors -> axes ordered max/mid/cross
-    src/BVH/BV_fitter.cpp:50-76 -> OBB centre/extent from min/max projections
-    src/BVH/BVH_utility.cpp:529-575), mean split along OBB axis 0
-    (src/BVH/BV_splitter.cpp:81-118,276-279), children allocated adjacently.
-
-Differences from the reference builder (it is a "next" row): the eigen-decomposition
-is LAPACK's (numpy.linalg.eigh) instead of the 50-sweep Jacobi of internal/tools.h:103-202, so axis
-signs -- and with them left/right child order -- can differ from hpp-fcl's trees; the RSS part of
-each node is a valid but looser fit (rectangle = OBB mid-plane, radius = OBB half-thickness) than
-the reference's PQP-style fit (BVH_utility.cpp:264-482).  Any tree produced here is a legal input;
-oracle and device traverse the same arrays."""
+  * `uv_sphere(seg, ring, r)`   generateBVHModel(Sphere), shape/geometric_shape_to_BVH_model.h:92-150
+  * `bumpy_sphere(...)`         cfg4's synthetic non-convex mesh
+  * `load_obj(path)`            the OBJ subset the reference's tests read (test/utility.cpp:98-162)
+  * `Mesh`, `MeshLibrary`       node / vertex / triangle buffers + the offset table of a mesh set."""
 import numpy as np
 
-from . import abi
+from . import abi, engine
 
 
 def uv_sphere(seg=50, ring=50, r=1.0):
@@ -60,75 +51,38 @@ def bumpy_sphere(seg=50, ring=50, r=1.0, amp=0.15, freq=3, phase=0.0):
     return v * (r * bump)[:, None], t
 
 
-def _fit(verts, tris, idx):
-    """BVFitter<OBBRSS>::fit (BV_fitter.cpp:501-531) for the triangles `idx`."""
-    P = verts[tris[idx].reshape(-1)]  # every triangle contributes its 3 vertices
-    n_points = len(P)
-    S1 = P.sum(axis=0)
-    S2 = P.T @ P
-    M = S2 - np.outer(S1, S1) / n_points
-    w, V = np.linalg.eigh(M)  # ascending
-    # axisFromEigen: col0 = largest, col1 = middle, col2 = col0 x col1
-    a0, a1 = V[:, 2], V[:, 1]
-    a2 = np.cross(a0, a1)
-    axes = np.stack([a0, a1, a2], axis=1)
-    proj = P @ axes
-    mx, mn = proj.max(axis=0), proj.min(axis=0)
-    center = axes @ ((mx + mn) / 2)
-    extent = (mx - mn) / 2
-    return axes, center, extent
+def load_obj(path):
+    """Vertices / triangles of a Wavefront OBJ, with the reference reader's behaviour
+    (test/utility.cpp:98-162): faces are fanned around their first vertex; when the file has
+    neither `vn` nor `vt` records every fan triangle repeats the first three indices (:139-143)."""
+    pts, tris = [], []
+    has_normal = has_texture = False
+    with open(path, "rb") as f:
+        for raw in f:
+            tok = raw.decode("latin-1").split()
+            if not tok or tok[0].startswith("#"):
+                continue
+            if tok[0][0] == "v":
+                if tok[0][1:2] == "n":
+                    has_normal = True
+                elif tok[0][1:2] == "t":
+                    has_texture = True
+                else:
+                    pts.append((float(tok[1]), float(tok[2]), float(tok[3])))
+            elif tok[0][0] == "f":
+                data = tok[1:]
+                vid = lambda s: int(s.split("/")[0]) - 1  # atoi stops at '/'
+                for t in range(len(data) - 2):
+                    if not has_texture and not has_normal:
+                        tris.append((vid(data[0]), vid(data[1]), vid(data[2])))
+                    else:
+                        tris.append((vid(data[0]), vid(data[t + 1]), vid(data[t + 2])))
+    return np.array(pts, dtype=np.float64).reshape(-1, 3), np.array(tris, dtype=np.uint32).reshape(-1, 3)
 
 
-def build_obbrss(vertices, triangles):
-    """-> (nodes[BVH_NODE_DTYPE], primitive_indices).  Node numbering as recursiveBuildTree."""
-    verts = np.ascontiguousarray(vertices, dtype=np.float64)
-    tris = np.ascontiguousarray(triangles, dtype=np.int64)
-    nt = len(tris)
-    nodes = np.zeros(2 * nt - 1, dtype=abi.BVH_NODE_DTYPE)
-    prim = np.arange(nt, dtype=np.int64)
-    centroids = verts[tris].mean(axis=1)
-    vsum = verts[tris].sum(axis=1)  # p1+p2+p3 per triangle
-    num_bvs = 1
-    # explicit stack, left subtree built before right one (same node numbering as the recursion)
-    stack = [(0, 0, nt)]
-    while stack:
-        bv_id, first, num = stack.pop()
-        idx = prim[first:first + num]
-        axes, center, extent = _fit(verts, tris, idx)
-        nd = nodes[bv_id]
-        nd["first_primitive"] = first
-        nd["num_primitives"] = num
-        nd["obb_axes"] = axes.T.reshape(-1)  # column-major
-        nd["obb_To"] = center
-        nd["obb_extent"] = extent
-        nd["rss_axes"] = axes.T.reshape(-1)
-        nd["rss_Tr"] = center - axes[:, 0] * extent[0] - axes[:, 1] * extent[1]
-        nd["rss_length"] = (2 * extent[0], 2 * extent[1])
-        nd["rss_radius"] = extent[2]
-        if num == 1:
-            nd["first_child"] = -(int(idx[0]) + 1)
-            continue
-        nd["first_child"] = num_bvs
-        left, right = num_bvs, num_bvs + 1
-        num_bvs += 2
-        split_vector = axes[:, 0]
-        split_value = vsum[idx].sum(axis=0) @ split_vector / (3 * num)
-        right_side = centroids[idx] @ split_vector > split_value
-        # the reference's in-place swap loop (BVH_model.cpp:917-948)
-        cur = idx.copy()
-        c1 = 0
-        for i in range(num):
-            if not right_side[i]:
-                cur[i], cur[c1] = cur[c1], cur[i]
-                # keep right_side aligned with cur for the elements not yet visited: the loop only
-                # ever swaps position i (being visited) with c1 <= i, whose flag is not read again
-                c1 += 1
-        if c1 == 0 or c1 == num:
-            c1 = num // 2
-        prim[first:first + num] = cur
-        stack.append((right, first + c1, num - c1))
-        stack.append((left, first, c1))
-    return nodes, prim.astype(np.uint32)
+def build_obbrss(vertices, triangles, n_threads=0):
+    """-> (nodes[BVH_NODE_DTYPE], primitive_indices) as BVHModel<OBBRSS>::endModel() lays them out."""
+    return engine.bvh_build(vertices, triangles, n_threads)
 
 
 class Mesh:

@@ -32,11 +32,14 @@ using namespace hfcl;
 #ifndef HFCL_WPE_GJK
 #define HFCL_WPE_GJK 3
 #endif
-#ifndef HFCL_WPE_EPA
-#define HFCL_WPE_EPA 2
-#endif
+// k_epa carries no occupancy attribute on purpose: forcing the fp64 instantiation to 2 waves/SIMD
+// (488 B/lane of scratch) produced wrong EPA results on gfx950 (profiles/r01_c_waves_per_eu_ab.txt);
+// the compiler's own choice (fp32: 2 waves, fp64: 1 wave + AGPRs) is what the parity tests cover.
 #ifndef HFCL_WPE_PRIM
 #define HFCL_WPE_PRIM 2
+#endif
+#ifndef HFCL_WPE_BVH
+#define HFCL_WPE_BVH 1
 #endif
 
 // ---------------------------------------------------------------------------------------
@@ -458,7 +461,7 @@ struct EpaSupport {  // any pair kind, evaluated by one lane group
 
 // TIER: 1 reads queue 1 and may push to queue 2; 2 reads queue 2 (never overflows: CAP = 64)
 template <typename T, int WE, int CAP, int TIER>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_EPA, 8))) k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+__global__ void __launch_bounds__(64) k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   constexpr int G = 64 / WE;
   __shared__ EpaScratch<T, CAP> scratch[G];
   const uint32_t cnt = wk.counts[TIER == 1 ? B_COUNT : B_COUNT + 1];
@@ -521,7 +524,7 @@ constexpr int BVH_STACK = 96;
 constexpr int BVH_BLOCK = 128;
 
 template <typename T>
-__global__ void __launch_bounds__(BVH_BLOCK) k_bvh_collide(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
+__global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH, 8))) k_bvh_collide(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
                                                           BvhParams bp, T break_distance2) {
   __shared__ uint32_t stack[BVH_STACK][BVH_BLOCK];
   const uint32_t cnt = wk.counts[B_BVH];
@@ -690,7 +693,7 @@ constexpr int BVHD_STACK = 64;
 constexpr int BVHD_BLOCK = 64;
 
 template <typename T>
-__global__ void __launch_bounds__(BVHD_BLOCK) k_bvh_distance(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q) {
+__global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH, 8))) k_bvh_distance(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q) {
   __shared__ uint32_t stack_e[BVHD_STACK][BVHD_BLOCK];
   __shared__ T stack_d[BVHD_STACK][BVHD_BLOCK];
   const uint32_t cnt = wk.counts[B_BVH];

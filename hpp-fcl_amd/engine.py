@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "hfcl_distance_request_init", "hfcl_lib_create", "hfcl_lib_destroy", "hfcl_lib_num_shapes", "hfcl_lib_device",
     "hfcl_lib_add_bvh", "hfcl_collide_batch", "hfcl_distance_batch", "hfcl_collide_batch_device",
     "hfcl_distance_batch_device", "hfcl_distance_batch_device_f32", "hfcl_collide_batch_device_f32",
-    "hfcl_collide_batch_contacts", "hfcl_last_kernel_ms", "hfcl_last_kernel_name",
+    "hfcl_collide_batch_contacts", "hfcl_last_kernel_ms", "hfcl_last_kernel_name", "hfcl_bvh_build",
 ]
 
 
@@ -70,6 +70,18 @@ def last_error():
 
 def device_count():
     return int(dll().hfcl_device_count())
+
+
+def bvh_build(vertices, triangles, n_threads=0):
+    """hfcl_bvh_build: (nodes[BVH_NODE_DTYPE], primitive_indices) of BVHModel<OBBRSS> (host, no GPU needed)."""
+    v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 3)
+    t = np.ascontiguousarray(triangles, dtype=np.uint32).reshape(-1, 3)
+    nodes = np.zeros(max(2 * len(t) - 1, 0), dtype=abi.BVH_NODE_DTYPE)
+    prim = np.zeros(len(t), dtype=np.uint32)
+    _check(dll().hfcl_bvh_build(C.c_void_p(v.ctypes.data), C.c_size_t(len(v)), C.c_void_p(t.ctypes.data),
+                                C.c_size_t(len(t)), C.c_void_p(nodes.ctypes.data), C.c_void_p(prim.ctypes.data),
+                                C.c_int(n_threads)))
+    return nodes, prim
 
 
 def _check(rc):

@@ -232,6 +232,15 @@ int hfcl_lib_add_bvh(hfcl_lib* lib, const hfcl_bvh_node* nodes, size_t n_nodes,
                      const double* vertices, size_t n_vertices,
                      const uint32_t* triangles, size_t n_tris);
 
+/* Host-side construction of the node array of a BVHModel<OBBRSS> from a triangle soup, as
+ * BVHModel<OBBRSS>::beginModel/addSubModel/endModel does (src/BVH/BVH_model.cpp:440-576,858-960;
+ * fit src/BVH/BV_fitter.cpp:501-531; split SPLIT_METHOD_MEAN src/BVH/BV_splitter.cpp:81-118,276-279).
+ * nodes_out: 2*n_tris-1 records; primitive_indices_out: n_tris (the model's permutation array).
+ * n_threads <= 0: pick automatically.  Runs on the host (the reference builds on the host too);
+ * needs no GPU. */
+int hfcl_bvh_build(const double* vertices, size_t n_vertices, const uint32_t* triangles, size_t n_tris,
+                   hfcl_bvh_node* nodes_out, uint32_t* primitive_indices_out, int n_threads);
+
 /* ---- batched queries, host buffers (H2D + kernels + D2H inside the call) ------------
  * shape1/shape2: n indices into the library; tf1/tf2: n poses (12 doubles each).
  * guess_in / guess_out: NULL or n records (used when q.gjk_initial_guess == CachedGuess).

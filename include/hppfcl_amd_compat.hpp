@@ -171,6 +171,83 @@ class ConvexBase : public ShapeBase {
   NODE_TYPE getNodeType() const override { return GEOM_CONVEX; }
 };
 
+struct Triangle {  // include/hpp/fcl/data_types.h:101-144
+  typedef std::size_t index_type;
+  Triangle() : vids{0, 0, 0} {}
+  Triangle(index_type a, index_type b, index_type c) : vids{a, b, c} {}
+  index_type operator[](index_type i) const { return vids[i]; }
+  index_type& operator[](index_type i) { return vids[i]; }
+  index_type vids[3];
+};
+struct OBBRSS {};  // tag: the one BV type in scope (include/hpp/fcl/BV/OBBRSS.h)
+enum BVHReturnCode { BVH_OK = 0, BVH_ERR_BUILD_OUT_OF_SEQUENCE = -2, BVH_ERR_BUILD_EMPTY_MODEL = -3 };
+
+/// BVHModel<OBBRSS> (include/hpp/fcl/BVH/BVH_model.h:61-368): triangle soup assembled with
+/// beginModel / addVertex / addTriangle / addSubModel / endModel; endModel() builds the tree on the
+/// host (hfcl_bvh_build, the reference's SPLIT_METHOD_MEAN construction).
+template <typename BV>
+class BVHModel : public CollisionGeometry {
+ public:
+  std::vector<Vec3f> vertices;
+  std::vector<Triangle> tri_indices;
+  unsigned int num_tris = 0, num_vertices = 0;
+
+  NODE_TYPE getNodeType() const override { return BV_OBBRSS; }
+  int beginModel(unsigned int = 0, unsigned int = 0) {  // BVH_model.cpp:264-306
+    vertices.clear();
+    tri_indices.clear();
+    nodes_.clear();
+    building_ = true;
+    return BVH_OK;
+  }
+  int addVertex(const Vec3f& p) {
+    if (!building_) return BVH_ERR_BUILD_OUT_OF_SEQUENCE;
+    vertices.push_back(p);
+    return BVH_OK;
+  }
+  int addTriangle(const Vec3f& p1, const Vec3f& p2, const Vec3f& p3) {  // BVH_model.cpp:385-438
+    if (!building_) return BVH_ERR_BUILD_OUT_OF_SEQUENCE;
+    const std::size_t o = vertices.size();
+    vertices.push_back(p1);
+    vertices.push_back(p2);
+    vertices.push_back(p3);
+    tri_indices.emplace_back(o, o + 1, o + 2);
+    return BVH_OK;
+  }
+  int addSubModel(const std::vector<Vec3f>& ps, const std::vector<Triangle>& ts) {  // BVH_model.cpp:440-506
+    if (!building_) return BVH_ERR_BUILD_OUT_OF_SEQUENCE;
+    const std::size_t o = vertices.size();
+    vertices.insert(vertices.end(), ps.begin(), ps.end());
+    for (const Triangle& t : ts) tri_indices.emplace_back(t[0] + o, t[1] + o, t[2] + o);
+    return BVH_OK;
+  }
+  int endModel() {  // BVH_model.cpp:508-576
+    if (!building_) return BVH_ERR_BUILD_OUT_OF_SEQUENCE;
+    if (tri_indices.empty() || vertices.empty()) return BVH_ERR_BUILD_EMPTY_MODEL;
+    num_tris = static_cast<unsigned int>(tri_indices.size());
+    num_vertices = static_cast<unsigned int>(vertices.size());
+    flat_tris_.resize(3 * tri_indices.size());
+    for (std::size_t i = 0; i < tri_indices.size(); ++i)
+      for (int k = 0; k < 3; ++k) flat_tris_[3 * i + k] = static_cast<uint32_t>(tri_indices[i][k]);
+    nodes_.resize(2 * tri_indices.size() - 1);
+    primitive_indices_.resize(tri_indices.size());
+    const int rc = hfcl_bvh_build(reinterpret_cast<const double*>(vertices.data()), vertices.size(), flat_tris_.data(),
+                                  tri_indices.size(), nodes_.data(), primitive_indices_.data(), 0);
+    if (rc) throw std::invalid_argument(hfcl_last_error());
+    building_ = false;
+    return BVH_OK;
+  }
+  unsigned int getNumBVs() const { return static_cast<unsigned int>(nodes_.size()); }
+  const hfcl_bvh_node& getBV(unsigned int i) const { return nodes_[i]; }
+  const std::vector<hfcl_bvh_node>& nodes() const { return nodes_; }
+  const std::vector<uint32_t>& flatTriangles() const { return flat_tris_; }
+
+ private:
+  bool building_ = false;
+  std::vector<hfcl_bvh_node> nodes_;
+  std::vector<uint32_t> flat_tris_, primitive_indices_;
+};
+
 struct QueryRequest {
   GJKInitialGuess gjk_initial_guess = DefaultGuess;
   mutable Vec3f cached_gjk_guess = Vec3f(1, 0, 0);
@@ -313,12 +390,29 @@ class BatchQueries {
         for (const Vec3f& p : *c->points) v.insert(v.end(), p.data(), p.data() + 3);
         break;
       }
+      case BV_OBBRSS: {
+        auto* m = dynamic_cast<const BVHModel<OBBRSS>*>(g);
+        if (!m || m->getNumBVs() == 0) throw std::invalid_argument("BVHModel: endModel() has not been called");
+        auto it = ids_.find(g);
+        // same object, same content?  (the address may have belonged to another geometry before)
+        if (it != ids_.end() && shapes_[it->second].type == BV_OBBRSS &&
+            static_cast<size_t>(shapes_[it->second].bvh_index) < meshes_.size()) {
+          const MeshRef& r = meshes_[static_cast<size_t>(shapes_[it->second].bvh_index)];
+          if (r.model == m && r.n_nodes == m->getNumBVs() && r.n_vertices == m->num_vertices &&
+              r.checksum == checksum(*m))
+            return it->second;
+        }
+        s.bvh_index = static_cast<int32_t>(meshes_.size());
+        s.num_points = m->num_vertices;
+        meshes_.push_back(MeshRef{m, m->getNumBVs(), m->num_vertices, checksum(*m)});
+        break;
+      }
       default: throw std::invalid_argument("unsupported node type");
     }
     // The cache is keyed by address; a hit is only trusted if the geometry's *content* is still
     // what was registered (addresses get reused once a geometry is destroyed).
     auto it = ids_.find(g);
-    if (it != ids_.end()) {
+    if (it != ids_.end() && s.type != BV_OBBRSS) {
       const hfcl_shape& o = shapes_[it->second];
       bool same = o.type == s.type && o.num_points == s.num_points && o.swept_sphere_radius == s.swept_sphere_radius &&
                   o.params[0] == s.params[0] && o.params[1] == s.params[1] && o.params[2] == s.params[2];
@@ -360,7 +454,22 @@ class BatchQueries {
         res.nearest_points = {{p1, p2}};
         res.normal = n;
       }
-      if (r.num_contacts > 0 && res.numContacts() < request.num_max_contacts) {
+      if (r.num_contacts > 1 && !contacts_.empty()) {
+        const uint32_t qi = static_cast<uint32_t>(&r - rec_.data());
+        for (const hfcl_contact& k : contacts_) {
+          if (k.pair != qi || res.numContacts() >= request.num_max_contacts) continue;
+          Contact c;
+          c.o1 = geoms_[p.first];
+          c.o2 = geoms_[p.second];
+          c.b1 = k.b1;
+          c.b2 = k.b2;
+          c.normal = Vec3f(k.normal[0], k.normal[1], k.normal[2]);
+          c.nearest_points = {{Vec3f(k.p1[0], k.p1[1], k.p1[2]), Vec3f(k.p2[0], k.p2[1], k.p2[2])}};
+          c.pos = (c.nearest_points[0] + c.nearest_points[1]) / 2;
+          c.penetration_depth = k.penetration_depth;
+          res.addContact(c);
+        }
+      } else if (r.num_contacts > 0 && res.numContacts() < request.num_max_contacts) {
         Contact c;
         c.o1 = geoms_[p.first];
         c.o2 = geoms_[p.second];
@@ -390,6 +499,7 @@ class BatchQueries {
     res.cached_support_func_guess = {{g.support_guess[0], g.support_guess[1]}};
   }
   const std::vector<hfcl_result>& records() const { return rec_; }
+  const std::vector<hfcl_contact>& contacts() const { return contacts_; }  // filled when num_max_contacts > 1 on meshes
   const std::vector<hfcl_guess>& guesses() const { return guess_; }
 
   void run(const std::vector<std::pair<uint32_t, uint32_t>>& pairs, const std::vector<Transform3f>& tf1,
@@ -398,6 +508,12 @@ class BatchQueries {
     if (!lib_) {
       lib_ = hfcl_lib_create(shapes_.data(), shapes_.size(), verts_.data(), verts_.size() / 3, device_);
       if (!lib_) throw std::runtime_error(hfcl_last_error());
+      for (const MeshRef& r : meshes_) {  // bvh_index = registration order
+        const auto* m = r.model;
+        if (hfcl_lib_add_bvh(lib_, m->nodes().data(), m->nodes().size(), reinterpret_cast<const double*>(m->vertices.data()),
+                             m->vertices.size(), m->flatTriangles().data(), m->flatTriangles().size() / 3) < 0)
+          throw std::runtime_error(hfcl_last_error());
+      }
     }
     std::vector<uint32_t> s1(pairs.size()), s2(pairs.size());
     for (size_t i = 0; i < pairs.size(); ++i) {
@@ -407,7 +523,22 @@ class BatchQueries {
     rec_.resize(pairs.size());
     guess_.resize(pairs.size());
     int rc;
-    if (creq) {
+    contacts_.clear();
+    if (creq && creq->num_max_contacts > 1 && !meshes_.empty()) {
+      // mesh-mesh queries can produce several contacts each: use the contact-list entry point
+      const hfcl_collision_request a = to_abi(*creq);
+      size_t cap = std::max<size_t>(1024, 64 * pairs.size()), produced = 0;
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        contacts_.resize(cap);
+        rc = hfcl_collide_batch_contacts(lib_, s1.data(), s2.data(), reinterpret_cast<const double*>(tf1.data()),
+                                         reinterpret_cast<const double*>(tf2.data()), pairs.size(), &a, rec_.data(),
+                                         contacts_.data(), cap, &produced);
+        if (rc || produced <= cap) break;
+        cap = produced;
+      }
+      contacts_.resize(rc ? 0 : std::min(produced, cap));
+      for (auto& g : guess_) g = hfcl_guess{{1, 0, 0}, {0, 0}};
+    } else if (creq) {
       const hfcl_collision_request a = to_abi(*creq);
       rc = hfcl_collide_batch(lib_, s1.data(), s2.data(), reinterpret_cast<const double*>(tf1.data()),
                               reinterpret_cast<const double*>(tf2.data()), pairs.size(), &a, rec_.data(), nullptr, guess_.data());
@@ -428,6 +559,18 @@ class BatchQueries {
   std::map<const CollisionGeometry*, uint32_t> ids_;
   std::vector<hfcl_result> rec_;
   std::vector<hfcl_guess> guess_;
+  std::vector<hfcl_contact> contacts_;
+  struct MeshRef {
+    const BVHModel<OBBRSS>* model;
+    unsigned int n_nodes, n_vertices;
+    double checksum;
+  };
+  std::vector<MeshRef> meshes_;
+  static double checksum(const BVHModel<OBBRSS>& m) {  // cheap content fingerprint for the address-keyed cache
+    double c = 0;
+    for (size_t i = 0; i < m.vertices.size(); i += 1 + m.vertices.size() / 64) c += m.vertices[i][0] + 2 * m.vertices[i][1] + 3 * m.vertices[i][2];
+    return c + m.getBV(0).rss_radius;
+  }
 };
 
 inline BatchQueries& default_context() {

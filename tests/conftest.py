@@ -37,3 +37,11 @@ def oracle():
     oracle_binding.build()
     oracle_binding.lib()
     return oracle_binding
+
+
+@pytest.fixture(scope="session")
+def hostsim():
+    """Host build of the device headers (tests/hostsim) -- validation of the device code on CPU."""
+    import hostsim_binding
+    hostsim_binding.lib()
+    return hostsim_binding

@@ -13,8 +13,10 @@ static int failures = 0;
 #define CHECK_CLOSE(x, ref, pct) CHECK(std::fabs((x) - (ref)) <= std::fabs(ref) * (pct) / 100.0)
 #define CHECK_CLOSE_TO_0(x, eps) CHECK(std::fabs(x) < (eps))
 
+#define STAGE(name) std::fprintf(stderr, "[stage] %s\n", name)
 int main() {
   using namespace hpp::fcl;
+  std::setvbuf(stdout, nullptr, _IONBF, 0);
   if (hfcl_device_count() < 1) {
     Sphere s(1.0);
     try {
@@ -92,6 +94,40 @@ int main() {
     batch.distance(pairs, tf1, tf2, rq, res);
     for (int k = 0; k < 100; ++k) CHECK(std::fabs(res[k].min_distance - (1.5 + 0.02 * k - 2.0)) < 1e-6);
   }
+  {  // BVHModel<OBBRSS>: two box meshes as in test/collision.cpp / geometric_shape_to_BVH_model.h (12 triangles each)
+    auto make_box_mesh = [](BVHModel<OBBRSS>& m, double hx, double hy, double hz) {
+      std::vector<Vec3f> ps;
+      for (int i = 0; i < 8; ++i) ps.push_back(Vec3f((i & 1) ? hx : -hx, (i & 2) ? hy : -hy, (i & 4) ? hz : -hz));
+      const int q[6][4] = {{0, 2, 3, 1}, {4, 5, 7, 6}, {0, 1, 5, 4}, {2, 6, 7, 3}, {0, 4, 6, 2}, {1, 3, 7, 5}};
+      std::vector<Triangle> ts;
+      for (auto& f : q) { ts.emplace_back(f[0], f[1], f[2]); ts.emplace_back(f[0], f[2], f[3]); }
+      CHECK(m.beginModel() == BVH_OK);
+      CHECK(m.addSubModel(ps, ts) == BVH_OK);
+      CHECK(m.endModel() == BVH_OK);
+    };
+    STAGE("mesh: build");
+    BVHModel<OBBRSS> m1, m2;
+    make_box_mesh(m1, 1, 1, 1);
+    make_box_mesh(m2, 0.5, 0.5, 0.5);
+    CHECK(m1.getNumBVs() == 23 && m1.num_tris == 12 && m1.getNodeType() == BV_OBBRSS);
+    STAGE("mesh: collide separated");
+    CollisionRequest rq; CollisionResult rs;
+    CHECK(collide(&m1, Transform3f(), &m2, Transform3f(Vec3f(3, 0, 0)), rq, rs) == 0);
+    CHECK(rs.distance_lower_bound > 0.0 && rs.distance_lower_bound <= 1.5 + 1e-9);  // OBB bound of a 1.5 gap
+    rs.clear();
+    CHECK(collide(&m1, Transform3f(), &m2, Transform3f(Vec3f(1.2, 0.1, 0.2)), rq, rs) == 1);
+    CHECK(rs.getContact(0).b1 >= 0 && rs.getContact(0).b1 < 12 && rs.getContact(0).b2 >= 0 && rs.getContact(0).o1 == &m1);
+    rs.clear();
+    STAGE("mesh: all contacts");
+    CollisionRequest all; all.num_max_contacts = 1000;
+    const std::size_t nall = collide(&m1, Transform3f(), &m2, Transform3f(Vec3f(1.2, 0.1, 0.2)), all, rs);
+    CHECK(nall > 1 && nall == rs.numContacts());
+    STAGE("mesh: distance");
+    DistanceRequest dq; DistanceResult dr;
+    const double d = distance(&m1, Transform3f(), &m2, Transform3f(Vec3f(3, 0, 0)), dq, dr);
+    CHECK(std::fabs(d - 1.5) < 1e-9 && dr.b1 >= 0 && dr.b2 >= 0);
+  }
+  STAGE("done");
   std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
   return failures ? 1 : 0;
 }

@@ -192,3 +192,16 @@ def sqr_tri_distance(S, T):
     out = np.zeros(6)
     d2 = L.orc_sqr_tri_distance(abi.ptr(S), abi.ptr(T), abi.ptr(out))
     return d2, out[:3].copy(), out[3:].copy()
+
+
+def bvh_build(vertices, triangles):
+    """Oracle restatement of BVHModel<OBBRSS>::endModel() (oracle/bvh_build.cpp)."""
+    abi = _pkg().abi
+    v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 3)
+    t = np.ascontiguousarray(triangles, dtype=np.uint32).reshape(-1, 3)
+    nodes = np.zeros(2 * len(t) - 1, dtype=abi.BVH_NODE_DTYPE)
+    prim = np.zeros(len(t), dtype=np.uint32)
+    rc = lib().orc_bvh_build(C.c_void_p(v.ctypes.data), C.c_size_t(len(v)), C.c_void_p(t.ctypes.data),
+                             C.c_size_t(len(t)), C.c_void_p(nodes.ctypes.data), C.c_void_p(prim.ctypes.data))
+    assert rc == 0
+    return nodes, prim

@@ -8,13 +8,6 @@ import pytest
 from compare import check_parity, check_properties
 
 
-@pytest.fixture(scope="module")
-def hostsim():
-    import hostsim_binding
-    hostsim_binding.lib()
-    return hostsim_binding
-
-
 CASES = ["cfg1_sphere_sphere", "cfg2_box_capsule", "cfg3_convex_convex", "cfg5_mixed"]
 
 

@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""Compact per-kernel resource table (VGPR / AGPR / scratch / LDS / occupancy) from hipcc's
+-Rpass-analysis=kernel-resource-usage.  usage: tools/kernel_resources.py [extra hipcc flags]"""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "hpp-fcl_amd", "csrc", "hfcl_kernels.hip")
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-value", "-Wno-pass-failed",
+       "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", src] + sys.argv[1:]
+err = subprocess.run(cmd, capture_output=True, text=True).stderr
+rows, cur = [], {}
+for line in err.splitlines():
+    m = re.search(r"remark: (?:\s*)([A-Za-z \[\]/]+): (.+?) \[-Rpass", line)
+    if not m:
+        continue
+    k, v = m.group(1).strip(), m.group(2).strip()
+    if k == "Function Name":
+        cur = {"name": subprocess.run(["c++filt", v], capture_output=True, text=True).stdout.strip()}
+        rows.append(cur)
+    else:
+        cur[k] = v
+print("%-60s %5s %5s %8s %6s %4s" % ("kernel", "VGPR", "AGPR", "scratch", "LDS", "occ"))
+for r in rows:
+    n = re.sub(r"\(.*", "", r["name"]).replace("void ", "")
+    if re.search(r"k_gjk_cvx<\w+, (8|16|32|64),", n):
+        continue
+    print("%-60s %5s %5s %8s %6s %4s" % (n[:60], r.get("VGPRs"), r.get("AGPRs"), r.get("ScratchSize [bytes/lane]"),
+                                         r.get("LDS Size [bytes/block]"), r.get("Occupancy [waves/SIMD]")))

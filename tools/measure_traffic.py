@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""HBM traffic per kernel launch from rocprofv3 PMC counters -> profiles/traffic_<workload>.json.
+
+Runs on the GPU box (`gpurun -- python tools/measure_traffic.py --workload cfg3`).  Two separate
+`--pmc` passes (FETCH_SIZE needs 3 of the 4 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md "rocprofv3
+PMC slots"), each with --kernel-trace only.  Values are KB per dispatch as rocprofv3 reports them;
+`bench.py` applies the gfx950 correction (FETCH_SIZE tallies 128-B requests at 64 B -> x2 for
+wide reads; narrower reads uncalibrated, so raw is a lower bound and 2x raw an upper bound)."""
+import argparse
+import collections
+import glob
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def one_pass(counter, workload, outdir, pairs):
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", outdir, "-o", "t", "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3",
+           "--warmup", "1", "--no-cpu-baseline"] + (["--pairs", str(pairs)] if pairs else [])
+    subprocess.run(cmd, check=True, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    dbs = glob.glob(os.path.join(outdir, "**", "*.db"), recursive=True)
+    assert dbs, "rocprofv3 wrote no database under " + outdir
+    con = sqlite3.connect(dbs[0])
+    rows = con.execute("select kernel_name, sum(value), count(*) from counters_collection "
+                       "where counter_name=? group by kernel_name", (counter,))
+    return {k: (v / n, n) for k, v, n in rows}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--pairs", type=int, default=0)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    scratch = os.path.join(ROOT, "gpurun_out", "traffic_" + a.workload)
+    res = collections.defaultdict(dict)
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        for k, (v, n) in one_pass(c, a.workload, os.path.join(scratch, c), a.pairs).items():
+            res[k][c + "_KB_per_dispatch"] = v
+            res[k]["dispatches"] = n
+    out = a.out or os.path.join(ROOT, "gpurun_out", "traffic_%s.json" % a.workload)
+    json.dump({"workload": a.workload, "pairs": a.pairs or None, "unit": "KB as reported by rocprofv3 (uncorrected)",
+               "kernels": {k: v for k, v in res.items() if k.startswith("void k_") or k.startswith("k_")}},
+              open(out, "w"), indent=1)
+    print(open(out).read())
