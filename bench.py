@@ -36,6 +36,7 @@ BYTES_PER_QUERY = {
     # (SURVEY.md 8d): 2 x 128 B (fp64 device node) per BV test, 2 x (3 x 24 B vertices + 12 B indices)
     # per leaf test; N_bv, N_leaf are measured with the oracle on a sample and reported.
     "cfg4": 8 + 2 * 96 + 96,
+    "cfg5": 8 + 2 * 96 + 96,   # mixed primitive+convex collide, fp64: as cfg2
 }
 CFG4_BYTES_PER_BV_TEST = 2 * 128
 CFG4_BYTES_PER_LEAF_TEST = 2 * (3 * 24 + 12)
@@ -46,8 +47,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4"])
-    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default 1M; cfg4: 100k)")
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4", "cfg5"])
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default 1M; cfg4: 100k; cfg5: 1.25M = 10M / 8)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of result records (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
@@ -98,12 +99,27 @@ def main():
 
     pkg = load_pkg()
     abi, wl = pkg.abi, pkg.workloads
-    n = args.pairs or (100_000 if args.workload == "cfg4" else 1_000_000)
+    n = args.pairs or {"cfg4": 100_000, "cfg5": 1_250_000}.get(args.workload, 1_000_000)
     if args.workload == "cfg3":
         batch = wl.cfg3_convex_convex(n=n, seed=1 + rank)
         dtype = "f32"
     elif args.workload == "cfg2":
         batch = wl.cfg2_box_capsule(n=n, seed=1 + rank)
+        dtype = "f64"
+    elif args.workload == "cfg5":
+        # pair list = host broadphase over a scene of n/10 posed objects (not in the timed region);
+        # every rank owns its own scene shard; the list is cut to exactly n pairs
+        over = 1.15
+        while True:
+            t_bp = time.perf_counter()
+            batch = wl.cfg5_broadphase_scene(n_objects=max(n // 10, 100), target_pairs=int(over * n), seed=1 + rank)
+            t_bp = time.perf_counter() - t_bp
+            if len(batch) >= n:
+                break
+            over *= 1.3
+        scene = {"objects": batch.scene["n_objects"], "broadphase_pairs": len(batch), "host_broadphase_s": t_bp}
+        batch = batch.slice(0, n)
+        batch.scene = scene
         dtype = "f64"
     else:
         batch = wl.cfg4_mesh_mesh(n=n, seed=1 + rank)
@@ -209,6 +225,8 @@ def main():
             nbv, nleaf = float(st0[:, 0].mean()), float(st0[:, 1].mean())
             bpq = bpq + CFG4_BYTES_PER_BV_TEST * nbv + CFG4_BYTES_PER_LEAF_TEST * nleaf
             extra_cfg = {"mean_bv_tests": nbv, "mean_leaf_tests": nleaf, "stats_sample": ns0}
+        if args.workload == "cfg5":
+            extra_cfg = dict(batch.scene)
         # units the dominant kernel processes in one launch
         if dominant.startswith("k_epa<fast"):
             units = buckets["epa_queue"]
@@ -263,7 +281,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": batch.name, **extra_cfg,
-                       "baseline_config": {"cfg3": "configs[2]", "cfg2": "configs[1]", "cfg4": "configs[3]"}[args.workload],
+                       "baseline_config": {"cfg3": "configs[2]", "cfg2": "configs[1]", "cfg4": "configs[3]", "cfg5": "configs[4]"}[args.workload],
                        "pairs_per_gpu_per_step": n, "contact_fraction": contact_frac, "buckets": buckets,
                        "request": batch.kind, "all_gather_results": bool(gather),
                        "lane_group_width": int(os.environ.get("HFCL_CVX_W", "4"))},

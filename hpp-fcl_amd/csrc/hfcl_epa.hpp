@@ -11,10 +11,15 @@
 //     plus an append stamp: the reference's list order (most recently appended first) only
 //     matters as the tie-break of findClosestFace, which becomes a lane-parallel
 //     arg-min over (d^2 ascending, stamp descending);
-//   * the recursive expand() is an explicit frame stack; encloseOrigin() is an explicit
-//     state machine (both recursions have bounded depth).
+//   * the recursive expand() is split in two: a serial silhouette walk (explicit frame stack) that
+//     only *lists* the horizon edges, then the new faces -- one per horizon edge, independent of
+//     each other -- are built by the lanes of the group in parallel.  The reference creates them
+//     inside the recursion; which of its failure exits fires first (stock exhausted, degenerate /
+//     non-convex face, invalid hull) is reproduced from the walk order (see expand_iteration);
+//   * encloseOrigin() is an explicit state machine.
 // One polytope is driven by one lane group; all lanes of the group execute the scalar
-// control flow redundantly (uniform LDS addresses broadcast), face scans are split over lanes.
+// control flow redundantly (uniform LDS addresses broadcast); face scans, face creation and
+// face removal are split over the lanes.
 #pragma once
 #include "hfcl_gjk.hpp"
 
@@ -53,10 +58,11 @@ struct EpaScratch {
   T fn[3][NF];   // face normal
   T fd[NF];      // face distance
   uint16_t fstamp[NF];
-  uint16_t stack[NF];  // expand() frames: face | edge<<8 | stage<<10
+  uint16_t stack[NF];  // silhouette-walk frames: face | edge<<8 | stage<<10
+  uint16_t hz[NF];     // horizon edges in walk order: kept face | its edge<<8
   uint8_t fvid[3][NF];
   uint8_t fadj[3][NF];
-  uint8_t fadje[NF];   // 3 x 2 bits
+  uint8_t fadje[3][NF];  // edge index on the neighbour's side
   uint8_t fflag[NF];   // bit0 in hull, bit1 ignore
   uint8_t fpass[NF];
   uint8_t stock[NF];   // free-face stack
@@ -101,11 +107,11 @@ struct Epa {
     m->v0[0][i] = w0.x; m->v0[1][i] = w0.y; m->v0[2][i] = w0.z;
   }
   HFCL_HD V3<T> fn(int f) const { return mk<T>(m->fn[0][f], m->fn[1][f], m->fn[2][f]); }
-  HFCL_HD int adj_edge(int f, int e) const { return (m->fadje[f] >> (2 * e)) & 3; }
+  HFCL_HD int adj_edge(int f, int e) const { return m->fadje[e][f]; }
   HFCL_HD void bind(int fa, int ea, int fb, int eb) {  // gjk.h:312-320
-    m->fadje[fa] = uint8_t((m->fadje[fa] & ~(3 << (2 * ea))) | (eb << (2 * ea)));
+    m->fadje[ea][fa] = uint8_t(eb);
     m->fadj[ea][fa] = uint8_t(fb);
-    m->fadje[fb] = uint8_t((m->fadje[fb] & ~(3 << (2 * eb))) | (ea << (2 * eb)));
+    m->fadje[eb][fb] = uint8_t(ea);
     m->fadj[eb][fb] = uint8_t(fa);
   }
   HFCL_HD void hull_remove(int f) {
@@ -134,24 +140,13 @@ struct Epa {
     Grp::sync();
   }
 
-  // newFace :1068-1138.  Returns face index or EPA_NULL.
-  HFCL_HD int new_face(int ia, int ib, int ic, bool force) {
-    if (stock_top == 0) {
-      if (cap_iterations < max_iterations) overflow = true;  // the reference still has faces in stock
-      status = EPA_OUT_OF_FACES;
-      return EPA_NULL;
-    }
-    const int f = m->stock[--stock_top];
-    ++hull_count;
-    m->fflag[f] = 1;
-    m->fstamp[f] = uint16_t(stamp++);
-    m->fpass[f] = 0;
-    m->fvid[0][f] = uint8_t(ia);
-    m->fvid[1][f] = uint8_t(ib);
-    m->fvid[2][f] = uint8_t(ic);
+  // Geometry part of newFace (:1081-1137) for the triangle (ia, ib, ic) stored in slot f.
+  // Returns 0 when the face is kept, else the status newFace sets (NonConvex / Degenerated).
+  HFCL_HD int face_geometry(int f, int ia, int ib, int ic, bool force) {
     const V3<T> a = vw(ia), b = vw(ib), c = vw(ic);
     V3<T> n = cross(b - a, c - a);
-    bool keep = false;
+    int fail = 0;
+    int flag = 1;
     if (norm(n) > Lim<T>::eps()) {
       n = normalized(n);
       const T a_dot_nab = dot(a, cross(b - a, n));
@@ -162,19 +157,35 @@ struct Epa {
         d = dot(a, n);
       } else {
         d = Lim<T>::max();
-        m->fflag[f] = 3;  // in hull + ignore
+        flag = 3;  // in hull + ignore
       }
-      m->fn[0][f] = n.x; m->fn[1][f] = n.y; m->fn[2][f] = n.z;
       m->fd[f] = d;
-      if (d >= -tolerance || force)
-        keep = true;
-      else
-        status = EPA_NON_CONVEX;
+      if (!(d >= -tolerance || force)) fail = EPA_NON_CONVEX;
     } else {
-      m->fn[0][f] = n.x; m->fn[1][f] = n.y; m->fn[2][f] = n.z;
-      status = EPA_DEGENERATED;
+      fail = EPA_DEGENERATED;
     }
-    if (keep) return f;
+    m->fn[0][f] = n.x; m->fn[1][f] = n.y; m->fn[2][f] = n.z;
+    m->fflag[f] = uint8_t(flag);
+    m->fpass[f] = 0;
+    m->fvid[0][f] = uint8_t(ia);
+    m->fvid[1][f] = uint8_t(ib);
+    m->fvid[2][f] = uint8_t(ic);
+    return fail;
+  }
+
+  // newFace :1068-1138 (serial form, used for the initial tetrahedron).  Face index or EPA_NULL.
+  HFCL_HD int new_face(int ia, int ib, int ic, bool force) {
+    if (stock_top == 0) {
+      if (cap_iterations < max_iterations) overflow = true;  // the reference still has faces in stock
+      status = EPA_OUT_OF_FACES;
+      return EPA_NULL;
+    }
+    const int f = m->stock[--stock_top];
+    ++hull_count;
+    m->fstamp[f] = uint16_t(stamp++);
+    const int fail = face_geometry(f, ia, ib, ic, force);
+    if (!fail) return f;
+    status = fail;
     hull_remove(f);
     return EPA_NULL;
   }
@@ -222,16 +233,14 @@ struct Epa {
     return best_f != EPA_NULL ? best_f : head_f;
   }
 
-  // expand :1361-1449, explicit stack.  Returns `valid`.
-  HFCL_HD bool expand(int pass, int f0, int e0, int& hz_current, int& hz_first, int& hz_count) {
-    // gjk.cpp:1410-1411: 3*sqrt(DBL_EPSILON) = 4.47e-8 in fp64.  In fp32 the literal formula
-    // would give 1e-3 (three orders above the solver tolerance: expand() then keeps faces the new
-    // vertex is clearly above), while 4.47e-8 is below fp32 round-off for coplanar supports of
-    // flat-faced shapes (degenerate faces).  2e-7 (~1.7 ulp) minimises the mismatch against the
-    // fp64 oracle on the cfg2/cfg3/cfg5 sets (see DESIGN.md, fp32 section).
-const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
-    const int id_w = num_vertices - 1;
-    const V3<T> ww = vw(id_w);
+  // Silhouette walk = the control flow of expand() (:1361-1449) from (f0, e0) without creating the
+  // faces: horizon edges are appended to m->hz in the order the reference would create their
+  // faces.  `level` emulates the reference's stock size along the walk (one pop per horizon edge,
+  // one push when a visible face is left, :1437-1446) so that its OutOfFaces exit fires at the
+  // same edge; `stop_kind/stop_at` record the first walk-level failure (OutOfFaces before the
+  // stop_at-th face, or InvalidHull after stop_at faces).
+  HFCL_HD void silhouette_walk(int pass, int f0, int e0, T dummy_precision, const V3<T>& ww, int& hz_count, int& level,
+                               int& stop_kind, int& stop_at) {
     int sp = 0;
     m->stack[sp++] = uint16_t(f0 | (e0 << 8));
     while (sp > 0) {
@@ -240,21 +249,20 @@ const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
       const int e1 = (e + 1) % 3, e2 = (e + 2) % 3;
       if (stage == 0) {
         if (m->fpass[f] == pass) {
-          status = EPA_INVALID_HULL;
-          return false;
+          stop_kind = EPA_INVALID_HULL;
+          stop_at = hz_count;
+          return;
         }
         if (dot(fn(f), ww - vw(m->fvid[e][f])) < dummy_precision) {
-          // case 1: the support point is "below" f: new face (f[e1], f[e], w)
-          const int nf = new_face(m->fvid[e1][f], m->fvid[e][f], id_w, false);
-          if (nf == EPA_NULL) return false;
-          bind(nf, 0, f, e);
-          if (hz_current != EPA_NULL)
-            bind(nf, 2, hz_current, 1);
-          else
-            hz_first = nf;
-          hz_current = nf;
-          ++hz_count;
-          --sp;  // return true
+          // case 1: the support point is "below" f: horizon edge, new face (f[e1], f[e], w)
+          if (level == 0) {
+            stop_kind = EPA_OUT_OF_FACES;
+            stop_at = hz_count;
+            return;
+          }
+          --level;
+          m->hz[hz_count++] = uint16_t(f | (e << 8));
+          --sp;
           continue;
         }
         // case 2: above f
@@ -265,11 +273,96 @@ const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
         m->stack[sp - 1] = uint16_t(f | (e << 8) | (2 << 10));
         m->stack[sp++] = uint16_t(m->fadj[e2][f] | (adj_edge(f, e2) << 8));
       } else {
-        hull_remove(f);
+        ++level;  // the reference returns f to the stock here
         --sp;
       }
     }
-    return true;
+  }
+
+  // One polytope expansion by vertex id_w seen from face `closest` (the body of the loop
+  // :1261-1280).  Returns true when the hull was updated (valid && horizon >= 3); on false the
+  // caller leaves the loop and `status` is what the reference's first failing step sets.
+  HFCL_HD bool expand_iteration(int pass, int closest, int id_w) {
+    // gjk.cpp:1410-1411: 3*sqrt(DBL_EPSILON) = 4.47e-8 in fp64.  In fp32 the literal formula
+    // would give 1e-3 (three orders above the solver tolerance: expand() then keeps faces the new
+    // vertex is clearly above), while 4.47e-8 is below fp32 round-off for coplanar supports of
+    // flat-faced shapes (degenerate faces).  2e-7 (~1.7 ulp) minimises the mismatch against the
+    // fp64 oracle on the cfg2/cfg3/cfg5 sets (see DESIGN.md, fp32 section).
+    const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
+    const V3<T> ww = vw(id_w);
+    int hz_count = 0, level = stock_top, stop_kind = 0, stop_at = 0;
+    for (int j = 0; j < 3 && !stop_kind; ++j)
+      silhouette_walk(pass, m->fadj[j][closest], adj_edge(closest, j), dummy_precision, ww, hz_count, level, stop_kind, stop_at);
+    const int n_new = stop_kind ? stop_at : hz_count;
+    Grp::sync();
+    // 1. visible faces (pass mark, includes `closest`) leave the hull and return to the stock
+    {
+      const int nf = 2 * cap_iterations + 4;
+      int mine = 0;
+      for (int f = Grp::lane(); f < nf; f += Grp::W)
+        if ((m->fflag[f] & 1) && m->fpass[f] == pass) ++mine;
+      int before = 0, total = mine;  // exclusive prefix / total over the group
+      for (int msk = 1; msk < Grp::W; msk <<= 1) {
+        const int o = Grp::shfl_xor(total, msk);
+        if (Grp::lane() & msk) before += o;
+        total += o;
+      }
+      int slot = stock_top + before;
+      for (int f = Grp::lane(); f < nf; f += Grp::W)
+        if ((m->fflag[f] & 1) && m->fpass[f] == pass) {
+          m->fflag[f] = 0;
+          m->stock[slot++] = uint8_t(f);
+        }
+      stock_top += total;
+      hull_count -= total;
+    }
+    Grp::sync();
+    // 2. the new faces, one per horizon edge, lanes in parallel; k-th face takes the k-th slot
+    //    from the top of the stock and the k-th stamp
+    int first_fail = n_new, fail_code = 0;
+    for (int k = Grp::lane(); k < n_new; k += Grp::W) {
+      const unsigned fr = m->hz[k];
+      const int f = fr & 255, e = (fr >> 8) & 3, e1 = (e + 1) % 3;
+      const int nfc = m->stock[stock_top - 1 - k];
+      const int kp = (k == 0) ? n_new - 1 : k - 1;  // previous face on the horizon loop
+      const int pf = m->stock[stock_top - 1 - kp];
+      m->fstamp[nfc] = uint16_t(stamp + k);
+      const int fail = face_geometry(nfc, m->fvid[e1][f], m->fvid[e][f], id_w, false);
+      // bind(nf, 0, f, e); bind(nf, 2, previous, 1)  (:1421-1425, closing bind :1273)
+      m->fadj[0][nfc] = uint8_t(f);
+      m->fadje[0][nfc] = uint8_t(e);
+      m->fadj[e][f] = uint8_t(nfc);
+      m->fadje[e][f] = 0;
+      m->fadj[2][nfc] = uint8_t(pf);
+      m->fadje[2][nfc] = 1;
+      m->fadj[1][pf] = uint8_t(nfc);
+      m->fadje[1][pf] = 2;
+      if (fail && k < first_fail) {
+        first_fail = k;
+        fail_code = fail;
+      }
+    }
+    for (int msk = 1; msk < Grp::W; msk <<= 1) {
+      const int ok = Grp::shfl_xor(first_fail, msk), oc = Grp::shfl_xor(fail_code, msk);
+      if (ok < first_fail) {
+        first_fail = ok;
+        fail_code = oc;
+      }
+    }
+    stock_top -= n_new;
+    hull_count += n_new;
+    stamp += n_new;
+    Grp::sync();
+    if (first_fail < n_new) {  // a face before the walk-level stop failed first
+      status = fail_code;
+      return false;
+    }
+    if (stop_kind) {
+      status = stop_kind;
+      if (stop_kind == EPA_OUT_OF_FACES && cap_iterations < max_iterations) overflow = true;
+      return false;
+    }
+    return hz_count >= 3;
   }
 
   // GJK::encloseOrigin :437-492 on verts[0..rank) (reference order).  sup(dir) -> (w, w0).
@@ -386,7 +479,6 @@ const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
             status = EPA_OUT_OF_VERTICES;
             break;
           }
-          int hz_current = EPA_NULL, hz_first = EPA_NULL, hz_count = 0;
           const int iw = num_vertices++;
           m->fpass[closest] = uint8_t(++pass);
           const V3<T> cn = fn(closest);
@@ -407,13 +499,7 @@ const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
             status = EPA_ACCURACY_REACHED;
             break;
           }
-          bool valid = true;
-          for (int j = 0; j < 3 && valid; ++j)
-            valid = valid && expand(pass, m->fadj[j][closest], adj_edge(closest, j), hz_current, hz_first, hz_count);
-          if (overflow) break;
-          if (!valid || hz_count < 3) break;
-          bind(hz_first, 2, hz_current, 1);
-          hull_remove(closest);
+          if (!expand_iteration(pass, closest, iw)) break;
           closest = find_closest_face();
           outer_n = fn(closest);
           outer_d = m->fd[closest];
@@ -438,8 +524,8 @@ const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
     const T nl = norm(n);
     out.normal = (nl > T(0)) ? (n / nl) : mk<T>(T(1), T(0), T(0));
     out.depth = T(0);
-    out.rw0_ = vw(0);
-    out.r00 = v0(0);
+    out.rw0_ = out.rw1_ = out.rw2_ = vw(0);
+    out.r00 = out.r01 = out.r02 = v0(0);
   }
 };
 

@@ -20,6 +20,8 @@ EXPORTED_SYMBOLS = [
     "hfcl_lib_add_bvh", "hfcl_collide_batch", "hfcl_distance_batch", "hfcl_collide_batch_device",
     "hfcl_distance_batch_device", "hfcl_distance_batch_device_f32", "hfcl_collide_batch_device_f32",
     "hfcl_collide_batch_contacts", "hfcl_last_kernel_ms", "hfcl_last_kernel_name", "hfcl_bvh_build",
+    "hfcl_world_aabbs", "hfcl_broadphase_self_pairs", "hfcl_broadphase_pairs_between", "hfcl_pairlist_size",
+    "hfcl_pairlist_data", "hfcl_pairlist_free",
 ]
 
 
@@ -60,6 +62,10 @@ def dll():
         d.hfcl_lib_num_shapes.restype = C.c_size_t
         d.hfcl_last_kernel_ms.restype = C.c_double
         d.hfcl_last_kernel_name.restype = C.c_char_p
+        d.hfcl_broadphase_self_pairs.restype = C.c_void_p
+        d.hfcl_broadphase_pairs_between.restype = C.c_void_p
+        d.hfcl_pairlist_size.restype = C.c_size_t
+        d.hfcl_pairlist_data.restype = C.c_void_p
         _DLL = d
     return _DLL
 
@@ -82,6 +88,44 @@ def bvh_build(vertices, triangles, n_threads=0):
                                 C.c_size_t(len(t)), C.c_void_p(nodes.ctypes.data), C.c_void_p(prim.ctypes.data),
                                 C.c_int(n_threads)))
     return nodes, prim
+
+
+def world_aabbs(shape_library, object_shape, object_tf, n_threads=0):
+    """hfcl_world_aabbs: (n, 6) world AABBs (min, max) of posed objects (host)."""
+    shapes = np.ascontiguousarray(shape_library.shapes_array())
+    verts = np.ascontiguousarray(shape_library.vertices_array(), dtype=np.float64)
+    ids = np.ascontiguousarray(object_shape, dtype=np.uint32)
+    tf = np.ascontiguousarray(object_tf, dtype=np.float64).reshape(-1, 12)
+    out = np.zeros((len(ids), 6), dtype=np.float64)
+    _check(dll().hfcl_world_aabbs(abi.ptr(shapes), C.c_size_t(len(shapes)), abi.ptr(verts), abi.ptr(ids), abi.ptr(tf),
+                                  C.c_size_t(len(ids)), abi.ptr(out), C.c_int(n_threads)))
+    return out
+
+
+def _take_pairlist(h):
+    d = dll()
+    h = C.c_void_p(h)
+    n = d.hfcl_pairlist_size(h)
+    if n:
+        buf = (C.c_uint32 * (2 * n)).from_address(d.hfcl_pairlist_data(h))
+        out = np.frombuffer(buf, dtype=np.uint32).reshape(-1, 2).copy()
+    else:
+        out = np.zeros((0, 2), dtype=np.uint32)
+    d.hfcl_pairlist_free(h)
+    return out
+
+
+def broadphase_self_pairs(aabbs, n_threads=0):
+    """All (i < j) with overlapping AABBs: what DynamicAABBTreeCollisionManager::collide reports."""
+    a = np.ascontiguousarray(aabbs, dtype=np.float64).reshape(-1, 6)
+    return _take_pairlist(dll().hfcl_broadphase_self_pairs(abi.ptr(a), C.c_size_t(len(a)), C.c_int(n_threads)))
+
+
+def broadphase_pairs_between(aabbs_a, aabbs_b, n_threads=0):
+    a = np.ascontiguousarray(aabbs_a, dtype=np.float64).reshape(-1, 6)
+    b = np.ascontiguousarray(aabbs_b, dtype=np.float64).reshape(-1, 6)
+    return _take_pairlist(dll().hfcl_broadphase_pairs_between(abi.ptr(a), C.c_size_t(len(a)), abi.ptr(b),
+                                                              C.c_size_t(len(b)), C.c_int(n_threads)))
 
 
 def _check(rc):

@@ -140,10 +140,7 @@ def cfg3_convex_convex(n=1_000_000, seed=1, nlib=4096, half_width=1.0, nverts=32
                  {"gjk_variant": abi.NesterovAcceleration})
 
 
-def cfg5_mixed(n=100_000, seed=1, nper=256, half_width=0.8):
-    """cfg5-style mixed primitive+convex pairs (type mix 20 % each of Box/Sphere/Capsule/
-    Ellipsoid/Convex32), synthetic pair list (the host broadphase is a later row)."""
-    rng = _rng(seed, 5)
+def _mixed_library(rng, nper):
     lib = geometry.ShapeLibrary()
     for s in rng.uniform(0.1, 1.0, (nper, 3)):
         lib.add_box(*map(float, s))
@@ -156,9 +153,39 @@ def cfg5_mixed(n=100_000, seed=1, nper=256, half_width=0.8):
     base = fibonacci_sphere(32)
     for radii in rng.uniform(0.1, 1.0, (nper, 3)):
         lib.add_convex(base * radii)
+    return lib
+
+
+def cfg5_mixed(n=100_000, seed=1, nper=256, half_width=0.8):
+    """cfg5-style mixed primitive+convex pairs (type mix 20 % each of Box/Sphere/Capsule/
+    Ellipsoid/Convex32), synthetic pair list (cfg5_broadphase_scene takes its pairs from the host broadphase)."""
+    rng = _rng(seed, 5)
+    lib = _mixed_library(rng, nper)
     s1, s2 = rng.integers(0, 5 * nper, n), rng.integers(0, 5 * nper, n)
     q1, T1, q2, T2 = _poses(rng, n, half_width)
     return Batch("cfg5_mixed_collide", lib, s1, s2, q1, T1, q2, T2, "collide")
+
+
+def cfg5_broadphase_scene(n_objects=100_000, target_pairs=1_000_000, seed=1, nper=256, n_threads=0):
+    """cfg5: a scene of posed {Box, Sphere, Capsule, Ellipsoid, Convex32} objects (20 % each); the
+    pair list comes from the host broadphase (engine.world_aabbs -> engine.broadphase_self_pairs,
+    i.e. what DynamicAABBTreeCollisionManager::collide + CollisionCallBackCollect would collect).
+    The cube side is chosen so that about `target_pairs` AABB pairs overlap."""
+    from . import engine
+    rng = _rng(seed, 55)
+    lib = _mixed_library(rng, nper)
+    obj_shape = rng.integers(0, 5 * nper, n_objects).astype(np.uint32)
+    quat = uniform_quaternions(rng, n_objects)
+    # expected pairs ~ n^2/2 * E[prod_k (w_ik + w_jk)/2 * 2] / L^3; the constant is measured on this library
+    side = (n_objects ** 2 * 30.5 / (2.0 * max(target_pairs, 1))) ** (1.0 / 3.0)
+    T = rng.uniform(-side / 2, side / 2, (n_objects, 3))
+    tf = geometry.make_pose(quat=quat, T=T)
+    aabbs = engine.world_aabbs(lib, obj_shape, tf, n_threads)
+    pairs = engine.broadphase_self_pairs(aabbs, n_threads)
+    i, j = pairs[:, 0], pairs[:, 1]
+    b = Batch("cfg5_broadphase_mixed_collide", lib, obj_shape[i], obj_shape[j], quat[i], T[i], quat[j], T[j], "collide")
+    b.scene = dict(n_objects=n_objects, side=side, aabbs=aabbs, pairs=pairs, obj_shape=obj_shape, obj_tf=tf)
+    return b
 
 
 _MESH_CACHE = {}

@@ -241,6 +241,27 @@ int hfcl_lib_add_bvh(hfcl_lib* lib, const hfcl_bvh_node* nodes, size_t n_nodes,
 int hfcl_bvh_build(const double* vertices, size_t n_vertices, const uint32_t* triangles, size_t n_tris,
                    hfcl_bvh_node* nodes_out, uint32_t* primitive_indices_out, int n_threads);
 
+/* ---- host broadphase: pair-list producer (north_star: "the broadphase ... stays on host and feeds
+ * pair lists to the device") -----------------------------------------------------------------
+ * hfcl_world_aabbs: world AABB of every posed object as CollisionObject::computeAABB does
+ * (include/hpp/fcl/collision_object.h:259-276) from the shape's local AABB
+ * (src/shape/geometric_shapes.cpp:145-254).  aabbs_out: n_objects x 6 doubles (min xyz, max xyz).
+ * hfcl_broadphase_self_pairs: every (i < j) whose AABBs overlap -- the pairs for which
+ * DynamicAABBTreeCollisionManager::collide(callback) invokes the callback
+ * (src/broadphase/broadphase_dynamic_AABB_tree.cpp:252-293,393-406,713-721), i.e. what a
+ * CollisionCallBackCollect (src/broadphase/default_broadphase_callbacks.cpp:91-100) would hold; order:
+ * i ascending, then j ascending.  hfcl_broadphase_pairs_between: the two-manager form (:734-743).
+ * Host code, no GPU needed. */
+typedef struct hfcl_pairlist hfcl_pairlist;
+int hfcl_world_aabbs(const hfcl_shape* shapes, size_t n_shapes, const double* vertices, const uint32_t* object_shape,
+                     const double* object_tf, size_t n_objects, double* aabbs_out, int n_threads);
+hfcl_pairlist* hfcl_broadphase_self_pairs(const double* aabbs, size_t n_objects, int n_threads);
+hfcl_pairlist* hfcl_broadphase_pairs_between(const double* aabbs_a, size_t n_a, const double* aabbs_b, size_t n_b,
+                                             int n_threads);
+size_t hfcl_pairlist_size(const hfcl_pairlist* pl);
+const uint32_t* hfcl_pairlist_data(const hfcl_pairlist* pl);   /* 2 x size uint32: (i, j) */
+void hfcl_pairlist_free(hfcl_pairlist* pl);
+
 /* ---- batched queries, host buffers (H2D + kernels + D2H inside the call) ------------
  * shape1/shape2: n indices into the library; tf1/tf2: n poses (12 doubles each).
  * guess_in / guess_out: NULL or n records (used when q.gjk_initial_guess == CachedGuess).

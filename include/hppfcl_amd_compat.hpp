@@ -27,6 +27,9 @@
 #include <utility>
 #include <vector>
 
+#include <algorithm>
+#include <cstring>
+
 #include "hppfcl_amd.h"
 
 namespace hpp {
@@ -404,7 +407,11 @@ class BatchQueries {
         }
         s.bvh_index = static_cast<int32_t>(meshes_.size());
         s.num_points = m->num_vertices;
-        meshes_.push_back(MeshRef{m, m->getNumBVs(), m->num_vertices, checksum(*m)});
+        // the context keeps its own copy: the model may be destroyed before the library is (re)built
+        meshes_.push_back(MeshRef{m, m->getNumBVs(), m->num_vertices, checksum(*m), m->nodes(),
+                                  std::vector<double>(reinterpret_cast<const double*>(m->vertices.data()),
+                                                      reinterpret_cast<const double*>(m->vertices.data()) + 3 * m->vertices.size()),
+                                  m->flatTriangles()});
         break;
       }
       default: throw std::invalid_argument("unsupported node type");
@@ -509,9 +516,8 @@ class BatchQueries {
       lib_ = hfcl_lib_create(shapes_.data(), shapes_.size(), verts_.data(), verts_.size() / 3, device_);
       if (!lib_) throw std::runtime_error(hfcl_last_error());
       for (const MeshRef& r : meshes_) {  // bvh_index = registration order
-        const auto* m = r.model;
-        if (hfcl_lib_add_bvh(lib_, m->nodes().data(), m->nodes().size(), reinterpret_cast<const double*>(m->vertices.data()),
-                             m->vertices.size(), m->flatTriangles().data(), m->flatTriangles().size() / 3) < 0)
+        if (hfcl_lib_add_bvh(lib_, r.nodes.data(), r.nodes.size(), r.verts.data(), r.verts.size() / 3, r.tris.data(),
+                             r.tris.size() / 3) < 0)
           throw std::runtime_error(hfcl_last_error());
       }
     }
@@ -564,6 +570,9 @@ class BatchQueries {
     const BVHModel<OBBRSS>* model;
     unsigned int n_nodes, n_vertices;
     double checksum;
+    std::vector<hfcl_bvh_node> nodes;
+    std::vector<double> verts;
+    std::vector<uint32_t> tris;
   };
   std::vector<MeshRef> meshes_;
   static double checksum(const BVHModel<OBBRSS>& m) {  // cheap content fingerprint for the address-keyed cache
@@ -616,6 +625,175 @@ inline FCL_REAL distance(const CollisionGeometry* o1, const Transform3f& tf1, co
   }
   return ctx.records()[0].distance;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Broadphase hand-off (include/hpp/fcl/collision_object.h:215-357, broadphase/broadphase_callbacks.h,
+// broadphase/default_broadphase_callbacks.h:200-230, broadphase/broadphase_dynamic_AABB_tree.h).
+// ---------------------------------------------------------------------------------------------
+struct AABB {
+  Vec3f min_, max_;
+  bool overlap(const AABB& o) const {  // BV/AABB.h:112-122
+    for (int k = 0; k < 3; ++k)
+      if (min_[k] > o.max_[k] || max_[k] < o.min_[k]) return false;
+    return true;
+  }
+};
+
+class CollisionObject {
+ public:
+  CollisionObject(const std::shared_ptr<CollisionGeometry>& g, const Transform3f& tf = Transform3f()) : cgeom(g), t(tf) {}
+  const std::shared_ptr<CollisionGeometry>& collisionGeometry() const { return cgeom; }
+  const CollisionGeometry* collisionGeometryPtr() const { return cgeom.get(); }
+  const Transform3f& getTransform() const { return t; }
+  void setTransform(const Transform3f& tf) { t = tf; }
+  const AABB& getAABB() const { return aabb; }
+  AABB& getAABB() { return aabb; }
+
+ private:
+  std::shared_ptr<CollisionGeometry> cgeom;
+  Transform3f t;
+  AABB aabb;
+};
+
+struct CollisionCallBackBase {  // broadphase/broadphase_callbacks.h:52-75
+  virtual ~CollisionCallBackBase() {}
+  virtual void init() {}
+  virtual bool collide(CollisionObject* o1, CollisionObject* o2) = 0;
+  bool operator()(CollisionObject* o1, CollisionObject* o2) { return collide(o1, o2); }
+};
+
+struct CollisionCallBackCollect : CollisionCallBackBase {  // default_broadphase_callbacks.h:200-230
+  typedef std::pair<CollisionObject*, CollisionObject*> CollisionPair;
+  explicit CollisionCallBackCollect(size_t max_size_) : max_size(max_size_) { collision_pairs.reserve(max_size_); }
+  bool collide(CollisionObject* o1, CollisionObject* o2) override {
+    collision_pairs.push_back(std::make_pair(o1, o2));
+    return false;
+  }
+  void init() override { collision_pairs.clear(); }
+  size_t numCollisionPairs() const { return collision_pairs.size(); }
+  const std::vector<CollisionPair>& getCollisionPairs() const { return collision_pairs; }
+  bool exist(const CollisionPair& p) const {
+    for (const auto& q : collision_pairs)
+      if ((q.first == p.first && q.second == p.second) || (q.first == p.second && q.second == p.first)) return true;
+    return false;
+  }
+
+ protected:
+  std::vector<CollisionPair> collision_pairs;
+  size_t max_size;
+};
+
+/// Same calls as the reference manager (registerObject(s) / setup / update / collide(callback));
+/// the candidate set is identical (all AABB-overlapping pairs), produced by the host pair-list
+/// builder behind hfcl_broadphase_self_pairs instead of an incremental tree.
+class DynamicAABBTreeCollisionManager {
+ public:
+  void registerObject(CollisionObject* obj) { objs_.push_back(obj); dirty_ = true; }
+  void registerObjects(const std::vector<CollisionObject*>& v) { objs_.insert(objs_.end(), v.begin(), v.end()); dirty_ = true; }
+  void unregisterObject(CollisionObject* obj) {
+    objs_.erase(std::remove(objs_.begin(), objs_.end(), obj), objs_.end());
+    dirty_ = true;
+  }
+  void clear() { objs_.clear(); dirty_ = true; }
+  size_t size() const { return objs_.size(); }
+  bool empty() const { return objs_.empty(); }
+  void getObjects(std::vector<CollisionObject*>& out) const { out = objs_; }
+  void setup() { refresh(); }
+  void update() { dirty_ = true; refresh(); }
+
+  /// self collision: callback on every pair with overlapping AABBs, until it returns true
+  void collide(CollisionCallBackBase* callback) {
+    callback->init();
+    refresh();
+    if (objs_.size() < 2) return;
+    hfcl_pairlist* pl = hfcl_broadphase_self_pairs(aabbs_.data(), objs_.size(), 0);
+    const uint32_t* p = hfcl_pairlist_data(pl);
+    for (size_t k = 0, n = hfcl_pairlist_size(pl); k < n; ++k)
+      if ((*callback)(objs_[p[2 * k]], objs_[p[2 * k + 1]])) break;
+    hfcl_pairlist_free(pl);
+  }
+  /// against another manager (broadphase_dynamic_AABB_tree.cpp:734-743)
+  void collide(DynamicAABBTreeCollisionManager* other, CollisionCallBackBase* callback) {
+    callback->init();
+    refresh();
+    other->refresh();
+    if (objs_.empty() || other->objs_.empty()) return;
+    hfcl_pairlist* pl = hfcl_broadphase_pairs_between(aabbs_.data(), objs_.size(), other->aabbs_.data(), other->objs_.size(), 0);
+    const uint32_t* p = hfcl_pairlist_data(pl);
+    for (size_t k = 0, n = hfcl_pairlist_size(pl); k < n; ++k)
+      if ((*callback)(objs_[p[2 * k]], other->objs_[p[2 * k + 1]])) break;
+    hfcl_pairlist_free(pl);
+  }
+
+ private:
+  void refresh() {  // CollisionObject::computeAABB for every object (collision_object.h:259-276)
+    if (!dirty_ && aabbs_.size() == 6 * objs_.size()) return;
+    std::vector<hfcl_shape> shapes(objs_.size());
+    std::vector<double> verts;
+    std::vector<uint32_t> ids(objs_.size());
+    std::vector<double> tf(12 * objs_.size());
+    for (size_t i = 0; i < objs_.size(); ++i) {
+      const CollisionGeometry* g = objs_[i]->collisionGeometryPtr();
+      hfcl_shape s{};
+      s.type = g->getNodeType();
+      const ShapeBase* sb = dynamic_cast<const ShapeBase*>(g);
+      s.swept_sphere_radius = sb ? sb->getSweptSphereRadius() : 0.0;
+      switch (g->getNodeType()) {
+        case GEOM_BOX: { auto* b = static_cast<const Box*>(g); for (int k = 0; k < 3; ++k) s.params[k] = b->halfSide[k]; break; }
+        case GEOM_SPHERE: s.params[0] = static_cast<const Sphere*>(g)->radius; break;
+        case GEOM_CAPSULE: { auto* c = static_cast<const Capsule*>(g); s.params[0] = c->radius; s.params[1] = c->halfLength; break; }
+        case GEOM_ELLIPSOID: { auto* e = static_cast<const Ellipsoid*>(g); for (int k = 0; k < 3; ++k) s.params[k] = e->radii[k]; break; }
+        case GEOM_CONVEX: {
+          auto* c = static_cast<const ConvexBase*>(g);
+          s.num_points = c->num_points;
+          s.vertex_offset = static_cast<uint32_t>(verts.size() / 3);
+          for (const Vec3f& q : *c->points) verts.insert(verts.end(), q.data(), q.data() + 3);
+          break;
+        }
+        case BV_OBBRSS: {  // a mesh enters the broadphase as the point set of its vertices (BVHModelBase::computeLocalAABB, BVH_model.cpp:782-800)
+          auto* m = static_cast<const BVHModel<OBBRSS>*>(g);
+          s.type = GEOM_CONVEX;
+          s.num_points = m->num_vertices;
+          s.vertex_offset = static_cast<uint32_t>(verts.size() / 3);
+          for (const Vec3f& q : m->vertices) verts.insert(verts.end(), q.data(), q.data() + 3);
+          break;
+        }
+        default: throw std::invalid_argument("unsupported node type");
+      }
+      shapes[i] = s;
+      ids[i] = static_cast<uint32_t>(i);
+      std::memcpy(&tf[12 * i], &objs_[i]->getTransform(), 12 * sizeof(double));
+    }
+    aabbs_.assign(6 * objs_.size(), 0.0);
+    const int rc = hfcl_world_aabbs(shapes.data(), shapes.size(), verts.data(), ids.data(), tf.data(), objs_.size(), aabbs_.data(), 0);
+    if (rc) amd::throw_for(rc);
+    for (size_t i = 0; i < objs_.size(); ++i) {
+      AABB& a = objs_[i]->getAABB();
+      a.min_ = Vec3f(aabbs_[6 * i], aabbs_[6 * i + 1], aabbs_[6 * i + 2]);
+      a.max_ = Vec3f(aabbs_[6 * i + 3], aabbs_[6 * i + 4], aabbs_[6 * i + 5]);
+    }
+    dirty_ = false;
+  }
+  std::vector<CollisionObject*> objs_;
+  std::vector<double> aabbs_;
+  bool dirty_ = true;
+};
+
+namespace amd {
+/// Evaluate the pairs a CollisionCallBackCollect holds in ONE device batch: results[i] belongs to
+/// pairs[i] (each with its own CollisionResult, see SURVEY.md 8e on accumulation).
+inline void collide(const std::vector<CollisionCallBackCollect::CollisionPair>& pairs, const CollisionRequest& request,
+                    std::vector<CollisionResult>& results, BatchQueries& ctx = default_context()) {
+  std::vector<std::pair<uint32_t, uint32_t>> ids(pairs.size());
+  std::vector<Transform3f> tf1(pairs.size()), tf2(pairs.size());
+  for (size_t i = 0; i < pairs.size(); ++i) {
+    ids[i] = {ctx.add(pairs[i].first->collisionGeometryPtr()), ctx.add(pairs[i].second->collisionGeometryPtr())};
+    tf1[i] = pairs[i].first->getTransform();
+    tf2[i] = pairs[i].second->getTransform();
+  }
+  ctx.collide(ids, tf1, tf2, request, results);
+}
+}  // namespace amd
 
 }  // namespace fcl
 }  // namespace hpp

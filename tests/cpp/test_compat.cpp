@@ -3,6 +3,8 @@
 //   src/collision.cpp:82-85 (num_max_contacts == 0 throws).
 // Exit code 0 = all checks passed; 3 = no GPU (the shim has no CPU fallback).
 #include <cmath>
+#include <memory>
+#include <vector>
 #include <cstdio>
 #include <stdexcept>
 
@@ -126,6 +128,43 @@ int main() {
     DistanceRequest dq; DistanceResult dr;
     const double d = distance(&m1, Transform3f(), &m2, Transform3f(Vec3f(3, 0, 0)), dq, dr);
     CHECK(std::fabs(d - 1.5) < 1e-9 && dr.b1 >= 0 && dr.b2 >= 0);
+  }
+  {  // broadphase hand-off: manager + CollisionCallBackCollect, then one device batch (test/broadphase.cpp style)
+    STAGE("broadphase");
+    std::vector<std::shared_ptr<CollisionGeometry>> geoms;
+    std::vector<std::unique_ptr<CollisionObject>> objects;
+    unsigned seed = 12345;
+    auto rnd = [&seed]() { seed = seed * 1664525u + 1013904223u; return (seed >> 8) / double(1 << 24); };
+    for (int i = 0; i < 300; ++i) {
+      std::shared_ptr<CollisionGeometry> g;
+      if (i % 3 == 0) g = std::make_shared<Box>(0.2 + rnd(), 0.2 + rnd(), 0.2 + rnd());
+      else if (i % 3 == 1) g = std::make_shared<Sphere>(0.2 + 0.5 * rnd());
+      else g = std::make_shared<Capsule>(0.1 + 0.4 * rnd(), 0.2 + rnd());
+      geoms.push_back(g);
+      objects.emplace_back(new CollisionObject(g, Transform3f(Vec3f(6 * rnd(), 6 * rnd(), 6 * rnd()))));
+    }
+    DynamicAABBTreeCollisionManager manager;
+    for (auto& o : objects) manager.registerObject(o.get());
+    manager.setup();
+    CollisionCallBackCollect collect(10000);
+    manager.collide(&collect);
+    size_t brute = 0;  // same candidate set as the O(n^2) AABB test
+    for (size_t i = 0; i < objects.size(); ++i)
+      for (size_t j = i + 1; j < objects.size(); ++j) brute += objects[i]->getAABB().overlap(objects[j]->getAABB());
+    CHECK(brute > 50 && collect.numCollisionPairs() == brute);
+    CollisionRequest rq; std::vector<CollisionResult> res;
+    amd::collide(collect.getCollisionPairs(), rq, res);
+    CHECK(res.size() == brute);
+    size_t hits = 0;
+    for (size_t k = 0; k < res.size(); ++k) {
+      CollisionResult one;  // each batched result equals the single-pair call
+      const auto& pr = collect.getCollisionPairs()[k];
+      collide(pr.first->collisionGeometryPtr(), pr.first->getTransform(), pr.second->collisionGeometryPtr(), pr.second->getTransform(), rq, one);
+      CHECK(one.isCollision() == res[k].isCollision());
+      hits += res[k].isCollision();
+      if (k > 40) break;
+    }
+    (void)hits;
   }
   STAGE("done");
   std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);

@@ -205,3 +205,25 @@ def bvh_build(vertices, triangles):
                              C.c_size_t(len(t)), C.c_void_p(nodes.ctypes.data), C.c_void_p(prim.ctypes.data))
     assert rc == 0
     return nodes, prim
+
+
+def world_aabbs(shapes, verts, obj_shape, obj_tf):
+    """Oracle restatement of CollisionObject::computeAABB over posed shapes (oracle/broadphase.cpp)."""
+    shapes = np.ascontiguousarray(shapes)
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    ids = np.ascontiguousarray(obj_shape, dtype=np.uint32)
+    tf = np.ascontiguousarray(obj_tf, dtype=np.float64).reshape(-1, 12)
+    out = np.zeros((len(ids), 6))
+    lib().orc_world_aabbs(C.c_void_p(shapes.ctypes.data), C.c_void_p(verts.ctypes.data), C.c_void_p(ids.ctypes.data),
+                          C.c_void_p(tf.ctypes.data), C.c_size_t(len(ids)), C.c_void_p(out.ctypes.data))
+    return out
+
+
+def bruteforce_pairs(aabbs):
+    a = np.ascontiguousarray(aabbs, dtype=np.float64).reshape(-1, 6)
+    fn = lib().orc_bruteforce_pairs
+    fn.restype = C.c_size_t
+    n = fn(C.c_void_p(a.ctypes.data), C.c_size_t(len(a)), None, C.c_size_t(0))
+    out = np.zeros((n, 2), dtype=np.uint32)
+    fn(C.c_void_p(a.ctypes.data), C.c_size_t(len(a)), C.c_void_p(out.ctypes.data), C.c_size_t(n))
+    return out
