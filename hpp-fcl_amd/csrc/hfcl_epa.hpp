@@ -279,6 +279,35 @@ struct Epa {
     }
   }
 
+  // The same walk without the stock-level bookkeeping (valid whenever the horizon has no more edges
+  // than there are free faces, checked by the caller): plain pre-order traversal, one frame per
+  // visited face.  Children are pushed second-edge first so that the first-edge subtree is walked
+  // first, as in the recursion; the three expand() calls of :1266-1268 are the three root frames.
+  HFCL_HD void silhouette_walk_fast(int pass, int closest, T dummy_precision, const V3<T>& ww, int& hz_count,
+                                    int& stop_kind, int& stop_at) {
+    int sp = 0;
+    m->stack[sp++] = uint16_t(m->fadj[2][closest] | (adj_edge(closest, 2) << 8));
+    m->stack[sp++] = uint16_t(m->fadj[1][closest] | (adj_edge(closest, 1) << 8));
+    m->stack[sp++] = uint16_t(m->fadj[0][closest] | (adj_edge(closest, 0) << 8));
+    while (sp > 0) {
+      const unsigned fr = m->stack[--sp];
+      const int f = fr & 255, e = (fr >> 8) & 3;
+      if (m->fpass[f] == pass) {
+        stop_kind = EPA_INVALID_HULL;
+        stop_at = hz_count;
+        return;
+      }
+      if (dot(fn(f), ww - vw(m->fvid[e][f])) < dummy_precision) {
+        m->hz[hz_count++] = uint16_t(fr);
+        continue;
+      }
+      m->fpass[f] = uint8_t(pass);
+      const int e1 = (e + 1) % 3, e2 = (e + 2) % 3;
+      m->stack[sp++] = uint16_t(m->fadj[e2][f] | (adj_edge(f, e2) << 8));
+      m->stack[sp++] = uint16_t(m->fadj[e1][f] | (adj_edge(f, e1) << 8));
+    }
+  }
+
   // One polytope expansion by vertex id_w seen from face `closest` (the body of the loop
   // :1261-1280).  Returns true when the hull was updated (valid && horizon >= 3); on false the
   // caller leaves the loop and `status` is what the reference's first failing step sets.
@@ -290,9 +319,24 @@ struct Epa {
     // fp64 oracle on the cfg2/cfg3/cfg5 sets.
     const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
     const V3<T> ww = vw(id_w);
-    int hz_count = 0, level = stock_top, stop_kind = 0, stop_at = 0;
-    for (int j = 0; j < 3 && !stop_kind; ++j)
-      silhouette_walk(pass, m->fadj[j][closest], adj_edge(closest, j), dummy_precision, ww, hz_count, level, stop_kind, stop_at);
+    int hz_count = 0, stop_kind = 0, stop_at = 0;
+    silhouette_walk_fast(pass, closest, dummy_precision, ww, hz_count, stop_kind, stop_at);
+    if (hz_count > stock_top) {
+      // More horizon edges than free faces: whether (and where) the reference runs out of faces
+      // depends on how its pops and pushes interleave -> undo the marks and redo the walk with
+      // the stock level tracked (rare: only near the capacity of the face store).
+      const int nf = 2 * cap_iterations + 4;
+      Grp::sync();
+      for (int f = Grp::lane(); f < nf; f += Grp::W)
+        if ((m->fflag[f] & 1) && m->fpass[f] == pass && f != closest) m->fpass[f] = 0;
+      Grp::sync();
+      hz_count = 0;
+      stop_kind = 0;
+      stop_at = 0;
+      int level = stock_top;
+      for (int j = 0; j < 3 && !stop_kind; ++j)
+        silhouette_walk(pass, m->fadj[j][closest], adj_edge(closest, j), dummy_precision, ww, hz_count, level, stop_kind, stop_at);
+    }
     const int n_new = stop_kind ? stop_at : hz_count;
     Grp::sync();
     // 1. visible faces (pass mark, includes `closest`) leave the hull and return to the stock

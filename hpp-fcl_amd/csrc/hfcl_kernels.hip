@@ -436,6 +436,10 @@ constexpr int EPA_FAST_CAP = HFCL_EPA_FAST_CAP;
 #define HFCL_EPA_WE 8
 #endif
 constexpr int EPA_WE = HFCL_EPA_WE;
+#ifndef HFCL_EPA_WE2
+#define HFCL_EPA_WE2 16
+#endif
+constexpr int EPA_WE2 = HFCL_EPA_WE2;  // lanes per polytope in the full-capacity tier
 
 template <typename T, int WE>
 struct EpaSupport {  // any pair kind, evaluated by one lane group
@@ -1325,7 +1329,7 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
     hipEventRecord(t->e1, st);
     t = timer_slot(lib, ti++, "k_epa<full>");
     hipEventRecord(t->e0, st);
-    hipLaunchKernelGGL((k_epa<T, 8, EPA_MAX_ITER, 2>), dim3(blocks_for(n / 64 + 1, 8)), dim3(64), 0, st, wk, lv, io, q);
+    hipLaunchKernelGGL((k_epa<T, EPA_WE2, EPA_MAX_ITER, 2>), dim3(blocks_for(n / 16 + 1, 64 / EPA_WE2)), dim3(64), 0, st, wk, lv, io, q);
     hipEventRecord(t->e1, st);
   }
   HIP_TRY(hipMemcpyAsync(lib->h_counts, lib->d_counts, (B_COUNT + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
