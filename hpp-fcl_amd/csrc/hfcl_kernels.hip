@@ -35,6 +35,9 @@ using namespace hfcl;
 // k_epa carries no occupancy attribute on purpose: forcing the fp64 instantiation to 2 waves/SIMD
 // (488 B/lane of scratch) produced wrong EPA results on gfx950 (profiles/r01_c_waves_per_eu_ab.txt);
 // the compiler's own choice (fp32: 2 waves, fp64: 1 wave + AGPRs) is what the parity tests cover.
+#ifndef HFCL_WPE_GJK64
+#define HFCL_WPE_GJK64 2
+#endif
 #ifndef HFCL_WPE_PRIM
 #define HFCL_WPE_PRIM 2
 #endif
@@ -389,7 +392,7 @@ struct CvxSupport {
 };
 
 template <typename T, int W, int M>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_GJK, 8))) k_gjk_cvx(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+__device__ __forceinline__ void gjk_cvx_body(const Work& wk, const LibView<T>& lib, const IO<T>& io, const QParams<T>& q) {
   constexpr int BUCKET = (M == 0) ? B_CC : (M == 1 ? B_PC : B_CP);
   const uint32_t cnt = wk.counts[BUCKET];
   const int lig = threadIdx.x & (W - 1);
@@ -411,6 +414,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_W
     gjk_run(g, q.gjk, guess0, r0 + r1, M == 0, sup);
     finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0);
   }
+}
+
+// Two entry points so that each precision gets its own register budget (waves per SIMD): the fp64
+// instantiation spills heavily at the fp32 setting (A/B in profiles/).
+template <int W, int M>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_GJK, 8)))
+k_gjk_cvx(Work wk, LibView<float> lib, IO<float> io, QParams<float> q) {
+  gjk_cvx_body<float, W, M>(wk, lib, io, q);
+}
+template <int W, int M>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_GJK64, 8)))
+k_gjk_cvx64(Work wk, LibView<double> lib, IO<double> io, QParams<double> q) {
+  gjk_cvx_body<double, W, M>(wk, lib, io, q);
+}
+template <int W, int M>
+static void launch_gjk_cvx(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q) {
+  hipLaunchKernelGGL((k_gjk_cvx<W, M>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+}
+template <int W, int M>
+static void launch_gjk_cvx(int grid, hipStream_t st, const Work& wk, const LibView<double>& lv, const IO<double>& io, const QParams<double>& q) {
+  hipLaunchKernelGGL((k_gjk_cvx64<W, M>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1222,15 +1246,15 @@ static void launch_cvx(hfcl_lib* lib, const Work& wk, const LibView<T>& lv, cons
   KernelTime* t;
   t = timer_slot(lib, ti++, "k_gjk_cvx<cc>");
   hipEventRecord(t->e0, st);
-  hipLaunchKernelGGL((k_gjk_cvx<T, W, 0>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+  launch_gjk_cvx<W, 0>(grid, st, wk, lv, io, q);
   hipEventRecord(t->e1, st);
   t = timer_slot(lib, ti++, "k_gjk_cvx<pc>");
   hipEventRecord(t->e0, st);
-  hipLaunchKernelGGL((k_gjk_cvx<T, W, 1>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+  launch_gjk_cvx<W, 1>(grid, st, wk, lv, io, q);
   hipEventRecord(t->e1, st);
   t = timer_slot(lib, ti++, "k_gjk_cvx<cp>");
   hipEventRecord(t->e0, st);
-  hipLaunchKernelGGL((k_gjk_cvx<T, W, 2>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+  launch_gjk_cvx<W, 2>(grid, st, wk, lv, io, q);
   hipEventRecord(t->e1, st);
 }
 

@@ -42,7 +42,8 @@ def check_parity(abi, got, ref, *, dist_tol, point_tol, flag_band, name="", allo
                  flag_mismatch=int(bad_flags.sum()), gjk_status_mismatch=int((~gjk_eq & ~near).sum()),
                  epa_status_mismatch=int((~epa_eq & ~near).sum()), dist_bad=int(bad_d.sum()),
                  nan_mismatch=int(bad_nan.sum()), sep_bad=int(bad_sep.sum()),
-                 max_dd=float(dd.max()) if n else 0.0, max_dsep=float(dsep.max()) if n else 0.0)
+                 max_dd=float(dd.max()) if n else 0.0,
+                 p999_dd=float(np.quantile(dd, 0.999)) if n else 0.0, max_dsep=float(dsep.max()) if n else 0.0)
     allowed = int(allow_bad_frac * n)
     assert stats["flag_mismatch"] <= allowed, "%s: contact flags differ outside the decision band: %s" % (name, stats)
     assert stats["dist_bad"] <= allowed, "%s: distances out of tolerance: %s" % (name, stats)
