@@ -8,6 +8,8 @@ BV_OBBRSS = 5
 GEOM_BOX = 9
 GEOM_SPHERE = 10
 GEOM_CAPSULE = 11
+GEOM_CONE = 12
+GEOM_CYLINDER = 13
 GEOM_CONVEX = 14
 GEOM_TRIANGLE = 17
 GEOM_ELLIPSOID = 19

@@ -46,6 +46,8 @@ Box3 shape_local_box(const hfcl_shape& s, const double* verts) {
     case HFCL_GEOM_ELLIPSOID: symmetric(s.params[0], s.params[1], s.params[2]); break;
     case HFCL_GEOM_SPHERE: symmetric(s.params[0], s.params[0], s.params[0]); break;
     case HFCL_GEOM_CAPSULE: symmetric(s.params[0], s.params[0], s.params[1] + s.params[0]); break;
+    case HFCL_GEOM_CONE:
+    case HFCL_GEOM_CYLINDER: symmetric(std::abs(s.params[0]), std::abs(s.params[0]), std::abs(s.params[1])); break;
     default: {  // point sets: Convex, Triangle
       const double big = std::numeric_limits<double>::max();
       for (int k = 0; k < 3; ++k) {
@@ -200,7 +202,7 @@ int hfcl_world_aabbs(const hfcl_shape* shapes, size_t n_shapes, const double* ve
   for (size_t s = 0; s < n_shapes; ++s) {
     const int t = shapes[s].type;
     if (t != HFCL_GEOM_BOX && t != HFCL_GEOM_SPHERE && t != HFCL_GEOM_CAPSULE && t != HFCL_GEOM_ELLIPSOID &&
-        t != HFCL_GEOM_CONVEX && t != HFCL_GEOM_TRIANGLE)
+        t != HFCL_GEOM_CONVEX && t != HFCL_GEOM_TRIANGLE && t != HFCL_GEOM_CONE && t != HFCL_GEOM_CYLINDER)
       return HFCL_ERR_UNSUPPORTED_PAIR;
     if ((t == HFCL_GEOM_CONVEX || t == HFCL_GEOM_TRIANGLE) && (!vertices || shapes[s].num_points == 0))
       return HFCL_ERR_INVALID_ARGUMENT;

@@ -954,7 +954,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
     const hfcl_shape& s = shapes[i];
     const bool ok_kind = s.type == HFCL_GEOM_BOX || s.type == HFCL_GEOM_SPHERE || s.type == HFCL_GEOM_CAPSULE ||
                          s.type == HFCL_GEOM_ELLIPSOID || s.type == HFCL_GEOM_CONVEX || s.type == HFCL_BV_OBBRSS ||
-                         s.type == HFCL_GEOM_TRIANGLE;
+                         s.type == HFCL_GEOM_TRIANGLE || s.type == HFCL_GEOM_CONE || s.type == HFCL_GEOM_CYLINDER;
     if (!ok_kind) {
       set_error("hfcl_lib_create: unsupported shape type " + std::to_string(s.type));
       return nullptr;

@@ -1,17 +1,17 @@
 // hfcl_shapes.hpp -- device shape records, primitive support functions, closed-form pairs.
 //
 // Behavioural contract (reference file:line):
-//   supports      src/narrowphase/support_functions.cpp:140-222 (Box, Sphere, Ellipsoid, Capsule;
+//   supports      src/narrowphase/support_functions.cpp:140-317 (Box, Sphere, Ellipsoid, Capsule, Cone, Cylinder;
 //                 NoSweptSphere option: sphere/capsule radii are added back after GJK/EPA,
 //                 src/narrowphase/minkowski_difference.cpp:103-125,183-201)
 //   closed forms  src/narrowphase/details.h:52-101 (sphere-capsule), :215-232 (sphere-sphere),
-//                 :435-495 (box-sphere), src/distance/capsule_capsule.cpp:52-167
+//                 :435-495 (box-sphere), :107-209 (sphere-cylinder), src/distance/capsule_capsule.cpp:52-167
 #pragma once
 #include "hfcl_math.hpp"
 
 namespace hfcl {
 
-enum { K_BOX = 9, K_SPHERE = 10, K_CAPSULE = 11, K_CONVEX = 14, K_TRIANGLE = 17, K_ELLIPSOID = 19, K_BVH = 5 };
+enum { K_BOX = 9, K_SPHERE = 10, K_CAPSULE = 11, K_CONE = 12, K_CYLINDER = 13, K_CONVEX = 14, K_TRIANGLE = 17, K_ELLIPSOID = 19, K_BVH = 5 };
 
 // Device image of one shape-library entry (both an fp64 and an fp32 table are resident).
 template <typename T>
@@ -28,7 +28,9 @@ struct DShape {
 // (include/hpp/fcl/internal/shape_shape_func.h:185-211)
 enum { CLS_CLOSED = 0, CLS_PRIM_GJK = 1, CLS_CONVEX = 2, CLS_BVH = 3, CLS_UNSUPPORTED = 4, CLS_COUNT = 5 };
 
-HFCL_HD bool kind_is_prim(int k) { return k == K_BOX || k == K_SPHERE || k == K_CAPSULE || k == K_ELLIPSOID; }
+HFCL_HD bool kind_is_prim(int k) {
+  return k == K_BOX || k == K_SPHERE || k == K_CAPSULE || k == K_ELLIPSOID || k == K_CONE || k == K_CYLINDER;
+}
 HFCL_HD int pair_class(int k1, int k2) {
   if (k1 == K_BVH && k2 == K_BVH) return CLS_BVH;
   const bool p1 = kind_is_prim(k1), p2 = kind_is_prim(k2);
@@ -36,6 +38,7 @@ HFCL_HD int pair_class(int k1, int k2) {
     const bool sc1 = (k1 == K_SPHERE || k1 == K_CAPSULE), sc2 = (k2 == K_SPHERE || k2 == K_CAPSULE);
     if (sc1 && sc2) return CLS_CLOSED;                                              // sph-sph, sph-cap, cap-cap
     if ((k1 == K_BOX && k2 == K_SPHERE) || (k1 == K_SPHERE && k2 == K_BOX)) return CLS_CLOSED;  // box-sphere
+    if ((k1 == K_CYLINDER && k2 == K_SPHERE) || (k1 == K_SPHERE && k2 == K_CYLINDER)) return CLS_CLOSED;
     return CLS_PRIM_GJK;
   }
   if ((p1 || k1 == K_CONVEX) && (p2 || k2 == K_CONVEX)) return CLS_CONVEX;
@@ -71,6 +74,42 @@ HFCL_HD V3<T> prim_support(const DShape<T>& s, const V3<T>& dir) {
     else if (dir.z < -tiny)
       z = -s.p1;
     return mk<T>(T(0), T(0), z);
+  }
+  if (s.kind == K_CONE) {  // support_functions.cpp:228-274; p0 = radius, p1 = halfLength
+    const T inflate = T(1) + T(1e-10);
+    const T h = s.p1, r = s.p0;
+    if (habs(dir.x) <= tiny && habs(dir.y) <= tiny) return mk<T>(T(0), T(0), (dir.z > tiny) ? h : -inflate * h);
+    T zdist = dir.x * dir.x + dir.y * dir.y;
+    const T len = hsqrt(zdist + dir.z * dir.z);
+    zdist = hsqrt(zdist);
+    const T sin_a = r / hsqrt(r * r + T(4) * h * h);
+    if (dir.z > T(0) && dir.z > len * sin_a) return mk<T>(T(0), T(0), h);
+    const T rad = r / zdist;
+    return mk<T>(rad * dir.x, rad * dir.y, -h);
+  }
+  if (s.kind == K_CYLINDER) {  // support_functions.cpp:280-317
+    const T inflate = T(1) + T(1e-10);
+    T half_h = s.p1, r = s.p0;
+    const bool aligned = habs(dir.x) <= tiny && habs(dir.y) <= tiny;
+    if (aligned) half_h *= inflate;
+    T z;
+    if (dir.z > tiny) {
+      z = half_h;
+    } else if (dir.z < -tiny) {
+      z = -half_h;
+    } else {
+      z = T(0);
+      r *= inflate;
+    }
+    if (aligned) return mk<T>(T(0), T(0), z);
+    const T n2 = dir.x * dir.x + dir.y * dir.y;
+    T nx = dir.x, ny = dir.y;
+    if (n2 > T(0)) {
+      const T n = hsqrt(n2);
+      nx = dir.x / n;
+      ny = dir.y / n;
+    }
+    return mk<T>(nx * r, ny * r, z);
   }
   return mk<T>(T(0), T(0), T(0));  // sphere: a point, radius is swept
 }
@@ -233,6 +272,59 @@ HFCL_HD T box_sphere(const DShape<T>& b, const Pose<T>& tfb, const DShape<T>& s,
   return dist;
 }
 
+// details::sphereCylinderDistance (src/narrowphase/details.h:107-209)
+template <typename T>
+HFCL_HD T sphere_cylinder(const DShape<T>& s1, const Pose<T>& tf1, const DShape<T>& s2, const Pose<T>& tf2, V3<T>& p1,
+                          V3<T>& p2, V3<T>& normal) {
+  const T eps = hsqrt(Lim<T>::eps());
+  const T r1 = s1.p0, r2 = s2.p0, lz2 = s2.p1;
+  const V3<T> A = xform(tf2, mk<T>(T(0), T(0), -lz2)), B = xform(tf2, mk<T>(T(0), T(0), lz2));
+  const V3<T> S = tf1.t;
+  const V3<T> u = mk<T>(tf2.R.r0.z, tf2.R.r1.z, tf2.R.r2.z);  // column 2
+  const T s = dot(u, S - A);
+  const V3<T> P = A + u * s;
+  const V3<T> PS = S - P;
+  const T dPS = norm(PS);
+  V3<T> v = mk<T>(T(0), T(0), T(0));
+  if (dPS > eps) v = PS * (T(1) / dPS);
+  T dist;
+  const bool below = s <= T(0), inside = !below && s <= lz2 * T(2);
+  if (inside) {
+    normal = -v;
+    dist = dPS - r1 - r2;
+    p2 = P + v * r2;
+    p1 = S - v * r1;
+  } else {
+    const V3<T> C = below ? A : B;            // centre of the nearer cap
+    const V3<T> un = below ? u : -u;          // normal when the cap's disc is closest
+    if (dPS <= r2) {
+      dist = (below ? -s : s - lz2 * T(2)) - r1;
+      p1 = S + un * r1;
+      p2 = C + v * dPS;
+      normal = un;
+    } else {  // the cap's rim is closest
+      p2 = C + v * r2;
+      const V3<T> Sp2 = p2 - S;
+      const T dSp2 = norm(Sp2);
+      if (dSp2 > eps) {
+        normal = Sp2 * (T(1) / dSp2);
+        p1 = S + normal * r1;
+        dist = dSp2 - r1;
+      } else {
+        normal = normalized(p2 - (A + B) * T(.5));
+        dist = -r1;
+        p1 = S + normal * r1;
+      }
+    }
+  }
+  if (s1.ssr > T(0) || s2.ssr > T(0)) {
+    p1 = p1 + normal * s1.ssr;
+    p2 = p2 - normal * s2.ssr;
+    dist -= (s1.ssr + s2.ssr);
+  }
+  return dist;
+}
+
 // Dispatch of the CLS_CLOSED bucket incl. the operand swaps of sphere_capsule.cpp:60-71 and
 // box_sphere.cpp:62-75.
 template <typename T>
@@ -247,6 +339,12 @@ HFCL_HD T closed_form_distance(const DShape<T>& s1, const Pose<T>& tf1, const DS
   }
   if (s1.kind == K_CAPSULE && s2.kind == K_CAPSULE) return capsule_capsule(s1, tf1, s2, tf2, p1, p2, n);
   if (s1.kind == K_BOX && s2.kind == K_SPHERE) return box_sphere(s1, tf1, s2, tf2, p1, p2, n);
+  if (s1.kind == K_SPHERE && s2.kind == K_CYLINDER) return sphere_cylinder(s1, tf1, s2, tf2, p1, p2, n);
+  if (s1.kind == K_CYLINDER && s2.kind == K_SPHERE) {  // sphere_cylinder.cpp:63-74
+    const T d = sphere_cylinder(s2, tf2, s1, tf1, p2, p1, n);
+    n = -n;
+    return d;
+  }
   // sphere - box
   const T d = box_sphere(s2, tf2, s1, tf1, p2, p1, n);
   n = -n;

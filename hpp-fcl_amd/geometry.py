@@ -30,6 +30,13 @@ class ShapeLibrary:
         """Capsule(radius, lz): halfLength = lz/2   geometric_shapes.h:386-387"""
         return self._add(abi.GEOM_CAPSULE, (radius, lz / 2.0, 0), swept_sphere_radius)
 
+    def add_cone(self, radius, lz, swept_sphere_radius=0.0):
+        """Cone(radius, lz): params = (radius, halfLength)  (geometric_shapes.h:437-500)."""
+        return self._add(abi.GEOM_CONE, (radius, lz / 2.0, 0), swept_sphere_radius)
+
+    def add_cylinder(self, radius, lz, swept_sphere_radius=0.0):
+        return self._add(abi.GEOM_CYLINDER, (radius, lz / 2.0, 0), swept_sphere_radius)
+
     def add_ellipsoid(self, rx, ry, rz, swept_sphere_radius=0.0):
         return self._add(abi.GEOM_ELLIPSOID, (rx, ry, rz), swept_sphere_radius)
 

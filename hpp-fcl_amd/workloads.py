@@ -156,6 +156,20 @@ def _mixed_library(rng, nper):
     return lib
 
 
+def all_primitives(n=100_000, seed=1, nper=128, half_width=0.8, kind="collide"):
+    """Every supported shape kind against every other (Box, Sphere, Capsule, Cone, Cylinder, Ellipsoid,
+    Convex32): exercises the whole dispatch table of shape_shape_func.h:185-211 that is in scope."""
+    rng = _rng(seed, 6)
+    lib = _mixed_library(rng, nper)
+    for r, lz in zip(rng.uniform(0.1, 0.8, nper), rng.uniform(0.2, 1.0, nper)):
+        lib.add_cone(float(r), float(lz))
+    for r, lz in zip(rng.uniform(0.1, 0.8, nper), rng.uniform(0.2, 1.0, nper)):
+        lib.add_cylinder(float(r), float(lz))
+    s1, s2 = rng.integers(0, 7 * nper, n), rng.integers(0, 7 * nper, n)
+    q1, T1, q2, T2 = _poses(rng, n, half_width)
+    return Batch("all_primitives_" + kind, lib, s1, s2, q1, T1, q2, T2, kind)
+
+
 def cfg5_mixed(n=100_000, seed=1, nper=256, half_width=0.8):
     """cfg5-style mixed primitive+convex pairs (type mix 20 % each of Box/Sphere/Capsule/
     Ellipsoid/Convex32), synthetic pair list (cfg5_broadphase_scene takes its pairs from the host broadphase)."""

@@ -37,6 +37,8 @@ enum {
   HFCL_GEOM_BOX      = 9,  /* params = halfSide[3]      (geometric_shapes.h:164) */
   HFCL_GEOM_SPHERE   = 10, /* params[0] = radius        (geometric_shapes.h:238) */
   HFCL_GEOM_CAPSULE  = 11, /* params[0] = radius, [1] = halfLength (:381-400)    */
+  HFCL_GEOM_CONE     = 12, /* params[0] = radius, [1] = halfLength (geometric_shapes.h:437-500) */
+  HFCL_GEOM_CYLINDER = 13, /* params[0] = radius, [1] = halfLength (:505-570)           */
   HFCL_GEOM_CONVEX   = 14, /* num_points vertices at vertex_offset (:638-872)    */
   HFCL_GEOM_TRIANGLE = 17, /* 3 vertices at vertex_offset (TriangleP, :109)      */
   HFCL_GEOM_ELLIPSOID= 19  /* params = radii[3]         (geometric_shapes.h:303) */

@@ -115,6 +115,7 @@ static_assert(sizeof(Transform3f) == HFCL_POSE_DOUBLES * sizeof(double), "Transf
 
 enum NODE_TYPE {  // include/hpp/fcl/collision_object.h:65-89 (subset in scope)
   BV_OBBRSS = HFCL_BV_OBBRSS, GEOM_BOX = HFCL_GEOM_BOX, GEOM_SPHERE = HFCL_GEOM_SPHERE, GEOM_CAPSULE = HFCL_GEOM_CAPSULE,
+  GEOM_CONE = HFCL_GEOM_CONE, GEOM_CYLINDER = HFCL_GEOM_CYLINDER,
   GEOM_CONVEX = HFCL_GEOM_CONVEX, GEOM_TRIANGLE = HFCL_GEOM_TRIANGLE, GEOM_ELLIPSOID = HFCL_GEOM_ELLIPSOID
 };
 enum GJKInitialGuess { DefaultGuess, CachedGuess, BoundingVolumeGuess };
@@ -157,6 +158,18 @@ class Capsule : public ShapeBase {
   Capsule(FCL_REAL r, FCL_REAL lz) : radius(r), halfLength(lz / 2) {}
   FCL_REAL radius, halfLength;
   NODE_TYPE getNodeType() const override { return GEOM_CAPSULE; }
+};
+class Cone : public ShapeBase {
+ public:
+  Cone(FCL_REAL r, FCL_REAL lz) : radius(r), halfLength(lz / 2) {}
+  FCL_REAL radius, halfLength;
+  NODE_TYPE getNodeType() const override { return GEOM_CONE; }
+};
+class Cylinder : public ShapeBase {
+ public:
+  Cylinder(FCL_REAL r, FCL_REAL lz) : radius(r), halfLength(lz / 2) {}
+  FCL_REAL radius, halfLength;
+  NODE_TYPE getNodeType() const override { return GEOM_CYLINDER; }
 };
 class Ellipsoid : public ShapeBase {
  public:
@@ -386,6 +399,8 @@ class BatchQueries {
       case GEOM_BOX: { auto* b = static_cast<const Box*>(g); for (int i = 0; i < 3; ++i) s.params[i] = b->halfSide[i]; break; }
       case GEOM_SPHERE: s.params[0] = static_cast<const Sphere*>(g)->radius; break;
       case GEOM_CAPSULE: { auto* c = static_cast<const Capsule*>(g); s.params[0] = c->radius; s.params[1] = c->halfLength; break; }
+      case GEOM_CONE: { auto* c = static_cast<const Cone*>(g); s.params[0] = c->radius; s.params[1] = c->halfLength; break; }
+      case GEOM_CYLINDER: { auto* c = static_cast<const Cylinder*>(g); s.params[0] = c->radius; s.params[1] = c->halfLength; break; }
       case GEOM_ELLIPSOID: { auto* e = static_cast<const Ellipsoid*>(g); for (int i = 0; i < 3; ++i) s.params[i] = e->radii[i]; break; }
       case GEOM_CONVEX: {
         auto* c = static_cast<const ConvexBase*>(g);
@@ -742,6 +757,8 @@ class DynamicAABBTreeCollisionManager {
         case GEOM_BOX: { auto* b = static_cast<const Box*>(g); for (int k = 0; k < 3; ++k) s.params[k] = b->halfSide[k]; break; }
         case GEOM_SPHERE: s.params[0] = static_cast<const Sphere*>(g)->radius; break;
         case GEOM_CAPSULE: { auto* c = static_cast<const Capsule*>(g); s.params[0] = c->radius; s.params[1] = c->halfLength; break; }
+        case GEOM_CONE: { auto* c = static_cast<const Cone*>(g); s.params[0] = c->radius; s.params[1] = c->halfLength; break; }
+        case GEOM_CYLINDER: { auto* c = static_cast<const Cylinder*>(g); s.params[0] = c->radius; s.params[1] = c->halfLength; break; }
         case GEOM_ELLIPSOID: { auto* e = static_cast<const Ellipsoid*>(g); for (int k = 0; k < 3; ++k) s.params[k] = e->radii[k]; break; }
         case GEOM_CONVEX: {
           auto* c = static_cast<const ConvexBase*>(g);

@@ -29,6 +29,12 @@ void local_aabb(const hfcl_shape& s, const double* verts, double mn[3], double m
       d[1] = 0 * s.params[1] + s.params[0];
       d[2] = 1 * s.params[1] + s.params[0];
       break;
+    case HFCL_GEOM_CONE:      // :334-366 with R = I: (|r| + 0 + 0, 0 + |r| + 0, 0 + 0 + |halfLength|)
+    case HFCL_GEOM_CYLINDER:
+      d[0] = std::fabs(1 * s.params[0]) + std::fabs(0 * s.params[0]) + std::fabs(0 * s.params[1]);
+      d[1] = std::fabs(0 * s.params[0]) + std::fabs(1 * s.params[0]) + std::fabs(0 * s.params[1]);
+      d[2] = std::fabs(0 * s.params[0]) + std::fabs(0 * s.params[0]) + std::fabs(1 * s.params[1]);
+      break;
     default: have = false;
   }
   if (have) {

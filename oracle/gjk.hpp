@@ -18,7 +18,7 @@
 
 namespace orc {
 
-enum ShapeKind { K_BOX = 9, K_SPHERE = 10, K_CAPSULE = 11, K_CONVEX = 14, K_TRIANGLE = 17, K_ELLIPSOID = 19 };
+enum ShapeKind { K_BOX = 9, K_SPHERE = 10, K_CAPSULE = 11, K_CONE = 12, K_CYLINDER = 13, K_CONVEX = 14, K_TRIANGLE = 17, K_ELLIPSOID = 19 };
 
 struct Shape {
   int kind = 0;
@@ -74,6 +74,63 @@ inline V3 shape_support(const Shape& s, const V3& dir, int& hint) {
       else if (dir[2] < -kDummyPrecision)
         r[2] = -s.p[1];
       return r;
+    }
+    case K_CONE: {  // :228-274  p[0] = radius, p[1] = halfLength
+      const double inflate = 1 + 1e-10;
+      const double h = s.p[1], r = s.p[0];
+      V3 sup(0, 0, 0);
+      if (std::abs(dir[0]) <= kDummyPrecision && std::abs(dir[1]) <= kDummyPrecision) {  // head<2>().isZero()
+        sup[2] = (dir[2] > kDummyPrecision) ? h : -inflate * h;
+      } else {
+        double zdist = dir[0] * dir[0] + dir[1] * dir[1];
+        double len = zdist + dir[2] * dir[2];
+        zdist = std::sqrt(zdist);
+        if (dir[2] <= 0) {
+          const double rad = r / zdist;
+          sup[0] = rad * dir[0];
+          sup[1] = rad * dir[1];
+          sup[2] = -h;
+        } else {
+          len = std::sqrt(len);
+          const double sin_a = r / std::sqrt(r * r + 4 * h * h);
+          if (dir[2] > len * sin_a) {
+            sup = V3(0, 0, h);
+          } else {
+            const double rad = r / zdist;
+            sup[0] = rad * dir[0];
+            sup[1] = rad * dir[1];
+            sup[2] = -h;
+          }
+        }
+      }
+      return sup;
+    }
+    case K_CYLINDER: {  // :280-317
+      const double inflate = 1 + 1e-10;
+      double half_h = s.p[1], r = s.p[0];
+      const bool aligned = std::abs(dir[0]) <= kDummyPrecision && std::abs(dir[1]) <= kDummyPrecision;
+      if (aligned) half_h *= inflate;
+      V3 sup(0, 0, 0);
+      if (dir[2] > kDummyPrecision) {
+        sup[2] = half_h;
+      } else if (dir[2] < -kDummyPrecision) {
+        sup[2] = -half_h;
+      } else {
+        sup[2] = 0;
+        r *= inflate;
+      }
+      if (!aligned) {  // dir.head<2>().normalized() * r
+        const double n2 = dir[0] * dir[0] + dir[1] * dir[1];
+        double nx = dir[0], ny = dir[1];
+        if (n2 > 0) {
+          const double n = std::sqrt(n2);
+          nx = dir[0] / n;
+          ny = dir[1] / n;
+        }
+        sup[0] = nx * r;
+        sup[1] = ny * r;
+      }
+      return sup;
     }
     case K_CONVEX: {  // getShapeSupportLinear :400-421 (num_points <= 32 path)
       hint = 0;

@@ -208,6 +208,69 @@ static double sphere_sphere(const Shape& s1, const Tf& tf1, const Shape& s2, con
   return dist;
 }
 
+// details::sphereCylinderDistance :107-209
+static double sphere_cylinder(const Shape& s1, const Tf& tf1, const Shape& s2, const Tf& tf2, V3& p1, V3& p2,
+                              V3& normal) {
+  const double eps = std::sqrt(std::numeric_limits<double>::epsilon());
+  const double r1 = s1.p[0], r2 = s2.p[0], lz2 = s2.p[1];
+  const V3 A = tf2.transform(V3(0, 0, -lz2)), B = tf2.transform(V3(0, 0, lz2));
+  const V3 S = tf1.T;
+  const V3 u = tf2.R.col(2);
+  const V3 AS = S - A;
+  const double s = dot(u, AS);
+  const V3 P = A + u * s;
+  const V3 PS = S - P;
+  const double dPS = norm(PS);
+  V3 v(0, 0, 0);
+  double dist;
+  if (dPS > eps) v = PS * (1 / dPS);
+  auto rim = [&](const V3& C) {  // closest point on a cylinder circle basis
+    p2 = C + v * r2;
+    const V3 Sp2 = p2 - S;
+    const double dSp2 = norm(Sp2);
+    if (dSp2 > eps) {
+      normal = Sp2 * (1 / dSp2);
+      p1 = S + normal * r1;
+      dist = dSp2 - r1;
+    } else {  // centre of the sphere on the cylinder boundary
+      normal = normalized(p2 - (A + B) * .5);
+      dist = -r1;
+      p1 = S + normal * r1;
+    }
+  };
+  if (s <= 0) {
+    if (dPS <= r2) {
+      dist = -s - r1;
+      p1 = S + u * r1;
+      p2 = A + v * dPS;
+      normal = u;
+    } else {
+      rim(A);
+    }
+  } else if (s <= (lz2 * 2)) {
+    normal = -v;
+    dist = dPS - r1 - r2;
+    p2 = P + v * r2;
+    p1 = S - v * r1;
+  } else {
+    if (dPS <= r2) {
+      dist = s - (lz2 * 2) - r1;
+      p1 = S - u * r1;
+      p2 = B + v * dPS;
+      normal = -u;
+    } else {
+      rim(B);
+    }
+  }
+  const double ssr1 = s1.ssr, ssr2 = s2.ssr;
+  if (ssr1 > 0 || ssr2 > 0) {
+    p1 = p1 + normal * ssr1;
+    p2 = p2 - normal * ssr2;
+    dist -= (ssr1 + ssr2);
+  }
+  return dist;
+}
+
 // details::lineSegmentPointClosestToPoint :52-70 + sphereCapsuleDistance :76-101
 static double sphere_capsule(const Shape& s1, const Tf& tf1, const Shape& s2, const Tf& tf2, V3& p1, V3& p2,
                              V3& normal) {
@@ -417,7 +480,8 @@ static double triangle_triangle(const Shape& s1, const Tf& tf1, const Shape& s2,
 bool shape_shape_distance(const Shape& s1, const Tf& tf1, const Shape& s2, const Tf& tf2, const GJKSolver& solver,
                           bool compute_signed_distance, double& dist, V3& p1, V3& p2, V3& normal) {
   auto is_gjk_kind = [](int k) {
-    return k == K_BOX || k == K_SPHERE || k == K_CAPSULE || k == K_ELLIPSOID || k == K_CONVEX;
+    return k == K_BOX || k == K_SPHERE || k == K_CAPSULE || k == K_ELLIPSOID || k == K_CONVEX || k == K_CONE ||
+           k == K_CYLINDER;
   };
   solver.stats = SolverStats();
   // closed-form table, shape_shape_func.h:185-211 + 281-306
@@ -444,6 +508,15 @@ bool shape_shape_distance(const Shape& s1, const Tf& tf1, const Shape& s2, const
   }
   if (s1.kind == K_SPHERE && s2.kind == K_BOX) {  // box_sphere.cpp:62-75
     dist = box_sphere(s2, tf2, s1, tf1, p2, p1, normal);
+    normal = -normal;
+    return true;
+  }
+  if (s1.kind == K_SPHERE && s2.kind == K_CYLINDER) {
+    dist = sphere_cylinder(s1, tf1, s2, tf2, p1, p2, normal);
+    return true;
+  }
+  if (s1.kind == K_CYLINDER && s2.kind == K_SPHERE) {  // sphere_cylinder.cpp:63-74
+    dist = sphere_cylinder(s2, tf2, s1, tf1, p2, p1, normal);
     normal = -normal;
     return true;
   }

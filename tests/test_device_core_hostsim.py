@@ -8,7 +8,7 @@ import pytest
 from compare import check_parity, check_properties
 
 
-CASES = ["cfg1_sphere_sphere", "cfg2_box_capsule", "cfg3_convex_convex", "cfg5_mixed"]
+CASES = ["cfg1_sphere_sphere", "cfg2_box_capsule", "cfg3_convex_convex", "cfg5_mixed", "all_primitives"]
 
 
 def _oracle(oracle, b, req, tf1, tf2):

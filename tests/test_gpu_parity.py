@@ -37,7 +37,8 @@ def test_native_library_is_loaded(pkg):
 
 
 @pytest.mark.parametrize("case,n", [("cfg1_sphere_sphere", 1000), ("cfg2_box_capsule", 100000),
-                                    ("cfg3_convex_convex", 100000), ("cfg5_mixed", 100000)])
+                                    ("cfg3_convex_convex", 100000), ("cfg5_mixed", 100000),
+                                    ("all_primitives", 100000)])
 def test_fp64_parity(pkg, oracle, case, n):
     """fp64 kernels vs oracle: flags/statuses exact (outside a 1e-9 decision band), distances and
     separation vectors to the solver tolerance 1e-6 (narrowphase_defaults.h:48,61)."""
@@ -46,10 +47,15 @@ def test_fp64_parity(pkg, oracle, case, n):
     req = wl.make_request(b, abi)
     ref = _oracle(oracle, b, req)
     got, buckets = _engine(pkg, b, req)
-    st = check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name=case)
+    # Smooth shapes (cone / cylinder mantle): EPA stops on its tolerance (1e-6 * (1 + |w|)), not on an exact
+    # face, so FMA contraction moves the depth by ~tolerance and the normal by ~sqrt(tolerance); polytopes
+    # and the other kinds terminate exactly and agree to ~1e-12.
+    smooth = case == "all_primitives"
+    st = check_parity(abi, got, ref, dist_tol=4e-6 if smooth else 1e-6, point_tol=2e-3 if smooth else 1e-5,
+                      flag_band=1e-9, name=case)
     # FMA contraction is the only arithmetic difference: ~1e-12 on all but a few ill-conditioned pairs
     # (EPA picking the other of two near-equidistant faces: still inside the solver tolerance)
-    assert st["p999_dd"] < 1e-9 and st["max_dd"] < 1e-6, st
+    assert st["p999_dd"] < (1e-6 if smooth else 1e-9) and st["max_dd"] < (4e-6 if smooth else 1e-6), st
     check_properties(abi, got, tol=1e-6, name=case)
     assert buckets["unsupported"] == 0
 
