@@ -11,6 +11,8 @@ GEOM_CAPSULE = 11
 GEOM_CONE = 12
 GEOM_CYLINDER = 13
 GEOM_CONVEX = 14
+GEOM_PLANE = 15
+GEOM_HALFSPACE = 16
 GEOM_TRIANGLE = 17
 GEOM_ELLIPSOID = 19
 
@@ -32,7 +34,7 @@ OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED_PAIR, ERR_NO_DEVICE, ERR_HIP, ERR_LIMI
 
 class Shape(C.Structure):
     _fields_ = [("type", C.c_int32), ("num_points", C.c_uint32), ("vertex_offset", C.c_uint32),
-                ("bvh_index", C.c_uint32), ("params", C.c_double * 3), ("swept_sphere_radius", C.c_double)]
+                ("bvh_index", C.c_uint32), ("params", C.c_double * 4), ("swept_sphere_radius", C.c_double)]
 
 
 class QueryRequest(C.Structure):
@@ -75,8 +77,8 @@ CONTACT_DTYPE = np.dtype([("pair", "<u4"), ("b1", "<i4"), ("b2", "<i4"), ("_pad"
                           ("penetration_depth", "<f8"), ("normal", "<f8", 3), ("p1", "<f8", 3), ("p2", "<f8", 3)])
 assert CONTACT_DTYPE.itemsize == 96
 SHAPE_DTYPE = np.dtype([("type", "<i4"), ("num_points", "<u4"), ("vertex_offset", "<u4"), ("bvh_index", "<u4"),
-                        ("params", "<f8", 3), ("swept_sphere_radius", "<f8")])
-assert SHAPE_DTYPE.itemsize == C.sizeof(Shape) == 48
+                        ("params", "<f8", 4), ("swept_sphere_radius", "<f8")])
+assert SHAPE_DTYPE.itemsize == C.sizeof(Shape) == 56
 BVH_NODE_DTYPE = np.dtype([("first_child", "<i4"), ("first_primitive", "<i4"), ("num_primitives", "<i4"),
                            ("_pad", "<i4"), ("obb_axes", "<f8", 9), ("obb_To", "<f8", 3), ("obb_extent", "<f8", 3),
                            ("rss_axes", "<f8", 9), ("rss_Tr", "<f8", 3), ("rss_length", "<f8", 2),

@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256) k_closed(Work wk, LibView<T> lib, IO<T> i
     const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
     const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
     PairOut<T> o;
-    o.distance = closed_form_distance(a, tf1, b, tf2, o.p1, o.p2, o.normal);
+    o.distance = closed_form_distance(a, tf1, b, tf2, lib.verts, o.p1, o.p2, o.normal);
     o.gjk_status = GJK_DID_NOT_RUN;
     o.epa_status = EPA_DID_NOT_RUN;
     o.gjk_iters = o.epa_iters = 0;
@@ -954,7 +954,8 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
     const hfcl_shape& s = shapes[i];
     const bool ok_kind = s.type == HFCL_GEOM_BOX || s.type == HFCL_GEOM_SPHERE || s.type == HFCL_GEOM_CAPSULE ||
                          s.type == HFCL_GEOM_ELLIPSOID || s.type == HFCL_GEOM_CONVEX || s.type == HFCL_BV_OBBRSS ||
-                         s.type == HFCL_GEOM_TRIANGLE || s.type == HFCL_GEOM_CONE || s.type == HFCL_GEOM_CYLINDER;
+                         s.type == HFCL_GEOM_TRIANGLE || s.type == HFCL_GEOM_CONE || s.type == HFCL_GEOM_CYLINDER ||
+                         s.type == HFCL_GEOM_PLANE || s.type == HFCL_GEOM_HALFSPACE;
     if (!ok_kind) {
       set_error("hfcl_lib_create: unsupported shape type " + std::to_string(s.type));
       return nullptr;
@@ -988,6 +989,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
     s64[i].p0 = s.params[0];
     s64[i].p1 = s.params[1];
     s64[i].p2 = s.params[2];
+    s64[i].p3 = s.params[3];
     s64[i].ssr = s.swept_sphere_radius;
     s32[i].kind = s.type;
     s32[i].num_points = s.num_points;
@@ -996,6 +998,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
     s32[i].p0 = float(s.params[0]);
     s32[i].p1 = float(s.params[1]);
     s32[i].p2 = float(s.params[2]);
+    s32[i].p3 = float(s.params[3]);
     s32[i].ssr = float(s.swept_sphere_radius);
     kinds[i] = uint8_t(s.type);
   }

@@ -11,7 +11,7 @@
 
 namespace hfcl {
 
-enum { K_BOX = 9, K_SPHERE = 10, K_CAPSULE = 11, K_CONE = 12, K_CYLINDER = 13, K_CONVEX = 14, K_TRIANGLE = 17, K_ELLIPSOID = 19, K_BVH = 5 };
+enum { K_BOX = 9, K_SPHERE = 10, K_CAPSULE = 11, K_CONE = 12, K_CYLINDER = 13, K_CONVEX = 14, K_PLANE = 15, K_HALFSPACE = 16, K_TRIANGLE = 17, K_ELLIPSOID = 19, K_BVH = 5 };
 
 // Device image of one shape-library entry (both an fp64 and an fp32 table are resident).
 template <typename T>
@@ -20,7 +20,8 @@ struct DShape {
   uint32_t num_points;
   uint32_t vertex_offset;  // in vertices, into the library vertex array of the same precision
   uint32_t bvh_index;
-  T p0, p1, p2;            // Box halfSide / Sphere r / Capsule r,halfLength / Ellipsoid radii
+  T p0, p1, p2;            // Box halfSide / Sphere r / Capsule r,halfLength / Ellipsoid radii / Plane, Halfspace n
+  T p3;                    // Plane, Halfspace: d
   T ssr;                   // swept sphere radius
 };
 
@@ -31,8 +32,13 @@ enum { CLS_CLOSED = 0, CLS_PRIM_GJK = 1, CLS_CONVEX = 2, CLS_BVH = 3, CLS_UNSUPP
 HFCL_HD bool kind_is_prim(int k) {
   return k == K_BOX || k == K_SPHERE || k == K_CAPSULE || k == K_ELLIPSOID || k == K_CONE || k == K_CYLINDER;
 }
+HFCL_HD bool kind_is_flat(int k) { return k == K_PLANE || k == K_HALFSPACE; }
 HFCL_HD int pair_class(int k1, int k2) {
   if (k1 == K_BVH && k2 == K_BVH) return CLS_BVH;
+  if (kind_is_flat(k1) || kind_is_flat(k2)) {  // every Plane / Halfspace row of the table is a closed form
+    const int o = kind_is_flat(k1) ? k2 : k1;
+    return (kind_is_flat(o) || kind_is_prim(o) || o == K_CONVEX || o == K_TRIANGLE) ? CLS_CLOSED : CLS_UNSUPPORTED;
+  }
   const bool p1 = kind_is_prim(k1), p2 = kind_is_prim(k2);
   if (p1 && p2) {
     const bool sc1 = (k1 == K_SPHERE || k1 == K_CAPSULE), sc2 = (k2 == K_SPHERE || k2 == K_CAPSULE);
@@ -325,11 +331,144 @@ HFCL_HD T sphere_cylinder(const DShape<T>& s1, const Pose<T>& tf1, const DShape<
   return dist;
 }
 
+// ---------------------------------------------------------------------------------------
+// Plane / Halfspace rows (src/narrowphase/details.h:347-428,509-691; src/distance/*_halfspace.cpp,
+// *_plane.cpp).  getSupport<WithSweptSphere> of the other shape decides everything.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+HFCL_HD V3<T> support_with_swept_sphere(const DShape<T>& s, const T* verts, const V3<T>& dir) {
+  const V3<T> u = normalized(dir);
+  if (s.kind == K_SPHERE) return u * (s.p0 + s.ssr);
+  V3<T> sup;
+  if (s.kind == K_CONVEX) {  // getShapeSupportLinear, first maximum (support_functions.cpp:400-421)
+    const T* v = verts + 3 * size_t(s.vertex_offset);
+    uint32_t best = 0;
+    T bd = v[0] * dir.x + v[1] * dir.y + v[2] * dir.z;
+    for (uint32_t i = 1; i < s.num_points; ++i) {
+      const T d = v[3 * i] * dir.x + v[3 * i + 1] * dir.y + v[3 * i + 2] * dir.z;
+      if (d > bd) {
+        bd = d;
+        best = i;
+      }
+    }
+    sup = mk<T>(v[3 * best], v[3 * best + 1], v[3 * best + 2]);
+  } else if (s.kind == K_TRIANGLE) {  // support_functions.cpp:110-134
+    const T* v = verts + 3 * size_t(s.vertex_offset);
+    const V3<T> a = mk<T>(v[0], v[1], v[2]), b = mk<T>(v[3], v[4], v[5]), c = mk<T>(v[6], v[7], v[8]);
+    const T da = dot(dir, a), db = dot(dir, b), dc = dot(dir, c);
+    if (da > db)
+      sup = (dc > da) ? c : a;
+    else
+      sup = (dc > db) ? c : b;
+  } else {
+    sup = prim_support(s, dir);
+  }
+  return sup + u * (s.kind == K_CAPSULE ? s.p0 + s.ssr : s.ssr);
+}
+
+template <typename T>
+struct PlaneEq {  // Plane / Halfspace in the world frame (transform(), geometric_shapes_utility.cpp:249-277)
+  V3<T> n;
+  T d, ssr;
+  HFCL_HD T signed_distance(const V3<T>& p) const { return dot(n, p) - (d + ssr); }  // geometric_shapes.h:913-915
+};
+template <typename T>
+HFCL_HD PlaneEq<T> world_plane(const DShape<T>& h, const Pose<T>& tf) {
+  PlaneEq<T> w;
+  w.n = mul(tf.R, mk<T>(h.p0, h.p1, h.p2));
+  w.d = h.p3 + dot(w.n, tf.t);
+  w.ssr = h.ssr;
+  return w;
+}
+
+// flat (Plane or Halfspace) vs a solid shape; p1 on the flat, p2 on the shape, normal = the flat's normal
+template <typename T>
+HFCL_HD T flat_solid_distance(const DShape<T>& f, const Pose<T>& tf1, const DShape<T>& s, const T* verts, const Pose<T>& tf2,
+                              V3<T>& p1, V3<T>& p2, V3<T>& normal) {
+  const PlaneEq<T> h0 = world_plane(f, tf1);
+  const V3<T> a = xform(tf2, support_with_swept_sphere(s, verts, -tmul(tf2.R, h0.n)));
+  const T dist1 = h0.signed_distance(a);
+  if (f.kind == K_PLANE) {  // second halfspace of the plane: (-n, -d)
+    PlaneEq<T> h1 = h0;
+    h1.n = -h0.n;
+    h1.d = -h0.d;
+    const V3<T> b = xform(tf2, support_with_swept_sphere(s, verts, -tmul(tf2.R, h1.n)));
+    const T dist2 = h1.signed_distance(b);
+    if (!(dist1 >= dist2)) {
+      p2 = b;
+      p1 = p2 - h1.n * dist2;
+      normal = h1.n;
+      return dist2;
+    }
+  }
+  p2 = a;
+  p1 = p2 - h0.n * dist1;
+  normal = h0.n;
+  return dist1;
+}
+
+// flat vs flat: halfspace-halfspace :509-568, halfspace-plane :585-628, plane-plane :646-691
+template <typename T>
+HFCL_HD T flat_flat_distance(const DShape<T>& s1, const Pose<T>& tf1, const DShape<T>& s2, const Pose<T>& tf2, V3<T>& p1,
+                             V3<T>& p2, V3<T>& normal) {
+  const PlaneEq<T> a = world_plane(s1, tf1), b = world_plane(s2, tf2);
+  const V3<T> dir = cross(a.n, b.n);
+  const T dsq = sqnorm(dir);
+  T distance;
+  if (dsq < Lim<T>::eps()) {  // parallel
+    p1 = a.n * a.d;
+    p2 = b.n * b.d;
+    normal = a.n;
+    const bool same = dot(a.n, b.n) > T(0);
+    if (s1.kind == K_PLANE) {  // plane-plane
+      distance = norm(p1 - p2);
+      if (distance > Lim<T>::tiny()) normal = normalized(p2 - p1);
+    } else if (s2.kind == K_PLANE) {  // halfspace-plane
+      distance = same ? (b.d - a.d) : -(a.d + b.d);
+    } else if (!same) {  // opposite halfspaces
+      distance = -(a.d + b.d);
+    } else {  // nested halfspaces: infinite penetration
+      distance = -Lim<T>::max();
+      if (a.d <= b.d) {
+        p1 = normal * distance;
+      } else {
+        normal = -a.n;
+        p2 = -(normal * distance);
+      }
+    }
+  } else {  // crossing: infinite penetration, witness = origin of the intersection line
+    distance = -Lim<T>::max();
+    normal = dir;
+    p1 = p2 = cross(b.n * a.d - a.n * b.d, dir) / dsq;
+  }
+  if (s1.ssr > T(0) || s2.ssr > T(0)) {
+    p1 = p1 + normal * s1.ssr;
+    p2 = p2 - normal * s2.ssr;
+    distance -= (s1.ssr + s2.ssr);
+  }
+  return distance;
+}
+
 // Dispatch of the CLS_CLOSED bucket incl. the operand swaps of sphere_capsule.cpp:60-71 and
 // box_sphere.cpp:62-75.
 template <typename T>
 HFCL_HD T closed_form_distance(const DShape<T>& s1, const Pose<T>& tf1, const DShape<T>& s2, const Pose<T>& tf2,
-                               V3<T>& p1, V3<T>& p2, V3<T>& n) {
+                               const T* verts, V3<T>& p1, V3<T>& p2, V3<T>& n) {
+  const bool f1 = kind_is_flat(s1.kind), f2 = kind_is_flat(s2.kind);
+  if (f1 && f2) {
+    if (s1.kind == K_PLANE && s2.kind == K_HALFSPACE) {  // halfspace_plane.cpp:57-68
+      const T d = flat_flat_distance(s2, tf2, s1, tf1, p2, p1, n);
+      n = -n;
+      return d;
+    }
+    return flat_flat_distance(s1, tf1, s2, tf2, p1, p2, n);
+  }
+  if (f1) return flat_solid_distance(s1, tf1, s2, verts, tf2, p1, p2, n);
+  if (f2) {  // e.g. box_halfspace.cpp:50-61
+    const T d = flat_solid_distance(s2, tf2, s1, verts, tf1, p2, p1, n);
+    n = -n;
+    return d;
+  }
   if (s1.kind == K_SPHERE && s2.kind == K_SPHERE) return sphere_sphere(s1, tf1, s2, tf2, p1, p2, n);
   if (s1.kind == K_SPHERE && s2.kind == K_CAPSULE) return sphere_capsule(s1, tf1, s2, tf2, p1, p2, n);
   if (s1.kind == K_CAPSULE && s2.kind == K_SPHERE) {

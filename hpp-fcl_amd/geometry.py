@@ -15,8 +15,8 @@ class ShapeLibrary:
         self._verts = []
         self._nverts = 0
 
-    def _add(self, type_, params=(0, 0, 0), ssr=0.0, num_points=0, vertex_offset=0, bvh_index=0):
-        self._shapes.append((type_, num_points, vertex_offset, bvh_index, tuple(params), ssr))
+    def _add(self, type_, params=(0, 0, 0, 0), ssr=0.0, num_points=0, vertex_offset=0, bvh_index=0):
+        self._shapes.append((type_, num_points, vertex_offset, bvh_index, (tuple(params) + (0, 0, 0, 0))[:4], ssr))
         return len(self._shapes) - 1
 
     def add_box(self, x, y, z, swept_sphere_radius=0.0):
@@ -36,6 +36,23 @@ class ShapeLibrary:
 
     def add_cylinder(self, radius, lz, swept_sphere_radius=0.0):
         return self._add(abi.GEOM_CYLINDER, (radius, lz / 2.0, 0), swept_sphere_radius)
+
+    def _unit_plane(self, n, d):
+        """unitNormalTest (geometric_shapes.cpp:121-143): normalise (n, d); zero normal -> (1,0,0), 0."""
+        n = np.asarray(n, dtype=np.float64)
+        l = float(np.sqrt((n * n).sum()))
+        if l > 0:
+            inv = 1.0 / l
+            return tuple(float(x) for x in n * inv) + (float(d) * inv,)
+        return (1.0, 0.0, 0.0, 0.0)
+
+    def add_halfspace(self, n, d, swept_sphere_radius=0.0):
+        """Halfspace {x : n.x <= d} (geometric_shapes.h:873-962)."""
+        return self._add(abi.GEOM_HALFSPACE, self._unit_plane(n, d), swept_sphere_radius)
+
+    def add_plane(self, n, d, swept_sphere_radius=0.0):
+        """Plane {x : n.x = d} (geometric_shapes.h:968-1049)."""
+        return self._add(abi.GEOM_PLANE, self._unit_plane(n, d), swept_sphere_radius)
 
     def add_ellipsoid(self, rx, ry, rz, swept_sphere_radius=0.0):
         return self._add(abi.GEOM_ELLIPSOID, (rx, ry, rz), swept_sphere_radius)

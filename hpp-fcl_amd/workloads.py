@@ -170,6 +170,32 @@ def all_primitives(n=100_000, seed=1, nper=128, half_width=0.8, kind="collide"):
     return Batch("all_primitives_" + kind, lib, s1, s2, q1, T1, q2, T2, kind)
 
 
+def flat_pairs(n=50_000, seed=1, nper=64, half_width=1.0, kind="collide"):
+    """Plane / Halfspace rows of the dispatch table: (solid, flat), (flat, solid) and (flat, flat) pairs, the
+    solids being every other supported kind (some with a swept-sphere radius)."""
+    rng = _rng(seed, 7)
+    lib = _mixed_library(rng, nper)
+    for r, lz in zip(rng.uniform(0.1, 0.8, nper), rng.uniform(0.2, 1.0, nper)):
+        lib.add_cone(float(r), float(lz))
+    for r, lz in zip(rng.uniform(0.1, 0.8, nper), rng.uniform(0.2, 1.0, nper)):
+        lib.add_cylinder(float(r), float(lz), swept_sphere_radius=float(rng.uniform(0, 0.1)))
+    n_solid = 7 * nper
+    nflat = 2 * nper
+    for k in range(nflat):
+        nrm, d, ssr = rng.normal(size=3), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(0, 0.05)) * (k % 3 == 0)
+        if k % 8 == 0:
+            nrm = np.array([0.0, 0.0, 1.0])  # parallel flats when both poses share a rotation
+        (lib.add_halfspace if k % 2 == 0 else lib.add_plane)(nrm, d, swept_sphere_radius=ssr)
+    u = rng.random(n)
+    solid, flat1, flat2 = rng.integers(0, n_solid, n), n_solid + rng.integers(0, nflat, n), n_solid + rng.integers(0, nflat, n)
+    s1 = np.where(u < 0.45, solid, flat1)
+    s2 = np.where(u < 0.45, flat2, np.where(u < 0.9, solid, flat2))
+    q1, T1, q2, T2 = _poses(rng, n, half_width)
+    par = rng.random(n) < 0.3  # same rotation on both sides: exercises the parallel branches of flat-flat
+    q2[par] = q1[par]
+    return Batch("flat_pairs_" + kind, lib, s1, s2, q1, T1, q2, T2, kind)
+
+
 def cfg5_mixed(n=100_000, seed=1, nper=256, half_width=0.8):
     """cfg5-style mixed primitive+convex pairs (type mix 20 % each of Box/Sphere/Capsule/
     Ellipsoid/Convex32), synthetic pair list (cfg5_broadphase_scene takes its pairs from the host broadphase)."""

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HFCL_ABI_VERSION 1
+#define HFCL_ABI_VERSION 2
 
 /* ---- geometry kinds: numeric values are hpp-fcl's NODE_TYPE
  *      (include/hpp/fcl/collision_object.h:65-89) so a caller can pass
@@ -40,6 +40,8 @@ enum {
   HFCL_GEOM_CONE     = 12, /* params[0] = radius, [1] = halfLength (geometric_shapes.h:437-500) */
   HFCL_GEOM_CYLINDER = 13, /* params[0] = radius, [1] = halfLength (:505-570)           */
   HFCL_GEOM_CONVEX   = 14, /* num_points vertices at vertex_offset (:638-872)    */
+  HFCL_GEOM_PLANE    = 15, /* params[0..2] = unit normal n, params[3] = d: n.x = d (:968-1049) */
+  HFCL_GEOM_HALFSPACE= 16, /* params[0..2] = unit normal n, params[3] = d: n.x <= d (:873-962) */
   HFCL_GEOM_TRIANGLE = 17, /* 3 vertices at vertex_offset (TriangleP, :109)      */
   HFCL_GEOM_ELLIPSOID= 19  /* params = radii[3]         (geometric_shapes.h:303) */
 };
@@ -51,7 +53,7 @@ typedef struct hfcl_shape {
   uint32_t num_points;          /* CONVEX: #vertices; TRIANGLE: 3; BVH: #vertices        */
   uint32_t vertex_offset;       /* first vertex in the library vertex array (units: vertices) */
   uint32_t bvh_index;           /* BVH only: index into the mesh table (hfcl_lib_add_bvh) */
-  double   params[3];
+  double   params[4];
   double   swept_sphere_radius; /* ShapeBase::getSweptSphereRadius(), geometric_shapes.h:59-102 */
 } hfcl_shape;
 

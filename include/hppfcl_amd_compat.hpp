@@ -115,7 +115,8 @@ static_assert(sizeof(Transform3f) == HFCL_POSE_DOUBLES * sizeof(double), "Transf
 
 enum NODE_TYPE {  // include/hpp/fcl/collision_object.h:65-89 (subset in scope)
   BV_OBBRSS = HFCL_BV_OBBRSS, GEOM_BOX = HFCL_GEOM_BOX, GEOM_SPHERE = HFCL_GEOM_SPHERE, GEOM_CAPSULE = HFCL_GEOM_CAPSULE,
-  GEOM_CONE = HFCL_GEOM_CONE, GEOM_CYLINDER = HFCL_GEOM_CYLINDER,
+  GEOM_CONE = HFCL_GEOM_CONE, GEOM_CYLINDER = HFCL_GEOM_CYLINDER, GEOM_PLANE = HFCL_GEOM_PLANE,
+  GEOM_HALFSPACE = HFCL_GEOM_HALFSPACE,
   GEOM_CONVEX = HFCL_GEOM_CONVEX, GEOM_TRIANGLE = HFCL_GEOM_TRIANGLE, GEOM_ELLIPSOID = HFCL_GEOM_ELLIPSOID
 };
 enum GJKInitialGuess { DefaultGuess, CachedGuess, BoundingVolumeGuess };
@@ -170,6 +171,37 @@ class Cylinder : public ShapeBase {
   Cylinder(FCL_REAL r, FCL_REAL lz) : radius(r), halfLength(lz / 2) {}
   FCL_REAL radius, halfLength;
   NODE_TYPE getNodeType() const override { return GEOM_CYLINDER; }
+};
+class Halfspace : public ShapeBase {  // {x : n.x <= d}, geometric_shapes.h:873-962
+ public:
+  Halfspace(const Vec3f& n_, FCL_REAL d_) : n(n_), d(d_) { unitNormalTest(); }
+  Halfspace(FCL_REAL a, FCL_REAL b, FCL_REAL c, FCL_REAL d_) : n(a, b, c), d(d_) { unitNormalTest(); }
+  Halfspace() : n(1, 0, 0), d(0) {}
+  Vec3f n;
+  FCL_REAL d;
+  FCL_REAL signedDistance(const Vec3f& p) const { return n.dot(p) - (d + getSweptSphereRadius()); }
+  NODE_TYPE getNodeType() const override { return GEOM_HALFSPACE; }
+
+ private:
+  void unitNormalTest() {  // geometric_shapes.cpp:121-131
+    const FCL_REAL l = n.norm();
+    if (l > 0) { n = n * (1.0 / l); d *= 1.0 / l; } else { n = Vec3f(1, 0, 0); d = 0; }
+  }
+};
+class Plane : public ShapeBase {  // {x : n.x = d}, geometric_shapes.h:968-1049
+ public:
+  Plane(const Vec3f& n_, FCL_REAL d_) : n(n_), d(d_) { unitNormalTest(); }
+  Plane(FCL_REAL a, FCL_REAL b, FCL_REAL c, FCL_REAL d_) : n(a, b, c), d(d_) { unitNormalTest(); }
+  Plane() : n(1, 0, 0), d(0) {}
+  Vec3f n;
+  FCL_REAL d;
+  NODE_TYPE getNodeType() const override { return GEOM_PLANE; }
+
+ private:
+  void unitNormalTest() {  // geometric_shapes.cpp:133-143
+    const FCL_REAL l = n.norm();
+    if (l > 0) { n = n * (1.0 / l); d *= 1.0 / l; } else { n = Vec3f(1, 0, 0); d = 0; }
+  }
 };
 class Ellipsoid : public ShapeBase {
  public:
@@ -402,6 +434,8 @@ class BatchQueries {
       case GEOM_CONE: { auto* c = static_cast<const Cone*>(g); s.params[0] = c->radius; s.params[1] = c->halfLength; break; }
       case GEOM_CYLINDER: { auto* c = static_cast<const Cylinder*>(g); s.params[0] = c->radius; s.params[1] = c->halfLength; break; }
       case GEOM_ELLIPSOID: { auto* e = static_cast<const Ellipsoid*>(g); for (int i = 0; i < 3; ++i) s.params[i] = e->radii[i]; break; }
+      case GEOM_HALFSPACE: { auto* h = static_cast<const Halfspace*>(g); for (int i = 0; i < 3; ++i) s.params[i] = h->n[i]; s.params[3] = h->d; break; }
+      case GEOM_PLANE: { auto* h = static_cast<const Plane*>(g); for (int i = 0; i < 3; ++i) s.params[i] = h->n[i]; s.params[3] = h->d; break; }
       case GEOM_CONVEX: {
         auto* c = static_cast<const ConvexBase*>(g);
         s.num_points = c->num_points;
@@ -437,7 +471,8 @@ class BatchQueries {
     if (it != ids_.end() && s.type != BV_OBBRSS) {
       const hfcl_shape& o = shapes_[it->second];
       bool same = o.type == s.type && o.num_points == s.num_points && o.swept_sphere_radius == s.swept_sphere_radius &&
-                  o.params[0] == s.params[0] && o.params[1] == s.params[1] && o.params[2] == s.params[2];
+                  o.params[0] == s.params[0] && o.params[1] == s.params[1] && o.params[2] == s.params[2] &&
+                  o.params[3] == s.params[3];
       if (same && s.type == GEOM_CONVEX)
         for (size_t k = 0; k < v.size() && same; ++k) same = verts_[3 * size_t(o.vertex_offset) + k] == v[k];
       if (same) return it->second;

@@ -16,6 +16,7 @@ static Shape make_shape(const hfcl_shape& s, const double* vertices) {
   r.p[0] = s.params[0];
   r.p[1] = s.params[1];
   r.p[2] = s.params[2];
+  r.p[3] = s.params[3];
   r.ssr = s.swept_sphere_radius;
   if (s.type == HFCL_GEOM_CONVEX || s.type == HFCL_GEOM_TRIANGLE) {
     r.verts = vertices + 3 * size_t(s.vertex_offset);

@@ -18,11 +18,11 @@
 
 namespace orc {
 
-enum ShapeKind { K_BOX = 9, K_SPHERE = 10, K_CAPSULE = 11, K_CONE = 12, K_CYLINDER = 13, K_CONVEX = 14, K_TRIANGLE = 17, K_ELLIPSOID = 19 };
+enum ShapeKind { K_BOX = 9, K_SPHERE = 10, K_CAPSULE = 11, K_CONE = 12, K_CYLINDER = 13, K_CONVEX = 14, K_PLANE = 15, K_HALFSPACE = 16, K_TRIANGLE = 17, K_ELLIPSOID = 19 };
 
 struct Shape {
   int kind = 0;
-  double p[3] = {0, 0, 0};   // Box halfSide / Sphere r / Capsule r,halfLength / Ellipsoid radii
+  double p[4] = {0, 0, 0, 0};   // Box halfSide / Sphere r / Capsule r,halfLength / Ellipsoid radii / Plane, Halfspace n,d
   double ssr = 0;            // swept sphere radius
   const double* verts = nullptr;  // CONVEX / TRIANGLE vertices (xyz)
   int nverts = 0;

@@ -208,6 +208,147 @@ static double sphere_sphere(const Shape& s1, const Tf& tf1, const Shape& s2, con
   return dist;
 }
 
+// getSupport<WithSweptSphere> (support_functions.cpp:47-63 + the WithSweptSphere tails of :110-421)
+static V3 support_with_swept_sphere(const Shape& s, const V3& dir) {
+  int hint = 0;
+  V3 sup = shape_support(s, dir, hint);
+  if (s.kind == K_SPHERE) return normalized(dir) * (s.p[0] + s.ssr);
+  if (s.kind == K_CAPSULE) return sup + normalized(dir) * (s.p[0] + s.ssr);
+  return sup + normalized(dir) * s.ssr;
+}
+
+struct PlaneEq {  // Halfspace / Plane expressed in the world frame: transform() geometric_shapes_utility.cpp:249-277
+  V3 n;
+  double d, ssr;
+  double signed_distance(const V3& p) const { return dot(n, p) - (d + ssr); }  // Halfspace::signedDistance :913-915
+};
+static PlaneEq world_plane(const Shape& h, const Tf& tf) {
+  PlaneEq w;
+  w.n = tf.R * V3(h.p[0], h.p[1], h.p[2]);
+  w.d = h.p[3] + dot(w.n, tf.T);
+  w.ssr = h.ssr;
+  return w;
+}
+
+// details::halfspaceDistance :347-375 (p1 on the halfspace, p2 on the shape, normal = halfspace normal)
+static double halfspace_distance(const Shape& h, const Tf& tf1, const Shape& s, const Tf& tf2, V3& p1, V3& p2, V3& normal) {
+  const PlaneEq nh = world_plane(h, tf1);
+  const V3 n_2 = transpose(tf2.R) * nh.n;
+  p2 = tf2.transform(support_with_swept_sphere(s, -n_2));
+  const double dist = nh.signed_distance(p2);
+  p1 = p2 - nh.n * dist;
+  normal = nh.n;
+  return dist;
+}
+
+// details::planeDistance :381-428: the plane as two opposite halfspaces, the farther one decides
+static double plane_distance(const Shape& pl, const Tf& tf1, const Shape& s, const Tf& tf2, V3& p1, V3& p2, V3& normal) {
+  PlaneEq h0 = world_plane(pl, tf1), h1 = h0;
+  h1.n = -h0.n;
+  h1.d = -h0.d;
+  const V3 n_h1 = transpose(tf2.R) * h0.n, n_h2 = transpose(tf2.R) * h1.n;
+  const V3 a = tf2.transform(support_with_swept_sphere(s, -n_h1));
+  const V3 b = tf2.transform(support_with_swept_sphere(s, -n_h2));
+  const double dist1 = h0.signed_distance(a), dist2 = h1.signed_distance(b);
+  if (dist1 >= dist2) {
+    p2 = a;
+    p1 = p2 - h0.n * dist1;
+    normal = h0.n;
+    return dist1;
+  }
+  p2 = b;
+  p1 = p2 - h1.n * dist2;
+  normal = h1.n;
+  return dist2;
+}
+
+static void apply_ssr(const Shape& s1, const Shape& s2, V3& p1, V3& p2, const V3& normal, double& distance) {
+  if (s1.ssr > 0 || s2.ssr > 0) {
+    p1 = p1 + normal * s1.ssr;
+    p2 = p2 - normal * s2.ssr;
+    distance -= (s1.ssr + s2.ssr);
+  }
+}
+static V3 intersection_line_origin(const PlaneEq& a, const PlaneEq& b, const V3& dir, double dir_sq_norm) {
+  return cross(b.n * a.d - a.n * b.d, dir) / dir_sq_norm;
+}
+
+// details::halfspaceHalfspaceDistance :509-568
+static double halfspace_halfspace(const Shape& s1, const Tf& tf1, const Shape& s2, const Tf& tf2, V3& p1, V3& p2, V3& normal) {
+  const PlaneEq a = world_plane(s1, tf1), b = world_plane(s2, tf2);
+  double distance;
+  const V3 dir = cross(a.n, b.n);
+  const double dir_sq_norm = sqnorm(dir);
+  if (dir_sq_norm < std::numeric_limits<double>::epsilon()) {
+    if (dot(a.n, b.n) > 0) {
+      distance = -std::numeric_limits<double>::max();
+      if (a.d <= b.d) {
+        normal = a.n;
+        p1 = normal * distance;
+        p2 = b.n * b.d;
+      } else {
+        normal = -a.n;
+        p1 = a.n * a.d;
+        p2 = -(normal * distance);
+      }
+    } else {
+      distance = -(a.d + b.d);
+      normal = a.n;
+      p1 = a.n * a.d;
+      p2 = b.n * b.d;
+    }
+  } else {
+    distance = -std::numeric_limits<double>::max();
+    normal = dir;
+    p1 = p2 = intersection_line_origin(a, b, dir, dir_sq_norm);
+  }
+  apply_ssr(s1, s2, p1, p2, normal, distance);
+  return distance;
+}
+
+// details::halfspacePlaneDistance :585-628
+static double halfspace_plane(const Shape& s1, const Tf& tf1, const Shape& s2, const Tf& tf2, V3& p1, V3& p2, V3& normal) {
+  const PlaneEq a = world_plane(s1, tf1), b = world_plane(s2, tf2);
+  double distance;
+  const V3 dir = cross(a.n, b.n);
+  const double dir_sq_norm = sqnorm(dir);
+  if (dir_sq_norm < std::numeric_limits<double>::epsilon()) {
+    normal = a.n;
+    distance = dot(a.n, b.n) > 0 ? (b.d - a.d) : -(a.d + b.d);
+    p1 = a.n * a.d;
+    p2 = b.n * b.d;
+  } else {
+    distance = -std::numeric_limits<double>::max();
+    normal = dir;
+    p1 = p2 = intersection_line_origin(a, b, dir, dir_sq_norm);
+  }
+  apply_ssr(s1, s2, p1, p2, normal, distance);
+  return distance;
+}
+
+// details::planePlaneDistance :646-691
+static double plane_plane(const Shape& s1, const Tf& tf1, const Shape& s2, const Tf& tf2, V3& p1, V3& p2, V3& normal) {
+  const PlaneEq a = world_plane(s1, tf1), b = world_plane(s2, tf2);
+  double distance;
+  const V3 dir = cross(a.n, b.n);
+  const double dir_sq_norm = sqnorm(dir);
+  if (dir_sq_norm < std::numeric_limits<double>::epsilon()) {
+    p1 = a.n * a.d;
+    p2 = b.n * b.d;
+    distance = norm(p1 - p2);
+    if (distance > kDummyPrecision)
+      normal = normalized(p2 - p1);
+    else
+      normal = a.n;
+  } else {
+    distance = -std::numeric_limits<double>::max();
+    normal = dir;
+    p1 = p2 = intersection_line_origin(a, b, dir, dir_sq_norm);
+  }
+  apply_ssr(s1, s2, p1, p2, normal, distance);
+  return distance;
+}
+
 // details::sphereCylinderDistance :107-209
 static double sphere_cylinder(const Shape& s1, const Tf& tf1, const Shape& s2, const Tf& tf2, V3& p1, V3& p2,
                               V3& normal) {
@@ -519,6 +660,36 @@ bool shape_shape_distance(const Shape& s1, const Tf& tf1, const Shape& s2, const
     dist = sphere_cylinder(s2, tf2, s1, tf1, p2, p1, normal);
     normal = -normal;
     return true;
+  }
+  {  // Halfspace / Plane rows of the table: src/distance/*_halfspace.cpp, *_plane.cpp, halfspace_*.cpp, plane_plane.cpp
+    const bool h1 = s1.kind == K_HALFSPACE, h2 = s2.kind == K_HALFSPACE, q1 = s1.kind == K_PLANE, q2 = s2.kind == K_PLANE;
+    auto solid = [&](int k) { return is_gjk_kind(k) || k == K_TRIANGLE; };
+    if (h1 && h2) {
+      dist = halfspace_halfspace(s1, tf1, s2, tf2, p1, p2, normal);
+      return true;
+    }
+    if (h1 && q2) {
+      dist = halfspace_plane(s1, tf1, s2, tf2, p1, p2, normal);
+      return true;
+    }
+    if (q1 && h2) {  // halfspace_plane.cpp:57-68
+      dist = halfspace_plane(s2, tf2, s1, tf1, p2, p1, normal);
+      normal = -normal;
+      return true;
+    }
+    if (q1 && q2) {
+      dist = plane_plane(s1, tf1, s2, tf2, p1, p2, normal);
+      return true;
+    }
+    if ((h1 || q1) && solid(s2.kind)) {
+      dist = h1 ? halfspace_distance(s1, tf1, s2, tf2, p1, p2, normal) : plane_distance(s1, tf1, s2, tf2, p1, p2, normal);
+      return true;
+    }
+    if (solid(s1.kind) && (h2 || q2)) {  // e.g. box_halfspace.cpp:50-61
+      dist = h2 ? halfspace_distance(s2, tf2, s1, tf1, p2, p1, normal) : plane_distance(s2, tf2, s1, tf1, p2, p1, normal);
+      normal = -normal;
+      return true;
+    }
   }
   if (s1.kind == K_TRIANGLE && s2.kind == K_TRIANGLE) {
     dist = triangle_triangle(s1, tf1, s2, tf2, solver, p1, p2, normal);

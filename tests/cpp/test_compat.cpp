@@ -129,6 +129,25 @@ int main() {
     const double d = distance(&m1, Transform3f(), &m2, Transform3f(Vec3f(3, 0, 0)), dq, dr);
     CHECK(std::fabs(d - 1.5) < 1e-9 && dr.b1 >= 0 && dr.b2 >= 0);
   }
+  {  // collide_halfspacesphere / collide_planebox (geometric_shapes.cpp:1275-1300, 1567-1590)
+    STAGE("halfspace / plane");
+    Sphere s(10);
+    Halfspace hs(Vec3f(1, 0, 0), 0);
+    CollisionRequest rq; CollisionResult rs;
+    CHECK(collide(&s, Transform3f(), &hs, Transform3f(Vec3f(5, 0, 0)), rq, rs) == 1);
+    CHECK(std::fabs(rs.getContact(0).penetration_depth + 15) < 1e-9 && std::fabs(rs.getContact(0).pos[0] + 2.5) < 1e-9);
+    CHECK(std::fabs(rs.getContact(0).normal[0] + 1) < 1e-12);
+    rs.clear();
+    CHECK(collide(&s, Transform3f(), &hs, Transform3f(Vec3f(-10.1, 0, 0)), rq, rs) == 0);
+    Box b(5, 10, 20);
+    Plane pl(Vec3f(2, 0, 0), 0);  // normalised by the constructor
+    rs.clear();
+    CHECK(collide(&b, Transform3f(), &pl, Transform3f(Vec3f(1.25, 0, 0)), rq, rs) == 1);
+    CHECK(std::fabs(rs.getContact(0).penetration_depth + 1.25) < 1e-9 && std::fabs(rs.getContact(0).normal[0] - 1) < 1e-12);
+    Cylinder cy(5, 10);
+    DistanceRequest dq; DistanceResult dr;
+    CHECK(std::fabs(distance(&cy, Transform3f(), &cy, Transform3f(Vec3f(40, 0, 0)), dq, dr) - 30) < 1e-3);
+  }
   {  // broadphase hand-off: manager + CollisionCallBackCollect, then one device batch (test/broadphase.cpp style)
     STAGE("broadphase");
     std::vector<std::shared_ptr<CollisionGeometry>> geoms;

@@ -25,6 +25,7 @@ static DShape<T> to_dshape(const hfcl_shape& s) {
   d.p0 = T(s.params[0]);
   d.p1 = T(s.params[1]);
   d.p2 = T(s.params[2]);
+  d.p3 = T(s.params[3]);
   d.ssr = T(s.swept_sphere_radius);
   return d;
 }
@@ -49,7 +50,7 @@ static void one_pair(const DShape<T>& a, const DShape<T>& b, const T* verts, con
   skipped = false;
   const int cls = pair_class(a.kind, b.kind);
   if (cls == CLS_CLOSED) {
-    o.distance = closed_form_distance(a, tf1, b, tf2, o.p1, o.p2, o.normal);
+    o.distance = closed_form_distance(a, tf1, b, tf2, verts, o.p1, o.p2, o.normal);
     o.gjk_status = GJK_DID_NOT_RUN;
     o.epa_status = EPA_DID_NOT_RUN;
     o.gjk_iters = o.epa_iters = 0;

@@ -17,14 +17,14 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(declared) >= 19
     for sym in sorted(declared):
         assert hasattr(lib, sym), "missing export: " + sym
-    assert lib.hfcl_abi_version() == 1
+    assert lib.hfcl_abi_version() == 2
     assert set(pkg.engine.EXPORTED_SYMBOLS) <= declared
 
 
 def test_struct_layouts_match_header(pkg):
     import ctypes as C
     abi = pkg.abi
-    assert C.sizeof(abi.Shape) == 48
+    assert C.sizeof(abi.Shape) == 56
     assert C.sizeof(abi.QueryRequest) == 80
     assert C.sizeof(abi.CollisionRequest) == 80 + 32
     assert C.sizeof(abi.DistanceRequest) == 80 + 24

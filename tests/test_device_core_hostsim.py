@@ -254,3 +254,28 @@ def test_bvh_distance_device_code_matches_oracle_and_brute_force(pkg, oracle, ho
         VB = B.vertices @ g.pose_R(tf2[k]).T + g.pose_T(tf2[k])
         best = min(oracle.sqr_tri_distance(VA[ta], VB[tb])[0] for ta in A.triangles[::1] for tb in B.triangles[::1])
         assert abs(np.sqrt(best) - ref["distance"][k]) < 1e-9
+
+
+# ------------------------------------------------------------------ Plane / Halfspace rows
+def _same(a, b, tol=0.0):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    both_nan = np.isnan(a) & np.isnan(b)
+    if tol == 0.0:
+        return bool(np.all(both_nan | (a == b)))
+    with np.errstate(invalid="ignore", over="ignore"):
+        return bool(np.all(both_nan | (a == b) | (np.abs(a - b) <= tol * (1 + np.abs(b)))))
+
+
+@pytest.mark.parametrize("kind", ["collide", "distance"])
+def test_flat_rows_match_oracle(pkg, oracle, hostsim, kind):
+    abi, wl = pkg.abi, pkg.workloads
+    b = wl.flat_pairs(n=20000, kind=kind)
+    req = wl.make_request(b, abi)
+    ref = _oracle(oracle, b, req, b.tf1, b.tf2)
+    got = hostsim.batch_f64(abi, b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req)
+    assert np.array_equal(got["status"], ref["status"])
+    assert not abi.status_skipped(ref["status"]).any()
+    for f in ("distance", "normal", "p1", "p2"):
+        assert _same(got[f], ref[f]), f
+    inf = ref["distance"] == -np.finfo(np.float64).max
+    assert 0.02 < inf.mean() < 0.2  # crossing / nested flats: infinite penetration (details.h:520-560)

@@ -33,7 +33,7 @@ def _engine(pkg, b, req):
 
 def test_native_library_is_loaded(pkg):
     assert pkg.engine.device_count() >= 1
-    assert pkg.engine.dll().hfcl_abi_version() == 1
+    assert pkg.engine.dll().hfcl_abi_version() == 2
 
 
 @pytest.mark.parametrize("case,n", [("cfg1_sphere_sphere", 1000), ("cfg2_box_capsule", 100000),
@@ -328,3 +328,24 @@ def test_cpp_shim_runs_reference_style_tests(pkg):
     subprocess.check_call(["make", "-s", "-C", d])
     r = subprocess.run([os.path.join(d, "test_compat")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("kind", ["collide", "distance"])
+def test_flat_rows_gpu(pkg, oracle, kind):
+    """Plane / Halfspace rows (closed forms, details.h:347-428,509-691) on the device vs the oracle: statuses
+    exact, numbers to 1e-9 relative (FMA contraction only), infinite penetrations (-DBL_MAX) exact."""
+    abi, wl = pkg.abi, pkg.workloads
+    b = wl.flat_pairs(n=60000, kind=kind)
+    req = wl.make_request(b, abi)
+    ref = _oracle(oracle, b, req)
+    got, buckets = _engine(pkg, b, req)
+    assert buckets["unsupported"] == 0 and buckets["closed"] == len(b)
+    assert np.array_equal(got["status"], ref["status"])
+    inf = ref["distance"] == -np.finfo(np.float64).max
+    assert np.array_equal(got["distance"] == -np.finfo(np.float64).max, inf) and 0.02 < inf.mean() < 0.2
+    with np.errstate(invalid="ignore", over="ignore"):
+        for f in ("distance", "normal", "p1", "p2"):
+            a, r = got[f].astype(np.float64), ref[f].astype(np.float64)
+            fin = np.isfinite(r) & (np.abs(r) < 1e300)
+            assert np.array_equal(np.isnan(a), np.isnan(r)), f
+            assert np.all(np.abs(a[fin] - r[fin]) <= 1e-9 * (1 + np.abs(r[fin]))), f
