@@ -49,10 +49,19 @@ using namespace hfcl;
 // bucket ids (finer than hfcl_shapes.hpp's pair_class: the convex bucket is split by which
 // side carries vertices so the kernel is specialised at compile time)
 // ---------------------------------------------------------------------------------------
-enum { B_CLOSED = 0, B_PRIM = 1, B_CC = 2, B_PC = 3, B_CP = 4, B_BVH = 5, B_UNSUPPORTED = 6, B_COUNT = 7 };
+enum { B_CLOSED = 0, B_PRIM = 1, B_CC = 2, B_PC = 3, B_CP = 4, B_BVH = 5, B_UNSUPPORTED = 6, B_LARGE = 7, B_COUNT = 8 };
+
+// Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
+// support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
+// the B_LARGE bucket whose kernel scans the vertices from memory instead of holding them in registers.
+constexpr int K_CONVEX_LARGE = 21;
 
 __host__ __device__ inline int bucket_of(int k1, int k2) {
+  const bool large = (k1 == K_CONVEX_LARGE) || (k2 == K_CONVEX_LARGE);
+  if (k1 == K_CONVEX_LARGE) k1 = K_CONVEX;
+  if (k2 == K_CONVEX_LARGE) k2 = K_CONVEX;
   const int c = pair_class(k1, k2);
+  if (large && c == CLS_CONVEX) return B_LARGE;
   if (c == CLS_CLOSED) return B_CLOSED;
   if (c == CLS_PRIM_GJK) return B_PRIM;
   if (c == CLS_BVH) return B_BVH;
@@ -280,15 +289,17 @@ __global__ void __launch_bounds__(256) k_closed(Work wk, LibView<T> lib, IO<T> i
 template <typename T>
 __device__ __forceinline__ void finish_gjk(const Gjk<T, PW0<T>>& g, const Work& wk, const IO<T>& io, const QParams<T>& q,
                                            uint32_t pair, const Pose<T>& tf1, T r0, T r1, const V3<T>& guess0,
-                                           bool writer) {
+                                           bool writer, bool full_tier = false) {
   PairOut<T> o;
   EpaSeed<T> seed;
   const bool to_epa = gjk_finish(g, q, tf1, r0, r1, guess0, o, seed);
   if (!writer) return;
   if (to_epa) {
-    const uint32_t slot = atomicAdd(&wk.counts[B_COUNT], 1u);
+    // full_tier: straight to the full-capacity EPA queue (pairs with a large hull: only that tier
+    // can scan vertices from memory)
+    const uint32_t slot = atomicAdd(&wk.counts[full_tier ? B_COUNT + 1 : B_COUNT], 1u);
     seed.pair = pair;
-    reinterpret_cast<EpaSeed<T>*>(wk.epa_queue)[slot] = seed;
+    reinterpret_cast<EpaSeed<T>*>(full_tier ? wk.epa_queue2 : wk.epa_queue)[slot] = seed;
   } else {
     write_out<T>(io, q, pair, o);
     write_guess<T>(io, pair, o.cached_guess, 0, 0);
@@ -323,6 +334,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_W
 // getShapeSupportLinear (support_functions.cpp:400-421): first index of the maximum dot.
 // ---------------------------------------------------------------------------------------
 constexpr int HULL_MAX = 32;  // ConvexBase::num_vertices_large_convex_threshold (geometric_shapes.h:709)
+constexpr int HULL_LARGE_MAX = 1 << 16;  // hulls above HULL_MAX are scanned from memory (k_gjk_large)
 
 template <typename T, int W>
 struct HullRegs {
@@ -438,6 +450,80 @@ static void launch_gjk_cvx(int grid, hipStream_t st, const Work& wk, const LibVi
 }
 
 // ---------------------------------------------------------------------------------------
+// k_gjk_large: GJK for pairs with a hull of more than 32 vertices (either side; the other side may be
+// any convex kind).  One pair per LW-lane group, vertices streamed from memory (L2-resident).
+// ---------------------------------------------------------------------------------------
+// Linear-scan support of a hull too large for registers: lane l of the W-lane group looks at vertices
+// l, l+W, ... (coalesced), the group reduces to the first index of the maximum (the tie rule of
+// getShapeSupportLinear; the reference's neighbour hill-climbing, support_functions.cpp:323-397, reaches
+// a vertex of the same support value, possibly another one on a plateau -- see DESIGN.md).
+template <typename T, int W>
+__device__ __forceinline__ V3<T> scan_support(const T* v, uint32_t n, const V3<T>& dir, int lig) {
+  T best = -Lim<T>::max();
+  uint32_t bi = 0xFFFFFFFFu;
+  for (uint32_t i = uint32_t(lig); i < n; i += W) {
+    const T d = v[3 * i] * dir.x + v[3 * i + 1] * dir.y + v[3 * i + 2] * dir.z;
+    if (d > best) {
+      best = d;
+      bi = i;
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < W; m <<= 1) {
+    const T od = __shfl_xor(best, m, W);
+    const uint32_t oi = __shfl_xor(bi, m, W);
+    if (od > best || (od == best && oi < bi)) {
+      best = od;
+      bi = oi;
+    }
+  }
+  return mk<T>(v[3 * bi], v[3 * bi + 1], v[3 * bi + 2]);
+}
+
+constexpr int LARGE_W = 16;
+template <typename T>
+struct LargeSupport {
+  DShape<T> a, b;
+  const T* va;
+  const T* vb;
+  MDiff<T> md;
+  int lig;
+  __device__ __forceinline__ V3<T> one(const DShape<T>& s, const T* v, const V3<T>& d) const {
+    return s.kind == K_CONVEX ? scan_support<T, LARGE_W>(v, s.num_points, d, lig) : prim_support(s, d);
+  }
+  __device__ __forceinline__ void operator()(const V3<T>& dir, V3<T>& w, V3<T>& w0) const {
+    w0 = one(a, va, dir);
+    const V3<T> d1 = md.identity ? -dir : -tmul(md.oR1, dir);
+    V3<T> s1 = one(b, vb, d1);
+    s1 = md.identity ? s1 : (mul(md.oR1, s1) + md.ot1);
+    w = w0 - s1;
+  }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_gjk_large(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  const uint32_t cnt = wk.counts[B_LARGE];
+  const int lig = threadIdx.x & (LARGE_W - 1);
+  const uint32_t groups = (gridDim.x * blockDim.x) / LARGE_W;
+  for (uint32_t it = (blockIdx.x * blockDim.x + threadIdx.x) / LARGE_W; it < cnt; it += groups) {
+    const uint32_t pair = wk.lists[size_t(B_LARGE) * wk.n + it];
+    LargeSupport<T> sup;
+    sup.a = lib.shapes[wk.shape1[pair]];
+    sup.b = lib.shapes[wk.shape2[pair]];
+    sup.va = lib.verts + 3 * size_t(sup.a.vertex_offset);
+    sup.vb = lib.verts + 3 * size_t(sup.b.vertex_offset);
+    sup.lig = lig;
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    sup.md = make_mdiff(tf1, tf2);
+    const T r0 = swept_radius(sup.a), r1 = swept_radius(sup.b);
+    const V3<T> guess0 = initial_guess<T>(io, q, pair);
+    Gjk<T, PW0<T>> g;
+    gjk_run(g, q.gjk, guess0, r0 + r1, sup.a.kind == K_CONVEX && sup.b.kind == K_CONVEX, sup);
+    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0, true);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // k_epa: EPA on the pairs GJK left in `Collision`.  One polytope per WE-lane group, 64/WE polytopes
 // per wavefront, scratch blocks in LDS.  Two tiers:
 //   tier 1  WE = 8, CAP = EPA_FAST_CAP iterations: 8 polytopes per wave share one instruction stream;
@@ -465,21 +551,29 @@ constexpr int EPA_WE = HFCL_EPA_WE;
 #endif
 constexpr int EPA_WE2 = HFCL_EPA_WE2;  // lanes per polytope in the full-capacity tier
 
-template <typename T, int WE>
+// LARGE: hulls of more than HULL_MAX vertices may occur (scanned from memory); only the
+// full-capacity tier is built that way, so the fast tier keeps its register budget.
+template <typename T, int WE, bool LARGE>
 struct EpaSupport {  // any pair kind, evaluated by one lane group
   DShape<T> a, b;
   HullRegs<T, WE> h0, h1;
+  const T* va;
+  const T* vb;
   MDiff<T> md;
   int lig;
+  __device__ __forceinline__ V3<T> hull(const DShape<T>& s, const HullRegs<T, WE>& h, const T* v, const V3<T>& d) const {
+    if (LARGE && s.num_points > uint32_t(HULL_MAX)) return scan_support<T, WE>(v, s.num_points, d, lig);
+    return h.support(d, lig);
+  }
   __device__ __forceinline__ void operator()(const V3<T>& dir, V3<T>& w, V3<T>& w0) const {
     if (a.kind == K_CONVEX)
-      w0 = h0.support(dir, lig);
+      w0 = hull(a, h0, va, dir);
     else
       w0 = prim_support(a, dir);
     const V3<T> d1 = md.identity ? -dir : -tmul(md.oR1, dir);
     V3<T> s1;
     if (b.kind == K_CONVEX)
-      s1 = h1.support(d1, lig);
+      s1 = hull(b, h1, vb, d1);
     else
       s1 = prim_support(b, d1);
     s1 = md.identity ? s1 : (mul(md.oR1, s1) + md.ot1);
@@ -499,12 +593,18 @@ __global__ void __launch_bounds__(64) k_epa(Work wk, LibView<T> lib, IO<T> io, Q
   for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += groups) {
     const EpaItem<T> item = queue[it];
     const uint32_t pair = item.pair;
-    EpaSupport<T, WE> sup;
+    EpaSupport<T, WE, TIER == 2> sup;
     sup.a = lib.shapes[wk.shape1[pair]];
     sup.b = lib.shapes[wk.shape2[pair]];
     sup.lig = lig;
-    if (sup.a.kind == K_CONVEX) sup.h0.load(lib.verts + 3 * size_t(sup.a.vertex_offset), sup.a.num_points, lig);
-    if (sup.b.kind == K_CONVEX) sup.h1.load(lib.verts + 3 * size_t(sup.b.vertex_offset), sup.b.num_points, lig);
+    const T* va = lib.verts + 3 * size_t(sup.a.vertex_offset);
+    const T* vb = lib.verts + 3 * size_t(sup.b.vertex_offset);
+    if (TIER == 2) {
+      sup.va = va;
+      sup.vb = vb;
+    }
+    if (sup.a.kind == K_CONVEX && (TIER != 2 || sup.a.num_points <= uint32_t(HULL_MAX))) sup.h0.load(va, sup.a.num_points, lig);
+    if (sup.b.kind == K_CONVEX && (TIER != 2 || sup.b.num_points <= uint32_t(HULL_MAX))) sup.h1.load(vb, sup.b.num_points, lig);
     const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
     sup.md = make_mdiff(tf1, tf2);
     const T r0 = swept_radius(sup.a), r1 = swept_radius(sup.b);
@@ -961,9 +1061,8 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
       return nullptr;
     }
     if (s.type == HFCL_GEOM_CONVEX) {
-      if (s.num_points == 0 || s.num_points > (uint32_t)HULL_MAX) {
-        set_error("hfcl_lib_create: convex shapes must have 1.." + std::to_string(HULL_MAX) +
-                  " vertices (linear-support path, support_functions.cpp:400-421); got " +
+      if (s.num_points == 0 || s.num_points > (uint32_t)HULL_LARGE_MAX) {
+        set_error("hfcl_lib_create: convex shapes must have 1.." + std::to_string(HULL_LARGE_MAX) + " vertices; got " +
                   std::to_string(s.num_points));
         return nullptr;
       }
@@ -1000,7 +1099,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
     s32[i].p2 = float(s.params[2]);
     s32[i].p3 = float(s.params[3]);
     s32[i].ssr = float(s.swept_sphere_radius);
-    kinds[i] = uint8_t(s.type);
+    kinds[i] = uint8_t(s.type == HFCL_GEOM_CONVEX && s.num_points > (uint32_t)HULL_MAX ? K_CONVEX_LARGE : s.type);
   }
   std::vector<float> v32(3 * n_vertices + 3);
   for (size_t i = 0; i < 3 * n_vertices; ++i) v32[i] = float(vertices[i]);
@@ -1319,6 +1418,11 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   else if (w == 64) launch_cvx<T, 64>(lib, wk, lv, io, q, st, ti, cgrid);
   else if (w == 8) launch_cvx<T, 8>(lib, wk, lv, io, q, st, ti, cgrid);
   else launch_cvx<T, 4>(lib, wk, lv, io, q, st, ti, cgrid);
+
+  t = timer_slot(lib, ti++, "k_gjk_large");
+  hipEventRecord(t->e0, st);
+  hipLaunchKernelGGL((k_gjk_large<T>), dim3(blocks_for(n, 256 / LARGE_W)), dim3(256), 0, st, wk, lv, io, q);
+  hipEventRecord(t->e1, st);
 
   if (!lib->h_meshes.empty()) {
     rc = upload_bvh(lib);
@@ -1661,8 +1765,8 @@ int hfcl_last_kernel_breakdown(hfcl_lib* lib, const char** names, double* ms, in
 
 // bucket populations of the last call (after a stream sync): closed, prim, cc, pc, cp, bvh, unsupported,
 // epa queue, epa overflow queue
-void hfcl_last_bucket_counts(hfcl_lib* lib, uint32_t* out9) {
-  for (int i = 0; i <= B_COUNT + 1; ++i) out9[i] = lib ? lib->h_counts[i] : 0;
+void hfcl_last_bucket_counts(hfcl_lib* lib, uint32_t* out10) {  // B_COUNT buckets + the two EPA queues
+  for (int i = 0; i <= B_COUNT + 1; ++i) out10[i] = lib ? lib->h_counts[i] : 0;
 }
 
 }  // extern "C"

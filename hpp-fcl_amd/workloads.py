@@ -196,6 +196,34 @@ def flat_pairs(n=50_000, seed=1, nper=64, half_width=1.0, kind="collide"):
     return Batch("flat_pairs_" + kind, lib, s1, s2, q1, T1, q2, T2, kind)
 
 
+def large_convex(n=50_000, seed=1, sizes=(33, 48, 64, 100, 256), nlib_each=12, half_width=1.0, kind="distance"):
+    """Hulls above ConvexBase::num_vertices_large_convex_threshold (32) against each other, small hulls and
+    primitives.  Points are random directions scaled onto an ellipsoid, so every point is a hull vertex."""
+    rng = _rng(seed, 8)
+    lib = geometry.ShapeLibrary()
+    for nv in sizes:
+        for radii in rng.uniform(0.2, 1.0, (nlib_each, 3)):
+            d = rng.normal(size=(nv, 3))
+            lib.add_convex(d / np.linalg.norm(d, axis=1, keepdims=True) * radii)
+    n_large = len(sizes) * nlib_each
+    base = fibonacci_sphere(32)
+    for radii in rng.uniform(0.2, 1.0, (nlib_each, 3)):
+        lib.add_convex(base * radii)
+    for s in rng.uniform(0.2, 1.0, (nlib_each, 3)):
+        lib.add_box(*map(float, s))
+    for r, lz in zip(rng.uniform(0.1, 0.6, nlib_each), rng.uniform(0.2, 1.0, nlib_each)):
+        lib.add_capsule(float(r), float(lz))
+    n_all = len(lib)
+    s1 = rng.integers(0, n_large, n)                       # always a large hull on one side ...
+    s2 = rng.integers(0, n_all, n)
+    swap = rng.random(n) < 0.5                             # ... which side is random
+    s1, s2 = np.where(swap, s2, s1), np.where(swap, s1, s2)
+    q1, T1, q2, T2 = _poses(rng, n, half_width)
+    b = Batch("large_convex_" + kind, lib, s1, s2, q1, T1, q2, T2, kind)
+    b.n_large = n_large
+    return b
+
+
 def cfg5_mixed(n=100_000, seed=1, nper=256, half_width=0.8):
     """cfg5-style mixed primitive+convex pairs (type mix 20 % each of Box/Sphere/Capsule/
     Ellipsoid/Convex32), synthetic pair list (cfg5_broadphase_scene takes its pairs from the host broadphase)."""

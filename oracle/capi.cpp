@@ -10,6 +10,24 @@
 
 using namespace orc;
 
+// Test-only registry of ConvexBase::neighbors for large hulls (the C ABI of the product does not carry
+// them: the device scans all vertices).  Keyed by vertex_offset of the hull.
+#include <map>
+struct NbrEntry {
+  std::vector<uint32_t> off, ids;
+};
+static std::map<uint32_t, NbrEntry>& nbr_registry() {
+  static std::map<uint32_t, NbrEntry> r;
+  return r;
+}
+extern "C" void orc_clear_neighbors() { nbr_registry().clear(); }
+extern "C" void orc_register_neighbors(uint32_t vertex_offset, const uint32_t* off, uint32_t n_points, const uint32_t* ids) {
+  NbrEntry e;
+  e.off.assign(off, off + n_points + 1);
+  e.ids.assign(ids, ids + off[n_points]);
+  nbr_registry()[vertex_offset] = std::move(e);
+}
+
 static Shape make_shape(const hfcl_shape& s, const double* vertices) {
   Shape r;
   r.kind = s.type;
@@ -21,6 +39,27 @@ static Shape make_shape(const hfcl_shape& s, const double* vertices) {
   if (s.type == HFCL_GEOM_CONVEX || s.type == HFCL_GEOM_TRIANGLE) {
     r.verts = vertices + 3 * size_t(s.vertex_offset);
     r.nverts = int(s.num_points);
+  }
+  if (s.type == HFCL_GEOM_CONVEX && s.num_points >= 32) {
+    auto it = nbr_registry().find(s.vertex_offset);
+    if (it != nbr_registry().end() && it->second.off.size() == size_t(s.num_points) + 1) {
+      r.nbr_off = it->second.off.data();
+      r.nbr = it->second.ids.data();
+      // buildSupportWarmStart (gjk.cpp:1470-1534): supports along +-e_i and the four cube diagonals,
+      // hint and support data carried from one call to the next
+      static const double dirs[14][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}, {1, 1, 1},
+                                         {-1, -1, -1}, {-1, 1, 1}, {1, -1, -1}, {-1, -1, 1}, {1, 1, -1}, {1, -1, 1}, {-1, 1, -1}};
+      SupportData sd;
+      int hint = 0;
+      r.n_warm = 0;  // grows while it is being built: each call already sees the earlier entries
+      for (int k = 0; k < 14; ++k) {
+        const V3 d(dirs[k][0], dirs[k][1], dirs[k][2]);
+        const V3 sp = shape_support(r, d, hint, &sd);
+        r.warm_pts[k][0] = sp.x; r.warm_pts[k][1] = sp.y; r.warm_pts[k][2] = sp.z;
+        r.warm_idx[k] = hint;
+        r.n_warm = k + 1;
+      }
+    }
   }
   return r;
 }

@@ -26,7 +26,68 @@ struct Shape {
   double ssr = 0;            // swept sphere radius
   const double* verts = nullptr;  // CONVEX / TRIANGLE vertices (xyz)
   int nverts = 0;
+  // ConvexBase::neighbors (CSR, ids ascending: fillNeighbors, details/convex.hxx:231-280) and
+  // ConvexBase::support_warm_starts (buildSupportWarmStart, gjk.cpp:1470-1534); only read for
+  // num_points > 32 (minkowski_difference.cpp:136-151)
+  const uint32_t* nbr_off = nullptr;
+  const uint32_t* nbr = nullptr;
+  int n_warm = 0;
+  double warm_pts[14][3];
+  int warm_idx[14];
 };
+
+// details::ShapeSupportData (support_functions.h:79-85)
+struct SupportData {
+  V3 last_dir = V3(0, 0, 0);
+  std::vector<int8_t> visited;
+};
+
+// getShapeSupportLog (support_functions.cpp:323-397, NoSweptSphere): neighbour hill climbing
+inline V3 convex_support_log(const Shape& s, const V3& dir, int& hint, SupportData& sd) {
+  const double use_warm_start_threshold = 0.9;
+  const V3 dir_normalized = normalized(dir);
+  const bool last_zero = std::abs(sd.last_dir.x) <= 1e-12 && std::abs(sd.last_dir.y) <= 1e-12 && std::abs(sd.last_dir.z) <= 1e-12;
+  if (!last_zero && s.n_warm > 0 && dot(sd.last_dir, dir_normalized) < use_warm_start_threshold) {
+    double maxdot = s.warm_pts[0][0] * dir.x + s.warm_pts[0][1] * dir.y + s.warm_pts[0][2] * dir.z;
+    hint = s.warm_idx[0];
+    for (int i = 1; i < s.n_warm; ++i) {
+      const double d = s.warm_pts[i][0] * dir.x + s.warm_pts[i][1] * dir.y + s.warm_pts[i][2] * dir.z;
+      if (d > maxdot) {
+        maxdot = d;
+        hint = s.warm_idx[i];
+      }
+    }
+  }
+  sd.last_dir = dir_normalized;
+  if (hint < 0 || hint >= s.nverts) hint = 0;
+  auto pt = [&](int i) { return V3(s.verts[3 * i], s.verts[3 * i + 1], s.verts[3 * i + 2]); };
+  double maxdot = dot(pt(hint), dir);
+  sd.visited.assign(size_t(s.nverts), 0);
+  sd.visited[size_t(hint)] = 1;
+  bool found = true, loose_check = true;
+  while (found) {
+    const uint32_t b = s.nbr_off[hint], e = s.nbr_off[hint + 1];
+    found = false;
+    for (uint32_t in = b; in < e; ++in) {
+      const uint32_t ip = s.nbr[in];
+      if (sd.visited[ip]) continue;
+      sd.visited[ip] = 1;
+      const double d = dot(pt(int(ip)), dir);
+      bool better = false;
+      if (d > maxdot) {
+        better = true;
+        loose_check = false;
+      } else if (loose_check && d == maxdot)
+        better = true;
+      if (better) {
+        maxdot = d;
+        hint = int(ip);
+        found = true;
+      }
+    }
+  }
+  return pt(hint);
+}
 
 enum GJKVariant { DefaultGJK = 0, PolyakAcceleration = 1, NesterovAcceleration = 2 };
 enum GJKCrit { CritDefault = 0, CritDualityGap = 1, CritHybrid = 2 };
@@ -41,7 +102,8 @@ constexpr double kDummyPrecision = 1e-12;  // Eigen::NumTraits<double>::dummy_pr
 
 // support_functions.cpp:110-222, 400-421 (NoSweptSphere option only: that is what
 // GJKSolver::runGJKAndEPA instantiates, narrowphase.h:420-421)
-inline V3 shape_support(const Shape& s, const V3& dir, int& hint) {
+inline V3 shape_support(const Shape& s, const V3& dir, int& hint, SupportData* sd = nullptr) {
+  if (s.kind == K_CONVEX && s.nverts > 32 && s.nbr_off && sd) return convex_support_log(s, dir, hint, *sd);
   switch (s.kind) {
     case K_TRIANGLE: {  // :110-134
       V3 a(s.verts[0], s.verts[1], s.verts[2]), b(s.verts[3], s.verts[4], s.verts[5]),
@@ -164,9 +226,12 @@ struct MinkowskiDiff {
     if (s.kind == K_SPHERE || s.kind == K_CAPSULE) r += s.p[0];
     return r;
   }
+  mutable SupportData data[2];  // minkowski_difference.h:76-77, reset by set() (:136-151 / :196-211)
   void set_common(const Shape* s0, const Shape* s1) {
     shapes[0] = s0;
     shapes[1] = s1;
+    data[0] = SupportData();
+    data[1] = SupportData();
     // geometric_shapes_traits.h:135-144 : only ConvexBase needs the heuristic; :261-266
     normalize_support_direction = (s0->kind == K_CONVEX) && (s1->kind == K_CONVEX);
     swept_sphere_radius[0] = radius_of(*s0);
@@ -186,11 +251,11 @@ struct MinkowskiDiff {
   }
   // getSupportTpl :47-63
   void support(const V3& dir, V3& s0, V3& s1, int hint[2]) const {
-    s0 = shape_support(*shapes[0], dir, hint[0]);
+    s0 = shape_support(*shapes[0], dir, hint[0], &data[0]);
     if (identity) {
-      s1 = shape_support(*shapes[1], -dir, hint[1]);
+      s1 = shape_support(*shapes[1], -dir, hint[1], &data[1]);
     } else {
-      s1 = shape_support(*shapes[1], -tmul(oR1, dir), hint[1]);
+      s1 = shape_support(*shapes[1], -tmul(oR1, dir), hint[1], &data[1]);
       s1 = oR1 * s1 + ot1;
     }
   }

@@ -227,3 +227,33 @@ def bruteforce_pairs(aabbs):
     out = np.zeros((n, 2), dtype=np.uint32)
     fn(C.c_void_p(a.ctypes.data), C.c_size_t(len(a)), C.c_void_p(out.ctypes.data), C.c_size_t(n))
     return out
+
+
+def register_hull_neighbors(shapes, verts):
+    """ConvexBase::neighbors for every hull of >= 32 vertices, as Convex<Triangle>::fillNeighbors builds them
+    (details/convex.hxx:231-280: per vertex the ascending set of vertices sharing a face edge) from the facets
+    scipy's Qhull wrapper reports -- the oracle's hill-climbing support (getShapeSupportLog) walks them."""
+    from scipy.spatial import ConvexHull
+    abi = _pkg().abi
+    L = lib()
+    L.orc_clear_neighbors()
+    verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+    keep = []
+    for s in shapes:
+        if s["type"] != abi.GEOM_CONVEX or s["num_points"] < 32:
+            continue
+        off, n = int(s["vertex_offset"]), int(s["num_points"])
+        hull = ConvexHull(verts[off:off + n])
+        assert len(hull.vertices) == n, "every point must be a hull vertex"
+        nb = [set() for _ in range(n)]
+        for tri in hull.simplices:
+            for j in range(3):
+                a, b = int(tri[j]), int(tri[(j + 1) % 3])
+                nb[a].add(b)
+                nb[b].add(a)
+        offs = np.zeros(n + 1, dtype=np.uint32)
+        offs[1:] = np.cumsum([len(x) for x in nb])
+        ids = np.array([v for x in nb for v in sorted(x)], dtype=np.uint32)
+        keep.append((offs, ids))
+        L.orc_register_neighbors(C.c_uint32(off), C.c_void_p(offs.ctypes.data), C.c_uint32(n), C.c_void_p(ids.ctypes.data))
+    return len(keep)

@@ -279,3 +279,25 @@ def test_flat_rows_match_oracle(pkg, oracle, hostsim, kind):
         assert _same(got[f], ref[f]), f
     inf = ref["distance"] == -np.finfo(np.float64).max
     assert 0.02 < inf.mean() < 0.2  # crossing / nested flats: infinite penetration (details.h:520-560)
+
+
+# ------------------------------------------------------------------ hulls above 32 vertices
+@pytest.mark.parametrize("kind", ["distance", "collide"])
+def test_large_hulls_scan_vs_reference_hill_climbing(pkg, oracle, hostsim, kind):
+    """The device scans all vertices of a large hull (first maximum); the reference climbs the neighbour graph
+    from a hint (support_functions.cpp:323-397).  On hulls in general position both reach the same vertex, so
+    GJK/EPA follow the same path: statuses equal, distances to round-off."""
+    abi, wl = pkg.abi, pkg.workloads
+    b = wl.large_convex(n=6000, kind=kind)
+    assert oracle.register_hull_neighbors(b.shapes, b.verts) >= 60
+    req = wl.make_request(b, abi)
+    ref = _oracle(oracle, b, req, b.tf1, b.tf2)
+    got = hostsim.batch_f64(abi, b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req)
+    st = check_parity(abi, got, ref, dist_tol=1e-9, point_tol=1e-7, flag_band=1e-9, name="large-" + kind)
+    assert st["max_dd"] < 1e-10
+    assert (abi.status_gjk(got["status"]) == abi.status_gjk(ref["status"])).all()
+    # (a climb can stop on a vertex whose rounded dot product ties with the scan's winner: ~1 % of the paths differ)
+    assert (abi.status_gjk_iters(got["status"]) == abi.status_gjk_iters(ref["status"])).mean() > 0.98
+    frac = float(abi.status_contact(ref["status"]).mean())
+    assert 0.15 < frac < 0.85, frac
+    oracle.lib().orc_clear_neighbors()

@@ -349,3 +349,22 @@ def test_flat_rows_gpu(pkg, oracle, kind):
             fin = np.isfinite(r) & (np.abs(r) < 1e300)
             assert np.array_equal(np.isnan(a), np.isnan(r)), f
             assert np.all(np.abs(a[fin] - r[fin]) <= 1e-9 * (1 + np.abs(r[fin]))), f
+
+
+@pytest.mark.parametrize("kind", ["distance", "collide"])
+def test_large_hulls_gpu(pkg, oracle, kind):
+    """Hulls of 33..256 vertices (k_gjk_large + full-capacity EPA tier, vertices scanned from memory) vs the
+    oracle's neighbour hill-climbing support (support_functions.cpp:323-397)."""
+    abi, wl = pkg.abi, pkg.workloads
+    b = wl.large_convex(n=60000, kind=kind)
+    oracle.register_hull_neighbors(b.shapes, b.verts)
+    try:
+        req = wl.make_request(b, abi)
+        ref = _oracle(oracle, b, req)
+    finally:
+        oracle.lib().orc_clear_neighbors()
+    got, buckets = _engine(pkg, b, req)
+    assert buckets["large"] == len(b) and buckets["unsupported"] == 0
+    st = check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name="large-" + kind)
+    assert st["p999_dd"] < 1e-9, st
+    check_properties(abi, got, tol=1e-6, name="large-" + kind)
