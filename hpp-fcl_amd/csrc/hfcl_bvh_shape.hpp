@@ -1,0 +1,429 @@
+// hfcl_bvh_shape.hpp -- BVHModel<OBBRSS> x convex shape collide(): one query.
+//
+// Behavioural contract (reference file:line):
+//   BVHShapeCollider<OBBRSS,S>::oriented      src/collision_func_matrix.cpp:102-155
+//   initialize(MeshShapeCollisionTraversalNode<BV,S,0>)   internal/traversal_node_setup.h:378-404
+//   computeBV<OBBRSS,S> = fit of getBoundVertices   shape/geometric_shapes_utility.h:73-82,
+//                              src/shape/geometric_shapes_utility.cpp:46-240, src/BVH/BV_fitter.cpp:131-143
+//                              (only the OBB half is read by collide(): OBBRSS::overlap -> OBB, OBBRSS.h:88-92)
+//   BVDisjoints / leafCollides                 internal/traversal_node_bvh_shape.h:121-186
+//   collisionRecurse with a leaf second node   src/traversal/traversal_recurse.cpp:44-85
+//   leaf = ShapeShapeDistance<TriangleP,S>     GJK/EPA (shape_shape_func.h table) or
+//                                              sphereTriangleDistance (src/narrowphase/details.h:235-340)
+//
+// The traversal state is sequential by nature (first contact in DFS order, running lower bound), so a
+// query is walked by ONE lane group: control flow is group-uniform, the group's lanes share the
+// support scans and the EPA face work exactly as in k_epa; the DFS stack and the polytope live in LDS.
+// On the host validation build the group is a single lane.
+#pragma once
+#include "hfcl_bvh.hpp"
+#include "hfcl_epa.hpp"
+
+namespace hfcl {
+
+// cyclic Jacobi eigen-decomposition of a symmetric 3x3 (internal/tools.h:103-202); returns false after
+// 50 sweeps without convergence (the reference then leaves its outputs unset; we zero them)
+template <typename T>
+HFCL_HD bool jacobi_eigen3(const T (&Min)[3][3], T (&dout)[3], T (&vout)[3][3]) {
+  T R[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[i][j] = Min[i][j];
+  T b[3], z[3], d[3], v[3][3] = {{T(1), T(0), T(0)}, {T(0), T(1), T(0)}, {T(0), T(0), T(1)}};
+  for (int ip = 0; ip < 3; ++ip) {
+    b[ip] = d[ip] = R[ip][ip];
+    z[ip] = T(0);
+  }
+  for (int i = 0; i < 50; ++i) {
+    const T sm = (habs(R[0][1]) + habs(R[0][2])) + habs(R[1][2]);
+    if (sm == T(0)) {
+      for (int a = 0; a < 3; ++a) {
+        dout[a] = d[a];
+        for (int c = 0; c < 3; ++c) vout[a][c] = v[a][c];
+      }
+      return true;
+    }
+    const T tresh = i < 3 ? T(0.2) * sm / T(9) : T(0);
+    for (int ip = 0; ip < 3; ++ip)
+      for (int iq = ip + 1; iq < 3; ++iq) {
+        T g = T(100) * habs(R[ip][iq]);
+        if (i > 3 && habs(d[ip]) + g == habs(d[ip]) && habs(d[iq]) + g == habs(d[iq])) {
+          R[ip][iq] = T(0);
+        } else if (habs(R[ip][iq]) > tresh) {
+          T h = d[iq] - d[ip], t;
+          if (habs(h) + g == habs(h)) {
+            t = R[ip][iq] / h;
+          } else {
+            const T theta = T(0.5) * h / R[ip][iq];
+            t = T(1) / (habs(theta) + hsqrt(T(1) + theta * theta));
+            if (theta < T(0)) t = -t;
+          }
+          const T c = T(1) / hsqrt(T(1) + t * t), s = t * c, tau = s / (T(1) + c);
+          h = t * R[ip][iq];
+          z[ip] -= h;
+          z[iq] += h;
+          d[ip] -= h;
+          d[iq] += h;
+          R[ip][iq] = T(0);
+          const int r = 3 - ip - iq;  // the third index of a 3x3
+          T* x;
+          T* y;
+          if (r < ip) {
+            x = &R[r][ip];
+            y = &R[r][iq];
+          } else if (r < iq) {
+            x = &R[ip][r];
+            y = &R[r][iq];
+          } else {
+            x = &R[ip][r];
+            y = &R[iq][r];
+          }
+          {
+            const T gg = *x, hh = *y;
+            *x = gg - s * (hh + gg * tau);
+            *y = hh + s * (gg - hh * tau);
+          }
+          for (int j = 0; j < 3; ++j) {
+            const T gg = v[j][ip], hh = v[j][iq];
+            v[j][ip] = gg - s * (hh + gg * tau);
+            v[j][iq] = hh + s * (gg - hh * tau);
+          }
+        }
+      }
+    for (int ip = 0; ip < 3; ++ip) {
+      b[ip] += z[ip];
+      d[ip] = b[ip];
+      z[ip] = T(0);
+    }
+  }
+  for (int a = 0; a < 3; ++a) {
+    dout[a] = T(0);
+    for (int c = 0; c < 3; ++c) vout[a][c] = T(0);
+  }
+  return false;
+}
+
+// getBoundVertices (geometric_shapes_utility.cpp:46-240): calls f(world point) in the reference's order.
+// Returns the number of points (0: kind without a polyhedral bound here).
+template <typename T, class F>
+HFCL_HD int for_each_bound_vertex(const DShape<T>& s, const T* verts, const Pose<T>& tf, F f) {
+  auto add = [&](T x, T y, T z) { f(xform(tf, mk<T>(x, y, z))); };
+  if (s.kind == K_BOX) {
+    const T a = s.p0, b = s.p1, c = s.p2;
+    add(a, b, c); add(a, b, -c); add(a, -b, c); add(a, -b, -c);
+    add(-a, b, c); add(-a, b, -c); add(-a, -b, c); add(-a, -b, -c);
+    return 8;
+  }
+  if (s.kind == K_SPHERE || s.kind == K_CAPSULE) {
+    const T m = (T(1) + hsqrt(T(5))) / T(2);
+    const T edge = s.p0 * T(6) / (hsqrt(T(27)) + hsqrt(T(15)));
+    const T a = edge, b = m * edge;
+    if (s.kind == K_SPHERE) {
+      add(T(0), a, b); add(T(0), -a, b); add(T(0), a, -b); add(T(0), -a, -b);
+      add(a, b, T(0)); add(-a, b, T(0)); add(a, -b, T(0)); add(-a, -b, T(0));
+      add(b, T(0), a); add(b, T(0), -a); add(-b, T(0), a); add(-b, T(0), -a);
+      return 12;
+    }
+    const T hl = s.p1, r2 = s.p0 * T(2) / hsqrt(T(3));
+    add(T(0), a, b + hl); add(T(0), -a, b + hl); add(T(0), a, -b + hl); add(T(0), -a, -b + hl);
+    add(a, b, hl); add(-a, b, hl); add(a, -b, hl); add(-a, -b, hl);
+    add(b, T(0), a + hl); add(b, T(0), -a + hl); add(-b, T(0), a + hl); add(-b, T(0), -a + hl);
+    add(T(0), a, b - hl); add(T(0), -a, b - hl); add(T(0), a, -b - hl); add(T(0), -a, -b - hl);
+    add(a, b, -hl); add(-a, b, -hl); add(a, -b, -hl); add(-a, -b, -hl);
+    add(b, T(0), a - hl); add(b, T(0), -a - hl); add(-b, T(0), a - hl); add(-b, T(0), -a - hl);
+    const T c = T(0.5) * r2, d = s.p0;
+    add(r2, T(0), hl); add(c, d, hl); add(-c, d, hl); add(-r2, T(0), hl); add(-c, -d, hl); add(c, -d, hl);
+    add(r2, T(0), -hl); add(c, d, -hl); add(-c, d, -hl); add(-r2, T(0), -hl); add(-c, -d, -hl); add(c, -d, -hl);
+    return 36;
+  }
+  if (s.kind == K_ELLIPSOID) {
+    const T phi = (T(1) + hsqrt(T(5))) / T(2);
+    const T a = hsqrt(T(3)) / (phi * phi), b = phi * a;
+    const T Aa = s.p0 * a, Ab = s.p0 * b, Ba = s.p1 * a, Bb = s.p1 * b, Ca = s.p2 * a, Cb = s.p2 * b;
+    add(T(0), Ba, Cb); add(T(0), -Ba, Cb); add(T(0), Ba, -Cb); add(T(0), -Ba, -Cb);
+    add(Aa, Bb, T(0)); add(-Aa, Bb, T(0)); add(Aa, -Bb, T(0)); add(-Aa, -Bb, T(0));
+    add(Ab, T(0), Ca); add(Ab, T(0), -Ca); add(-Ab, T(0), Ca); add(-Ab, T(0), -Ca);
+    return 12;
+  }
+  if (s.kind == K_CONE || s.kind == K_CYLINDER) {
+    const T hl = s.p1, r2 = s.p0 * T(2) / hsqrt(T(3)), a = T(0.5) * r2, b = s.p0;
+    add(r2, T(0), -hl); add(a, b, -hl); add(-a, b, -hl); add(-r2, T(0), -hl); add(-a, -b, -hl); add(a, -b, -hl);
+    if (s.kind == K_CONE) {
+      add(T(0), T(0), hl);
+      return 7;
+    }
+    add(r2, T(0), hl); add(a, b, hl); add(-a, b, hl); add(-r2, T(0), hl); add(-a, -b, hl); add(a, -b, hl);
+    return 12;
+  }
+  if (s.kind == K_CONVEX) {
+    const T* v = verts + 3 * size_t(s.vertex_offset);
+    for (uint32_t i = 0; i < s.num_points; ++i) add(v[3 * i], v[3 * i + 1], v[3 * i + 2]);
+    return int(s.num_points);
+  }
+  return 0;
+}
+
+// computeBV<OBB-half of OBBRSS>(shape, tf): OBB_fit_functions::fitn on the bound vertices.
+// Returns false when the reference path is not restated (fewer than 4 points, swept-sphere radius).
+template <typename T>
+HFCL_HD bool shape_obb(const DShape<T>& s, const T* verts, const Pose<T>& tf, DNode<T>& bv) {
+  if (s.ssr > T(0)) return false;  // "Swept-sphere radius not yet supported." (geometric_shapes_utility.h:75-78)
+  V3<T> S1 = mk<T>(T(0), T(0), T(0));
+  T sxx = T(0), syy = T(0), szz = T(0), sxy = T(0), sxz = T(0), syz = T(0);
+  const int n = for_each_bound_vertex(s, verts, tf, [&](const V3<T>& p) {  // getCovariance, point-cloud branch
+    S1 = S1 + p;
+    sxx += (p.x * p.x);
+    syy += (p.y * p.y);
+    szz += (p.z * p.z);
+    sxy += (p.x * p.y);
+    sxz += (p.x * p.z);
+    syz += (p.y * p.z);
+  });
+  if (n < 4) return false;
+  const T np = T(n);
+  T M[3][3];
+  M[0][0] = sxx - S1.x * S1.x / np;
+  M[1][1] = syy - S1.y * S1.y / np;
+  M[2][2] = szz - S1.z * S1.z / np;
+  M[0][1] = M[1][0] = sxy - S1.x * S1.y / np;
+  M[1][2] = M[2][1] = syz - S1.y * S1.z / np;
+  M[0][2] = M[2][0] = sxz - S1.x * S1.z / np;
+  T ev[3], E[3][3];
+  jacobi_eigen3(M, ev, E);
+  int mn, mid, mx;  // axisFromEigen
+  if (ev[0] > ev[1]) {
+    mx = 0;
+    mn = 1;
+  } else {
+    mn = 0;
+    mx = 1;
+  }
+  if (ev[2] < ev[mn]) {
+    mid = mn;
+    mn = 2;
+  } else if (ev[2] > ev[mx]) {
+    mid = mx;
+    mx = 2;
+  } else {
+    mid = 2;
+  }
+  (void)mn;
+  const V3<T> a0 = mk<T>(E[0][mx], E[1][mx], E[2][mx]), a1 = mk<T>(E[0][mid], E[1][mid], E[2][mid]);
+  const V3<T> a2 = mk<T>(E[1][mx] * E[2][mid] - E[1][mid] * E[2][mx], E[0][mid] * E[2][mx] - E[0][mx] * E[2][mid],
+                         E[0][mx] * E[1][mid] - E[0][mid] * E[1][mx]);
+  const T big = Lim<T>::max();
+  V3<T> lo = mk<T>(big, big, big), hi = mk<T>(-big, -big, -big);
+  for_each_bound_vertex(s, verts, tf, [&](const V3<T>& p) {  // getExtentAndCenter_pointcloud
+    const V3<T> q = mk<T>(dot(a0, p), dot(a1, p), dot(a2, p));
+    if (q.x > hi.x) hi.x = q.x;
+    if (q.x < lo.x) lo.x = q.x;
+    if (q.y > hi.y) hi.y = q.y;
+    if (q.y < lo.y) lo.y = q.y;
+    if (q.z > hi.z) hi.z = q.z;
+    if (q.z < lo.z) lo.z = q.z;
+  });
+  const V3<T> sum = hi + lo;
+  // axes matrix: columns a0 a1 a2 -> rows r_i = (a0[i], a1[i], a2[i])
+  bv.axes.r0 = mk<T>(a0.x, a1.x, a2.x);
+  bv.axes.r1 = mk<T>(a0.y, a1.y, a2.y);
+  bv.axes.r2 = mk<T>(a0.z, a1.z, a2.z);
+  bv.To = mul(bv.axes, sum) / T(2);
+  bv.extent = (hi - lo) / T(2);
+  bv.first_child = -1;
+  bv.pad_ = 0;
+  return true;
+}
+
+// details::segmentSqrDistance :235-255, projectInTriangle :258-279, sphereTriangleDistance :286-340
+template <typename T>
+HFCL_HD T segment_sqr_distance(const V3<T>& from, const V3<T>& to, const V3<T>& p, V3<T>& nearest) {
+  V3<T> diff = p - from;
+  const V3<T> v = to - from;
+  T t = dot(v, diff);
+  if (t > T(0)) {
+    const T vv = sqnorm(v);
+    if (t < vv) {
+      t /= vv;
+      diff = diff - v * t;
+    } else {
+      t = T(1);
+      diff = diff - v;
+    }
+  } else {
+    t = T(0);
+  }
+  nearest = from + v * t;
+  return sqnorm(diff);
+}
+template <typename T>
+HFCL_HD T sphere_triangle(const DShape<T>& s, const Pose<T>& tf1, const V3<T>& P1, const V3<T>& P2, const V3<T>& P3, V3<T>& p1,
+                          V3<T>& p2, V3<T>& normal) {
+  V3<T> tn = normalized(cross(P2 - P1, P3 - P1));
+  const V3<T> center = tf1.t;
+  const T radius = s.p0 + s.ssr;  // + the triangle's swept-sphere radius (0 for mesh triangles)
+  T dplane = dot(center - P1, tn);
+  if (dplane < T(0)) {
+    dplane = -dplane;
+    tn = tn * T(-1);
+  }
+  const T r1 = dot(cross(P2 - P1, tn), center - P1), r2 = dot(cross(P3 - P2, tn), center - P2),
+          r3 = dot(cross(P1 - P3, tn), center - P3);
+  V3<T> closest;
+  T mind;
+  if ((r1 > T(0) && r2 > T(0) && r3 > T(0)) || (r1 <= T(0) && r2 <= T(0) && r3 <= T(0))) {
+    closest = center - tn * dplane;
+    mind = dplane * dplane;
+  } else {
+    V3<T> e;
+    mind = segment_sqr_distance(P1, P2, center, closest);
+    T d2 = segment_sqr_distance(P2, P3, center, e);
+    if (d2 < mind) {
+      mind = d2;
+      closest = e;
+    }
+    d2 = segment_sqr_distance(P3, P1, center, e);
+    if (d2 < mind) {
+      mind = d2;
+      closest = e;
+    }
+  }
+  normal = normalized(closest - center);
+  p1 = center + normal * (s.p0 + s.ssr);
+  p2 = closest;
+  return hsqrt(mind) - radius;
+}
+
+// MinkowskiDiff of (TriangleP in the mesh frame, solid shape): shape 0 = the triangle.
+template <typename T, class Solid>
+struct TriSolidSupport {
+  V3<T> a, b, c;
+  const Solid* solid;  // V3<T> (*solid)(dir): support of the solid in its own frame (NoSweptSphere)
+  MDiff<T> md;
+  HFCL_HD void operator()(const V3<T>& dir, V3<T>& w, V3<T>& w0) const {
+    w0 = tri_support(a, b, c, dir);
+    const V3<T> d1 = md.identity ? -dir : -tmul(md.oR1, dir);
+    V3<T> s1 = (*solid)(d1);
+    s1 = md.identity ? s1 : (mul(md.oR1, s1) + md.ot1);
+    w = w0 - s1;
+  }
+};
+
+template <typename T>
+struct MeshShapeState {  // the CollisionResult fields the traversal maintains
+  T dlb, rec_dist;
+  V3<T> np1, np2, nn;
+  uint32_t ncontacts;
+  int first_prim;
+  V3<T> guess;  // the solver's cached guess (persists over the leaves of one query)
+  bool overflow, unsupported;
+};
+
+// One (mesh, solid) query.  stack: cap entries of group-shared memory; scratch: group-shared EPA block.
+// on_contact(prim, distance, p1, p2, n) is called for every Contact added (lane-uniform values).
+template <typename T, class Grp, class Solid, class OnContact>
+HFCL_HD void mesh_shape_collide(const DNode<T>* nodes, const T* mverts, const uint32_t* tris, const Pose<T>& tfm,
+                                const DShape<T>& shape, const T* sverts, const Pose<T>& tfs, const Solid& solid,
+                                const QParams<T>& q, uint32_t num_max_contacts, T break_distance2, uint16_t* stack, int cap,
+                                EpaScratch<T, EPA_MAX_ITER>* scratch, const V3<T>& initial_guess, OnContact on_contact,
+                                MeshShapeState<T>& st) {
+  const T nanv = Lim<T>::nan();
+  st.guess = initial_guess;
+  st.dlb = st.rec_dist = Lim<T>::max();
+  st.np1 = st.np2 = st.nn = mk<T>(nanv, nanv, nanv);
+  st.ncontacts = 0;
+  st.first_prim = -1;
+  st.overflow = false;
+  st.unsupported = false;
+  DNode<T> bv2;
+  if (!shape_obb(shape, sverts, tfs, bv2)) {
+    st.unsupported = true;
+    return;
+  }
+  const MDiff<T> md = make_mdiff(tfm, tfs);
+  const T r1 = swept_radius(shape);
+  int sp = 0;
+  Grp::sync();
+  if (Grp::lane() == 0) stack[0] = 0;
+  sp = 1;
+  Grp::sync();
+  while (sp > 0) {
+    const uint32_t b1 = stack[--sp];
+    const DNode<T> n1 = nodes[b1];
+    if (n1.first_child >= 0) {
+      T sq;
+      const bool disjoint = obb_disjoint(tfm.R, tfm.t, n1, bv2, q.security_margin, break_distance2, sq);
+      if (disjoint) {  // updateDistanceLowerBoundFromBV
+        if (!(st.dlb <= T(0))) {
+          const T nd = hsqrt(sq);
+          if (nd < st.dlb) {
+            st.dlb = nd;
+            st.rec_dist = nd + q.security_margin;
+          }
+        }
+        continue;
+      }
+      if (sp + 2 > cap) {
+        st.overflow = true;
+        return;
+      }
+      Grp::sync();
+      if (Grp::lane() == 0) {
+        stack[sp] = uint16_t(n1.first_child + 1);  // right child below
+        stack[sp + 1] = uint16_t(n1.first_child);  // left child on top
+      }
+      sp += 2;
+      Grp::sync();
+      continue;
+    }
+    // ---- leaf: ShapeShapeDistance<TriangleP, S>(tri, tf_mesh, shape, tf_shape)
+    const uint32_t prim = uint32_t(-(n1.first_child + 1));
+    const uint32_t* t3 = tris + 3 * size_t(prim);
+    auto vtx = [&](uint32_t i) { return mk<T>(mverts[3 * size_t(i)], mverts[3 * size_t(i) + 1], mverts[3 * size_t(i) + 2]); };
+    const V3<T> ta = vtx(t3[0]), tb = vtx(t3[1]), tc = vtx(t3[2]);
+    T distance;
+    V3<T> p1, p2, n;
+    if (shape.kind == K_SPHERE) {  // triangle_sphere.cpp:45-56
+      distance = sphere_triangle(shape, tfs, xform(tfm, ta), xform(tfm, tb), xform(tfm, tc), p2, p1, n);
+      n = -n;
+    } else {
+      TriSolidSupport<T, Solid> sup;
+      sup.a = ta;
+      sup.b = tb;
+      sup.c = tc;
+      sup.solid = &solid;
+      sup.md = md;
+      const V3<T> guess0 = (q.guess_mode == HFCL_GUESS_CACHED) ? st.guess : mk<T>(T(1), T(0), T(0));
+      Gjk<T, PW0<T>> g;
+      gjk_run(g, q.gjk, guess0, r1, false, sup);
+      PairOut<T> o;
+      EpaSeed<T> seed;
+      if (gjk_finish(g, q, tfm, T(0), r1, guess0, o, seed)) {
+        Grp::sync();
+        epa_run<T, Grp, EPA_MAX_ITER>(scratch, seed, q, tfm, T(0), r1, sup, o);
+        Grp::sync();
+      }
+      distance = o.distance;
+      p1 = o.p1;
+      p2 = o.p2;
+      n = o.normal;
+      st.guess = o.cached_guess;
+    }
+    const T dtc = distance - q.security_margin;
+    if (dtc < st.dlb) {  // updateDistanceLowerBoundFromLeaf
+      st.dlb = dtc;
+      st.rec_dist = distance;
+      st.np1 = p1;
+      st.np2 = p2;
+      st.nn = n;
+    }
+    if (dtc <= q.collision_distance_threshold) {
+      if (st.ncontacts < num_max_contacts) {
+        if (st.ncontacts == 0) st.first_prim = int(prim);
+        ++st.ncontacts;
+        on_contact(int(prim), distance, p1, p2, n);
+      }
+      if (st.ncontacts >= num_max_contacts) return;  // canStop()
+    }
+  }
+}
+
+}  // namespace hfcl

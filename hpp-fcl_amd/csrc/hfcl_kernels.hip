@@ -24,6 +24,7 @@
 
 #include "../../include/hppfcl_amd.h"
 #include "hfcl_bvh.hpp"
+#include "hfcl_bvh_shape.hpp"
 #include "hfcl_pair.hpp"
 
 using namespace hfcl;
@@ -49,7 +50,7 @@ using namespace hfcl;
 // bucket ids (finer than hfcl_shapes.hpp's pair_class: the convex bucket is split by which
 // side carries vertices so the kernel is specialised at compile time)
 // ---------------------------------------------------------------------------------------
-enum { B_CLOSED = 0, B_PRIM = 1, B_CC = 2, B_PC = 3, B_CP = 4, B_BVH = 5, B_UNSUPPORTED = 6, B_LARGE = 7, B_COUNT = 8 };
+enum { B_CLOSED = 0, B_PRIM = 1, B_CC = 2, B_PC = 3, B_CP = 4, B_BVH = 5, B_UNSUPPORTED = 6, B_LARGE = 7, B_BVHSHAPE = 8, B_COUNT = 9 };
 
 // Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
 // support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
@@ -60,6 +61,10 @@ __host__ __device__ inline int bucket_of(int k1, int k2) {
   const bool large = (k1 == K_CONVEX_LARGE) || (k2 == K_CONVEX_LARGE);
   if (k1 == K_CONVEX_LARGE) k1 = K_CONVEX;
   if (k2 == K_CONVEX_LARGE) k2 = K_CONVEX;
+  if ((k1 == K_BVH) != (k2 == K_BVH)) {  // BVHModel x convex solid, either operand order (k_bvh_shape)
+    const int o = (k1 == K_BVH) ? k2 : k1;
+    return (kind_is_prim(o) || o == K_CONVEX) ? B_BVHSHAPE : B_UNSUPPORTED;
+  }
   const int c = pair_class(k1, k2);
   if (large && c == CLS_CONVEX) return B_LARGE;
   if (c == CLS_CLOSED) return B_CLOSED;
@@ -251,10 +256,10 @@ __global__ void __launch_bounds__(256) k_classify(Work wk, const uint8_t* kinds,
 
 // pairs the engine cannot evaluate: flagged, never silently computed elsewhere
 template <typename T>
-__global__ void __launch_bounds__(256) k_unsupported(Work wk, IO<T> io) {
-  const uint32_t cnt = wk.counts[B_UNSUPPORTED];
+__global__ void __launch_bounds__(256) k_unsupported(Work wk, IO<T> io, int bucket) {
+  const uint32_t cnt = wk.counts[bucket];
   for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
-    const uint32_t pair = wk.lists[size_t(B_UNSUPPORTED) * wk.n + it];
+    const uint32_t pair = wk.lists[size_t(bucket) * wk.n + it];
     auto r = io.out[pair];
     memset(&r, 0, sizeof(r));
     r.status = 0x80000000u;
@@ -808,6 +813,91 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// k_bvh_shape: BVHModel<OBBRSS> x convex solid collide(), either operand order.  One query per BS_W-lane
+// group (hfcl_bvh_shape.hpp: sequential traversal, the group's lanes share support scans and EPA face
+// work); DFS stack and the full-capacity polytope of each group in LDS.
+// ---------------------------------------------------------------------------------------
+constexpr int BS_W = 16;
+constexpr int BS_STACK = 128;
+
+template <typename T>
+struct GroupSolid {  // support of the solid in its own frame, evaluated by the lane group
+  DShape<T> s;
+  HullRegs<T, BS_W> h;
+  const T* v;
+  int lig;
+  __device__ __forceinline__ V3<T> operator()(const V3<T>& d) const {
+    if (s.kind != K_CONVEX) return prim_support(s, d);
+    if (s.num_points > uint32_t(HULL_MAX)) return scan_support<T, BS_W>(v, s.num_points, d, lig);
+    return h.support(d, lig);
+  }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(64) k_bvh_shape(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhParams bp,
+                                                  T break_distance2) {
+  constexpr int G = 64 / BS_W;
+  __shared__ EpaScratch<T, EPA_MAX_ITER> scratch[G];
+  __shared__ uint16_t stacks[G][BS_STACK];
+  const uint32_t cnt = wk.counts[B_BVHSHAPE];
+  const int lane = threadIdx.x & 63, grp = lane / BS_W, lig = lane & (BS_W - 1);
+  for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += gridDim.x * G) {
+    const uint32_t pair = wk.lists[size_t(B_BVHSHAPE) * wk.n + it];
+    const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+    const bool swapped = a.kind != K_BVH;  // (shape, BVH): collide(o2, o1) then swapObjects (collision.cpp:93-108)
+    const DShape<T> ms = swapped ? b : a;
+    GroupSolid<T> solid;
+    solid.s = swapped ? a : b;
+    solid.v = lib.verts + 3 * size_t(solid.s.vertex_offset);
+    solid.lig = lig;
+    if (solid.s.kind == K_CONVEX && solid.s.num_points <= uint32_t(HULL_MAX)) solid.h.load(solid.v, solid.s.num_points, lig);
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    const Pose<T> tfm = swapped ? tf2 : tf1, tfs = swapped ? tf1 : tf2;
+    const DMesh m = bv.meshes[ms.bvh_index];
+    MeshShapeState<T> st;
+    auto on_contact = [&](int prim, T distance, const V3<T>& p1, const V3<T>& p2, const V3<T>& nn) {
+      if (lig != 0 || !bp.contacts) return;
+      const uint32_t slot = atomicAdd(bp.contacts_count, 1u);
+      if (slot >= bp.contacts_cap) return;
+      hfcl_contact c;
+      c.pair = pair;
+      c.b1 = swapped ? -1 : prim;
+      c.b2 = swapped ? prim : -1;
+      c._pad = 0;
+      c.penetration_depth = double(distance);
+      const V3<T> a1 = swapped ? p2 : p1, a2 = swapped ? p1 : p2, an = swapped ? -nn : nn;
+      c.normal[0] = an.x; c.normal[1] = an.y; c.normal[2] = an.z;
+      c.p1[0] = a1.x; c.p1[1] = a1.y; c.p1[2] = a1.z;
+      c.p2[0] = a2.x; c.p2[1] = a2.y; c.p2[2] = a2.z;
+      bp.contacts[slot] = c;
+    };
+    mesh_shape_collide<T, LaneGroup<BS_W>>(bv.nodes + m.node_off, bv.verts + 3 * size_t(m.vert_off), bv.tris + 3 * size_t(m.tri_off),
+                                           tfm, solid.s, lib.verts, tfs, solid, q, bp.num_max_contacts, break_distance2,
+                                           stacks[grp], BS_STACK, &scratch[grp], initial_guess<T>(io, q, pair), on_contact, st);
+    if (lig == 0) {
+      if (st.unsupported) {
+        auto r = io.out[pair];
+        memset(&r, 0, sizeof(r));
+        r.status = 0x80000000u;
+        io.out[pair] = r;
+      } else {
+        PairOut<T> o;
+        o.distance = st.rec_dist;
+        o.normal = swapped ? -st.nn : st.nn;
+        o.p1 = swapped ? st.np2 : st.np1;
+        o.p2 = swapped ? st.np1 : st.np2;
+        o.gjk_status = GJK_DID_NOT_RUN;
+        o.epa_status = EPA_DID_NOT_RUN;
+        o.gjk_iters = o.epa_iters = 0;
+        store_bvh_record(io, pair, o, st.ncontacts, swapped ? -1 : st.first_prim, swapped ? st.first_prim : -1, st.overflow);
+        write_guess<T>(io, pair, st.guess, 0, 0);
+      }
+    }
+    LaneGroup<BS_W>::sync();
+  }
+}
 
 // ---------------------------------------------------------------------------------------
 // k_bvh_distance: BVHModel<OBBRSS> x BVHModel<OBBRSS> distance().  distanceRecurse
@@ -1435,6 +1525,11 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
     bv.meshes = lib->d_meshes;
     bv.n_meshes = uint32_t(lib->h_meshes.size());
     if (q.mode == 1) {
+      t = timer_slot(lib, ti++, "k_bvh_shape");
+      hipEventRecord(t->e0, st);
+      hipLaunchKernelGGL((k_bvh_shape<T>), dim3(blocks_for(n / 8 + 1, 64 / BS_W)), dim3(64), 0, st, wk, lv, bv, io, q, lib->bvh_params,
+                         T(lib->break_distance * lib->break_distance));
+      hipEventRecord(t->e1, st);
       t = timer_slot(lib, ti++, "k_bvh_collide");
       hipEventRecord(t->e0, st);
       hipLaunchKernelGGL((k_bvh_collide<T>), dim3(blocks_for(n, BVH_BLOCK)), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q,
@@ -1450,7 +1545,9 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
 
   t = timer_slot(lib, ti++, "k_unsupported");
   hipEventRecord(t->e0, st);
-  hipLaunchKernelGGL((k_unsupported<T>), dim3(blocks_for(n, 256 * 64)), dim3(256), 0, st, wk, io);
+  hipLaunchKernelGGL((k_unsupported<T>), dim3(blocks_for(n, 256 * 64)), dim3(256), 0, st, wk, io, int(B_UNSUPPORTED));
+  if (q.mode != 1 || lib->h_meshes.empty())  // BVHModel x shape is built for collide() only
+    hipLaunchKernelGGL((k_unsupported<T>), dim3(blocks_for(n, 256 * 64)), dim3(256), 0, st, wk, io, int(B_BVHSHAPE));
   hipEventRecord(t->e1, st);
 
   if (q.compute_penetration) {
@@ -1667,7 +1764,15 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
               std::to_string(lib->h_counts[B_UNSUPPORTED]) + " pairs; their records carry status bit 31)");
     return HFCL_ERR_UNSUPPORTED_PAIR;
   }
-  if (!skipped && lib->h_counts[B_BVH] > 0 && lib->h_meshes.empty()) {
+  if (!skipped && lib->h_counts[B_BVHSHAPE] > 0 && !creq) {
+    set_error("distance() between a BVHModel and a shape is not yet supported (collide() is)");
+    return HFCL_ERR_UNSUPPORTED_PAIR;
+  }
+  if (!skipped && creq && creq->security_margin < 0 && lib->h_counts[B_BVHSHAPE] > 0) {
+    set_error("Negative security margin are not handled yet for BVHModel");  // collision_func_matrix.cpp:109-112
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  if (!skipped && (lib->h_counts[B_BVH] > 0 || lib->h_counts[B_BVHSHAPE] > 0) && lib->h_meshes.empty()) {
     set_error("BVH shapes in the batch but no BVHModel registered (hfcl_lib_add_bvh)");
     return HFCL_ERR_INVALID_ARGUMENT;
   }

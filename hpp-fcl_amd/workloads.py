@@ -224,6 +224,41 @@ def large_convex(n=50_000, seed=1, sizes=(33, 48, 64, 100, 256), nlib_each=12, h
     return b
 
 
+def mesh_vs_shapes(n=20_000, seed=1, seg=14, ring=14, n_variants=3, nper=16, half_width=1.2):
+    """BVHModel<OBBRSS> against the convex shape kinds, both operand orders, plus some mesh x mesh and
+    shape x shape pairs: the BVH rows / columns of the collision matrix (collision_func_matrix.cpp:471-733)."""
+    rng = _rng(seed, 9)
+    meshes = mesh_variants(n_variants, seg, ring)
+    lib = geometry.ShapeLibrary()
+    for k, m in enumerate(meshes):
+        lib.add_bvh(k, len(m.vertices))
+    for s in rng.uniform(0.2, 0.9, (nper, 3)):
+        lib.add_box(*map(float, s))
+    for r in rng.uniform(0.1, 0.6, nper):
+        lib.add_sphere(float(r))
+    for r, lz in zip(rng.uniform(0.1, 0.4, nper), rng.uniform(0.2, 1.0, nper)):
+        lib.add_capsule(float(r), float(lz))
+    for r, lz in zip(rng.uniform(0.1, 0.5, nper), rng.uniform(0.2, 1.0, nper)):
+        lib.add_cone(float(r), float(lz))
+    for r, lz in zip(rng.uniform(0.1, 0.5, nper), rng.uniform(0.2, 1.0, nper)):
+        lib.add_cylinder(float(r), float(lz))
+    for r in rng.uniform(0.1, 0.7, (nper, 3)):
+        lib.add_ellipsoid(*map(float, r))
+    base = fibonacci_sphere(24)
+    for radii in rng.uniform(0.1, 0.7, (nper, 3)):
+        lib.add_convex(base * radii)
+    n_all = len(lib)
+    u = rng.random(n)
+    mesh = rng.integers(0, n_variants, n)
+    solid = rng.integers(n_variants, n_all, n)
+    s1 = np.where(u < 0.45, mesh, np.where(u < 0.9, solid, np.where(u < 0.95, mesh, solid)))
+    s2 = np.where(u < 0.45, solid, np.where(u < 0.9, mesh, np.where(u < 0.95, rng.integers(0, n_variants, n), rng.integers(n_variants, n_all, n))))
+    q1, T1, q2, T2 = _poses(rng, n, half_width)
+    b = Batch("mesh_vs_shapes_collide", lib, s1, s2, q1, T1, q2, T2, "collide")
+    b.meshes = meshes
+    return b
+
+
 def cfg5_mixed(n=100_000, seed=1, nper=256, half_width=0.8):
     """cfg5-style mixed primitive+convex pairs (type mix 20 % each of Box/Sphere/Capsule/
     Ellipsoid/Convex32), synthetic pair list (cfg5_broadphase_scene takes its pairs from the host broadphase)."""

@@ -30,6 +30,14 @@ int bvh_collide_pair(const MeshView& m1, const Tf& tf1, const MeshView& m2, cons
                      const hfcl_collision_request& req, hfcl_result& out, std::vector<hfcl_contact>* contacts,
                      uint32_t pair_index, BvhStats* stats);
 
+// BVHModel<OBBRSS> x convex shape collide() (oracle/bvh_shape.cpp).  `swapped`: the caller's order was
+// (shape, BVH); the record is returned in the caller's order (src/collision.cpp:93-108).
+int bvh_shape_collide_pair(const MeshView& m1, const Tf& tf1, const Shape& s2, const Tf& tf2, const hfcl_collision_request& req,
+                           bool swapped, hfcl_result& out, std::vector<hfcl_contact>* contacts, uint32_t pair_index,
+                           hfcl_guess* guess_out, BvhStats* stats);
+// computeBV<OBBRSS,S>(shape, tf): fit of the shape's bound vertices (geometric_shapes_utility.h:73-82)
+int shape_obbrss(const Shape& s, const Tf& tf, hfcl_bvh_node& bv);
+
 // OBB overlap (exposed for unit tests): returns true when NOT disjoint.
 bool obb_overlap(const M3& R0, const V3& T0, const hfcl_bvh_node& b1, const hfcl_bvh_node& b2, double security_margin,
                  double break_distance, double& sqrDistLowerBound);

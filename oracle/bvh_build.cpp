@@ -316,6 +316,10 @@ struct Builder {
 
 }  // namespace
 
+namespace orc {
+void jacobi_eigen3(const double M[3][3], double dout[3], double vout[3][3]) { Builder::jacobi(M, dout, vout); }
+}  // namespace orc
+
 // nodes: 2*n_tris-1 records; prim: n_tris indices (the model's primitive_indices permutation)
 extern "C" int orc_bvh_build(const double* verts, size_t n_verts, const uint32_t* tris, size_t n_tris,
                              hfcl_bvh_node* nodes, uint32_t* prim) {

@@ -233,6 +233,61 @@ int orc_bvh_collide_batch(const hfcl_bvh_node* nodes, const double* verts, const
   return err;
 }
 
+// collide() over one shape table that may hold BVHModel<OBBRSS> entries (type HFCL_BV_OBBRSS, bvh_index into
+// the mesh table) next to convex shapes: mesh x mesh, mesh x shape, shape x mesh (operand swap of
+// src/collision.cpp:93-108) and shape x shape, dispatched like the reference's collision matrix.
+int orc_mixed_collide_batch(const hfcl_shape* shapes, size_t n_shapes, const double* shape_verts, const hfcl_bvh_node* nodes,
+                            const double* mesh_verts, const uint32_t* tris, const uint64_t* mesh_table, size_t n_meshes,
+                            const uint32_t* s1, const uint32_t* s2, const double* tf1, const double* tf2, size_t n,
+                            const hfcl_collision_request* req, hfcl_result* out, hfcl_guess* guess_out,
+                            hfcl_contact* contacts, size_t max_contacts, size_t* n_contacts, int n_threads) {
+  std::vector<MeshView> meshes(n_meshes);
+  for (size_t i = 0; i < n_meshes; ++i) {
+    meshes[i].nodes = nodes + mesh_table[4 * i];
+    meshes[i].n_nodes = mesh_table[4 * i + 1];
+    meshes[i].verts = mesh_verts + 3 * mesh_table[4 * i + 2];
+    meshes[i].tris = tris + 3 * mesh_table[4 * i + 3];
+  }
+  std::vector<Shape> lib(n_shapes);
+  for (size_t i = 0; i < n_shapes; ++i) lib[i] = make_shape(shapes[i], shape_verts);
+  int err = 0;
+  std::vector<std::vector<hfcl_contact>> per_thread(std::max(1, n_threads));
+  size_t chunk = (n + std::max(1, n_threads) - 1) / std::max(1, n_threads);
+  parallel_for(n, n_threads, [&](size_t b, size_t e) {
+    std::vector<hfcl_contact>& cl = per_thread[chunk ? b / chunk : 0];
+    for (size_t i = b; i < e; ++i) {
+      const hfcl_shape &a = shapes[s1[i]], &c = shapes[s2[i]];
+      const bool ma = a.type == HFCL_BV_OBBRSS, mc = c.type == HFCL_BV_OBBRSS;
+      const Tf t1 = tf_from_abi(tf1 + 12 * i), t2 = tf_from_abi(tf2 + 12 * i);
+      hfcl_guess* go = guess_out ? guess_out + i : nullptr;
+      int rc;
+      if (ma && mc) {
+        rc = bvh_collide_pair(meshes[a.bvh_index], t1, meshes[c.bvh_index], t2, *req, out[i], contacts ? &cl : nullptr,
+                              uint32_t(i), nullptr);
+        if (go) *go = hfcl_guess{{req->q.cached_gjk_guess[0], req->q.cached_gjk_guess[1], req->q.cached_gjk_guess[2]},
+                                 {req->q.cached_support_func_guess[0], req->q.cached_support_func_guess[1]}};
+      } else if (ma) {
+        rc = bvh_shape_collide_pair(meshes[a.bvh_index], t1, lib[s2[i]], t2, *req, false, out[i], contacts ? &cl : nullptr,
+                                    uint32_t(i), go, nullptr);
+      } else if (mc) {
+        rc = bvh_shape_collide_pair(meshes[c.bvh_index], t2, lib[s1[i]], t1, *req, true, out[i], contacts ? &cl : nullptr,
+                                    uint32_t(i), go, nullptr);
+      } else {
+        rc = collide_pair(lib[s1[i]], t1, lib[s2[i]], t2, *req, nullptr, out[i], go);
+      }
+      if (rc) err = rc;
+    }
+  });
+  if (contacts) {
+    size_t k = 0;
+    for (auto& cl : per_thread)
+      for (auto& c : cl)
+        if (k < max_contacts) contacts[k++] = c;
+    if (n_contacts) *n_contacts = k;
+  }
+  return err;
+}
+
 // BVHModel<OBBRSS> x BVHModel<OBBRSS> distance(); same mesh table as orc_bvh_collide_batch.
 int orc_bvh_distance_batch(const hfcl_bvh_node* nodes, const double* verts, const uint32_t* tris,
                            const uint64_t* mesh_table, size_t n_meshes, const uint32_t* m1, const uint32_t* m2,

@@ -349,6 +349,68 @@ static double plane_plane(const Shape& s1, const Tf& tf1, const Shape& s2, const
   return distance;
 }
 
+// details::segmentSqrDistance :235-255, projectInTriangle :258-279, sphereTriangleDistance :286-340
+static double segment_sqr_distance(const V3& from, const V3& to, const V3& p, V3& nearest) {
+  V3 diff = p - from;
+  const V3 v = to - from;
+  double t = dot(v, diff);
+  if (t > 0) {
+    const double dotVV = sqnorm(v);
+    if (t < dotVV) {
+      t /= dotVV;
+      diff = diff - v * t;
+    } else {
+      t = 1;
+      diff = diff - v;
+    }
+  } else
+    t = 0;
+  nearest = from + v * t;
+  return sqnorm(diff);
+}
+static bool project_in_triangle(const V3& p1, const V3& p2, const V3& p3, const V3& normal, const V3& p) {
+  const V3 e1 = p2 - p1, e2 = p3 - p2, e3 = p1 - p3;
+  const double r1 = dot(cross(e1, normal), p - p1), r2 = dot(cross(e2, normal), p - p2), r3 = dot(cross(e3, normal), p - p3);
+  return (r1 > 0 && r2 > 0 && r3 > 0) || (r1 <= 0 && r2 <= 0 && r3 <= 0);
+}
+static double sphere_triangle(const Shape& s, const Tf& tf1, const Shape& tri, const Tf& tf2, V3& p1, V3& p2, V3& normal) {
+  const V3 P1 = tf2.transform(V3(tri.verts[0], tri.verts[1], tri.verts[2]));
+  const V3 P2 = tf2.transform(V3(tri.verts[3], tri.verts[4], tri.verts[5]));
+  const V3 P3 = tf2.transform(V3(tri.verts[6], tri.verts[7], tri.verts[8]));
+  V3 tri_normal = normalized(cross(P2 - P1, P3 - P1));
+  const V3 center = tf1.T;
+  const double radius = s.p[0] + s.ssr + tri.ssr;
+  double distance_from_plane = dot(center - P1, tri_normal);
+  const double nanv = std::numeric_limits<double>::quiet_NaN();
+  V3 closest_point(nanv, nanv, nanv);
+  double min_distance_sqr, distance_sqr;
+  if (distance_from_plane < 0) {
+    distance_from_plane *= -1;
+    tri_normal = tri_normal * -1.0;
+  }
+  if (project_in_triangle(P1, P2, P3, tri_normal, center)) {
+    closest_point = center - tri_normal * distance_from_plane;
+    min_distance_sqr = distance_from_plane * distance_from_plane;
+  } else {
+    V3 nearest_on_edge;
+    min_distance_sqr = segment_sqr_distance(P1, P2, center, closest_point);
+    distance_sqr = segment_sqr_distance(P2, P3, center, nearest_on_edge);
+    if (distance_sqr < min_distance_sqr) {
+      min_distance_sqr = distance_sqr;
+      closest_point = nearest_on_edge;
+    }
+    distance_sqr = segment_sqr_distance(P3, P1, center, nearest_on_edge);
+    if (distance_sqr < min_distance_sqr) {
+      min_distance_sqr = distance_sqr;
+      closest_point = nearest_on_edge;
+    }
+  }
+  normal = normalized(closest_point - center);
+  p1 = center + normal * (s.p[0] + s.ssr);
+  p2 = closest_point - normal * tri.ssr;
+  return std::sqrt(min_distance_sqr) - radius;
+}
+
 // details::sphereCylinderDistance :107-209
 static double sphere_cylinder(const Shape& s1, const Tf& tf1, const Shape& s2, const Tf& tf2, V3& p1, V3& p2,
                               V3& normal) {
@@ -691,8 +753,23 @@ bool shape_shape_distance(const Shape& s1, const Tf& tf1, const Shape& s2, const
       return true;
     }
   }
+  if (s1.kind == K_SPHERE && s2.kind == K_TRIANGLE) {
+    dist = sphere_triangle(s1, tf1, s2, tf2, p1, p2, normal);
+    return true;
+  }
+  if (s1.kind == K_TRIANGLE && s2.kind == K_SPHERE) {  // triangle_sphere.cpp:45-56
+    dist = sphere_triangle(s2, tf2, s1, tf1, p2, p1, normal);
+    normal = -normal;
+    return true;
+  }
   if (s1.kind == K_TRIANGLE && s2.kind == K_TRIANGLE) {
     dist = triangle_triangle(s1, tf1, s2, tf2, solver, p1, p2, normal);
+    return true;
+  }
+  // TriangleP against the other solids: generic GJK/EPA (the "1" entries of the triangle column,
+  // shape_shape_func.h:185-211); TriangleP is not a ConvexBase: no support-direction normalisation
+  if ((s1.kind == K_TRIANGLE && is_gjk_kind(s2.kind)) || (is_gjk_kind(s1.kind) && s2.kind == K_TRIANGLE)) {
+    dist = solver.run_gjk_epa(s1, tf1, s2, tf2, compute_signed_distance, p1, p2, normal);
     return true;
   }
   if (is_gjk_kind(s1.kind) && is_gjk_kind(s2.kind)) {

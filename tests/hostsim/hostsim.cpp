@@ -11,6 +11,7 @@
 
 #include "../../include/hppfcl_amd.h"
 #include "../../hpp-fcl_amd/csrc/hfcl_bvh.hpp"
+#include "../../hpp-fcl_amd/csrc/hfcl_bvh_shape.hpp"
 #include "../../hpp-fcl_amd/csrc/hfcl_pair.hpp"
 
 using namespace hfcl;
@@ -357,6 +358,98 @@ int sim_bvh_distance_f64(const hfcl_bvh_node* nodes, size_t n_nodes, const doubl
   for (size_t i = 0; i < n; ++i)
     bvh_distance_pair<double>(dn, dr, v, tris, mesh_table + 4 * m1[i], mesh_table + 4 * m2[i], pose_from_abi<double>(tf1 + 12 * i),
                               pose_from_abi<double>(tf2 + 12 * i), out[i]);
+  return 0;
+}
+
+// BVHModel<OBBRSS> x convex shape (either operand order): the device header's mesh_shape_collide on one lane.
+struct HostSolid {
+  DShape<double> s;
+  const double* verts;
+  V3<double> operator()(const V3<double>& d) const {
+    SerialSupport<double> ss;
+    return ss.one(s, verts + 3 * size_t(s.vertex_offset), d);
+  }
+};
+int sim_mesh_shape_collide_f64(const hfcl_shape* shapes, size_t n_shapes, const double* shape_verts, const hfcl_bvh_node* nodes,
+                               size_t n_nodes, const double* verts, size_t n_verts, const uint32_t* tris,
+                               const uint64_t* mesh_table, const uint32_t* s1, const uint32_t* s2, const double* tf1,
+                               const double* tf2, size_t n, const hfcl_collision_request* creq, hfcl_result* out,
+                               hfcl_guess* gout, hfcl_contact* contacts, size_t max_contacts, size_t* n_contacts) {
+  std::vector<DNode<double>> dn(n_nodes);
+  for (size_t i = 0; i < n_nodes; ++i) {
+    const double* a = nodes[i].obb_axes;
+    dn[i].first_child = nodes[i].first_child;
+    dn[i].axes.r0 = mk<double>(a[0], a[3], a[6]);
+    dn[i].axes.r1 = mk<double>(a[1], a[4], a[7]);
+    dn[i].axes.r2 = mk<double>(a[2], a[5], a[8]);
+    dn[i].To = mk<double>(nodes[i].obb_To[0], nodes[i].obb_To[1], nodes[i].obb_To[2]);
+    dn[i].extent = mk<double>(nodes[i].obb_extent[0], nodes[i].obb_extent[1], nodes[i].obb_extent[2]);
+  }
+  (void)n_verts;
+  QParams<double> q;
+  fill_q(q, creq->q);
+  q.mode = 1;
+  q.compute_penetration = (creq->enable_contact || creq->security_margin < 0) ? 1 : 0;
+  q.security_margin = creq->security_margin;
+  const double ub = creq->distance_upper_bound > creq->security_margin ? creq->distance_upper_bound : creq->security_margin;
+  q.gjk.distance_upper_bound = ub < 0 ? 0 : ub;
+  std::vector<hfcl_contact> cl;
+  static thread_local EpaScratch<double, EPA_MAX_ITER> scratch;
+  uint16_t stack[128];
+  for (size_t i = 0; i < n; ++i) {
+    const hfcl_shape &a = shapes[s1[i]], &b = shapes[s2[i]];
+    const bool swapped = a.type != HFCL_BV_OBBRSS;
+    const hfcl_shape& ms = swapped ? b : a;
+    const DShape<double> solid = to_dshape<double>(swapped ? a : b);
+    const Pose<double> tfm = pose_from_abi<double>((swapped ? tf2 : tf1) + 12 * i);
+    const Pose<double> tfs = pose_from_abi<double>((swapped ? tf1 : tf2) + 12 * i);
+    const uint64_t* mt = mesh_table + 4 * ms.bvh_index;
+    HostSolid hs{solid, shape_verts};
+    MeshShapeState<double> st;
+    auto on_contact = [&](int prim, double distance, const V3<double>& p1, const V3<double>& p2, const V3<double>& nn) {
+      if (!contacts) return;
+      hfcl_contact c;
+      c.pair = uint32_t(i);
+      c.b1 = swapped ? -1 : prim;
+      c.b2 = swapped ? prim : -1;
+      c._pad = 0;
+      c.penetration_depth = distance;
+      const V3<double> a1 = swapped ? p2 : p1, a2 = swapped ? p1 : p2, an = swapped ? -nn : nn;
+      c.normal[0] = an.x; c.normal[1] = an.y; c.normal[2] = an.z;
+      c.p1[0] = a1.x; c.p1[1] = a1.y; c.p1[2] = a1.z;
+      c.p2[0] = a2.x; c.p2[1] = a2.y; c.p2[2] = a2.z;
+      cl.push_back(c);
+    };
+    mesh_shape_collide<double, SerialGroup<1>>(dn.data() + mt[0], verts + 3 * mt[2], tris + 3 * mt[3], tfm, solid, shape_verts, tfs, hs,
+                                              q, creq->num_max_contacts, creq->break_distance * creq->break_distance, stack, 128,
+                                              &scratch, mk<double>(q.guess[0], q.guess[1], q.guess[2]), on_contact, st);
+    hfcl_result& r = out[i];
+    std::memset(&r, 0, sizeof(r));
+    if (st.unsupported) {
+      r.status = 0x80000000u;
+      continue;
+    }
+    const V3<double> p1 = swapped ? st.np2 : st.np1, p2 = swapped ? st.np1 : st.np2, nn = swapped ? -st.nn : st.nn;
+    r.distance = st.rec_dist;
+    r.normal[0] = nn.x; r.normal[1] = nn.y; r.normal[2] = nn.z;
+    r.p1[0] = p1.x; r.p1[1] = p1.y; r.p1[2] = p1.z;
+    r.p2[0] = p2.x; r.p2[1] = p2.y; r.p2[2] = p2.z;
+    r.b1 = swapped ? -1 : st.first_prim;
+    r.b2 = swapped ? st.first_prim : -1;
+    r.status = (st.ncontacts ? 128u : 0u) | (st.overflow ? 0xC0000000u : 0u);
+    r.num_contacts = int(st.ncontacts);
+    if (gout) {
+      gout[i].gjk_guess[0] = st.guess.x; gout[i].gjk_guess[1] = st.guess.y; gout[i].gjk_guess[2] = st.guess.z;
+      gout[i].support_guess[0] = gout[i].support_guess[1] = 0;
+    }
+  }
+  (void)n_shapes;
+  if (contacts) {
+    size_t k = 0;
+    for (auto& c : cl)
+      if (k < max_contacts) contacts[k++] = c;
+    *n_contacts = cl.size();
+  }
   return 0;
 }
 

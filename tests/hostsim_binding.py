@@ -102,3 +102,30 @@ def sqr_tri_distance(abi, S, T):
     T = np.ascontiguousarray(T, dtype=np.float64)
     out = np.zeros(6)
     return L.sim_sqr_tri_distance(abi.ptr(S), abi.ptr(T), abi.ptr(out)), out[:3].copy(), out[3:].copy()
+
+
+def mesh_shape_collide_f64(abi, shapes, verts, meshlib, s1, s2, tf1, tf2, req, max_contacts=0, want_guess=False):
+    """BVHModel<OBBRSS> x convex shape pairs (either order) through the device header's mesh_shape_collide."""
+    shapes = np.ascontiguousarray(shapes)
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    s1 = np.ascontiguousarray(s1, dtype=np.uint32)
+    s2 = np.ascontiguousarray(s2, dtype=np.uint32)
+    tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
+    tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
+    n = len(s1)
+    out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    gout = np.zeros(n, dtype=abi.GUESS_DTYPE) if want_guess else None
+    contacts = np.zeros(max(1, max_contacts), dtype=abi.CONTACT_DTYPE)
+    nc = C.c_size_t(0)
+    nodes = np.ascontiguousarray(meshlib.nodes)
+    lib().sim_mesh_shape_collide_f64(abi.ptr(shapes), C.c_size_t(len(shapes)), abi.ptr(verts), abi.ptr(nodes),
+                                     C.c_size_t(len(nodes)), abi.ptr(meshlib.verts), C.c_size_t(len(meshlib.verts)),
+                                     abi.ptr(meshlib.tris), abi.ptr(meshlib.table), abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1),
+                                     abi.ptr(tf2), C.c_size_t(n), C.byref(req), abi.ptr(out), abi.ptr(gout),
+                                     abi.ptr(contacts) if max_contacts else None, C.c_size_t(max_contacts), C.byref(nc))
+    res = [out]
+    if max_contacts:
+        res.append(contacts[:min(nc.value, max_contacts)])
+    if want_guess:
+        res.append(gout)
+    return res[0] if len(res) == 1 else tuple(res)

@@ -257,3 +257,36 @@ def register_hull_neighbors(shapes, verts):
         keep.append((offs, ids))
         L.orc_register_neighbors(C.c_uint32(off), C.c_void_p(offs.ctypes.data), C.c_uint32(n), C.c_void_p(ids.ctypes.data))
     return len(keep)
+
+
+def mixed_collide_batch(shapes, verts, meshlib, s1, s2, tf1, tf2, req=None, max_contacts=0, n_threads=1, want_guess=False):
+    """collide() over a shape table that mixes BVHModel<OBBRSS> entries (bvh_index -> meshlib) and convex
+    shapes: mesh x mesh, mesh x shape, shape x mesh, shape x shape (oracle/capi.cpp orc_mixed_collide_batch)."""
+    abi = _pkg().abi
+    req = req or abi.default_collision_request()
+    shapes = np.ascontiguousarray(shapes)
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    s1 = np.ascontiguousarray(s1, dtype=np.uint32)
+    s2 = np.ascontiguousarray(s2, dtype=np.uint32)
+    tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
+    tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
+    n = len(s1)
+    out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    gout = np.zeros(n, dtype=abi.GUESS_DTYPE) if want_guess else None
+    contacts = np.zeros(max(1, max_contacts), dtype=abi.CONTACT_DTYPE)
+    nc = C.c_size_t(0)
+    nodes = np.ascontiguousarray(meshlib.nodes)
+    rc = lib().orc_mixed_collide_batch(abi.ptr(shapes), C.c_size_t(len(shapes)), abi.ptr(verts), abi.ptr(nodes),
+                                       abi.ptr(meshlib.verts), abi.ptr(meshlib.tris), abi.ptr(meshlib.table),
+                                       C.c_size_t(len(meshlib.table)), abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1), abi.ptr(tf2),
+                                       C.c_size_t(n), C.byref(req), abi.ptr(out), abi.ptr(gout),
+                                       abi.ptr(contacts) if max_contacts else None, C.c_size_t(max_contacts), C.byref(nc),
+                                       C.c_int(n_threads))
+    if rc:
+        raise ValueError("oracle mixed collide: error %d" % rc)
+    res = [out]
+    if max_contacts:
+        res.append(contacts[:nc.value])
+    if want_guess:
+        res.append(gout)
+    return res[0] if len(res) == 1 else tuple(res)

@@ -1,0 +1,192 @@
+"""BVHModel<OBBRSS> x convex shape collide(): oracle restatement of
+BVHShapeCollider / MeshShapeCollisionTraversalNode (collision_func_matrix.cpp:102-155,
+traversal_node_bvh_shape.h:98-188) checked against brute force over all triangles, then the device."""
+import numpy as np
+import pytest
+
+
+def _scene(pkg, n=400, seed=1, **kw):
+    return pkg.workloads.mesh_vs_shapes(n=n, seed=seed, **kw)
+
+
+def test_oracle_mesh_shape_contacts_equal_brute_force(pkg, oracle):
+    """With num_max_contacts = inf the contact set is every triangle whose distance to the shape is <= 0:
+    compare with the shape-vs-triangle narrow phase run on ALL triangles (no BVH)."""
+    abi, g, bb = pkg.abi, pkg.geometry, pkg.bvh_builder
+    b = _scene(pkg, n=120, seed=3)
+    ML = bb.MeshLibrary(b.meshes)
+    req = abi.default_collision_request()
+    req.num_max_contacts = 10 ** 6
+    kinds = b.shapes["type"]
+    is_mesh1, is_mesh2 = kinds[b.s1] == abi.BV_OBBRSS, kinds[b.s2] == abi.BV_OBBRSS
+    sel = np.nonzero(is_mesh1 != is_mesh2)[0]
+    out, cs = oracle.mixed_collide_batch(b.shapes, b.verts, ML, b.s1[sel], b.s2[sel], b.tf1[sel], b.tf2[sel], req,
+                                         max_contacts=10 ** 6)
+    assert 0.2 < (out["num_contacts"] > 0).mean() < 0.95
+    checked = 0
+    for k, i in enumerate(sel[:60]):
+        mesh_first = bool(is_mesh1[i])
+        ms, ss = (b.s1[i], b.s2[i]) if mesh_first else (b.s2[i], b.s1[i])
+        tfm, tfs = (b.tf1[i], b.tf2[i]) if mesh_first else (b.tf2[i], b.tf1[i])
+        m = b.meshes[int(b.shapes[ms]["bvh_index"])]
+        L = g.ShapeLibrary()
+        for t3 in m.triangles:
+            L.add_triangle(*m.vertices[t3])
+        # the solid shape, copied into the brute-force library
+        src = b.shapes[ss]
+        base = len(L)
+        if src["type"] == abi.GEOM_CONVEX:
+            L.add_convex(b.verts[src["vertex_offset"]:src["vertex_offset"] + src["num_points"]])
+        else:
+            L._add(int(src["type"]), tuple(src["params"]), float(src["swept_sphere_radius"]))
+        nt = m.num_tris
+        r = oracle.collide_batch(L.shapes_array(), L.vertices_array(), np.arange(nt), np.full(nt, base), np.tile(tfm, (nt, 1)),
+                                 np.tile(tfs, (nt, 1)), req)
+        brute = set(np.nonzero(r["num_contacts"] > 0)[0].tolist())
+        ck = cs[cs["pair"] == k]
+        got = set((ck["b1"] if mesh_first else ck["b2"]).tolist())
+        assert got == brute, (i, len(got), len(brute))
+        assert out["num_contacts"][k] == len(brute)
+        # the other primitive id is Contact::NONE; normals point from the caller's first object to the second
+        assert ((ck["b2"] if mesh_first else ck["b1"]) == -1).all()
+        checked += len(brute)
+    assert checked > 100
+
+
+def test_oracle_operand_swap(pkg, oracle):
+    """collide(shape, mesh) = collide(mesh, shape) with contacts mirrored (src/collision.cpp:93-108)."""
+    abi, bb = pkg.abi, pkg.bvh_builder
+    b = _scene(pkg, n=300, seed=4)
+    ML = bb.MeshLibrary(b.meshes)
+    req = abi.default_collision_request()
+    a = oracle.mixed_collide_batch(b.shapes, b.verts, ML, b.s1, b.s2, b.tf1, b.tf2, req)
+    s = oracle.mixed_collide_batch(b.shapes, b.verts, ML, b.s2, b.s1, b.tf2, b.tf1, req)
+    kinds = b.shapes["type"]
+    mixed = (kinds[b.s1] == abi.BV_OBBRSS) != (kinds[b.s2] == abi.BV_OBBRSS)
+    assert mixed.sum() > 200
+    assert np.array_equal(a["num_contacts"][mixed], s["num_contacts"][mixed])
+    assert np.array_equal(a["b1"][mixed], s["b2"][mixed]) and np.array_equal(a["b2"][mixed], s["b1"][mixed])
+    same = lambda x, y: np.all((x == y) | (np.isnan(x) & np.isnan(y)))
+    assert same(a["distance"][mixed], s["distance"][mixed])
+    assert same(a["normal"][mixed], -s["normal"][mixed]) and same(a["p1"][mixed], s["p2"][mixed])
+
+
+def test_oracle_shape_bv_encloses_shape(pkg, oracle):
+    """computeBV<OBBRSS,S>: the OBB fitted to the bound vertices contains them (and the shape's support points
+    along its axes stay within the polyhedral bound the reference uses)."""
+    # exercised through the traversal: a shape far away from the mesh never reports a contact and the lower
+    # bound it reports is a true lower bound of the brute-force distance
+    abi, g, bb = pkg.abi, pkg.geometry, pkg.bvh_builder
+    b = _scene(pkg, n=200, seed=5, half_width=3.0)
+    ML = bb.MeshLibrary(b.meshes)
+    req = abi.default_collision_request()
+    out = oracle.mixed_collide_batch(b.shapes, b.verts, ML, b.s1, b.s2, b.tf1, b.tf2, req)
+    kinds = b.shapes["type"]
+    mixed = (kinds[b.s1] == abi.BV_OBBRSS) != (kinds[b.s2] == abi.BV_OBBRSS)
+    free = mixed & (out["num_contacts"] == 0)
+    assert free.sum() > 50
+    assert (out["distance"][free] > 0).all()
+
+
+def _mixed_only(pkg, b):
+    kinds = b.shapes["type"]
+    return np.nonzero((kinds[b.s1] == pkg.abi.BV_OBBRSS) != (kinds[b.s2] == pkg.abi.BV_OBBRSS))[0]
+
+
+def _same(a, b, tol=0.0):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        return bool(np.all((a == b) | (np.isnan(a) & np.isnan(b)) | (np.abs(a - b) <= tol)))
+
+
+@pytest.mark.parametrize("nmax,margin,cached", [(1, 0.0, False), (10 ** 6, 0.0, False), (2, 0.03, False), (1, 0.0, True)])
+def test_device_headers_match_oracle(pkg, oracle, hostsim, nmax, margin, cached):
+    """Host build of hfcl_bvh_shape.hpp (one lane per query) vs the oracle: contact counts, primitive ids,
+    contact order and distances are identical; normals / witness points agree to the last bits (the two
+    code bases normalise vectors with differently ordered divisions: ~1 ulp)."""
+    abi, bb = pkg.abi, pkg.bvh_builder
+    b = _scene(pkg, n=3000, seed=6)
+    ML = bb.MeshLibrary(b.meshes)
+    sel = _mixed_only(pkg, b)
+    req = abi.default_collision_request()
+    req.num_max_contacts, req.security_margin = nmax, margin
+    if cached:
+        req.q.gjk_initial_guess = abi.CachedGuess
+        req.q.cached_gjk_guess[:] = [0.3, -0.2, 0.9]
+    a = (b.shapes, b.verts, ML, b.s1[sel], b.s2[sel], b.tf1[sel], b.tf2[sel], req)
+    ref, cref, gref = oracle.mixed_collide_batch(*a, max_contacts=10 ** 6, want_guess=True)
+    got, cgot, ggot = hostsim.mesh_shape_collide_f64(abi, *a, max_contacts=10 ** 6, want_guess=True)
+    assert 0.2 < (ref["num_contacts"] > 0).mean() < 0.9
+    assert np.array_equal(ref["num_contacts"], got["num_contacts"])
+    assert np.array_equal(ref["b1"], got["b1"]) and np.array_equal(ref["b2"], got["b2"])
+    assert _same(got["distance"], ref["distance"], 1e-15)
+    for f in ("normal", "p1", "p2"):
+        assert _same(got[f], ref[f], 1e-11), f
+    assert len(cref) == len(cgot) and np.array_equal(cref["pair"], cgot["pair"])
+    assert np.array_equal(cref["b1"], cgot["b1"]) and np.array_equal(cref["b2"], cgot["b2"])
+    for f in ("penetration_depth", "normal", "p1", "p2"):
+        assert _same(cgot[f], cref[f], 1e-11), f  # normals of near-touching pairs amplify the last-bit differences
+    assert _same(ggot["gjk_guess"], gref["gjk_guess"], 1e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nmax,margin", [(1, 0.0), (10 ** 6, 0.0), (3, 0.02)])
+def test_gpu_mesh_vs_shapes(pkg, oracle, nmax, margin):
+    """k_bvh_shape (+ mesh x mesh and shape x shape pairs of the same batch) vs the oracle."""
+    abi, wl, bb = pkg.abi, pkg.workloads, pkg.bvh_builder
+    b = _scene(pkg, n=20000, seed=7)
+    ML = bb.MeshLibrary(b.meshes)
+    req = abi.default_collision_request()
+    req.num_max_contacts, req.security_margin = nmax, margin
+    ref, cref = oracle.mixed_collide_batch(b.shapes, b.verts, ML, b.s1, b.s2, b.tf1, b.tf2, req, max_contacts=4 * 10 ** 6,
+                                           n_threads=16)
+    lib = wl.make_library(pkg, b)
+    try:
+        got, cgot, produced = lib.collide_contacts(b.s1, b.s2, b.tf1, b.tf2, req, 4 * 10 ** 6)
+        buckets = lib.last_bucket_counts()
+    finally:
+        lib.close()
+    assert buckets["bvh_shape"] > 15000 and buckets["unsupported"] == 0
+    assert not ((got["status"] >> 30) & 1).any()
+    kinds = b.shapes["type"]
+    mixed = (kinds[b.s1] == abi.BV_OBBRSS) != (kinds[b.s2] == abi.BV_OBBRSS)
+    near = np.abs(ref["distance"]) < 1e-9  # decision boundary
+    ok = (got["num_contacts"] == ref["num_contacts"]) | near
+    assert ok[mixed].all(), int((~ok[mixed]).sum())
+    m = mixed & ~near & (got["num_contacts"] == ref["num_contacts"])
+    assert np.array_equal(got["b1"][m], ref["b1"][m]) and np.array_equal(got["b2"][m], ref["b2"][m])
+    # distance field: exact semantics for contacts; for contact-free queries it is the running lower bound, which
+    # mixes leaf distances with OBB-vs-OBB bounds.  The solid's OBB is a PCA fit of its bound vertices
+    # (geometric_shapes_utility.h:73-82): for solids of revolution (sphere, capsule, cone, cylinder) two or three
+    # eigenvalues coincide and the box orientation is decided by rounding noise -- in the reference as well --
+    # so there only "a valid positive lower bound" can be asserted (checked against brute force below).
+    solid = np.where(kinds[b.s1] == abi.BV_OBBRSS, kinds[b.s2], kinds[b.s1])
+    round_solid = np.isin(solid, [abi.GEOM_SPHERE, abi.GEOM_CAPSULE, abi.GEOM_CONE, abi.GEOM_CYLINDER])
+    fin = m & (np.abs(ref["distance"]) < 1e300)
+    strict = fin & ((ref["num_contacts"] > 0) | ~round_solid)
+    assert np.abs(got["distance"][strict] - ref["distance"][strict]).max() < 4e-6  # EPA on smooth solids: test_gpu_parity
+    loose = fin & ~strict
+    assert loose.sum() > 1000 and (got["distance"][loose] > 0).all()
+    g = pkg.geometry
+    for i in np.nonzero(loose)[0][:25]:  # true distance = min over all triangles (no BVH)
+        mesh_first = kinds[b.s1[i]] == abi.BV_OBBRSS
+        ms, ss = (b.s1[i], b.s2[i]) if mesh_first else (b.s2[i], b.s1[i])
+        tfm, tfs = (b.tf1[i], b.tf2[i]) if mesh_first else (b.tf2[i], b.tf1[i])
+        mesh = b.meshes[int(b.shapes[ms]["bvh_index"])]
+        L = g.ShapeLibrary()
+        for t3 in mesh.triangles:
+            L.add_triangle(*mesh.vertices[t3])
+        src = b.shapes[ss]
+        base = L._add(int(src["type"]), tuple(src["params"]), float(src["swept_sphere_radius"]))
+        nt = mesh.num_tris
+        r = oracle.distance_batch(L.shapes_array(), L.vertices_array(), np.arange(nt), np.full(nt, base), np.tile(tfm, (nt, 1)),
+                                  np.tile(tfs, (nt, 1)), None, n_threads=8)
+        assert got["distance"][i] <= r["distance"].min() + 1e-9 + margin, (i, got["distance"][i], r["distance"].min())
+    assert np.array_equal(np.isnan(got["p1"][strict]), np.isnan(ref["p1"][strict]))
+    # contact lists of the mixed pairs: same (pair, b1, b2) multiset
+    pm = np.nonzero(m)[0]
+    key = lambda c: sorted((int(p), int(x), int(y)) for p, x, y in zip(c["pair"], c["b1"], c["b2"]) if mixed[p] and not near[p])
+    if nmax > 3:
+        assert key(cref) == key(cgot)
+    frac = (ref["num_contacts"][mixed] > 0).mean()
+    assert 0.2 < frac < 0.9, frac
