@@ -161,7 +161,6 @@ def main():
         return work
 
     comm_stream = torch.cuda.Stream(device=dev) if gather else None
-    pending = []
 
     def flush_gather(work):
         buf, ev = work
@@ -181,14 +180,18 @@ def main():
         if w:
             flush_gather(w).wait()
     sync_all()
+    inflight = {}  # result buffer -> all-gather still reading it
     t0 = time.perf_counter()
     for i in range(args.steps):
+        # double buffering: the kernels of step i overwrite the buffer the all-gather of step i-2 read;
+        # make the launch stream wait for that collective first (stream-side wait, the host does not block)
+        h = inflight.pop(i & 1, None)
+        if h is not None:
+            h.wait()
         w = one_step(i, False)
         if w:
-            if len(pending) >= 2:
-                pending.pop(0).wait()
-            pending.append(flush_gather(w))
-    for h in pending:
+            inflight[i & 1] = flush_gather(w)
+    for h in inflight.values():
         h.wait()
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -246,7 +249,7 @@ def main():
             "kernels_ms": avg,
         }
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_binding as ob  # checker/baseline only -- never on the product path
             ns = min(args.cpu_sample, n)
