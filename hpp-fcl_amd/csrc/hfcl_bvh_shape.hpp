@@ -162,10 +162,12 @@ HFCL_HD int for_each_bound_vertex(const DShape<T>& s, const T* verts, const Pose
   return 0;
 }
 
-// computeBV<OBB-half of OBBRSS>(shape, tf): OBB_fit_functions::fitn on the bound vertices.
+// computeBV<OBBRSS,S>(shape, tf): OBB_fit_functions::fitn (+ RSS_fit_functions::fitn on the same axes when
+// `rss` is given: getRadiusAndOriginAndRectangleSize, BVH_utility.cpp:264-482, point-cloud branch; the
+// reference stores the projections in an array, here every pass re-projects the bound vertices).
 // Returns false when the reference path is not restated (fewer than 4 points, swept-sphere radius).
 template <typename T>
-HFCL_HD bool shape_obb(const DShape<T>& s, const T* verts, const Pose<T>& tf, DNode<T>& bv) {
+HFCL_HD bool shape_obbrss(const DShape<T>& s, const T* verts, const Pose<T>& tf, DNode<T>& bv, DRss<T>* rss) {
   if (s.ssr > T(0)) return false;  // "Swept-sphere radius not yet supported." (geometric_shapes_utility.h:75-78)
   V3<T> S1 = mk<T>(T(0), T(0), T(0));
   T sxx = T(0), syy = T(0), szz = T(0), sxy = T(0), sxz = T(0), syz = T(0);
@@ -230,7 +232,104 @@ HFCL_HD bool shape_obb(const DShape<T>& s, const T* verts, const Pose<T>& tf, DN
   bv.extent = (hi - lo) / T(2);
   bv.first_child = -1;
   bv.pad_ = 0;
+  if (!rss) return true;
+  // ---- RSS on the same axes.  Pass 1: slab along axis 2 (the first point seeds both ends)
+  auto prj = [&](const V3<T>& p) { return mk<T>(dot(a0, p), dot(a1, p), dot(a2, p)); };
+  T minz = T(0), maxz = T(0);
+  int idx = 0;
+  for_each_bound_vertex(s, verts, tf, [&](const V3<T>& p) {
+    const T z = dot(a2, p);
+    if (idx == 0) {
+      minz = maxz = z;
+    } else if (z < minz) {
+      minz = z;
+    } else if (z > maxz) {
+      maxz = z;
+    }
+    ++idx;
+  });
+  const T r = T(0.5) * (maxz - minz), radsqr = r * r, cz = T(0.5) * (maxz + minz);
+  auto cap = [&](T z) {
+    const T dz = z - cz;
+    return hsqrt(hmax(radsqr - dz * dz, T(0)));
+  };
+  T rlo[2], rhi[2];
+  for (int k = 0; k < 2; ++k) {
+    // extreme points along axis k (strictly smaller / larger than everything before, as the reference's scan)
+    T wlo = T(0), whi = T(0), zlo = T(0), zhi = T(0);
+    idx = 0;
+    for_each_bound_vertex(s, verts, tf, [&](const V3<T>& p) {
+      const V3<T> q = prj(p);
+      const T w = k == 0 ? q.x : q.y;
+      if (idx == 0) {
+        wlo = whi = w;
+        zlo = zhi = q.z;
+      } else if (w < wlo) {
+        wlo = w;
+        zlo = q.z;
+      } else if (w > whi) {
+        whi = w;
+        zhi = q.z;
+      }
+      ++idx;
+    });
+    T lo_k = wlo + cap(zlo), hi_k = whi - cap(zhi);
+    for_each_bound_vertex(s, verts, tf, [&](const V3<T>& p) {
+      const V3<T> q = prj(p);
+      const T w = k == 0 ? q.x : q.y;
+      if (w < lo_k) {
+        const T x = w + cap(q.z);
+        if (x < lo_k) lo_k = x;
+      } else if (w > hi_k) {
+        const T x = w - cap(q.z);
+        if (x > hi_k) hi_k = x;
+      }
+    });
+    rlo[k] = lo_k;
+    rhi[k] = hi_k;
+  }
+  const T h = hsqrt(T(0.5));
+  for_each_bound_vertex(s, verts, tf, [&](const V3<T>& p) {  // corner growth
+    const V3<T> q = prj(p);
+    const int sx = q.x > rhi[0] ? 1 : (q.x < rlo[0] ? -1 : 0);
+    if (!sx) return;
+    const int sy = q.y > rhi[1] ? 1 : (q.y < rlo[1] ? -1 : 0);
+    if (!sy) return;
+    const T dx = q.x - (sx > 0 ? rhi[0] : rlo[0]), dy = q.y - (sy > 0 ? rhi[1] : rlo[1]);
+    T u;
+    if (sx > 0 && sy > 0)
+      u = dx * h + dy * h;
+    else if (sx > 0)
+      u = dx * h - dy * h;
+    else if (sy > 0)
+      u = dy * h - dx * h;
+    else
+      u = -dx * h - dy * h;
+    const T ex = (sx > 0 ? h * u : -h * u) - dx, ey = (sy > 0 ? h * u : -h * u) - dy;
+    const T t = ex * ex + ey * ey + (cz - q.z) * (cz - q.z);
+    u = u - hsqrt(hmax(radsqr - t, T(0)));
+    if (u > T(0)) {
+      if (sx > 0)
+        rhi[0] += u * h;
+      else
+        rlo[0] -= u * h;
+      if (sy > 0)
+        rhi[1] += u * h;
+      else
+        rlo[1] -= u * h;
+    }
+  });
+  // origin = axes * (minx, miny, cz)
+  rss->Tr = mk<T>(a0.x * rlo[0] + a1.x * rlo[1] + a2.x * cz, a0.y * rlo[0] + a1.y * rlo[1] + a2.y * cz,
+                  a0.z * rlo[0] + a1.z * rlo[1] + a2.z * cz);
+  rss->l0 = hmax(rhi[0] - rlo[0], T(0));
+  rss->l1 = hmax(rhi[1] - rlo[1], T(0));
+  rss->r = r;
   return true;
+}
+template <typename T>
+HFCL_HD bool shape_obb(const DShape<T>& s, const T* verts, const Pose<T>& tf, DNode<T>& bv) {
+  return shape_obbrss<T>(s, verts, tf, bv, nullptr);
 }
 
 // details::segmentSqrDistance :235-255, projectInTriangle :258-279, sphereTriangleDistance :286-340
@@ -405,7 +504,9 @@ HFCL_HD void mesh_shape_collide(const DNode<T>* nodes, const T* mverts, const ui
       p1 = o.p1;
       p2 = o.p2;
       n = o.normal;
-      st.guess = o.cached_guess;
+      // GJK::Collision without penetration information leaves the solver's cached guess untouched
+      // (narrowphase.h:638-656): the previous leaf's value persists
+      if (!(o.gjk_status == GJK_COLLISION && !q.compute_penetration)) st.guess = o.cached_guess;
     }
     const T dtc = distance - q.security_margin;
     if (dtc < st.dlb) {  // updateDistanceLowerBoundFromLeaf
@@ -423,6 +524,122 @@ HFCL_HD void mesh_shape_collide(const DNode<T>* nodes, const T* mverts, const ui
       }
       if (st.ncontacts >= num_max_contacts) return;  // canStop()
     }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// distance(): MeshShapeDistanceTraversalNodeOBBRSS (traversal_node_bvh_shape.h:276-478) + distanceRecurse
+// (traversal_recurse.cpp:153-203) with a leaf second node, rel_err = abs_err = 0.  stack_n / stack_d: cap
+// entries each of group-shared memory (node id, RSS lower bound of the pending subtree).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct MeshShapeDist {
+  T min_distance;
+  int prim;
+  V3<T> np1, np2, nn;
+  V3<T> guess;
+  bool overflow, unsupported;
+};
+
+template <typename T, class Grp, class Solid>
+HFCL_HD void mesh_shape_distance(const DNode<T>* nodes, const DRss<T>* rss, const T* mverts, const uint32_t* tris,
+                                 const Pose<T>& tfm, const DShape<T>& shape, const T* sverts, const Pose<T>& tfs,
+                                 const Solid& solid, const QParams<T>& q, uint16_t* stack_n, T* stack_d, int cap,
+                                 EpaScratch<T, EPA_MAX_ITER>* scratch, const V3<T>& initial_guess, MeshShapeDist<T>& st) {
+  const T nanv = Lim<T>::nan();
+  st.min_distance = Lim<T>::max();
+  st.prim = -1;
+  st.np1 = st.np2 = st.nn = mk<T>(nanv, nanv, nanv);
+  st.guess = initial_guess;
+  st.overflow = st.unsupported = false;
+  DNode<T> bv2;
+  DRss<T> rss2;
+  if (!shape_obbrss(shape, sverts, tfs, bv2, &rss2)) {
+    st.unsupported = true;
+    return;
+  }
+  const MDiff<T> md = make_mdiff(tfm, tfs);
+  const T r1 = swept_radius(shape);
+  auto leaf = [&](uint32_t prim) {
+    const uint32_t* t3 = tris + 3 * size_t(prim);
+    auto vtx = [&](uint32_t i) { return mk<T>(mverts[3 * size_t(i)], mverts[3 * size_t(i) + 1], mverts[3 * size_t(i) + 2]); };
+    const V3<T> ta = vtx(t3[0]), tb = vtx(t3[1]), tc = vtx(t3[2]);
+    T distance;
+    V3<T> p1, p2, n;
+    if (shape.kind == K_SPHERE) {
+      distance = sphere_triangle(shape, tfs, xform(tfm, ta), xform(tfm, tb), xform(tfm, tc), p2, p1, n);
+      n = -n;
+    } else {
+      TriSolidSupport<T, Solid> sup;
+      sup.a = ta;
+      sup.b = tb;
+      sup.c = tc;
+      sup.solid = &solid;
+      sup.md = md;
+      const V3<T> guess0 = (q.guess_mode == HFCL_GUESS_CACHED) ? st.guess : mk<T>(T(1), T(0), T(0));
+      Gjk<T, PW0<T>> g;
+      gjk_run(g, q.gjk, guess0, r1, false, sup);
+      PairOut<T> o;
+      EpaSeed<T> seed;
+      if (gjk_finish(g, q, tfm, T(0), r1, guess0, o, seed)) {
+        Grp::sync();
+        epa_run<T, Grp, EPA_MAX_ITER>(scratch, seed, q, tfm, T(0), r1, sup, o);
+        Grp::sync();
+      }
+      distance = o.distance;
+      p1 = o.p1;
+      p2 = o.p2;
+      n = o.normal;
+      // GJK::Collision without penetration information leaves the solver's cached guess untouched
+      // (narrowphase.h:638-656): the previous leaf's value persists
+      if (!(o.gjk_status == GJK_COLLISION && !q.compute_penetration)) st.guess = o.cached_guess;
+    }
+    if (st.min_distance > distance) {  // DistanceResult::update
+      st.min_distance = distance;
+      st.prim = int(prim);
+      st.np1 = p1;
+      st.np2 = p2;
+      st.nn = n;
+    }
+  };
+  leaf(0u);  // preprocess(): triangle 0
+  int sp = 0;
+  Grp::sync();
+  if (Grp::lane() == 0) {
+    stack_n[0] = 0;
+    stack_d[0] = T(-1);
+  }
+  sp = 1;
+  Grp::sync();
+  while (sp > 0) {
+    --sp;
+    const uint32_t b = stack_n[sp];
+    const T db = stack_d[sp];
+    if (db >= T(0) && db >= st.min_distance) continue;  // canStop(d)
+    const DNode<T> n1 = nodes[b];
+    if (n1.first_child < 0) {
+      leaf(uint32_t(-(n1.first_child + 1)));
+      continue;
+    }
+    const uint32_t a1 = uint32_t(n1.first_child), c1 = a1 + 1;
+    // distance(tf1.R, tf1.T, model2_bv, model1.bv(b)): the mesh node placed by the mesh pose, seen from the solid's RSS
+    const T d1 = rss_lower_bound(tfm.R, tfm.t, bv2, rss2, nodes[a1], rss[a1]);
+    const T d2 = rss_lower_bound(tfm.R, tfm.t, bv2, rss2, nodes[c1], rss[c1]);
+    if (sp + 2 > cap) {
+      st.overflow = true;
+      return;
+    }
+    const bool c_first = d2 < d1;
+    Grp::sync();
+    if (Grp::lane() == 0) {
+      stack_n[sp] = uint16_t(c_first ? a1 : c1);  // visited second
+      stack_d[sp] = c_first ? d1 : d2;
+      stack_n[sp + 1] = uint16_t(c_first ? c1 : a1);  // visited first
+      stack_d[sp + 1] = c_first ? d2 : d1;
+    }
+    sp += 2;
+    Grp::sync();
   }
 }
 

@@ -899,6 +899,56 @@ __global__ void __launch_bounds__(64) k_bvh_shape(Work wk, LibView<T> lib, BvhVi
   }
 }
 
+// distance() counterpart: same lane-group layout, RSS lower bounds instead of OBB overlap tests.
+template <typename T>
+__global__ void __launch_bounds__(64) k_bvh_shape_distance(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q) {
+  constexpr int G = 64 / BS_W;
+  __shared__ EpaScratch<T, EPA_MAX_ITER> scratch[G];
+  __shared__ uint16_t stack_n[G][BS_STACK];
+  __shared__ T stack_d[G][BS_STACK];
+  const uint32_t cnt = wk.counts[B_BVHSHAPE];
+  const int lane = threadIdx.x & 63, grp = lane / BS_W, lig = lane & (BS_W - 1);
+  for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += gridDim.x * G) {
+    const uint32_t pair = wk.lists[size_t(B_BVHSHAPE) * wk.n + it];
+    const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+    const bool swapped = a.kind != K_BVH;  // distance.cpp:74-88
+    const DShape<T> ms = swapped ? b : a;
+    GroupSolid<T> solid;
+    solid.s = swapped ? a : b;
+    solid.v = lib.verts + 3 * size_t(solid.s.vertex_offset);
+    solid.lig = lig;
+    if (solid.s.kind == K_CONVEX && solid.s.num_points <= uint32_t(HULL_MAX)) solid.h.load(solid.v, solid.s.num_points, lig);
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    const Pose<T> tfm = swapped ? tf2 : tf1, tfs = swapped ? tf1 : tf2;
+    const DMesh m = bv.meshes[ms.bvh_index];
+    MeshShapeDist<T> st;
+    mesh_shape_distance<T, LaneGroup<BS_W>>(bv.nodes + m.node_off, bv.rss + m.node_off, bv.verts + 3 * size_t(m.vert_off),
+                                            bv.tris + 3 * size_t(m.tri_off), tfm, solid.s, lib.verts, tfs, solid, q, stack_n[grp],
+                                            stack_d[grp], BS_STACK, &scratch[grp], initial_guess<T>(io, q, pair), st);
+    if (lig == 0) {
+      if (st.unsupported) {
+        auto r = io.out[pair];
+        memset(&r, 0, sizeof(r));
+        r.status = 0x80000000u;
+        io.out[pair] = r;
+      } else {
+        PairOut<T> o;
+        o.distance = st.min_distance;
+        o.normal = swapped ? -st.nn : st.nn;
+        o.p1 = swapped ? st.np2 : st.np1;
+        o.p2 = swapped ? st.np1 : st.np2;
+        o.gjk_status = GJK_DID_NOT_RUN;
+        o.epa_status = EPA_DID_NOT_RUN;
+        o.gjk_iters = o.epa_iters = 0;
+        // b1 = the triangle, b2 = NONE whatever the operand order (distance.cpp:84-88 swaps o1/o2 only)
+        store_bvh_record(io, pair, o, st.min_distance <= T(0) ? 0x80000000u : 0u, st.prim, -1, st.overflow);
+        write_guess<T>(io, pair, st.guess, 0, 0);
+      }
+    }
+    LaneGroup<BS_W>::sync();
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // k_bvh_distance: BVHModel<OBBRSS> x BVHModel<OBBRSS> distance().  distanceRecurse
 // (src/traversal/traversal_recurse.cpp:153-203) flattened: both child pairs get their RSS lower
@@ -1536,6 +1586,10 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
                          lib->bvh_params, T(lib->break_distance * lib->break_distance));
       hipEventRecord(t->e1, st);
     } else {
+      t = timer_slot(lib, ti++, "k_bvh_shape_distance");
+      hipEventRecord(t->e0, st);
+      hipLaunchKernelGGL((k_bvh_shape_distance<T>), dim3(blocks_for(n / 8 + 1, 64 / BS_W)), dim3(64), 0, st, wk, lv, bv, io, q);
+      hipEventRecord(t->e1, st);
       t = timer_slot(lib, ti++, "k_bvh_distance");
       hipEventRecord(t->e0, st);
       hipLaunchKernelGGL((k_bvh_distance<T>), dim3(blocks_for(n, BVHD_BLOCK)), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q);
@@ -1546,7 +1600,7 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   t = timer_slot(lib, ti++, "k_unsupported");
   hipEventRecord(t->e0, st);
   hipLaunchKernelGGL((k_unsupported<T>), dim3(blocks_for(n, 256 * 64)), dim3(256), 0, st, wk, io, int(B_UNSUPPORTED));
-  if (q.mode != 1 || lib->h_meshes.empty())  // BVHModel x shape is built for collide() only
+  if (lib->h_meshes.empty())  // BVHModel x shape pairs without any registered mesh
     hipLaunchKernelGGL((k_unsupported<T>), dim3(blocks_for(n, 256 * 64)), dim3(256), 0, st, wk, io, int(B_BVHSHAPE));
   hipEventRecord(t->e1, st);
 
@@ -1762,10 +1816,6 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
   if (!skipped && lib->h_counts[B_UNSUPPORTED] > 0) {
     set_error("Collision/distance function between some node types of the batch is not yet supported (" +
               std::to_string(lib->h_counts[B_UNSUPPORTED]) + " pairs; their records carry status bit 31)");
-    return HFCL_ERR_UNSUPPORTED_PAIR;
-  }
-  if (!skipped && lib->h_counts[B_BVHSHAPE] > 0 && !creq) {
-    set_error("distance() between a BVHModel and a shape is not yet supported (collide() is)");
     return HFCL_ERR_UNSUPPORTED_PAIR;
   }
   if (!skipped && creq && creq->security_margin < 0 && lib->h_counts[B_BVHSHAPE] > 0) {

@@ -367,6 +367,105 @@ struct MeshShapeTraversal {
 };
 }  // namespace
 
+// ---- distance(): BVHShapeDistancer<OBBRSS,S> (src/distance_func_matrix.cpp:111-168),
+// MeshShapeDistanceTraversalNodeOBBRSS (traversal_node_bvh_shape.h:276-478), distanceRecurse
+// (src/traversal/traversal_recurse.cpp:153-203) with a leaf second node; rel_err = abs_err = 0 (the node's
+// constructor values: setupMeshShapeDistanceOrientedNode does not copy them, traversal_node_setup.h:747-772).
+double rss_distance(const M3& R0, const V3& T0, const hfcl_bvh_node& b1, const hfcl_bvh_node& b2);
+
+namespace {
+struct MeshShapeDistTraversal {
+  const MeshView& m1;
+  const Tf tf1, tf2;
+  const Shape& s2;
+  hfcl_bvh_node bv2;
+  GJKSolver solver;
+  bool signed_distance;
+  double min_distance = std::numeric_limits<double>::max();
+  int b1 = -1;
+  V3 np1, np2, normal;
+  bool ok = true;
+  MeshShapeDistTraversal(const MeshView& a, const Tf& t1, const Shape& b, const Tf& t2, const hfcl_distance_request& r)
+      : m1(a), tf1(t1), tf2(t2), s2(b), signed_distance(r.enable_signed_distance != 0) {
+    const double nanv = std::numeric_limits<double>::quiet_NaN();
+    np1 = np2 = normal = V3(nanv, nanv, nanv);
+    solver.set(r);
+    solver.out_cached_guess = solver.cached_guess;
+    solver.out_support_guess[0] = solver.support_func_cached_guess[0];
+    solver.out_support_guess[1] = solver.support_func_cached_guess[1];
+  }
+  void leaf(int pid) {
+    double t[9];
+    for (int k = 0; k < 3; ++k)
+      for (int c = 0; c < 3; ++c) t[3 * k + c] = m1.verts[3 * size_t(m1.tris[3 * pid + k]) + c];
+    Shape tri;
+    tri.kind = K_TRIANGLE;
+    tri.verts = t;
+    tri.nverts = 3;
+    double d;
+    V3 p1, p2, n;
+    if (!shape_shape_distance(tri, tf1, s2, tf2, solver, signed_distance, d, p1, p2, n)) {
+      ok = false;
+      return;
+    }
+    solver.cached_guess = solver.out_cached_guess;
+    solver.support_func_cached_guess[0] = solver.out_support_guess[0];
+    solver.support_func_cached_guess[1] = solver.out_support_guess[1];
+    if (min_distance > d) {  // DistanceResult::update (collision_data.h:1115-1160)
+      min_distance = d;
+      b1 = pid;
+      np1 = p1;
+      np2 = p2;
+      normal = n;
+    }
+  }
+  bool can_stop(double c) const { return c >= min_distance; }
+  double lower_bound(unsigned b) const { return rss_distance(tf1.R, tf1.T, bv2, m1.nodes[b]); }
+  void recurse(unsigned b) {
+    const hfcl_bvh_node& n1 = m1.nodes[b];
+    if (n1.first_child < 0) {
+      leaf(-(n1.first_child + 1));
+      return;
+    }
+    const unsigned a1 = unsigned(n1.first_child), c1 = a1 + 1;
+    const double d1 = lower_bound(a1), d2 = lower_bound(c1);
+    if (d2 < d1) {
+      if (!can_stop(d2)) recurse(c1);
+      if (!can_stop(d1)) recurse(a1);
+    } else {
+      if (!can_stop(d1)) recurse(a1);
+      if (!can_stop(d2)) recurse(c1);
+    }
+  }
+};
+}  // namespace
+
+int bvh_shape_distance_pair(const MeshView& m1, const Tf& tf1, const Shape& s2, const Tf& tf2, const hfcl_distance_request& req,
+                            bool swapped, hfcl_result& out, hfcl_guess* guess_out) {
+  MeshShapeDistTraversal t(m1, tf1, s2, tf2, req);
+  int rc = shape_obbrss(s2, tf2, t.bv2);
+  if (rc) return rc;
+  t.leaf(0);  // preprocess(): triangle 0
+  if (t.ok) t.recurse(0);
+  if (!t.ok) return HFCL_ERR_UNSUPPORTED_PAIR;
+  out.distance = t.min_distance;
+  for (int k = 0; k < 3; ++k) {  // distance.cpp:84-88 swaps o1/o2, the points and the normal -- not b1/b2
+    out.normal[k] = swapped ? -t.normal[k] : t.normal[k];
+    out.p1[k] = swapped ? t.np2[k] : t.np1[k];
+    out.p2[k] = swapped ? t.np1[k] : t.np2[k];
+  }
+  out.b1 = t.b1;
+  out.b2 = -1;
+  out.status = (t.min_distance <= 0) ? 128u : 0u;
+  out.num_contacts = 0;
+  if (guess_out) {
+    for (int k = 0; k < 3; ++k) guess_out->gjk_guess[k] = t.solver.cached_guess[k];
+    guess_out->support_guess[0] = t.solver.support_func_cached_guess[0];
+    guess_out->support_guess[1] = t.solver.support_func_cached_guess[1];
+  }
+  return HFCL_OK;
+}
+
 // (BVH, shape) in this order; `swapped`: the caller had (shape, BVH) -> collision.cpp:101-107
 int bvh_shape_collide_pair(const MeshView& m1, const Tf& tf1, const Shape& s2, const Tf& tf2, const hfcl_collision_request& req,
                            bool swapped, hfcl_result& out, std::vector<hfcl_contact>* contacts, uint32_t pair_index,

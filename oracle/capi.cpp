@@ -288,6 +288,42 @@ int orc_mixed_collide_batch(const hfcl_shape* shapes, size_t n_shapes, const dou
   return err;
 }
 
+// distance() counterpart of orc_mixed_collide_batch.
+int orc_mixed_distance_batch(const hfcl_shape* shapes, size_t n_shapes, const double* shape_verts, const hfcl_bvh_node* nodes,
+                             const double* mesh_verts, const uint32_t* tris, const uint64_t* mesh_table, size_t n_meshes,
+                             const uint32_t* s1, const uint32_t* s2, const double* tf1, const double* tf2, size_t n,
+                             const hfcl_distance_request* req, hfcl_result* out, hfcl_guess* guess_out, int n_threads) {
+  std::vector<MeshView> meshes(n_meshes);
+  for (size_t i = 0; i < n_meshes; ++i) {
+    meshes[i].nodes = nodes + mesh_table[4 * i];
+    meshes[i].n_nodes = mesh_table[4 * i + 1];
+    meshes[i].verts = mesh_verts + 3 * mesh_table[4 * i + 2];
+    meshes[i].tris = tris + 3 * mesh_table[4 * i + 3];
+  }
+  std::vector<Shape> lib(n_shapes);
+  for (size_t i = 0; i < n_shapes; ++i) lib[i] = make_shape(shapes[i], shape_verts);
+  int err = 0;
+  parallel_for(n, n_threads, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      const hfcl_shape &a = shapes[s1[i]], &c = shapes[s2[i]];
+      const bool ma = a.type == HFCL_BV_OBBRSS, mc = c.type == HFCL_BV_OBBRSS;
+      const Tf t1 = tf_from_abi(tf1 + 12 * i), t2 = tf_from_abi(tf2 + 12 * i);
+      hfcl_guess* go = guess_out ? guess_out + i : nullptr;
+      int rc;
+      if (ma && mc)
+        rc = bvh_distance_pair(meshes[a.bvh_index], t1, meshes[c.bvh_index], t2, out[i], nullptr);
+      else if (ma)
+        rc = bvh_shape_distance_pair(meshes[a.bvh_index], t1, lib[s2[i]], t2, *req, false, out[i], go);
+      else if (mc)
+        rc = bvh_shape_distance_pair(meshes[c.bvh_index], t2, lib[s1[i]], t1, *req, true, out[i], go);
+      else
+        rc = distance_pair(lib[s1[i]], t1, lib[s2[i]], t2, *req, nullptr, out[i], go);
+      if (rc) err = rc;
+    }
+  });
+  return err;
+}
+
 // BVHModel<OBBRSS> x BVHModel<OBBRSS> distance(); same mesh table as orc_bvh_collide_batch.
 int orc_bvh_distance_batch(const hfcl_bvh_node* nodes, const double* verts, const uint32_t* tris,
                            const uint64_t* mesh_table, size_t n_meshes, const uint32_t* m1, const uint32_t* m2,

@@ -453,6 +453,73 @@ int sim_mesh_shape_collide_f64(const hfcl_shape* shapes, size_t n_shapes, const 
   return 0;
 }
 
+int sim_mesh_shape_distance_f64(const hfcl_shape* shapes, size_t n_shapes, const double* shape_verts, const hfcl_bvh_node* nodes,
+                                size_t n_nodes, const double* verts, size_t n_verts, const uint32_t* tris,
+                                const uint64_t* mesh_table, const uint32_t* s1, const uint32_t* s2, const double* tf1,
+                                const double* tf2, size_t n, const hfcl_distance_request* dreq, hfcl_result* out,
+                                hfcl_guess* gout) {
+  std::vector<DNode<double>> dn(n_nodes);
+  std::vector<DRss<double>> dr(n_nodes);
+  for (size_t i = 0; i < n_nodes; ++i) {
+    const double* a = nodes[i].obb_axes;
+    dn[i].first_child = nodes[i].first_child;
+    dn[i].axes.r0 = mk<double>(a[0], a[3], a[6]);
+    dn[i].axes.r1 = mk<double>(a[1], a[4], a[7]);
+    dn[i].axes.r2 = mk<double>(a[2], a[5], a[8]);
+    dn[i].To = mk<double>(nodes[i].obb_To[0], nodes[i].obb_To[1], nodes[i].obb_To[2]);
+    dn[i].extent = mk<double>(nodes[i].obb_extent[0], nodes[i].obb_extent[1], nodes[i].obb_extent[2]);
+    dr[i].Tr = mk<double>(nodes[i].rss_Tr[0], nodes[i].rss_Tr[1], nodes[i].rss_Tr[2]);
+    dr[i].l0 = nodes[i].rss_length[0];
+    dr[i].l1 = nodes[i].rss_length[1];
+    dr[i].r = nodes[i].rss_radius;
+  }
+  (void)n_verts;
+  (void)n_shapes;
+  QParams<double> q;
+  fill_q(q, dreq->q);
+  q.mode = 0;
+  q.compute_penetration = dreq->enable_signed_distance ? 1 : 0;
+  q.security_margin = 0;
+  q.gjk.distance_upper_bound = Lim<double>::max();
+  static thread_local EpaScratch<double, EPA_MAX_ITER> scratch;
+  uint16_t stack_n[128];
+  double stack_d[128];
+  for (size_t i = 0; i < n; ++i) {
+    const hfcl_shape &a = shapes[s1[i]], &b = shapes[s2[i]];
+    const bool swapped = a.type != HFCL_BV_OBBRSS;
+    const hfcl_shape& ms = swapped ? b : a;
+    const DShape<double> solid = to_dshape<double>(swapped ? a : b);
+    const Pose<double> tfm = pose_from_abi<double>((swapped ? tf2 : tf1) + 12 * i);
+    const Pose<double> tfs = pose_from_abi<double>((swapped ? tf1 : tf2) + 12 * i);
+    const uint64_t* mt = mesh_table + 4 * ms.bvh_index;
+    HostSolid hs{solid, shape_verts};
+    MeshShapeDist<double> st;
+    mesh_shape_distance<double, SerialGroup<1>>(dn.data() + mt[0], dr.data() + mt[0], verts + 3 * mt[2], tris + 3 * mt[3], tfm, solid,
+                                               shape_verts, tfs, hs, q, stack_n, stack_d, 128, &scratch,
+                                               mk<double>(q.guess[0], q.guess[1], q.guess[2]), st);
+    hfcl_result& r = out[i];
+    std::memset(&r, 0, sizeof(r));
+    if (st.unsupported) {
+      r.status = 0x80000000u;
+      continue;
+    }
+    const V3<double> p1 = swapped ? st.np2 : st.np1, p2 = swapped ? st.np1 : st.np2, nn = swapped ? -st.nn : st.nn;
+    r.distance = st.min_distance;
+    r.normal[0] = nn.x; r.normal[1] = nn.y; r.normal[2] = nn.z;
+    r.p1[0] = p1.x; r.p1[1] = p1.y; r.p1[2] = p1.z;
+    r.p2[0] = p2.x; r.p2[1] = p2.y; r.p2[2] = p2.z;
+    r.b1 = st.prim;  // distance.cpp:84-88 does not swap b1 / b2
+    r.b2 = -1;
+    r.status = (st.min_distance <= 0 ? 128u : 0u) | (st.overflow ? 0xC0000000u : 0u);
+    r.num_contacts = 0;
+    if (gout) {
+      gout[i].gjk_guess[0] = st.guess.x; gout[i].gjk_guess[1] = st.guess.y; gout[i].gjk_guess[2] = st.guess.z;
+      gout[i].support_guess[0] = gout[i].support_guess[1] = 0;
+    }
+  }
+  return 0;
+}
+
 int sim_bvh_collide_f64(const hfcl_bvh_node* nodes, size_t n_nodes, const double* verts, size_t n_verts,
                         const uint32_t* tris, const uint64_t* mesh_table, const uint32_t* m1, const uint32_t* m2,
                         const double* tf1, const double* tf2, size_t n, const hfcl_collision_request* creq, hfcl_result* out,

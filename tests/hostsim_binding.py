@@ -129,3 +129,22 @@ def mesh_shape_collide_f64(abi, shapes, verts, meshlib, s1, s2, tf1, tf2, req, m
     if want_guess:
         res.append(gout)
     return res[0] if len(res) == 1 else tuple(res)
+
+
+def mesh_shape_distance_f64(abi, shapes, verts, meshlib, s1, s2, tf1, tf2, req, want_guess=False):
+    """distance() of BVHModel<OBBRSS> x convex shape pairs through the device header's mesh_shape_distance."""
+    shapes = np.ascontiguousarray(shapes)
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    s1 = np.ascontiguousarray(s1, dtype=np.uint32)
+    s2 = np.ascontiguousarray(s2, dtype=np.uint32)
+    tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
+    tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
+    n = len(s1)
+    out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    gout = np.zeros(n, dtype=abi.GUESS_DTYPE) if want_guess else None
+    nodes = np.ascontiguousarray(meshlib.nodes)
+    lib().sim_mesh_shape_distance_f64(abi.ptr(shapes), C.c_size_t(len(shapes)), abi.ptr(verts), abi.ptr(nodes),
+                                      C.c_size_t(len(nodes)), abi.ptr(meshlib.verts), C.c_size_t(len(meshlib.verts)),
+                                      abi.ptr(meshlib.tris), abi.ptr(meshlib.table), abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1),
+                                      abi.ptr(tf2), C.c_size_t(n), C.byref(req), abi.ptr(out), abi.ptr(gout))
+    return (out, gout) if want_guess else out

@@ -290,3 +290,26 @@ def mixed_collide_batch(shapes, verts, meshlib, s1, s2, tf1, tf2, req=None, max_
     if want_guess:
         res.append(gout)
     return res[0] if len(res) == 1 else tuple(res)
+
+
+def mixed_distance_batch(shapes, verts, meshlib, s1, s2, tf1, tf2, req=None, n_threads=1, want_guess=False):
+    """distance() counterpart of mixed_collide_batch."""
+    abi = _pkg().abi
+    req = req or abi.default_distance_request()
+    shapes = np.ascontiguousarray(shapes)
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    s1 = np.ascontiguousarray(s1, dtype=np.uint32)
+    s2 = np.ascontiguousarray(s2, dtype=np.uint32)
+    tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
+    tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
+    n = len(s1)
+    out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    gout = np.zeros(n, dtype=abi.GUESS_DTYPE) if want_guess else None
+    nodes = np.ascontiguousarray(meshlib.nodes)
+    rc = lib().orc_mixed_distance_batch(abi.ptr(shapes), C.c_size_t(len(shapes)), abi.ptr(verts), abi.ptr(nodes),
+                                        abi.ptr(meshlib.verts), abi.ptr(meshlib.tris), abi.ptr(meshlib.table),
+                                        C.c_size_t(len(meshlib.table)), abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1), abi.ptr(tf2),
+                                        C.c_size_t(n), C.byref(req), abi.ptr(out), abi.ptr(gout), C.c_int(n_threads))
+    if rc:
+        raise ValueError("oracle mixed distance: error %d" % rc)
+    return (out, gout) if want_guess else out
