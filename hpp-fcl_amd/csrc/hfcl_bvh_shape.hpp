@@ -169,6 +169,45 @@ HFCL_HD int for_each_bound_vertex(const DShape<T>& s, const T* verts, const Pose
 template <typename T>
 HFCL_HD bool shape_obbrss(const DShape<T>& s, const T* verts, const Pose<T>& tf, DNode<T>& bv, DRss<T>* rss) {
   if (s.ssr > T(0)) return false;  // "Swept-sphere radius not yet supported." (geometric_shapes_utility.h:75-78)
+  if (s.kind == K_HALFSPACE || s.kind == K_PLANE) {  // unbounded "very rough" volumes, geometric_shapes_utility.cpp:545-581,803-850
+    const T big = Lim<T>::max();
+    bv.first_child = -1;
+    bv.pad_ = 0;
+    if (s.kind == K_HALFSPACE) {
+      bv.axes.r0 = mk<T>(T(1), T(0), T(0));
+      bv.axes.r1 = mk<T>(T(0), T(1), T(0));
+      bv.axes.r2 = mk<T>(T(0), T(0), T(1));
+      bv.To = mk<T>(T(0), T(0), T(0));
+      bv.extent = mk<T>(big, big, big);
+      if (rss) {
+        rss->Tr = bv.To;
+        rss->l0 = rss->l1 = rss->r = big;
+      }
+      return true;
+    }
+    const V3<T> n = mul(tf.R, mk<T>(s.p0, s.p1, s.p2));
+    V3<T> u, v;  // generateCoordinateSystem, internal/tools.h:60-87
+    if (habs(n.x) >= habs(n.y)) {
+      const T inv = T(1) / hsqrt(n.x * n.x + n.z * n.z);
+      u = mk<T>(-n.z * inv, T(0), n.x * inv);
+      v = mk<T>(n.y * u.z, n.z * u.x - n.x * u.z, -n.y * u.x);
+    } else {
+      const T inv = T(1) / hsqrt(n.y * n.y + n.z * n.z);
+      u = mk<T>(T(0), n.z * inv, -n.y * inv);
+      v = mk<T>(n.y * u.z - n.z * u.y, -n.x * u.z, n.x * u.y);
+    }
+    bv.axes.r0 = mk<T>(n.x, u.x, v.x);
+    bv.axes.r1 = mk<T>(n.y, u.y, v.y);
+    bv.axes.r2 = mk<T>(n.z, u.z, v.z);
+    bv.To = xform(tf, mk<T>(s.p0, s.p1, s.p2) * s.p3);
+    bv.extent = mk<T>(T(0), big, big);
+    if (rss) {
+      rss->Tr = bv.To;
+      rss->l0 = rss->l1 = big;
+      rss->r = T(0);
+    }
+    return true;
+  }
   V3<T> S1 = mk<T>(T(0), T(0), T(0));
   T sxx = T(0), syy = T(0), szz = T(0), sxy = T(0), sxz = T(0), syz = T(0);
   const int n = for_each_bound_vertex(s, verts, tf, [&](const V3<T>& p) {  // getCovariance, point-cloud branch
@@ -483,6 +522,9 @@ HFCL_HD void mesh_shape_collide(const DNode<T>* nodes, const T* mverts, const ui
     if (shape.kind == K_SPHERE) {  // triangle_sphere.cpp:45-56
       distance = sphere_triangle(shape, tfs, xform(tfm, ta), xform(tfm, tb), xform(tfm, tc), p2, p1, n);
       n = -n;
+    } else if (kind_is_flat(shape.kind)) {  // triangle_halfspace.cpp:46-57, triangle_plane.cpp:46-57
+      distance = flat_triangle_distance(shape, tfs, ta, tb, tc, tfm, p2, p1, n);
+      n = -n;
     } else {
       TriSolidSupport<T, Solid> sup;
       sup.a = ta;
@@ -569,6 +611,9 @@ HFCL_HD void mesh_shape_distance(const DNode<T>* nodes, const DRss<T>* rss, cons
     V3<T> p1, p2, n;
     if (shape.kind == K_SPHERE) {
       distance = sphere_triangle(shape, tfs, xform(tfm, ta), xform(tfm, tb), xform(tfm, tc), p2, p1, n);
+      n = -n;
+    } else if (kind_is_flat(shape.kind)) {
+      distance = flat_triangle_distance(shape, tfs, ta, tb, tc, tfm, p2, p1, n);
       n = -n;
     } else {
       TriSolidSupport<T, Solid> sup;

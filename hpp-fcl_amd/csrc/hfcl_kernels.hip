@@ -63,7 +63,7 @@ __host__ __device__ inline int bucket_of(int k1, int k2) {
   if (k2 == K_CONVEX_LARGE) k2 = K_CONVEX;
   if ((k1 == K_BVH) != (k2 == K_BVH)) {  // BVHModel x convex solid, either operand order (k_bvh_shape)
     const int o = (k1 == K_BVH) ? k2 : k1;
-    return (kind_is_prim(o) || o == K_CONVEX) ? B_BVHSHAPE : B_UNSUPPORTED;
+    return (kind_is_prim(o) || o == K_CONVEX || kind_is_flat(o)) ? B_BVHSHAPE : B_UNSUPPORTED;
   }
   const int c = pair_class(k1, k2);
   if (large && c == CLS_CONVEX) return B_LARGE;

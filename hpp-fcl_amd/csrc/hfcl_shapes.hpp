@@ -407,6 +407,42 @@ HFCL_HD T flat_solid_distance(const DShape<T>& f, const Pose<T>& tf1, const DSha
   return dist1;
 }
 
+// flat vs a triangle given by three points in the frame of tf2 (mesh triangles: src/distance/triangle_halfspace.cpp,
+// triangle_plane.cpp); p1 on the flat, p2 on the triangle, normal = the flat's normal
+template <typename T>
+HFCL_HD T flat_triangle_distance(const DShape<T>& f, const Pose<T>& tf1, const V3<T>& a, const V3<T>& b, const V3<T>& c,
+                                 const Pose<T>& tf2, V3<T>& p1, V3<T>& p2, V3<T>& normal) {
+  auto sup = [&](const V3<T>& dir) {  // getSupport<WithSweptSphere>(TriangleP): swept-sphere radius 0
+    const T da = dot(dir, a), db = dot(dir, b), dc = dot(dir, c);
+    V3<T> s;
+    if (da > db)
+      s = (dc > da) ? c : a;
+    else
+      s = (dc > db) ? c : b;
+    return s + normalized(dir) * T(0);
+  };
+  const PlaneEq<T> h0 = world_plane(f, tf1);
+  const V3<T> pa = xform(tf2, sup(-tmul(tf2.R, h0.n)));
+  const T dist1 = h0.signed_distance(pa);
+  if (f.kind == K_PLANE) {
+    PlaneEq<T> h1 = h0;
+    h1.n = -h0.n;
+    h1.d = -h0.d;
+    const V3<T> pb = xform(tf2, sup(-tmul(tf2.R, h1.n)));
+    const T dist2 = h1.signed_distance(pb);
+    if (!(dist1 >= dist2)) {
+      p2 = pb;
+      p1 = p2 - h1.n * dist2;
+      normal = h1.n;
+      return dist2;
+    }
+  }
+  p2 = pa;
+  p1 = p2 - h0.n * dist1;
+  normal = h0.n;
+  return dist1;
+}
+
 // flat vs flat: halfspace-halfspace :509-568, halfspace-plane :585-628, plane-plane :646-691
 template <typename T>
 HFCL_HD T flat_flat_distance(const DShape<T>& s1, const Pose<T>& tf1, const DShape<T>& s2, const Pose<T>& tf2, V3<T>& p1,

@@ -224,7 +224,7 @@ def large_convex(n=50_000, seed=1, sizes=(33, 48, 64, 100, 256), nlib_each=12, h
     return b
 
 
-def mesh_vs_shapes(n=20_000, seed=1, seg=14, ring=14, n_variants=3, nper=16, half_width=1.2):
+def mesh_vs_shapes(n=20_000, seed=1, seg=14, ring=14, n_variants=3, nper=16, half_width=1.2, flats_only=False):
     """BVHModel<OBBRSS> against the convex shape kinds, both operand orders, plus some mesh x mesh and
     shape x shape pairs: the BVH rows / columns of the collision matrix (collision_func_matrix.cpp:471-733)."""
     rng = _rng(seed, 9)
@@ -247,12 +247,16 @@ def mesh_vs_shapes(n=20_000, seed=1, seg=14, ring=14, n_variants=3, nper=16, hal
     base = fibonacci_sphere(24)
     for radii in rng.uniform(0.1, 0.7, (nper, 3)):
         lib.add_convex(base * radii)
+    n_solid_end = len(lib)
+    for k in range(nper):  # Plane / Halfspace: unbounded BVs, every triangle of the mesh is tested
+        nrm, d = rng.normal(size=3), float(rng.uniform(-0.6, 0.6))
+        (lib.add_halfspace if k % 2 == 0 else lib.add_plane)(nrm, d)
     n_all = len(lib)
     u = rng.random(n)
     mesh = rng.integers(0, n_variants, n)
-    solid = rng.integers(n_variants, n_all, n)
+    solid = rng.integers(n_solid_end, n_all, n) if flats_only else rng.integers(n_variants, n_solid_end, n)
     s1 = np.where(u < 0.45, mesh, np.where(u < 0.9, solid, np.where(u < 0.95, mesh, solid)))
-    s2 = np.where(u < 0.45, solid, np.where(u < 0.9, mesh, np.where(u < 0.95, rng.integers(0, n_variants, n), rng.integers(n_variants, n_all, n))))
+    s2 = np.where(u < 0.45, solid, np.where(u < 0.9, mesh, np.where(u < 0.95, rng.integers(0, n_variants, n), rng.integers(n_variants, n_solid_end, n))))
     q1, T1, q2, T2 = _poses(rng, n, half_width)
     b = Batch("mesh_vs_shapes_collide", lib, s1, s2, q1, T1, q2, T2, "collide")
     b.meshes = meshes

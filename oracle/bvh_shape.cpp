@@ -268,8 +268,49 @@ int fit_points_obbrss(const std::vector<V3>& ps, hfcl_bvh_node& bv) {
   return HFCL_OK;
 }
 
+// include/hpp/fcl/internal/tools.h:60-87
+static void generate_coordinate_system(const V3& w, V3& u, V3& v) {
+  if (std::abs(w[0]) >= std::abs(w[1])) {
+    const double inv_length = 1.0 / std::sqrt(w[0] * w[0] + w[2] * w[2]);
+    u = V3(-w[2] * inv_length, 0, w[0] * inv_length);
+    v = V3(w[1] * u[2], w[2] * u[0] - w[0] * u[2], -w[1] * u[0]);
+  } else {
+    const double inv_length = 1.0 / std::sqrt(w[1] * w[1] + w[2] * w[2]);
+    u = V3(0, w[2] * inv_length, -w[1] * inv_length);
+    v = V3(w[1] * u[2] - w[2] * u[1], -w[0] * u[2], w[0] * u[1]);
+  }
+}
+
 int shape_obbrss(const Shape& s, const Tf& tf, hfcl_bvh_node& bv) {
   if (s.ssr > 0) return HFCL_ERR_UNSUPPORTED_PAIR;  // "Swept-sphere radius not yet supported."
+  const double big = std::numeric_limits<double>::max();
+  if (s.kind == K_HALFSPACE) {  // geometric_shapes_utility.cpp:545-581: "very rough" unbounded volumes
+    std::memset(&bv, 0, sizeof(bv));
+    for (int k = 0; k < 3; ++k) {
+      bv.obb_axes[4 * k] = bv.rss_axes[4 * k] = 1;
+      bv.obb_extent[k] = big;
+    }
+    bv.rss_length[0] = bv.rss_length[1] = bv.rss_radius = big;
+    return HFCL_OK;
+  }
+  if (s.kind == K_PLANE) {  // :803-850
+    std::memset(&bv, 0, sizeof(bv));
+    const V3 n = tf.R * V3(s.p[0], s.p[1], s.p[2]);
+    V3 u, v;
+    generate_coordinate_system(n, u, v);
+    for (int r = 0; r < 3; ++r) {
+      bv.obb_axes[r] = bv.rss_axes[r] = n[r];
+      bv.obb_axes[3 + r] = bv.rss_axes[3 + r] = u[r];
+      bv.obb_axes[6 + r] = bv.rss_axes[6 + r] = v[r];
+    }
+    bv.obb_extent[0] = 0;
+    bv.obb_extent[1] = bv.obb_extent[2] = big;
+    const V3 p = tf.transform(V3(s.p[0], s.p[1], s.p[2]) * s.p[3]);
+    for (int r = 0; r < 3; ++r) bv.obb_To[r] = bv.rss_Tr[r] = p[r];
+    bv.rss_length[0] = bv.rss_length[1] = big;
+    bv.rss_radius = 0;
+    return HFCL_OK;
+  }
   const std::vector<V3> pts = bound_vertices(s, tf);
   if (pts.empty()) return HFCL_ERR_UNSUPPORTED_PAIR;
   return fit_points_obbrss(pts, bv);

@@ -286,3 +286,71 @@ def test_gpu_mesh_vs_shapes_distance(pkg, oracle):
     err = np.abs(sg[sep] - sr[sep]).max(axis=1)
     assert err.max() < 2e-3 and np.quantile(err, 0.99) < 1e-6
     assert (got["b2"][mixed] == -1).all()
+
+
+def test_mesh_vs_flats_headers_match_oracle(pkg, oracle, hostsim):
+    """Meshes against Plane / Halfspace: the flats' BVs are unbounded (geometric_shapes_utility.cpp:545-581,
+    803-850), so the reference tests every triangle; contacts = triangles reaching into the halfspace."""
+    abi, bb = pkg.abi, pkg.bvh_builder
+    b = _scene(pkg, n=400, seed=11, flats_only=True)
+    ML = bb.MeshLibrary(b.meshes)
+    sel = _mixed_only(pkg, b)
+    req = abi.default_collision_request()
+    req.num_max_contacts = 10 ** 6
+    a = (b.shapes, b.verts, ML, b.s1[sel], b.s2[sel], b.tf1[sel], b.tf2[sel], req)
+    ref, cref = oracle.mixed_collide_batch(*a, max_contacts=10 ** 6)
+    got, cgot = hostsim.mesh_shape_collide_f64(abi, *a, max_contacts=10 ** 6)
+    assert (ref["num_contacts"] > 0).mean() > 0.5 and np.array_equal(ref["num_contacts"], got["num_contacts"])
+    assert np.array_equal(cref["b1"], cgot["b1"]) and np.array_equal(cref["b2"], cgot["b2"])
+    assert _same(got["distance"], ref["distance"], 1e-15) and _same(cgot["penetration_depth"], cref["penetration_depth"], 1e-15)
+    # brute force for halfspaces: a triangle is in contact iff its lowest vertex along the normal is below the plane
+    kinds = b.shapes["type"]
+    checked = 0
+    for k, i in enumerate(sel[:40]):
+        mesh_first = kinds[b.s1[i]] == abi.BV_OBBRSS
+        fs = b.s2[i] if mesh_first else b.s1[i]
+        if kinds[fs] != abi.GEOM_HALFSPACE:
+            continue
+        tfm, tff = (b.tf1[i], b.tf2[i]) if mesh_first else (b.tf2[i], b.tf1[i])
+        mesh = b.meshes[int(b.shapes[b.s1[i] if mesh_first else b.s2[i]]["bvh_index"])]
+        R, T = pkg.geometry.pose_R(tfm), np.asarray(tfm)[9:]
+        W = mesh.vertices @ R.T + T
+        Rf, Tf = pkg.geometry.pose_R(tff), np.asarray(tff)[9:]
+        nw = Rf @ b.shapes[fs]["params"][:3]
+        dw = b.shapes[fs]["params"][3] + nw @ Tf
+        sd = W @ nw - dw
+        brute = int((sd[mesh.triangles].min(axis=1) <= 0).sum())
+        assert ref["num_contacts"][k] == brute
+        checked += 1
+    assert checked > 5
+    d_ref = oracle.mixed_distance_batch(b.shapes, b.verts, ML, b.s1[sel], b.s2[sel], b.tf1[sel], b.tf2[sel], None)
+    d_got = hostsim.mesh_shape_distance_f64(abi, b.shapes, b.verts, ML, b.s1[sel], b.s2[sel], b.tf1[sel], b.tf2[sel],
+                                            abi.default_distance_request())
+    assert _same(d_got["distance"], d_ref["distance"], 1e-15) and np.array_equal(d_got["b1"], d_ref["b1"])
+
+
+@pytest.mark.gpu
+def test_gpu_mesh_vs_flats(pkg, oracle):
+    abi, wl, bb = pkg.abi, pkg.workloads, pkg.bvh_builder
+    b = _scene(pkg, n=3000, seed=12, flats_only=True)
+    ML = bb.MeshLibrary(b.meshes)
+    req = abi.default_collision_request()
+    ref = oracle.mixed_collide_batch(b.shapes, b.verts, ML, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=16)
+    dref = oracle.mixed_distance_batch(b.shapes, b.verts, ML, b.s1, b.s2, b.tf1, b.tf2, None, n_threads=16)
+    lib = wl.make_library(pkg, b)
+    try:
+        got = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
+        dgot = lib.distance(b.s1, b.s2, b.tf1, b.tf2, abi.default_distance_request())
+    finally:
+        lib.close()
+    kinds = b.shapes["type"]
+    mixed = (kinds[b.s1] == abi.BV_OBBRSS) != (kinds[b.s2] == abi.BV_OBBRSS)
+    near = np.abs(ref["distance"]) < 1e-9
+    m = mixed & ~near
+    assert np.array_equal(got["num_contacts"][m], ref["num_contacts"][m])
+    assert np.array_equal(got["b1"][m], ref["b1"][m]) and np.array_equal(got["b2"][m], ref["b2"][m])
+    assert np.abs(got["distance"][m] - ref["distance"][m]).max() < 1e-9
+    # distance(): traversal order among equal RSS bounds (all 0 / NaN here) decides which penetrating triangle is met first
+    sepd = mixed & (dref["distance"] > 1e-9)
+    assert np.abs(dgot["distance"][sepd] - dref["distance"][sepd]).max() < 1e-9
+    assert (dgot["distance"][mixed & (dref["distance"] <= 0)] <= 1e-9).all()
