@@ -3,16 +3,23 @@
 // needs a HIP device and fails loudly without one.
 //
 // Kernel map (pair buckets follow the reference's dispatch table,
-// include/hpp/fcl/internal/shape_shape_func.h:185-211):
-//   k_classify      pair -> bucket lists (wave-aggregated atomics), one pass over the shape ids
-//   k_closed<T>     sphere-sphere / sphere-capsule / capsule-capsule / box-sphere, one pair per lane
-//   k_gjk_prim<T>   GJK for Box/Capsule/Ellipsoid/Sphere pairs, one pair per lane (no vertices to share)
-//   k_gjk_cvx<T,W,M> GJK with convex hulls: one pair per W-lane group, hull vertices distributed
-//                   over the group's registers, support = per-lane dots + xor-butterfly arg-max
-//   k_epa<T>        EPA on the pairs GJK left in `Collision`: one pair per wavefront, polytope in LDS
-//   k_bvh_collide<T> BVHModel<OBBRSS> x BVHModel<OBBRSS> collide(): one mesh pair per lane, explicit DFS
-//                   stack in LDS (reference order, so the first contact is the reference's), OBB SAT per
-//                   node pair, triangle-triangle GJK at the leaves (batched per wave to limit divergence)
+// include/hpp/fcl/internal/shape_shape_func.h:185-211 and src/collision_func_matrix.cpp:279-733):
+//   k_classify       pair -> bucket lists (block-aggregated atomics), one pass over the shape ids
+//   k_closed<T>      closed forms (sphere / capsule / cylinder / box-sphere pairs, every Plane / Halfspace
+//                    row), one pair per lane
+//   k_gjk_prim<T>    GJK for Box/Capsule/Cone/Cylinder/Ellipsoid/Sphere pairs, one pair per lane
+//   k_gjk_cvx<W,M>   GJK with hulls of <= 32 vertices: one pair per W-lane group, hull vertices in the
+//                    group's registers, support = per-lane dots + xor-butterfly arg-max (fp32 / fp64
+//                    entry points with their own register budgets)
+//   k_gjk_large<T>   GJK when a hull has more than 32 vertices: 16-lane groups scan the vertices from memory
+//   k_epa<T,WE,CAP,TIER>  EPA on the pairs GJK left in `Collision`: one polytope per WE-lane group in LDS;
+//                    tier 1 = 8 polytopes per wave in small blocks, tier 2 = full capacity (overflow of
+//                    tier 1 and every pair with a large hull)
+//   k_bvh_collide<T> / k_bvh_distance<T>   BVHModel<OBBRSS> x BVHModel<OBBRSS>: one mesh pair per lane,
+//                    explicit DFS stack in LDS (reference order), OBB SAT / RSS bounds, triangle-triangle leaves
+//   k_bvh_shape<T> / k_bvh_shape_distance<T>   BVHModel<OBBRSS> x convex solid or Plane/Halfspace: one query
+//                    per 16-lane group, sequential traversal, leaves = TriangleP-vs-solid GJK + EPA in LDS
+//   k_unsupported<T> flags the pairs of a bucket the engine cannot evaluate (never computed elsewhere)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
