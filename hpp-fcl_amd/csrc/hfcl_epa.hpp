@@ -49,14 +49,18 @@ HFCL_HD PW0<T> psel(bool c, const PW0<T>& a, const PW0<T>& b) {
 // Scratch layout (SoA), sized for CAP iterations: CAP+4 vertices, 2*CAP+4 faces (gjk.cpp:1020-1021).
 // CAP = 64 is the reference capacity; the fast kernel uses a smaller CAP (several polytopes per
 // wave fit in LDS) and hands polytopes that outgrow it to the full-capacity kernel.
+template <typename T>
+struct alignas(4 * sizeof(T) > 16 ? 16 : 4 * sizeof(T)) Quad {  // one LDS vector load/store per record
+  T x, y, z, w;
+};
 template <typename T, int CAP>
 struct EpaScratch {
   static constexpr int NV = CAP + 4;
   static constexpr int NF = 2 * CAP + 4;
-  T vw[3][NV];   // vertex w
-  T v0[3][NV];   // vertex w0
-  T fn[3][NF];   // face normal
-  T fd[NF];      // face distance
+  Quad<T> vw[NV];   // vertex w (xyz)
+  Quad<T> v0[NV];   // vertex w0 (xyz)
+  Quad<T> fn[NF];   // face normal (xyz) and distance (w)
+  uint32_t top;     // stock top while faces are being released by several lanes
   uint16_t fstamp[NF];
   uint16_t stack[NF];  // silhouette-walk frames: face | edge<<8 | stage<<10
   uint16_t hz[NF];     // horizon edges in walk order: kept face | its edge<<8
@@ -75,6 +79,7 @@ struct SerialGroup {
   static HFCL_HD int lane() { return 0; }
   template <class X> static HFCL_HD X shfl_xor(X v, int) { return v; }
   static HFCL_HD void sync() {}
+  static HFCL_HD uint32_t atomic_inc(uint32_t* p) { return (*p)++; }
 };
 
 template <typename T>
@@ -99,14 +104,25 @@ struct Epa {
   int hull_count;
   int stock_top;
   int stamp;
+  int pending_release;  // pass mark of faces still to be released by the next find_closest_face(), or -1
 
-  HFCL_HD V3<T> vw(int i) const { return mk<T>(m->vw[0][i], m->vw[1][i], m->vw[2][i]); }
-  HFCL_HD V3<T> v0(int i) const { return mk<T>(m->v0[0][i], m->v0[1][i], m->v0[2][i]); }
-  HFCL_HD void set_vert(int i, const V3<T>& w, const V3<T>& w0) {
-    m->vw[0][i] = w.x; m->vw[1][i] = w.y; m->vw[2][i] = w.z;
-    m->v0[0][i] = w0.x; m->v0[1][i] = w0.y; m->v0[2][i] = w0.z;
+  HFCL_HD V3<T> vw(int i) const {
+    const Quad<T> q = m->vw[i];
+    return mk<T>(q.x, q.y, q.z);
   }
-  HFCL_HD V3<T> fn(int f) const { return mk<T>(m->fn[0][f], m->fn[1][f], m->fn[2][f]); }
+  HFCL_HD V3<T> v0(int i) const {
+    const Quad<T> q = m->v0[i];
+    return mk<T>(q.x, q.y, q.z);
+  }
+  HFCL_HD void set_vert(int i, const V3<T>& w, const V3<T>& w0) {
+    m->vw[i] = Quad<T>{w.x, w.y, w.z, T(0)};
+    m->v0[i] = Quad<T>{w0.x, w0.y, w0.z, T(0)};
+  }
+  HFCL_HD V3<T> fn(int f) const {
+    const Quad<T> q = m->fn[f];
+    return mk<T>(q.x, q.y, q.z);
+  }
+  HFCL_HD T fd(int f) const { return m->fn[f].w; }
   HFCL_HD int adj_edge(int f, int e) const { return m->fadje[e][f]; }
   HFCL_HD void bind(int fa, int ea, int fb, int eb) {  // gjk.h:312-320
     m->fadje[ea][fa] = uint8_t(eb);
@@ -130,6 +146,7 @@ struct Epa {
     num_vertices = 0;
     hull_count = 0;
     stamp = 0;
+    pending_release = -1;
     const int nf = 2 * cap_iterations + 4;
     // face 0 on top of the stock, as in the reference (stock filled in reverse order)
     for (int i = Grp::lane(); i < nf; i += Grp::W) {
@@ -147,6 +164,7 @@ struct Epa {
     V3<T> n = cross(b - a, c - a);
     int fail = 0;
     int flag = 1;
+    T dist = T(0);
     if (norm(n) > Lim<T>::eps()) {
       n = normalized(n);
       const T a_dot_nab = dot(a, cross(b - a, n));
@@ -159,12 +177,12 @@ struct Epa {
         d = Lim<T>::max();
         flag = 3;  // in hull + ignore
       }
-      m->fd[f] = d;
+      dist = d;
       if (!(d >= -tolerance || force)) fail = EPA_NON_CONVEX;
     } else {
       fail = EPA_DEGENERATED;
     }
-    m->fn[0][f] = n.x; m->fn[1][f] = n.y; m->fn[2][f] = n.z;
+    m->fn[f] = Quad<T>{n.x, n.y, n.z, dist};
     m->fflag[f] = uint8_t(flag);
     m->fpass[f] = 0;
     m->fvid[0][f] = uint8_t(ia);
@@ -192,7 +210,13 @@ struct Epa {
 
   // findClosestFace :1141-1154: min d^2 over non-ignored hull faces, first in list order
   // (= largest append stamp) on ties; if every face is ignored: the list head.
+  // The same scan also releases the faces the last expansion made obsolete (pending_release = their pass
+  // mark): they go back to the stock through a group-shared counter, in no particular order (slot
+  // numbers never influence a result, ties are decided by the stamps).
   HFCL_HD int find_closest_face() {
+    const int rel = pending_release;
+    pending_release = -1;
+    if (rel >= 0 && Grp::lane() == 0) m->top = uint32_t(stock_top);
     Grp::sync();
     const int nf = 2 * cap_iterations + 4;
     T best = Lim<T>::max();
@@ -201,13 +225,18 @@ struct Epa {
     for (int f = Grp::lane(); f < nf; f += Grp::W) {
       const int fl = m->fflag[f];
       if (!(fl & 1)) continue;
+      if (rel >= 0 && m->fpass[f] == rel) {
+        m->fflag[f] = 0;
+        m->stock[Grp::atomic_inc(&m->top)] = uint8_t(f);
+        continue;
+      }
       const int st = m->fstamp[f];
       if (st > head_stamp) {
         head_stamp = st;
         head_f = f;
       }
       if (fl & 2) continue;
-      const T d = m->fd[f];
+      const T d = fd(f);
       const T sq = d * d;
       if (sq < best || (sq == best && st > best_stamp && best_f != EPA_NULL)) {
         best = sq;
@@ -230,7 +259,30 @@ struct Epa {
         head_f = ohf;
       }
     }
+    if (rel >= 0) {
+      Grp::sync();
+      const int new_top = int(m->top);
+      hull_count -= new_top - stock_top;
+      stock_top = new_top;
+    }
     return best_f != EPA_NULL ? best_f : head_f;
+  }
+
+  // Releases the faces marked `pass` right away (needed before the new faces are built only when the
+  // stock holds fewer free faces than the horizon has edges).
+  HFCL_HD void release_visible(int pass) {
+    if (Grp::lane() == 0) m->top = uint32_t(stock_top);
+    Grp::sync();
+    const int nf = 2 * cap_iterations + 4;
+    for (int f = Grp::lane(); f < nf; f += Grp::W)
+      if ((m->fflag[f] & 1) && m->fpass[f] == pass) {
+        m->fflag[f] = 0;
+        m->stock[Grp::atomic_inc(&m->top)] = uint8_t(f);
+      }
+    Grp::sync();
+    const int new_top = int(m->top);
+    hull_count -= new_top - stock_top;
+    stock_top = new_top;
   }
 
   // Silhouette walk = the control flow of expand() (:1361-1449) from (f0, e0) without creating the
@@ -339,28 +391,12 @@ struct Epa {
     }
     const int n_new = stop_kind ? stop_at : hz_count;
     Grp::sync();
-    // 1. visible faces (pass mark, includes `closest`) leave the hull and return to the stock
-    {
-      const int nf = 2 * cap_iterations + 4;
-      int mine = 0;
-      for (int f = Grp::lane(); f < nf; f += Grp::W)
-        if ((m->fflag[f] & 1) && m->fpass[f] == pass) ++mine;
-      int before = 0, total = mine;  // exclusive prefix / total over the group
-      for (int msk = 1; msk < Grp::W; msk <<= 1) {
-        const int o = Grp::shfl_xor(total, msk);
-        if (Grp::lane() & msk) before += o;
-        total += o;
-      }
-      int slot = stock_top + before;
-      for (int f = Grp::lane(); f < nf; f += Grp::W)
-        if ((m->fflag[f] & 1) && m->fpass[f] == pass) {
-          m->fflag[f] = 0;
-          m->stock[slot++] = uint8_t(f);
-        }
-      stock_top += total;
-      hull_count -= total;
-    }
-    Grp::sync();
+    // 1. the visible faces (pass mark, includes `closest`) leave the hull: normally during the next
+    //    closest-face scan; right away only if the stock is too short for the new faces
+    if (stock_top < n_new)
+      release_visible(pass);
+    else
+      pending_release = pass;
     // 2. the new faces, one per horizon edge, lanes in parallel; k-th face takes the k-th slot
     //    from the top of the stock and the k-th stamp
     int first_fail = n_new, fail_code = 0;
@@ -509,7 +545,7 @@ struct Epa {
         bind(t2, 2, t3, 1);
         int closest = find_closest_face();
         V3<T> outer_n = fn(closest);
-        T outer_d = m->fd[closest];
+        T outer_d = fd(closest);
         int o0 = m->fvid[0][closest], o1 = m->fvid[1][closest], o2 = m->fvid[2][closest];
         status = EPA_VALID;
         int iterations = 0;
@@ -546,7 +582,7 @@ struct Epa {
           if (!expand_iteration(pass, closest, iw)) break;
           closest = find_closest_face();
           outer_n = fn(closest);
-          outer_d = m->fd[closest];
+          outer_d = fd(closest);
           o0 = m->fvid[0][closest];
           o1 = m->fvid[1][closest];
           o2 = m->fvid[2][closest];

@@ -548,6 +548,7 @@ struct LaneGroup {
   static __device__ __forceinline__ int lane() { return threadIdx.x & (W_ - 1); }
   template <class X> static __device__ __forceinline__ X shfl_xor(X v, int m) { return __shfl_xor(v, m, W_); }
   static __device__ __forceinline__ void sync() { __builtin_amdgcn_wave_barrier(); }
+  static __device__ __forceinline__ uint32_t atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }  // LDS (ds_add_rtn)
 };
 
 #ifndef HFCL_EPA_FAST_CAP
