@@ -49,6 +49,21 @@ HFCL_HD PW0<T> psel(bool c, const PW0<T>& a, const PW0<T>& b) {
 // Scratch layout (SoA), sized for CAP iterations: CAP+4 vertices, 2*CAP+4 faces (gjk.cpp:1020-1021).
 // CAP = 64 is the reference capacity; the fast kernel uses a smaller CAP (several polytopes per
 // wave fit in LDS) and hands polytopes that outgrow it to the full-capacity kernel.
+// Per-face connectivity, read with one 16-byte LDS access; single fields are updated with byte stores
+// (two lanes may bind different edges of the same kept face concurrently, so no read-modify-write).
+struct alignas(16) FaceTopo {
+  uint32_t vf;     // vertex ids of the 3 corners (bytes 0-2), flags (byte 3: bit0 in hull, bit1 ignore)
+  uint32_t ap;     // neighbour face across edge 0..2 (bytes 0-2), pass mark (byte 3)
+  uint32_t ae;     // edge index on the neighbour's side for edge 0..2 (bytes 0-2)
+  uint32_t stamp;  // append order (the reference's hull list position)
+  HFCL_HD int vid(int e) const { return int((vf >> (8 * e)) & 255u); }
+  HFCL_HD int flag() const { return int(vf >> 24); }
+  HFCL_HD int adj(int e) const { return int((ap >> (8 * e)) & 255u); }
+  HFCL_HD int pass() const { return int(ap >> 24); }
+  HFCL_HD int adje(int e) const { return int((ae >> (8 * e)) & 255u); }
+};
+HFCL_HD uint8_t* topo_bytes(FaceTopo& t, int word) { return reinterpret_cast<uint8_t*>(&t) + 4 * word; }
+
 template <typename T>
 struct alignas(4 * sizeof(T) > 16 ? 16 : 4 * sizeof(T)) Quad {  // one LDS vector load/store per record
   T x, y, z, w;
@@ -60,15 +75,10 @@ struct EpaScratch {
   Quad<T> vw[NV];   // vertex w (xyz)
   Quad<T> v0[NV];   // vertex w0 (xyz)
   Quad<T> fn[NF];   // face normal (xyz) and distance (w)
+  FaceTopo ft[NF];  // connectivity + flags + stamp of a face, one 16-byte record
   uint32_t top;     // stock top while faces are being released by several lanes
-  uint16_t fstamp[NF];
   uint16_t stack[NF];  // silhouette-walk frames: face | edge<<8 | stage<<10
   uint16_t hz[NF];     // horizon edges in walk order: kept face | its edge<<8
-  uint8_t fvid[3][NF];
-  uint8_t fadj[3][NF];
-  uint8_t fadje[3][NF];  // edge index on the neighbour's side
-  uint8_t fflag[NF];   // bit0 in hull, bit1 ignore
-  uint8_t fpass[NF];
   uint8_t stock[NF];   // free-face stack
 };
 
@@ -123,15 +133,18 @@ struct Epa {
     return mk<T>(q.x, q.y, q.z);
   }
   HFCL_HD T fd(int f) const { return m->fn[f].w; }
-  HFCL_HD int adj_edge(int f, int e) const { return m->fadje[e][f]; }
+  HFCL_HD void set_adj(int f, int e, int nb, int nb_edge) {
+    topo_bytes(m->ft[f], 1)[e] = uint8_t(nb);
+    topo_bytes(m->ft[f], 2)[e] = uint8_t(nb_edge);
+  }
+  HFCL_HD void set_flag(int f, int v) { topo_bytes(m->ft[f], 0)[3] = uint8_t(v); }
+  HFCL_HD void set_pass(int f, int v) { topo_bytes(m->ft[f], 1)[3] = uint8_t(v); }
   HFCL_HD void bind(int fa, int ea, int fb, int eb) {  // gjk.h:312-320
-    m->fadje[ea][fa] = uint8_t(eb);
-    m->fadj[ea][fa] = uint8_t(fb);
-    m->fadje[eb][fb] = uint8_t(ea);
-    m->fadj[eb][fb] = uint8_t(fa);
+    set_adj(fa, ea, fb, eb);
+    set_adj(fb, eb, fa, ea);
   }
   HFCL_HD void hull_remove(int f) {
-    m->fflag[f] &= uint8_t(~1);
+    set_flag(f, m->ft[f].flag() & ~1);
     --hull_count;
     m->stock[stock_top++] = uint8_t(f);
   }
@@ -151,7 +164,7 @@ struct Epa {
     // face 0 on top of the stock, as in the reference (stock filled in reverse order)
     for (int i = Grp::lane(); i < nf; i += Grp::W) {
       m->stock[i] = uint8_t(nf - 1 - i);
-      m->fflag[i] = 0;
+      set_flag(i, 0);
     }
     stock_top = nf;
     Grp::sync();
@@ -183,11 +196,9 @@ struct Epa {
       fail = EPA_DEGENERATED;
     }
     m->fn[f] = Quad<T>{n.x, n.y, n.z, dist};
-    m->fflag[f] = uint8_t(flag);
-    m->fpass[f] = 0;
-    m->fvid[0][f] = uint8_t(ia);
-    m->fvid[1][f] = uint8_t(ib);
-    m->fvid[2][f] = uint8_t(ic);
+    // corners + flags in one word; the pass mark is cleared; adjacency bytes are written by the binds
+    m->ft[f].vf = uint32_t(ia) | (uint32_t(ib) << 8) | (uint32_t(ic) << 16) | (uint32_t(flag) << 24);
+    set_pass(f, 0);
     return fail;
   }
 
@@ -200,7 +211,7 @@ struct Epa {
     }
     const int f = m->stock[--stock_top];
     ++hull_count;
-    m->fstamp[f] = uint16_t(stamp++);
+    m->ft[f].stamp = uint32_t(stamp++);
     const int fail = face_geometry(f, ia, ib, ic, force);
     if (!fail) return f;
     status = fail;
@@ -223,14 +234,15 @@ struct Epa {
     int best_stamp = -1, best_f = EPA_NULL;
     int head_stamp = -1, head_f = EPA_NULL;
     for (int f = Grp::lane(); f < nf; f += Grp::W) {
-      const int fl = m->fflag[f];
+      const FaceTopo t = m->ft[f];
+      const int fl = t.flag();
       if (!(fl & 1)) continue;
-      if (rel >= 0 && m->fpass[f] == rel) {
-        m->fflag[f] = 0;
+      if (rel >= 0 && t.pass() == rel) {
+        set_flag(f, 0);
         m->stock[Grp::atomic_inc(&m->top)] = uint8_t(f);
         continue;
       }
-      const int st = m->fstamp[f];
+      const int st = int(t.stamp);
       if (st > head_stamp) {
         head_stamp = st;
         head_f = f;
@@ -275,8 +287,8 @@ struct Epa {
     Grp::sync();
     const int nf = 2 * cap_iterations + 4;
     for (int f = Grp::lane(); f < nf; f += Grp::W)
-      if ((m->fflag[f] & 1) && m->fpass[f] == pass) {
-        m->fflag[f] = 0;
+      if ((m->ft[f].flag() & 1) && m->ft[f].pass() == pass) {
+        set_flag(f, 0);
         m->stock[Grp::atomic_inc(&m->top)] = uint8_t(f);
       }
     Grp::sync();
@@ -299,13 +311,14 @@ struct Epa {
       const unsigned fr = m->stack[sp - 1];
       const int f = fr & 255, e = (fr >> 8) & 3, stage = (fr >> 10) & 3;
       const int e1 = (e + 1) % 3, e2 = (e + 2) % 3;
+      const FaceTopo t = m->ft[f];
       if (stage == 0) {
-        if (m->fpass[f] == pass) {
+        if (t.pass() == pass) {
           stop_kind = EPA_INVALID_HULL;
           stop_at = hz_count;
           return;
         }
-        if (dot(fn(f), ww - vw(m->fvid[e][f])) < dummy_precision) {
+        if (dot(fn(f), ww - vw(t.vid(e))) < dummy_precision) {
           // case 1: the support point is "below" f: horizon edge, new face (f[e1], f[e], w)
           if (level == 0) {
             stop_kind = EPA_OUT_OF_FACES;
@@ -318,12 +331,12 @@ struct Epa {
           continue;
         }
         // case 2: above f
-        m->fpass[f] = uint8_t(pass);
+        set_pass(f, pass);
         m->stack[sp - 1] = uint16_t(f | (e << 8) | (1 << 10));
-        m->stack[sp++] = uint16_t(m->fadj[e1][f] | (adj_edge(f, e1) << 8));
+        m->stack[sp++] = uint16_t(t.adj(e1) | (t.adje(e1) << 8));
       } else if (stage == 1) {
         m->stack[sp - 1] = uint16_t(f | (e << 8) | (2 << 10));
-        m->stack[sp++] = uint16_t(m->fadj[e2][f] | (adj_edge(f, e2) << 8));
+        m->stack[sp++] = uint16_t(t.adj(e2) | (t.adje(e2) << 8));
       } else {
         ++level;  // the reference returns f to the stock here
         --sp;
@@ -338,25 +351,27 @@ struct Epa {
   HFCL_HD void silhouette_walk_fast(int pass, int closest, T dummy_precision, const V3<T>& ww, int& hz_count,
                                     int& stop_kind, int& stop_at) {
     int sp = 0;
-    m->stack[sp++] = uint16_t(m->fadj[2][closest] | (adj_edge(closest, 2) << 8));
-    m->stack[sp++] = uint16_t(m->fadj[1][closest] | (adj_edge(closest, 1) << 8));
-    m->stack[sp++] = uint16_t(m->fadj[0][closest] | (adj_edge(closest, 0) << 8));
+    const FaceTopo tc = m->ft[closest];
+    m->stack[sp++] = uint16_t(tc.adj(2) | (tc.adje(2) << 8));
+    m->stack[sp++] = uint16_t(tc.adj(1) | (tc.adje(1) << 8));
+    m->stack[sp++] = uint16_t(tc.adj(0) | (tc.adje(0) << 8));
     while (sp > 0) {
       const unsigned fr = m->stack[--sp];
       const int f = fr & 255, e = (fr >> 8) & 3;
-      if (m->fpass[f] == pass) {
+      const FaceTopo t = m->ft[f];
+      if (t.pass() == pass) {
         stop_kind = EPA_INVALID_HULL;
         stop_at = hz_count;
         return;
       }
-      if (dot(fn(f), ww - vw(m->fvid[e][f])) < dummy_precision) {
+      if (dot(fn(f), ww - vw(t.vid(e))) < dummy_precision) {
         m->hz[hz_count++] = uint16_t(fr);
         continue;
       }
-      m->fpass[f] = uint8_t(pass);
+      set_pass(f, pass);
       const int e1 = (e + 1) % 3, e2 = (e + 2) % 3;
-      m->stack[sp++] = uint16_t(m->fadj[e2][f] | (adj_edge(f, e2) << 8));
-      m->stack[sp++] = uint16_t(m->fadj[e1][f] | (adj_edge(f, e1) << 8));
+      m->stack[sp++] = uint16_t(t.adj(e2) | (t.adje(e2) << 8));
+      m->stack[sp++] = uint16_t(t.adj(e1) | (t.adje(e1) << 8));
     }
   }
 
@@ -380,14 +395,14 @@ struct Epa {
       const int nf = 2 * cap_iterations + 4;
       Grp::sync();
       for (int f = Grp::lane(); f < nf; f += Grp::W)
-        if ((m->fflag[f] & 1) && m->fpass[f] == pass && f != closest) m->fpass[f] = 0;
+        if ((m->ft[f].flag() & 1) && m->ft[f].pass() == pass && f != closest) set_pass(f, 0);
       Grp::sync();
       hz_count = 0;
       stop_kind = 0;
       stop_at = 0;
       int level = stock_top;
       for (int j = 0; j < 3 && !stop_kind; ++j)
-        silhouette_walk(pass, m->fadj[j][closest], adj_edge(closest, j), dummy_precision, ww, hz_count, level, stop_kind, stop_at);
+        silhouette_walk(pass, m->ft[closest].adj(j), m->ft[closest].adje(j), dummy_precision, ww, hz_count, level, stop_kind, stop_at);
     }
     const int n_new = stop_kind ? stop_at : hz_count;
     Grp::sync();
@@ -406,17 +421,14 @@ struct Epa {
       const int nfc = m->stock[stock_top - 1 - k];
       const int kp = (k == 0) ? n_new - 1 : k - 1;  // previous face on the horizon loop
       const int pf = m->stock[stock_top - 1 - kp];
-      m->fstamp[nfc] = uint16_t(stamp + k);
-      const int fail = face_geometry(nfc, m->fvid[e1][f], m->fvid[e][f], id_w, false);
+      const uint32_t fv = m->ft[f].vf;
+      m->ft[nfc].stamp = uint32_t(stamp + k);
+      const int fail = face_geometry(nfc, int((fv >> (8 * e1)) & 255u), int((fv >> (8 * e)) & 255u), id_w, false);
       // bind(nf, 0, f, e); bind(nf, 2, previous, 1)  (:1421-1425, closing bind :1273)
-      m->fadj[0][nfc] = uint8_t(f);
-      m->fadje[0][nfc] = uint8_t(e);
-      m->fadj[e][f] = uint8_t(nfc);
-      m->fadje[e][f] = 0;
-      m->fadj[2][nfc] = uint8_t(pf);
-      m->fadje[2][nfc] = 1;
-      m->fadj[1][pf] = uint8_t(nfc);
-      m->fadje[1][pf] = 2;
+      set_adj(nfc, 0, f, e);
+      set_adj(f, e, nfc, 0);
+      set_adj(nfc, 2, pf, 1);
+      set_adj(pf, 1, nfc, 2);
       if (fail && k < first_fail) {
         first_fail = k;
         fail_code = fail;
@@ -546,7 +558,7 @@ struct Epa {
         int closest = find_closest_face();
         V3<T> outer_n = fn(closest);
         T outer_d = fd(closest);
-        int o0 = m->fvid[0][closest], o1 = m->fvid[1][closest], o2 = m->fvid[2][closest];
+        int o0 = m->ft[closest].vid(0), o1 = m->ft[closest].vid(1), o2 = m->ft[closest].vid(2);
         status = EPA_VALID;
         int iterations = 0;
         int pass = 0;
@@ -560,14 +572,15 @@ struct Epa {
             break;
           }
           const int iw = num_vertices++;
-          m->fpass[closest] = uint8_t(++pass);
+          set_pass(closest, ++pass);
           const V3<T> cn = fn(closest);
           V3<T> w, w0;
           sup(cn, w, w0);
           Grp::sync();
           set_vert(iw, w, w0);
           Grp::sync();
-          const V3<T> vf1 = vw(m->fvid[0][closest]), vf2 = vw(m->fvid[1][closest]), vf3 = vw(m->fvid[2][closest]);
+          const FaceTopo tcl = m->ft[closest];
+          const V3<T> vf1 = vw(tcl.vid(0)), vf2 = vw(tcl.vid(1)), vf3 = vw(tcl.vid(2));
           const T fdist = dot(cn, w - vf1);
           const T wnorm = norm(w);
           const T thr = tolerance + tolerance * wnorm;
@@ -583,9 +596,9 @@ struct Epa {
           closest = find_closest_face();
           outer_n = fn(closest);
           outer_d = fd(closest);
-          o0 = m->fvid[0][closest];
-          o1 = m->fvid[1][closest];
-          o2 = m->fvid[2][closest];
+          o0 = m->ft[closest].vid(0);
+          o1 = m->ft[closest].vid(1);
+          o2 = m->ft[closest].vid(2);
         }
         status = (iterations < max_iterations) ? status : EPA_FAILED;
         out.status = status;
