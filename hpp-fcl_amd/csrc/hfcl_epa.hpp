@@ -68,6 +68,12 @@ template <typename T>
 struct alignas(4 * sizeof(T) > 16 ? 16 : 4 * sizeof(T)) Quad {  // one LDS vector load/store per record
   T x, y, z, w;
 };
+// What has to travel with a polytope that outgrew its small scratch block so that the full-capacity
+// tier can continue it instead of starting over (the first CAP iterations are the reference's in
+// either tier, so continuing is bit-identical to restarting).
+struct EpaHeader {
+  int32_t closest, iterations, pass, status, num_vertices, hull_count, stock_top, stamp;
+};
 template <typename T, int CAP>
 struct EpaScratch {
   static constexpr int NV = CAP + 4;
@@ -76,6 +82,7 @@ struct EpaScratch {
   Quad<T> v0[NV];   // vertex w0 (xyz)
   Quad<T> fn[NF];   // face normal (xyz) and distance (w)
   FaceTopo ft[NF];  // connectivity + flags + stamp of a face, one 16-byte record
+  EpaHeader hdr;    // loop state of a polytope that is handed over to the full-capacity tier
   uint32_t top;     // stock top while faces are being released by several lanes
   uint16_t stack[NF];  // silhouette-walk frames: face | edge<<8 | stage<<10
   uint16_t hz[NF];     // horizon edges in walk order: kept face | its edge<<8
@@ -109,6 +116,7 @@ struct Epa {
   int max_iterations;  // the request's (reference) limit
   int cap_iterations;  // min(max_iterations, CAP): what this scratch block can hold
   bool overflow;       // the polytope outgrew CAP although the reference's capacity would not be exhausted
+  bool resumable;      // ... at an iteration boundary: the scratch block (incl. its hdr) describes it completely
   int status;
   int num_vertices;
   int hull_count;
@@ -155,6 +163,7 @@ struct Epa {
     max_iterations = max_it;
     cap_iterations = max_it < CAP ? max_it : CAP;
     overflow = false;
+    resumable = false;
     status = EPA_DID_NOT_RUN;
     num_vertices = 0;
     hull_count = 0;
@@ -394,6 +403,9 @@ struct Epa {
       // the stock level tracked (rare: only near the capacity of the face store).
       const int nf = 2 * cap_iterations + 4;
       Grp::sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
       for (int f = Grp::lane(); f < nf; f += Grp::W)
         if ((m->ft[f].flag() & 1) && m->ft[f].pass() == pass && f != closest) set_pass(f, 0);
       Grp::sync();
@@ -403,6 +415,21 @@ struct Epa {
       int level = stock_top;
       for (int j = 0; j < 3 && !stop_kind; ++j)
         silhouette_walk(pass, m->ft[closest].adj(j), m->ft[closest].adje(j), dummy_precision, ww, hz_count, level, stop_kind, stop_at);
+      if (stop_kind == EPA_OUT_OF_FACES && cap_iterations < max_iterations) {
+        // A block smaller than the reference's face store ran out where the reference still has faces.
+        // Nothing but pass marks was touched so far; with them undone the polytope is exactly as at the
+        // start of this iteration and the full-capacity tier can redo the iteration from there.
+        Grp::sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+        for (int f = Grp::lane(); f < nf; f += Grp::W)
+          if ((m->ft[f].flag() & 1) && m->ft[f].pass() == pass) set_pass(f, 0);
+        Grp::sync();
+        overflow = true;
+        resumable = true;
+        return false;
+      }
     }
     const int n_new = stop_kind ? stop_at : hz_count;
     Grp::sync();
@@ -451,7 +478,6 @@ struct Epa {
     }
     if (stop_kind) {
       status = stop_kind;
-      if (stop_kind == EPA_OUT_OF_FACES && cap_iterations < max_iterations) overflow = true;
       return false;
     }
     return hz_count >= 3;
@@ -555,17 +581,40 @@ struct Epa {
         bind(t1, 1, t3, 2);
         bind(t1, 2, t2, 1);
         bind(t2, 2, t3, 1);
-        int closest = find_closest_face();
+        const int closest0 = find_closest_face();
+        status = EPA_VALID;
+        run_loop(closest0, 0, 0, ssr_sum, sup, out);
+        return;
+      }
+    }
+    // FallBack :1299-1315
+    status = EPA_FALLBACK;
+    out.status = status;
+    V3<T> n = -guess;
+    const T nl = norm(n);
+    out.normal = (nl > T(0)) ? (n / nl) : mk<T>(T(1), T(0), T(0));
+    out.depth = T(0);
+    out.rw0_ = out.rw1_ = out.rw2_ = vw(0);
+    out.r00 = out.r01 = out.r02 = v0(0);
+  }
+
+  // The expansion loop of evaluate() (:1231-1296), entered at iteration `iterations` with `closest` the
+  // current best face: from evaluate() (iteration 0) or for a polytope handed over by a smaller tier.
+  template <class Sup>
+  HFCL_HD void run_loop(int closest, int iterations, int pass, T ssr_sum, Sup& sup, EpaResult<T>& out) {
+    {
+      {
         V3<T> outer_n = fn(closest);
         T outer_d = fd(closest);
         int o0 = m->ft[closest].vid(0), o1 = m->ft[closest].vid(1), o2 = m->ft[closest].vid(2);
-        status = EPA_VALID;
-        int iterations = 0;
-        int pass = 0;
         for (; iterations < max_iterations; ++iterations) {
           if (iterations >= cap_iterations && cap_iterations < max_iterations) {
-            overflow = true;  // capacity of this scratch block reached before the reference's limit
-            break;
+            // capacity of this scratch block reached before the reference's limit: hand over
+            overflow = true;
+            resumable = true;
+            if (Grp::lane() == 0) m->hdr = EpaHeader{closest, iterations, pass, status, num_vertices, hull_count, stock_top, stamp};
+            Grp::sync();
+            return;
           }
           if (num_vertices >= max_iterations + 4) {
             status = EPA_OUT_OF_VERTICES;
@@ -592,7 +641,16 @@ struct Epa {
             status = EPA_ACCURACY_REACHED;
             break;
           }
-          if (!expand_iteration(pass, closest, iw)) break;
+          if (!expand_iteration(pass, closest, iw)) {
+            if (resumable) {  // hand over as of the start of this iteration (vertex iw is recomputed there)
+              --num_vertices;
+              --pass;
+              if (Grp::lane() == 0) m->hdr = EpaHeader{closest, iterations, pass, status, num_vertices, hull_count, stock_top, stamp};
+              Grp::sync();
+              return;
+            }
+            break;
+          }
           closest = find_closest_face();
           outer_n = fn(closest);
           outer_d = fd(closest);
@@ -610,17 +668,57 @@ struct Epa {
         return;
       }
     }
-    // FallBack :1299-1315
-    status = EPA_FALLBACK;
-    out.status = status;
-    V3<T> n = -guess;
-    const T nl = norm(n);
-    out.normal = (nl > T(0)) ? (n / nl) : mk<T>(T(1), T(0), T(0));
-    out.depth = T(0);
-    out.rw0_ = out.rw1_ = out.rw2_ = vw(0);
-    out.r00 = out.r01 = out.r02 = v0(0);
+  }
+
+  // Continue a polytope saved by a tier with capacity CAP_SRC in this (already reset()) block: vertices and
+  // faces keep their indices, the extra faces of the larger block join the stock.
+  template <int CAP_SRC>
+  HFCL_HD EpaHeader load(const EpaScratch<T, CAP_SRC>* src) {
+    typedef EpaScratch<T, CAP_SRC> Src;
+    const EpaHeader h = src->hdr;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int i = Grp::lane(); i < Src::NV; i += Grp::W) {
+      m->vw[i] = src->vw[i];
+      m->v0[i] = src->v0[i];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int f = Grp::lane(); f < Src::NF; f += Grp::W) {
+      m->fn[f] = src->fn[f];
+      m->ft[f] = src->ft[f];
+    }
+    const int extra = (2 * cap_iterations + 4) - Src::NF;
+    for (int i = Grp::lane(); i < h.stock_top; i += Grp::W) m->stock[i] = src->stock[i];
+    for (int i = Grp::lane(); i < extra; i += Grp::W) m->stock[h.stock_top + i] = uint8_t(Src::NF + i);
+    status = h.status;
+    num_vertices = h.num_vertices;
+    hull_count = h.hull_count;
+    stock_top = h.stock_top + extra;
+    stamp = h.stamp;
+    Grp::sync();
+    return h;
   }
 };
+
+// Group-cooperative copy of a resumable polytope (scratch block incl. its header) to `dst`.
+template <typename T, class Grp, int CAP>
+HFCL_HD void epa_save_block(const EpaScratch<T, CAP>* block, EpaScratch<T, CAP>* dst) {
+  Grp::sync();
+  struct alignas(16) Chunk {
+    uint32_t w[4];
+  };
+  static_assert(sizeof(EpaScratch<T, CAP>) % sizeof(Chunk) == 0 && alignof(EpaScratch<T, CAP>) >= alignof(Chunk), "block is copied in 16-byte chunks");
+  const Chunk* src = reinterpret_cast<const Chunk*>(block);
+  Chunk* d = reinterpret_cast<Chunk*>(dst);
+  // rolled on purpose: this is the rare path and must not cost the expansion loop registers
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int i = Grp::lane(); i < int(sizeof(EpaScratch<T, CAP>) / sizeof(Chunk)); i += Grp::W) d[i] = src[i];
+}
 
 // EPA::getWitnessPointsAndNormal (:1451-1466) + inflate, shape-0 frame
 template <typename T>

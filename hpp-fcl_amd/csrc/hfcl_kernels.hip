@@ -22,6 +22,7 @@
 //   k_unsupported<T> flags the pairs of a bucket the engine cannot evaluate (never computed elsewhere)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -48,6 +49,12 @@ using namespace hfcl;
 #endif
 #ifndef HFCL_WPE_PRIM
 #define HFCL_WPE_PRIM 2
+#endif
+#ifndef HFCL_WPE_EPA32
+#define HFCL_WPE_EPA32 2  // fp32 EPA: the LDS block allows 2 waves/SIMD, keep the registers within that
+#endif
+#ifndef HFCL_WPE_EPA64
+#define HFCL_WPE_EPA64 1
 #endif
 #ifndef HFCL_WPE_BVH
 #define HFCL_WPE_BVH 1
@@ -121,7 +128,10 @@ struct Work {
   uint32_t* counts;  // B_COUNT counters + [B_COUNT] = epa queue length + [B_COUNT+1] = overflow queue length
   void* epa_queue;
   void* epa_queue2;  // polytopes that outgrew the fast EPA kernel's scratch block
+  void* epa_resume;  // saved polytopes (EpaScratch<T, EPA_FAST_CAP>) of the first `resume_cap` slots of epa_queue2
+  uint32_t resume_cap;
 };
+constexpr int32_t EPA_RESUME_FLAG = 0x100;  // EpaSeed::rank bit: "continue the saved polytope of this slot"
 
 __device__ __forceinline__ Pose<double> load_pose(const double* base, uint32_t i) { return pose_from_abi<double>(base + 12 * size_t(i)); }
 __device__ __forceinline__ Pose<float> load_pose(const float* base, uint32_t i) { return pose_from_quat<float>(base + 7 * size_t(i)); }
@@ -547,7 +557,14 @@ struct LaneGroup {
   static constexpr int W = W_;
   static __device__ __forceinline__ int lane() { return threadIdx.x & (W_ - 1); }
   template <class X> static __device__ __forceinline__ X shfl_xor(X v, int m) { return __shfl_xor(v, m, W_); }
-  static __device__ __forceinline__ void sync() { __builtin_amdgcn_wave_barrier(); }
+  // Lanes of a group exchange data through LDS: the wavefront-scope fence keeps the compiler from moving or
+  // reusing LDS accesses across the exchange point (the barrier alone only pins instruction scheduling).
+  static __device__ __forceinline__ void sync() {
+#ifndef HFCL_AB_NO_FENCE
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#endif
+    __builtin_amdgcn_wave_barrier();
+  }
   static __device__ __forceinline__ uint32_t atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }  // LDS (ds_add_rtn)
 };
 
@@ -596,7 +613,8 @@ struct EpaSupport {  // any pair kind, evaluated by one lane group
 
 // TIER: 1 reads queue 1 and may push to queue 2; 2 reads queue 2 (never overflows: CAP = 64)
 template <typename T, int WE, int CAP, int TIER>
-__global__ void __launch_bounds__(64) k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? HFCL_WPE_EPA32 : HFCL_WPE_EPA64, 8)))
+k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   constexpr int G = 64 / WE;
   __shared__ EpaScratch<T, CAP> scratch[G];
   const uint32_t cnt = wk.counts[TIER == 1 ? B_COUNT : B_COUNT + 1];
@@ -622,14 +640,38 @@ __global__ void __launch_bounds__(64) k_epa(Work wk, LibView<T> lib, IO<T> io, Q
     sup.md = make_mdiff(tf1, tf2);
     const T r0 = swept_radius(sup.a), r1 = swept_radius(sup.b);
     PairOut<T> o;
-    const bool done = epa_run<T, LaneGroup<WE>, CAP>(&scratch[grp], item, q, tf1, r0, r1, sup, o);
-    if (lig == 0) {
-      if (done) {
+    int rc = 1;
+    if constexpr (TIER == 2) {
+      if (item.rank & EPA_RESUME_FLAG) {  // continue what the fast tier saved for this slot
+        EpaItem<T> seed = item;
+        seed.rank &= ~EPA_RESUME_FLAG;
+        epa_resume<T, LaneGroup<WE>, EPA_FAST_CAP, CAP>(&scratch[grp], reinterpret_cast<const EpaScratch<T, EPA_FAST_CAP>*>(wk.epa_resume) + it,
+                                                         seed, q, tf1, r0, r1, sup, o);
+      } else {
+        rc = epa_run<T, LaneGroup<WE>, CAP>(&scratch[grp], item, q, tf1, r0, r1, sup, o);
+      }
+      if (lig == 0) {
         write_out<T>(io, q, pair, o);
         write_guess<T>(io, pair, o.cached_guess, 0, 0);
-      } else if (TIER == 1) {
-        const uint32_t slot = atomicAdd(&wk.counts[B_COUNT + 1], 1u);
-        reinterpret_cast<EpaItem<T>*>(wk.epa_queue2)[slot] = item;
+      }
+    } else {
+      rc = epa_run<T, LaneGroup<WE>, CAP>(&scratch[grp], item, q, tf1, r0, r1, sup, o);
+      if (rc == 1) {
+        if (lig == 0) {
+          write_out<T>(io, q, pair, o);
+          write_guess<T>(io, pair, o.cached_guess, 0, 0);
+        }
+      } else {  // hand over to the full-capacity tier: the seed, and the polytope itself when it can be continued
+        uint32_t slot = 0;
+        if (lig == 0) slot = atomicAdd(&wk.counts[B_COUNT + 1], 1u);
+        slot = __shfl(slot, 0, WE);
+        const bool save = rc == 2 && slot < wk.resume_cap;
+        if (save) epa_save_block<T, LaneGroup<WE>, CAP>(&scratch[grp], reinterpret_cast<EpaScratch<T, CAP>*>(wk.epa_resume) + slot);
+        if (lig == 0) {
+          EpaItem<T> item2 = item;
+          if (save) item2.rank |= EPA_RESUME_FLAG;
+          reinterpret_cast<EpaItem<T>*>(wk.epa_queue2)[slot] = item2;
+        }
       }
     }
     LaneGroup<WE>::sync();
@@ -1098,6 +1140,8 @@ struct hfcl_lib {
   uint32_t* d_counts = nullptr;
   void* d_epa_queue = nullptr;
   void* d_epa_queue2 = nullptr;
+  void* d_epa_resume = nullptr;
+  size_t resume_cap = 0;
   // host-call staging buffers
   size_t st_capacity = 0;
   uint32_t *d_s1 = nullptr, *d_s2 = nullptr;
@@ -1293,6 +1337,7 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_lists);
   hipFree(lib->d_epa_queue);
   hipFree(lib->d_epa_queue2);
+  hipFree(lib->d_epa_resume);
   hipFree(lib->d_s1);
   hipFree(lib->d_s2);
   hipFree(lib->d_tf1);
@@ -1366,13 +1411,21 @@ static int ensure_workspace(hfcl_lib* lib, size_t n) {
   hipFree(lib->d_lists);
   hipFree(lib->d_epa_queue);
   hipFree(lib->d_epa_queue2);
+  hipFree(lib->d_epa_resume);
   lib->d_lists = nullptr;
   lib->d_epa_queue = nullptr;
   lib->d_epa_queue2 = nullptr;
+  lib->d_epa_resume = nullptr;
+  lib->resume_cap = 0;
   lib->ws_capacity = 0;
   HIP_TRY(hipMalloc(&lib->d_lists, size_t(B_COUNT) * cap * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&lib->d_epa_queue, cap * sizeof(EpaItem<double>)));
   HIP_TRY(hipMalloc(&lib->d_epa_queue2, cap * sizeof(EpaItem<double>)));
+  // saved polytopes for the tier hand-over: room for a third of the batch (beyond that the full tier
+  // simply redoes the pair from its seed); 4 KB per slot in fp64
+  const size_t rcap = std::min(cap, std::max<size_t>(65536, cap / 3));
+  HIP_TRY(hipMalloc(&lib->d_epa_resume, rcap * sizeof(EpaScratch<double, EPA_FAST_CAP>)));
+  lib->resume_cap = rcap;
   lib->ws_capacity = cap;
   return HFCL_OK;
 }
@@ -1528,6 +1581,8 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   wk.counts = lib->d_counts;
   wk.epa_queue = lib->d_epa_queue;
   wk.epa_queue2 = lib->d_epa_queue2;
+  wk.epa_resume = lib->d_epa_resume;
+  wk.resume_cap = uint32_t(std::min<size_t>(lib->resume_cap, 0xFFFFFFFFu));
   LibView<T> lv;
   lv.shapes = std::is_same<T, double>::value ? (const DShape<T>*)lib->d_shapes64 : (const DShape<T>*)lib->d_shapes32;
   lv.verts = std::is_same<T, double>::value ? (const T*)lib->d_verts64 : (const T*)lib->d_verts32;

@@ -127,12 +127,17 @@ HFCL_HD bool gjk_finish(const Gjk<T, PW0<T>>& g, const QParams<T>& q, const Pose
   return false;
 }
 
-// EPA branch of runGJKAndEPA (narrowphase.h:505-584) for one seed.  Returns false when the
-// polytope outgrew the CAP-sized scratch block (the caller re-queues the seed for the
-// full-capacity kernel; `out` is then meaningless).
+// EPAExtractWitnessPointsAndNormal / EPAFailedExtractWitnessPointsAndNormal (narrowphase.h:658-723)
+template <typename T>
+HFCL_HD void epa_finish(const EpaResult<T>& res, const EpaSeed<T>& seed, const Pose<T>& tf1, T r0, T r1, PairOut<T>& out);
+
+// EPA branch of runGJKAndEPA (narrowphase.h:505-584) for one seed.  Returns 1 when `out` is final; 0 when
+// the polytope outgrew the CAP-sized scratch block and must be redone by the full-capacity kernel; 2 when
+// it outgrew the block at an iteration boundary: the scratch block (incl. its hdr) then describes it
+// completely and the full-capacity kernel can continue it (epa_resume).
 template <typename T, class Grp, int CAP, class Sup>
-HFCL_HD bool epa_run(EpaScratch<T, CAP>* scratch, const EpaSeed<T>& seed, const QParams<T>& q, const Pose<T>& tf1, T r0,
-                     T r1, Sup& sup, PairOut<T>& out) {
+HFCL_HD int epa_run(EpaScratch<T, CAP>* scratch, const EpaSeed<T>& seed, const QParams<T>& q, const Pose<T>& tf1, T r0,
+                    T r1, Sup& sup, PairOut<T>& out) {
   Epa<T, Grp, CAP> epa;
   epa.reset(scratch, q.epa_max_iterations, q.epa_tolerance);
   // all four slots are written (slots >= rank are scratch that encloseOrigin overwrites): constant
@@ -144,7 +149,25 @@ HFCL_HD bool epa_run(EpaScratch<T, CAP>* scratch, const EpaSeed<T>& seed, const 
   Grp::sync();
   EpaResult<T> res;
   epa.evaluate(seed.rank, -seed.guess, r0 + r1, sup, res);
-  if (epa.overflow) return false;
+  if (epa.overflow) return epa.resumable ? 2 : 0;
+  epa_finish(res, seed, tf1, r0, r1, out);
+  return 1;
+}
+
+// Continue a polytope a CAP_SRC-tier saved (blob) in a CAP-sized block.  CAP must be the reference capacity.
+template <typename T, class Grp, int CAP_SRC, int CAP, class Sup>
+HFCL_HD void epa_resume(EpaScratch<T, CAP>* scratch, const EpaScratch<T, CAP_SRC>* blob, const EpaSeed<T>& seed,
+                        const QParams<T>& q, const Pose<T>& tf1, T r0, T r1, Sup& sup, PairOut<T>& out) {
+  Epa<T, Grp, CAP> epa;
+  epa.reset(scratch, q.epa_max_iterations, q.epa_tolerance);
+  const EpaHeader h = epa.template load<CAP_SRC>(blob);
+  EpaResult<T> res;
+  epa.run_loop(h.closest, h.iterations, h.pass, r0 + r1, sup, res);
+  epa_finish(res, seed, tf1, r0, r1, out);
+}
+
+template <typename T>
+HFCL_HD void epa_finish(const EpaResult<T>& res, const EpaSeed<T>& seed, const Pose<T>& tf1, T r0, T r1, PairOut<T>& out) {
   out.gjk_status = GJK_COLLISION;
   out.gjk_iters = int(seed.gjk_iters);
   out.epa_status = res.status;
@@ -154,7 +177,7 @@ HFCL_HD bool epa_run(EpaScratch<T, CAP>* scratch, const EpaSeed<T>& seed, const 
     out.distance = -Lim<T>::max();
     out.normal = out.p1 = out.p2 = mk<T>(nanv, nanv, nanv);
     out.cached_guess = mk<T>(T(1), T(0), T(0));
-    return true;
+    return;
   }
   // EPAExtractWitnessPointsAndNormal :658-711
   out.cached_guess = -(res.depth * res.normal);
@@ -166,7 +189,6 @@ HFCL_HD bool epa_run(EpaScratch<T, CAP>* scratch, const EpaSeed<T>& seed, const 
   out.normal = n;
   out.p1 = p1;
   out.p2 = p2;
-  return true;
 }
 
 // Record semantics on a fresh result object.  Returns the contact flag; for collide() the

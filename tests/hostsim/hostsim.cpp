@@ -68,11 +68,17 @@ static void one_pair(const DShape<T>& a, const DShape<T>& b, const T* verts, con
     gjk_run(g, q.gjk, guess0, r0 + r1, a.kind == K_CONVEX && b.kind == K_CONVEX, sup);
     EpaSeed<T> seed;
     if (gjk_finish(g, q, tf1, r0, r1, guess0, o, seed)) {
-      // same two-tier scheme as the kernels: small-capacity block first, full capacity on overflow
-      static thread_local EpaScratch<T, 24> small;
+      // same two-tier scheme as the kernels: small-capacity block first; on overflow the polytope is saved
+      // and continued in the full-capacity block (or redone there when it is not at an iteration boundary)
+      static thread_local EpaScratch<T, 20> small, saved;
       static thread_local EpaScratch<T, EPA_MAX_ITER> full;
-      if (!epa_run<T, SerialGroup<1>, 24>(&small, seed, q, tf1, r0, r1, sup, o))
+      const int rc = epa_run<T, SerialGroup<1>, 20>(&small, seed, q, tf1, r0, r1, sup, o);
+      if (rc == 2) {
+        epa_save_block<T, SerialGroup<1>, 20>(&small, &saved);
+        epa_resume<T, SerialGroup<1>, 20, EPA_MAX_ITER>(&full, &saved, seed, q, tf1, r0, r1, sup, o);
+      } else if (rc == 0) {
         epa_run<T, SerialGroup<1>, EPA_MAX_ITER>(&full, seed, q, tf1, r0, r1, sup, o);
+      }
     }
   } else {
     skipped = true;
