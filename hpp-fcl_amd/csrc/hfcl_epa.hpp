@@ -21,6 +21,8 @@
 // control flow redundantly (uniform LDS addresses broadcast); face scans, face creation and
 // face removal are split over the lanes.
 #pragma once
+#include <type_traits>
+
 #include "hfcl_gjk.hpp"
 
 namespace hfcl {
@@ -89,12 +91,23 @@ struct EpaScratch {
   uint8_t stock[NF];   // free-face stack
 };
 
+// All-reduce over a lane group: stage M = 1, 2, 4, .. < W hands every lane the value of a partner lane
+// (Grp::exchange<M>) such that after the last stage all lanes have seen all values.  The partner of a
+// stage is a lane of the "other half" at that level, not necessarily lane ^ M: only reductions with a
+// total order (min/max with a unique tie-break) may be built on it.
+template <int W, int M = 1, class F>
+HFCL_HD void butterfly_stages(F&& f) {
+  if constexpr (M < W) {
+    f(std::integral_constant<int, M>());
+    butterfly_stages<W, 2 * M>(f);
+  }
+}
 // Lane-group operations.  W = 1 on the host validation build.
 template <int W_>
 struct SerialGroup {
   static constexpr int W = 1;
   static HFCL_HD int lane() { return 0; }
-  template <class X> static HFCL_HD X shfl_xor(X v, int) { return v; }
+  template <int M, class X> static HFCL_HD X exchange(X v) { return v; }
   static HFCL_HD void sync() {}
   static HFCL_HD uint32_t atomic_inc(uint32_t* p) { return (*p)++; }
 };
@@ -265,10 +278,11 @@ struct Epa {
         best_f = f;
       }
     }
-    for (int msk = 1; msk < Grp::W; msk <<= 1) {
-      const T ob = Grp::shfl_xor(best, msk);
-      const int os = Grp::shfl_xor(best_stamp, msk), of = Grp::shfl_xor(best_f, msk);
-      const int ohs = Grp::shfl_xor(head_stamp, msk), ohf = Grp::shfl_xor(head_f, msk);
+    butterfly_stages<Grp::W>([&](auto stage) {
+      constexpr int M = decltype(stage)::value;
+      const T ob = Grp::template exchange<M>(best);
+      const int os = Grp::template exchange<M>(best_stamp), of = Grp::template exchange<M>(best_f);
+      const int ohs = Grp::template exchange<M>(head_stamp), ohf = Grp::template exchange<M>(head_f);
       const bool take = (of != EPA_NULL) && (best_f == EPA_NULL || ob < best || (ob == best && os > best_stamp));
       if (take) {
         best = ob;
@@ -279,7 +293,7 @@ struct Epa {
         head_stamp = ohs;
         head_f = ohf;
       }
-    }
+    });
     if (rel >= 0) {
       Grp::sync();
       const int new_top = int(m->top);
@@ -461,13 +475,14 @@ struct Epa {
         fail_code = fail;
       }
     }
-    for (int msk = 1; msk < Grp::W; msk <<= 1) {
-      const int ok = Grp::shfl_xor(first_fail, msk), oc = Grp::shfl_xor(fail_code, msk);
+    butterfly_stages<Grp::W>([&](auto stage) {
+      constexpr int M = decltype(stage)::value;
+      const int ok = Grp::template exchange<M>(first_fail), oc = Grp::template exchange<M>(fail_code);
       if (ok < first_fail) {
         first_fail = ok;
         fail_code = oc;
       }
-    }
+    });
     stock_top -= n_new;
     hull_count += n_new;
     stamp += n_new;

@@ -355,6 +355,39 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_W
 // Convex hull held by a W-lane group: lane l owns vertices [l*VPL, (l+1)*VPL).
 // getShapeSupportLinear (support_functions.cpp:400-421): first index of the maximum dot.
 // ---------------------------------------------------------------------------------------
+// Partner value for stage M of an all-reduce over an aligned W-lane group (see butterfly_stages).  Stages
+// within a row of 16 lanes are DPP moves (VALU rate, no LDS-pipe round trip as ds_bpermute has):
+// quad_perm [1,0,3,2] / [2,3,0,1] for M = 1 / 2, row_half_mirror (lane ^ 7) for M = 4, row_mirror
+// (lane ^ 15) for M = 8; wider stages go through __shfl_xor.
+template <int CTRL, class X>
+__device__ __forceinline__ X dpp_move(X v) {
+  static_assert(sizeof(X) % 4 == 0, "32-bit words");
+  int w[sizeof(X) / 4];
+  __builtin_memcpy(w, &v, sizeof(X));
+#pragma unroll
+  for (int i = 0; i < int(sizeof(X) / 4); ++i) w[i] = __builtin_amdgcn_update_dpp(w[i], w[i], CTRL, 0xF, 0xF, false);
+  X r;
+  __builtin_memcpy(&r, w, sizeof(X));
+  return r;
+}
+template <int W, int M, class X>
+__device__ __forceinline__ X group_exchange(X v) {
+  static_assert(M >= 1 && M < W, "stage of a W-lane butterfly");
+  if constexpr (M == 1) return dpp_move<0xB1>(v);
+  else if constexpr (M == 2) return dpp_move<0x4E>(v);
+  else if constexpr (M == 4) return dpp_move<0x141>(v);
+  else if constexpr (M == 8) return dpp_move<0x140>(v);
+  else {
+    int w[sizeof(X) / 4];
+    __builtin_memcpy(w, &v, sizeof(X));
+#pragma unroll
+    for (int i = 0; i < int(sizeof(X) / 4); ++i) w[i] = __shfl_xor(w[i], M, W);
+    X r;
+    __builtin_memcpy(&r, w, sizeof(X));
+    return r;
+  }
+}
+
 constexpr int HULL_MAX = 32;  // ConvexBase::num_vertices_large_convex_threshold (geometric_shapes.h:709)
 constexpr int HULL_LARGE_MAX = 1 << 16;  // hulls above HULL_MAX are scanned from memory (k_gjk_large)
 
@@ -383,15 +416,17 @@ struct HullRegs {
         bi = lig * VPL + k;
       }
     }
-#pragma unroll
-    for (int m = 1; m < W; m <<= 1) {
-      const T od = __shfl_xor(best, m, W);
-      const int oi = __shfl_xor(bi, m, W);
+    butterfly_stages<W>([&](auto stage) {
+      constexpr int M = decltype(stage)::value;
+      const T od = group_exchange<W, M>(best);
+      const int oi = group_exchange<W, M>(bi);
       if (od > best || (od == best && oi < bi)) {
         best = od;
         bi = oi;
       }
-    }
+    });
+    // the winner's coordinates come from a run-time lane (ds_bpermute): carrying them through the stages,
+    // or OR-reducing the owner's bits, costs the GJK kernels registers they do not have (spills; measured)
     const int owner = bi / VPL, slot = bi % VPL;
     V3<T> c = v[0];
 #pragma unroll
@@ -490,15 +525,15 @@ __device__ __forceinline__ V3<T> scan_support(const T* v, uint32_t n, const V3<T
       bi = i;
     }
   }
-#pragma unroll
-  for (int m = 1; m < W; m <<= 1) {
-    const T od = __shfl_xor(best, m, W);
-    const uint32_t oi = __shfl_xor(bi, m, W);
+  butterfly_stages<W>([&](auto stage) {
+    constexpr int M = decltype(stage)::value;
+    const T od = group_exchange<W, M>(best);
+    const uint32_t oi = group_exchange<W, M>(bi);
     if (od > best || (od == best && oi < bi)) {
       best = od;
       bi = oi;
     }
-  }
+  });
   return mk<T>(v[3 * bi], v[3 * bi + 1], v[3 * bi + 2]);
 }
 
@@ -556,7 +591,7 @@ template <int W_>
 struct LaneGroup {
   static constexpr int W = W_;
   static __device__ __forceinline__ int lane() { return threadIdx.x & (W_ - 1); }
-  template <class X> static __device__ __forceinline__ X shfl_xor(X v, int m) { return __shfl_xor(v, m, W_); }
+  template <int M, class X> static __device__ __forceinline__ X exchange(X v) { return group_exchange<W_, M>(v); }
   // Lanes of a group exchange data through LDS: the wavefront-scope fence keeps the compiler from moving or
   // reusing LDS accesses across the exchange point (the barrier alone only pins instruction scheduling).
   static __device__ __forceinline__ void sync() {
