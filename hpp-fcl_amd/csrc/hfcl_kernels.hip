@@ -648,7 +648,7 @@ struct EpaSupport {  // any pair kind, evaluated by one lane group
 
 // TIER: 1 reads queue 1 and may push to queue 2; 2 reads queue 2 (never overflows: CAP = 64)
 template <typename T, int WE, int CAP, int TIER>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? HFCL_WPE_EPA32 : HFCL_WPE_EPA64, 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? (TIER == 1 ? HFCL_WPE_EPA32 : 2) : HFCL_WPE_EPA64, 8)))
 k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   constexpr int G = 64 / WE;
   __shared__ EpaScratch<T, CAP> scratch[G];
