@@ -113,6 +113,14 @@ struct SerialGroup {
 };
 
 template <typename T>
+struct EpaLoop {  // state of the expansion loop between two trips
+  int closest, iterations, pass;
+  V3<T> outer_n;
+  T outer_d;
+  int o0, o1, o2;
+};
+
+template <typename T>
 struct EpaResult {
   int status;
   int iterations;
@@ -573,6 +581,13 @@ struct Epa {
   // reference's order (oldest first).  guess = the vector passed as `guess` to evaluate().
   template <class Sup>
   HFCL_HD void evaluate(int rank, const V3<T>& guess, T ssr_sum, Sup& sup, EpaResult<T>& out) {
+    const int closest0 = begin(rank, guess, sup, out);
+    if (closest0 != EPA_NULL) run_loop(closest0, 0, 0, ssr_sum, sup, out);
+  }
+  // evaluate() up to the loop (:1188-1230): the first closest face, or EPA_NULL when `out` is already
+  // final (FallBack :1299-1315).
+  template <class Sup>
+  HFCL_HD int begin(int rank, const V3<T>& guess, Sup& sup, EpaResult<T>& out) {
     const bool enclosed = enclose_origin(rank, sup);
     out.iterations = 0;
     if (rank > 1 && enclosed) {
@@ -598,8 +613,7 @@ struct Epa {
         bind(t2, 2, t3, 1);
         const int closest0 = find_closest_face();
         status = EPA_VALID;
-        run_loop(closest0, 0, 0, ssr_sum, sup, out);
-        return;
+        return closest0;
       }
     }
     // FallBack :1299-1315
@@ -611,78 +625,96 @@ struct Epa {
     out.depth = T(0);
     out.rw0_ = out.rw1_ = out.rw2_ = vw(0);
     out.r00 = out.r01 = out.r02 = v0(0);
+    return EPA_NULL;
   }
 
-  // The expansion loop of evaluate() (:1231-1296), entered at iteration `iterations` with `closest` the
-  // current best face: from evaluate() (iteration 0) or for a polytope handed over by a smaller tier.
+  // The expansion loop of evaluate() (:1231-1296) as enter / step / result, so that a kernel can interleave
+  // the trips of several polytopes with other work (refilling finished lane groups).  `L` is what the
+  // reference keeps in locals across trips: the current best face and the last valid `outer` face.
+  HFCL_HD void loop_enter(EpaLoop<T>& L, int closest, int iterations, int pass) const {
+    L.closest = closest;
+    L.iterations = iterations;
+    L.pass = pass;
+    L.outer_n = fn(closest);
+    L.outer_d = fd(closest);
+    const FaceTopo t = m->ft[closest];
+    L.o0 = t.vid(0);
+    L.o1 = t.vid(1);
+    L.o2 = t.vid(2);
+  }
+  // One trip.  0: go on; 1: the loop is over, `status` is final; 2: the polytope outgrew this block and
+  // was prepared for hand-over (overflow && resumable, header written).
+  template <class Sup>
+  HFCL_HD int step(EpaLoop<T>& L, Sup& sup) {
+    if (!(L.iterations < max_iterations)) {
+      status = EPA_FAILED;
+      return 1;
+    }
+    if (L.iterations >= cap_iterations && cap_iterations < max_iterations) {
+      // capacity of this scratch block reached before the reference's limit: hand over
+      overflow = true;
+      resumable = true;
+      if (Grp::lane() == 0) m->hdr = EpaHeader{L.closest, L.iterations, L.pass, status, num_vertices, hull_count, stock_top, stamp};
+      Grp::sync();
+      return 2;
+    }
+    if (num_vertices >= max_iterations + 4) {
+      status = EPA_OUT_OF_VERTICES;
+      return 1;
+    }
+    const int closest = L.closest;
+    const int iw = num_vertices++;
+    set_pass(closest, ++L.pass);
+    const V3<T> cn = fn(closest);
+    V3<T> w, w0;
+    sup(cn, w, w0);
+    Grp::sync();
+    set_vert(iw, w, w0);
+    Grp::sync();
+    const FaceTopo tcl = m->ft[closest];
+    const V3<T> vf1 = vw(tcl.vid(0)), vf2 = vw(tcl.vid(1)), vf3 = vw(tcl.vid(2));
+    const T fdist = dot(cn, w - vf1);
+    const T wnorm = norm(w);
+    const T thr = tolerance + tolerance * wnorm;
+    if (fdist <= thr) {
+      status = EPA_ACCURACY_REACHED;
+      return 1;
+    }
+    if (norm(w - vf1) <= thr || norm(w - vf2) <= thr || norm(w - vf3) <= thr) {
+      status = EPA_ACCURACY_REACHED;
+      return 1;
+    }
+    if (!expand_iteration(L.pass, closest, iw)) {
+      if (resumable) {  // hand over as of the start of this iteration (vertex iw is recomputed there)
+        --num_vertices;
+        --L.pass;
+        if (Grp::lane() == 0) m->hdr = EpaHeader{closest, L.iterations, L.pass, status, num_vertices, hull_count, stock_top, stamp};
+        Grp::sync();
+        return 2;
+      }
+      return 1;
+    }
+    loop_enter(L, find_closest_face(), L.iterations + 1, L.pass);
+    return 0;
+  }
+  HFCL_HD void loop_result(const EpaLoop<T>& L, T ssr_sum, EpaResult<T>& out) const {
+    out.status = status;
+    out.iterations = L.iterations;
+    out.normal = L.outer_n;
+    out.depth = L.outer_d + ssr_sum;
+    out.rw0_ = vw(L.o0); out.rw1_ = vw(L.o1); out.rw2_ = vw(L.o2);
+    out.r00 = v0(L.o0); out.r01 = v0(L.o1); out.r02 = v0(L.o2);
+  }
+  // The whole loop from (closest, iterations, pass): evaluate() enters at iteration 0, a polytope handed
+  // over by a smaller tier where it stopped.  Nothing is written to `out` on a hand-over.
   template <class Sup>
   HFCL_HD void run_loop(int closest, int iterations, int pass, T ssr_sum, Sup& sup, EpaResult<T>& out) {
-    {
-      {
-        V3<T> outer_n = fn(closest);
-        T outer_d = fd(closest);
-        int o0 = m->ft[closest].vid(0), o1 = m->ft[closest].vid(1), o2 = m->ft[closest].vid(2);
-        for (; iterations < max_iterations; ++iterations) {
-          if (iterations >= cap_iterations && cap_iterations < max_iterations) {
-            // capacity of this scratch block reached before the reference's limit: hand over
-            overflow = true;
-            resumable = true;
-            if (Grp::lane() == 0) m->hdr = EpaHeader{closest, iterations, pass, status, num_vertices, hull_count, stock_top, stamp};
-            Grp::sync();
-            return;
-          }
-          if (num_vertices >= max_iterations + 4) {
-            status = EPA_OUT_OF_VERTICES;
-            break;
-          }
-          const int iw = num_vertices++;
-          set_pass(closest, ++pass);
-          const V3<T> cn = fn(closest);
-          V3<T> w, w0;
-          sup(cn, w, w0);
-          Grp::sync();
-          set_vert(iw, w, w0);
-          Grp::sync();
-          const FaceTopo tcl = m->ft[closest];
-          const V3<T> vf1 = vw(tcl.vid(0)), vf2 = vw(tcl.vid(1)), vf3 = vw(tcl.vid(2));
-          const T fdist = dot(cn, w - vf1);
-          const T wnorm = norm(w);
-          const T thr = tolerance + tolerance * wnorm;
-          if (fdist <= thr) {
-            status = EPA_ACCURACY_REACHED;
-            break;
-          }
-          if (norm(w - vf1) <= thr || norm(w - vf2) <= thr || norm(w - vf3) <= thr) {
-            status = EPA_ACCURACY_REACHED;
-            break;
-          }
-          if (!expand_iteration(pass, closest, iw)) {
-            if (resumable) {  // hand over as of the start of this iteration (vertex iw is recomputed there)
-              --num_vertices;
-              --pass;
-              if (Grp::lane() == 0) m->hdr = EpaHeader{closest, iterations, pass, status, num_vertices, hull_count, stock_top, stamp};
-              Grp::sync();
-              return;
-            }
-            break;
-          }
-          closest = find_closest_face();
-          outer_n = fn(closest);
-          outer_d = fd(closest);
-          o0 = m->ft[closest].vid(0);
-          o1 = m->ft[closest].vid(1);
-          o2 = m->ft[closest].vid(2);
-        }
-        status = (iterations < max_iterations) ? status : EPA_FAILED;
-        out.status = status;
-        out.iterations = iterations;
-        out.normal = outer_n;
-        out.depth = outer_d + ssr_sum;
-        out.rw0_ = vw(o0); out.rw1_ = vw(o1); out.rw2_ = vw(o2);
-        out.r00 = v0(o0); out.r01 = v0(o1); out.r02 = v0(o2);
-        return;
-      }
+    EpaLoop<T> L;
+    loop_enter(L, closest, iterations, pass);
+    int r;
+    while ((r = step(L, sup)) == 0) {
     }
+    if (r == 1) loop_result(L, ssr_sum, out);
   }
 
   // Continue a polytope saved by a tier with capacity CAP_SRC in this (already reset()) block: vertices and

@@ -713,6 +713,124 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   }
 }
 
+// Fast tier as a stream: the 64/WE lane groups of a wave walk through the wave's share of queue 1 and a
+// group that is done does not wait for the slowest polytope of the wave (EPA runs 1 .. CAP trips per
+// polytope, mean ~7 on convex pairs: in lockstep batches of 8 only ~56 % of the trips are useful).
+// The wave alternates between two uniform phases:
+//   trip   : every group with a live polytope does one expansion step (Epa::step);
+//   refill : once at least EPA_REFILL_MIN groups are without one (or none is live), those groups write
+//            the record of the polytope they finished (or hand it over to the full-capacity tier) and
+//            start the next item of the wave: seed, hulls, encloseOrigin, first tetrahedron (Epa::begin).
+// Batching the refills matters: a refill costs about 1.5 trips of the whole wave whoever takes part.
+#ifndef HFCL_EPA_REFILL_MIN
+#define HFCL_EPA_REFILL_MIN 3
+#endif
+template <typename T, int WE, int CAP>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_EPA32, 8)))
+k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  constexpr int G = 64 / WE;
+  typedef LaneGroup<WE> Grp;
+  __shared__ EpaScratch<T, CAP> scratch[G];
+  const uint32_t cnt = wk.counts[B_COUNT];
+  const int lane = threadIdx.x & 63, grp = lane / WE, lig = lane & (WE - 1);
+  const EpaItem<T>* queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
+  enum { IDLE = 0, LIVE = 1, DONE = 2, HANDOVER = 3 };
+  int state = IDLE;
+  uint32_t it = 0;              // queue slot of this group's polytope
+  uint32_t next = blockIdx.x;   // wave-uniform: the wave's items are next, next + gridDim.x, ...
+  EpaSupport<T, WE, false> sup;
+  sup.lig = lig;
+  Epa<T, Grp, CAP> epa;
+  EpaLoop<T> L;
+  Pose<T> tf1;
+  T r0 = T(0), r1 = T(0);
+  while (true) {
+    const uint64_t live = __ballot(state == LIVE);
+    const int n_live = __popcll(live) / WE;
+    const bool more = next < cnt;
+    if (n_live == 0 || (more && G - n_live >= HFCL_EPA_REFILL_MIN)) {
+      // ---- refill phase (uniform decision; groups with a live polytope sit it out) ----
+      if (state != LIVE) {
+        if (state != IDLE) {
+          const EpaItem<T> item = queue[it];
+          if (state == DONE) {
+            EpaResult<T> res;
+            epa.loop_result(L, r0 + r1, res);
+            PairOut<T> o;
+            epa_finish(res, item, tf1, r0, r1, o);
+            if (lig == 0) {
+              write_out<T>(io, q, item.pair, o);
+              write_guess<T>(io, item.pair, o.cached_guess, 0, 0);
+            }
+          } else {  // hand over to the full-capacity tier: the seed and, room permitting, the polytope itself
+            uint32_t slot = 0;
+            if (lig == 0) slot = atomicAdd(&wk.counts[B_COUNT + 1], 1u);
+            slot = __shfl(slot, 0, WE);
+            const bool save = epa.resumable && slot < wk.resume_cap;
+            if (save) epa_save_block<T, Grp, CAP>(&scratch[grp], reinterpret_cast<EpaScratch<T, CAP>*>(wk.epa_resume) + slot);
+            if (lig == 0) {
+              EpaItem<T> item2 = item;
+              if (save) item2.rank |= EPA_RESUME_FLAG;
+              reinterpret_cast<EpaItem<T>*>(wk.epa_queue2)[slot] = item2;
+            }
+          }
+          Grp::sync();
+          state = IDLE;
+        }
+        // rank of this group among the groups taking part, in lane order
+        const uint64_t lower = live | ~((uint64_t(1) << (grp * WE)) - 1);  // live lanes and lanes >= mine do not count
+        const uint32_t rank = uint32_t(__popcll(~lower)) / WE;
+        it = next + rank * gridDim.x;
+        if (it < cnt) {
+          const EpaItem<T> item = queue[it];
+          const uint32_t pair = item.pair;
+          sup.a = lib.shapes[wk.shape1[pair]];
+          sup.b = lib.shapes[wk.shape2[pair]];
+          if (sup.a.kind == K_CONVEX) sup.h0.load(lib.verts + 3 * size_t(sup.a.vertex_offset), sup.a.num_points, lig);
+          if (sup.b.kind == K_CONVEX) sup.h1.load(lib.verts + 3 * size_t(sup.b.vertex_offset), sup.b.num_points, lig);
+          tf1 = load_pose(io.tf1, pair);
+          const Pose<T> tf2 = load_pose(io.tf2, pair);
+          sup.md = make_mdiff(tf1, tf2);
+          r0 = swept_radius(sup.a);
+          r1 = swept_radius(sup.b);
+          epa.reset(&scratch[grp], q.epa_max_iterations, q.epa_tolerance);
+          epa.set_vert(0, item.w[0], item.w0[0]);
+          epa.set_vert(1, item.w[1], item.w0[1]);
+          epa.set_vert(2, item.w[2], item.w0[2]);
+          epa.set_vert(3, item.w[3], item.w0[3]);
+          Grp::sync();
+          EpaResult<T> res;
+          const int closest0 = epa.begin(item.rank, -item.guess, sup, res);
+          if (closest0 != EPA_NULL) {
+            epa.loop_enter(L, closest0, 0, 0);
+            state = LIVE;
+          } else if (epa.overflow) {
+            state = HANDOVER;  // (a block too small for the first tetrahedron: not with CAP >= 1)
+          } else {  // FallBack: final without a loop
+            PairOut<T> o;
+            epa_finish(res, item, tf1, r0, r1, o);
+            if (lig == 0) {
+              write_out<T>(io, q, pair, o);
+              write_guess<T>(io, pair, o.cached_guess, 0, 0);
+            }
+          }
+        }
+      }
+      next += uint32_t(G - n_live) * gridDim.x;
+      if (n_live == 0 && !more) {
+        // nothing was live and nothing was left to start: only a FallBack/empty refill can have happened
+        if (__ballot(state == LIVE) == 0) break;
+      }
+      continue;
+    }
+    // ---- trip ----
+    if (state == LIVE) {
+      const int r = epa.step(L, sup);
+      if (r != 0) state = r == 1 ? DONE : HANDOVER;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // k_bvh_collide: BVHModel<OBBRSS> x BVHModel<OBBRSS> collide().
 // Traversal = collisionRecurse (src/traversal/traversal_recurse.cpp:44-85) with the recursion
@@ -1705,7 +1823,13 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   if (q.compute_penetration) {
     t = timer_slot(lib, ti++, "k_epa<fast>");
     hipEventRecord(t->e0, st);
-    hipLaunchKernelGGL((k_epa<T, EPA_WE, EPA_FAST_CAP, 1>), dim3(blocks_for(n, 64 / EPA_WE)), dim3(64), 0, st, wk, lv, io, q);
+    // fp32 streams (two waves per SIMD hide the refill's global loads: k_epa<fast> 1.87 -> 1.76 ms on cfg3);
+    // fp64 runs one wave per SIMD, where the more frequent refills cost more than the idle groups (cfg5
+    // 1.27 -> 1.55 ms), and stays with the batch form
+    if constexpr (sizeof(T) == 4)
+      hipLaunchKernelGGL((k_epa_stream<T, EPA_WE, EPA_FAST_CAP>), dim3(blocks_for(n, 64 / EPA_WE)), dim3(64), 0, st, wk, lv, io, q);
+    else
+      hipLaunchKernelGGL((k_epa<T, EPA_WE, EPA_FAST_CAP, 1>), dim3(blocks_for(n, 64 / EPA_WE)), dim3(64), 0, st, wk, lv, io, q);
     hipEventRecord(t->e1, st);
     t = timer_slot(lib, ti++, "k_epa<full>");
     hipEventRecord(t->e0, st);
