@@ -72,7 +72,10 @@ def load_traffic(workload, dominant, n):
     base, tag = m.group(1), m.group(2)
     sel = {"fast": ", 1>(", "full": ", 2>(", "cc": ", 0>(", "pc": ", 1>(", "cp": ", 2>("}.get(tag, "")
     for name, v in t["kernels"].items():
-        if base in name and sel in name and "FETCH_SIZE_KB_per_dispatch" in v and "WRITE_SIZE_KB_per_dispatch" in v:
+        hit = base + "<" in name and sel in name
+        if tag == "fast" and "k_epa_stream<" in name:  # the fp32 fast tier is the streaming form of the same kernel
+            hit = True
+        if hit and "FETCH_SIZE_KB_per_dispatch" in v and "WRITE_SIZE_KB_per_dispatch" in v:
             f, w = v["FETCH_SIZE_KB_per_dispatch"] * 1024, v["WRITE_SIZE_KB_per_dispatch"] * 1024
             return 2 * f + w, "PMC per launch: FETCH_SIZE raw %.3g B (x2 gfx950 correction applied), WRITE_SIZE %.3g B; %s" % (f, w, os.path.relpath(path, ROOT))
     return None, "kernel not found in " + os.path.relpath(path, ROOT)

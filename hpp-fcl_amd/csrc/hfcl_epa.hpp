@@ -76,12 +76,14 @@ struct alignas(4 * sizeof(T) > 16 ? 16 : 4 * sizeof(T)) Quad {  // one LDS vecto
 struct EpaHeader {
   int32_t closest, iterations, pass, status, num_vertices, hull_count, stock_top, stamp;
 };
-template <typename T, int CAP>
+// V0IN = false: the shape-0 support points (needed once, for the witness points) live in a caller-provided
+// array outside the block (global memory in the full-capacity kernel, whose LDS bounds its occupancy).
+template <typename T, int CAP, bool V0IN = true>
 struct EpaScratch {
   static constexpr int NV = CAP + 4;
   static constexpr int NF = 2 * CAP + 4;
   Quad<T> vw[NV];   // vertex w (xyz)
-  Quad<T> v0[NV];   // vertex w0 (xyz)
+  Quad<T> v0[V0IN ? NV : 1];  // vertex w0 (xyz)
   Quad<T> fn[NF];   // face normal (xyz) and distance (w)
   FaceTopo ft[NF];  // connectivity + flags + stamp of a face, one 16-byte record
   EpaHeader hdr;    // loop state of a polytope that is handed over to the full-capacity tier
@@ -130,9 +132,10 @@ struct EpaResult {
   V3<T> rw0_, rw1_, rw2_, r00, r01, r02;
 };
 
-template <typename T, class Grp, int CAP = EPA_MAX_ITER>
+template <typename T, class Grp, int CAP = EPA_MAX_ITER, bool V0IN = true>
 struct Epa {
-  EpaScratch<T, CAP>* m;
+  EpaScratch<T, CAP, V0IN>* m;
+  Quad<T>* v0p;  // m->v0, or the caller's array when the block has none
   T tolerance;
   int max_iterations;  // the request's (reference) limit
   int cap_iterations;  // min(max_iterations, CAP): what this scratch block can hold
@@ -150,12 +153,22 @@ struct Epa {
     return mk<T>(q.x, q.y, q.z);
   }
   HFCL_HD V3<T> v0(int i) const {
-    const Quad<T> q = m->v0[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (!V0IN) {
+      // written by lane 0 of this group, possibly long ago and for an earlier polytope of the same slot:
+      // read past the per-CU cache
+      const T* q = &v0p[i].x;
+      return mk<T>(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+#endif
+    const Quad<T> q = v0p[i];
     return mk<T>(q.x, q.y, q.z);
   }
   HFCL_HD void set_vert(int i, const V3<T>& w, const V3<T>& w0) {
     m->vw[i] = Quad<T>{w.x, w.y, w.z, T(0)};
-    m->v0[i] = Quad<T>{w0.x, w0.y, w0.z, T(0)};
+    if (V0IN || Grp::lane() == 0) v0p[i] = Quad<T>{w0.x, w0.y, w0.z, T(0)};
   }
   HFCL_HD V3<T> fn(int f) const {
     const Quad<T> q = m->fn[f];
@@ -178,8 +191,9 @@ struct Epa {
     m->stock[stock_top++] = uint8_t(f);
   }
 
-  HFCL_HD void reset(EpaScratch<T, CAP>* mem, int max_it, T tol) {  // :1014-1037
+  HFCL_HD void reset(EpaScratch<T, CAP, V0IN>* mem, int max_it, T tol, Quad<T>* v0_ext = nullptr) {  // :1014-1037
     m = mem;
+    v0p = V0IN ? mem->v0 : v0_ext;
     tolerance = tol;
     max_iterations = max_it;
     cap_iterations = max_it < CAP ? max_it : CAP;
@@ -728,7 +742,7 @@ struct Epa {
 #endif
     for (int i = Grp::lane(); i < Src::NV; i += Grp::W) {
       m->vw[i] = src->vw[i];
-      m->v0[i] = src->v0[i];
+      v0p[i] = src->v0[i];
     }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1

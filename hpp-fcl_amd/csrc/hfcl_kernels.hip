@@ -128,6 +128,7 @@ struct Work {
   uint32_t* counts;  // B_COUNT counters + [B_COUNT] = epa queue length + [B_COUNT+1] = overflow queue length
   void* epa_queue;
   void* epa_queue2;  // polytopes that outgrew the fast EPA kernel's scratch block
+  void* epa_v0;      // shape-0 support points of the polytopes in flight in the full-capacity EPA kernel
   void* epa_resume;  // saved polytopes (EpaScratch<T, EPA_FAST_CAP>) of the first `resume_cap` slots of epa_queue2
   uint32_t resume_cap;
 };
@@ -651,7 +652,11 @@ template <typename T, int WE, int CAP, int TIER>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? (TIER == 1 ? HFCL_WPE_EPA32 : 2) : HFCL_WPE_EPA64, 8)))
 k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   constexpr int G = 64 / WE;
-  __shared__ EpaScratch<T, CAP> scratch[G];
+  // the full-capacity tier keeps the shape-0 support points in global memory: its LDS block bounds the
+  // occupancy (fp64: 45.5 KB -> 3 waves per CU with them, 36.5 KB -> 4 without)
+  constexpr bool V0IN = TIER == 1;
+  __shared__ EpaScratch<T, CAP, V0IN> scratch[G];
+  Quad<T>* const v0_ext = V0IN ? nullptr : reinterpret_cast<Quad<T>*>(wk.epa_v0) + size_t(blockIdx.x * G + threadIdx.x / WE) * (CAP + 4);
   const uint32_t cnt = wk.counts[TIER == 1 ? B_COUNT : B_COUNT + 1];
   const int lane = threadIdx.x & 63, grp = lane / WE, lig = lane & (WE - 1);
   const uint32_t groups = gridDim.x * G;
@@ -681,9 +686,9 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
         EpaItem<T> seed = item;
         seed.rank &= ~EPA_RESUME_FLAG;
         epa_resume<T, LaneGroup<WE>, EPA_FAST_CAP, CAP>(&scratch[grp], reinterpret_cast<const EpaScratch<T, EPA_FAST_CAP>*>(wk.epa_resume) + it,
-                                                         seed, q, tf1, r0, r1, sup, o);
+                                                         seed, q, tf1, r0, r1, sup, o, v0_ext);
       } else {
-        rc = epa_run<T, LaneGroup<WE>, CAP>(&scratch[grp], item, q, tf1, r0, r1, sup, o);
+        rc = epa_run<T, LaneGroup<WE>, CAP>(&scratch[grp], item, q, tf1, r0, r1, sup, o, v0_ext);
       }
       if (lig == 0) {
         write_out<T>(io, q, pair, o);
@@ -1294,6 +1299,7 @@ struct hfcl_lib {
   void* d_epa_queue = nullptr;
   void* d_epa_queue2 = nullptr;
   void* d_epa_resume = nullptr;
+  void* d_epa_v0 = nullptr;
   size_t resume_cap = 0;
   // host-call staging buffers
   size_t st_capacity = 0;
@@ -1471,6 +1477,12 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) lib->n_cus = prop.multiProcessorCount;
+  // one slot per lane group of the largest full-capacity EPA grid (run_batch caps grids at n_cus * 16 blocks)
+  if (hipMalloc(&lib->d_epa_v0, size_t(lib->n_cus) * 16 * (64 / EPA_WE2) * EPA_MAX_VERTS * sizeof(Quad<double>)) != hipSuccess) {
+    set_error("hfcl_lib_create: HIP allocation failed");
+    hfcl_lib_destroy(lib);
+    return nullptr;
+  }
   if (const char* w = getenv("HFCL_CVX_W")) {
     int v = atoi(w);
     if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) lib->cvx_w = v;
@@ -1491,6 +1503,7 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_epa_queue);
   hipFree(lib->d_epa_queue2);
   hipFree(lib->d_epa_resume);
+  hipFree(lib->d_epa_v0);
   hipFree(lib->d_s1);
   hipFree(lib->d_s2);
   hipFree(lib->d_tf1);
@@ -1735,6 +1748,7 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   wk.epa_queue = lib->d_epa_queue;
   wk.epa_queue2 = lib->d_epa_queue2;
   wk.epa_resume = lib->d_epa_resume;
+  wk.epa_v0 = lib->d_epa_v0;
   wk.resume_cap = uint32_t(std::min<size_t>(lib->resume_cap, 0xFFFFFFFFu));
   LibView<T> lv;
   lv.shapes = std::is_same<T, double>::value ? (const DShape<T>*)lib->d_shapes64 : (const DShape<T>*)lib->d_shapes32;
