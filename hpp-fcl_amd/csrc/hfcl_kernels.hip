@@ -1589,7 +1589,8 @@ static int ensure_workspace(hfcl_lib* lib, size_t n) {
   HIP_TRY(hipMalloc(&lib->d_epa_queue2, cap * sizeof(EpaItem<double>)));
   // saved polytopes for the tier hand-over: room for a third of the batch (beyond that the full tier
   // simply redoes the pair from its seed); 4 KB per slot in fp64
-  const size_t rcap = std::min(cap, std::max<size_t>(65536, cap / 3));
+  size_t rcap = std::min(cap, std::max<size_t>(65536, cap / 3));
+  if (const char* e = getenv("HFCL_EPA_RESUME_SLOTS")) rcap = std::max<size_t>(1, std::min<size_t>(cap, strtoull(e, nullptr, 10)));  // test knob
   HIP_TRY(hipMalloc(&lib->d_epa_resume, rcap * sizeof(EpaScratch<double, EPA_FAST_CAP>)));
   lib->resume_cap = rcap;
   lib->ws_capacity = cap;

@@ -60,6 +60,21 @@ def test_fp64_parity(pkg, oracle, case, n):
     assert buckets["unsupported"] == 0
 
 
+def test_epa_hand_over_equals_restart(pkg, monkeypatch):
+    """A polytope that outgrows the 20-iteration block is continued by the full-capacity kernel from the
+    saved block; when the save area is full it is redone from its seed.  Both must give the same record
+    bit for bit (the first iterations are the reference's in either tier)."""
+    abi, wl = pkg.abi, pkg.workloads
+    b = wl.cfg5_mixed(n=60000, seed=11)
+    req = wl.make_request(b, abi)
+    got, buckets = _engine(pkg, b, req)
+    assert buckets["epa_overflow"] > 500, buckets  # the workload does exercise the hand-over
+    monkeypatch.setenv("HFCL_EPA_RESUME_SLOTS", "64")  # nearly every hand-over now falls back to the seed
+    redo, buckets2 = _engine(pkg, b, req)
+    assert buckets2["epa_overflow"] == buckets["epa_overflow"]
+    assert got.tobytes() == redo.tobytes()
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_fp64_gjk_variants(pkg, oracle, variant):
     abi, wl = pkg.abi, pkg.workloads
