@@ -662,7 +662,8 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   const uint32_t groups = gridDim.x * G;
   const EpaItem<T>* queue = reinterpret_cast<const EpaItem<T>*>(TIER == 1 ? wk.epa_queue : wk.epa_queue2);
   for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += groups) {
-    const EpaItem<T> item = queue[it];
+    // the seed stays in memory and is read where it is used (as a local copy it is spilled across the hull loads)
+    const EpaItem<T>& item = queue[it];
     const uint32_t pair = item.pair;
     EpaSupport<T, WE, TIER == 2> sup;
     sup.a = lib.shapes[wk.shape1[pair]];
@@ -682,11 +683,9 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
     PairOut<T> o;
     int rc = 1;
     if constexpr (TIER == 2) {
-      if (item.rank & EPA_RESUME_FLAG) {  // continue what the fast tier saved for this slot
-        EpaItem<T> seed = item;
-        seed.rank &= ~EPA_RESUME_FLAG;
+      if (item.rank & EPA_RESUME_FLAG) {  // continue what the fast tier saved for this slot (the seed's rank is not used)
         epa_resume<T, LaneGroup<WE>, EPA_FAST_CAP, CAP>(&scratch[grp], reinterpret_cast<const EpaScratch<T, EPA_FAST_CAP>*>(wk.epa_resume) + it,
-                                                         seed, q, tf1, r0, r1, sup, o, v0_ext);
+                                                         item, q, tf1, r0, r1, sup, o, v0_ext);
       } else {
         rc = epa_run<T, LaneGroup<WE>, CAP>(&scratch[grp], item, q, tf1, r0, r1, sup, o, v0_ext);
       }
@@ -757,15 +756,15 @@ k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
       // ---- refill phase (uniform decision; groups with a live polytope sit it out) ----
       if (state != LIVE) {
         if (state != IDLE) {
-          const EpaItem<T> item = queue[it];
           if (state == DONE) {
             EpaResult<T> res;
             epa.loop_result(L, r0 + r1, res);
             PairOut<T> o;
-            epa_finish(res, item, tf1, r0, r1, o);
+            epa_finish(res, queue[it].gjk_iters, tf1, r0, r1, o);
             if (lig == 0) {
-              write_out<T>(io, q, item.pair, o);
-              write_guess<T>(io, item.pair, o.cached_guess, 0, 0);
+              const uint32_t pair = queue[it].pair;
+              write_out<T>(io, q, pair, o);
+              write_guess<T>(io, pair, o.cached_guess, 0, 0);
             }
           } else {  // hand over to the full-capacity tier: the seed and, room permitting, the polytope itself
             uint32_t slot = 0;
@@ -774,7 +773,7 @@ k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
             const bool save = epa.resumable && slot < wk.resume_cap;
             if (save) epa_save_block<T, Grp, CAP>(&scratch[grp], reinterpret_cast<EpaScratch<T, CAP>*>(wk.epa_resume) + slot);
             if (lig == 0) {
-              EpaItem<T> item2 = item;
+              EpaItem<T> item2 = queue[it];
               if (save) item2.rank |= EPA_RESUME_FLAG;
               reinterpret_cast<EpaItem<T>*>(wk.epa_queue2)[slot] = item2;
             }
@@ -787,8 +786,10 @@ k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
         const uint32_t rank = uint32_t(__popcll(~lower)) / WE;
         it = next + rank * gridDim.x;
         if (it < cnt) {
-          const EpaItem<T> item = queue[it];
-          const uint32_t pair = item.pair;
+          // the seed is read field by field where it is used: as one struct it would sit in registers
+          // across the hull loads and get spilled (1.6 KB of scratch traffic per polytope, measured)
+          const EpaItem<T>* ip = queue + it;
+          const uint32_t pair = ip->pair;
           sup.a = lib.shapes[wk.shape1[pair]];
           sup.b = lib.shapes[wk.shape2[pair]];
           if (sup.a.kind == K_CONVEX) sup.h0.load(lib.verts + 3 * size_t(sup.a.vertex_offset), sup.a.num_points, lig);
@@ -799,13 +800,13 @@ k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
           r0 = swept_radius(sup.a);
           r1 = swept_radius(sup.b);
           epa.reset(&scratch[grp], q.epa_max_iterations, q.epa_tolerance);
-          epa.set_vert(0, item.w[0], item.w0[0]);
-          epa.set_vert(1, item.w[1], item.w0[1]);
-          epa.set_vert(2, item.w[2], item.w0[2]);
-          epa.set_vert(3, item.w[3], item.w0[3]);
+          epa.set_vert(0, ip->w[0], ip->w0[0]);
+          epa.set_vert(1, ip->w[1], ip->w0[1]);
+          epa.set_vert(2, ip->w[2], ip->w0[2]);
+          epa.set_vert(3, ip->w[3], ip->w0[3]);
           Grp::sync();
           EpaResult<T> res;
-          const int closest0 = epa.begin(item.rank, -item.guess, sup, res);
+          const int closest0 = epa.begin(ip->rank, -ip->guess, sup, res);
           if (closest0 != EPA_NULL) {
             epa.loop_enter(L, closest0, 0, 0);
             state = LIVE;
@@ -813,7 +814,7 @@ k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
             state = HANDOVER;  // (a block too small for the first tetrahedron: not with CAP >= 1)
           } else {  // FallBack: final without a loop
             PairOut<T> o;
-            epa_finish(res, item, tf1, r0, r1, o);
+            epa_finish(res, ip->gjk_iters, tf1, r0, r1, o);
             if (lig == 0) {
               write_out<T>(io, q, pair, o);
               write_guess<T>(io, pair, o.cached_guess, 0, 0);

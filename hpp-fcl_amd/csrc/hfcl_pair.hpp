@@ -129,7 +129,11 @@ HFCL_HD bool gjk_finish(const Gjk<T, PW0<T>>& g, const QParams<T>& q, const Pose
 
 // EPAExtractWitnessPointsAndNormal / EPAFailedExtractWitnessPointsAndNormal (narrowphase.h:658-723)
 template <typename T>
-HFCL_HD void epa_finish(const EpaResult<T>& res, const EpaSeed<T>& seed, const Pose<T>& tf1, T r0, T r1, PairOut<T>& out);
+HFCL_HD void epa_finish(const EpaResult<T>& res, uint32_t gjk_iters, const Pose<T>& tf1, T r0, T r1, PairOut<T>& out);
+template <typename T>
+HFCL_HD void epa_finish(const EpaResult<T>& res, const EpaSeed<T>& seed, const Pose<T>& tf1, T r0, T r1, PairOut<T>& out) {
+  epa_finish(res, seed.gjk_iters, tf1, r0, r1, out);
+}
 
 // EPA branch of runGJKAndEPA (narrowphase.h:505-584) for one seed.  Returns 1 when `out` is final; 0 when
 // the polytope outgrew the CAP-sized scratch block and must be redone by the full-capacity kernel; 2 when
@@ -167,9 +171,9 @@ HFCL_HD void epa_resume(EpaScratch<T, CAP, V0IN>* scratch, const EpaScratch<T, C
 }
 
 template <typename T>
-HFCL_HD void epa_finish(const EpaResult<T>& res, const EpaSeed<T>& seed, const Pose<T>& tf1, T r0, T r1, PairOut<T>& out) {
+HFCL_HD void epa_finish(const EpaResult<T>& res, uint32_t gjk_iters, const Pose<T>& tf1, T r0, T r1, PairOut<T>& out) {
   out.gjk_status = GJK_COLLISION;
-  out.gjk_iters = int(seed.gjk_iters);
+  out.gjk_iters = int(gjk_iters);
   out.epa_status = res.status;
   out.epa_iters = res.iterations;
   if (res.status == EPA_FALLBACK) {  // EPAFailedExtractWitnessPointsAndNormal :713-723
