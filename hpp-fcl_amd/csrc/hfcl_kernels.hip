@@ -9,12 +9,14 @@
 //                    row), one pair per lane
 //   k_gjk_prim<T>    GJK for Box/Capsule/Cone/Cylinder/Ellipsoid/Sphere pairs, one pair per lane
 //   k_gjk_cvx<W,M>   GJK with hulls of <= 32 vertices: one pair per W-lane group, hull vertices in the
-//                    group's registers, support = per-lane dots + xor-butterfly arg-max (fp32 / fp64
+//                    group's registers, support = per-lane dots + DPP-butterfly arg-max (fp32 / fp64
 //                    entry points with their own register budgets)
 //   k_gjk_large<T>   GJK when a hull has more than 32 vertices: 16-lane groups scan the vertices from memory
 //   k_epa<T,WE,CAP,TIER>  EPA on the pairs GJK left in `Collision`: one polytope per WE-lane group in LDS;
-//                    tier 1 = 8 polytopes per wave in small blocks, tier 2 = full capacity (overflow of
-//                    tier 1 and every pair with a large hull)
+//                    tier 1 = 8 polytopes per wave in small blocks, tier 2 = full capacity (continues the
+//                    polytopes tier 1 saved when they outgrew their block; every pair with a large hull)
+//   k_epa_stream<T,WE,CAP>  tier 1 for fp32: same blocks, but a lane group whose polytope is done starts the
+//                    wave's next item instead of waiting for the slowest of the 8
 //   k_bvh_collide<T> / k_bvh_distance<T>   BVHModel<OBBRSS> x BVHModel<OBBRSS>: one mesh pair per lane,
 //                    explicit DFS stack in LDS (reference order), OBB SAT / RSS bounds, triangle-triangle leaves
 //   k_bvh_shape<T> / k_bvh_shape_distance<T>   BVHModel<OBBRSS> x convex solid or Plane/Halfspace: one query
@@ -596,9 +598,7 @@ struct LaneGroup {
   // Lanes of a group exchange data through LDS: the wavefront-scope fence keeps the compiler from moving or
   // reusing LDS accesses across the exchange point (the barrier alone only pins instruction scheduling).
   static __device__ __forceinline__ void sync() {
-#ifndef HFCL_AB_NO_FENCE
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#endif
     __builtin_amdgcn_wave_barrier();
   }
   static __device__ __forceinline__ uint32_t atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }  // LDS (ds_add_rtn)
