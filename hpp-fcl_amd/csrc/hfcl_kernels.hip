@@ -128,6 +128,7 @@ struct Work {
   uint32_t n;
   uint32_t* lists;   // B_COUNT lists of capacity n each
   uint32_t* counts;  // B_COUNT counters + [B_COUNT] = epa queue length + [B_COUNT+1] = overflow queue length
+                     // + [B_COUNT+2] = ticket counter of the streaming BVH kernel
   void* epa_queue;
   void* epa_queue2;  // polytopes that outgrew the fast EPA kernel's scratch block
   void* epa_v0;      // shape-0 support points of the polytopes in flight in the full-capacity EPA kernel
@@ -864,160 +865,199 @@ struct BvhParams {
 
 constexpr int BVH_STACK = 96;
 constexpr int BVH_BLOCK = 128;
+#ifndef HFCL_BVH_REFILL_MIN
+#define HFCL_BVH_REFILL_MIN 8
+#endif
+constexpr int BVH_REFILL_MIN = HFCL_BVH_REFILL_MIN;  // idle lanes of a wave that trigger a refill (4 / 8 / 16 / 24: 17.5 / 17.1 / 18.7 / 20.3 ms per 1M cfg4 queries)
 
 template <typename T>
 __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH, 8))) k_bvh_collide(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
                                                           BvhParams bp, T break_distance2) {
   __shared__ uint32_t stack[BVH_STACK][BVH_BLOCK];
   const uint32_t cnt = wk.counts[B_BVH];
-  const int tid = threadIdx.x;
-  const uint32_t stride = gridDim.x * blockDim.x;
+  uint32_t* const ticket = &wk.counts[B_COUNT + 2];
+  const int tid = threadIdx.x, lane = tid & 63;
   const T nanv = Lim<T>::nan();
-  for (uint32_t base = blockIdx.x * blockDim.x; base < cnt; base += stride) {
-    const uint32_t it = base + tid;
-    const bool valid = it < cnt;
-    uint32_t pair = 0;
-    DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
-    Pose<T> tf1, tf2;
-    M3<T> RT_R;
-    V3<T> RT_T;
-    int sp = 0;
-    bool overflow = false;
-    if (valid) {
-      pair = wk.lists[size_t(B_BVH) * wk.n + it];
-      const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
-      m1 = bv.meshes[a.bvh_index];
-      m2 = bv.meshes[b.bvh_index];
-      tf1 = load_pose(io.tf1, pair);
-      tf2 = load_pose(io.tf2, pair);
-      RT_R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
-      RT_T = tmul(tf1.R, tf2.t - tf1.t);
-      stack[0][tid] = 0u;  // (b1 = 0, b2 = 0)
-      sp = 1;
+  // Per-lane query state.  Queries differ by an order of magnitude in length (cfg4: 135 BV tests on
+  // average, 663 for the longest of 64), so the lanes of a wave do not advance through the batch in
+  // lockstep: a lane whose traversal is over parks its result (`pending`) and, as soon as
+  // BVH_REFILL_MIN lanes of the wave are idle, all of them write their records and take the next
+  // queries from a global ticket counter.
+  constexpr int refill_min = BVH_REFILL_MIN;
+  bool live = false, pending = false, exhausted = false;  // exhausted is wave-uniform
+  uint32_t pair = 0;
+  DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
+  Pose<T> tf1, tf2;
+  M3<T> RT_R;
+  V3<T> RT_T;
+  int sp = 0;
+  bool overflow = false;
+  uint32_t ncontacts = 0;
+  T dlb = Lim<T>::max(), rec_dist = Lim<T>::max();
+  V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1, nn = np1;
+  int fb1 = -1, fb2 = -1;
+  bool have_leaf = false;
+  uint32_t lb1 = 0, lb2 = 0;
+  auto flush = [&]() {  // record of the query this lane finished
+    PairOut<T> o;
+    o.distance = rec_dist;
+    o.normal = nn;
+    o.p1 = np1;
+    o.p2 = np2;
+    o.gjk_status = GJK_DID_NOT_RUN;
+    o.epa_status = EPA_DID_NOT_RUN;
+    o.gjk_iters = o.epa_iters = 0;
+    store_bvh_record(io, pair, o, ncontacts, fb1, fb2, overflow);
+  };
+  for (;;) {
+    if (live && !have_leaf && sp == 0) {  // traversal over
+      live = false;
+      pending = true;
     }
-    uint32_t ncontacts = 0;
-    T dlb = Lim<T>::max(), rec_dist = Lim<T>::max();
-    V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1, nn = np1;
-    int fb1 = -1, fb2 = -1;
-    bool have_leaf = false;
-    uint32_t lb1 = 0, lb2 = 0;
+    const uint64_t live_mask = __ballot(live);
+    const int n_live = __popcll(live_mask);
+    if (exhausted ? n_live == 0 : 64 - n_live >= refill_min) {
+      // ---- refill (wave-uniform decision; live lanes sit it out)
+      if (pending) {
+        flush();
+        pending = false;
+      }
+      if (exhausted) break;
+      const int n_need = 64 - n_live;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ticket, uint32_t(n_need));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (!live) {
+        const uint32_t rank = uint32_t(__popcll(~live_mask & ((uint64_t(1) << lane) - 1)));
+        const uint32_t it = base + rank;
+        if (it < cnt) {
+          pair = wk.lists[size_t(B_BVH) * wk.n + it];
+          const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+          m1 = bv.meshes[a.bvh_index];
+          m2 = bv.meshes[b.bvh_index];
+          tf1 = load_pose(io.tf1, pair);
+          tf2 = load_pose(io.tf2, pair);
+          RT_R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
+          RT_T = tmul(tf1.R, tf2.t - tf1.t);
+          stack[0][tid] = 0u;  // (b1 = 0, b2 = 0)
+          sp = 1;
+          overflow = false;
+          ncontacts = 0;
+          dlb = rec_dist = Lim<T>::max();
+          np1 = np2 = nn = mk<T>(nanv, nanv, nanv);
+          fb1 = fb2 = -1;
+          have_leaf = false;
+          live = true;
+        }
+      }
+      if (base + uint32_t(n_need) >= cnt) exhausted = true;
+      continue;
+    }
+    // ---- BV phase: advance every lane that has no leaf test pending, until half the wave waits for a
+    // leaf test, nobody can advance, or enough lanes ran out of work to make a refill due
     for (;;) {
-      // ---- BV phase: advance every lane that has no leaf test pending
-      for (;;) {
-        const bool can_bv = !have_leaf && sp > 0;
-        if (!__any(can_bv)) break;
-        if (__popcll(__ballot(have_leaf)) >= 32) break;
-        if (can_bv) {
-          const uint32_t e = stack[--sp][tid];
-          const uint32_t b1 = e & 0xFFFFu, b2 = e >> 16;
-          const DNode<T> n1 = bv.nodes[m1.node_off + b1];
-          const DNode<T> n2 = bv.nodes[m2.node_off + b2];
-          const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
-          if (l1 && l2) {
-            have_leaf = true;
-            lb1 = uint32_t(-(n1.first_child + 1));
-            lb2 = uint32_t(-(n2.first_child + 1));
+      const bool can_bv = live && !have_leaf && sp > 0;
+      if (!__any(can_bv)) break;
+      if (__popcll(__ballot(have_leaf)) >= 32) break;
+      if (!exhausted && 64 - __popcll(__ballot(live && (have_leaf || sp > 0))) >= refill_min) break;
+      if (can_bv) {
+        const uint32_t e = stack[--sp][tid];
+        const uint32_t b1 = e & 0xFFFFu, b2 = e >> 16;
+        const DNode<T> n1 = bv.nodes[m1.node_off + b1];
+        const DNode<T> n2 = bv.nodes[m2.node_off + b2];
+        const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
+        if (l1 && l2) {
+          have_leaf = true;
+          lb1 = uint32_t(-(n1.first_child + 1));
+          lb2 = uint32_t(-(n2.first_child + 1));
+        } else {
+          T sq;
+          // argument order of the reference: overlap(RT.R, RT.T, model2.bv(b2), model1.bv(b1))
+          const bool disjoint = obb_disjoint(RT_R, RT_T, n2, n1, q.security_margin, break_distance2, sq);
+          if (disjoint) {  // updateDistanceLowerBoundFromBV
+            if (!(dlb <= T(0))) {
+              const T nd = hsqrt(sq);
+              if (nd < dlb) {
+                dlb = nd;
+                rec_dist = nd + q.security_margin;
+              }
+            }
           } else {
-            T sq;
-            // argument order of the reference: overlap(RT.R, RT.T, model2.bv(b2), model1.bv(b1))
-            const bool disjoint = obb_disjoint(RT_R, RT_T, n2, n1, q.security_margin, break_distance2, sq);
-            if (disjoint) {  // updateDistanceLowerBoundFromBV
-              if (!(dlb <= T(0))) {
-                const T nd = hsqrt(sq);
-                if (nd < dlb) {
-                  dlb = nd;
-                  rec_dist = nd + q.security_margin;
-                }
-              }
+            const T sz1 = sqnorm(n1.extent), sz2 = sqnorm(n2.extent);
+            const bool first = l2 || (!l1 && (sz1 > sz2));  // firstOverSecond
+            uint32_t ea, eb;
+            if (first) {
+              const uint32_t c1 = uint32_t(n1.first_child);
+              ea = c1 | (b2 << 16);
+              eb = (c1 + 1) | (b2 << 16);
             } else {
-              const T sz1 = sqnorm(n1.extent), sz2 = sqnorm(n2.extent);
-              const bool first = l2 || (!l1 && (sz1 > sz2));  // firstOverSecond
-              uint32_t ea, eb;
-              if (first) {
-                const uint32_t c1 = uint32_t(n1.first_child);
-                ea = c1 | (b2 << 16);
-                eb = (c1 + 1) | (b2 << 16);
-              } else {
-                const uint32_t c1 = uint32_t(n2.first_child);
-                ea = b1 | (c1 << 16);
-                eb = b1 | ((c1 + 1) << 16);
-              }
-              if (sp + 2 > BVH_STACK) {
-                overflow = true;
-                sp = 0;
-              } else {
-                stack[sp++][tid] = eb;  // second child below
-                stack[sp++][tid] = ea;  // first child on top
-              }
+              const uint32_t c1 = uint32_t(n2.first_child);
+              ea = b1 | (c1 << 16);
+              eb = b1 | ((c1 + 1) << 16);
+            }
+            if (sp + 2 > BVH_STACK) {
+              overflow = true;
+              sp = 0;
+            } else {
+              stack[sp++][tid] = eb;  // second child below
+              stack[sp++][tid] = ea;  // first child on top
             }
           }
-        }
-      }
-      if (!__any(have_leaf)) break;
-      // ---- leaf phase (leafCollides, traversal_node_bvhs.h:184-233)
-      if (have_leaf) {
-        have_leaf = false;
-        const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + lb1);
-        const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + lb2);
-        const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
-        const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
-        auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
-        TriSupport<T> tri;
-        tri.p1 = xform(tf1, vtx(v1, t1[0]));
-        tri.p2 = xform(tf1, vtx(v1, t1[1]));
-        tri.p3 = xform(tf1, vtx(v1, t1[2]));
-        tri.q1 = xform(tf2, vtx(v2, t2[0]));
-        tri.q2 = xform(tf2, vtx(v2, t2[1]));
-        tri.q3 = xform(tf2, vtx(v2, t2[2]));
-        V3<T> p1, p2, n;
-        int gst, git;
-        const T distance = tri_tri_distance(tri, q.gjk, q.guess_mode == HFCL_GUESS_CACHED,
-                                            mk<T>(q.guess[0], q.guess[1], q.guess[2]), p1, p2, n, gst, git);
-        const T dtc = distance - q.security_margin;
-        if (dtc < dlb) {  // updateDistanceLowerBoundFromLeaf
-          dlb = dtc;
-          rec_dist = distance;
-          np1 = p1;
-          np2 = p2;
-          nn = n;
-        }
-        if (dtc <= q.collision_distance_threshold) {
-          if (ncontacts < bp.num_max_contacts) {
-            if (ncontacts == 0) {
-              fb1 = int(lb1);
-              fb2 = int(lb2);
-            }
-            ++ncontacts;
-            if (bp.contacts) {
-              const uint32_t slot = atomicAdd(bp.contacts_count, 1u);
-              if (slot < bp.contacts_cap) {
-                hfcl_contact c;
-                c.pair = pair;
-                c.b1 = int(lb1);
-                c.b2 = int(lb2);
-                c._pad = 0;
-                c.penetration_depth = double(distance);
-                c.normal[0] = n.x; c.normal[1] = n.y; c.normal[2] = n.z;
-                c.p1[0] = p1.x; c.p1[1] = p1.y; c.p1[2] = p1.z;
-                c.p2[0] = p2.x; c.p2[1] = p2.y; c.p2[2] = p2.z;
-                bp.contacts[slot] = c;
-              }
-            }
-          }
-          if (ncontacts >= bp.num_max_contacts) sp = 0;  // canStop(): nothing else is visited
         }
       }
     }
-    if (valid) {
-      PairOut<T> o;
-      o.distance = rec_dist;
-      o.normal = nn;
-      o.p1 = np1;
-      o.p2 = np2;
-      o.gjk_status = GJK_DID_NOT_RUN;
-      o.epa_status = EPA_DID_NOT_RUN;
-      o.gjk_iters = o.epa_iters = 0;
-      store_bvh_record(io, pair, o, ncontacts, fb1, fb2, overflow);
+    // ---- leaf phase (leafCollides, traversal_node_bvhs.h:184-233)
+    if (have_leaf) {
+      have_leaf = false;
+      const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + lb1);
+      const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + lb2);
+      const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
+      const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
+      auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
+      TriSupport<T> tri;
+      tri.p1 = xform(tf1, vtx(v1, t1[0]));
+      tri.p2 = xform(tf1, vtx(v1, t1[1]));
+      tri.p3 = xform(tf1, vtx(v1, t1[2]));
+      tri.q1 = xform(tf2, vtx(v2, t2[0]));
+      tri.q2 = xform(tf2, vtx(v2, t2[1]));
+      tri.q3 = xform(tf2, vtx(v2, t2[2]));
+      V3<T> p1, p2, n;
+      int gst, git;
+      const T distance = tri_tri_distance(tri, q.gjk, q.guess_mode == HFCL_GUESS_CACHED,
+                                          mk<T>(q.guess[0], q.guess[1], q.guess[2]), p1, p2, n, gst, git);
+      const T dtc = distance - q.security_margin;
+      if (dtc < dlb) {  // updateDistanceLowerBoundFromLeaf
+        dlb = dtc;
+        rec_dist = distance;
+        np1 = p1;
+        np2 = p2;
+        nn = n;
+      }
+      if (dtc <= q.collision_distance_threshold) {
+        if (ncontacts < bp.num_max_contacts) {
+          if (ncontacts == 0) {
+            fb1 = int(lb1);
+            fb2 = int(lb2);
+          }
+          ++ncontacts;
+          if (bp.contacts) {
+            const uint32_t slot = atomicAdd(bp.contacts_count, 1u);
+            if (slot < bp.contacts_cap) {
+              hfcl_contact c;
+              c.pair = pair;
+              c.b1 = int(lb1);
+              c.b2 = int(lb2);
+              c._pad = 0;
+              c.penetration_depth = double(distance);
+              c.normal[0] = n.x; c.normal[1] = n.y; c.normal[2] = n.z;
+              c.p1[0] = p1.x; c.p1[1] = p1.y; c.p1[2] = p1.z;
+              c.p2[0] = p2.x; c.p2[1] = p2.y; c.p2[2] = p2.z;
+              bp.contacts[slot] = c;
+            }
+          }
+        }
+        if (ncontacts >= bp.num_max_contacts) sp = 0;  // canStop(): nothing else is visited
+      }
     }
   }
 }
@@ -1461,7 +1501,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   ok = ok && hipMalloc(&lib->d_kinds, n_shapes) == hipSuccess;
   ok = ok && hipMalloc(&lib->d_verts64, (3 * n_vertices + 3) * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc(&lib->d_verts32, (3 * n_vertices + 3) * sizeof(float)) == hipSuccess;
-  ok = ok && hipMalloc(&lib->d_counts, (B_COUNT + 2) * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_counts, (B_COUNT + 3) * sizeof(uint32_t)) == hipSuccess;
   if (ok) {
     ok = ok && hipMemcpy(lib->d_shapes64, s64.data(), n_shapes * sizeof(DShape<double>), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(lib->d_shapes32, s32.data(), n_shapes * sizeof(DShape<float>), hipMemcpyHostToDevice) == hipSuccess;
@@ -1767,7 +1807,7 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
     if (b > (size_t)max_blocks) b = max_blocks;
     return int(b);
   };
-  HIP_TRY(hipMemsetAsync(lib->d_counts, 0, (B_COUNT + 2) * sizeof(uint32_t), st));
+  HIP_TRY(hipMemsetAsync(lib->d_counts, 0, (B_COUNT + 3) * sizeof(uint32_t), st));
   KernelTime* t = timer_slot(lib, ti++, "k_classify");
   hipEventRecord(t->e0, st);
   hipLaunchKernelGGL(k_classify, dim3(blocks_for(n, 256 * 8)), dim3(256), 0, st, wk, lib->d_kinds, uint32_t(lib->n_shapes));
