@@ -66,7 +66,8 @@ def load_traffic(workload, dominant, n):
     if not os.path.exists(path):
         return None, "no PMC pass committed for this workload"
     t = json.load(open(path))
-    if t.get("pairs") not in (None, n):
+    default_n = {"cfg4": 100_000, "cfg5": 1_250_000}.get(workload, 1_000_000)
+    if (t.get("pairs") or default_n) != n:
         return None, "PMC pass was taken at a different batch size"
     m = re.match(r"(k_\w+)(?:<(\w+)>)?", dominant)
     base, tag = m.group(1), m.group(2)

@@ -707,10 +707,10 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
         slot = __shfl(slot, 0, WE);
         const bool save = rc == 2 && slot < wk.resume_cap;
         if (save) epa_save_block<T, LaneGroup<WE>, CAP>(&scratch[grp], reinterpret_cast<EpaScratch<T, CAP>*>(wk.epa_resume) + slot);
-        if (lig == 0) {
-          EpaItem<T> item2 = item;
-          if (save) item2.rank |= EPA_RESUME_FLAG;
-          reinterpret_cast<EpaItem<T>*>(wk.epa_queue2)[slot] = item2;
+        if (lig == 0) {  // queue to queue, no local copy (a local EpaItem lives in scratch memory)
+          EpaItem<T>* dst = reinterpret_cast<EpaItem<T>*>(wk.epa_queue2) + slot;
+          *dst = item;
+          if (save) dst->rank = item.rank | EPA_RESUME_FLAG;
         }
       }
     }
@@ -773,10 +773,10 @@ k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
             slot = __shfl(slot, 0, WE);
             const bool save = epa.resumable && slot < wk.resume_cap;
             if (save) epa_save_block<T, Grp, CAP>(&scratch[grp], reinterpret_cast<EpaScratch<T, CAP>*>(wk.epa_resume) + slot);
-            if (lig == 0) {
-              EpaItem<T> item2 = queue[it];
-              if (save) item2.rank |= EPA_RESUME_FLAG;
-              reinterpret_cast<EpaItem<T>*>(wk.epa_queue2)[slot] = item2;
+            if (lig == 0) {  // queue to queue, no local copy (a local EpaItem lives in scratch memory)
+              EpaItem<T>* dst = reinterpret_cast<EpaItem<T>*>(wk.epa_queue2) + slot;
+              *dst = queue[it];
+              if (save) dst->rank = queue[it].rank | EPA_RESUME_FLAG;
             }
           }
           Grp::sync();
