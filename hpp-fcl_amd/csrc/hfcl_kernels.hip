@@ -1214,42 +1214,94 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
   __shared__ uint32_t stack_e[BVHD_STACK][BVHD_BLOCK];
   __shared__ T stack_d[BVHD_STACK][BVHD_BLOCK];
   const uint32_t cnt = wk.counts[B_BVH];
-  const int tid = threadIdx.x;
+  uint32_t* const ticket = &wk.counts[B_COUNT + 2];
+  const int tid = threadIdx.x, lane = tid & 63;
   const T nanv = Lim<T>::nan();
-  for (uint32_t it = blockIdx.x * blockDim.x + tid; it < cnt; it += gridDim.x * blockDim.x) {
-    const uint32_t pair = wk.lists[size_t(B_BVH) * wk.n + it];
-    const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
-    const DMesh m1 = bv.meshes[a.bvh_index], m2 = bv.meshes[b.bvh_index];
-    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
-    const M3<T> RT_R = tmul(tf1.R, tf2.R);
-    const V3<T> RT_T = tmul(tf1.R, tf2.t - tf1.t);
+  // streaming as in k_bvh_collide: per-lane query state, refill once BVH_REFILL_MIN lanes are idle
+  bool live = false, pending = false, exhausted = false;  // exhausted is wave-uniform
+  uint32_t pair = 0;
+  DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
+  Pose<T> tf1;
+  M3<T> RT_R;
+  V3<T> RT_T;
+  T mind = Lim<T>::max();
+  int fb1 = -1, fb2 = -1;
+  V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1;
+  bool overflow = false;
+  int sp = 0;
+  auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
+  auto leaf = [&](uint32_t p1i, uint32_t p2i) {
     const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
     const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
-    T mind = Lim<T>::max();
-    int fb1 = -1, fb2 = -1;
-    V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1;
-    bool overflow = false;
-    auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
-    auto leaf = [&](uint32_t p1i, uint32_t p2i) {
-      const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + p1i);
-      const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + p2i);
-      V3<T> P, Q;
-      const T d2 = sqr_tri_distance(vtx(v1, t1[0]), vtx(v1, t1[1]), vtx(v1, t1[2]), mul(RT_R, vtx(v2, t2[0])) + RT_T,
-                                    mul(RT_R, vtx(v2, t2[1])) + RT_T, mul(RT_R, vtx(v2, t2[2])) + RT_T, P, Q);
-      const T d = hsqrt(d2);
-      if (mind > d) {  // DistanceResult::update
-        mind = d;
-        fb1 = int(p1i);
-        fb2 = int(p2i);
-        np1 = P;
-        np2 = Q;
+    const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + p1i);
+    const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + p2i);
+    V3<T> P, Q;
+    const T d2 = sqr_tri_distance(vtx(v1, t1[0]), vtx(v1, t1[1]), vtx(v1, t1[2]), mul(RT_R, vtx(v2, t2[0])) + RT_T,
+                                  mul(RT_R, vtx(v2, t2[1])) + RT_T, mul(RT_R, vtx(v2, t2[2])) + RT_T, P, Q);
+    const T d = hsqrt(d2);
+    if (mind > d) {  // DistanceResult::update
+      mind = d;
+      fb1 = int(p1i);
+      fb2 = int(p2i);
+      np1 = P;
+      np2 = Q;
+    }
+  };
+  for (;;) {
+    if (live && sp == 0) {
+      live = false;
+      pending = true;
+    }
+    const uint64_t live_mask = __ballot(live);
+    const int n_live = __popcll(live_mask);
+    if (exhausted ? n_live == 0 : 64 - n_live >= BVH_REFILL_MIN) {
+      if (pending) {
+        PairOut<T> o;
+        o.distance = mind;
+        o.normal = mk<T>(nanv, nanv, nanv);  // not set by the reference on this path (traversal_node_bvhs.h:454,465)
+        o.p1 = xform(tf1, np1);              // postprocess(): model-1 frame -> world
+        o.p2 = xform(tf1, np2);
+        o.gjk_status = GJK_DID_NOT_RUN;
+        o.epa_status = EPA_DID_NOT_RUN;
+        o.gjk_iters = o.epa_iters = 0;
+        store_bvh_record(io, pair, o, mind <= T(0) ? 0x80000000u : 0u, fb1, fb2, overflow);
+        pending = false;
       }
-    };
-    leaf(0u, 0u);  // preprocess()
-    int sp = 1;
-    stack_e[0][tid] = 0u;
-    stack_d[0][tid] = T(-1);
-    while (sp > 0) {
+      if (exhausted) break;
+      const int n_need = 64 - n_live;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ticket, uint32_t(n_need));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (!live) {
+        const uint32_t it = base + uint32_t(__popcll(~live_mask & ((uint64_t(1) << lane) - 1)));
+        if (it < cnt) {
+          pair = wk.lists[size_t(B_BVH) * wk.n + it];
+          const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+          m1 = bv.meshes[a.bvh_index];
+          m2 = bv.meshes[b.bvh_index];
+          tf1 = load_pose(io.tf1, pair);
+          const Pose<T> tf2 = load_pose(io.tf2, pair);
+          RT_R = tmul(tf1.R, tf2.R);
+          RT_T = tmul(tf1.R, tf2.t - tf1.t);
+          mind = Lim<T>::max();
+          fb1 = fb2 = -1;
+          np1 = np2 = mk<T>(nanv, nanv, nanv);
+          overflow = false;
+          leaf(0u, 0u);  // preprocess()
+          sp = 1;
+          stack_e[0][tid] = 0u;
+          stack_d[0][tid] = T(-1);
+          live = true;
+        }
+      }
+      if (base + uint32_t(n_need) >= cnt) exhausted = true;
+      continue;
+    }
+    for (;;) {
+      const bool run = live && sp > 0;
+      const int n_run = __popcll(__ballot(run));
+      if (n_run == 0 || (!exhausted && 64 - n_run >= BVH_REFILL_MIN)) break;
+      if (!run) continue;
       --sp;
       const uint32_t e = stack_e[sp][tid];
       const T de = stack_d[sp][tid];
@@ -1280,7 +1332,8 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
                                    bv.nodes[m2.node_off + c2], bv.rss[m2.node_off + c2]);
       if (sp + 2 > BVHD_STACK) {
         overflow = true;
-        break;
+        sp = 0;
+        continue;
       }
       const uint32_t ea = a1 | (a2 << 16), ec = c1 | (c2 << 16);
       const bool c_first = d2 < d1;  // visit (c1,c2) first when it is strictly nearer
@@ -1291,15 +1344,6 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
       stack_d[sp][tid] = c_first ? d2 : d1;
       ++sp;
     }
-    PairOut<T> o;
-    o.distance = mind;
-    o.normal = mk<T>(nanv, nanv, nanv);  // not set by the reference on this path (traversal_node_bvhs.h:454,465)
-    o.p1 = xform(tf1, np1);              // postprocess(): model-1 frame -> world
-    o.p2 = xform(tf1, np2);
-    o.gjk_status = GJK_DID_NOT_RUN;
-    o.epa_status = EPA_DID_NOT_RUN;
-    o.gjk_iters = o.epa_iters = 0;
-    store_bvh_record(io, pair, o, mind <= T(0) ? 0x80000000u : 0u, fb1, fb2, overflow);
   }
 }
 
