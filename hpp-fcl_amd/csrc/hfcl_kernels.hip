@@ -587,9 +587,9 @@ __global__ void __launch_bounds__(256) k_gjk_large(Work wk, LibView<T> lib, IO<T
 // ---------------------------------------------------------------------------------------
 // k_epa: EPA on the pairs GJK left in `Collision`.  One polytope per WE-lane group, 64/WE polytopes
 // per wavefront, scratch blocks in LDS.  Two tiers:
-//   tier 1  WE = 8, CAP = EPA_FAST_CAP iterations: 8 polytopes per wave share one instruction stream;
-//           a polytope that outgrows the small block is re-queued (seed unchanged)
-//   tier 2  WE = 64, CAP = 64 (the reference capacity): one polytope per wave for the re-queued rest
+//   tier 1  WE = 8, CAP = 20 (fp32) / 24 (fp64) iterations: 8 polytopes per wave share one instruction
+//           stream; a polytope that outgrows the small block is saved at the start of that iteration and queued
+//   tier 2  WE = 16, CAP = 64 (the reference capacity): 4 polytopes per wave, continues the saved polytopes
 // ---------------------------------------------------------------------------------------
 template <int W_>
 struct LaneGroup {
@@ -609,6 +609,11 @@ struct LaneGroup {
 #define HFCL_EPA_FAST_CAP 20
 #endif
 constexpr int EPA_FAST_CAP = HFCL_EPA_FAST_CAP;
+#ifndef HFCL_EPA_FAST_CAP64
+#define HFCL_EPA_FAST_CAP64 24  // cfg5 (fast + full ms): 12: 0.84+2.16, 16: 1.06+1.74, 20: 1.28+1.19, 24: 1.49+0.89; 28 would cost a wave per CU
+#endif
+// capacity of the fast tier's block per precision (fp64 blocks are twice the size; the LDS holds 4 waves x 8 either way)
+template <typename T> constexpr int epa_fast_cap = sizeof(T) == 4 ? EPA_FAST_CAP : HFCL_EPA_FAST_CAP64;
 #ifndef HFCL_EPA_WE
 #define HFCL_EPA_WE 8
 #endif
@@ -685,7 +690,7 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
     int rc = 1;
     if constexpr (TIER == 2) {
       if (item.rank & EPA_RESUME_FLAG) {  // continue what the fast tier saved for this slot (the seed's rank is not used)
-        epa_resume<T, LaneGroup<WE>, EPA_FAST_CAP, CAP>(&scratch[grp], reinterpret_cast<const EpaScratch<T, EPA_FAST_CAP>*>(wk.epa_resume) + it,
+        epa_resume<T, LaneGroup<WE>, epa_fast_cap<T>, CAP>(&scratch[grp], reinterpret_cast<const EpaScratch<T, epa_fast_cap<T>>*>(wk.epa_resume) + it,
                                                          item, q, tf1, r0, r1, sup, o, v0_ext);
       } else {
         rc = epa_run<T, LaneGroup<WE>, CAP>(&scratch[grp], item, q, tf1, r0, r1, sup, o, v0_ext);
@@ -1676,7 +1681,7 @@ static int ensure_workspace(hfcl_lib* lib, size_t n) {
   // simply redoes the pair from its seed); 4 KB per slot in fp64
   size_t rcap = std::min(cap, std::max<size_t>(65536, cap / 3));
   if (const char* e = getenv("HFCL_EPA_RESUME_SLOTS")) rcap = std::max<size_t>(1, std::min<size_t>(cap, strtoull(e, nullptr, 10)));  // test knob
-  HIP_TRY(hipMalloc(&lib->d_epa_resume, rcap * sizeof(EpaScratch<double, EPA_FAST_CAP>)));
+  HIP_TRY(hipMalloc(&lib->d_epa_resume, rcap * sizeof(EpaScratch<double, epa_fast_cap<double>>)));
   lib->resume_cap = rcap;
   lib->ws_capacity = cap;
   return HFCL_OK;
@@ -1929,7 +1934,7 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
     if constexpr (sizeof(T) == 4)
       hipLaunchKernelGGL((k_epa_stream<T, EPA_WE, EPA_FAST_CAP>), dim3(blocks_for(n, 64 / EPA_WE)), dim3(64), 0, st, wk, lv, io, q);
     else
-      hipLaunchKernelGGL((k_epa<T, EPA_WE, EPA_FAST_CAP, 1>), dim3(blocks_for(n, 64 / EPA_WE)), dim3(64), 0, st, wk, lv, io, q);
+      hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_fast_cap<T>, 1>), dim3(blocks_for(n, 64 / EPA_WE)), dim3(64), 0, st, wk, lv, io, q);
     hipEventRecord(t->e1, st);
     t = timer_slot(lib, ti++, "k_epa<full>");
     hipEventRecord(t->e0, st);
