@@ -37,6 +37,11 @@ BYTES_PER_QUERY = {
     # per leaf test; N_bv, N_leaf are measured with the oracle on a sample and reported.
     "cfg4": 8 + 2 * 96 + 96,
     "cfg5": 8 + 2 * 96 + 96,   # mixed primitive+convex collide, fp64: as cfg2
+    # cfg1's shape pair (Sphere-Sphere distance(), closed form) at a batch that is not launch bound, through
+    # the general boundary: ids + full Transform3f images + 96-B record (SURVEY's 144 B assumes a
+    # sphere-only entry point that reads centres and radii alone; the drop-in ABI does not have one)
+    "cfg1": 8 + 2 * 96 + 96,
+    "cfg3u": 8 + 2 * 28 + 44 + 2 * 32 * 12,  # cfg3 with one hull pair per query: + 2 x 32 fp32 vertices = 876 B
 }
 CFG4_BYTES_PER_BV_TEST = 2 * 128
 CFG4_BYTES_PER_LEAF_TEST = 2 * (3 * 24 + 12)
@@ -47,7 +52,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4", "cfg5"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4", "cfg5", "cfg1", "cfg3u"])
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default 1M; cfg4: 100k; cfg5: 1.25M = 10M / 8)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of result records (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -66,7 +71,7 @@ def load_traffic(workload, dominant, n):
     if not os.path.exists(path):
         return None, "no PMC pass committed for this workload"
     t = json.load(open(path))
-    default_n = {"cfg4": 100_000, "cfg5": 1_250_000}.get(workload, 1_000_000)
+    default_n = {"cfg4": 100_000, "cfg5": 1_250_000, "cfg1": 4_000_000}.get(workload, 1_000_000)
     if (t.get("pairs") or default_n) != n:
         return None, "PMC pass was taken at a different batch size"
     m = re.match(r"(k_\w+)(?:<(\w+)>)?", dominant)
@@ -103,10 +108,16 @@ def main():
 
     pkg = load_pkg()
     abi, wl = pkg.abi, pkg.workloads
-    n = args.pairs or {"cfg4": 100_000, "cfg5": 1_250_000}.get(args.workload, 1_000_000)
+    n = args.pairs or {"cfg4": 100_000, "cfg5": 1_250_000, "cfg1": 4_000_000}.get(args.workload, 1_000_000)
     if args.workload == "cfg3":
         batch = wl.cfg3_convex_convex(n=n, seed=1 + rank)
         dtype = "f32"
+    elif args.workload == "cfg3u":
+        batch = wl.cfg3_unique_hulls(n=n, seed=1 + rank)
+        dtype = "f32"
+    elif args.workload == "cfg1":
+        batch = wl.cfg1_sphere_sphere(n=n, seed=1 + rank)
+        dtype = "f64"
     elif args.workload == "cfg2":
         batch = wl.cfg2_box_capsule(n=n, seed=1 + rank)
         dtype = "f64"
@@ -179,6 +190,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    lib.set_kernel_timing(False)  # the timed region runs without the per-kernel event markers
     for i in range(args.warmup):
         w = one_step(i, False)
         if w:
@@ -206,6 +218,7 @@ def main():
 
     # per-kernel durations (HIP events inside the library, on the launch stream), separate pass so
     # the event reads do not serialise the timed region
+    lib.set_kernel_timing(True)
     for i in range(min(args.steps, 10)):
         one_step(i, True)
     torch.cuda.synchronize()
@@ -288,7 +301,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": batch.name, **extra_cfg,
-                       "baseline_config": {"cfg3": "configs[2]", "cfg2": "configs[1]", "cfg4": "configs[3]", "cfg5": "configs[4]"}[args.workload],
+                       "baseline_config": {"cfg3": "configs[2]", "cfg2": "configs[1]", "cfg4": "configs[3]", "cfg5": "configs[4]",
+                                           "cfg1": "configs[0] (shape pair; GPU batch size)",
+                                           "cfg3u": "configs[2], one hull pair per query"}[args.workload],
                        "pairs_per_gpu_per_step": n, "contact_fraction": contact_frac, "buckets": buckets,
                        "request": batch.kind, "all_gather_results": bool(gather),
                        "lane_group_width": int(os.environ.get("HFCL_CVX_W", "4"))},

@@ -1399,6 +1399,8 @@ struct hfcl_lib {
   hfcl_guess *d_gin = nullptr, *d_gout = nullptr;
   // instrumentation
   std::vector<KernelTime> timers;
+  bool kernel_timing = true;         // HIP events around every kernel (hfcl_lib_set_kernel_timing)
+  uint32_t possible_buckets = ~0u;   // bit b: some pair of this library's shape kinds classifies into bucket b
   int cvx_w = 4;
   int n_cus = 256;
   std::string dominant;
@@ -1541,6 +1543,16 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
     s32[i].p3 = float(s.params[3]);
     s32[i].ssr = float(s.swept_sphere_radius);
     kinds[i] = uint8_t(s.type == HFCL_GEOM_CONVEX && s.num_points > (uint32_t)HULL_MAX ? K_CONVEX_LARGE : s.type);
+  }
+  {
+    bool present[256] = {false};
+    for (size_t i = 0; i < n_shapes; ++i) present[kinds[i]] = true;
+    uint32_t mask = 1u << B_UNSUPPORTED;  // shape ids out of range can always occur
+    for (int a = 0; a < 256; ++a)
+      if (present[a])
+        for (int b = 0; b < 256; ++b)
+          if (present[b]) mask |= 1u << bucket_of(a, b);
+    lib->possible_buckets = mask;
   }
   std::vector<float> v32(3 * n_vertices + 3);
   for (size_t i = 0; i < 3 * n_vertices; ++i) v32[i] = float(vertices[i]);
@@ -1803,19 +1815,30 @@ static int validate_query(const hfcl_query_request& q) {
 template <typename T, int W>
 static void launch_cvx(hfcl_lib* lib, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q,
                        hipStream_t st, size_t& ti, int grid) {
-  KernelTime* t;
-  t = timer_slot(lib, ti++, "k_gjk_cvx<cc>");
-  hipEventRecord(t->e0, st);
-  launch_gjk_cvx<W, 0>(grid, st, wk, lv, io, q);
-  hipEventRecord(t->e1, st);
-  t = timer_slot(lib, ti++, "k_gjk_cvx<pc>");
-  hipEventRecord(t->e0, st);
-  launch_gjk_cvx<W, 1>(grid, st, wk, lv, io, q);
-  hipEventRecord(t->e1, st);
-  t = timer_slot(lib, ti++, "k_gjk_cvx<cp>");
-  hipEventRecord(t->e0, st);
-  launch_gjk_cvx<W, 2>(grid, st, wk, lv, io, q);
-  hipEventRecord(t->e1, st);
+  KernelTime* t = nullptr;
+  auto tbeg = [&](const char* name) {
+    if (!lib->kernel_timing) return;
+    t = timer_slot(lib, ti++, name);
+    hipEventRecord(t->e0, st);
+  };
+  auto tend = [&]() {
+    if (lib->kernel_timing) hipEventRecord(t->e1, st);
+  };
+  if ((lib->possible_buckets >> B_CC) & 1u) {
+    tbeg("k_gjk_cvx<cc>");
+    launch_gjk_cvx<W, 0>(grid, st, wk, lv, io, q);
+    tend();
+  }
+  if ((lib->possible_buckets >> B_PC) & 1u) {
+    tbeg("k_gjk_cvx<pc>");
+    launch_gjk_cvx<W, 1>(grid, st, wk, lv, io, q);
+    tend();
+  }
+  if ((lib->possible_buckets >> B_CP) & 1u) {
+    tbeg("k_gjk_cvx<cp>");
+    launch_gjk_cvx<W, 2>(grid, st, wk, lv, io, q);
+    tend();
+  }
 }
 
 // The whole pipeline for one batch, asynchronous on `st`.
@@ -1856,21 +1879,33 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
     if (b > (size_t)max_blocks) b = max_blocks;
     return int(b);
   };
+  KernelTime* t = nullptr;
+  auto tbeg = [&](const char* name) {
+    if (!lib->kernel_timing) return;
+    t = timer_slot(lib, ti++, name);
+    hipEventRecord(t->e0, st);
+  };
+  auto tend = [&]() {
+    if (lib->kernel_timing) hipEventRecord(t->e1, st);
+  };
+  // buckets no pair of this library's shape kinds can fall into are not launched at all
+  auto may = [&](int b) { return (lib->possible_buckets >> b) & 1u; };
+  const bool any_gjk = may(B_PRIM) || may(B_CC) || may(B_PC) || may(B_CP) || may(B_LARGE);
   HIP_TRY(hipMemsetAsync(lib->d_counts, 0, (B_COUNT + 3) * sizeof(uint32_t), st));
-  KernelTime* t = timer_slot(lib, ti++, "k_classify");
-  hipEventRecord(t->e0, st);
+  tbeg("k_classify");
   hipLaunchKernelGGL(k_classify, dim3(blocks_for(n, 256 * 8)), dim3(256), 0, st, wk, lib->d_kinds, uint32_t(lib->n_shapes));
-  hipEventRecord(t->e1, st);
+  tend();
 
-  t = timer_slot(lib, ti++, "k_closed");
-  hipEventRecord(t->e0, st);
-  hipLaunchKernelGGL((k_closed<T>), dim3(blocks_for(n, 256)), dim3(256), 0, st, wk, lv, io, q);
-  hipEventRecord(t->e1, st);
-
-  t = timer_slot(lib, ti++, "k_gjk_prim");
-  hipEventRecord(t->e0, st);
-  hipLaunchKernelGGL((k_gjk_prim<T>), dim3(blocks_for(n, 256)), dim3(256), 0, st, wk, lv, io, q);
-  hipEventRecord(t->e1, st);
+  if (may(B_CLOSED)) {
+    tbeg("k_closed");
+    hipLaunchKernelGGL((k_closed<T>), dim3(blocks_for(n, 256)), dim3(256), 0, st, wk, lv, io, q);
+    tend();
+  }
+  if (may(B_PRIM)) {
+    tbeg("k_gjk_prim");
+    hipLaunchKernelGGL((k_gjk_prim<T>), dim3(blocks_for(n, 256)), dim3(256), 0, st, wk, lv, io, q);
+    tend();
+  }
 
   const int w = lib->cvx_w;
   const int cgrid = blocks_for(n, 256 / w);
@@ -1880,12 +1915,13 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   else if (w == 8) launch_cvx<T, 8>(lib, wk, lv, io, q, st, ti, cgrid);
   else launch_cvx<T, 4>(lib, wk, lv, io, q, st, ti, cgrid);
 
-  t = timer_slot(lib, ti++, "k_gjk_large");
-  hipEventRecord(t->e0, st);
-  hipLaunchKernelGGL((k_gjk_large<T>), dim3(blocks_for(n, 256 / LARGE_W)), dim3(256), 0, st, wk, lv, io, q);
-  hipEventRecord(t->e1, st);
+  if (may(B_LARGE)) {
+    tbeg("k_gjk_large");
+    hipLaunchKernelGGL((k_gjk_large<T>), dim3(blocks_for(n, 256 / LARGE_W)), dim3(256), 0, st, wk, lv, io, q);
+    tend();
+  }
 
-  if (!lib->h_meshes.empty()) {
+  if (!lib->h_meshes.empty() && (may(B_BVH) || may(B_BVHSHAPE))) {
     rc = upload_bvh(lib);
     if (rc) return rc;
     BvhView<T> bv;
@@ -1896,38 +1932,32 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
     bv.meshes = lib->d_meshes;
     bv.n_meshes = uint32_t(lib->h_meshes.size());
     if (q.mode == 1) {
-      t = timer_slot(lib, ti++, "k_bvh_shape");
-      hipEventRecord(t->e0, st);
+      tbeg("k_bvh_shape");
       hipLaunchKernelGGL((k_bvh_shape<T>), dim3(blocks_for(n / 8 + 1, 64 / BS_W)), dim3(64), 0, st, wk, lv, bv, io, q, lib->bvh_params,
                          T(lib->break_distance * lib->break_distance));
-      hipEventRecord(t->e1, st);
-      t = timer_slot(lib, ti++, "k_bvh_collide");
-      hipEventRecord(t->e0, st);
+      tend();
+      tbeg("k_bvh_collide");
       hipLaunchKernelGGL((k_bvh_collide<T>), dim3(blocks_for(n, BVH_BLOCK)), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q,
                          lib->bvh_params, T(lib->break_distance * lib->break_distance));
-      hipEventRecord(t->e1, st);
+      tend();
     } else {
-      t = timer_slot(lib, ti++, "k_bvh_shape_distance");
-      hipEventRecord(t->e0, st);
+      tbeg("k_bvh_shape_distance");
       hipLaunchKernelGGL((k_bvh_shape_distance<T>), dim3(blocks_for(n / 8 + 1, 64 / BS_W)), dim3(64), 0, st, wk, lv, bv, io, q);
-      hipEventRecord(t->e1, st);
-      t = timer_slot(lib, ti++, "k_bvh_distance");
-      hipEventRecord(t->e0, st);
+      tend();
+      tbeg("k_bvh_distance");
       hipLaunchKernelGGL((k_bvh_distance<T>), dim3(blocks_for(n, BVHD_BLOCK)), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q);
-      hipEventRecord(t->e1, st);
+      tend();
     }
   }
 
-  t = timer_slot(lib, ti++, "k_unsupported");
-  hipEventRecord(t->e0, st);
+  tbeg("k_unsupported");
   hipLaunchKernelGGL((k_unsupported<T>), dim3(blocks_for(n, 256 * 64)), dim3(256), 0, st, wk, io, int(B_UNSUPPORTED));
-  if (lib->h_meshes.empty())  // BVHModel x shape pairs without any registered mesh
+  if (lib->h_meshes.empty() && may(B_BVHSHAPE))  // BVHModel x shape pairs without any registered mesh
     hipLaunchKernelGGL((k_unsupported<T>), dim3(blocks_for(n, 256 * 64)), dim3(256), 0, st, wk, io, int(B_BVHSHAPE));
-  hipEventRecord(t->e1, st);
+  tend();
 
-  if (q.compute_penetration) {
-    t = timer_slot(lib, ti++, "k_epa<fast>");
-    hipEventRecord(t->e0, st);
+  if (q.compute_penetration && any_gjk) {
+    tbeg("k_epa<fast>");
     // fp32 streams (two waves per SIMD hide the refill's global loads: k_epa<fast> 1.87 -> 1.76 ms on cfg3);
     // fp64 runs one wave per SIMD, where the more frequent refills cost more than the idle groups (cfg5
     // 1.27 -> 1.55 ms), and stays with the batch form
@@ -1935,11 +1965,10 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
       hipLaunchKernelGGL((k_epa_stream<T, EPA_WE, EPA_FAST_CAP>), dim3(blocks_for(n, 64 / EPA_WE)), dim3(64), 0, st, wk, lv, io, q);
     else
       hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_fast_cap<T>, 1>), dim3(blocks_for(n, 64 / EPA_WE)), dim3(64), 0, st, wk, lv, io, q);
-    hipEventRecord(t->e1, st);
-    t = timer_slot(lib, ti++, "k_epa<full>");
-    hipEventRecord(t->e0, st);
+    tend();
+    tbeg("k_epa<full>");
     hipLaunchKernelGGL((k_epa<T, EPA_WE2, EPA_MAX_ITER, 2>), dim3(blocks_for(n / 16 + 1, 64 / EPA_WE2)), dim3(64), 0, st, wk, lv, io, q);
-    hipEventRecord(t->e1, st);
+    tend();
   }
   HIP_TRY(hipMemcpyAsync(lib->h_counts, lib->d_counts, (B_COUNT + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipGetLastError());
@@ -2227,6 +2256,12 @@ double hfcl_last_kernel_ms(hfcl_lib* lib) {
   return total;
 }
 const char* hfcl_last_kernel_name(hfcl_lib* lib) { return lib ? lib->dominant.c_str() : ""; }
+void hfcl_lib_set_kernel_timing(hfcl_lib* lib, int on) {
+  if (!lib) return;
+  lib->kernel_timing = on != 0;
+  if (!on)
+    for (auto& t : lib->timers) t.used = false;
+}
 
 // breakdown: up to `cap` (name, ms) entries of the last call; returns the number written
 int hfcl_last_kernel_breakdown(hfcl_lib* lib, const char** names, double* ms, int cap) {

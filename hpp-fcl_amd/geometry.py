@@ -11,13 +11,29 @@ class ShapeLibrary:
     """Flat table of shapes + one vertex array: the host image of hfcl_lib_create's inputs."""
 
     def __init__(self):
-        self._shapes = []
+        self._shapes = []   # pending single entries (tuples)
+        self._chunks = []   # finished SHAPE_DTYPE arrays, in shape-id order
+        self._count = 0
         self._verts = []
         self._nverts = 0
 
     def _add(self, type_, params=(0, 0, 0, 0), ssr=0.0, num_points=0, vertex_offset=0, bvh_index=0):
         self._shapes.append((type_, num_points, vertex_offset, bvh_index, (tuple(params) + (0, 0, 0, 0))[:4], ssr))
-        return len(self._shapes) - 1
+        self._count += 1
+        return self._count - 1
+
+    def _flush(self):
+        if self._shapes:
+            a = np.zeros(len(self._shapes), dtype=abi.SHAPE_DTYPE)
+            for i, (t, n, off, bi, p, ssr) in enumerate(self._shapes):
+                a[i]["type"] = t
+                a[i]["num_points"] = n
+                a[i]["vertex_offset"] = off
+                a[i]["bvh_index"] = bi
+                a[i]["params"] = p
+                a[i]["swept_sphere_radius"] = ssr
+            self._chunks.append(a)
+            self._shapes = []
 
     def add_box(self, x, y, z, swept_sphere_radius=0.0):
         """Box(x,y,z): halfSide = (x/2,y/2,z/2)   geometric_shapes.h:166"""
@@ -64,6 +80,24 @@ class ShapeLibrary:
         self._nverts += len(pts)
         return self._add(abi.GEOM_CONVEX, (0, 0, 0), swept_sphere_radius, len(pts), off)
 
+    def add_convex_many(self, points, swept_sphere_radius=0.0):
+        """m hulls of k points each from one (m, k, 3) array (bulk form of add_convex: one hull per
+        pair workloads carry millions of them).  Returns the id of the first."""
+        pts = np.ascontiguousarray(points, dtype=np.float64)
+        m, k = pts.shape[0], pts.shape[1]
+        self._flush()
+        a = np.zeros(m, dtype=abi.SHAPE_DTYPE)
+        a["type"] = abi.GEOM_CONVEX
+        a["num_points"] = k
+        a["vertex_offset"] = self._nverts + k * np.arange(m, dtype=np.uint32)
+        a["swept_sphere_radius"] = swept_sphere_radius
+        self._chunks.append(a)
+        self._verts.append(pts.reshape(-1, 3))
+        self._nverts += m * k
+        first = self._count
+        self._count += m
+        return first
+
     def add_triangle(self, a, b, c, swept_sphere_radius=0.0):
         pts = np.array([a, b, c], dtype=np.float64)
         off = self._nverts
@@ -75,18 +109,15 @@ class ShapeLibrary:
         return self._add(abi.BV_OBBRSS, (0, 0, 0), 0.0, num_vertices, 0, bvh_index)
 
     def __len__(self):
-        return len(self._shapes)
+        return self._count
 
     def shapes_array(self):
-        a = np.zeros(len(self._shapes), dtype=abi.SHAPE_DTYPE)
-        for i, (t, n, off, bi, p, ssr) in enumerate(self._shapes):
-            a[i]["type"] = t
-            a[i]["num_points"] = n
-            a[i]["vertex_offset"] = off
-            a[i]["bvh_index"] = bi
-            a[i]["params"] = p
-            a[i]["swept_sphere_radius"] = ssr
-        return a
+        self._flush()
+        if not self._chunks:
+            return np.zeros(0, dtype=abi.SHAPE_DTYPE)
+        if len(self._chunks) > 1:
+            self._chunks = [np.concatenate(self._chunks)]
+        return self._chunks[0]
 
     def vertices_array(self):
         if not self._verts:

@@ -140,6 +140,22 @@ def cfg3_convex_convex(n=1_000_000, seed=1, nlib=4096, half_width=1.0, nverts=32
                  {"gjk_variant": abi.NesterovAcceleration})
 
 
+def cfg3_unique_hulls(n=1_000_000, seed=1, half_width=1.0, nverts=32):
+    """cfg3, variant (ii) of SURVEY.md 8d: every pair brings its own two hulls (pair i = hulls 2i, 2i+1 of a
+    2n-hull library), so the 2 x 32 x 12 B of vertices are compulsory HBM traffic per query (876 B/query)."""
+    rng = _rng(seed, 33)
+    base = fibonacci_sphere(nverts)
+    radii = rng.uniform(0.1, 1.0, (2 * n, 1, 3))
+    lib = geometry.ShapeLibrary()
+    lib.add_convex_many(base[None, :, :] * radii)
+    s1 = 2 * np.arange(n, dtype=np.int64)
+    s2 = s1 + 1
+    q1, T1, q2, T2 = _poses(rng, n, half_width)
+    from . import abi
+    return Batch("cfg3_convex32_unique_hulls_distance_nesterov", lib, s1, s2, q1, T1, q2, T2, "distance",
+                 {"gjk_variant": abi.NesterovAcceleration})
+
+
 def _mixed_library(rng, nper):
     lib = geometry.ShapeLibrary()
     for s in rng.uniform(0.1, 1.0, (nper, 3)):

@@ -322,6 +322,9 @@ int hfcl_collide_batch_contacts(hfcl_lib* lib, const uint32_t* shape1, const uin
 double hfcl_last_kernel_ms(hfcl_lib* lib);
 /* Name of the dominant kernel of the last call (for matching rocprofv3 output). */
 const char* hfcl_last_kernel_name(hfcl_lib* lib);
+/* Per-kernel HIP events are recorded by default; a caller that does not read them can switch
+ * them off (on = 0) and save two stream markers per kernel launch. */
+void hfcl_lib_set_kernel_timing(hfcl_lib* lib, int on);
 
 #ifdef __cplusplus
 }
