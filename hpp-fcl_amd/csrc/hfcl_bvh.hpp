@@ -117,7 +117,7 @@ struct TriSupport {
 // ShapeShapeDistance<TriangleP,TriangleP>: returns the distance, fills world-frame p1,p2,normal.
 template <typename T>
 HFCL_HD T tri_tri_distance(const TriSupport<T>& tri, const GjkParams<T>& prm_in, bool cached_guess, const V3<T>& guess_c,
-                           V3<T>& p1, V3<T>& p2, V3<T>& normal, int& status, int& iters) {
+                           V3<T>& p1, V3<T>& p2, V3<T>& normal, int& status, int& iters, V3<T>* ray_out = nullptr) {
   GjkParams<T> prm = prm_in;  // fresh GJKSolver(request): DefaultGJK, Default/Relative criterion, no early stop
   prm.variant = VAR_DEFAULT;
   prm.crit = CRIT_DEFAULT;
@@ -129,6 +129,7 @@ HFCL_HD T tri_tri_distance(const TriSupport<T>& tri, const GjkParams<T>& prm_in,
   gjk_run(g, prm, guess, T(0), false, sup);
   status = g.status;
   iters = g.iterations;
+  if (ray_out) *ray_out = g.ray;  // solver->cached_guess = gjk.getGuessFromSimplex() (:80)
   // gjk.getWitnessPointsAndNormal for any rank (1..4); reference order: ref[i] = s[rank-1-i]
   typedef SimplexV<T, PW0<T>> SV;
   const int r = g.rank;

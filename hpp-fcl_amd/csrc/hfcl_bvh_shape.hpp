@@ -430,20 +430,93 @@ HFCL_HD T sphere_triangle(const DShape<T>& s, const Pose<T>& tf1, const V3<T>& P
   return hsqrt(mind) - radius;
 }
 
-// MinkowskiDiff of (TriangleP in the mesh frame, solid shape): shape 0 = the triangle.
+// MinkowskiDiff of (solid shape, TriangleP moved into the solid's frame): shape 0 = the solid, identity
+// relative transform (MinkowskiDiff::set(&s1, &tri), narrowphase.h:320-336).
 template <typename T, class Solid>
-struct TriSolidSupport {
-  V3<T> a, b, c;
+struct SolidTriSupport {
+  V3<T> a, b, c;       // the triangle in the solid's frame
   const Solid* solid;  // V3<T> (*solid)(dir): support of the solid in its own frame (NoSweptSphere)
-  MDiff<T> md;
   HFCL_HD void operator()(const V3<T>& dir, V3<T>& w, V3<T>& w0) const {
-    w0 = tri_support(a, b, c, dir);
-    const V3<T> d1 = md.identity ? -dir : -tmul(md.oR1, dir);
-    V3<T> s1 = (*solid)(d1);
-    s1 = md.identity ? s1 : (mul(md.oR1, s1) + md.ot1);
-    w = w0 - s1;
+    w0 = (*solid)(dir);
+    w = w0 - tri_support(a, b, c, -dir);
   }
 };
+
+// ShapeShapeDistance<TriangleP, S>(tri, tf_tri, solid, tf_solid) for the solids that go through GJK/EPA:
+// overload resolution in GJKSolver::shapeDistance (narrowphase.h:320-348) turns it into the swapped call
+// shapeDistance(solid, tf_solid, tri, tf_tri) with the triangle moved into the solid's frame by
+// tf_solid.inverseTimes(tf_tri), the relative transform precomputed (identity), and on return the points
+// exchanged and the normal negated.  `o` keeps the statuses / cached guess of that run (solid = shape 0);
+// p_tri / p_solid / n are the world-frame results in (triangle, solid) order.
+template <typename T, class Grp, class Solid>
+HFCL_HD T triangle_solid_distance(const V3<T>& ta, const V3<T>& tb, const V3<T>& tc, const Pose<T>& tft, const Pose<T>& tfs,
+                                  const Solid& solid, T r_solid, const QParams<T>& q, const V3<T>& guess0,
+                                  EpaScratch<T, EPA_MAX_ITER>* scratch, PairOut<T>& o, V3<T>& p_tri, V3<T>& p_solid, V3<T>& n) {
+  const MDiff<T> sMt = make_mdiff(tfs, tft);  // Transform3f::inverseTimes
+  SolidTriSupport<T, Solid> sup;
+  sup.a = mul(sMt.oR1, ta) + sMt.ot1;
+  sup.b = mul(sMt.oR1, tb) + sMt.ot1;
+  sup.c = mul(sMt.oR1, tc) + sMt.ot1;
+  sup.solid = &solid;
+  Gjk<T, PW0<T>> g;
+  gjk_run(g, q.gjk, guess0, r_solid, false, sup);
+  EpaSeed<T> seed;
+  if (gjk_finish(g, q, tfs, r_solid, T(0), guess0, o, seed)) {
+    Grp::sync();
+    epa_run<T, Grp, EPA_MAX_ITER>(scratch, seed, q, tfs, r_solid, T(0), sup, o);
+    Grp::sync();
+  }
+  p_tri = o.p2;
+  p_solid = o.p1;
+  n = -o.normal;
+  return o.distance;
+}
+
+// One top-level pair with a TriangleP on either side (not against Plane / Halfspace: closed forms):
+// TriangleP x TriangleP (triangle_triangle.cpp:46-105), TriangleP x Sphere (triangle_sphere.cpp:45-68), and
+// the GJK solids through triangle_solid_distance.  `solid` = support of the non-triangle shape.
+template <typename T, class Grp, class Solid>
+HFCL_HD void triangle_pair(const DShape<T>& a, const DShape<T>& b, const T* verts, const Pose<T>& tf1, const Pose<T>& tf2,
+                           const Solid& solid, const QParams<T>& q, const V3<T>& guess_in,
+                           EpaScratch<T, EPA_MAX_ITER>* scratch, PairOut<T>& o) {
+  auto vtx = [&](const DShape<T>& s, uint32_t i) {
+    const T* p = verts + 3 * (size_t(s.vertex_offset) + i);
+    return mk<T>(p[0], p[1], p[2]);
+  };
+  o.gjk_status = GJK_DID_NOT_RUN;
+  o.epa_status = EPA_DID_NOT_RUN;
+  o.gjk_iters = o.epa_iters = 0;
+  o.cached_guess = guess_in;
+  const bool t1 = a.kind == K_TRIANGLE, t2 = b.kind == K_TRIANGLE;
+  if (t1 && t2) {
+    TriSupport<T> ts;
+    ts.p1 = xform(tf1, vtx(a, 0)); ts.p2 = xform(tf1, vtx(a, 1)); ts.p3 = xform(tf1, vtx(a, 2));
+    ts.q1 = xform(tf2, vtx(b, 0)); ts.q2 = xform(tf2, vtx(b, 1)); ts.q3 = xform(tf2, vtx(b, 2));
+    o.distance = tri_tri_distance(ts, q.gjk, q.guess_mode == HFCL_GUESS_CACHED, guess_in, o.p1, o.p2, o.normal, o.gjk_status,
+                                  o.gjk_iters, &o.cached_guess);
+    return;
+  }
+  const DShape<T>& tri = t1 ? a : b;
+  const DShape<T>& sol = t1 ? b : a;
+  const Pose<T>& tft = t1 ? tf1 : tf2;
+  const Pose<T>& tfs = t1 ? tf2 : tf1;
+  const V3<T> ta = vtx(tri, 0), tb = vtx(tri, 1), tc = vtx(tri, 2);
+  V3<T> p_tri, p_solid, n;  // n: from the triangle to the solid
+  if (sol.kind == K_SPHERE) {
+    o.distance = sphere_triangle(sol, tfs, xform(tft, ta), xform(tft, tb), xform(tft, tc), p_solid, p_tri, n);
+    n = -n;
+  } else {
+    const V3<T> guess0 = (q.guess_mode == HFCL_GUESS_CACHED) ? guess_in : mk<T>(T(1), T(0), T(0));
+    PairOut<T> og;
+    const T d = triangle_solid_distance<T, Grp>(ta, tb, tc, tft, tfs, solid, swept_radius(sol), q, guess0, scratch, og, p_tri,
+                                                p_solid, n);
+    o = og;
+    o.distance = d;
+  }
+  o.p1 = t1 ? p_tri : p_solid;
+  o.p2 = t1 ? p_solid : p_tri;
+  o.normal = t1 ? n : -n;
+}
 
 template <typename T>
 struct MeshShapeState {  // the CollisionResult fields the traversal maintains
@@ -476,7 +549,6 @@ HFCL_HD void mesh_shape_collide(const DNode<T>* nodes, const T* mverts, const ui
     st.unsupported = true;
     return;
   }
-  const MDiff<T> md = make_mdiff(tfm, tfs);
   const T r1 = swept_radius(shape);
   int sp = 0;
   Grp::sync();
@@ -526,26 +598,9 @@ HFCL_HD void mesh_shape_collide(const DNode<T>* nodes, const T* mverts, const ui
       distance = flat_triangle_distance(shape, tfs, ta, tb, tc, tfm, p2, p1, n);
       n = -n;
     } else {
-      TriSolidSupport<T, Solid> sup;
-      sup.a = ta;
-      sup.b = tb;
-      sup.c = tc;
-      sup.solid = &solid;
-      sup.md = md;
       const V3<T> guess0 = (q.guess_mode == HFCL_GUESS_CACHED) ? st.guess : mk<T>(T(1), T(0), T(0));
-      Gjk<T, PW0<T>> g;
-      gjk_run(g, q.gjk, guess0, r1, false, sup);
       PairOut<T> o;
-      EpaSeed<T> seed;
-      if (gjk_finish(g, q, tfm, T(0), r1, guess0, o, seed)) {
-        Grp::sync();
-        epa_run<T, Grp, EPA_MAX_ITER>(scratch, seed, q, tfm, T(0), r1, sup, o);
-        Grp::sync();
-      }
-      distance = o.distance;
-      p1 = o.p1;
-      p2 = o.p2;
-      n = o.normal;
+      distance = triangle_solid_distance<T, Grp>(ta, tb, tc, tfm, tfs, solid, r1, q, guess0, scratch, o, p1, p2, n);
       // GJK::Collision without penetration information leaves the solver's cached guess untouched
       // (narrowphase.h:638-656): the previous leaf's value persists
       if (!(o.gjk_status == GJK_COLLISION && !q.compute_penetration)) st.guess = o.cached_guess;
@@ -601,7 +656,6 @@ HFCL_HD void mesh_shape_distance(const DNode<T>* nodes, const DRss<T>* rss, cons
     st.unsupported = true;
     return;
   }
-  const MDiff<T> md = make_mdiff(tfm, tfs);
   const T r1 = swept_radius(shape);
   auto leaf = [&](uint32_t prim) {
     const uint32_t* t3 = tris + 3 * size_t(prim);
@@ -616,26 +670,9 @@ HFCL_HD void mesh_shape_distance(const DNode<T>* nodes, const DRss<T>* rss, cons
       distance = flat_triangle_distance(shape, tfs, ta, tb, tc, tfm, p2, p1, n);
       n = -n;
     } else {
-      TriSolidSupport<T, Solid> sup;
-      sup.a = ta;
-      sup.b = tb;
-      sup.c = tc;
-      sup.solid = &solid;
-      sup.md = md;
       const V3<T> guess0 = (q.guess_mode == HFCL_GUESS_CACHED) ? st.guess : mk<T>(T(1), T(0), T(0));
-      Gjk<T, PW0<T>> g;
-      gjk_run(g, q.gjk, guess0, r1, false, sup);
       PairOut<T> o;
-      EpaSeed<T> seed;
-      if (gjk_finish(g, q, tfm, T(0), r1, guess0, o, seed)) {
-        Grp::sync();
-        epa_run<T, Grp, EPA_MAX_ITER>(scratch, seed, q, tfm, T(0), r1, sup, o);
-        Grp::sync();
-      }
-      distance = o.distance;
-      p1 = o.p1;
-      p2 = o.p2;
-      n = o.normal;
+      distance = triangle_solid_distance<T, Grp>(ta, tb, tc, tfm, tfs, solid, r1, q, guess0, scratch, o, p1, p2, n);
       // GJK::Collision without penetration information leaves the solver's cached guess untouched
       // (narrowphase.h:638-656): the previous leaf's value persists
       if (!(o.gjk_status == GJK_COLLISION && !q.compute_penetration)) st.guess = o.cached_guess;

@@ -66,7 +66,7 @@ using namespace hfcl;
 // bucket ids (finer than hfcl_shapes.hpp's pair_class: the convex bucket is split by which
 // side carries vertices so the kernel is specialised at compile time)
 // ---------------------------------------------------------------------------------------
-enum { B_CLOSED = 0, B_PRIM = 1, B_CC = 2, B_PC = 3, B_CP = 4, B_BVH = 5, B_UNSUPPORTED = 6, B_LARGE = 7, B_BVHSHAPE = 8, B_COUNT = 9 };
+enum { B_CLOSED = 0, B_PRIM = 1, B_CC = 2, B_PC = 3, B_CP = 4, B_BVH = 5, B_UNSUPPORTED = 6, B_LARGE = 7, B_BVHSHAPE = 8, B_TRI = 9, B_COUNT = 10 };
 
 // Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
 // support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
@@ -80,6 +80,11 @@ __host__ __device__ inline int bucket_of(int k1, int k2) {
   if ((k1 == K_BVH) != (k2 == K_BVH)) {  // BVHModel x convex solid, either operand order (k_bvh_shape)
     const int o = (k1 == K_BVH) ? k2 : k1;
     return (kind_is_prim(o) || o == K_CONVEX || kind_is_flat(o)) ? B_BVHSHAPE : B_UNSUPPORTED;
+  }
+  if ((k1 == K_TRIANGLE || k2 == K_TRIANGLE) && !kind_is_flat(k1) && !kind_is_flat(k2)) {
+    // top-level TriangleP rows of the table (collision_func_matrix.cpp:295-469): k_triangle
+    const int o = (k1 == K_TRIANGLE) ? k2 : k1;
+    return (o == K_TRIANGLE || kind_is_prim(o) || o == K_CONVEX) ? B_TRI : B_UNSUPPORTED;
   }
   const int c = pair_class(k1, k2);
   if (large && c == CLS_CONVEX) return B_LARGE;
@@ -1153,6 +1158,38 @@ __global__ void __launch_bounds__(64) k_bvh_shape(Work wk, LibView<T> lib, BvhVi
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_triangle: top-level TriangleP pairs (other than against Plane / Halfspace, which are closed forms):
+// TriangleP x TriangleP (triangle_triangle.cpp:46-105), TriangleP x Sphere (triangle_sphere.cpp:45-68) and
+// TriangleP x {Box, Capsule, Cone, Cylinder, Ellipsoid, ConvexBase} through GJKSolver::shapeDistance's
+// TriangleP overloads (narrowphase.h:320-348).  One pair per BS_W-lane group, as the mesh x solid leaves.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64) k_triangle(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  constexpr int G = 64 / BS_W;
+  __shared__ EpaScratch<T, EPA_MAX_ITER> scratch[G];
+  const uint32_t cnt = wk.counts[B_TRI];
+  const int lane = threadIdx.x & 63, grp = lane / BS_W, lig = lane & (BS_W - 1);
+  for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += gridDim.x * G) {
+    const uint32_t pair = wk.lists[size_t(B_TRI) * wk.n + it];
+    const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    const bool t1 = a.kind == K_TRIANGLE;
+    GroupSolid<T> solid;  // the non-triangle shape (unused for TriangleP x TriangleP)
+    solid.s = t1 ? b : a;
+    solid.v = lib.verts + 3 * size_t(solid.s.vertex_offset);
+    solid.lig = lig;
+    if (solid.s.kind == K_CONVEX && solid.s.num_points <= uint32_t(HULL_MAX)) solid.h.load(solid.v, solid.s.num_points, lig);
+    PairOut<T> o;
+    triangle_pair<T, LaneGroup<BS_W>>(a, b, lib.verts, tf1, tf2, solid, q, initial_guess<T>(io, q, pair), &scratch[grp], o);
+    if (lig == 0) {
+      write_out<T>(io, q, pair, o);
+      write_guess<T>(io, pair, o.cached_guess, 0, 0);
+    }
+    LaneGroup<BS_W>::sync();
+  }
+}
+
 // distance() counterpart: same lane-group layout, RSS lower bounds instead of OBB overlap tests.
 template <typename T>
 __global__ void __launch_bounds__(64) k_bvh_shape_distance(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q) {
@@ -1921,6 +1958,12 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
     tend();
   }
 
+  if (may(B_TRI)) {
+    tbeg("k_triangle");
+    hipLaunchKernelGGL((k_triangle<T>), dim3(blocks_for(n / 8 + 1, 64 / BS_W)), dim3(64), 0, st, wk, lv, io, q);
+    tend();
+  }
+
   if (!lib->h_meshes.empty() && (may(B_BVH) || may(B_BVHSHAPE))) {
     rc = upload_bvh(lib);
     if (rc) return rc;
@@ -2282,8 +2325,8 @@ int hfcl_last_kernel_breakdown(hfcl_lib* lib, const char** names, double* ms, in
 
 // bucket populations of the last call (after a stream sync): closed, prim, cc, pc, cp, bvh, unsupported,
 // epa queue, epa overflow queue
-void hfcl_last_bucket_counts(hfcl_lib* lib, uint32_t* out10) {  // B_COUNT buckets + the two EPA queues
-  for (int i = 0; i <= B_COUNT + 1; ++i) out10[i] = lib ? lib->h_counts[i] : 0;
+void hfcl_last_bucket_counts(hfcl_lib* lib, uint32_t* out12) {  // B_COUNT buckets + the two EPA queues
+  for (int i = 0; i <= B_COUNT + 1; ++i) out12[i] = lib ? lib->h_counts[i] : 0;
 }
 
 }  // extern "C"

@@ -260,7 +260,7 @@ class Library:
         return [(names[i].decode(), float(ms[i])) for i in range(k)]
 
     def last_bucket_counts(self):
-        out = (C.c_uint32 * 11)()
+        out = (C.c_uint32 * 12)()
         dll().hfcl_last_bucket_counts(self._h, out)
-        keys = ["closed", "prim", "cc", "pc", "cp", "bvh", "unsupported", "large", "bvh_shape", "epa_queue", "epa_overflow"]
+        keys = ["closed", "prim", "cc", "pc", "cp", "bvh", "unsupported", "large", "bvh_shape", "tri", "epa_queue", "epa_overflow"]
         return dict(zip(keys, [int(v) for v in out]))

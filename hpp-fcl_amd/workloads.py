@@ -186,6 +186,32 @@ def all_primitives(n=100_000, seed=1, nper=128, half_width=0.8, kind="collide"):
     return Batch("all_primitives_" + kind, lib, s1, s2, q1, T1, q2, T2, kind)
 
 
+def triangle_pairs(n=50_000, seed=1, nper=48, half_width=0.45, kind="distance"):
+    """Top-level TriangleP rows of the dispatch table (collision_func_matrix.cpp:295-469): a TriangleP against
+    every solid kind, both operand orders, and TriangleP x TriangleP."""
+    rng = _rng(seed, 9)
+    lib = _mixed_library(rng, nper)
+    for r, lz in zip(rng.uniform(0.1, 0.8, nper), rng.uniform(0.2, 1.0, nper)):
+        lib.add_cone(float(r), float(lz))
+    for r, lz in zip(rng.uniform(0.1, 0.8, nper), rng.uniform(0.2, 1.0, nper)):
+        lib.add_cylinder(float(r), float(lz))
+    base48 = fibonacci_sphere(48)
+    for radii in rng.uniform(0.1, 1.0, (nper, 3)):
+        lib.add_convex(base48 * radii)  # above the 32-vertex threshold: scanned from memory
+    n_solid = 8 * nper
+    ntri = 4 * nper
+    for k in range(ntri):
+        c = rng.uniform(-0.3, 0.3, 3)
+        lib.add_triangle(*(c + rng.uniform(-0.6, 0.6, (3, 3))))
+    other = rng.integers(0, n_solid + ntri, n)  # a solid or another triangle
+    tri = n_solid + rng.integers(0, ntri, n)
+    first = rng.integers(0, 2, n).astype(bool)
+    s1 = np.where(first, tri, other)
+    s2 = np.where(first, other, tri)
+    q1, T1, q2, T2 = _poses(rng, n, half_width)
+    return Batch("triangle_pairs_" + kind, lib, s1, s2, q1, T1, q2, T2, kind)
+
+
 def flat_pairs(n=50_000, seed=1, nper=64, half_width=1.0, kind="collide"):
     """Plane / Halfspace rows of the dispatch table: (solid, flat), (flat, solid) and (flat, flat) pairs, the
     solids being every other supported kind (some with a swept-sphere radius)."""

@@ -636,6 +636,22 @@ static double compute_penetration_tri(const V3& P1, const V3& P2, const V3& P3, 
   return std::max(depth1, std::max(depth2, depth3));
 }
 
+// GJKSolver::shapeDistance(const S1&, tf1, const TriangleP&, tf2, ...), narrowphase.h:320-336
+static double solid_triangle(const Shape& s1, const Tf& tf1, const Shape& tri, const Tf& tf2, const GJKSolver& sv,
+                             bool compute_penetration, V3& p1, V3& p2, V3& normal) {
+  const Tf tf_1M2 = inverse_times(tf1, tf2);
+  double t[9];
+  for (int k = 0; k < 3; ++k) {
+    const V3 v = tf_1M2.transform(V3(tri.verts[3 * k], tri.verts[3 * k + 1], tri.verts[3 * k + 2]));
+    t[3 * k] = v[0];
+    t[3 * k + 1] = v[1];
+    t[3 * k + 2] = v[2];
+  }
+  Shape moved = tri;
+  moved.verts = t;
+  return sv.run_gjk_epa(s1, tf1, moved, tf_1M2, compute_penetration, p1, p2, normal, /*relative_precomputed=*/true);
+}
+
 // ShapeShapeDistance<TriangleP,TriangleP>, src/distance/triangle_triangle.cpp:46-105
 static double triangle_triangle(const Shape& s1, const Tf& tf1, const Shape& s2, const Tf& tf2, const GJKSolver& sv,
                                 V3& p1, V3& p2, V3& normal) {
@@ -767,9 +783,17 @@ bool shape_shape_distance(const Shape& s1, const Tf& tf1, const Shape& s2, const
     return true;
   }
   // TriangleP against the other solids: generic GJK/EPA (the "1" entries of the triangle column,
-  // shape_shape_func.h:185-211); TriangleP is not a ConvexBase: no support-direction normalisation
-  if ((s1.kind == K_TRIANGLE && is_gjk_kind(s2.kind)) || (is_gjk_kind(s1.kind) && s2.kind == K_TRIANGLE)) {
-    dist = solver.run_gjk_epa(s1, tf1, s2, tf2, compute_signed_distance, p1, p2, normal);
+  // shape_shape_func.h:185-211) through GJKSolver::shapeDistance's TriangleP overloads (narrowphase.h:320-348):
+  // the solid is always shape 0 of the Minkowski difference, the triangle is moved into the solid's frame
+  // (relative transform precomputed = identity), and (TriangleP, S) is the swapped call with the points
+  // exchanged and the normal negated.  TriangleP is not a ConvexBase: no support-direction normalisation.
+  if (is_gjk_kind(s1.kind) && s2.kind == K_TRIANGLE) {
+    dist = solid_triangle(s1, tf1, s2, tf2, solver, compute_signed_distance, p1, p2, normal);
+    return true;
+  }
+  if (s1.kind == K_TRIANGLE && is_gjk_kind(s2.kind)) {  // narrowphase.h:339-348
+    dist = solid_triangle(s2, tf2, s1, tf1, solver, compute_signed_distance, p2, p1, normal);
+    normal = -normal;
     return true;
   }
   if (is_gjk_kind(s1.kind) && is_gjk_kind(s2.kind)) {

@@ -46,6 +46,16 @@ static void fill_q(QParams<T>& q, const hfcl_query_request& r) {
 }
 
 template <typename T>
+struct TriPairSolid {  // support of the non-triangle shape of a top-level TriangleP pair, in its own frame
+  DShape<T> s;
+  const T* verts;
+  V3<T> operator()(const V3<T>& d) const {
+    SerialSupport<T> ss;
+    return ss.one(s, verts + 3 * size_t(s.vertex_offset), d);
+  }
+};
+
+template <typename T>
 static void one_pair(const DShape<T>& a, const DShape<T>& b, const T* verts, const Pose<T>& tf1, const Pose<T>& tf2,
                      const QParams<T>& q, const V3<T>& guess0, PairOut<T>& o, bool& contact, int& nc, bool& skipped) {
   skipped = false;
@@ -80,6 +90,15 @@ static void one_pair(const DShape<T>& a, const DShape<T>& b, const T* verts, con
         epa_run<T, SerialGroup<1>, EPA_MAX_ITER>(&full, seed, q, tf1, r0, r1, sup, o);
       }
     }
+  } else if ((a.kind == K_TRIANGLE || b.kind == K_TRIANGLE) && cls != CLS_BVH) {
+    const DShape<T>& other = (a.kind == K_TRIANGLE) ? b : a;
+    if (!(other.kind == K_TRIANGLE || kind_is_prim(other.kind) || other.kind == K_CONVEX)) {
+      skipped = true;
+      return;
+    }
+    static thread_local EpaScratch<T, EPA_MAX_ITER> full;
+    TriPairSolid<T> hs{other, verts};
+    triangle_pair<T, SerialGroup<1>>(a, b, verts, tf1, tf2, hs, q, guess0, &full, o);
   } else {
     skipped = true;
     return;

@@ -8,7 +8,7 @@ import pytest
 from compare import check_parity, check_properties
 
 
-CASES = ["cfg1_sphere_sphere", "cfg2_box_capsule", "cfg3_convex_convex", "cfg5_mixed", "all_primitives"]
+CASES = ["cfg1_sphere_sphere", "cfg2_box_capsule", "cfg3_convex_convex", "cfg5_mixed", "all_primitives", "triangle_pairs"]
 
 
 def _oracle(oracle, b, req, tf1, tf2):
@@ -27,7 +27,14 @@ def test_fp64_core_matches_oracle(pkg, oracle, hostsim, case):
     # both are fp64 without FMA contraction: in practice they agree to the last bits
     assert st["max_dd"] < 1e-12
     assert np.array_equal(got["status"], ref["status"])
-    check_properties(abi, got, tol=1e-6, name=case)
+    keep = np.ones(len(b), dtype=bool)
+    if case == "triangle_pairs":
+        # penetrating TriangleP x TriangleP: the reference reports -computePenetration along triangle 1's normal
+        # next to GJK's (coinciding) witness points (triangle_triangle.cpp:88-92): p2 = p1 + d n does not apply
+        k1, k2 = b.shapes["type"][b.s1], b.shapes["type"][b.s2]
+        keep = ~((k1 == abi.GEOM_TRIANGLE) & (k2 == abi.GEOM_TRIANGLE) & (ref["distance"] <= 0))
+        assert 0.15 < abi.status_contact(ref["status"]).mean() < 0.6
+    check_properties(abi, got[keep], tol=1e-6, name=case)
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2])

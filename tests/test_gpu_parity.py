@@ -166,7 +166,7 @@ def test_edge_cases(pkg, oracle):
     # unsupported pair kinds are reported, not silently computed
     Lb = pkg.ShapeLibrary()
     t = Lb.add_triangle([0, 0, 0], [1, 0, 0], [0, 1, 0])
-    b2 = Lb.add_box(1, 1, 1)
+    b2 = Lb.add_bvh(0)  # (TriangleP, BVHModel) is not in the reference's function matrices either
     lib2 = pkg.Library(Lb)
     with pytest.raises(pkg.EngineError) as e:
         lib2.distance([t], [b2], [g.make_pose()], [g.make_pose()])
