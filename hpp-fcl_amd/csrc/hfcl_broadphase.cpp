@@ -42,6 +42,25 @@ Box3 shape_local_box(const hfcl_shape& s, const double* verts) {
     }
   };
   switch (s.type) {
+    case HFCL_GEOM_HALFSPACE:
+    case HFCL_GEOM_PLANE: {
+      // computeBV<AABB, Halfspace|Plane> in the shape's own frame (geometric_shapes_utility.cpp:391-455): the volume
+      // is unbounded (+-DBL_MAX) except along a coordinate axis the normal is aligned with
+      const double big = std::numeric_limits<double>::max();
+      for (int k = 0; k < 3; ++k) {
+        b.lo[k] = -big;
+        b.hi[k] = big;
+      }
+      const double* n = s.params;
+      const int axis = (n[1] == 0.0 && n[2] == 0.0) ? 0 : (n[0] == 0.0 && n[2] == 0.0) ? 1 : (n[0] == 0.0 && n[1] == 0.0) ? 2 : -1;
+      if (axis >= 0 && n[axis] != 0.0) {
+        const double v = n[axis] < 0 ? -s.params[3] : s.params[3];
+        if (s.type == HFCL_GEOM_PLANE) b.lo[axis] = b.hi[axis] = v;
+        else if (n[axis] < 0) b.lo[axis] = v;
+        else b.hi[axis] = v;
+      }
+      break;
+    }
     case HFCL_GEOM_BOX:
     case HFCL_GEOM_ELLIPSOID: symmetric(s.params[0], s.params[1], s.params[2]); break;
     case HFCL_GEOM_SPHERE: symmetric(s.params[0], s.params[0], s.params[0]); break;
@@ -100,6 +119,12 @@ int pick_threads(int n_threads) {
   return int(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32));
 }
 
+// twice the centre of [lo, hi]; unbounded boxes (Plane / Halfspace objects: +-DBL_MAX, +-inf after a rotation) sort as 0
+inline double centre2(double lo, double hi) {
+  const double c = lo + hi;
+  return std::isfinite(c) ? c : 0.0;
+}
+
 // Static box tree over object centres (implicit layout: node k covers ids_[first, first+count)).
 struct BoxTree {
   struct Node {
@@ -136,7 +161,7 @@ struct BoxTree {
         for (int a = 0; a < 3; ++a) {
           nd.box[a] = std::min(nd.box[a], q[a]);
           nd.box[3 + a] = std::max(nd.box[3 + a], q[3 + a]);
-          const double c = q[a] + q[3 + a];
+          const double c = centre2(q[a], q[3 + a]);
           clo[a] = std::min(clo[a], c);
           chi[a] = std::max(chi[a], c);
         }
@@ -149,8 +174,8 @@ struct BoxTree {
         const uint32_t half = nd.count / 2;
         uint32_t* base = ids.data() + nd.first;
         std::nth_element(base, base + half, base + nd.count, [&](uint32_t x, uint32_t y) {
-          const double cx = boxes[6 * size_t(x) + ax] + boxes[6 * size_t(x) + 3 + ax];
-          const double cy = boxes[6 * size_t(y) + ax] + boxes[6 * size_t(y) + 3 + ax];
+          const double cx = centre2(boxes[6 * size_t(x) + ax], boxes[6 * size_t(x) + 3 + ax]);
+          const double cy = centre2(boxes[6 * size_t(y) + ax], boxes[6 * size_t(y) + 3 + ax]);
           return cx < cy || (cx == cy && x < y);
         });
         nd.left = int32_t(nodes.size());
@@ -202,7 +227,8 @@ int hfcl_world_aabbs(const hfcl_shape* shapes, size_t n_shapes, const double* ve
   for (size_t s = 0; s < n_shapes; ++s) {
     const int t = shapes[s].type;
     if (t != HFCL_GEOM_BOX && t != HFCL_GEOM_SPHERE && t != HFCL_GEOM_CAPSULE && t != HFCL_GEOM_ELLIPSOID &&
-        t != HFCL_GEOM_CONVEX && t != HFCL_GEOM_TRIANGLE && t != HFCL_GEOM_CONE && t != HFCL_GEOM_CYLINDER)
+        t != HFCL_GEOM_CONVEX && t != HFCL_GEOM_TRIANGLE && t != HFCL_GEOM_CONE && t != HFCL_GEOM_CYLINDER &&
+        t != HFCL_GEOM_PLANE && t != HFCL_GEOM_HALFSPACE)
       return HFCL_ERR_UNSUPPORTED_PAIR;
     if ((t == HFCL_GEOM_CONVEX || t == HFCL_GEOM_TRIANGLE) && (!vertices || shapes[s].num_points == 0))
       return HFCL_ERR_INVALID_ARGUMENT;

@@ -219,6 +219,13 @@ class ConvexBase : public ShapeBase {
   NODE_TYPE getNodeType() const override { return GEOM_CONVEX; }
 };
 
+class TriangleP : public ShapeBase {  // geometric_shapes.h:98-134
+ public:
+  TriangleP(const Vec3f& a_, const Vec3f& b_, const Vec3f& c_) : a(a_), b(b_), c(c_) {}
+  Vec3f a, b, c;
+  NODE_TYPE getNodeType() const override { return GEOM_TRIANGLE; }
+};
+
 struct Triangle {  // include/hpp/fcl/data_types.h:101-144
   typedef std::size_t index_type;
   Triangle() : vids{0, 0, 0} {}
@@ -440,6 +447,12 @@ class BatchQueries {
         auto* c = static_cast<const ConvexBase*>(g);
         s.num_points = c->num_points;
         for (const Vec3f& p : *c->points) v.insert(v.end(), p.data(), p.data() + 3);
+        break;
+      }
+      case GEOM_TRIANGLE: {
+        auto* t = static_cast<const TriangleP*>(g);
+        s.num_points = 3;
+        for (const Vec3f* p : {&t->a, &t->b, &t->c}) v.insert(v.end(), p->data(), p->data() + 3);
         break;
       }
       case BV_OBBRSS: {

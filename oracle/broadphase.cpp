@@ -17,7 +17,40 @@
 
 namespace {
 
+// Plane / Halfspace: computeBV<AABB, Halfspace|Plane> with tf = identity (geometric_shapes_utility.cpp:391-455):
+// unbounded (+-DBL_MAX) except along an axis the normal is aligned with.
+bool flat_local_aabb(const hfcl_shape& s, double mn[3], double mx[3]) {
+  if (s.type != HFCL_GEOM_HALFSPACE && s.type != HFCL_GEOM_PLANE) return false;
+  const double big = std::numeric_limits<double>::max();
+  const double* n = s.params;
+  const double d = s.params[3];
+  for (int k = 0; k < 3; ++k) {
+    mn[k] = -big;
+    mx[k] = big;
+  }
+  int axis = -1;
+  if (n[1] == 0.0 && n[2] == 0.0) axis = 0;
+  else if (n[0] == 0.0 && n[2] == 0.0) axis = 1;
+  else if (n[0] == 0.0 && n[1] == 0.0) axis = 2;
+  if (axis >= 0) {
+    if (s.type == HFCL_GEOM_HALFSPACE) {
+      if (n[axis] < 0) mn[axis] = -d;
+      else if (n[axis] > 0) mx[axis] = d;
+    } else {
+      if (n[axis] < 0) mn[axis] = mx[axis] = -d;
+      else if (n[axis] > 0) mn[axis] = mx[axis] = d;
+    }
+  }
+  if (s.swept_sphere_radius > 0)  // geometric_shapes.cpp:222-243
+    for (int k = 0; k < 3; ++k) {
+      mn[k] -= s.swept_sphere_radius;
+      mx[k] += s.swept_sphere_radius;
+    }
+  return true;
+}
+
 void local_aabb(const hfcl_shape& s, const double* verts, double mn[3], double mx[3]) {
+  if (flat_local_aabb(s, mn, mx)) return;
   double d[3] = {0, 0, 0};
   bool have = true;
   switch (s.type) {

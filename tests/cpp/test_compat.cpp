@@ -148,6 +148,24 @@ int main() {
     DistanceRequest dq; DistanceResult dr;
     CHECK(std::fabs(distance(&cy, Transform3f(), &cy, Transform3f(Vec3f(40, 0, 0)), dq, dr) - 30) < 1e-3);
   }
+  {  // collide_spheretriangle (geometric_shapes.cpp:844-880) + a TriangleP against a GJK solid
+    STAGE("TriangleP");
+    Sphere s(10);
+    TriangleP tri(Vec3f(20, 0, 0), Vec3f(-20, 0, 0), Vec3f(0, 20, 0));
+    CollisionRequest rq; CollisionResult rs;
+    CHECK(collide(&s, Transform3f(), &tri, Transform3f(Vec3f(0, 0, 0.001)), rq, rs) == 1);
+    CHECK(std::fabs(rs.getContact(0).normal[2] - 1) < 1e-9);
+    rs.clear();
+    CHECK(collide(&tri, Transform3f(Vec3f(0, 0, -0.001)), &s, Transform3f(), rq, rs) == 1);
+    CHECK(std::fabs(rs.getContact(0).normal[2] - 1) < 1e-9);  // from the triangle (below) towards the sphere
+    Box b(2, 2, 2);
+    DistanceRequest dq; DistanceResult dr;
+    CHECK(std::fabs(distance(&b, Transform3f(), &tri, Transform3f(Vec3f(0, 0, 3)), dq, dr) - 2) < 1e-6);
+    CHECK(std::fabs(dr.normal[2] - 1) < 1e-6 && std::fabs(dr.nearest_points[1][2] - 3) < 1e-6);
+    dr.clear();
+    CHECK(std::fabs(distance(&tri, Transform3f(Vec3f(0, 0, 3)), &b, Transform3f(), dq, dr) - 2) < 1e-6);
+    CHECK(std::fabs(dr.normal[2] + 1) < 1e-6 && std::fabs(dr.nearest_points[0][2] - 3) < 1e-6);
+  }
   {  // broadphase hand-off: manager + CollisionCallBackCollect, then one device batch (test/broadphase.cpp style)
     STAGE("broadphase");
     std::vector<std::shared_ptr<CollisionGeometry>> geoms;

@@ -95,3 +95,35 @@ def test_gpu_narrowphase_on_broadphase_pairs(pkg, oracle):
     compare.check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name="cfg5-broadphase")
     assert 0.05 < (ref["num_contacts"] > 0).mean() < 0.9
     lib.close()
+
+
+def test_plane_and_halfspace_objects(pkg, oracle):
+    """Plane / Halfspace objects: unbounded local AABBs (computeBV<AABB, Halfspace|Plane>,
+    geometric_shapes_utility.cpp:391-455; bounded only along an axis the normal is aligned with), posed by
+    CollisionObject::computeAABB like any other; the candidate set is still the brute-force AABB-overlap set."""
+    g = pkg.geometry
+    rng = np.random.default_rng(6)
+    L = g.ShapeLibrary()
+    for s in rng.uniform(0.1, 0.6, (40, 3)):
+        L.add_box(*map(float, s))
+    flats = [L.add_halfspace([0, 0, 1], -1.0), L.add_halfspace([0, 0, -1], 0.5), L.add_plane([1, 0, 0], 0.3),
+             L.add_plane([0, -2, 0], 0.4), L.add_halfspace([1, 1, 0], 0.0), L.add_plane([0.3, 0.2, 0.9], 0.1),
+             L.add_halfspace([0, 1, 0], 0.2, swept_sphere_radius=0.05)]
+    n = 600
+    obj_shape = rng.integers(0, 40, n).astype(np.uint32)
+    obj_shape[:: n // 20] = rng.choice(flats, len(obj_shape[:: n // 20]))
+    q = rng.normal(size=(n, 4))
+    tf = g.make_pose(quat=q / np.linalg.norm(q, axis=1, keepdims=True), T=rng.uniform(-3, 3, (n, 3)))
+    tf[: n // 2, :9] = np.eye(3).reshape(-1)  # half of the objects unrotated: axis-aligned flats stay half-bounded
+    got = pkg.engine.world_aabbs(L, obj_shape, tf)
+    ref = oracle.world_aabbs(L.shapes_array(), L.vertices_array(), obj_shape, tf)
+    assert not np.isnan(got).any()
+    assert got.tobytes() == ref.tobytes()
+    big = np.finfo(np.float64).max
+    k = int(np.nonzero((obj_shape == flats[0]) & (np.arange(n) < n // 2))[0][0]) if ((obj_shape == flats[0]) & (np.arange(n) < n // 2)).any() else None
+    if k is not None:  # z <= -1 shifted by T: bounded above in z only
+        assert got[k, 5] == -1.0 + tf[k, 11] and got[k, 2] == -big and got[k, 0] == -big and got[k, 3] == big
+    for threads in (1, 5):
+        pairs = pkg.engine.broadphase_self_pairs(got, threads)
+        assert np.array_equal(pairs, oracle.bruteforce_pairs(got))
+    assert len(pairs) > n  # every unbounded flat meets nearly every object
