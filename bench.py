@@ -60,7 +60,12 @@ def parse():
     return ap.parse_args()
 
 
-def load_traffic(workload, dominant, n):
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles (16 lanes per SIMD) at the 2.4 GHz
+# peak clock (MI355X_MICROARCH.md) = 614 G wave-instructions/s.  Packed / dual-issue forms are not assumed.
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4
+
+
+def load_traffic(workload, dominant, n, want="traffic"):
     """HBM bytes per launch of the dominant kernel from the committed PMC pass
     (tools/measure_traffic.py -> profiles/traffic_<workload>.json; FETCH_SIZE / WRITE_SIZE in KB).
     gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-B requests at
@@ -81,6 +86,10 @@ def load_traffic(workload, dominant, n):
         hit = base + "<" in name and sel in name
         if tag == "fast" and "k_epa_stream<" in name:  # the fp32 fast tier is the streaming form of the same kernel
             hit = True
+        if hit and want == "valu":
+            if "SQ_INSTS_VALU_per_dispatch" in v:
+                return v["SQ_INSTS_VALU_per_dispatch"], {k: v[k] for k in v if k.startswith("SQ_")}
+            continue
         if hit and "FETCH_SIZE_KB_per_dispatch" in v and "WRITE_SIZE_KB_per_dispatch" in v:
             f, w = v["FETCH_SIZE_KB_per_dispatch"] * 1024, v["WRITE_SIZE_KB_per_dispatch"] * 1024
             return 2 * f + w, "PMC per launch: FETCH_SIZE raw %.3g B (x2 gfx950 correction applied), WRITE_SIZE %.3g B; %s" % (f, w, os.path.relpath(path, ROOT))
@@ -258,12 +267,19 @@ def main():
         achieved = (units * bpq) / (dom_ms * 1e-3) / 1e9 if dom_ms == dom_ms and dom_ms > 0 else None
         pipeline_ms = float(sum(avg.values()))
         traffic, traffic_note = load_traffic(args.workload, dominant, n)
+        valu_insts, sq = load_traffic(args.workload, dominant, n, want="valu")
+        valu = None
+        if valu_insts and dom_ms == dom_ms and dom_ms > 0:
+            # the bound that actually applies to the iterative kernels: wave-level VALU instructions issued per
+            # launch (SQ_INSTS_VALU, committed PMC pass) against the issue peak over the live kernel duration
+            valu = {"insts_per_launch": valu_insts, "issue_peak_per_s": VALU_ISSUE_PEAK,
+                    "frac": valu_insts / (dom_ms * 1e-3) / VALU_ISSUE_PEAK, "sq_counters_per_launch": sq}
         roofline = {
             "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_note": traffic_note,
             "bytes_per_query": bpq, "units_per_launch": units, "kernel_ms": dom_ms,
             "pipeline_ms": pipeline_ms, "pipeline_achieved": (n * bpq) / (pipeline_ms * 1e-3) / 1e9 if pipeline_ms else None,
-            "kernels_ms": avg,
+            "kernels_ms": avg, "valu_issue": valu,
         }
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only

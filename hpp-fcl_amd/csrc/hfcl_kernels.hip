@@ -143,6 +143,7 @@ struct Work {
 constexpr int32_t EPA_RESUME_FLAG = 0x100;  // EpaSeed::rank bit: "continue the saved polytope of this slot"
 
 __device__ __forceinline__ Pose<double> load_pose(const double* base, uint32_t i) { return pose_from_abi<double>(base + 12 * size_t(i)); }
+__device__ __forceinline__ void put_record(hfcl_result* dst, const hfcl_result& r) { *dst = r; }
 __device__ __forceinline__ Pose<float> load_pose(const float* base, uint32_t i) { return pose_from_quat<float>(base + 7 * size_t(i)); }
 
 // One finished query -> result record (tail of ShapeShapeDistancer::run / ShapeShapeCollider::run).
@@ -157,7 +158,7 @@ __device__ __forceinline__ void store_record(const IO<double>& io, uint32_t pair
   r.b2 = -1;
   r.status = pack_status(o.gjk_status, o.epa_status, contact, o.gjk_iters, o.epa_iters);
   r.num_contacts = nc;
-  io.out[pair] = r;
+  put_record(&io.out[pair], r);
 }
 __device__ __forceinline__ void store_record(const IO<float>& io, uint32_t pair, const PairOut<float>& o, bool contact,
                                              int) {
@@ -233,11 +234,15 @@ __device__ __forceinline__ V3<double> initial_guess<double>(const IO<double>& io
 // ---------------------------------------------------------------------------------------
 // k_classify: bucket every pair by (kind1, kind2).  Wave-aggregated list append.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_classify(Work wk, const uint8_t* kinds, uint32_t n_shapes) {
+// One global atomic per (block trip, bucket) reserves the block's range in the bucket list: these same-address
+// atomics serialise (~20 ns each), so the trips are made large -- 1024 threads x 8 pairs (4M pairs: 39 us at
+// 2048 pairs per trip).
+constexpr int CLS_BLOCK = 1024;
+__global__ void __launch_bounds__(CLS_BLOCK) k_classify(Work wk, const uint8_t* kinds, uint32_t n_shapes) {
   // Each block handles CHUNK consecutive pairs per trip: per-bucket counts are built in LDS, one
   // global atomic per (block, bucket) reserves a range, then every lane writes its pair index.
   constexpr int PER_THREAD = 8;
-  constexpr uint32_t CHUNK = 256 * PER_THREAD;
+  constexpr uint32_t CHUNK = CLS_BLOCK * PER_THREAD;
   __shared__ uint32_t s_count[B_COUNT];
   __shared__ uint32_t s_base[B_COUNT];
   for (uint32_t start = blockIdx.x * CHUNK; start < wk.n; start += gridDim.x * CHUNK) {
@@ -247,23 +252,25 @@ __global__ void __launch_bounds__(256) k_classify(Work wk, const uint8_t* kinds,
     uint32_t rk[PER_THREAD];
 #pragma unroll
     for (int k = 0; k < PER_THREAD; ++k) {
-      const uint32_t i = start + k * 256 + threadIdx.x;
+      const uint32_t i = start + k * CLS_BLOCK + threadIdx.x;
       bk[k] = -1;
       rk[k] = 0;
       if (i < wk.n) {
         const uint32_t s1 = wk.shape1[i], s2 = wk.shape2[i];
         bk[k] = (s1 < n_shapes && s2 < n_shapes) ? bucket_of(kinds[s1], kinds[s2]) : B_UNSUPPORTED;
       }
-      // wave-aggregated LDS counter update
-      for (int c = 0; c < B_COUNT; ++c) {
+      // wave-aggregated LDS counter update: one trip per bucket present in the wave (one for a homogeneous batch)
+      unsigned long long todo = __ballot(bk[k] >= 0);
+      const int lane = threadIdx.x & 63;
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int c = __shfl(bk[k], leader, 64);
         const unsigned long long m = __ballot(bk[k] == c);
-        if (m == 0ull) continue;
-        const int lane = threadIdx.x & 63;
-        const int leader = __ffsll((long long)m) - 1;
         uint32_t base = 0;
         if (lane == leader) base = atomicAdd(&s_count[c], (uint32_t)__popcll(m));
         base = __shfl(base, leader, 64);
         if (bk[k] == c) rk[k] = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
       }
     }
     __syncthreads();
@@ -274,7 +281,7 @@ __global__ void __launch_bounds__(256) k_classify(Work wk, const uint8_t* kinds,
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER_THREAD; ++k) {
-      if (bk[k] >= 0) wk.lists[size_t(bk[k]) * wk.n + s_base[bk[k]] + rk[k]] = start + k * 256 + threadIdx.x;
+      if (bk[k] >= 0) wk.lists[size_t(bk[k]) * wk.n + s_base[bk[k]] + rk[k]] = start + k * CLS_BLOCK + threadIdx.x;
     }
     __syncthreads();
   }
@@ -311,6 +318,59 @@ __global__ void __launch_bounds__(256) k_closed(Work wk, LibView<T> lib, IO<T> i
     write_out<T>(io, q, pair, o);
     // the closed forms never touch the solver's cached guess: it stays at its initial value
     write_guess<T>(io, pair, initial_guess<T>(io, q, pair), 0, 0);
+  }
+}
+
+// fp64 form with the poses and records staged through LDS: a lane's own 96-byte pose / record is six 16-byte
+// pieces 96 bytes apart from its neighbour's, which the memory system only turns into full-line traffic through
+// cache merging (non-temporal accesses: 2.5x slower, profiles/); here the block's 256 poses are fetched as
+// 1536 consecutive 16-byte pieces (lane-contiguous when the bucket list is in input order, as it is up to the
+// interleaving of blocks in k_classify), handed over in LDS, and the records leave the same way.
+typedef double hfcl_d2 __attribute__((ext_vector_type(2)));
+#ifndef HFCL_WPE_CLOSED
+#define HFCL_WPE_CLOSED 2
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_CLOSED, 8))) k_closed_staged(Work wk, LibView<double> lib, IO<double> io, QParams<double> q) {
+  constexpr int NB = 256, PIECES = 6;  // 96 B = 6 x 16 B
+  __shared__ uint32_t s_pair[NB];
+  __shared__ hfcl_d2 s_a[NB * PIECES];  // poses of shape 1, later the records
+  __shared__ hfcl_d2 s_b[NB * PIECES];  // poses of shape 2
+  static_assert(sizeof(hfcl_result) == 96, "record = 6 pieces");
+  const uint32_t cnt = wk.counts[B_CLOSED];
+  const uint32_t t = threadIdx.x;
+  for (uint32_t base = blockIdx.x * NB; base < cnt; base += gridDim.x * NB) {
+    const uint32_t nvalid = min(uint32_t(NB), cnt - base);
+    s_pair[t] = wk.lists[size_t(B_CLOSED) * wk.n + base + (t < nvalid ? t : 0u)];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      const uint32_t c = t + NB * j, p = c / PIECES, part = c % PIECES;
+      const size_t pr = s_pair[p];
+      s_a[c] = reinterpret_cast<const hfcl_d2*>(io.tf1 + 12 * pr)[part];
+      s_b[c] = reinterpret_cast<const hfcl_d2*>(io.tf2 + 12 * pr)[part];
+    }
+    const uint32_t pair = s_pair[t];
+    const DShape<double> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+    __syncthreads();
+    const Pose<double> tf1 = pose_from_abi<double>(reinterpret_cast<const double*>(s_a + PIECES * t));
+    const Pose<double> tf2 = pose_from_abi<double>(reinterpret_cast<const double*>(s_b + PIECES * t));
+    PairOut<double> o;
+    o.distance = closed_form_distance(a, tf1, b, tf2, lib.verts, o.p1, o.p2, o.normal);
+    o.gjk_status = GJK_DID_NOT_RUN;
+    o.epa_status = EPA_DID_NOT_RUN;
+    o.gjk_iters = o.epa_iters = 0;
+    __syncthreads();  // every pose has been read: s_a becomes the record buffer
+    IO<double> lio = io;
+    lio.out = reinterpret_cast<hfcl_result*>(s_a);
+    write_out<double>(lio, q, t, o);
+    if (t < nvalid) write_guess<double>(io, pair, initial_guess<double>(io, q, pair), 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      const uint32_t c = t + NB * j, p = c / PIECES, part = c % PIECES;
+      if (p < nvalid) reinterpret_cast<hfcl_d2*>(io.out + s_pair[p])[part] = s_a[c];
+    }
+    __syncthreads();
   }
 }
 
@@ -1439,6 +1499,7 @@ struct hfcl_lib {
   bool kernel_timing = true;         // HIP events around every kernel (hfcl_lib_set_kernel_timing)
   uint32_t possible_buckets = ~0u;   // bit b: some pair of this library's shape kinds classifies into bucket b
   int cvx_w = 4;
+  bool closed_staged = true;  // HFCL_CLOSED_STAGED=0: A/B switch back to the direct-access k_closed<double>
   int n_cus = 256;
   std::string dominant;
   uint32_t h_counts[B_COUNT + 2] = {0};
@@ -1622,6 +1683,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
     hfcl_lib_destroy(lib);
     return nullptr;
   }
+  if (const char* v = getenv("HFCL_CLOSED_STAGED")) lib->closed_staged = atoi(v) != 0;
   if (const char* w = getenv("HFCL_CVX_W")) {
     int v = atoi(w);
     if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) lib->cvx_w = v;
@@ -1930,12 +1992,19 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   const bool any_gjk = may(B_PRIM) || may(B_CC) || may(B_PC) || may(B_CP) || may(B_LARGE);
   HIP_TRY(hipMemsetAsync(lib->d_counts, 0, (B_COUNT + 3) * sizeof(uint32_t), st));
   tbeg("k_classify");
-  hipLaunchKernelGGL(k_classify, dim3(blocks_for(n, 256 * 8)), dim3(256), 0, st, wk, lib->d_kinds, uint32_t(lib->n_shapes));
+  hipLaunchKernelGGL(k_classify, dim3(blocks_for(n, CLS_BLOCK * 8)), dim3(CLS_BLOCK), 0, st, wk, lib->d_kinds, uint32_t(lib->n_shapes));
   tend();
 
   if (may(B_CLOSED)) {
     tbeg("k_closed");
-    hipLaunchKernelGGL((k_closed<T>), dim3(blocks_for(n, 256)), dim3(256), 0, st, wk, lv, io, q);
+    if constexpr (sizeof(T) == 8) {
+      if (lib->closed_staged)
+        hipLaunchKernelGGL(k_closed_staged, dim3(blocks_for(n, 256)), dim3(256), 0, st, wk, lv, io, q);
+      else
+        hipLaunchKernelGGL((k_closed<T>), dim3(blocks_for(n, 256)), dim3(256), 0, st, wk, lv, io, q);
+    } else {
+      hipLaunchKernelGGL((k_closed<T>), dim3(blocks_for(n, 256)), dim3(256), 0, st, wk, lv, io, q);
+    }
     tend();
   }
   if (may(B_PRIM)) {

@@ -18,18 +18,24 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def one_pass(counter, workload, outdir, pairs):
+def one_pass(counters, workload, outdir, pairs):
+    """One rocprofv3 pass collecting `counters` (str or list) -> {counter: {kernel: (mean per dispatch, dispatches)}}"""
+    single = isinstance(counters, str)
+    names = [counters] if single else list(counters)
     env = dict(os.environ, TMPDIR="/tmp")
-    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", outdir, "-o", "t", "--",
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + names + ["-d", outdir, "-o", "t", "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3",
            "--warmup", "1", "--no-cpu-baseline"] + (["--pairs", str(pairs)] if pairs else [])
     subprocess.run(cmd, check=True, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
     dbs = glob.glob(os.path.join(outdir, "**", "*.db"), recursive=True)
     assert dbs, "rocprofv3 wrote no database under " + outdir
     con = sqlite3.connect(dbs[0])
-    rows = con.execute("select kernel_name, sum(value), count(*) from counters_collection "
-                       "where counter_name=? group by kernel_name", (counter,))
-    return {k: (v / n, n) for k, v, n in rows}
+    res = {}
+    for c in names:
+        rows = con.execute("select kernel_name, sum(value), count(*) from counters_collection "
+                           "where counter_name=? group by kernel_name", (c,))
+        res[c] = {k: (v / n, n) for k, v, n in rows}
+    return res[names[0]] if single else res
 
 
 if __name__ == "__main__":
@@ -44,6 +50,15 @@ if __name__ == "__main__":
         for k, (v, n) in one_pass(c, a.workload, os.path.join(scratch, c), a.pairs).items():
             res[k][c + "_KB_per_dispatch"] = v
             res[k]["dispatches"] = n
+    # issue-side counters in their own pass: wave instructions by type per dispatch (the iterative kernels are bound
+    # by VALU issue, not by HBM: bench.py reports SQ_INSTS_VALU against the chip's issue peak next to the HBM fraction)
+    sq = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES")
+    try:
+        for c, per_kernel in one_pass(sq, a.workload, os.path.join(scratch, "SQ"), a.pairs).items():
+            for k, (v, n) in per_kernel.items():
+                res[k][c + "_per_dispatch"] = v
+    except Exception as e:  # the traffic figures stand on their own
+        print("SQ pass failed:", e, file=sys.stderr)
     out = a.out or os.path.join(ROOT, "gpurun_out", "traffic_%s.json" % a.workload)
     json.dump({"workload": a.workload, "pairs": a.pairs or None, "unit": "KB as reported by rocprofv3 (uncorrected)",
                "kernels": {k: v for k, v in res.items() if k.startswith("void k_") or k.startswith("k_")}},
