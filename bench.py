@@ -86,6 +86,8 @@ def load_traffic(workload, dominant, n, want="traffic"):
         hit = base + "<" in name and sel in name
         if tag == "fast" and "k_epa_stream<" in name:  # the fp32 fast tier is the streaming form of the same kernel
             hit = True
+        if base == "k_closed" and "k_closed_staged(" in name:  # the fp64 closed-form kernel (LDS-staged I/O)
+            hit = True
         if hit and want == "valu":
             if "SQ_INSTS_VALU_per_dispatch" in v:
                 return v["SQ_INSTS_VALU_per_dispatch"], {k: v[k] for k in v if k.startswith("SQ_")}
@@ -273,7 +275,9 @@ def main():
             # the bound that actually applies to the iterative kernels: wave-level VALU instructions issued per
             # launch (SQ_INSTS_VALU, committed PMC pass) against the issue peak over the live kernel duration
             valu = {"insts_per_launch": valu_insts, "issue_peak_per_s": VALU_ISSUE_PEAK,
-                    "frac": valu_insts / (dom_ms * 1e-3) / VALU_ISSUE_PEAK, "sq_counters_per_launch": sq}
+                    "frac": valu_insts / (dom_ms * 1e-3) / VALU_ISSUE_PEAK, "sq_counters_per_launch": sq,
+                    "note": "wave-level VALU instructions / (kernel time x 256 CUs x 4 SIMDs x 2.4 GHz / 4); "
+                            "fp64 arithmetic issues at half that rate, so an fp64 kernel saturates near 0.5"}
         roofline = {
             "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_note": traffic_note,
@@ -322,7 +326,7 @@ def main():
                                            "cfg3u": "configs[2], one hull pair per query"}[args.workload],
                        "pairs_per_gpu_per_step": n, "contact_fraction": contact_frac, "buckets": buckets,
                        "request": batch.kind, "all_gather_results": bool(gather),
-                       "lane_group_width": int(os.environ.get("HFCL_CVX_W", "4"))},
+                       "lane_group_width": os.environ.get("HFCL_CVX_W", "auto (2; fp64 convex-convex 4)")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -40,6 +40,9 @@
 using namespace hfcl;
 
 // minimum waves per SIMD the register allocator must allow for (A/B-tuned, see profiles/)
+#ifndef HFCL_WPE_GJK_W2
+#define HFCL_WPE_GJK_W2 2  // 2-lane groups hold 16 vertices of each hull per lane (96 VGPRs)
+#endif
 #ifndef HFCL_WPE_GJK
 #define HFCL_WPE_GJK 3
 #endif
@@ -557,7 +560,7 @@ __device__ __forceinline__ void gjk_cvx_body(const Work& wk, const LibView<T>& l
 // Two entry points so that each precision gets its own register budget (waves per SIMD): the fp64
 // instantiation spills heavily at the fp32 setting (A/B in profiles/).
 template <int W, int M>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_GJK, 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 2 ? HFCL_WPE_GJK_W2 : HFCL_WPE_GJK, 8)))
 k_gjk_cvx(Work wk, LibView<float> lib, IO<float> io, QParams<float> q) {
   gjk_cvx_body<float, W, M>(wk, lib, io, q);
 }
@@ -1498,7 +1501,7 @@ struct hfcl_lib {
   std::vector<KernelTime> timers;
   bool kernel_timing = true;         // HIP events around every kernel (hfcl_lib_set_kernel_timing)
   uint32_t possible_buckets = ~0u;   // bit b: some pair of this library's shape kinds classifies into bucket b
-  int cvx_w = 4;
+  int cvx_w = 0;  // 0 = per kernel (auto_cvx_w); HFCL_CVX_W forces one width for all
   bool closed_staged = true;  // HFCL_CLOSED_STAGED=0: A/B switch back to the direct-access k_closed<double>
   int n_cus = 256;
   std::string dominant;
@@ -1686,7 +1689,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_CLOSED_STAGED")) lib->closed_staged = atoi(v) != 0;
   if (const char* w = getenv("HFCL_CVX_W")) {
     int v = atoi(w);
-    if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) lib->cvx_w = v;
+    if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) lib->cvx_w = v;
   }
   return lib;
 }
@@ -1911,9 +1914,33 @@ static int validate_query(const hfcl_query_request& q) {
   return HFCL_OK;
 }
 
-template <typename T, int W>
+// Lane-group width of the convex GJK kernels.  A/B on cfg3 / cfg5 (profiles/r01_k_gjk_lane_group_w2.txt): 2-lane
+// groups (16 vertices of each hull per lane, 32 pairs per wave: half the redundancy of the serial simplex code)
+// beat 4-lane groups wherever their 96 / 192 vertex registers fit -- everywhere but fp64 convex x convex.
+template <typename T, int M>
+static int auto_cvx_w() {
+  return (sizeof(T) == 8 && M == 0) ? 4 : 2;
+}
+template <typename T, int M>
+static void launch_cvx_m(hfcl_lib* lib, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q,
+                         hipStream_t st, size_t n) {
+  const int w = lib->cvx_w ? lib->cvx_w : auto_cvx_w<T, M>();
+  size_t b = (n + size_t(256 / w) - 1) / size_t(256 / w);
+  if (b < 1) b = 1;
+  if (b > size_t(lib->n_cus) * 16) b = size_t(lib->n_cus) * 16;
+  const int grid = int(b);
+  switch (w) {
+    case 2: launch_gjk_cvx<2, M>(grid, st, wk, lv, io, q); break;
+    case 8: launch_gjk_cvx<8, M>(grid, st, wk, lv, io, q); break;
+    case 16: launch_gjk_cvx<16, M>(grid, st, wk, lv, io, q); break;
+    case 32: launch_gjk_cvx<32, M>(grid, st, wk, lv, io, q); break;
+    case 64: launch_gjk_cvx<64, M>(grid, st, wk, lv, io, q); break;
+    default: launch_gjk_cvx<4, M>(grid, st, wk, lv, io, q); break;
+  }
+}
+template <typename T>
 static void launch_cvx(hfcl_lib* lib, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q,
-                       hipStream_t st, size_t& ti, int grid) {
+                       hipStream_t st, size_t& ti, size_t n) {
   KernelTime* t = nullptr;
   auto tbeg = [&](const char* name) {
     if (!lib->kernel_timing) return;
@@ -1925,17 +1952,17 @@ static void launch_cvx(hfcl_lib* lib, const Work& wk, const LibView<T>& lv, cons
   };
   if ((lib->possible_buckets >> B_CC) & 1u) {
     tbeg("k_gjk_cvx<cc>");
-    launch_gjk_cvx<W, 0>(grid, st, wk, lv, io, q);
+    launch_cvx_m<T, 0>(lib, wk, lv, io, q, st, n);
     tend();
   }
   if ((lib->possible_buckets >> B_PC) & 1u) {
     tbeg("k_gjk_cvx<pc>");
-    launch_gjk_cvx<W, 1>(grid, st, wk, lv, io, q);
+    launch_cvx_m<T, 1>(lib, wk, lv, io, q, st, n);
     tend();
   }
   if ((lib->possible_buckets >> B_CP) & 1u) {
     tbeg("k_gjk_cvx<cp>");
-    launch_gjk_cvx<W, 2>(grid, st, wk, lv, io, q);
+    launch_cvx_m<T, 2>(lib, wk, lv, io, q, st, n);
     tend();
   }
 }
@@ -2013,13 +2040,7 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
     tend();
   }
 
-  const int w = lib->cvx_w;
-  const int cgrid = blocks_for(n, 256 / w);
-  if (w == 16) launch_cvx<T, 16>(lib, wk, lv, io, q, st, ti, cgrid);
-  else if (w == 32) launch_cvx<T, 32>(lib, wk, lv, io, q, st, ti, cgrid);
-  else if (w == 64) launch_cvx<T, 64>(lib, wk, lv, io, q, st, ti, cgrid);
-  else if (w == 8) launch_cvx<T, 8>(lib, wk, lv, io, q, st, ti, cgrid);
-  else launch_cvx<T, 4>(lib, wk, lv, io, q, st, ti, cgrid);
+  launch_cvx<T>(lib, wk, lv, io, q, st, ti, n);
 
   if (may(B_LARGE)) {
     tbeg("k_gjk_large");
