@@ -1546,6 +1546,10 @@ static int ensure_device(int device) {
 extern "C" {
 
 int hfcl_abi_version(void) { return HFCL_ABI_VERSION; }
+int hfcl_pair_supported(int32_t t1, int32_t t2) {
+  if (t1 < 0 || t1 > 255 || t2 < 0 || t2 > 255) return 0;
+  return bucket_of(t1, t2) != B_UNSUPPORTED;
+}
 int hfcl_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

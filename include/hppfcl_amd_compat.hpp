@@ -689,6 +689,46 @@ inline FCL_REAL distance(const CollisionGeometry* o1, const Transform3f& tf1, co
   return ctx.records()[0].distance;
 }
 
+/// ComputeCollision / ComputeDistance (include/hpp/fcl/collision.h:79-117, distance.h:74-112): the geometry pair is
+/// looked up once at construction (std::invalid_argument for a pair without an evaluator, src/collision.cpp:132-158,
+/// src/distance.cpp:111-137); every call is the batch-of-one path of collide() / distance().
+class ComputeCollision {
+ public:
+  ComputeCollision(const CollisionGeometry* o1_, const CollisionGeometry* o2_) : o1(o1_), o2(o2_) {
+    if (!hfcl_pair_supported(o1->getNodeType(), o2->getNodeType()))
+      throw std::invalid_argument("Collision function between the two node types is not yet supported.");
+  }
+  virtual ~ComputeCollision() {}
+  std::size_t operator()(const Transform3f& tf1, const Transform3f& tf2, const CollisionRequest& request,
+                         CollisionResult& result) const {
+    return collide(o1, tf1, o2, tf2, request, result);
+  }
+  bool operator==(const ComputeCollision& other) const { return o1 == other.o1 && o2 == other.o2; }
+  bool operator!=(const ComputeCollision& other) const { return !(*this == other); }
+
+ protected:
+  const CollisionGeometry* o1;
+  const CollisionGeometry* o2;
+};
+class ComputeDistance {
+ public:
+  ComputeDistance(const CollisionGeometry* o1_, const CollisionGeometry* o2_) : o1(o1_), o2(o2_) {
+    if (!hfcl_pair_supported(o1->getNodeType(), o2->getNodeType()))
+      throw std::invalid_argument("Distance function between the two node types is not yet supported.");
+  }
+  virtual ~ComputeDistance() {}
+  FCL_REAL operator()(const Transform3f& tf1, const Transform3f& tf2, const DistanceRequest& request,
+                      DistanceResult& result) const {
+    return distance(o1, tf1, o2, tf2, request, result);
+  }
+  bool operator==(const ComputeDistance& other) const { return o1 == other.o1 && o2 == other.o2; }
+  bool operator!=(const ComputeDistance& other) const { return !(*this == other); }
+
+ protected:
+  const CollisionGeometry* o1;
+  const CollisionGeometry* o2;
+};
+
 // ---------------------------------------------------------------------------------------------
 // Broadphase hand-off (include/hpp/fcl/collision_object.h:215-357, broadphase/broadphase_callbacks.h,
 // broadphase/default_broadphase_callbacks.h:200-230, broadphase/broadphase_dynamic_AABB_tree.h).

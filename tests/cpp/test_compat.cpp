@@ -166,6 +166,26 @@ int main() {
     CHECK(std::fabs(distance(&tri, Transform3f(Vec3f(0, 0, 3)), &b, Transform3f(), dq, dr) - 2) < 1e-6);
     CHECK(std::fabs(dr.normal[2] + 1) < 1e-6 && std::fabs(dr.nearest_points[0][2] - 3) < 1e-6);
   }
+  {  // functors (collision.h:79-117, distance.h:74-112)
+    STAGE("ComputeCollision / ComputeDistance");
+    Box b(2, 2, 2);
+    Capsule c(0.5, 2);
+    ComputeCollision cc(&b, &c);
+    ComputeDistance cd(&b, &c);
+    CollisionRequest rq; CollisionResult rs, rs2;
+    DistanceRequest dq; DistanceResult dr, dr2;
+    const Transform3f tf2(Vec3f(1.2, 0.1, 0.3));
+    CHECK(cc(Transform3f(), tf2, rq, rs) == collide(&b, Transform3f(), &c, tf2, rq, rs2));
+    CHECK(rs.numContacts() == 1 && rs.getContact(0).penetration_depth == rs2.getContact(0).penetration_depth);
+    const Transform3f far(Vec3f(4, 0, 0));
+    CHECK(cd(Transform3f(), far, dq, dr) == distance(&b, Transform3f(), &c, far, dq, dr2));
+    CHECK(std::fabs(dr.min_distance - 2.5) < 1e-6);
+    BVHModel<OBBRSS> empty_model;
+    TriangleP tri(Vec3f(0, 0, 0), Vec3f(1, 0, 0), Vec3f(0, 1, 0));
+    bool threw = false;
+    try { ComputeCollision bad(&tri, &empty_model); } catch (const std::invalid_argument&) { threw = true; }
+    CHECK(threw);  // (TriangleP, BVHModel) has no entry in the reference's matrices either
+  }
   {  // broadphase hand-off: manager + CollisionCallBackCollect, then one device batch (test/broadphase.cpp style)
     STAGE("broadphase");
     std::vector<std::shared_ptr<CollisionGeometry>> geoms;
