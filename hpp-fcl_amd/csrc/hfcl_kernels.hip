@@ -76,7 +76,11 @@ enum { B_CLOSED = 0, B_PRIM = 1, B_CC = 2, B_PC = 3, B_CP = 4, B_BVH = 5, B_UNSU
 // the B_LARGE bucket whose kernel scans the vertices from memory instead of holding them in registers.
 constexpr int K_CONVEX_LARGE = 21;
 
-__host__ __device__ inline int bucket_of(int k1, int k2) {
+// distance_mode: the reference's *distance* function matrix has no TriangleP row or column at all
+// (src/distance_func_matrix.cpp:283-560; only collide() knows GEOM_TRIANGLE, collision_func_matrix.cpp:295-469):
+// distance() on such a pair throws there and is reported as unsupported here.
+__host__ __device__ inline int bucket_of(int k1, int k2, bool distance_mode = false) {
+  if (distance_mode && (k1 == K_TRIANGLE || k2 == K_TRIANGLE)) return B_UNSUPPORTED;
   const bool large = (k1 == K_CONVEX_LARGE) || (k2 == K_CONVEX_LARGE);
   if (k1 == K_CONVEX_LARGE) k1 = K_CONVEX;
   if (k2 == K_CONVEX_LARGE) k2 = K_CONVEX;
@@ -241,7 +245,7 @@ __device__ __forceinline__ V3<double> initial_guess<double>(const IO<double>& io
 // atomics serialise (~20 ns each), so the trips are made large -- 1024 threads x 8 pairs (4M pairs: 39 us at
 // 2048 pairs per trip).
 constexpr int CLS_BLOCK = 1024;
-__global__ void __launch_bounds__(CLS_BLOCK) k_classify(Work wk, const uint8_t* kinds, uint32_t n_shapes) {
+__global__ void __launch_bounds__(CLS_BLOCK) k_classify(Work wk, const uint8_t* kinds, uint32_t n_shapes, bool distance_mode) {
   // Each block handles CHUNK consecutive pairs per trip: per-bucket counts are built in LDS, one
   // global atomic per (block, bucket) reserves a range, then every lane writes its pair index.
   constexpr int PER_THREAD = 8;
@@ -260,7 +264,7 @@ __global__ void __launch_bounds__(CLS_BLOCK) k_classify(Work wk, const uint8_t* 
       rk[k] = 0;
       if (i < wk.n) {
         const uint32_t s1 = wk.shape1[i], s2 = wk.shape2[i];
-        bk[k] = (s1 < n_shapes && s2 < n_shapes) ? bucket_of(kinds[s1], kinds[s2]) : B_UNSUPPORTED;
+        bk[k] = (s1 < n_shapes && s2 < n_shapes) ? bucket_of(kinds[s1], kinds[s2], distance_mode) : B_UNSUPPORTED;
       }
       // wave-aggregated LDS counter update: one trip per bucket present in the wave (one for a homogeneous batch)
       unsigned long long todo = __ballot(bk[k] >= 0);
@@ -1546,9 +1550,9 @@ static int ensure_device(int device) {
 extern "C" {
 
 int hfcl_abi_version(void) { return HFCL_ABI_VERSION; }
-int hfcl_pair_supported(int32_t t1, int32_t t2) {
+int hfcl_pair_supported(int32_t t1, int32_t t2, int for_distance) {
   if (t1 < 0 || t1 > 255 || t2 < 0 || t2 > 255) return 0;
-  return bucket_of(t1, t2) != B_UNSUPPORTED;
+  return bucket_of(t1, t2, for_distance != 0) != B_UNSUPPORTED;
 }
 int hfcl_device_count(void) {
   int n = 0;
@@ -2023,7 +2027,7 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   const bool any_gjk = may(B_PRIM) || may(B_CC) || may(B_PC) || may(B_CP) || may(B_LARGE);
   HIP_TRY(hipMemsetAsync(lib->d_counts, 0, (B_COUNT + 3) * sizeof(uint32_t), st));
   tbeg("k_classify");
-  hipLaunchKernelGGL(k_classify, dim3(blocks_for(n, CLS_BLOCK * 8)), dim3(CLS_BLOCK), 0, st, wk, lib->d_kinds, uint32_t(lib->n_shapes));
+  hipLaunchKernelGGL(k_classify, dim3(blocks_for(n, CLS_BLOCK * 8)), dim3(CLS_BLOCK), 0, st, wk, lib->d_kinds, uint32_t(lib->n_shapes), q.mode != 1);
   tend();
 
   if (may(B_CLOSED)) {

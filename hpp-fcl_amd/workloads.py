@@ -186,9 +186,10 @@ def all_primitives(n=100_000, seed=1, nper=128, half_width=0.8, kind="collide"):
     return Batch("all_primitives_" + kind, lib, s1, s2, q1, T1, q2, T2, kind)
 
 
-def triangle_pairs(n=50_000, seed=1, nper=48, half_width=0.45, kind="distance"):
+def triangle_pairs(n=50_000, seed=1, nper=48, half_width=0.45, kind="collide"):
     """Top-level TriangleP rows of the dispatch table (collision_func_matrix.cpp:295-469): a TriangleP against
-    every solid kind, both operand orders, and TriangleP x TriangleP."""
+    every solid kind, both operand orders, and TriangleP x TriangleP.  collide() only: the reference's distance
+    matrix has no TriangleP entries (src/distance_func_matrix.cpp)."""
     rng = _rng(seed, 9)
     lib = _mixed_library(rng, nper)
     for r, lz in zip(rng.uniform(0.1, 0.8, nper), rng.uniform(0.2, 1.0, nper)):

@@ -200,8 +200,9 @@ int  hfcl_abi_version(void);
 int  hfcl_device_count(void);
 /* 1 if a (node_type1, node_type2) pair has an evaluator, 0 otherwise: the lookup the reference makes in its
  * function matrices (getCollisionFunctionLookTable / getDistanceFunctionLookTable, src/collision.cpp:132-158,
- * src/distance.cpp:111-137).  Host-only, needs no device. */
-int  hfcl_pair_supported(int32_t node_type1, int32_t node_type2);
+ * src/distance.cpp:111-137).  for_distance selects the distance matrix, which -- unlike the collision matrix --
+ * has no GEOM_TRIANGLE entries (src/distance_func_matrix.cpp).  Host-only, needs no device. */
+int  hfcl_pair_supported(int32_t node_type1, int32_t node_type2, int for_distance);
 const char* hfcl_last_error(void);
 
 void hfcl_collision_request_init(hfcl_collision_request* r);

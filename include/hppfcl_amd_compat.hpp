@@ -695,7 +695,7 @@ inline FCL_REAL distance(const CollisionGeometry* o1, const Transform3f& tf1, co
 class ComputeCollision {
  public:
   ComputeCollision(const CollisionGeometry* o1_, const CollisionGeometry* o2_) : o1(o1_), o2(o2_) {
-    if (!hfcl_pair_supported(o1->getNodeType(), o2->getNodeType()))
+    if (!hfcl_pair_supported(o1->getNodeType(), o2->getNodeType(), 0))
       throw std::invalid_argument("Collision function between the two node types is not yet supported.");
   }
   virtual ~ComputeCollision() {}
@@ -713,7 +713,7 @@ class ComputeCollision {
 class ComputeDistance {
  public:
   ComputeDistance(const CollisionGeometry* o1_, const CollisionGeometry* o2_) : o1(o1_), o2(o2_) {
-    if (!hfcl_pair_supported(o1->getNodeType(), o2->getNodeType()))
+    if (!hfcl_pair_supported(o1->getNodeType(), o2->getNodeType(), 1))
       throw std::invalid_argument("Distance function between the two node types is not yet supported.");
   }
   virtual ~ComputeDistance() {}

@@ -845,6 +845,9 @@ int distance_pair(const Shape& s1, const Tf& tf1, const Shape& s2, const Tf& tf2
   solver.out_support_guess[1] = solver.support_func_cached_guess[1];
   double d;
   V3 p1, p2, n;
+  // the distance function matrix has no GEOM_TRIANGLE row or column (src/distance_func_matrix.cpp:283-560):
+  // distance() throws "not yet supported" for a top-level TriangleP (src/distance.cpp:69-75)
+  if (s1.kind == K_TRIANGLE || s2.kind == K_TRIANGLE) return HFCL_ERR_UNSUPPORTED_PAIR;
   if (!shape_shape_distance(s1, tf1, s2, tf2, solver, req.enable_signed_distance != 0, d, p1, p2, n))
     return HFCL_ERR_UNSUPPORTED_PAIR;
   fill_result(out, d, n, p1, p2);

@@ -159,12 +159,25 @@ int main() {
     CHECK(collide(&tri, Transform3f(Vec3f(0, 0, -0.001)), &s, Transform3f(), rq, rs) == 1);
     CHECK(std::fabs(rs.getContact(0).normal[2] - 1) < 1e-9);  // from the triangle (below) towards the sphere
     Box b(2, 2, 2);
+    rs.clear();
+    CHECK(collide(&b, Transform3f(), &tri, Transform3f(Vec3f(0, 0, 3)), rq, rs) == 0);
+    CHECK(std::fabs(rs.distance_lower_bound - 2) < 1e-6 && std::fabs(rs.normal[2] - 1) < 1e-6);
+    CHECK(std::fabs(rs.nearest_points[1][2] - 3) < 1e-6);
+    rs.clear();
+    CHECK(collide(&tri, Transform3f(Vec3f(0, 0, 3)), &b, Transform3f(), rq, rs) == 0);
+    CHECK(std::fabs(rs.distance_lower_bound - 2) < 1e-6 && std::fabs(rs.normal[2] + 1) < 1e-6);
+    CHECK(std::fabs(rs.nearest_points[0][2] - 3) < 1e-6);
+    rs.clear();
+    CHECK(collide(&b, Transform3f(), &tri, Transform3f(Vec3f(0, 0, 0.5)), rq, rs) == 1);
+    CHECK(std::fabs(rs.getContact(0).penetration_depth + 0.5) < 1e-6);
+    // the reference's distance matrix has no TriangleP entries: distance() throws (src/distance.cpp:69-75)
+    bool threw_d = false;
     DistanceRequest dq; DistanceResult dr;
-    CHECK(std::fabs(distance(&b, Transform3f(), &tri, Transform3f(Vec3f(0, 0, 3)), dq, dr) - 2) < 1e-6);
-    CHECK(std::fabs(dr.normal[2] - 1) < 1e-6 && std::fabs(dr.nearest_points[1][2] - 3) < 1e-6);
-    dr.clear();
-    CHECK(std::fabs(distance(&tri, Transform3f(Vec3f(0, 0, 3)), &b, Transform3f(), dq, dr) - 2) < 1e-6);
-    CHECK(std::fabs(dr.normal[2] + 1) < 1e-6 && std::fabs(dr.nearest_points[0][2] - 3) < 1e-6);
+    try { distance(&b, Transform3f(), &tri, Transform3f(Vec3f(0, 0, 3)), dq, dr); } catch (const std::invalid_argument&) { threw_d = true; }
+    CHECK(threw_d);
+    bool threw_f = false;
+    try { ComputeDistance bad(&b, &tri); } catch (const std::invalid_argument&) { threw_f = true; }
+    CHECK(threw_f);
   }
   {  // functors (collision.h:79-117, distance.h:74-112)
     STAGE("ComputeCollision / ComputeDistance");

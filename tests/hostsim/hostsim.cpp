@@ -59,6 +59,10 @@ template <typename T>
 static void one_pair(const DShape<T>& a, const DShape<T>& b, const T* verts, const Pose<T>& tf1, const Pose<T>& tf2,
                      const QParams<T>& q, const V3<T>& guess0, PairOut<T>& o, bool& contact, int& nc, bool& skipped) {
   skipped = false;
+  if (q.mode != 1 && (a.kind == K_TRIANGLE || b.kind == K_TRIANGLE)) {  // no TriangleP in the distance matrix
+    skipped = true;
+    return;
+  }
   const int cls = pair_class(a.kind, b.kind);
   if (cls == CLS_CLOSED) {
     o.distance = closed_form_distance(a, tf1, b, tf2, verts, o.p1, o.p2, o.normal);

@@ -71,3 +71,25 @@ def test_cpp_shim_compiles_and_fails_loudly_without_gpu(pkg):
         pytest.skip("a GPU is visible (the GPU suite runs the binary)")
     r = subprocess.run([os.path.join(d, "test_compat")], capture_output=True, text=True)
     assert r.returncode == 3 and "no CPU fallback" in r.stdout
+
+
+def test_pair_supported_matches_the_reference_function_matrices(pkg):
+    """hfcl_pair_supported = "is there an entry in collision_matrix / distance_matrix" (collision_func_matrix.cpp:
+    244-469 for the kinds in scope): every solid x solid, flat and TriangleP row, BVHModel<OBBRSS> x itself and
+    x every shape; no (BVHModel, TriangleP) and no unknown node types.  Host-only: needs no device."""
+    a = pkg.abi
+    f = pkg.engine.dll().hfcl_pair_supported
+    solids = [a.GEOM_BOX, a.GEOM_SPHERE, a.GEOM_CAPSULE, a.GEOM_CONE, a.GEOM_CYLINDER, a.GEOM_CONVEX, a.GEOM_ELLIPSOID]
+    flats = [a.GEOM_PLANE, a.GEOM_HALFSPACE]
+    shapes = solids + flats + [a.GEOM_TRIANGLE]
+    for dist in (0, 1):
+        for s1 in shapes:
+            for s2 in shapes:
+                tri = a.GEOM_TRIANGLE in (s1, s2)  # src/distance_func_matrix.cpp has no TriangleP entries
+                assert f(s1, s2, dist) == (0 if (dist and tri) else 1), (s1, s2, dist)
+        assert f(a.BV_OBBRSS, a.BV_OBBRSS, dist) == 1
+        for s in solids + flats:
+            assert f(a.BV_OBBRSS, s, dist) == 1 and f(s, a.BV_OBBRSS, dist) == 1, s
+        assert f(a.BV_OBBRSS, a.GEOM_TRIANGLE, dist) == 0 and f(a.GEOM_TRIANGLE, a.BV_OBBRSS, dist) == 0
+        for bad in (0, 1, 8, 18, 20, 22, 300, -1):  # BV_AABB.., GEOM_OCTREE, HF_*, out of range
+            assert f(bad, a.GEOM_BOX, dist) == 0 and f(a.GEOM_BOX, bad, dist) == 0, bad

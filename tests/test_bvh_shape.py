@@ -179,8 +179,10 @@ def test_gpu_mesh_vs_shapes(pkg, oracle, nmax, margin):
         src = b.shapes[ss]
         base = L._add(int(src["type"]), tuple(src["params"]), float(src["swept_sphere_radius"]))
         nt = mesh.num_tris
-        r = oracle.distance_batch(L.shapes_array(), L.vertices_array(), np.arange(nt), np.full(nt, base), np.tile(tfm, (nt, 1)),
-                                  np.tile(tfs, (nt, 1)), None, n_threads=8)
+        # per-triangle internal::ShapeShapeDistance<TriangleP, S> = what collide() runs for a top-level TriangleP
+        # (distance() has no TriangleP rows, src/distance_func_matrix.cpp); default request: penetration computed
+        r = oracle.collide_batch(L.shapes_array(), L.vertices_array(), np.arange(nt), np.full(nt, base), np.tile(tfm, (nt, 1)),
+                                 np.tile(tfs, (nt, 1)), None, n_threads=8)
         assert got["distance"][i] <= r["distance"].min() + 1e-9 + margin, (i, got["distance"][i], r["distance"].min())
     assert np.array_equal(np.isnan(got["p1"][strict]), np.isnan(ref["p1"][strict]))
     # contact lists of the mixed pairs: same (pair, b1, b2) multiset
@@ -217,8 +219,9 @@ def test_oracle_mesh_shape_distance_equals_brute_force(pkg, oracle):
         else:
             base = L._add(int(src["type"]), tuple(src["params"]), float(src["swept_sphere_radius"]))
         nt = mesh.num_tris
-        r = oracle.distance_batch(L.shapes_array(), L.vertices_array(), np.arange(nt), np.full(nt, base), np.tile(tfm, (nt, 1)),
-                                  np.tile(tfs, (nt, 1)), req, n_threads=4)
+        # per-triangle signed distance through collide() (the distance matrix has no TriangleP rows)
+        r = oracle.collide_batch(L.shapes_array(), L.vertices_array(), np.arange(nt), np.full(nt, base), np.tile(tfm, (nt, 1)),
+                                 np.tile(tfs, (nt, 1)), None, n_threads=4)
         if r["distance"].min() > 0:
             assert abs(out["distance"][k] - r["distance"].min()) < 1e-9, (i, out["distance"][k], r["distance"].min())
         else:

@@ -234,7 +234,7 @@ def test_sqr_tri_distance_vs_gjk(pkg, oracle, hostsim):
     for i in range(n):
         L.add_triangle(*T[i])
     I = np.tile(g.make_pose(), (n, 1))
-    r = oracle.distance_batch(L.shapes_array(), L.vertices_array(), np.arange(n), n + np.arange(n), I, I)
+    r = oracle.collide_batch(L.shapes_array(), L.vertices_array(), np.arange(n), n + np.arange(n), I, I)  # TriangleP: collide() only
     for i in range(n):
         d2, P, Q = oracle.sqr_tri_distance(S[i], T[i])
         d2s, Ps, Qs = hostsim.sqr_tri_distance(abi, S[i], T[i])

@@ -70,9 +70,9 @@ def test_oracle_triangle_overloads_vs_generic_route(oracle, pkg):
     abi, wl = pkg.abi, pkg.workloads
     b = wl.triangle_pairs(n=20000, seed=2)
     req = wl.make_request(b, abi)
-    ref = oracle.distance_batch(b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=4)
+    ref = oracle.collide_batch(b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=4)
     shapes3, tri = _as_convex3(pkg, b)
-    alt = oracle.distance_batch(shapes3, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=4)
+    alt = oracle.collide_batch(shapes3, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=4)
     k1, k2 = b.shapes["type"][b.s1], b.shapes["type"][b.s2]
     # tri x tri has its own routine (no EPA, computePenetration) and sphere has a closed form: compare the GJK solids,
     # away from smooth shapes whose EPA stops on its tolerance
@@ -93,15 +93,13 @@ def test_oracle_triangle_overloads_vs_generic_route(oracle, pkg):
     assert np.abs(ref["distance"][sph][sep] - alt["distance"][sph][sep]).max() < 5e-6
 
 
-@pytest.mark.parametrize("kind", ["distance", "collide"])
-def test_device_header_triangle_pairs(pkg, oracle, hostsim, kind):
+@pytest.mark.parametrize("margin", [0.0, 0.02])
+def test_device_header_triangle_pairs(pkg, oracle, hostsim, margin):
     abi, wl = pkg.abi, pkg.workloads
-    b = wl.triangle_pairs(n=20000, seed=3, kind=kind)
+    b = wl.triangle_pairs(n=20000, seed=3)
     req = wl.make_request(b, abi)
-    if kind == "collide":
-        req.security_margin = 0.02
-    fn = oracle.distance_batch if kind == "distance" else oracle.collide_batch
-    ref, gref = fn(b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=4, want_guess=True)
+    req.security_margin = margin
+    ref, gref = oracle.collide_batch(b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=4, want_guess=True)
     got, ggot = hostsim.batch_f64(abi, b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, want_guess=True)
     assert np.array_equal(got["status"], ref["status"])
     assert np.array_equal(got["num_contacts"], ref["num_contacts"])
@@ -110,18 +108,35 @@ def test_device_header_triangle_pairs(pkg, oracle, hostsim, kind):
     assert np.nanmax(np.abs(ggot["gjk_guess"] - gref["gjk_guess"])) < 1e-12
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["distance", "collide"])
-def test_triangle_pairs_gpu(pkg, oracle, kind):
+def test_distance_on_a_triangle_is_unsupported_as_in_the_reference(pkg, oracle, hostsim):
+    """src/distance_func_matrix.cpp has no GEOM_TRIANGLE row or column: hpp::fcl::distance() throws for it."""
     abi, wl = pkg.abi, pkg.workloads
-    b = wl.triangle_pairs(n=50000, seed=4, kind=kind)
+    b = wl.triangle_pairs(n=200, seed=5, kind="distance")
     req = wl.make_request(b, abi)
-    fn = oracle.distance_batch if kind == "distance" else oracle.collide_batch
-    ref = fn(b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=8)
+    with pytest.raises(Exception):
+        oracle.distance_batch(b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req)
+    got = hostsim.batch_f64(abi, b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req)
+    assert abi.status_skipped(got["status"]).all()
+    f = pkg.engine.dll().hfcl_pair_supported
+    assert f(abi.GEOM_TRIANGLE, abi.GEOM_BOX, 0) == 1 and f(abi.GEOM_TRIANGLE, abi.GEOM_BOX, 1) == 0
+    assert f(abi.GEOM_PLANE, abi.GEOM_TRIANGLE, 0) == 1 and f(abi.GEOM_PLANE, abi.GEOM_TRIANGLE, 1) == 0
+
+
+@pytest.mark.gpu
+def test_triangle_pairs_gpu(pkg, oracle):
+    abi, wl = pkg.abi, pkg.workloads
+    kind = "collide"
+    b = wl.triangle_pairs(n=50000, seed=4)
+    req = wl.make_request(b, abi)
+    ref = oracle.collide_batch(b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=8)
     lib = pkg.Library(b.lib, device=0)
     try:
-        got = (lib.distance if kind == "distance" else lib.collide)(b.s1, b.s2, b.tf1, b.tf2, req)
+        got = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
         buckets = lib.last_bucket_counts()
+        bd = wl.triangle_pairs(n=100, seed=4, kind="distance")
+        with pytest.raises(pkg.EngineError) as e:  # distance(): no TriangleP in the reference's distance matrix
+            lib.distance(bd.s1, bd.s2, bd.tf1, bd.tf2, wl.make_request(bd, abi))
+        assert e.value.code == abi.ERR_UNSUPPORTED_PAIR
     finally:
         lib.close()
     assert buckets["tri"] == len(b) and buckets["unsupported"] == 0
