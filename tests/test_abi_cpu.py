@@ -93,3 +93,23 @@ def test_pair_supported_matches_the_reference_function_matrices(pkg):
         assert f(a.BV_OBBRSS, a.GEOM_TRIANGLE, dist) == 0 and f(a.GEOM_TRIANGLE, a.BV_OBBRSS, dist) == 0
         for bad in (0, 1, 8, 18, 20, 22, 300, -1):  # BV_AABB.., GEOM_OCTREE, HF_*, out of range
             assert f(bad, a.GEOM_BOX, dist) == 0 and f(a.GEOM_BOX, bad, dist) == 0, bad
+
+
+def test_dispatch_equals_the_reference_function_matrices(pkg):
+    """tests/golden/function_matrices.json = the entries src/collision_func_matrix.cpp / src/distance_func_matrix.cpp
+    set for the node types in scope (tools/extract_function_matrices.py, run where /root/reference exists).
+    hfcl_pair_supported answers what collide() / distance() accept: an entry, or -- for (GEOM, BVH) -- the entry of
+    the swapped pair (src/collision.cpp:87-108, src/distance.cpp:76-92)."""
+    import json
+    a = pkg.abi
+    f = pkg.engine.dll().hfcl_pair_supported
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "function_matrices.json")))
+    val = {n: getattr(a, n) for n in g["node_types"]}
+    assert len(g["collision"]) == 110 and len(g["distance"]) == 91
+    for mode, key in ((0, "collision"), (1, "distance")):
+        ref = {(x, y) for x, y in g[key]}
+        for x in g["node_types"]:
+            for y in g["node_types"]:
+                swap = x.startswith("GEOM_") and y.startswith("BV_")
+                expect = ((y, x) in ref) if swap else ((x, y) in ref)
+                assert bool(f(val[x], val[y], mode)) == expect, (key, x, y)
