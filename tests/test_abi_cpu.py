@@ -113,3 +113,39 @@ def test_dispatch_equals_the_reference_function_matrices(pkg):
                 swap = x.startswith("GEOM_") and y.startswith("BV_")
                 expect = ((y, x) in ref) if swap else ((x, y) in ref)
                 assert bool(f(val[x], val[y], mode)) == expect, (key, x, y)
+
+
+def test_request_defaults_equal_the_reference_headers(pkg):
+    """tests/golden/request_defaults.json = default-constructor values and enum orders parsed from the reference's
+    collision_data.h / narrowphase_defaults.h / data_types.h (tools/extract_request_defaults.py); the C library's
+    hfcl_*_request_init must fill exactly those, and the ABI's integer codes must follow the enum orders."""
+    import json
+    a = pkg.abi
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "request_defaults.json")))
+    lib = pkg.engine.dll()
+    c = a.CollisionRequest()
+    lib.hfcl_collision_request_init(C.byref(c))
+    d = a.DistanceRequest()
+    lib.hfcl_distance_request_init(C.byref(d))
+    en = g["enums"]
+    for q in (c.q, d.q):
+        r = g["QueryRequest"]
+        assert q.gjk_initial_guess == en["GJKInitialGuess"].index(r["gjk_initial_guess"])
+        assert q.gjk_variant == en["GJKVariant"].index(r["gjk_variant"])
+        assert q.gjk_convergence_criterion == en["GJKConvergenceCriterion"].index(r["gjk_convergence_criterion"])
+        assert q.gjk_convergence_criterion_type == en["GJKConvergenceCriterionType"].index(r["gjk_convergence_criterion_type"])
+        assert q.gjk_max_iterations == r["gjk_max_iterations"] and q.epa_max_iterations == r["epa_max_iterations"]
+        assert q.gjk_tolerance == r["gjk_tolerance"] and q.epa_tolerance == r["epa_tolerance"]
+        assert q.collision_distance_threshold == r["collision_distance_threshold"]
+        assert list(q.cached_gjk_guess) == [float(x) for x in r["cached_gjk_guess"].split(",")]
+    r = g["CollisionRequest"]
+    assert c.num_max_contacts == r["num_max_contacts"] and bool(c.enable_contact) == r["enable_contact"]
+    assert c.security_margin == r["security_margin"] and c.break_distance == r["break_distance"]
+    assert c.distance_upper_bound == r["distance_upper_bound"]
+    r = g["DistanceRequest"]
+    assert bool(d.enable_nearest_points) == r["enable_nearest_points"] and bool(d.enable_signed_distance) == r["enable_signed_distance"]
+    assert d.rel_err == r["rel_err"] and d.abs_err == r["abs_err"]
+    # integer codes of the ABI follow the reference's enum orders
+    assert [a.DefaultGJK, a.PolyakAcceleration, a.NesterovAcceleration] == [en["GJKVariant"].index(n) for n in
+                                                                           ("DefaultGJK", "PolyakAcceleration", "NesterovAcceleration")]
+    assert [a.Default, a.DualityGap, a.Hybrid] == [en["GJKConvergenceCriterion"].index(n) for n in ("Default", "DualityGap", "Hybrid")]
