@@ -119,6 +119,7 @@ def test_request_defaults_equal_the_reference_headers(pkg):
     """tests/golden/request_defaults.json = default-constructor values and enum orders parsed from the reference's
     collision_data.h / narrowphase_defaults.h / data_types.h (tools/extract_request_defaults.py); the C library's
     hfcl_*_request_init must fill exactly those, and the ABI's integer codes must follow the enum orders."""
+    import ctypes as C
     import json
     a = pkg.abi
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "request_defaults.json")))
