@@ -105,6 +105,8 @@ def test_dispatch_equals_the_reference_function_matrices(pkg):
     f = pkg.engine.dll().hfcl_pair_supported
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "function_matrices.json")))
     val = {n: getattr(a, n) for n in g["node_types"]}
+    for n in g["node_types"]:  # the ABI passes NODE_TYPE values through unchanged (collision_object.h:65-89)
+        assert val[n] == g["node_type_values"][n], n
     assert len(g["collision"]) == 110 and len(g["distance"]) == 91
     for mode, key in ((0, "collision"), (1, "distance")):
         ref = {(x, y) for x, y in g[key]}

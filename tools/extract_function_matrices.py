@@ -21,7 +21,12 @@ def entries(path, name):
     return sorted([a, b] for a, b in found if a in IN_SCOPE and b in IN_SCOPE)
 
 
-out = {"source": "hpp-fcl src/collision_func_matrix.cpp, src/distance_func_matrix.cpp", "node_types": IN_SCOPE,
+co = open(os.path.join(REF, "include/hpp/fcl/collision_object.h")).read()
+m = re.search(r"enum\s+NODE_TYPE\s*\{([^}]*)\}", co)
+node_type_values = {e.strip(): i for i, e in enumerate(x for x in m.group(1).split(",") if x.strip())}
+
+out = {"source": "hpp-fcl src/collision_func_matrix.cpp, src/distance_func_matrix.cpp, include/hpp/fcl/collision_object.h",
+       "node_types": IN_SCOPE, "node_type_values": node_type_values,
        "collision": entries(os.path.join(REF, "src/collision_func_matrix.cpp"), "collision_matrix"),
        "distance": entries(os.path.join(REF, "src/distance_func_matrix.cpp"), "distance_matrix")}
 dst = os.path.join(ROOT, "tests", "golden", "function_matrices.json")
