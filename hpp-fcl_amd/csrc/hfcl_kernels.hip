@@ -226,7 +226,8 @@ __device__ __forceinline__ void write_guess<double>(const IO<double>& io, uint32
 
 template <typename T>
 __device__ __forceinline__ V3<T> initial_guess(const IO<T>& io, const QParams<T>& q, uint32_t pair) {
-  if (q.guess_mode == HFCL_GUESS_CACHED) return mk<T>(q.guess[0], q.guess[1], q.guess[2]);
+  if (q.guess_mode == HFCL_GUESS_CACHED || q.guess_mode == HFCL_GUESS_BOUNDING_VOLUME)
+    return mk<T>(q.guess[0], q.guess[1], q.guess[2]);  // BoundingVolumeGuess: the solver's cached guess = the request's
   return mk<T>(T(1), T(0), T(0));
 }
 template <>
@@ -235,6 +236,7 @@ __device__ __forceinline__ V3<double> initial_guess<double>(const IO<double>& io
     if (io.gin) return mk<double>(io.gin[pair].gjk_guess[0], io.gin[pair].gjk_guess[1], io.gin[pair].gjk_guess[2]);
     return mk<double>(q.guess[0], q.guess[1], q.guess[2]);
   }
+  if (q.guess_mode == HFCL_GUESS_BOUNDING_VOLUME) return mk<double>(q.guess[0], q.guess[1], q.guess[2]);
   return mk<double>(1.0, 0.0, 0.0);
 }
 
@@ -407,7 +409,10 @@ __device__ __forceinline__ void finish_gjk(const Gjk<T, PW0<T>>& g, const Work& 
 // ---------------------------------------------------------------------------------------
 // k_gjk_prim: primitive x primitive GJK, one pair per lane.
 // ---------------------------------------------------------------------------------------
-template <typename T>
+// BVG: GJKInitialGuess::BoundingVolumeGuess.  A separate instantiation on purpose: the register allocation of the GJK
+// kernels is sensitive to anything live across their loop (the run-time form of this one select cost k_gjk_cvx<2,0>
+// 0.96 -> 1.51 ms), so the default-guess kernels are compiled without it.
+template <typename T, bool BVG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_PRIM, 8))) k_gjk_prim(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   const uint32_t cnt = wk.counts[B_PRIM];
   for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
@@ -422,7 +427,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_W
     const T r0 = swept_radius(a), r1 = swept_radius(b);
     const V3<T> guess0 = initial_guess<T>(io, q, pair);
     Gjk<T, PW0<T>> g;
-    gjk_run(g, q.gjk, guess0, r0 + r1, false, sup);
+    if constexpr (BVG)
+      gjk_run(g, q.gjk, start_guess(q, a, b, sup.md, guess0), r0 + r1, false, sup);
+    else
+      gjk_run(g, q.gjk, guess0, r0 + r1, false, sup);
     finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, true);
   }
 }
@@ -536,7 +544,7 @@ struct CvxSupport {
   __device__ __forceinline__ void operator()(const V3<T>& dir, V3<T>& w, V3<T>& w0) const { eval(dir, w, w0); }
 };
 
-template <typename T, int W, int M>
+template <typename T, int W, int M, bool BVG>
 __device__ __forceinline__ void gjk_cvx_body(const Work& wk, const LibView<T>& lib, const IO<T>& io, const QParams<T>& q) {
   constexpr int BUCKET = (M == 0) ? B_CC : (M == 1 ? B_PC : B_CP);
   const uint32_t cnt = wk.counts[BUCKET];
@@ -556,30 +564,33 @@ __device__ __forceinline__ void gjk_cvx_body(const Work& wk, const LibView<T>& l
     const V3<T> guess0 = initial_guess<T>(io, q, pair);
     Gjk<T, PW0<T>> g;
     // normalize_support_direction only when both are ConvexBase (minkowski_difference.cpp:261-266)
-    gjk_run(g, q.gjk, guess0, r0 + r1, M == 0, sup);
+    if constexpr (BVG)
+      gjk_run(g, q.gjk, start_guess(q, sup.a, sup.b, sup.md, guess0), r0 + r1, M == 0, sup);
+    else
+      gjk_run(g, q.gjk, guess0, r0 + r1, M == 0, sup);
     finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0);
   }
 }
 
 // Two entry points so that each precision gets its own register budget (waves per SIMD): the fp64
 // instantiation spills heavily at the fp32 setting (A/B in profiles/).
-template <int W, int M>
+template <int W, int M, bool BVG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 2 ? HFCL_WPE_GJK_W2 : HFCL_WPE_GJK, 8)))
 k_gjk_cvx(Work wk, LibView<float> lib, IO<float> io, QParams<float> q) {
-  gjk_cvx_body<float, W, M>(wk, lib, io, q);
+  gjk_cvx_body<float, W, M, BVG>(wk, lib, io, q);
 }
-template <int W, int M>
+template <int W, int M, bool BVG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_GJK64, 8)))
 k_gjk_cvx64(Work wk, LibView<double> lib, IO<double> io, QParams<double> q) {
-  gjk_cvx_body<double, W, M>(wk, lib, io, q);
+  gjk_cvx_body<double, W, M, BVG>(wk, lib, io, q);
 }
-template <int W, int M>
+template <int W, int M, bool BVG = false>
 static void launch_gjk_cvx(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q) {
-  hipLaunchKernelGGL((k_gjk_cvx<W, M>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+  hipLaunchKernelGGL((k_gjk_cvx<W, M, BVG>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
 }
-template <int W, int M>
+template <int W, int M, bool BVG = false>
 static void launch_gjk_cvx(int grid, hipStream_t st, const Work& wk, const LibView<double>& lv, const IO<double>& io, const QParams<double>& q) {
-  hipLaunchKernelGGL((k_gjk_cvx64<W, M>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+  hipLaunchKernelGGL((k_gjk_cvx64<W, M, BVG>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -633,7 +644,7 @@ struct LargeSupport {
   }
 };
 
-template <typename T>
+template <typename T, bool BVG>
 __global__ void __launch_bounds__(256) k_gjk_large(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   const uint32_t cnt = wk.counts[B_LARGE];
   const int lig = threadIdx.x & (LARGE_W - 1);
@@ -651,7 +662,10 @@ __global__ void __launch_bounds__(256) k_gjk_large(Work wk, LibView<T> lib, IO<T
     const T r0 = swept_radius(sup.a), r1 = swept_radius(sup.b);
     const V3<T> guess0 = initial_guess<T>(io, q, pair);
     Gjk<T, PW0<T>> g;
-    gjk_run(g, q.gjk, guess0, r0 + r1, sup.a.kind == K_CONVEX && sup.b.kind == K_CONVEX, sup);
+    if constexpr (BVG)
+      gjk_run(g, q.gjk, start_guess(q, sup.a, sup.b, sup.md, guess0), r0 + r1, sup.a.kind == K_CONVEX && sup.b.kind == K_CONVEX, sup);
+    else
+      gjk_run(g, q.gjk, guess0, r0 + r1, sup.a.kind == K_CONVEX && sup.b.kind == K_CONVEX, sup);
     finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0, true);
   }
 }
@@ -1651,6 +1665,19 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
     s32[i].p2 = float(s.params[2]);
     s32[i].p3 = float(s.params[3]);
     s32[i].ssr = float(s.swept_sphere_radius);
+    if (s.type == HFCL_GEOM_CONVEX && s.num_points > 0 && vertices &&
+        size_t(s.vertex_offset) + s.num_points <= n_vertices) {  // centre of aabb_local, for BoundingVolumeGuess
+      double mn[3], mx[3];
+      const double* v = vertices + 3 * size_t(s.vertex_offset);
+      for (int k = 0; k < 3; ++k) mn[k] = mx[k] = v[k];
+      for (uint32_t j = 1; j < s.num_points; ++j)
+        for (int k = 0; k < 3; ++k) {
+          mn[k] = std::min(mn[k], v[3 * size_t(j) + k]);
+          mx[k] = std::max(mx[k], v[3 * size_t(j) + k]);
+        }
+      s64[i].p0 = (mn[0] + mx[0]) * 0.5; s64[i].p1 = (mn[1] + mx[1]) * 0.5; s64[i].p2 = (mn[2] + mx[2]) * 0.5;
+      s32[i].p0 = float(s64[i].p0); s32[i].p1 = float(s64[i].p1); s32[i].p2 = float(s64[i].p2);
+    }
     kinds[i] = uint8_t(s.type == HFCL_GEOM_CONVEX && s.num_points > (uint32_t)HULL_MAX ? K_CONVEX_LARGE : s.type);
   }
   {
@@ -1915,9 +1942,9 @@ static int validate_query(const hfcl_query_request& q) {
     set_error("invalid GJK variant / convergence criterion");
     return HFCL_ERR_INVALID_ARGUMENT;
   }
-  if (q.gjk_initial_guess == HFCL_GUESS_BOUNDING_VOLUME) {
-    set_error("GJKInitialGuess::BoundingVolumeGuess is not supported by the batched engine yet");
-    return HFCL_ERR_LIMIT;
+  if (q.gjk_initial_guess < 0 || q.gjk_initial_guess > HFCL_GUESS_BOUNDING_VOLUME) {
+    set_error("Wrong initial guess for GJK.");  // narrowphase.h:379-380
+    return HFCL_ERR_INVALID_ARGUMENT;
   }
   return HFCL_OK;
 }
@@ -1937,6 +1964,11 @@ static void launch_cvx_m(hfcl_lib* lib, const Work& wk, const LibView<T>& lv, co
   if (b < 1) b = 1;
   if (b > size_t(lib->n_cus) * 16) b = size_t(lib->n_cus) * 16;
   const int grid = int(b);
+  if (q.guess_mode == HFCL_GUESS_BOUNDING_VOLUME) {  // instantiated for the widths in use only
+    if (w == 2) launch_gjk_cvx<2, M, true>(grid, st, wk, lv, io, q);
+    else launch_gjk_cvx<4, M, true>(grid, st, wk, lv, io, q);
+    return;
+  }
   switch (w) {
     case 2: launch_gjk_cvx<2, M>(grid, st, wk, lv, io, q); break;
     case 8: launch_gjk_cvx<8, M>(grid, st, wk, lv, io, q); break;
@@ -2025,6 +2057,7 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   // buckets no pair of this library's shape kinds can fall into are not launched at all
   auto may = [&](int b) { return (lib->possible_buckets >> b) & 1u; };
   const bool any_gjk = may(B_PRIM) || may(B_CC) || may(B_PC) || may(B_CP) || may(B_LARGE);
+  const bool bvg = q.guess_mode == HFCL_GUESS_BOUNDING_VOLUME;
   HIP_TRY(hipMemsetAsync(lib->d_counts, 0, (B_COUNT + 3) * sizeof(uint32_t), st));
   tbeg("k_classify");
   hipLaunchKernelGGL(k_classify, dim3(blocks_for(n, CLS_BLOCK * 8)), dim3(CLS_BLOCK), 0, st, wk, lib->d_kinds, uint32_t(lib->n_shapes), q.mode != 1);
@@ -2044,7 +2077,10 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   }
   if (may(B_PRIM)) {
     tbeg("k_gjk_prim");
-    hipLaunchKernelGGL((k_gjk_prim<T>), dim3(blocks_for(n, 256)), dim3(256), 0, st, wk, lv, io, q);
+    if (bvg)
+      hipLaunchKernelGGL((k_gjk_prim<T, true>), dim3(blocks_for(n, 256)), dim3(256), 0, st, wk, lv, io, q);
+    else
+      hipLaunchKernelGGL((k_gjk_prim<T, false>), dim3(blocks_for(n, 256)), dim3(256), 0, st, wk, lv, io, q);
     tend();
   }
 
@@ -2052,7 +2088,10 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
 
   if (may(B_LARGE)) {
     tbeg("k_gjk_large");
-    hipLaunchKernelGGL((k_gjk_large<T>), dim3(blocks_for(n, 256 / LARGE_W)), dim3(256), 0, st, wk, lv, io, q);
+    if (bvg)
+      hipLaunchKernelGGL((k_gjk_large<T, true>), dim3(blocks_for(n, 256 / LARGE_W)), dim3(256), 0, st, wk, lv, io, q);
+    else
+      hipLaunchKernelGGL((k_gjk_large<T, false>), dim3(blocks_for(n, 256 / LARGE_W)), dim3(256), 0, st, wk, lv, io, q);
     tend();
   }
 
@@ -2314,6 +2353,16 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
     set_error("Collision/distance function between some node types of the batch is not yet supported (" +
               std::to_string(lib->h_counts[B_UNSUPPORTED]) + " pairs; their records carry status bit 31)");
     return HFCL_ERR_UNSUPPORTED_PAIR;
+  }
+  {
+    // a TriangleP built inside the reference (top-level TriangleP overloads, mesh x shape leaves) never had
+    // computeLocalAABB() called: BoundingVolumeGuess throws there (narrowphase.h:366-373)
+    const hfcl_query_request& qq = creq ? creq->q : dreq->q;
+    if (!skipped && qq.gjk_initial_guess == HFCL_GUESS_BOUNDING_VOLUME &&
+        (lib->h_counts[B_TRI] > 0 || lib->h_counts[B_BVHSHAPE] > 0)) {
+      set_error("computeLocalAABB must have been called on the shapes before using GJKInitialGuess::BoundingVolumeGuess.");
+      return HFCL_ERR_INVALID_ARGUMENT;
+    }
   }
   if (!skipped && creq && creq->security_margin < 0 && lib->h_counts[B_BVHSHAPE] > 0) {
     set_error("Negative security margin are not handled yet for BVHModel");  // collision_func_matrix.cpp:109-112

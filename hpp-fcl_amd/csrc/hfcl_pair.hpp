@@ -45,6 +45,20 @@ HFCL_HD MDiff<T> make_mdiff(const Pose<T>& tf0, const Pose<T>& tf1) {
   return m;
 }
 
+// GJKInitialGuess::BoundingVolumeGuess (narrowphase.h:366-378): centre of shape 0's local AABB minus the centre of
+// shape 1's, in the frame of shape 0.  The local AABBs of the primitives are symmetric (centre 0); a ConvexBase
+// carries the centre of its vertices' box in p0..p2 (filled by hfcl_lib_create).
+template <typename T>
+HFCL_HD V3<T> bv_center(const DShape<T>& s) {
+  return s.kind == K_CONVEX ? mk<T>(s.p0, s.p1, s.p2) : mk<T>(T(0), T(0), T(0));
+}
+template <typename T>
+HFCL_HD V3<T> start_guess(const QParams<T>& q, const DShape<T>& a, const DShape<T>& b, const MDiff<T>& md,
+                                             const V3<T>& cached0) {
+  if (q.guess_mode != HFCL_GUESS_BOUNDING_VOLUME) return cached0;
+  return bv_center(a) - (mul(md.oR1, bv_center(b)) + md.ot1);
+}
+
 // What one finished query reports (world frame).
 template <typename T>
 struct PairOut {

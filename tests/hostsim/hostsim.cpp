@@ -6,6 +6,7 @@
 // be checked against the fp64 oracle in this GPU-less container (fp64 and fp32 instantiations).
 // It is NOT a fallback: the product library (csrc/libhppfcl_amd.so) neither links nor loads
 // this file, and the C ABI fails with HFCL_ERR_NO_DEVICE when there is no GPU.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -28,6 +29,25 @@ static DShape<T> to_dshape(const hfcl_shape& s) {
   d.p2 = T(s.params[2]);
   d.p3 = T(s.params[3]);
   d.ssr = T(s.swept_sphere_radius);
+  return d;
+}
+// as hfcl_lib_create: a ConvexBase carries the centre of its vertices' box in p0..p2 (BoundingVolumeGuess)
+template <typename T>
+static DShape<T> to_dshape(const hfcl_shape& s, const double* vertices) {
+  DShape<T> d = to_dshape<T>(s);
+  if (s.type == HFCL_GEOM_CONVEX && s.num_points > 0 && vertices) {
+    double mn[3], mx[3];
+    const double* v = vertices + 3 * size_t(s.vertex_offset);
+    for (int k = 0; k < 3; ++k) mn[k] = mx[k] = v[k];
+    for (uint32_t j = 1; j < s.num_points; ++j)
+      for (int k = 0; k < 3; ++k) {
+        mn[k] = std::min(mn[k], v[3 * size_t(j) + k]);
+        mx[k] = std::max(mx[k], v[3 * size_t(j) + k]);
+      }
+    d.p0 = T((mn[0] + mx[0]) * 0.5);
+    d.p1 = T((mn[1] + mx[1]) * 0.5);
+    d.p2 = T((mn[2] + mx[2]) * 0.5);
+  }
   return d;
 }
 
@@ -79,7 +99,7 @@ static void one_pair(const DShape<T>& a, const DShape<T>& b, const T* verts, con
     sup.md = make_mdiff(tf1, tf2);
     const T r0 = swept_radius(a), r1 = swept_radius(b);
     Gjk<T, PW0<T>> g;
-    gjk_run(g, q.gjk, guess0, r0 + r1, a.kind == K_CONVEX && b.kind == K_CONVEX, sup);
+    gjk_run(g, q.gjk, start_guess(q, a, b, sup.md, guess0), r0 + r1, a.kind == K_CONVEX && b.kind == K_CONVEX, sup);
     EpaSeed<T> seed;
     if (gjk_finish(g, q, tf1, r0, r1, guess0, o, seed)) {
       // same two-tier scheme as the kernels: small-capacity block first; on overflow the polytope is saved
@@ -117,7 +137,7 @@ int sim_batch_f64(const hfcl_shape* shapes, size_t n_shapes, const double* verti
                   const uint32_t* s2, const double* tf1, const double* tf2, size_t n, const hfcl_collision_request* creq,
                   const hfcl_distance_request* dreq, hfcl_result* out, const hfcl_guess* gin, hfcl_guess* gout) {
   std::vector<DShape<double>> lib(n_shapes);
-  for (size_t i = 0; i < n_shapes; ++i) lib[i] = to_dshape<double>(shapes[i]);
+  for (size_t i = 0; i < n_shapes; ++i) lib[i] = to_dshape<double>(shapes[i], vertices);
   QParams<double> q;
   if (creq) {
     fill_q(q, creq->q);
@@ -135,6 +155,7 @@ int sim_batch_f64(const hfcl_shape* shapes, size_t n_shapes, const double* verti
   }
   for (size_t i = 0; i < n; ++i) {
     V3<double> g0 = mk<double>(1, 0, 0);
+    if (q.guess_mode == HFCL_GUESS_BOUNDING_VOLUME) g0 = mk<double>(q.guess[0], q.guess[1], q.guess[2]);
     if (q.guess_mode == HFCL_GUESS_CACHED)
       g0 = gin ? mk<double>(gin[i].gjk_guess[0], gin[i].gjk_guess[1], gin[i].gjk_guess[2])
                : mk<double>(q.guess[0], q.guess[1], q.guess[2]);

@@ -53,6 +53,25 @@ def test_fp64_core_variants(pkg, oracle, hostsim, variant, crit):
     assert np.nanmax(np.abs(got["distance"] - ref["distance"])) < 1e-12
 
 
+@pytest.mark.parametrize("case", ["cfg5_mixed", "cfg3_convex_convex"])
+def test_fp64_core_bounding_volume_guess(pkg, oracle, hostsim, case):
+    """GJKInitialGuess::BoundingVolumeGuess (narrowphase.h:366-378): centre difference of the local AABBs."""
+    abi, wl = pkg.abi, pkg.workloads
+    b = getattr(wl, case)(n=6000, seed=5)
+    req = wl.make_request(b, abi)
+    req.q.gjk_initial_guess = abi.BoundingVolumeGuess
+    ref = _oracle(oracle, b, req, b.tf1, b.tf2)
+    got = hostsim.batch_f64(abi, b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req)
+    assert np.array_equal(got["status"], ref["status"])
+    fin = np.isfinite(ref["distance"]) & (np.abs(ref["distance"]) < 1e300)
+    assert np.abs(got["distance"][fin] - ref["distance"][fin]).max() < 1e-12
+    # it is a different start than the default guess: the iteration counts differ somewhere
+    req0 = wl.make_request(b, abi)
+    ref0 = _oracle(oracle, b, req0, b.tf1, b.tf2)
+    assert (abi.status_gjk_iters(ref0["status"]) != abi.status_gjk_iters(ref["status"])).mean() > 0.2
+    assert np.abs(ref0["distance"][fin] - ref["distance"][fin]).max() < 1e-5
+
+
 def test_fp64_core_collide_options(pkg, oracle, hostsim):
     """security margin, early stop (distance_upper_bound), enable_contact=false, cached guesses."""
     abi, wl = pkg.abi, pkg.workloads
