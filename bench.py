@@ -114,8 +114,13 @@ def main():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    # HFCL_BENCH_FORCE_DIST=1: run the N>1 code path (RCCL group, comm stream, async all-gather, barriers, max over
+    # ranks) with a single rank -- a dry run of the multi-GPU plumbing on a 1-GPU box
+    dist_on = world > 1 or os.environ.get("HFCL_BENCH_FORCE_DIST") == "1"
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     pkg = load_pkg()
     abi, wl = pkg.abi, pkg.workloads
@@ -166,7 +171,7 @@ def main():
         rec_words = 24
         launch = lib.distance_device if batch.kind == "distance" else lib.collide_device
     outs = [torch.zeros(n * rec_words, dtype=torch.int32, device=dev) for _ in range(2)]
-    gather = world > 1 and not args.no_gather
+    gather = dist_on and not args.no_gather
     gathered = [torch.empty(world * n * rec_words, dtype=torch.int32, device=dev) for _ in range(2)] if gather else None
     stream = torch.cuda.current_stream()
 
@@ -197,7 +202,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -222,7 +227,7 @@ def main():
         h.wait()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -330,7 +335,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     lib.close()
