@@ -334,11 +334,22 @@ def main():
                        "lane_group_width": os.environ.get("HFCL_CVX_W", "auto (2; fp64 convex-convex 4)")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+    else:
+        line = None
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     lib.close()
+    if line is not None:
+        # the JSON line goes out last: RCCL writes a version banner to the C stdout, which would otherwise be
+        # flushed after Python's buffer when stdout is a file or pipe
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
