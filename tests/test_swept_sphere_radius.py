@@ -61,7 +61,7 @@ def _check(abi, r0, r1, ra, rb, name):
     assert np.abs(r1["p2"][fin] - (r0["p2"][fin] - rb[:, None] * n0)).max() < 2 * tol, name
     # the bulk agrees to round-off: the radii are added after GJK / EPA, never inside the iterations
     assert np.quantile(np.abs(d1 - (d0 - ra - rb)), 0.99) < 1e-9, name
-    assert (d0 <= 0).mean() > 0.05 and (d0 > 0).mean() > 0.3
+    assert (d0 <= 0).mean() > 0.03 and (d0 > 0).mean() > 0.3
 
 
 def test_oracle_and_device_headers(pkg, oracle, hostsim):
