@@ -1523,7 +1523,9 @@ struct hfcl_lib {
   bool closed_staged = true;  // HFCL_CLOSED_STAGED=0: A/B switch back to the direct-access k_closed<double>
   int n_cus = 256;
   std::string dominant;
-  uint32_t h_counts[B_COUNT + 2] = {0};
+  // bucket populations of the last call; PINNED host memory so that the device-to-host copy at the end of a batch is
+  // asynchronous (a pageable destination makes hipMemcpyAsync block the host until the whole batch has run)
+  uint32_t* h_counts = nullptr;
   // BVH models (host staging + device images in both precisions; uploaded lazily)
   std::vector<hfcl_bvh_node> h_bvh_nodes;
   std::vector<double> h_bvh_verts;
@@ -1699,6 +1701,8 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   ok = ok && hipMalloc(&lib->d_verts64, (3 * n_vertices + 3) * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc(&lib->d_verts32, (3 * n_vertices + 3) * sizeof(float)) == hipSuccess;
   ok = ok && hipMalloc(&lib->d_counts, (B_COUNT + 3) * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&lib->h_counts, (B_COUNT + 2) * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+  if (ok) memset(lib->h_counts, 0, (B_COUNT + 2) * sizeof(uint32_t));
   if (ok) {
     ok = ok && hipMemcpy(lib->d_shapes64, s64.data(), n_shapes * sizeof(DShape<double>), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(lib->d_shapes32, s32.data(), n_shapes * sizeof(DShape<float>), hipMemcpyHostToDevice) == hipSuccess;
@@ -1738,6 +1742,7 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_verts64);
   hipFree(lib->d_verts32);
   hipFree(lib->d_counts);
+  if (lib->h_counts) hipHostFree(lib->h_counts);
   hipFree(lib->d_lists);
   hipFree(lib->d_epa_queue);
   hipFree(lib->d_epa_queue2);
@@ -2473,7 +2478,11 @@ int hfcl_last_kernel_breakdown(hfcl_lib* lib, const char** names, double* ms, in
 // bucket populations of the last call (after a stream sync): closed, prim, cc, pc, cp, bvh, unsupported,
 // epa queue, epa overflow queue
 void hfcl_last_bucket_counts(hfcl_lib* lib, uint32_t* out12) {  // B_COUNT buckets + the two EPA queues
-  for (int i = 0; i <= B_COUNT + 1; ++i) out12[i] = lib ? lib->h_counts[i] : 0;
+  if (lib) {  // the counters travel with an asynchronous copy at the end of the batch: wait for it
+    hipSetDevice(lib->device);
+    hipDeviceSynchronize();
+  }
+  for (int i = 0; i <= B_COUNT + 1; ++i) out12[i] = (lib && lib->h_counts) ? lib->h_counts[i] : 0;
 }
 
 }  // extern "C"
