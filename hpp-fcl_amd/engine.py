@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "hfcl_distance_batch_device", "hfcl_distance_batch_device_f32", "hfcl_collide_batch_device_f32",
     "hfcl_collide_batch_contacts", "hfcl_last_kernel_ms", "hfcl_last_kernel_name", "hfcl_bvh_build",
     "hfcl_world_aabbs", "hfcl_broadphase_self_pairs", "hfcl_broadphase_pairs_between", "hfcl_pairlist_size",
-    "hfcl_pairlist_data", "hfcl_pairlist_free", "hfcl_lib_set_kernel_timing", "hfcl_pair_supported",
+    "hfcl_pairlist_data", "hfcl_pairlist_free", "hfcl_lib_set_kernel_timing", "hfcl_pair_supported", "hfcl_last_kernel_breakdown", "hfcl_last_bucket_counts",
 ]
 
 

@@ -327,6 +327,13 @@ int hfcl_collide_batch_contacts(hfcl_lib* lib, const uint32_t* shape1, const uin
 double hfcl_last_kernel_ms(hfcl_lib* lib);
 /* Name of the dominant kernel of the last call (for matching rocprofv3 output). */
 const char* hfcl_last_kernel_name(hfcl_lib* lib);
+/* (name, milliseconds) of the kernels of the last call, up to `cap` entries; returns the number written.
+ * Synchronises on the recorded events. */
+int hfcl_last_kernel_breakdown(hfcl_lib* lib, const char** names, double* ms, int cap);
+/* Populations of the last call: the 10 kernel buckets (closed, prim, cc, pc, cp, bvh, unsupported, large,
+ * bvh_shape, tri) followed by the two EPA queue lengths.  Waits for the device (the counters come back with an
+ * asynchronous copy into pinned memory at the end of the batch). */
+void hfcl_last_bucket_counts(hfcl_lib* lib, uint32_t* out12);
 /* Per-kernel HIP events are recorded by default; a caller that does not read them can switch
  * them off (on = 0) and save two stream markers per kernel launch. */
 void hfcl_lib_set_kernel_timing(hfcl_lib* lib, int on);
