@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4", "cfg5", "cfg1", "cfg3u"])
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default 1M; cfg4: 100k; cfg5: 1.25M = 10M / 8)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of result records (N>1)")
+    ap.add_argument("--split", type=int, default=0, help="0: the library decides (two half-batches on two streams for "
+                    "mixed libraries); 1: one stream; 2: always split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     return ap.parse_args()
@@ -157,6 +159,8 @@ def main():
         dtype = "f64"
     req = wl.make_request(batch, abi)
     lib = wl.make_library(pkg, batch, device=local_rank)
+    if args.split:
+        lib.set_split(args.split)
 
     d_s1 = torch.from_numpy(batch.s1.astype(np.int32)).to(dev)
     d_s2 = torch.from_numpy(batch.s2.astype(np.int32)).to(dev)
@@ -270,6 +274,8 @@ def main():
             units = buckets["epa_overflow"]
         else:
             units = n
+        split = lib.last_split_parts()
+        units = units / split  # a launch covers one half of a split batch
         dom_ms = avg.get(dominant, float("nan"))
         achieved = (units * bpq) / (dom_ms * 1e-3) / 1e9 if dom_ms == dom_ms and dom_ms > 0 else None
         pipeline_ms = float(sum(avg.values()))
@@ -287,7 +293,7 @@ def main():
             "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_note": traffic_note,
             "bytes_per_query": bpq, "units_per_launch": units, "kernel_ms": dom_ms,
-            "pipeline_ms": pipeline_ms, "pipeline_achieved": (n * bpq) / (pipeline_ms * 1e-3) / 1e9 if pipeline_ms else None,
+            "pipeline_ms": pipeline_ms, "pipeline_achieved": (n * bpq) / (ms_per_step * 1e-3) / 1e9,
             "kernels_ms": avg, "valu_issue": valu,
         }
         cpu = None
@@ -330,7 +336,7 @@ def main():
                                            "cfg1": "configs[0] (shape pair; GPU batch size)",
                                            "cfg3u": "configs[2], one hull pair per query"}[args.workload],
                        "pairs_per_gpu_per_step": n, "contact_fraction": contact_frac, "buckets": buckets,
-                       "request": batch.kind, "all_gather_results": bool(gather),
+                       "request": batch.kind, "all_gather_results": bool(gather), "split_parts": lib.last_split_parts(),
                        "lane_group_width": os.environ.get("HFCL_CVX_W", "auto (2; fp64 convex-convex 4)")},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -1517,6 +1517,15 @@ struct hfcl_lib {
   hfcl_guess *d_gin = nullptr, *d_gout = nullptr;
   // instrumentation
   std::vector<KernelTime> timers;
+  // A batch can run as two halves on two streams (hfcl_lib_set_split): the second half goes to `helper`, a shallow
+  // clone (same device shape tables, own workspace / counters / timers) on the internal stream `side`, whose kernels
+  // fill the drain phases of the first half's GJK / EPA launches (profiles/r01_k_two_stream_overlap.txt).
+  int split = 0;  // 0 = automatic (auto_split), 1 = never, 2 = always (large batches without meshes)
+  hfcl_lib* helper = nullptr;
+  bool is_helper = false;   // does not own the shape tables
+  bool last_split = false;  // the last batch ran split: counters / timers of the helper belong to it
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool kernel_timing = true;         // HIP events around every kernel (hfcl_lib_set_kernel_timing)
   uint32_t possible_buckets = ~0u;   // bit b: some pair of this library's shape kinds classifies into bucket b
   int cvx_w = 0;  // 0 = per kernel (auto_cvx_w); HFCL_CVX_W forces one width for all
@@ -1547,6 +1556,13 @@ struct hfcl_lib {
   BvhParams bvh_params = {1u, nullptr, 0u, nullptr};
   double break_distance = 1e-3;
 };
+
+// bucket population i of the last batch (both halves of a split batch)
+static uint32_t total_count(const hfcl_lib* lib, int i) {
+  uint32_t c = lib->h_counts ? lib->h_counts[i] : 0u;
+  if (lib->last_split && lib->helper && lib->helper->h_counts) c += lib->helper->h_counts[i];
+  return c;
+}
 
 static int ensure_device(int device) {
   int n = 0;
@@ -1726,6 +1742,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
     return nullptr;
   }
   if (const char* v = getenv("HFCL_CLOSED_STAGED")) lib->closed_staged = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_SPLIT")) lib->split = atoi(v) >= 2 ? 2 : (atoi(v) == 1 ? 1 : 0);
   if (const char* w = getenv("HFCL_CVX_W")) {
     int v = atoi(w);
     if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) lib->cvx_w = v;
@@ -1736,11 +1753,18 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
 void hfcl_lib_destroy(hfcl_lib* lib) {
   if (!lib) return;
   hipSetDevice(lib->device);
-  hipFree(lib->d_shapes64);
-  hipFree(lib->d_shapes32);
-  hipFree(lib->d_kinds);
-  hipFree(lib->d_verts64);
-  hipFree(lib->d_verts32);
+  hipDeviceSynchronize();
+  if (lib->helper) hfcl_lib_destroy(lib->helper);
+  if (lib->side) hipStreamDestroy(lib->side);
+  if (lib->ev_fork) hipEventDestroy(lib->ev_fork);
+  if (lib->ev_join) hipEventDestroy(lib->ev_join);
+  if (!lib->is_helper) {
+    hipFree(lib->d_shapes64);
+    hipFree(lib->d_shapes32);
+    hipFree(lib->d_kinds);
+    hipFree(lib->d_verts64);
+    hipFree(lib->d_verts32);
+  }
   hipFree(lib->d_counts);
   if (lib->h_counts) hipHostFree(lib->h_counts);
   hipFree(lib->d_lists);
@@ -2014,8 +2038,8 @@ static void launch_cvx(hfcl_lib* lib, const Work& wk, const LibView<T>& lv, cons
 
 // The whole pipeline for one batch, asynchronous on `st`.
 template <typename T>
-static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, IO<T> io, size_t n, QParams<T> q,
-                     hipStream_t st) {
+static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, IO<T> io, size_t n, QParams<T> q,
+                         hipStream_t st) {
   if (n == 0) return HFCL_OK;
   if (n > 0xFFFFFFF0ull) {
     set_error("batch too large (max 2^32-16 pairs per call)");
@@ -2157,6 +2181,84 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
   }
   HIP_TRY(hipMemcpyAsync(lib->h_counts, lib->d_counts, (B_COUNT + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipGetLastError());
+  return HFCL_OK;
+}
+
+// shallow clone for the second half of a split batch: shares the device shape tables, owns everything else
+static hfcl_lib* make_helper(hfcl_lib* lib) {
+  hfcl_lib* h = new hfcl_lib;
+  h->is_helper = true;
+  h->device = lib->device;
+  h->n_shapes = lib->n_shapes;
+  h->d_shapes64 = lib->d_shapes64;
+  h->d_shapes32 = lib->d_shapes32;
+  h->d_verts64 = lib->d_verts64;
+  h->d_verts32 = lib->d_verts32;
+  h->d_kinds = lib->d_kinds;
+  h->possible_buckets = lib->possible_buckets;
+  h->cvx_w = lib->cvx_w;
+  h->closed_staged = lib->closed_staged;
+  h->n_cus = lib->n_cus;
+  bool ok = hipMalloc(&h->d_counts, (B_COUNT + 3) * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&h->h_counts, (B_COUNT + 2) * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipMalloc(&h->d_epa_v0, size_t(h->n_cus) * 16 * (64 / EPA_WE2) * EPA_MAX_VERTS * sizeof(Quad<double>)) == hipSuccess;
+  if (!ok) {
+    hfcl_lib_destroy(h);
+    return nullptr;
+  }
+  memset(h->h_counts, 0, (B_COUNT + 2) * sizeof(uint32_t));
+  return h;
+}
+
+template <typename T> static IO<T> io_at(const IO<T>& io, size_t lo);
+template <> IO<double> io_at(const IO<double>& io, size_t lo) {
+  return IO<double>{io.tf1 + 12 * lo, io.tf2 + 12 * lo, io.out + lo, io.gin ? io.gin + lo : nullptr, io.gout ? io.gout + lo : nullptr};
+}
+template <> IO<float> io_at(const IO<float>& io, size_t lo) {
+  return IO<float>{io.tf1 + 7 * lo, io.tf2 + 7 * lo, io.out + lo, nullptr, nullptr};
+}
+
+template <typename T>
+static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, IO<T> io, size_t n, QParams<T> q,
+                     hipStream_t st) {
+  constexpr size_t MIN_SPLIT = 1u << 17;
+  lib->last_split = false;
+  // Automatic choice: a library whose pairs spread over three or more of the iterative buckets (mixed scenes: cfg5
+  // 4.05 -> 3.80 ms) -- the halves then run different kernels side by side; with one or two kernels in the batch the
+  // halves only share the machine phase by phase and the doubled fixed costs lose 3 % (cfg2, cfg3).  A/B in
+  // profiles/r01_k_two_stream_overlap.txt.
+  int parts = lib->split;
+  if (parts == 0) {
+    int kinds = 0;
+    for (int b : {int(B_PRIM), int(B_CC), int(B_PC), int(B_CP), int(B_LARGE)}) kinds += (lib->possible_buckets >> b) & 1u;
+    parts = kinds >= 3 ? 2 : 1;
+  }
+  // meshes keep query-wide side state (contact lists, pair ids in them): they run unsplit
+  if (parts < 2 || n < MIN_SPLIT || !lib->h_meshes.empty()) return run_batch_one<T>(lib, d_s1, d_s2, io, n, q, st);
+  HIP_TRY(hipSetDevice(lib->device));
+  if (!lib->helper) {
+    lib->helper = make_helper(lib);
+    if (!lib->helper || hipStreamCreateWithFlags(&lib->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&lib->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&lib->ev_join, hipEventDisableTiming) != hipSuccess) {
+      set_error("split batches: HIP allocation failed");
+      return HFCL_ERR_HIP;
+    }
+  }
+  hfcl_lib* h2 = lib->helper;
+  h2->kernel_timing = lib->kernel_timing;
+  h2->break_distance = lib->break_distance;
+  h2->bvh_params = lib->bvh_params;
+  const size_t h = n / 2;
+  HIP_TRY(hipEventRecord(lib->ev_fork, st));  // the inputs are ready where the caller's stream stands now
+  HIP_TRY(hipStreamWaitEvent(lib->side, lib->ev_fork, 0));
+  int rc = run_batch_one<T>(lib, d_s1, d_s2, io, h, q, st);
+  if (rc) return rc;
+  rc = run_batch_one<T>(h2, d_s1 + h, d_s2 + h, io_at<T>(io, h), n - h, q, lib->side);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(lib->ev_join, lib->side));
+  HIP_TRY(hipStreamWaitEvent(st, lib->ev_join, 0));  // results are complete in the caller's stream order
+  lib->last_split = true;
   return HFCL_OK;
 }
 
@@ -2354,9 +2456,9 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
   HIP_TRY(hipMemcpy(out, lib->d_out, n * sizeof(hfcl_result), hipMemcpyDeviceToHost));
   if (gout) HIP_TRY(hipMemcpy(gout, lib->d_gout, n * sizeof(hfcl_guess), hipMemcpyDeviceToHost));
   const bool skipped = creq && creq->security_margin == -__builtin_inf();
-  if (!skipped && lib->h_counts[B_UNSUPPORTED] > 0) {
+  if (!skipped && total_count(lib, B_UNSUPPORTED) > 0) {
     set_error("Collision/distance function between some node types of the batch is not yet supported (" +
-              std::to_string(lib->h_counts[B_UNSUPPORTED]) + " pairs; their records carry status bit 31)");
+              std::to_string(total_count(lib, B_UNSUPPORTED)) + " pairs; their records carry status bit 31)");
     return HFCL_ERR_UNSUPPORTED_PAIR;
   }
   {
@@ -2364,16 +2466,16 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
     // computeLocalAABB() called: BoundingVolumeGuess throws there (narrowphase.h:366-373)
     const hfcl_query_request& qq = creq ? creq->q : dreq->q;
     if (!skipped && qq.gjk_initial_guess == HFCL_GUESS_BOUNDING_VOLUME &&
-        (lib->h_counts[B_TRI] > 0 || lib->h_counts[B_BVHSHAPE] > 0)) {
+        (total_count(lib, B_TRI) > 0 || total_count(lib, B_BVHSHAPE) > 0)) {
       set_error("computeLocalAABB must have been called on the shapes before using GJKInitialGuess::BoundingVolumeGuess.");
       return HFCL_ERR_INVALID_ARGUMENT;
     }
   }
-  if (!skipped && creq && creq->security_margin < 0 && lib->h_counts[B_BVHSHAPE] > 0) {
+  if (!skipped && creq && creq->security_margin < 0 && total_count(lib, B_BVHSHAPE) > 0) {
     set_error("Negative security margin are not handled yet for BVHModel");  // collision_func_matrix.cpp:109-112
     return HFCL_ERR_INVALID_ARGUMENT;
   }
-  if (!skipped && (lib->h_counts[B_BVH] > 0 || lib->h_counts[B_BVHSHAPE] > 0) && lib->h_meshes.empty()) {
+  if (!skipped && (total_count(lib, B_BVH) > 0 || total_count(lib, B_BVHSHAPE) > 0) && lib->h_meshes.empty()) {
     set_error("BVH shapes in the batch but no BVHModel registered (hfcl_lib_add_bvh)");
     return HFCL_ERR_INVALID_ARGUMENT;
   }
@@ -2468,12 +2570,26 @@ int hfcl_last_kernel_breakdown(hfcl_lib* lib, const char** names, double* ms, in
     float m = 0;
     if (hipEventSynchronize(t.e1) != hipSuccess) continue;
     if (hipEventElapsedTime(&m, t.e0, t.e1) != hipSuccess) continue;
+    // split batch: the two halves ran the same launch sequence on two streams; report the mean as-run duration of a launch
+    const size_t i = size_t(&t - lib->timers.data());
+    if (lib->last_split && lib->helper && i < lib->helper->timers.size() && lib->helper->timers[i].used) {
+      KernelTime& u = lib->helper->timers[i];
+      float m2 = 0;
+      if (hipEventSynchronize(u.e1) == hipSuccess && hipEventElapsedTime(&m2, u.e0, u.e1) == hipSuccess) m = 0.5f * (m + m2);
+    }
     names[k] = t.name;
     ms[k] = m;
     ++k;
   }
   return k;
 }
+
+// parts = 2: batches of at least 128k pairs (libraries without meshes) run as two halves on two streams; 1: one stream
+void hfcl_lib_set_split(hfcl_lib* lib, int parts) {
+  if (lib) lib->split = parts >= 2 ? 2 : (parts == 1 ? 1 : 0);
+}
+int hfcl_lib_get_split(const hfcl_lib* lib) { return lib ? lib->split : 0; }
+int hfcl_lib_last_split_parts(const hfcl_lib* lib) { return (lib && lib->last_split) ? 2 : 1; }
 
 // bucket populations of the last call (after a stream sync): closed, prim, cc, pc, cp, bvh, unsupported,
 // epa queue, epa overflow queue
@@ -2482,7 +2598,7 @@ void hfcl_last_bucket_counts(hfcl_lib* lib, uint32_t* out12) {  // B_COUNT bucke
     hipSetDevice(lib->device);
     hipDeviceSynchronize();
   }
-  for (int i = 0; i <= B_COUNT + 1; ++i) out12[i] = (lib && lib->h_counts) ? lib->h_counts[i] : 0;
+  for (int i = 0; i <= B_COUNT + 1; ++i) out12[i] = lib ? total_count(lib, i) : 0;
 }
 
 }  // extern "C"

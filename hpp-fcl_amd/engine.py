@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "hfcl_distance_batch_device", "hfcl_distance_batch_device_f32", "hfcl_collide_batch_device_f32",
     "hfcl_collide_batch_contacts", "hfcl_last_kernel_ms", "hfcl_last_kernel_name", "hfcl_bvh_build",
     "hfcl_world_aabbs", "hfcl_broadphase_self_pairs", "hfcl_broadphase_pairs_between", "hfcl_pairlist_size",
-    "hfcl_pairlist_data", "hfcl_pairlist_free", "hfcl_lib_set_kernel_timing", "hfcl_pair_supported", "hfcl_last_kernel_breakdown", "hfcl_last_bucket_counts",
+    "hfcl_pairlist_data", "hfcl_pairlist_free", "hfcl_lib_set_kernel_timing", "hfcl_pair_supported", "hfcl_last_kernel_breakdown", "hfcl_last_bucket_counts", "hfcl_lib_set_split", "hfcl_lib_get_split", "hfcl_lib_last_split_parts",
 ]
 
 
@@ -243,6 +243,17 @@ class Library:
                                                     C.c_void_p(stream)))
 
     # ---- instrumentation ----
+    def set_split(self, parts):
+        """2: large batches run as two halves on two streams (hfcl_lib_set_split); 1: one stream."""
+        dll().hfcl_lib_set_split(self._h, C.c_int(int(parts)))
+
+    def get_split(self):
+        return int(dll().hfcl_lib_get_split(self._h))
+
+    def last_split_parts(self):
+        """1 or 2: how the last batch actually ran."""
+        return int(dll().hfcl_lib_last_split_parts(self._h))
+
     def set_kernel_timing(self, on):
         """Per-kernel HIP events on/off (on by default; off saves two stream markers per launch)."""
         dll().hfcl_lib_set_kernel_timing(self._h, C.c_int(1 if on else 0))

@@ -334,6 +334,14 @@ int hfcl_last_kernel_breakdown(hfcl_lib* lib, const char** names, double* ms, in
  * bvh_shape, tri) followed by the two EPA queue lengths.  Waits for the device (the counters come back with an
  * asynchronous copy into pinned memory at the end of the batch). */
 void hfcl_last_bucket_counts(hfcl_lib* lib, uint32_t* out12);
+/* Batches of >= 128k pairs (library without meshes) can run as two halves on two streams -- the caller's and an
+ * internal one, forked and joined with events, so the call stays asynchronous and ordered on the caller's stream.
+ * Pays when the halves run different kernels side by side (mixed scenes: -6 % per batch) and costs ~3 % when the
+ * batch has one or two kernels.  parts: 0 = automatic (on when the library's shape kinds spread the pairs over three or
+ * more iterative buckets; the default), 1 = never, 2 = always.  Results are bit-identical either way. */
+void hfcl_lib_set_split(hfcl_lib* lib, int parts);
+int  hfcl_lib_get_split(const hfcl_lib* lib);
+int  hfcl_lib_last_split_parts(const hfcl_lib* lib);  /* 1 or 2: how the last batch ran */
 /* Per-kernel HIP events are recorded by default; a caller that does not read them can switch
  * them off (on = 0) and save two stream markers per kernel launch. */
 void hfcl_lib_set_kernel_timing(hfcl_lib* lib, int on);

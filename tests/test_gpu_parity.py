@@ -243,6 +243,48 @@ def test_full_size_properties(pkg, oracle, torch_cuda, case):
     lib.close()
 
 
+@pytest.mark.parametrize("case", ["cfg3_convex_convex", "cfg5_mixed"])
+def test_split_batches_are_bit_identical(pkg, torch_cuda, case):
+    """hfcl_lib_set_split(2): the two halves of a batch run on two streams; every record (and cached guess) is the
+    one the unsplit call produces, and the bucket populations add up."""
+    abi, wl = pkg.abi, pkg.workloads
+    b = getattr(wl, case)(n=300_001)
+    req = wl.make_request(b, abi)
+    lib = pkg.Library(b.lib)
+    fn = lib.distance if b.kind == "distance" else lib.collide
+    lib.set_split(1)
+    one, g1 = fn(b.s1, b.s2, b.tf1, b.tf2, req, want_guess=True)
+    assert lib.last_split_parts() == 1
+    c1 = lib.last_bucket_counts()
+    lib.set_split(0)  # automatic: on for the mixed library only
+    fn(b.s1, b.s2, b.tf1, b.tf2, req)
+    assert lib.last_split_parts() == (2 if case == "cfg5_mixed" else 1)
+    lib.set_split(2)
+    assert lib.get_split() == 2
+    for _ in range(2):  # twice: the helper's workspace is reused
+        two, g2 = fn(b.s1, b.s2, b.tf1, b.tf2, req, want_guess=True)
+        c2 = lib.last_bucket_counts()
+        assert one.tobytes() == two.tobytes() and g1.tobytes() == g2.tobytes()
+        assert c1 == c2
+    # fp32 device-resident entry point on a caller-owned stream
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    d = [torch.from_numpy(x).to(dev) for x in (b.s1.astype(np.int32), b.s2.astype(np.int32), b.pose1_f32, b.pose2_f32)]
+    f32 = lib.distance_device_f32 if b.kind == "distance" else lib.collide_device_f32
+    outs = []
+    for parts in (1, 2):
+        lib.set_split(parts)
+        o = torch.zeros(len(b) * 11, dtype=torch.int32, device=dev)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            f32(*d, len(b), req, o, stream=st.cuda_stream)
+            o2 = o.clone()  # ordered after the call on the caller's stream: must see complete results
+        torch.cuda.synchronize()
+        outs.append((o.cpu().numpy(), o2.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[1][0], outs[1][1])
+    lib.close()
+
+
 # ------------------------------------------------------------------------------------- BVH (cfg4)
 def _run_bvh(pkg, oracle, b, req, max_contacts=0):
     bb = pkg.bvh_builder
