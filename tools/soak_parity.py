@@ -55,6 +55,52 @@ def main():
               "(oracle %d thr %.1fs, engine %.2fs incl. copies)" %
               (name, str(over or kw or ""), len(b), st["contact_frac"], st["flag_mismatch"], st["gjk_status_mismatch"],
                st["epa_status_mismatch"], st["dist_bad"], st["sep_bad"], st["max_dd"], st["p999_dd"], threads, t_cpu, t_gpu), flush=True)
+    # ---- meshes (cfg4): collide (first contact in DFS order) and distance, 5 000-triangle models
+    bb = pkg.bvh_builder
+    nm = max(n // 10, 1000)
+    for seed, hw in ((31, 1.25), (32, 1.0)):
+        b = wl.cfg4_mesh_mesh(n=nm, seed=seed, half_width=hw)
+        ML = bb.MeshLibrary(b.meshes)
+        req = wl.make_request(b, abi)
+        lib = wl.make_library(pkg, b)
+        got = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
+        gd = lib.distance(b.s1, b.s2, b.tf1, b.tf2)
+        lib.close()
+        ref = ob.bvh_collide_batch(ML, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=threads)
+        rd = ob.bvh_distance_batch(ML, b.s1, b.s2, b.tf1, b.tf2, n_threads=threads)
+        assert not np.any((got["status"] >> 30) & 1) and not np.any((gd["status"] >> 30) & 1), "traversal stack overflow"
+        near = np.abs(ref["distance"]) < 1e-9
+        same = got["num_contacts"] == ref["num_contacts"]
+        ok = same & ~near
+        ids = (got["b1"][ok] == ref["b1"][ok]) & (got["b2"][ok] == ref["b2"][ok])
+        fin = ok & (np.abs(ref["distance"]) < 1e300)
+        dd = np.abs(got["distance"][fin] - ref["distance"][fin]).max()
+        ddist = np.abs(gd["distance"] - rd["distance"]).max()
+        assert np.all(same | near) and ids.all() and dd < 1e-6 and ddist < 1e-9, (same.mean(), ids.mean(), dd, ddist)
+        total += 2 * len(b)
+        print("cfg4_mesh_mesh seed %d      n=%8d  collide: contact counts / first-contact ids identical (%d near-zero skipped), "
+              "max|dd| %.1e, contacts %.3f;  distance: max|dd| %.1e" %
+              (seed, len(b), int(near.sum()), dd, float((ref["num_contacts"] > 0).mean()), ddist), flush=True)
+    # ---- fp32 device-resident path (cfg3, the bench configuration): envelope of DESIGN.md "fp32 path"
+    import torch
+    dev = torch.device("cuda:0")
+    for seed in (41, 42):
+        b = wl.cfg3_convex_convex(n=n, seed=seed)
+        req = wl.make_request(b, abi)
+        tf1, tf2 = b.tf_from_f32()
+        ref = ob.distance_batch(b.shapes, b.verts, b.s1, b.s2, tf1, tf2, req, n_threads=threads)
+        lib = pkg.Library(b.lib)
+        d = [torch.from_numpy(x).to(dev) for x in (b.s1.astype(np.int32), b.s2.astype(np.int32), b.pose1_f32, b.pose2_f32)]
+        o = torch.zeros(len(b) * 11, dtype=torch.int32, device=dev)
+        lib.distance_device_f32(*d, len(b), req, o, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = o.cpu().numpy().view(abi.RESULT_F32_DTYPE)
+        lib.close()
+        st = check_parity(abi, got, ref, dist_tol=1e-4, point_tol=5e-4, flag_band=1e-4, name="cfg3-f32", fp32=True,
+                          allow_bad_frac=2e-5)
+        total += len(b)
+        print("cfg3 fp32 device path seed %d n=%8d contacts %.3f  flag/dist/sep outside the fp32 envelope %d/%d/%d  max|dd| %.2e" %
+              (seed, len(b), st["contact_frac"], st["flag_mismatch"], st["dist_bad"], st["sep_bad"], st["max_dd"]), flush=True)
     print("soak: %d pairs compared in %.0f s" % (total, time.time() - t_all))
 
 
