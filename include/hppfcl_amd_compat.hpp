@@ -486,7 +486,7 @@ class BatchQueries {
       bool same = o.type == s.type && o.num_points == s.num_points && o.swept_sphere_radius == s.swept_sphere_radius &&
                   o.params[0] == s.params[0] && o.params[1] == s.params[1] && o.params[2] == s.params[2] &&
                   o.params[3] == s.params[3];
-      if (same && s.type == GEOM_CONVEX)
+      if (same && (s.type == GEOM_CONVEX || s.type == GEOM_TRIANGLE))  // both carry their vertices in verts_
         for (size_t k = 0; k < v.size() && same; ++k) same = verts_[3 * size_t(o.vertex_offset) + k] == v[k];
       if (same) return it->second;
     }
@@ -525,9 +525,13 @@ class BatchQueries {
         res.normal = n;
       }
       if (r.num_contacts > 1 && !contacts_.empty()) {
+        // contacts_ is ordered by query (run() sorts it once): this query's contacts are one contiguous range
         const uint32_t qi = static_cast<uint32_t>(&r - rec_.data());
-        for (const hfcl_contact& k : contacts_) {
-          if (k.pair != qi || res.numContacts() >= request.num_max_contacts) continue;
+        auto lo = std::lower_bound(contacts_.begin(), contacts_.end(), qi,
+                                   [](const hfcl_contact& c, uint32_t q) { return c.pair < q; });
+        for (; lo != contacts_.end() && lo->pair == qi; ++lo) {
+          const hfcl_contact& k = *lo;
+          if (res.numContacts() >= request.num_max_contacts) break;
           Contact c;
           c.o1 = geoms_[p.first];
           c.o2 = geoms_[p.second];
@@ -606,6 +610,10 @@ class BatchQueries {
         cap = produced;
       }
       contacts_.resize(rc ? 0 : std::min(produced, cap));
+      // the device appends contacts in completion order: group them by query once (the order of one query's
+      // contacts -- its traversal order -- is kept), so that fill() finds a query's range by binary search
+      std::stable_sort(contacts_.begin(), contacts_.end(),
+                       [](const hfcl_contact& x, const hfcl_contact& y) { return x.pair < y.pair; });
       for (auto& g : guess_) g = hfcl_guess{{1, 0, 0}, {0, 0}};
     } else if (creq) {
       const hfcl_collision_request a = to_abi(*creq);

@@ -170,6 +170,16 @@ int main() {
     rs.clear();
     CHECK(collide(&b, Transform3f(), &tri, Transform3f(Vec3f(0, 0, 0.5)), rq, rs) == 1);
     CHECK(std::fabs(rs.getContact(0).penetration_depth + 0.5) < 1e-6);
+    {  // a TriangleP whose corners change between two calls (same address) must not hit the shape cache
+      TriangleP moving(Vec3f(-5, -5, 3), Vec3f(5, -5, 3), Vec3f(0, 5, 3));
+      rs.clear();
+      CHECK(collide(&b, Transform3f(), &moving, Transform3f(), rq, rs) == 0);
+      CHECK(std::fabs(rs.distance_lower_bound - 2) < 1e-6);
+      moving.a[2] = moving.b[2] = moving.c[2] = 0.5;  // now cuts the box
+      rs.clear();
+      CHECK(collide(&b, Transform3f(), &moving, Transform3f(), rq, rs) == 1);
+      CHECK(std::fabs(rs.getContact(0).penetration_depth + 0.5) < 1e-6);
+    }
     // the reference's distance matrix has no TriangleP entries: distance() throws (src/distance.cpp:69-75)
     bool threw_d = false;
     DistanceRequest dq; DistanceResult dr;
