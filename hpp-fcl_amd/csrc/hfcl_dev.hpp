@@ -1,0 +1,409 @@
+// hfcl_dev.hpp -- what the kernel translation units (hfcl_k_gjk.hip, hfcl_k_epa.hip, hfcl_k_bvh.hip) and the host side
+// (hfcl_host.hip) share: bucket ids, kernel parameter blocks, result-record writers, lane-group primitives, the
+// register-resident hull, tier constants of the EPA kernels and the BVH views.  gfx950 / wave64 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <type_traits>
+
+#include "../../include/hppfcl_amd.h"
+#include "hfcl_bvh.hpp"
+#include "hfcl_bvh_shape.hpp"
+#include "hfcl_pair.hpp"
+
+using namespace hfcl;
+
+// minimum waves per SIMD the register allocator must allow for (A/B-tuned, see profiles/)
+#ifndef HFCL_WPE_GJK_W2
+#define HFCL_WPE_GJK_W2 2  // 2-lane groups hold 16 vertices of each hull per lane (96 VGPRs)
+#endif
+#ifndef HFCL_WPE_GJK
+#define HFCL_WPE_GJK 3
+#endif
+// k_epa carries no occupancy attribute on purpose: forcing the fp64 instantiation to 2 waves/SIMD
+// (488 B/lane of scratch) produced wrong EPA results on gfx950 (profiles/r01_c_waves_per_eu_ab.txt);
+// the compiler's own choice (fp32: 2 waves, fp64: 1 wave + AGPRs) is what the parity tests cover.
+#ifndef HFCL_WPE_GJK64
+#define HFCL_WPE_GJK64 2
+#endif
+#ifndef HFCL_WPE_PRIM
+#define HFCL_WPE_PRIM 2
+#endif
+#ifndef HFCL_WPE_EPA32
+#define HFCL_WPE_EPA32 2  // fp32 EPA: the LDS block allows 2 waves/SIMD, keep the registers within that
+#endif
+#ifndef HFCL_WPE_EPA64
+#define HFCL_WPE_EPA64 1
+#endif
+#ifndef HFCL_WPE_BVH
+#define HFCL_WPE_BVH 1
+#endif
+
+// ---------------------------------------------------------------------------------------
+// bucket ids (finer than hfcl_shapes.hpp's pair_class: the convex bucket is split by which
+// side carries vertices so the kernel is specialised at compile time)
+// ---------------------------------------------------------------------------------------
+enum { B_CLOSED = 0, B_PRIM = 1, B_CC = 2, B_PC = 3, B_CP = 4, B_BVH = 5, B_UNSUPPORTED = 6, B_LARGE = 7, B_BVHSHAPE = 8, B_TRI = 9, B_COUNT = 10 };
+
+// Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
+// support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
+// the B_LARGE bucket whose kernel scans the vertices from memory instead of holding them in registers.
+constexpr int K_CONVEX_LARGE = 21;
+
+// distance_mode: the reference's *distance* function matrix has no TriangleP row or column at all
+// (src/distance_func_matrix.cpp:283-560; only collide() knows GEOM_TRIANGLE, collision_func_matrix.cpp:295-469):
+// distance() on such a pair throws there and is reported as unsupported here.
+__host__ __device__ inline int bucket_of(int k1, int k2, bool distance_mode = false) {
+  if (distance_mode && (k1 == K_TRIANGLE || k2 == K_TRIANGLE)) return B_UNSUPPORTED;
+  const bool large = (k1 == K_CONVEX_LARGE) || (k2 == K_CONVEX_LARGE);
+  if (k1 == K_CONVEX_LARGE) k1 = K_CONVEX;
+  if (k2 == K_CONVEX_LARGE) k2 = K_CONVEX;
+  if ((k1 == K_BVH) != (k2 == K_BVH)) {  // BVHModel x convex solid, either operand order (k_bvh_shape)
+    const int o = (k1 == K_BVH) ? k2 : k1;
+    return (kind_is_prim(o) || o == K_CONVEX || kind_is_flat(o)) ? B_BVHSHAPE : B_UNSUPPORTED;
+  }
+  if ((k1 == K_TRIANGLE || k2 == K_TRIANGLE) && !kind_is_flat(k1) && !kind_is_flat(k2)) {
+    // top-level TriangleP rows of the table (collision_func_matrix.cpp:295-469): k_triangle
+    const int o = (k1 == K_TRIANGLE) ? k2 : k1;
+    return (o == K_TRIANGLE || kind_is_prim(o) || o == K_CONVEX) ? B_TRI : B_UNSUPPORTED;
+  }
+  const int c = pair_class(k1, k2);
+  if (large && c == CLS_CONVEX) return B_LARGE;
+  if (c == CLS_CLOSED) return B_CLOSED;
+  if (c == CLS_PRIM_GJK) return B_PRIM;
+  if (c == CLS_BVH) return B_BVH;
+  if (c == CLS_CONVEX) {
+    if (k1 == K_CONVEX && k2 == K_CONVEX) return B_CC;
+    return (k1 == K_CONVEX) ? B_CP : B_PC;
+  }
+  return B_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel parameter blocks
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct LibView {
+  const DShape<T>* shapes;
+  const T* verts;
+  const uint8_t* kinds;
+  uint32_t n_shapes;
+};
+
+template <typename T> struct IO;
+template <> struct IO<double> {
+  const double* tf1;
+  const double* tf2;
+  hfcl_result* out;
+  const hfcl_guess* gin;
+  hfcl_guess* gout;
+};
+template <> struct IO<float> {
+  const float* tf1;
+  const float* tf2;
+  hfcl_result_f32* out;
+  const hfcl_guess* gin;  // unused
+  hfcl_guess* gout;       // unused
+};
+
+template <typename T> using EpaItem = EpaSeed<T>;
+
+struct Work {
+  const uint32_t* shape1;
+  const uint32_t* shape2;
+  uint32_t n;
+  uint32_t* lists;   // B_COUNT lists of capacity n each
+  uint32_t* counts;  // B_COUNT counters + [B_COUNT] = epa queue length + [B_COUNT+1] = overflow queue length
+                     // + [B_COUNT+2] = ticket counter of the streaming BVH kernel
+  void* epa_queue;
+  void* epa_queue2;  // polytopes that outgrew the fast EPA kernel's scratch block
+  void* epa_v0;      // shape-0 support points of the polytopes in flight in the full-capacity EPA kernel
+  void* epa_resume;  // saved polytopes (EpaScratch<T, EPA_FAST_CAP>) of the first `resume_cap` slots of epa_queue2
+  uint32_t resume_cap;
+};
+constexpr int32_t EPA_RESUME_FLAG = 0x100;  // EpaSeed::rank bit: "continue the saved polytope of this slot"
+
+__device__ __forceinline__ Pose<double> load_pose(const double* base, uint32_t i) { return pose_from_abi<double>(base + 12 * size_t(i)); }
+__device__ __forceinline__ void put_record(hfcl_result* dst, const hfcl_result& r) { *dst = r; }
+__device__ __forceinline__ Pose<float> load_pose(const float* base, uint32_t i) { return pose_from_quat<float>(base + 7 * size_t(i)); }
+
+// One finished query -> result record (tail of ShapeShapeDistancer::run / ShapeShapeCollider::run).
+__device__ __forceinline__ void store_record(const IO<double>& io, uint32_t pair, const PairOut<double>& o, bool contact,
+                                             int nc) {
+  hfcl_result r;
+  r.distance = o.distance;
+  r.normal[0] = o.normal.x; r.normal[1] = o.normal.y; r.normal[2] = o.normal.z;
+  r.p1[0] = o.p1.x; r.p1[1] = o.p1.y; r.p1[2] = o.p1.z;
+  r.p2[0] = o.p2.x; r.p2[1] = o.p2.y; r.p2[2] = o.p2.z;
+  r.b1 = -1;
+  r.b2 = -1;
+  r.status = pack_status(o.gjk_status, o.epa_status, contact, o.gjk_iters, o.epa_iters);
+  r.num_contacts = nc;
+  put_record(&io.out[pair], r);
+}
+__device__ __forceinline__ void store_record(const IO<float>& io, uint32_t pair, const PairOut<float>& o, bool contact,
+                                             int) {
+  hfcl_result_f32 r;
+  r.distance = o.distance;
+  r.p1[0] = o.p1.x; r.p1[1] = o.p1.y; r.p1[2] = o.p1.z;
+  r.p2[0] = o.p2.x; r.p2[1] = o.p2.y; r.p2[2] = o.p2.z;
+  r.normal[0] = o.normal.x; r.normal[1] = o.normal.y; r.normal[2] = o.normal.z;
+  r.status = pack_status(o.gjk_status, o.epa_status, contact, o.gjk_iters, o.epa_iters);
+  io.out[pair] = r;
+}
+template <typename T>
+__device__ __forceinline__ void write_out(const IO<T>& io, const QParams<T>& q, uint32_t pair, PairOut<T> o) {
+  int nc;
+  const bool contact = apply_query_semantics(q, o, nc);
+  store_record(io, pair, o, contact, nc);
+}
+
+// BVH pair record: distance = distance_lower_bound + margin (= the first contact's penetration depth
+// when num_max_contacts == 1), p1/p2/normal = CollisionResult::nearest_points/normal, b1/b2 = first contact.
+__device__ __forceinline__ void store_bvh_record(const IO<double>& io, uint32_t pair, const PairOut<double>& o, uint32_t nc,
+                                                 int b1, int b2, bool overflow) {
+  hfcl_result r;
+  r.distance = o.distance;
+  r.normal[0] = o.normal.x; r.normal[1] = o.normal.y; r.normal[2] = o.normal.z;
+  r.p1[0] = o.p1.x; r.p1[1] = o.p1.y; r.p1[2] = o.p1.z;
+  r.p2[0] = o.p2.x; r.p2[1] = o.p2.y; r.p2[2] = o.p2.z;
+  r.b1 = b1;
+  r.b2 = b2;
+  // nc: number of contacts (collide) ; bit 31 set = "distance(): contact flag only, no Contact object"
+  r.status = (nc ? 128u : 0u) | (overflow ? 0xC0000000u : 0u);
+  r.num_contacts = int(nc & 0x7FFFFFFFu);
+  io.out[pair] = r;
+}
+__device__ __forceinline__ void store_bvh_record(const IO<float>& io, uint32_t pair, const PairOut<float>& o, uint32_t nc,
+                                                 int, int, bool overflow) {
+  hfcl_result_f32 r;
+  r.distance = o.distance;
+  r.p1[0] = o.p1.x; r.p1[1] = o.p1.y; r.p1[2] = o.p1.z;
+  r.p2[0] = o.p2.x; r.p2[1] = o.p2.y; r.p2[2] = o.p2.z;
+  r.normal[0] = o.normal.x; r.normal[1] = o.normal.y; r.normal[2] = o.normal.z;
+  r.status = (nc ? 128u : 0u) | (overflow ? 0xC0000000u : 0u);
+  io.out[pair] = r;
+}
+
+template <typename T>
+__device__ __forceinline__ void write_guess(const IO<T>&, uint32_t, const V3<T>&, int, int) {}
+template <>
+__device__ __forceinline__ void write_guess<double>(const IO<double>& io, uint32_t pair, const V3<double>& g, int h0, int h1) {
+  if (io.gout) {
+    hfcl_guess r;
+    r.gjk_guess[0] = g.x; r.gjk_guess[1] = g.y; r.gjk_guess[2] = g.z;
+    r.support_guess[0] = h0;
+    r.support_guess[1] = h1;
+    io.gout[pair] = r;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ V3<T> initial_guess(const IO<T>& io, const QParams<T>& q, uint32_t pair) {
+  if (q.guess_mode == HFCL_GUESS_CACHED || q.guess_mode == HFCL_GUESS_BOUNDING_VOLUME)
+    return mk<T>(q.guess[0], q.guess[1], q.guess[2]);  // BoundingVolumeGuess: the solver's cached guess = the request's
+  return mk<T>(T(1), T(0), T(0));
+}
+template <>
+__device__ __forceinline__ V3<double> initial_guess<double>(const IO<double>& io, const QParams<double>& q, uint32_t pair) {
+  if (q.guess_mode == HFCL_GUESS_CACHED) {
+    if (io.gin) return mk<double>(io.gin[pair].gjk_guess[0], io.gin[pair].gjk_guess[1], io.gin[pair].gjk_guess[2]);
+    return mk<double>(q.guess[0], q.guess[1], q.guess[2]);
+  }
+  if (q.guess_mode == HFCL_GUESS_BOUNDING_VOLUME) return mk<double>(q.guess[0], q.guess[1], q.guess[2]);
+  return mk<double>(1.0, 0.0, 0.0);
+}
+// ---------------------------------------------------------------------------------------
+// Convex hull held by a W-lane group: lane l owns vertices [l*VPL, (l+1)*VPL).
+// getShapeSupportLinear (support_functions.cpp:400-421): first index of the maximum dot.
+// ---------------------------------------------------------------------------------------
+// Partner value for stage M of an all-reduce over an aligned W-lane group (see butterfly_stages).  Stages
+// within a row of 16 lanes are DPP moves (VALU rate, no LDS-pipe round trip as ds_bpermute has):
+// quad_perm [1,0,3,2] / [2,3,0,1] for M = 1 / 2, row_half_mirror (lane ^ 7) for M = 4, row_mirror
+// (lane ^ 15) for M = 8; wider stages go through __shfl_xor.
+template <int CTRL, class X>
+__device__ __forceinline__ X dpp_move(X v) {
+  static_assert(sizeof(X) % 4 == 0, "32-bit words");
+  int w[sizeof(X) / 4];
+  __builtin_memcpy(w, &v, sizeof(X));
+#pragma unroll
+  for (int i = 0; i < int(sizeof(X) / 4); ++i) w[i] = __builtin_amdgcn_update_dpp(w[i], w[i], CTRL, 0xF, 0xF, false);
+  X r;
+  __builtin_memcpy(&r, w, sizeof(X));
+  return r;
+}
+template <int W, int M, class X>
+__device__ __forceinline__ X group_exchange(X v) {
+  static_assert(M >= 1 && M < W, "stage of a W-lane butterfly");
+  if constexpr (M == 1) return dpp_move<0xB1>(v);
+  else if constexpr (M == 2) return dpp_move<0x4E>(v);
+  else if constexpr (M == 4) return dpp_move<0x141>(v);
+  else if constexpr (M == 8) return dpp_move<0x140>(v);
+  else {
+    int w[sizeof(X) / 4];
+    __builtin_memcpy(w, &v, sizeof(X));
+#pragma unroll
+    for (int i = 0; i < int(sizeof(X) / 4); ++i) w[i] = __shfl_xor(w[i], M, W);
+    X r;
+    __builtin_memcpy(&r, w, sizeof(X));
+    return r;
+  }
+}
+
+constexpr int HULL_MAX = 32;  // ConvexBase::num_vertices_large_convex_threshold (geometric_shapes.h:709)
+constexpr int HULL_LARGE_MAX = 1 << 16;  // hulls above HULL_MAX are scanned from memory (k_gjk_large)
+
+template <typename T, int W>
+struct HullRegs {
+  static constexpr int VPL = (HULL_MAX + W - 1) / W;
+  V3<T> v[VPL];
+
+  __device__ __forceinline__ void load(const T* verts, uint32_t n, int lig) {
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      uint32_t idx = uint32_t(lig * VPL + k);
+      idx = idx < n ? idx : 0u;  // padding duplicates vertex 0 (never wins the first-index tie-break)
+      const T* p = verts + 3 * size_t(idx);
+      v[k] = mk<T>(p[0], p[1], p[2]);
+    }
+  }
+  __device__ __forceinline__ V3<T> support(const V3<T>& dir, int lig) const {
+    T best = dot(v[0], dir);
+    int bi = lig * VPL;
+#pragma unroll
+    for (int k = 1; k < VPL; ++k) {
+      const T d = dot(v[k], dir);
+      if (d > best) {
+        best = d;
+        bi = lig * VPL + k;
+      }
+    }
+    butterfly_stages<W>([&](auto stage) {
+      constexpr int M = decltype(stage)::value;
+      const T od = group_exchange<W, M>(best);
+      const int oi = group_exchange<W, M>(bi);
+      if (od > best || (od == best && oi < bi)) {
+        best = od;
+        bi = oi;
+      }
+    });
+    // the winner's coordinates come from a run-time lane (ds_bpermute): carrying them through the stages,
+    // or OR-reducing the owner's bits, costs the GJK kernels registers they do not have (spills; measured)
+    const int owner = bi / VPL, slot = bi % VPL;
+    V3<T> c = v[0];
+#pragma unroll
+    for (int k = 1; k < VPL; ++k)
+      if (slot == k) c = v[k];
+    return mk<T>(__shfl(c.x, owner, W), __shfl(c.y, owner, W), __shfl(c.z, owner, W));
+  }
+};
+// ---------------------------------------------------------------------------------------
+// k_gjk_large: GJK for pairs with a hull of more than 32 vertices (either side; the other side may be
+// any convex kind).  One pair per LW-lane group, vertices streamed from memory (L2-resident).
+// ---------------------------------------------------------------------------------------
+// Linear-scan support of a hull too large for registers: lane l of the W-lane group looks at vertices
+// l, l+W, ... (coalesced), the group reduces to the first index of the maximum (the tie rule of
+// getShapeSupportLinear; the reference's neighbour hill-climbing, support_functions.cpp:323-397, reaches
+// a vertex of the same support value, possibly another one on a plateau -- see DESIGN.md).
+template <typename T, int W>
+__device__ __forceinline__ V3<T> scan_support(const T* v, uint32_t n, const V3<T>& dir, int lig) {
+  T best = -Lim<T>::max();
+  uint32_t bi = 0xFFFFFFFFu;
+  for (uint32_t i = uint32_t(lig); i < n; i += W) {
+    const T d = v[3 * i] * dir.x + v[3 * i + 1] * dir.y + v[3 * i + 2] * dir.z;
+    if (d > best) {
+      best = d;
+      bi = i;
+    }
+  }
+  butterfly_stages<W>([&](auto stage) {
+    constexpr int M = decltype(stage)::value;
+    const T od = group_exchange<W, M>(best);
+    const uint32_t oi = group_exchange<W, M>(bi);
+    if (od > best || (od == best && oi < bi)) {
+      best = od;
+      bi = oi;
+    }
+  });
+  return mk<T>(v[3 * bi], v[3 * bi + 1], v[3 * bi + 2]);
+}
+// ---------------------------------------------------------------------------------------
+// k_epa: EPA on the pairs GJK left in `Collision`.  One polytope per WE-lane group, 64/WE polytopes
+// per wavefront, scratch blocks in LDS.  Two tiers:
+//   tier 1  WE = 8, CAP = 20 (fp32) / 24 (fp64) iterations: 8 polytopes per wave share one instruction
+//           stream; a polytope that outgrows the small block is saved at the start of that iteration and queued
+//   tier 2  WE = 16, CAP = 64 (the reference capacity): 4 polytopes per wave, continues the saved polytopes
+// ---------------------------------------------------------------------------------------
+template <int W_>
+struct LaneGroup {
+  static constexpr int W = W_;
+  static __device__ __forceinline__ int lane() { return threadIdx.x & (W_ - 1); }
+  template <int M, class X> static __device__ __forceinline__ X exchange(X v) { return group_exchange<W_, M>(v); }
+  // Lanes of a group exchange data through LDS: the wavefront-scope fence keeps the compiler from moving or
+  // reusing LDS accesses across the exchange point (the barrier alone only pins instruction scheduling).
+  static __device__ __forceinline__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  static __device__ __forceinline__ uint32_t atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }  // LDS (ds_add_rtn)
+};
+
+#ifndef HFCL_EPA_FAST_CAP
+#define HFCL_EPA_FAST_CAP 20
+#endif
+constexpr int EPA_FAST_CAP = HFCL_EPA_FAST_CAP;
+#ifndef HFCL_EPA_FAST_CAP64
+#define HFCL_EPA_FAST_CAP64 24  // cfg5 (fast + full ms): 12: 0.84+2.16, 16: 1.06+1.74, 20: 1.28+1.19, 24: 1.49+0.89; 28 would cost a wave per CU
+#endif
+// capacity of the fast tier's block per precision (fp64 blocks are twice the size; the LDS holds 4 waves x 8 either way)
+template <typename T> constexpr int epa_fast_cap = sizeof(T) == 4 ? EPA_FAST_CAP : HFCL_EPA_FAST_CAP64;
+#ifndef HFCL_EPA_WE
+#define HFCL_EPA_WE 8
+#endif
+constexpr int EPA_WE = HFCL_EPA_WE;
+#ifndef HFCL_EPA_WE2
+#define HFCL_EPA_WE2 16
+#endif
+constexpr int EPA_WE2 = HFCL_EPA_WE2;  // lanes per polytope in the full-capacity tier
+
+// ---------------------------------------------------------------------------------------
+// k_bvh_collide: BVHModel<OBBRSS> x BVHModel<OBBRSS> collide().
+// Traversal = collisionRecurse (src/traversal/traversal_recurse.cpp:44-85) with the recursion
+// flattened into a per-lane LDS stack; children are pushed right-then-left so they pop in the
+// reference's order, and the walk ends as soon as num_max_contacts contacts exist (canStop()).
+// ---------------------------------------------------------------------------------------
+struct DMesh {
+  uint32_t node_off, vert_off, tri_off, n_nodes;
+};
+template <typename T>
+struct BvhView {
+  const DNode<T>* nodes;
+  const DRss<T>* rss;
+  const T* verts;        // xyz
+  const uint32_t* tris;  // 3 local vertex ids per triangle
+  const DMesh* meshes;
+  uint32_t n_meshes;
+};
+struct BvhParams {
+  uint32_t num_max_contacts;
+  hfcl_contact* contacts;   // optional device contact list
+  uint32_t contacts_cap;
+  uint32_t* contacts_count;
+};
+
+constexpr int BVH_STACK = 96;
+constexpr int BVH_BLOCK = 128;
+#ifndef HFCL_BVH_REFILL_MIN
+#define HFCL_BVH_REFILL_MIN 8
+#endif
+constexpr int BVH_REFILL_MIN = HFCL_BVH_REFILL_MIN;  // idle lanes of a wave that trigger a refill (4 / 8 / 16 / 24: 17.5 / 17.1 / 18.7 / 20.3 ms per 1M cfg4 queries)
+
+// block shapes the host needs to size the grids
+constexpr int CLS_BLOCK = 1024;  // k_classify
+constexpr int LARGE_W = 16;      // lanes per pair in k_gjk_large
+constexpr int BS_W = 16;         // lanes per query in k_bvh_shape / k_bvh_shape_distance / k_triangle
+constexpr int BS_STACK = 128;
+constexpr int BVHD_STACK = 64;
+constexpr int BVHD_BLOCK = 64;   // k_bvh_distance

@@ -1,0 +1,1108 @@
+// hfcl_host.hip -- host side: library object, batch pipeline and the C-ABI implementation of
+// include/hppfcl_amd.h (the kernels live in hfcl_k_gjk.hip / hfcl_k_epa.hip / hfcl_k_bvh.hip, see hfcl_launch.hpp).  No CPU fallback anywhere in this file: every compute entry point
+// needs a HIP device and fails loudly without one.
+//
+// Kernel map (pair buckets follow the reference's dispatch table,
+// include/hpp/fcl/internal/shape_shape_func.h:185-211 and src/collision_func_matrix.cpp:279-733):
+//   k_classify       pair -> bucket lists (block-aggregated atomics), one pass over the shape ids
+//   k_closed<T>      closed forms (sphere / capsule / cylinder / box-sphere pairs, every Plane / Halfspace
+//                    row), one pair per lane
+//   k_gjk_prim<T>    GJK for Box/Capsule/Cone/Cylinder/Ellipsoid/Sphere pairs, one pair per lane
+//   k_gjk_cvx<W,M>   GJK with hulls of <= 32 vertices: one pair per W-lane group, hull vertices in the
+//                    group's registers, support = per-lane dots + DPP-butterfly arg-max (fp32 / fp64
+//                    entry points with their own register budgets)
+//   k_gjk_large<T>   GJK when a hull has more than 32 vertices: 16-lane groups scan the vertices from memory
+//   k_epa<T,WE,CAP,TIER>  EPA on the pairs GJK left in `Collision`: one polytope per WE-lane group in LDS;
+//                    tier 1 = 8 polytopes per wave in small blocks, tier 2 = full capacity (continues the
+//                    polytopes tier 1 saved when they outgrew their block; every pair with a large hull)
+//   k_epa_stream<T,WE,CAP>  tier 1 for fp32: same blocks, but a lane group whose polytope is done starts the
+//                    wave's next item instead of waiting for the slowest of the 8
+//   k_bvh_collide<T> / k_bvh_distance<T>   BVHModel<OBBRSS> x BVHModel<OBBRSS>: one mesh pair per lane,
+//                    explicit DFS stack in LDS (reference order), OBB SAT / RSS bounds, triangle-triangle leaves
+//   k_bvh_shape<T> / k_bvh_shape_distance<T>   BVHModel<OBBRSS> x convex solid or Plane/Halfspace: one query
+//                    per 16-lane group, sequential traversal, leaves = TriangleP-vs-solid GJK + EPA in LDS
+//   k_unsupported<T> flags the pairs of a bucket the engine cannot evaluate (never computed elsewhere)
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "hfcl_dev.hpp"
+#include "hfcl_launch.hpp"
+
+// =======================================================================================
+// Host side: library object + C ABI
+// =======================================================================================
+static thread_local std::string g_last_error;
+static void set_error(const std::string& s) { g_last_error = s; }
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                           \
+      return HFCL_ERR_HIP;                                                                    \
+    }                                                                                         \
+  } while (0)
+
+struct KernelTime {
+  const char* name;
+  hipEvent_t e0, e1;
+  bool used;
+};
+
+struct hfcl_lib {
+  int device = 0;
+  size_t n_shapes = 0;
+  std::vector<hfcl_shape> h_shapes;
+  DShape<double>* d_shapes64 = nullptr;
+  DShape<float>* d_shapes32 = nullptr;
+  double* d_verts64 = nullptr;
+  float* d_verts32 = nullptr;
+  uint8_t* d_kinds = nullptr;
+  // workspace (grown on demand)
+  size_t ws_capacity = 0;  // pairs
+  uint32_t* d_lists = nullptr;
+  uint32_t* d_counts = nullptr;
+  void* d_epa_queue = nullptr;
+  void* d_epa_queue2 = nullptr;
+  void* d_epa_resume = nullptr;
+  void* d_epa_v0 = nullptr;
+  size_t resume_cap = 0;
+  // host-call staging buffers
+  size_t st_capacity = 0;
+  uint32_t *d_s1 = nullptr, *d_s2 = nullptr;
+  double *d_tf1 = nullptr, *d_tf2 = nullptr;
+  hfcl_result* d_out = nullptr;
+  hfcl_guess *d_gin = nullptr, *d_gout = nullptr;
+  // instrumentation
+  std::vector<KernelTime> timers;
+  // A batch can run as two halves on two streams (hfcl_lib_set_split): the second half goes to `helper`, a shallow
+  // clone (same device shape tables, own workspace / counters / timers) on the internal stream `side`, whose kernels
+  // fill the drain phases of the first half's GJK / EPA launches (profiles/r01_k_two_stream_overlap.txt).
+  int split = 0;  // 0 = automatic (auto_split), 1 = never, 2 = always (large batches without meshes)
+  hfcl_lib* helper = nullptr;
+  bool is_helper = false;   // does not own the shape tables
+  bool last_split = false;  // the last batch ran split: counters / timers of the helper belong to it
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool kernel_timing = true;         // HIP events around every kernel (hfcl_lib_set_kernel_timing)
+  uint32_t possible_buckets = ~0u;   // bit b: some pair of this library's shape kinds classifies into bucket b
+  int cvx_w = 0;  // 0 = per kernel (auto_cvx_w); HFCL_CVX_W forces one width for all
+  bool closed_staged = true;  // HFCL_CLOSED_STAGED=0: A/B switch back to the direct-access k_closed<double>
+  int n_cus = 256;
+  std::string dominant;
+  // bucket populations of the last call; PINNED host memory so that the device-to-host copy at the end of a batch is
+  // asynchronous (a pageable destination makes hipMemcpyAsync block the host until the whole batch has run)
+  uint32_t* h_counts = nullptr;
+  // BVH models (host staging + device images in both precisions; uploaded lazily)
+  std::vector<hfcl_bvh_node> h_bvh_nodes;
+  std::vector<double> h_bvh_verts;
+  std::vector<uint32_t> h_bvh_tris;
+  std::vector<DMesh> h_meshes;
+  bool bvh_dirty = false;
+  DNode<double>* d_nodes64 = nullptr;
+  DNode<float>* d_nodes32 = nullptr;
+  DRss<double>* d_rss64 = nullptr;
+  DRss<float>* d_rss32 = nullptr;
+  double* d_bverts64 = nullptr;
+  float* d_bverts32 = nullptr;
+  uint32_t* d_btris = nullptr;
+  DMesh* d_meshes = nullptr;
+  // contact list of the last hfcl_collide_batch_contacts call
+  hfcl_contact* d_contacts = nullptr;
+  size_t contacts_cap = 0;
+  uint32_t* d_contacts_count = nullptr;
+  BvhParams bvh_params = {1u, nullptr, 0u, nullptr};
+  double break_distance = 1e-3;
+};
+
+// bucket population i of the last batch (both halves of a split batch)
+static uint32_t total_count(const hfcl_lib* lib, int i) {
+  uint32_t c = lib->h_counts ? lib->h_counts[i] : 0u;
+  if (lib->last_split && lib->helper && lib->helper->h_counts) c += lib->helper->h_counts[i];
+  return c;
+}
+
+static int ensure_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    set_error("no HIP device available (hipGetDeviceCount): the engine has no CPU fallback");
+    return HFCL_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    set_error("device index out of range");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(device));
+  return HFCL_OK;
+}
+
+extern "C" {
+
+int hfcl_abi_version(void) { return HFCL_ABI_VERSION; }
+int hfcl_pair_supported(int32_t t1, int32_t t2, int for_distance) {
+  if (t1 < 0 || t1 > 255 || t2 < 0 || t2 > 255) return 0;
+  return bucket_of(t1, t2, for_distance != 0) != B_UNSUPPORTED;
+}
+int hfcl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+const char* hfcl_last_error(void) { return g_last_error.c_str(); }
+
+static void query_defaults(hfcl_query_request* q) {
+  q->gjk_initial_guess = HFCL_GUESS_DEFAULT;
+  q->gjk_variant = HFCL_GJK_DEFAULT;
+  q->gjk_convergence_criterion = HFCL_CRIT_DEFAULT;
+  q->gjk_convergence_criterion_type = HFCL_CRIT_RELATIVE;
+  q->gjk_max_iterations = 128;
+  q->epa_max_iterations = 64;
+  q->gjk_tolerance = 1e-6;
+  q->epa_tolerance = 1e-6;
+  q->collision_distance_threshold = 1e-12;
+  q->cached_gjk_guess[0] = 1.0;
+  q->cached_gjk_guess[1] = 0.0;
+  q->cached_gjk_guess[2] = 0.0;
+  q->cached_support_func_guess[0] = 0;
+  q->cached_support_func_guess[1] = 0;
+}
+void hfcl_collision_request_init(hfcl_collision_request* r) {
+  memset(r, 0, sizeof(*r));
+  query_defaults(&r->q);
+  r->num_max_contacts = 1;
+  r->enable_contact = 1;
+  r->security_margin = 0.0;
+  r->break_distance = 1e-3;
+  r->distance_upper_bound = 1.7976931348623157e+308;
+}
+void hfcl_distance_request_init(hfcl_distance_request* r) {
+  memset(r, 0, sizeof(*r));
+  query_defaults(&r->q);
+  r->enable_nearest_points = 1;
+  r->enable_signed_distance = 1;
+  r->rel_err = 0.0;
+  r->abs_err = 0.0;
+}
+
+hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const double* vertices, size_t n_vertices,
+                          int device) {
+  if (ensure_device(device) != HFCL_OK) return nullptr;
+  if (!shapes || n_shapes == 0) {
+    set_error("hfcl_lib_create: empty shape table");
+    return nullptr;
+  }
+  for (size_t i = 0; i < n_shapes; ++i) {
+    const hfcl_shape& s = shapes[i];
+    const bool ok_kind = s.type == HFCL_GEOM_BOX || s.type == HFCL_GEOM_SPHERE || s.type == HFCL_GEOM_CAPSULE ||
+                         s.type == HFCL_GEOM_ELLIPSOID || s.type == HFCL_GEOM_CONVEX || s.type == HFCL_BV_OBBRSS ||
+                         s.type == HFCL_GEOM_TRIANGLE || s.type == HFCL_GEOM_CONE || s.type == HFCL_GEOM_CYLINDER ||
+                         s.type == HFCL_GEOM_PLANE || s.type == HFCL_GEOM_HALFSPACE;
+    if (!ok_kind) {
+      set_error("hfcl_lib_create: unsupported shape type " + std::to_string(s.type));
+      return nullptr;
+    }
+    if (s.type == HFCL_GEOM_CONVEX) {
+      if (s.num_points == 0 || s.num_points > (uint32_t)HULL_LARGE_MAX) {
+        set_error("hfcl_lib_create: convex shapes must have 1.." + std::to_string(HULL_LARGE_MAX) + " vertices; got " +
+                  std::to_string(s.num_points));
+        return nullptr;
+      }
+      if (size_t(s.vertex_offset) + s.num_points > n_vertices) {
+        set_error("hfcl_lib_create: convex vertex range out of bounds");
+        return nullptr;
+      }
+    }
+  }
+  hfcl_lib* lib = new hfcl_lib();
+  lib->device = device;
+  lib->n_shapes = n_shapes;
+  lib->h_shapes.assign(shapes, shapes + n_shapes);
+  std::vector<DShape<double>> s64(n_shapes);
+  std::vector<DShape<float>> s32(n_shapes);
+  std::vector<uint8_t> kinds(n_shapes);
+  for (size_t i = 0; i < n_shapes; ++i) {
+    const hfcl_shape& s = shapes[i];
+    s64[i].kind = s.type;
+    s64[i].num_points = s.num_points;
+    s64[i].vertex_offset = s.vertex_offset;
+    s64[i].bvh_index = s.bvh_index;
+    s64[i].p0 = s.params[0];
+    s64[i].p1 = s.params[1];
+    s64[i].p2 = s.params[2];
+    s64[i].p3 = s.params[3];
+    s64[i].ssr = s.swept_sphere_radius;
+    s32[i].kind = s.type;
+    s32[i].num_points = s.num_points;
+    s32[i].vertex_offset = s.vertex_offset;
+    s32[i].bvh_index = s.bvh_index;
+    s32[i].p0 = float(s.params[0]);
+    s32[i].p1 = float(s.params[1]);
+    s32[i].p2 = float(s.params[2]);
+    s32[i].p3 = float(s.params[3]);
+    s32[i].ssr = float(s.swept_sphere_radius);
+    if (s.type == HFCL_GEOM_CONVEX && s.num_points > 0 && vertices &&
+        size_t(s.vertex_offset) + s.num_points <= n_vertices) {  // centre of aabb_local, for BoundingVolumeGuess
+      double mn[3], mx[3];
+      const double* v = vertices + 3 * size_t(s.vertex_offset);
+      for (int k = 0; k < 3; ++k) mn[k] = mx[k] = v[k];
+      for (uint32_t j = 1; j < s.num_points; ++j)
+        for (int k = 0; k < 3; ++k) {
+          mn[k] = std::min(mn[k], v[3 * size_t(j) + k]);
+          mx[k] = std::max(mx[k], v[3 * size_t(j) + k]);
+        }
+      s64[i].p0 = (mn[0] + mx[0]) * 0.5; s64[i].p1 = (mn[1] + mx[1]) * 0.5; s64[i].p2 = (mn[2] + mx[2]) * 0.5;
+      s32[i].p0 = float(s64[i].p0); s32[i].p1 = float(s64[i].p1); s32[i].p2 = float(s64[i].p2);
+    }
+    kinds[i] = uint8_t(s.type == HFCL_GEOM_CONVEX && s.num_points > (uint32_t)HULL_MAX ? K_CONVEX_LARGE : s.type);
+  }
+  {
+    bool present[256] = {false};
+    for (size_t i = 0; i < n_shapes; ++i) present[kinds[i]] = true;
+    uint32_t mask = 1u << B_UNSUPPORTED;  // shape ids out of range can always occur
+    for (int a = 0; a < 256; ++a)
+      if (present[a])
+        for (int b = 0; b < 256; ++b)
+          if (present[b]) mask |= 1u << bucket_of(a, b);
+    lib->possible_buckets = mask;
+  }
+  std::vector<float> v32(3 * n_vertices + 3);
+  for (size_t i = 0; i < 3 * n_vertices; ++i) v32[i] = float(vertices[i]);
+  bool ok = true;
+  ok = ok && hipMalloc(&lib->d_shapes64, n_shapes * sizeof(DShape<double>)) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_shapes32, n_shapes * sizeof(DShape<float>)) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_kinds, n_shapes) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_verts64, (3 * n_vertices + 3) * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_verts32, (3 * n_vertices + 3) * sizeof(float)) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_counts, (B_COUNT + 3) * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&lib->h_counts, (B_COUNT + 2) * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+  if (ok) memset(lib->h_counts, 0, (B_COUNT + 2) * sizeof(uint32_t));
+  if (ok) {
+    ok = ok && hipMemcpy(lib->d_shapes64, s64.data(), n_shapes * sizeof(DShape<double>), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(lib->d_shapes32, s32.data(), n_shapes * sizeof(DShape<float>), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(lib->d_kinds, kinds.data(), n_shapes, hipMemcpyHostToDevice) == hipSuccess;
+    if (n_vertices) {
+      ok = ok && hipMemcpy(lib->d_verts64, vertices, 3 * n_vertices * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+      ok = ok && hipMemcpy(lib->d_verts32, v32.data(), 3 * n_vertices * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    }
+  }
+  if (!ok) {
+    set_error("hfcl_lib_create: HIP allocation/copy failed");
+    hfcl_lib_destroy(lib);
+    return nullptr;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) lib->n_cus = prop.multiProcessorCount;
+  // one slot per lane group of the largest full-capacity EPA grid (run_batch caps grids at n_cus * 16 blocks)
+  if (hipMalloc(&lib->d_epa_v0, size_t(lib->n_cus) * 16 * (64 / EPA_WE2) * EPA_MAX_VERTS * sizeof(Quad<double>)) != hipSuccess) {
+    set_error("hfcl_lib_create: HIP allocation failed");
+    hfcl_lib_destroy(lib);
+    return nullptr;
+  }
+  if (const char* v = getenv("HFCL_CLOSED_STAGED")) lib->closed_staged = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_SPLIT")) lib->split = atoi(v) >= 2 ? 2 : (atoi(v) == 1 ? 1 : 0);
+  if (const char* w = getenv("HFCL_CVX_W")) {
+    int v = atoi(w);
+    if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) lib->cvx_w = v;
+  }
+  return lib;
+}
+
+void hfcl_lib_destroy(hfcl_lib* lib) {
+  if (!lib) return;
+  hipSetDevice(lib->device);
+  hipDeviceSynchronize();
+  if (lib->helper) hfcl_lib_destroy(lib->helper);
+  if (lib->side) hipStreamDestroy(lib->side);
+  if (lib->ev_fork) hipEventDestroy(lib->ev_fork);
+  if (lib->ev_join) hipEventDestroy(lib->ev_join);
+  if (!lib->is_helper) {
+    hipFree(lib->d_shapes64);
+    hipFree(lib->d_shapes32);
+    hipFree(lib->d_kinds);
+    hipFree(lib->d_verts64);
+    hipFree(lib->d_verts32);
+  }
+  hipFree(lib->d_counts);
+  if (lib->h_counts) hipHostFree(lib->h_counts);
+  hipFree(lib->d_lists);
+  hipFree(lib->d_epa_queue);
+  hipFree(lib->d_epa_queue2);
+  hipFree(lib->d_epa_resume);
+  hipFree(lib->d_epa_v0);
+  hipFree(lib->d_s1);
+  hipFree(lib->d_s2);
+  hipFree(lib->d_tf1);
+  hipFree(lib->d_tf2);
+  hipFree(lib->d_out);
+  hipFree(lib->d_gin);
+  hipFree(lib->d_gout);
+  hipFree(lib->d_nodes64);
+  hipFree(lib->d_nodes32);
+  hipFree(lib->d_rss64);
+  hipFree(lib->d_rss32);
+  hipFree(lib->d_bverts64);
+  hipFree(lib->d_bverts32);
+  hipFree(lib->d_btris);
+  hipFree(lib->d_meshes);
+  hipFree(lib->d_contacts);
+  hipFree(lib->d_contacts_count);
+  for (auto& t : lib->timers) {
+    hipEventDestroy(t.e0);
+    hipEventDestroy(t.e1);
+  }
+  delete lib;
+}
+size_t hfcl_lib_num_shapes(const hfcl_lib* lib) { return lib ? lib->n_shapes : 0; }
+int hfcl_lib_device(const hfcl_lib* lib) { return lib ? lib->device : -1; }
+
+int hfcl_lib_add_bvh(hfcl_lib* lib, const hfcl_bvh_node* nodes, size_t n_nodes, const double* vertices,
+                     size_t n_vertices, const uint32_t* triangles, size_t n_tris) {
+  if (!lib || !nodes || !vertices || !triangles || n_tris == 0) {
+    set_error("hfcl_lib_add_bvh: null/empty input");
+    return -1;
+  }
+  if (n_nodes != 2 * n_tris - 1) {  // BVH_model.cpp:821-825
+    set_error("hfcl_lib_add_bvh: a BVHModel with T triangles has exactly 2T-1 nodes");
+    return -1;
+  }
+  if (n_nodes > 65535) {
+    set_error("hfcl_lib_add_bvh: more than 65535 BV nodes per model (16-bit node ids on the device stack)");
+    return -1;
+  }
+  for (size_t i = 0; i < n_nodes; ++i) {
+    const int fc = nodes[i].first_child;
+    if (fc == 0 || (fc > 0 && size_t(fc) + 1 > n_nodes - 1) || (fc < 0 && size_t(-(fc + 1)) >= n_tris)) {
+      set_error("hfcl_lib_add_bvh: malformed node array (first_child out of range)");
+      return -1;
+    }
+  }
+  for (size_t i = 0; i < 3 * n_tris; ++i)
+    if (triangles[i] >= n_vertices) {
+      set_error("hfcl_lib_add_bvh: triangle vertex index out of range");
+      return -1;
+    }
+  DMesh m;
+  m.node_off = uint32_t(lib->h_bvh_nodes.size());
+  m.vert_off = uint32_t(lib->h_bvh_verts.size() / 3);
+  m.tri_off = uint32_t(lib->h_bvh_tris.size() / 3);
+  m.n_nodes = uint32_t(n_nodes);
+  lib->h_bvh_nodes.insert(lib->h_bvh_nodes.end(), nodes, nodes + n_nodes);
+  lib->h_bvh_verts.insert(lib->h_bvh_verts.end(), vertices, vertices + 3 * n_vertices);
+  lib->h_bvh_tris.insert(lib->h_bvh_tris.end(), triangles, triangles + 3 * n_tris);
+  lib->h_meshes.push_back(m);
+  lib->bvh_dirty = true;
+  return int(lib->h_meshes.size() - 1);
+}
+
+}  // extern "C"
+
+static int ensure_workspace(hfcl_lib* lib, size_t n) {
+  if (n <= lib->ws_capacity) return HFCL_OK;
+  size_t cap = n + n / 8 + 1024;
+  hipFree(lib->d_lists);
+  hipFree(lib->d_epa_queue);
+  hipFree(lib->d_epa_queue2);
+  hipFree(lib->d_epa_resume);
+  lib->d_lists = nullptr;
+  lib->d_epa_queue = nullptr;
+  lib->d_epa_queue2 = nullptr;
+  lib->d_epa_resume = nullptr;
+  lib->resume_cap = 0;
+  lib->ws_capacity = 0;
+  HIP_TRY(hipMalloc(&lib->d_lists, size_t(B_COUNT) * cap * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&lib->d_epa_queue, cap * sizeof(EpaItem<double>)));
+  HIP_TRY(hipMalloc(&lib->d_epa_queue2, cap * sizeof(EpaItem<double>)));
+  // saved polytopes for the tier hand-over: room for a third of the batch (beyond that the full tier
+  // simply redoes the pair from its seed); 4 KB per slot in fp64
+  size_t rcap = std::min(cap, std::max<size_t>(65536, cap / 3));
+  if (const char* e = getenv("HFCL_EPA_RESUME_SLOTS")) rcap = std::max<size_t>(1, std::min<size_t>(cap, strtoull(e, nullptr, 10)));  // test knob
+  HIP_TRY(hipMalloc(&lib->d_epa_resume, rcap * sizeof(EpaScratch<double, epa_fast_cap<double>>)));
+  lib->resume_cap = rcap;
+  lib->ws_capacity = cap;
+  return HFCL_OK;
+}
+
+template <typename T>
+static DNode<T> pack_node(const hfcl_bvh_node& n) {
+  DNode<T> d;
+  d.first_child = n.first_child;
+  d.pad_ = 0;
+  const double* a = n.obb_axes;  // column-major
+  d.axes.r0 = mk<T>(T(a[0]), T(a[3]), T(a[6]));
+  d.axes.r1 = mk<T>(T(a[1]), T(a[4]), T(a[7]));
+  d.axes.r2 = mk<T>(T(a[2]), T(a[5]), T(a[8]));
+  d.To = mk<T>(T(n.obb_To[0]), T(n.obb_To[1]), T(n.obb_To[2]));
+  d.extent = mk<T>(T(n.obb_extent[0]), T(n.obb_extent[1]), T(n.obb_extent[2]));
+  return d;
+}
+
+static int upload_bvh(hfcl_lib* lib) {
+  if (!lib->bvh_dirty) return HFCL_OK;
+  hipFree(lib->d_nodes64); hipFree(lib->d_nodes32); hipFree(lib->d_bverts64); hipFree(lib->d_bverts32);
+  hipFree(lib->d_btris); hipFree(lib->d_meshes); hipFree(lib->d_rss64); hipFree(lib->d_rss32);
+  lib->d_rss64 = nullptr; lib->d_rss32 = nullptr;
+  lib->d_nodes64 = nullptr; lib->d_nodes32 = nullptr; lib->d_bverts64 = nullptr; lib->d_bverts32 = nullptr;
+  lib->d_btris = nullptr; lib->d_meshes = nullptr;
+  const size_t nn = lib->h_bvh_nodes.size(), nv = lib->h_bvh_verts.size(), nt = lib->h_bvh_tris.size();
+  std::vector<DNode<double>> n64(nn);
+  std::vector<DNode<float>> n32(nn);
+  std::vector<DRss<double>> r64(nn);
+  std::vector<DRss<float>> r32(nn);
+  for (size_t i = 0; i < nn; ++i) {
+    const hfcl_bvh_node& hn = lib->h_bvh_nodes[i];
+    n64[i] = pack_node<double>(hn);
+    n32[i] = pack_node<float>(hn);
+    r64[i].Tr = mk<double>(hn.rss_Tr[0], hn.rss_Tr[1], hn.rss_Tr[2]);
+    r64[i].l0 = hn.rss_length[0];
+    r64[i].l1 = hn.rss_length[1];
+    r64[i].r = hn.rss_radius;
+    r32[i].Tr = mk<float>(float(hn.rss_Tr[0]), float(hn.rss_Tr[1]), float(hn.rss_Tr[2]));
+    // fp32 image of the RSS must still contain the fp64 one: round the radius up a little
+    r32[i].l0 = float(hn.rss_length[0]);
+    r32[i].l1 = float(hn.rss_length[1]);
+    r32[i].r = float(hn.rss_radius) * (1.0f + 4e-7f) + 1e-7f;
+  }
+  std::vector<float> v32(nv);
+  for (size_t i = 0; i < nv; ++i) v32[i] = float(lib->h_bvh_verts[i]);
+  HIP_TRY(hipMalloc(&lib->d_nodes64, nn * sizeof(DNode<double>)));
+  HIP_TRY(hipMalloc(&lib->d_nodes32, nn * sizeof(DNode<float>)));
+  HIP_TRY(hipMalloc(&lib->d_bverts64, nv * sizeof(double)));
+  HIP_TRY(hipMalloc(&lib->d_bverts32, nv * sizeof(float)));
+  HIP_TRY(hipMalloc(&lib->d_btris, nt * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&lib->d_meshes, lib->h_meshes.size() * sizeof(DMesh)));
+  HIP_TRY(hipMemcpy(lib->d_nodes64, n64.data(), nn * sizeof(DNode<double>), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_nodes32, n32.data(), nn * sizeof(DNode<float>), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&lib->d_rss64, nn * sizeof(DRss<double>)));
+  HIP_TRY(hipMalloc(&lib->d_rss32, nn * sizeof(DRss<float>)));
+  HIP_TRY(hipMemcpy(lib->d_rss64, r64.data(), nn * sizeof(DRss<double>), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_rss32, r32.data(), nn * sizeof(DRss<float>), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_bverts64, lib->h_bvh_verts.data(), nv * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_bverts32, v32.data(), nv * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_btris, lib->h_bvh_tris.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_meshes, lib->h_meshes.data(), lib->h_meshes.size() * sizeof(DMesh), hipMemcpyHostToDevice));
+  lib->bvh_dirty = false;
+  return HFCL_OK;
+}
+
+static KernelTime* timer_slot(hfcl_lib* lib, size_t i, const char* name) {
+  while (lib->timers.size() <= i) {
+    KernelTime t;
+    t.name = "";
+    t.used = false;
+    hipEventCreate(&t.e0);
+    hipEventCreate(&t.e1);
+    lib->timers.push_back(t);
+  }
+  lib->timers[i].name = name;
+  lib->timers[i].used = true;
+  return &lib->timers[i];
+}
+
+template <typename T>
+static void fill_qparams(QParams<T>& q, const hfcl_query_request& r) {
+  q.gjk.tolerance = T(r.gjk_tolerance);
+  q.gjk.max_iterations = r.gjk_max_iterations;
+  q.gjk.variant = r.gjk_variant;
+  q.gjk.crit = r.gjk_convergence_criterion;
+  q.gjk.crit_type = r.gjk_convergence_criterion_type;
+  q.epa_tolerance = T(r.epa_tolerance);
+  q.epa_max_iterations = int(r.epa_max_iterations);
+  q.collision_distance_threshold = T(r.collision_distance_threshold);
+  q.guess_mode = r.gjk_initial_guess;
+  q.guess[0] = T(r.cached_gjk_guess[0]);
+  q.guess[1] = T(r.cached_gjk_guess[1]);
+  q.guess[2] = T(r.cached_gjk_guess[2]);
+}
+
+static int validate_query(const hfcl_query_request& q) {
+  if (!(q.gjk_tolerance > 0) || !(q.epa_tolerance > 0)) {
+    set_error("tolerance must be positive (gjk.cpp:62)");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  if (q.epa_max_iterations > (uint32_t)EPA_MAX_ITER) {
+    set_error("epa_max_iterations > 64 exceeds the device polytope capacity");
+    return HFCL_ERR_LIMIT;
+  }
+  if (q.gjk_variant < 0 || q.gjk_variant > 2 || q.gjk_convergence_criterion < 0 || q.gjk_convergence_criterion > 2 ||
+      q.gjk_convergence_criterion_type < 0 || q.gjk_convergence_criterion_type > 1) {
+    set_error("invalid GJK variant / convergence criterion");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  if (q.gjk_initial_guess < 0 || q.gjk_initial_guess > HFCL_GUESS_BOUNDING_VOLUME) {
+    set_error("Wrong initial guess for GJK.");  // narrowphase.h:379-380
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  return HFCL_OK;
+}
+
+// Lane-group width of the convex GJK kernels.  A/B on cfg3 / cfg5 (profiles/r01_k_gjk_lane_group_w2.txt): 2-lane
+// groups (16 vertices of each hull per lane, 32 pairs per wave: half the redundancy of the serial simplex code)
+// beat 4-lane groups wherever their 96 / 192 vertex registers fit -- everywhere but fp64 convex x convex.
+template <typename T, int M>
+static int auto_cvx_w() {
+  return (sizeof(T) == 8 && M == 0) ? 4 : 2;
+}
+template <typename T, int M>
+static void launch_cvx_m(hfcl_lib* lib, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q,
+                         hipStream_t st, size_t n) {
+  const int w = lib->cvx_w ? lib->cvx_w : auto_cvx_w<T, M>();
+  size_t b = (n + size_t(256 / w) - 1) / size_t(256 / w);
+  if (b < 1) b = 1;
+  if (b > size_t(lib->n_cus) * 16) b = size_t(lib->n_cus) * 16;
+  launch_gjk_cvx<T>(M, w, q.guess_mode == HFCL_GUESS_BOUNDING_VOLUME, int(b), st, wk, lv, io, q);
+}
+template <typename T>
+static void launch_cvx(hfcl_lib* lib, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q,
+                       hipStream_t st, size_t& ti, size_t n) {
+  KernelTime* t = nullptr;
+  auto tbeg = [&](const char* name) {
+    if (!lib->kernel_timing) return;
+    t = timer_slot(lib, ti++, name);
+    hipEventRecord(t->e0, st);
+  };
+  auto tend = [&]() {
+    if (lib->kernel_timing) hipEventRecord(t->e1, st);
+  };
+  if ((lib->possible_buckets >> B_CC) & 1u) {
+    tbeg("k_gjk_cvx<cc>");
+    launch_cvx_m<T, 0>(lib, wk, lv, io, q, st, n);
+    tend();
+  }
+  if ((lib->possible_buckets >> B_PC) & 1u) {
+    tbeg("k_gjk_cvx<pc>");
+    launch_cvx_m<T, 1>(lib, wk, lv, io, q, st, n);
+    tend();
+  }
+  if ((lib->possible_buckets >> B_CP) & 1u) {
+    tbeg("k_gjk_cvx<cp>");
+    launch_cvx_m<T, 2>(lib, wk, lv, io, q, st, n);
+    tend();
+  }
+}
+
+// The whole pipeline for one batch, asynchronous on `st`.
+template <typename T>
+static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, IO<T> io, size_t n, QParams<T> q,
+                         hipStream_t st) {
+  if (n == 0) return HFCL_OK;
+  if (n > 0xFFFFFFF0ull) {
+    set_error("batch too large (max 2^32-16 pairs per call)");
+    return HFCL_ERR_LIMIT;
+  }
+  HIP_TRY(hipSetDevice(lib->device));
+  int rc = ensure_workspace(lib, n);
+  if (rc) return rc;
+  Work wk;
+  wk.shape1 = d_s1;
+  wk.shape2 = d_s2;
+  wk.n = uint32_t(n);
+  wk.lists = lib->d_lists;
+  wk.counts = lib->d_counts;
+  wk.epa_queue = lib->d_epa_queue;
+  wk.epa_queue2 = lib->d_epa_queue2;
+  wk.epa_resume = lib->d_epa_resume;
+  wk.epa_v0 = lib->d_epa_v0;
+  wk.resume_cap = uint32_t(std::min<size_t>(lib->resume_cap, 0xFFFFFFFFu));
+  LibView<T> lv;
+  lv.shapes = std::is_same<T, double>::value ? (const DShape<T>*)lib->d_shapes64 : (const DShape<T>*)lib->d_shapes32;
+  lv.verts = std::is_same<T, double>::value ? (const T*)lib->d_verts64 : (const T*)lib->d_verts32;
+  lv.kinds = lib->d_kinds;
+  lv.n_shapes = uint32_t(lib->n_shapes);
+
+  for (auto& t : lib->timers) t.used = false;
+  size_t ti = 0;
+  const int max_blocks = lib->n_cus * 16;
+  auto blocks_for = [&](size_t items, size_t per_block) {
+    size_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > (size_t)max_blocks) b = max_blocks;
+    return int(b);
+  };
+  KernelTime* t = nullptr;
+  auto tbeg = [&](const char* name) {
+    if (!lib->kernel_timing) return;
+    t = timer_slot(lib, ti++, name);
+    hipEventRecord(t->e0, st);
+  };
+  auto tend = [&]() {
+    if (lib->kernel_timing) hipEventRecord(t->e1, st);
+  };
+  // buckets no pair of this library's shape kinds can fall into are not launched at all
+  auto may = [&](int b) { return (lib->possible_buckets >> b) & 1u; };
+  const bool any_gjk = may(B_PRIM) || may(B_CC) || may(B_PC) || may(B_CP) || may(B_LARGE);
+  const bool bvg = q.guess_mode == HFCL_GUESS_BOUNDING_VOLUME;
+  HIP_TRY(hipMemsetAsync(lib->d_counts, 0, (B_COUNT + 3) * sizeof(uint32_t), st));
+  tbeg("k_classify");
+  launch_classify(blocks_for(n, CLS_BLOCK * 8), st, wk, lib->d_kinds, uint32_t(lib->n_shapes), q.mode != 1);
+  tend();
+
+  if (may(B_CLOSED)) {
+    tbeg("k_closed");
+    launch_closed<T>(blocks_for(n, 256), st, wk, lv, io, q, lib->closed_staged);
+    tend();
+  }
+  if (may(B_PRIM)) {
+    tbeg("k_gjk_prim");
+    launch_gjk_prim<T>(blocks_for(n, 256), st, wk, lv, io, q, bvg);
+    tend();
+  }
+
+  launch_cvx<T>(lib, wk, lv, io, q, st, ti, n);
+
+  if (may(B_LARGE)) {
+    tbeg("k_gjk_large");
+    launch_gjk_large<T>(blocks_for(n, 256 / LARGE_W), st, wk, lv, io, q, bvg);
+    tend();
+  }
+
+  if (may(B_TRI)) {
+    tbeg("k_triangle");
+    launch_triangle<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, io, q);
+    tend();
+  }
+
+  if (!lib->h_meshes.empty() && (may(B_BVH) || may(B_BVHSHAPE))) {
+    rc = upload_bvh(lib);
+    if (rc) return rc;
+    BvhView<T> bv;
+    bv.nodes = std::is_same<T, double>::value ? (const DNode<T>*)lib->d_nodes64 : (const DNode<T>*)lib->d_nodes32;
+    bv.rss = std::is_same<T, double>::value ? (const DRss<T>*)lib->d_rss64 : (const DRss<T>*)lib->d_rss32;
+    bv.verts = std::is_same<T, double>::value ? (const T*)lib->d_bverts64 : (const T*)lib->d_bverts32;
+    bv.tris = lib->d_btris;
+    bv.meshes = lib->d_meshes;
+    bv.n_meshes = uint32_t(lib->h_meshes.size());
+    if (q.mode == 1) {
+      tbeg("k_bvh_shape");
+      launch_bvh_shape<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance));
+      tend();
+      tbeg("k_bvh_collide");
+      launch_bvh_collide<T>(blocks_for(n, BVH_BLOCK), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance));
+      tend();
+    } else {
+      tbeg("k_bvh_shape_distance");
+      launch_bvh_shape_distance<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q);
+      tend();
+      tbeg("k_bvh_distance");
+      launch_bvh_distance<T>(blocks_for(n, BVHD_BLOCK), st, wk, lv, bv, io, q);
+      tend();
+    }
+  }
+
+  tbeg("k_unsupported");
+  launch_unsupported<T>(blocks_for(n, 256 * 64), st, wk, io, int(B_UNSUPPORTED));
+  if (lib->h_meshes.empty() && may(B_BVHSHAPE))  // BVHModel x shape pairs without any registered mesh
+    launch_unsupported<T>(blocks_for(n, 256 * 64), st, wk, io, int(B_BVHSHAPE));
+  tend();
+
+  if (q.compute_penetration && any_gjk) {
+    tbeg("k_epa<fast>");
+    launch_epa_fast<T>(blocks_for(n, 64 / EPA_WE), st, wk, lv, io, q);
+    tend();
+    tbeg("k_epa<full>");
+    launch_epa_full<T>(blocks_for(n / 16 + 1, 64 / EPA_WE2), st, wk, lv, io, q);
+    tend();
+  }
+  HIP_TRY(hipMemcpyAsync(lib->h_counts, lib->d_counts, (B_COUNT + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipGetLastError());
+  return HFCL_OK;
+}
+
+// shallow clone for the second half of a split batch: shares the device shape tables, owns everything else
+static hfcl_lib* make_helper(hfcl_lib* lib) {
+  hfcl_lib* h = new hfcl_lib;
+  h->is_helper = true;
+  h->device = lib->device;
+  h->n_shapes = lib->n_shapes;
+  h->d_shapes64 = lib->d_shapes64;
+  h->d_shapes32 = lib->d_shapes32;
+  h->d_verts64 = lib->d_verts64;
+  h->d_verts32 = lib->d_verts32;
+  h->d_kinds = lib->d_kinds;
+  h->possible_buckets = lib->possible_buckets;
+  h->cvx_w = lib->cvx_w;
+  h->closed_staged = lib->closed_staged;
+  h->n_cus = lib->n_cus;
+  bool ok = hipMalloc(&h->d_counts, (B_COUNT + 3) * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&h->h_counts, (B_COUNT + 2) * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipMalloc(&h->d_epa_v0, size_t(h->n_cus) * 16 * (64 / EPA_WE2) * EPA_MAX_VERTS * sizeof(Quad<double>)) == hipSuccess;
+  if (!ok) {
+    hfcl_lib_destroy(h);
+    return nullptr;
+  }
+  memset(h->h_counts, 0, (B_COUNT + 2) * sizeof(uint32_t));
+  return h;
+}
+
+template <typename T> static IO<T> io_at(const IO<T>& io, size_t lo);
+template <> IO<double> io_at(const IO<double>& io, size_t lo) {
+  return IO<double>{io.tf1 + 12 * lo, io.tf2 + 12 * lo, io.out + lo, io.gin ? io.gin + lo : nullptr, io.gout ? io.gout + lo : nullptr};
+}
+template <> IO<float> io_at(const IO<float>& io, size_t lo) {
+  return IO<float>{io.tf1 + 7 * lo, io.tf2 + 7 * lo, io.out + lo, nullptr, nullptr};
+}
+
+template <typename T>
+static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, IO<T> io, size_t n, QParams<T> q,
+                     hipStream_t st) {
+  constexpr size_t MIN_SPLIT = 1u << 17;
+  lib->last_split = false;
+  // Automatic choice: a library whose pairs spread over three or more of the iterative buckets (mixed scenes: cfg5
+  // 4.05 -> 3.80 ms) -- the halves then run different kernels side by side; with one or two kernels in the batch the
+  // halves only share the machine phase by phase and the doubled fixed costs lose 3 % (cfg2, cfg3).  A/B in
+  // profiles/r01_k_two_stream_overlap.txt.
+  int parts = lib->split;
+  if (parts == 0) {
+    int kinds = 0;
+    for (int b : {int(B_PRIM), int(B_CC), int(B_PC), int(B_CP), int(B_LARGE)}) kinds += (lib->possible_buckets >> b) & 1u;
+    parts = kinds >= 3 ? 2 : 1;
+  }
+  // meshes keep query-wide side state (contact lists, pair ids in them): they run unsplit
+  if (parts < 2 || n < MIN_SPLIT || !lib->h_meshes.empty()) return run_batch_one<T>(lib, d_s1, d_s2, io, n, q, st);
+  HIP_TRY(hipSetDevice(lib->device));
+  if (!lib->helper) {
+    lib->helper = make_helper(lib);
+    if (!lib->helper || hipStreamCreateWithFlags(&lib->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&lib->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&lib->ev_join, hipEventDisableTiming) != hipSuccess) {
+      set_error("split batches: HIP allocation failed");
+      return HFCL_ERR_HIP;
+    }
+  }
+  hfcl_lib* h2 = lib->helper;
+  h2->kernel_timing = lib->kernel_timing;
+  h2->break_distance = lib->break_distance;
+  h2->bvh_params = lib->bvh_params;
+  const size_t h = n / 2;  // unequal parts (0.35 / 0.6 / 0.7 of the batch first) measured slower on cfg3 and cfg5
+  HIP_TRY(hipEventRecord(lib->ev_fork, st));  // the inputs are ready where the caller's stream stands now
+  HIP_TRY(hipStreamWaitEvent(lib->side, lib->ev_fork, 0));
+  int rc = run_batch_one<T>(lib, d_s1, d_s2, io, h, q, st);
+  if (rc) return rc;
+  rc = run_batch_one<T>(h2, d_s1 + h, d_s2 + h, io_at<T>(io, h), n - h, q, lib->side);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(lib->ev_join, lib->side));
+  HIP_TRY(hipStreamWaitEvent(st, lib->ev_join, 0));  // results are complete in the caller's stream order
+  lib->last_split = true;
+  return HFCL_OK;
+}
+
+template <typename T>
+static int setup_collide(const hfcl_collision_request* req, QParams<T>& q, bool& skip_all) {
+  skip_all = false;
+  if (!req) {
+    set_error("null request");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  if (req->num_max_contacts == 0) {  // src/collision.cpp:82-85
+    set_error("Invalid number of max contacts (current value is 0).");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  int rc = validate_query(req->q);
+  if (rc) return rc;
+  fill_qparams(q, req->q);
+  q.mode = 1;
+  q.compute_penetration = (req->enable_contact || req->security_margin < 0) ? 1 : 0;  // shape_shape_func.h:141-142
+  q.security_margin = T(req->security_margin);
+  // narrowphase.h:228-229
+  double ub = req->distance_upper_bound > req->security_margin ? req->distance_upper_bound : req->security_margin;
+  if (ub < 0) ub = 0;
+  q.gjk.distance_upper_bound = (ub >= double(Lim<T>::max())) ? Lim<T>::max() : T(ub);
+  if (req->security_margin == -__builtin_inf()) skip_all = true;  // src/collision.cpp:73-76
+  return HFCL_OK;
+}
+template <typename T>
+static int setup_distance(const hfcl_distance_request* req, QParams<T>& q) {
+  if (!req) {
+    set_error("null request");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  int rc = validate_query(req->q);
+  if (rc) return rc;
+  fill_qparams(q, req->q);
+  q.mode = 0;
+  q.compute_penetration = req->enable_signed_distance ? 1 : 0;
+  q.security_margin = T(0);
+  q.gjk.distance_upper_bound = Lim<T>::max();  // narrowphase.h:175
+  return HFCL_OK;
+}
+
+extern "C" {
+
+int hfcl_collide_batch_device(hfcl_lib* lib, const uint32_t* d_shape1, const uint32_t* d_shape2, const double* d_tf1,
+                              const double* d_tf2, size_t n, const hfcl_collision_request* req, hfcl_result* d_out,
+                              const hfcl_guess* d_guess_in, hfcl_guess* d_guess_out, void* stream) {
+  if (!lib) {
+    set_error("null library");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  QParams<double> q;
+  bool skip;
+  int rc = setup_collide<double>(req, q, skip);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (skip) {
+    HIP_TRY(hipSetDevice(lib->device));
+    if (n) launch_fill_skipped(st, d_out, uint32_t(n));
+    return HFCL_OK;
+  }
+  IO<double> io{d_tf1, d_tf2, d_out, d_guess_in, d_guess_out};
+  lib->bvh_params.num_max_contacts = req->num_max_contacts;
+  lib->break_distance = req->break_distance;
+  return run_batch<double>(lib, d_shape1, d_shape2, io, n, q, st);
+}
+
+int hfcl_distance_batch_device(hfcl_lib* lib, const uint32_t* d_shape1, const uint32_t* d_shape2, const double* d_tf1,
+                               const double* d_tf2, size_t n, const hfcl_distance_request* req, hfcl_result* d_out,
+                               const hfcl_guess* d_guess_in, hfcl_guess* d_guess_out, void* stream) {
+  if (!lib) {
+    set_error("null library");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  QParams<double> q;
+  int rc = setup_distance<double>(req, q);
+  if (rc) return rc;
+  IO<double> io{d_tf1, d_tf2, d_out, d_guess_in, d_guess_out};
+  return run_batch<double>(lib, d_shape1, d_shape2, io, n, q, (hipStream_t)stream);
+}
+
+int hfcl_distance_batch_device_f32(hfcl_lib* lib, const uint32_t* d_shape1, const uint32_t* d_shape2,
+                                   const float* d_pose1, const float* d_pose2, size_t n,
+                                   const hfcl_distance_request* req, hfcl_result_f32* d_out, void* stream) {
+  if (!lib) {
+    set_error("null library");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  QParams<float> q;
+  int rc = setup_distance<float>(req, q);
+  if (rc) return rc;
+  IO<float> io{d_pose1, d_pose2, d_out, nullptr, nullptr};
+  return run_batch<float>(lib, d_shape1, d_shape2, io, n, q, (hipStream_t)stream);
+}
+
+int hfcl_collide_batch_device_f32(hfcl_lib* lib, const uint32_t* d_shape1, const uint32_t* d_shape2,
+                                  const float* d_pose1, const float* d_pose2, size_t n,
+                                  const hfcl_collision_request* req, hfcl_result_f32* d_out, void* stream) {
+  if (!lib) {
+    set_error("null library");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  QParams<float> q;
+  bool skip;
+  int rc = setup_collide<float>(req, q, skip);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (skip) {
+    HIP_TRY(hipSetDevice(lib->device));
+    if (n) launch_fill_skipped(st, d_out, uint32_t(n));
+    return HFCL_OK;
+  }
+  IO<float> io{d_pose1, d_pose2, d_out, nullptr, nullptr};
+  lib->bvh_params.num_max_contacts = req->num_max_contacts;
+  lib->break_distance = req->break_distance;
+  return run_batch<float>(lib, d_shape1, d_shape2, io, n, q, st);
+}
+
+static int ensure_staging(hfcl_lib* lib, size_t n, bool gin, bool gout) {
+  if (n > lib->st_capacity) {
+    hipFree(lib->d_s1); hipFree(lib->d_s2); hipFree(lib->d_tf1); hipFree(lib->d_tf2); hipFree(lib->d_out);
+    hipFree(lib->d_gin); hipFree(lib->d_gout);
+    lib->d_s1 = lib->d_s2 = nullptr;
+    lib->d_tf1 = lib->d_tf2 = nullptr;
+    lib->d_out = nullptr;
+    lib->d_gin = lib->d_gout = nullptr;
+    lib->st_capacity = 0;
+    size_t cap = n + n / 8 + 256;
+    HIP_TRY(hipMalloc(&lib->d_s1, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&lib->d_s2, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&lib->d_tf1, cap * 12 * sizeof(double)));
+    HIP_TRY(hipMalloc(&lib->d_tf2, cap * 12 * sizeof(double)));
+    HIP_TRY(hipMalloc(&lib->d_out, cap * sizeof(hfcl_result)));
+    lib->st_capacity = cap;
+  }
+  if (gin && !lib->d_gin) HIP_TRY(hipMalloc(&lib->d_gin, lib->st_capacity * sizeof(hfcl_guess)));
+  if (gout && !lib->d_gout) HIP_TRY(hipMalloc(&lib->d_gout, lib->st_capacity * sizeof(hfcl_guess)));
+  return HFCL_OK;
+}
+
+static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, const double* tf1, const double* tf2,
+                      size_t n, const hfcl_collision_request* creq, const hfcl_distance_request* dreq, hfcl_result* out,
+                      const hfcl_guess* gin, hfcl_guess* gout) {
+  if (!lib) {
+    set_error("null library");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  if (n == 0) return HFCL_OK;
+  if (!s1 || !s2 || !tf1 || !tf2 || !out) {
+    set_error("null buffer");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(lib->device));
+  int rc = ensure_staging(lib, n, gin != nullptr, gout != nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(lib->d_s1, s1, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_s2, s2, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_tf1, tf1, n * 12 * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(lib->d_tf2, tf2, n * 12 * sizeof(double), hipMemcpyHostToDevice));
+  if (gin) HIP_TRY(hipMemcpy(lib->d_gin, gin, n * sizeof(hfcl_guess), hipMemcpyHostToDevice));
+  if (creq)
+    rc = hfcl_collide_batch_device(lib, lib->d_s1, lib->d_s2, lib->d_tf1, lib->d_tf2, n, creq, lib->d_out,
+                                   gin ? lib->d_gin : nullptr, gout ? lib->d_gout : nullptr, nullptr);
+  else
+    rc = hfcl_distance_batch_device(lib, lib->d_s1, lib->d_s2, lib->d_tf1, lib->d_tf2, n, dreq, lib->d_out,
+                                    gin ? lib->d_gin : nullptr, gout ? lib->d_gout : nullptr, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, lib->d_out, n * sizeof(hfcl_result), hipMemcpyDeviceToHost));
+  if (gout) HIP_TRY(hipMemcpy(gout, lib->d_gout, n * sizeof(hfcl_guess), hipMemcpyDeviceToHost));
+  const bool skipped = creq && creq->security_margin == -__builtin_inf();
+  if (!skipped && total_count(lib, B_UNSUPPORTED) > 0) {
+    set_error("Collision/distance function between some node types of the batch is not yet supported (" +
+              std::to_string(total_count(lib, B_UNSUPPORTED)) + " pairs; their records carry status bit 31)");
+    return HFCL_ERR_UNSUPPORTED_PAIR;
+  }
+  {
+    // a TriangleP built inside the reference (top-level TriangleP overloads, mesh x shape leaves) never had
+    // computeLocalAABB() called: BoundingVolumeGuess throws there (narrowphase.h:366-373)
+    const hfcl_query_request& qq = creq ? creq->q : dreq->q;
+    if (!skipped && qq.gjk_initial_guess == HFCL_GUESS_BOUNDING_VOLUME &&
+        (total_count(lib, B_TRI) > 0 || total_count(lib, B_BVHSHAPE) > 0)) {
+      set_error("computeLocalAABB must have been called on the shapes before using GJKInitialGuess::BoundingVolumeGuess.");
+      return HFCL_ERR_INVALID_ARGUMENT;
+    }
+  }
+  if (!skipped && creq && creq->security_margin < 0 && total_count(lib, B_BVHSHAPE) > 0) {
+    set_error("Negative security margin are not handled yet for BVHModel");  // collision_func_matrix.cpp:109-112
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  if (!skipped && (total_count(lib, B_BVH) > 0 || total_count(lib, B_BVHSHAPE) > 0) && lib->h_meshes.empty()) {
+    set_error("BVH shapes in the batch but no BVHModel registered (hfcl_lib_add_bvh)");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  return HFCL_OK;
+}
+
+int hfcl_collide_batch(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2, const double* tf1,
+                       const double* tf2, size_t n, const hfcl_collision_request* req, hfcl_result* out,
+                       const hfcl_guess* guess_in, hfcl_guess* guess_out) {
+  if (!req) {
+    set_error("null request");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  return host_batch(lib, shape1, shape2, tf1, tf2, n, req, nullptr, out, guess_in, guess_out);
+}
+int hfcl_distance_batch(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2, const double* tf1,
+                        const double* tf2, size_t n, const hfcl_distance_request* req, hfcl_result* out,
+                        const hfcl_guess* guess_in, hfcl_guess* guess_out) {
+  if (!req) {
+    set_error("null request");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  return host_batch(lib, shape1, shape2, tf1, tf2, n, nullptr, req, out, guess_in, guess_out);
+}
+
+int hfcl_collide_batch_contacts(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2, const double* tf1,
+                                const double* tf2, size_t n, const hfcl_collision_request* req, hfcl_result* out,
+                                hfcl_contact* contacts, size_t max_contacts_total, size_t* n_contacts_out) {
+  if (!lib || !req || !contacts || !n_contacts_out) {
+    set_error("null argument");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(lib->device));
+  if (max_contacts_total > lib->contacts_cap) {
+    hipFree(lib->d_contacts);
+    lib->d_contacts = nullptr;
+    lib->contacts_cap = 0;
+    HIP_TRY(hipMalloc(&lib->d_contacts, max_contacts_total * sizeof(hfcl_contact)));
+    lib->contacts_cap = max_contacts_total;
+  }
+  if (!lib->d_contacts_count) HIP_TRY(hipMalloc(&lib->d_contacts_count, sizeof(uint32_t)));
+  HIP_TRY(hipMemset(lib->d_contacts_count, 0, sizeof(uint32_t)));
+  lib->bvh_params.contacts = lib->d_contacts;
+  lib->bvh_params.contacts_cap = uint32_t(max_contacts_total > 0xFFFFFFFFull ? 0xFFFFFFFFull : max_contacts_total);
+  lib->bvh_params.contacts_count = lib->d_contacts_count;
+  int rc = host_batch(lib, shape1, shape2, tf1, tf2, n, req, nullptr, out, nullptr, nullptr);
+  lib->bvh_params.contacts = nullptr;
+  lib->bvh_params.contacts_cap = 0;
+  lib->bvh_params.contacts_count = nullptr;
+  if (rc) return rc;
+  uint32_t cnt = 0;
+  HIP_TRY(hipMemcpy(&cnt, lib->d_contacts_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  const size_t stored = cnt < max_contacts_total ? cnt : max_contacts_total;
+  if (stored) HIP_TRY(hipMemcpy(contacts, lib->d_contacts, stored * sizeof(hfcl_contact), hipMemcpyDeviceToHost));
+  *n_contacts_out = cnt;  // number produced (may exceed the capacity; the excess was dropped)
+  return HFCL_OK;
+}
+
+double hfcl_last_kernel_ms(hfcl_lib* lib) {
+  if (!lib) return 0.0;
+  hipSetDevice(lib->device);
+  double total = 0, best = -1;
+  lib->dominant = "";
+  for (auto& t : lib->timers) {
+    if (!t.used) continue;
+    if (hipEventSynchronize(t.e1) != hipSuccess) continue;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, t.e0, t.e1) != hipSuccess) continue;
+    total += ms;
+    if (ms > best) {
+      best = ms;
+      lib->dominant = t.name;
+    }
+  }
+  return total;
+}
+const char* hfcl_last_kernel_name(hfcl_lib* lib) { return lib ? lib->dominant.c_str() : ""; }
+void hfcl_lib_set_kernel_timing(hfcl_lib* lib, int on) {
+  if (!lib) return;
+  lib->kernel_timing = on != 0;
+  if (!on)
+    for (auto& t : lib->timers) t.used = false;
+}
+
+// breakdown: up to `cap` (name, ms) entries of the last call; returns the number written
+int hfcl_last_kernel_breakdown(hfcl_lib* lib, const char** names, double* ms, int cap) {
+  if (!lib) return 0;
+  hipSetDevice(lib->device);
+  int k = 0;
+  for (auto& t : lib->timers) {
+    if (!t.used || k >= cap) continue;
+    float m = 0;
+    if (hipEventSynchronize(t.e1) != hipSuccess) continue;
+    if (hipEventElapsedTime(&m, t.e0, t.e1) != hipSuccess) continue;
+    // split batch: the two halves ran the same launch sequence on two streams; report the mean as-run duration of a launch
+    const size_t i = size_t(&t - lib->timers.data());
+    if (lib->last_split && lib->helper && i < lib->helper->timers.size() && lib->helper->timers[i].used) {
+      KernelTime& u = lib->helper->timers[i];
+      float m2 = 0;
+      if (hipEventSynchronize(u.e1) == hipSuccess && hipEventElapsedTime(&m2, u.e0, u.e1) == hipSuccess) m = 0.5f * (m + m2);
+    }
+    names[k] = t.name;
+    ms[k] = m;
+    ++k;
+  }
+  return k;
+}
+
+// parts = 2: batches of at least 128k pairs (libraries without meshes) run as two halves on two streams; 1: one stream
+void hfcl_lib_set_split(hfcl_lib* lib, int parts) {
+  if (lib) lib->split = parts >= 2 ? 2 : (parts == 1 ? 1 : 0);
+}
+int hfcl_lib_get_split(const hfcl_lib* lib) { return lib ? lib->split : 0; }
+int hfcl_lib_last_split_parts(const hfcl_lib* lib) { return (lib && lib->last_split) ? 2 : 1; }
+
+// bucket populations of the last call (after a stream sync): closed, prim, cc, pc, cp, bvh, unsupported,
+// epa queue, epa overflow queue
+void hfcl_last_bucket_counts(hfcl_lib* lib, uint32_t* out12) {  // B_COUNT buckets + the two EPA queues
+  if (lib) {  // the counters travel with an asynchronous copy at the end of the batch: wait for it
+    hipSetDevice(lib->device);
+    hipDeviceSynchronize();
+  }
+  for (int i = 0; i <= B_COUNT + 1; ++i) out12[i] = lib ? total_count(lib, i) : 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,541 @@
+// hfcl_k_bvh.hip -- BVHModel<OBBRSS> kernels (mesh x mesh collide / distance, mesh x solid) and top-level TriangleP pairs.
+#include "hfcl_dev.hpp"
+#include "hfcl_launch.hpp"
+
+template <typename T>
+__global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH, 8))) k_bvh_collide(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
+                                                          BvhParams bp, T break_distance2) {
+  __shared__ uint32_t stack[BVH_STACK][BVH_BLOCK];
+  const uint32_t cnt = wk.counts[B_BVH];
+  uint32_t* const ticket = &wk.counts[B_COUNT + 2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const T nanv = Lim<T>::nan();
+  // Per-lane query state.  Queries differ by an order of magnitude in length (cfg4: 135 BV tests on
+  // average, 663 for the longest of 64), so the lanes of a wave do not advance through the batch in
+  // lockstep: a lane whose traversal is over parks its result (`pending`) and, as soon as
+  // BVH_REFILL_MIN lanes of the wave are idle, all of them write their records and take the next
+  // queries from a global ticket counter.
+  constexpr int refill_min = BVH_REFILL_MIN;
+  bool live = false, pending = false, exhausted = false;  // exhausted is wave-uniform
+  uint32_t pair = 0;
+  DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
+  Pose<T> tf1, tf2;
+  M3<T> RT_R;
+  V3<T> RT_T;
+  int sp = 0;
+  bool overflow = false;
+  uint32_t ncontacts = 0;
+  T dlb = Lim<T>::max(), rec_dist = Lim<T>::max();
+  V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1, nn = np1;
+  int fb1 = -1, fb2 = -1;
+  bool have_leaf = false;
+  uint32_t lb1 = 0, lb2 = 0;
+  auto flush = [&]() {  // record of the query this lane finished
+    PairOut<T> o;
+    o.distance = rec_dist;
+    o.normal = nn;
+    o.p1 = np1;
+    o.p2 = np2;
+    o.gjk_status = GJK_DID_NOT_RUN;
+    o.epa_status = EPA_DID_NOT_RUN;
+    o.gjk_iters = o.epa_iters = 0;
+    store_bvh_record(io, pair, o, ncontacts, fb1, fb2, overflow);
+  };
+  for (;;) {
+    if (live && !have_leaf && sp == 0) {  // traversal over
+      live = false;
+      pending = true;
+    }
+    const uint64_t live_mask = __ballot(live);
+    const int n_live = __popcll(live_mask);
+    if (exhausted ? n_live == 0 : 64 - n_live >= refill_min) {
+      // ---- refill (wave-uniform decision; live lanes sit it out)
+      if (pending) {
+        flush();
+        pending = false;
+      }
+      if (exhausted) break;
+      const int n_need = 64 - n_live;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ticket, uint32_t(n_need));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (!live) {
+        const uint32_t rank = uint32_t(__popcll(~live_mask & ((uint64_t(1) << lane) - 1)));
+        const uint32_t it = base + rank;
+        if (it < cnt) {
+          pair = wk.lists[size_t(B_BVH) * wk.n + it];
+          const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+          m1 = bv.meshes[a.bvh_index];
+          m2 = bv.meshes[b.bvh_index];
+          tf1 = load_pose(io.tf1, pair);
+          tf2 = load_pose(io.tf2, pair);
+          RT_R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
+          RT_T = tmul(tf1.R, tf2.t - tf1.t);
+          stack[0][tid] = 0u;  // (b1 = 0, b2 = 0)
+          sp = 1;
+          overflow = false;
+          ncontacts = 0;
+          dlb = rec_dist = Lim<T>::max();
+          np1 = np2 = nn = mk<T>(nanv, nanv, nanv);
+          fb1 = fb2 = -1;
+          have_leaf = false;
+          live = true;
+        }
+      }
+      if (base + uint32_t(n_need) >= cnt) exhausted = true;
+      continue;
+    }
+    // ---- BV phase: advance every lane that has no leaf test pending, until half the wave waits for a
+    // leaf test, nobody can advance, or enough lanes ran out of work to make a refill due
+    for (;;) {
+      const bool can_bv = live && !have_leaf && sp > 0;
+      if (!__any(can_bv)) break;
+      if (__popcll(__ballot(have_leaf)) >= 32) break;
+      if (!exhausted && 64 - __popcll(__ballot(live && (have_leaf || sp > 0))) >= refill_min) break;
+      if (can_bv) {
+        const uint32_t e = stack[--sp][tid];
+        const uint32_t b1 = e & 0xFFFFu, b2 = e >> 16;
+        const DNode<T> n1 = bv.nodes[m1.node_off + b1];
+        const DNode<T> n2 = bv.nodes[m2.node_off + b2];
+        const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
+        if (l1 && l2) {
+          have_leaf = true;
+          lb1 = uint32_t(-(n1.first_child + 1));
+          lb2 = uint32_t(-(n2.first_child + 1));
+        } else {
+          T sq;
+          // argument order of the reference: overlap(RT.R, RT.T, model2.bv(b2), model1.bv(b1))
+          const bool disjoint = obb_disjoint(RT_R, RT_T, n2, n1, q.security_margin, break_distance2, sq);
+          if (disjoint) {  // updateDistanceLowerBoundFromBV
+            if (!(dlb <= T(0))) {
+              const T nd = hsqrt(sq);
+              if (nd < dlb) {
+                dlb = nd;
+                rec_dist = nd + q.security_margin;
+              }
+            }
+          } else {
+            const T sz1 = sqnorm(n1.extent), sz2 = sqnorm(n2.extent);
+            const bool first = l2 || (!l1 && (sz1 > sz2));  // firstOverSecond
+            uint32_t ea, eb;
+            if (first) {
+              const uint32_t c1 = uint32_t(n1.first_child);
+              ea = c1 | (b2 << 16);
+              eb = (c1 + 1) | (b2 << 16);
+            } else {
+              const uint32_t c1 = uint32_t(n2.first_child);
+              ea = b1 | (c1 << 16);
+              eb = b1 | ((c1 + 1) << 16);
+            }
+            if (sp + 2 > BVH_STACK) {
+              overflow = true;
+              sp = 0;
+            } else {
+              stack[sp++][tid] = eb;  // second child below
+              stack[sp++][tid] = ea;  // first child on top
+            }
+          }
+        }
+      }
+    }
+    // ---- leaf phase (leafCollides, traversal_node_bvhs.h:184-233)
+    if (have_leaf) {
+      have_leaf = false;
+      const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + lb1);
+      const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + lb2);
+      const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
+      const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
+      auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
+      TriSupport<T> tri;
+      tri.p1 = xform(tf1, vtx(v1, t1[0]));
+      tri.p2 = xform(tf1, vtx(v1, t1[1]));
+      tri.p3 = xform(tf1, vtx(v1, t1[2]));
+      tri.q1 = xform(tf2, vtx(v2, t2[0]));
+      tri.q2 = xform(tf2, vtx(v2, t2[1]));
+      tri.q3 = xform(tf2, vtx(v2, t2[2]));
+      V3<T> p1, p2, n;
+      int gst, git;
+      const T distance = tri_tri_distance(tri, q.gjk, q.guess_mode == HFCL_GUESS_CACHED,
+                                          mk<T>(q.guess[0], q.guess[1], q.guess[2]), p1, p2, n, gst, git);
+      const T dtc = distance - q.security_margin;
+      if (dtc < dlb) {  // updateDistanceLowerBoundFromLeaf
+        dlb = dtc;
+        rec_dist = distance;
+        np1 = p1;
+        np2 = p2;
+        nn = n;
+      }
+      if (dtc <= q.collision_distance_threshold) {
+        if (ncontacts < bp.num_max_contacts) {
+          if (ncontacts == 0) {
+            fb1 = int(lb1);
+            fb2 = int(lb2);
+          }
+          ++ncontacts;
+          if (bp.contacts) {
+            const uint32_t slot = atomicAdd(bp.contacts_count, 1u);
+            if (slot < bp.contacts_cap) {
+              hfcl_contact c;
+              c.pair = pair;
+              c.b1 = int(lb1);
+              c.b2 = int(lb2);
+              c._pad = 0;
+              c.penetration_depth = double(distance);
+              c.normal[0] = n.x; c.normal[1] = n.y; c.normal[2] = n.z;
+              c.p1[0] = p1.x; c.p1[1] = p1.y; c.p1[2] = p1.z;
+              c.p2[0] = p2.x; c.p2[1] = p2.y; c.p2[2] = p2.z;
+              bp.contacts[slot] = c;
+            }
+          }
+        }
+        if (ncontacts >= bp.num_max_contacts) sp = 0;  // canStop(): nothing else is visited
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// k_bvh_shape: BVHModel<OBBRSS> x convex solid collide(), either operand order.  One query per BS_W-lane
+// group (hfcl_bvh_shape.hpp: sequential traversal, the group's lanes share support scans and EPA face
+// work); DFS stack and the full-capacity polytope of each group in LDS.
+// ---------------------------------------------------------------------------------------
+
+template <typename T>
+struct GroupSolid {  // support of the solid in its own frame, evaluated by the lane group
+  DShape<T> s;
+  HullRegs<T, BS_W> h;
+  const T* v;
+  int lig;
+  __device__ __forceinline__ V3<T> operator()(const V3<T>& d) const {
+    if (s.kind != K_CONVEX) return prim_support(s, d);
+    if (s.num_points > uint32_t(HULL_MAX)) return scan_support<T, BS_W>(v, s.num_points, d, lig);
+    return h.support(d, lig);
+  }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(64) k_bvh_shape(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhParams bp,
+                                                  T break_distance2) {
+  constexpr int G = 64 / BS_W;
+  __shared__ EpaScratch<T, EPA_MAX_ITER> scratch[G];
+  __shared__ uint16_t stacks[G][BS_STACK];
+  const uint32_t cnt = wk.counts[B_BVHSHAPE];
+  const int lane = threadIdx.x & 63, grp = lane / BS_W, lig = lane & (BS_W - 1);
+  for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += gridDim.x * G) {
+    const uint32_t pair = wk.lists[size_t(B_BVHSHAPE) * wk.n + it];
+    const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+    const bool swapped = a.kind != K_BVH;  // (shape, BVH): collide(o2, o1) then swapObjects (collision.cpp:93-108)
+    const DShape<T> ms = swapped ? b : a;
+    GroupSolid<T> solid;
+    solid.s = swapped ? a : b;
+    solid.v = lib.verts + 3 * size_t(solid.s.vertex_offset);
+    solid.lig = lig;
+    if (solid.s.kind == K_CONVEX && solid.s.num_points <= uint32_t(HULL_MAX)) solid.h.load(solid.v, solid.s.num_points, lig);
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    const Pose<T> tfm = swapped ? tf2 : tf1, tfs = swapped ? tf1 : tf2;
+    const DMesh m = bv.meshes[ms.bvh_index];
+    MeshShapeState<T> st;
+    auto on_contact = [&](int prim, T distance, const V3<T>& p1, const V3<T>& p2, const V3<T>& nn) {
+      if (lig != 0 || !bp.contacts) return;
+      const uint32_t slot = atomicAdd(bp.contacts_count, 1u);
+      if (slot >= bp.contacts_cap) return;
+      hfcl_contact c;
+      c.pair = pair;
+      c.b1 = swapped ? -1 : prim;
+      c.b2 = swapped ? prim : -1;
+      c._pad = 0;
+      c.penetration_depth = double(distance);
+      const V3<T> a1 = swapped ? p2 : p1, a2 = swapped ? p1 : p2, an = swapped ? -nn : nn;
+      c.normal[0] = an.x; c.normal[1] = an.y; c.normal[2] = an.z;
+      c.p1[0] = a1.x; c.p1[1] = a1.y; c.p1[2] = a1.z;
+      c.p2[0] = a2.x; c.p2[1] = a2.y; c.p2[2] = a2.z;
+      bp.contacts[slot] = c;
+    };
+    mesh_shape_collide<T, LaneGroup<BS_W>>(bv.nodes + m.node_off, bv.verts + 3 * size_t(m.vert_off), bv.tris + 3 * size_t(m.tri_off),
+                                           tfm, solid.s, lib.verts, tfs, solid, q, bp.num_max_contacts, break_distance2,
+                                           stacks[grp], BS_STACK, &scratch[grp], initial_guess<T>(io, q, pair), on_contact, st);
+    if (lig == 0) {
+      if (st.unsupported) {
+        auto r = io.out[pair];
+        memset(&r, 0, sizeof(r));
+        r.status = 0x80000000u;
+        io.out[pair] = r;
+      } else {
+        PairOut<T> o;
+        o.distance = st.rec_dist;
+        o.normal = swapped ? -st.nn : st.nn;
+        o.p1 = swapped ? st.np2 : st.np1;
+        o.p2 = swapped ? st.np1 : st.np2;
+        o.gjk_status = GJK_DID_NOT_RUN;
+        o.epa_status = EPA_DID_NOT_RUN;
+        o.gjk_iters = o.epa_iters = 0;
+        store_bvh_record(io, pair, o, st.ncontacts, swapped ? -1 : st.first_prim, swapped ? st.first_prim : -1, st.overflow);
+        write_guess<T>(io, pair, st.guess, 0, 0);
+      }
+    }
+    LaneGroup<BS_W>::sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_triangle: top-level TriangleP pairs (other than against Plane / Halfspace, which are closed forms):
+// TriangleP x TriangleP (triangle_triangle.cpp:46-105), TriangleP x Sphere (triangle_sphere.cpp:45-68) and
+// TriangleP x {Box, Capsule, Cone, Cylinder, Ellipsoid, ConvexBase} through GJKSolver::shapeDistance's
+// TriangleP overloads (narrowphase.h:320-348).  One pair per BS_W-lane group, as the mesh x solid leaves.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64) k_triangle(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  constexpr int G = 64 / BS_W;
+  __shared__ EpaScratch<T, EPA_MAX_ITER> scratch[G];
+  const uint32_t cnt = wk.counts[B_TRI];
+  const int lane = threadIdx.x & 63, grp = lane / BS_W, lig = lane & (BS_W - 1);
+  for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += gridDim.x * G) {
+    const uint32_t pair = wk.lists[size_t(B_TRI) * wk.n + it];
+    const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    const bool t1 = a.kind == K_TRIANGLE;
+    GroupSolid<T> solid;  // the non-triangle shape (unused for TriangleP x TriangleP)
+    solid.s = t1 ? b : a;
+    solid.v = lib.verts + 3 * size_t(solid.s.vertex_offset);
+    solid.lig = lig;
+    if (solid.s.kind == K_CONVEX && solid.s.num_points <= uint32_t(HULL_MAX)) solid.h.load(solid.v, solid.s.num_points, lig);
+    PairOut<T> o;
+    triangle_pair<T, LaneGroup<BS_W>>(a, b, lib.verts, tf1, tf2, solid, q, initial_guess<T>(io, q, pair), &scratch[grp], o);
+    if (lig == 0) {
+      write_out<T>(io, q, pair, o);
+      write_guess<T>(io, pair, o.cached_guess, 0, 0);
+    }
+    LaneGroup<BS_W>::sync();
+  }
+}
+
+// distance() counterpart: same lane-group layout, RSS lower bounds instead of OBB overlap tests.
+template <typename T>
+__global__ void __launch_bounds__(64) k_bvh_shape_distance(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q) {
+  constexpr int G = 64 / BS_W;
+  __shared__ EpaScratch<T, EPA_MAX_ITER> scratch[G];
+  __shared__ uint16_t stack_n[G][BS_STACK];
+  __shared__ T stack_d[G][BS_STACK];
+  const uint32_t cnt = wk.counts[B_BVHSHAPE];
+  const int lane = threadIdx.x & 63, grp = lane / BS_W, lig = lane & (BS_W - 1);
+  for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += gridDim.x * G) {
+    const uint32_t pair = wk.lists[size_t(B_BVHSHAPE) * wk.n + it];
+    const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+    const bool swapped = a.kind != K_BVH;  // distance.cpp:74-88
+    const DShape<T> ms = swapped ? b : a;
+    GroupSolid<T> solid;
+    solid.s = swapped ? a : b;
+    solid.v = lib.verts + 3 * size_t(solid.s.vertex_offset);
+    solid.lig = lig;
+    if (solid.s.kind == K_CONVEX && solid.s.num_points <= uint32_t(HULL_MAX)) solid.h.load(solid.v, solid.s.num_points, lig);
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    const Pose<T> tfm = swapped ? tf2 : tf1, tfs = swapped ? tf1 : tf2;
+    const DMesh m = bv.meshes[ms.bvh_index];
+    MeshShapeDist<T> st;
+    mesh_shape_distance<T, LaneGroup<BS_W>>(bv.nodes + m.node_off, bv.rss + m.node_off, bv.verts + 3 * size_t(m.vert_off),
+                                            bv.tris + 3 * size_t(m.tri_off), tfm, solid.s, lib.verts, tfs, solid, q, stack_n[grp],
+                                            stack_d[grp], BS_STACK, &scratch[grp], initial_guess<T>(io, q, pair), st);
+    if (lig == 0) {
+      if (st.unsupported) {
+        auto r = io.out[pair];
+        memset(&r, 0, sizeof(r));
+        r.status = 0x80000000u;
+        io.out[pair] = r;
+      } else {
+        PairOut<T> o;
+        o.distance = st.min_distance;
+        o.normal = swapped ? -st.nn : st.nn;
+        o.p1 = swapped ? st.np2 : st.np1;
+        o.p2 = swapped ? st.np1 : st.np2;
+        o.gjk_status = GJK_DID_NOT_RUN;
+        o.epa_status = EPA_DID_NOT_RUN;
+        o.gjk_iters = o.epa_iters = 0;
+        // b1 = the triangle, b2 = NONE whatever the operand order (distance.cpp:84-88 swaps o1/o2 only)
+        store_bvh_record(io, pair, o, st.min_distance <= T(0) ? 0x80000000u : 0u, st.prim, -1, st.overflow);
+        write_guess<T>(io, pair, st.guess, 0, 0);
+      }
+    }
+    LaneGroup<BS_W>::sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_bvh_distance: BVHModel<OBBRSS> x BVHModel<OBBRSS> distance().  distanceRecurse
+// (src/traversal/traversal_recurse.cpp:153-203) flattened: both child pairs get their RSS lower
+// bound, the farther one is pushed first (with its bound), the nearer one on top; a popped entry is
+// skipped when its bound can no longer beat the current minimum (canStop, rel_err = abs_err = 0 as
+// latched by the reference's traversal node, traversal_node_bvhs.h:409-410).  Leaves =
+// sqrTriDistance in model 1's frame; the result is seeded with triangle 0 x triangle 0 (preprocess).
+// ---------------------------------------------------------------------------------------
+
+template <typename T>
+__global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH, 8))) k_bvh_distance(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q) {
+  __shared__ uint32_t stack_e[BVHD_STACK][BVHD_BLOCK];
+  __shared__ T stack_d[BVHD_STACK][BVHD_BLOCK];
+  const uint32_t cnt = wk.counts[B_BVH];
+  uint32_t* const ticket = &wk.counts[B_COUNT + 2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const T nanv = Lim<T>::nan();
+  // streaming as in k_bvh_collide: per-lane query state, refill once BVH_REFILL_MIN lanes are idle
+  bool live = false, pending = false, exhausted = false;  // exhausted is wave-uniform
+  uint32_t pair = 0;
+  DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
+  Pose<T> tf1;
+  M3<T> RT_R;
+  V3<T> RT_T;
+  T mind = Lim<T>::max();
+  int fb1 = -1, fb2 = -1;
+  V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1;
+  bool overflow = false;
+  int sp = 0;
+  auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
+  auto leaf = [&](uint32_t p1i, uint32_t p2i) {
+    const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
+    const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
+    const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + p1i);
+    const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + p2i);
+    V3<T> P, Q;
+    const T d2 = sqr_tri_distance(vtx(v1, t1[0]), vtx(v1, t1[1]), vtx(v1, t1[2]), mul(RT_R, vtx(v2, t2[0])) + RT_T,
+                                  mul(RT_R, vtx(v2, t2[1])) + RT_T, mul(RT_R, vtx(v2, t2[2])) + RT_T, P, Q);
+    const T d = hsqrt(d2);
+    if (mind > d) {  // DistanceResult::update
+      mind = d;
+      fb1 = int(p1i);
+      fb2 = int(p2i);
+      np1 = P;
+      np2 = Q;
+    }
+  };
+  for (;;) {
+    if (live && sp == 0) {
+      live = false;
+      pending = true;
+    }
+    const uint64_t live_mask = __ballot(live);
+    const int n_live = __popcll(live_mask);
+    if (exhausted ? n_live == 0 : 64 - n_live >= BVH_REFILL_MIN) {
+      if (pending) {
+        PairOut<T> o;
+        o.distance = mind;
+        o.normal = mk<T>(nanv, nanv, nanv);  // not set by the reference on this path (traversal_node_bvhs.h:454,465)
+        o.p1 = xform(tf1, np1);              // postprocess(): model-1 frame -> world
+        o.p2 = xform(tf1, np2);
+        o.gjk_status = GJK_DID_NOT_RUN;
+        o.epa_status = EPA_DID_NOT_RUN;
+        o.gjk_iters = o.epa_iters = 0;
+        store_bvh_record(io, pair, o, mind <= T(0) ? 0x80000000u : 0u, fb1, fb2, overflow);
+        pending = false;
+      }
+      if (exhausted) break;
+      const int n_need = 64 - n_live;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ticket, uint32_t(n_need));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (!live) {
+        const uint32_t it = base + uint32_t(__popcll(~live_mask & ((uint64_t(1) << lane) - 1)));
+        if (it < cnt) {
+          pair = wk.lists[size_t(B_BVH) * wk.n + it];
+          const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+          m1 = bv.meshes[a.bvh_index];
+          m2 = bv.meshes[b.bvh_index];
+          tf1 = load_pose(io.tf1, pair);
+          const Pose<T> tf2 = load_pose(io.tf2, pair);
+          RT_R = tmul(tf1.R, tf2.R);
+          RT_T = tmul(tf1.R, tf2.t - tf1.t);
+          mind = Lim<T>::max();
+          fb1 = fb2 = -1;
+          np1 = np2 = mk<T>(nanv, nanv, nanv);
+          overflow = false;
+          leaf(0u, 0u);  // preprocess()
+          sp = 1;
+          stack_e[0][tid] = 0u;
+          stack_d[0][tid] = T(-1);
+          live = true;
+        }
+      }
+      if (base + uint32_t(n_need) >= cnt) exhausted = true;
+      continue;
+    }
+    for (;;) {
+      const bool run = live && sp > 0;
+      const int n_run = __popcll(__ballot(run));
+      if (n_run == 0 || (!exhausted && 64 - n_run >= BVH_REFILL_MIN)) break;
+      if (!run) continue;
+      --sp;
+      const uint32_t e = stack_e[sp][tid];
+      const T de = stack_d[sp][tid];
+      if (de >= T(0) && de >= mind) continue;  // canStop(d)
+      const uint32_t b1 = e & 0xFFFFu, b2 = e >> 16;
+      const DNode<T> n1 = bv.nodes[m1.node_off + b1];
+      const DNode<T> n2 = bv.nodes[m2.node_off + b2];
+      const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
+      if (l1 && l2) {
+        leaf(uint32_t(-(n1.first_child + 1)), uint32_t(-(n2.first_child + 1)));
+        continue;
+      }
+      uint32_t a1, a2, c1, c2;
+      if (l2 || (!l1 && (sqnorm(n1.extent) > sqnorm(n2.extent)))) {
+        a1 = uint32_t(n1.first_child);
+        a2 = b2;
+        c1 = a1 + 1;
+        c2 = b2;
+      } else {
+        a1 = b1;
+        a2 = uint32_t(n2.first_child);
+        c1 = b1;
+        c2 = a2 + 1;
+      }
+      const T d1 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + a1], bv.rss[m1.node_off + a1],
+                                   bv.nodes[m2.node_off + a2], bv.rss[m2.node_off + a2]);
+      const T d2 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + c1], bv.rss[m1.node_off + c1],
+                                   bv.nodes[m2.node_off + c2], bv.rss[m2.node_off + c2]);
+      if (sp + 2 > BVHD_STACK) {
+        overflow = true;
+        sp = 0;
+        continue;
+      }
+      const uint32_t ea = a1 | (a2 << 16), ec = c1 | (c2 << 16);
+      const bool c_first = d2 < d1;  // visit (c1,c2) first when it is strictly nearer
+      stack_e[sp][tid] = c_first ? ea : ec;
+      stack_d[sp][tid] = c_first ? d1 : d2;
+      ++sp;
+      stack_e[sp][tid] = c_first ? ec : ea;
+      stack_d[sp][tid] = c_first ? d2 : d1;
+      ++sp;
+    }
+  }
+}
+
+// =======================================================================================
+// launchers (hfcl_launch.hpp)
+// =======================================================================================
+template <typename T>
+void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2) {
+  hipLaunchKernelGGL((k_bvh_collide<T>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2);
+}
+template <typename T>
+void launch_bvh_distance(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q) {
+  hipLaunchKernelGGL((k_bvh_distance<T>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q);
+}
+template <typename T>
+void launch_bvh_shape(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2) {
+  hipLaunchKernelGGL((k_bvh_shape<T>), dim3(grid), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2);
+}
+template <typename T>
+void launch_bvh_shape_distance(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q) {
+  hipLaunchKernelGGL((k_bvh_shape_distance<T>), dim3(grid), dim3(64), 0, st, wk, lv, bv, io, q);
+}
+template <typename T>
+void launch_triangle(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {
+  hipLaunchKernelGGL((k_triangle<T>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
+}
+#define HFCL_INST(T)                                                                                                             \
+  template void launch_bvh_collide<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T); \
+  template void launch_bvh_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&);                \
+  template void launch_bvh_shape<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T);   \
+  template void launch_bvh_shape_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&);          \
+  template void launch_triangle<T>(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&);
+HFCL_INST(float)
+HFCL_INST(double)
+#undef HFCL_INST

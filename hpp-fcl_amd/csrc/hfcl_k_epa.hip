@@ -1,0 +1,247 @@
+// hfcl_k_epa.hip -- the EPA kernels: tier 1 (8 polytopes per wave in small LDS blocks; batch and streaming form)
+// and tier 2 (reference capacity, continues the polytopes tier 1 saved).
+#include "hfcl_dev.hpp"
+#include "hfcl_launch.hpp"
+
+// LARGE: hulls of more than HULL_MAX vertices may occur (scanned from memory); only the
+// full-capacity tier is built that way, so the fast tier keeps its register budget.
+template <typename T, int WE, bool LARGE>
+struct EpaSupport {  // any pair kind, evaluated by one lane group
+  DShape<T> a, b;
+  HullRegs<T, WE> h0, h1;
+  const T* va;
+  const T* vb;
+  MDiff<T> md;
+  int lig;
+  __device__ __forceinline__ V3<T> hull(const DShape<T>& s, const HullRegs<T, WE>& h, const T* v, const V3<T>& d) const {
+    if (LARGE && s.num_points > uint32_t(HULL_MAX)) return scan_support<T, WE>(v, s.num_points, d, lig);
+    return h.support(d, lig);
+  }
+  __device__ __forceinline__ void operator()(const V3<T>& dir, V3<T>& w, V3<T>& w0) const {
+    if (a.kind == K_CONVEX)
+      w0 = hull(a, h0, va, dir);
+    else
+      w0 = prim_support(a, dir);
+    const V3<T> d1 = md.identity ? -dir : -tmul(md.oR1, dir);
+    V3<T> s1;
+    if (b.kind == K_CONVEX)
+      s1 = hull(b, h1, vb, d1);
+    else
+      s1 = prim_support(b, d1);
+    s1 = md.identity ? s1 : (mul(md.oR1, s1) + md.ot1);
+    w = w0 - s1;
+  }
+};
+
+// TIER: 1 reads queue 1 and may push to queue 2; 2 reads queue 2 (never overflows: CAP = 64)
+template <typename T, int WE, int CAP, int TIER>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? (TIER == 1 ? HFCL_WPE_EPA32 : 2) : HFCL_WPE_EPA64, 8)))
+k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  constexpr int G = 64 / WE;
+  // the full-capacity tier keeps the shape-0 support points in global memory: its LDS block bounds the
+  // occupancy (fp64: 45.5 KB -> 3 waves per CU with them, 36.5 KB -> 4 without)
+  constexpr bool V0IN = TIER == 1;
+  __shared__ EpaScratch<T, CAP, V0IN> scratch[G];
+  Quad<T>* const v0_ext = V0IN ? nullptr : reinterpret_cast<Quad<T>*>(wk.epa_v0) + size_t(blockIdx.x * G + threadIdx.x / WE) * (CAP + 4);
+  const uint32_t cnt = wk.counts[TIER == 1 ? B_COUNT : B_COUNT + 1];
+  const int lane = threadIdx.x & 63, grp = lane / WE, lig = lane & (WE - 1);
+  const uint32_t groups = gridDim.x * G;
+  const EpaItem<T>* queue = reinterpret_cast<const EpaItem<T>*>(TIER == 1 ? wk.epa_queue : wk.epa_queue2);
+  for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += groups) {
+    // the seed stays in memory and is read where it is used (as a local copy it is spilled across the hull loads)
+    const EpaItem<T>& item = queue[it];
+    const uint32_t pair = item.pair;
+    EpaSupport<T, WE, TIER == 2> sup;
+    sup.a = lib.shapes[wk.shape1[pair]];
+    sup.b = lib.shapes[wk.shape2[pair]];
+    sup.lig = lig;
+    const T* va = lib.verts + 3 * size_t(sup.a.vertex_offset);
+    const T* vb = lib.verts + 3 * size_t(sup.b.vertex_offset);
+    if (TIER == 2) {
+      sup.va = va;
+      sup.vb = vb;
+    }
+    if (sup.a.kind == K_CONVEX && (TIER != 2 || sup.a.num_points <= uint32_t(HULL_MAX))) sup.h0.load(va, sup.a.num_points, lig);
+    if (sup.b.kind == K_CONVEX && (TIER != 2 || sup.b.num_points <= uint32_t(HULL_MAX))) sup.h1.load(vb, sup.b.num_points, lig);
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    sup.md = make_mdiff(tf1, tf2);
+    const T r0 = swept_radius(sup.a), r1 = swept_radius(sup.b);
+    PairOut<T> o;
+    int rc = 1;
+    if constexpr (TIER == 2) {
+      if (item.rank & EPA_RESUME_FLAG) {  // continue what the fast tier saved for this slot (the seed's rank is not used)
+        epa_resume<T, LaneGroup<WE>, epa_fast_cap<T>, CAP>(&scratch[grp], reinterpret_cast<const EpaScratch<T, epa_fast_cap<T>>*>(wk.epa_resume) + it,
+                                                         item, q, tf1, r0, r1, sup, o, v0_ext);
+      } else {
+        rc = epa_run<T, LaneGroup<WE>, CAP>(&scratch[grp], item, q, tf1, r0, r1, sup, o, v0_ext);
+      }
+      if (lig == 0) {
+        write_out<T>(io, q, pair, o);
+        write_guess<T>(io, pair, o.cached_guess, 0, 0);
+      }
+    } else {
+      rc = epa_run<T, LaneGroup<WE>, CAP>(&scratch[grp], item, q, tf1, r0, r1, sup, o);
+      if (rc == 1) {
+        if (lig == 0) {
+          write_out<T>(io, q, pair, o);
+          write_guess<T>(io, pair, o.cached_guess, 0, 0);
+        }
+      } else {  // hand over to the full-capacity tier: the seed, and the polytope itself when it can be continued
+        uint32_t slot = 0;
+        if (lig == 0) slot = atomicAdd(&wk.counts[B_COUNT + 1], 1u);
+        slot = __shfl(slot, 0, WE);
+        const bool save = rc == 2 && slot < wk.resume_cap;
+        if (save) epa_save_block<T, LaneGroup<WE>, CAP>(&scratch[grp], reinterpret_cast<EpaScratch<T, CAP>*>(wk.epa_resume) + slot);
+        if (lig == 0) {  // queue to queue, no local copy (a local EpaItem lives in scratch memory)
+          EpaItem<T>* dst = reinterpret_cast<EpaItem<T>*>(wk.epa_queue2) + slot;
+          *dst = item;
+          if (save) dst->rank = item.rank | EPA_RESUME_FLAG;
+        }
+      }
+    }
+    LaneGroup<WE>::sync();
+  }
+}
+
+// Fast tier as a stream: the 64/WE lane groups of a wave walk through the wave's share of queue 1 and a
+// group that is done does not wait for the slowest polytope of the wave (EPA runs 1 .. CAP trips per
+// polytope, mean ~7 on convex pairs: in lockstep batches of 8 only ~56 % of the trips are useful).
+// The wave alternates between two uniform phases:
+//   trip   : every group with a live polytope does one expansion step (Epa::step);
+//   refill : once at least EPA_REFILL_MIN groups are without one (or none is live), those groups write
+//            the record of the polytope they finished (or hand it over to the full-capacity tier) and
+//            start the next item of the wave: seed, hulls, encloseOrigin, first tetrahedron (Epa::begin).
+// Batching the refills matters: a refill costs about 1.5 trips of the whole wave whoever takes part.
+#ifndef HFCL_EPA_REFILL_MIN
+#define HFCL_EPA_REFILL_MIN 3
+#endif
+template <typename T, int WE, int CAP>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_EPA32, 8)))
+k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  constexpr int G = 64 / WE;
+  typedef LaneGroup<WE> Grp;
+  __shared__ EpaScratch<T, CAP> scratch[G];
+  const uint32_t cnt = wk.counts[B_COUNT];
+  const int lane = threadIdx.x & 63, grp = lane / WE, lig = lane & (WE - 1);
+  const EpaItem<T>* queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
+  enum { IDLE = 0, LIVE = 1, DONE = 2, HANDOVER = 3 };
+  int state = IDLE;
+  uint32_t it = 0;              // queue slot of this group's polytope
+  uint32_t next = blockIdx.x;   // wave-uniform: the wave's items are next, next + gridDim.x, ...
+  EpaSupport<T, WE, false> sup;
+  sup.lig = lig;
+  Epa<T, Grp, CAP> epa;
+  EpaLoop<T> L;
+  Pose<T> tf1;
+  T r0 = T(0), r1 = T(0);
+  while (true) {
+    const uint64_t live = __ballot(state == LIVE);
+    const int n_live = __popcll(live) / WE;
+    const bool more = next < cnt;
+    if (n_live == 0 || (more && G - n_live >= HFCL_EPA_REFILL_MIN)) {
+      // ---- refill phase (uniform decision; groups with a live polytope sit it out) ----
+      if (state != LIVE) {
+        if (state != IDLE) {
+          if (state == DONE) {
+            EpaResult<T> res;
+            epa.loop_result(L, r0 + r1, res);
+            PairOut<T> o;
+            epa_finish(res, queue[it].gjk_iters, tf1, r0, r1, o);
+            if (lig == 0) {
+              const uint32_t pair = queue[it].pair;
+              write_out<T>(io, q, pair, o);
+              write_guess<T>(io, pair, o.cached_guess, 0, 0);
+            }
+          } else {  // hand over to the full-capacity tier: the seed and, room permitting, the polytope itself
+            uint32_t slot = 0;
+            if (lig == 0) slot = atomicAdd(&wk.counts[B_COUNT + 1], 1u);
+            slot = __shfl(slot, 0, WE);
+            const bool save = epa.resumable && slot < wk.resume_cap;
+            if (save) epa_save_block<T, Grp, CAP>(&scratch[grp], reinterpret_cast<EpaScratch<T, CAP>*>(wk.epa_resume) + slot);
+            if (lig == 0) {  // queue to queue, no local copy (a local EpaItem lives in scratch memory)
+              EpaItem<T>* dst = reinterpret_cast<EpaItem<T>*>(wk.epa_queue2) + slot;
+              *dst = queue[it];
+              if (save) dst->rank = queue[it].rank | EPA_RESUME_FLAG;
+            }
+          }
+          Grp::sync();
+          state = IDLE;
+        }
+        // rank of this group among the groups taking part, in lane order
+        const uint64_t lower = live | ~((uint64_t(1) << (grp * WE)) - 1);  // live lanes and lanes >= mine do not count
+        const uint32_t rank = uint32_t(__popcll(~lower)) / WE;
+        it = next + rank * gridDim.x;
+        if (it < cnt) {
+          // the seed is read field by field where it is used: as one struct it would sit in registers
+          // across the hull loads and get spilled (1.6 KB of scratch traffic per polytope, measured)
+          const EpaItem<T>* ip = queue + it;
+          const uint32_t pair = ip->pair;
+          sup.a = lib.shapes[wk.shape1[pair]];
+          sup.b = lib.shapes[wk.shape2[pair]];
+          if (sup.a.kind == K_CONVEX) sup.h0.load(lib.verts + 3 * size_t(sup.a.vertex_offset), sup.a.num_points, lig);
+          if (sup.b.kind == K_CONVEX) sup.h1.load(lib.verts + 3 * size_t(sup.b.vertex_offset), sup.b.num_points, lig);
+          tf1 = load_pose(io.tf1, pair);
+          const Pose<T> tf2 = load_pose(io.tf2, pair);
+          sup.md = make_mdiff(tf1, tf2);
+          r0 = swept_radius(sup.a);
+          r1 = swept_radius(sup.b);
+          epa.reset(&scratch[grp], q.epa_max_iterations, q.epa_tolerance);
+          epa.set_vert(0, ip->w[0], ip->w0[0]);
+          epa.set_vert(1, ip->w[1], ip->w0[1]);
+          epa.set_vert(2, ip->w[2], ip->w0[2]);
+          epa.set_vert(3, ip->w[3], ip->w0[3]);
+          Grp::sync();
+          EpaResult<T> res;
+          const int closest0 = epa.begin(ip->rank, -ip->guess, sup, res);
+          if (closest0 != EPA_NULL) {
+            epa.loop_enter(L, closest0, 0, 0);
+            state = LIVE;
+          } else if (epa.overflow) {
+            state = HANDOVER;  // (a block too small for the first tetrahedron: not with CAP >= 1)
+          } else {  // FallBack: final without a loop
+            PairOut<T> o;
+            epa_finish(res, ip->gjk_iters, tf1, r0, r1, o);
+            if (lig == 0) {
+              write_out<T>(io, q, pair, o);
+              write_guess<T>(io, pair, o.cached_guess, 0, 0);
+            }
+          }
+        }
+      }
+      next += uint32_t(G - n_live) * gridDim.x;
+      if (n_live == 0 && !more) {
+        // nothing was live and nothing was left to start: only a FallBack/empty refill can have happened
+        if (__ballot(state == LIVE) == 0) break;
+      }
+      continue;
+    }
+    // ---- trip ----
+    if (state == LIVE) {
+      const int r = epa.step(L, sup);
+      if (r != 0) state = r == 1 ? DONE : HANDOVER;
+    }
+  }
+}
+
+// =======================================================================================
+// launchers (hfcl_launch.hpp)
+// =======================================================================================
+// fp32 streams (two waves per SIMD hide the refill's global loads: k_epa<fast> 1.87 -> 1.76 ms on cfg3);
+// fp64 runs one wave per SIMD, where the more frequent refills cost more than the idle groups (cfg5
+// 1.27 -> 1.55 ms), and stays with the batch form
+template <typename T>
+void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {
+  if constexpr (sizeof(T) == 4)
+    hipLaunchKernelGGL((k_epa_stream<T, EPA_WE, EPA_FAST_CAP>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
+  else
+    hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_fast_cap<T>, 1>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
+}
+template void launch_epa_fast<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&);
+template void launch_epa_fast<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&);
+
+template <typename T>
+void launch_epa_full(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {
+  hipLaunchKernelGGL((k_epa<T, EPA_WE2, EPA_MAX_ITER, 2>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
+}
+template void launch_epa_full<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&);
+template void launch_epa_full<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&);

@@ -1,0 +1,418 @@
+// hfcl_k_gjk.hip -- classification, closed forms and the GJK kernels (see hfcl_launch.hpp for the kernel map).
+#include "hfcl_dev.hpp"
+#include "hfcl_launch.hpp"
+
+// ---------------------------------------------------------------------------------------
+// k_classify: bucket every pair by (kind1, kind2).  Wave-aggregated list append.
+// ---------------------------------------------------------------------------------------
+// One global atomic per (block trip, bucket) reserves the block's range in the bucket list: these same-address
+// atomics serialise (~20 ns each), so the trips are made large -- 1024 threads x 8 pairs (4M pairs: 39 us at
+// 2048 pairs per trip).
+__global__ void __launch_bounds__(CLS_BLOCK) k_classify(Work wk, const uint8_t* kinds, uint32_t n_shapes, bool distance_mode) {
+  // Each block handles CHUNK consecutive pairs per trip: per-bucket counts are built in LDS, one
+  // global atomic per (block, bucket) reserves a range, then every lane writes its pair index.
+  constexpr int PER_THREAD = 8;
+  constexpr uint32_t CHUNK = CLS_BLOCK * PER_THREAD;
+  __shared__ uint32_t s_count[B_COUNT];
+  __shared__ uint32_t s_base[B_COUNT];
+  for (uint32_t start = blockIdx.x * CHUNK; start < wk.n; start += gridDim.x * CHUNK) {
+    if (threadIdx.x < B_COUNT) s_count[threadIdx.x] = 0;
+    __syncthreads();
+    int bk[PER_THREAD];
+    uint32_t rk[PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+      const uint32_t i = start + k * CLS_BLOCK + threadIdx.x;
+      bk[k] = -1;
+      rk[k] = 0;
+      if (i < wk.n) {
+        const uint32_t s1 = wk.shape1[i], s2 = wk.shape2[i];
+        bk[k] = (s1 < n_shapes && s2 < n_shapes) ? bucket_of(kinds[s1], kinds[s2], distance_mode) : B_UNSUPPORTED;
+      }
+      // wave-aggregated LDS counter update: one trip per bucket present in the wave (one for a homogeneous batch)
+      unsigned long long todo = __ballot(bk[k] >= 0);
+      const int lane = threadIdx.x & 63;
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int c = __shfl(bk[k], leader, 64);
+        const unsigned long long m = __ballot(bk[k] == c);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&s_count[c], (uint32_t)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (bk[k] == c) rk[k] = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < B_COUNT) {
+      const uint32_t c = s_count[threadIdx.x];
+      s_base[threadIdx.x] = c ? atomicAdd(&wk.counts[threadIdx.x], c) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+      if (bk[k] >= 0) wk.lists[size_t(bk[k]) * wk.n + s_base[bk[k]] + rk[k]] = start + k * CLS_BLOCK + threadIdx.x;
+    }
+    __syncthreads();
+  }
+}
+
+// pairs the engine cannot evaluate: flagged, never silently computed elsewhere
+template <typename T>
+__global__ void __launch_bounds__(256) k_unsupported(Work wk, IO<T> io, int bucket) {
+  const uint32_t cnt = wk.counts[bucket];
+  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
+    const uint32_t pair = wk.lists[size_t(bucket) * wk.n + it];
+    auto r = io.out[pair];
+    memset(&r, 0, sizeof(r));
+    r.status = 0x80000000u;
+    io.out[pair] = r;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_closed: closed-form pairs, one pair per lane.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_closed(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  const uint32_t cnt = wk.counts[B_CLOSED];
+  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
+    const uint32_t pair = wk.lists[size_t(B_CLOSED) * wk.n + it];
+    const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    PairOut<T> o;
+    o.distance = closed_form_distance(a, tf1, b, tf2, lib.verts, o.p1, o.p2, o.normal);
+    o.gjk_status = GJK_DID_NOT_RUN;
+    o.epa_status = EPA_DID_NOT_RUN;
+    o.gjk_iters = o.epa_iters = 0;
+    write_out<T>(io, q, pair, o);
+    // the closed forms never touch the solver's cached guess: it stays at its initial value
+    write_guess<T>(io, pair, initial_guess<T>(io, q, pair), 0, 0);
+  }
+}
+
+// fp64 form with the poses and records staged through LDS: a lane's own 96-byte pose / record is six 16-byte
+// pieces 96 bytes apart from its neighbour's, which the memory system only turns into full-line traffic through
+// cache merging (non-temporal accesses: 2.5x slower, profiles/); here the block's 256 poses are fetched as
+// 1536 consecutive 16-byte pieces (lane-contiguous when the bucket list is in input order, as it is up to the
+// interleaving of blocks in k_classify), handed over in LDS, and the records leave the same way.
+typedef double hfcl_d2 __attribute__((ext_vector_type(2)));
+#ifndef HFCL_WPE_CLOSED
+#define HFCL_WPE_CLOSED 2
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_CLOSED, 8))) k_closed_staged(Work wk, LibView<double> lib, IO<double> io, QParams<double> q) {
+  constexpr int NB = 256, PIECES = 6;  // 96 B = 6 x 16 B
+  __shared__ uint32_t s_pair[NB];
+  __shared__ hfcl_d2 s_a[NB * PIECES];  // poses of shape 1, later the records
+  __shared__ hfcl_d2 s_b[NB * PIECES];  // poses of shape 2
+  static_assert(sizeof(hfcl_result) == 96, "record = 6 pieces");
+  const uint32_t cnt = wk.counts[B_CLOSED];
+  const uint32_t t = threadIdx.x;
+  for (uint32_t base = blockIdx.x * NB; base < cnt; base += gridDim.x * NB) {
+    const uint32_t nvalid = min(uint32_t(NB), cnt - base);
+    s_pair[t] = wk.lists[size_t(B_CLOSED) * wk.n + base + (t < nvalid ? t : 0u)];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      const uint32_t c = t + NB * j, p = c / PIECES, part = c % PIECES;
+      const size_t pr = s_pair[p];
+      s_a[c] = reinterpret_cast<const hfcl_d2*>(io.tf1 + 12 * pr)[part];
+      s_b[c] = reinterpret_cast<const hfcl_d2*>(io.tf2 + 12 * pr)[part];
+    }
+    const uint32_t pair = s_pair[t];
+    const DShape<double> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+    __syncthreads();
+    const Pose<double> tf1 = pose_from_abi<double>(reinterpret_cast<const double*>(s_a + PIECES * t));
+    const Pose<double> tf2 = pose_from_abi<double>(reinterpret_cast<const double*>(s_b + PIECES * t));
+    PairOut<double> o;
+    o.distance = closed_form_distance(a, tf1, b, tf2, lib.verts, o.p1, o.p2, o.normal);
+    o.gjk_status = GJK_DID_NOT_RUN;
+    o.epa_status = EPA_DID_NOT_RUN;
+    o.gjk_iters = o.epa_iters = 0;
+    __syncthreads();  // every pose has been read: s_a becomes the record buffer
+    IO<double> lio = io;
+    lio.out = reinterpret_cast<hfcl_result*>(s_a);
+    write_out<double>(lio, q, t, o);
+    if (t < nvalid) write_guess<double>(io, pair, initial_guess<double>(io, q, pair), 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      const uint32_t c = t + NB * j, p = c / PIECES, part = c % PIECES;
+      if (p < nvalid) reinterpret_cast<hfcl_d2*>(io.out + s_pair[p])[part] = s_a[c];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Shared GJK epilogue: final record, or hand-off to k_epa through the device queue.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void finish_gjk(const Gjk<T, PW0<T>>& g, const Work& wk, const IO<T>& io, const QParams<T>& q,
+                                           uint32_t pair, const Pose<T>& tf1, T r0, T r1, const V3<T>& guess0,
+                                           bool writer, bool full_tier = false) {
+  PairOut<T> o;
+  EpaSeed<T> seed;
+  const bool to_epa = gjk_finish(g, q, tf1, r0, r1, guess0, o, seed);
+  if (!writer) return;
+  if (to_epa) {
+    // full_tier: straight to the full-capacity EPA queue (pairs with a large hull: only that tier
+    // can scan vertices from memory)
+    const uint32_t slot = atomicAdd(&wk.counts[full_tier ? B_COUNT + 1 : B_COUNT], 1u);
+    seed.pair = pair;
+    reinterpret_cast<EpaSeed<T>*>(full_tier ? wk.epa_queue2 : wk.epa_queue)[slot] = seed;
+  } else {
+    write_out<T>(io, q, pair, o);
+    write_guess<T>(io, pair, o.cached_guess, 0, 0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_gjk_prim: primitive x primitive GJK, one pair per lane.
+// ---------------------------------------------------------------------------------------
+// BVG: GJKInitialGuess::BoundingVolumeGuess.  A separate instantiation on purpose: the register allocation of the GJK
+// kernels is sensitive to anything live across their loop (the run-time form of this one select cost k_gjk_cvx<2,0>
+// 0.96 -> 1.51 ms), so the default-guess kernels are compiled without it.
+template <typename T, bool BVG>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_PRIM, 8))) k_gjk_prim(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  const uint32_t cnt = wk.counts[B_PRIM];
+  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
+    const uint32_t pair = wk.lists[size_t(B_PRIM) * wk.n + it];
+    const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    SerialSupport<T> sup;
+    sup.a = a;
+    sup.b = b;
+    sup.va = sup.vb = nullptr;
+    sup.md = make_mdiff(tf1, tf2);
+    const T r0 = swept_radius(a), r1 = swept_radius(b);
+    const V3<T> guess0 = initial_guess<T>(io, q, pair);
+    Gjk<T, PW0<T>> g;
+    if constexpr (BVG)
+      gjk_run(g, q.gjk, start_guess(q, a, b, sup.md, guess0), r0 + r1, false, sup);
+    else
+      gjk_run(g, q.gjk, guess0, r0 + r1, false, sup);
+    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, true);
+  }
+}
+// M: 0 = convex-convex, 1 = prim-convex, 2 = convex-prim
+template <typename T, int W, int M>
+struct CvxSupport {
+  DShape<T> a, b;
+  HullRegs<T, W> h0, h1;
+  MDiff<T> md;
+  int lig;
+  __device__ __forceinline__ void eval(const V3<T>& dir, V3<T>& w, V3<T>& w0) const {
+    if (M == 1)
+      w0 = prim_support(a, dir);
+    else
+      w0 = h0.support(dir, lig);
+    const V3<T> d1 = md.identity ? -dir : -tmul(md.oR1, dir);
+    V3<T> s1;
+    if (M == 2)
+      s1 = prim_support(b, d1);
+    else
+      s1 = h1.support(d1, lig);
+    s1 = md.identity ? s1 : (mul(md.oR1, s1) + md.ot1);
+    w = w0 - s1;
+  }
+  __device__ __forceinline__ void operator()(const V3<T>& dir, V3<T>& w, V3<T>& w0) const { eval(dir, w, w0); }
+};
+
+template <typename T, int W, int M, bool BVG>
+__device__ __forceinline__ void gjk_cvx_body(const Work& wk, const LibView<T>& lib, const IO<T>& io, const QParams<T>& q) {
+  constexpr int BUCKET = (M == 0) ? B_CC : (M == 1 ? B_PC : B_CP);
+  const uint32_t cnt = wk.counts[BUCKET];
+  const int lig = threadIdx.x & (W - 1);
+  const uint32_t groups = (gridDim.x * blockDim.x) / W;
+  for (uint32_t it = (blockIdx.x * blockDim.x + threadIdx.x) / W; it < cnt; it += groups) {
+    const uint32_t pair = wk.lists[size_t(BUCKET) * wk.n + it];
+    CvxSupport<T, W, M> sup;
+    sup.a = lib.shapes[wk.shape1[pair]];
+    sup.b = lib.shapes[wk.shape2[pair]];
+    sup.lig = lig;
+    if (M != 1) sup.h0.load(lib.verts + 3 * size_t(sup.a.vertex_offset), sup.a.num_points, lig);
+    if (M != 2) sup.h1.load(lib.verts + 3 * size_t(sup.b.vertex_offset), sup.b.num_points, lig);
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    sup.md = make_mdiff(tf1, tf2);
+    const T r0 = swept_radius(sup.a), r1 = swept_radius(sup.b);
+    const V3<T> guess0 = initial_guess<T>(io, q, pair);
+    Gjk<T, PW0<T>> g;
+    // normalize_support_direction only when both are ConvexBase (minkowski_difference.cpp:261-266)
+    if constexpr (BVG)
+      gjk_run(g, q.gjk, start_guess(q, sup.a, sup.b, sup.md, guess0), r0 + r1, M == 0, sup);
+    else
+      gjk_run(g, q.gjk, guess0, r0 + r1, M == 0, sup);
+    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0);
+  }
+}
+
+// Two entry points so that each precision gets its own register budget (waves per SIMD): the fp64
+// instantiation spills heavily at the fp32 setting (A/B in profiles/).
+template <int W, int M, bool BVG>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W == 2 ? HFCL_WPE_GJK_W2 : HFCL_WPE_GJK, 8)))
+k_gjk_cvx(Work wk, LibView<float> lib, IO<float> io, QParams<float> q) {
+  gjk_cvx_body<float, W, M, BVG>(wk, lib, io, q);
+}
+template <int W, int M, bool BVG>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_GJK64, 8)))
+k_gjk_cvx64(Work wk, LibView<double> lib, IO<double> io, QParams<double> q) {
+  gjk_cvx_body<double, W, M, BVG>(wk, lib, io, q);
+}
+template <int W, int M, bool BVG = false>
+static void launch_gjk_cvx(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q) {
+  hipLaunchKernelGGL((k_gjk_cvx<W, M, BVG>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+}
+template <int W, int M, bool BVG = false>
+static void launch_gjk_cvx(int grid, hipStream_t st, const Work& wk, const LibView<double>& lv, const IO<double>& io, const QParams<double>& q) {
+  hipLaunchKernelGGL((k_gjk_cvx64<W, M, BVG>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+}
+template <typename T>
+struct LargeSupport {
+  DShape<T> a, b;
+  const T* va;
+  const T* vb;
+  MDiff<T> md;
+  int lig;
+  __device__ __forceinline__ V3<T> one(const DShape<T>& s, const T* v, const V3<T>& d) const {
+    return s.kind == K_CONVEX ? scan_support<T, LARGE_W>(v, s.num_points, d, lig) : prim_support(s, d);
+  }
+  __device__ __forceinline__ void operator()(const V3<T>& dir, V3<T>& w, V3<T>& w0) const {
+    w0 = one(a, va, dir);
+    const V3<T> d1 = md.identity ? -dir : -tmul(md.oR1, dir);
+    V3<T> s1 = one(b, vb, d1);
+    s1 = md.identity ? s1 : (mul(md.oR1, s1) + md.ot1);
+    w = w0 - s1;
+  }
+};
+
+template <typename T, bool BVG>
+__global__ void __launch_bounds__(256) k_gjk_large(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  const uint32_t cnt = wk.counts[B_LARGE];
+  const int lig = threadIdx.x & (LARGE_W - 1);
+  const uint32_t groups = (gridDim.x * blockDim.x) / LARGE_W;
+  for (uint32_t it = (blockIdx.x * blockDim.x + threadIdx.x) / LARGE_W; it < cnt; it += groups) {
+    const uint32_t pair = wk.lists[size_t(B_LARGE) * wk.n + it];
+    LargeSupport<T> sup;
+    sup.a = lib.shapes[wk.shape1[pair]];
+    sup.b = lib.shapes[wk.shape2[pair]];
+    sup.va = lib.verts + 3 * size_t(sup.a.vertex_offset);
+    sup.vb = lib.verts + 3 * size_t(sup.b.vertex_offset);
+    sup.lig = lig;
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    sup.md = make_mdiff(tf1, tf2);
+    const T r0 = swept_radius(sup.a), r1 = swept_radius(sup.b);
+    const V3<T> guess0 = initial_guess<T>(io, q, pair);
+    Gjk<T, PW0<T>> g;
+    if constexpr (BVG)
+      gjk_run(g, q.gjk, start_guess(q, sup.a, sup.b, sup.md, guess0), r0 + r1, sup.a.kind == K_CONVEX && sup.b.kind == K_CONVEX, sup);
+    else
+      gjk_run(g, q.gjk, guess0, r0 + r1, sup.a.kind == K_CONVEX && sup.b.kind == K_CONVEX, sup);
+    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0, true);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// -inf security margin: cleared results, nothing computed (src/collision.cpp:73-76)
+// ---------------------------------------------------------------------------------------
+template <typename R>
+__global__ void k_fill_skipped(R* out, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    R r;
+    memset(&r, 0, sizeof(r));
+    r.distance = 3.402823466e+38f;
+    r.status = 0x80000000u;
+    out[i] = r;
+  }
+}
+template <>
+__global__ void k_fill_skipped<hfcl_result>(hfcl_result* out, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    hfcl_result r;
+    const double x = __builtin_nan("");
+    r.distance = 1.7976931348623157e+308;
+    for (int k = 0; k < 3; ++k) r.normal[k] = r.p1[k] = r.p2[k] = x;
+    r.b1 = r.b2 = -1;
+    r.status = 0x80000000u;
+    r.num_contacts = 0;
+    out[i] = r;
+  }
+}
+
+// =======================================================================================
+// launchers (hfcl_launch.hpp)
+// =======================================================================================
+void launch_classify(int grid, hipStream_t st, const Work& wk, const uint8_t* kinds, uint32_t n_shapes, bool distance_mode) {
+  hipLaunchKernelGGL(k_classify, dim3(grid), dim3(CLS_BLOCK), 0, st, wk, kinds, n_shapes, distance_mode);
+}
+template <typename T>
+void launch_unsupported(int grid, hipStream_t st, const Work& wk, const IO<T>& io, int bucket) {
+  hipLaunchKernelGGL((k_unsupported<T>), dim3(grid), dim3(256), 0, st, wk, io, bucket);
+}
+template void launch_unsupported<float>(int, hipStream_t, const Work&, const IO<float>&, int);
+template void launch_unsupported<double>(int, hipStream_t, const Work&, const IO<double>&, int);
+
+template <typename T>
+void launch_closed(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool staged) {
+  if constexpr (sizeof(T) == 8) {
+    if (staged) {
+      hipLaunchKernelGGL(k_closed_staged, dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_closed<T>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+}
+template void launch_closed<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&, bool);
+template void launch_closed<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&, bool);
+
+template <typename T>
+void launch_gjk_prim(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool bvg) {
+  if (bvg)
+    hipLaunchKernelGGL((k_gjk_prim<T, true>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+  else
+    hipLaunchKernelGGL((k_gjk_prim<T, false>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+}
+template void launch_gjk_prim<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&, bool);
+template void launch_gjk_prim<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&, bool);
+
+template <typename T, int M>
+static void launch_gjk_cvx_m(int w, bool bvg, int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {
+  if (bvg) {  // instantiated for the widths in use only
+    if (w == 2) launch_gjk_cvx<2, M, true>(grid, st, wk, lv, io, q);
+    else launch_gjk_cvx<4, M, true>(grid, st, wk, lv, io, q);
+    return;
+  }
+  switch (w) {
+    case 2: launch_gjk_cvx<2, M>(grid, st, wk, lv, io, q); break;
+    case 8: launch_gjk_cvx<8, M>(grid, st, wk, lv, io, q); break;
+    case 16: launch_gjk_cvx<16, M>(grid, st, wk, lv, io, q); break;
+    case 32: launch_gjk_cvx<32, M>(grid, st, wk, lv, io, q); break;
+    case 64: launch_gjk_cvx<64, M>(grid, st, wk, lv, io, q); break;
+    default: launch_gjk_cvx<4, M>(grid, st, wk, lv, io, q); break;
+  }
+}
+template <typename T>
+void launch_gjk_cvx(int m, int w, bool bvg, int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {
+  if (m == 0) launch_gjk_cvx_m<T, 0>(w, bvg, grid, st, wk, lv, io, q);
+  else if (m == 1) launch_gjk_cvx_m<T, 1>(w, bvg, grid, st, wk, lv, io, q);
+  else launch_gjk_cvx_m<T, 2>(w, bvg, grid, st, wk, lv, io, q);
+}
+template void launch_gjk_cvx<float>(int, int, bool, int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&);
+template void launch_gjk_cvx<double>(int, int, bool, int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&);
+
+template <typename T>
+void launch_gjk_large(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool bvg) {
+  if (bvg)
+    hipLaunchKernelGGL((k_gjk_large<T, true>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+  else
+    hipLaunchKernelGGL((k_gjk_large<T, false>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+}
+template void launch_gjk_large<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&, bool);
+template void launch_gjk_large<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&, bool);
+
+void launch_fill_skipped(hipStream_t st, hfcl_result* out, uint32_t n) {
+  hipLaunchKernelGGL((k_fill_skipped<hfcl_result>), dim3(1024), dim3(256), 0, st, out, n);
+}
+void launch_fill_skipped(hipStream_t st, hfcl_result_f32* out, uint32_t n) {
+  hipLaunchKernelGGL((k_fill_skipped<hfcl_result_f32>), dim3(1024), dim3(256), 0, st, out, n);
+}

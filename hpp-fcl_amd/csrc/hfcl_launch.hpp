@@ -1,0 +1,39 @@
+// hfcl_launch.hpp -- host-callable launchers of the HIP kernels.  One translation unit per kernel family, so that a
+// change to one kernel recompiles in parallel with nothing else and A/B builds of a single family are cheap:
+//
+//   hfcl_k_gjk.hip   k_classify       pair -> bucket lists (block-aggregated atomics), one pass over the shape ids
+//                    k_closed<T>      closed forms (sphere / capsule / cylinder / box-sphere pairs, every Plane /
+//                                     Halfspace row), one pair per lane (fp64: poses / records staged through LDS)
+//                    k_gjk_prim<T>    GJK for Box/Capsule/Cone/Cylinder/Ellipsoid/Sphere pairs, one pair per lane
+//                    k_gjk_cvx<W,M>   GJK with hulls of <= 32 vertices: one pair per W-lane group, hull vertices in the
+//                                     group's registers, support = per-lane dots + DPP-butterfly arg-max
+//                    k_gjk_large<T>   GJK when a hull has more than 32 vertices (scan / hill-climb from memory)
+//                    k_unsupported<T>, k_fill_skipped
+//   hfcl_k_epa.hip   k_epa<T,WE,CAP,TIER>, k_epa_stream<T,WE,CAP>   EPA on the pairs GJK left in `Collision`
+//   hfcl_k_bvh.hip   k_bvh_collide<T> / k_bvh_distance<T>   BVHModel<OBBRSS> x BVHModel<OBBRSS>
+//                    k_bvh_shape<T> / k_bvh_shape_distance<T>   BVHModel<OBBRSS> x convex solid or Plane/Halfspace
+//                    k_triangle<T>    top-level TriangleP pairs
+//
+// Every launcher is asynchronous on `st` and does no error checking of its own (run_batch_one checks hipGetLastError once).
+#pragma once
+#include "hfcl_dev.hpp"
+
+void launch_classify(int grid, hipStream_t st, const Work& wk, const uint8_t* kinds, uint32_t n_shapes, bool distance_mode);
+template <typename T> void launch_unsupported(int grid, hipStream_t st, const Work& wk, const IO<T>& io, int bucket);
+template <typename T> void launch_closed(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool staged);
+template <typename T> void launch_gjk_prim(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool bvg);
+// m: 0 = convex-convex, 1 = prim-convex, 2 = convex-prim; w: lanes per pair (2 / 4 / 8 / 16 / 32 / 64)
+template <typename T> void launch_gjk_cvx(int m, int w, bool bvg, int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q);
+template <typename T> void launch_gjk_large(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool bvg);
+void launch_fill_skipped(hipStream_t st, hfcl_result* out, uint32_t n);
+void launch_fill_skipped(hipStream_t st, hfcl_result_f32* out, uint32_t n);
+
+// tier 1 (fp32: streaming form) and tier 2 of EPA; the grids are in blocks of one wavefront
+template <typename T> void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q);
+template <typename T> void launch_epa_full(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q);
+
+template <typename T> void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2);
+template <typename T> void launch_bvh_distance(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q);
+template <typename T> void launch_bvh_shape(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2);
+template <typename T> void launch_bvh_shape_distance(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q);
+template <typename T> void launch_triangle(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q);

@@ -33,7 +33,7 @@ class EngineError(RuntimeError):
 
 def build_native(verbose=False):
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", _CSRC]
+    cmd = ["make", "-j8", "-C", _CSRC]
     if not verbose:
         cmd.insert(1, "-s")
     subprocess.check_call(cmd)

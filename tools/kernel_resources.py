@@ -1,16 +1,22 @@
 #!/usr/bin/env python
 """Compact per-kernel resource table (VGPR / AGPR / scratch / LDS / occupancy) from hipcc's
--Rpass-analysis=kernel-resource-usage.  usage: tools/kernel_resources.py [extra hipcc flags]"""
+-Rpass-analysis=kernel-resource-usage.
+usage: tools/kernel_resources.py [gjk|epa|bvh ...] [extra hipcc flags]   (default: all three kernel translation units)"""
 import os
 import re
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "hpp-fcl_amd", "csrc", "hfcl_kernels.hip")
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-value", "-Wno-pass-failed",
-       "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", src] + sys.argv[1:]
-err = subprocess.run(cmd, capture_output=True, text=True).stderr
+units = [a for a in sys.argv[1:] if a in ("gjk", "epa", "bvh")] or ["gjk", "epa", "bvh"]
+flags = [a for a in sys.argv[1:] if a not in ("gjk", "epa", "bvh")]
+procs = []
+for u in units:  # the translation units compile side by side
+    src = os.path.join(ROOT, "hpp-fcl_amd", "csrc", "hfcl_k_%s.hip" % u)
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-value", "-Wno-pass-failed",
+           "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", src] + flags
+    procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+err = "".join(p.communicate()[1] for p in procs)
 rows, cur = [], {}
 for line in err.splitlines():
     m = re.search(r"remark: (?:\s*)([A-Za-z \[\]/]+): (.+?) \[-Rpass", line)
