@@ -407,3 +407,40 @@ constexpr int BS_W = 16;         // lanes per query in k_bvh_shape / k_bvh_shape
 constexpr int BS_STACK = 128;
 constexpr int BVHD_STACK = 64;
 constexpr int BVHD_BLOCK = 64;   // k_bvh_distance
+
+// ---------------------------------------------------------------------------------------
+// Witness payload of the GJK simplex parked in LDS (policy of gjk_run / gjk_finish, hfcl_pair.hpp).  The support
+// point on shape 0 of each simplex vertex is only read after the loop, but as a register payload it is 12 VGPRs
+// (24 in fp64) that every simplex shift / Voronoi-region select drags along -- state the register allocator ends up
+// spilling to scratch memory, i.e. through L2 to HBM.  Here a vertex carries a 2-bit slot number instead and the
+// point sits in a per-lane LDS slab (slot-major, lane-minor: conflict-free); a new vertex takes the slot no live
+// vertex uses (at most 3 are live when one is appended).
+// ---------------------------------------------------------------------------------------
+struct PSlot {
+  uint32_t s;
+};
+__device__ __forceinline__ PSlot psel(bool c, const PSlot& a, const PSlot& b) { return PSlot{c ? a.s : b.s}; }
+template <typename T, int NT>
+struct W0Lds {
+  typedef PSlot P;
+  static constexpr int WORDS = 4 * 3 * NT;  // slab size in T
+  T* lane;                                   // &slab[threadIdx.x]
+  template <class G>
+  __device__ __forceinline__ P put(const G& g, const V3<T>& w0) const {
+    uint32_t used = g.rank > 0 ? 1u << (g.s0.p.s & 3u) : 0u;
+    used |= g.rank > 1 ? 1u << (g.s1.p.s & 3u) : 0u;
+    used |= g.rank > 2 ? 1u << (g.s2.p.s & 3u) : 0u;
+    const uint32_t s = uint32_t(__builtin_ctz(~used)) & 3u;
+    lane[(3 * s + 0) * NT] = w0.x;
+    lane[(3 * s + 1) * NT] = w0.y;
+    lane[(3 * s + 2) * NT] = w0.z;
+    return P{s};
+  }
+  __device__ __forceinline__ V3<T> get(const P& p) const {
+    const uint32_t s = p.s & 3u;
+    return mk<T>(lane[(3 * s + 0) * NT], lane[(3 * s + 1) * NT], lane[(3 * s + 2) * NT]);
+  }
+};
+#ifndef HFCL_GJK_W0_LDS
+#define HFCL_GJK_W0_LDS 1
+#endif

@@ -147,13 +147,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_W
 // ---------------------------------------------------------------------------------------
 // Shared GJK epilogue: final record, or hand-off to k_epa through the device queue.
 // ---------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void finish_gjk(const Gjk<T, PW0<T>>& g, const Work& wk, const IO<T>& io, const QParams<T>& q,
+template <typename T, class P, class PS>
+__device__ __forceinline__ void finish_gjk(const Gjk<T, P>& g, const Work& wk, const IO<T>& io, const QParams<T>& q,
                                            uint32_t pair, const Pose<T>& tf1, T r0, T r1, const V3<T>& guess0,
-                                           bool writer, bool full_tier = false) {
+                                           bool writer, const PS& ps, bool full_tier = false) {
   PairOut<T> o;
   EpaSeed<T> seed;
-  const bool to_epa = gjk_finish(g, q, tf1, r0, r1, guess0, o, seed);
+  const bool to_epa = gjk_finish(g, q, tf1, r0, r1, guess0, o, seed, ps);
   if (!writer) return;
   if (to_epa) {
     // full_tier: straight to the full-capacity EPA queue (pairs with a large hull: only that tier
@@ -167,6 +167,18 @@ __device__ __forceinline__ void finish_gjk(const Gjk<T, PW0<T>>& g, const Work& 
   }
 }
 
+// The simplex payload policy of a GJK kernel with NT threads per block (HFCL_GJK_W0_LDS=0: A/B switch back to
+// register payloads).
+#if HFCL_GJK_W0_LDS
+template <typename T, int NT> using GjkW0 = W0Lds<T, NT>;
+#define HFCL_GJK_W0_SLAB(T, NT, name)          \
+  __shared__ T name##_slab[W0Lds<T, NT>::WORDS]; \
+  const W0Lds<T, NT> name{name##_slab + threadIdx.x}
+#else
+template <typename T, int NT> using GjkW0 = W0Regs<T>;
+#define HFCL_GJK_W0_SLAB(T, NT, name) const W0Regs<T> name = W0Regs<T>()
+#endif
+
 // ---------------------------------------------------------------------------------------
 // k_gjk_prim: primitive x primitive GJK, one pair per lane.
 // ---------------------------------------------------------------------------------------
@@ -175,6 +187,7 @@ __device__ __forceinline__ void finish_gjk(const Gjk<T, PW0<T>>& g, const Work& 
 // 0.96 -> 1.51 ms), so the default-guess kernels are compiled without it.
 template <typename T, bool BVG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_PRIM, 8))) k_gjk_prim(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  HFCL_GJK_W0_SLAB(T, 256, ps);
   const uint32_t cnt = wk.counts[B_PRIM];
   for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
     const uint32_t pair = wk.lists[size_t(B_PRIM) * wk.n + it];
@@ -187,19 +200,74 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_W
     sup.md = make_mdiff(tf1, tf2);
     const T r0 = swept_radius(a), r1 = swept_radius(b);
     const V3<T> guess0 = initial_guess<T>(io, q, pair);
-    Gjk<T, PW0<T>> g;
+    Gjk<T, typename GjkW0<T, 256>::P> g;
     if constexpr (BVG)
-      gjk_run(g, q.gjk, start_guess(q, a, b, sup.md, guess0), r0 + r1, false, sup);
+      gjk_run(g, q.gjk, start_guess(q, a, b, sup.md, guess0), r0 + r1, false, sup, ps);
     else
-      gjk_run(g, q.gjk, guess0, r0 + r1, false, sup);
-    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, true);
+      gjk_run(g, q.gjk, guess0, r0 + r1, false, sup, ps);
+    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, true, ps);
   }
 }
+// Hull of a W-lane group held in LDS instead of registers: element (vertex k, component c) of thread t at
+// base[(3 * k + c) * NT + t] (lane-minor: conflict-free).  Two register-resident hulls of 16 vertices per lane are
+// 96 VGPRs, which together with the simplex does not fit: the allocator then spills hull vertices to scratch memory
+// and reloads them one by one, each behind an s_waitcnt vmcnt(0), inside the support scan of every GJK trip
+// (13 serialised scratch loads per trip in k_gjk_cvx<2,0>).  With the second hull in LDS the scan issues
+// its reads back to back, the winner's coordinates are one indexed LDS read instead of a select chain, and nothing
+// is spilled.
+template <typename T, int W, int NT>
+struct HullLds {
+  static constexpr int VPL = (HULL_MAX + W - 1) / W;
+  static constexpr int WORDS = VPL * 3 * NT;
+  T* lane;  // &slab[threadIdx.x]
+  __device__ __forceinline__ void load(const T* verts, uint32_t n, int lig) {
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      uint32_t idx = uint32_t(lig * VPL + k);
+      idx = idx < n ? idx : 0u;  // padding duplicates vertex 0 (never wins the first-index tie-break)
+      const T* p = verts + 3 * size_t(idx);
+      lane[(3 * k + 0) * NT] = p[0];
+      lane[(3 * k + 1) * NT] = p[1];
+      lane[(3 * k + 2) * NT] = p[2];
+    }
+  }
+  __device__ __forceinline__ V3<T> support(const V3<T>& dir, int lig) const {
+    T best = lane[0] * dir.x + lane[NT] * dir.y + lane[2 * NT] * dir.z;
+    int bi = lig * VPL;
+#pragma unroll
+    for (int k = 1; k < VPL; ++k) {
+      const T d = lane[(3 * k + 0) * NT] * dir.x + lane[(3 * k + 1) * NT] * dir.y + lane[(3 * k + 2) * NT] * dir.z;
+      if (d > best) {
+        best = d;
+        bi = lig * VPL + k;
+      }
+    }
+    butterfly_stages<W>([&](auto stage) {
+      constexpr int M = decltype(stage)::value;
+      const T od = group_exchange<W, M>(best);
+      const int oi = group_exchange<W, M>(bi);
+      if (od > best || (od == best && oi < bi)) {
+        best = od;
+        bi = oi;
+      }
+    });
+    const int owner = bi / VPL, slot = bi % VPL;
+    const T cx = lane[(3 * slot + 0) * NT], cy = lane[(3 * slot + 1) * NT], cz = lane[(3 * slot + 2) * NT];
+    return mk<T>(__shfl(cx, owner, W), __shfl(cy, owner, W), __shfl(cz, owner, W));
+  }
+};
+#ifndef HFCL_GJK_HULLB_LDS
+#define HFCL_GJK_HULLB_LDS 1
+#endif
+// the second hull of a convex-convex pair lives in LDS where the block's slab fits (2- and 4-lane groups)
+template <typename T, int W, int M> constexpr bool hull_b_in_lds = HFCL_GJK_HULLB_LDS && M == 0 && W <= 4 && (HULL_MAX / W) * sizeof(T) <= 64;
+
 // M: 0 = convex-convex, 1 = prim-convex, 2 = convex-prim
 template <typename T, int W, int M>
 struct CvxSupport {
   DShape<T> a, b;
-  HullRegs<T, W> h0, h1;
+  HullRegs<T, W> h0;
+  typename std::conditional<hull_b_in_lds<T, W, M>, HullLds<T, W, 256>, HullRegs<T, W>>::type h1;
   MDiff<T> md;
   int lig;
   __device__ __forceinline__ void eval(const V3<T>& dir, V3<T>& w, V3<T>& w0) const {
@@ -222,12 +290,15 @@ struct CvxSupport {
 template <typename T, int W, int M, bool BVG>
 __device__ __forceinline__ void gjk_cvx_body(const Work& wk, const LibView<T>& lib, const IO<T>& io, const QParams<T>& q) {
   constexpr int BUCKET = (M == 0) ? B_CC : (M == 1 ? B_PC : B_CP);
+  HFCL_GJK_W0_SLAB(T, 256, ps);
+  __shared__ T hull_slab[hull_b_in_lds<T, W, M> ? HullLds<T, W, 256>::WORDS : 1];
   const uint32_t cnt = wk.counts[BUCKET];
   const int lig = threadIdx.x & (W - 1);
   const uint32_t groups = (gridDim.x * blockDim.x) / W;
   for (uint32_t it = (blockIdx.x * blockDim.x + threadIdx.x) / W; it < cnt; it += groups) {
     const uint32_t pair = wk.lists[size_t(BUCKET) * wk.n + it];
     CvxSupport<T, W, M> sup;
+    if constexpr (hull_b_in_lds<T, W, M>) sup.h1.lane = hull_slab + threadIdx.x;
     sup.a = lib.shapes[wk.shape1[pair]];
     sup.b = lib.shapes[wk.shape2[pair]];
     sup.lig = lig;
@@ -237,13 +308,13 @@ __device__ __forceinline__ void gjk_cvx_body(const Work& wk, const LibView<T>& l
     sup.md = make_mdiff(tf1, tf2);
     const T r0 = swept_radius(sup.a), r1 = swept_radius(sup.b);
     const V3<T> guess0 = initial_guess<T>(io, q, pair);
-    Gjk<T, PW0<T>> g;
+    Gjk<T, typename GjkW0<T, 256>::P> g;
     // normalize_support_direction only when both are ConvexBase (minkowski_difference.cpp:261-266)
     if constexpr (BVG)
-      gjk_run(g, q.gjk, start_guess(q, sup.a, sup.b, sup.md, guess0), r0 + r1, M == 0, sup);
+      gjk_run(g, q.gjk, start_guess(q, sup.a, sup.b, sup.md, guess0), r0 + r1, M == 0, sup, ps);
     else
-      gjk_run(g, q.gjk, guess0, r0 + r1, M == 0, sup);
-    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0);
+      gjk_run(g, q.gjk, guess0, r0 + r1, M == 0, sup, ps);
+    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0, ps);
   }
 }
 
@@ -288,6 +359,7 @@ struct LargeSupport {
 
 template <typename T, bool BVG>
 __global__ void __launch_bounds__(256) k_gjk_large(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  HFCL_GJK_W0_SLAB(T, 256, ps);
   const uint32_t cnt = wk.counts[B_LARGE];
   const int lig = threadIdx.x & (LARGE_W - 1);
   const uint32_t groups = (gridDim.x * blockDim.x) / LARGE_W;
@@ -303,12 +375,12 @@ __global__ void __launch_bounds__(256) k_gjk_large(Work wk, LibView<T> lib, IO<T
     sup.md = make_mdiff(tf1, tf2);
     const T r0 = swept_radius(sup.a), r1 = swept_radius(sup.b);
     const V3<T> guess0 = initial_guess<T>(io, q, pair);
-    Gjk<T, PW0<T>> g;
+    Gjk<T, typename GjkW0<T, 256>::P> g;
     if constexpr (BVG)
-      gjk_run(g, q.gjk, start_guess(q, sup.a, sup.b, sup.md, guess0), r0 + r1, sup.a.kind == K_CONVEX && sup.b.kind == K_CONVEX, sup);
+      gjk_run(g, q.gjk, start_guess(q, sup.a, sup.b, sup.md, guess0), r0 + r1, sup.a.kind == K_CONVEX && sup.b.kind == K_CONVEX, sup, ps);
     else
-      gjk_run(g, q.gjk, guess0, r0 + r1, sup.a.kind == K_CONVEX && sup.b.kind == K_CONVEX, sup);
-    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0, true);
+      gjk_run(g, q.gjk, guess0, r0 + r1, sup.a.kind == K_CONVEX && sup.b.kind == K_CONVEX, sup, ps);
+    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0, ps, true);
   }
 }
 

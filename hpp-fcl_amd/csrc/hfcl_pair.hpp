@@ -78,24 +78,42 @@ struct EpaSeed {
   uint32_t gjk_iters;
 };
 
-template <typename T, class Sup>
-HFCL_HD void gjk_run(Gjk<T, PW0<T>>& g, const GjkParams<T>& prm, const V3<T>& guess, T ssr_sum, bool normalize, Sup& sup) {
+// Where the simplex vertices keep their witness data (the support point on shape 0, needed only after the loop):
+// W0Regs carries it with the vertex in registers (payload PW0); the HIP kernels can plug in a policy that parks
+// it outside the register file and carries a slot number instead (hfcl_dev.hpp: W0Lds).
+//   P put(g, w0)  payload for the vertex about to be appended to g (g.rank vertices are live at that point)
+//   V3 get(p)     the support point of a live vertex
+template <typename T>
+struct W0Regs {
+  typedef PW0<T> P;
+  template <class G> HFCL_HD P put(const G&, const V3<T>& w0) const { return P{w0}; }
+  HFCL_HD V3<T> get(const P& p) const { return p.w0; }
+};
+
+template <typename T, class P, class Sup, class PS>
+HFCL_HD void gjk_run(Gjk<T, P>& g, const GjkParams<T>& prm, const V3<T>& guess, T ssr_sum, bool normalize, Sup& sup, const PS& ps) {
   gjk_init(g, prm, guess, ssr_sum, normalize);
   while (!g.done) {
     V3<T> sd;
     if (gjk_begin(g, prm, sd)) {
-      SimplexV<T, PW0<T>> v;
-      sup(sd, v.w, v.p.w0);
+      SimplexV<T, P> v;
+      V3<T> w0;
+      sup(sd, v.w, w0);
+      v.p = ps.put(g, w0);
       gjk_end(g, prm, v);
     }
   }
 }
+template <typename T, class Sup>
+HFCL_HD void gjk_run(Gjk<T, PW0<T>>& g, const GjkParams<T>& prm, const V3<T>& guess, T ssr_sum, bool normalize, Sup& sup) {
+  gjk_run(g, prm, guess, ssr_sum, normalize, sup, W0Regs<T>());
+}
 
 // Returns true when the pair must go through EPA (seed filled); otherwise `out` is final.
-template <typename T>
-HFCL_HD bool gjk_finish(const Gjk<T, PW0<T>>& g, const QParams<T>& q, const Pose<T>& tf1, T r0, T r1,
-                        const V3<T>& guess0, PairOut<T>& out, EpaSeed<T>& seed) {
-  typedef SimplexV<T, PW0<T>> SV;
+template <typename T, class P, class PS>
+HFCL_HD bool gjk_finish(const Gjk<T, P>& g, const QParams<T>& q, const Pose<T>& tf1, T r0, T r1,
+                        const V3<T>& guess0, PairOut<T>& out, EpaSeed<T>& seed, const PS& ps) {
+  typedef SimplexV<T, P> SV;
   const T nanv = Lim<T>::nan();
   const V3<T> nan3 = mk<T>(nanv, nanv, nanv);
   const int st = g.status;
@@ -110,10 +128,10 @@ HFCL_HD bool gjk_finish(const Gjk<T, PW0<T>>& g, const QParams<T>& q, const Pose
     const SV ref1 = svsel(r == 2, g.s0, svsel(r == 3, g.s1, g.s2));
     const SV ref2 = svsel(r == 3, g.s0, g.s1);
     seed.rank = r;
-    seed.w[0] = ref0.w; seed.w0[0] = ref0.p.w0;
-    seed.w[1] = ref1.w; seed.w0[1] = ref1.p.w0;
-    seed.w[2] = ref2.w; seed.w0[2] = ref2.p.w0;
-    seed.w[3] = g.s0.w; seed.w0[3] = g.s0.p.w0;
+    seed.w[0] = ref0.w; seed.w0[0] = ps.get(ref0.p);
+    seed.w[1] = ref1.w; seed.w0[1] = ps.get(ref1.p);
+    seed.w[2] = ref2.w; seed.w0[2] = ps.get(ref2.p);
+    seed.w[3] = g.s0.w; seed.w0[3] = ps.get(g.s0.p);
     seed.guess = guess0;
     seed.gjk_iters = uint32_t(g.iterations);
     return true;
@@ -128,9 +146,9 @@ HFCL_HD bool gjk_finish(const Gjk<T, PW0<T>>& g, const QParams<T>& q, const Pose
   // NoCollision / CollisionWithPenetrationInformation / Failed: GJKExtractWitnessPointsAndNormal :610-636
   const SV ref0 = svsel(r == 1, g.s0, svsel(r == 2, g.s1, g.s2));
   const SV ref1 = svsel(r == 2, g.s0, g.s1);
+  const V3<T> a0 = ps.get(ref0.p), b0 = ps.get(ref1.p), c0 = ps.get(g.s0.p);
   V3<T> p1, p2, n;
-  closest_points(r, ref0.w, ref1.w, g.s0.w, ref0.p.w0, ref1.p.w0, g.s0.p.w0, ref0.p.w0 - ref0.w, ref1.p.w0 - ref1.w,
-                 g.s0.p.w0 - g.s0.w, p1, p2);
+  closest_points(r, ref0.w, ref1.w, g.s0.w, a0, b0, c0, a0 - ref0.w, b0 - ref1.w, c0 - g.s0.w, p1, p2);
   gjk_witness_normal(g.ray, r0, r1, p1, p2, n);
   to_world(tf1, g.distance, p1, p2, n);
   out.distance = g.distance;
@@ -139,6 +157,11 @@ HFCL_HD bool gjk_finish(const Gjk<T, PW0<T>>& g, const QParams<T>& q, const Pose
   out.p2 = p2;
   out.cached_guess = g.ray;
   return false;
+}
+template <typename T>
+HFCL_HD bool gjk_finish(const Gjk<T, PW0<T>>& g, const QParams<T>& q, const Pose<T>& tf1, T r0, T r1,
+                        const V3<T>& guess0, PairOut<T>& out, EpaSeed<T>& seed) {
+  return gjk_finish(g, q, tf1, r0, r1, guess0, out, seed, W0Regs<T>());
 }
 
 // EPAExtractWitnessPointsAndNormal / EPAFailedExtractWitnessPointsAndNormal (narrowphase.h:658-723)
