@@ -46,6 +46,7 @@ using namespace hfcl;
 // side carries vertices so the kernel is specialised at compile time)
 // ---------------------------------------------------------------------------------------
 enum { B_CLOSED = 0, B_PRIM = 1, B_CC = 2, B_PC = 3, B_CP = 4, B_BVH = 5, B_UNSUPPORTED = 6, B_LARGE = 7, B_BVHSHAPE = 8, B_TRI = 9, B_COUNT = 10 };
+constexpr int N_COUNTERS = B_COUNT + 4;  // the bucket populations + the four counters of Work::counts
 
 // Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
 // support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
@@ -116,11 +117,12 @@ struct Work {
   uint32_t n;
   uint32_t* lists;   // B_COUNT lists of capacity n each
   uint32_t* counts;  // B_COUNT counters + [B_COUNT] = epa queue length + [B_COUNT+1] = overflow queue length
-                     // + [B_COUNT+2] = ticket counter of the streaming BVH kernel
+                     // + [B_COUNT+2] = ticket counter of the streaming BVH kernel + [B_COUNT+3] = length of the
+                     // fp32 convex x convex EPA queue (the top end of epa_queue, filled downwards from slot n-1)
   void* epa_queue;
   void* epa_queue2;  // polytopes that outgrew the fast EPA kernel's scratch block
   void* epa_v0;      // shape-0 support points of the polytopes in flight in the full-capacity EPA kernel
-  void* epa_resume;  // saved polytopes (EpaScratch<T, EPA_FAST_CAP>) of the first `resume_cap` slots of epa_queue2
+  void* epa_resume;  // saved polytopes (EpaSaved, epa_resume_stride<T> bytes apart) of the first `resume_cap` slots of epa_queue2
   uint32_t resume_cap;
 };
 constexpr int32_t EPA_RESUME_FLAG = 0x100;  // EpaSeed::rank bit: "continue the saved polytope of this slot"
@@ -269,7 +271,8 @@ struct HullRegs {
       v[k] = mk<T>(p[0], p[1], p[2]);
     }
   }
-  __device__ __forceinline__ V3<T> support(const V3<T>& dir, int lig) const {
+  // idx_out: the index of the returned vertex in the hull (first index of the maximum)
+  __device__ __forceinline__ V3<T> support(const V3<T>& dir, int lig, int* idx_out = nullptr) const {
     T best = dot(v[0], dir);
     int bi = lig * VPL;
 #pragma unroll
@@ -296,6 +299,7 @@ struct HullRegs {
 #pragma unroll
     for (int k = 1; k < VPL; ++k)
       if (slot == k) c = v[k];
+    if (idx_out) *idx_out = bi;
     return mk<T>(__shfl(c.x, owner, W), __shfl(c.y, owner, W), __shfl(c.z, owner, W));
   }
 };
@@ -350,15 +354,21 @@ struct LaneGroup {
   static __device__ __forceinline__ uint32_t atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }  // LDS (ds_add_rtn)
 };
 
+// Capacity (iterations) of the fast tier's block.  fp32: 17 -- the convex x convex form (k_epa_stream<.., CC>) then has
+// a 1568-byte block per polytope (no shape-0 support points: tags; 12-byte face topology; one-byte horizon entries),
+// 12544 bytes per wave of 8 = ten of the 1280-byte units the hardware hands LDS out in (tools/occupancy_probe.hip), so
+// 12 waves fit a CU (3 per SIMD).  18 iterations are 13184 bytes = 11 units = 11 waves.
 #ifndef HFCL_EPA_FAST_CAP
-#define HFCL_EPA_FAST_CAP 20
+#define HFCL_EPA_FAST_CAP 17
 #endif
 constexpr int EPA_FAST_CAP = HFCL_EPA_FAST_CAP;
 #ifndef HFCL_EPA_FAST_CAP64
 #define HFCL_EPA_FAST_CAP64 24  // cfg5 (fast + full ms): 12: 0.84+2.16, 16: 1.06+1.74, 20: 1.28+1.19, 24: 1.49+0.89; 28 would cost a wave per CU
 #endif
-// capacity of the fast tier's block per precision (fp64 blocks are twice the size; the LDS holds 4 waves x 8 either way)
+// capacity of the fast tier's block per precision
 template <typename T> constexpr int epa_fast_cap = sizeof(T) == 4 ? EPA_FAST_CAP : HFCL_EPA_FAST_CAP64;
+// one slot of the hand-over area
+template <typename T> constexpr size_t epa_resume_stride = sizeof(EpaSaved<T, epa_fast_cap<T>>);
 #ifndef HFCL_EPA_WE
 #define HFCL_EPA_WE 8
 #endif

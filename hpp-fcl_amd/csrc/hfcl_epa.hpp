@@ -51,18 +51,21 @@ HFCL_HD PW0<T> psel(bool c, const PW0<T>& a, const PW0<T>& b) {
 // Scratch layout (SoA), sized for CAP iterations: CAP+4 vertices, 2*CAP+4 faces (gjk.cpp:1020-1021).
 // CAP = 64 is the reference capacity; the fast kernel uses a smaller CAP (several polytopes per
 // wave fit in LDS) and hands polytopes that outgrow it to the full-capacity kernel.
-// Per-face connectivity, read with one 16-byte LDS access; single fields are updated with byte stores
-// (two lanes may bind different edges of the same kept face concurrently, so no read-modify-write).
-struct alignas(16) FaceTopo {
-  uint32_t vf;     // vertex ids of the 3 corners (bytes 0-2), flags (byte 3: bit0 in hull, bit1 ignore)
-  uint32_t ap;     // neighbour face across edge 0..2 (bytes 0-2), pass mark (byte 3)
-  uint32_t ae;     // edge index on the neighbour's side for edge 0..2 (bytes 0-2)
-  uint32_t stamp;  // append order (the reference's hull list position)
+// Per-face connectivity: three 32-bit words (12 bytes per face; it was 16 with a 32-bit stamp of its own: the block
+// size bounds the number of resident waves of the EPA kernels).  Single fields are updated with byte stores (two lanes
+// may bind different edges of the same kept face concurrently, so no read-modify-write).  The append stamp (the
+// reference's hull list position; 14 bits: a polytope creates far fewer than 16384 faces in 64 iterations) is split
+// over the two spare bytes: both are written when the face is created and only read while it is in the hull.
+struct alignas(4) FaceTopo {
+  uint32_t vf;  // vertex ids of the 3 corners (bytes 0-2); byte 3: bit0 in hull, bit1 ignore, bits 2-7 = stamp >> 8
+  uint32_t ap;  // neighbour face across edge 0..2 (bytes 0-2), pass mark (byte 3)
+  uint32_t ae;  // edge index on the neighbour's side for edge 0..2 (bytes 0-2), stamp & 255 (byte 3)
   HFCL_HD int vid(int e) const { return int((vf >> (8 * e)) & 255u); }
-  HFCL_HD int flag() const { return int(vf >> 24); }
+  HFCL_HD int flag() const { return int((vf >> 24) & 3u); }
   HFCL_HD int adj(int e) const { return int((ap >> (8 * e)) & 255u); }
   HFCL_HD int pass() const { return int(ap >> 24); }
   HFCL_HD int adje(int e) const { return int((ae >> (8 * e)) & 255u); }
+  HFCL_HD int stamp() const { return int((ae >> 24) | ((vf >> 26) << 8)); }
 };
 HFCL_HD uint8_t* topo_bytes(FaceTopo& t, int word) { return reinterpret_cast<uint8_t*>(&t) + 4 * word; }
 
@@ -76,21 +79,48 @@ struct alignas(4 * sizeof(T) > 16 ? 16 : 4 * sizeof(T)) Quad {  // one LDS vecto
 struct EpaHeader {
   int32_t closest, iterations, pass, status, num_vertices, hull_count, stock_top, stamp;
 };
-// V0IN = false: the shape-0 support points (needed once, for the witness points) live in a caller-provided
-// array outside the block (global memory in the full-capacity kernel, whose LDS bounds its occupancy).
-template <typename T, int CAP, bool V0IN = true>
-struct EpaScratch {
+// Where the shape-0 support point of every polytope vertex lives (needed once, for the witness points):
+//   V0_BLOCK   in the scratch block itself;
+//   V0_EXTERN  in a caller-provided array outside the block (global memory in the full-capacity kernel, whose LDS
+//              block bounds its occupancy);
+//   V0_TAG     nowhere: the fourth component of the vertex record carries a tag the caller can turn back into the point
+//              (tag >= 0: vertex index of shape 0's hull; tag < 0: vertex -1-tag of GJK's final simplex), see
+//              Epa::v0r.  The convex x convex fast tier works this way.
+// (The first two are the former `bool V0IN` values false / true.)
+enum { V0_EXTERN = 0, V0_BLOCK = 1, V0_TAG = 2 };
+template <typename T, int N, bool ON>
+struct V0Store {
+  Quad<T> v0[N];  // vertex w0 (xyz)
+};
+template <typename T, int N>
+struct V0Store<T, N, false> {};
+template <typename T, int CAP, int V0M = V0_BLOCK>
+struct EpaScratch : V0Store<T, CAP + 4, V0M == V0_BLOCK> {
   static constexpr int NV = CAP + 4;
   static constexpr int NF = 2 * CAP + 4;
-  Quad<T> vw[NV];   // vertex w (xyz)
-  Quad<T> v0[V0IN ? NV : 1];  // vertex w0 (xyz)
+  static constexpr int V0MODE = V0M;
+  // horizon entries: kept face | its edge << HZ_SHIFT; one byte where the face ids leave two bits free
+  typedef typename std::conditional<(NF <= 64), uint8_t, uint16_t>::type HzT;
+  static constexpr int HZ_SHIFT = NF <= 64 ? 6 : 8;
+  Quad<T> vw[NV];   // vertex w (xyz); w: tag (V0_TAG)
   Quad<T> fn[NF];   // face normal (xyz) and distance (w)
-  FaceTopo ft[NF];  // connectivity + flags + stamp of a face, one 16-byte record
-  EpaHeader hdr;    // loop state of a polytope that is handed over to the full-capacity tier
-  uint32_t top;     // stock top while faces are being released by several lanes
-  uint16_t stack[NF];  // silhouette-walk frames: face | edge<<8 | stage<<10
-  uint16_t hz[NF];     // horizon edges in walk order: kept face | its edge<<8
+  FaceTopo ft[NF];  // connectivity + flags + stamp of a face, one 12-byte record
+  union {
+    uint16_t stack[NF];  // silhouette-walk frames: face | edge<<8 | stage<<10
+    EpaHeader hdr;       // loop state of a polytope that is handed over to the full-capacity tier (the walk is over then)
+  };
+  uint32_t top;        // stock top while faces are being released by several lanes
+  HzT hz[NF];          // horizon edges in walk order
   uint8_t stock[NF];   // free-face stack
+  static_assert(sizeof(uint16_t) * NF >= sizeof(EpaHeader), "the header overlays the walk stack");
+};
+// A polytope saved for the tier hand-over, one format whatever way the saving tier kept the shape-0 support points:
+// the block without them (= the V0_TAG layout; the members after the V0Store base are laid out the same in every
+// mode) plus the points as coordinates.
+template <typename T, int CAP>
+struct EpaSaved {
+  EpaScratch<T, CAP, V0_TAG> blk;
+  Quad<T> v0[CAP + 4];
 };
 
 // All-reduce over a lane group: stage M = 1, 2, 4, .. < W hands every lane the value of a partner lane
@@ -132,10 +162,27 @@ struct EpaResult {
   V3<T> rw0_, rw1_, rw2_, r00, r01, r02;
 };
 
-template <typename T, class Grp, int CAP = EPA_MAX_ITER, bool V0IN = true>
+// Resolver of V0_TAG tags for the modes that do not use tags (never called).
+struct NoTags {
+  template <typename I> HFCL_HD int operator()(I) const { return 0; }
+};
+// sup(dir, w, w0[, tag]): supports that can name the shape-0 vertex they return take a fourth argument
+template <bool TAGGED, typename T, class Sup>
+HFCL_HD void epa_support(Sup& sup, const V3<T>& dir, V3<T>& w, V3<T>& w0, int& tag) {
+  if constexpr (TAGGED) {
+    sup(dir, w, w0, tag);
+  } else {
+    sup(dir, w, w0);
+    tag = 0;
+  }
+}
+
+template <typename T, class Grp, int CAP = EPA_MAX_ITER, int V0M = V0_BLOCK>
 struct Epa {
-  EpaScratch<T, CAP, V0IN>* m;
-  Quad<T>* v0p;  // m->v0, or the caller's array when the block has none
+  static constexpr bool TAGGED = V0M == V0_TAG;
+  typedef EpaScratch<T, CAP, V0M> Block;
+  Block* m;
+  Quad<T>* v0p;  // m->v0, or the caller's array (V0_EXTERN); unused with tags
   T tolerance;
   int max_iterations;  // the request's (reference) limit
   int cap_iterations;  // min(max_iterations, CAP): what this scratch block can hold
@@ -152,9 +199,9 @@ struct Epa {
     const Quad<T> q = m->vw[i];
     return mk<T>(q.x, q.y, q.z);
   }
-  HFCL_HD V3<T> v0(int i) const {
+  HFCL_HD V3<T> v0(int i) const {  // V0_BLOCK / V0_EXTERN
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (!V0IN) {
+    if constexpr (V0M == V0_EXTERN) {
       // written by lane 0 of this group, possibly long ago and for an earlier polytope of the same slot:
       // read past the per-CU cache
       const T* q = &v0p[i].x;
@@ -166,10 +213,23 @@ struct Epa {
     const Quad<T> q = v0p[i];
     return mk<T>(q.x, q.y, q.z);
   }
-  HFCL_HD void set_vert(int i, const V3<T>& w, const V3<T>& w0) {
-    m->vw[i] = Quad<T>{w.x, w.y, w.z, T(0)};
-    if (V0IN || Grp::lane() == 0) v0p[i] = Quad<T>{w0.x, w0.y, w0.z, T(0)};
+  // the shape-0 support point of vertex i in any mode; `tags`: int -> V3 (V0_TAG only)
+  template <class Tags>
+  HFCL_HD V3<T> v0r(int i, const Tags& tags) const {
+    if constexpr (TAGGED)
+      return tags(int(m->vw[i].w));
+    else
+      return v0(i);
   }
+  HFCL_HD void set_vert(int i, const V3<T>& w, const V3<T>& w0, int tag = 0) {
+    m->vw[i] = Quad<T>{w.x, w.y, w.z, T(tag)};
+    if constexpr (V0M == V0_BLOCK) v0p[i] = Quad<T>{w0.x, w0.y, w0.z, T(0)};
+    if constexpr (V0M == V0_EXTERN)
+      if (Grp::lane() == 0) v0p[i] = Quad<T>{w0.x, w0.y, w0.z, T(0)};
+  }
+  HFCL_HD static unsigned hz_pack(int f, int e) { return unsigned(f) | (unsigned(e) << Block::HZ_SHIFT); }
+  HFCL_HD static int hz_face(unsigned h) { return int(h & ((1u << Block::HZ_SHIFT) - 1u)); }
+  HFCL_HD static int hz_edge(unsigned h) { return int((h >> Block::HZ_SHIFT) & 3u); }
   HFCL_HD V3<T> fn(int f) const {
     const Quad<T> q = m->fn[f];
     return mk<T>(q.x, q.y, q.z);
@@ -191,9 +251,12 @@ struct Epa {
     m->stock[stock_top++] = uint8_t(f);
   }
 
-  HFCL_HD void reset(EpaScratch<T, CAP, V0IN>* mem, int max_it, T tol, Quad<T>* v0_ext = nullptr) {  // :1014-1037
+  HFCL_HD void reset(Block* mem, int max_it, T tol, Quad<T>* v0_ext = nullptr) {  // :1014-1037
     m = mem;
-    v0p = V0IN ? mem->v0 : v0_ext;
+    if constexpr (V0M == V0_BLOCK)
+      v0p = mem->v0;
+    else
+      v0p = v0_ext;
     tolerance = tol;
     max_iterations = max_it;
     cap_iterations = max_it < CAP ? max_it : CAP;
@@ -216,7 +279,7 @@ struct Epa {
 
   // Geometry part of newFace (:1081-1137) for the triangle (ia, ib, ic) stored in slot f.
   // Returns 0 when the face is kept, else the status newFace sets (NonConvex / Degenerated).
-  HFCL_HD int face_geometry(int f, int ia, int ib, int ic, bool force) {
+  HFCL_HD int face_geometry(int f, int ia, int ib, int ic, bool force, int face_stamp) {
     const V3<T> a = vw(ia), b = vw(ib), c = vw(ic);
     V3<T> n = cross(b - a, c - a);
     int fail = 0;
@@ -240,8 +303,10 @@ struct Epa {
       fail = EPA_DEGENERATED;
     }
     m->fn[f] = Quad<T>{n.x, n.y, n.z, dist};
-    // corners + flags in one word; the pass mark is cleared; adjacency bytes are written by the binds
-    m->ft[f].vf = uint32_t(ia) | (uint32_t(ib) << 8) | (uint32_t(ic) << 16) | (uint32_t(flag) << 24);
+    // corners + flags + high stamp bits in one word; the pass mark is cleared; adjacency bytes are written by the binds
+    m->ft[f].vf = uint32_t(ia) | (uint32_t(ib) << 8) | (uint32_t(ic) << 16) | (uint32_t(flag) << 24) |
+                  ((uint32_t(face_stamp) >> 8) << 26);
+    topo_bytes(m->ft[f], 2)[3] = uint8_t(face_stamp);
     set_pass(f, 0);
     return fail;
   }
@@ -255,8 +320,7 @@ struct Epa {
     }
     const int f = m->stock[--stock_top];
     ++hull_count;
-    m->ft[f].stamp = uint32_t(stamp++);
-    const int fail = face_geometry(f, ia, ib, ic, force);
+    const int fail = face_geometry(f, ia, ib, ic, force, stamp++);
     if (!fail) return f;
     status = fail;
     hull_remove(f);
@@ -286,7 +350,7 @@ struct Epa {
         m->stock[Grp::atomic_inc(&m->top)] = uint8_t(f);
         continue;
       }
-      const int st = int(t.stamp);
+      const int st = t.stamp();
       if (st > head_stamp) {
         head_stamp = st;
         head_f = f;
@@ -371,7 +435,7 @@ struct Epa {
             return;
           }
           --level;
-          m->hz[hz_count++] = uint16_t(f | (e << 8));
+          m->hz[hz_count++] = typename Block::HzT(hz_pack(f, e));
           --sp;
           continue;
         }
@@ -410,7 +474,7 @@ struct Epa {
         return;
       }
       if (dot(fn(f), ww - vw(t.vid(e))) < dummy_precision) {
-        m->hz[hz_count++] = uint16_t(fr);
+        m->hz[hz_count++] = typename Block::HzT(hz_pack(f, e));
         continue;
       }
       set_pass(f, pass);
@@ -480,13 +544,12 @@ struct Epa {
     int first_fail = n_new, fail_code = 0;
     for (int k = Grp::lane(); k < n_new; k += Grp::W) {
       const unsigned fr = m->hz[k];
-      const int f = fr & 255, e = (fr >> 8) & 3, e1 = (e + 1) % 3;
+      const int f = hz_face(fr), e = hz_edge(fr), e1 = (e + 1) % 3;
       const int nfc = m->stock[stock_top - 1 - k];
       const int kp = (k == 0) ? n_new - 1 : k - 1;  // previous face on the horizon loop
       const int pf = m->stock[stock_top - 1 - kp];
       const uint32_t fv = m->ft[f].vf;
-      m->ft[nfc].stamp = uint32_t(stamp + k);
-      const int fail = face_geometry(nfc, int((fv >> (8 * e1)) & 255u), int((fv >> (8 * e)) & 255u), id_w, false);
+      const int fail = face_geometry(nfc, int((fv >> (8 * e1)) & 255u), int((fv >> (8 * e)) & 255u), id_w, false, stamp + k);
       // bind(nf, 0, f, e); bind(nf, 2, previous, 1)  (:1421-1425, closing bind :1273)
       set_adj(nfc, 0, f, e);
       set_adj(f, e, nfc, 0);
@@ -582,9 +645,10 @@ struct Epa {
       if (rank == 2) ++c2;
       if (rank == 3) ++c3;
       V3<T> w, w0;
-      sup(dir, w, w0);
+      int tag;
+      epa_support<TAGGED>(sup, dir, w, w0, tag);
       Grp::sync();
-      set_vert(rank, w, w0);
+      set_vert(rank, w, w0, tag);
       Grp::sync();
       ++rank;
       entering = true;
@@ -593,26 +657,34 @@ struct Epa {
 
   // EPA::evaluate :1156-1316.  verts[0..rank) must already hold GJK's final simplex in the
   // reference's order (oldest first).  guess = the vector passed as `guess` to evaluate().
-  template <class Sup>
-  HFCL_HD void evaluate(int rank, const V3<T>& guess, T ssr_sum, Sup& sup, EpaResult<T>& out) {
-    const int closest0 = begin(rank, guess, sup, out);
-    if (closest0 != EPA_NULL) run_loop(closest0, 0, 0, ssr_sum, sup, out);
+  template <class Sup, class Tags = NoTags>
+  HFCL_HD void evaluate(int rank, const V3<T>& guess, T ssr_sum, Sup& sup, EpaResult<T>& out, const Tags& tags = Tags()) {
+    const int closest0 = begin(rank, guess, sup, out, tags);
+    if (closest0 != EPA_NULL) run_loop(closest0, 0, 0, ssr_sum, sup, out, tags);
   }
   // evaluate() up to the loop (:1188-1230): the first closest face, or EPA_NULL when `out` is already
   // final (FallBack :1299-1315).
-  template <class Sup>
-  HFCL_HD int begin(int rank, const V3<T>& guess, Sup& sup, EpaResult<T>& out) {
+  template <class Sup, class Tags = NoTags>
+  HFCL_HD int begin(int rank, const V3<T>& guess, Sup& sup, EpaResult<T>& out, const Tags& tags = Tags()) {
     const bool enclosed = enclose_origin(rank, sup);
     out.iterations = 0;
     if (rank > 1 && enclosed) {
       status = EPA_VALID;
       num_vertices = 4;
       if (dot(vw(0) - vw(3), cross(vw(1) - vw(3), vw(2) - vw(3))) < T(0)) {
-        const V3<T> a = vw(0), a0 = v0(0), b = vw(1), b0 = v0(1);
-        Grp::sync();
-        set_vert(0, b, b0);
-        set_vert(1, a, a0);
-        Grp::sync();
+        if constexpr (TAGGED) {  // the tags travel with the records
+          const Quad<T> a = m->vw[0], b = m->vw[1];
+          Grp::sync();
+          m->vw[0] = b;
+          m->vw[1] = a;
+          Grp::sync();
+        } else {
+          const V3<T> a = vw(0), a0 = v0(0), b = vw(1), b0 = v0(1);
+          Grp::sync();
+          set_vert(0, b, b0);
+          set_vert(1, a, a0);
+          Grp::sync();
+        }
       }
       int t0 = new_face(0, 1, 2, true);
       int t1 = new_face(1, 0, 3, true);
@@ -638,7 +710,7 @@ struct Epa {
     out.normal = (nl > T(0)) ? (n / nl) : mk<T>(T(1), T(0), T(0));
     out.depth = T(0);
     out.rw0_ = out.rw1_ = out.rw2_ = vw(0);
-    out.r00 = out.r01 = out.r02 = v0(0);
+    out.r00 = out.r01 = out.r02 = v0r(0, tags);
     return EPA_NULL;
   }
 
@@ -681,9 +753,10 @@ struct Epa {
     set_pass(closest, ++L.pass);
     const V3<T> cn = fn(closest);
     V3<T> w, w0;
-    sup(cn, w, w0);
+    int tag;
+    epa_support<TAGGED>(sup, cn, w, w0, tag);
     Grp::sync();
-    set_vert(iw, w, w0);
+    set_vert(iw, w, w0, tag);
     Grp::sync();
     const FaceTopo tcl = m->ft[closest];
     const V3<T> vf1 = vw(tcl.vid(0)), vf2 = vw(tcl.vid(1)), vf3 = vw(tcl.vid(2));
@@ -711,38 +784,42 @@ struct Epa {
     loop_enter(L, find_closest_face(), L.iterations + 1, L.pass);
     return 0;
   }
-  HFCL_HD void loop_result(const EpaLoop<T>& L, T ssr_sum, EpaResult<T>& out) const {
+  template <class Tags = NoTags>
+  HFCL_HD void loop_result(const EpaLoop<T>& L, T ssr_sum, EpaResult<T>& out, const Tags& tags = Tags()) const {
     out.status = status;
     out.iterations = L.iterations;
     out.normal = L.outer_n;
     out.depth = L.outer_d + ssr_sum;
     out.rw0_ = vw(L.o0); out.rw1_ = vw(L.o1); out.rw2_ = vw(L.o2);
-    out.r00 = v0(L.o0); out.r01 = v0(L.o1); out.r02 = v0(L.o2);
+    out.r00 = v0r(L.o0, tags); out.r01 = v0r(L.o1, tags); out.r02 = v0r(L.o2, tags);
   }
   // The whole loop from (closest, iterations, pass): evaluate() enters at iteration 0, a polytope handed
   // over by a smaller tier where it stopped.  Nothing is written to `out` on a hand-over.
-  template <class Sup>
-  HFCL_HD void run_loop(int closest, int iterations, int pass, T ssr_sum, Sup& sup, EpaResult<T>& out) {
+  template <class Sup, class Tags = NoTags>
+  HFCL_HD void run_loop(int closest, int iterations, int pass, T ssr_sum, Sup& sup, EpaResult<T>& out, const Tags& tags = Tags()) {
     EpaLoop<T> L;
     loop_enter(L, closest, iterations, pass);
     int r;
     while ((r = step(L, sup)) == 0) {
     }
-    if (r == 1) loop_result(L, ssr_sum, out);
+    if (r == 1) loop_result(L, ssr_sum, out, tags);
   }
 
   // Continue a polytope saved by a tier with capacity CAP_SRC in this (already reset()) block: vertices and
   // faces keep their indices, the extra faces of the larger block join the stock.
   template <int CAP_SRC>
-  HFCL_HD EpaHeader load(const EpaScratch<T, CAP_SRC>* src) {
-    typedef EpaScratch<T, CAP_SRC> Src;
+  HFCL_HD EpaHeader load(const EpaSaved<T, CAP_SRC>* saved) {
+    static_assert(V0M != V0_TAG, "a continued polytope keeps its support points as coordinates");
+    typedef EpaScratch<T, CAP_SRC, V0_TAG> Src;
+    const Src* src = &saved->blk;
     const EpaHeader h = src->hdr;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-    for (int i = Grp::lane(); i < Src::NV; i += Grp::W) {
-      m->vw[i] = src->vw[i];
-      v0p[i] = src->v0[i];
+    for (int i = Grp::lane(); i < h.num_vertices; i += Grp::W) {
+      const Quad<T> q = src->vw[i];
+      m->vw[i] = Quad<T>{q.x, q.y, q.z, T(0)};
+      v0p[i] = saved->v0[i];
     }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
@@ -764,21 +841,35 @@ struct Epa {
   }
 };
 
-// Group-cooperative copy of a resumable polytope (scratch block incl. its header) to `dst`.
-template <typename T, class Grp, int CAP>
-HFCL_HD void epa_save_block(const EpaScratch<T, CAP>* block, EpaScratch<T, CAP>* dst) {
+// Group-cooperative copy of a resumable polytope (scratch block incl. its header) to `dst`, with the shape-0 support
+// points of its vertices written out as coordinates (`tags`: int -> V3, V0_TAG blocks only; V0_BLOCK blocks carry them).
+template <typename T, class Grp, int CAP, int V0M, class Tags = NoTags>
+HFCL_HD void epa_save_block(const EpaScratch<T, CAP, V0M>* block, EpaSaved<T, CAP>* dst, const Tags& tags = Tags()) {
+  static_assert(V0M != V0_EXTERN, "only the fast tiers hand polytopes over");
   Grp::sync();
-  struct alignas(16) Chunk {
-    uint32_t w[4];
-  };
-  static_assert(sizeof(EpaScratch<T, CAP>) % sizeof(Chunk) == 0 && alignof(EpaScratch<T, CAP>) >= alignof(Chunk), "block is copied in 16-byte chunks");
-  const Chunk* src = reinterpret_cast<const Chunk*>(block);
-  Chunk* d = reinterpret_cast<Chunk*>(dst);
+  typedef EpaScratch<T, CAP, V0_TAG> Tail;
+  static_assert(sizeof(Tail) % 4 == 0, "block is copied in 4-byte words");
+  static_assert(sizeof(EpaScratch<T, CAP, V0M>) - sizeof(Tail) == (V0M == V0_BLOCK ? sizeof(Quad<T>) * (CAP + 4) : 0),
+                "the members after the support points are laid out as in the V0_TAG block");
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&block->vw[0]);
+  uint32_t* d = reinterpret_cast<uint32_t*>(&dst->blk);
   // rolled on purpose: this is the rare path and must not cost the expansion loop registers
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-  for (int i = Grp::lane(); i < int(sizeof(EpaScratch<T, CAP>) / sizeof(Chunk)); i += Grp::W) d[i] = src[i];
+  for (int i = Grp::lane(); i < int(sizeof(Tail) / 4); i += Grp::W) d[i] = src[i];
+  const int nv = block->hdr.num_vertices;  // the records beyond hold whatever the LDS held before: no tags to resolve
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int i = Grp::lane(); i < nv; i += Grp::W) {
+    if constexpr (V0M == V0_TAG) {
+      const V3<T> p = tags(int(block->vw[i].w));
+      dst->v0[i] = Quad<T>{p.x, p.y, p.z, T(0)};
+    } else {
+      dst->v0[i] = block->v0[i];
+    }
+  }
 }
 
 // EPA::getWitnessPointsAndNormal (:1451-1466) + inflate, shape-0 frame

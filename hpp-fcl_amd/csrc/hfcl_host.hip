@@ -122,8 +122,12 @@ struct hfcl_lib {
 
 // bucket population i of the last batch (both halves of a split batch)
 static uint32_t total_count(const hfcl_lib* lib, int i) {
-  uint32_t c = lib->h_counts ? lib->h_counts[i] : 0u;
-  if (lib->last_split && lib->helper && lib->helper->h_counts) c += lib->helper->h_counts[i];
+  auto one = [i](const uint32_t* c) {
+    // the EPA queue of a batch = the general queue + the fp32 convex x convex queue
+    return c[i] + (i == B_COUNT ? c[B_COUNT + 3] : 0u);
+  };
+  uint32_t c = lib->h_counts ? one(lib->h_counts) : 0u;
+  if (lib->last_split && lib->helper && lib->helper->h_counts) c += one(lib->helper->h_counts);
   return c;
 }
 
@@ -279,9 +283,9 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   ok = ok && hipMalloc(&lib->d_kinds, n_shapes) == hipSuccess;
   ok = ok && hipMalloc(&lib->d_verts64, (3 * n_vertices + 3) * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc(&lib->d_verts32, (3 * n_vertices + 3) * sizeof(float)) == hipSuccess;
-  ok = ok && hipMalloc(&lib->d_counts, (B_COUNT + 3) * sizeof(uint32_t)) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&lib->h_counts, (B_COUNT + 2) * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
-  if (ok) memset(lib->h_counts, 0, (B_COUNT + 2) * sizeof(uint32_t));
+  ok = ok && hipMalloc(&lib->d_counts, N_COUNTERS * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&lib->h_counts, N_COUNTERS * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+  if (ok) memset(lib->h_counts, 0, N_COUNTERS * sizeof(uint32_t));
   if (ok) {
     ok = ok && hipMemcpy(lib->d_shapes64, s64.data(), n_shapes * sizeof(DShape<double>), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(lib->d_shapes32, s32.data(), n_shapes * sizeof(DShape<float>), hipMemcpyHostToDevice) == hipSuccess;
@@ -422,7 +426,7 @@ static int ensure_workspace(hfcl_lib* lib, size_t n) {
   // simply redoes the pair from its seed); 4 KB per slot in fp64
   size_t rcap = std::min(cap, std::max<size_t>(65536, cap / 3));
   if (const char* e = getenv("HFCL_EPA_RESUME_SLOTS")) rcap = std::max<size_t>(1, std::min<size_t>(cap, strtoull(e, nullptr, 10)));  // test knob
-  HIP_TRY(hipMalloc(&lib->d_epa_resume, rcap * sizeof(EpaScratch<double, epa_fast_cap<double>>)));
+  HIP_TRY(hipMalloc(&lib->d_epa_resume, rcap * std::max(epa_resume_stride<double>, epa_resume_stride<float>)));
   lib->resume_cap = rcap;
   lib->ws_capacity = cap;
   return HFCL_OK;
@@ -637,7 +641,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
   auto may = [&](int b) { return (lib->possible_buckets >> b) & 1u; };
   const bool any_gjk = may(B_PRIM) || may(B_CC) || may(B_PC) || may(B_CP) || may(B_LARGE);
   const bool bvg = q.guess_mode == HFCL_GUESS_BOUNDING_VOLUME;
-  HIP_TRY(hipMemsetAsync(lib->d_counts, 0, (B_COUNT + 3) * sizeof(uint32_t), st));
+  HIP_TRY(hipMemsetAsync(lib->d_counts, 0, N_COUNTERS * sizeof(uint32_t), st));
   tbeg("k_classify");
   launch_classify(blocks_for(n, CLS_BLOCK * 8), st, wk, lib->d_kinds, uint32_t(lib->n_shapes), q.mode != 1);
   tend();
@@ -702,13 +706,15 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
 
   if (q.compute_penetration && any_gjk) {
     tbeg("k_epa<fast>");
-    launch_epa_fast<T>(blocks_for(n, 64 / EPA_WE), st, wk, lv, io, q);
+    // (the launcher sizes the grid of the persistent forms itself: here only the number of wave-sized batches)
+    launch_epa_fast<T>(int(std::min<size_t>((n + 64 / EPA_WE - 1) / (64 / EPA_WE), size_t(1) << 22)), st, wk, lv, io, q, may(B_CC),
+                       may(B_PRIM) || may(B_PC) || may(B_CP), lib->n_cus);
     tend();
     tbeg("k_epa<full>");
     launch_epa_full<T>(blocks_for(n / 16 + 1, 64 / EPA_WE2), st, wk, lv, io, q);
     tend();
   }
-  HIP_TRY(hipMemcpyAsync(lib->h_counts, lib->d_counts, (B_COUNT + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(lib->h_counts, lib->d_counts, N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipGetLastError());
   return HFCL_OK;
 }
@@ -728,14 +734,14 @@ static hfcl_lib* make_helper(hfcl_lib* lib) {
   h->cvx_w = lib->cvx_w;
   h->closed_staged = lib->closed_staged;
   h->n_cus = lib->n_cus;
-  bool ok = hipMalloc(&h->d_counts, (B_COUNT + 3) * sizeof(uint32_t)) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&h->h_counts, (B_COUNT + 2) * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+  bool ok = hipMalloc(&h->d_counts, N_COUNTERS * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&h->h_counts, N_COUNTERS * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipMalloc(&h->d_epa_v0, size_t(h->n_cus) * 16 * (64 / EPA_WE2) * EPA_MAX_VERTS * sizeof(Quad<double>)) == hipSuccess;
   if (!ok) {
     hfcl_lib_destroy(h);
     return nullptr;
   }
-  memset(h->h_counts, 0, (B_COUNT + 2) * sizeof(uint32_t));
+  memset(h->h_counts, 0, N_COUNTERS * sizeof(uint32_t));
   return h;
 }
 

@@ -1,5 +1,13 @@
 // hfcl_k_epa.hip -- the EPA kernels: tier 1 (8 polytopes per wave in small LDS blocks; batch and streaming form)
 // and tier 2 (reference capacity, continues the polytopes tier 1 saved).
+//
+// Occupancy is what these kernels live on.  profiles/r02_a_valu_issue_peak.txt: one wave issues a VALU instruction every
+// ~5 clocks at best and waits ~76 clocks for every dependent LDS round trip of the silhouette walk, so the kernel time is
+// the serial time of its waves divided by the number of resident waves (1 wave per SIMD instead of 2: 1.74 -> 3.16 ms,
+// profiles/r02_c).  Resident waves are bounded by the LDS block (8 polytopes) and by the registers of a wave; the
+// convex x convex form of the streaming tier is built to fit three waves per SIMD on both counts.
+#include <algorithm>
+
 #include "hfcl_dev.hpp"
 #include "hfcl_launch.hpp"
 
@@ -33,6 +41,39 @@ struct EpaSupport {  // any pair kind, evaluated by one lane group
   }
 };
 
+// Two hulls of at most HULL_MAX vertices: nothing but the register hulls and the relative pose is live across a trip,
+// and the support names the shape-0 vertex it returns (the polytope keeps that tag instead of the point, V0_TAG).
+template <typename T, int WE>
+struct EpaSupportCC {
+  HullRegs<T, WE> h0, h1;
+  MDiff<T> md;
+  int lig;
+  __device__ __forceinline__ void operator()(const V3<T>& dir, V3<T>& w, V3<T>& w0, int& tag) const {
+    w0 = h0.support(dir, lig, &tag);
+    const V3<T> d1 = md.identity ? -dir : -tmul(md.oR1, dir);
+    V3<T> s1 = h1.support(d1, lig);
+    s1 = md.identity ? s1 : (mul(md.oR1, s1) + md.ot1);
+    w = w0 - s1;
+  }
+};
+// tag -> shape-0 support point (Epa::v0r): a vertex of shape 0's hull, or vertex -1-tag of GJK's final simplex, which
+// is still in the queue entry
+template <typename T>
+struct SeedTags {
+  const T* va;
+  const EpaSeed<T>* ip;
+  __device__ __forceinline__ V3<T> operator()(int tag) const {
+    if (tag >= 0) return mk<T>(va[3 * tag], va[3 * tag + 1], va[3 * tag + 2]);
+    return ip->w0[-1 - tag];
+  }
+};
+
+template <typename T, int CAP>
+__device__ __forceinline__ EpaSaved<T, CAP>* resume_slot(const Work& wk, uint32_t slot) {
+  static_assert(sizeof(EpaSaved<T, CAP>) <= epa_resume_stride<T>, "hand-over slots hold any fast tier's polytope");
+  return reinterpret_cast<EpaSaved<T, CAP>*>(reinterpret_cast<char*>(wk.epa_resume) + size_t(slot) * epa_resume_stride<T>);
+}
+
 // TIER: 1 reads queue 1 and may push to queue 2; 2 reads queue 2 (never overflows: CAP = 64)
 template <typename T, int WE, int CAP, int TIER>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? (TIER == 1 ? HFCL_WPE_EPA32 : 2) : HFCL_WPE_EPA64, 8)))
@@ -40,9 +81,9 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   constexpr int G = 64 / WE;
   // the full-capacity tier keeps the shape-0 support points in global memory: its LDS block bounds the
   // occupancy (fp64: 45.5 KB -> 3 waves per CU with them, 36.5 KB -> 4 without)
-  constexpr bool V0IN = TIER == 1;
-  __shared__ EpaScratch<T, CAP, V0IN> scratch[G];
-  Quad<T>* const v0_ext = V0IN ? nullptr : reinterpret_cast<Quad<T>*>(wk.epa_v0) + size_t(blockIdx.x * G + threadIdx.x / WE) * (CAP + 4);
+  constexpr int V0M = TIER == 1 ? V0_BLOCK : V0_EXTERN;
+  __shared__ EpaScratch<T, CAP, V0M> scratch[G];
+  Quad<T>* const v0_ext = TIER == 1 ? nullptr : reinterpret_cast<Quad<T>*>(wk.epa_v0) + size_t(blockIdx.x * G + threadIdx.x / WE) * (CAP + 4);
   const uint32_t cnt = wk.counts[TIER == 1 ? B_COUNT : B_COUNT + 1];
   const int lane = threadIdx.x & 63, grp = lane / WE, lig = lane & (WE - 1);
   const uint32_t groups = gridDim.x * G;
@@ -70,8 +111,8 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
     int rc = 1;
     if constexpr (TIER == 2) {
       if (item.rank & EPA_RESUME_FLAG) {  // continue what the fast tier saved for this slot (the seed's rank is not used)
-        epa_resume<T, LaneGroup<WE>, epa_fast_cap<T>, CAP>(&scratch[grp], reinterpret_cast<const EpaScratch<T, epa_fast_cap<T>>*>(wk.epa_resume) + it,
-                                                         item, q, tf1, r0, r1, sup, o, v0_ext);
+        epa_resume<T, LaneGroup<WE>, epa_fast_cap<T>, CAP>(&scratch[grp], resume_slot<T, epa_fast_cap<T>>(wk, it), item, q, tf1, r0, r1,
+                                                         sup, o, v0_ext);
       } else {
         rc = epa_run<T, LaneGroup<WE>, CAP>(&scratch[grp], item, q, tf1, r0, r1, sup, o, v0_ext);
       }
@@ -91,7 +132,7 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
         if (lig == 0) slot = atomicAdd(&wk.counts[B_COUNT + 1], 1u);
         slot = __shfl(slot, 0, WE);
         const bool save = rc == 2 && slot < wk.resume_cap;
-        if (save) epa_save_block<T, LaneGroup<WE>, CAP>(&scratch[grp], reinterpret_cast<EpaScratch<T, CAP>*>(wk.epa_resume) + slot);
+        if (save) epa_save_block<T, LaneGroup<WE>, CAP>(&scratch[grp], resume_slot<T, CAP>(wk, slot));
         if (lig == 0) {  // queue to queue, no local copy (a local EpaItem lives in scratch memory)
           EpaItem<T>* dst = reinterpret_cast<EpaItem<T>*>(wk.epa_queue2) + slot;
           *dst = item;
@@ -103,7 +144,7 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   }
 }
 
-// Fast tier as a stream: the 64/WE lane groups of a wave walk through the wave's share of queue 1 and a
+// Fast tier as a stream: the 64/WE lane groups of a wave walk through the wave's share of the queue and a
 // group that is done does not wait for the slowest polytope of the wave (EPA runs 1 .. CAP trips per
 // polytope, mean ~7 on convex pairs: in lockstep batches of 8 only ~56 % of the trips are useful).
 // The wave alternates between two uniform phases:
@@ -112,28 +153,57 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
 //            the record of the polytope they finished (or hand it over to the full-capacity tier) and
 //            start the next item of the wave: seed, hulls, encloseOrigin, first tetrahedron (Epa::begin).
 // Batching the refills matters: a refill costs about 1.5 trips of the whole wave whoever takes part.
+//
+// CC = true: the convex x convex queue (the top end of epa_queue, slots n-1 downwards; filled by k_gjk_cvx<.,0>).  Both
+// shapes are hulls of <= 32 vertices, which lets the wave drop everything a trip does not need: no shape records,
+// no shape-0 support points (V0_TAG), pose and radii re-read when the record is written.  That and the 1.6 KB block
+// put three waves on a SIMD (two in the general form).
 #ifndef HFCL_EPA_REFILL_MIN
 #define HFCL_EPA_REFILL_MIN 3
 #endif
-template <typename T, int WE, int CAP>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_EPA32, 8)))
+#ifndef HFCL_WPE_EPA32_CC
+#define HFCL_WPE_EPA32_CC 3
+#endif
+template <typename T, int WE, int CAP, bool CC>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CC ? HFCL_WPE_EPA32_CC : HFCL_WPE_EPA32, 8)))
 k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   constexpr int G = 64 / WE;
+  constexpr int V0M = CC ? V0_TAG : V0_BLOCK;
   typedef LaneGroup<WE> Grp;
-  __shared__ EpaScratch<T, CAP> scratch[G];
-  const uint32_t cnt = wk.counts[B_COUNT];
+  __shared__ EpaScratch<T, CAP, V0M> scratch[G];
+#ifdef HFCL_EPA_PAD_LDS  // occupancy experiment: extra LDS per wave lowers the number of resident waves
+  __shared__ uint32_t lds_pad[HFCL_EPA_PAD_LDS / 4];
+  if (wk.n == 0xFFFFFFFFu) lds_pad[threadIdx.x] = wk.n;
+#endif
+  const uint32_t cnt = wk.counts[CC ? B_COUNT + 3 : B_COUNT];
   const int lane = threadIdx.x & 63, grp = lane / WE, lig = lane & (WE - 1);
-  const EpaItem<T>* queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
+  const EpaItem<T>* const queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
+  // item i of this kernel's queue
+  auto item_ptr = [&](uint32_t i) { return CC ? queue + (wk.n - 1u - i) : queue + i; };
   enum { IDLE = 0, LIVE = 1, DONE = 2, HANDOVER = 3 };
   int state = IDLE;
   uint32_t it = 0;              // queue slot of this group's polytope
   uint32_t next = blockIdx.x;   // wave-uniform: the wave's items are next, next + gridDim.x, ...
-  EpaSupport<T, WE, false> sup;
+  typename std::conditional<CC, EpaSupportCC<T, WE>, EpaSupport<T, WE, false>>::type sup;
   sup.lig = lig;
-  Epa<T, Grp, CAP> epa;
+  Epa<T, Grp, CAP, V0M> epa;
   EpaLoop<T> L;
-  Pose<T> tf1;
-  T r0 = T(0), r1 = T(0);
+  // what the record needs beyond the polytope is read again when it is written (a pose and two radii held across the
+  // trips are 14 registers of every lane)
+  auto finish = [&](const EpaResult<T>& res, const EpaItem<T>* ip) {
+    const uint32_t pair = ip->pair;
+    const Pose<T> tf1 = load_pose(io.tf1, pair);
+    const T r0 = swept_radius(lib.shapes[wk.shape1[pair]]), r1 = swept_radius(lib.shapes[wk.shape2[pair]]);
+    PairOut<T> o;
+    epa_finish(res, ip->gjk_iters, tf1, r0, r1, o);
+    if (lig == 0) {
+      write_out<T>(io, q, pair, o);
+      write_guess<T>(io, pair, o.cached_guess, 0, 0);
+    }
+  };
+  auto tags_of = [&](const EpaItem<T>* ip) {
+    return SeedTags<T>{lib.verts + 3 * size_t(lib.shapes[wk.shape1[ip->pair]].vertex_offset), ip};
+  };
   while (true) {
     const uint64_t live = __ballot(state == LIVE);
     const int n_live = __popcll(live) / WE;
@@ -142,26 +212,31 @@ k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
       // ---- refill phase (uniform decision; groups with a live polytope sit it out) ----
       if (state != LIVE) {
         if (state != IDLE) {
+          const EpaItem<T>* ip = item_ptr(it);
           if (state == DONE) {
+            const uint32_t pair = ip->pair;
+            const T ssr = swept_radius(lib.shapes[wk.shape1[pair]]) + swept_radius(lib.shapes[wk.shape2[pair]]);
             EpaResult<T> res;
-            epa.loop_result(L, r0 + r1, res);
-            PairOut<T> o;
-            epa_finish(res, queue[it].gjk_iters, tf1, r0, r1, o);
-            if (lig == 0) {
-              const uint32_t pair = queue[it].pair;
-              write_out<T>(io, q, pair, o);
-              write_guess<T>(io, pair, o.cached_guess, 0, 0);
-            }
+            if constexpr (CC)
+              epa.loop_result(L, ssr, res, tags_of(ip));
+            else
+              epa.loop_result(L, ssr, res);
+            finish(res, ip);
           } else {  // hand over to the full-capacity tier: the seed and, room permitting, the polytope itself
             uint32_t slot = 0;
             if (lig == 0) slot = atomicAdd(&wk.counts[B_COUNT + 1], 1u);
             slot = __shfl(slot, 0, WE);
             const bool save = epa.resumable && slot < wk.resume_cap;
-            if (save) epa_save_block<T, Grp, CAP>(&scratch[grp], reinterpret_cast<EpaScratch<T, CAP>*>(wk.epa_resume) + slot);
+            if (save) {
+              if constexpr (CC)
+                epa_save_block<T, Grp, CAP>(&scratch[grp], resume_slot<T, CAP>(wk, slot), tags_of(ip));
+              else
+                epa_save_block<T, Grp, CAP>(&scratch[grp], resume_slot<T, CAP>(wk, slot));
+            }
             if (lig == 0) {  // queue to queue, no local copy (a local EpaItem lives in scratch memory)
               EpaItem<T>* dst = reinterpret_cast<EpaItem<T>*>(wk.epa_queue2) + slot;
-              *dst = queue[it];
-              if (save) dst->rank = queue[it].rank | EPA_RESUME_FLAG;
+              *dst = *ip;
+              if (save) dst->rank = ip->rank | EPA_RESUME_FLAG;
             }
           }
           Grp::sync();
@@ -174,37 +249,37 @@ k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
         if (it < cnt) {
           // the seed is read field by field where it is used: as one struct it would sit in registers
           // across the hull loads and get spilled (1.6 KB of scratch traffic per polytope, measured)
-          const EpaItem<T>* ip = queue + it;
+          const EpaItem<T>* ip = item_ptr(it);
           const uint32_t pair = ip->pair;
-          sup.a = lib.shapes[wk.shape1[pair]];
-          sup.b = lib.shapes[wk.shape2[pair]];
-          if (sup.a.kind == K_CONVEX) sup.h0.load(lib.verts + 3 * size_t(sup.a.vertex_offset), sup.a.num_points, lig);
-          if (sup.b.kind == K_CONVEX) sup.h1.load(lib.verts + 3 * size_t(sup.b.vertex_offset), sup.b.num_points, lig);
-          tf1 = load_pose(io.tf1, pair);
-          const Pose<T> tf2 = load_pose(io.tf2, pair);
-          sup.md = make_mdiff(tf1, tf2);
-          r0 = swept_radius(sup.a);
-          r1 = swept_radius(sup.b);
+          {
+            const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+            if (CC || a.kind == K_CONVEX) sup.h0.load(lib.verts + 3 * size_t(a.vertex_offset), a.num_points, lig);
+            if (CC || b.kind == K_CONVEX) sup.h1.load(lib.verts + 3 * size_t(b.vertex_offset), b.num_points, lig);
+            if constexpr (!CC) {
+              sup.a = a;
+              sup.b = b;
+            }
+            sup.md = make_mdiff(load_pose(io.tf1, pair), load_pose(io.tf2, pair));
+          }
           epa.reset(&scratch[grp], q.epa_max_iterations, q.epa_tolerance);
-          epa.set_vert(0, ip->w[0], ip->w0[0]);
-          epa.set_vert(1, ip->w[1], ip->w0[1]);
-          epa.set_vert(2, ip->w[2], ip->w0[2]);
-          epa.set_vert(3, ip->w[3], ip->w0[3]);
+          epa.set_vert(0, ip->w[0], ip->w0[0], -1);
+          epa.set_vert(1, ip->w[1], ip->w0[1], -2);
+          epa.set_vert(2, ip->w[2], ip->w0[2], -3);
+          epa.set_vert(3, ip->w[3], ip->w0[3], -4);
           Grp::sync();
           EpaResult<T> res;
-          const int closest0 = epa.begin(ip->rank, -ip->guess, sup, res);
+          int closest0;
+          if constexpr (CC)
+            closest0 = epa.begin(ip->rank, -ip->guess, sup, res, tags_of(ip));
+          else
+            closest0 = epa.begin(ip->rank, -ip->guess, sup, res);
           if (closest0 != EPA_NULL) {
             epa.loop_enter(L, closest0, 0, 0);
             state = LIVE;
           } else if (epa.overflow) {
             state = HANDOVER;  // (a block too small for the first tetrahedron: not with CAP >= 1)
           } else {  // FallBack: final without a loop
-            PairOut<T> o;
-            epa_finish(res, ip->gjk_iters, tf1, r0, r1, o);
-            if (lig == 0) {
-              write_out<T>(io, q, pair, o);
-              write_guess<T>(io, pair, o.cached_guess, 0, 0);
-            }
+            finish(res, ip);
           }
         }
       }
@@ -226,18 +301,44 @@ k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
 // =======================================================================================
 // launchers (hfcl_launch.hpp)
 // =======================================================================================
-// fp32 streams (two waves per SIMD hide the refill's global loads: k_epa<fast> 1.87 -> 1.76 ms on cfg3);
+// fp32 streams (two or three waves per SIMD hide the refill's global loads: k_epa<fast> 1.87 -> 1.76 ms on cfg3);
 // fp64 runs one wave per SIMD, where the more frequent refills cost more than the idle groups (cfg5
 // 1.27 -> 1.55 ms), and stays with the batch form
-template <typename T>
-void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {
-  if constexpr (sizeof(T) == 4)
-    hipLaunchKernelGGL((k_epa_stream<T, EPA_WE, EPA_FAST_CAP>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
-  else
-    hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_fast_cap<T>, 1>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
+// The streaming kernels are persistent (every wave walks through its share of the queue), so their grid is sized from
+// the number of waves the chip holds at once: HFCL_EPA_GRID_ROUNDS x that (1 round: the slowest wave decides and there
+// is nothing to fill its tail with, 1.755 ms; 2 rounds: 1.679 ms on cfg3; a grid that is not a multiple -- 16 waves per
+// CU with 11 or 12 resident -- runs its last round nearly empty).  The runtime's occupancy query over-estimates what
+// the LDS admits: the hardware hands LDS out in 1280-byte units (160 KB / 128; tools/occupancy_probe.hip,
+// profiles/r02_g: 13184 B -> 11 workgroups per CU where the API says 12), so that bound is applied here.
+#ifndef HFCL_EPA_GRID_ROUNDS
+#define HFCL_EPA_GRID_ROUNDS 2
+#endif
+template <class K>
+static int resident_blocks_per_cu(K kernel) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kernel), 64, 0) != hipSuccess || nb < 1) nb = 8;
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) == hipSuccess && fa.sharedSizeBytes > 0) {
+    const int units = int((fa.sharedSizeBytes + 1279) / 1280);
+    nb = std::min(nb, 128 / units);
+  }
+  return std::max(nb, 1);
 }
-template void launch_epa_fast<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&);
-template void launch_epa_fast<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&);
+template <typename T>
+void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool cc_queue, bool general_queue, int n_cus) {
+  if constexpr (sizeof(T) == 4) {
+    static const int per_cu_cc = resident_blocks_per_cu(k_epa_stream<T, EPA_WE, EPA_FAST_CAP, true>);
+    static const int per_cu_gen = resident_blocks_per_cu(k_epa_stream<T, EPA_WE, EPA_FAST_CAP, false>);
+    if (cc_queue)
+      hipLaunchKernelGGL((k_epa_stream<T, EPA_WE, EPA_FAST_CAP, true>), dim3(std::min(grid, n_cus * per_cu_cc * HFCL_EPA_GRID_ROUNDS)), dim3(64), 0, st, wk, lv, io, q);
+    if (general_queue)
+      hipLaunchKernelGGL((k_epa_stream<T, EPA_WE, EPA_FAST_CAP, false>), dim3(std::min(grid, n_cus * per_cu_gen * HFCL_EPA_GRID_ROUNDS)), dim3(64), 0, st, wk, lv, io, q);
+  } else {
+    hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_fast_cap<T>, 1>), dim3(std::min(grid, n_cus * 16)), dim3(64), 0, st, wk, lv, io, q);
+  }
+}
+template void launch_epa_fast<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&, bool, bool, int);
+template void launch_epa_fast<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&, bool, bool, int);
 
 template <typename T>
 void launch_epa_full(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {

@@ -150,17 +150,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_W
 template <typename T, class P, class PS>
 __device__ __forceinline__ void finish_gjk(const Gjk<T, P>& g, const Work& wk, const IO<T>& io, const QParams<T>& q,
                                            uint32_t pair, const Pose<T>& tf1, T r0, T r1, const V3<T>& guess0,
-                                           bool writer, const PS& ps, bool full_tier = false) {
+                                           bool writer, const PS& ps, bool full_tier = false, bool cc_queue = false) {
   PairOut<T> o;
   EpaSeed<T> seed;
   const bool to_epa = gjk_finish(g, q, tf1, r0, r1, guess0, o, seed, ps);
   if (!writer) return;
   if (to_epa) {
-    // full_tier: straight to the full-capacity EPA queue (pairs with a large hull: only that tier
-    // can scan vertices from memory)
-    const uint32_t slot = atomicAdd(&wk.counts[full_tier ? B_COUNT + 1 : B_COUNT], 1u);
     seed.pair = pair;
-    reinterpret_cast<EpaSeed<T>*>(full_tier ? wk.epa_queue2 : wk.epa_queue)[slot] = seed;
+    if (cc_queue) {
+      // fp32 convex x convex pairs have a fast tier of their own (k_epa_stream<.., CC>): its queue is the top end of
+      // epa_queue, filled downwards from slot n-1 (the two queues of a batch hold at most n items together)
+      const uint32_t slot = atomicAdd(&wk.counts[B_COUNT + 3], 1u);
+      reinterpret_cast<EpaSeed<T>*>(wk.epa_queue)[wk.n - 1u - slot] = seed;
+    } else {
+      // full_tier: straight to the full-capacity EPA queue (pairs with a large hull: only that tier
+      // can scan vertices from memory)
+      const uint32_t slot = atomicAdd(&wk.counts[full_tier ? B_COUNT + 1 : B_COUNT], 1u);
+      reinterpret_cast<EpaSeed<T>*>(full_tier ? wk.epa_queue2 : wk.epa_queue)[slot] = seed;
+    }
   } else {
     write_out<T>(io, q, pair, o);
     write_guess<T>(io, pair, o.cached_guess, 0, 0);
@@ -314,7 +321,7 @@ __device__ __forceinline__ void gjk_cvx_body(const Work& wk, const LibView<T>& l
       gjk_run(g, q.gjk, start_guess(q, sup.a, sup.b, sup.md, guess0), r0 + r1, M == 0, sup, ps);
     else
       gjk_run(g, q.gjk, guess0, r0 + r1, M == 0, sup, ps);
-    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0, ps);
+    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0, ps, false, sizeof(T) == 4 && M == 0);
   }
 }
 

@@ -29,7 +29,9 @@ void launch_fill_skipped(hipStream_t st, hfcl_result* out, uint32_t n);
 void launch_fill_skipped(hipStream_t st, hfcl_result_f32* out, uint32_t n);
 
 // tier 1 (fp32: streaming form) and tier 2 of EPA; the grids are in blocks of one wavefront
-template <typename T> void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q);
+// cc_queue / general_queue (fp32): which of the two streaming forms have anything to do (convex x convex pairs have a
+// queue and a kernel of their own)
+template <typename T> void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool cc_queue, bool general_queue, int n_cus);
 template <typename T> void launch_epa_full(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q);
 
 template <typename T> void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2);

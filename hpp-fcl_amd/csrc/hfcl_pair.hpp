@@ -176,10 +176,11 @@ HFCL_HD void epa_finish(const EpaResult<T>& res, const EpaSeed<T>& seed, const P
 // the polytope outgrew the CAP-sized scratch block and must be redone by the full-capacity kernel; 2 when
 // it outgrew the block at an iteration boundary: the scratch block (incl. its hdr) then describes it
 // completely and the full-capacity kernel can continue it (epa_resume).
-template <typename T, class Grp, int CAP, class Sup, bool V0IN>
-HFCL_HD int epa_run(EpaScratch<T, CAP, V0IN>* scratch, const EpaSeed<T>& seed, const QParams<T>& q, const Pose<T>& tf1, T r0,
+template <typename T, class Grp, int CAP, class Sup, int V0M>
+HFCL_HD int epa_run(EpaScratch<T, CAP, V0M>* scratch, const EpaSeed<T>& seed, const QParams<T>& q, const Pose<T>& tf1, T r0,
                     T r1, Sup& sup, PairOut<T>& out, Quad<T>* v0_ext = nullptr) {
-  Epa<T, Grp, CAP, V0IN> epa;
+  static_assert(V0M != V0_TAG, "the batch form keeps coordinates");
+  Epa<T, Grp, CAP, V0M> epa;
   epa.reset(scratch, q.epa_max_iterations, q.epa_tolerance, v0_ext);
   // all four slots are written (slots >= rank are scratch that encloseOrigin overwrites): constant
   // indices keep the seed in registers
@@ -196,10 +197,10 @@ HFCL_HD int epa_run(EpaScratch<T, CAP, V0IN>* scratch, const EpaSeed<T>& seed, c
 }
 
 // Continue a polytope a CAP_SRC-tier saved (blob) in a CAP-sized block.  CAP must be the reference capacity.
-template <typename T, class Grp, int CAP_SRC, int CAP, class Sup, bool V0IN>
-HFCL_HD void epa_resume(EpaScratch<T, CAP, V0IN>* scratch, const EpaScratch<T, CAP_SRC>* blob, const EpaSeed<T>& seed,
+template <typename T, class Grp, int CAP_SRC, int CAP, class Sup, int V0M>
+HFCL_HD void epa_resume(EpaScratch<T, CAP, V0M>* scratch, const EpaSaved<T, CAP_SRC>* blob, const EpaSeed<T>& seed,
                         const QParams<T>& q, const Pose<T>& tf1, T r0, T r1, Sup& sup, PairOut<T>& out, Quad<T>* v0_ext = nullptr) {
-  Epa<T, Grp, CAP, V0IN> epa;
+  Epa<T, Grp, CAP, V0M> epa;
   epa.reset(scratch, q.epa_max_iterations, q.epa_tolerance, v0_ext);
   const EpaHeader h = epa.template load<CAP_SRC>(blob);
   EpaResult<T> res;

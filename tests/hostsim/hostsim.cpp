@@ -104,7 +104,8 @@ static void one_pair(const DShape<T>& a, const DShape<T>& b, const T* verts, con
     if (gjk_finish(g, q, tf1, r0, r1, guess0, o, seed)) {
       // same two-tier scheme as the kernels: small-capacity block first; on overflow the polytope is saved
       // and continued in the full-capacity block (or redone there when it is not at an iteration boundary)
-      static thread_local EpaScratch<T, 20> small, saved;
+      static thread_local EpaScratch<T, 20> small;
+      static thread_local EpaSaved<T, 20> saved;
       static thread_local EpaScratch<T, EPA_MAX_ITER> full;
       const int rc = epa_run<T, SerialGroup<1>, 20>(&small, seed, q, tf1, r0, r1, sup, o);
       if (rc == 2) {
