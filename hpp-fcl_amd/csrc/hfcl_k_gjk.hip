@@ -418,6 +418,24 @@ __global__ void k_fill_skipped<hfcl_result>(hfcl_result* out, uint32_t n) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// compact host poses (quaternion w,x,y,z + translation, 7 doubles) -> the 12-double Transform3f image the fp64
+// kernels read (column-major R, then T).  Runs on the device so that only 56 bytes per pose cross the host link.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_expand_poses(const double* qt, double* tf, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const Pose<double> p = pose_from_quat<double, double>(qt + 7 * size_t(i));
+    double* o = tf + 12 * size_t(i);
+    o[0] = p.R.r0.x; o[1] = p.R.r1.x; o[2] = p.R.r2.x;
+    o[3] = p.R.r0.y; o[4] = p.R.r1.y; o[5] = p.R.r2.y;
+    o[6] = p.R.r0.z; o[7] = p.R.r1.z; o[8] = p.R.r2.z;
+    o[9] = p.t.x; o[10] = p.t.y; o[11] = p.t.z;
+  }
+}
+void launch_expand_poses(hipStream_t st, const double* qt, double* tf, uint32_t n) {
+  hipLaunchKernelGGL(k_expand_poses, dim3(1024), dim3(256), 0, st, qt, tf, n);
+}
+
 // =======================================================================================
 // launchers (hfcl_launch.hpp)
 // =======================================================================================

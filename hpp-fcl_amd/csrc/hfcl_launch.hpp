@@ -25,6 +25,8 @@ template <typename T> void launch_gjk_prim(int grid, hipStream_t st, const Work&
 // m: 0 = convex-convex, 1 = prim-convex, 2 = convex-prim; w: lanes per pair (2 / 4 / 8 / 16 / 32 / 64)
 template <typename T> void launch_gjk_cvx(int m, int w, bool bvg, int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q);
 template <typename T> void launch_gjk_large(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool bvg);
+// 7-double (quaternion w,x,y,z + translation) poses -> 12-double Transform3f images
+void launch_expand_poses(hipStream_t st, const double* qt, double* tf, uint32_t n);
 void launch_fill_skipped(hipStream_t st, hfcl_result* out, uint32_t n);
 void launch_fill_skipped(hipStream_t st, hfcl_result_f32* out, uint32_t n);
 

@@ -124,7 +124,7 @@ template <typename T> HFCL_HD Pose<T> pose_from_abi(const double* p) {
   return r;
 }
 // compact fp32 pose: quaternion (w,x,y,z) + translation; Eigen Quaternion::toRotationMatrix order
-template <typename T> HFCL_HD Pose<T> pose_from_quat(const float* p) {
+template <typename T, typename S = float> HFCL_HD Pose<T> pose_from_quat(const S* p) {
   T w = T(p[0]), x = T(p[1]), y = T(p[2]), z = T(p[3]);
   T tx = T(2) * x, ty = T(2) * y, tz = T(2) * z;
   T twx = tx * w, twy = ty * w, twz = tz * w;

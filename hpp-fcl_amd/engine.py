@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = [
     "hfcl_collide_batch_contacts", "hfcl_last_kernel_ms", "hfcl_last_kernel_name", "hfcl_bvh_build",
     "hfcl_world_aabbs", "hfcl_broadphase_self_pairs", "hfcl_broadphase_pairs_between", "hfcl_pairlist_size",
     "hfcl_pairlist_data", "hfcl_pairlist_free", "hfcl_lib_set_kernel_timing", "hfcl_pair_supported", "hfcl_last_kernel_breakdown", "hfcl_last_bucket_counts", "hfcl_lib_set_split", "hfcl_lib_get_split", "hfcl_lib_last_split_parts",
+    "hfcl_collide_batch_qt", "hfcl_distance_batch_qt", "hfcl_lib_set_host_chunk",
 ]
 
 
@@ -194,11 +195,11 @@ class Library:
         return out, contacts[:min(nc.value, max_contacts)], int(nc.value)
 
     # ---- host-buffer entry points (H2D + kernels + D2H inside the call) ----
-    def _host(self, fn, s1, s2, tf1, tf2, req, guess_in, want_guess):
+    def _host(self, fn, s1, s2, tf1, tf2, req, guess_in, want_guess, pose_width=12):
         s1 = np.ascontiguousarray(s1, dtype=np.uint32)
         s2 = np.ascontiguousarray(s2, dtype=np.uint32)
-        tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
-        tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
+        tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, pose_width)
+        tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, pose_width)
         n = len(s1)
         if not (len(s2) == n and len(tf1) == n and len(tf2) == n):
             raise ValueError("batch arrays must have equal length")
@@ -220,6 +221,20 @@ class Library:
         """Batched hpp::fcl::distance (src/distance.cpp:60-109)."""
         return self._host(dll().hfcl_distance_batch, s1, s2, tf1, tf2, req or abi.default_distance_request(),
                           guess_in, want_guess)
+
+    def collide_qt(self, s1, s2, pose1, pose2, req=None, guess_in=None, want_guess=False):
+        """collide() with compact host poses: (n, 7) float64 = quaternion (w, x, y, z) + translation."""
+        return self._host(dll().hfcl_collide_batch_qt, s1, s2, pose1, pose2, req or abi.default_collision_request(),
+                          guess_in, want_guess, pose_width=7)
+
+    def distance_qt(self, s1, s2, pose1, pose2, req=None, guess_in=None, want_guess=False):
+        """distance() with compact host poses: (n, 7) float64 = quaternion (w, x, y, z) + translation."""
+        return self._host(dll().hfcl_distance_batch_qt, s1, s2, pose1, pose2, req or abi.default_distance_request(),
+                          guess_in, want_guess, pose_width=7)
+
+    def set_host_chunk(self, pairs):
+        """Pairs per chunk of the host-buffer pipeline (0 = automatic)."""
+        dll().hfcl_lib_set_host_chunk(self._h, C.c_size_t(int(pairs)))
 
     # ---- device-resident entry points (torch tensors or raw device pointers) ----
     def collide_device(self, d_s1, d_s2, d_tf1, d_tf2, n, req, d_out, d_gin=None, d_gout=None, stream=0):

@@ -65,6 +65,15 @@ class Batch:
     def pose2_f32(self):
         return geometry.pose_f32_from_quat(self.quat2, self.T2)
 
+    @property
+    def pose1_qt(self):
+        """(n, 7) float64 compact host poses (quaternion w, x, y, z + translation) for the *_qt entry points."""
+        return np.concatenate([np.asarray(self.quat1, dtype=np.float64), np.asarray(self.T1, dtype=np.float64)], axis=-1)
+
+    @property
+    def pose2_qt(self):
+        return np.concatenate([np.asarray(self.quat2, dtype=np.float64), np.asarray(self.T2, dtype=np.float64)], axis=-1)
+
     def tf_from_f32(self):
         """fp64 poses built from the *rounded* fp32 quaternion/translation (what the fp32 path sees)."""
         p1, p2 = self.pose1_f32.astype(np.float64), self.pose2_f32.astype(np.float64)

@@ -274,7 +274,10 @@ void hfcl_pairlist_free(hfcl_pairlist* pl);
 /* ---- batched queries, host buffers (H2D + kernels + D2H inside the call) ------------
  * shape1/shape2: n indices into the library; tf1/tf2: n poses (12 doubles each).
  * guess_in / guess_out: NULL or n records (used when q.gjk_initial_guess == CachedGuess).
- * Replaces: collide() src/collision.cpp:69-130 ; distance() src/distance.cpp:60-109. */
+ * Replaces: collide() src/collision.cpp:69-130 ; distance() src/distance.cpp:60-109.
+ * The batch flows through a chunked three-stage pipeline on three internal streams (H2D of chunk k+1 | kernels of
+ * chunk k | D2H of chunk k-1, straight from / to the caller's arrays); the call returns when every record is in `out`.
+ * It synchronises its own streams only, never the device. */
 int hfcl_collide_batch(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2,
                        const double* tf1, const double* tf2, size_t n,
                        const hfcl_collision_request* req, hfcl_result* out,
@@ -284,6 +287,21 @@ int hfcl_distance_batch(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* s
                         const double* tf1, const double* tf2, size_t n,
                         const hfcl_distance_request* req, hfcl_result* out,
                         const hfcl_guess* guess_in, hfcl_guess* guess_out);
+
+/* Same calls with compact poses: 7 doubles per pose = unit quaternion (w, x, y, z: the order of the fp32 device path
+ * below; Transform3f::getQuatRotation(), math/transform.h:108) followed by the translation.  112 instead of 192
+ * bytes of pose per pair over the host link, which bounds the host-buffer entry points; the rotation matrix is rebuilt
+ * on the device exactly as Eigen's Quaternion::toRotationMatrix does. */
+int hfcl_collide_batch_qt(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2,
+                          const double* pose1, const double* pose2, size_t n,
+                          const hfcl_collision_request* req, hfcl_result* out,
+                          const hfcl_guess* guess_in, hfcl_guess* guess_out);
+int hfcl_distance_batch_qt(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2,
+                           const double* pose1, const double* pose2, size_t n,
+                           const hfcl_distance_request* req, hfcl_result* out,
+                           const hfcl_guess* guess_in, hfcl_guess* guess_out);
+/* pairs per chunk of the host-buffer pipeline; 0 = automatic (n/8 clamped to 32k .. 256k) */
+void hfcl_lib_set_host_chunk(hfcl_lib* lib, size_t pairs);
 
 /* ---- batched queries, device-resident buffers (no copies; asynchronous on `stream`,
  * a hipStream_t passed as void*; NULL = the null stream).  All pointers are device

@@ -251,6 +251,7 @@ def test_split_batches_are_bit_identical(pkg, torch_cuda, case):
     b = getattr(wl, case)(n=300_001)
     req = wl.make_request(b, abi)
     lib = pkg.Library(b.lib)
+    lib.set_host_chunk(len(b))  # the host entry points pipeline chunks; here the batch is one chunk (chunking: its own test)
     fn = lib.distance if b.kind == "distance" else lib.collide
     lib.set_split(1)
     one, g1 = fn(b.s1, b.s2, b.tf1, b.tf2, req, want_guess=True)
@@ -282,6 +283,49 @@ def test_split_batches_are_bit_identical(pkg, torch_cuda, case):
         torch.cuda.synchronize()
         outs.append((o.cpu().numpy(), o2.cpu().numpy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[1][0], outs[1][1])
+    lib.close()
+
+
+@pytest.mark.parametrize("case", ["cfg2_box_capsule", "cfg5_mixed", "cfg3_convex_convex"])
+def test_host_pipeline_equals_device_path(pkg, torch_cuda, case):
+    """The host-buffer entry points (chunked H2D | kernels | D2H pipeline, what hpp::fcl::collide()/distance() callers
+    get) return byte-identical records, warm-start guesses and bucket populations to one device-resident call, for
+    any chunk size (ragged last chunk, more chunks than pipeline slots, split chunks)."""
+    torch = torch_cuda
+    abi, wl = pkg.abi, pkg.workloads
+    b = getattr(wl, case)(n=300000)
+    req = wl.make_request(b, abi)
+    lib = pkg.Library(b.lib)
+    dev = torch.device("cuda:0")
+    n = len(b)
+    d = [torch.from_numpy(x).to(dev) for x in (b.s1.astype(np.int32), b.s2.astype(np.int32), b.tf1, b.tf2)]
+    d_out = torch.zeros(n * 24, dtype=torch.int32, device=dev)
+    d_g = torch.zeros(n * 8, dtype=torch.int32, device=dev)
+    fn_dev = lib.distance_device if b.kind == "distance" else lib.collide_device
+    lib.set_split(1)
+    fn_dev(*d, n, req, d_out, d_gout=d_g, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = d_out.cpu().numpy().view(abi.RESULT_DTYPE)
+    ref_g = d_g.cpu().numpy().view(abi.GUESS_DTYPE)
+    ref_counts = lib.last_bucket_counts()
+    fn_host = lib.distance if b.kind == "distance" else lib.collide
+    for chunk, split in ((0, 1), (7777, 1), (70001, 1), (150000, 2), (n, 1)):
+        lib.set_host_chunk(chunk)
+        lib.set_split(split)
+        got, g = fn_host(b.s1, b.s2, b.tf1, b.tf2, req, want_guess=True)
+        assert got.tobytes() == ref.tobytes(), "records differ (chunk %d)" % chunk
+        assert g.tobytes() == ref_g.tobytes(), "guesses differ (chunk %d)" % chunk
+        assert lib.last_bucket_counts() == ref_counts, "bucket populations differ (chunk %d)" % chunk
+    # compact poses (quaternion + translation): the rotation is rebuilt on the device, so only round-off may differ
+    lib.set_host_chunk(0)
+    fn_qt = lib.distance_qt if b.kind == "distance" else lib.collide_qt
+    got = fn_qt(b.s1, b.s2, b.pose1_qt, b.pose2_qt, req)
+    ok = np.isfinite(ref["distance"]) & (np.abs(ref["distance"]) < 1e300)
+    assert np.array_equal(np.isfinite(got["distance"]), np.isfinite(ref["distance"]))
+    dd = np.abs(got["distance"][ok] - ref["distance"][ok])
+    assert dd.max() < 1e-9, dd.max()
+    near = np.abs(ref["distance"]) < 1e-9
+    assert np.all((abi.status_contact(got["status"]) == abi.status_contact(ref["status"])) | near)
     lib.close()
 
 
