@@ -2,19 +2,28 @@
 """bench.py -- queries/second of the batched narrow phase on N MI355X (one process per GPU).
 
 A "step" is one pass of the hot path over one batch of synthetic pairs that is already resident
-in HBM: classify -> GJK kernels -> EPA kernel, through the C ABI's device-resident entry point.
-Default workload = BASELINE.json configs[2] (the configuration north_star's target is quoted on):
-1M Convex-Convex (32-vertex hulls, shared 4096-hull library) distance() queries, signed
-distance (GJK+EPA), Nesterov acceleration, fp32.  `--workload cfg2` runs configs[1]
-(1M Box-Capsule collide(), fp64) instead.
+in HBM: classify -> GJK kernels -> EPA kernels (or the BVH traversal), through the C ABI's device-resident entry point.
 
-N > 1 (launched by torch.distributed.run): every rank owns its own 1M-pair shard (weak scaling,
-different seed per rank) and the per-shard result records are all-gathered over RCCL/xGMI
-(north_star), overlapped with the next step's kernels on a separate stream.
+Headline (the `value` of the JSON line) = BASELINE.json configs[2], the configuration north_star's target is quoted on:
+1M Convex-Convex (32-vertex hulls, shared 4096-hull library) distance() queries, signed distance (GJK+EPA), Nesterov
+acceleration, fp32.  Without `--workload` the line also carries `secondary`: the other BASELINE configurations, each with
+its own timed region, roofline and (trimmed) CPU baseline --
+  cfg2  1M Box-Capsule collide(), fp64 (+ the same batch through the host-buffer boundary, `host_buffers`)
+  cfg4  100k BVHModel<OBBRSS> mesh-mesh collide(), fp64
+  cfg5  1.25M (= 10M / 8) mixed pairs from the host broadphase, fp64, per GPU (weak)
+  cfg5_strong  ONE 10M-pair list from the host broadphase, sharded over the ranks with sharding.shard_range and its
+        real records all-gathered (north_star's configs[4] as written; `--scaling strong --workload cfg5 --pairs 10000000`
+        runs it as the headline)
+`--workload X` runs X alone as the headline (used by the profiling tools).
+
+N > 1 (launched by torch.distributed.run): weak scaling -- every rank owns its own shard (different seed per rank) --
+and the per-shard result records are all-gathered over RCCL/xGMI (north_star) on a separate stream, overlapped with the
+next step's kernels.  `--scaling strong`: one list, rank r owns sharding.shard_range(n, r, world).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,6 +36,8 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_pkg  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# Link rates of the GPU box measured with tools/valu_peak.hip (profiles/r02_a): one direction at a time / both at once
+LINK_H2D_GBS, LINK_D2H_GBS, LINK_BOTH_GBS = 57.4, 57.0, 2 * 37.6
 
 # ALGORITHMIC bytes per query (DESIGN.md "Measurement"): compulsory traffic only
 BYTES_PER_QUERY = {
@@ -45,6 +56,15 @@ BYTES_PER_QUERY = {
 }
 CFG4_BYTES_PER_BV_TEST = 2 * 128
 CFG4_BYTES_PER_LEAF_TEST = 2 * (3 * 24 + 12)
+DEFAULT_PAIRS = {"cfg4": 100_000, "cfg5": 1_250_000, "cfg1": 4_000_000}
+BASELINE_CONFIG = {"cfg3": "configs[2]", "cfg2": "configs[1]", "cfg4": "configs[3]", "cfg5": "configs[4]",
+                   "cfg1": "configs[0] (shape pair; GPU batch size)", "cfg3u": "configs[2], one hull pair per query"}
+
+# VALU issue peak, MEASURED on the box (tools/valu_peak.hip, profiles/r02_a_valu_issue_peak.txt): the select / compare /
+# fma mix these kernels are made of tops out at 1.00e12 wave64 instructions per second chip-wide with 8 waves per SIMD
+# (0.96e12 with 2; pure v_fma_f32: 0.88e12, the clock drops to ~2.0 GHz; fp64 FMA: 0.56e12).  The guide's nominal figure
+# (a wave64 VALU op every 2 clocks at 2.4 GHz) is 1.229e12.  Round 1 priced against 0.614e12 (4 clocks): wrong.
+VALU_ISSUE_PEAK = 1.0e12
 
 
 def parse():
@@ -52,19 +72,29 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg4", "cfg5", "cfg1", "cfg3u"])
-    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default 1M; cfg4: 100k; cfg5: 1.25M = 10M / 8)")
+    ap.add_argument("--workload", default=None, choices=["cfg3", "cfg2", "cfg4", "cfg5", "cfg1", "cfg3u"],
+                    help="run this workload alone as the headline (default: cfg3 + the secondary list)")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default 1M; cfg4: 100k; cfg5: 1.25M = 10M / 8); "
+                    "with --scaling strong: pairs of the whole job")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of result records (N>1)")
     ap.add_argument("--split", type=int, default=0, help="0: the library decides (two half-batches on two streams for "
                     "mixed libraries); 1: one stream; 2: always split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     return ap.parse_args()
 
 
-# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles (16 lanes per SIMD) at the 2.4 GHz
-# peak clock (MI355X_MICROARCH.md) = 614 G wave-instructions/s.  Packed / dual-issue forms are not assumed.
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4
+def kernel_source_sha():
+    """Fingerprint of the device code: a committed PMC pass is only quoted for the code it was taken on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "hpp-fcl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load_traffic(workload, dominant, n, want="traffic"):
@@ -72,18 +102,22 @@ def load_traffic(workload, dominant, n, want="traffic"):
     (tools/measure_traffic.py -> profiles/traffic_<workload>.json; FETCH_SIZE / WRITE_SIZE in KB).
     gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE tallies 128-B requests at
     64 B, exact x2 for wide streaming reads and uncalibrated otherwise -> we report
-    2 x FETCH + WRITE (upper bound) and keep the raw figures in the note."""
+    2 x FETCH + WRITE (upper bound) and keep the raw figures in the note.
+    The pass is only used when it was taken on the present device code (`source_sha`) and batch size: a kernel change that
+    was not re-profiled yields traffic = null, never stale counters."""
     import re
     path = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
     if not os.path.exists(path):
         return None, "no PMC pass committed for this workload"
     t = json.load(open(path))
-    default_n = {"cfg4": 100_000, "cfg5": 1_250_000, "cfg1": 4_000_000}.get(workload, 1_000_000)
-    if (t.get("pairs") or default_n) != n:
+    if (t.get("pairs") or DEFAULT_PAIRS.get(workload, 1_000_000)) != n:
         return None, "PMC pass was taken at a different batch size"
+    if t.get("source_sha") != kernel_source_sha():
+        return None, "committed PMC pass (%s) was taken on other device code (source_sha %s, now %s): re-run tools/measure_traffic.py" % (
+            os.path.relpath(path, ROOT), t.get("source_sha"), kernel_source_sha())
     m = re.match(r"(k_\w+)(?:<(\w+)>)?", dominant)
     base, tag = m.group(1), m.group(2)
-    sel = {"fast": ", 1>(", "full": ", 2>(", "cc": ", 0>(", "pc": ", 1>(", "cp": ", 2>("}.get(tag, "")
+    sel = {"fast": ", 1>(", "full": ", 2>(", "cc": ", 0, ", "pc": ", 1, ", "cp": ", 2, "}.get(tag, "")
     for name, v in t["kernels"].items():
         hit = base + "<" in name and sel in name
         if tag == "fast" and "k_epa_stream<" in name:  # the fp32 fast tier is the streaming form of the same kernel
@@ -100,65 +134,96 @@ def load_traffic(workload, dominant, n, want="traffic"):
     return None, "kernel not found in " + os.path.relpath(path, ROOT)
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
+class Ctx:
+    pass
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" %
-                             (args.gpus, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # HFCL_BENCH_FORCE_DIST=1: run the N>1 code path (RCCL group, comm stream, async all-gather, barriers, max over
-    # ranks) with a single rank -- a dry run of the multi-GPU plumbing on a 1-GPU box
-    dist_on = world > 1 or os.environ.get("HFCL_BENCH_FORCE_DIST") == "1"
-    if dist_on:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
-    pkg = load_pkg()
-    abi, wl = pkg.abi, pkg.workloads
-    n = args.pairs or {"cfg4": 100_000, "cfg5": 1_250_000, "cfg1": 4_000_000}.get(args.workload, 1_000_000)
-    if args.workload == "cfg3":
-        batch = wl.cfg3_convex_convex(n=n, seed=1 + rank)
-        dtype = "f32"
-    elif args.workload == "cfg3u":
-        batch = wl.cfg3_unique_hulls(n=n, seed=1 + rank)
-        dtype = "f32"
-    elif args.workload == "cfg1":
-        batch = wl.cfg1_sphere_sphere(n=n, seed=1 + rank)
-        dtype = "f64"
-    elif args.workload == "cfg2":
-        batch = wl.cfg2_box_capsule(n=n, seed=1 + rank)
-        dtype = "f64"
-    elif args.workload == "cfg5":
-        # pair list = host broadphase over a scene of n/10 posed objects (not in the timed region);
-        # every rank owns its own scene shard; the list is cut to exactly n pairs
+def make_batch(ctx, workload, n, strong):
+    """The synthetic batch of this rank: (batch, dtype, extra config).  weak: own seed per rank; strong: one list
+    (same seed everywhere), rank r keeps sharding.shard_range(n, r, world)."""
+    wl, pkg = ctx.pkg.workloads, ctx.pkg
+    seed = 1 if strong else 1 + ctx.rank
+    extra = {}
+    if workload == "cfg3":
+        batch, dtype = wl.cfg3_convex_convex(n=n, seed=seed), "f32"
+    elif workload == "cfg3u":
+        batch, dtype = wl.cfg3_unique_hulls(n=n, seed=seed), "f32"
+    elif workload == "cfg1":
+        batch, dtype = wl.cfg1_sphere_sphere(n=n, seed=seed), "f64"
+    elif workload == "cfg2":
+        batch, dtype = wl.cfg2_box_capsule(n=n, seed=seed), "f64"
+    elif workload == "cfg5":
+        # pair list = host broadphase over a scene of n/10 posed objects (not in the timed region); the list is cut to
+        # exactly n pairs.  Several ranks on one host share its cores.
         over = 1.15
+        threads = max(1, (os.cpu_count() or 1) // max(1, ctx.world))
         while True:
             t_bp = time.perf_counter()
-            batch = wl.cfg5_broadphase_scene(n_objects=max(n // 10, 100), target_pairs=int(over * n), seed=1 + rank)
+            batch = wl.cfg5_broadphase_scene(n_objects=max(n // 10, 100), target_pairs=int(over * n), seed=seed, n_threads=threads)
             t_bp = time.perf_counter() - t_bp
             if len(batch) >= n:
                 break
             over *= 1.3
-        scene = {"objects": batch.scene["n_objects"], "broadphase_pairs": len(batch), "host_broadphase_s": t_bp}
+        extra = {"objects": batch.scene["n_objects"], "broadphase_pairs": len(batch), "host_broadphase_s": t_bp}
         batch = batch.slice(0, n)
-        batch.scene = scene
         dtype = "f64"
     else:
-        batch = wl.cfg4_mesh_mesh(n=n, seed=1 + rank)
-        dtype = "f64"
+        batch, dtype = wl.cfg4_mesh_mesh(n=n, seed=seed), "f64"
+    if strong:
+        lo, hi = pkg.sharding.shard_range(n, ctx.rank, ctx.world)
+        extra["shard"] = [lo, hi]
+        batch_local = batch.slice(lo, hi)
+        batch_local.meshes = getattr(batch, "meshes", None)
+        return batch_local, dtype, extra, batch
+    return batch, dtype, extra, batch
+
+
+def cpu_baseline(ctx, workload, batch, req, sample, budget_s, all_cores=True):
+    """The fp64 CPU oracle (oracle/, a restatement of the reference's algorithm: kind "port") on a bounded sample of
+    the same workload: 1 thread (the reference is single-threaded) and, for scale, all host threads."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob  # checker/baseline only -- never on the product path
+    ns = min(sample, len(batch))
+    sb = batch.slice(0, ns)
+    tf1, tf2 = sb.tf1, sb.tf2
+    if workload == "cfg4":
+        MLc = ctx.pkg.bvh_builder.MeshLibrary(batch.meshes)
+
+        def run_cpu(lo, hi, threads):
+            ob.bvh_collide_batch(MLc, sb.s1[lo:hi], sb.s2[lo:hi], tf1[lo:hi], tf2[lo:hi], req, n_threads=threads)
+    else:
+        fn = ob.distance_batch if sb.kind == "distance" else ob.collide_batch
+
+        def run_cpu(lo, hi, threads):
+            fn(sb.shapes, sb.verts, sb.s1[lo:hi], sb.s2[lo:hi], tf1[lo:hi], tf2[lo:hi], req, n_threads=threads)
+    run_cpu(0, min(1000, ns), 1)  # warm-up
+    reps, t_cpu = 0, 0.0
+    while t_cpu < budget_s and reps < 5:
+        t1 = time.perf_counter()
+        run_cpu(0, ns, 1)
+        t_cpu += time.perf_counter() - t1
+        reps += 1
+    out = {"value": reps * ns / t_cpu, "unit": "queries/s", "cores": 1, "kind": "port",
+           "sample": "%d pairs of the same workload x %d repeats, fp64 CPU oracle (oracle/), 1 thread" % (ns, reps)}
+    if all_cores:
+        cores_all = os.cpu_count() or 1
+        t1 = time.perf_counter()
+        run_cpu(0, ns, cores_all)
+        out["all_cores"] = {"value": ns / (time.perf_counter() - t1), "cores": cores_all}
+    return out
+
+
+def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s=10.0, cpu_sample=1_000_000, host_buffers=False):
+    """One timed region: `steps` passes of the hot path over this rank's batch.  Returns the result dict on rank 0."""
+    import torch
+    import torch.distributed as dist
+    args, pkg, dev = ctx.args, ctx.pkg, ctx.dev
+    abi, wl = pkg.abi, pkg.workloads
+    n_total = n_arg or DEFAULT_PAIRS.get(workload, 1_000_000)
+    batch, dtype, extra_cfg, full = make_batch(ctx, workload, n_total, strong)
+    n = len(batch)  # pairs of this rank per step
     req = wl.make_request(batch, abi)
-    lib = wl.make_library(pkg, batch, device=local_rank)
+    lib = wl.make_library(pkg, full, device=ctx.local_rank)
     if args.split:
         lib.set_split(args.split)
 
@@ -174,23 +239,25 @@ def main():
         d_p2 = torch.from_numpy(batch.tf2).to(dev)
         rec_words = 24
         launch = lib.distance_device if batch.kind == "distance" else lib.collide_device
-    outs = [torch.zeros(n * rec_words, dtype=torch.int32, device=dev) for _ in range(2)]
-    gather = dist_on and not args.no_gather
-    gathered = [torch.empty(world * n * rec_words, dtype=torch.int32, device=dev) for _ in range(2)] if gather else None
+    # strong scaling: shards may be ragged; the collective moves equal-sized (padded) blocks
+    per = pkg.sharding.padded_shard_len(n_total, ctx.world) if strong else n
+    outs = [torch.zeros(per * rec_words, dtype=torch.int32, device=dev) for _ in range(2)]
+    gather = ctx.dist_on and not args.no_gather
+    gathered = [torch.empty(ctx.world * per * rec_words, dtype=torch.int32, device=dev) for _ in range(2)] if gather else None
     stream = torch.cuda.current_stream()
-
     kernel_ms = {}
 
     def one_step(i, record_times):
         buf = i & 1
-        launch(d_s1, d_s2, d_p1, d_p2, n, req, outs[buf], stream=stream.cuda_stream)
+        if n:
+            launch(d_s1, d_s2, d_p1, d_p2, n, req, outs[buf], stream=stream.cuda_stream)
         work = None
         if gather:
             # results of this step travel over xGMI while the next step's kernels run
             ev = torch.cuda.Event()
             ev.record(stream)
             work = (buf, ev)
-        if record_times:
+        if record_times and n:
             for name, ms in lib.last_kernel_breakdown():  # HIP events on the launch stream
                 kernel_ms.setdefault(name, []).append(ms)
         return work
@@ -206,19 +273,19 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if dist_on:
+        if ctx.dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     lib.set_kernel_timing(False)  # the timed region runs without the per-kernel event markers
-    for i in range(args.warmup):
+    for i in range(warmup):
         w = one_step(i, False)
         if w:
             flush_gather(w).wait()
     sync_all()
     inflight = {}  # result buffer -> all-gather still reading it
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         # double buffering: the kernels of step i overwrite the buffer the all-gather of step i-2 read;
         # make the launch stream wait for that collective first (stream-side wait, the host does not block)
         h = inflight.pop(i & 1, None)
@@ -231,7 +298,7 @@ def main():
         h.wait()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist_on:
+    if ctx.dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -239,23 +306,23 @@ def main():
     # per-kernel durations (HIP events inside the library, on the launch stream), separate pass so
     # the event reads do not serialise the timed region
     lib.set_kernel_timing(True)
-    for i in range(min(args.steps, 10)):
+    for i in range(min(steps, 10)):
         one_step(i, True)
     torch.cuda.synchronize()
 
-    if rank == 0:
-        res = outs[(args.steps - 1) & 1].cpu().numpy()
+    result = None
+    if ctx.rank == 0:
+        res = outs[(steps - 1) & 1][:n * rec_words].cpu().numpy()
         status = res.view(abi.RESULT_F32_DTYPE if dtype == "f32" else abi.RESULT_DTYPE)["status"]
-        contact_frac = float(abi.status_contact(status).mean())
+        contact_frac = float(abi.status_contact(status).mean()) if n else 0.0
         buckets = lib.last_bucket_counts()
-        total_q = args.steps * n * world
+        total_q = steps * (n_total if strong else n * ctx.world)
         qps = total_q / elapsed
-        ms_per_step = 1e3 * elapsed / args.steps
+        ms_per_step = 1e3 * elapsed / steps
         avg = {k: float(np.mean(v)) for k, v in kernel_ms.items() if np.mean(v) > 0}
         dominant = max(avg, key=avg.get) if avg else ""
-        bpq = BYTES_PER_QUERY[args.workload]
-        extra_cfg = {}
-        if args.workload == "cfg4":
+        bpq = BYTES_PER_QUERY[workload]
+        if workload == "cfg4":
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_binding as ob0  # measures N_bv / N_leaf of the reference DFS on a sample
             ns0 = min(2000, n)
@@ -264,9 +331,7 @@ def main():
                                            n_threads=os.cpu_count() or 1, want_stats=True)
             nbv, nleaf = float(st0[:, 0].mean()), float(st0[:, 1].mean())
             bpq = bpq + CFG4_BYTES_PER_BV_TEST * nbv + CFG4_BYTES_PER_LEAF_TEST * nleaf
-            extra_cfg = {"mean_bv_tests": nbv, "mean_leaf_tests": nleaf, "stats_sample": ns0}
-        if args.workload == "cfg5":
-            extra_cfg = dict(batch.scene)
+            extra_cfg.update({"mean_bv_tests": nbv, "mean_leaf_tests": nleaf, "stats_sample": ns0})
         # units the dominant kernel processes in one launch
         if dominant.startswith("k_epa<fast"):
             units = buckets["epa_queue"]
@@ -279,16 +344,16 @@ def main():
         dom_ms = avg.get(dominant, float("nan"))
         achieved = (units * bpq) / (dom_ms * 1e-3) / 1e9 if dom_ms == dom_ms and dom_ms > 0 else None
         pipeline_ms = float(sum(avg.values()))
-        traffic, traffic_note = load_traffic(args.workload, dominant, n)
-        valu_insts, sq = load_traffic(args.workload, dominant, n, want="valu")
+        traffic, traffic_note = load_traffic(workload, dominant, n)
+        valu_insts, sq = load_traffic(workload, dominant, n, want="valu")
         valu = None
         if valu_insts and dom_ms == dom_ms and dom_ms > 0:
             # the bound that actually applies to the iterative kernels: wave-level VALU instructions issued per
-            # launch (SQ_INSTS_VALU, committed PMC pass) against the issue peak over the live kernel duration
+            # launch (SQ_INSTS_VALU, committed PMC pass of this code) against the MEASURED issue peak over the live kernel duration
             valu = {"insts_per_launch": valu_insts, "issue_peak_per_s": VALU_ISSUE_PEAK,
                     "frac": valu_insts / (dom_ms * 1e-3) / VALU_ISSUE_PEAK, "sq_counters_per_launch": sq,
-                    "note": "wave-level VALU instructions / (kernel time x 256 CUs x 4 SIMDs x 2.4 GHz / 4); "
-                            "fp64 arithmetic issues at half that rate, so an fp64 kernel saturates near 0.5"}
+                    "note": "wave-level VALU instructions / (kernel time x measured chip-wide issue peak, tools/valu_peak.hip); "
+                            "fp64 arithmetic issues at 0.56 of that rate"}
         roofline = {
             "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_note": traffic_note,
@@ -297,55 +362,111 @@ def main():
             "kernels_ms": avg, "valu_issue": valu,
         }
         cpu = None
-        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_binding as ob  # checker/baseline only -- never on the product path
-            ns = min(args.cpu_sample, n)
-            sb = batch.slice(0, ns)
-            tf1, tf2 = sb.tf1, sb.tf2
-            if args.workload == "cfg4":
-                MLc = pkg.bvh_builder.MeshLibrary(batch.meshes)
-
-                def run_cpu(lo, hi, threads):
-                    ob.bvh_collide_batch(MLc, sb.s1[lo:hi], sb.s2[lo:hi], tf1[lo:hi], tf2[lo:hi], req, n_threads=threads)
-            else:
-                fn = ob.distance_batch if sb.kind == "distance" else ob.collide_batch
-
-                def run_cpu(lo, hi, threads):
-                    fn(sb.shapes, sb.verts, sb.s1[lo:hi], sb.s2[lo:hi], tf1[lo:hi], tf2[lo:hi], req, n_threads=threads)
-            run_cpu(0, min(1000, ns), 1)  # warm-up
-            reps, t_cpu = 0, 0.0
-            while t_cpu < 10.0 and reps < 5:
-                t1 = time.perf_counter()
-                run_cpu(0, ns, 1)
-                t_cpu += time.perf_counter() - t1
-                reps += 1
-            cores_all = os.cpu_count() or 1
-            t1 = time.perf_counter()
-            run_cpu(0, ns, cores_all)
-            t_all = time.perf_counter() - t1
-            cpu = {"value": reps * ns / t_cpu, "unit": "queries/s", "cores": 1, "kind": "port",
-                   "sample": "%d pairs of the same workload x %d repeats, fp64 CPU oracle (oracle/), 1 thread" % (ns, reps),
-                   "all_cores": {"value": ns / t_all, "cores": cores_all}}
-        line = {
-            "metric": "narrow-phase queries/s (collision+distance)", "value": qps, "unit": "queries/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": batch.name, **extra_cfg,
-                       "baseline_config": {"cfg3": "configs[2]", "cfg2": "configs[1]", "cfg4": "configs[3]", "cfg5": "configs[4]",
-                                           "cfg1": "configs[0] (shape pair; GPU batch size)",
-                                           "cfg3u": "configs[2], one hull pair per query"}[args.workload],
-                       "pairs_per_gpu_per_step": n, "contact_fraction": contact_frac, "buckets": buckets,
+        if not args.no_cpu_baseline and ctx.world == 1 and cpu_budget_s > 0:  # reported on rank 0 at N=1 only
+            cpu = cpu_baseline(ctx, workload, batch, req, cpu_sample, cpu_budget_s)
+        result = {
+            "workload": batch.name, "value": qps, "unit": "queries/s", "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
+            "dtype": dtype, "scaling": "strong" if strong else "weak",
+            "config": {"workload": batch.name, **extra_cfg, "baseline_config": BASELINE_CONFIG[workload],
+                       "pairs_per_gpu_per_step": n, "pairs_per_step_all_gpus": n_total if strong else n * ctx.world,
+                       "contact_fraction": contact_frac, "buckets": buckets,
                        "request": batch.kind, "all_gather_results": bool(gather), "split_parts": lib.last_split_parts(),
                        "lane_group_width": os.environ.get("HFCL_CVX_W", "auto (2; fp64 convex-convex 4)")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-    else:
-        line = None
-    if dist_on:
+        if host_buffers and dtype == "f64" and ctx.world == 1:
+            # the same batch through the host-buffer boundary (what a hpp::fcl::collide()/distance() caller gets):
+            # PCIe inclusive, never the headline value
+            import ctypes as C
+            dll = pkg.engine.dll()
+            cfn = dll.hfcl_distance_batch if batch.kind == "distance" else dll.hfcl_collide_batch
+            s1, s2 = batch.s1.astype(np.uint32), batch.s2.astype(np.uint32)
+            tf1, tf2 = np.ascontiguousarray(batch.tf1), np.ascontiguousarray(batch.tf2)
+            out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+            out[:] = out  # touched: first-touch page faults of a fresh array are the allocator's, not the link's
+            ts = []
+            for _ in range(4):
+                t1 = time.perf_counter()
+                rc = cfn(lib._h, abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1), abi.ptr(tf2), C.c_size_t(n), C.byref(req), abi.ptr(out), None, None)
+                ts.append(time.perf_counter() - t1)
+                assert rc == 0, pkg.engine.last_error()
+            t_h = min(ts[1:])
+            b_in, b_out = 8 + 192, 96
+            bound_s = max(n * b_in / (LINK_H2D_GBS * 1e9), n * b_out / (LINK_D2H_GBS * 1e9), n * (b_in + b_out) / (LINK_BOTH_GBS * 1e9))
+            same = bool(np.array_equal(out.view(np.int32), res.view(np.int32)))
+            result["host_buffers"] = {
+                "value": n / t_h, "unit": "queries/s", "ms_per_call": 1e3 * t_h, "bytes_in_per_pair": b_in, "bytes_out_per_pair": b_out,
+                "link_GBps_measured": {"h2d": LINK_H2D_GBS, "d2h": LINK_D2H_GBS, "both_directions_total": LINK_BOTH_GBS},
+                "link_bound_ms": 1e3 * bound_s, "frac_of_link_bound": bound_s / t_h, "records_identical_to_device_path": same,
+                "note": "hfcl_%s_batch on pageable host arrays: chunked H2D | kernels | D2H pipeline; PCIe inclusive" % batch.kind}
+    lib.close()
+    del d_s1, d_s2, d_p1, d_p2, outs, gathered
+    torch.cuda.empty_cache()
+    return result
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    ctx = Ctx()
+    ctx.args = args
+    ctx.rank = int(os.environ.get("RANK", "0"))
+    ctx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != ctx.world:
+        if ctx.world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" %
+                             (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(ctx.local_rank)
+    ctx.dev = torch.device("cuda", ctx.local_rank)
+    # HFCL_BENCH_FORCE_DIST=1: run the N>1 code path (RCCL group, comm stream, async all-gather, barriers, max over
+    # ranks) with a single rank -- a dry run of the multi-GPU plumbing on a 1-GPU box
+    ctx.dist_on = ctx.world > 1 or os.environ.get("HFCL_BENCH_FORCE_DIST") == "1"
+    if ctx.dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=ctx.dev, rank=ctx.rank, world_size=ctx.world)
+    ctx.pkg = load_pkg()
+
+    headline_wl = args.workload or "cfg3"
+    strong = args.scaling == "strong"
+    head = run_workload(ctx, headline_wl, args.pairs, args.steps, args.warmup, strong=strong,
+                        cpu_budget_s=10.0, cpu_sample=args.cpu_sample, host_buffers=(headline_wl == "cfg2"))
+    secondary = []
+    if args.workload is None and not args.no_secondary:
+        sec_steps = max(3, min(args.steps, 10))
+        plan = [("cfg2", 0, False, dict(host_buffers=True)), ("cfg4", 0, False, {}), ("cfg5", 0, False, {}),
+                ("cfg5", 10_000_000, True, {})]
+        for wl_name, pairs, st, kw in plan:
+            try:
+                r = run_workload(ctx, wl_name, pairs, sec_steps if not st else 5, 2, strong=st, cpu_budget_s=2.5,
+                                 cpu_sample=100_000 if wl_name != "cfg4" else 20_000, **kw)
+            except Exception as e:  # a secondary must never take the headline down
+                r = {"workload": wl_name + ("_strong" if st else ""), "error": repr(e)} if ctx.rank == 0 else None
+            if r is not None:
+                if st:
+                    r["workload"] += " (one %d-pair list sharded over the ranks, records all-gathered)" % pairs
+                secondary.append(r)
+
+    line = None
+    if ctx.rank == 0:
+        line = {
+            "metric": "narrow-phase queries/s (collision+distance)", "value": head["value"], "unit": "queries/s",
+            "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": head["scaling"], "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
+            "config": head["config"], "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"],
+        }
+        if "host_buffers" in head:
+            line["host_buffers"] = head["host_buffers"]
+        if secondary:
+            line["secondary"] = secondary
+    if ctx.dist_on:
         dist.barrier()
         dist.destroy_process_group()
-    lib.close()
     if line is not None:
         # the JSON line goes out last: RCCL writes a version banner to the C stdout, which would otherwise be
         # flushed after Python's buffer when stdout is a file or pipe

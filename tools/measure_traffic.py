@@ -60,7 +60,10 @@ if __name__ == "__main__":
     except Exception as e:  # the traffic figures stand on their own
         print("SQ pass failed:", e, file=sys.stderr)
     out = a.out or os.path.join(ROOT, "gpurun_out", "traffic_%s.json" % a.workload)
-    json.dump({"workload": a.workload, "pairs": a.pairs or None, "unit": "KB as reported by rocprofv3 (uncorrected)",
+    sys.path.insert(0, ROOT)
+    from bench import kernel_source_sha  # the pass is only quoted by bench.py for the device code it was taken on
+    json.dump({"workload": a.workload, "pairs": a.pairs or None, "source_sha": kernel_source_sha(),
+               "unit": "KB as reported by rocprofv3 (uncorrected)",
                "kernels": {k: v for k, v in res.items() if k.startswith("void k_") or k.startswith("k_")}},
               open(out, "w"), indent=1)
     print(open(out).read())
