@@ -403,6 +403,46 @@ struct BvhParams {
   uint32_t* contacts_count;
 };
 
+// ---- long mesh x mesh traversals cut into tasks (k_bvh_collide / k_bvh_combine, hfcl_k_bvh.hip) ----
+struct BvhTask {
+  uint32_t pair;    // the query
+  uint32_t parent;  // summary slot of the unit that made the task
+  uint32_t entry;   // the subtree pair to walk (b1 | b2 << 16); 0xFFFFFFFF: no-op (the task table was full)
+  uint32_t pad_;
+};
+enum { BVH_SUM_SUSPENDED = 1u, BVH_SUM_OVERFLOW = 2u };
+template <typename T>
+struct BvhSum {  // what a unit (query or task) knows when it ends or suspends
+  T dlb, rec_dist;   // lower bound over its events, and the record distance that goes with it
+  T cand_val;        // value of its last leaf that lowered the bound (max(): none) ...
+  V3<T> np1, np2, nn;  // ... and that leaf's witness points / normal
+  int32_t fb1, fb2;  // first contact
+  uint32_t ncontacts, first_child, n_child, flags;
+};
+// counters of a split traversal (device words)
+enum { BVH_CTR_TASKS = 0, BVH_CTR_SUSPENDED = 1, BVH_CTR_LEVEL0 = 2 /* [2 + k] = number of tasks made before level k ended */, BVH_CTR_WORDS = 16 };
+struct BvhSplit {
+  BvhTask* tasks;       // task table (cap entries)
+  void* sums;           // BvhSum<T>[n_queries + cap]: suspended queries first, then one per task
+  uint32_t* suspended;  // pairs of the suspended queries (slot i <-> sums[i])
+  uint32_t* ctr;        // BVH_CTR_*
+  uint32_t cap, n_queries;
+  uint32_t budget;      // BV-test steps before a unit suspends (0: never)
+  uint32_t level, n_levels;
+  uint32_t can_suspend;
+};
+// Step budget per unit.  0 (default): units only suspend when their LDS stack is full -- the task mechanism is then the
+// overflow path of deep traversals and costs nothing otherwise.  Budgets were measured and do not pay with level-wise
+// launches (profiles/r02_k_bvh_task_split.txt: cfg4 7.3 ms unsplit, 7.9 .. 30 ms split): the stack of a long query
+// is one huge subtree next to many small ones, so every level only halves the longest chain, and the siblings of a
+// contact query's spine are speculative work the sequential walk never does.
+#ifndef HFCL_BVH_BUDGET
+#define HFCL_BVH_BUDGET 0
+#endif
+#ifndef HFCL_BVH_LEVELS
+#define HFCL_BVH_LEVELS 4
+#endif
+
 constexpr int BVH_STACK = 96;
 constexpr int BVH_BLOCK = 128;
 #ifndef HFCL_BVH_REFILL_MIN

@@ -130,6 +130,13 @@ struct hfcl_lib {
   float* d_bverts32 = nullptr;
   uint32_t* d_btris = nullptr;
   DMesh* d_meshes = nullptr;
+  // split mesh x mesh traversals (BvhSplit): task table, unit summaries, suspended-query list, counters
+  BvhTask* d_bvh_tasks = nullptr;
+  void* d_bvh_sums = nullptr;
+  uint32_t* d_bvh_susp = nullptr;
+  uint32_t* d_bvh_ctr = nullptr;
+  size_t bvh_split_n = 0, bvh_split_cap = 0;
+  uint32_t bvh_budget = HFCL_BVH_BUDGET, bvh_levels = HFCL_BVH_LEVELS;  // HFCL_BVH_BUDGET / HFCL_BVH_LEVELS (1: unsplit)
   // contact list of the last hfcl_collide_batch_contacts call
   hfcl_contact* d_contacts = nullptr;
   size_t contacts_cap = 0;
@@ -338,6 +345,8 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_CLOSED_STAGED")) lib->closed_staged = atoi(v) != 0;
   if (const char* v = getenv("HFCL_SPLIT")) lib->split = atoi(v) >= 2 ? 2 : (atoi(v) == 1 ? 1 : 0);
   if (const char* v = getenv("HFCL_PIPE_CHUNK")) lib->pipe_chunk = strtoull(v, nullptr, 10);
+  if (const char* v = getenv("HFCL_BVH_BUDGET")) lib->bvh_budget = uint32_t(std::max(0, atoi(v)));
+  if (const char* v = getenv("HFCL_BVH_LEVELS")) lib->bvh_levels = uint32_t(std::min(12, std::max(1, atoi(v))));
   if (const char* w = getenv("HFCL_CVX_W")) {
     int v = atoi(w);
     if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) lib->cvx_w = v;
@@ -395,6 +404,10 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_meshes);
   hipFree(lib->d_contacts);
   hipFree(lib->d_contacts_count);
+  hipFree(lib->d_bvh_tasks);
+  hipFree(lib->d_bvh_sums);
+  hipFree(lib->d_bvh_susp);
+  hipFree(lib->d_bvh_ctr);
   for (auto& t : lib->timers) {
     hipEventDestroy(t.e0);
     hipEventDestroy(t.e1);
@@ -468,6 +481,23 @@ static int ensure_workspace(hfcl_lib* lib, size_t n) {
   HIP_TRY(hipMalloc(&lib->d_epa_resume, rcap * std::max(epa_resume_stride<double>, epa_resume_stride<float>)));
   lib->resume_cap = rcap;
   lib->ws_capacity = cap;
+  return HFCL_OK;
+}
+
+// Tables of a split mesh x mesh traversal for a batch of n queries: room for 8 tasks per query (a long query suspends
+// with a stack of ~20 entries, one query in five is long) -- ~1.2 KB of device memory per query in fp64.
+static int ensure_bvh_split(hfcl_lib* lib, size_t n) {
+  if (n <= lib->bvh_split_n) return HFCL_OK;
+  hipFree(lib->d_bvh_tasks); hipFree(lib->d_bvh_sums); hipFree(lib->d_bvh_susp);
+  lib->d_bvh_tasks = nullptr; lib->d_bvh_sums = nullptr; lib->d_bvh_susp = nullptr;
+  lib->bvh_split_n = 0;
+  const size_t nq = n + n / 8 + 1024, cap = 8 * nq + 65536;
+  HIP_TRY(hipMalloc(&lib->d_bvh_tasks, cap * sizeof(BvhTask)));
+  HIP_TRY(hipMalloc(&lib->d_bvh_sums, (nq + cap) * sizeof(BvhSum<double>)));
+  HIP_TRY(hipMalloc(&lib->d_bvh_susp, nq * sizeof(uint32_t)));
+  if (!lib->d_bvh_ctr) HIP_TRY(hipMalloc(&lib->d_bvh_ctr, BVH_CTR_WORDS * sizeof(uint32_t)));
+  lib->bvh_split_n = nq;
+  lib->bvh_split_cap = cap;
   return HFCL_OK;
 }
 
@@ -733,7 +763,24 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       launch_bvh_shape<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance));
       tend();
       tbeg("k_bvh_collide");
-      launch_bvh_collide<T>(blocks_for(n, BVH_BLOCK), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance));
+      BvhSplit split;
+      memset(&split, 0, sizeof(split));
+      // long traversals are cut into tasks when the batch is large enough for the tail to matter and the request
+      // keeps no query-wide contact count
+      if (may(B_BVH) && lib->bvh_levels > 1 && n >= 2048 && lib->bvh_params.num_max_contacts == 1 && !lib->bvh_params.contacts) {
+        rc = ensure_bvh_split(lib, n);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(lib->d_bvh_ctr, 0, BVH_CTR_WORDS * sizeof(uint32_t), st));
+        split.tasks = lib->d_bvh_tasks;
+        split.sums = lib->d_bvh_sums;
+        split.suspended = lib->d_bvh_susp;
+        split.ctr = lib->d_bvh_ctr;
+        split.cap = uint32_t(std::min<size_t>(lib->bvh_split_cap, 0x7FFFFFFFu));
+        split.n_queries = uint32_t(lib->bvh_split_n);
+        split.budget = lib->bvh_budget;
+        split.n_levels = lib->bvh_levels;
+      }
+      launch_bvh_collide<T>(blocks_for(n, BVH_BLOCK), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance), split);
       tend();
     } else {
       tbeg("k_bvh_shape_distance");

@@ -1,23 +1,49 @@
 // hfcl_k_bvh.hip -- BVHModel<OBBRSS> kernels (mesh x mesh collide / distance, mesh x solid) and top-level TriangleP pairs.
+#include <algorithm>
+
 #include "hfcl_dev.hpp"
 #include "hfcl_launch.hpp"
 
+// ---------------------------------------------------------------------------------------
+// k_bvh_collide: BVHModel<OBBRSS> x BVHModel<OBBRSS> collide().
+// Traversal = collisionRecurse (src/traversal/traversal_recurse.cpp:44-85) with the recursion
+// flattened into a per-lane LDS stack; children are pushed right-then-left so they pop in the
+// reference's order, and the walk ends as soon as num_max_contacts contacts exist (canStop()).
+//
+// Long traversals are cut into tasks.  Queries differ by two orders of magnitude in length (cfg4: 135 BV tests on
+// average, > 2000 for the longest), and with 1.5 queries per resident lane the kernel used to last as long as its longest
+// query.  Now a unit of work (level 0: a query; deeper levels: a task = one pending (b1, b2) subtree pair) that has used
+// up its step budget -- or whose LDS stack is full -- *suspends*: every entry of its stack becomes a task of the next
+// level (in DFS order: top of the stack first), its state so far is parked as a summary, and the lane takes new work.
+// The levels run as separate launches; afterwards k_bvh_combine folds the children of every suspended unit back, deepest
+// level first, exactly as the sequential walk would have seen them:
+//   * the walk's running lower bound is a minimum over all its BV / leaf events: order-free;
+//   * the reported witness points are those of the LAST leaf that lowered the bound when it was visited.  Within a task
+//     those leaves have decreasing values, so only its last one can also lie below the bound accumulated before the task:
+//     a task reports that leaf (cand_val, np1, np2, nn) and its overall minimum (dlb, rec_dist), nothing else;
+//   * a contact ends the walk: children after the first one with a contact are ignored (their work was speculative).
+// Contact lists (num_max_contacts > 1) need the running count of the whole query and run unsplit.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ BvhSum<T>* bvh_sum(const BvhSplit& sp, uint32_t slot) { return reinterpret_cast<BvhSum<T>*>(sp.sums) + slot; }
+
 template <typename T>
 __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH, 8))) k_bvh_collide(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
-                                                          BvhParams bp, T break_distance2) {
+                                                          BvhParams bp, T break_distance2, BvhSplit split) {
   __shared__ uint32_t stack[BVH_STACK][BVH_BLOCK];
-  const uint32_t cnt = wk.counts[B_BVH];
+  const uint32_t level = split.level;
+  const uint32_t unit0 = level ? split.ctr[BVH_CTR_LEVEL0 + level - 1] : 0u;  // first task of this level
+  const uint32_t cnt = level ? min(split.ctr[BVH_CTR_LEVEL0 + level], split.cap) - min(unit0, split.cap) : wk.counts[B_BVH];
   uint32_t* const ticket = &wk.counts[B_COUNT + 2];
+  const uint32_t budget = split.budget;  // steps a unit may take before it suspends (0: never)
   const int tid = threadIdx.x, lane = tid & 63;
   const T nanv = Lim<T>::nan();
-  // Per-lane query state.  Queries differ by an order of magnitude in length (cfg4: 135 BV tests on
-  // average, 663 for the longest of 64), so the lanes of a wave do not advance through the batch in
-  // lockstep: a lane whose traversal is over parks its result (`pending`) and, as soon as
-  // BVH_REFILL_MIN lanes of the wave are idle, all of them write their records and take the next
-  // queries from a global ticket counter.
+  // Per-lane unit state.  The lanes of a wave do not advance through the batch in lockstep: a lane whose traversal is
+  // over parks its result (`pending`) and, as soon as BVH_REFILL_MIN lanes of the wave are idle, all of them write
+  // their records and take the next units from a global ticket counter.
   constexpr int refill_min = BVH_REFILL_MIN;
   bool live = false, pending = false, exhausted = false;  // exhausted is wave-uniform
-  uint32_t pair = 0;
+  uint32_t pair = 0, unit = 0, steps = 0;
   DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
   Pose<T> tf1, tf2;
   M3<T> RT_R;
@@ -25,12 +51,24 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   int sp = 0;
   bool overflow = false;
   uint32_t ncontacts = 0;
-  T dlb = Lim<T>::max(), rec_dist = Lim<T>::max();
+  T dlb = Lim<T>::max(), rec_dist = Lim<T>::max(), cand_val = Lim<T>::max();
   V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1, nn = np1;
   int fb1 = -1, fb2 = -1;
   bool have_leaf = false;
   uint32_t lb1 = 0, lb2 = 0;
-  auto flush = [&]() {  // record of the query this lane finished
+  auto write_sum = [&](uint32_t slot, uint32_t first_child, uint32_t n_child, uint32_t flags) {
+    BvhSum<T> s;
+    s.dlb = dlb; s.rec_dist = rec_dist; s.cand_val = cand_val;
+    s.np1 = np1; s.np2 = np2; s.nn = nn;
+    s.fb1 = fb1; s.fb2 = fb2;
+    s.ncontacts = ncontacts; s.first_child = first_child; s.n_child = n_child; s.flags = flags;
+    *bvh_sum<T>(split, slot) = s;
+  };
+  auto flush = [&]() {  // the unit this lane finished: a query's record, or a task's summary
+    if (level) {
+      write_sum(split.n_queries + unit, 0u, 0u, overflow ? BVH_SUM_OVERFLOW : 0u);
+      return;
+    }
     PairOut<T> o;
     o.distance = rec_dist;
     o.normal = nn;
@@ -40,6 +78,32 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
     o.epa_status = EPA_DID_NOT_RUN;
     o.gjk_iters = o.epa_iters = 0;
     store_bvh_record(io, pair, o, ncontacts, fb1, fb2, overflow);
+  };
+  // Turn the `n_extra` entries in `extra` (children about to be pushed: first one on top) and the whole stack into tasks
+  // of the next level and park this unit.  false: no room in the task table (the unit then simply goes on).
+  auto suspend = [&](uint32_t ea, uint32_t eb, int n_extra) -> bool {
+    const uint32_t n_child = uint32_t(sp + n_extra);
+    if (!split.can_suspend || n_child == 0) return false;
+    const uint32_t first = atomicAdd(&split.ctr[BVH_CTR_TASKS], n_child);
+    if (first + n_child > split.cap) {  // table full: the slots taken become no-ops for the next level
+      for (uint32_t j = first; j < min(first + n_child, split.cap); ++j) split.tasks[j] = BvhTask{0u, 0u, 0xFFFFFFFFu, 0u};
+      return false;
+    }
+    uint32_t my_slot;
+    if (level) {
+      my_slot = split.n_queries + unit;
+    } else {
+      my_slot = atomicAdd(&split.ctr[BVH_CTR_SUSPENDED], 1u);  // < n_queries: one per query at most
+      split.suspended[my_slot] = pair;
+    }
+    uint32_t j = first;
+    if (n_extra > 0) split.tasks[j++] = BvhTask{pair, my_slot, ea, 0u};
+    if (n_extra > 1) split.tasks[j++] = BvhTask{pair, my_slot, eb, 0u};
+    for (int k = sp - 1; k >= 0; --k) split.tasks[j++] = BvhTask{pair, my_slot, stack[k][tid], 0u};  // DFS order: top first
+    write_sum(my_slot, first, n_child, BVH_SUM_SUSPENDED);
+    sp = 0;
+    live = false;  // nothing to flush: the summary is written
+    return true;
   };
   for (;;) {
     if (live && !have_leaf && sp == 0) {  // traversal over
@@ -63,23 +127,36 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
         const uint32_t rank = uint32_t(__popcll(~live_mask & ((uint64_t(1) << lane) - 1)));
         const uint32_t it = base + rank;
         if (it < cnt) {
-          pair = wk.lists[size_t(B_BVH) * wk.n + it];
-          const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
-          m1 = bv.meshes[a.bvh_index];
-          m2 = bv.meshes[b.bvh_index];
-          tf1 = load_pose(io.tf1, pair);
-          tf2 = load_pose(io.tf2, pair);
-          RT_R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
-          RT_T = tmul(tf1.R, tf2.t - tf1.t);
-          stack[0][tid] = 0u;  // (b1 = 0, b2 = 0)
-          sp = 1;
-          overflow = false;
-          ncontacts = 0;
-          dlb = rec_dist = Lim<T>::max();
-          np1 = np2 = nn = mk<T>(nanv, nanv, nanv);
-          fb1 = fb2 = -1;
-          have_leaf = false;
-          live = true;
+          uint32_t entry = 0u;  // (b1 = 0, b2 = 0)
+          bool valid = true;
+          if (level) {
+            unit = unit0 + it;
+            const BvhTask t = split.tasks[unit];
+            pair = t.pair;
+            entry = t.entry;
+            valid = entry != 0xFFFFFFFFu;
+          } else {
+            pair = wk.lists[size_t(B_BVH) * wk.n + it];
+          }
+          if (valid) {
+            const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+            m1 = bv.meshes[a.bvh_index];
+            m2 = bv.meshes[b.bvh_index];
+            tf1 = load_pose(io.tf1, pair);
+            tf2 = load_pose(io.tf2, pair);
+            RT_R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
+            RT_T = tmul(tf1.R, tf2.t - tf1.t);
+            stack[0][tid] = entry;
+            sp = 1;
+            steps = 0;
+            overflow = false;
+            ncontacts = 0;
+            dlb = rec_dist = cand_val = Lim<T>::max();
+            np1 = np2 = nn = mk<T>(nanv, nanv, nanv);
+            fb1 = fb2 = -1;
+            have_leaf = false;
+            live = true;
+          }
         }
       }
       if (base + uint32_t(n_need) >= cnt) exhausted = true;
@@ -93,6 +170,8 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
       if (__popcll(__ballot(have_leaf)) >= 32) break;
       if (!exhausted && 64 - __popcll(__ballot(live && (have_leaf || sp > 0))) >= refill_min) break;
       if (can_bv) {
+        if (budget && steps >= budget && suspend(0u, 0u, 0)) continue;
+        ++steps;
         const uint32_t e = stack[--sp][tid];
         const uint32_t b1 = e & 0xFFFFu, b2 = e >> 16;
         const DNode<T> n1 = bv.nodes[m1.node_off + b1];
@@ -128,8 +207,12 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
               eb = b1 | ((c1 + 1) << 16);
             }
             if (sp + 2 > BVH_STACK) {
-              overflow = true;
-              sp = 0;
+              // the LDS stack is full: the whole stack (and the two children) go on as tasks; only where that is not
+              // possible (contact lists, last level, task table full) the unit is flagged as overflowed
+              if (!suspend(ea, eb, 2)) {
+                overflow = true;
+                sp = 0;
+              }
             } else {
               stack[sp++][tid] = eb;  // second child below
               stack[sp++][tid] = ea;  // first child on top
@@ -141,6 +224,7 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
     // ---- leaf phase (leafCollides, traversal_node_bvhs.h:184-233)
     if (have_leaf) {
       have_leaf = false;
+      steps += 8;  // a triangle pair costs about as much as eight BV tests
       const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + lb1);
       const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + lb2);
       const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
@@ -160,6 +244,7 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
       const T dtc = distance - q.security_margin;
       if (dtc < dlb) {  // updateDistanceLowerBoundFromLeaf
         dlb = dtc;
+        cand_val = dtc;
         rec_dist = distance;
         np1 = p1;
         np2 = p2;
@@ -194,6 +279,63 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   }
 }
 
+// Between two levels: the tasks made so far are the next level's units; the ticket counter starts over.
+__global__ void k_bvh_level_mark(Work wk, BvhSplit split) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    split.ctr[BVH_CTR_LEVEL0 + split.level + 1] = split.ctr[BVH_CTR_TASKS];
+    wk.counts[B_COUNT + 2] = 0u;
+  }
+}
+
+// Fold the children of the suspended units of level `split.level` back (the children's own children are folded already).
+template <typename T>
+__global__ void __launch_bounds__(256) k_bvh_combine(Work wk, IO<T> io, BvhSplit split) {
+  const uint32_t level = split.level;
+  const uint32_t unit0 = level ? min(split.ctr[BVH_CTR_LEVEL0 + level - 1], split.cap) : 0u;
+  const uint32_t cnt = level ? min(split.ctr[BVH_CTR_LEVEL0 + level], split.cap) - unit0 : split.ctr[BVH_CTR_SUSPENDED];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+    const uint32_t slot = level ? split.n_queries + unit0 + i : i;
+    BvhSum<T> s = *bvh_sum<T>(split, slot);
+    if (level && !(s.flags & BVH_SUM_SUSPENDED)) continue;  // (level 0: the suspended list holds nothing else)
+    if (level && split.tasks[unit0 + i].entry == 0xFFFFFFFFu) continue;
+    bool overflow = (s.flags & BVH_SUM_OVERFLOW) != 0;
+    for (uint32_t j = 0; j < s.n_child; ++j) {
+      const BvhSum<T> c = *bvh_sum<T>(split, split.n_queries + s.first_child + j);
+      overflow = overflow || (c.flags & BVH_SUM_OVERFLOW);
+      if (c.cand_val < s.dlb) {  // the child's last bound-lowering leaf also lowers the bound as it stood before the child
+        s.cand_val = c.cand_val;
+        s.np1 = c.np1;
+        s.np2 = c.np2;
+        s.nn = c.nn;
+      }
+      if (c.dlb < s.dlb) {
+        s.dlb = c.dlb;
+        s.rec_dist = c.rec_dist;
+      }
+      if (c.ncontacts) {  // the walk ended here
+        s.ncontacts = c.ncontacts;
+        s.fb1 = c.fb1;
+        s.fb2 = c.fb2;
+        break;
+      }
+    }
+    if (level) {
+      s.flags = overflow ? BVH_SUM_OVERFLOW : 0u;
+      s.n_child = 0;
+      *bvh_sum<T>(split, slot) = s;
+    } else {
+      PairOut<T> o;
+      o.distance = s.rec_dist;
+      o.normal = s.nn;
+      o.p1 = s.np1;
+      o.p2 = s.np2;
+      o.gjk_status = GJK_DID_NOT_RUN;
+      o.epa_status = EPA_DID_NOT_RUN;
+      o.gjk_iters = o.epa_iters = 0;
+      store_bvh_record(io, split.suspended[i], o, s.ncontacts, s.fb1, s.fb2, overflow);
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------
 // k_bvh_shape: BVHModel<OBBRSS> x convex solid collide(), either operand order.  One query per BS_W-lane
@@ -510,9 +652,31 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
 // =======================================================================================
 // launchers (hfcl_launch.hpp)
 // =======================================================================================
+// One level per launch (levels > 0 walk the tasks the level before made), the fold-back launches in reverse order.
+// split.tasks == nullptr (or split.n_levels <= 1): the plain single-pass traversal.
 template <typename T>
-void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2) {
-  hipLaunchKernelGGL((k_bvh_collide<T>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2);
+void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split) {
+  const bool splitting = split.tasks && split.n_levels > 1 && bp.num_max_contacts == 1 && !bp.contacts;
+  if (!splitting) {
+    split.tasks = nullptr;
+    split.budget = 0;
+    split.level = 0;
+    hipLaunchKernelGGL((k_bvh_collide<T>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split);
+    return;
+  }
+  const uint32_t budget = split.budget;
+  for (uint32_t l = 0; l < split.n_levels; ++l) {
+    split.level = l;
+    split.budget = l + 1 < split.n_levels ? budget : 0u;  // the last level runs to the end
+    BvhSplit s = split;
+    s.can_suspend = l + 1 < split.n_levels;  // ... and cannot suspend (its stack overflows are flagged)
+    hipLaunchKernelGGL((k_bvh_collide<T>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, s);
+    hipLaunchKernelGGL(k_bvh_level_mark, dim3(1), dim3(64), 0, st, wk, s);
+  }
+  for (int l = int(split.n_levels) - 2; l >= 0; --l) {
+    split.level = uint32_t(l);
+    hipLaunchKernelGGL((k_bvh_combine<T>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, io, split);
+  }
 }
 template <typename T>
 void launch_bvh_distance(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q) {
@@ -531,7 +695,7 @@ void launch_triangle(int grid, hipStream_t st, const Work& wk, const LibView<T>&
   hipLaunchKernelGGL((k_triangle<T>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
 }
 #define HFCL_INST(T)                                                                                                             \
-  template void launch_bvh_collide<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T); \
+  template void launch_bvh_collide<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit); \
   template void launch_bvh_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&);                \
   template void launch_bvh_shape<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T);   \
   template void launch_bvh_shape_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&);          \
