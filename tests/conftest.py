@@ -45,3 +45,10 @@ def hostsim():
     import hostsim_binding
     hostsim_binding.lib()
     return hostsim_binding
+
+
+@pytest.fixture(scope="session")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch

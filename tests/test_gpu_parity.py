@@ -8,13 +8,6 @@ from compare import check_parity, check_properties
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def torch_cuda():
-    import torch
-    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
-    return torch
-
-
 def _oracle(oracle, b, req, tf1=None, tf2=None):
     fn = oracle.distance_batch if b.kind == "distance" else oracle.collide_batch
     return fn(b.shapes, b.verts, b.s1, b.s2, b.tf1 if tf1 is None else tf1, b.tf2 if tf2 is None else tf2, req,
@@ -85,6 +78,37 @@ def test_fp64_gjk_variants(pkg, oracle, variant):
     ref = _oracle(oracle, b, req)
     got, _ = _engine(pkg, b, req)
     check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name="variant%d" % variant)
+
+
+@pytest.mark.parametrize("crit", [(0, 0), (1, 0), (1, 1), (2, 0), (2, 1)])
+@pytest.mark.parametrize("variant", [0, 2])
+def test_fp64_convergence_criteria(pkg, oracle, variant, crit):
+    """GJKConvergenceCriterion {Default, DualityGap, Hybrid} x {Relative, Absolute} (gjk.cpp:372-425) on the device,
+    with and without Nesterov acceleration: statuses and iteration counts are the oracle's."""
+    abi, wl = pkg.abi, pkg.workloads
+    b = wl.cfg5_mixed(n=20000, seed=12)
+    b.kind = "distance"
+    req = abi.default_distance_request()
+    req.q.gjk_variant = variant
+    req.q.gjk_convergence_criterion, req.q.gjk_convergence_criterion_type = crit
+    ref = _oracle(oracle, b, req)
+    got, _ = _engine(pkg, b, req)
+    name = "crit%d%d-v%d" % (crit + (variant,))
+    # The *relative* form of the duality-gap and hybrid tests asks diff <= tol^2 = 1e-12 with diff = 2 ray.(ray - w) or
+    # |ray|^2 - alpha^2 (the reference's formula, gjk.cpp:405-422): on a strictly convex shape (Ellipsoid) GJK then runs
+    # 25-40 iterations until that difference of nearly equal numbers falls below 1e-12 by cancellation, i.e. round-off
+    # decides the last iterations (the device contracts a*b+c, the oracle does not; the reference itself would move with
+    # its compiler flags).  Those pairs are held to the solver's accuracy instead of to the oracle's last digits;
+    # everything else matches as usual.
+    smooth = (crit in ((1, 0), (2, 0))) & ((b.shapes["type"][b.s1] == abi.GEOM_ELLIPSOID) | (b.shapes["type"][b.s2] == abi.GEOM_ELLIPSOID))
+    check_parity(abi, got[~smooth], ref[~smooth], dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name=name)
+    if smooth.any():
+        dd = np.abs(got["distance"][smooth] - ref["distance"][smooth])
+        assert np.array_equal(abi.status_contact(got["status"][smooth]), abi.status_contact(ref["status"][smooth])) or \
+            np.all(np.abs(ref["distance"][smooth][abi.status_contact(got["status"][smooth]) != abi.status_contact(ref["status"][smooth])]) < 1e-4)
+        assert (dd > 1e-4 * (1 + np.abs(ref["distance"][smooth]))).mean() < 2e-3, name
+    same_it = abi.status_gjk_iters(got["status"][~smooth]) == abi.status_gjk_iters(ref["status"][~smooth])
+    assert same_it.mean() > 0.99, same_it.mean()
 
 
 @pytest.mark.parametrize("case", ["cfg5_mixed", "cfg3_convex_convex"])
@@ -174,10 +198,21 @@ def test_edge_cases(pkg, oracle):
         else:
             got = lib.collide(s1, s2, tf1, tf2)
             ref = oracle.collide_batch(L.shapes_array(), L.vertices_array(), s1, s2, tf1, tf2)
-        check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-6, name="edge-" + kind,
-                     allow_bad_frac=1e-3)
-    one = lib.distance(s1[:1], s2[:1], tf1[:1], tf2[:1])
-    assert one["status"][0] == got["status"][0] or True
+        # Every record matches with no allowance, except one documented class: a hull against ITSELF at the same pose.
+        # Its Minkowski difference is centrally symmetric, so the closest faces come in opposite pairs at exactly the
+        # same distance and which of the two EPA ends on is decided by last-bit rounding in GJK's first steps (the GPU
+        # contracts a*b+c, the oracle does not).  There the depth must agree and the separation vectors must be equal
+        # or opposite; nothing else is excused.
+        twin = (s1 == s2) & (np.abs(tf1 - tf2).max(axis=1) == 0) & (L.shapes_array()["type"][s1] == abi.GEOM_CONVEX)
+        assert 0 < twin.sum() < 20
+        check_parity(abi, got[~twin], ref[~twin], dist_tol=1e-6, point_tol=1e-5, flag_band=1e-6, name="edge-" + kind)
+        gt, rt = got[twin], ref[twin]
+        assert np.array_equal(abi.status_contact(gt["status"]), abi.status_contact(rt["status"]))
+        assert np.abs(gt["distance"] - rt["distance"]).max() < 1e-9
+        sg, sr = gt["p2"] - gt["p1"], rt["p2"] - rt["p1"]
+        assert np.all(np.minimum(np.abs(sg - sr).max(axis=1), np.abs(sg + sr).max(axis=1)) < 1e-5)
+    one = lib.distance(s1[:1], s2[:1], tf1[:1], tf2[:1])  # a batch of one pair gives the record it has in the big batch
+    assert one.tobytes() == got[:1].tobytes() if kind == "distance" else True
     # unsupported pair kinds are reported, not silently computed
     Lb = pkg.ShapeLibrary()
     t = Lb.add_triangle([0, 0, 0], [1, 0, 0], [0, 1, 0])
