@@ -533,7 +533,7 @@ struct MeshShapeState {  // the CollisionResult fields the traversal maintains
 template <typename T, class Grp, class Solid, class OnContact>
 HFCL_HD void mesh_shape_collide(const DNode<T>* nodes, const T* mverts, const uint32_t* tris, const Pose<T>& tfm,
                                 const DShape<T>& shape, const T* sverts, const Pose<T>& tfs, const Solid& solid,
-                                const QParams<T>& q, uint32_t num_max_contacts, T break_distance2, uint16_t* stack, int cap,
+                                const QParams<T>& q, uint32_t num_max_contacts, T break_distance2, uint32_t* stack, int cap,
                                 EpaScratch<T, EPA_MAX_ITER>* scratch, const V3<T>& initial_guess, OnContact on_contact,
                                 MeshShapeState<T>& st) {
   const T nanv = Lim<T>::nan();
@@ -577,8 +577,8 @@ HFCL_HD void mesh_shape_collide(const DNode<T>* nodes, const T* mverts, const ui
       }
       Grp::sync();
       if (Grp::lane() == 0) {
-        stack[sp] = uint16_t(n1.first_child + 1);  // right child below
-        stack[sp + 1] = uint16_t(n1.first_child);  // left child on top
+        stack[sp] = uint32_t(n1.first_child + 1);  // right child below
+        stack[sp + 1] = uint32_t(n1.first_child);  // left child on top
       }
       sp += 2;
       Grp::sync();
@@ -642,7 +642,7 @@ struct MeshShapeDist {
 template <typename T, class Grp, class Solid>
 HFCL_HD void mesh_shape_distance(const DNode<T>* nodes, const DRss<T>* rss, const T* mverts, const uint32_t* tris,
                                  const Pose<T>& tfm, const DShape<T>& shape, const T* sverts, const Pose<T>& tfs,
-                                 const Solid& solid, const QParams<T>& q, uint16_t* stack_n, T* stack_d, int cap,
+                                 const Solid& solid, const QParams<T>& q, uint32_t* stack_n, T* stack_d, int cap,
                                  EpaScratch<T, EPA_MAX_ITER>* scratch, const V3<T>& initial_guess, MeshShapeDist<T>& st) {
   const T nanv = Lim<T>::nan();
   st.min_distance = Lim<T>::max();
@@ -715,9 +715,9 @@ HFCL_HD void mesh_shape_distance(const DNode<T>* nodes, const DRss<T>* rss, cons
     const bool c_first = d2 < d1;
     Grp::sync();
     if (Grp::lane() == 0) {
-      stack_n[sp] = uint16_t(c_first ? a1 : c1);  // visited second
+      stack_n[sp] = uint32_t(c_first ? a1 : c1);  // visited second
       stack_d[sp] = c_first ? d1 : d2;
-      stack_n[sp + 1] = uint16_t(c_first ? c1 : a1);  // visited first
+      stack_n[sp + 1] = uint32_t(c_first ? c1 : a1);  // visited first
       stack_d[sp + 1] = c_first ? d2 : d1;
     }
     sp += 2;

@@ -439,6 +439,15 @@ struct BvhSplit {
 #ifndef HFCL_BVH_BUDGET
 #define HFCL_BVH_BUDGET 0
 #endif
+// Global-memory continuation of the per-lane traversal stacks (models with more than 65535 BV nodes): `cap` entries per
+// lane of the launch, sized by the host from the depths of the registered models; the grid is limited to `max_blocks` so
+// that the slabs of all lanes fit the allocation.
+struct BvhSpill {
+  void* slab;
+  uint32_t cap;         // entries per lane
+  uint32_t max_blocks;  // blocks the slab allocation covers
+  uint32_t wide;        // 32-bit node ids in the stack entries
+};
 #ifndef HFCL_BVH_LEVELS
 #define HFCL_BVH_LEVELS 4
 #endif

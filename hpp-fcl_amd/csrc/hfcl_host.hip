@@ -130,6 +130,11 @@ struct hfcl_lib {
   float* d_bverts32 = nullptr;
   uint32_t* d_btris = nullptr;
   DMesh* d_meshes = nullptr;
+  // models too large (> 65535 nodes) or too deep for the LDS stacks: 32-bit node ids + per-lane global slabs (BvhSpill)
+  uint32_t bvh_max_depth = 0;
+  size_t bvh_max_nodes = 0;
+  void* d_bvh_slab = nullptr;
+  size_t bvh_slab_bytes = 0;
   // split mesh x mesh traversals (BvhSplit): task table, unit summaries, suspended-query list, counters
   BvhTask* d_bvh_tasks = nullptr;
   void* d_bvh_sums = nullptr;
@@ -405,6 +410,7 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_contacts);
   hipFree(lib->d_contacts_count);
   hipFree(lib->d_bvh_tasks);
+  hipFree(lib->d_bvh_slab);
   hipFree(lib->d_bvh_sums);
   hipFree(lib->d_bvh_susp);
   hipFree(lib->d_bvh_ctr);
@@ -427,8 +433,8 @@ int hfcl_lib_add_bvh(hfcl_lib* lib, const hfcl_bvh_node* nodes, size_t n_nodes, 
     set_error("hfcl_lib_add_bvh: a BVHModel with T triangles has exactly 2T-1 nodes");
     return -1;
   }
-  if (n_nodes > 65535) {
-    set_error("hfcl_lib_add_bvh: more than 65535 BV nodes per model (16-bit node ids on the device stack)");
+  if (n_nodes > 0x7FFFFFF0u || n_vertices > 0xFFFFFFF0u) {
+    set_error("hfcl_lib_add_bvh: model too large (node / vertex ids are 32-bit)");
     return -1;
   }
   for (size_t i = 0; i < n_nodes; ++i) {
@@ -452,6 +458,23 @@ int hfcl_lib_add_bvh(hfcl_lib* lib, const hfcl_bvh_node* nodes, size_t n_nodes, 
   lib->h_bvh_verts.insert(lib->h_bvh_verts.end(), vertices, vertices + 3 * n_vertices);
   lib->h_bvh_tris.insert(lib->h_bvh_tris.end(), triangles, triangles + 3 * n_tris);
   lib->h_meshes.push_back(m);
+  {  // depth of the tree (the traversal stacks are sized from it) -- iterative: degenerate models are as deep as they are big
+    std::vector<std::pair<uint32_t, uint32_t>> todo;
+    todo.emplace_back(0u, 1u);
+    uint32_t depth = 1;
+    while (!todo.empty()) {
+      const auto [i, d] = todo.back();
+      todo.pop_back();
+      depth = std::max(depth, d);
+      const int fc = nodes[i].first_child;
+      if (fc > 0) {
+        todo.emplace_back(uint32_t(fc), d + 1);
+        todo.emplace_back(uint32_t(fc) + 1u, d + 1);
+      }
+    }
+    lib->bvh_max_depth = std::max(lib->bvh_max_depth, depth);
+    lib->bvh_max_nodes = std::max<size_t>(lib->bvh_max_nodes, n_nodes);
+  }
   lib->bvh_dirty = true;
   return int(lib->h_meshes.size() - 1);
 }
@@ -498,6 +521,34 @@ static int ensure_bvh_split(hfcl_lib* lib, size_t n) {
   if (!lib->d_bvh_ctr) HIP_TRY(hipMalloc(&lib->d_bvh_ctr, BVH_CTR_WORDS * sizeof(uint32_t)));
   lib->bvh_split_n = nq;
   lib->bvh_split_cap = cap;
+  return HFCL_OK;
+}
+
+// How the mesh x mesh traversals of this library keep their stacks.  A stack never holds more than depth1 + depth2 + 2
+// entries (every step pops one entry and pushes at most two, one level deeper in one of the trees).
+static int make_bvh_spill(hfcl_lib* lib, BvhSpill& sp, bool distance) {
+  memset(&sp, 0, sizeof(sp));
+  const size_t need = 2 * size_t(lib->bvh_max_depth) + 4;
+  // collide(): a full LDS stack first suspends into tasks (HFCL_BVH_LEVELS levels of BVH_STACK entries); distance() has
+  // no task form: anything deeper than its LDS stack takes the wide form with slabs
+  const size_t narrow_holds = distance ? size_t(BVHD_STACK) : size_t(BVH_STACK) * HFCL_BVH_LEVELS;
+  sp.wide = (lib->bvh_max_nodes > 65535 || need > narrow_holds) ? 1u : 0u;
+  if (getenv("HFCL_BVH_FORCE_WIDE")) sp.wide = 1u;  // test knob: the wide form (and its slabs) on small models
+  if (!sp.wide || need <= size_t(BVH_STACK) / 2) return HFCL_OK;  // the LDS stack of the wide form suffices
+  const size_t cap = ((need + 63) / 64) * 64;                     // entries per lane
+  const size_t per_block = size_t(BVH_BLOCK) * cap * 2 * sizeof(uint64_t);  // (entry, bound) records: k_bvh_distance
+  size_t blocks = std::min<size_t>(size_t(lib->n_cus) * 16, std::max<size_t>(1, (size_t(2) << 30) / per_block));
+  const size_t bytes = blocks * per_block;
+  if (bytes > lib->bvh_slab_bytes) {
+    hipFree(lib->d_bvh_slab);
+    lib->d_bvh_slab = nullptr;
+    lib->bvh_slab_bytes = 0;
+    HIP_TRY(hipMalloc(&lib->d_bvh_slab, bytes));
+    lib->bvh_slab_bytes = bytes;
+  }
+  sp.slab = lib->d_bvh_slab;
+  sp.cap = uint32_t(cap);
+  sp.max_blocks = uint32_t(blocks);
   return HFCL_OK;
 }
 
@@ -758,6 +809,9 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     bv.tris = lib->d_btris;
     bv.meshes = lib->d_meshes;
     bv.n_meshes = uint32_t(lib->h_meshes.size());
+    BvhSpill spill;
+    rc = make_bvh_spill(lib, spill, q.mode != 1);
+    if (rc) return rc;
     if (q.mode == 1) {
       tbeg("k_bvh_shape");
       launch_bvh_shape<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance));
@@ -767,7 +821,8 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       memset(&split, 0, sizeof(split));
       // long traversals are cut into tasks when the batch is large enough for the tail to matter and the request
       // keeps no query-wide contact count
-      if (may(B_BVH) && lib->bvh_levels > 1 && n >= 2048 && lib->bvh_params.num_max_contacts == 1 && !lib->bvh_params.contacts) {
+      if (may(B_BVH) && !spill.wide && lib->bvh_levels > 1 && (n >= 2048 || 2 * size_t(lib->bvh_max_depth) + 4 > size_t(BVH_STACK)) &&
+          lib->bvh_params.num_max_contacts == 1 && !lib->bvh_params.contacts) {
         rc = ensure_bvh_split(lib, n);
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(lib->d_bvh_ctr, 0, BVH_CTR_WORDS * sizeof(uint32_t), st));
@@ -780,14 +835,14 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         split.budget = lib->bvh_budget;
         split.n_levels = lib->bvh_levels;
       }
-      launch_bvh_collide<T>(blocks_for(n, BVH_BLOCK), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance), split);
+      launch_bvh_collide<T>(blocks_for(n, BVH_BLOCK), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance), split, spill);
       tend();
     } else {
       tbeg("k_bvh_shape_distance");
       launch_bvh_shape_distance<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q);
       tend();
       tbeg("k_bvh_distance");
-      launch_bvh_distance<T>(blocks_for(n, BVHD_BLOCK), st, wk, lv, bv, io, q);
+      launch_bvh_distance<T>(blocks_for(n, BVHD_BLOCK), st, wk, lv, bv, io, q, spill);
       tend();
     }
   }

@@ -27,10 +27,36 @@
 template <typename T>
 __device__ __forceinline__ BvhSum<T>* bvh_sum(const BvhSplit& sp, uint32_t slot) { return reinterpret_cast<BvhSum<T>*>(sp.sums) + slot; }
 
-template <typename T>
+// WIDE: models of more than 65535 BV nodes.  A stack entry is then two 32-bit node ids (the LDS stack holds half as
+// many), and a lane whose LDS stack is full moves its lower half to a slab of its own in global memory (BvhSpill) and
+// takes it back when the LDS part runs empty: the reference's stack is a growable std::vector
+// (traversal_recurse.cpp:95), a traversal here is bounded by the slab the host sized from the depths of the models.
+template <bool WIDE> struct BvhEntry;
+template <> struct BvhEntry<false> {
+  typedef uint32_t E;
+  static constexpr int STACK = BVH_STACK;
+  static __device__ __forceinline__ E pack(uint32_t b1, uint32_t b2) { return b1 | (b2 << 16); }
+  static __device__ __forceinline__ uint32_t first(E e) { return e & 0xFFFFu; }
+  static __device__ __forceinline__ uint32_t second(E e) { return e >> 16; }
+};
+template <> struct BvhEntry<true> {
+  typedef uint64_t E;
+  static constexpr int STACK = BVH_STACK / 2;
+  static __device__ __forceinline__ E pack(uint32_t b1, uint32_t b2) { return uint64_t(b1) | (uint64_t(b2) << 32); }
+  static __device__ __forceinline__ uint32_t first(E e) { return uint32_t(e); }
+  static __device__ __forceinline__ uint32_t second(E e) { return uint32_t(e >> 32); }
+};
+
+template <typename T, bool WIDE>
 __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH, 8))) k_bvh_collide(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
-                                                          BvhParams bp, T break_distance2, BvhSplit split) {
-  __shared__ uint32_t stack[BVH_STACK][BVH_BLOCK];
+                                                          BvhParams bp, T break_distance2, BvhSplit split, BvhSpill spill) {
+  typedef BvhEntry<WIDE> EN;
+  typedef typename EN::E E;
+  constexpr int STACK = EN::STACK, HALF = EN::STACK / 2;
+  __shared__ E stack[STACK][BVH_BLOCK];
+  // this lane's slab of spilled entries (WIDE only)
+  E* const slab = WIDE && spill.slab ? reinterpret_cast<E*>(spill.slab) + size_t(blockIdx.x * BVH_BLOCK + threadIdx.x) * spill.cap : nullptr;
+  uint32_t nspill = 0;
   const uint32_t level = split.level;
   const uint32_t unit0 = level ? split.ctr[BVH_CTR_LEVEL0 + level - 1] : 0u;  // first task of this level
   const uint32_t cnt = level ? min(split.ctr[BVH_CTR_LEVEL0 + level], split.cap) - min(unit0, split.cap) : wk.counts[B_BVH];
@@ -83,7 +109,7 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   // of the next level and park this unit.  false: no room in the task table (the unit then simply goes on).
   auto suspend = [&](uint32_t ea, uint32_t eb, int n_extra) -> bool {
     const uint32_t n_child = uint32_t(sp + n_extra);
-    if (!split.can_suspend || n_child == 0) return false;
+    if (WIDE || !split.can_suspend || n_child == 0) return false;  // (tasks carry 16-bit node ids)
     const uint32_t first = atomicAdd(&split.ctr[BVH_CTR_TASKS], n_child);
     if (first + n_child > split.cap) {  // table full: the slots taken become no-ops for the next level
       for (uint32_t j = first; j < min(first + n_child, split.cap); ++j) split.tasks[j] = BvhTask{0u, 0u, 0xFFFFFFFFu, 0u};
@@ -99,13 +125,19 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
     uint32_t j = first;
     if (n_extra > 0) split.tasks[j++] = BvhTask{pair, my_slot, ea, 0u};
     if (n_extra > 1) split.tasks[j++] = BvhTask{pair, my_slot, eb, 0u};
-    for (int k = sp - 1; k >= 0; --k) split.tasks[j++] = BvhTask{pair, my_slot, stack[k][tid], 0u};  // DFS order: top first
+    for (int k = sp - 1; k >= 0; --k) split.tasks[j++] = BvhTask{pair, my_slot, uint32_t(stack[k][tid]), 0u};  // DFS order: top first
     write_sum(my_slot, first, n_child, BVH_SUM_SUSPENDED);
     sp = 0;
     live = false;  // nothing to flush: the summary is written
     return true;
   };
   for (;;) {
+    if (WIDE && live && !have_leaf && sp == 0 && nspill > 0) {  // the LDS part ran empty: take spilled entries back
+      const uint32_t m = min(nspill, uint32_t(HALF));
+      for (uint32_t k = 0; k < m; ++k) stack[k][tid] = slab[nspill - m + k];
+      nspill -= m;
+      sp = int(m);
+    }
     if (live && !have_leaf && sp == 0) {  // traversal over
       live = false;
       pending = true;
@@ -127,14 +159,14 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
         const uint32_t rank = uint32_t(__popcll(~live_mask & ((uint64_t(1) << lane) - 1)));
         const uint32_t it = base + rank;
         if (it < cnt) {
-          uint32_t entry = 0u;  // (b1 = 0, b2 = 0)
+          E entry = 0u;  // (b1 = 0, b2 = 0)
           bool valid = true;
           if (level) {
             unit = unit0 + it;
             const BvhTask t = split.tasks[unit];
             pair = t.pair;
             entry = t.entry;
-            valid = entry != 0xFFFFFFFFu;
+            valid = t.entry != 0xFFFFFFFFu;
           } else {
             pair = wk.lists[size_t(B_BVH) * wk.n + it];
           }
@@ -148,6 +180,7 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
             RT_T = tmul(tf1.R, tf2.t - tf1.t);
             stack[0][tid] = entry;
             sp = 1;
+            nspill = 0;
             steps = 0;
             overflow = false;
             ncontacts = 0;
@@ -168,12 +201,12 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
       const bool can_bv = live && !have_leaf && sp > 0;
       if (!__any(can_bv)) break;
       if (__popcll(__ballot(have_leaf)) >= 32) break;
-      if (!exhausted && 64 - __popcll(__ballot(live && (have_leaf || sp > 0))) >= refill_min) break;
+      if (!exhausted && 64 - __popcll(__ballot(live && (have_leaf || sp > 0 || nspill > 0))) >= refill_min) break;
       if (can_bv) {
         if (budget && steps >= budget && suspend(0u, 0u, 0)) continue;
         ++steps;
-        const uint32_t e = stack[--sp][tid];
-        const uint32_t b1 = e & 0xFFFFu, b2 = e >> 16;
+        const E e = stack[--sp][tid];
+        const uint32_t b1 = EN::first(e), b2 = EN::second(e);
         const DNode<T> n1 = bv.nodes[m1.node_off + b1];
         const DNode<T> n2 = bv.nodes[m2.node_off + b2];
         const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
@@ -196,22 +229,30 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
           } else {
             const T sz1 = sqnorm(n1.extent), sz2 = sqnorm(n2.extent);
             const bool first = l2 || (!l1 && (sz1 > sz2));  // firstOverSecond
-            uint32_t ea, eb;
+            E ea, eb;
             if (first) {
               const uint32_t c1 = uint32_t(n1.first_child);
-              ea = c1 | (b2 << 16);
-              eb = (c1 + 1) | (b2 << 16);
+              ea = EN::pack(c1, b2);
+              eb = EN::pack(c1 + 1, b2);
             } else {
               const uint32_t c1 = uint32_t(n2.first_child);
-              ea = b1 | (c1 << 16);
-              eb = b1 | ((c1 + 1) << 16);
+              ea = EN::pack(b1, c1);
+              eb = EN::pack(b1, c1 + 1);
             }
-            if (sp + 2 > BVH_STACK) {
+            if (WIDE && sp + 2 > STACK && slab && nspill + uint32_t(HALF) <= spill.cap) {
+              // the LDS stack is full: its lower half (the entries needed last) moves to the lane's slab
+              for (int k = 0; k < HALF; ++k) slab[nspill + k] = stack[k][tid];
+              nspill += uint32_t(HALF);
+              for (int k = HALF; k < sp; ++k) stack[k - HALF][tid] = stack[k][tid];
+              sp -= HALF;
+            }
+            if (sp + 2 > STACK) {
               // the LDS stack is full: the whole stack (and the two children) go on as tasks; only where that is not
-              // possible (contact lists, last level, task table full) the unit is flagged as overflowed
-              if (!suspend(ea, eb, 2)) {
+              // possible (contact lists, last level, task table full, slab full) the unit is flagged as overflowed
+              if (!suspend(uint32_t(ea), uint32_t(eb), 2)) {
                 overflow = true;
                 sp = 0;
+                nspill = 0;
               }
             } else {
               stack[sp++][tid] = eb;  // second child below
@@ -273,7 +314,10 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
             }
           }
         }
-        if (ncontacts >= bp.num_max_contacts) sp = 0;  // canStop(): nothing else is visited
+        if (ncontacts >= bp.num_max_contacts) {  // canStop(): nothing else is visited
+          sp = 0;
+          nspill = 0;
+        }
       }
     }
   }
@@ -361,7 +405,7 @@ __global__ void __launch_bounds__(64) k_bvh_shape(Work wk, LibView<T> lib, BvhVi
                                                   T break_distance2) {
   constexpr int G = 64 / BS_W;
   __shared__ EpaScratch<T, EPA_MAX_ITER> scratch[G];
-  __shared__ uint16_t stacks[G][BS_STACK];
+  __shared__ uint32_t stacks[G][BS_STACK];  // 32-bit node ids: models of any size
   const uint32_t cnt = wk.counts[B_BVHSHAPE];
   const int lane = threadIdx.x & 63, grp = lane / BS_W, lig = lane & (BS_W - 1);
   for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += gridDim.x * G) {
@@ -457,7 +501,7 @@ template <typename T>
 __global__ void __launch_bounds__(64) k_bvh_shape_distance(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q) {
   constexpr int G = 64 / BS_W;
   __shared__ EpaScratch<T, EPA_MAX_ITER> scratch[G];
-  __shared__ uint16_t stack_n[G][BS_STACK];
+  __shared__ uint32_t stack_n[G][BS_STACK];
   __shared__ T stack_d[G][BS_STACK];
   const uint32_t cnt = wk.counts[B_BVHSHAPE];
   const int lane = threadIdx.x & 63, grp = lane / BS_W, lig = lane & (BS_W - 1);
@@ -511,10 +555,17 @@ __global__ void __launch_bounds__(64) k_bvh_shape_distance(Work wk, LibView<T> l
 // sqrTriDistance in model 1's frame; the result is seeded with triangle 0 x triangle 0 (preprocess).
 // ---------------------------------------------------------------------------------------
 
-template <typename T>
-__global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH, 8))) k_bvh_distance(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q) {
-  __shared__ uint32_t stack_e[BVHD_STACK][BVHD_BLOCK];
-  __shared__ T stack_d[BVHD_STACK][BVHD_BLOCK];
+template <typename T, bool WIDE>
+__global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH, 8))) k_bvh_distance(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhSpill spill) {
+  typedef BvhEntry<WIDE> EN;
+  typedef typename EN::E E;
+  constexpr int STACK = WIDE ? (BVHD_STACK * 3) / 4 : BVHD_STACK, HALF = STACK / 2;
+  __shared__ E stack_e[STACK][BVHD_BLOCK];
+  __shared__ T stack_d[STACK][BVHD_BLOCK];
+  // this lane's slab of spilled (entry, bound) records (WIDE only): entries first, bounds behind them
+  E* const slab_e = WIDE && spill.slab ? reinterpret_cast<E*>(spill.slab) + size_t(blockIdx.x * BVHD_BLOCK + threadIdx.x) * spill.cap * 2 : nullptr;
+  T* const slab_d = reinterpret_cast<T*>(slab_e + spill.cap);
+  uint32_t nspill = 0;
   const uint32_t cnt = wk.counts[B_BVH];
   uint32_t* const ticket = &wk.counts[B_COUNT + 2];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -531,6 +582,16 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
   V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1;
   bool overflow = false;
   int sp = 0;
+  auto reload = [&]() {  // the LDS part ran empty: take spilled records back (WIDE)
+    if (!WIDE || nspill == 0) return;
+    const uint32_t m = min(nspill, uint32_t(HALF));
+    for (uint32_t k = 0; k < m; ++k) {
+      stack_e[k][tid] = slab_e[nspill - m + k];
+      stack_d[k][tid] = slab_d[nspill - m + k];
+    }
+    nspill -= m;
+    sp = int(m);
+  };
   auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
   auto leaf = [&](uint32_t p1i, uint32_t p2i) {
     const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
@@ -550,6 +611,7 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
     }
   };
   for (;;) {
+    if (live && sp == 0) reload();
     if (live && sp == 0) {
       live = false;
       pending = true;
@@ -589,6 +651,7 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
           fb1 = fb2 = -1;
           np1 = np2 = mk<T>(nanv, nanv, nanv);
           overflow = false;
+          nspill = 0;
           leaf(0u, 0u);  // preprocess()
           sp = 1;
           stack_e[0][tid] = 0u;
@@ -601,14 +664,17 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
     }
     for (;;) {
       const bool run = live && sp > 0;
-      const int n_run = __popcll(__ballot(run));
+      const int n_run = __popcll(__ballot(run || (live && nspill > 0)));
       if (n_run == 0 || (!exhausted && 64 - n_run >= BVH_REFILL_MIN)) break;
-      if (!run) continue;
+      if (!run) {
+        if (live) reload();
+        continue;
+      }
       --sp;
-      const uint32_t e = stack_e[sp][tid];
+      const E e = stack_e[sp][tid];
       const T de = stack_d[sp][tid];
       if (de >= T(0) && de >= mind) continue;  // canStop(d)
-      const uint32_t b1 = e & 0xFFFFu, b2 = e >> 16;
+      const uint32_t b1 = EN::first(e), b2 = EN::second(e);
       const DNode<T> n1 = bv.nodes[m1.node_off + b1];
       const DNode<T> n2 = bv.nodes[m2.node_off + b2];
       const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
@@ -632,12 +698,25 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
                                    bv.nodes[m2.node_off + a2], bv.rss[m2.node_off + a2]);
       const T d2 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + c1], bv.rss[m1.node_off + c1],
                                    bv.nodes[m2.node_off + c2], bv.rss[m2.node_off + c2]);
-      if (sp + 2 > BVHD_STACK) {
+      if (WIDE && sp + 2 > STACK && slab_e && nspill + uint32_t(HALF) <= spill.cap) {  // lower half -> the lane's slab
+        for (int k = 0; k < HALF; ++k) {
+          slab_e[nspill + k] = stack_e[k][tid];
+          slab_d[nspill + k] = stack_d[k][tid];
+        }
+        nspill += uint32_t(HALF);
+        for (int k = HALF; k < sp; ++k) {
+          stack_e[k - HALF][tid] = stack_e[k][tid];
+          stack_d[k - HALF][tid] = stack_d[k][tid];
+        }
+        sp -= HALF;
+      }
+      if (sp + 2 > STACK) {
         overflow = true;
         sp = 0;
+        nspill = 0;
         continue;
       }
-      const uint32_t ea = a1 | (a2 << 16), ec = c1 | (c2 << 16);
+      const E ea = EN::pack(a1, a2), ec = EN::pack(c1, c2);
       const bool c_first = d2 < d1;  // visit (c1,c2) first when it is strictly nearer
       stack_e[sp][tid] = c_first ? ea : ec;
       stack_d[sp][tid] = c_first ? d1 : d2;
@@ -655,13 +734,23 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
 // One level per launch (levels > 0 walk the tasks the level before made), the fold-back launches in reverse order.
 // split.tasks == nullptr (or split.n_levels <= 1): the plain single-pass traversal.
 template <typename T>
-void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split) {
+void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill) {
+  if (spill.wide) {  // models with 32-bit node ids: single pass, global spill instead of tasks
+    split.tasks = nullptr;
+    split.budget = 0;
+    split.level = 0;
+    split.can_suspend = 0;
+    if (spill.slab) grid = std::min(grid, int(spill.max_blocks));
+    hipLaunchKernelGGL((k_bvh_collide<T, true>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
+    return;
+  }
   const bool splitting = split.tasks && split.n_levels > 1 && bp.num_max_contacts == 1 && !bp.contacts;
   if (!splitting) {
     split.tasks = nullptr;
     split.budget = 0;
     split.level = 0;
-    hipLaunchKernelGGL((k_bvh_collide<T>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split);
+    split.can_suspend = 0;
+    hipLaunchKernelGGL((k_bvh_collide<T, false>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
     return;
   }
   const uint32_t budget = split.budget;
@@ -670,7 +759,7 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
     split.budget = l + 1 < split.n_levels ? budget : 0u;  // the last level runs to the end
     BvhSplit s = split;
     s.can_suspend = l + 1 < split.n_levels;  // ... and cannot suspend (its stack overflows are flagged)
-    hipLaunchKernelGGL((k_bvh_collide<T>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, s);
+    hipLaunchKernelGGL((k_bvh_collide<T, false>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, s, spill);
     hipLaunchKernelGGL(k_bvh_level_mark, dim3(1), dim3(64), 0, st, wk, s);
   }
   for (int l = int(split.n_levels) - 2; l >= 0; --l) {
@@ -679,8 +768,13 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
   }
 }
 template <typename T>
-void launch_bvh_distance(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q) {
-  hipLaunchKernelGGL((k_bvh_distance<T>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q);
+void launch_bvh_distance(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, BvhSpill spill) {
+  if (spill.wide) {
+    if (spill.slab) grid = std::min(grid, int(spill.max_blocks) * (BVH_BLOCK / BVHD_BLOCK));
+    hipLaunchKernelGGL((k_bvh_distance<T, true>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q, spill);
+  } else {
+    hipLaunchKernelGGL((k_bvh_distance<T, false>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q, spill);
+  }
 }
 template <typename T>
 void launch_bvh_shape(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2) {
@@ -695,8 +789,8 @@ void launch_triangle(int grid, hipStream_t st, const Work& wk, const LibView<T>&
   hipLaunchKernelGGL((k_triangle<T>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
 }
 #define HFCL_INST(T)                                                                                                             \
-  template void launch_bvh_collide<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit); \
-  template void launch_bvh_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&);                \
+  template void launch_bvh_collide<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill); \
+  template void launch_bvh_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, BvhSpill);                \
   template void launch_bvh_shape<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T);   \
   template void launch_bvh_shape_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&);          \
   template void launch_triangle<T>(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&);

@@ -446,7 +446,7 @@ int sim_mesh_shape_collide_f64(const hfcl_shape* shapes, size_t n_shapes, const 
   q.gjk.distance_upper_bound = ub < 0 ? 0 : ub;
   std::vector<hfcl_contact> cl;
   static thread_local EpaScratch<double, EPA_MAX_ITER> scratch;
-  uint16_t stack[128];
+  uint32_t stack[128];
   for (size_t i = 0; i < n; ++i) {
     const hfcl_shape &a = shapes[s1[i]], &b = shapes[s2[i]];
     const bool swapped = a.type != HFCL_BV_OBBRSS;
@@ -533,7 +533,7 @@ int sim_mesh_shape_distance_f64(const hfcl_shape* shapes, size_t n_shapes, const
   q.security_margin = 0;
   q.gjk.distance_upper_bound = Lim<double>::max();
   static thread_local EpaScratch<double, EPA_MAX_ITER> scratch;
-  uint16_t stack_n[128];
+  uint32_t stack_n[128];
   double stack_d[128];
   for (size_t i = 0; i < n; ++i) {
     const hfcl_shape &a = shapes[s1[i]], &b = shapes[s2[i]];

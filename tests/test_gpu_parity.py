@@ -471,6 +471,84 @@ def test_bvh_distance(pkg, oracle, seg, n, hw):
     assert np.abs(np.linalg.norm(got["p2"][pos] - got["p1"][pos], axis=1) - got["distance"][pos]).max() < 1e-7
 
 
+def _mesh_batch(pkg, meshes, n, seed, half_width):
+    wl, g = pkg.workloads, pkg.geometry
+    rng = np.random.default_rng(seed)
+    lib = g.ShapeLibrary()
+    for k, m in enumerate(meshes):
+        lib.add_bvh(k, len(m.vertices))
+    s1, s2 = rng.integers(0, len(meshes), n), rng.integers(0, len(meshes), n)
+    q1, T1, q2, T2 = wl._poses(rng, n, half_width)
+    b = wl.Batch("mesh_pairs", lib, s1, s2, q1, T1, q2, T2, "collide")
+    b.meshes = meshes
+    return b
+
+
+def test_bvh_models_beyond_16_bit_node_ids(pkg, oracle):
+    """A BVHModel of 72 200 triangles (144 399 nodes: node ids no longer fit 16 bits, BV_node.h:57 uses int): collide()
+    and distance() against the oracle, no traversal flagged as overflowed."""
+    abi, bb = pkg.abi, pkg.bvh_builder
+    big = bb.Mesh(*bb.bumpy_sphere(190, 190, r=1.0, amp=0.1, freq=3, phase=0.3))
+    small = bb.Mesh(*bb.bumpy_sphere(20, 20, r=0.7, amp=0.1, freq=2, phase=0.1))
+    assert len(big.nodes) > 65535
+    b = _mesh_batch(pkg, [big, small], 600, 3, 1.1)
+    ML = bb.MeshLibrary(b.meshes)
+    lib = pkg.workloads.make_library(pkg, b)
+    req = pkg.workloads.make_request(b, abi)
+    got = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
+    ref = oracle.bvh_collide_batch(ML, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=16)
+    _check_bvh_records(abi, got, ref, "bvh-wide")
+    assert 0.1 < (ref["num_contacts"] > 0).mean() < 0.9
+    gd = lib.distance(b.s1, b.s2, b.tf1, b.tf2)
+    rd = oracle.bvh_distance_batch(ML, b.s1, b.s2, b.tf1, b.tf2, n_threads=16)
+    assert not np.any((gd["status"] >> 30) & 1)
+    assert np.abs(gd["distance"] - rd["distance"]).max() < 1e-9
+    lib.close()
+
+
+@pytest.mark.parametrize("force_wide", [False, True])
+def test_bvh_degenerate_deep_tree(pkg, oracle, force_wide, monkeypatch):
+    """A strip of triangles whose positions grow geometrically: the mean split (BV_splitter) peels a few triangles off
+    per level and the tree gets deep (133 levels here; a mean split can only stay this lopsided while the coordinates
+    grow faster than geometrically, so the range of a double bounds the depth of any BVHModel to a few hundred levels).
+    The reference's traversal stack is a growable vector (traversal_recurse.cpp:95).  Here a full 96-entry LDS stack
+    suspends into tasks (default form), or continues in a per-lane global slab (wide form: models beyond 65535 nodes or
+    deeper than the task levels hold; forced here with HFCL_BVH_FORCE_WIDE).  collide() and distance() vs the oracle."""
+    abi, bb = pkg.abi, pkg.bvh_builder
+    if force_wide:
+        monkeypatch.setenv("HFCL_BVH_FORCE_WIDE", "1")
+    nt, r = 1200, 3.2
+    x = r ** (np.arange(nt // 2 + 2) - float(nt // 2 + 1))  # largest coordinate 1
+    v = np.zeros((2 * (nt // 2 + 2), 3))
+    k = np.arange(len(v) // 2)
+    v[0::2] = np.stack([x[k], 0 * x[k], 0.02 * x[k]], 1)
+    v[1::2] = np.stack([x[k], 0.3 * x[k], -0.02 * x[k]], 1)
+    t = np.array([[i, i + 1, i + 2] for i in range(nt)], dtype=np.uint32)
+    m = bb.Mesh(v, t)
+    depth = 1 + int(_depths(m.nodes).max())
+    assert depth > 100, depth
+    b = _mesh_batch(pkg, [m], 256, 4, 0.05)
+    ML = bb.MeshLibrary(b.meshes)
+    lib = pkg.workloads.make_library(pkg, b)
+    req = pkg.workloads.make_request(b, abi)
+    got = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
+    ref = oracle.bvh_collide_batch(ML, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=16)
+    _check_bvh_records(abi, got, ref, "bvh-deep")
+    gd = lib.distance(b.s1, b.s2, b.tf1, b.tf2)
+    rd = oracle.bvh_distance_batch(ML, b.s1, b.s2, b.tf1, b.tf2, n_threads=16)
+    assert not np.any((gd["status"] >> 30) & 1)
+    assert np.abs(gd["distance"] - rd["distance"]).max() < 1e-9
+    lib.close()
+
+
+def _depths(nodes):
+    d = np.zeros(len(nodes), dtype=np.int64)
+    for i, fc in enumerate(nodes["first_child"]):  # children always follow their parent in the node array
+        if fc > 0:
+            d[fc] = d[fc + 1] = d[i] + 1
+    return d
+
+
 def test_cpp_shim_runs_reference_style_tests(pkg):
     """tests/cpp/test_compat.cpp: hpp-fcl-named C++ (collide/distance/CollisionRequest/...) on the GPU."""
     import os
