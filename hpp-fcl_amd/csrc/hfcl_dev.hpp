@@ -408,7 +408,7 @@ struct BvhTask {
   uint32_t pair;    // the query
   uint32_t parent;  // summary slot of the unit that made the task
   uint32_t entry;   // the subtree pair to walk (b1 | b2 << 16); 0xFFFFFFFF: no-op (the task table was full)
-  uint32_t pad_;
+  uint32_t order;   // position among the parent's children (0 = visited first)
 };
 enum { BVH_SUM_SUSPENDED = 1u, BVH_SUM_OVERFLOW = 2u };
 template <typename T>
@@ -418,6 +418,9 @@ struct BvhSum {  // what a unit (query or task) knows when it ends or suspends
   V3<T> np1, np2, nn;  // ... and that leaf's witness points / normal
   int32_t fb1, fb2;  // first contact
   uint32_t ncontacts, first_child, n_child, flags;
+  // cancellation of speculative work: the smallest `order` among this unit's children that found a contact (the walk
+  // ends there: children after it, and everything below them, are moot), and where the unit itself hangs
+  uint32_t contact_order, parent, order, pad_;
 };
 // counters of a split traversal (device words)
 enum { BVH_CTR_TASKS = 0, BVH_CTR_SUSPENDED = 1, BVH_CTR_LEVEL0 = 2 /* [2 + k] = number of tasks made before level k ended */, BVH_CTR_WORDS = 16 };

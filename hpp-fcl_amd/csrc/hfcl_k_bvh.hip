@@ -82,8 +82,10 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   int fb1 = -1, fb2 = -1;
   bool have_leaf = false;
   uint32_t lb1 = 0, lb2 = 0;
+  uint32_t my_parent = 0xFFFFFFFFu, my_order = 0;  // (tasks) where this unit hangs
   auto write_sum = [&](uint32_t slot, uint32_t first_child, uint32_t n_child, uint32_t flags) {
     BvhSum<T> s;
+    s.contact_order = 0xFFFFFFFFu; s.parent = my_parent; s.order = my_order; s.pad_ = 0;
     s.dlb = dlb; s.rec_dist = rec_dist; s.cand_val = cand_val;
     s.np1 = np1; s.np2 = np2; s.nn = nn;
     s.fb1 = fb1; s.fb2 = fb2;
@@ -105,6 +107,26 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
     o.gjk_iters = o.epa_iters = 0;
     store_bvh_record(io, pair, o, ncontacts, fb1, fb2, overflow);
   };
+  // Is the work of the task (parent slot p, position o) still needed?  Not if an earlier sibling -- of it or of any of its
+  // ancestors -- has found a contact: the sequential walk would have ended there.
+  auto moot = [&](uint32_t p, uint32_t o) -> bool {
+    for (int hop = 0; hop < HFCL_BVH_LEVELS + 1 && p != 0xFFFFFFFFu; ++hop) {
+      const BvhSum<T>* ps = bvh_sum<T>(split, p);
+      if (__hip_atomic_load(&ps->contact_order, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o) return true;
+      o = ps->order;
+      p = ps->parent;
+    }
+    return false;
+  };
+  // a contact in this task ends the walk of every unit above it at this child's position
+  auto report_contact = [&](uint32_t p, uint32_t o) {
+    for (int hop = 0; hop < HFCL_BVH_LEVELS + 1 && p != 0xFFFFFFFFu; ++hop) {
+      BvhSum<T>* ps = bvh_sum<T>(split, p);
+      atomicMin(&ps->contact_order, o);
+      o = ps->order;
+      p = ps->parent;
+    }
+  };
   // Turn the `n_extra` entries in `extra` (children about to be pushed: first one on top) and the whole stack into tasks
   // of the next level and park this unit.  false: no room in the task table (the unit then simply goes on).
   auto suspend = [&](uint32_t ea, uint32_t eb, int n_extra) -> bool {
@@ -122,11 +144,12 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
       my_slot = atomicAdd(&split.ctr[BVH_CTR_SUSPENDED], 1u);  // < n_queries: one per query at most
       split.suspended[my_slot] = pair;
     }
-    uint32_t j = first;
-    if (n_extra > 0) split.tasks[j++] = BvhTask{pair, my_slot, ea, 0u};
-    if (n_extra > 1) split.tasks[j++] = BvhTask{pair, my_slot, eb, 0u};
-    for (int k = sp - 1; k >= 0; --k) split.tasks[j++] = BvhTask{pair, my_slot, uint32_t(stack[k][tid]), 0u};  // DFS order: top first
-    write_sum(my_slot, first, n_child, BVH_SUM_SUSPENDED);
+    write_sum(my_slot, first, n_child, BVH_SUM_SUSPENDED);  // (before the tasks: they point at it)
+    __threadfence();
+    uint32_t j = first, o = 0;
+    if (n_extra > 0) split.tasks[j++] = BvhTask{pair, my_slot, ea, o++};
+    if (n_extra > 1) split.tasks[j++] = BvhTask{pair, my_slot, eb, o++};
+    for (int k = sp - 1; k >= 0; --k) split.tasks[j++] = BvhTask{pair, my_slot, uint32_t(stack[k][tid]), o++};  // DFS order: top first
     sp = 0;
     live = false;  // nothing to flush: the summary is written
     return true;
@@ -166,7 +189,16 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
             const BvhTask t = split.tasks[unit];
             pair = t.pair;
             entry = t.entry;
+            my_parent = t.parent;
+            my_order = t.order;
             valid = t.entry != 0xFFFFFFFFu;
+            if (valid && moot(my_parent, my_order)) {  // speculative work nobody will read: an empty summary
+              valid = false;
+              dlb = rec_dist = cand_val = Lim<T>::max();
+              ncontacts = 0;
+              overflow = false;
+              write_sum(split.n_queries + unit, 0u, 0u, 0u);
+            }
           } else {
             pair = wk.lists[size_t(B_BVH) * wk.n + it];
           }
@@ -204,6 +236,10 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
       if (!exhausted && 64 - __popcll(__ballot(live && (have_leaf || sp > 0 || nspill > 0))) >= refill_min) break;
       if (can_bv) {
         if (budget && steps >= budget && suspend(0u, 0u, 0)) continue;
+        if (level && (steps & 15u) == 15u && moot(my_parent, my_order)) {  // an earlier sibling ended the walk meanwhile
+          sp = 0;
+          continue;
+        }
         ++steps;
         const E e = stack[--sp][tid];
         const uint32_t b1 = EN::first(e), b2 = EN::second(e);
@@ -296,6 +332,7 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
           if (ncontacts == 0) {
             fb1 = int(lb1);
             fb2 = int(lb2);
+            if (level) report_contact(my_parent, my_order);
           }
           ++ncontacts;
           if (bp.contacts) {
