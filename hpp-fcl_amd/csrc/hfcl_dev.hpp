@@ -433,6 +433,7 @@ struct BvhSplit {
   uint32_t budget;      // BV-test steps before a unit suspends (0: never)
   uint32_t level, n_levels;
   uint32_t can_suspend;
+  uint32_t steal;       // 1: k_bvh_collide_ws (work stealing inside the wavefront; `sums` is its segment pool)
 };
 // Step budget per unit.  0 (default): units only suspend when their LDS stack is full -- the task mechanism is then the
 // overflow path of deep traversals and costs nothing otherwise.  Budgets were measured and do not pay with level-wise

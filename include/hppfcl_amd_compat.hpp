@@ -766,6 +766,16 @@ class CollisionObject {
   AABB aabb;
 };
 
+// collide() / distance() on CollisionObjects (src/collision.cpp:60-67, src/distance.cpp:51-58)
+inline std::size_t collide(const CollisionObject* o1, const CollisionObject* o2, const CollisionRequest& request,
+                           CollisionResult& result) {
+  return collide(o1->collisionGeometryPtr(), o1->getTransform(), o2->collisionGeometryPtr(), o2->getTransform(), request, result);
+}
+inline FCL_REAL distance(const CollisionObject* o1, const CollisionObject* o2, const DistanceRequest& request,
+                         DistanceResult& result) {
+  return distance(o1->collisionGeometryPtr(), o1->getTransform(), o2->collisionGeometryPtr(), o2->getTransform(), request, result);
+}
+
 struct CollisionCallBackBase {  // broadphase/broadphase_callbacks.h:52-75
   virtual ~CollisionCallBackBase() {}
   virtual void init() {}
@@ -792,6 +802,66 @@ struct CollisionCallBackCollect : CollisionCallBackBase {  // default_broadphase
  protected:
   std::vector<CollisionPair> collision_pairs;
   size_t max_size;
+};
+
+struct DistanceCallBackBase {  // broadphase/broadphase_callbacks.h:77-103
+  virtual ~DistanceCallBackBase() {}
+  virtual void init() {}
+  virtual bool distance(CollisionObject* o1, CollisionObject* o2, FCL_REAL& dist) = 0;
+  bool operator()(CollisionObject* o1, CollisionObject* o2, FCL_REAL& dist) { return distance(o1, o2, dist); }
+};
+
+/// CollisionData / DistanceData and the default callbacks (broadphase/default_broadphase_callbacks.h:55-98,118,192;
+/// src/broadphase/default_broadphase_callbacks.cpp:43-91): every culled pair is evaluated with collide() / distance()
+/// (one query each, as in the reference; to evaluate all culled pairs in ONE device batch collect them with
+/// CollisionCallBackCollect and call amd::collide).
+struct CollisionData {
+  CollisionData() : done(false) {}
+  CollisionRequest request;
+  CollisionResult result;
+  bool done;  // the broadphase evaluation stops when set
+  void clear() {
+    result.clear();
+    done = false;
+  }
+};
+struct DistanceData {
+  DistanceData() : done(false) {}
+  DistanceRequest request;
+  DistanceResult result;
+  bool done;
+  void clear() {
+    result.clear();
+    done = false;
+  }
+};
+inline bool defaultCollisionFunction(CollisionObject* o1, CollisionObject* o2, void* data) {
+  CollisionData* cd = static_cast<CollisionData*>(data);
+  if (cd->done) return true;
+  collide(o1, o2, cd->request, cd->result);
+  if (cd->result.isCollision() && cd->result.numContacts() >= cd->request.num_max_contacts) cd->done = true;
+  return cd->done;
+}
+inline bool defaultDistanceFunction(CollisionObject* o1, CollisionObject* o2, void* data, FCL_REAL& dist) {
+  DistanceData* cd = static_cast<DistanceData*>(data);
+  if (cd->done) {
+    dist = cd->result.min_distance;
+    return true;
+  }
+  distance(o1, o2, cd->request, cd->result);
+  dist = cd->result.min_distance;
+  if (dist <= 0) return true;  // in collision or in touch
+  return cd->done;
+}
+struct CollisionCallBackDefault : CollisionCallBackBase {
+  void init() override { data.clear(); }
+  bool collide(CollisionObject* o1, CollisionObject* o2) override { return defaultCollisionFunction(o1, o2, &data); }
+  CollisionData data;
+};
+struct DistanceCallBackDefault : DistanceCallBackBase {
+  void init() override { data.clear(); }
+  bool distance(CollisionObject* o1, CollisionObject* o2, FCL_REAL& dist) override { return defaultDistanceFunction(o1, o2, &data, dist); }
+  DistanceData data;
 };
 
 /// Same calls as the reference manager (registerObject(s) / setup / update / collide(callback));
@@ -823,6 +893,24 @@ class DynamicAABBTreeCollisionManager {
       if ((*callback)(objs_[p[2 * k]], objs_[p[2 * k + 1]])) break;
     hfcl_pairlist_free(pl);
   }
+  /// self distance (broadphase_dynamic_AABB_tree.cpp:745-751): the callback sees the pairs whose AABBs are closer than the
+  /// smallest distance reported so far (the pruning rule of distanceRecurse, :350-420), nearest boxes first, until it
+  /// returns true.  The reference visits them in tree order; the minimum a callback accumulates is the same.
+  void distance(DistanceCallBackBase* callback) {
+    callback->init();
+    refresh();
+    const size_t n = objs_.size();
+    std::vector<std::pair<FCL_REAL, std::pair<uint32_t, uint32_t>>> cand;
+    cand.reserve(n * (n - 1) / 2);
+    for (size_t i = 0; i < n; ++i)
+      for (size_t j = i + 1; j < n; ++j) cand.push_back({aabb_distance(i, j), {uint32_t(i), uint32_t(j)}});
+    std::sort(cand.begin(), cand.end());
+    FCL_REAL min_dist = std::numeric_limits<FCL_REAL>::max();
+    for (const auto& c : cand) {
+      if (c.first >= min_dist) break;  // no closer pair can be left
+      if ((*callback)(objs_[c.second.first], objs_[c.second.second], min_dist)) break;
+    }
+  }
   /// against another manager (broadphase_dynamic_AABB_tree.cpp:734-743)
   void collide(DynamicAABBTreeCollisionManager* other, CollisionCallBackBase* callback) {
     callback->init();
@@ -837,6 +925,15 @@ class DynamicAABBTreeCollisionManager {
   }
 
  private:
+  FCL_REAL aabb_distance(size_t i, size_t j) const {  // AABB::distance (BV/AABB.cpp:53-110): 0 when the boxes overlap
+    FCL_REAL s = 0;
+    for (int k = 0; k < 3; ++k) {
+      const FCL_REAL lo = aabbs_[6 * i + k] - aabbs_[6 * j + 3 + k], hi = aabbs_[6 * j + k] - aabbs_[6 * i + 3 + k];
+      const FCL_REAL d = std::max(FCL_REAL(0), std::max(lo, hi));
+      s += d * d;
+    }
+    return std::sqrt(s);
+  }
   void refresh() {  // CollisionObject::computeAABB for every object (collision_object.h:259-276)
     if (!dirty_ && aabbs_.size() == 6 * objs_.size()) return;
     std::vector<hfcl_shape> shapes(objs_.size());

@@ -232,6 +232,28 @@ int main() {
     for (size_t i = 0; i < objects.size(); ++i)
       for (size_t j = i + 1; j < objects.size(); ++j) brute += objects[i]->getAABB().overlap(objects[j]->getAABB());
     CHECK(brute > 50 && collect.numCollisionPairs() == brute);
+    {  // the default callbacks (test/broadphase.cpp style): stop at the first collision / global minimum distance
+      std::vector<std::unique_ptr<CollisionObject>> few;
+      DynamicAABBTreeCollisionManager m2;
+      for (int i = 0; i < 12; ++i) {
+        few.emplace_back(new CollisionObject(std::make_shared<Sphere>(0.4), Transform3f(Vec3f(1.5 * i, 0.1 * i, 0))));
+        m2.registerObject(few.back().get());
+      }
+      m2.setup();
+      CollisionCallBackDefault cb;
+      m2.collide(&cb);
+      CHECK(!cb.data.result.isCollision());  // centres 1.5+ apart, radii 0.4
+      DistanceCallBackDefault db;
+      m2.distance(&db);
+      const double expect = std::sqrt(1.5 * 1.5 + 0.1 * 0.1) - 0.8;
+      CHECK(std::fabs(db.data.result.min_distance - expect) < 1e-9);
+      few[3]->setTransform(Transform3f(Vec3f(1.5 * 2 + 0.5, 0.2, 0)));  // now sphere 3 cuts sphere 2
+      m2.update();
+      m2.collide(&cb);
+      CHECK(cb.data.result.isCollision() && cb.data.done);
+      m2.distance(&db);
+      CHECK(db.data.result.min_distance < 0);
+    }
     CollisionRequest rq; std::vector<CollisionResult> res;
     amd::collide(collect.getCollisionPairs(), rq, res);
     CHECK(res.size() == brute);

@@ -397,11 +397,15 @@ def _check_bvh_records(abi, got, ref, name):
     assert np.abs(sep_g[m] - sep_r[m]).max() < 1e-5
 
 
+@pytest.mark.parametrize("steal", [False, True])
 @pytest.mark.parametrize("seg,n", [(12, 20000), (50, 4000)])
-def test_bvh_collide_first_contact(pkg, oracle, seg, n):
+def test_bvh_collide_first_contact(pkg, oracle, seg, n, steal, monkeypatch):
     """Default request (num_max_contacts = 1): collision flag and the first contact's (b1, b2) in the
-    reference's DFS order are exact; depth / witness data to 1e-6."""
+    reference's DFS order are exact; depth / witness data to 1e-6.  steal: the same through k_bvh_collide_ws (segments
+    of a traversal walked by several lanes, folded back in DFS order)."""
     abi, wl = pkg.abi, pkg.workloads
+    if steal:
+        monkeypatch.setenv("HFCL_BVH_STEAL", "1")
     b = wl.cfg4_mesh_mesh(n=n, seg=seg, ring=seg, n_variants=4)
     req = wl.make_request(b, abi)
     got, ref, kt = _run_bvh(pkg, oracle, b, req)
