@@ -82,6 +82,7 @@ def parse():
                     "mixed libraries); 1: one stream; 2: always split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--host-buffers", action="store_true", help="with --workload cfg2/cfg5/...: also time the batch through the host-buffer boundary")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     return ap.parse_args()
 
@@ -435,7 +436,7 @@ def main():
     headline_wl = args.workload or "cfg3"
     strong = args.scaling == "strong"
     head = run_workload(ctx, headline_wl, args.pairs, args.steps, args.warmup, strong=strong,
-                        cpu_budget_s=10.0, cpu_sample=args.cpu_sample, host_buffers=(headline_wl == "cfg2"))
+                        cpu_budget_s=10.0, cpu_sample=args.cpu_sample, host_buffers=args.host_buffers)
     secondary = []
     if args.workload is None and not args.no_secondary:
         sec_steps = max(3, min(args.steps, 10))
