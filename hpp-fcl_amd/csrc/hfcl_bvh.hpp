@@ -115,38 +115,39 @@ struct TriSupport {
 };
 
 // ShapeShapeDistance<TriangleP,TriangleP>: returns the distance, fills world-frame p1,p2,normal.
-template <typename T>
+// PS: where the simplex keeps its witness payload (hfcl_pair.hpp: W0Regs; the traversal kernels park it in LDS).
+template <typename T, class PS>
 HFCL_HD T tri_tri_distance(const TriSupport<T>& tri, const GjkParams<T>& prm_in, bool cached_guess, const V3<T>& guess_c,
-                           V3<T>& p1, V3<T>& p2, V3<T>& normal, int& status, int& iters, V3<T>* ray_out = nullptr) {
+                           V3<T>& p1, V3<T>& p2, V3<T>& normal, int& status, int& iters, V3<T>* ray_out, const PS& ps) {
   GjkParams<T> prm = prm_in;  // fresh GJKSolver(request): DefaultGJK, Default/Relative criterion, no early stop
   prm.variant = VAR_DEFAULT;
   prm.crit = CRIT_DEFAULT;
   prm.crit_type = CRIT_RELATIVE;
   prm.distance_upper_bound = Lim<T>::max();
   const V3<T> guess = cached_guess ? guess_c : ((tri.p1 + tri.p2 + tri.p3 - tri.q1 - tri.q2 - tri.q3) / T(3));
-  Gjk<T, PW0<T>> g;
+  Gjk<T, typename PS::P> g;
   TriSupport<T> sup = tri;
-  gjk_run(g, prm, guess, T(0), false, sup);
+  gjk_run(g, prm, guess, T(0), false, sup, ps);
   status = g.status;
   iters = g.iterations;
   if (ray_out) *ray_out = g.ray;  // solver->cached_guess = gjk.getGuessFromSimplex() (:80)
   // gjk.getWitnessPointsAndNormal for any rank (1..4); reference order: ref[i] = s[rank-1-i]
-  typedef SimplexV<T, PW0<T>> SV;
+  typedef SimplexV<T, typename PS::P> SV;
   const int r = g.rank;
   const SV ref0 = svsel(r == 1, g.s0, svsel(r == 2, g.s1, svsel(r == 3, g.s2, g.s3)));
   const SV ref1 = svsel(r == 2, g.s0, svsel(r == 3, g.s1, g.s2));
   const SV ref2 = svsel(r == 3, g.s0, g.s1);
   const SV ref3 = g.s0;
+  const V3<T> a0 = ps.get(ref0.p), b0 = r > 1 ? ps.get(ref1.p) : a0, c0 = r > 2 ? ps.get(ref2.p) : a0;
   if (r == 4) {
+    const V3<T> d0 = ps.get(ref3.p);
     T prm4[4];
     project_tetra_origin(ref0.w, ref1.w, ref2.w, ref3.w, prm4);
     const V3<T> z = mk<T>(T(0), T(0), T(0));
-    p1 = (((z + prm4[0] * ref0.p.w0) + prm4[1] * ref1.p.w0) + prm4[2] * ref2.p.w0) + prm4[3] * ref3.p.w0;
-    p2 = (((z + prm4[0] * (ref0.p.w0 - ref0.w)) + prm4[1] * (ref1.p.w0 - ref1.w)) + prm4[2] * (ref2.p.w0 - ref2.w)) +
-         prm4[3] * (ref3.p.w0 - ref3.w);
+    p1 = (((z + prm4[0] * a0) + prm4[1] * b0) + prm4[2] * c0) + prm4[3] * d0;
+    p2 = (((z + prm4[0] * (a0 - ref0.w)) + prm4[1] * (b0 - ref1.w)) + prm4[2] * (c0 - ref2.w)) + prm4[3] * (d0 - ref3.w);
   } else {
-    closest_points(r, ref0.w, ref1.w, ref2.w, ref0.p.w0, ref1.p.w0, ref2.p.w0, ref0.p.w0 - ref0.w, ref1.p.w0 - ref1.w,
-                   ref2.p.w0 - ref2.w, p1, p2);
+    closest_points(r, ref0.w, ref1.w, ref2.w, a0, b0, c0, a0 - ref0.w, b0 - ref1.w, c0 - ref2.w, p1, p2);
   }
   gjk_witness_normal(g.ray, T(0), T(0), p1, p2, normal);
   T distance = g.distance;
@@ -157,6 +158,12 @@ HFCL_HD T tri_tri_distance(const TriSupport<T>& tri, const GjkParams<T>& prm_in,
     distance = -hmax(d1, hmax(d2, d3));
   }
   return distance;
+}
+
+template <typename T>
+HFCL_HD T tri_tri_distance(const TriSupport<T>& tri, const GjkParams<T>& prm_in, bool cached_guess, const V3<T>& guess_c,
+                           V3<T>& p1, V3<T>& p2, V3<T>& normal, int& status, int& iters, V3<T>* ray_out = nullptr) {
+  return tri_tri_distance(tri, prm_in, cached_guess, guess_c, p1, p2, normal, status, iters, ray_out, W0Regs<T>());
 }
 
 // ---------------------------------------------------------------------------------------

@@ -189,6 +189,42 @@ __device__ __forceinline__ void store_bvh_record(const IO<float>& io, uint32_t p
   io.out[pair] = r;
 }
 
+// The witness part of a BVH pair record (p1, p2, normal) and the rest of it, written separately: the mesh x mesh
+// traversal updates the witness in place whenever a leaf lowers its bound (a handful of times per query) instead of
+// carrying 9 values in registers for the whole walk (k_bvh_collide runs on its register budget: two waves per SIMD).
+__device__ __forceinline__ void store_witness(const IO<double>& io, uint32_t pair, const V3<double>& p1, const V3<double>& p2, const V3<double>& n) {
+  hfcl_result* r = &io.out[pair];
+  r->normal[0] = n.x; r->normal[1] = n.y; r->normal[2] = n.z;
+  r->p1[0] = p1.x; r->p1[1] = p1.y; r->p1[2] = p1.z;
+  r->p2[0] = p2.x; r->p2[1] = p2.y; r->p2[2] = p2.z;
+}
+__device__ __forceinline__ void store_witness(const IO<float>& io, uint32_t pair, const V3<float>& p1, const V3<float>& p2, const V3<float>& n) {
+  hfcl_result_f32* r = &io.out[pair];
+  r->p1[0] = p1.x; r->p1[1] = p1.y; r->p1[2] = p1.z;
+  r->p2[0] = p2.x; r->p2[1] = p2.y; r->p2[2] = p2.z;
+  r->normal[0] = n.x; r->normal[1] = n.y; r->normal[2] = n.z;
+}
+template <typename T>
+__device__ __forceinline__ void load_witness(const IO<T>& io, uint32_t pair, V3<T>& p1, V3<T>& p2, V3<T>& n) {
+  const auto* r = &io.out[pair];
+  n = mk<T>(T(r->normal[0]), T(r->normal[1]), T(r->normal[2]));
+  p1 = mk<T>(T(r->p1[0]), T(r->p1[1]), T(r->p1[2]));
+  p2 = mk<T>(T(r->p2[0]), T(r->p2[1]), T(r->p2[2]));
+}
+__device__ __forceinline__ void store_bvh_record_head(const IO<double>& io, uint32_t pair, double distance, uint32_t nc, int b1, int b2, bool overflow) {
+  hfcl_result* r = &io.out[pair];
+  r->distance = distance;
+  r->b1 = b1;
+  r->b2 = b2;
+  r->status = (nc ? 128u : 0u) | (overflow ? 0xC0000000u : 0u);
+  r->num_contacts = int(nc & 0x7FFFFFFFu);
+}
+__device__ __forceinline__ void store_bvh_record_head(const IO<float>& io, uint32_t pair, float distance, uint32_t nc, int, int, bool overflow) {
+  hfcl_result_f32* r = &io.out[pair];
+  r->distance = distance;
+  r->status = (nc ? 128u : 0u) | (overflow ? 0xC0000000u : 0u);
+}
+
 template <typename T>
 __device__ __forceinline__ void write_guess(const IO<T>&, uint32_t, const V3<T>&, int, int) {}
 template <>
@@ -472,10 +508,13 @@ struct BvhSpill {
   uint32_t wide;        // 32-bit node ids in the stack entries
 };
 #ifndef HFCL_BVH_LEVELS
-#define HFCL_BVH_LEVELS 4
+#define HFCL_BVH_LEVELS 6
 #endif
 
-constexpr int BVH_STACK = 96;
+// LDS stack entries per lane of k_bvh_collide.  48 (it was 96): with the witness slab of the leaf GJK the block is 36 KB =
+// 29 allocation units, so that the four blocks of two waves per SIMD fit a CU; a 5000-triangle model needs ~30
+// (depth1 + depth2 + 2), deeper traversals suspend into tasks (HFCL_BVH_LEVELS levels) or take the wide form.
+constexpr int BVH_STACK = 48;
 constexpr int BVH_BLOCK = 128;
 #ifndef HFCL_BVH_REFILL_MIN
 #define HFCL_BVH_REFILL_MIN 8

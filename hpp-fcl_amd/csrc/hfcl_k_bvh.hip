@@ -47,13 +47,18 @@ template <> struct BvhEntry<true> {
   static __device__ __forceinline__ uint32_t second(E e) { return uint32_t(e >> 32); }
 };
 
+#ifndef HFCL_WPE_BVH_COLLIDE
+#define HFCL_WPE_BVH_COLLIDE 2  // two waves per SIMD: the walk waits for its node gathers most of the time (profiles/r02_m)
+#endif
 template <typename T, bool WIDE>
-__global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH, 8))) k_bvh_collide(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
+__global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH_COLLIDE, 8))) k_bvh_collide(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
                                                           BvhParams bp, T break_distance2, BvhSplit split, BvhSpill spill) {
   typedef BvhEntry<WIDE> EN;
   typedef typename EN::E E;
   constexpr int STACK = EN::STACK, HALF = EN::STACK / 2;
   __shared__ E stack[STACK][BVH_BLOCK];
+  __shared__ T w0_slab[W0Lds<T, BVH_BLOCK>::WORDS];  // witness payload of the leaf tests' GJK simplex (hfcl_dev.hpp: W0Lds)
+  const W0Lds<T, BVH_BLOCK> leaf_ps{w0_slab + threadIdx.x};
   // this lane's slab of spilled entries (WIDE only)
   E* const slab = WIDE && spill.slab ? reinterpret_cast<E*>(spill.slab) + size_t(blockIdx.x * BVH_BLOCK + threadIdx.x) * spill.cap : nullptr;
   uint32_t nspill = 0;
@@ -70,42 +75,42 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   constexpr int refill_min = BVH_REFILL_MIN;
   bool live = false, pending = false, exhausted = false;  // exhausted is wave-uniform
   uint32_t pair = 0, unit = 0, steps = 0;
+  // What a lane keeps in registers across a walk is what the BV tests need: the relative pose and the running bounds.
+  // The poses themselves (leaf tests only: ~5 per query) are re-read there, the witness of the bound (p1, p2, normal:
+  // updated a handful of times) lives where it will be read -- the query's record, or the task's summary.
   DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
-  Pose<T> tf1, tf2;
   M3<T> RT_R;
   V3<T> RT_T;
   int sp = 0;
   bool overflow = false;
   uint32_t ncontacts = 0;
   T dlb = Lim<T>::max(), rec_dist = Lim<T>::max(), cand_val = Lim<T>::max();
-  V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1, nn = np1;
   int fb1 = -1, fb2 = -1;
   bool have_leaf = false;
   uint32_t lb1 = 0, lb2 = 0;
   uint32_t my_parent = 0xFFFFFFFFu, my_order = 0;  // (tasks) where this unit hangs
-  auto write_sum = [&](uint32_t slot, uint32_t first_child, uint32_t n_child, uint32_t flags) {
-    BvhSum<T> s;
-    s.contact_order = 0xFFFFFFFFu; s.parent = my_parent; s.order = my_order; s.pad_ = 0;
-    s.dlb = dlb; s.rec_dist = rec_dist; s.cand_val = cand_val;
-    s.np1 = np1; s.np2 = np2; s.nn = nn;
-    s.fb1 = fb1; s.fb2 = fb2;
-    s.ncontacts = ncontacts; s.first_child = first_child; s.n_child = n_child; s.flags = flags;
-    *bvh_sum<T>(split, slot) = s;
-  };
-  auto flush = [&]() {  // the unit this lane finished: a query's record, or a task's summary
+  auto witness_store = [&](const V3<T>& p1, const V3<T>& p2, const V3<T>& n) {  // the witness of the bound, in place
     if (level) {
-      write_sum(split.n_queries + unit, 0u, 0u, overflow ? BVH_SUM_OVERFLOW : 0u);
-      return;
+      BvhSum<T>* sm = bvh_sum<T>(split, split.n_queries + unit);
+      sm->np1 = p1;
+      sm->np2 = p2;
+      sm->nn = n;
+    } else {
+      store_witness(io, pair, p1, p2, n);
     }
-    PairOut<T> o;
-    o.distance = rec_dist;
-    o.normal = nn;
-    o.p1 = np1;
-    o.p2 = np2;
-    o.gjk_status = GJK_DID_NOT_RUN;
-    o.epa_status = EPA_DID_NOT_RUN;
-    o.gjk_iters = o.epa_iters = 0;
-    store_bvh_record(io, pair, o, ncontacts, fb1, fb2, overflow);
+  };
+  auto write_sum_head = [&](uint32_t slot, uint32_t first_child, uint32_t n_child, uint32_t flags) {  // all but np1 / np2 / nn
+    BvhSum<T>* sm = bvh_sum<T>(split, slot);
+    sm->contact_order = 0xFFFFFFFFu; sm->parent = my_parent; sm->order = my_order; sm->pad_ = 0;
+    sm->dlb = dlb; sm->rec_dist = rec_dist; sm->cand_val = cand_val;
+    sm->fb1 = fb1; sm->fb2 = fb2;
+    sm->ncontacts = ncontacts; sm->first_child = first_child; sm->n_child = n_child; sm->flags = flags;
+  };
+  auto flush = [&]() {  // the unit this lane finished: a query's record, or a task's summary (the witness is in place)
+    if (level)
+      write_sum_head(split.n_queries + unit, 0u, 0u, overflow ? BVH_SUM_OVERFLOW : 0u);
+    else
+      store_bvh_record_head(io, pair, rec_dist, ncontacts, fb1, fb2, overflow);
   };
   // Is the work of the task (parent slot p, position o) still needed?  Not if an earlier sibling -- of it or of any of its
   // ancestors -- has found a contact: the sequential walk would have ended there.
@@ -144,7 +149,11 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
       my_slot = atomicAdd(&split.ctr[BVH_CTR_SUSPENDED], 1u);  // < n_queries: one per query at most
       split.suspended[my_slot] = pair;
     }
-    write_sum(my_slot, first, n_child, BVH_SUM_SUSPENDED);  // (before the tasks: they point at it)
+    write_sum_head(my_slot, first, n_child, BVH_SUM_SUSPENDED);  // (before the tasks: they point at it)
+    if (!level) {  // a query's witness so far sits in its record: the summary needs a copy
+      BvhSum<T>* sm = bvh_sum<T>(split, my_slot);
+      load_witness(io, pair, sm->np1, sm->np2, sm->nn);
+    }
     __threadfence();
     uint32_t j = first, o = 0;
     if (n_extra > 0) split.tasks[j++] = BvhTask{pair, my_slot, ea, o++};
@@ -197,7 +206,7 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
               dlb = rec_dist = cand_val = Lim<T>::max();
               ncontacts = 0;
               overflow = false;
-              write_sum(split.n_queries + unit, 0u, 0u, 0u);
+              write_sum_head(split.n_queries + unit, 0u, 0u, 0u);
             }
           } else {
             pair = wk.lists[size_t(B_BVH) * wk.n + it];
@@ -206,10 +215,11 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
             const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
             m1 = bv.meshes[a.bvh_index];
             m2 = bv.meshes[b.bvh_index];
-            tf1 = load_pose(io.tf1, pair);
-            tf2 = load_pose(io.tf2, pair);
-            RT_R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
-            RT_T = tmul(tf1.R, tf2.t - tf1.t);
+            {
+              const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+              RT_R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
+              RT_T = tmul(tf1.R, tf2.t - tf1.t);
+            }
             stack[0][tid] = entry;
             sp = 1;
             nspill = 0;
@@ -217,7 +227,7 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
             overflow = false;
             ncontacts = 0;
             dlb = rec_dist = cand_val = Lim<T>::max();
-            np1 = np2 = nn = mk<T>(nanv, nanv, nanv);
+            witness_store(mk<T>(nanv, nanv, nanv), mk<T>(nanv, nanv, nanv), mk<T>(nanv, nanv, nanv));
             fb1 = fb2 = -1;
             have_leaf = false;
             live = true;
@@ -308,24 +318,28 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
       const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
       auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
       TriSupport<T> tri;
-      tri.p1 = xform(tf1, vtx(v1, t1[0]));
-      tri.p2 = xform(tf1, vtx(v1, t1[1]));
-      tri.p3 = xform(tf1, vtx(v1, t1[2]));
-      tri.q1 = xform(tf2, vtx(v2, t2[0]));
-      tri.q2 = xform(tf2, vtx(v2, t2[1]));
-      tri.q3 = xform(tf2, vtx(v2, t2[2]));
+      {
+        const Pose<T> tf1 = load_pose(io.tf1, pair);
+        tri.p1 = xform(tf1, vtx(v1, t1[0]));
+        tri.p2 = xform(tf1, vtx(v1, t1[1]));
+        tri.p3 = xform(tf1, vtx(v1, t1[2]));
+      }
+      {
+        const Pose<T> tf2 = load_pose(io.tf2, pair);
+        tri.q1 = xform(tf2, vtx(v2, t2[0]));
+        tri.q2 = xform(tf2, vtx(v2, t2[1]));
+        tri.q3 = xform(tf2, vtx(v2, t2[2]));
+      }
       V3<T> p1, p2, n;
       int gst, git;
       const T distance = tri_tri_distance(tri, q.gjk, q.guess_mode == HFCL_GUESS_CACHED,
-                                          mk<T>(q.guess[0], q.guess[1], q.guess[2]), p1, p2, n, gst, git);
+                                          mk<T>(q.guess[0], q.guess[1], q.guess[2]), p1, p2, n, gst, git, (V3<T>*)nullptr, leaf_ps);
       const T dtc = distance - q.security_margin;
       if (dtc < dlb) {  // updateDistanceLowerBoundFromLeaf
         dlb = dtc;
         cand_val = dtc;
         rec_dist = distance;
-        np1 = p1;
-        np2 = p2;
-        nn = n;
+        witness_store(p1, p2, n);
       }
       if (dtc <= q.collision_distance_threshold) {
         if (ncontacts < bp.num_max_contacts) {
