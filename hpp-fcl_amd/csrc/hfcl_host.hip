@@ -67,6 +67,7 @@ struct hfcl_lib {
   uint8_t* d_kinds = nullptr;
   // workspace (grown on demand)
   size_t ws_capacity = 0;  // pairs
+  size_t epa_capacity = 0;  // pairs the EPA queues / hand-over area are sized for (0: not allocated yet)
   uint32_t* d_lists = nullptr;
   uint32_t* d_counts = nullptr;
   void* d_epa_queue = nullptr;
@@ -227,12 +228,10 @@ void hfcl_distance_request_init(hfcl_distance_request* r) {
   r->abs_err = 0.0;
 }
 
-hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const double* vertices, size_t n_vertices,
-                          int device) {
-  if (ensure_device(device) != HFCL_OK) return nullptr;
+static bool validate_shapes(const char* who, const hfcl_shape* shapes, size_t n_shapes, const double* vertices, size_t n_vertices) {
   if (!shapes || n_shapes == 0) {
-    set_error("hfcl_lib_create: empty shape table");
-    return nullptr;
+    set_error(std::string(who) + ": empty shape table");
+    return false;
   }
   for (size_t i = 0; i < n_shapes; ++i) {
     const hfcl_shape& s = shapes[i];
@@ -241,31 +240,35 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
                          s.type == HFCL_GEOM_TRIANGLE || s.type == HFCL_GEOM_CONE || s.type == HFCL_GEOM_CYLINDER ||
                          s.type == HFCL_GEOM_PLANE || s.type == HFCL_GEOM_HALFSPACE;
     if (!ok_kind) {
-      set_error("hfcl_lib_create: unsupported shape type " + std::to_string(s.type));
-      return nullptr;
+      set_error(std::string(who) + ": unsupported shape type " + std::to_string(s.type));
+      return false;
     }
     if (s.type == HFCL_GEOM_CONVEX) {
       if (s.num_points == 0 || s.num_points > (uint32_t)HULL_LARGE_MAX) {
-        set_error("hfcl_lib_create: convex shapes must have 1.." + std::to_string(HULL_LARGE_MAX) + " vertices; got " +
+        set_error(std::string(who) + ": convex shapes must have 1.." + std::to_string(HULL_LARGE_MAX) + " vertices; got " +
                   std::to_string(s.num_points));
-        return nullptr;
+        return false;
       }
       if (size_t(s.vertex_offset) + s.num_points > n_vertices) {
-        set_error("hfcl_lib_create: convex vertex range out of bounds");
-        return nullptr;
+        set_error(std::string(who) + ": convex vertex range out of bounds");
+        return false;
       }
     }
     if (s.type == HFCL_GEOM_TRIANGLE && size_t(s.vertex_offset) + 3 > n_vertices) {  // its corners are 3 vertices of the array
-      set_error("hfcl_lib_create: TriangleP vertex range out of bounds");
-      return nullptr;
+      set_error(std::string(who) + ": TriangleP vertex range out of bounds");
+      return false;
     }
     if ((s.type == HFCL_GEOM_CONVEX || s.type == HFCL_GEOM_TRIANGLE) && !vertices) {
-      set_error("hfcl_lib_create: shapes with vertices but no vertex array");
-      return nullptr;
+      set_error(std::string(who) + ": shapes with vertices but no vertex array");
+      return false;
     }
   }
-  hfcl_lib* lib = new hfcl_lib();
-  lib->device = device;
+  return true;
+}
+
+// (Re)build the device shape tables of `lib` from a shape / vertex table: both precisions, the kind bytes of k_classify
+// and the set of buckets a pair of these kinds can fall into.
+static bool upload_shapes(hfcl_lib* lib, const hfcl_shape* shapes, size_t n_shapes, const double* vertices, size_t n_vertices) {
   lib->n_shapes = n_shapes;
   lib->h_shapes.assign(shapes, shapes + n_shapes);
   std::vector<DShape<double>> s64(n_shapes);
@@ -318,15 +321,14 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   }
   std::vector<float> v32(3 * n_vertices + 3);
   for (size_t i = 0; i < 3 * n_vertices; ++i) v32[i] = float(vertices[i]);
+  hipFree(lib->d_shapes64); hipFree(lib->d_shapes32); hipFree(lib->d_kinds); hipFree(lib->d_verts64); hipFree(lib->d_verts32);
+  lib->d_shapes64 = nullptr; lib->d_shapes32 = nullptr; lib->d_kinds = nullptr; lib->d_verts64 = nullptr; lib->d_verts32 = nullptr;
   bool ok = true;
   ok = ok && hipMalloc(&lib->d_shapes64, n_shapes * sizeof(DShape<double>)) == hipSuccess;
   ok = ok && hipMalloc(&lib->d_shapes32, n_shapes * sizeof(DShape<float>)) == hipSuccess;
   ok = ok && hipMalloc(&lib->d_kinds, n_shapes) == hipSuccess;
   ok = ok && hipMalloc(&lib->d_verts64, (3 * n_vertices + 3) * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc(&lib->d_verts32, (3 * n_vertices + 3) * sizeof(float)) == hipSuccess;
-  ok = ok && hipMalloc(&lib->d_counts, N_COUNTERS * sizeof(uint32_t)) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&lib->h_counts, N_COUNTERS * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
-  if (ok) memset(lib->h_counts, 0, N_COUNTERS * sizeof(uint32_t));
   if (ok) {
     ok = ok && hipMemcpy(lib->d_shapes64, s64.data(), n_shapes * sizeof(DShape<double>), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(lib->d_shapes32, s32.data(), n_shapes * sizeof(DShape<float>), hipMemcpyHostToDevice) == hipSuccess;
@@ -336,6 +338,19 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
       ok = ok && hipMemcpy(lib->d_verts32, v32.data(), 3 * n_vertices * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
     }
   }
+  return ok;
+}
+
+hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const double* vertices, size_t n_vertices,
+                          int device) {
+  if (ensure_device(device) != HFCL_OK) return nullptr;
+  if (!validate_shapes("hfcl_lib_create", shapes, n_shapes, vertices, n_vertices)) return nullptr;
+  hfcl_lib* lib = new hfcl_lib();
+  lib->device = device;
+  bool ok = upload_shapes(lib, shapes, n_shapes, vertices, n_vertices);
+  ok = ok && hipMalloc(&lib->d_counts, N_COUNTERS * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&lib->h_counts, N_COUNTERS * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+  if (ok) memset(lib->h_counts, 0, N_COUNTERS * sizeof(uint32_t));
   if (!ok) {
     set_error("hfcl_lib_create: HIP allocation/copy failed");
     hfcl_lib_destroy(lib);
@@ -423,6 +438,31 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   }
   delete lib;
 }
+// Replace the shape table of a library in place: registered BVH models, workspaces, staging buffers and streams stay
+// (a caller that keeps adding geometries -- the hpp::fcl shim -- does not pay a full rebuild with every new shape).
+int hfcl_lib_set_shapes(hfcl_lib* lib, const hfcl_shape* shapes, size_t n_shapes, const double* vertices, size_t n_vertices) {
+  if (!lib) {
+    set_error("null library");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  if (!validate_shapes("hfcl_lib_set_shapes", shapes, n_shapes, vertices, n_vertices)) return HFCL_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(lib->device));
+  HIP_TRY(hipDeviceSynchronize());  // nothing of this library may still be reading the old tables
+  if (!upload_shapes(lib, shapes, n_shapes, vertices, n_vertices)) {
+    set_error("hfcl_lib_set_shapes: HIP allocation/copy failed");
+    return HFCL_ERR_HIP;
+  }
+  if (hfcl_lib* h = lib->helper) {  // the second half of split batches reads the same tables
+    h->n_shapes = lib->n_shapes;
+    h->d_shapes64 = lib->d_shapes64;
+    h->d_shapes32 = lib->d_shapes32;
+    h->d_verts64 = lib->d_verts64;
+    h->d_verts32 = lib->d_verts32;
+    h->d_kinds = lib->d_kinds;
+    h->possible_buckets = lib->possible_buckets;
+  }
+  return HFCL_OK;
+}
 size_t hfcl_lib_num_shapes(const hfcl_lib* lib) { return lib ? lib->n_shapes : 0; }
 int hfcl_lib_device(const hfcl_lib* lib) { return lib ? lib->device : -1; }
 
@@ -484,29 +524,39 @@ int hfcl_lib_add_bvh(hfcl_lib* lib, const hfcl_bvh_node* nodes, size_t n_nodes, 
 
 }  // extern "C"
 
-static int ensure_workspace(hfcl_lib* lib, size_t n) {
-  if (n <= lib->ws_capacity) return HFCL_OK;
-  size_t cap = n + n / 8 + 1024;
-  hipFree(lib->d_lists);
-  hipFree(lib->d_epa_queue);
-  hipFree(lib->d_epa_queue2);
-  hipFree(lib->d_epa_resume);
-  lib->d_lists = nullptr;
-  lib->d_epa_queue = nullptr;
-  lib->d_epa_queue2 = nullptr;
-  lib->d_epa_resume = nullptr;
-  lib->resume_cap = 0;
-  lib->ws_capacity = 0;
-  HIP_TRY(hipMalloc(&lib->d_lists, size_t(B_COUNT) * cap * sizeof(uint32_t)));
-  HIP_TRY(hipMalloc(&lib->d_epa_queue, cap * sizeof(EpaItem<double>)));
-  HIP_TRY(hipMalloc(&lib->d_epa_queue2, cap * sizeof(EpaItem<double>)));
-  // saved polytopes for the tier hand-over: room for a third of the batch (beyond that the full tier
-  // simply redoes the pair from its seed); 4 KB per slot in fp64
-  size_t rcap = std::min(cap, std::max<size_t>(65536, cap / 3));
-  if (const char* e = getenv("HFCL_EPA_RESUME_SLOTS")) rcap = std::max<size_t>(1, std::min<size_t>(cap, strtoull(e, nullptr, 10)));  // test knob
-  HIP_TRY(hipMalloc(&lib->d_epa_resume, rcap * std::max(epa_resume_stride<double>, epa_resume_stride<float>)));
-  lib->resume_cap = rcap;
-  lib->ws_capacity = cap;
+// Device workspace of a batch of n pairs.  The bucket lists (4 B per pair and bucket the library's shape kinds can reach)
+// are always needed; the EPA queues (two seeds of ~230 B per pair) and the hand-over area (one slot of ~4 KB per 8 pairs)
+// only when the batch has a GJK bucket and asks for penetration data -- a closed-form or mesh-only library never pays
+// for them.  ~0.05 KB per pair without EPA, ~1 KB with (it was 1.8 KB for every library).
+static int ensure_workspace(hfcl_lib* lib, size_t n, bool need_epa) {
+  if (n > lib->ws_capacity) {
+    hipFree(lib->d_lists);
+    lib->d_lists = nullptr;
+    lib->ws_capacity = 0;
+    const size_t cap = n + n / 8 + 1024;
+    HIP_TRY(hipMalloc(&lib->d_lists, size_t(B_COUNT) * cap * sizeof(uint32_t)));
+    lib->ws_capacity = cap;
+  }
+  if (need_epa && lib->ws_capacity > lib->epa_capacity) {
+    hipFree(lib->d_epa_queue);
+    hipFree(lib->d_epa_queue2);
+    hipFree(lib->d_epa_resume);
+    lib->d_epa_queue = nullptr;
+    lib->d_epa_queue2 = nullptr;
+    lib->d_epa_resume = nullptr;
+    lib->resume_cap = 0;
+    lib->epa_capacity = 0;
+    const size_t cap = lib->ws_capacity;
+    HIP_TRY(hipMalloc(&lib->d_epa_queue, cap * sizeof(EpaItem<double>)));
+    HIP_TRY(hipMalloc(&lib->d_epa_queue2, cap * sizeof(EpaItem<double>)));
+    // saved polytopes for the tier hand-over: room for an eighth of the batch (cfg5: 4 % of the pairs outgrow the fast
+    // tier; beyond the area the full tier simply redoes the pair from its seed)
+    size_t rcap = std::min(cap, std::max<size_t>(65536, cap / 8));
+    if (const char* e = getenv("HFCL_EPA_RESUME_SLOTS")) rcap = std::max<size_t>(1, std::min<size_t>(cap, strtoull(e, nullptr, 10)));  // test knob
+    HIP_TRY(hipMalloc(&lib->d_epa_resume, rcap * std::max(epa_resume_stride<double>, epa_resume_stride<float>)));
+    lib->resume_cap = rcap;
+    lib->epa_capacity = cap;
+  }
   return HFCL_OK;
 }
 
@@ -723,7 +773,9 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     return HFCL_ERR_LIMIT;
   }
   HIP_TRY(hipSetDevice(lib->device));
-  int rc = ensure_workspace(lib, n);
+  const bool any_gjk_bucket = ((lib->possible_buckets >> B_PRIM) | (lib->possible_buckets >> B_CC) | (lib->possible_buckets >> B_PC) |
+                               (lib->possible_buckets >> B_CP) | (lib->possible_buckets >> B_LARGE)) & 1u;
+  int rc = ensure_workspace(lib, n, any_gjk_bucket && q.compute_penetration);
   if (rc) return rc;
   Work wk;
   wk.shape1 = d_s1;

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "hfcl_collide_batch_contacts", "hfcl_last_kernel_ms", "hfcl_last_kernel_name", "hfcl_bvh_build",
     "hfcl_world_aabbs", "hfcl_broadphase_self_pairs", "hfcl_broadphase_pairs_between", "hfcl_pairlist_size",
     "hfcl_pairlist_data", "hfcl_pairlist_free", "hfcl_lib_set_kernel_timing", "hfcl_pair_supported", "hfcl_last_kernel_breakdown", "hfcl_last_bucket_counts", "hfcl_lib_set_split", "hfcl_lib_get_split", "hfcl_lib_last_split_parts",
-    "hfcl_collide_batch_qt", "hfcl_distance_batch_qt", "hfcl_lib_set_host_chunk",
+    "hfcl_collide_batch_qt", "hfcl_distance_batch_qt", "hfcl_lib_set_host_chunk", "hfcl_lib_set_shapes",
 ]
 
 

@@ -212,6 +212,10 @@ void hfcl_distance_request_init(hfcl_distance_request* r);
  * Returns NULL (and sets hfcl_last_error) on failure -- never a CPU fallback. */
 hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes,
                           const double* vertices, size_t n_vertices, int device);
+/* Replace the shape / vertex table of an existing library (same rules as hfcl_lib_create); registered BVH models,
+ * workspaces and streams are kept.  Waits for the device.  Shape ids of pairs refer to the new table. */
+int hfcl_lib_set_shapes(hfcl_lib* lib, const hfcl_shape* shapes, size_t n_shapes,
+                        const double* vertices, size_t n_vertices);
 void      hfcl_lib_destroy(hfcl_lib* lib);
 size_t    hfcl_lib_num_shapes(const hfcl_lib* lib);
 int       hfcl_lib_device(const hfcl_lib* lib);

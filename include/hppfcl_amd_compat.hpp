@@ -428,6 +428,24 @@ class BatchQueries {
   BatchQueries(const BatchQueries&) = delete;
   BatchQueries& operator=(const BatchQueries&) = delete;
 
+  /// Forget every registered geometry (and free the device library): a long-lived context that has seen many temporary
+  /// geometries -- the thread's default one behind collide() / distance() -- is pruned this way.
+  void reset() {
+    hfcl_lib_destroy(lib_);
+    lib_ = nullptr;
+    shapes_.clear();
+    verts_.clear();
+    geoms_.clear();
+    ids_.clear();
+    meshes_.clear();
+    rec_.clear();
+    guess_.clear();
+    contacts_.clear();
+    shapes_dirty_ = false;
+    meshes_uploaded_ = 0;
+  }
+  size_t numGeometries() const { return shapes_.size(); }
+
   uint32_t add(const CollisionGeometry* g) {
     hfcl_shape s{};
     std::vector<double> v;
@@ -494,8 +512,7 @@ class BatchQueries {
     verts_.insert(verts_.end(), v.begin(), v.end());
     shapes_.push_back(s);
     geoms_.push_back(g);
-    hfcl_lib_destroy(lib_);
-    lib_ = nullptr;
+    shapes_dirty_ = true;  // the device tables follow at the next query (hfcl_lib_set_shapes: meshes and workspaces stay)
     const uint32_t id = static_cast<uint32_t>(shapes_.size() - 1);
     ids_[g] = id;
     return id;
@@ -582,11 +599,17 @@ class BatchQueries {
     if (!lib_) {
       lib_ = hfcl_lib_create(shapes_.data(), shapes_.size(), verts_.data(), verts_.size() / 3, device_);
       if (!lib_) throw std::runtime_error(hfcl_last_error());
-      for (const MeshRef& r : meshes_) {  // bvh_index = registration order
-        if (hfcl_lib_add_bvh(lib_, r.nodes.data(), r.nodes.size(), r.verts.data(), r.verts.size() / 3, r.tris.data(),
-                             r.tris.size() / 3) < 0)
-          throw std::runtime_error(hfcl_last_error());
-      }
+      meshes_uploaded_ = 0;
+    } else if (shapes_dirty_) {  // geometries were added since the last query: new shape tables, everything else stays
+      const int rc = hfcl_lib_set_shapes(lib_, shapes_.data(), shapes_.size(), verts_.data(), verts_.size() / 3);
+      if (rc) throw_for(rc);
+    }
+    shapes_dirty_ = false;
+    for (; meshes_uploaded_ < meshes_.size(); ++meshes_uploaded_) {  // bvh_index = registration order
+      const MeshRef& r = meshes_[meshes_uploaded_];
+      if (hfcl_lib_add_bvh(lib_, r.nodes.data(), r.nodes.size(), r.verts.data(), r.verts.size() / 3, r.tris.data(),
+                           r.tris.size() / 3) < 0)
+        throw std::runtime_error(hfcl_last_error());
     }
     std::vector<uint32_t> s1(pairs.size()), s2(pairs.size());
     for (size_t i = 0; i < pairs.size(); ++i) {
@@ -637,6 +660,8 @@ class BatchQueries {
   std::vector<hfcl_result> rec_;
   std::vector<hfcl_guess> guess_;
   std::vector<hfcl_contact> contacts_;
+  bool shapes_dirty_ = false;
+  size_t meshes_uploaded_ = 0;
   struct MeshRef {
     const BVHModel<OBBRSS>* model;
     unsigned int n_nodes, n_vertices;

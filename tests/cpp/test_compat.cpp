@@ -268,6 +268,23 @@ int main() {
     }
     (void)hits;
   }
+  {  // temporaries: every call registers a new geometry; the context follows with new shape tables and can be pruned
+    STAGE("context growth / reset");
+    CollisionRequest rq;
+    const size_t before = amd::default_context().numGeometries();
+    for (int i = 0; i < 20; ++i) {
+      Sphere a(0.5 + 0.01 * i), b(0.4);
+      CollisionResult rs;
+      CHECK(collide(&a, Transform3f(), &b, Transform3f(Vec3f(0.85 + 0.01 * i, 0, 0)), rq, rs) == 1);
+      CHECK(std::fabs(rs.getContact(0).penetration_depth + 0.05) < 1e-9);
+    }
+    CHECK(amd::default_context().numGeometries() >= before);
+    amd::default_context().reset();
+    CHECK(amd::default_context().numGeometries() == 0);
+    Box bx(1, 1, 1);
+    CollisionResult rs;
+    CHECK(collide(&bx, Transform3f(), &bx, Transform3f(Vec3f(0.5, 0, 0)), rq, rs) == 1);
+  }
   STAGE("done");
   std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
   return failures ? 1 : 0;
