@@ -86,12 +86,45 @@ __host__ __device__ inline int bucket_of(int k1, int k2, bool distance_mode = fa
 // kernel parameter blocks
 // ---------------------------------------------------------------------------------------
 template <typename T>
+struct NbrEntry;
+// one neighbour of a hull vertex: its coordinates (in the precision of the vertex table, same rounding) and its index
+template <> struct alignas(16) NbrEntry<float> { float x, y, z; uint32_t id; };
+template <> struct alignas(32) NbrEntry<double> { double x, y, z; uint32_t id; uint32_t pad_; };
+
+template <typename T>
 struct LibView {
   const DShape<T>* shapes;
   const T* verts;
   const uint8_t* kinds;
   uint32_t n_shapes;
+  // vertex adjacency of the convex shapes that registered one (hfcl_lib_set_convex_neighbors): graph_base[shape] is the
+  // index in graph_off of the shape's num_points+1 offsets into graph_ent (HFCL_NO_GRAPH: none; the 14 warm-start
+  // vertices of the shape sit just before its offsets); hulls of >= climb_min vertices with a graph hill-climb
+  const uint32_t* graph_base;
+  const uint32_t* graph_off;
+  const NbrEntry<T>* graph_ent;
+  uint32_t climb_min;
 };
+static constexpr uint32_t HFCL_NO_GRAPH = 0xFFFFFFFFu;
+#ifndef HFCL_CLIMB_MIN
+#define HFCL_CLIMB_MIN 512u  // climb_support overtakes scan_support between 256 and 1024 vertices (profiles/r02_p)
+#endif
+static constexpr int HFCL_WARM_STARTS = 14;  // ConvexBase::num_support_warm_starts (shape/geometric_shapes.h)
+template <typename T>
+struct HullGraph {
+  const uint32_t* off;  // nullptr: no graph, scan the vertices
+  const NbrEntry<T>* ent;
+};
+template <typename T>
+__device__ __forceinline__ HullGraph<T> hull_graph(const LibView<T>& lib, uint32_t shape_id, uint32_t num_points) {
+  HullGraph<T> g{nullptr, nullptr};
+  if (lib.graph_base == nullptr || num_points < lib.climb_min) return g;
+  const uint32_t base = lib.graph_base[shape_id];
+  if (base == HFCL_NO_GRAPH) return g;
+  g.off = lib.graph_off + base;
+  g.ent = lib.graph_ent;
+  return g;
+}
 
 template <typename T> struct IO;
 template <> struct IO<double> {
@@ -387,6 +420,84 @@ __device__ __forceinline__ V3<T> scan_support(const T* v, uint32_t n, const V3<T
     }
   });
   return mk<T>(v[3 * bi], v[3 * bi + 1], v[3 * bi + 2]);
+}
+// ---------------------------------------------------------------------------------------
+// Hill-climbing support over the vertex adjacency (getShapeSupportLog, support_functions.cpp:323-397): start at `hint`
+// (the vertex the previous call of this query returned; < 0: the best of the hull's 14 warm-start vertices,
+// ConvexBase::support_warm_starts, geometric_shapes.cpp buildSupportWarmStart), look at all neighbours of the current
+// vertex at once -- one per lane, coordinates inline in the adjacency entry so a hop is two dependent fetches (offsets,
+// entries) -- and move to the best one while it is strictly better.  On a convex polytope that ends at a vertex of
+// maximal support; where several vertices tie (a plateau) it may be another one than the scan's / the reference's
+// (which also accepts equal neighbours until its first strict improvement and keeps a visited set to stay finite).
+// A hop costs O(degree) instead of O(num_points): measured crossover against scan_support in profiles/r02_p.
+template <typename T, int W>
+__device__ __forceinline__ V3<T> climb_support(const T* v, const HullGraph<T>& g, const V3<T>& dir, int lig, int& hint) {
+  uint32_t cur;
+  T best;
+  if (hint < 0) {
+    best = -Lim<T>::max();
+    cur = 0;
+    uint32_t bk = 0xFFFFFFFFu;
+    for (int k = lig; k < HFCL_WARM_STARTS; k += W) {
+      const uint32_t id = g.off[k - HFCL_WARM_STARTS];
+      const T d = v[3 * size_t(id)] * dir.x + v[3 * size_t(id) + 1] * dir.y + v[3 * size_t(id) + 2] * dir.z;
+      if (d > best) {
+        best = d;
+        cur = id;
+        bk = uint32_t(k);
+      }
+    }
+    butterfly_stages<W>([&](auto stage) {
+      constexpr int M = decltype(stage)::value;
+      const T od = group_exchange<W, M>(best);
+      const uint32_t oc = group_exchange<W, M>(cur);
+      const uint32_t ok = group_exchange<W, M>(bk);
+      if (od > best || (od == best && ok < bk)) {
+        best = od;
+        cur = oc;
+        bk = ok;
+      }
+    });
+  } else {
+    cur = uint32_t(hint);
+    best = v[3 * size_t(cur)] * dir.x + v[3 * size_t(cur) + 1] * dir.y + v[3 * size_t(cur) + 2] * dir.z;
+  }
+  for (;;) {
+    const uint32_t b = g.off[cur], e = g.off[cur + 1];
+    T mb = best;
+    uint32_t mi = 0xFFFFFFFFu, mpos = 0xFFFFFFFFu;
+    for (uint32_t k = b + uint32_t(lig); k < e; k += W) {
+      const NbrEntry<T> nb = g.ent[k];
+      const T d = nb.x * dir.x + nb.y * dir.y + nb.z * dir.z;
+      if (d > mb) {
+        mb = d;
+        mi = nb.id;
+        mpos = k;
+      }
+    }
+    butterfly_stages<W>([&](auto stage) {
+      constexpr int M = decltype(stage)::value;
+      const T od = group_exchange<W, M>(mb);
+      const uint32_t oi = group_exchange<W, M>(mi);
+      const uint32_t ok = group_exchange<W, M>(mpos);
+      if (od > mb || (od == mb && ok < mpos)) {
+        mb = od;
+        mi = oi;
+        mpos = ok;
+      }
+    });
+    if (mi == 0xFFFFFFFFu) break;  // no neighbour is strictly better (uniform over the group)
+    cur = mi;
+    best = mb;
+  }
+  hint = int(cur);
+  return mk<T>(v[3 * size_t(cur)], v[3 * size_t(cur) + 1], v[3 * size_t(cur) + 2]);
+}
+// scan or climb: what a hull too large for registers answers a support query with
+template <typename T, int W>
+__device__ __forceinline__ V3<T> large_hull_support(const T* v, uint32_t n, const HullGraph<T>& g, const V3<T>& dir, int lig, int& hint) {
+  if (g.off != nullptr) return climb_support<T, W>(v, g, dir, lig, hint);
+  return scan_support<T, W>(v, n, dir, lig);
 }
 // ---------------------------------------------------------------------------------------
 // k_epa: EPA on the pairs GJK left in `Collision`.  One polytope per WE-lane group, 64/WE polytopes

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -65,6 +66,16 @@ struct hfcl_lib {
   double* d_verts64 = nullptr;
   float* d_verts32 = nullptr;
   uint8_t* d_kinds = nullptr;
+  // vertex adjacency of convex shapes (hfcl_lib_set_convex_neighbors): host copies per shape, device image built lazily
+  std::vector<double> h_verts;
+  struct HostGraph { std::vector<uint32_t> off, ids; };
+  std::map<uint32_t, HostGraph> h_graphs;
+  bool graph_dirty = false;
+  uint32_t* d_graph_base = nullptr;
+  uint32_t* d_graph_off = nullptr;
+  NbrEntry<float>* d_graph_ent32 = nullptr;
+  NbrEntry<double>* d_graph_ent64 = nullptr;
+  uint32_t climb_min = HFCL_CLIMB_MIN;  // HFCL_CLIMB_MIN: hulls of at least this many vertices with a graph hill-climb
   // workspace (grown on demand)
   size_t ws_capacity = 0;  // pairs
   size_t epa_capacity = 0;  // pairs the EPA queues / hand-over area are sized for (0: not allocated yet)
@@ -152,6 +163,8 @@ struct hfcl_lib {
   BvhParams bvh_params = {1u, nullptr, 0u, nullptr};
   double break_distance = 1e-3;
 };
+
+static void share_tables(hfcl_lib* h, const hfcl_lib* lib);
 
 // bucket population i of the last batch (both halves of a split batch)
 static uint32_t one_count(const uint32_t* c, int i) {
@@ -271,6 +284,9 @@ static bool validate_shapes(const char* who, const hfcl_shape* shapes, size_t n_
 static bool upload_shapes(hfcl_lib* lib, const hfcl_shape* shapes, size_t n_shapes, const double* vertices, size_t n_vertices) {
   lib->n_shapes = n_shapes;
   lib->h_shapes.assign(shapes, shapes + n_shapes);
+  lib->h_verts.assign(vertices, vertices + (vertices ? 3 * n_vertices : 0));
+  lib->h_graphs.clear();  // shape ids / vertex ranges may have changed: adjacency is registered again by the caller
+  lib->graph_dirty = true;
   std::vector<DShape<double>> s64(n_shapes);
   std::vector<DShape<float>> s32(n_shapes);
   std::vector<uint8_t> kinds(n_shapes);
@@ -368,6 +384,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_SPLIT")) lib->split = atoi(v) >= 2 ? 2 : (atoi(v) == 1 ? 1 : 0);
   if (const char* v = getenv("HFCL_PIPE_CHUNK")) lib->pipe_chunk = strtoull(v, nullptr, 10);
   if (const char* v = getenv("HFCL_BVH_STEAL")) lib->bvh_steal = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_CLIMB_MIN")) lib->climb_min = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_BUDGET")) lib->bvh_budget = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_LEVELS")) lib->bvh_levels = uint32_t(std::min(12, std::max(1, atoi(v))));
   if (const char* w = getenv("HFCL_CVX_W")) {
@@ -391,6 +408,10 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
     hipFree(lib->d_kinds);
     hipFree(lib->d_verts64);
     hipFree(lib->d_verts32);
+    hipFree(lib->d_graph_base);
+    hipFree(lib->d_graph_off);
+    hipFree(lib->d_graph_ent32);
+    hipFree(lib->d_graph_ent64);
   }
   hipFree(lib->d_counts);
   if (lib->h_counts) hipHostFree(lib->h_counts);
@@ -452,15 +473,42 @@ int hfcl_lib_set_shapes(hfcl_lib* lib, const hfcl_shape* shapes, size_t n_shapes
     set_error("hfcl_lib_set_shapes: HIP allocation/copy failed");
     return HFCL_ERR_HIP;
   }
-  if (hfcl_lib* h = lib->helper) {  // the second half of split batches reads the same tables
-    h->n_shapes = lib->n_shapes;
-    h->d_shapes64 = lib->d_shapes64;
-    h->d_shapes32 = lib->d_shapes32;
-    h->d_verts64 = lib->d_verts64;
-    h->d_verts32 = lib->d_verts32;
-    h->d_kinds = lib->d_kinds;
-    h->possible_buckets = lib->possible_buckets;
+  if (lib->helper) share_tables(lib->helper, lib);  // the second half of split batches reads the same tables
+  return HFCL_OK;
+}
+
+// Vertex adjacency of a convex shape (ConvexBase::neighbors, shape/geometric_shapes.h; Convex<PolygonT>::fillNeighbors,
+// shape/details/convex.hxx:231-280): offsets[num_points + 1] into neighbors[], vertex indices relative to the shape's first
+// vertex.  Hulls of at least HFCL_CLIMB_MIN vertices that have one answer support queries by hill-climbing
+// (getShapeSupportLog) instead of scanning all vertices; without one (or below the threshold) nothing changes.
+int hfcl_lib_set_convex_neighbors(hfcl_lib* lib, uint32_t shape_id, const uint32_t* offsets, const uint32_t* neighbors) {
+  if (!lib || !offsets || !neighbors) {
+    set_error("hfcl_lib_set_convex_neighbors: null argument");
+    return HFCL_ERR_INVALID_ARGUMENT;
   }
+  if (shape_id >= lib->n_shapes || lib->h_shapes[shape_id].type != HFCL_GEOM_CONVEX) {
+    set_error("hfcl_lib_set_convex_neighbors: not a convex shape of this library");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  const uint32_t n = lib->h_shapes[shape_id].num_points;
+  if (offsets[0] != 0) {
+    set_error("hfcl_lib_set_convex_neighbors: offsets[0] must be 0");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  for (uint32_t i = 0; i < n; ++i)
+    if (offsets[i + 1] < offsets[i]) {
+      set_error("hfcl_lib_set_convex_neighbors: offsets must not decrease");
+      return HFCL_ERR_INVALID_ARGUMENT;
+    }
+  for (uint32_t k = 0; k < offsets[n]; ++k)
+    if (neighbors[k] >= n) {
+      set_error("hfcl_lib_set_convex_neighbors: neighbour index outside the shape's vertices");
+      return HFCL_ERR_INVALID_ARGUMENT;
+    }
+  hfcl_lib::HostGraph& g = lib->h_graphs[shape_id];
+  g.off.assign(offsets, offsets + n + 1);
+  g.ids.assign(neighbors, neighbors + offsets[n]);
+  lib->graph_dirty = true;
   return HFCL_OK;
 }
 size_t hfcl_lib_num_shapes(const hfcl_lib* lib) { return lib ? lib->n_shapes : 0; }
@@ -617,6 +665,76 @@ static DNode<T> pack_node(const hfcl_bvh_node& n) {
   d.To = mk<T>(T(n.obb_To[0]), T(n.obb_To[1]), T(n.obb_To[2]));
   d.extent = mk<T>(T(n.obb_extent[0]), T(n.obb_extent[1]), T(n.obb_extent[2]));
   return d;
+}
+
+// Device image of the registered vertex adjacencies: per shape [14 warm-start vertices][num_points + 1 offsets] in
+// d_graph_off, the neighbours with their coordinates inline in d_graph_ent32/64 (one fetch per hop instead of two).
+// The warm-start vertices are the support vertices along the 14 directions of ConvexBase::buildSupportWarmStart
+// (src/shape/geometric_shapes.cpp: the six axis directions and the eight cube diagonals).
+static int upload_graph(hfcl_lib* lib) {
+  if (!lib->graph_dirty) return HFCL_OK;
+  HIP_TRY(hipSetDevice(lib->device));
+  HIP_TRY(hipDeviceSynchronize());
+  hipFree(lib->d_graph_base); hipFree(lib->d_graph_off); hipFree(lib->d_graph_ent32); hipFree(lib->d_graph_ent64);
+  lib->d_graph_base = nullptr; lib->d_graph_off = nullptr; lib->d_graph_ent32 = nullptr; lib->d_graph_ent64 = nullptr;
+  lib->graph_dirty = false;
+  if (lib->h_graphs.empty()) {
+    if (lib->helper) share_tables(lib->helper, lib);
+    return HFCL_OK;
+  }
+  std::vector<uint32_t> base(lib->n_shapes, HFCL_NO_GRAPH), off;
+  std::vector<NbrEntry<float>> e32;
+  std::vector<NbrEntry<double>> e64;
+  static const double dirs[HFCL_WARM_STARTS][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1},
+                                                   {1, 1, 1}, {-1, 1, 1}, {1, -1, 1}, {-1, -1, 1}, {1, 1, -1}, {-1, 1, -1}, {1, -1, -1}, {-1, -1, -1}};
+  for (const auto& kv : lib->h_graphs) {
+    const hfcl_shape& sh = lib->h_shapes[kv.first];
+    const hfcl_lib::HostGraph& g = kv.second;
+    const double* v = lib->h_verts.data() + 3 * size_t(sh.vertex_offset);
+    for (int k = 0; k < HFCL_WARM_STARTS; ++k) {
+      uint32_t bi = 0;
+      double best = -1.7976931348623157e+308;
+      for (uint32_t j = 0; j < sh.num_points; ++j) {
+        if (g.off[j + 1] == g.off[j]) continue;  // not a hull vertex: no way on from there
+        const double d = v[3 * size_t(j)] * dirs[k][0] + v[3 * size_t(j) + 1] * dirs[k][1] + v[3 * size_t(j) + 2] * dirs[k][2];
+        if (d > best) {
+          best = d;
+          bi = j;
+        }
+      }
+      off.push_back(bi);
+    }
+    base[kv.first] = uint32_t(off.size());
+    const size_t e0 = e64.size();
+    if (e0 + g.ids.size() > 0xFFFFFFF0u) {
+      set_error("hfcl_lib_set_convex_neighbors: more than 2^32 adjacency entries in one library");
+      return HFCL_ERR_INVALID_ARGUMENT;
+    }
+    for (uint32_t o : g.off) off.push_back(uint32_t(e0) + o);
+    for (uint32_t id : g.ids) {
+      const double* p = v + 3 * size_t(id);
+      NbrEntry<double> a;
+      a.x = p[0]; a.y = p[1]; a.z = p[2]; a.id = id; a.pad_ = 0;
+      NbrEntry<float> b;
+      b.x = float(p[0]); b.y = float(p[1]); b.z = float(p[2]); b.id = id;
+      e64.push_back(a);
+      e32.push_back(b);
+    }
+  }
+  bool ok = hipMalloc(&lib->d_graph_base, base.size() * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_graph_off, off.size() * sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_graph_ent32, (e32.size() + 1) * sizeof(NbrEntry<float>)) == hipSuccess;
+  ok = ok && hipMalloc(&lib->d_graph_ent64, (e64.size() + 1) * sizeof(NbrEntry<double>)) == hipSuccess;
+  ok = ok && hipMemcpy(lib->d_graph_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy(lib->d_graph_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && (e32.empty() || hipMemcpy(lib->d_graph_ent32, e32.data(), e32.size() * sizeof(NbrEntry<float>), hipMemcpyHostToDevice) == hipSuccess);
+  ok = ok && (e64.empty() || hipMemcpy(lib->d_graph_ent64, e64.data(), e64.size() * sizeof(NbrEntry<double>), hipMemcpyHostToDevice) == hipSuccess);
+  if (!ok) {
+    set_error("vertex adjacency: HIP allocation/copy failed");
+    return HFCL_ERR_HIP;
+  }
+  if (lib->helper) share_tables(lib->helper, lib);
+  return HFCL_OK;
 }
 
 static int upload_bvh(hfcl_lib* lib) {
@@ -793,6 +911,10 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
   lv.verts = std::is_same<T, double>::value ? (const T*)lib->d_verts64 : (const T*)lib->d_verts32;
   lv.kinds = lib->d_kinds;
   lv.n_shapes = uint32_t(lib->n_shapes);
+  lv.graph_base = lib->d_graph_base;
+  lv.graph_off = lib->d_graph_off;
+  lv.graph_ent = std::is_same<T, double>::value ? (const NbrEntry<T>*)lib->d_graph_ent64 : (const NbrEntry<T>*)lib->d_graph_ent32;
+  lv.climb_min = lib->climb_min;
 
   for (auto& t : lib->timers) t.used = false;
   size_t ti = 0;
@@ -930,10 +1052,8 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
 }
 
 // shallow clone for the second half of a split batch: shares the device shape tables, owns everything else
-static hfcl_lib* make_helper(hfcl_lib* lib) {
-  hfcl_lib* h = new hfcl_lib;
-  h->is_helper = true;
-  h->device = lib->device;
+// the device tables a split batch's second half shares with its owner
+static void share_tables(hfcl_lib* h, const hfcl_lib* lib) {
   h->n_shapes = lib->n_shapes;
   h->d_shapes64 = lib->d_shapes64;
   h->d_shapes32 = lib->d_shapes32;
@@ -941,6 +1061,17 @@ static hfcl_lib* make_helper(hfcl_lib* lib) {
   h->d_verts32 = lib->d_verts32;
   h->d_kinds = lib->d_kinds;
   h->possible_buckets = lib->possible_buckets;
+  h->d_graph_base = lib->d_graph_base;
+  h->d_graph_off = lib->d_graph_off;
+  h->d_graph_ent32 = lib->d_graph_ent32;
+  h->d_graph_ent64 = lib->d_graph_ent64;
+  h->climb_min = lib->climb_min;
+}
+static hfcl_lib* make_helper(hfcl_lib* lib) {
+  hfcl_lib* h = new hfcl_lib;
+  h->is_helper = true;
+  h->device = lib->device;
+  share_tables(h, lib);
   h->cvx_w = lib->cvx_w;
   h->closed_staged = lib->closed_staged;
   h->n_cus = lib->n_cus;
@@ -1000,6 +1131,10 @@ static int run_batch(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_s2, 
                      hipStream_t st) {
   lib->last_split = false;
   if (!lib->in_host_batch) lib->last_host = false;
+  if (lib->graph_dirty) {
+    const int rcg = upload_graph(lib);
+    if (rcg) return rcg;
+  }
   if (!batch_splits(lib, n)) return run_batch_one<T>(lib, d_s1, d_s2, io, n, q, st);
   int rc0 = ensure_helper(lib);
   if (rc0) return rc0;

@@ -19,21 +19,23 @@ struct EpaSupport {  // any pair kind, evaluated by one lane group
   HullRegs<T, WE> h0, h1;
   const T* va;
   const T* vb;
+  HullGraph<T> ga, gb;       // LARGE only: adjacency of a hull beyond HULL_MAX vertices (climb_support), if registered
+  mutable int hint0, hint1;  // ... and where its last support call ended
   MDiff<T> md;
   int lig;
-  __device__ __forceinline__ V3<T> hull(const DShape<T>& s, const HullRegs<T, WE>& h, const T* v, const V3<T>& d) const {
-    if (LARGE && s.num_points > uint32_t(HULL_MAX)) return scan_support<T, WE>(v, s.num_points, d, lig);
+  __device__ __forceinline__ V3<T> hull(const DShape<T>& s, const HullRegs<T, WE>& h, const T* v, const HullGraph<T>& g, const V3<T>& d, int& hint) const {
+    if (LARGE && s.num_points > uint32_t(HULL_MAX)) return large_hull_support<T, WE>(v, s.num_points, g, d, lig, hint);
     return h.support(d, lig);
   }
   __device__ __forceinline__ void operator()(const V3<T>& dir, V3<T>& w, V3<T>& w0) const {
     if (a.kind == K_CONVEX)
-      w0 = hull(a, h0, va, dir);
+      w0 = hull(a, h0, va, ga, dir, hint0);
     else
       w0 = prim_support(a, dir);
     const V3<T> d1 = md.identity ? -dir : -tmul(md.oR1, dir);
     V3<T> s1;
     if (b.kind == K_CONVEX)
-      s1 = hull(b, h1, vb, d1);
+      s1 = hull(b, h1, vb, gb, d1, hint1);
     else
       s1 = prim_support(b, d1);
     s1 = md.identity ? s1 : (mul(md.oR1, s1) + md.ot1);
@@ -93,14 +95,18 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
     const EpaItem<T>& item = queue[it];
     const uint32_t pair = item.pair;
     EpaSupport<T, WE, TIER == 2> sup;
-    sup.a = lib.shapes[wk.shape1[pair]];
-    sup.b = lib.shapes[wk.shape2[pair]];
+    const uint32_t sid1 = wk.shape1[pair], sid2 = wk.shape2[pair];
+    sup.a = lib.shapes[sid1];
+    sup.b = lib.shapes[sid2];
     sup.lig = lig;
     const T* va = lib.verts + 3 * size_t(sup.a.vertex_offset);
     const T* vb = lib.verts + 3 * size_t(sup.b.vertex_offset);
     if (TIER == 2) {
       sup.va = va;
       sup.vb = vb;
+      sup.ga = sup.a.kind == K_CONVEX ? hull_graph(lib, sid1, sup.a.num_points) : HullGraph<T>{nullptr, nullptr};
+      sup.gb = sup.b.kind == K_CONVEX ? hull_graph(lib, sid2, sup.b.num_points) : HullGraph<T>{nullptr, nullptr};
+      sup.hint0 = sup.hint1 = -1;
     }
     if (sup.a.kind == K_CONVEX && (TIER != 2 || sup.a.num_points <= uint32_t(HULL_MAX))) sup.h0.load(va, sup.a.num_points, lig);
     if (sup.b.kind == K_CONVEX && (TIER != 2 || sup.b.num_points <= uint32_t(HULL_MAX))) sup.h1.load(vb, sup.b.num_points, lig);

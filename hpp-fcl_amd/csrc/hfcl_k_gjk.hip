@@ -350,15 +350,17 @@ struct LargeSupport {
   DShape<T> a, b;
   const T* va;
   const T* vb;
+  HullGraph<T> ga, gb;
+  mutable int hint0, hint1;  // the vertex each hull's last support call returned (hill-climbing start; -1: warm start)
   MDiff<T> md;
   int lig;
-  __device__ __forceinline__ V3<T> one(const DShape<T>& s, const T* v, const V3<T>& d) const {
-    return s.kind == K_CONVEX ? scan_support<T, LARGE_W>(v, s.num_points, d, lig) : prim_support(s, d);
+  __device__ __forceinline__ V3<T> one(const DShape<T>& s, const T* v, const HullGraph<T>& g, const V3<T>& d, int& hint) const {
+    return s.kind == K_CONVEX ? large_hull_support<T, LARGE_W>(v, s.num_points, g, d, lig, hint) : prim_support(s, d);
   }
   __device__ __forceinline__ void operator()(const V3<T>& dir, V3<T>& w, V3<T>& w0) const {
-    w0 = one(a, va, dir);
+    w0 = one(a, va, ga, dir, hint0);
     const V3<T> d1 = md.identity ? -dir : -tmul(md.oR1, dir);
-    V3<T> s1 = one(b, vb, d1);
+    V3<T> s1 = one(b, vb, gb, d1, hint1);
     s1 = md.identity ? s1 : (mul(md.oR1, s1) + md.ot1);
     w = w0 - s1;
   }
@@ -373,10 +375,14 @@ __global__ void __launch_bounds__(256) k_gjk_large(Work wk, LibView<T> lib, IO<T
   for (uint32_t it = (blockIdx.x * blockDim.x + threadIdx.x) / LARGE_W; it < cnt; it += groups) {
     const uint32_t pair = wk.lists[size_t(B_LARGE) * wk.n + it];
     LargeSupport<T> sup;
-    sup.a = lib.shapes[wk.shape1[pair]];
-    sup.b = lib.shapes[wk.shape2[pair]];
+    const uint32_t sid1 = wk.shape1[pair], sid2 = wk.shape2[pair];
+    sup.a = lib.shapes[sid1];
+    sup.b = lib.shapes[sid2];
     sup.va = lib.verts + 3 * size_t(sup.a.vertex_offset);
     sup.vb = lib.verts + 3 * size_t(sup.b.vertex_offset);
+    sup.ga = sup.a.kind == K_CONVEX ? hull_graph(lib, sid1, sup.a.num_points) : HullGraph<T>{nullptr, nullptr};
+    sup.gb = sup.b.kind == K_CONVEX ? hull_graph(lib, sid2, sup.b.num_points) : HullGraph<T>{nullptr, nullptr};
+    sup.hint0 = sup.hint1 = -1;
     sup.lig = lig;
     const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
     sup.md = make_mdiff(tf1, tf2);

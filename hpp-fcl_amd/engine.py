@@ -23,6 +23,7 @@ EXPORTED_SYMBOLS = [
     "hfcl_world_aabbs", "hfcl_broadphase_self_pairs", "hfcl_broadphase_pairs_between", "hfcl_pairlist_size",
     "hfcl_pairlist_data", "hfcl_pairlist_free", "hfcl_lib_set_kernel_timing", "hfcl_pair_supported", "hfcl_last_kernel_breakdown", "hfcl_last_bucket_counts", "hfcl_lib_set_split", "hfcl_lib_get_split", "hfcl_lib_last_split_parts",
     "hfcl_collide_batch_qt", "hfcl_distance_batch_qt", "hfcl_lib_set_host_chunk", "hfcl_lib_set_shapes",
+    "hfcl_lib_set_convex_neighbors",
 ]
 
 
@@ -231,6 +232,14 @@ class Library:
         """distance() with compact host poses: (n, 7) float64 = quaternion (w, x, y, z) + translation."""
         return self._host(dll().hfcl_distance_batch_qt, s1, s2, pose1, pose2, req or abi.default_distance_request(),
                           guess_in, want_guess, pose_width=7)
+
+    def set_convex_neighbors(self, shape_id, offsets, neighbors):
+        """ConvexBase::neighbors of one convex shape (CSR: offsets[num_points + 1], vertex indices relative to the
+        shape): large hulls that have them hill-climb instead of scanning (hfcl_lib_set_convex_neighbors)."""
+        off = np.ascontiguousarray(offsets, dtype=np.uint32)
+        ids = np.ascontiguousarray(neighbors, dtype=np.uint32)
+        _check(dll().hfcl_lib_set_convex_neighbors(self._h, C.c_uint32(int(shape_id)), C.c_void_p(off.ctypes.data),
+                                                   C.c_void_p(ids.ctypes.data)))
 
     def set_host_chunk(self, pairs):
         """Pairs per chunk of the host-buffer pipeline (0 = automatic)."""

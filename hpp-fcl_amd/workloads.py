@@ -248,6 +248,38 @@ def flat_pairs(n=50_000, seed=1, nper=64, half_width=1.0, kind="collide"):
     return Batch("flat_pairs_" + kind, lib, s1, s2, q1, T1, q2, T2, kind)
 
 
+def hull_adjacency(points):
+    """Vertex adjacency of a convex point set as Convex<Triangle>::fillNeighbors builds it (shape/details/convex.hxx:
+    231-280: per vertex the ascending set of vertices it shares a facet edge with), from the facets of scipy's Qhull
+    wrapper.  Returns CSR (offsets[n + 1], ids) for hfcl_lib_set_convex_neighbors / Library.set_convex_neighbors."""
+    from scipy.spatial import ConvexHull
+    pts = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+    n = len(pts)
+    hull = ConvexHull(pts)
+    edges = np.concatenate([hull.simplices[:, [0, 1]], hull.simplices[:, [1, 2]], hull.simplices[:, [2, 0]]])
+    edges = np.concatenate([edges, edges[:, ::-1]])
+    edges = np.unique(edges, axis=0)  # sorted by (vertex, neighbour)
+    offs = np.zeros(n + 1, dtype=np.uint32)
+    np.cumsum(np.bincount(edges[:, 0], minlength=n), out=offs[1:])
+    return offs, edges[:, 1].astype(np.uint32)
+
+
+def register_adjacency(library, shapes, verts, min_points=33):
+    """hull_adjacency for every convex shape of at least `min_points` vertices of a shape table, registered with the
+    engine library.  Returns the number of shapes registered."""
+    from . import abi
+    count = 0
+    verts = np.asarray(verts, dtype=np.float64).reshape(-1, 3)
+    for i, s in enumerate(shapes):
+        if s["type"] != abi.GEOM_CONVEX or s["num_points"] < min_points:
+            continue
+        off, n = int(s["vertex_offset"]), int(s["num_points"])
+        offs, ids = hull_adjacency(verts[off:off + n])
+        library.set_convex_neighbors(i, offs, ids)
+        count += 1
+    return count
+
+
 def large_convex(n=50_000, seed=1, sizes=(33, 48, 64, 100, 256), nlib_each=12, half_width=1.0, kind="distance"):
     """Hulls above ConvexBase::num_vertices_large_convex_threshold (32) against each other, small hulls and
     primitives.  Points are random directions scaled onto an ellipsoid, so every point is a hull vertex."""

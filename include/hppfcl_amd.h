@@ -216,6 +216,14 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes,
  * workspaces and streams are kept.  Waits for the device.  Shape ids of pairs refer to the new table. */
 int hfcl_lib_set_shapes(hfcl_lib* lib, const hfcl_shape* shapes, size_t n_shapes,
                         const double* vertices, size_t n_vertices);
+/* Vertex adjacency of a convex shape -- ConvexBase::neighbors (include/hpp/fcl/shape/geometric_shapes.h:ConvexBase,
+ * built by Convex<PolygonT>::fillNeighbors, shape/details/convex.hxx:231-280): offsets[num_points + 1] into neighbors[],
+ * indices relative to the shape's first vertex.  A hull of at least HFCL_CLIMB_MIN (default 512, environment) vertices
+ * that has one answers GJK / EPA support queries by neighbour hill-climbing from the previous answer, as
+ * getShapeSupportLog does (src/narrowphase/support_functions.cpp:323-397), instead of scanning every vertex; smaller
+ * hulls and hulls without adjacency are unaffected.  hfcl_lib_set_shapes drops all registered adjacencies. */
+int hfcl_lib_set_convex_neighbors(hfcl_lib* lib, uint32_t shape_id, const uint32_t* offsets,
+                                  const uint32_t* neighbors);
 void      hfcl_lib_destroy(hfcl_lib* lib);
 size_t    hfcl_lib_num_shapes(const hfcl_lib* lib);
 int       hfcl_lib_device(const hfcl_lib* lib);

@@ -584,10 +584,12 @@ def test_flat_rows_gpu(pkg, oracle, kind):
             assert np.all(np.abs(a[fin] - r[fin]) <= 1e-9 * (1 + np.abs(r[fin]))), f
 
 
+@pytest.mark.parametrize("support", ["scan", "climb"])
 @pytest.mark.parametrize("kind", ["distance", "collide"])
-def test_large_hulls_gpu(pkg, oracle, kind):
-    """Hulls of 33..256 vertices (k_gjk_large + full-capacity EPA tier, vertices scanned from memory) vs the
-    oracle's neighbour hill-climbing support (support_functions.cpp:323-397)."""
+def test_large_hulls_gpu(pkg, oracle, kind, support, monkeypatch):
+    """Hulls of 33..256 vertices (k_gjk_large + full-capacity EPA tier) vs the oracle's neighbour hill-climbing support
+    (support_functions.cpp:323-397): with the vertices scanned from memory, and with the registered vertex adjacency
+    climbed from the previous answer (hfcl_lib_set_convex_neighbors; HFCL_CLIMB_MIN lowered so that these hulls use it)."""
     abi, wl = pkg.abi, pkg.workloads
     b = wl.large_convex(n=60000, kind=kind)
     oracle.register_hull_neighbors(b.shapes, b.verts)
@@ -596,7 +598,19 @@ def test_large_hulls_gpu(pkg, oracle, kind):
         ref = _oracle(oracle, b, req)
     finally:
         oracle.lib().orc_clear_neighbors()
-    got, buckets = _engine(pkg, b, req)
+    if support == "climb":
+        monkeypatch.setenv("HFCL_CLIMB_MIN", "33")
+        lib = pkg.Library(b.lib, device=0)
+        try:
+            assert wl.register_adjacency(lib, b.shapes, b.verts) == b.n_large
+            run = lib.distance if b.kind == "distance" else lib.collide
+            got, buckets = run(b.s1, b.s2, b.tf1, b.tf2, req), lib.last_bucket_counts()
+            again = run(b.s1, b.s2, b.tf1, b.tf2, req)  # deterministic: the walk has no scheduling-dependent choice
+            assert got.tobytes() == again.tobytes()
+        finally:
+            lib.close()
+    else:
+        got, buckets = _engine(pkg, b, req)
     assert buckets["large"] == len(b) and buckets["unsupported"] == 0
     st = check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name="large-" + kind)
     assert st["p999_dd"] < 1e-9, st
