@@ -216,6 +216,10 @@ class ConvexBase : public ShapeBase {
   }
   std::shared_ptr<std::vector<Vec3f>> points;
   unsigned int num_points;
+  /// ConvexBase::neighbors (geometric_shapes.h: per vertex the vertices it shares a facet edge with), kept as CSR:
+  /// neighbor_offsets[num_points + 1] into neighbor_ids.  Empty: none known (Convex<PolygonT> fills them).  The engine
+  /// climbs them for hulls of HFCL_CLIMB_MIN vertices and more (hfcl_lib_set_convex_neighbors).
+  std::vector<uint32_t> neighbor_offsets, neighbor_ids;
   NODE_TYPE getNodeType() const override { return GEOM_CONVEX; }
 };
 
@@ -234,6 +238,50 @@ struct Triangle {  // include/hpp/fcl/data_types.h:101-144
   index_type& operator[](index_type i) { return vids[i]; }
   index_type vids[3];
 };
+/// Convex<PolygonT> (include/hpp/fcl/shape/convex.h:49-105): a convex polytope given by its vertices and facets; the
+/// constructor derives the vertex adjacency from the facets (fillNeighbors, shape/details/convex.hxx:231-280: the
+/// ascending set of the two facet-cycle neighbours of every vertex over all facets).
+template <typename PolygonT>
+class Convex : public ConvexBase {
+ public:
+  Convex(std::shared_ptr<std::vector<Vec3f>> points_, unsigned int num_points_, std::shared_ptr<std::vector<PolygonT>> polygons_,
+         unsigned int num_polygons_)
+      : ConvexBase(std::move(points_)), polygons(std::move(polygons_)), num_polygons(num_polygons_) {
+    if (num_points_ < num_points) num_points = num_points_;
+    fillNeighbors();
+  }
+  std::shared_ptr<std::vector<PolygonT>> polygons;
+  unsigned int num_polygons;
+
+ protected:
+  void fillNeighbors() {
+    std::vector<std::vector<uint32_t>> nb(num_points);
+    if (!polygons) return;
+    for (unsigned int l = 0; l < num_polygons && l < polygons->size(); ++l) {
+      const PolygonT& poly = (*polygons)[l];
+      const std::size_t n = poly_size(poly);
+      for (std::size_t j = 0; j < n; ++j) {
+        const std::size_t pi = poly[static_cast<typename PolygonT::index_type>(j == 0 ? n - 1 : j - 1)], pj = poly[static_cast<typename PolygonT::index_type>(j)],
+                          pk = poly[static_cast<typename PolygonT::index_type>(j == n - 1 ? 0 : j + 1)];
+        if (pj >= num_points || pi >= num_points || pk >= num_points) throw std::invalid_argument("Convex: polygon vertex index out of range");
+        nb[pj].push_back(static_cast<uint32_t>(pi));
+        nb[pj].push_back(static_cast<uint32_t>(pk));
+      }
+    }
+    neighbor_offsets.assign(num_points + 1, 0);
+    neighbor_ids.clear();
+    for (unsigned int i = 0; i < num_points; ++i) {
+      std::sort(nb[i].begin(), nb[i].end());
+      nb[i].erase(std::unique(nb[i].begin(), nb[i].end()), nb[i].end());
+      neighbor_ids.insert(neighbor_ids.end(), nb[i].begin(), nb[i].end());
+      neighbor_offsets[i + 1] = static_cast<uint32_t>(neighbor_ids.size());
+    }
+  }
+  static std::size_t poly_size(const Triangle&) { return 3; }
+  template <typename P>
+  static std::size_t poly_size(const P& p) { return p.size(); }
+};
+
 struct OBBRSS {};  // tag: the one BV type in scope (include/hpp/fcl/BV/OBBRSS.h)
 enum BVHReturnCode { BVH_OK = 0, BVH_ERR_BUILD_OUT_OF_SEQUENCE = -2, BVH_ERR_BUILD_EMPTY_MODEL = -3 };
 
@@ -443,6 +491,8 @@ class BatchQueries {
     contacts_.clear();
     shapes_dirty_ = false;
     meshes_uploaded_ = 0;
+    adjacency_.clear();
+    adjacency_pending_ = false;
   }
   size_t numGeometries() const { return shapes_.size(); }
 
@@ -464,7 +514,7 @@ class BatchQueries {
       case GEOM_CONVEX: {
         auto* c = static_cast<const ConvexBase*>(g);
         s.num_points = c->num_points;
-        for (const Vec3f& p : *c->points) v.insert(v.end(), p.data(), p.data() + 3);
+        for (unsigned int k = 0; k < c->num_points; ++k) v.insert(v.end(), (*c->points)[k].data(), (*c->points)[k].data() + 3);
         break;
       }
       case GEOM_TRIANGLE: {
@@ -515,6 +565,13 @@ class BatchQueries {
     shapes_dirty_ = true;  // the device tables follow at the next query (hfcl_lib_set_shapes: meshes and workspaces stay)
     const uint32_t id = static_cast<uint32_t>(shapes_.size() - 1);
     ids_[g] = id;
+    if (s.type == GEOM_CONVEX) {  // a copy, like the vertices: the geometry may be gone by the next query
+      auto* c = static_cast<const ConvexBase*>(g);
+      if (c->neighbor_offsets.size() == size_t(c->num_points) + 1) {
+        adjacency_[id] = std::make_pair(c->neighbor_offsets, c->neighbor_ids);
+        adjacency_pending_ = true;
+      }
+    }
     return id;
   }
 
@@ -604,6 +661,13 @@ class BatchQueries {
       const int rc = hfcl_lib_set_shapes(lib_, shapes_.data(), shapes_.size(), verts_.data(), verts_.size() / 3);
       if (rc) throw_for(rc);
     }
+    if (shapes_dirty_ || adjacency_pending_) {  // (hfcl_lib_set_shapes dropped the adjacencies of the old table)
+      for (const auto& kv : adjacency_) {
+        const int rc = hfcl_lib_set_convex_neighbors(lib_, kv.first, kv.second.first.data(), kv.second.second.data());
+        if (rc) throw_for(rc);
+      }
+      adjacency_pending_ = false;
+    }
     shapes_dirty_ = false;
     for (; meshes_uploaded_ < meshes_.size(); ++meshes_uploaded_) {  // bvh_index = registration order
       const MeshRef& r = meshes_[meshes_uploaded_];
@@ -661,6 +725,8 @@ class BatchQueries {
   std::vector<hfcl_guess> guess_;
   std::vector<hfcl_contact> contacts_;
   bool shapes_dirty_ = false;
+  std::map<uint32_t, std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> adjacency_;  // shape id -> ConvexBase::neighbors (CSR)
+  bool adjacency_pending_ = false;
   size_t meshes_uploaded_ = 0;
   struct MeshRef {
     const BVHModel<OBBRSS>* model;

@@ -285,6 +285,57 @@ int main() {
     CollisionResult rs;
     CHECK(collide(&bx, Transform3f(), &bx, Transform3f(Vec3f(0.5, 0, 0)), rq, rs) == 1);
   }
+  {  // Convex<Triangle>: the facets give ConvexBase::neighbors; a 642-vertex hull climbs them on the device, the same
+     // points without facets are scanned -- same answers
+    STAGE("Convex<Triangle> adjacency (hill-climbing support)");
+    std::vector<Vec3f> pts = {Vec3f(-1, 1.618033988749895, 0), Vec3f(1, 1.618033988749895, 0), Vec3f(-1, -1.618033988749895, 0), Vec3f(1, -1.618033988749895, 0),
+                              Vec3f(0, -1, 1.618033988749895), Vec3f(0, 1, 1.618033988749895), Vec3f(0, -1, -1.618033988749895), Vec3f(0, 1, -1.618033988749895),
+                              Vec3f(1.618033988749895, 0, -1), Vec3f(1.618033988749895, 0, 1), Vec3f(-1.618033988749895, 0, -1), Vec3f(-1.618033988749895, 0, 1)};
+    std::vector<Triangle> tris = {{0, 11, 5}, {0, 5, 1}, {0, 1, 7}, {0, 7, 10}, {0, 10, 11}, {1, 5, 9}, {5, 11, 4}, {11, 10, 2}, {10, 7, 6}, {7, 1, 8},
+                                  {3, 9, 4}, {3, 4, 2}, {3, 2, 6}, {3, 6, 8}, {3, 8, 9}, {4, 9, 5}, {2, 4, 11}, {6, 2, 10}, {8, 6, 7}, {9, 8, 1}};
+    for (Vec3f& p : pts) p = p / p.norm();
+    for (int level = 0; level < 3; ++level) {  // 12 -> 42 -> 162 -> 642 vertices on the unit sphere (all extreme)
+      std::map<std::pair<size_t, size_t>, size_t> mid;
+      auto midpoint = [&](size_t a, size_t b) {
+        const auto key = std::make_pair(std::min(a, b), std::max(a, b));
+        auto it = mid.find(key);
+        if (it != mid.end()) return it->second;
+        Vec3f m = (pts[a] + pts[b]) * 0.5;
+        pts.push_back(m / m.norm());
+        return mid[key] = pts.size() - 1;
+      };
+      std::vector<Triangle> next;
+      for (const Triangle& t : tris) {
+        const size_t a = midpoint(t[0], t[1]), b = midpoint(t[1], t[2]), c = midpoint(t[2], t[0]);
+        next.push_back(Triangle(t[0], a, c));
+        next.push_back(Triangle(t[1], b, a));
+        next.push_back(Triangle(t[2], c, b));
+        next.push_back(Triangle(a, b, c));
+      }
+      tris.swap(next);
+    }
+    for (Vec3f& p : pts) p = Vec3f(0.9 * p[0], 0.6 * p[1], 0.4 * p[2]);
+    CHECK(pts.size() == 642 && tris.size() == 1280);
+    auto shared_pts = std::make_shared<std::vector<Vec3f>>(pts);
+    Convex<Triangle> with_facets(shared_pts, unsigned(pts.size()), std::make_shared<std::vector<Triangle>>(tris), unsigned(tris.size()));
+    ConvexBase points_only(shared_pts);
+    CHECK(with_facets.neighbor_offsets.size() == 643 && with_facets.neighbor_ids.size() == 2 * (642 + 1280 - 2));  // 2E, E = V + F - 2
+    CHECK(with_facets.neighbor_offsets[1] - with_facets.neighbor_offsets[0] == 5);                                 // an icosahedron corner
+    Box other(0.5, 0.4, 0.3);
+    DistanceRequest dq;
+    int compared = 0;
+    for (int i = 0; i < 60; ++i) {
+      const double a = 0.37 * i, r = 0.2 + 0.02 * i;  // from deep penetration to well apart
+      Transform3f tf(Vec3f(r * std::cos(a), r * std::sin(a), 0.3 * std::sin(1.7 * a)));
+      DistanceResult r1, r2;
+      const double d1 = distance(&with_facets, Transform3f(), &other, tf, dq, r1);
+      const double d2 = distance(&points_only, Transform3f(), &other, tf, dq, r2);
+      CHECK(std::fabs(d1 - d2) < 1e-6);
+      CHECK((r1.nearest_points[0] - r2.nearest_points[0]).norm() < 1e-4);
+      ++compared;
+    }
+    CHECK(compared == 60);
+  }
   STAGE("done");
   std::printf("%s (%d failures)\n", failures ? "FAILED" : "ok", failures);
   return failures ? 1 : 0;
