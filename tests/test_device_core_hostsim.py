@@ -160,14 +160,29 @@ def test_bvh_builder_tree_is_well_formed(pkg, small_meshes):
         assert sorted((-(leaves + 1)).tolist()) == list(range(m.num_tris))
         inner = nodes["first_child"][nodes["first_child"] > 0]
         assert sorted(np.concatenate([inner, inner + 1]).tolist()) == list(range(1, len(nodes)))
-        # every OBB contains the vertices of its triangles
-        for i in (0, 1, len(nodes) // 2):
-            nd = nodes[i]
-            axes = nd["obb_axes"].reshape(3, 3).T
+        # every node, leaves included: its OBB and its RSS contain the vertices of all its triangles (what culling on a
+        # node relies on; fitted boxes of children may poke out of the parent's, the primitives never do), and a parent's
+        # primitive range is the concatenation of its children's
+        for i, nd in enumerate(nodes):
             prims = m.primitive_indices[nd["first_primitive"]:nd["first_primitive"] + nd["num_primitives"]]
+            assert len(prims) == nd["num_primitives"] >= 1
             P = m.vertices[m.triangles[prims].reshape(-1)]
+            axes = nd["obb_axes"].reshape(3, 3).T
             loc = (P - nd["obb_To"]) @ axes
-            assert np.all(np.abs(loc) <= nd["obb_extent"] + 1e-9)
+            assert np.all(np.abs(loc) <= nd["obb_extent"] + 1e-9), i
+            raxes = nd["rss_axes"].reshape(3, 3).T  # columns = axes; Tr = the rectangle's origin corner (BV/RSS.h)
+            rl = (P - nd["rss_Tr"]) @ raxes
+            dx = rl[:, 0] - np.clip(rl[:, 0], 0.0, nd["rss_length"][0])
+            dy = rl[:, 1] - np.clip(rl[:, 1], 0.0, nd["rss_length"][1])
+            assert np.all(np.sqrt(dx * dx + dy * dy + rl[:, 2] ** 2) <= nd["rss_radius"] + 1e-9), i
+            fc = nd["first_child"]
+            if fc > 0:
+                l, r = nodes[fc], nodes[fc + 1]
+                assert l["first_primitive"] == nd["first_primitive"]
+                assert r["first_primitive"] == l["first_primitive"] + l["num_primitives"]
+                assert l["num_primitives"] + r["num_primitives"] == nd["num_primitives"]
+            else:
+                assert nd["num_primitives"] == 1 and -(fc + 1) == prims[0]
 
 
 def test_oracle_bvh_contact_set_equals_brute_force(pkg, oracle, small_meshes):
