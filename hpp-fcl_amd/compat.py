@@ -206,14 +206,30 @@ class StdVec_Triangle(list):
 
 
 class Convex(ShapeBase):
-    """Convex<Triangle>(points, triangles): the narrow phase reads the points only (linear support scan up to 32
-    vertices, lane-group scan above; the reference's neighbour hill-climb reaches the same support value)."""
+    """Convex<Triangle>(points, triangles).  Up to 32 vertices the narrow phase scans the points in registers, above it
+    scans them from memory; with facets given, hulls of HFCL_CLIMB_MIN (512) vertices and more climb the vertex adjacency
+    the facets define, as the reference does (fillNeighbors, shape/details/convex.hxx:231-280; getShapeSupportLog)."""
     _node_type = NODE_TYPE.GEOM_CONVEX
 
     def __init__(self, points, polygons=None):
         self.points = np.array([_v3(p) for p in points], dtype=np.float64)
         self.num_points = len(self.points)
         self.polygons = list(polygons) if polygons is not None else []
+
+    def neighbors(self):
+        """ConvexBase::neighbors as CSR (offsets[num_points + 1], ids), or None without facets."""
+        if not self.polygons:
+            return None
+        nb = [set() for _ in range(self.num_points)]
+        for poly in self.polygons:
+            idx = [int(poly[k]) for k in range(3)] if isinstance(poly, Triangle) else [int(k) for k in poly]
+            n = len(idx)
+            for j in range(n):
+                nb[idx[j]].add(idx[j - 1])
+                nb[idx[j]].add(idx[(j + 1) % n])
+        offs = np.zeros(self.num_points + 1, dtype=np.uint32)
+        offs[1:] = np.cumsum([len(x) for x in nb])
+        return offs, np.array([v for x in nb for v in sorted(x)], dtype=np.uint32)
 
     def _register(self, L):
         return L.add_convex(self.points, self._swept)
@@ -441,6 +457,11 @@ class _Context:
             self.lib = engine.Library(self.L, device=self.device)
             for m in self.meshes:
                 self.lib.add_bvh(m)
+            for g in self.keep:  # large hulls with facets: the adjacency the device climbs
+                if isinstance(g, Convex) and g.num_points > 32:
+                    nb = g.neighbors()
+                    if nb is not None:
+                        self.lib.set_convex_neighbors(self.ids[id(g)][0], *nb)
             self.built = len(self.L)
         return self.lib
 

@@ -500,6 +500,10 @@ int hfcl_lib_set_convex_neighbors(hfcl_lib* lib, uint32_t shape_id, const uint32
       set_error("hfcl_lib_set_convex_neighbors: offsets must not decrease");
       return HFCL_ERR_INVALID_ARGUMENT;
     }
+  if (offsets[n] == 0) {
+    set_error("hfcl_lib_set_convex_neighbors: empty adjacency");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
   for (uint32_t k = 0; k < offsets[n]; ++k)
     if (neighbors[k] >= n) {
       set_error("hfcl_lib_set_convex_neighbors: neighbour index outside the shape's vertices");

@@ -602,6 +602,15 @@ def test_large_hulls_gpu(pkg, oracle, kind, support, monkeypatch):
         monkeypatch.setenv("HFCL_CLIMB_MIN", "33")
         lib = pkg.Library(b.lib, device=0)
         try:
+            first = int(np.flatnonzero(b.shapes["num_points"] > 32)[0])
+            n0 = int(b.shapes["num_points"][first])
+            for offs, ids in ((np.zeros(n0 + 1, np.uint32), np.zeros(1, np.uint32)),                  # empty
+                              (np.arange(n0 + 1, dtype=np.uint32), np.full(n0, n0, np.uint32)),     # index out of range
+                              (np.arange(n0 + 1, dtype=np.uint32)[::-1].copy(), np.zeros(n0, np.uint32))):  # offsets decrease
+                with pytest.raises(pkg.EngineError):
+                    lib.set_convex_neighbors(first, offs, ids)
+            with pytest.raises(pkg.EngineError):  # not a convex shape / not a shape
+                lib.set_convex_neighbors(len(b.shapes), np.zeros(2, np.uint32), np.zeros(1, np.uint32))
             assert wl.register_adjacency(lib, b.shapes, b.verts) == b.n_large
             run = lib.distance if b.kind == "distance" else lib.collide
             got, buckets = run(b.s1, b.s2, b.tf1, b.tf2, req), lib.last_bucket_counts()

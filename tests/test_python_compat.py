@@ -58,6 +58,35 @@ def tetahedron(hppfcl):  # collision.py:8-20
     return hppfcl.Convex(pts, tri)
 
 
+def test_convex_neighbors_from_facets(hppfcl):  # fillNeighbors, shape/details/convex.hxx:231-280 (CPU only)
+    offs, ids = tetahedron(hppfcl).neighbors()
+    assert offs.tolist() == [0, 3, 6, 9, 12]
+    assert ids.reshape(4, 3).tolist() == [[1, 2, 3], [0, 2, 3], [0, 1, 3], [0, 1, 2]]
+    assert hppfcl.Convex([(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)]).neighbors() is None
+
+
+@pytest.mark.gpu
+def test_large_convex_with_facets_climbs_its_adjacency(hppfcl):
+    """A 700-vertex Convex given with its facets (Qhull) answers like the same points without facets (scanned)."""
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(5)
+    d = rng.normal(size=(700, 3))
+    pts = d / np.linalg.norm(d, axis=1, keepdims=True) * (0.8, 0.5, 0.3)
+    tris = hppfcl.StdVec_Triangle()
+    for a, b, c in ConvexHull(pts).simplices:
+        tris.append(hppfcl.Triangle(int(a), int(b), int(c)))
+    facetted, plain = hppfcl.Convex(pts, tris), hppfcl.Convex(pts)
+    offs, ids = facetted.neighbors()
+    assert len(ids) == 2 * (700 + len(tris) - 2)  # 2E, E = V + F - 2
+    box = hppfcl.Box(0.4, 0.3, 0.2)
+    for k in range(12):
+        tf = hppfcl.Transform3f(np.eye(3), np.array([0.1 + 0.1 * k, 0.05 * k, 0.2]))
+        r1, r2 = hppfcl.DistanceResult(), hppfcl.DistanceResult()
+        d1 = hppfcl.distance(facetted, hppfcl.Transform3f(), box, tf, hppfcl.DistanceRequest(), r1)
+        d2 = hppfcl.distance(plain, hppfcl.Transform3f(), box, tf, hppfcl.DistanceRequest(), r2)
+        assert abs(d1 - d2) < 1e-6 and np.allclose(r1.getNearestPoint1(), r2.getNearestPoint1(), atol=1e-4)
+
+
 @pytest.mark.gpu
 def test_api_collision_and_distance(hppfcl):  # api.py:9-27
     capsule = hppfcl.Capsule(1.0, 2.0)
