@@ -529,7 +529,7 @@ struct LaneGroup {
 #endif
 constexpr int EPA_FAST_CAP = HFCL_EPA_FAST_CAP;
 #ifndef HFCL_EPA_FAST_CAP64
-#define HFCL_EPA_FAST_CAP64 24  // cfg5 (fast + full ms): 12: 0.84+2.16, 16: 1.06+1.74, 20: 1.28+1.19, 24: 1.49+0.89; 28 would cost a wave per CU
+#define HFCL_EPA_FAST_CAP64 29  // the largest whose block (40 832 B) still puts four waves on a CU (32 of the 128 LDS units each); cfg5 fast + full ms: 24: 1.20+0.89, 26: 1.34+0.64, 28: 1.45+0.51, 29: 1.45+0.46
 #endif
 // capacity of the fast tier's block per precision
 template <typename T> constexpr int epa_fast_cap = sizeof(T) == 4 ? EPA_FAST_CAP : HFCL_EPA_FAST_CAP64;

@@ -77,7 +77,7 @@ __device__ __forceinline__ EpaSaved<T, CAP>* resume_slot(const Work& wk, uint32_
 }
 
 // TIER: 1 reads queue 1 and may push to queue 2; 2 reads queue 2 (never overflows: CAP = 64)
-template <typename T, int WE, int CAP, int TIER>
+template <typename T, int WE, int CAP, int TIER, bool BOTH = true>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? (TIER == 1 ? HFCL_WPE_EPA32 : 2) : HFCL_WPE_EPA64, 8)))
 k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   constexpr int G = 64 / WE;
@@ -86,13 +86,16 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   constexpr int V0M = TIER == 1 ? V0_BLOCK : V0_EXTERN;
   __shared__ EpaScratch<T, CAP, V0M> scratch[G];
   Quad<T>* const v0_ext = TIER == 1 ? nullptr : reinterpret_cast<Quad<T>*>(wk.epa_v0) + size_t(blockIdx.x * G + threadIdx.x / WE) * (CAP + 4);
-  const uint32_t cnt = wk.counts[TIER == 1 ? B_COUNT : B_COUNT + 1];
+  // tier 1 walks both queues of epa_queue one after the other: the polytope pairs (slots 0 upwards), then the pairs with a
+  // curved shape (slots n-1 downwards; finish_gjk) -- the G polytopes a wave steps in lockstep are of one class
+  const uint32_t cnt0 = wk.counts[TIER == 1 ? B_COUNT : B_COUNT + 1];
+  const uint32_t cnt = cnt0 + (TIER == 1 && BOTH ? wk.counts[B_COUNT + 3] : 0u);
   const int lane = threadIdx.x & 63, grp = lane / WE, lig = lane & (WE - 1);
   const uint32_t groups = gridDim.x * G;
   const EpaItem<T>* queue = reinterpret_cast<const EpaItem<T>*>(TIER == 1 ? wk.epa_queue : wk.epa_queue2);
   for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += groups) {
     // the seed stays in memory and is read where it is used (as a local copy it is spilled across the hull loads)
-    const EpaItem<T>& item = queue[it];
+    const EpaItem<T>& item = queue[it < cnt0 ? it : wk.n - 1u - (it - cnt0)];
     const uint32_t pair = item.pair;
     EpaSupport<T, WE, TIER == 2> sup;
     const uint32_t sid1 = wk.shape1[pair], sid2 = wk.shape2[pair];
@@ -170,8 +173,9 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
 #ifndef HFCL_WPE_EPA32_CC
 #define HFCL_WPE_EPA32_CC 3
 #endif
-template <typename T, int WE, int CAP, bool CC>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CC ? HFCL_WPE_EPA32_CC : HFCL_WPE_EPA32, 8)))
+// TOPQ: the queue at the top end of epa_queue (fp32: convex x convex, fp64: pairs with a curved shape)
+template <typename T, int WE, int CAP, bool CC, bool TOPQ = CC>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? HFCL_WPE_EPA64 : (CC ? HFCL_WPE_EPA32_CC : HFCL_WPE_EPA32), 8)))
 k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   constexpr int G = 64 / WE;
   constexpr int V0M = CC ? V0_TAG : V0_BLOCK;
@@ -181,11 +185,11 @@ k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   __shared__ uint32_t lds_pad[HFCL_EPA_PAD_LDS / 4];
   if (wk.n == 0xFFFFFFFFu) lds_pad[threadIdx.x] = wk.n;
 #endif
-  const uint32_t cnt = wk.counts[CC ? B_COUNT + 3 : B_COUNT];
+  const uint32_t cnt = wk.counts[TOPQ ? B_COUNT + 3 : B_COUNT];
   const int lane = threadIdx.x & 63, grp = lane / WE, lig = lane & (WE - 1);
   const EpaItem<T>* const queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
   // item i of this kernel's queue
-  auto item_ptr = [&](uint32_t i) { return CC ? queue + (wk.n - 1u - i) : queue + i; };
+  auto item_ptr = [&](uint32_t i) { return TOPQ ? queue + (wk.n - 1u - i) : queue + i; };
   enum { IDLE = 0, LIVE = 1, DONE = 2, HANDOVER = 3 };
   int state = IDLE;
   uint32_t it = 0;              // queue slot of this group's polytope
@@ -340,7 +344,13 @@ void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>&
     if (general_queue)
       hipLaunchKernelGGL((k_epa_stream<T, EPA_WE, EPA_FAST_CAP, false>), dim3(std::min(grid, n_cus * per_cu_gen * HFCL_EPA_GRID_ROUNDS)), dim3(64), 0, st, wk, lv, io, q);
   } else {
+#ifdef HFCL_EPA64_STREAM_CURVED  // A/B (profiles/r02_q): the curved-shape queue through the streaming kernel -- slower at one wave per SIMD
+    static const int per_cu = resident_blocks_per_cu(k_epa_stream<T, EPA_WE, epa_fast_cap<T>, false, true>);
+    hipLaunchKernelGGL((k_epa_stream<T, EPA_WE, epa_fast_cap<T>, false, true>), dim3(std::min(grid, n_cus * per_cu * HFCL_EPA_GRID_ROUNDS)), dim3(64), 0, st, wk, lv, io, q);
+    hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_fast_cap<T>, 1, false>), dim3(std::min(grid, n_cus * 16)), dim3(64), 0, st, wk, lv, io, q);
+#else
     hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_fast_cap<T>, 1>), dim3(std::min(grid, n_cus * 16)), dim3(64), 0, st, wk, lv, io, q);
+#endif
   }
 }
 template void launch_epa_fast<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&, bool, bool, int);

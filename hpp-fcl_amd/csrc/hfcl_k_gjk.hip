@@ -147,6 +147,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_W
 // ---------------------------------------------------------------------------------------
 // Shared GJK epilogue: final record, or hand-off to k_epa through the device queue.
 // ---------------------------------------------------------------------------------------
+// EPA on a pair with a curved shape (Ellipsoid, Cone, Cylinder: supports that are not vertices) approaches the surface
+// until its tolerance is met -- 20 to 30 iterations on average, against 4 to 8 where both shapes are polytopes or
+// sphere / capsule cores (measured on cfg5 with the oracle).  The fp64 fast tier steps the 8 polytopes of a wave in
+// lockstep, so the two classes get a queue each (the second one is the fp32 convex x convex queue, unused in fp64) and
+// a wave's polytopes are of one class: the short ones are not held to the length of the long ones.
+__device__ __forceinline__ bool curved_pair(int k1, int k2) {
+  return k1 == K_ELLIPSOID || k1 == K_CONE || k1 == K_CYLINDER || k2 == K_ELLIPSOID || k2 == K_CONE || k2 == K_CYLINDER;
+}
 template <typename T, class P, class PS>
 __device__ __forceinline__ void finish_gjk(const Gjk<T, P>& g, const Work& wk, const IO<T>& io, const QParams<T>& q,
                                            uint32_t pair, const Pose<T>& tf1, T r0, T r1, const V3<T>& guess0,
@@ -212,7 +220,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_W
       gjk_run(g, q.gjk, start_guess(q, a, b, sup.md, guess0), r0 + r1, false, sup, ps);
     else
       gjk_run(g, q.gjk, guess0, r0 + r1, false, sup, ps);
-    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, true, ps);
+    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, true, ps, false, sizeof(T) == 8 && curved_pair(a.kind, b.kind));
   }
 }
 // Hull of a W-lane group held in LDS instead of registers: element (vertex k, component c) of thread t at
@@ -321,7 +329,9 @@ __device__ __forceinline__ void gjk_cvx_body(const Work& wk, const LibView<T>& l
       gjk_run(g, q.gjk, start_guess(q, sup.a, sup.b, sup.md, guess0), r0 + r1, M == 0, sup, ps);
     else
       gjk_run(g, q.gjk, guess0, r0 + r1, M == 0, sup, ps);
-    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0, ps, false, sizeof(T) == 4 && M == 0);
+    // second EPA queue: fp32 -- the convex x convex pairs (their own kernel); fp64 -- the pairs with a curved shape
+    finish_gjk<T>(g, wk, io, q, pair, tf1, r0, r1, guess0, lig == 0, ps, false,
+                  sizeof(T) == 4 ? M == 0 : (M != 0 && curved_pair(sup.a.kind, sup.b.kind)));
   }
 }
 

@@ -30,20 +30,38 @@ def main():
              ("cfg5_mixed", {"security_margin": -0.03}, 14), ("cfg5_mixed", {"enable_contact": 0}, 15),
              ("all_primitives", {"kind": "distance"}, 16), ("cfg3_convex_convex", {"gjk_variant": abi.PolyakAcceleration}, 17),
              ("cfg3_convex_convex", {"gjk_variant": abi.DefaultGJK, "gjk_convergence_criterion": abi.Hybrid}, 18),
-             ("flat_pairs", {}, 19), ("triangle_pairs", {}, 20), ("large_convex", {}, 21)]
+             ("flat_pairs", {}, 19), ("triangle_pairs", {}, 20), ("large_convex", {}, 21),
+             ("large_convex", {"support": "climb"}, 22), ("cfg5_mixed", {"entry": "qt"}, 23)]
     total, t_all = 0, time.time()
     for name, over, seed in runs:
         kw = {"kind": over.pop("kind")} if "kind" in over else {}
+        climb = over.pop("support", None) == "climb"  # hulls climb their registered adjacency (oracle: getShapeSupportLog)
+        qt = over.pop("entry", None) == "qt"          # compact host poses (unit quaternion + translation)
+        label = dict(over, **kw, **({"support": "climb"} if climb else {}), **({"entry": "qt"} if qt else {}))
         nn = n if name not in ("flat_pairs", "triangle_pairs", "large_convex") else max(n // 5, 1000)
         b = getattr(wl, name)(n=nn, seed=seed, **kw)
         req = wl.make_request(b, abi, **over)
         t0 = time.time()
         fn_o = ob.distance_batch if b.kind == "distance" else ob.collide_batch
-        ref = fn_o(b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=threads)
+        if climb:
+            ob.register_hull_neighbors(b.shapes, b.verts)
+        try:
+            ref = fn_o(b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=threads)
+        finally:
+            if climb:
+                ob.lib().orc_clear_neighbors()
         t_cpu = time.time() - t0
+        if climb:
+            os.environ["HFCL_CLIMB_MIN"] = "33"
         lib = pkg.Library(b.lib, device=0)
+        os.environ.pop("HFCL_CLIMB_MIN", None)
+        if climb:
+            wl.register_adjacency(lib, b.shapes, b.verts)
         t0 = time.time()
-        got = (lib.distance if b.kind == "distance" else lib.collide)(b.s1, b.s2, b.tf1, b.tf2, req)
+        if qt:
+            got = (lib.distance_qt if b.kind == "distance" else lib.collide_qt)(b.s1, b.s2, b.pose1_qt, b.pose2_qt, req)
+        else:
+            got = (lib.distance if b.kind == "distance" else lib.collide)(b.s1, b.s2, b.tf1, b.tf2, req)
         t_gpu = time.time() - t0
         lib.close()
         smooth = name in ("all_primitives", "flat_pairs", "triangle_pairs", "large_convex")
@@ -53,7 +71,7 @@ def main():
         total += len(b)
         print("%-22s %-58s n=%8d contacts %.3f  flag/gjk/epa/dist/sep mismatches %d/%d/%d/%d/%d  max|dd| %.2e p99.9 %.1e  "
               "(oracle %d thr %.1fs, engine %.2fs incl. copies)" %
-              (name, str(over or kw or ""), len(b), st["contact_frac"], st["flag_mismatch"], st["gjk_status_mismatch"],
+              (name, str(label or ""), len(b), st["contact_frac"], st["flag_mismatch"], st["gjk_status_mismatch"],
                st["epa_status_mismatch"], st["dist_bad"], st["sep_bad"], st["max_dd"], st["p999_dd"], threads, t_cpu, t_gpu), flush=True)
     # ---- meshes (cfg4): collide (first contact in DFS order) and distance, 5 000-triangle models
     bb = pkg.bvh_builder
