@@ -46,7 +46,13 @@ using namespace hfcl;
 // side carries vertices so the kernel is specialised at compile time)
 // ---------------------------------------------------------------------------------------
 enum { B_CLOSED = 0, B_PRIM = 1, B_CC = 2, B_PC = 3, B_CP = 4, B_BVH = 5, B_UNSUPPORTED = 6, B_LARGE = 7, B_BVHSHAPE = 8, B_TRI = 9, B_COUNT = 10 };
-constexpr int N_COUNTERS = B_COUNT + 4;  // the bucket populations + the four counters of Work::counts
+// Pairs with a curved shape (Ellipsoid, Cone, Cylinder) take two to three times the GJK iterations of the others (their
+// supports are not vertices: cfg5 with the oracle, 10 against 4.5 on average, p99 23 against 8), and a GJK kernel steps
+// the 32 / 64 pairs of a wave in lockstep.  k_classify therefore files them from the top end of their bucket's list
+// (population in counts[B_CURVED0 + bucket]); a kernel walks the list's bottom part, then its top part (BucketList), and
+// the pairs of a wave are of one class but for one wave per bucket.
+constexpr int B_CURVED0 = B_COUNT + 4;
+constexpr int N_COUNTERS = 2 * B_COUNT + 4;  // bucket populations + the four counters of Work::counts + curved populations
 
 // Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
 // support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
@@ -151,13 +157,28 @@ struct Work {
   uint32_t* lists;   // B_COUNT lists of capacity n each
   uint32_t* counts;  // B_COUNT counters + [B_COUNT] = epa queue length + [B_COUNT+1] = overflow queue length
                      // + [B_COUNT+2] = ticket counter of the streaming BVH kernel + [B_COUNT+3] = length of the
-                     // fp32 convex x convex EPA queue (the top end of epa_queue, filled downwards from slot n-1)
+                     // second EPA queue (the top end of epa_queue, filled downwards from slot n-1: fp32 convex x convex,
+                     // fp64 pairs with a curved shape) + [B_CURVED0 + b] = curved pairs of bucket b (top end of its list)
   void* epa_queue;
   void* epa_queue2;  // polytopes that outgrew the fast EPA kernel's scratch block
   void* epa_v0;      // shape-0 support points of the polytopes in flight in the full-capacity EPA kernel
   void* epa_resume;  // saved polytopes (EpaSaved, epa_resume_stride<T> bytes apart) of the first `resume_cap` slots of epa_queue2
   uint32_t resume_cap;
 };
+// a pair with a shape whose support is not a vertex
+__host__ __device__ inline bool curved_pair(int k1, int k2) {
+  return k1 == K_ELLIPSOID || k1 == K_CONE || k1 == K_CYLINDER || k2 == K_ELLIPSOID || k2 == K_CONE || k2 == K_CYLINDER;
+}
+// bucket `b` of a batch in processing order: the bottom part of its list, then the curved pairs from the top end
+struct BucketList {
+  const uint32_t* base;
+  uint32_t n, c0, cnt;
+  __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return i < c0 ? base[i] : base[n - 1u - (i - c0)]; }
+};
+__device__ __forceinline__ BucketList bucket_list(const Work& wk, int b) {
+  const uint32_t c0 = wk.counts[b];
+  return BucketList{wk.lists + size_t(b) * wk.n, wk.n, c0, c0 + wk.counts[B_CURVED0 + b]};
+}
 constexpr int32_t EPA_RESUME_FLAG = 0x100;  // EpaSeed::rank bit: "continue the saved polytope of this slot"
 
 __device__ __forceinline__ Pose<double> load_pose(const double* base, uint32_t i) { return pose_from_abi<double>(base + 12 * size_t(i)); }

@@ -169,7 +169,8 @@ static void share_tables(hfcl_lib* h, const hfcl_lib* lib);
 // bucket population i of the last batch (both halves of a split batch)
 static uint32_t one_count(const uint32_t* c, int i) {
   // the EPA queue of a batch = the general queue + the fp32 convex x convex queue
-  return c[i] + (i == B_COUNT ? c[B_COUNT + 3] : 0u);
+  // a bucket = its bottom part + its curved part; the EPA queue of a batch = the general queue + the second queue
+  return c[i] + (i < B_COUNT ? c[B_CURVED0 + i] : 0u) + (i == B_COUNT ? c[B_COUNT + 3] : 0u);
 }
 static uint32_t total_count(const hfcl_lib* lib, int i) {
   if (lib->last_host) return one_count(lib->acc_counts, i);

@@ -13,10 +13,11 @@ __global__ void __launch_bounds__(CLS_BLOCK) k_classify(Work wk, const uint8_t* 
   // global atomic per (block, bucket) reserves a range, then every lane writes its pair index.
   constexpr int PER_THREAD = 8;
   constexpr uint32_t CHUNK = CLS_BLOCK * PER_THREAD;
-  __shared__ uint32_t s_count[B_COUNT];
-  __shared__ uint32_t s_base[B_COUNT];
+  // virtual buckets B_COUNT + b: the curved pairs of bucket b (GJK buckets only), filed from the top end of b's list
+  __shared__ uint32_t s_count[2 * B_COUNT];
+  __shared__ uint32_t s_base[2 * B_COUNT];
   for (uint32_t start = blockIdx.x * CHUNK; start < wk.n; start += gridDim.x * CHUNK) {
-    if (threadIdx.x < B_COUNT) s_count[threadIdx.x] = 0;
+    if (threadIdx.x < 2 * B_COUNT) s_count[threadIdx.x] = 0;
     __syncthreads();
     int bk[PER_THREAD];
     uint32_t rk[PER_THREAD];
@@ -27,7 +28,13 @@ __global__ void __launch_bounds__(CLS_BLOCK) k_classify(Work wk, const uint8_t* 
       rk[k] = 0;
       if (i < wk.n) {
         const uint32_t s1 = wk.shape1[i], s2 = wk.shape2[i];
-        bk[k] = (s1 < n_shapes && s2 < n_shapes) ? bucket_of(kinds[s1], kinds[s2], distance_mode) : B_UNSUPPORTED;
+        if (s1 < n_shapes && s2 < n_shapes) {
+          const int k1 = kinds[s1], k2 = kinds[s2];
+          bk[k] = bucket_of(k1, k2, distance_mode);
+          if ((bk[k] == B_PRIM || bk[k] == B_PC || bk[k] == B_CP) && curved_pair(k1, k2)) bk[k] += B_COUNT;
+        } else {
+          bk[k] = B_UNSUPPORTED;
+        }
       }
       // wave-aggregated LDS counter update: one trip per bucket present in the wave (one for a homogeneous batch)
       unsigned long long todo = __ballot(bk[k] >= 0);
@@ -44,14 +51,20 @@ __global__ void __launch_bounds__(CLS_BLOCK) k_classify(Work wk, const uint8_t* 
       }
     }
     __syncthreads();
-    if (threadIdx.x < B_COUNT) {
+    if (threadIdx.x < 2 * B_COUNT) {
       const uint32_t c = s_count[threadIdx.x];
-      s_base[threadIdx.x] = c ? atomicAdd(&wk.counts[threadIdx.x], c) : 0u;
+      const int counter = threadIdx.x < B_COUNT ? int(threadIdx.x) : B_CURVED0 + int(threadIdx.x) - B_COUNT;
+      s_base[threadIdx.x] = c ? atomicAdd(&wk.counts[counter], c) : 0u;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER_THREAD; ++k) {
-      if (bk[k] >= 0) wk.lists[size_t(bk[k]) * wk.n + s_base[bk[k]] + rk[k]] = start + k * CLS_BLOCK + threadIdx.x;
+      if (bk[k] < 0) continue;
+      const uint32_t slot = s_base[bk[k]] + rk[k], id = start + k * CLS_BLOCK + threadIdx.x;
+      if (bk[k] < B_COUNT)
+        wk.lists[size_t(bk[k]) * wk.n + slot] = id;
+      else
+        wk.lists[size_t(bk[k] - B_COUNT) * wk.n + (wk.n - 1u - slot)] = id;
     }
     __syncthreads();
   }
@@ -152,9 +165,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_W
 // sphere / capsule cores (measured on cfg5 with the oracle).  The fp64 fast tier steps the 8 polytopes of a wave in
 // lockstep, so the two classes get a queue each (the second one is the fp32 convex x convex queue, unused in fp64) and
 // a wave's polytopes are of one class: the short ones are not held to the length of the long ones.
-__device__ __forceinline__ bool curved_pair(int k1, int k2) {
-  return k1 == K_ELLIPSOID || k1 == K_CONE || k1 == K_CYLINDER || k2 == K_ELLIPSOID || k2 == K_CONE || k2 == K_CYLINDER;
-}
 template <typename T, class P, class PS>
 __device__ __forceinline__ void finish_gjk(const Gjk<T, P>& g, const Work& wk, const IO<T>& io, const QParams<T>& q,
                                            uint32_t pair, const Pose<T>& tf1, T r0, T r1, const V3<T>& guess0,
@@ -203,9 +213,9 @@ template <typename T, int NT> using GjkW0 = W0Regs<T>;
 template <typename T, bool BVG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_PRIM, 8))) k_gjk_prim(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   HFCL_GJK_W0_SLAB(T, 256, ps);
-  const uint32_t cnt = wk.counts[B_PRIM];
-  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
-    const uint32_t pair = wk.lists[size_t(B_PRIM) * wk.n + it];
+  const BucketList list = bucket_list(wk, B_PRIM);
+  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < list.cnt; it += gridDim.x * blockDim.x) {
+    const uint32_t pair = list[it];
     const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
     const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
     SerialSupport<T> sup;
@@ -307,11 +317,11 @@ __device__ __forceinline__ void gjk_cvx_body(const Work& wk, const LibView<T>& l
   constexpr int BUCKET = (M == 0) ? B_CC : (M == 1 ? B_PC : B_CP);
   HFCL_GJK_W0_SLAB(T, 256, ps);
   __shared__ T hull_slab[hull_b_in_lds<T, W, M> ? HullLds<T, W, 256>::WORDS : 1];
-  const uint32_t cnt = wk.counts[BUCKET];
+  const BucketList list = bucket_list(wk, BUCKET);
   const int lig = threadIdx.x & (W - 1);
   const uint32_t groups = (gridDim.x * blockDim.x) / W;
-  for (uint32_t it = (blockIdx.x * blockDim.x + threadIdx.x) / W; it < cnt; it += groups) {
-    const uint32_t pair = wk.lists[size_t(BUCKET) * wk.n + it];
+  for (uint32_t it = (blockIdx.x * blockDim.x + threadIdx.x) / W; it < list.cnt; it += groups) {
+    const uint32_t pair = list[it];
     CvxSupport<T, W, M> sup;
     if constexpr (hull_b_in_lds<T, W, M>) sup.h1.lane = hull_slab + threadIdx.x;
     sup.a = lib.shapes[wk.shape1[pair]];
