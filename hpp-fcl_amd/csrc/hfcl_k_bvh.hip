@@ -47,6 +47,9 @@ template <> struct BvhEntry<true> {
   static __device__ __forceinline__ uint32_t second(E e) { return uint32_t(e >> 32); }
 };
 
+#ifndef HFCL_BVH_PREFETCH
+#define HFCL_BVH_PREFETCH 1  // cfg4 100k: 7.5 -> 6.7 ms, 1M: 61.6 -> 67.6 M q/s (profiles/r02_r); 2 (also the sibling): no further gain
+#endif
 #ifndef HFCL_WPE_BVH_COLLIDE
 #define HFCL_WPE_BVH_COLLIDE 2  // two waves per SIMD: the walk waits for its node gathers most of the time (profiles/r02_m)
 #endif
@@ -261,9 +264,27 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
           lb1 = uint32_t(-(n1.first_child + 1));
           lb2 = uint32_t(-(n2.first_child + 1));
         } else {
+          const T sz1 = sqnorm(n1.extent), sz2 = sqnorm(n2.extent);
+          const bool first = l2 || (!l1 && (sz1 > sz2));  // firstOverSecond
+#if HFCL_BVH_PREFETCH
+          // The pair this lane pops next, if the boxes overlap, is (first child of the node that gets split, other node):
+          // touch that child's record (one 128-byte line in fp64) before the separating-axis test, so that the gather of
+          // the next step finds it on its way up the cache hierarchy instead of starting after the test.
+          const DNode<T>* const next = bv.nodes + (first ? m1.node_off + uint32_t(n1.first_child) : m2.node_off + uint32_t(n2.first_child));
+          const int32_t touched = next[0].first_child;
+#if HFCL_BVH_PREFETCH >= 2  // ... and its sibling, popped right after it when the first child's test says "disjoint"
+          const int32_t touched2 = next[1].first_child;
+#endif
+#endif
           T sq;
           // argument order of the reference: overlap(RT.R, RT.T, model2.bv(b2), model1.bv(b1))
           const bool disjoint = obb_disjoint(RT_R, RT_T, n2, n1, q.security_margin, break_distance2, sq);
+#if HFCL_BVH_PREFETCH
+          asm volatile("" ::"v"(touched));
+#if HFCL_BVH_PREFETCH >= 2
+          asm volatile("" ::"v"(touched2));
+#endif
+#endif
           if (disjoint) {  // updateDistanceLowerBoundFromBV
             if (!(dlb <= T(0))) {
               const T nd = hsqrt(sq);
@@ -273,8 +294,6 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
               }
             }
           } else {
-            const T sz1 = sqnorm(n1.extent), sz2 = sqnorm(n2.extent);
-            const bool first = l2 || (!l1 && (sz1 > sz2));  // firstOverSecond
             E ea, eb;
             if (first) {
               const uint32_t c1 = uint32_t(n1.first_child);
