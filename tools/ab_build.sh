@@ -15,8 +15,11 @@ objs=""
 pids=""
 for u in host k_gjk k_epa k_bvh; do
   short=${u#k_}
+  unit_flags=""  # the per-unit flags of the Makefile (FLAGS_k_gjk / FLAGS_k_epa)
+  if [[ $short == gjk || $short == epa ]]; then unit_flags="-fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt"; fi
+  if [[ $short == epa ]]; then unit_flags="$unit_flags -ffp-contract=on"; fi
   if [[ " $units " == *" $short "* ]]; then
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -Wno-pass-failed $flags -c -o "$out/hfcl_$u.o" "$src/hfcl_$u.hip" &
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -Wno-pass-failed $unit_flags $flags -c -o "$out/hfcl_$u.o" "$src/hfcl_$u.hip" &
     pids="$pids $!"
     objs="$objs $out/hfcl_$u.o"
   else

@@ -14,7 +14,9 @@ procs = []
 for u in units:  # the translation units compile side by side
     src = os.path.join(ROOT, "hpp-fcl_amd", "csrc", "hfcl_k_%s.hip" % u)
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-value", "-Wno-pass-failed",
-           "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", src] + flags
+           "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", src] + \
+        (["-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt"] if u in ("gjk", "epa") else []) + \
+        (["-ffp-contract=on"] if u == "epa" else []) + flags  # (the Makefile's per-unit flags)
     procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
 err = "".join(p.communicate()[1] for p in procs)
 rows, cur = [], {}
