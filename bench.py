@@ -92,7 +92,7 @@ def kernel_source_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "hpp-fcl_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
+        if f.endswith((".hip", ".hpp")) or f == "Makefile":  # (the per-unit compiler flags are part of the code)
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

@@ -1,0 +1,22 @@
+#!/bin/bash
+# On the GPU box: the measurement pass behind the numbers of DESIGN.md / README.md / bench.py's roofline.traffic.
+#   gpurun -- tools/measure_all.sh <tag>      (results under gpurun_out/<tag>/; copy what is cited into profiles/)
+# 1. PMC passes (HBM traffic, VALU / LDS instruction counts) per workload -> traffic_<workload>.json
+# 2. rocprofv3 --kernel-trace --stats of the cfg3 bench command -> *_kernel_trace_stats.txt
+# 3. the default bench.py line (headline + secondaries + CPU baselines)
+tag=${1:-final}
+out=gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+for wl in cfg3 cfg2 cfg5 cfg4 cfg1; do
+  timeout 900 python tools/measure_traffic.py --workload $wl --out $out/traffic_$wl.json > $out/traffic_$wl.log 2>&1 || echo "traffic $wl FAILED"
+done
+for wl in cfg3 cfg5; do
+  rm -rf $out/prof_$wl
+  timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof_$wl -o $wl -- python bench.py --workload $wl --no-cpu-baseline --no-secondary > $out/prof_$wl.log 2>&1
+  db=$(find $out/prof_$wl -name "*.db" | head -1)
+  [ -n "$db" ] && python tools/rocprof_summary.py $db > $out/${wl}_kernel_trace_stats.txt
+  rm -rf $out/prof_$wl
+done
+timeout 1500 python bench.py > $out/bench_default.json 2> $out/bench_default.err
+tail -1 $out/bench_default.json | cut -c1-400
