@@ -118,9 +118,11 @@ def load_traffic(workload, dominant, n, want="traffic"):
             os.path.relpath(path, ROOT), t.get("source_sha"), kernel_source_sha())
     m = re.match(r"(k_\w+)(?:<(\w+)>)?", dominant)
     base, tag = m.group(1), m.group(2)
-    sel = {"fast": ", 1>(", "full": ", 2>(", "cc": ", 0, ", "pc": ", 1, ", "cp": ", 2, "}.get(tag, "")
+    # template arguments that tell the instantiations of one kernel apart: k_epa<T, WE, CAP, TIER, ...>, k_gjk_cvx<W, M, BVG>
+    sel = {"fast": r"k_epa<\w+, \d+, \d+, 1[,>]", "full": r"k_epa<\w+, \d+, \d+, 2[,>]", "cc": r"k_gjk_cvx(?:64)?<\d+, 0, ",
+           "pc": r"k_gjk_cvx(?:64)?<\d+, 1, ", "cp": r"k_gjk_cvx(?:64)?<\d+, 2, "}.get(tag, "")
     for name, v in t["kernels"].items():
-        hit = base + "<" in name and sel in name
+        hit = any(base + suffix in name for suffix in ("<", "64<", "(")) and re.search(sel, name) is not None
         if tag == "fast" and "k_epa_stream<" in name:  # the fp32 fast tier is the streaming form of the same kernel
             hit = True
         if base == "k_closed" and "k_closed_staged(" in name:  # the fp64 closed-form kernel (LDS-staged I/O)
