@@ -179,7 +179,8 @@ __device__ __forceinline__ BucketList bucket_list(const Work& wk, int b) {
   const uint32_t c0 = wk.counts[b];
   return BucketList{wk.lists + size_t(b) * wk.n, wk.n, c0, c0 + wk.counts[B_CURVED0 + b]};
 }
-constexpr int32_t EPA_RESUME_FLAG = 0x100;  // EpaSeed::rank bit: "continue the saved polytope of this slot"
+constexpr int32_t EPA_RESUME_FLAG = 0x100;   // EpaSeed::rank bit: "continue the saved polytope of this slot"
+constexpr int32_t EPA_RESUME_SMALL = 0x200;  // ... "saved by the fast tier of the polytope class" (EpaSaved<T, epa_small_cap<T>>)
 
 __device__ __forceinline__ Pose<double> load_pose(const double* base, uint32_t i) { return pose_from_abi<double>(base + 12 * size_t(i)); }
 __device__ __forceinline__ void put_record(hfcl_result* dst, const hfcl_result& r) { *dst = r; }
@@ -552,8 +553,14 @@ constexpr int EPA_FAST_CAP = HFCL_EPA_FAST_CAP;
 #ifndef HFCL_EPA_FAST_CAP64
 #define HFCL_EPA_FAST_CAP64 29  // the largest whose block (40 832 B) still puts four waves on a CU (32 of the 128 LDS units each); cfg5 fast + full ms: 24: 1.20+0.89, 26: 1.34+0.64, 28: 1.45+0.51, 29: 1.45+0.46
 #endif
-// capacity of the fast tier's block per precision
+// fp64: the pairs without a curved shape (their own queue, finish_gjk) end after 2-8 iterations on average; a block for 13
+// is 20 208 B per wave of 8 = 16 LDS units, which puts two waves on a SIMD where the curved class's block allows one
+#ifndef HFCL_EPA_SMALL_CAP64
+#define HFCL_EPA_SMALL_CAP64 13
+#endif
+// capacity of the fast tier's block per precision (fp64: of the curved class), and of the fp64 polytope class
 template <typename T> constexpr int epa_fast_cap = sizeof(T) == 4 ? EPA_FAST_CAP : HFCL_EPA_FAST_CAP64;
+template <typename T> constexpr int epa_small_cap = sizeof(T) == 4 ? EPA_FAST_CAP : HFCL_EPA_SMALL_CAP64;
 // one slot of the hand-over area
 template <typename T> constexpr size_t epa_resume_stride = sizeof(EpaSaved<T, epa_fast_cap<T>>);
 #ifndef HFCL_EPA_WE

@@ -77,8 +77,15 @@ __device__ __forceinline__ EpaSaved<T, CAP>* resume_slot(const Work& wk, uint32_
 }
 
 // TIER: 1 reads queue 1 and may push to queue 2; 2 reads queue 2 (never overflows: CAP = 64)
-template <typename T, int WE, int CAP, int TIER, bool BOTH = true>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? (TIER == 1 ? HFCL_WPE_EPA32 : 2) : HFCL_WPE_EPA64, 8)))
+// QSEL (tier 1): 0 = both queues of epa_queue one after the other, 1 = the bottom queue only, 2 = the top queue only
+// (fp64: polytope pairs / pairs with a curved shape, finish_gjk).
+// Waves per SIMD the compiler allocates registers for: fp64 tier 1 gets two when its LDS block admits two (16 of the 128
+// units per wave), one otherwise (more registers, no spills, where the LDS would not admit a second wave anyway).
+template <typename T, int WE, int CAP, int TIER>
+constexpr int epa_waves_per_simd = sizeof(T) == 4 ? (TIER == 1 ? HFCL_WPE_EPA32 : 2)
+                                                  : (TIER == 1 && sizeof(EpaScratch<T, CAP, V0_BLOCK>) * (64 / WE) <= 16 * 1280 ? 2 : HFCL_WPE_EPA64);
+template <typename T, int WE, int CAP, int TIER, int QSEL = 0>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(epa_waves_per_simd<T, WE, CAP, TIER>, 8)))
 k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   constexpr int G = 64 / WE;
   // the full-capacity tier keeps the shape-0 support points in global memory: its LDS block bounds the
@@ -88,8 +95,8 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   Quad<T>* const v0_ext = TIER == 1 ? nullptr : reinterpret_cast<Quad<T>*>(wk.epa_v0) + size_t(blockIdx.x * G + threadIdx.x / WE) * (CAP + 4);
   // tier 1 walks both queues of epa_queue one after the other: the polytope pairs (slots 0 upwards), then the pairs with a
   // curved shape (slots n-1 downwards; finish_gjk) -- the G polytopes a wave steps in lockstep are of one class
-  const uint32_t cnt0 = wk.counts[TIER == 1 ? B_COUNT : B_COUNT + 1];
-  const uint32_t cnt = cnt0 + (TIER == 1 && BOTH ? wk.counts[B_COUNT + 3] : 0u);
+  const uint32_t cnt0 = (TIER == 1 && QSEL == 2) ? 0u : wk.counts[TIER == 1 ? B_COUNT : B_COUNT + 1];
+  const uint32_t cnt = cnt0 + (TIER == 1 && QSEL != 1 ? wk.counts[B_COUNT + 3] : 0u);
   const int lane = threadIdx.x & 63, grp = lane / WE, lig = lane & (WE - 1);
   const uint32_t groups = gridDim.x * G;
   const EpaItem<T>* queue = reinterpret_cast<const EpaItem<T>*>(TIER == 1 ? wk.epa_queue : wk.epa_queue2);
@@ -120,8 +127,12 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
     int rc = 1;
     if constexpr (TIER == 2) {
       if (item.rank & EPA_RESUME_FLAG) {  // continue what the fast tier saved for this slot (the seed's rank is not used)
-        epa_resume<T, LaneGroup<WE>, epa_fast_cap<T>, CAP>(&scratch[grp], resume_slot<T, epa_fast_cap<T>>(wk, it), item, q, tf1, r0, r1,
-                                                         sup, o, v0_ext);
+        if (epa_small_cap<T> != epa_fast_cap<T> && (item.rank & EPA_RESUME_SMALL))
+          epa_resume<T, LaneGroup<WE>, epa_small_cap<T>, CAP>(&scratch[grp], resume_slot<T, epa_small_cap<T>>(wk, it), item, q, tf1, r0, r1,
+                                                            sup, o, v0_ext);
+        else
+          epa_resume<T, LaneGroup<WE>, epa_fast_cap<T>, CAP>(&scratch[grp], resume_slot<T, epa_fast_cap<T>>(wk, it), item, q, tf1, r0, r1,
+                                                           sup, o, v0_ext);
       } else {
         rc = epa_run<T, LaneGroup<WE>, CAP>(&scratch[grp], item, q, tf1, r0, r1, sup, o, v0_ext);
       }
@@ -145,7 +156,7 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
         if (lig == 0) {  // queue to queue, no local copy (a local EpaItem lives in scratch memory)
           EpaItem<T>* dst = reinterpret_cast<EpaItem<T>*>(wk.epa_queue2) + slot;
           *dst = item;
-          if (save) dst->rank = item.rank | EPA_RESUME_FLAG;
+          if (save) dst->rank = item.rank | EPA_RESUME_FLAG | (CAP != epa_fast_cap<T> ? EPA_RESUME_SMALL : 0);
         }
       }
     }
@@ -320,6 +331,10 @@ k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
 // CU with 11 or 12 resident -- runs its last round nearly empty).  The runtime's occupancy query over-estimates what
 // the LDS admits: the hardware hands LDS out in 1280-byte units (160 KB / 128; tools/occupancy_probe.hip,
 // profiles/r02_g: 13184 B -> 11 workgroups per CU where the API says 12), so that bound is applied here.
+#ifndef HFCL_EPA64_CURVED_WE
+#define HFCL_EPA64_CURVED_WE 16  // lanes per polytope of the fp64 curved-class fast tier: 4 polytopes x 5104 B = 16 LDS units per
+                                 // wave = two waves per SIMD (8 lanes: 8 polytopes, 40 KB, one wave); cfg5 k_epa<fast> 1.37 -> 1.07 ms
+#endif
 #ifndef HFCL_EPA_GRID_ROUNDS
 #define HFCL_EPA_GRID_ROUNDS 2
 #endif
@@ -347,9 +362,13 @@ void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>&
 #ifdef HFCL_EPA64_STREAM_CURVED  // A/B (profiles/r02_q): the curved-shape queue through the streaming kernel -- slower at one wave per SIMD
     static const int per_cu = resident_blocks_per_cu(k_epa_stream<T, EPA_WE, epa_fast_cap<T>, false, true>);
     hipLaunchKernelGGL((k_epa_stream<T, EPA_WE, epa_fast_cap<T>, false, true>), dim3(std::min(grid, n_cus * per_cu * HFCL_EPA_GRID_ROUNDS)), dim3(64), 0, st, wk, lv, io, q);
-    hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_fast_cap<T>, 1, false>), dim3(std::min(grid, n_cus * 16)), dim3(64), 0, st, wk, lv, io, q);
+    hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_fast_cap<T>, 1, 1>), dim3(std::min(grid, n_cus * 16)), dim3(64), 0, st, wk, lv, io, q);
 #else
-    hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_fast_cap<T>, 1>), dim3(std::min(grid, n_cus * 16)), dim3(64), 0, st, wk, lv, io, q);
+    // one kernel per class, both sized for two waves per SIMD (20 KB of LDS per wave): the curved pairs with 16 lanes per
+    // polytope and the large block (CAP 29, 4 polytopes per wave), the polytope pairs with 8 lanes and a block for 13
+    // iterations (8 per wave) -- profiles/r02_u
+    hipLaunchKernelGGL((k_epa<T, HFCL_EPA64_CURVED_WE, epa_fast_cap<T>, 1, 2>), dim3(std::min(grid * (HFCL_EPA64_CURVED_WE / EPA_WE), n_cus * 16)), dim3(64), 0, st, wk, lv, io, q);
+    hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_small_cap<T>, 1, 1>), dim3(std::min(grid, n_cus * 32)), dim3(64), 0, st, wk, lv, io, q);
 #endif
   }
 }
