@@ -570,7 +570,11 @@ constexpr int EPA_WE = HFCL_EPA_WE;
 #ifndef HFCL_EPA_WE2
 #define HFCL_EPA_WE2 16
 #endif
-constexpr int EPA_WE2 = HFCL_EPA_WE2;  // lanes per polytope in the full-capacity tier
+constexpr int EPA_WE2 = HFCL_EPA_WE2;  // lanes per polytope in the full-capacity tier (fp32)
+#ifndef HFCL_EPA_WE2_64
+#define HFCL_EPA_WE2_64 32  // fp64: 2 polytopes x 8.6 KB per wave = two waves per SIMD (16 lanes: 4 polytopes, 34 KB, one wave); cfg5 k_epa<full> 0.445 -> 0.35 ms
+#endif
+template <typename T> constexpr int epa_we2 = sizeof(T) == 4 ? HFCL_EPA_WE2 : HFCL_EPA_WE2_64;
 
 // ---------------------------------------------------------------------------------------
 // k_bvh_collide: BVHModel<OBBRSS> x BVHModel<OBBRSS> collide().

@@ -1048,7 +1048,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
                        may(B_PRIM) || may(B_PC) || may(B_CP), lib->n_cus);
     tend();
     tbeg("k_epa<full>");
-    launch_epa_full<T>(blocks_for(n / 16 + 1, 64 / EPA_WE2), st, wk, lv, io, q);
+    launch_epa_full<T>(blocks_for(n / 16 + 1, 64 / epa_we2<T>), st, wk, lv, io, q);
     tend();
   }
   HIP_TRY(hipMemcpyAsync(lib->counts_dst ? lib->counts_dst : lib->h_counts, lib->d_counts, N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

@@ -83,7 +83,7 @@ __device__ __forceinline__ EpaSaved<T, CAP>* resume_slot(const Work& wk, uint32_
 // units per wave), one otherwise (more registers, no spills, where the LDS would not admit a second wave anyway).
 template <typename T, int WE, int CAP, int TIER>
 constexpr int epa_waves_per_simd = sizeof(T) == 4 ? (TIER == 1 ? HFCL_WPE_EPA32 : 2)
-                                                  : (TIER == 1 && sizeof(EpaScratch<T, CAP, V0_BLOCK>) * (64 / WE) <= 16 * 1280 ? 2 : HFCL_WPE_EPA64);
+                                                  : (sizeof(EpaScratch<T, CAP, TIER == 1 ? V0_BLOCK : V0_EXTERN>) * (64 / WE) <= 16 * 1280 ? 2 : HFCL_WPE_EPA64);
 template <typename T, int WE, int CAP, int TIER, int QSEL = 0>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(epa_waves_per_simd<T, WE, CAP, TIER>, 8)))
 k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
@@ -186,7 +186,7 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
 #endif
 // TOPQ: the queue at the top end of epa_queue (fp32: convex x convex, fp64: pairs with a curved shape)
 template <typename T, int WE, int CAP, bool CC, bool TOPQ = CC>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? HFCL_WPE_EPA64 : (CC ? HFCL_WPE_EPA32_CC : HFCL_WPE_EPA32), 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? epa_waves_per_simd<T, WE, CAP, 1> : (CC ? HFCL_WPE_EPA32_CC : HFCL_WPE_EPA32), 8)))
 k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   constexpr int G = 64 / WE;
   constexpr int V0M = CC ? V0_TAG : V0_BLOCK;
@@ -359,10 +359,10 @@ void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>&
     if (general_queue)
       hipLaunchKernelGGL((k_epa_stream<T, EPA_WE, EPA_FAST_CAP, false>), dim3(std::min(grid, n_cus * per_cu_gen * HFCL_EPA_GRID_ROUNDS)), dim3(64), 0, st, wk, lv, io, q);
   } else {
-#ifdef HFCL_EPA64_STREAM_CURVED  // A/B (profiles/r02_q): the curved-shape queue through the streaming kernel -- slower at one wave per SIMD
-    static const int per_cu = resident_blocks_per_cu(k_epa_stream<T, EPA_WE, epa_fast_cap<T>, false, true>);
-    hipLaunchKernelGGL((k_epa_stream<T, EPA_WE, epa_fast_cap<T>, false, true>), dim3(std::min(grid, n_cus * per_cu * HFCL_EPA_GRID_ROUNDS)), dim3(64), 0, st, wk, lv, io, q);
-    hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_fast_cap<T>, 1, 1>), dim3(std::min(grid, n_cus * 16)), dim3(64), 0, st, wk, lv, io, q);
+#ifdef HFCL_EPA64_STREAM_CURVED  // A/B (profiles/r02_q, r02_u): the curved-shape queue through the streaming kernel
+    static const int per_cu = resident_blocks_per_cu(k_epa_stream<T, HFCL_EPA64_CURVED_WE, epa_fast_cap<T>, false, true>);
+    hipLaunchKernelGGL((k_epa_stream<T, HFCL_EPA64_CURVED_WE, epa_fast_cap<T>, false, true>), dim3(std::min(grid * (HFCL_EPA64_CURVED_WE / EPA_WE), n_cus * per_cu * HFCL_EPA_GRID_ROUNDS)), dim3(64), 0, st, wk, lv, io, q);
+    hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_small_cap<T>, 1, 1>), dim3(std::min(grid, n_cus * 32)), dim3(64), 0, st, wk, lv, io, q);
 #else
     // one kernel per class, both sized for two waves per SIMD (20 KB of LDS per wave): the curved pairs with 16 lanes per
     // polytope and the large block (CAP 29, 4 polytopes per wave), the polytope pairs with 8 lanes and a block for 13
@@ -377,7 +377,7 @@ template void launch_epa_fast<double>(int, hipStream_t, const Work&, const LibVi
 
 template <typename T>
 void launch_epa_full(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {
-  hipLaunchKernelGGL((k_epa<T, EPA_WE2, EPA_MAX_ITER, 2>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
+  hipLaunchKernelGGL((k_epa<T, epa_we2<T>, EPA_MAX_ITER, 2>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
 }
 template void launch_epa_full<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&);
 template void launch_epa_full<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&);
