@@ -121,19 +121,35 @@ def load_traffic(workload, dominant, n, want="traffic"):
     # template arguments that tell the instantiations of one kernel apart: k_epa<T, WE, CAP, TIER, ...>, k_gjk_cvx<W, M, BVG>
     sel = {"fast": r"k_epa<\w+, \d+, \d+, 1[,>]", "full": r"k_epa<\w+, \d+, \d+, 2[,>]", "cc": r"k_gjk_cvx(?:64)?<\d+, 0, ",
            "pc": r"k_gjk_cvx(?:64)?<\d+, 1, ", "cp": r"k_gjk_cvx(?:64)?<\d+, 2, "}.get(tag, "")
+    # a timer label can stand for several instantiations launched back to back (the fp64 fast EPA tier is one kernel per
+    # class of pairs): their counters add up
+    tot_f = tot_w = tot_v = 0.0
+    sq = {}
+    found = False
     for name, v in t["kernels"].items():
         hit = any(base + suffix in name for suffix in ("<", "64<", "(")) and re.search(sel, name) is not None
         if tag == "fast" and "k_epa_stream<" in name:  # the fp32 fast tier is the streaming form of the same kernel
             hit = True
         if base == "k_closed" and "k_closed_staged(" in name:  # the fp64 closed-form kernel (LDS-staged I/O)
             hit = True
-        if hit and want == "valu":
-            if "SQ_INSTS_VALU_per_dispatch" in v:
-                return v["SQ_INSTS_VALU_per_dispatch"], {k: v[k] for k in v if k.startswith("SQ_")}
+        if not hit:
             continue
-        if hit and "FETCH_SIZE_KB_per_dispatch" in v and "WRITE_SIZE_KB_per_dispatch" in v:
-            f, w = v["FETCH_SIZE_KB_per_dispatch"] * 1024, v["WRITE_SIZE_KB_per_dispatch"] * 1024
-            return 2 * f + w, "PMC per launch: FETCH_SIZE raw %.3g B (x2 gfx950 correction applied), WRITE_SIZE %.3g B; %s" % (f, w, os.path.relpath(path, ROOT))
+        if want == "valu":
+            if "SQ_INSTS_VALU_per_dispatch" in v:
+                found = True
+                tot_v += v["SQ_INSTS_VALU_per_dispatch"]
+                for k in v:
+                    if k.startswith("SQ_"):
+                        sq[k] = sq.get(k, 0.0) + v[k]
+        elif "FETCH_SIZE_KB_per_dispatch" in v and "WRITE_SIZE_KB_per_dispatch" in v:
+            found = True
+            tot_f += v["FETCH_SIZE_KB_per_dispatch"] * 1024
+            tot_w += v["WRITE_SIZE_KB_per_dispatch"] * 1024
+    if found and want == "valu":
+        return tot_v, sq
+    if found:
+        return 2 * tot_f + tot_w, "PMC per launch: FETCH_SIZE raw %.3g B (x2 gfx950 correction applied), WRITE_SIZE %.3g B; %s" % (
+            tot_f, tot_w, os.path.relpath(path, ROOT))
     return None, "kernel not found in " + os.path.relpath(path, ROOT)
 
 
