@@ -629,6 +629,7 @@ struct BvhSplit {
   uint32_t* ctr;        // BVH_CTR_*
   uint32_t cap, n_queries;
   uint32_t budget;      // BV-test steps before a unit suspends (0: never)
+  uint32_t budget0;     // ... of the queries themselves (level 0); `budget` is that of the tasks
   uint32_t level, n_levels;
   uint32_t can_suspend;
   uint32_t steal;       // 1: k_bvh_collide_ws (work stealing inside the wavefront; `sums` is its segment pool)
@@ -640,6 +641,9 @@ struct BvhSplit {
 // contact query's spine are speculative work the sequential walk never does.
 #ifndef HFCL_BVH_BUDGET
 #define HFCL_BVH_BUDGET 0
+#endif
+#ifndef HFCL_BVH_BUDGET0
+#define HFCL_BVH_BUDGET0 HFCL_BVH_BUDGET
 #endif
 // Global-memory continuation of the per-lane traversal stacks (models with more than 65535 BV nodes): `cap` entries per
 // lane of the launch, sized by the host from the depths of the registered models; the grid is limited to `max_blocks` so

@@ -153,6 +153,7 @@ struct hfcl_lib {
   uint32_t* d_bvh_susp = nullptr;
   uint32_t* d_bvh_ctr = nullptr;
   size_t bvh_split_n = 0, bvh_split_cap = 0;
+  uint32_t bvh_budget0 = HFCL_BVH_BUDGET0;  // HFCL_BVH_BUDGET0: step budget of the queries (level 0); bvh_budget: of the tasks
   uint32_t bvh_budget = HFCL_BVH_BUDGET, bvh_levels = HFCL_BVH_LEVELS;  // HFCL_BVH_BUDGET / HFCL_BVH_LEVELS (1: unsplit)
   bool bvh_steal = false;  // HFCL_BVH_STEAL=1: k_bvh_collide_ws (work stealing inside the wavefront, pre-tested stack entries) instead
                            // of the single pass; measured slower (profiles/r02_m_bvh_work_stealing.txt), kept for the record and tested
@@ -386,7 +387,8 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_PIPE_CHUNK")) lib->pipe_chunk = strtoull(v, nullptr, 10);
   if (const char* v = getenv("HFCL_BVH_STEAL")) lib->bvh_steal = atoi(v) != 0;
   if (const char* v = getenv("HFCL_CLIMB_MIN")) lib->climb_min = uint32_t(std::max(0, atoi(v)));
-  if (const char* v = getenv("HFCL_BVH_BUDGET")) lib->bvh_budget = uint32_t(std::max(0, atoi(v)));
+  if (const char* v = getenv("HFCL_BVH_BUDGET")) lib->bvh_budget = lib->bvh_budget0 = uint32_t(std::max(0, atoi(v)));
+  if (const char* v = getenv("HFCL_BVH_BUDGET0")) lib->bvh_budget0 = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_LEVELS")) lib->bvh_levels = uint32_t(std::min(12, std::max(1, atoi(v))));
   if (const char* w = getenv("HFCL_CVX_W")) {
     int v = atoi(w);
@@ -1015,6 +1017,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         split.cap = uint32_t(std::min<size_t>(lib->bvh_split_cap, 0x7FFFFFFFu));
         split.n_queries = uint32_t(lib->bvh_split_n);
         split.budget = lib->bvh_budget;
+        split.budget0 = lib->bvh_budget0;
         split.n_levels = lib->bvh_levels;
         // work stealing inside the wavefront wherever the LDS stack holds the traversal (the task levels remain the
         // overflow path of deeper trees)

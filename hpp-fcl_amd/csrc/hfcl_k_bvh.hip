@@ -1255,7 +1255,7 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
   const uint32_t budget = split.budget;
   for (uint32_t l = 0; l < split.n_levels; ++l) {
     split.level = l;
-    split.budget = l + 1 < split.n_levels ? budget : 0u;  // the last level runs to the end
+    split.budget = l + 1 < split.n_levels ? (l == 0 ? split.budget0 : budget) : 0u;  // the last level runs to the end
     BvhSplit s = split;
     s.can_suspend = l + 1 < split.n_levels;  // ... and cannot suspend (its stack overflows are flagged)
     hipLaunchKernelGGL((k_bvh_collide<T, false>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, s, spill);
