@@ -654,6 +654,7 @@ struct BvhSpill {
   uint32_t max_blocks;  // blocks the slab allocation covers
   uint32_t wide;        // 32-bit node ids in the stack entries
 };
+constexpr int BVH_MAX_LEVELS = 12;  // most task levels a batch can be given (HFCL_BVH_LEVELS, the automatic choice)
 #ifndef HFCL_BVH_LEVELS
 #define HFCL_BVH_LEVELS 6
 #endif

@@ -154,6 +154,11 @@ struct hfcl_lib {
   uint32_t* d_bvh_ctr = nullptr;
   size_t bvh_split_n = 0, bvh_split_cap = 0;
   uint32_t bvh_budget0 = HFCL_BVH_BUDGET0;  // HFCL_BVH_BUDGET0: step budget of the queries (level 0); bvh_budget: of the tasks
+  // No budget given by the environment: chosen per batch.  A batch that does not fill the chip's lanes more than ~1.5
+  // times is a walk with one query per lane whose waves run on with most lanes finished; there the queries are cut at
+  // 512 steps and their remainders spread over levels of small tasks (profiles/r02_w: 100k queries 6.4 -> 5.1 ms,
+  // 10k 4.7 -> 3.4 ms).  A larger batch keeps its lanes busy by refilling and loses with the split (1M: 68 -> 51 M q/s).
+  bool bvh_auto = true;
   uint32_t bvh_budget = HFCL_BVH_BUDGET, bvh_levels = HFCL_BVH_LEVELS;  // HFCL_BVH_BUDGET / HFCL_BVH_LEVELS (1: unsplit)
   bool bvh_steal = false;  // HFCL_BVH_STEAL=1: k_bvh_collide_ws (work stealing inside the wavefront, pre-tested stack entries) instead
                            // of the single pass; measured slower (profiles/r02_m_bvh_work_stealing.txt), kept for the record and tested
@@ -389,7 +394,8 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_CLIMB_MIN")) lib->climb_min = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_BUDGET")) lib->bvh_budget = lib->bvh_budget0 = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_BUDGET0")) lib->bvh_budget0 = uint32_t(std::max(0, atoi(v)));
-  if (const char* v = getenv("HFCL_BVH_LEVELS")) lib->bvh_levels = uint32_t(std::min(12, std::max(1, atoi(v))));
+  if (getenv("HFCL_BVH_BUDGET") || getenv("HFCL_BVH_BUDGET0") || getenv("HFCL_BVH_LEVELS")) lib->bvh_auto = false;
+  if (const char* v = getenv("HFCL_BVH_LEVELS")) lib->bvh_levels = uint32_t(std::min(BVH_MAX_LEVELS, std::max(1, atoi(v))));
   if (const char* w = getenv("HFCL_CVX_W")) {
     int v = atoi(w);
     if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) lib->cvx_w = v;
@@ -1019,6 +1025,11 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         split.budget = lib->bvh_budget;
         split.budget0 = lib->bvh_budget0;
         split.n_levels = lib->bvh_levels;
+        if (lib->bvh_auto && 2 * n <= 3 * size_t(lib->n_cus) * 512) {  // (8 waves of 64 lanes per CU are resident)
+          split.budget0 = 512;
+          split.budget = 16;
+          split.n_levels = BVH_MAX_LEVELS;
+        }
         // work stealing inside the wavefront wherever the LDS stack holds the traversal (the task levels remain the
         // overflow path of deeper trees)
         // (its stack holds one entry per level of the two trees: the pending sibling)

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   // Is the work of the task (parent slot p, position o) still needed?  Not if an earlier sibling -- of it or of any of its
   // ancestors -- has found a contact: the sequential walk would have ended there.
   auto moot = [&](uint32_t p, uint32_t o) -> bool {
-    for (int hop = 0; hop < HFCL_BVH_LEVELS + 1 && p != 0xFFFFFFFFu; ++hop) {
+    for (int hop = 0; hop < BVH_MAX_LEVELS + 1 && p != 0xFFFFFFFFu; ++hop) {
       const BvhSum<T>* ps = bvh_sum<T>(split, p);
       if (__hip_atomic_load(&ps->contact_order, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o) return true;
       o = ps->order;
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   };
   // a contact in this task ends the walk of every unit above it at this child's position
   auto report_contact = [&](uint32_t p, uint32_t o) {
-    for (int hop = 0; hop < HFCL_BVH_LEVELS + 1 && p != 0xFFFFFFFFu; ++hop) {
+    for (int hop = 0; hop < BVH_MAX_LEVELS + 1 && p != 0xFFFFFFFFu; ++hop) {
       BvhSum<T>* ps = bvh_sum<T>(split, p);
       atomicMin(&ps->contact_order, o);
       o = ps->order;
