@@ -76,8 +76,9 @@ def main():
     # ---- meshes (cfg4): collide (first contact in DFS order) and distance, 5 000-triangle models
     bb = pkg.bvh_builder
     nm = max(n // 10, 1000)
-    for seed, hw in ((31, 1.25), (32, 1.0)):
-        b = wl.cfg4_mesh_mesh(n=nm, seed=seed, half_width=hw)
+    # (the third leg is small enough for the automatic task split of batches that do not fill the chip's lanes)
+    for seed, hw, nq in ((31, 1.25, nm), (32, 1.0, nm), (33, 1.1, min(nm, 100000))):
+        b = wl.cfg4_mesh_mesh(n=nq, seed=seed, half_width=hw)
         ML = bb.MeshLibrary(b.meshes)
         req = wl.make_request(b, abi)
         lib = wl.make_library(pkg, b)
