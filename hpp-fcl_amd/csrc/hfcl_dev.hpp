@@ -22,9 +22,9 @@ using namespace hfcl;
 #ifndef HFCL_WPE_GJK
 #define HFCL_WPE_GJK 3
 #endif
-// k_epa carries no occupancy attribute on purpose: forcing the fp64 instantiation to 2 waves/SIMD
-// (488 B/lane of scratch) produced wrong EPA results on gfx950 (profiles/r01_c_waves_per_eu_ab.txt);
-// the compiler's own choice (fp32: 2 waves, fp64: 1 wave + AGPRs) is what the parity tests cover.
+// k_epa's occupancy attribute follows from its LDS block (hfcl_k_epa.hip: epa_waves_per_simd): the fp64 tiers are sized
+// for two waves per SIMD.  (Round 1 found a forced two-wave fp64 build to miscompute -- profiles/r01_c_waves_per_eu_ab.txt;
+// that was the hand-over save reading unwritten vertex records, fixed in round 2: profiles/r02_u.)
 #ifndef HFCL_WPE_GJK64
 #define HFCL_WPE_GJK64 2
 #endif
@@ -35,7 +35,7 @@ using namespace hfcl;
 #define HFCL_WPE_EPA32 2  // fp32 EPA: the LDS block allows 2 waves/SIMD, keep the registers within that
 #endif
 #ifndef HFCL_WPE_EPA64
-#define HFCL_WPE_EPA64 1
+#define HFCL_WPE_EPA64 1  // (only where an fp64 EPA block is too large for two waves per SIMD: A/B builds)
 #endif
 #ifndef HFCL_WPE_BVH
 #define HFCL_WPE_BVH 1
@@ -524,9 +524,11 @@ __device__ __forceinline__ V3<T> large_hull_support(const T* v, uint32_t n, cons
 // ---------------------------------------------------------------------------------------
 // k_epa: EPA on the pairs GJK left in `Collision`.  One polytope per WE-lane group, 64/WE polytopes
 // per wavefront, scratch blocks in LDS.  Two tiers:
-//   tier 1  WE = 8, CAP = 20 (fp32) / 24 (fp64) iterations: 8 polytopes per wave share one instruction
-//           stream; a polytope that outgrows the small block is saved at the start of that iteration and queued
-//   tier 2  WE = 16, CAP = 64 (the reference capacity): 4 polytopes per wave, continues the saved polytopes
+//   tier 1  fp32: WE = 8, CAP = 17, 8 polytopes per wave share one instruction stream (streaming form, k_epa_stream);
+//           fp64: one kernel per class of pairs -- polytope pairs WE = 8, CAP = 13; pairs with a curved shape WE = 16,
+//           CAP = 29 -- each 20 KB of LDS per wave (two waves per SIMD).  A polytope that outgrows the block is saved at
+//           the start of that iteration and queued
+//   tier 2  CAP = 64 (the reference capacity), WE = 16 (fp32) / 32 (fp64): continues the saved polytopes
 // ---------------------------------------------------------------------------------------
 template <int W_>
 struct LaneGroup {
@@ -634,11 +636,12 @@ struct BvhSplit {
   uint32_t can_suspend;
   uint32_t steal;       // 1: k_bvh_collide_ws (work stealing inside the wavefront; `sums` is its segment pool)
 };
-// Step budget per unit.  0 (default): units only suspend when their LDS stack is full -- the task mechanism is then the
-// overflow path of deep traversals and costs nothing otherwise.  Budgets were measured and do not pay with level-wise
-// launches (profiles/r02_k_bvh_task_split.txt: cfg4 7.3 ms unsplit, 7.9 .. 30 ms split): the stack of a long query
-// is one huge subtree next to many small ones, so every level only halves the longest chain, and the siblings of a
-// contact query's spine are speculative work the sequential walk never does.
+// Step budget per unit (the compile-time default; without HFCL_BVH_* in the environment the host chooses per batch, see
+// hfcl_lib::bvh_auto).  0: units only suspend when their LDS stack is full -- the task mechanism is then the overflow path
+// of deep traversals and costs nothing otherwise.  One budget for all levels does not pay (profiles/r02_k: cfg4 7.3 ms
+// unsplit, 7.9 .. 30 ms split: a stack is one heavy subtree next to many small ones, every level halves the longest chain
+// at best, small budgets drown in tasks).  What pays for batches that do not fill the chip's lanes is a generous budget for
+// the queries themselves (level 0) and a small one for the tasks of their remainders (profiles/r02_w).
 #ifndef HFCL_BVH_BUDGET
 #define HFCL_BVH_BUDGET 0
 #endif

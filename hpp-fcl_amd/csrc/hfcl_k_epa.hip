@@ -323,8 +323,8 @@ k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
 // launchers (hfcl_launch.hpp)
 // =======================================================================================
 // fp32 streams (two or three waves per SIMD hide the refill's global loads: k_epa<fast> 1.87 -> 1.76 ms on cfg3);
-// fp64 runs one wave per SIMD, where the more frequent refills cost more than the idle groups (cfg5
-// 1.27 -> 1.55 ms), and stays with the batch form
+// fp64 stays with the batch form: its refills cost more than the idle groups, at one wave per SIMD (round 1: cfg5
+// 1.27 -> 1.55 ms) and at two (round 2: 1.07 -> 1.22 ms, profiles/r02_u)
 // The streaming kernels are persistent (every wave walks through its share of the queue), so their grid is sized from
 // the number of waves the chip holds at once: HFCL_EPA_GRID_ROUNDS x that (1 round: the slowest wave decides and there
 // is nothing to fill its tail with, 1.755 ms; 2 rounds: 1.679 ms on cfg3; a grid that is not a multiple -- 16 waves per
