@@ -120,8 +120,9 @@ k_epa(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
     }
     if (sup.a.kind == K_CONVEX && (TIER != 2 || sup.a.num_points <= uint32_t(HULL_MAX))) sup.h0.load(va, sup.a.num_points, lig);
     if (sup.b.kind == K_CONVEX && (TIER != 2 || sup.b.num_points <= uint32_t(HULL_MAX))) sup.h1.load(vb, sup.b.num_points, lig);
-    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
-    sup.md = make_mdiff(tf1, tf2);
+    sup.md = make_mdiff(load_pose(io.tf1, pair), load_pose(io.tf2, pair));
+    // (the pose of shape 1 is read again when the record is written: 12 scalars less across the expansion)
+    auto tf1 = [&]() { return load_pose(io.tf1, pair); };
     const T r0 = swept_radius(sup.a), r1 = swept_radius(sup.b);
     PairOut<T> o;
     int rc = 1;

@@ -176,8 +176,15 @@ HFCL_HD void epa_finish(const EpaResult<T>& res, const EpaSeed<T>& seed, const P
 // the polytope outgrew the CAP-sized scratch block and must be redone by the full-capacity kernel; 2 when
 // it outgrew the block at an iteration boundary: the scratch block (incl. its hdr) then describes it
 // completely and the full-capacity kernel can continue it (epa_resume).
-template <typename T, class Grp, int CAP, class Sup, int V0M>
-HFCL_HD int epa_run(EpaScratch<T, CAP, V0M>* scratch, const EpaSeed<T>& seed, const QParams<T>& q, const Pose<T>& tf1, T r0,
+// The pose of shape 1 is needed once, for the record: a caller may pass the pose itself or something that produces it then
+// (a batch kernel re-reads it instead of carrying 12 scalars through the whole expansion).
+template <typename T>
+HFCL_HD const Pose<T>& pose_now(const Pose<T>& p) { return p; }
+template <typename T, class F>
+HFCL_HD auto pose_now(const F& f) -> decltype(f()) { return f(); }
+
+template <typename T, class Grp, int CAP, class Sup, int V0M, class TF>
+HFCL_HD int epa_run(EpaScratch<T, CAP, V0M>* scratch, const EpaSeed<T>& seed, const QParams<T>& q, const TF& tf1, T r0,
                     T r1, Sup& sup, PairOut<T>& out, Quad<T>* v0_ext = nullptr) {
   static_assert(V0M != V0_TAG, "the batch form keeps coordinates");
   Epa<T, Grp, CAP, V0M> epa;
@@ -192,20 +199,20 @@ HFCL_HD int epa_run(EpaScratch<T, CAP, V0M>* scratch, const EpaSeed<T>& seed, co
   EpaResult<T> res;
   epa.evaluate(seed.rank, -seed.guess, r0 + r1, sup, res);
   if (epa.overflow) return epa.resumable ? 2 : 0;
-  epa_finish(res, seed, tf1, r0, r1, out);
+  epa_finish(res, seed, pose_now<T>(tf1), r0, r1, out);
   return 1;
 }
 
 // Continue a polytope a CAP_SRC-tier saved (blob) in a CAP-sized block.  CAP must be the reference capacity.
-template <typename T, class Grp, int CAP_SRC, int CAP, class Sup, int V0M>
+template <typename T, class Grp, int CAP_SRC, int CAP, class Sup, int V0M, class TF>
 HFCL_HD void epa_resume(EpaScratch<T, CAP, V0M>* scratch, const EpaSaved<T, CAP_SRC>* blob, const EpaSeed<T>& seed,
-                        const QParams<T>& q, const Pose<T>& tf1, T r0, T r1, Sup& sup, PairOut<T>& out, Quad<T>* v0_ext = nullptr) {
+                        const QParams<T>& q, const TF& tf1, T r0, T r1, Sup& sup, PairOut<T>& out, Quad<T>* v0_ext = nullptr) {
   Epa<T, Grp, CAP, V0M> epa;
   epa.reset(scratch, q.epa_max_iterations, q.epa_tolerance, v0_ext);
   const EpaHeader h = epa.template load<CAP_SRC>(blob);
   EpaResult<T> res;
   epa.run_loop(h.closest, h.iterations, h.pass, r0 + r1, sup, res);
-  epa_finish(res, seed, tf1, r0, r1, out);
+  epa_finish(res, seed, pose_now<T>(tf1), r0, r1, out);
 }
 
 template <typename T>
