@@ -109,9 +109,16 @@ HFCL_HD void gjk_run(Gjk<T, PW0<T>>& g, const GjkParams<T>& prm, const V3<T>& gu
   gjk_run(g, prm, guess, ssr_sum, normalize, sup, W0Regs<T>());
 }
 
+// The pose of shape 1 is needed once, for the record: a caller may pass the pose itself or something that produces it then
+// (a batch kernel re-reads it instead of carrying 12 scalars through the whole GJK / EPA loop).
+template <typename T>
+HFCL_HD const Pose<T>& pose_now(const Pose<T>& p) { return p; }
+template <typename T, class F>
+HFCL_HD auto pose_now(const F& f) -> decltype(f()) { return f(); }
+
 // Returns true when the pair must go through EPA (seed filled); otherwise `out` is final.
-template <typename T, class P, class PS>
-HFCL_HD bool gjk_finish(const Gjk<T, P>& g, const QParams<T>& q, const Pose<T>& tf1, T r0, T r1,
+template <typename T, class P, class PS, class TF>
+HFCL_HD bool gjk_finish(const Gjk<T, P>& g, const QParams<T>& q, const TF& tf1, T r0, T r1,
                         const V3<T>& guess0, PairOut<T>& out, EpaSeed<T>& seed, const PS& ps) {
   typedef SimplexV<T, P> SV;
   const T nanv = Lim<T>::nan();
@@ -150,7 +157,7 @@ HFCL_HD bool gjk_finish(const Gjk<T, P>& g, const QParams<T>& q, const Pose<T>& 
   V3<T> p1, p2, n;
   closest_points(r, ref0.w, ref1.w, g.s0.w, a0, b0, c0, a0 - ref0.w, b0 - ref1.w, c0 - g.s0.w, p1, p2);
   gjk_witness_normal(g.ray, r0, r1, p1, p2, n);
-  to_world(tf1, g.distance, p1, p2, n);
+  to_world(pose_now<T>(tf1), g.distance, p1, p2, n);
   out.distance = g.distance;
   out.normal = n;
   out.p1 = p1;
@@ -176,13 +183,6 @@ HFCL_HD void epa_finish(const EpaResult<T>& res, const EpaSeed<T>& seed, const P
 // the polytope outgrew the CAP-sized scratch block and must be redone by the full-capacity kernel; 2 when
 // it outgrew the block at an iteration boundary: the scratch block (incl. its hdr) then describes it
 // completely and the full-capacity kernel can continue it (epa_resume).
-// The pose of shape 1 is needed once, for the record: a caller may pass the pose itself or something that produces it then
-// (a batch kernel re-reads it instead of carrying 12 scalars through the whole expansion).
-template <typename T>
-HFCL_HD const Pose<T>& pose_now(const Pose<T>& p) { return p; }
-template <typename T, class F>
-HFCL_HD auto pose_now(const F& f) -> decltype(f()) { return f(); }
-
 template <typename T, class Grp, int CAP, class Sup, int V0M, class TF>
 HFCL_HD int epa_run(EpaScratch<T, CAP, V0M>* scratch, const EpaSeed<T>& seed, const QParams<T>& q, const TF& tf1, T r0,
                     T r1, Sup& sup, PairOut<T>& out, Quad<T>* v0_ext = nullptr) {
