@@ -258,7 +258,7 @@ k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
             if (lig == 0) {  // queue to queue, no local copy (a local EpaItem lives in scratch memory)
               EpaItem<T>* dst = reinterpret_cast<EpaItem<T>*>(wk.epa_queue2) + slot;
               *dst = *ip;
-              if (save) dst->rank = ip->rank | EPA_RESUME_FLAG;
+              if (save) dst->rank = ip->rank | EPA_RESUME_FLAG | (CAP != epa_fast_cap<T> ? EPA_RESUME_SMALL : 0);
             }
           }
           Grp::sync();
