@@ -16,9 +16,13 @@ its own timed region, roofline and (trimmed) CPU baseline --
         runs it as the headline)
 `--workload X` runs X alone as the headline (used by the profiling tools).
 
-N > 1 (launched by torch.distributed.run): weak scaling -- every rank owns its own shard (different seed per rank) --
-and the per-shard result records are all-gathered over RCCL/xGMI (north_star) on a separate stream, overlapped with the
-next step's kernels.  `--scaling strong`: one list, rank r owns sharding.shard_range(n, r, world).
+N > 1: one process per GPU.  `python bench.py --gpus N` started as a plain process spawns its N ranks itself
+(torch.distributed.run, loopback rendezvous); started by torch.distributed.run (WORLD_SIZE in the environment) it is one
+of the ranks.  Weak scaling -- every rank owns its own shard (different seed per rank) -- and the per-shard result records
+are all-gathered over RCCL/xGMI (north_star) on a separate stream, overlapped with the next step's kernels
+(`--gather full|compact|none`: 96/44-B records, 24/8-B hfcl_result_compact records, no exchange; DESIGN.md section 5 has the
+byte budget).  `--scaling strong`: one list, rank r owns sharding.shard_range(n, r, world).
+`--backend gloo --device-map 0,0` runs two ranks on one GPU (tests; RCCL refuses duplicate devices).
 
 Prints ONE JSON line on rank 0.
 """
@@ -53,12 +57,14 @@ BYTES_PER_QUERY = {
     # sphere-only entry point that reads centres and radii alone; the drop-in ABI does not have one)
     "cfg1": 8 + 2 * 96 + 96,
     "cfg3u": 8 + 2 * 28 + 44 + 2 * 32 * 12,  # cfg3 with one hull pair per query: + 2 x 32 fp32 vertices = 876 B
+    "cfg2f": 8 + 2 * 28 + 44,  # cfg2's pairs through the fp32 device path (7-float poses, 44-B records)
 }
 CFG4_BYTES_PER_BV_TEST = 2 * 128
 CFG4_BYTES_PER_LEAF_TEST = 2 * (3 * 24 + 12)
 DEFAULT_PAIRS = {"cfg4": 100_000, "cfg5": 1_250_000, "cfg1": 4_000_000}
 BASELINE_CONFIG = {"cfg3": "configs[2]", "cfg2": "configs[1]", "cfg4": "configs[3]", "cfg5": "configs[4]",
-                   "cfg1": "configs[0] (shape pair; GPU batch size)", "cfg3u": "configs[2], one hull pair per query"}
+                   "cfg1": "configs[0] (shape pair; GPU batch size)", "cfg3u": "configs[2], one hull pair per query",
+                   "cfg2f": "configs[1] through the fp32 device path"}
 
 # VALU issue peak, MEASURED on the box (tools/valu_peak.hip, profiles/r02_a_valu_issue_peak.txt): the select / compare /
 # fma mix these kernels are made of tops out at 1.00e12 wave64 instructions per second chip-wide with 8 waves per SIMD
@@ -72,12 +78,20 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=None, choices=["cfg3", "cfg2", "cfg4", "cfg5", "cfg1", "cfg3u"],
+    ap.add_argument("--workload", default=None, choices=["cfg3", "cfg2", "cfg4", "cfg5", "cfg1", "cfg3u", "cfg2f"],
                     help="run this workload alone as the headline (default: cfg3 + the secondary list)")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default 1M; cfg4: 100k; cfg5: 1.25M = 10M / 8); "
                     "with --scaling strong: pairs of the whole job")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of result records (N>1)")
+    ap.add_argument("--gather", default="full", choices=["full", "compact", "none"],
+                    help="N>1: what the ranks exchange after every step -- full result records (north_star: CollisionResult "
+                    "buffers), hfcl_result_compact records (24 / 8 B), or nothing")
+    ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo "
+                    "stages the records through host memory and allows several ranks per device)")
+    ap.add_argument("--device-map", default="", help="comma list: device of each local rank (default: rank r -> device r)")
+    ap.add_argument("--verify-gather", action="store_true", help="after the timed region check what the exchange "
+                    "delivered: block checksums of every rank; --scaling strong: bytes equal to the whole list run on rank 0")
     ap.add_argument("--split", type=int, default=0, help="0: the library decides (two half-batches on two streams for "
                     "mixed libraries); 1: one stream; 2: always split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,6 +185,8 @@ def make_batch(ctx, workload, n, strong):
         batch, dtype = wl.cfg1_sphere_sphere(n=n, seed=seed), "f64"
     elif workload == "cfg2":
         batch, dtype = wl.cfg2_box_capsule(n=n, seed=seed), "f64"
+    elif workload == "cfg2f":
+        batch, dtype = wl.cfg2_box_capsule(n=n, seed=seed), "f32"
     elif workload == "cfg5":
         # pair list = host broadphase over a scene of n/10 posed objects (not in the timed region); the list is cut to
         # exactly n pairs.  Several ranks on one host share its cores.
@@ -232,7 +248,8 @@ def cpu_baseline(ctx, workload, batch, req, sample, budget_s, all_cores=True):
     return out
 
 
-def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s=10.0, cpu_sample=1_000_000, host_buffers=False):
+def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s=10.0, cpu_sample=1_000_000, host_buffers=False,
+                 gather=None):
     """One timed region: `steps` passes of the hot path over this rank's batch.  Returns the result dict on rank 0."""
     import torch
     import torch.distributed as dist
@@ -242,7 +259,7 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
     batch, dtype, extra_cfg, full = make_batch(ctx, workload, n_total, strong)
     n = len(batch)  # pairs of this rank per step
     req = wl.make_request(batch, abi)
-    lib = wl.make_library(pkg, full, device=ctx.local_rank)
+    lib = wl.make_library(pkg, full, device=ctx.device_index)
     if args.split:
         lib.set_split(args.split)
 
@@ -261,34 +278,27 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
     # strong scaling: shards may be ragged; the collective moves equal-sized (padded) blocks
     per = pkg.sharding.padded_shard_len(n_total, ctx.world) if strong else n
     outs = [torch.zeros(per * rec_words, dtype=torch.int32, device=dev) for _ in range(2)]
-    gather = ctx.dist_on and not args.no_gather
-    gathered = [torch.empty(ctx.world * per * rec_words, dtype=torch.int32, device=dev) for _ in range(2)] if gather else None
+    gather_mode = ("none" if args.no_gather else (gather or args.gather)) if ctx.dist_on else "none"
+    xch = pkg.multigpu.RecordExchange(lib, dev, per, dtype, gather_mode if ctx.dist_on else "none",
+                                      dist=dist if ctx.dist_on else None, staged=ctx.backend == "gloo")
+    gather = xch.dist is not None
     stream = torch.cuda.current_stream()
     kernel_ms = {}
+    sent = {}
 
-    def one_step(i, record_times):
+    def one_step(i, record_times, exchange=True):
         buf = i & 1
+        if exchange:
+            # double buffering: the kernels of step i overwrite the buffer the exchange of step i-2 read
+            xch.before_launch(buf)
         if n:
             launch(d_s1, d_s2, d_p1, d_p2, n, req, outs[buf], stream=stream.cuda_stream)
-        work = None
-        if gather:
+        if exchange:
             # results of this step travel over xGMI while the next step's kernels run
-            ev = torch.cuda.Event()
-            ev.record(stream)
-            work = (buf, ev)
+            sent[buf] = xch.after_launch(buf, outs[buf], n, stream)
         if record_times and n:
             for name, ms in lib.last_kernel_breakdown():  # HIP events on the launch stream
                 kernel_ms.setdefault(name, []).append(ms)
-        return work
-
-    comm_stream = torch.cuda.Stream(device=dev) if gather else None
-
-    def flush_gather(work):
-        buf, ev = work
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(ev)
-            h = dist.all_gather_into_tensor(gathered[buf], outs[buf], async_op=True)
-        return h
 
     def sync_all():
         torch.cuda.synchronize()
@@ -298,35 +308,48 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
 
     lib.set_kernel_timing(False)  # the timed region runs without the per-kernel event markers
     for i in range(warmup):
-        w = one_step(i, False)
-        if w:
-            flush_gather(w).wait()
+        one_step(i, False)
+        xch.drain()
     sync_all()
-    inflight = {}  # result buffer -> all-gather still reading it
     t0 = time.perf_counter()
     for i in range(steps):
-        # double buffering: the kernels of step i overwrite the buffer the all-gather of step i-2 read;
-        # make the launch stream wait for that collective first (stream-side wait, the host does not block)
-        h = inflight.pop(i & 1, None)
-        if h is not None:
-            h.wait()
-        w = one_step(i, False)
-        if w:
-            inflight[i & 1] = flush_gather(w)
-    for h in inflight.values():
-        h.wait()
+        one_step(i, False)
+    xch.drain()
     sync_all()
     elapsed = time.perf_counter() - t0
     if ctx.dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if ctx.backend != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # what did the exchange deliver?  (outside the timed region)
+    last = (steps - 1) & 1
+    gather_check = None
+    if gather and steps > 0:
+        gather_check = {"block_checksums": xch.verify(last, sent[last], ctx.rank)}
+        if args.verify_gather and strong:
+            # the whole list on ONE rank, through the same entry point: the gathered buffer must hold exactly these bytes
+            ok = None
+            if ctx.rank == 0:
+                f_s1 = torch.from_numpy(full.s1.astype(np.int32)).to(dev)
+                f_s2 = torch.from_numpy(full.s2.astype(np.int32)).to(dev)
+                f_p1 = torch.from_numpy(full.pose1_f32 if dtype == "f32" else full.tf1).to(dev)
+                f_p2 = torch.from_numpy(full.pose2_f32 if dtype == "f32" else full.tf2).to(dev)
+                f_out = torch.zeros(n_total * rec_words, dtype=torch.int32, device=dev)
+                launch(f_s1, f_s2, f_p1, f_p2, n_total, req, f_out, stream=stream.cuda_stream)
+                torch.cuda.synchronize()
+                rec = f_out.cpu().numpy().view(abi.RESULT_F32_DTYPE if dtype == "f32" else abi.RESULT_DTYPE)
+                want = pkg.multigpu.expected_exchange(rec, dtype, gather_mode)
+                got = xch.gathered[last][:want.size].cpu().numpy()
+                ok = bool(np.array_equal(got, want))
+                del f_s1, f_s2, f_p1, f_p2, f_out
+            gather_check["equals_single_rank_run"] = ok
 
     # per-kernel durations (HIP events inside the library, on the launch stream), separate pass so
     # the event reads do not serialise the timed region
     lib.set_kernel_timing(True)
     for i in range(min(steps, 10)):
-        one_step(i, True)
+        one_step(i, True, exchange=False)
     torch.cuda.synchronize()
 
     result = None
@@ -389,7 +412,10 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
             "config": {"workload": batch.name, **extra_cfg, "baseline_config": BASELINE_CONFIG[workload],
                        "pairs_per_gpu_per_step": n, "pairs_per_step_all_gpus": n_total if strong else n * ctx.world,
                        "contact_fraction": contact_frac, "buckets": buckets,
-                       "request": batch.kind, "all_gather_results": bool(gather), "split_parts": lib.last_split_parts(),
+                       "request": batch.kind, "all_gather_results": bool(gather), "gather": gather_mode,
+                       "gather_bytes_per_rank_per_step": dict(zip(("sent", "received"), xch.bytes_per_rank_per_step())),
+                       "gather_check": gather_check, "backend": ctx.backend if ctx.dist_on else None,
+                       "split_parts": lib.last_split_parts(),
                        "lane_group_width": os.environ.get("HFCL_CVX_W", "auto (2; fp64 convex-convex 4)")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
@@ -419,13 +445,23 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
                 "link_bound_ms": 1e3 * bound_s, "frac_of_link_bound": bound_s / t_h, "records_identical_to_device_path": same,
                 "note": "hfcl_%s_batch on pageable host arrays: chunked H2D | kernels | D2H pipeline; PCIe inclusive" % batch.kind}
     lib.close()
-    del d_s1, d_s2, d_p1, d_p2, outs, gathered
+    del d_s1, d_s2, d_p1, d_p2, outs, xch
     torch.cuda.empty_cache()
     return result
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as a plain process: become the launcher of the N ranks (one process per GPU) and pass their output through
+        pkg = load_pkg()
+        if not args.device_map:
+            import torch
+            have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if have < args.gpus:
+                raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node (several ranks can share a device "
+                                 "with --backend gloo --device-map 0,0,...)" % (args.gpus, have))
+        raise SystemExit(pkg.multigpu.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     import torch
     import torch.distributed as dist
 
@@ -434,22 +470,25 @@ def main():
     ctx.rank = int(os.environ.get("RANK", "0"))
     ctx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx.backend = args.backend
     if args.gpus != ctx.world:
-        if ctx.world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" %
-                             (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, ctx.world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
-    torch.cuda.set_device(ctx.local_rank)
-    ctx.dev = torch.device("cuda", ctx.local_rank)
-    # HFCL_BENCH_FORCE_DIST=1: run the N>1 code path (RCCL group, comm stream, async all-gather, barriers, max over
+    ctx.pkg = load_pkg()
+    ctx.device_index = ctx.pkg.multigpu.device_of_rank(ctx.local_rank, args.device_map)
+    torch.cuda.set_device(ctx.device_index)
+    ctx.dev = torch.device("cuda", ctx.device_index)
+    # HFCL_BENCH_FORCE_DIST=1: run the N>1 code path (process group, comm stream, async all-gather, barriers, max over
     # ranks) with a single rank -- a dry run of the multi-GPU plumbing on a 1-GPU box
     ctx.dist_on = ctx.world > 1 or os.environ.get("HFCL_BENCH_FORCE_DIST") == "1"
     if ctx.dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=ctx.dev, rank=ctx.rank, world_size=ctx.world)
-    ctx.pkg = load_pkg()
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=ctx.dev, rank=ctx.rank, world_size=ctx.world)
+        else:
+            dist.init_process_group("gloo", rank=ctx.rank, world_size=ctx.world)
 
     headline_wl = args.workload or "cfg3"
     strong = args.scaling == "strong"
@@ -459,7 +498,9 @@ def main():
     if args.workload is None and not args.no_secondary:
         sec_steps = max(3, min(args.steps, 10))
         plan = [("cfg2", 0, False, dict(host_buffers=True)), ("cfg4", 0, False, {}), ("cfg5", 0, False, {}),
-                ("cfg5", 10_000_000, True, {})]
+                ("cfg5", 10_000_000, True, {}), ("cfg3u", 0, False, {}), ("cfg2f", 0, False, {})]
+        if ctx.world > 1:  # the same list with the 24-B exchange format, and the headline without any exchange
+            plan += [("cfg5", 10_000_000, True, dict(gather="compact")), ("cfg3", 0, False, dict(gather="none"))]
         for wl_name, pairs, st, kw in plan:
             try:
                 r = run_workload(ctx, wl_name, pairs, sec_steps if not st else 5, 2, strong=st, cpu_budget_s=2.5,
@@ -468,7 +509,8 @@ def main():
                 r = {"workload": wl_name + ("_strong" if st else ""), "error": repr(e)} if ctx.rank == 0 else None
             if r is not None:
                 if st:
-                    r["workload"] += " (one %d-pair list sharded over the ranks, records all-gathered)" % pairs
+                    r["workload"] += " (one %d-pair list sharded over the ranks, gather=%s)" % (pairs, r["config"]["gather"]) \
+                        if "config" in r else ""
                 secondary.append(r)
 
     line = None

@@ -7,6 +7,6 @@ contains a hyphen (it is the project name); import it through `tests/conftest.py
 This module holds plumbing only.  All compute happens in csrc/libhppfcl_amd.so (HIP kernels,
 gfx950).  There is no CPU fallback: without the built library or without a GPU every compute
 call raises."""
-from . import abi, bvh_builder, compat, engine, geometry, sharding, workloads  # noqa: F401
+from . import abi, bvh_builder, compat, engine, geometry, multigpu, sharding, workloads  # noqa: F401
 from .engine import EngineError, Library  # noqa: F401
 from .geometry import ShapeLibrary, make_pose, quat_to_matrix  # noqa: F401

@@ -71,6 +71,10 @@ assert RESULT_DTYPE.itemsize == 96
 RESULT_F32_DTYPE = np.dtype([("distance", "<f4"), ("p1", "<f4", 3), ("p2", "<f4", 3), ("normal", "<f4", 3),
                              ("status", "<u4")])
 assert RESULT_F32_DTYPE.itemsize == 44
+RESULT_COMPACT_DTYPE = np.dtype([("distance", "<f8"), ("b1", "<i4"), ("b2", "<i4"), ("status", "<u4"), ("num_contacts", "<i4")])
+assert RESULT_COMPACT_DTYPE.itemsize == 24
+RESULT_COMPACT_F32_DTYPE = np.dtype([("distance", "<f4"), ("status", "<u4")])
+assert RESULT_COMPACT_F32_DTYPE.itemsize == 8
 GUESS_DTYPE = np.dtype([("gjk_guess", "<f8", 3), ("support_guess", "<i4", 2)])
 assert GUESS_DTYPE.itemsize == 32
 CONTACT_DTYPE = np.dtype([("pair", "<u4"), ("b1", "<i4"), ("b2", "<i4"), ("_pad", "<u4"),
@@ -84,6 +88,15 @@ BVH_NODE_DTYPE = np.dtype([("first_child", "<i4"), ("first_primitive", "<i4"), (
                            ("rss_axes", "<f8", 9), ("rss_Tr", "<f8", 3), ("rss_length", "<f8", 2),
                            ("rss_radius", "<f8")])
 assert BVH_NODE_DTYPE.itemsize == C.sizeof(BvhNode) == 256
+
+
+def compact_records(records):
+    """Host-side image of hfcl_compact_results_device: the fields a compact record keeps (bit copies)."""
+    f32 = records.dtype == RESULT_F32_DTYPE
+    out = np.zeros(len(records), dtype=RESULT_COMPACT_F32_DTYPE if f32 else RESULT_COMPACT_DTYPE)
+    for k in out.dtype.names:
+        out[k] = records[k]
+    return out
 
 
 def status_gjk(s):

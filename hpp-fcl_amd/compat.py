@@ -5,6 +5,8 @@ test/python_unit/api.py, collision.py, collision_manager.py -- runs on `import h
 
 Plumbing only: every query is a batch of one (or, through `collide_pairs` / the collision manager, one batch)
 on the HIP library.  No CPU fallback."""
+import os
+
 import numpy as np
 
 from . import abi, bvh_builder, engine, geometry
@@ -217,9 +219,11 @@ class Convex(ShapeBase):
         self.polygons = list(polygons) if polygons is not None else []
 
     def neighbors(self):
-        """ConvexBase::neighbors as CSR (offsets[num_points + 1], ids), or None without facets."""
+        """ConvexBase::neighbors as CSR (offsets[num_points + 1], ids), or None without facets.  Built once per object."""
         if not self.polygons:
             return None
+        if getattr(self, "_nb_cache", None) is not None and self._nb_cache[0] == (self.num_points, len(self.polygons)):
+            return self._nb_cache[1]
         nb = [set() for _ in range(self.num_points)]
         for poly in self.polygons:
             idx = [int(poly[k]) for k in range(3)] if isinstance(poly, Triangle) else [int(k) for k in poly]
@@ -229,7 +233,9 @@ class Convex(ShapeBase):
                 nb[idx[j]].add(idx[(j + 1) % n])
         offs = np.zeros(self.num_points + 1, dtype=np.uint32)
         offs[1:] = np.cumsum([len(x) for x in nb])
-        return offs, np.array([v for x in nb for v in sorted(x)], dtype=np.uint32)
+        out = (offs, np.array([v for x in nb for v in sorted(x)], dtype=np.uint32))
+        self._nb_cache = ((self.num_points, len(self.polygons)), out)
+        return out
 
     def _register(self, L):
         return L.add_convex(self.points, self._swept)
@@ -457,8 +463,11 @@ class _Context:
             self.lib = engine.Library(self.L, device=self.device)
             for m in self.meshes:
                 self.lib.add_bvh(m)
-            for g in self.keep:  # large hulls with facets: the adjacency the device climbs
-                if isinstance(g, Convex) and g.num_points > 32:
+            # large hulls with facets: the adjacency the device climbs.  Only hulls the engine will climb (HFCL_CLIMB_MIN
+            # vertices, default 512: below that the scan is faster) pay the host loop and the device copy.
+            climb_min = int(os.environ.get("HFCL_CLIMB_MIN", "512"))
+            for g in self.keep:
+                if isinstance(g, Convex) and g.num_points >= max(33, climb_min):
                     nb = g.neighbors()
                     if nb is not None:
                         self.lib.set_convex_neighbors(self.ids[id(g)][0], *nb)

@@ -403,7 +403,7 @@ struct HullRegs {
 // getShapeSupportLinear; the reference's neighbour hill-climbing, support_functions.cpp:323-397, reaches
 // a vertex of the same support value, possibly another one on a plateau -- see DESIGN.md).
 template <typename T, int W>
-__device__ __forceinline__ V3<T> scan_support(const T* v, uint32_t n, const V3<T>& dir, int lig) {
+__device__ __forceinline__ V3<T> scan_support(const T* v, uint32_t n, const V3<T>& dir, int lig, uint32_t* idx_out = nullptr) {
   T best = -Lim<T>::max();
   uint32_t bi = 0xFFFFFFFFu;
   // The scan is a chain of loads unless several vertices are in flight at once: UNR vertices per lane are fetched
@@ -441,6 +441,7 @@ __device__ __forceinline__ V3<T> scan_support(const T* v, uint32_t n, const V3<T
       bi = oi;
     }
   });
+  if (idx_out) *idx_out = bi;
   return mk<T>(v[3 * bi], v[3 * bi + 1], v[3 * bi + 2]);
 }
 // ---------------------------------------------------------------------------------------
@@ -448,12 +449,18 @@ __device__ __forceinline__ V3<T> scan_support(const T* v, uint32_t n, const V3<T
 // (the vertex the previous call of this query returned; < 0: the best of the hull's 14 warm-start vertices,
 // ConvexBase::support_warm_starts, geometric_shapes.cpp buildSupportWarmStart), look at all neighbours of the current
 // vertex at once -- one per lane, coordinates inline in the adjacency entry so a hop is two dependent fetches (offsets,
-// entries) -- and move to the best one while it is strictly better.  On a convex polytope that ends at a vertex of
-// maximal support; where several vertices tie (a plateau) it may be another one than the scan's / the reference's
-// (which also accepts equal neighbours until its first strict improvement and keeps a visited set to stay finite).
+// entries) -- and move to the best one while it is strictly better.  On a convex polytope whose listed points are all
+// extreme that ends at a vertex of maximal support (no improving edge = optimal).  A point in the interior of a flat,
+// triangulated facet (a subdivided box, the cap centre of a cylinder mesh) has all its neighbours in the facet's plane:
+// along the facet's INWARD normal every neighbour ties and none improves although the facet is the hull's minimum.
+// The reference walks on over equal neighbours until its first strict improvement (loose_check, with a visited set to
+// stay finite, :368-382); here a climb that ends where it started, without any strict improvement and with a neighbour
+// that ties, is that plateau case and is answered by the scan (the only place a tie can hide a better vertex: after a
+// strict improvement a plateau reached is a maximum).  Where several vertices tie at the maximum the result may be
+// another of them than the scan's / the reference's.
 // A hop costs O(degree) instead of O(num_points): measured crossover against scan_support in profiles/r02_p.
 template <typename T, int W>
-__device__ __forceinline__ V3<T> climb_support(const T* v, const HullGraph<T>& g, const V3<T>& dir, int lig, int& hint) {
+__device__ __forceinline__ V3<T> climb_support(const T* v, uint32_t n, const HullGraph<T>& g, const V3<T>& dir, int lig, int& hint) {
   uint32_t cur;
   T best;
   if (hint < 0) {
@@ -484,13 +491,16 @@ __device__ __forceinline__ V3<T> climb_support(const T* v, const HullGraph<T>& g
     cur = uint32_t(hint);
     best = v[3 * size_t(cur)] * dir.x + v[3 * size_t(cur) + 1] * dir.y + v[3 * size_t(cur) + 2] * dir.z;
   }
+  bool improved = false;
   for (;;) {
     const uint32_t b = g.off[cur], e = g.off[cur + 1];
     T mb = best;
     uint32_t mi = 0xFFFFFFFFu, mpos = 0xFFFFFFFFu;
+    bool tie = false;
     for (uint32_t k = b + uint32_t(lig); k < e; k += W) {
       const NbrEntry<T> nb = g.ent[k];
       const T d = nb.x * dir.x + nb.y * dir.y + nb.z * dir.z;
+      tie = tie || d == best;
       if (d > mb) {
         mb = d;
         mi = nb.id;
@@ -508,7 +518,23 @@ __device__ __forceinline__ V3<T> climb_support(const T* v, const HullGraph<T>& g
         mpos = ok;
       }
     });
-    if (mi == 0xFFFFFFFFu) break;  // no neighbour is strictly better (uniform over the group)
+    if (mi == 0xFFFFFFFFu) {  // no neighbour is strictly better (uniform over the group)
+      if (!improved) {        // ... and none ever was: a neighbour that ties may hide a better vertex behind the plateau
+        uint32_t any = tie ? 1u : 0u;
+        butterfly_stages<W>([&](auto stage) {
+          constexpr int M = decltype(stage)::value;
+          any |= group_exchange<W, M>(any);
+        });
+        if (any) {
+          uint32_t si = 0;
+          const V3<T> r = scan_support<T, W>(v, n, dir, lig, &si);
+          hint = int(si);
+          return r;
+        }
+      }
+      break;
+    }
+    improved = true;
     cur = mi;
     best = mb;
   }
@@ -518,7 +544,7 @@ __device__ __forceinline__ V3<T> climb_support(const T* v, const HullGraph<T>& g
 // scan or climb: what a hull too large for registers answers a support query with
 template <typename T, int W>
 __device__ __forceinline__ V3<T> large_hull_support(const T* v, uint32_t n, const HullGraph<T>& g, const V3<T>& dir, int lig, int& hint) {
-  if (g.off != nullptr) return climb_support<T, W>(v, g, dir, lig, hint);
+  if (g.off != nullptr) return climb_support<T, W>(v, n, g, dir, lig, hint);
   return scan_support<T, W>(v, n, dir, lig);
 }
 // ---------------------------------------------------------------------------------------

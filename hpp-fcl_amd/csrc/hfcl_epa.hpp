@@ -35,6 +35,10 @@ enum {
 constexpr int EPA_MAX_ITER = 64;                 // device limit (reference default, narrowphase_defaults.h:60)
 constexpr int EPA_MAX_VERTS = EPA_MAX_ITER + 4;  // gjk.cpp:1020
 constexpr int EPA_MAX_FACES = 2 * EPA_MAX_ITER + 4;  // gjk.cpp:1021
+// The append stamp of a face is packed into 14 bits of its topology record (FaceTopo).  A polytope appends 4 faces at the
+// start and, per iteration, at most as many as it has faces: the bound below holds for the reference's capacity; raising
+// EPA_MAX_ITER needs a wider stamp (the hull-order tie-break of find_closest_face would silently truncate otherwise).
+static_assert((2 * EPA_MAX_ITER + 4) * EPA_MAX_ITER + 4 < (1 << 14), "EPA face stamps no longer fit 14 bits");
 constexpr int EPA_NULL = 255;
 
 template <typename T>

@@ -742,7 +742,11 @@ static int upload_graph(hfcl_lib* lib) {
   ok = ok && hipMemcpy(lib->d_graph_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
   ok = ok && (e32.empty() || hipMemcpy(lib->d_graph_ent32, e32.data(), e32.size() * sizeof(NbrEntry<float>), hipMemcpyHostToDevice) == hipSuccess);
   ok = ok && (e64.empty() || hipMemcpy(lib->d_graph_ent64, e64.data(), e64.size() * sizeof(NbrEntry<double>), hipMemcpyHostToDevice) == hipSuccess);
-  if (!ok) {
+  if (!ok) {  // nothing half-built stays behind: the next batch retries the upload from the host copies
+    hipFree(lib->d_graph_base); hipFree(lib->d_graph_off); hipFree(lib->d_graph_ent32); hipFree(lib->d_graph_ent64);
+    lib->d_graph_base = nullptr; lib->d_graph_off = nullptr; lib->d_graph_ent32 = nullptr; lib->d_graph_ent64 = nullptr;
+    lib->graph_dirty = true;
+    if (lib->helper) share_tables(lib->helper, lib);
     set_error("vertex adjacency: HIP allocation/copy failed");
     return HFCL_ERR_HIP;
   }
@@ -1215,6 +1219,27 @@ static int setup_distance(const hfcl_distance_request* req, QParams<T>& q) {
   return HFCL_OK;
 }
 
+// full records -> compact records (hfcl_result_compact), for the multi-GPU exchange of results
+template <typename R, typename C>
+static int compact_results(hfcl_lib* lib, const R* d_records, size_t n, C* d_out, void* stream) {
+  if (!lib) {
+    set_error("null library");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  if (n == 0) return HFCL_OK;
+  if (!d_records || !d_out) {
+    set_error("hfcl_compact_results_device: null buffer");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  if (n > 0xFFFFFFF0ull) {
+    set_error("batch too large (max 2^32-16 pairs per call)");
+    return HFCL_ERR_LIMIT;
+  }
+  HIP_TRY(hipSetDevice(lib->device));
+  launch_compact_records((hipStream_t)stream, d_records, d_out, uint32_t(n));
+  HIP_TRY(hipGetLastError());
+  return HFCL_OK;
+}
 extern "C" {
 
 int hfcl_collide_batch_device(hfcl_lib* lib, const uint32_t* d_shape1, const uint32_t* d_shape2, const double* d_tf1,
@@ -1289,6 +1314,14 @@ int hfcl_collide_batch_device_f32(hfcl_lib* lib, const uint32_t* d_shape1, const
   lib->bvh_params.num_max_contacts = req->num_max_contacts;
   lib->break_distance = req->break_distance;
   return run_batch<float>(lib, d_shape1, d_shape2, io, n, q, st);
+}
+
+int hfcl_compact_results_device(hfcl_lib* lib, const hfcl_result* d_records, size_t n, hfcl_result_compact* d_out, void* stream) {
+  return compact_results(lib, d_records, n, d_out, stream);
+}
+int hfcl_compact_results_device_f32(hfcl_lib* lib, const hfcl_result_f32* d_records, size_t n, hfcl_result_compact_f32* d_out,
+                                    void* stream) {
+  return compact_results(lib, d_records, n, d_out, stream);
 }
 
 static int ensure_staging(hfcl_lib* lib, size_t n, bool gin, bool gout, bool compact) {

@@ -29,6 +29,9 @@ template <typename T> void launch_gjk_large(int grid, hipStream_t st, const Work
 void launch_expand_poses(hipStream_t st, const double* qt, double* tf, uint32_t n);
 void launch_fill_skipped(hipStream_t st, hfcl_result* out, uint32_t n);
 void launch_fill_skipped(hipStream_t st, hfcl_result_f32* out, uint32_t n);
+// hfcl_k_util.hip: full records -> compact records (hfcl_result_compact{,_f32})
+void launch_compact_records(hipStream_t st, const hfcl_result* in, hfcl_result_compact* out, uint32_t n);
+void launch_compact_records(hipStream_t st, const hfcl_result_f32* in, hfcl_result_compact_f32* out, uint32_t n);
 
 // tier 1 (fp32: streaming form) and tier 2 of EPA; the grids are in blocks of one wavefront
 // cc_queue / general_queue (fp32): which of the two streaming forms have anything to do (convex x convex pairs have a

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "hfcl_world_aabbs", "hfcl_broadphase_self_pairs", "hfcl_broadphase_pairs_between", "hfcl_pairlist_size",
     "hfcl_pairlist_data", "hfcl_pairlist_free", "hfcl_lib_set_kernel_timing", "hfcl_pair_supported", "hfcl_last_kernel_breakdown", "hfcl_last_bucket_counts", "hfcl_lib_set_split", "hfcl_lib_get_split", "hfcl_lib_last_split_parts",
     "hfcl_collide_batch_qt", "hfcl_distance_batch_qt", "hfcl_lib_set_host_chunk", "hfcl_lib_set_shapes",
-    "hfcl_lib_set_convex_neighbors",
+    "hfcl_lib_set_convex_neighbors", "hfcl_compact_results_device", "hfcl_compact_results_device_f32",
 ]
 
 
@@ -265,6 +265,11 @@ class Library:
         _check(dll().hfcl_collide_batch_device_f32(self._h, _dptr(d_s1), _dptr(d_s2), _dptr(d_pose1),
                                                     _dptr(d_pose2), C.c_size_t(n), C.byref(req), _dptr(d_out),
                                                     C.c_void_p(stream)))
+
+    def compact_results_device(self, d_records, n, d_out, f32=False, stream=0):
+        """Full device records -> hfcl_result_compact{,_f32} records (24 / 8 B): the multi-GPU exchange format."""
+        fn = dll().hfcl_compact_results_device_f32 if f32 else dll().hfcl_compact_results_device
+        _check(fn(self._h, _dptr(d_records), C.c_size_t(n), _dptr(d_out), C.c_void_p(stream)))
 
     # ---- instrumentation ----
     def set_split(self, parts):

@@ -156,7 +156,9 @@ def make_pose(R=None, T=None, quat=None):
     if T is None:
         T = np.zeros(R.shape[:-2] + (3,))
     T = np.asarray(T, dtype=np.float64)
-    out = np.empty(R.shape[:-2] + (12,), dtype=np.float64)
+    batch = np.broadcast_shapes(R.shape[:-2], T.shape[:-1])  # one rotation for many translations, or the reverse
+    R = np.broadcast_to(R, batch + (3, 3))
+    out = np.empty(batch + (12,), dtype=np.float64)
     out[..., 0:9] = np.swapaxes(R, -1, -2).reshape(R.shape[:-2] + (9,))  # column-major
     out[..., 9:12] = T
     return out

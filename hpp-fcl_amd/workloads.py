@@ -264,6 +264,42 @@ def hull_adjacency(points):
     return offs, edges[:, 1].astype(np.uint32)
 
 
+def subdivided_box(m=11, half=(1.0, 1.0, 1.0)):
+    """A box whose faces are m x m grids of points, triangulated: (points, offsets, ids).  Most of its points are NOT
+    extreme -- they lie inside a flat facet or an edge, with every neighbour in that facet's plane -- which is what a
+    meshed CAD part handed to Convex<Triangle> looks like (m = 11: 602 points, above the hill-climb threshold)."""
+    idx = {}
+    pts = []
+    for i in range(m):
+        for j in range(m):
+            for k in range(m):
+                if i in (0, m - 1) or j in (0, m - 1) or k in (0, m - 1):
+                    idx[(i, j, k)] = len(pts)
+                    pts.append([half[0] * (2.0 * i / (m - 1) - 1), half[1] * (2.0 * j / (m - 1) - 1), half[2] * (2.0 * k / (m - 1) - 1)])
+    nb = [set() for _ in pts]
+
+    def edge(a, b):
+        nb[a].add(b)
+        nb[b].add(a)
+
+    for axis in range(3):
+        for side in (0, m - 1):
+            for u in range(m - 1):
+                for w in range(m - 1):
+                    def at(du, dw):
+                        c = [0, 0, 0]
+                        c[axis] = side
+                        c[(axis + 1) % 3] = u + du
+                        c[(axis + 2) % 3] = w + dw
+                        return idx[tuple(c)]
+                    a, b, c, d = at(0, 0), at(1, 0), at(1, 1), at(0, 1)
+                    for x, y in ((a, b), (b, c), (c, d), (d, a), (a, c)):  # two triangles per grid cell
+                        edge(x, y)
+    offs = np.zeros(len(pts) + 1, dtype=np.uint32)
+    offs[1:] = np.cumsum([len(x) for x in nb])
+    return np.array(pts), offs, np.array([v for x in nb for v in sorted(x)], dtype=np.uint32)
+
+
 def register_adjacency(library, shapes, verts, min_points=33):
     """hull_adjacency for every convex shape of at least `min_points` vertices of a shape table, registered with the
     engine library.  Returns the number of shapes registered."""

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HFCL_ABI_VERSION 2
+#define HFCL_ABI_VERSION 3
 
 /* ---- geometry kinds: numeric values are hpp-fcl's NODE_TYPE
  *      (include/hpp/fcl/collision_object.h:65-89) so a caller can pass
@@ -164,6 +164,23 @@ typedef struct hfcl_result_f32 {
   uint32_t status;
 } hfcl_result_f32;
 
+/* Compact records: what a caller that only folds the answers (CollisionResult::isCollision(), numContacts(),
+ * distance_lower_bound, Contact::b1 / b2 -- collision_data.h:391-494; DistanceResult::min_distance, b1, b2 --
+ * :1053-1090) needs of a record, without the witness points and the normal.  They exist for the multi-GPU exchange:
+ * an all-gather of full records moves 96 B (44 B fp32) per pair to every rank, which at the measured rates is as long
+ * as the compute step itself on 8 GPUs; the compact form is 24 B (8 B).  Produced on the device from
+ * full records by hfcl_compact_results_device{,_f32}; every field is a bit copy of the full record's field. */
+typedef struct hfcl_result_compact {
+  double   distance;
+  int32_t  b1, b2;
+  uint32_t status;
+  int32_t  num_contacts;
+} hfcl_result_compact;      /* 24 bytes */
+typedef struct hfcl_result_compact_f32 {
+  float    distance;
+  uint32_t status;
+} hfcl_result_compact_f32;  /* 8 bytes */
+
 /* Warm-start cache (QueryRequest::cached_gjk_guess / cached_support_func_guess flowing
  * request -> solver -> result -> request, src/collision.cpp:125-127). Optional arrays. */
 typedef struct hfcl_guess {
@@ -221,7 +238,9 @@ int hfcl_lib_set_shapes(hfcl_lib* lib, const hfcl_shape* shapes, size_t n_shapes
  * indices relative to the shape's first vertex.  A hull of at least HFCL_CLIMB_MIN (default 512, environment) vertices
  * that has one answers GJK / EPA support queries by neighbour hill-climbing from the previous answer, as
  * getShapeSupportLog does (src/narrowphase/support_functions.cpp:323-397), instead of scanning every vertex; smaller
- * hulls and hulls without adjacency are unaffected.  hfcl_lib_set_shapes drops all registered adjacencies. */
+ * hulls and hulls without adjacency are unaffected.  hfcl_lib_set_shapes drops all registered adjacencies.
+ * The device image is (re)built by the first batch after a registration; that batch waits for the device once (batches
+ * of other streams may still be reading the previous image). */
 int hfcl_lib_set_convex_neighbors(hfcl_lib* lib, uint32_t shape_id, const uint32_t* offsets,
                                   const uint32_t* neighbors);
 void      hfcl_lib_destroy(hfcl_lib* lib);
@@ -341,6 +360,12 @@ int hfcl_collide_batch_device_f32(hfcl_lib* lib, const uint32_t* d_shape1, const
                                   const float* d_pose1, const float* d_pose2, size_t n,
                                   const hfcl_collision_request* req, hfcl_result_f32* d_out,
                                   void* stream);
+
+/* Device-resident full records -> compact records (see hfcl_result_compact); asynchronous on `stream`. */
+int hfcl_compact_results_device(hfcl_lib* lib, const hfcl_result* d_records, size_t n,
+                                hfcl_result_compact* d_out, void* stream);
+int hfcl_compact_results_device_f32(hfcl_lib* lib, const hfcl_result_f32* d_records, size_t n,
+                                    hfcl_result_compact_f32* d_out, void* stream);
 
 /* Mesh-mesh collide with more than one contact: per-pair records as above plus a
  * compacted contact list (capacity max_contacts_total; *n_contacts_out receives the

@@ -2,7 +2,7 @@
 import numpy as np
 
 
-def check_parity(abi, got, ref, *, dist_tol, point_tol, flag_band, name="", allow_bad_frac=0.0, fp32=False):
+def check_parity(abi, got, ref, *, dist_tol, point_tol, flag_band, name="", allow_bad_frac=0.0, fp32=False, collect_only=False):
     """got/ref: result record arrays (RESULT_DTYPE or RESULT_F32_DTYPE).  Asserts:
        - contact flags, GJK status and EPA status equal, except where |d_ref| <= flag_band
          (decision boundary) -- bit-exact integer outputs;
@@ -44,6 +44,9 @@ def check_parity(abi, got, ref, *, dist_tol, point_tol, flag_band, name="", allo
                  nan_mismatch=int(bad_nan.sum()), sep_bad=int(bad_sep.sum()),
                  max_dd=float(dd.max()) if n else 0.0,
                  p999_dd=float(np.quantile(dd, 0.999)) if n else 0.0, max_dsep=float(dsep.max()) if n else 0.0)
+    if collect_only:  # the caller enumerates the violating records itself (per-record masks instead of assertions)
+        stats.update(flag_bad_mask=bad_flags, dist_bad_mask=bad_d, nan_bad_mask=bad_nan, sep_bad_mask=bad_sep)
+        return stats
     allowed = int(allow_bad_frac * n)
     assert stats["flag_mismatch"] <= allowed, "%s: contact flags differ outside the decision band: %s" % (name, stats)
     assert stats["dist_bad"] <= allowed, "%s: distances out of tolerance: %s" % (name, stats)

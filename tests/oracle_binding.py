@@ -229,20 +229,28 @@ def bruteforce_pairs(aabbs):
     return out
 
 
-def register_hull_neighbors(shapes, verts):
+def register_hull_neighbors(shapes, verts, graphs=None):
     """ConvexBase::neighbors for every hull of >= 32 vertices, as Convex<Triangle>::fillNeighbors builds them
     (details/convex.hxx:231-280: per vertex the ascending set of vertices sharing a face edge) from the facets
-    scipy's Qhull wrapper reports -- the oracle's hill-climbing support (getShapeSupportLog) walks them."""
+    scipy's Qhull wrapper reports -- the oracle's hill-climbing support (getShapeSupportLog) walks them.
+    graphs: {shape index: (offsets, ids)} -- adjacency given by the caller (a triangulated surface whose points are not
+    all extreme, which Qhull would not report) instead of the Qhull facets."""
     from scipy.spatial import ConvexHull
     abi = _pkg().abi
     L = lib()
     L.orc_clear_neighbors()
     verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
     keep = []
-    for s in shapes:
+    for si, s in enumerate(shapes):
         if s["type"] != abi.GEOM_CONVEX or s["num_points"] < 32:
             continue
         off, n = int(s["vertex_offset"]), int(s["num_points"])
+        if graphs is not None and si in graphs:
+            offs = np.ascontiguousarray(graphs[si][0], dtype=np.uint32)
+            ids = np.ascontiguousarray(graphs[si][1], dtype=np.uint32)
+            keep.append((offs, ids))
+            L.orc_register_neighbors(C.c_uint32(off), C.c_void_p(offs.ctypes.data), C.c_uint32(n), C.c_void_p(ids.ctypes.data))
+            continue
         hull = ConvexHull(verts[off:off + n])
         assert len(hull.vertices) == n, "every point must be a hull vertex"
         nb = [set() for _ in range(n)]

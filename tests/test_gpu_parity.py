@@ -26,7 +26,7 @@ def _engine(pkg, b, req):
 
 def test_native_library_is_loaded(pkg):
     assert pkg.engine.device_count() >= 1
-    assert pkg.engine.dll().hfcl_abi_version() == 2
+    assert pkg.engine.dll().hfcl_abi_version() == 3
 
 
 @pytest.mark.parametrize("case,n", [("cfg1_sphere_sphere", 1000), ("cfg2_box_capsule", 100000),
@@ -211,8 +211,11 @@ def test_edge_cases(pkg, oracle):
         assert np.abs(gt["distance"] - rt["distance"]).max() < 1e-9
         sg, sr = gt["p2"] - gt["p1"], rt["p2"] - rt["p1"]
         assert np.all(np.minimum(np.abs(sg - sr).max(axis=1), np.abs(sg + sr).max(axis=1)) < 1e-5)
-    one = lib.distance(s1[:1], s2[:1], tf1[:1], tf2[:1])  # a batch of one pair gives the record it has in the big batch
-    assert one.tobytes() == got[:1].tobytes() if kind == "distance" else True
+        # a batch of one pair gives, byte for byte, the record that pair has in the big batch (first, a middle and the last pair)
+        run1 = lib.distance if kind == "distance" else lib.collide
+        for k in (0, 55, 2500, n - 1):
+            one = run1(s1[k:k + 1], s2[k:k + 1], tf1[k:k + 1], tf2[k:k + 1])
+            assert one.tobytes() == got[k:k + 1].tobytes(), (kind, k)
     # unsupported pair kinds are reported, not silently computed
     Lb = pkg.ShapeLibrary()
     t = Lb.add_triangle([0, 0, 0], [1, 0, 0], [0, 1, 0])
@@ -246,10 +249,48 @@ def test_fp32_device_path(pkg, oracle, torch_cuda, case):
     fn(d_s1, d_s2, d_p1, d_p2, len(b), req, d_out, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     got = d_out.cpu().numpy().view(abi.RESULT_F32_DTYPE)
-    check_parity(abi, got, ref, dist_tol=1e-4, point_tol=5e-4, flag_band=1e-4, name=case + "-f32", fp32=True,
-                 allow_bad_frac=2e-5)
+    # No blanket allowance.  One class of records is excused, enumerated and checked for its stated reason: a polytope
+    # with two near-equidistant closest faces, where fp32 EPA ends on the other one.  Depth and flags must still be inside
+    # the envelope; only the separation DIRECTION may differ, and it must be one that realises the same penetration depth
+    # (overlap of the two shapes along the GPU's normal, evaluated in fp64 from the shapes, within the envelope of the
+    # oracle's depth).  At most 4 such records in a batch (the 2M-pair soak finds 1 per million).
+    bad = check_parity(abi, got, ref, dist_tol=1e-4, point_tol=5e-4, flag_band=1e-4, name=case + "-f32", fp32=True,
+                       collect_only=True)
+    excused = bad["sep_bad_mask"] & ~bad["flag_bad_mask"] & ~bad["dist_bad_mask"] & ~bad["nan_bad_mask"]
+    assert excused.sum() <= 4, "%s: %d records outside the fp32 envelope: %s" % (case, excused.sum(), np.flatnonzero(excused)[:20])
+    for k in np.flatnonzero(excused):
+        assert abi.status_contact(ref["status"][k]) == 1, "only penetrating pairs (EPA) are excused"
+        nrm = got["normal"][k].astype(np.float64)
+        ext = _overlap_extent(abi, b, k, tf1[k], tf2[k], nrm / np.linalg.norm(nrm))
+        d = abs(float(ref["distance"][k]))
+        assert abs(ext - d) <= 1e-4 * (1 + d), "record %d: the GPU's normal does not realise the oracle's depth (%g vs %g)" % (k, ext, d)
+    check_parity(abi, got[~excused], ref[~excused], dist_tol=1e-4, point_tol=5e-4, flag_band=1e-4, name=case + "-f32", fp32=True)
     check_properties(abi, got, tol=2e-4, name=case + "-f32")
     lib.close()
+
+
+def _support(abi, b, shape_id, R, T, n):
+    """max over the posed shape of x . n (fp64, from the shape table): Box / Capsule / Convex."""
+    sh = b.shapes[shape_id]
+    nl = R.T @ n
+    p = sh["params"]
+    if sh["type"] == abi.GEOM_BOX:
+        v = np.sign(nl) * p[:3]
+    elif sh["type"] == abi.GEOM_CAPSULE:
+        v = np.array([0, 0, np.sign(nl[2]) * p[1]]) + p[0] * nl / np.linalg.norm(nl)
+    else:
+        assert sh["type"] == abi.GEOM_CONVEX
+        V = b.verts[sh["vertex_offset"]:sh["vertex_offset"] + sh["num_points"]]
+        v = V[np.argmax(V @ nl)]
+    return float((R @ v + T) @ n)
+
+
+def _overlap_extent(abi, b, k, tf1, tf2, n):
+    """Length of the overlap of the two posed shapes of pair k along the unit direction n (from shape 1 to shape 2): the
+    penetration depth is the minimum of this over all directions."""
+    g = __import__("hppfcl_amd").geometry
+    R1, T1, R2, T2 = g.pose_R(tf1), g.pose_T(tf1), g.pose_R(tf2), g.pose_T(tf2)
+    return _support(abi, b, b.s1[k], R1, T1, n) + _support(abi, b, b.s2[k], R2, T2, -n)
 
 
 @pytest.mark.parametrize("case", ["cfg2_box_capsule", "cfg3_convex_convex"])
@@ -412,6 +453,29 @@ def test_bvh_collide_first_contact(pkg, oracle, seg, n, steal, monkeypatch):
     _check_bvh_records(abi, got, ref, "bvh-first-%d" % seg)
     frac = (ref["num_contacts"] > 0).mean()
     assert 0.2 < frac < 0.8, frac
+
+
+@pytest.mark.parametrize("n", [100_000, 250_000])
+def test_bvh_collide_baseline_size(pkg, oracle, n):
+    """BASELINE.json configs[3] at its size: 100k mesh pairs of 5 000-triangle models (the batch form the host picks for
+    it: queries cut at 512 steps, remainders as levels of tasks), and a 250k-query batch (beyond the ~196k queries up to
+    which bvh_auto splits: the unsplit streaming form).  Every record against the oracle: contact counts, first-contact
+    triangle ids in DFS order, depth and witness data."""
+    abi, wl = pkg.abi, pkg.workloads
+    b = wl.cfg4_mesh_mesh(n=n)
+    assert len(b.meshes) == 8 and all(len(m.triangles) == 5000 for m in b.meshes)
+    req = wl.make_request(b, abi)
+    ML = pkg.bvh_builder.MeshLibrary(b.meshes)
+    lib = wl.make_library(pkg, b)
+    try:
+        got = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
+        again = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
+    finally:
+        lib.close()
+    assert got.tobytes() == again.tobytes()  # no scheduling-dependent choice in either form
+    ref = oracle.bvh_collide_batch(ML, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=32)
+    _check_bvh_records(abi, got, ref, "bvh-cfg4-%d" % n)
+    assert 0.2 < (ref["num_contacts"] > 0).mean() < 0.8
 
 
 def test_bvh_collide_all_contacts(pkg, oracle):
@@ -624,3 +688,65 @@ def test_large_hulls_gpu(pkg, oracle, kind, support, monkeypatch):
     st = check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name="large-" + kind)
     assert st["p999_dd"] < 1e-9, st
     check_properties(abi, got, tol=1e-6, name="large-" + kind)
+
+
+@pytest.mark.parametrize("kind", ["distance", "collide"])
+def test_hill_climb_on_flat_triangulated_facets(pkg, oracle, kind):
+    """A subdivided box (602 points, most of them inside a flat facet with all their neighbours in the facet's plane) climbed
+    along axis-aligned directions: every neighbour of such a point ties, and along the facet's inward normal none improves
+    although the facet is the hull's minimum.  The reference walks over equal neighbours (loose_check,
+    support_functions.cpp:368-382); the device answers that plateau with the scan.  Axis-aligned placements (identity
+    rotations: GJK's directions stay on the axes) and random poses, against the analytic box distance, the oracle's
+    hill-climb and the device's own scan."""
+    abi, wl, g = pkg.abi, pkg.workloads, pkg.geometry
+    pts, offs, ids = wl.subdivided_box(11)
+    assert len(pts) >= 512
+    L = pkg.ShapeLibrary()
+    hull, sph, box = L.add_convex(pts), L.add_sphere(0.5), L.add_box(1.0, 1.0, 1.0)
+    rng = np.random.default_rng(17)
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=np.float64)
+    offsets = np.concatenate([axes * d for d in (3.0, 2.0, 1.6, 1.2, 0.7)])  # separated ... deeply penetrating
+    n_ax = len(offsets)
+    n = n_ax * 4 + 4000
+    s1 = np.full(n, hull)
+    s2 = np.where(np.arange(n) % 2 == 0, sph, box)
+    tf1, tf2 = g.make_pose(T=np.zeros((n, 3))), g.make_pose(T=np.zeros((n, 3)))
+    for rep in range(4):  # hull first / second, sphere / box as the other shape
+        sl = slice(rep * n_ax, (rep + 1) * n_ax)
+        tf2[sl] = g.make_pose(T=offsets)
+        s2[sl] = sph if rep < 2 else box
+    sw = slice(n_ax, 2 * n_ax), slice(3 * n_ax, 4 * n_ax)
+    for sl in sw:  # operands exchanged: the hull is shape 2
+        s1[sl], s2[sl] = s2[sl].copy(), hull
+        tf1[sl], tf2[sl] = tf2[sl].copy(), g.make_pose(T=np.zeros((n_ax, 3)))
+    q = rng.normal(size=(4000, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    tf2[4 * n_ax:] = g.make_pose(quat=q, T=rng.uniform(-2.2, 2.2, (4000, 3)))
+    req = abi.default_distance_request() if kind == "distance" else abi.default_collision_request()
+    S, V = L.shapes_array(), L.vertices_array()
+    oracle.register_hull_neighbors(S, V, graphs={int(hull): (offs, ids)})
+    try:
+        ofn = oracle.distance_batch if kind == "distance" else oracle.collide_batch
+        ref = ofn(S, V, s1, s2, tf1, tf2, req, n_threads=8)
+    finally:
+        oracle.lib().orc_clear_neighbors()
+    outs = {}
+    for mode in ("climb", "scan"):
+        lib = pkg.Library(L, device=0)
+        try:
+            if mode == "climb":
+                lib.set_convex_neighbors(hull, offs, ids)
+            run = lib.distance if kind == "distance" else lib.collide
+            outs[mode] = run(s1, s2, tf1, tf2, req)
+            assert lib.last_bucket_counts()["large"] == n
+        finally:
+            lib.close()
+    # analytic: a sphere of radius 0.5 whose centre sits at distance t on an axis from a unit-half-side box: t - 1 - 0.5
+    for rep in (0, 1):
+        sl = slice(rep * n_ax, (rep + 1) * n_ax)
+        want = np.linalg.norm(offsets, axis=1) - 1.5
+        for mode in outs:
+            assert np.abs(outs[mode]["distance"][sl] - want).max() < 1e-6, (mode, rep)
+    for mode in outs:
+        check_parity(abi, outs[mode], ref, dist_tol=1e-6, point_tol=2e-5, flag_band=1e-9, name="subdivided-box-" + mode)
+    assert np.abs(outs["climb"]["distance"] - outs["scan"]["distance"]).max() < 1e-9

@@ -1,0 +1,126 @@
+"""The N > 1 path: launcher, ragged shards, padded all-gather, exchange formats.
+
+CPU: bench.py's launcher and multigpu.RecordExchange over gloo with two spawned ranks.
+GPU (-m gpu): the REAL bench.py code path with two ranks sharing device 0 over gloo (RCCL refuses duplicate devices): what
+the ranks gather must equal, byte for byte, the records of the whole list computed by one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rank_command_is_the_documented_launch(pkg):
+    cmd = pkg.multigpu.rank_command("bench.py", ["--gpus", "8"], 8, port=29999, python="python")
+    assert cmd == ["python", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                   "--master-port", "29999", "bench.py", "--gpus", "8"]
+    assert pkg.multigpu.device_of_rank(3) == 3
+    assert [pkg.multigpu.device_of_rank(r, "0,0") for r in range(2)] == [0, 0]
+
+
+def test_spawned_ranks_exchange_cpu(pkg, tmp_path):
+    out = str(tmp_path / "gathered.npy")
+    rc = pkg.multigpu.spawn_ranks(os.path.join(ROOT, "tests", "multigpu_worker.py"), [out, "1001"], 2, timeout=300)
+    assert rc == 0
+    ok, world, recv = np.load(out)
+    assert ok == 1 and world == 2
+    assert recv == 501 * 96  # a rank receives the other rank's padded shard: ceil(1001 / 2) records of 96 B
+
+
+def test_compact_records_host_image(pkg):
+    abi = pkg.abi
+    r = np.zeros(5, dtype=abi.RESULT_DTYPE)
+    r["distance"] = np.arange(5) - 2.5
+    r["b1"], r["b2"], r["status"], r["num_contacts"] = 7, -1, 0x80 | 3, 1
+    c = abi.compact_records(r)
+    assert c.dtype.itemsize == 24 and np.array_equal(c["distance"], r["distance"]) and np.all(c["status"] == 0x83)
+    f = np.zeros(3, dtype=abi.RESULT_F32_DTYPE)
+    f["distance"], f["status"] = 1.5, 5
+    assert abi.compact_records(f).dtype.itemsize == 8
+
+
+def test_bench_refuses_missing_gpus_instead_of_hanging():
+    """`python bench.py --gpus 2` as a plain process is the launcher; without enough devices it says so and exits != 0."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two devices present")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "GPU(s) visible" in (p.stderr + p.stdout)
+
+
+def _bench(args, timeout=900):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gather", ["full", "compact"])
+def test_two_ranks_on_one_gpu_strong_cfg5(torch_cuda, gather):
+    """One ragged broadphase pair list cut over 2 ranks (sharding.shard_range), records exchanged: the gathered buffer
+    equals the single-rank records of the whole list byte for byte (full and 24-B compact form)."""
+    line = _bench(["--gpus", "2", "--backend", "gloo", "--device-map", "0,0", "--workload", "cfg5", "--scaling", "strong",
+                   "--pairs", "100001", "--steps", "3", "--warmup", "1", "--gather", gather, "--verify-gather",
+                   "--no-cpu-baseline"])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert cfg["shard"] == [0, 50001] and cfg["pairs_per_step_all_gpus"] == 100001
+    assert cfg["gather"] == gather and cfg["all_gather_results"] is True
+    assert cfg["gather_check"] == {"block_checksums": True, "equals_single_rank_run": True}
+    words = 6 if gather == "compact" else 24
+    assert cfg["gather_bytes_per_rank_per_step"] == {"sent": 50001 * words * 4, "received": 50001 * words * 4}
+    assert line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_weak_cfg3(torch_cuda):
+    """The headline's N > 1 form: own batch per rank, fp32 records all-gathered; block checksums of both ranks agree."""
+    line = _bench(["--gpus", "2", "--backend", "gloo", "--device-map", "0,0", "--workload", "cfg3", "--pairs", "65537",
+                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and cfg["pairs_per_step_all_gpus"] == 2 * 65537
+    assert cfg["gather_check"]["block_checksums"] is True
+    assert cfg["gather_bytes_per_rank_per_step"]["received"] == 65537 * 44
+
+
+@pytest.mark.gpu
+def test_compact_records_device(torch_cuda, pkg):
+    """hfcl_compact_results_device{,_f32}: every field of a compact record is a bit copy of the full record's."""
+    torch = torch_cuda
+    abi, wl = pkg.abi, pkg.workloads
+    b = wl.cfg5_mixed(n=30011, seed=3)
+    req = wl.make_request(b, abi)
+    lib = pkg.Library(b.lib, device=0)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    out = torch.zeros(len(b) * 24, dtype=torch.int32, device=dev)
+    lib.collide_device(t(b.s1.astype(np.int32)), t(b.s2.astype(np.int32)), t(b.tf1), t(b.tf2), len(b), req, out)
+    comp = torch.zeros(len(b) * 6, dtype=torch.int32, device=dev)
+    lib.compact_results_device(out, len(b), comp)
+    torch.cuda.synchronize()
+    full = out.cpu().numpy().view(abi.RESULT_DTYPE)
+    got = comp.cpu().numpy().view(abi.RESULT_COMPACT_DTYPE)
+    assert got.tobytes() == abi.compact_records(full).tobytes()
+    b3 = wl.cfg3_convex_convex(n=20003, seed=2)
+    lib3 = pkg.Library(b3.lib, device=0)
+    out3 = torch.zeros(len(b3) * 11, dtype=torch.int32, device=dev)
+    lib3.distance_device_f32(t(b3.s1.astype(np.int32)), t(b3.s2.astype(np.int32)), t(b3.pose1_f32), t(b3.pose2_f32), len(b3),
+                             wl.make_request(b3, abi), out3)
+    comp3 = torch.zeros(len(b3) * 2, dtype=torch.int32, device=dev)
+    lib3.compact_results_device(out3, len(b3), comp3, f32=True)
+    torch.cuda.synchronize()
+    assert comp3.cpu().numpy().view(abi.RESULT_COMPACT_F32_DTYPE).tobytes() == \
+        abi.compact_records(out3.cpu().numpy().view(abi.RESULT_F32_DTYPE)).tobytes()
+    lib.close()
+    lib3.close()

@@ -3,6 +3,8 @@ test-suite.  Each test cites the reference test it restates.  CPU
 import numpy as np
 import pytest
 
+from kat_solver import oracle  # noqa: F401 -- every test below runs on the oracle AND (-m gpu) on the HIP path
+
 SQ2 = np.sqrt(2.0)
 
 

@@ -4,6 +4,8 @@ test/geometric_shapes.cpp:595-842 (collide flags + contact normals) and :3830-40
 import numpy as np
 import pytest
 
+from kat_solver import oracle  # noqa: F401 -- every test below runs on the oracle AND (-m gpu) on the HIP path
+
 TOL_GJK = 0.01  # test/geometric_shapes.cpp:55
 
 

@@ -6,6 +6,8 @@ common rigid transform.  CPU only."""
 import numpy as np
 import pytest
 
+from kat_solver import oracle  # noqa: F401 -- every test below runs on the oracle AND (-m gpu) on the HIP path
+
 
 def _coll(oracle, L, a, b, tf1, tf2):
     return oracle.collide_batch(L.shapes_array(), L.vertices_array(), [a], [b], [tf1], [tf2], None)[0]
