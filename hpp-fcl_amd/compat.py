@@ -434,7 +434,7 @@ class _Context:
             return ("bvh", id(g._mesh))
         vals = []
         for k, v in sorted(vars(g).items()):
-            if k != "polygons":
+            if k not in ("polygons", "_nb_cache"):  # (the cached adjacency is derived from the polygons)
                 vals.append((k, np.asarray(v, dtype=np.float64).tobytes() if not isinstance(v, list) else None))
         return (type(g).__name__, tuple(vals))
 

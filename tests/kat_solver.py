@@ -42,7 +42,14 @@ class GpuSolver:
         lib = self._lib(shapes, verts)
         tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
         tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
-        return getattr(lib, which)(np.asarray(s1), np.asarray(s2), tf1, tf2, req)
+        try:
+            return getattr(lib, which)(np.asarray(s1), np.asarray(s2), tf1, tf2, req)
+        except self.pkg.EngineError as e:
+            # the C ABI reports what the reference throws as std::invalid_argument (collision.cpp:82-85,95-100) as error
+            # codes; the oracle binding raises ValueError for them, like include/hppfcl_amd_compat.hpp rethrows
+            if e.code in (self.pkg.abi.ERR_INVALID_ARGUMENT, self.pkg.abi.ERR_UNSUPPORTED_PAIR):
+                raise ValueError(str(e)) from e
+            raise
 
     def distance_batch(self, shapes, verts, s1, s2, tf1, tf2, req=None, **kw):
         return self._run("distance", shapes, verts, s1, s2, tf1, tf2, req, **kw)
