@@ -8,6 +8,11 @@
 //   triangle support           src/narrowphase/support_functions.cpp:110-134
 #pragma once
 #include "hfcl_pair.hpp"
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <algorithm>
+#include <utility>
+#include <vector>
+#endif
 
 namespace hfcl {
 
@@ -95,6 +100,183 @@ HFCL_HD bool obb_disjoint(const M3<T>& R0, const V3<T>& T0, const DNode<T>& b1, 
   const V3<T> Tv = tmul(b1.axes, Ttemp);
   const M3<T> R = tmul(b1.axes, tmul(R0, b2.axes));  // b1.axes^T * R0^T * b2.axes
   return obb_disjoint_lb(R, Tv, b1.extent, b2.extent, security_margin, break_distance2, sq);
+}
+
+// ---------------------------------------------------------------------------------------
+// fp32 FILTER in front of the fp64 separating-axis test (mesh x mesh collide()).
+//
+// A step of the traversal is a chain of ~300 dependent fp64 instructions on two 128-byte node records.  Nearly all of
+// those tests are decided far from any threshold, so they are evaluated in fp32 on 64-byte records with a rigorous bound
+// on what rounding can have done to every tested quantity, and the fp64 test (obb_disjoint above: the reference's
+// arithmetic) runs only where the fp32 result does not *prove* what the fp64 test would do:
+//   OBBF_OVERLAP   the fp64 test returns "not disjoint" (no check point exceeds break_distance^2): push the children;
+//   OBBF_DISJOINT  the fp64 test returns "disjoint" and the value it reports satisfies nd_lo <= sqrt(sq) <= nd_hi.  The
+//                  caller skips the fp64 test if nd_lo >= its running lower bound (nothing would change); otherwise the pair
+//                  is a candidate for the minimum, whose exact value is computed when something is compared with it;
+//   OBBF_UNSURE    anything else (a tested quantity within the error bound of its threshold, nearly parallel edge axes,
+//                  a node whose third axis is not the cross product of the first two): run the fp64 test.
+// So every decision of the walk, and every number that reaches a record, is the fp64 test's.
+//
+// Error bound (u = 2^-24; S = |To1|_1 + |To2|_1 + |T0|_1, Eb = |a|_1 + |b|_1 + 3|margin|; rotations have unit rows):
+//   stored axes: u per entry, third axis = +-(a0 x a1): <= 8u;   M = R0^T A2: <= 30u;   R = A1^T M: <= 72u per entry
+//   Ttemp = R0^T (To2 - T0) - To1: <= 8u S;   Tv = A1^T Ttemp: <= 32u S
+//   A-axis value |Tv_i| - a_i - sum_j |R_ij| b_j:  <= 40u S + 80u Eb
+//   B-axis value |col_j(R) . Tv| - col_j(|R|) . a - b_j:  <= 190u S + 80u Eb
+//   edge value |Tv_k R_ji - Tv_j R_ki| - (four extent x |R| products):  <= 320u S + 80u Eb;   1 - R_ij^2: <= 150u
+// One bound is used for all of them: delta = 384u (S + Eb) (~2.3e-5 per unit of scene size: 20-100x what rounding
+// actually does, tests/test_device_core_hostsim.py measures both), and OBBF_DELTA_SIN = 256u for the sine terms.
+// ---------------------------------------------------------------------------------------
+struct DNodeF {         // 64 bytes
+  int32_t first_child;  // as DNode
+  uint32_t rank;        // bits 0-29: rank of extent.squaredNorm() (fp64, ties share a rank) among ALL nodes of the library --
+                        // firstOverSecond's size comparison (traversal_node_bvhs.h:160-170) as an exact integer compare;
+                        // bit 31: third axis = -(a0 x a1);  bit 30: never trust the filter on this node
+  float a0[3], a1[3];   // OBB axes 0 and 1 (columns of obb.axes)
+  float To[3];
+  float extent[3];
+  float mag;            // >= |To|_1 + |extent|_1 (rounded up)
+  float pad_;
+};
+constexpr uint32_t OBBF_RANK_MASK = 0x3FFFFFFFu, OBBF_UNSAFE = 0x40000000u, OBBF_LEFT = 0x80000000u;
+enum { OBBF_OVERLAP = 0, OBBF_DISJOINT = 1, OBBF_UNSURE = 2 };
+constexpr float OBBF_U = 5.9604645e-8f;  // 2^-24
+constexpr float OBBF_DELTA = 384.f * OBBF_U, OBBF_DELTA_SIN = 256.f * OBBF_U;
+
+// host side: the filter record of a reference node
+inline DNodeF pack_fnode(const hfcl_bvh_node& n, uint32_t rank) {
+  DNodeF f;
+  f.first_child = n.first_child;
+  const double* a = n.obb_axes;  // column-major: columns = axes
+  const double c[3] = {a[1] * a[5] - a[2] * a[4], a[2] * a[3] - a[0] * a[5], a[0] * a[4] - a[1] * a[3]};  // a0 x a1
+  const double dp = c[0] * a[6] + c[1] * a[7] + c[2] * a[8];
+  const double sgn = dp < 0 ? -1.0 : 1.0;
+  bool safe = true;
+  for (int k = 0; k < 3; ++k) safe = safe && fabs(sgn * c[k] - a[6 + k]) <= 1e-9;  // orthonormal to well below fp32 rounding
+  for (int k = 0; k < 9; ++k) safe = safe && fabs(a[k]) <= 1.0 + 1e-9;
+  const double l0 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], l1 = a[3] * a[3] + a[4] * a[4] + a[5] * a[5];
+  safe = safe && fabs(l0 - 1.0) <= 1e-9 && fabs(l1 - 1.0) <= 1e-9 && fabs(a[0] * a[3] + a[1] * a[4] + a[2] * a[5]) <= 1e-9;
+  f.rank = (rank & OBBF_RANK_MASK) | (sgn < 0 ? OBBF_LEFT : 0u) | (safe ? 0u : OBBF_UNSAFE);
+  double mag = 0;
+  for (int k = 0; k < 3; ++k) {
+    f.a0[k] = float(a[k]);
+    f.a1[k] = float(a[3 + k]);
+    f.To[k] = float(n.obb_To[k]);
+    f.extent[k] = float(n.obb_extent[k]);
+    mag += fabs(n.obb_To[k]) + fabs(n.obb_extent[k]);
+    safe = safe && n.obb_extent[k] >= 0;
+  }
+  if (!(mag < 1e30)) f.rank |= OBBF_UNSAFE;  // NaN / huge: the fp64 test decides
+  f.mag = float(mag) * (1.f + 4.f * OBBF_U) + 1e-37f;
+  f.pad_ = 0.f;
+  return f;
+}
+
+// host side: rank of every node's size (extent.squaredNorm() in fp64, evaluated without contraction like the reference's
+// default build) among all n nodes; equal sizes share a rank, so rank1 > rank2  <=>  size1 > size2
+inline void obbf_size_ranks(const hfcl_bvh_node* nodes, size_t n, uint32_t* rank_out) {
+  std::vector<std::pair<double, uint32_t>> key(n);
+  for (size_t i = 0; i < n; ++i) {
+    const volatile double x = nodes[i].obb_extent[0] * nodes[i].obb_extent[0], y = nodes[i].obb_extent[1] * nodes[i].obb_extent[1],
+                          z = nodes[i].obb_extent[2] * nodes[i].obb_extent[2];  // (volatile: no fused multiply-add)
+    const double sz = (x + y) + z;
+    key[i] = std::make_pair(sz == sz ? sz : 1.7976931348623157e+308, uint32_t(i));  // (NaN would break the sort's ordering)
+  }
+  std::sort(key.begin(), key.end());
+  uint32_t r = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (i > 0 && key[i].first != key[i - 1].first) ++r;
+    rank_out[key[i].second] = r;
+  }
+}
+
+// The filter.  Same argument roles as obb_disjoint: (R0, T0) = pose of OBB 2's frame in OBB 1's frame, b1 / b2 the nodes;
+// t0mag >= |T0|_1; margin = request.security_margin (>= 0 expected; any value is handled), bd2 = break_distance^2.
+HFCL_HD int obb_filter(const M3<float>& R0, const V3<float>& T0, float t0mag, const DNodeF& b1, const DNodeF& b2, float margin,
+                       float bd2, float& nd_lo, float& nd_hi) {
+  nd_lo = 0.f;
+  nd_hi = 3.402823466e+38f;
+  if ((b1.rank | b2.rank) & OBBF_UNSAFE) return OBBF_UNSURE;
+  // axes as rows of A^T: A1[k] = axis k of b1 (a vector); third axis from the first two
+  const V3<float> p0 = mk<float>(b1.a0[0], b1.a0[1], b1.a0[2]), p1 = mk<float>(b1.a1[0], b1.a1[1], b1.a1[2]);
+  const V3<float> q0 = mk<float>(b2.a0[0], b2.a0[1], b2.a0[2]), q1 = mk<float>(b2.a1[0], b2.a1[1], b2.a1[2]);
+  const V3<float> p2 = (b1.rank & OBBF_LEFT) ? cross(p1, p0) : cross(p0, p1);
+  const V3<float> q2 = (b2.rank & OBBF_LEFT) ? cross(q1, q0) : cross(q0, q1);
+  // M_k = R0^T q_k (axis k of b2 in OBB-1-parent frame); R_ij = p_i . M_j
+  const V3<float> m0 = tmul(R0, q0), m1 = tmul(R0, q1), m2 = tmul(R0, q2);
+  const float R[3][3] = {{dot(p0, m0), dot(p0, m1), dot(p0, m2)}, {dot(p1, m0), dot(p1, m1), dot(p1, m2)}, {dot(p2, m0), dot(p2, m1), dot(p2, m2)}};
+  const V3<float> To2 = mk<float>(b2.To[0], b2.To[1], b2.To[2]), To1 = mk<float>(b1.To[0], b1.To[1], b1.To[2]);
+  const V3<float> Ttemp = tmul(R0, To2 - T0) - To1;
+  const float Tc[3] = {dot(p0, Ttemp), dot(p1, Ttemp), dot(p2, Ttemp)};
+  const float hm = 0.5f * margin;
+  const float av[3] = {hmax(b1.extent[0] + hm, 0.f), hmax(b1.extent[1] + hm, 0.f), hmax(b1.extent[2] + hm, 0.f)};
+  const float bv[3] = {hmax(b2.extent[0] + hm, 0.f), hmax(b2.extent[1] + hm, 0.f), hmax(b2.extent[2] + hm, 0.f)};
+  const float delta = OBBF_DELTA * (b1.mag + b2.mag + t0mag + 3.f * habs(margin));
+  const float bd_hi = bd2 * (1.f + 16.f * OBBF_U), bd_lo = bd2 * (1.f - 16.f * OBBF_U);
+  float F[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) F[i][j] = habs(R[i][j]);
+  // ---- A axes: sq = sum_i max(|Tc_i| - a_i - sum_j F_ij b_j, 0)^2
+  {
+    float lo = 0.f, hi = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float v = habs(Tc[i]) - av[i] - (F[i][0] * bv[0] + F[i][1] * bv[1] + F[i][2] * bv[2]);
+      const float l = hmax(v - delta, 0.f), h = hmax(v + delta, 0.f);
+      lo += l * l;
+      hi += h * h;
+    }
+    if (lo > bd_hi) {
+      nd_lo = hsqrt(lo) * (1.f - 8.f * OBBF_U);
+      nd_hi = hsqrt(hi) * (1.f + 8.f * OBBF_U);
+      return OBBF_DISJOINT;
+    }
+    if (!(hi <= bd_lo)) return OBBF_UNSURE;
+  }
+  // ---- B axes: sq = sum_j max(|col_j(R) . Tc| - col_j(F) . a - b_j, 0)^2
+  {
+    float lo = 0.f, hi = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float v = habs(R[0][j] * Tc[0] + R[1][j] * Tc[1] + R[2][j] * Tc[2]) - (F[0][j] * av[0] + F[1][j] * av[1] + F[2][j] * av[2]) - bv[j];
+      const float l = hmax(v - delta, 0.f), h = hmax(v + delta, 0.f);
+      lo += l * l;
+      hi += h * h;
+    }
+    if (lo > bd_hi) {
+      nd_lo = hsqrt(lo) * (1.f - 8.f * OBBF_U);
+      nd_hi = hsqrt(hi) * (1.f + 8.f * OBBF_U);
+      return OBBF_DISJOINT;
+    }
+    if (!(hi <= bd_lo)) return OBBF_UNSURE;
+  }
+  // ---- edge axes A_ia x B_ib, in the reference's order; each decides on its own
+#pragma unroll
+  for (int ia = 0; ia < 3; ++ia) {
+    const int ja = (ia + 1) % 3, ka = (ia + 2) % 3;
+#pragma unroll
+    for (int ib = 0; ib < 3; ++ib) {
+      const int jb = (ib + 1) % 3, kb = (ib + 2) % 3;
+      const float f = F[ia][ib];
+      const float sin2 = 1.f - f * f;
+      // fp64 skips the axis when sinus2 < 1e-6: only provable here when the fp32 value is clear of it on the upper side
+      if (!(sin2 - OBBF_DELTA_SIN >= 1e-6f)) return OBBF_UNSURE;
+      const float s = Tc[ka] * R[ja][ib] - Tc[ja] * R[ka][ib];
+      const float diff = habs(s) - (av[ja] * F[ka][ib] + av[ka] * F[ja][ib] + bv[jb] * F[ia][kb] + bv[kb] * F[ia][jb]);
+      const float dh = diff + delta;
+      if (dh <= 0.f) continue;  // fp64: diff <= 0, the axis does not separate
+      const float dl = diff - delta;
+      const float s_hi = sin2 + OBBF_DELTA_SIN, s_lo = sin2 - OBBF_DELTA_SIN;
+      if (dl > 0.f && dl * dl > bd_hi * s_hi) {
+        nd_lo = dl / hsqrt(s_hi) * (1.f - 8.f * OBBF_U);
+        nd_hi = dh / hsqrt(s_lo) * (1.f + 8.f * OBBF_U);
+        return OBBF_DISJOINT;
+      }
+      if (!(dh * dh <= bd_lo * s_lo)) return OBBF_UNSURE;
+    }
+  }
+  return OBBF_OVERLAP;
 }
 
 // getShapeSupport(TriangleP), support_functions.cpp:110-134

@@ -616,6 +616,7 @@ struct DMesh {
 template <typename T>
 struct BvhView {
   const DNode<T>* nodes;
+  const DNodeF* fnodes;  // filter records of the same nodes (hfcl_bvh.hpp: obb_filter); nullptr: plain fp64 tests
   const DRss<T>* rss;
   const T* verts;        // xyz
   const uint32_t* tris;  // 3 local vertex ids per triangle
@@ -691,7 +692,14 @@ constexpr int BVH_MAX_LEVELS = 12;  // most task levels a batch can be given (HF
 // LDS stack entries per lane of k_bvh_collide.  48 (it was 96): with the witness slab of the leaf GJK the block is 36 KB =
 // 29 allocation units, so that the four blocks of two waves per SIMD fit a CU; a 5000-triangle model needs ~30
 // (depth1 + depth2 + 2), deeper traversals suspend into tasks (HFCL_BVH_LEVELS levels) or take the wide form.
-constexpr int BVH_STACK = 48;
+#ifndef HFCL_BVH_STACK
+#define HFCL_BVH_STACK 48
+#endif
+constexpr int BVH_STACK = HFCL_BVH_STACK;
+#ifndef HFCL_BVH_STACK_FILT
+#define HFCL_BVH_STACK_FILT 26  // 26 x 4 B x 128 lanes + the 12 KB witness slab = 25 600 B = 20 LDS units: six blocks per CU
+#endif
+constexpr int BVH_STACK_FILT = HFCL_BVH_STACK_FILT;
 constexpr int BVH_BLOCK = 128;
 #ifndef HFCL_BVH_REFILL_MIN
 #define HFCL_BVH_REFILL_MIN 8

@@ -136,6 +136,8 @@ struct hfcl_lib {
   bool bvh_dirty = false;
   DNode<double>* d_nodes64 = nullptr;
   DNode<float>* d_nodes32 = nullptr;
+  DNodeF* d_fnodes = nullptr;  // 64-byte records of the fp32 separating-axis filter (fp64 collide)
+  bool bvh_filter = false;     // HFCL_BVH_FILTER=1: the fp32 filter form of k_bvh_collide (exact, measured slower: profiles/r03_b)
   DRss<double>* d_rss64 = nullptr;
   DRss<float>* d_rss32 = nullptr;
   double* d_bverts64 = nullptr;
@@ -391,6 +393,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_SPLIT")) lib->split = atoi(v) >= 2 ? 2 : (atoi(v) == 1 ? 1 : 0);
   if (const char* v = getenv("HFCL_PIPE_CHUNK")) lib->pipe_chunk = strtoull(v, nullptr, 10);
   if (const char* v = getenv("HFCL_BVH_STEAL")) lib->bvh_steal = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_BVH_FILTER")) lib->bvh_filter = atoi(v) != 0;
   if (const char* v = getenv("HFCL_CLIMB_MIN")) lib->climb_min = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_BUDGET")) lib->bvh_budget = lib->bvh_budget0 = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_BUDGET0")) lib->bvh_budget0 = uint32_t(std::max(0, atoi(v)));
@@ -449,6 +452,7 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   if (lib->s_d2h) hipStreamDestroy(lib->s_d2h);
   hipFree(lib->d_nodes64);
   hipFree(lib->d_nodes32);
+  hipFree(lib->d_fnodes);
   hipFree(lib->d_rss64);
   hipFree(lib->d_rss32);
   hipFree(lib->d_bverts64);
@@ -645,10 +649,10 @@ static int make_bvh_spill(hfcl_lib* lib, BvhSpill& sp, bool distance) {
   const size_t need = 2 * size_t(lib->bvh_max_depth) + 4;
   // collide(): a full LDS stack first suspends into tasks (HFCL_BVH_LEVELS levels of BVH_STACK entries); distance() has
   // no task form: anything deeper than its LDS stack takes the wide form with slabs
-  const size_t narrow_holds = distance ? size_t(BVHD_STACK) : size_t(BVH_STACK) * HFCL_BVH_LEVELS;
+  const size_t narrow_holds = distance ? size_t(BVHD_STACK) : size_t(std::min(BVH_STACK, BVH_STACK_FILT)) * HFCL_BVH_LEVELS;
   sp.wide = (lib->bvh_max_nodes > 65535 || need > narrow_holds) ? 1u : 0u;
   if (getenv("HFCL_BVH_FORCE_WIDE")) sp.wide = 1u;  // test knob: the wide form (and its slabs) on small models
-  if (!sp.wide || need <= size_t(BVH_STACK) / 2) return HFCL_OK;  // the LDS stack of the wide form suffices
+  if (!sp.wide || need <= size_t(std::min(BVH_STACK, BVH_STACK_FILT)) / 2) return HFCL_OK;  // the LDS stack of the wide form suffices
   const size_t cap = ((need + 63) / 64) * 64;                     // entries per lane
   const size_t per_block = size_t(BVH_BLOCK) * cap * 2 * sizeof(uint64_t);  // (entry, bound) records: k_bvh_distance
   size_t blocks = std::min<size_t>(size_t(lib->n_cus) * 16, std::max<size_t>(1, (size_t(2) << 30) / per_block));
@@ -757,8 +761,8 @@ static int upload_graph(hfcl_lib* lib) {
 static int upload_bvh(hfcl_lib* lib) {
   if (!lib->bvh_dirty) return HFCL_OK;
   hipFree(lib->d_nodes64); hipFree(lib->d_nodes32); hipFree(lib->d_bverts64); hipFree(lib->d_bverts32);
-  hipFree(lib->d_btris); hipFree(lib->d_meshes); hipFree(lib->d_rss64); hipFree(lib->d_rss32);
-  lib->d_rss64 = nullptr; lib->d_rss32 = nullptr;
+  hipFree(lib->d_btris); hipFree(lib->d_meshes); hipFree(lib->d_rss64); hipFree(lib->d_rss32); hipFree(lib->d_fnodes);
+  lib->d_rss64 = nullptr; lib->d_rss32 = nullptr; lib->d_fnodes = nullptr;
   lib->d_nodes64 = nullptr; lib->d_nodes32 = nullptr; lib->d_bverts64 = nullptr; lib->d_bverts32 = nullptr;
   lib->d_btris = nullptr; lib->d_meshes = nullptr;
   const size_t nn = lib->h_bvh_nodes.size(), nv = lib->h_bvh_verts.size(), nt = lib->h_bvh_tris.size();
@@ -782,6 +786,14 @@ static int upload_bvh(hfcl_lib* lib) {
   }
   std::vector<float> v32(nv);
   for (size_t i = 0; i < nv; ++i) v32[i] = float(lib->h_bvh_verts[i]);
+  {  // filter records: sizes compared through their rank among all nodes of the library (exact, hfcl_bvh.hpp)
+    std::vector<uint32_t> rank(nn);
+    obbf_size_ranks(lib->h_bvh_nodes.data(), nn, rank.data());
+    std::vector<DNodeF> fn(nn);
+    for (size_t i = 0; i < nn; ++i) fn[i] = pack_fnode(lib->h_bvh_nodes[i], rank[i]);
+    HIP_TRY(hipMalloc(&lib->d_fnodes, nn * sizeof(DNodeF)));
+    HIP_TRY(hipMemcpy(lib->d_fnodes, fn.data(), nn * sizeof(DNodeF), hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMalloc(&lib->d_nodes64, nn * sizeof(DNode<double>)));
   HIP_TRY(hipMalloc(&lib->d_nodes32, nn * sizeof(DNode<float>)));
   HIP_TRY(hipMalloc(&lib->d_bverts64, nv * sizeof(double)));
@@ -998,6 +1010,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     if (rc) return rc;
     BvhView<T> bv;
     bv.nodes = std::is_same<T, double>::value ? (const DNode<T>*)lib->d_nodes64 : (const DNode<T>*)lib->d_nodes32;
+    bv.fnodes = (std::is_same<T, double>::value && lib->bvh_filter) ? lib->d_fnodes : nullptr;
     bv.rss = std::is_same<T, double>::value ? (const DRss<T>*)lib->d_rss64 : (const DRss<T>*)lib->d_rss32;
     bv.verts = std::is_same<T, double>::value ? (const T*)lib->d_bverts64 : (const T*)lib->d_bverts32;
     bv.tris = lib->d_btris;
@@ -1015,7 +1028,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       memset(&split, 0, sizeof(split));
       // long traversals are cut into tasks when the batch is large enough for the tail to matter and the request
       // keeps no query-wide contact count
-      if (may(B_BVH) && !spill.wide && (lib->bvh_levels > 1 || lib->bvh_steal) && (n >= 256 || 2 * size_t(lib->bvh_max_depth) + 4 > size_t(BVH_STACK)) &&
+      if (may(B_BVH) && !spill.wide && (lib->bvh_levels > 1 || lib->bvh_steal) && (n >= 256 || 2 * size_t(lib->bvh_max_depth) + 4 > size_t(std::min(BVH_STACK, BVH_STACK_FILT))) &&
           lib->bvh_params.num_max_contacts == 1 && !lib->bvh_params.contacts) {
         rc = ensure_bvh_split(lib, n);
         if (rc) return rc;

@@ -53,12 +53,34 @@ template <> struct BvhEntry<true> {
 #ifndef HFCL_WPE_BVH_COLLIDE
 #define HFCL_WPE_BVH_COLLIDE 2  // two waves per SIMD: the walk waits for its node gathers most of the time (profiles/r02_m)
 #endif
-template <typename T, bool WIDE>
-__global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH_COLLIDE, 8))) k_bvh_collide(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
+// FILT (fp64 only): the separating-axis test runs as an fp32 filter on 64-byte node records (hfcl_bvh.hpp: obb_filter, with
+// its error analysis) and the fp64 test of the reference -- on the 128-byte records, with the relative pose rebuilt from the
+// query's poses -- only where the filter cannot prove what that test would do: 4 % of the steps on cfg4 (3.9 %: a
+// disjoint pair whose value could lower the running bound, i.e. the record lows of the bound; 0.4 %: a quantity within the
+// error bound of its threshold).  A lane that needs the fp64 test parks (like a lane waiting for its leaf test) and the wave
+// runs it for all parked lanes at once.  Decisions and reported numbers are the fp64 test's throughout; the walk's
+// persistent state is the fp32 relative pose (13 registers instead of 24).
+// MEASURED SLOWER than the plain fp64 kernel and therefore off by default (HFCL_BVH_FILTER=1 selects it; profiles/r03_b):
+// cfg4 100k queries 6.9 against 5.3 ms, 1M queries 53 against 68 M q/s.  The fp32 test is ~1.3x the instructions of the
+// fp64 one (bounds, rebuilt third axes) at 1.8x the issue rate, the kernel keeps the registers of its fp64 leaf phase (256:
+// two waves per SIMD either way; forced to three it spills 396 B per lane and takes 10.8 ms), and the step is a gather
+// round trip in both forms.  The walk ALONE (no leaf tests, no fp64 re-tests) fits 152 registers = three waves per SIMD
+// and does 29 G steps/s against the 12 G/s of the full kernel: the headroom is in separating the walk from the fp64
+// phases, not in the arithmetic of the test.
+#ifndef HFCL_WPE_BVH_FILT
+#define HFCL_WPE_BVH_FILT 2
+#endif
+#ifndef HFCL_BVH_PARK_MAX
+#define HFCL_BVH_PARK_MAX 32  // lanes waiting for a leaf test or an fp64 re-test that end the BV phase of a wave
+#endif
+template <typename T, bool WIDE, bool FILT = false>
+__global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(FILT ? HFCL_WPE_BVH_FILT : HFCL_WPE_BVH_COLLIDE, 8))) k_bvh_collide(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
                                                           BvhParams bp, T break_distance2, BvhSplit split, BvhSpill spill) {
+  static_assert(!FILT || sizeof(T) == 8, "the fp32 filter stands in front of the fp64 test");
   typedef BvhEntry<WIDE> EN;
   typedef typename EN::E E;
-  constexpr int STACK = EN::STACK, HALF = EN::STACK / 2;
+  // the filter form is built for three waves per SIMD: six 128-thread blocks per CU = 20 LDS allocation units (25 600 B) each
+  constexpr int STACK = FILT ? (WIDE ? BVH_STACK_FILT / 2 : BVH_STACK_FILT) : EN::STACK, HALF = STACK / 2;
   __shared__ E stack[STACK][BVH_BLOCK];
   __shared__ T w0_slab[W0Lds<T, BVH_BLOCK>::WORDS];  // witness payload of the leaf tests' GJK simplex (hfcl_dev.hpp: W0Lds)
   const W0Lds<T, BVH_BLOCK> leaf_ps{w0_slab + threadIdx.x};
@@ -82,8 +104,19 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   // The poses themselves (leaf tests only: ~5 per query) are re-read there, the witness of the bound (p1, p2, normal:
   // updated a handful of times) lives where it will be read -- the query's record, or the task's summary.
   DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
-  M3<T> RT_R;
-  V3<T> RT_T;
+  typedef typename std::conditional<FILT, float, T>::type TR;  // precision the walk keeps the relative pose in
+  M3<TR> RT_R;
+  V3<TR> RT_T;
+  float t0mag = 0.f;        // FILT: >= |RT_T|_1 (error bound of the filter)
+  // FILT: a lane that needs the fp64 test parks with need_exact = 1 (the pair `pend`, which the filter could not decide)
+  // or 2 (the candidate `cand`: a disjoint pair whose value may be the minimum of the bound, known to [cand_lo, cand_hi];
+  // its fp64 value is computed only when something is compared with it -- a leaf test, a second candidate it cannot be
+  // told apart from, the end of a contact-free walk, a suspension)
+  int need_exact = 0;
+  bool pend_first = false, has_cand = false;
+  E pend = 0, cand = 0;
+  float cand_lo = 0.f, cand_hi = 0.f;
+  const float marginf = float(q.security_margin), bd2f = float(break_distance2);
   int sp = 0;
   bool overflow = false;
   uint32_t ncontacts = 0;
@@ -167,13 +200,19 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
     return true;
   };
   for (;;) {
-    if (WIDE && live && !have_leaf && sp == 0 && nspill > 0) {  // the LDS part ran empty: take spilled entries back
+    if (WIDE && live && !have_leaf && !need_exact && sp == 0 && nspill > 0) {  // the LDS part ran empty: take spilled entries back
       const uint32_t m = min(nspill, uint32_t(HALF));
       for (uint32_t k = 0; k < m; ++k) stack[k][tid] = slab[nspill - m + k];
       nspill -= m;
       sp = int(m);
     }
-    if (live && !have_leaf && sp == 0) {  // traversal over
+    if (FILT && live && !have_leaf && !need_exact && sp == 0 && has_cand) {  // the walk is over: does its bound matter?
+      if (ncontacts == 0 && !overflow)
+        need_exact = 2;  // a contact-free walk reports its bound: the candidate's value is needed
+      else
+        has_cand = false;
+    }
+    if (live && !have_leaf && !need_exact && sp == 0) {  // traversal over
       live = false;
       pending = true;
     }
@@ -220,8 +259,13 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
             m2 = bv.meshes[b.bvh_index];
             {
               const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
-              RT_R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
-              RT_T = tmul(tf1.R, tf2.t - tf1.t);
+              const M3<T> R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
+              const V3<T> t = tmul(tf1.R, tf2.t - tf1.t);
+              RT_R.r0 = mk<TR>(TR(R.r0.x), TR(R.r0.y), TR(R.r0.z));
+              RT_R.r1 = mk<TR>(TR(R.r1.x), TR(R.r1.y), TR(R.r1.z));
+              RT_R.r2 = mk<TR>(TR(R.r2.x), TR(R.r2.y), TR(R.r2.z));
+              RT_T = mk<TR>(TR(t.x), TR(t.y), TR(t.z));
+              if (FILT) t0mag = (habs(float(RT_T.x)) + habs(float(RT_T.y)) + habs(float(RT_T.z))) * (1.f + 4.f * OBBF_U);
             }
             stack[0][tid] = entry;
             sp = 1;
@@ -233,6 +277,8 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
             witness_store(mk<T>(nanv, nanv, nanv), mk<T>(nanv, nanv, nanv), mk<T>(nanv, nanv, nanv));
             fb1 = fb2 = -1;
             have_leaf = false;
+            need_exact = 0;
+            has_cand = false;
             live = true;
           }
         }
@@ -240,22 +286,116 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
       if (base + uint32_t(n_need) >= cnt) exhausted = true;
       continue;
     }
-    // ---- BV phase: advance every lane that has no leaf test pending, until half the wave waits for a
-    // leaf test, nobody can advance, or enough lanes ran out of work to make a refill due
+    // ---- BV phase: advance every lane that has no leaf test (or fp64 re-test) pending, until half the wave waits for
+    // one, nobody can advance, or enough lanes ran out of work to make a refill due
+    // what a BV test's outcome does to the walk (the same for the filter's verdict and the fp64 test's):
+    auto on_disjoint = [&](T sq) {  // updateDistanceLowerBoundFromBV
+      if (!(dlb <= T(0))) {
+        const T nd = hsqrt(sq);
+        if (nd < dlb) {
+          dlb = nd;
+          rec_dist = nd + q.security_margin;
+        }
+      }
+    };
+    auto on_overlap = [&](bool first, uint32_t b1, uint32_t b2, int32_t fc1, int32_t fc2) {
+      E ea, eb;
+      if (first) {
+        const uint32_t c1 = uint32_t(fc1);
+        ea = EN::pack(c1, b2);
+        eb = EN::pack(c1 + 1, b2);
+      } else {
+        const uint32_t c1 = uint32_t(fc2);
+        ea = EN::pack(b1, c1);
+        eb = EN::pack(b1, c1 + 1);
+      }
+      if (WIDE && sp + 2 > STACK && slab && nspill + uint32_t(HALF) <= spill.cap) {
+        // the LDS stack is full: its lower half (the entries needed last) moves to the lane's slab
+        for (int k = 0; k < HALF; ++k) slab[nspill + k] = stack[k][tid];
+        nspill += uint32_t(HALF);
+        for (int k = HALF; k < sp; ++k) stack[k - HALF][tid] = stack[k][tid];
+        sp -= HALF;
+      }
+      if (sp + 2 > STACK) {
+        // the LDS stack is full: the whole stack (and the two children) go on as tasks; only where that is not
+        // possible (contact lists, last level, task table full, slab full) the unit is flagged as overflowed
+        if (!suspend(uint32_t(ea), uint32_t(eb), 2)) {
+          overflow = true;
+          sp = 0;
+          nspill = 0;
+        }
+      } else {
+        stack[sp++][tid] = eb;  // second child below
+        stack[sp++][tid] = ea;  // first child on top
+      }
+    };
     for (;;) {
-      const bool can_bv = live && !have_leaf && sp > 0;
+      const bool can_bv = live && !have_leaf && !need_exact && sp > 0;
       if (!__any(can_bv)) break;
-      if (__popcll(__ballot(have_leaf)) >= 32) break;
-      if (!exhausted && 64 - __popcll(__ballot(live && (have_leaf || sp > 0 || nspill > 0))) >= refill_min) break;
+      if (__popcll(__ballot(have_leaf || need_exact)) >= HFCL_BVH_PARK_MAX) break;
+      if (!exhausted && 64 - __popcll(__ballot(live && (have_leaf || need_exact || sp > 0 || nspill > 0))) >= refill_min) break;
       if (can_bv) {
+        if (FILT && has_cand && budget && steps >= budget) {
+          // about to suspend (step budget): a summary carries an exact bound, so the candidate is resolved first
+          need_exact = 2;
+          continue;
+        }
         if (budget && steps >= budget && suspend(0u, 0u, 0)) continue;
         if (level && (steps & 15u) == 15u && moot(my_parent, my_order)) {  // an earlier sibling ended the walk meanwhile
           sp = 0;
+          has_cand = false;
           continue;
         }
         ++steps;
         const E e = stack[--sp][tid];
         const uint32_t b1 = EN::first(e), b2 = EN::second(e);
+        if constexpr (FILT) {
+          const DNodeF f1 = bv.fnodes[m1.node_off + b1];
+          const DNodeF f2 = bv.fnodes[m2.node_off + b2];
+          const bool l1 = f1.first_child < 0, l2 = f2.first_child < 0;
+          if (l1 && l2) {
+            have_leaf = true;
+            lb1 = uint32_t(-(f1.first_child + 1));
+            lb2 = uint32_t(-(f2.first_child + 1));
+            if (has_cand) need_exact = 2;  // the leaf's distance is compared with the bound: the bound must be exact
+          } else {
+            const bool first = l2 || (!l1 && ((f1.rank & OBBF_RANK_MASK) > (f2.rank & OBBF_RANK_MASK)));  // firstOverSecond
+#if HFCL_BVH_PREFETCH
+            const DNodeF* const next = bv.fnodes + (first ? m1.node_off + uint32_t(f1.first_child) : m2.node_off + uint32_t(f2.first_child));
+            const int32_t touched = next[0].first_child;
+#endif
+            float nd_lo, nd_hi;
+            // argument order of the reference: overlap(RT.R, RT.T, model2.bv(b2), model1.bv(b1))
+            const int verdict = obb_filter(RT_R, RT_T, t0mag, f2, f1, marginf, bd2f, nd_lo, nd_hi);
+#if HFCL_BVH_PREFETCH
+            asm volatile("" ::"v"(touched));
+#endif
+            if (verdict == OBBF_OVERLAP) {
+              if (sp + 2 > STACK && has_cand && !WIDE) {  // this expansion will suspend the unit: candidate first, then again
+                stack[sp++][tid] = e;
+                need_exact = 2;
+              } else {
+                on_overlap(first, b1, b2, f1.first_child, f2.first_child);
+              }
+            } else if (verdict == OBBF_DISJOINT) {
+              if (dlb <= T(0) || T(nd_lo) >= dlb || (has_cand && nd_lo >= cand_hi)) {
+                // the value the fp64 test would report cannot lower the bound: nothing changes
+              } else if (!has_cand || nd_hi < cand_lo) {
+                has_cand = true;  // (a candidate that is certainly above this one is dropped)
+                cand = e;
+                cand_lo = nd_lo;
+                cand_hi = nd_hi;
+              } else {  // two candidates that cannot be told apart: the old one is resolved, this pair is looked at again
+                stack[sp++][tid] = e;
+                need_exact = 2;
+              }
+            } else {
+              need_exact = 1;
+              pend = e;
+              pend_first = first;
+            }
+          }
+        } else {
         const DNode<T> n1 = bv.nodes[m1.node_off + b1];
         const DNode<T> n2 = bv.nodes[m2.node_off + b2];
         const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
@@ -285,45 +425,38 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
           asm volatile("" ::"v"(touched2));
 #endif
 #endif
-          if (disjoint) {  // updateDistanceLowerBoundFromBV
-            if (!(dlb <= T(0))) {
-              const T nd = hsqrt(sq);
-              if (nd < dlb) {
-                dlb = nd;
-                rec_dist = nd + q.security_margin;
-              }
-            }
-          } else {
-            E ea, eb;
-            if (first) {
-              const uint32_t c1 = uint32_t(n1.first_child);
-              ea = EN::pack(c1, b2);
-              eb = EN::pack(c1 + 1, b2);
-            } else {
-              const uint32_t c1 = uint32_t(n2.first_child);
-              ea = EN::pack(b1, c1);
-              eb = EN::pack(b1, c1 + 1);
-            }
-            if (WIDE && sp + 2 > STACK && slab && nspill + uint32_t(HALF) <= spill.cap) {
-              // the LDS stack is full: its lower half (the entries needed last) moves to the lane's slab
-              for (int k = 0; k < HALF; ++k) slab[nspill + k] = stack[k][tid];
-              nspill += uint32_t(HALF);
-              for (int k = HALF; k < sp; ++k) stack[k - HALF][tid] = stack[k][tid];
-              sp -= HALF;
-            }
-            if (sp + 2 > STACK) {
-              // the LDS stack is full: the whole stack (and the two children) go on as tasks; only where that is not
-              // possible (contact lists, last level, task table full, slab full) the unit is flagged as overflowed
-              if (!suspend(uint32_t(ea), uint32_t(eb), 2)) {
-                overflow = true;
-                sp = 0;
-                nspill = 0;
-              }
-            } else {
-              stack[sp++][tid] = eb;  // second child below
-              stack[sp++][tid] = ea;  // first child on top
-            }
-          }
+          if (disjoint)
+            on_disjoint(sq);
+          else
+            on_overlap(first, b1, b2, n1.first_child, n2.first_child);
+        }
+        }
+      }
+    }
+    // ---- fp64 tests (FILT): pairs the filter could not decide, and candidates whose exact value is needed now
+    if constexpr (FILT) {
+      if (need_exact) {
+        const bool is_cand = need_exact == 2;
+        need_exact = 0;
+        const E e = is_cand ? cand : pend;
+        const uint32_t b1 = EN::first(e), b2 = EN::second(e);
+        const DNode<T> n1 = bv.nodes[m1.node_off + b1];
+        const DNode<T> n2 = bv.nodes[m2.node_off + b2];
+        const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+        const M3<T> R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
+        const V3<T> t = tmul(tf1.R, tf2.t - tf1.t);
+        T sq;
+        const bool disjoint = obb_disjoint(R, t, n2, n1, q.security_margin, break_distance2, sq);
+        if (is_cand) {
+          has_cand = false;
+          on_disjoint(sq);  // (the filter proved "disjoint")
+        } else if (disjoint) {
+          on_disjoint(sq);
+        } else if (sp + 2 > STACK && has_cand && !WIDE) {  // this expansion will suspend the unit: candidate first, then again
+          stack[sp++][tid] = e;
+          need_exact = 2;
+        } else {
+          on_overlap(pend_first, b1, b2, n1.first_child, n2.first_child);
         }
       }
     }
@@ -1228,6 +1361,24 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
 // =======================================================================================
 // One level per launch (levels > 0 walk the tasks the level before made), the fold-back launches in reverse order.
 // split.tasks == nullptr (or split.n_levels <= 1): the plain single-pass traversal.
+// one launch of the collide kernel in the form the batch asks for: WIDE (32-bit node ids) or not, with the fp32 filter in
+// front of the fp64 test (fp64 batches of a library whose filter records are uploaded, bv.fnodes) or without
+template <typename T>
+static void launch_collide_kernel(bool wide, int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, const BvhSplit& split, const BvhSpill& spill) {
+  if constexpr (sizeof(T) == 8) {
+    if (bv.fnodes) {
+      if (wide)
+        hipLaunchKernelGGL((k_bvh_collide<T, true, true>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
+      else
+        hipLaunchKernelGGL((k_bvh_collide<T, false, true>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
+      return;
+    }
+  }
+  if (wide)
+    hipLaunchKernelGGL((k_bvh_collide<T, true, false>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
+  else
+    hipLaunchKernelGGL((k_bvh_collide<T, false, false>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
+}
 template <typename T>
 void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill) {
   if (spill.wide) {  // models with 32-bit node ids: single pass, global spill instead of tasks
@@ -1236,7 +1387,7 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
     split.level = 0;
     split.can_suspend = 0;
     if (spill.slab) grid = std::min(grid, int(spill.max_blocks));
-    hipLaunchKernelGGL((k_bvh_collide<T, true>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
+    launch_collide_kernel<T>(true, grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
     return;
   }
   if (split.steal && split.sums && bp.num_max_contacts == 1 && !bp.contacts) {
@@ -1249,7 +1400,7 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
     split.budget = 0;
     split.level = 0;
     split.can_suspend = 0;
-    hipLaunchKernelGGL((k_bvh_collide<T, false>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
+    launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
     return;
   }
   const uint32_t budget = split.budget;
@@ -1258,7 +1409,7 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
     split.budget = l + 1 < split.n_levels ? (l == 0 ? split.budget0 : budget) : 0u;  // the last level runs to the end
     BvhSplit s = split;
     s.can_suspend = l + 1 < split.n_levels;  // ... and cannot suspend (its stack overflows are flagged)
-    hipLaunchKernelGGL((k_bvh_collide<T, false>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, s, spill);
+    launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s, spill);
     hipLaunchKernelGGL(k_bvh_level_mark, dim3(1), dim3(64), 0, st, wk, s);
   }
   for (int l = int(split.n_levels) - 2; l >= 0; --l) {

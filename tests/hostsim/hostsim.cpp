@@ -239,13 +239,24 @@ int sim_batch_f32(const hfcl_shape* shapes, size_t n_shapes, const double* verti
 
 // BVHModel<OBBRSS> collide through the device headers' BV test / leaf test with a serial DFS
 // (same push order and stop rule as k_bvh_collide).  mesh_table: (node_off, n_nodes, vert_off, tri_off).
+// fnodes != nullptr: the walk of k_bvh_collide<double, ., FILT>: the fp32 filter (hfcl_bvh.hpp: obb_filter) decides where it
+// can prove the fp64 test's outcome, the fp64 test runs elsewhere; sizes are compared through the library-wide ranks.
+// fstats (7 counters): BV tests, filter says overlap, filter says disjoint and the bound makes the value irrelevant,
+// disjoint but the exact value is needed, unsure, UNSAFE verdicts (filter contradicted by the fp64 test: must stay 0),
+// rank comparisons that differ from the fp64 size comparison (must stay 0).
 template <typename T>
 static void bvh_pair(const std::vector<DNode<T>>& nodes, const std::vector<T>& verts, const uint32_t* tris,
                      const uint64_t* m1, const uint64_t* m2, const Pose<T>& tf1, const Pose<T>& tf2, const QParams<T>& q,
                      uint32_t num_max_contacts, T break_distance2, hfcl_result& r, std::vector<hfcl_contact>* contacts,
-                     uint32_t pair) {
+                     uint32_t pair, const DNodeF* fnodes = nullptr, uint64_t* fstats = nullptr) {
   const M3<T> RT_R = tmul(tf1.R, tf2.R);
   const V3<T> RT_T = tmul(tf1.R, tf2.t - tf1.t);
+  M3<float> RT_Rf;
+  RT_Rf.r0 = mk<float>(float(RT_R.r0.x), float(RT_R.r0.y), float(RT_R.r0.z));
+  RT_Rf.r1 = mk<float>(float(RT_R.r1.x), float(RT_R.r1.y), float(RT_R.r1.z));
+  RT_Rf.r2 = mk<float>(float(RT_R.r2.x), float(RT_R.r2.y), float(RT_R.r2.z));
+  const V3<float> RT_Tf = mk<float>(float(RT_T.x), float(RT_T.y), float(RT_T.z));
+  const float t0mag = (fabsf(RT_Tf.x) + fabsf(RT_Tf.y) + fabsf(RT_Tf.z)) * (1.f + 4.f * OBBF_U);
   std::vector<uint32_t> stack;
   stack.push_back(0);
   uint32_t nc = 0;
@@ -253,6 +264,22 @@ static void bvh_pair(const std::vector<DNode<T>>& nodes, const std::vector<T>& v
   const T nanv = Lim<T>::nan();
   V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1, nn = np1;
   int fb1 = -1, fb2 = -1;
+  bool has_cand = false;
+  uint32_t cand = 0;
+  float cand_lo = 0.f, cand_hi = 0.f;
+  auto resolve_cand = [&]() {  // the fp64 value of the candidate enters the bound
+    if (!has_cand) return;
+    has_cand = false;
+    const uint32_t c1 = cand & 0xFFFFu, c2 = cand >> 16;
+    T sqc;
+    const bool dj = obb_disjoint(RT_R, RT_T, nodes[m2[0] + c2], nodes[m1[0] + c1], q.security_margin, break_distance2, sqc);
+    ++fstats[3];
+    if (!dj) ++fstats[5];
+    if (!(dlb <= T(0))) {
+      const T nd = hsqrt(sqc);
+      if (nd < dlb) { dlb = nd; rec = nd + q.security_margin; }
+    }
+  };
   while (!stack.empty()) {
     const uint32_t e = stack.back();
     stack.pop_back();
@@ -261,6 +288,7 @@ static void bvh_pair(const std::vector<DNode<T>>& nodes, const std::vector<T>& v
     const DNode<T>& n2 = nodes[m2[0] + b2];
     const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
     if (l1 && l2) {
+      if (fnodes) resolve_cand();  // the leaf's distance is compared with the bound: the bound must be exact
       const uint32_t p1i = uint32_t(-(n1.first_child + 1)), p2i = uint32_t(-(n2.first_child + 1));
       const uint32_t* t1 = tris + 3 * (m1[3] + p1i);
       const uint32_t* t2 = tris + 3 * (m2[3] + p2i);
@@ -291,14 +319,54 @@ static void bvh_pair(const std::vector<DNode<T>>& nodes, const std::vector<T>& v
       continue;
     }
     T sq;
-    if (obb_disjoint(RT_R, RT_T, n2, n1, q.security_margin, break_distance2, sq)) {
+    bool disjoint;
+    if (fnodes) {
+      // the state machine of k_bvh_collide<double, ., true>: a disjoint pair whose value could be the new minimum of the
+      // bound becomes THE candidate (cand, [cand_lo, cand_hi]); its exact value is computed only when something has to be
+      // compared with it (a leaf test, a second candidate it cannot be told apart from, the end of a contact-free walk)
+      float nd_lo, nd_hi;
+      const int v = obb_filter(RT_Rf, RT_Tf, t0mag, fnodes[m2[0] + b2], fnodes[m1[0] + b1], float(q.security_margin),
+                               float(break_distance2), nd_lo, nd_hi);
+      const bool dj64 = obb_disjoint(RT_R, RT_T, n2, n1, q.security_margin, break_distance2, sq);  // (the checker)
+      ++fstats[0];
+      if (v == OBBF_OVERLAP) {
+        ++fstats[1];
+        if (dj64) ++fstats[5];
+        disjoint = false;
+      } else if (v == OBBF_DISJOINT) {
+        if (!dj64 || !(double(hsqrt(sq)) >= double(nd_lo)) || !(double(hsqrt(sq)) <= double(nd_hi))) ++fstats[5];
+        if (dlb <= T(0) || T(nd_lo) >= dlb || (has_cand && nd_lo >= cand_hi)) {
+          ++fstats[2];  // nothing would change: the value is not needed
+        } else if (!has_cand || nd_hi < cand_lo) {
+          has_cand = true;  // (a candidate that is certainly above this one is dropped)
+          cand = e;
+          cand_lo = nd_lo;
+          cand_hi = nd_hi;
+        } else {  // two candidates that cannot be told apart: the old one is resolved, this pair is looked at again
+          resolve_cand();
+          stack.push_back(e);
+        }
+        continue;
+      } else {
+        ++fstats[4];
+        disjoint = dj64;
+      }
+    } else {
+      disjoint = obb_disjoint(RT_R, RT_T, n2, n1, q.security_margin, break_distance2, sq);
+    }
+    if (disjoint) {
       if (!(dlb <= T(0))) {
         const T nd = hsqrt(sq);
         if (nd < dlb) { dlb = nd; rec = nd + q.security_margin; }
       }
       continue;
     }
-    const bool first = l2 || (!l1 && (sqnorm(n1.extent) > sqnorm(n2.extent)));
+    bool first = l2 || (!l1 && (sqnorm(n1.extent) > sqnorm(n2.extent)));
+    if (fnodes) {
+      const bool first_r = l2 || (!l1 && ((fnodes[m1[0] + b1].rank & OBBF_RANK_MASK) > (fnodes[m2[0] + b2].rank & OBBF_RANK_MASK)));
+      if (first_r != first) ++fstats[6];
+      first = first_r;
+    }
     if (first) {
       const uint32_t c1 = uint32_t(n1.first_child);
       stack.push_back((c1 + 1) | (b2 << 16));
@@ -309,6 +377,7 @@ static void bvh_pair(const std::vector<DNode<T>>& nodes, const std::vector<T>& v
       stack.push_back(b1 | (c1 << 16));
     }
   }
+  if (fnodes && nc == 0) resolve_cand();  // a contact-free walk reports its bound
   r.distance = rec;
   r.normal[0] = nn.x; r.normal[1] = nn.y; r.normal[2] = nn.z;
   r.p1[0] = np1.x; r.p1[1] = np1.y; r.p1[2] = np1.z;
@@ -571,10 +640,44 @@ int sim_mesh_shape_distance_f64(const hfcl_shape* shapes, size_t n_shapes, const
   return 0;
 }
 
+// library-wide ranks of the node sizes (extent.squaredNorm(), fp64, ties share a rank) -> filter records; what
+// hfcl_host.hip: upload_bvh builds (the same function is used there)
+static std::vector<DNodeF> make_fnodes(const hfcl_bvh_node* nodes, size_t n_nodes) {
+  std::vector<uint32_t> rank(n_nodes);
+  obbf_size_ranks(nodes, n_nodes, rank.data());
+  std::vector<DNodeF> f(n_nodes);
+  for (size_t i = 0; i < n_nodes; ++i) f[i] = pack_fnode(nodes[i], rank[i]);
+  return f;
+}
+
+static int sim_bvh_collide_impl(const hfcl_bvh_node* nodes, size_t n_nodes, const double* verts, size_t n_verts,
+                        const uint32_t* tris, const uint64_t* mesh_table, const uint32_t* m1, const uint32_t* m2,
+                        const double* tf1, const double* tf2, size_t n, const hfcl_collision_request* creq, hfcl_result* out,
+                        hfcl_contact* contacts, size_t max_contacts, size_t* n_contacts, uint64_t* fstats);
+
 int sim_bvh_collide_f64(const hfcl_bvh_node* nodes, size_t n_nodes, const double* verts, size_t n_verts,
                         const uint32_t* tris, const uint64_t* mesh_table, const uint32_t* m1, const uint32_t* m2,
                         const double* tf1, const double* tf2, size_t n, const hfcl_collision_request* creq, hfcl_result* out,
                         hfcl_contact* contacts, size_t max_contacts, size_t* n_contacts) {
+  return sim_bvh_collide_impl(nodes, n_nodes, verts, n_verts, tris, mesh_table, m1, m2, tf1, tf2, n, creq, out, contacts,
+                              max_contacts, n_contacts, nullptr);
+}
+// the same walk with the fp32 filter in front of the fp64 separating-axis test; fstats: 7 counters (bvh_pair)
+int sim_bvh_collide_filtered_f64(const hfcl_bvh_node* nodes, size_t n_nodes, const double* verts, size_t n_verts,
+                        const uint32_t* tris, const uint64_t* mesh_table, const uint32_t* m1, const uint32_t* m2,
+                        const double* tf1, const double* tf2, size_t n, const hfcl_collision_request* creq, hfcl_result* out,
+                        uint64_t* fstats) {
+  for (int k = 0; k < 7; ++k) fstats[k] = 0;
+  return sim_bvh_collide_impl(nodes, n_nodes, verts, n_verts, tris, mesh_table, m1, m2, tf1, tf2, n, creq, out, nullptr, 0,
+                              nullptr, fstats);
+}
+
+static int sim_bvh_collide_impl(const hfcl_bvh_node* nodes, size_t n_nodes, const double* verts, size_t n_verts,
+                        const uint32_t* tris, const uint64_t* mesh_table, const uint32_t* m1, const uint32_t* m2,
+                        const double* tf1, const double* tf2, size_t n, const hfcl_collision_request* creq, hfcl_result* out,
+                        hfcl_contact* contacts, size_t max_contacts, size_t* n_contacts, uint64_t* fstats) {
+  std::vector<DNodeF> fn;
+  if (fstats) fn = make_fnodes(nodes, n_nodes);
   std::vector<DNode<double>> dn(n_nodes);
   for (size_t i = 0; i < n_nodes; ++i) {
     const double* a = nodes[i].obb_axes;
@@ -596,7 +699,8 @@ int sim_bvh_collide_f64(const hfcl_bvh_node* nodes, size_t n_nodes, const double
   for (size_t i = 0; i < n; ++i)
     bvh_pair<double>(dn, v, tris, mesh_table + 4 * m1[i], mesh_table + 4 * m2[i], pose_from_abi<double>(tf1 + 12 * i),
                      pose_from_abi<double>(tf2 + 12 * i), q, creq->num_max_contacts,
-                     creq->break_distance * creq->break_distance, out[i], contacts ? &cl : nullptr, uint32_t(i));
+                     creq->break_distance * creq->break_distance, out[i], contacts ? &cl : nullptr, uint32_t(i),
+                     fstats ? fn.data() : nullptr, fstats);
   if (contacts) {
     size_t k = 0;
     for (auto& c : cl)

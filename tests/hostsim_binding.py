@@ -71,6 +71,25 @@ def bvh_collide_f64(abi, meshlib, m1, m2, tf1, tf2, req, max_contacts=0):
     return out
 
 
+def bvh_collide_filtered_f64(abi, meshlib, m1, m2, tf1, tf2, req):
+    """The walk of k_bvh_collide with the fp32 separating-axis filter in front of the fp64 test; returns (records, stats):
+    stats = dict of the 7 counters of hostsim.cpp: bvh_pair (unsafe / rank_mismatch must be 0)."""
+    m1 = np.ascontiguousarray(m1, dtype=np.uint32)
+    m2 = np.ascontiguousarray(m2, dtype=np.uint32)
+    tf1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(-1, 12)
+    tf2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(-1, 12)
+    n = len(m1)
+    out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    st = np.zeros(7, dtype=np.uint64)
+    nodes = np.ascontiguousarray(meshlib.nodes)
+    lib().sim_bvh_collide_filtered_f64(abi.ptr(nodes), C.c_size_t(len(nodes)), abi.ptr(meshlib.verts),
+                                       C.c_size_t(len(meshlib.verts)), abi.ptr(meshlib.tris), abi.ptr(meshlib.table),
+                                       abi.ptr(m1), abi.ptr(m2), abi.ptr(tf1), abi.ptr(tf2), C.c_size_t(n), C.byref(req),
+                                       abi.ptr(out), abi.ptr(st))
+    keys = ["bv_tests", "overlap", "disjoint_skipped", "disjoint_value_needed", "unsure", "unsafe", "rank_mismatch"]
+    return out, dict(zip(keys, [int(x) for x in st]))
+
+
 def bvh_distance_f64(abi, meshlib, m1, m2, tf1, tf2):
     m1 = np.ascontiguousarray(m1, dtype=np.uint32)
     m2 = np.ascontiguousarray(m2, dtype=np.uint32)

@@ -342,3 +342,24 @@ def test_large_hulls_scan_vs_reference_hill_climbing(pkg, oracle, hostsim, kind)
     frac = float(abi.status_contact(ref["status"]).mean())
     assert 0.15 < frac < 0.85, frac
     oracle.lib().orc_clear_neighbors()
+
+
+@pytest.mark.parametrize("margin", [0.0, 0.05])
+def test_bvh_fp32_filter_is_exact(pkg, hostsim, margin):
+    """The fp32 separating-axis filter of k_bvh_collide<double, ., FILT> (hfcl_bvh.hpp: obb_filter) in front of the fp64 test:
+    every verdict it commits to is the fp64 test's (no unsafe decision in ~600k node pairs of real traversals), the rank
+    comparison is the fp64 size comparison, and the walk built on it -- candidates for the minimum of the bound resolved in
+    fp64 only when something is compared with them -- produces byte-identical records to the plain fp64 walk."""
+    abi, wl = pkg.abi, pkg.workloads
+    for kw in (dict(n=1500), dict(n=3000, seg=12, ring=12, n_variants=4)):
+        b = wl.cfg4_mesh_mesh(**kw)
+        ML = pkg.bvh_builder.MeshLibrary(b.meshes)
+        req = wl.make_request(b, abi, security_margin=margin)
+        plain = hostsim.bvh_collide_f64(abi, ML, b.s1, b.s2, b.tf1, b.tf2, req)
+        filt, st = hostsim.bvh_collide_filtered_f64(abi, ML, b.s1, b.s2, b.tf1, b.tf2, req)
+        assert st["unsafe"] == 0 and st["rank_mismatch"] == 0, st
+        assert plain.tobytes() == filt.tobytes()
+        assert st["bv_tests"] > 100 * len(b) * 0.5
+        # the filter decides nearly everything: fp64 tests per query stay a handful
+        assert (st["disjoint_value_needed"] + st["unsure"]) < 4 * len(b), st
+        assert st["unsure"] < 0.01 * st["bv_tests"], st
