@@ -40,8 +40,9 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_pkg  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-# Link rates of the GPU box measured with tools/valu_peak.hip (profiles/r02_a): one direction at a time / both at once
-LINK_H2D_GBS, LINK_D2H_GBS, LINK_BOTH_GBS = 57.4, 57.0, 2 * 37.6
+# Link rates of the GPU box between PAGEABLE host arrays and the device, measured with tools/link_probe.hip
+# (profiles/r03_c): one direction at a time / both at once from two host threads (46.5 - 50 GB/s per direction)
+LINK_H2D_GBS, LINK_D2H_GBS, LINK_BOTH_GBS = 57.4, 57.0, 2 * 47.0
 
 # ALGORITHMIC bytes per query (DESIGN.md "Measurement"): compulsory traffic only
 BYTES_PER_QUERY = {
@@ -248,6 +249,38 @@ def cpu_baseline(ctx, workload, batch, req, sample, budget_s, all_cores=True):
     return out
 
 
+def host_boundary(pkg, lib, batch, req, device_records):
+    """hfcl_collide_batch / hfcl_distance_batch on pageable host arrays: queries/s, and the time against what the link
+    admits (inputs in, records out, both directions at once)."""
+    import ctypes as C
+    abi = pkg.abi
+    n = len(batch)
+    dll = pkg.engine.dll()
+    cfn = dll.hfcl_distance_batch if batch.kind == "distance" else dll.hfcl_collide_batch
+    s1, s2 = batch.s1.astype(np.uint32), batch.s2.astype(np.uint32)
+    tf1, tf2 = np.ascontiguousarray(batch.tf1), np.ascontiguousarray(batch.tf2)
+    out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    out[:] = out  # touched: first-touch page faults of a fresh array are the allocator's, not the link's
+    ts = []
+    for _ in range(5):
+        t1 = time.perf_counter()
+        rc = cfn(lib._h, abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1), abi.ptr(tf2), C.c_size_t(n), C.byref(req), abi.ptr(out), None, None)
+        ts.append(time.perf_counter() - t1)
+        assert rc == 0, pkg.engine.last_error()
+    t_h = min(ts[1:])
+    b_in, b_out = 8 + 192, 96
+    bound_s = max(n * b_in / (LINK_H2D_GBS * 1e9), n * b_out / (LINK_D2H_GBS * 1e9), n * (b_in + b_out) / (LINK_BOTH_GBS * 1e9))
+    r = {"pairs": n, "value": n / t_h, "unit": "queries/s", "ms_per_call": 1e3 * t_h, "ms_first_call": 1e3 * ts[0],
+         "bytes_in_per_pair": b_in, "bytes_out_per_pair": b_out,
+         "link_GBps_measured": {"h2d": LINK_H2D_GBS, "d2h": LINK_D2H_GBS, "both_directions_total": LINK_BOTH_GBS},
+         "link_bound_ms": 1e3 * bound_s, "frac_of_link_bound": bound_s / t_h,
+         "note": "hfcl_%s_batch on pageable host arrays: chunked H2D | kernels | D2H pipeline; PCIe inclusive; best of 4 calls on "
+                 "the same arrays (the first call on fresh arrays also pays the pinning of their pages: ms_first_call)" % batch.kind}
+    if device_records is not None:
+        r["records_identical_to_device_path"] = bool(np.array_equal(out.view(np.int32), device_records.view(np.int32)))
+    return r
+
+
 def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s=10.0, cpu_sample=1_000_000, host_buffers=False,
                  gather=None):
     """One timed region: `steps` passes of the hot path over this rank's batch.  Returns the result dict on rank 0."""
@@ -422,28 +455,10 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
         if host_buffers and dtype == "f64" and ctx.world == 1:
             # the same batch through the host-buffer boundary (what a hpp::fcl::collide()/distance() caller gets):
             # PCIe inclusive, never the headline value
-            import ctypes as C
-            dll = pkg.engine.dll()
-            cfn = dll.hfcl_distance_batch if batch.kind == "distance" else dll.hfcl_collide_batch
-            s1, s2 = batch.s1.astype(np.uint32), batch.s2.astype(np.uint32)
-            tf1, tf2 = np.ascontiguousarray(batch.tf1), np.ascontiguousarray(batch.tf2)
-            out = np.zeros(n, dtype=abi.RESULT_DTYPE)
-            out[:] = out  # touched: first-touch page faults of a fresh array are the allocator's, not the link's
-            ts = []
-            for _ in range(4):
-                t1 = time.perf_counter()
-                rc = cfn(lib._h, abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1), abi.ptr(tf2), C.c_size_t(n), C.byref(req), abi.ptr(out), None, None)
-                ts.append(time.perf_counter() - t1)
-                assert rc == 0, pkg.engine.last_error()
-            t_h = min(ts[1:])
-            b_in, b_out = 8 + 192, 96
-            bound_s = max(n * b_in / (LINK_H2D_GBS * 1e9), n * b_out / (LINK_D2H_GBS * 1e9), n * (b_in + b_out) / (LINK_BOTH_GBS * 1e9))
-            same = bool(np.array_equal(out.view(np.int32), res.view(np.int32)))
-            result["host_buffers"] = {
-                "value": n / t_h, "unit": "queries/s", "ms_per_call": 1e3 * t_h, "bytes_in_per_pair": b_in, "bytes_out_per_pair": b_out,
-                "link_GBps_measured": {"h2d": LINK_H2D_GBS, "d2h": LINK_D2H_GBS, "both_directions_total": LINK_BOTH_GBS},
-                "link_bound_ms": 1e3 * bound_s, "frac_of_link_bound": bound_s / t_h, "records_identical_to_device_path": same,
-                "note": "hfcl_%s_batch on pageable host arrays: chunked H2D | kernels | D2H pipeline; PCIe inclusive" % batch.kind}
+            result["host_buffers"] = host_boundary(pkg, lib, batch, req, res)
+            if workload == "cfg2":  # ... and at a quarter / four times the size
+                result["host_buffers"]["other_sizes"] = [
+                    host_boundary(pkg, lib, wl.cfg2_box_capsule(n=m, seed=1 + ctx.rank), req, None) for m in (250_000, 4_000_000)]
     lib.close()
     del d_s1, d_s2, d_p1, d_p2, outs, xch
     torch.cuda.empty_cache()

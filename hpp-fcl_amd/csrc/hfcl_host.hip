@@ -23,6 +23,7 @@
 //                    per 16-lane group, sequential traversal, leaves = TriangleP-vs-solid GJK + EPA in LDS
 //   k_unsupported<T> flags the pairs of a bucket the engine cannot evaluate (never computed elsewhere)
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -88,21 +89,21 @@ struct hfcl_lib {
   size_t resume_cap = 0;
   // host-call staging: PIPE_SLOTS device buffer sets of `st_capacity` pairs each (a chunk of a host batch), three streams
   // (H2D | kernels | D2H) and per-slot events / pinned counter blocks (host_batch)
-  static constexpr int PIPE_SLOTS = 3;
+  static constexpr int PIPE_SLOTS = 6;  // (three left the feeder waiting for records to leave: profiles/r03_c)
   struct Staging {
     uint32_t *d_s1 = nullptr, *d_s2 = nullptr;
     double *d_tf1 = nullptr, *d_tf2 = nullptr;
     double *d_qt1 = nullptr, *d_qt2 = nullptr;  // compact host poses (7 doubles), expanded into d_tf1/2 on the device
     hfcl_result* d_out = nullptr;
     hfcl_guess *d_gin = nullptr, *d_gout = nullptr;
-    hipEvent_t ev_in = nullptr, ev_done = nullptr;
+    hipEvent_t ev_in = nullptr, ev_in2 = nullptr, ev_done = nullptr;  // inputs of object 1 / object 2 arrived, kernels done
     uint32_t* h_counts = nullptr;  // pinned: bucket populations of the chunk that last ran in this slot
     uint32_t* h_counts2 = nullptr; // ... of its second half when the chunk ran split
     bool split = false;
   };
   Staging stage[PIPE_SLOTS];
   size_t st_capacity = 0;
-  hipStream_t s_h2d = nullptr, s_cmp = nullptr, s_d2h = nullptr;
+  hipStream_t s_h2d = nullptr, s_h2d2 = nullptr, s_cmp = nullptr, s_d2h = nullptr;
   uint32_t acc_counts[N_COUNTERS] = {0};  // host batches: bucket populations summed over the chunks
   bool last_host = false;                 // the last call was a host batch: acc_counts are its populations
   bool in_host_batch = false;
@@ -444,10 +445,12 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
     hipFree(sg.d_gout);
     if (sg.ev_in) hipEventDestroy(sg.ev_in);
     if (sg.ev_done) hipEventDestroy(sg.ev_done);
+    if (sg.ev_in2) hipEventDestroy(sg.ev_in2);
     if (sg.h_counts) hipHostFree(sg.h_counts);
     if (sg.h_counts2) hipHostFree(sg.h_counts2);
   }
   if (lib->s_h2d) hipStreamDestroy(lib->s_h2d);
+  if (lib->s_h2d2) hipStreamDestroy(lib->s_h2d2);
   if (lib->s_cmp) hipStreamDestroy(lib->s_cmp);
   if (lib->s_d2h) hipStreamDestroy(lib->s_d2h);
   hipFree(lib->d_nodes64);
@@ -1340,11 +1343,13 @@ int hfcl_compact_results_device_f32(hfcl_lib* lib, const hfcl_result_f32* d_reco
 static int ensure_staging(hfcl_lib* lib, size_t n, bool gin, bool gout, bool compact) {
   if (!lib->s_cmp) {
     HIP_TRY(hipStreamCreateWithFlags(&lib->s_h2d, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&lib->s_h2d2, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&lib->s_cmp, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&lib->s_d2h, hipStreamNonBlocking));
     for (auto& sg : lib->stage) {
       HIP_TRY(hipEventCreateWithFlags(&sg.ev_in, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&sg.ev_done, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&sg.ev_in2, hipEventDisableTiming));
       HIP_TRY(hipHostMalloc((void**)&sg.h_counts, N_COUNTERS * sizeof(uint32_t), hipHostMallocDefault));
       HIP_TRY(hipHostMalloc((void**)&sg.h_counts2, N_COUNTERS * sizeof(uint32_t), hipHostMallocDefault));
     }
@@ -1400,28 +1405,104 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
     return HFCL_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(hipSetDevice(lib->device));
-  // chunk size: large enough that a chunk's fixed costs (a dozen launches, ~0.1 ms) vanish, small enough that the
-  // pipeline has >= 8 chunks to overlap on big batches
-  size_t chunk = n;
-  if (pipelined) {
-    chunk = lib->pipe_chunk ? lib->pipe_chunk : std::min<size_t>(std::max<size_t>(n / 8, size_t(1) << 15), size_t(1) << 18);
-    if (chunk > n) chunk = n;
+  // Chunks: large enough that a chunk's fixed costs (a dozen launches, ~0.1 ms) vanish, small enough that the pipeline
+  // has several chunks to overlap.  The link is busy from the first byte to the last only if the first chunk is small
+  // (nothing computes until it has arrived) and the last one too (nothing overlaps its way back): the sizes ramp up
+  // geometrically from 16k pairs to the steady size and down again (1M pairs: 6.4 -> see profiles/r03_c).
+  std::vector<size_t> bounds;  // chunk k = [bounds[k], bounds[k + 1])
+  bounds.push_back(0);
+  size_t max_chunk = n;
+  if (pipelined && lib->pipe_chunk) {
+    for (size_t lo = 0; lo < n; lo += lib->pipe_chunk) bounds.push_back(std::min(n, lo + lib->pipe_chunk));
+    max_chunk = std::min(n, lib->pipe_chunk);
+  } else if (pipelined && n > (size_t(1) << 16)) {
+    const size_t steady = std::min<size_t>(std::max<size_t>(n / 6, size_t(1) << 16), size_t(1) << 18);
+    std::vector<size_t> up;    // 16k, 32k, ... below the steady size
+    for (size_t c = size_t(1) << 14; c < steady; c *= 2) up.push_back(c);
+    size_t ramp = 0;
+    for (size_t c : up) ramp += c;
+    while (!up.empty() && 2 * ramp + steady > n) {  // a batch too small for the whole ramp: shorten it from the top
+      ramp -= up.back();
+      up.pop_back();
+    }
+    size_t lo = 0;
+    for (size_t c : up) bounds.push_back(lo += c);
+    const size_t mid_end = n - ramp;
+    while (mid_end - lo > steady + steady / 2) bounds.push_back(lo += steady);
+    if (mid_end > lo) bounds.push_back(lo = mid_end);
+    for (size_t k = up.size(); k-- > 0;) bounds.push_back(lo += up[k]);
+    max_chunk = 0;
+    for (size_t k = 0; k + 1 < bounds.size(); ++k) max_chunk = std::max(max_chunk, bounds[k + 1] - bounds[k]);
+  } else {
+    bounds.push_back(n);
   }
-  const size_t n_chunks = (n + chunk - 1) / chunk;
-  int rc = ensure_staging(lib, chunk, gin != nullptr, gout != nullptr, compact);
+  const size_t n_chunks = bounds.size() - 1;
+  int rc = ensure_staging(lib, max_chunk, gin != nullptr, gout != nullptr, compact);
   if (rc) return rc;
   constexpr int S = hfcl_lib::PIPE_SLOTS;
   memset(lib->acc_counts, 0, sizeof(lib->acc_counts));
   lib->in_host_batch = true;
 
-  // pipeline state shared with the drain thread
+  // Host threads keep the streams busy.  A copy between pageable memory and the device holds its caller until the data
+  // has moved (above a few MB; the first time a range of host memory is used it is also pinned, several times slower),
+  // so every stream that copies has a thread of its own: two feeders (the arrays of object 1 and of object 2, on two
+  // streams: one blocking copy at a time leaves the link idle between copies, 42 instead of 50 GB/s), the drainer
+  // (records out, queued behind the chunk's kernels on the stream; bucket populations), and the caller's thread, which
+  // launches the kernels of a chunk as soon as its inputs are on their way (profiles/r03_c).
   std::mutex mu;
   std::condition_variable cv;
-  size_t issued = 0, drained = 0;  // chunks launched / chunks whose records are back on the host
-  int drain_rc = HFCL_OK;
-  std::string drain_err;
+  size_t copied[2] = {0, 0}, issued = 0, drained = 0;  // chunks whose inputs are queued / whose kernels are launched / whose records are back
+  int side_rc = HFCL_OK;                       // first failure of the feeder or the drainer
+  std::string side_err;
   bool abort_all = false;
+  auto side_fail = [&](const char* who, hipError_t e) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (side_rc == HFCL_OK) {
+      side_rc = HFCL_ERR_HIP;
+      side_err = std::string("host batch (") + who + "): " + hipGetErrorString(e);
+    }
+    abort_all = true;
+    cv.notify_all();
+  };
 
+  // HFCL_PIPE_TRACE=1: per-chunk time line of the three threads on stderr (ms since the call started)
+  const bool trace = getenv("HFCL_PIPE_TRACE") != nullptr;
+  const auto t_call = std::chrono::steady_clock::now();
+  auto ms_now = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
+  std::vector<double> tr(trace ? 6 * n_chunks : 0);
+  // `copied[h]`: chunks whose arrays of object h + 1 (ids, poses; h = 0 also the guesses) are queued
+  auto feed = [&](int h) {
+    hipSetDevice(lib->device);
+    hipStream_t st = h ? lib->s_h2d2 : lib->s_h2d;
+    for (size_t k = 0; k < n_chunks; ++k) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return drained + S > k || abort_all; });  // the slot's previous chunk must be back on the host
+        if (abort_all) return;
+      }
+      hfcl_lib::Staging& sg = lib->stage[k % S];
+      const size_t lo = bounds[k], m = bounds[k + 1] - lo;
+      if (trace && !h) tr[6 * k] = ms_now();
+      const uint32_t* ids = h ? s2 : s1;
+      const double* tf = h ? tf2 : tf1;
+      hipError_t e = hipMemcpyAsync(h ? sg.d_s2 : sg.d_s1, ids + lo, m * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+      if (compact) {  // tf1 / tf2 are 7-double poses: expanded to Transform3f images by the first kernel of the chunk
+        if (e == hipSuccess) e = hipMemcpyAsync(h ? sg.d_qt2 : sg.d_qt1, tf + 7 * lo, m * 7 * sizeof(double), hipMemcpyHostToDevice, st);
+      } else {
+        if (e == hipSuccess) e = hipMemcpyAsync(h ? sg.d_tf2 : sg.d_tf1, tf + 12 * lo, m * 12 * sizeof(double), hipMemcpyHostToDevice, st);
+      }
+      if (e == hipSuccess && gin && !h) e = hipMemcpyAsync(sg.d_gin, gin + lo, m * sizeof(hfcl_guess), hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipEventRecord(h ? sg.ev_in2 : sg.ev_in, st);
+      if (e != hipSuccess) {
+        side_fail("feed", e);
+        return;
+      }
+      if (trace && !h) tr[6 * k + 1] = ms_now();
+      std::lock_guard<std::mutex> lk(mu);
+      copied[h] = k + 1;
+      cv.notify_all();
+    }
+  };
   auto drain = [&]() {
     hipSetDevice(lib->device);
     for (size_t k = 0; k < n_chunks; ++k) {
@@ -1431,26 +1512,33 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
         if (abort_all && issued <= k) return;
       }
       hfcl_lib::Staging& sg = lib->stage[k % S];
-      const size_t lo = k * chunk, m = std::min(chunk, n - lo);
-      hipError_t e = hipEventSynchronize(sg.ev_done);  // kernels + counter copy of chunk k are complete
-      if (e == hipSuccess) {
+      const size_t lo = bounds[k], m = bounds[k + 1] - lo;
+      // the records' way back is queued behind the chunk's kernels on the third stream (no host round trip between the two)
+      hipError_t e = trace ? hipEventSynchronize(sg.ev_done) : hipSuccess;
+      if (trace) tr[6 * k + 4] = ms_now();
+      if (e == hipSuccess) e = hipStreamWaitEvent(lib->s_d2h, sg.ev_done, 0);
+      if (e == hipSuccess) e = hipMemcpyAsync(out + lo, sg.d_out, m * sizeof(hfcl_result), hipMemcpyDeviceToHost, lib->s_d2h);
+      if (e == hipSuccess && gout) e = hipMemcpyAsync(gout + lo, sg.d_gout, m * sizeof(hfcl_guess), hipMemcpyDeviceToHost, lib->s_d2h);
+      if (e == hipSuccess) e = hipStreamSynchronize(lib->s_d2h);  // (ev_done has passed: the counters are on the host too)
+      if (e == hipSuccess)
         for (int i = 0; i < N_COUNTERS; ++i) lib->acc_counts[i] += sg.h_counts[i] + (sg.split ? sg.h_counts2[i] : 0u);
-        e = hipMemcpyAsync(out + lo, sg.d_out, m * sizeof(hfcl_result), hipMemcpyDeviceToHost, lib->s_d2h);
-        if (e == hipSuccess && gout) e = hipMemcpyAsync(gout + lo, sg.d_gout, m * sizeof(hfcl_guess), hipMemcpyDeviceToHost, lib->s_d2h);
-        if (e == hipSuccess) e = hipStreamSynchronize(lib->s_d2h);
+      if (e != hipSuccess) {
+        side_fail("drain", e);
+        return;
       }
+      if (trace) tr[6 * k + 5] = ms_now();
       std::lock_guard<std::mutex> lk(mu);
-      if (e != hipSuccess && drain_rc == HFCL_OK) {
-        drain_rc = HFCL_ERR_HIP;
-        drain_err = std::string("host batch (drain): ") + hipGetErrorString(e);
-      }
       drained = k + 1;
       cv.notify_all();
     }
   };
-  std::thread drainer;
   const bool threaded = n_chunks > 1;
-  if (threaded) drainer = std::thread(drain);
+  std::thread feeder, feeder2, drainer;
+  if (threaded) {
+    feeder = std::thread(feed, 0);
+    feeder2 = std::thread(feed, 1);
+    drainer = std::thread(drain);
+  }
 
   auto fail = [&](int code) {  // stop the pipeline and leave
     {
@@ -1458,8 +1546,15 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
       abort_all = true;
     }
     cv.notify_all();
-    if (threaded) drainer.join();
+    if (threaded) {
+      feeder.join();
+      feeder2.join();
+      drainer.join();
+    }
+    hipStreamSynchronize(lib->s_h2d);
+    hipStreamSynchronize(lib->s_h2d2);
     hipStreamSynchronize(lib->s_cmp);
+    hipStreamSynchronize(lib->s_d2h);
     lib->in_host_batch = false;
     lib->counts_dst = nullptr;
     if (lib->helper) lib->helper->counts_dst = nullptr;
@@ -1474,30 +1569,25 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
     }                                                                        \
   } while (0)
 
+  if (!threaded) {
+    feed(0);
+    feed(1);
+  }
   for (size_t k = 0; k < n_chunks; ++k) {
     hfcl_lib::Staging& sg = lib->stage[k % S];
-    const size_t lo = k * chunk, m = std::min(chunk, n - lo);
-    if (k >= size_t(S)) {  // the slot's previous chunk must be back on the host
+    const size_t m = bounds[k + 1] - bounds[k];
+    {
       std::unique_lock<std::mutex> lk(mu);
-      cv.wait(lk, [&] { return drained + S > k; });
-      if (drain_rc) {
+      cv.wait(lk, [&] { return (copied[0] > k && copied[1] > k) || abort_all; });
+      if (side_rc) {
         lk.unlock();
-        set_error(drain_err);
-        return fail(drain_rc);
+        set_error(side_err);
+        return fail(side_rc);
       }
     }
-    PIPE_TRY(hipMemcpyAsync(sg.d_s1, s1 + lo, m * sizeof(uint32_t), hipMemcpyHostToDevice, lib->s_h2d));
-    PIPE_TRY(hipMemcpyAsync(sg.d_s2, s2 + lo, m * sizeof(uint32_t), hipMemcpyHostToDevice, lib->s_h2d));
-    if (compact) {  // tf1 / tf2 are 7-double poses: expanded to Transform3f images by the first kernel of the chunk
-      PIPE_TRY(hipMemcpyAsync(sg.d_qt1, tf1 + 7 * lo, m * 7 * sizeof(double), hipMemcpyHostToDevice, lib->s_h2d));
-      PIPE_TRY(hipMemcpyAsync(sg.d_qt2, tf2 + 7 * lo, m * 7 * sizeof(double), hipMemcpyHostToDevice, lib->s_h2d));
-    } else {
-      PIPE_TRY(hipMemcpyAsync(sg.d_tf1, tf1 + 12 * lo, m * 12 * sizeof(double), hipMemcpyHostToDevice, lib->s_h2d));
-      PIPE_TRY(hipMemcpyAsync(sg.d_tf2, tf2 + 12 * lo, m * 12 * sizeof(double), hipMemcpyHostToDevice, lib->s_h2d));
-    }
-    if (gin) PIPE_TRY(hipMemcpyAsync(sg.d_gin, gin + lo, m * sizeof(hfcl_guess), hipMemcpyHostToDevice, lib->s_h2d));
-    PIPE_TRY(hipEventRecord(sg.ev_in, lib->s_h2d));
+    if (trace) tr[6 * k + 2] = ms_now();
     PIPE_TRY(hipStreamWaitEvent(lib->s_cmp, sg.ev_in, 0));
+    PIPE_TRY(hipStreamWaitEvent(lib->s_cmp, sg.ev_in2, 0));
     if (compact) {
       launch_expand_poses(lib->s_cmp, sg.d_qt1, sg.d_tf1, uint32_t(m));
       launch_expand_poses(lib->s_cmp, sg.d_qt2, sg.d_tf2, uint32_t(m));
@@ -1519,6 +1609,7 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
     if (rc) return fail(rc);
     sg.split = lib->last_split;
     PIPE_TRY(hipEventRecord(sg.ev_done, lib->s_cmp));
+    if (trace) tr[6 * k + 3] = ms_now();
     {
       std::lock_guard<std::mutex> lk(mu);
       issued = k + 1;
@@ -1527,14 +1618,24 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
     if (!threaded) drain();
   }
 #undef PIPE_TRY
-  if (threaded) drainer.join();
+  if (threaded) {
+    feeder.join();
+    feeder2.join();
+    drainer.join();
+  }
+  if (trace) {
+    fprintf(stderr, "[hfcl pipe] %zu pairs, %zu chunks, %.3f ms\n", n, n_chunks, ms_now());
+    for (size_t k = 0; k < n_chunks; ++k)
+      fprintf(stderr, "[hfcl pipe] chunk %2zu %7zu pairs: copy-in issued %.3f..%.3f  launches %.3f..%.3f  kernels done %.3f  records out %.3f\n", k,
+              bounds[k + 1] - bounds[k], tr[6 * k], tr[6 * k + 1], tr[6 * k + 2], tr[6 * k + 3], tr[6 * k + 4], tr[6 * k + 5]);
+  }
   lib->in_host_batch = false;
   lib->counts_dst = nullptr;
   if (lib->helper) lib->helper->counts_dst = nullptr;
   lib->last_host = true;
-  if (drain_rc) {
-    set_error(drain_err);
-    return drain_rc;
+  if (side_rc) {
+    set_error(side_err);
+    return side_rc;
   }
   const bool skipped = creq && creq->security_margin == -__builtin_inf();
   if (!skipped && total_count(lib, B_UNSUPPORTED) > 0) {
