@@ -25,6 +25,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <typeinfo>
 #include <vector>
 
 #include <algorithm>
@@ -903,9 +904,12 @@ struct DistanceCallBackBase {  // broadphase/broadphase_callbacks.h:77-103
 };
 
 /// CollisionData / DistanceData and the default callbacks (broadphase/default_broadphase_callbacks.h:55-98,118,192;
-/// src/broadphase/default_broadphase_callbacks.cpp:43-91): every culled pair is evaluated with collide() / distance()
-/// (one query each, as in the reference; to evaluate all culled pairs in ONE device batch collect them with
-/// CollisionCallBackCollect and call amd::collide).
+/// src/broadphase/default_broadphase_callbacks.cpp:43-91).  Called directly, a default callback evaluates its pair with
+/// collide() / distance(): one query = one batch of one, tens of microseconds of launch latency where the reference
+/// spends two.  Handed to DynamicAABBTreeCollisionManager::collide / distance, the manager recognises the default
+/// callbacks and evaluates the culled pairs in device batches (geometrically growing: 256, 1024, ... pairs), then folds
+/// the records into the callback's CollisionData / DistanceData in the order, and with the stop rule, of the sequential
+/// calls: same result object, a fraction of a microsecond per pair (tests/cpp/test_compat.cpp measures both).
 struct CollisionData {
   CollisionData() : done(false) {}
   CollisionRequest request;
@@ -980,9 +984,12 @@ class DynamicAABBTreeCollisionManager {
     if (objs_.size() < 2) return;
     hfcl_pairlist* pl = hfcl_broadphase_self_pairs(aabbs_.data(), objs_.size(), 0);
     const uint32_t* p = hfcl_pairlist_data(pl);
-    for (size_t k = 0, n = hfcl_pairlist_size(pl); k < n; ++k)
+    const size_t n = hfcl_pairlist_size(pl);
+    struct Free { hfcl_pairlist* l; ~Free() { hfcl_pairlist_free(l); } } guard{pl};
+    auto at = [&](size_t k) { return std::make_pair(objs_[p[2 * k]], objs_[p[2 * k + 1]]); };
+    if (collide_default_batched(callback, n, at)) return;
+    for (size_t k = 0; k < n; ++k)
       if ((*callback)(objs_[p[2 * k]], objs_[p[2 * k + 1]])) break;
-    hfcl_pairlist_free(pl);
   }
   /// self distance (broadphase_dynamic_AABB_tree.cpp:745-751): the callback sees the pairs whose AABBs are closer than the
   /// smallest distance reported so far (the pruning rule of distanceRecurse, :350-420), nearest boxes first, until it
@@ -997,6 +1004,38 @@ class DynamicAABBTreeCollisionManager {
       for (size_t j = i + 1; j < n; ++j) cand.push_back({aabb_distance(i, j), {uint32_t(i), uint32_t(j)}});
     std::sort(cand.begin(), cand.end());
     FCL_REAL min_dist = std::numeric_limits<FCL_REAL>::max();
+    if (auto* def = dynamic_cast<DistanceCallBackDefault*>(callback)) {
+      if (typeid(*callback) == typeid(DistanceCallBackDefault) && def->data.request.gjk_initial_guess != CachedGuess) {
+        // the default callback: the candidates in device batches, folded in the sequential order with the sequential rules
+        DistanceData& d = def->data;
+        amd::BatchQueries& ctx = amd::default_context();
+        size_t k = 0, batch = 256;
+        while (k < cand.size() && !d.done && cand[k].first < min_dist) {
+          size_t m = 0;  // candidates of this batch: those the sequential walk could still look at
+          std::vector<std::pair<uint32_t, uint32_t>> ids;
+          std::vector<Transform3f> tf1, tf2;
+          while (k + m < cand.size() && m < batch && cand[k + m].first < min_dist) {
+            CollisionObject *a = objs_[cand[k + m].second.first], *b = objs_[cand[k + m].second.second];
+            ids.push_back({ctx.add(a->collisionGeometryPtr()), ctx.add(b->collisionGeometryPtr())});
+            tf1.push_back(a->getTransform());
+            tf2.push_back(b->getTransform());
+            ++m;
+          }
+          ctx.run(ids, tf1, tf2, nullptr, &d.request);
+          bool stop = false;
+          for (size_t j = 0; j < m && !stop; ++j) {
+            if (cand[k + j].first >= min_dist) { stop = true; break; }  // no closer pair can be left
+            if (!(d.result.min_distance <= 0)) ctx.fill(d.result, ids[j], ctx.records()[j], ctx.guesses()[j]);  // distance(): isSatisfied
+            min_dist = d.result.min_distance;
+            if (min_dist <= 0) stop = true;  // in collision or in touch
+          }
+          if (stop) return;
+          k += m;
+          batch = std::min<size_t>(batch * 4, size_t(1) << 20);
+        }
+        return;
+      }
+    }
     for (const auto& c : cand) {
       if (c.first >= min_dist) break;  // no closer pair can be left
       if ((*callback)(objs_[c.second.first], objs_[c.second.second], min_dist)) break;
@@ -1010,12 +1049,51 @@ class DynamicAABBTreeCollisionManager {
     if (objs_.empty() || other->objs_.empty()) return;
     hfcl_pairlist* pl = hfcl_broadphase_pairs_between(aabbs_.data(), objs_.size(), other->aabbs_.data(), other->objs_.size(), 0);
     const uint32_t* p = hfcl_pairlist_data(pl);
-    for (size_t k = 0, n = hfcl_pairlist_size(pl); k < n; ++k)
+    const size_t n = hfcl_pairlist_size(pl);
+    struct Free { hfcl_pairlist* l; ~Free() { hfcl_pairlist_free(l); } } guard{pl};
+    auto at = [&](size_t k) { return std::make_pair(objs_[p[2 * k]], other->objs_[p[2 * k + 1]]); };
+    if (collide_default_batched(callback, n, at)) return;
+    for (size_t k = 0; k < n; ++k)
       if ((*callback)(objs_[p[2 * k]], other->objs_[p[2 * k + 1]])) break;
-    hfcl_pairlist_free(pl);
   }
 
  private:
+  /// The default collision callback over a list of culled pairs, evaluated in device batches.  Returns false (nothing
+  /// done) for any other callback -- a user callback sees its pairs one by one -- and for requests that chain the GJK guess
+  /// from pair to pair (CachedGuess: QueryRequest::updateGuess makes pair k depend on pair k - 1).
+  /// Sequential semantics kept: records are folded in pair order by the same routine collide() uses, and nothing is
+  /// folded once data.done is set (default_broadphase_callbacks.cpp:43-57); pairs of a batch beyond that point were
+  /// evaluated for nothing, which is why the batches start small and grow.
+  template <class At>
+  bool collide_default_batched(CollisionCallBackBase* callback, size_t n, At at) {
+    auto* def = dynamic_cast<CollisionCallBackDefault*>(callback);
+    if (!def || typeid(*callback) != typeid(CollisionCallBackDefault)) return false;
+    CollisionData& d = def->data;
+    if (d.request.gjk_initial_guess == CachedGuess) return false;
+    if (d.request.security_margin == -std::numeric_limits<FCL_REAL>::infinity() || d.request.num_max_contacts == 0) return false;
+    amd::BatchQueries& ctx = amd::default_context();
+    size_t k = 0, batch = 256;
+    while (k < n && !d.done) {
+      const size_t m = std::min(batch, n - k);
+      std::vector<std::pair<uint32_t, uint32_t>> ids(m);
+      std::vector<Transform3f> tf1(m), tf2(m);
+      for (size_t j = 0; j < m; ++j) {
+        const auto pr = at(k + j);
+        ids[j] = {ctx.add(pr.first->collisionGeometryPtr()), ctx.add(pr.second->collisionGeometryPtr())};
+        tf1[j] = pr.first->getTransform();
+        tf2[j] = pr.second->getTransform();
+      }
+      ctx.run(ids, tf1, tf2, &d.request, nullptr);
+      for (size_t j = 0; j < m && !d.done; ++j) {
+        if (!(d.result.isCollision() && d.request.num_max_contacts <= d.result.numContacts()))  // collide()'s early return
+          ctx.fill(d.result, ids[j], d.request, ctx.records()[j], ctx.guesses()[j]);
+        if (d.result.isCollision() && d.result.numContacts() >= d.request.num_max_contacts) d.done = true;
+      }
+      k += m;
+      batch = std::min<size_t>(batch * 4, size_t(1) << 20);
+    }
+    return true;
+  }
   FCL_REAL aabb_distance(size_t i, size_t j) const {  // AABB::distance (BV/AABB.cpp:53-110): 0 when the boxes overlap
     FCL_REAL s = 0;
     for (int k = 0; k < 3; ++k) {
