@@ -661,7 +661,6 @@ struct BvhSplit {
   uint32_t budget0;     // ... of the queries themselves (level 0); `budget` is that of the tasks
   uint32_t level, n_levels;
   uint32_t can_suspend;
-  uint32_t steal;       // 1: k_bvh_collide_ws (work stealing inside the wavefront; `sums` is its segment pool)
 };
 // Step budget per unit (the compile-time default; without HFCL_BVH_* in the environment the host chooses per batch, see
 // hfcl_lib::bvh_auto).  0: units only suspend when their LDS stack is full -- the task mechanism is then the overflow path

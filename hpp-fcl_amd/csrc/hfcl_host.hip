@@ -170,8 +170,6 @@ struct hfcl_lib {
   // 10k 4.7 -> 3.4 ms).  A larger batch keeps its lanes busy by refilling and loses with the split (1M: 68 -> 51 M q/s).
   bool bvh_auto = true;
   uint32_t bvh_budget = HFCL_BVH_BUDGET, bvh_levels = HFCL_BVH_LEVELS;  // HFCL_BVH_BUDGET / HFCL_BVH_LEVELS (1: unsplit)
-  bool bvh_steal = false;  // HFCL_BVH_STEAL=1: k_bvh_collide_ws (work stealing inside the wavefront, pre-tested stack entries) instead
-                           // of the single pass; measured slower (profiles/r02_m_bvh_work_stealing.txt), kept for the record and tested
   // contact list of the last hfcl_collide_batch_contacts call
   hfcl_contact* d_contacts = nullptr;
   size_t contacts_cap = 0;
@@ -401,7 +399,6 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_CLOSED_STAGED")) lib->closed_staged = atoi(v) != 0;
   if (const char* v = getenv("HFCL_SPLIT")) lib->split = atoi(v) >= 2 ? 2 : (atoi(v) == 1 ? 1 : 0);
   if (const char* v = getenv("HFCL_PIPE_CHUNK")) lib->pipe_chunk = strtoull(v, nullptr, 10);
-  if (const char* v = getenv("HFCL_BVH_STEAL")) lib->bvh_steal = atoi(v) != 0;
   if (const char* v = getenv("HFCL_BVH_FILTER")) lib->bvh_filter = atoi(v) != 0;
   if (const char* v = getenv("HFCL_CLIMB_MIN")) lib->climb_min = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_BUDGET")) lib->bvh_budget = lib->bvh_budget0 = uint32_t(std::max(0, atoi(v)));
@@ -1042,7 +1039,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       memset(&split, 0, sizeof(split));
       // long traversals are cut into tasks when the batch is large enough for the tail to matter and the request
       // keeps no query-wide contact count
-      if (may(B_BVH) && !spill.wide && (lib->bvh_levels > 1 || lib->bvh_steal) && (n >= 256 || 2 * size_t(lib->bvh_max_depth) + 4 > size_t(std::min(BVH_STACK, BVH_STACK_FILT))) &&
+      if (may(B_BVH) && !spill.wide && lib->bvh_levels > 1 && (n >= 256 || 2 * size_t(lib->bvh_max_depth) + 4 > size_t(std::min(BVH_STACK, BVH_STACK_FILT))) &&
           lib->bvh_params.num_max_contacts == 1 && !lib->bvh_params.contacts) {
         rc = ensure_bvh_split(lib, n);
         if (rc) return rc;
@@ -1061,10 +1058,6 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
           split.budget = 16;
           split.n_levels = BVH_MAX_LEVELS;
         }
-        // work stealing inside the wavefront wherever the LDS stack holds the traversal (the task levels remain the
-        // overflow path of deeper trees)
-        // (its stack holds one entry per level of the two trees: the pending sibling)
-        split.steal = lib->bvh_steal && size_t(lib->bvh_max_depth) * 2 + 2 <= 48 && lib->bvh_max_nodes <= 65535 ? 1u : 0u;
       }
       launch_bvh_collide<T>(blocks_for(n, BVH_BLOCK), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance), split, spill);
       tend();

@@ -48,7 +48,7 @@ template <> struct BvhEntry<true> {
 };
 
 #ifndef HFCL_BVH_PREFETCH
-#define HFCL_BVH_PREFETCH 1  // cfg4 100k: 7.5 -> 6.7 ms, 1M: 61.6 -> 67.6 M q/s (profiles/r02_r); 2 (also the sibling): no further gain
+#define HFCL_BVH_PREFETCH 1  // cfg4 100k: 7.5 -> 6.7 ms, 1M: 61.6 -> 67.6 M q/s (profiles/r02_r); touching the sibling as well gave nothing more
 #endif
 #ifndef HFCL_WPE_BVH_COLLIDE
 #define HFCL_WPE_BVH_COLLIDE 2  // two waves per SIMD: the walk waits for its node gathers most of the time (profiles/r02_m)
@@ -412,18 +412,12 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
           // the next step finds it on its way up the cache hierarchy instead of starting after the test.
           const DNode<T>* const next = bv.nodes + (first ? m1.node_off + uint32_t(n1.first_child) : m2.node_off + uint32_t(n2.first_child));
           const int32_t touched = next[0].first_child;
-#if HFCL_BVH_PREFETCH >= 2  // ... and its sibling, popped right after it when the first child's test says "disjoint"
-          const int32_t touched2 = next[1].first_child;
-#endif
 #endif
           T sq;
           // argument order of the reference: overlap(RT.R, RT.T, model2.bv(b2), model1.bv(b1))
           const bool disjoint = obb_disjoint(RT_R, RT_T, n2, n1, q.security_margin, break_distance2, sq);
 #if HFCL_BVH_PREFETCH
           asm volatile("" ::"v"(touched));
-#if HFCL_BVH_PREFETCH >= 2
-          asm volatile("" ::"v"(touched2));
-#endif
 #endif
           if (disjoint)
             on_disjoint(sq);
@@ -521,431 +515,6 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
           sp = 0;
           nspill = 0;
         }
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// k_bvh_collide_ws: the same traversal with WORK STEALING inside a wavefront.
-//
-// With 1.5 queries per resident lane the single-pass kernel lasts as long as its longest query (cfg4: 2000+ BV tests in
-// a row, one lane of a wave busy, 63 idle).  Here, once the queue of queries is empty, the idle lanes of a wave take work
-// from the busy ones: a thief removes the BOTTOM entry of a victim's DFS stack -- the subtree the victim would visit last,
-// and the largest one pending -- and walks it as a segment of its own; segments can be stolen from in turn, so the work of
-// a long query spreads over the wave geometrically.  Everything happens inside one wavefront (the stacks of its lanes are
-// columns of one LDS array, the lanes run in lockstep): no inter-wave communication, no waiting, nothing that can hang.
-//
-// The sequential result is restored afterwards.  A segment keeps the summary k_bvh_combine works with (lower bound, last
-// bound-lowering leaf, first contact); its record in the pool (BvhSum: first_child = its most recent steal, n_child =
-// the steal made from the same victim just before it, order = its position) links the segments of a query into a
-// tree whose pre-order -- own work, then the steals from the most recent to the first -- is the DFS order of the
-// reference's walk: what was stolen later sat higher in the stack.  The lane that completes the last segment of a query
-// folds the tree in that order and writes the record.  A contact ends the walk: it is recorded up the tree
-// (contact_order) and segments that lie behind it drop their work at their next check.
-// ---------------------------------------------------------------------------------------
-constexpr uint32_t WS_NONE = 0xFFFFFFFFu, WS_POSBASE = 0x7FFFFFFFu;
-__device__ __forceinline__ int nth_set_bit(uint64_t m, int r) {  // position of the r-th (0-based) set bit of m
-  int pos = 0;
-#pragma unroll
-  for (int shift = 32; shift >= 1; shift >>= 1) {
-    const int c = __popcll((m >> pos) & ((uint64_t(1) << shift) - 1));
-    if (r >= c) {
-      r -= c;
-      pos += shift;
-    }
-  }
-  return pos;
-}
-template <typename X>
-__device__ __forceinline__ X shfl_any(X v, int src) {
-  static_assert(sizeof(X) % 4 == 0, "32-bit words");
-  int w[sizeof(X) / 4];
-  __builtin_memcpy(w, &v, sizeof(X));
-#pragma unroll
-  for (int i = 0; i < int(sizeof(X) / 4); ++i) w[i] = __shfl(w[i], src, 64);
-  X r;
-  __builtin_memcpy(&r, w, sizeof(X));
-  return r;
-}
-
-// Stack entries of k_bvh_collide_ws are PRE-TESTED: the BV test of a pair of nodes is made when the pair is created (its
-// parent is expanded), not when it is visited -- the test is a pure function of the two nodes, only its effects have to
-// happen in DFS order.  An entry therefore says what to do when its turn comes:
-//   WS_EXPAND  e = child base id c | other id o << 16, d = -1 (children c, c+1 of model 1's node against o) or -3
-//              (children of model 2's node): the pair overlaps and is not a leaf pair; its children were chosen
-//              (firstOverSecond) while its nodes were in registers;
-//   WS_LEAF    e = triangle ids, d = -2: both nodes are leaves;
-//   WS_EVENT   d = lower bound >= 0: the pair is disjoint (updateDistanceLowerBoundFromBV when its turn comes).
-// Expanding a pair is ONE memory round trip -- the two children are neighbours in the node array, the other side's
-// node comes with them -- followed by two BV tests; the single-pass kernel pays a round trip per test, and at one wave
-// per SIMD that latency (scattered 128-byte gathers from L2 / MALL) is what its time consists of
-// (profiles/r02_m: 15k vector-memory instructions per wave, 10 % VALU).
-constexpr int WS_BLOCK = 64, WS_STACK = 48;
-template <typename T> struct WsItem {
-  uint32_t e;
-  T d;
-};
-template <typename T> __device__ __forceinline__ bool ws_is_event(const WsItem<T>& x) { return x.d >= T(0); }
-template <typename T> __device__ __forceinline__ bool ws_is_leaf(const WsItem<T>& x) { return x.d == T(-2); }
-
-template <typename T>
-__global__ void __launch_bounds__(WS_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH, 8))) k_bvh_collide_ws(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
-                                                            BvhParams bp, T break_distance2, BvhSplit split) {
-  __shared__ uint32_t stack_e[WS_STACK][WS_BLOCK];
-  __shared__ T stack_d[WS_STACK][WS_BLOCK];
-  __shared__ uint32_t q_count[WS_BLOCK], q_root[WS_BLOCK], q_pair[WS_BLOCK];  // query slots of the wave (one per lane)
-  const uint32_t cnt = wk.counts[B_BVH];
-  uint32_t* const ticket = &wk.counts[B_COUNT + 2];
-  uint32_t* const pool_ctr = &split.ctr[BVH_CTR_TASKS];
-  const uint32_t pool_cap = split.n_queries + split.cap;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const uint64_t lt_mask = (uint64_t(1) << lane) - 1;
-  const T nanv = Lim<T>::nan();
-  constexpr int refill_min = BVH_REFILL_MIN;
-  bool live = false, exhausted = false, pool_full = false;  // exhausted / pool_full are wave-uniform
-  // the segment this lane walks
-  uint32_t seg = WS_NONE, my_parent = WS_NONE, my_pos = 0, my_prev = WS_NONE, last_steal = WS_NONE, nsteals = 0, depth = 0, steps = 0;
-  int root_slot = tid;
-  uint32_t pair = 0;
-  DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
-  Pose<T> tf1, tf2;
-  M3<T> RT_R;
-  V3<T> RT_T;
-  int sp = 0, bot = 0;
-  bool have_cur = false;  // `cur` is the item whose turn it is
-  WsItem<T> cur = {0u, T(0)};
-  bool overflow = false;
-  uint32_t ncontacts = 0;
-  T dlb = Lim<T>::max(), rec_dist = Lim<T>::max(), cand_val = Lim<T>::max();
-  V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1, nn = np1;
-  int fb1 = -1, fb2 = -1;
-  q_count[tid] = 0;
-  auto rec = [&](uint32_t id) { return bvh_sum<T>(split, id); };
-  auto reset_summary = [&]() {
-    overflow = false;
-    ncontacts = 0;
-    dlb = rec_dist = cand_val = Lim<T>::max();
-    np1 = np2 = nn = mk<T>(nanv, nanv, nanv);
-    fb1 = fb2 = -1;
-    nsteals = 0;
-    last_steal = WS_NONE;
-    steps = 0;
-  };
-  auto final_record = [&](uint32_t pr, T rd, const V3<T>& a, const V3<T>& b, const V3<T>& n, uint32_t nc, int f1, int f2, bool ovf) {
-    PairOut<T> o;
-    o.distance = rd;
-    o.normal = n;
-    o.p1 = a;
-    o.p2 = b;
-    o.gjk_status = GJK_DID_NOT_RUN;
-    o.epa_status = EPA_DID_NOT_RUN;
-    o.gjk_iters = o.epa_iters = 0;
-    store_bvh_record(io, pr, o, nc, f1, f2, ovf);
-  };
-  // the BV test of a pair of nodes, made when the pair is created (na of model 1, nb of model 2)
-  auto pretest = [&](const DNode<T>& na, const DNode<T>& nb, uint32_t ia, uint32_t ib) -> WsItem<T> {
-    const bool la = na.first_child < 0, lb = nb.first_child < 0;
-    if (la && lb) return WsItem<T>{uint32_t(-(na.first_child + 1)) | (uint32_t(-(nb.first_child + 1)) << 16), T(-2)};
-    T sq;
-    // argument order of the reference: overlap(RT.R, RT.T, model2.bv(b2), model1.bv(b1))
-    if (obb_disjoint(RT_R, RT_T, nb, na, q.security_margin, break_distance2, sq)) return WsItem<T>{0u, hsqrt(sq)};
-    const bool first = lb || (!la && (sqnorm(na.extent) > sqnorm(nb.extent)));  // firstOverSecond
-    return first ? WsItem<T>{uint32_t(na.first_child) | (ib << 16), T(-1)} : WsItem<T>{uint32_t(nb.first_child) | (ia << 16), T(-3)};
-  };
-  // fold the segment tree of the query in `slot` in DFS order (see k_bvh_combine for the rules) and write its record
-  auto fold = [&](int slot) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the records were written by other lanes of this wave
-    const uint32_t root = q_root[slot];
-    T a_dlb = Lim<T>::max(), a_rd = Lim<T>::max();
-    V3<T> a1 = mk<T>(nanv, nanv, nanv), a2 = a1, an = a1;
-    uint32_t a_nc = 0;
-    int a_f1 = -1, a_f2 = -1;
-    bool a_ovf = false;
-    uint32_t cur_seg = root;
-    for (;;) {
-      const BvhSum<T> c = *rec(cur_seg);
-      a_ovf = a_ovf || (c.flags & BVH_SUM_OVERFLOW);
-      if (c.cand_val < a_dlb) {
-        a1 = c.np1;
-        a2 = c.np2;
-        an = c.nn;
-      }
-      if (c.dlb < a_dlb) {
-        a_dlb = c.dlb;
-        a_rd = c.rec_dist;
-      }
-      if (c.ncontacts) {
-        a_nc = c.ncontacts;
-        a_f1 = c.fb1;
-        a_f2 = c.fb2;
-        break;
-      }
-      if (c.first_child != WS_NONE) {  // its most recent steal comes next
-        cur_seg = c.first_child;
-        continue;
-      }
-      // no steals: the next segment in order is the previous steal of the nearest ancestor-or-self that has one
-      uint32_t up = cur_seg, prev = c.n_child, par = c.parent;
-      while (up != root && prev == WS_NONE) {
-        up = par;
-        if (up == root) break;
-        const BvhSum<T>* u = rec(up);
-        prev = u->n_child;
-        par = u->parent;
-      }
-      if (up == root || prev == WS_NONE) break;
-      cur_seg = prev;
-    }
-    final_record(q_pair[slot], a_rd, a1, a2, an, a_nc, a_f1, a_f2, a_ovf);
-  };
-  auto finish_segment = [&]() {
-    if (seg == WS_NONE) {  // a query that could not get a record (pool full): nobody stole from it
-      final_record(pair, rec_dist, np1, np2, nn, ncontacts, fb1, fb2, overflow);
-      return;
-    }
-    BvhSum<T>* r = rec(seg);  // (contact_order is left alone: other lanes update it atomically)
-    r->dlb = dlb; r->rec_dist = rec_dist; r->cand_val = cand_val;
-    r->np1 = np1; r->np2 = np2; r->nn = nn;
-    r->fb1 = fb1; r->fb2 = fb2;
-    r->ncontacts = ncontacts; r->first_child = last_steal; r->flags = overflow ? BVH_SUM_OVERFLOW : 0u;
-    __threadfence();
-    if (atomicSub(&q_count[root_slot], 1u) == 1u) fold(root_slot);
-  };
-  auto link_record = [&]() {  // the immutable part of this lane's new segment record
-    BvhSum<T>* r = rec(seg);
-    r->parent = my_parent;
-    r->order = my_pos;
-    r->n_child = my_prev;
-    r->first_child = WS_NONE;
-    r->contact_order = WS_NONE;
-    r->pad_ = 0;
-  };
-  auto moot = [&]() -> bool {  // has a contact earlier in DFS order ended the walk?
-    uint32_t p = my_parent, o = my_pos;
-    for (int hop = 0; hop < 40 && p != WS_NONE; ++hop) {
-      const BvhSum<T>* ps = rec(p);
-      if (__hip_atomic_load(&ps->contact_order, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o) return true;
-      o = ps->order;
-      p = ps->parent;
-    }
-    return false;
-  };
-  auto report_contact = [&]() {  // own work has position 0: every steal of this segment lies behind it ...
-    if (seg == WS_NONE) return;
-    atomicMin(&rec(seg)->contact_order, 0u);
-    uint32_t p = my_parent, o = my_pos;  // ... and so do the steals the ancestors made before the one this segment is in
-    for (int hop = 0; hop < 40 && p != WS_NONE; ++hop) {
-      BvhSum<T>* ps = rec(p);
-      atomicMin(&ps->contact_order, o);
-      o = ps->order;
-      p = ps->parent;
-    }
-  };
-  for (;;) {
-    // ---- items whose effect is immediate: BV events update the bound, then the next item is taken from the stack
-    while (live && (!have_cur || ws_is_event(cur))) {
-      if (have_cur) {  // updateDistanceLowerBoundFromBV
-        if (!(dlb <= T(0)) && cur.d < dlb) {
-          dlb = cur.d;
-          rec_dist = cur.d + q.security_margin;
-        }
-        have_cur = false;
-      }
-      if (sp == bot) break;
-      --sp;
-      cur = WsItem<T>{stack_e[sp][tid], stack_d[sp][tid]};
-      have_cur = true;
-    }
-    if (live && !have_cur) {  // segment over
-      finish_segment();
-      live = false;
-    }
-    const uint64_t live_mask = __ballot(live);
-    const int n_live = __popcll(live_mask);
-    if (exhausted && n_live == 0) break;
-    if (!exhausted && 64 - n_live >= refill_min) {
-      // ---- refill from the queue of queries (wave-uniform decision; live lanes sit it out)
-      const int n_need = 64 - n_live;
-      uint32_t base = 0, sbase = 0;
-      if (lane == 0) {
-        base = atomicAdd(ticket, uint32_t(n_need));
-        sbase = atomicAdd(pool_ctr, uint32_t(n_need));
-      }
-      base = __builtin_amdgcn_readfirstlane(base);
-      sbase = __builtin_amdgcn_readfirstlane(sbase);
-      if (!live) {
-        const uint32_t rank = uint32_t(__popcll(~live_mask & lt_mask));
-        const uint32_t it = base + rank;
-        if (it < cnt) {
-          pair = wk.lists[size_t(B_BVH) * wk.n + it];
-          const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
-          m1 = bv.meshes[a.bvh_index];
-          m2 = bv.meshes[b.bvh_index];
-          tf1 = load_pose(io.tf1, pair);
-          tf2 = load_pose(io.tf2, pair);
-          RT_R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
-          RT_T = tmul(tf1.R, tf2.t - tf1.t);
-          bot = sp = 0;
-          reset_summary();
-          cur = pretest(bv.nodes[m1.node_off], bv.nodes[m2.node_off], 0u, 0u);  // the root pair
-          have_cur = true;
-          root_slot = tid;
-          my_parent = WS_NONE;
-          my_pos = 0;
-          my_prev = WS_NONE;
-          depth = 0;
-          seg = sbase + rank < pool_cap ? sbase + rank : WS_NONE;
-          if (seg != WS_NONE) {
-            link_record();
-            q_count[tid] = 1u;
-            q_root[tid] = seg;
-            q_pair[tid] = pair;
-          }
-          live = true;
-        }
-      }
-      if (sbase + uint32_t(n_need) >= pool_cap) pool_full = true;
-      if (base + uint32_t(n_need) >= cnt) exhausted = true;
-      continue;
-    }
-    if (exhausted && !pool_full) {
-      // ---- steal round: the k-th idle lane takes the bottom stack entry of the k-th lane that can spare one
-      const bool idle = !live;
-      const bool victim = live && sp - bot >= 1 && seg != WS_NONE && depth < 30;
-      const uint64_t I = __ballot(idle), V = __ballot(victim);
-      const int n = min(__popcll(I), __popcll(V));
-      if (n > 0) {
-        uint32_t sbase = 0;
-        if (lane == 0) sbase = atomicAdd(pool_ctr, uint32_t(n));
-        sbase = __builtin_amdgcn_readfirstlane(sbase);
-        if (sbase + uint32_t(n) > pool_cap) {
-          pool_full = true;
-        } else {
-          const int rI = __popcll(I & lt_mask), rV = __popcll(V & lt_mask);
-          const bool thief = idle && rI < n, donor = victim && rV < n;
-          // what a donor hands over (computed by every lane, read from the donor's by its thief)
-          WsItem<T> give = {0u, T(0)};
-          uint32_t give_prev = last_steal, give_pos = 0;
-          if (donor) {
-            give = WsItem<T>{stack_e[bot][tid], stack_d[bot][tid]};
-            ++bot;
-            ++nsteals;
-            give_pos = WS_POSBASE - nsteals;
-            last_steal = sbase + uint32_t(rV);
-          }
-          const int src = nth_set_bit(V, thief ? rI : 0);
-          const WsItem<T> t_item = shfl_any(give, src);
-          const uint32_t t_prev = __shfl(give_prev, src, 64), t_pos = __shfl(give_pos, src, 64);
-          const uint32_t t_parent = __shfl(seg, src, 64), t_pair = __shfl(pair, src, 64), t_depth = __shfl(depth, src, 64);
-          const int t_root = __shfl(root_slot, src, 64);
-          const DMesh t_m1 = shfl_any(m1, src), t_m2 = shfl_any(m2, src);
-          const Pose<T> t_tf1 = shfl_any(tf1, src), t_tf2 = shfl_any(tf2, src);
-          const M3<T> t_R = shfl_any(RT_R, src);
-          const V3<T> t_T = shfl_any(RT_T, src);
-          if (thief) {
-            pair = t_pair;
-            m1 = t_m1; m2 = t_m2;
-            tf1 = t_tf1; tf2 = t_tf2;
-            RT_R = t_R; RT_T = t_T;
-            root_slot = t_root;
-            my_parent = t_parent;
-            my_pos = t_pos;
-            my_prev = t_prev;
-            depth = t_depth + 1;
-            seg = sbase + uint32_t(rI);
-            reset_summary();
-            bot = sp = 0;
-            cur = t_item;
-            have_cur = true;
-            link_record();
-            atomicAdd(&q_count[root_slot], 1u);
-            live = true;
-          }
-        }
-      }
-    }
-    // ---- expansion: every lane whose item is an overlapping pair loads its two children (neighbours in the node array)
-    // and the other side's node in one go, tests both children, keeps the first as its item and stacks the second
-    const bool do_expand = live && have_cur && !ws_is_event(cur) && !ws_is_leaf(cur);
-    const int n_leaf = __popcll(__ballot(live && have_cur && ws_is_leaf(cur)));
-    if (__any(do_expand) && n_leaf < 32) {
-      if (do_expand) {
-        if (my_parent != WS_NONE && (steps & 15u) == 15u && moot()) {  // a contact earlier in DFS order ended the walk
-          sp = bot;
-          have_cur = false;
-        } else {
-          ++steps;
-          const bool side1 = cur.d == T(-1);
-          const uint32_t c = cur.e & 0xFFFFu, o = cur.e >> 16;
-          WsItem<T> A, B;
-          if (side1) {
-            const DNode<T> no = bv.nodes[m2.node_off + o];
-            A = pretest(bv.nodes[m1.node_off + c], no, c, o);
-            B = pretest(bv.nodes[m1.node_off + c + 1], no, c + 1, o);
-          } else {
-            const DNode<T> no = bv.nodes[m1.node_off + o];
-            A = pretest(no, bv.nodes[m2.node_off + c], o, c);
-            B = pretest(no, bv.nodes[m2.node_off + c + 1], o, c + 1);
-          }
-          if (sp + 1 > WS_STACK && bot > 0) {  // the space below the bottom was given away: move the stack down
-            for (int k = bot; k < sp; ++k) {
-              stack_e[k - bot][tid] = stack_e[k][tid];
-              stack_d[k - bot][tid] = stack_d[k][tid];
-            }
-            sp -= bot;
-            bot = 0;
-          }
-          if (sp + 1 > WS_STACK) {
-            overflow = true;
-            sp = bot;
-            have_cur = false;
-          } else {
-            stack_e[sp][tid] = B.e;
-            stack_d[sp][tid] = B.d;
-            ++sp;
-            cur = A;
-          }
-        }
-      }
-      continue;
-    }
-    // ---- leaf phase (leafCollides, traversal_node_bvhs.h:184-233): the lanes whose item is a triangle pair
-    if (live && have_cur && ws_is_leaf(cur)) {
-      have_cur = false;
-      steps += 8;
-      const uint32_t lb1 = cur.e & 0xFFFFu, lb2 = cur.e >> 16;
-      const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + lb1);
-      const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + lb2);
-      const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
-      const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
-      auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
-      TriSupport<T> tri;
-      tri.p1 = xform(tf1, vtx(v1, t1[0]));
-      tri.p2 = xform(tf1, vtx(v1, t1[1]));
-      tri.p3 = xform(tf1, vtx(v1, t1[2]));
-      tri.q1 = xform(tf2, vtx(v2, t2[0]));
-      tri.q2 = xform(tf2, vtx(v2, t2[1]));
-      tri.q3 = xform(tf2, vtx(v2, t2[2]));
-      V3<T> p1, p2, n;
-      int gst, git;
-      const T distance = tri_tri_distance(tri, q.gjk, q.guess_mode == HFCL_GUESS_CACHED,
-                                          mk<T>(q.guess[0], q.guess[1], q.guess[2]), p1, p2, n, gst, git);
-      const T dtc = distance - q.security_margin;
-      if (dtc < dlb) {  // updateDistanceLowerBoundFromLeaf
-        dlb = dtc;
-        cand_val = dtc;
-        rec_dist = distance;
-        np1 = p1;
-        np2 = p2;
-        nn = n;
-      }
-      if (dtc <= q.collision_distance_threshold) {  // num_max_contacts == 1: the walk ends (canStop())
-        fb1 = int(lb1);
-        fb2 = int(lb2);
-        ncontacts = 1;
-        report_contact();
-        sp = bot;
       }
     }
   }
@@ -1388,10 +957,6 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
     split.can_suspend = 0;
     if (spill.slab) grid = std::min(grid, int(spill.max_blocks));
     launch_collide_kernel<T>(true, grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
-    return;
-  }
-  if (split.steal && split.sums && bp.num_max_contacts == 1 && !bp.contacts) {
-    hipLaunchKernelGGL((k_bvh_collide_ws<T>), dim3(grid * (BVH_BLOCK / WS_BLOCK)), dim3(WS_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split);
     return;
   }
   const bool splitting = split.tasks && split.n_levels > 1 && bp.num_max_contacts == 1 && !bp.contacts;

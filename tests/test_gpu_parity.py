@@ -438,16 +438,13 @@ def _check_bvh_records(abi, got, ref, name):
     assert np.abs(sep_g[m] - sep_r[m]).max() < 1e-5
 
 
-@pytest.mark.parametrize("form", ["default", "steal", "filter"])
+@pytest.mark.parametrize("form", ["default", "filter"])
 @pytest.mark.parametrize("seg,n", [(12, 20000), (50, 4000)])
 def test_bvh_collide_first_contact(pkg, oracle, seg, n, form, monkeypatch):
     """Default request (num_max_contacts = 1): collision flag and the first contact's (b1, b2) in the
-    reference's DFS order are exact; depth / witness data to 1e-6.  steal: the same through k_bvh_collide_ws (segments
-    of a traversal walked by several lanes, folded back in DFS order); filter: through the fp32 separating-axis filter in
+    reference's DFS order are exact; depth / witness data to 1e-6.  filter: through the fp32 separating-axis filter in
     front of the fp64 test (HFCL_BVH_FILTER=1: the decisions of the default form, numbers to the last bits)."""
     abi, wl = pkg.abi, pkg.workloads
-    if form == "steal":
-        monkeypatch.setenv("HFCL_BVH_STEAL", "1")
     if form == "filter":
         b0 = wl.cfg4_mesh_mesh(n=n, seg=seg, ring=seg, n_variants=4)
         plain, _, _ = _run_bvh(pkg, oracle, b0, wl.make_request(b0, abi))
