@@ -95,6 +95,8 @@ def parse():
                     "delivered: block checksums of every rank; --scaling strong: bytes equal to the whole list run on rank 0")
     ap.add_argument("--split", type=int, default=0, help="0: the library decides (two half-batches on two streams for "
                     "mixed libraries); 1: one stream; 2: always split")
+    ap.add_argument("--two-streams", action="store_true", help="with --workload: even / odd steps on two streams (two batches in "
+                    "flight); a throughput figure beside the one-stream headline, never instead of it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--host-buffers", action="store_true", help="with --workload cfg2/cfg5/...: also time the batch through the host-buffer boundary")
@@ -282,7 +284,7 @@ def host_boundary(pkg, lib, batch, req, device_records):
 
 
 def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s=10.0, cpu_sample=1_000_000, host_buffers=False,
-                 gather=None):
+                 gather=None, two_streams=False):
     """One timed region: `steps` passes of the hot path over this rank's batch.  Returns the result dict on rank 0."""
     import torch
     import torch.distributed as dist
@@ -295,6 +297,11 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
     lib = wl.make_library(pkg, full, device=ctx.device_index)
     if args.split:
         lib.set_split(args.split)
+    # two_streams (a secondary line only, never the headline): even steps on the caller's stream, odd steps on a second
+    # stream through a second library object (own workspace), as a throughput-oriented caller with independent batches
+    # would run them -- the GJK kernels of one batch fill the drain of the other's EPA kernels
+    lib2 = wl.make_library(pkg, full, device=ctx.device_index) if two_streams else None
+    stream2 = torch.cuda.Stream(device=dev) if two_streams else None
 
     d_s1 = torch.from_numpy(batch.s1.astype(np.int32)).to(dev)
     d_s2 = torch.from_numpy(batch.s2.astype(np.int32)).to(dev)
@@ -324,7 +331,9 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
         if exchange:
             # double buffering: the kernels of step i overwrite the buffer the exchange of step i-2 read
             xch.before_launch(buf)
-        if n:
+        if n and two_streams and buf and not record_times:
+            launch2(d_s1, d_s2, d_p1, d_p2, n, req, outs[buf], stream=stream2.cuda_stream)
+        elif n:
             launch(d_s1, d_s2, d_p1, d_p2, n, req, outs[buf], stream=stream.cuda_stream)
         if exchange:
             # results of this step travel over xGMI while the next step's kernels run
@@ -340,6 +349,11 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
         torch.cuda.synchronize()
 
     lib.set_kernel_timing(False)  # the timed region runs without the per-kernel event markers
+    if two_streams:
+        assert not gather, "the two-stream form is a single-GPU secondary line"
+        lib2.set_kernel_timing(False)
+        kind_fn = ("distance" if batch.kind == "distance" else "collide") + "_device" + ("_f32" if dtype == "f32" else "")
+        launch2 = getattr(lib2, kind_fn)
     for i in range(warmup):
         one_step(i, False)
         xch.drain()
@@ -440,7 +454,8 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
         if not args.no_cpu_baseline and ctx.world == 1 and cpu_budget_s > 0:  # reported on rank 0 at N=1 only
             cpu = cpu_baseline(ctx, workload, batch, req, cpu_sample, cpu_budget_s)
         result = {
-            "workload": batch.name, "value": qps, "unit": "queries/s", "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
+            "workload": batch.name + (" (two batches in flight: even / odd steps on two streams)" if two_streams else ""),
+            "value": qps, "unit": "queries/s", "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
             "dtype": dtype, "scaling": "strong" if strong else "weak",
             "config": {"workload": batch.name, **extra_cfg, "baseline_config": BASELINE_CONFIG[workload],
                        "pairs_per_gpu_per_step": n, "pairs_per_step_all_gpus": n_total if strong else n * ctx.world,
@@ -460,6 +475,8 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
                 result["host_buffers"]["other_sizes"] = [
                     host_boundary(pkg, lib, wl.cfg2_box_capsule(n=m, seed=1 + ctx.rank), req, None) for m in (250_000, 4_000_000)]
     lib.close()
+    if lib2 is not None:
+        lib2.close()
     del d_s1, d_s2, d_p1, d_p2, outs, xch
     torch.cuda.empty_cache()
     return result
@@ -508,12 +525,15 @@ def main():
     headline_wl = args.workload or "cfg3"
     strong = args.scaling == "strong"
     head = run_workload(ctx, headline_wl, args.pairs, args.steps, args.warmup, strong=strong,
-                        cpu_budget_s=10.0, cpu_sample=args.cpu_sample, host_buffers=args.host_buffers)
+                        cpu_budget_s=10.0, cpu_sample=args.cpu_sample, host_buffers=args.host_buffers,
+                        two_streams=bool(args.two_streams and args.workload and ctx.world == 1))
     secondary = []
     if args.workload is None and not args.no_secondary:
         sec_steps = max(3, min(args.steps, 10))
         plan = [("cfg2", 0, False, dict(host_buffers=True)), ("cfg4", 0, False, {}), ("cfg5", 0, False, {}),
                 ("cfg5", 10_000_000, True, {}), ("cfg3u", 0, False, {}), ("cfg2f", 0, False, {})]
+        if ctx.world == 1:  # what the drain phases of the headline's kernels cost: the same steps, two batches in flight
+            plan += [("cfg3", 0, False, dict(two_streams=True)), ("cfg4", 0, False, dict(two_streams=True))]
         if ctx.world > 1:  # the same list with the 24-B exchange format, and the headline without any exchange
             plan += [("cfg5", 10_000_000, True, dict(gather="compact")), ("cfg3", 0, False, dict(gather="none"))]
         for wl_name, pairs, st, kw in plan:

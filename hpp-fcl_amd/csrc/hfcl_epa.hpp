@@ -181,9 +181,16 @@ HFCL_HD void epa_support(Sup& sup, const V3<T>& dir, V3<T>& w, V3<T>& w0, int& t
   }
 }
 
+// HFCL_EPA_PAR_HZ: 1 = the fp32 convex x convex fast tier (the V0_TAG blocks) finds the horizon of an expansion with all
+// lanes at once (Epa::silhouette_parallel) instead of walking it; 2 = every fp32 polytope (validation builds); 0 = never.
+// fp64 always walks: its statuses and iteration counts are the reference's to the letter.
+#ifndef HFCL_EPA_PAR_HZ
+#define HFCL_EPA_PAR_HZ 1
+#endif
 template <typename T, class Grp, int CAP = EPA_MAX_ITER, int V0M = V0_BLOCK>
 struct Epa {
   static constexpr bool TAGGED = V0M == V0_TAG;
+  static constexpr bool PARALLEL_HORIZON = sizeof(T) == 4 && (HFCL_EPA_PAR_HZ >= 2 || (HFCL_EPA_PAR_HZ == 1 && V0M == V0_TAG));
   typedef EpaScratch<T, CAP, V0M> Block;
   Block* m;
   Quad<T>* v0p;  // m->v0, or the caller's array (V0_EXTERN); unused with tags
@@ -488,6 +495,111 @@ struct Epa {
     }
   }
 
+  // The horizon without a walk (fp32 fast tier).  expand() (:1361-1449) walks from the closest face over the faces the new
+  // vertex is above and lists the edges where it meets a face the vertex is below: a chain of dependent LDS round trips
+  // (frame, face record, plane, vertex: ~300 clocks per visited face, a dozen faces per expansion), executed by every lane
+  // of the group, with the groups of a wave diverging on it.  Here every lane classifies its share of the hull's faces --
+  // independent loads -- marks the visible ones with the pass mark the rest of the expansion works with, and appends
+  // (kept face, edge) for every edge of a kept face whose neighbour is marked.  Two tables (vertex -> the new face that starts
+  // / ends there along the horizon; they overlay the walk's stack) give every new face its two neighbours without an order
+  // on the horizon.  What differs from the walk, and why this form is fp32 only: a face is tested against its first
+  // vertex, not the vertex of the edge it was entered through (last bits); a face the vertex is above is removed wherever
+  // it lies, not only when it is connected to the closest face through such faces; the new faces get their stamps in list
+  // order, not walk order (stamps only break exact ties of the closest-face search).  The expansion remains a valid
+  // hull update, so EPA converges to the same depth (tests/test_epa_ground_truth.py holds it to the qhull ground truth).
+  // Returns false -- marks undone by the caller, the walk decides -- when the marked faces do not leave a horizon of simple
+  // closed loops (a vertex with two outgoing or two incoming horizon edges, or an open end).
+  HFCL_HD bool silhouette_parallel(int pass, int closest, T dummy_precision, const V3<T>& ww, int& hz_count) {
+    const int nf = 2 * cap_iterations + 4;
+    uint8_t* const start_at = reinterpret_cast<uint8_t*>(m->stack);  // [vertex] -> horizon entry whose new face starts there
+    uint8_t* const end_at = start_at + Block::NV;                     // [vertex] -> ... ends there
+    static_assert(2 * Block::NV <= int(sizeof(uint16_t)) * Block::NF, "the vertex tables overlay the walk stack");
+    // (fixed trip counts, loads of all of a lane's faces issued before any is used: the point is independent loads)
+    constexpr int PER_LANE = (Block::NF + Grp::W - 1) / Grp::W;
+    {
+      FaceTopo t[PER_LANE];
+      Quad<T> pl[PER_LANE];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int j = 0; j < PER_LANE; ++j) {
+        const int f = Grp::lane() + j * Grp::W;
+        const int fc = f < nf ? f : 0;
+        t[j] = m->ft[fc];
+        pl[j] = m->fn[fc];
+      }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int j = 0; j < PER_LANE; ++j) {
+        const int f = Grp::lane() + j * Grp::W;
+        const V3<T> v = vw(t[j].vid(0));
+        const bool in_play = f < nf && (t[j].flag() & 1) && f != closest;
+        if (in_play && !(dot(mk<T>(pl[j].x, pl[j].y, pl[j].z), ww - v) < dummy_precision)) set_pass(f, pass);
+      }
+    }
+    for (int v = Grp::lane(); v < 2 * Block::NV; v += Grp::W) start_at[v] = 255;
+    if (Grp::lane() == 0) m->top = 0u;
+    Grp::sync();
+    {
+      FaceTopo t[PER_LANE];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int j = 0; j < PER_LANE; ++j) {
+        const int f = Grp::lane() + j * Grp::W;
+        t[j] = m->ft[f < nf ? f : 0];
+      }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int j = 0; j < PER_LANE; ++j) {
+        const int f = Grp::lane() + j * Grp::W;
+        const bool kept = f < nf && (t[j].flag() & 1) && t[j].pass() != pass;
+        const int p0 = m->ft[t[j].adj(0)].pass(), p1 = m->ft[t[j].adj(1)].pass(), p2 = m->ft[t[j].adj(2)].pass();
+        if (kept) {
+          if (p0 == pass) {
+            const uint32_t k = Grp::atomic_inc(&m->top);
+            if (k < uint32_t(Block::NF)) m->hz[k] = typename Block::HzT(hz_pack(f, 0));
+          }
+          if (p1 == pass) {
+            const uint32_t k = Grp::atomic_inc(&m->top);
+            if (k < uint32_t(Block::NF)) m->hz[k] = typename Block::HzT(hz_pack(f, 1));
+          }
+          if (p2 == pass) {
+            const uint32_t k = Grp::atomic_inc(&m->top);
+            if (k < uint32_t(Block::NF)) m->hz[k] = typename Block::HzT(hz_pack(f, 2));
+          }
+        }
+      }
+    }
+    Grp::sync();
+    hz_count = int(m->top);
+    if (hz_count > Block::NF) return false;
+    // new face of entry k: (a = f[e+1], b = f[e], w): it starts at a and ends at b along the horizon
+    for (int k = Grp::lane(); k < hz_count; k += Grp::W) {
+      const unsigned fr = m->hz[k];
+      const FaceTopo t = m->ft[hz_face(fr)];
+      const int e = hz_edge(fr);
+      start_at[t.vid((e + 1) % 3)] = uint8_t(k);
+      end_at[t.vid(e)] = uint8_t(k);
+    }
+    Grp::sync();
+    int bad = 0;
+    for (int k = Grp::lane(); k < hz_count; k += Grp::W) {
+      const unsigned fr = m->hz[k];
+      const FaceTopo t = m->ft[hz_face(fr)];
+      const int e = hz_edge(fr), a = t.vid((e + 1) % 3), b = t.vid(e);
+      // the only entry that starts at a / ends at b, and the loop goes on at both ends
+      if (start_at[a] != k || end_at[b] != k || start_at[b] == 255 || end_at[a] == 255) bad = 1;
+    }
+    butterfly_stages<Grp::W>([&](auto stage) {
+      constexpr int M = decltype(stage)::value;
+      bad |= Grp::template exchange<M>(bad);
+    });
+    return bad == 0;
+  }
+
   // One polytope expansion by vertex id_w seen from face `closest` (the body of the loop
   // :1261-1280).  Returns true when the hull was updated (valid && horizon >= 3); on false the
   // caller leaves the loop and `status` is what the reference's first failing step sets.
@@ -500,8 +612,21 @@ struct Epa {
     const T dummy_precision = sizeof(T) == 4 ? T(2e-7) : T(4.470348358154297e-08);
     const V3<T> ww = vw(id_w);
     int hz_count = 0, stop_kind = 0, stop_at = 0;
-    silhouette_walk_fast(pass, closest, dummy_precision, ww, hz_count, stop_kind, stop_at);
+    bool by_tables = false;  // the new faces find their neighbours through the vertex tables (no order on the horizon)
+    if constexpr (PARALLEL_HORIZON) {
+      by_tables = silhouette_parallel(pass, closest, dummy_precision, ww, hz_count);
+      if (!by_tables) {  // not a horizon of simple loops: marks undone, the walk decides
+        const int nfu = 2 * cap_iterations + 4;
+        Grp::sync();
+        for (int f = Grp::lane(); f < nfu; f += Grp::W)
+          if ((m->ft[f].flag() & 1) && m->ft[f].pass() == pass && f != closest) set_pass(f, 0);
+        Grp::sync();
+        hz_count = 0;
+      }
+    }
+    if (!by_tables) silhouette_walk_fast(pass, closest, dummy_precision, ww, hz_count, stop_kind, stop_at);
     if (hz_count > stock_top) {
+      by_tables = false;
       // More horizon edges than free faces: whether (and where) the reference runs out of faces
       // depends on how its pops and pushes interleave -> undo the marks and redo the walk with
       // the stock level tracked (rare: only near the capacity of the face store).
@@ -550,10 +675,12 @@ struct Epa {
       const unsigned fr = m->hz[k];
       const int f = hz_face(fr), e = hz_edge(fr), e1 = (e + 1) % 3;
       const int nfc = m->stock[stock_top - 1 - k];
-      const int kp = (k == 0) ? n_new - 1 : k - 1;  // previous face on the horizon loop
-      const int pf = m->stock[stock_top - 1 - kp];
       const uint32_t fv = m->ft[f].vf;
-      const int fail = face_geometry(nfc, int((fv >> (8 * e1)) & 255u), int((fv >> (8 * e)) & 255u), id_w, false, stamp + k);
+      const int va = int((fv >> (8 * e1)) & 255u), vb = int((fv >> (8 * e)) & 255u);
+      // previous face on the horizon loop: the one before it in walk order, or the one that ends where this one starts
+      const int kp = by_tables ? int(reinterpret_cast<const uint8_t*>(m->stack)[Block::NV + va]) : ((k == 0) ? n_new - 1 : k - 1);
+      const int pf = m->stock[stock_top - 1 - kp];
+      const int fail = face_geometry(nfc, va, vb, id_w, false, stamp + k);
       // bind(nf, 0, f, e); bind(nf, 2, previous, 1)  (:1421-1425, closing bind :1273)
       set_adj(nfc, 0, f, e);
       set_adj(f, e, nfc, 0);
