@@ -183,7 +183,8 @@ HFCL_HD void epa_support(Sup& sup, const V3<T>& dir, V3<T>& w, V3<T>& w0, int& t
 
 // HFCL_EPA_PAR_HZ: 1 = the fp32 convex x convex fast tier (the V0_TAG blocks) finds the horizon of an expansion with all
 // lanes at once (Epa::silhouette_parallel) instead of walking it; 2 = every fp32 polytope (validation builds); 0 = never.
-// fp64 always walks: its statuses and iteration counts are the reference's to the letter.
+// fp64 always walks: its statuses and iteration counts are the reference's to the letter.  (The full-capacity fp32 tier walks
+// too: with 132 face slots, 9 per lane, classifying all of them costs more than walking a dozen: 0.215 against 0.18 ms.)
 #ifndef HFCL_EPA_PAR_HZ
 #define HFCL_EPA_PAR_HZ 1
 #endif
