@@ -129,6 +129,7 @@ struct hfcl_lib {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool kernel_timing = true;         // HIP events around every kernel (hfcl_lib_set_kernel_timing)
   uint32_t possible_buckets = ~0u;   // bit b: some pair of this library's shape kinds classifies into bucket b
+  bool has_curved = true;            // some shape is an Ellipsoid / Cone / Cylinder: the curved class of the fp64 EPA tiers can occur
   int cvx_w = 0;  // 0 = per kernel (auto_cvx_w); HFCL_CVX_W forces one width for all
   bool closed_staged = true;  // HFCL_CLOSED_STAGED=0: A/B switch back to the direct-access k_closed<double>
   int n_cus = 256;
@@ -349,6 +350,7 @@ static bool upload_shapes(hfcl_lib* lib, const hfcl_shape* shapes, size_t n_shap
         for (int b = 0; b < 256; ++b)
           if (present[b]) mask |= 1u << bucket_of(a, b);
     lib->possible_buckets = mask;
+    lib->has_curved = present[K_ELLIPSOID] || present[K_CONE] || present[K_CYLINDER];
   }
   lib->h_kinds = kinds;
   std::vector<float> v32(3 * n_vertices + 3);
@@ -1075,7 +1077,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     tbeg("k_epa<fast>");
     // (the launcher sizes the grid of the persistent forms itself: here only the number of wave-sized batches)
     launch_epa_fast<T>(int(std::min<size_t>((n + 64 / EPA_WE - 1) / (64 / EPA_WE), size_t(1) << 22)), st, wk, lv, io, q, may(B_CC),
-                       may(B_PRIM) || may(B_PC) || may(B_CP), lib->n_cus);
+                       may(B_PRIM) || may(B_PC) || may(B_CP), lib->n_cus, lib->has_curved);
     tend();
     tbeg("k_epa<full>");
     launch_epa_full<T>(blocks_for(n / 16 + 1, 64 / epa_we2<T>), st, wk, lv, io, q);
@@ -1105,6 +1107,7 @@ static void share_tables(hfcl_lib* h, const hfcl_lib* lib) {
   h->d_verts32 = lib->d_verts32;
   h->d_kinds = lib->d_kinds;
   h->possible_buckets = lib->possible_buckets;
+  h->has_curved = lib->has_curved;
   h->d_graph_base = lib->d_graph_base;
   h->d_graph_off = lib->d_graph_off;
   h->d_graph_ent32 = lib->d_graph_ent32;

@@ -35,8 +35,9 @@ void launch_compact_records(hipStream_t st, const hfcl_result_f32* in, hfcl_resu
 
 // tier 1 (fp32: streaming form) and tier 2 of EPA; the grids are in blocks of one wavefront
 // cc_queue / general_queue (fp32): which of the two streaming forms have anything to do (convex x convex pairs have a
-// queue and a kernel of their own)
-template <typename T> void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool cc_queue, bool general_queue, int n_cus);
+// queue and a kernel of their own); curved_class (fp64): the library has a shape whose support is not a vertex, i.e. the
+// curved class of pairs -- a queue and a fast-tier kernel of its own -- can occur
+template <typename T> void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool cc_queue, bool general_queue, int n_cus, bool curved_class = true);
 template <typename T> void launch_epa_full(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q);
 
 // split: the task tables of a split traversal (tasks == nullptr: single pass)
