@@ -38,13 +38,13 @@ def one_pass(counters, workload, outdir, pairs):
         per = collections.defaultdict(list)
         for k, _, v in rows:
             per[k].append(v)
-        # mean over the dispatches that did work: a kernel that is also launched on (nearly) empty ranges -- the task
-        # levels of k_bvh_collide, the chunks of a host call -- would otherwise dilute the per-launch figure
-        res[c] = {}
-        for k, vals in per.items():
-            top = max(vals)
-            heavy = [v for v in vals if v >= 0.25 * top] if top > 0 else vals
-            res[c][k] = (sum(heavy) / len(heavy), len(heavy))
+        # PER PASS OF THE PIPELINE, like the kernel times of the bench line (the HIP events of a timer label span all
+        # launches of that kernel within one pass: the twelve task-level launches of k_bvh_collide are one figure
+        # there): every counter summed over all dispatches of the kernel, divided by the number of passes = dispatches
+        # of k_classify (one per batch, or per half of a split batch).  Round 2 averaged over the "heavy" dispatches
+        # only, which did not match the summed times.
+        passes = max([len(v) for k, v in per.items() if "k_classify" in k] or [1])
+        res[c] = {k: (sum(vals) / passes, len(vals) / passes) for k, vals in per.items()}
     return res[names[0]] if single else res
 
 
@@ -58,7 +58,7 @@ if __name__ == "__main__":
     res = collections.defaultdict(dict)
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for k, (v, n) in one_pass(c, a.workload, os.path.join(scratch, c), a.pairs).items():
-            res[k][c + "_KB_per_dispatch"] = v
+            res[k][c + "_KB_per_dispatch"] = v  # (per pass of the pipeline: all dispatches of the kernel in one batch)
             res[k]["dispatches"] = n
     # issue-side counters in their own pass: wave instructions by type per dispatch (the iterative kernels are bound
     # by VALU issue, not by HBM: bench.py reports SQ_INSTS_VALU against the chip's issue peak next to the HBM fraction)
@@ -73,7 +73,7 @@ if __name__ == "__main__":
     sys.path.insert(0, ROOT)
     from bench import kernel_source_sha  # the pass is only quoted by bench.py for the device code it was taken on
     json.dump({"workload": a.workload, "pairs": a.pairs or None, "source_sha": kernel_source_sha(),
-               "unit": "KB as reported by rocprofv3 (uncorrected)",
+               "unit": "KB as reported by rocprofv3 (uncorrected), summed over the kernel's dispatches within one pass of the pipeline",
                "kernels": {k: v for k, v in res.items() if k.startswith("void k_") or k.startswith("k_")}},
               open(out, "w"), indent=1)
     print(open(out).read())
