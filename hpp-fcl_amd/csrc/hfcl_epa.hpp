@@ -81,7 +81,7 @@ struct alignas(4 * sizeof(T) > 16 ? 16 : 4 * sizeof(T)) Quad {  // one LDS vecto
 // tier can continue it instead of starting over (the first CAP iterations are the reference's in
 // either tier, so continuing is bit-identical to restarting).
 struct EpaHeader {
-  int32_t closest, iterations, pass, status, num_vertices, hull_count, stock_top, stamp;
+  int32_t closest, iterations, pass, status, num_vertices, hull_count, stock_top, stamp, hw;
 };
 // Where the shape-0 support point of every polytope vertex lives (needed once, for the witness points):
 //   V0_BLOCK   in the scratch block itself;
@@ -206,6 +206,11 @@ struct Epa {
   int stock_top;
   int stamp;
   int pending_release;  // pass mark of faces still to be released by the next find_closest_face(), or -1
+  // High-water mark of the face store: slots >= hw were never used.  The stock hands out slot 0, 1, 2, ... and reuses
+  // released slots first, so a polytope at iteration i occupies the first ~2i + 4 slots of its block, and every scan over
+  // "all faces" (closest face, releases, horizon) stops at hw instead of the block's capacity -- half the slots of a
+  // fast-tier block for the average polytope, a third of the full tier's 132.
+  int hw;
 
   HFCL_HD V3<T> vw(int i) const {
     const Quad<T> q = m->vw[i];
@@ -279,6 +284,7 @@ struct Epa {
     hull_count = 0;
     stamp = 0;
     pending_release = -1;
+    hw = 0;
     const int nf = 2 * cap_iterations + 4;
     // face 0 on top of the stock, as in the reference (stock filled in reverse order)
     for (int i = Grp::lane(); i < nf; i += Grp::W) {
@@ -332,6 +338,7 @@ struct Epa {
     }
     const int f = m->stock[--stock_top];
     ++hull_count;
+    if (f + 1 > hw) hw = f + 1;
     const int fail = face_geometry(f, ia, ib, ic, force, stamp++);
     if (!fail) return f;
     status = fail;
@@ -349,7 +356,7 @@ struct Epa {
     pending_release = -1;
     if (rel >= 0 && Grp::lane() == 0) m->top = uint32_t(stock_top);
     Grp::sync();
-    const int nf = 2 * cap_iterations + 4;
+    const int nf = hw;
     T best = Lim<T>::max();
     int best_stamp = -1, best_f = EPA_NULL;
     int head_stamp = -1, head_f = EPA_NULL;
@@ -406,7 +413,7 @@ struct Epa {
   HFCL_HD void release_visible(int pass) {
     if (Grp::lane() == 0) m->top = uint32_t(stock_top);
     Grp::sync();
-    const int nf = 2 * cap_iterations + 4;
+    const int nf = hw;
     for (int f = Grp::lane(); f < nf; f += Grp::W)
       if ((m->ft[f].flag() & 1) && m->ft[f].pass() == pass) {
         set_flag(f, 0);
@@ -511,7 +518,7 @@ struct Epa {
   // Returns false -- marks undone by the caller, the walk decides -- when the marked faces do not leave a horizon of simple
   // closed loops (a vertex with two outgoing or two incoming horizon edges, or an open end).
   HFCL_HD bool silhouette_parallel(int pass, int closest, T dummy_precision, const V3<T>& ww, int& hz_count) {
-    const int nf = 2 * cap_iterations + 4;
+    const int nf = hw;
     uint8_t* const start_at = reinterpret_cast<uint8_t*>(m->stack);  // [vertex] -> horizon entry whose new face starts there
     uint8_t* const end_at = start_at + Block::NV;                     // [vertex] -> ... ends there
     static_assert(2 * Block::NV <= int(sizeof(uint16_t)) * Block::NF, "the vertex tables overlay the walk stack");
@@ -617,7 +624,7 @@ struct Epa {
     if constexpr (PARALLEL_HORIZON) {
       by_tables = silhouette_parallel(pass, closest, dummy_precision, ww, hz_count);
       if (!by_tables) {  // not a horizon of simple loops: marks undone, the walk decides
-        const int nfu = 2 * cap_iterations + 4;
+        const int nfu = hw;
         Grp::sync();
         for (int f = Grp::lane(); f < nfu; f += Grp::W)
           if ((m->ft[f].flag() & 1) && m->ft[f].pass() == pass && f != closest) set_pass(f, 0);
@@ -631,7 +638,7 @@ struct Epa {
       // More horizon edges than free faces: whether (and where) the reference runs out of faces
       // depends on how its pops and pushes interleave -> undo the marks and redo the walk with
       // the stock level tracked (rare: only near the capacity of the face store).
-      const int nf = 2 * cap_iterations + 4;
+      const int nf = hw;
       Grp::sync();
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
@@ -671,11 +678,12 @@ struct Epa {
       pending_release = pass;
     // 2. the new faces, one per horizon edge, lanes in parallel; k-th face takes the k-th slot
     //    from the top of the stock and the k-th stamp
-    int first_fail = n_new, fail_code = 0;
+    int first_fail = n_new, fail_code = 0, top_slot = hw;
     for (int k = Grp::lane(); k < n_new; k += Grp::W) {
       const unsigned fr = m->hz[k];
       const int f = hz_face(fr), e = hz_edge(fr), e1 = (e + 1) % 3;
       const int nfc = m->stock[stock_top - 1 - k];
+      if (nfc + 1 > top_slot) top_slot = nfc + 1;
       const uint32_t fv = m->ft[f].vf;
       const int va = int((fv >> (8 * e1)) & 255u), vb = int((fv >> (8 * e)) & 255u);
       // previous face on the horizon loop: the one before it in walk order, or the one that ends where this one starts
@@ -695,11 +703,14 @@ struct Epa {
     butterfly_stages<Grp::W>([&](auto stage) {
       constexpr int M = decltype(stage)::value;
       const int ok = Grp::template exchange<M>(first_fail), oc = Grp::template exchange<M>(fail_code);
+      const int ot = Grp::template exchange<M>(top_slot);
       if (ok < first_fail) {
         first_fail = ok;
         fail_code = oc;
       }
+      if (ot > top_slot) top_slot = ot;
     });
+    hw = top_slot;
     stock_top -= n_new;
     hull_count += n_new;
     stamp += n_new;
@@ -872,7 +883,7 @@ struct Epa {
       // capacity of this scratch block reached before the reference's limit: hand over
       overflow = true;
       resumable = true;
-      if (Grp::lane() == 0) m->hdr = EpaHeader{L.closest, L.iterations, L.pass, status, num_vertices, hull_count, stock_top, stamp};
+      if (Grp::lane() == 0) m->hdr = EpaHeader{L.closest, L.iterations, L.pass, status, num_vertices, hull_count, stock_top, stamp, hw};
       Grp::sync();
       return 2;
     }
@@ -907,7 +918,7 @@ struct Epa {
       if (resumable) {  // hand over as of the start of this iteration (vertex iw is recomputed there)
         --num_vertices;
         --L.pass;
-        if (Grp::lane() == 0) m->hdr = EpaHeader{closest, L.iterations, L.pass, status, num_vertices, hull_count, stock_top, stamp};
+        if (Grp::lane() == 0) m->hdr = EpaHeader{closest, L.iterations, L.pass, status, num_vertices, hull_count, stock_top, stamp, hw};
         Grp::sync();
         return 2;
       }
@@ -960,14 +971,17 @@ struct Epa {
       m->fn[f] = src->fn[f];
       m->ft[f] = src->ft[f];
     }
+    // the extra slots of the larger block go UNDER the saved stock, lowest index on top of them: they are used once the
+    // polytope's own free slots are, in increasing order, so that the high-water mark keeps growing slowly
     const int extra = (2 * cap_iterations + 4) - Src::NF;
-    for (int i = Grp::lane(); i < h.stock_top; i += Grp::W) m->stock[i] = src->stock[i];
-    for (int i = Grp::lane(); i < extra; i += Grp::W) m->stock[h.stock_top + i] = uint8_t(Src::NF + i);
+    for (int i = Grp::lane(); i < extra; i += Grp::W) m->stock[i] = uint8_t(Src::NF + extra - 1 - i);
+    for (int i = Grp::lane(); i < h.stock_top; i += Grp::W) m->stock[extra + i] = src->stock[i];
     status = h.status;
     num_vertices = h.num_vertices;
     hull_count = h.hull_count;
     stock_top = h.stock_top + extra;
     stamp = h.stamp;
+    hw = h.hw;
     Grp::sync();
     return h;
   }
