@@ -119,7 +119,6 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   const float marginf = float(q.security_margin), bd2f = float(break_distance2);
   int sp = 0;
   bool overflow = false;
-  bool no_room = false;  // the task table was found full: this lane stops trying to suspend
   uint32_t ncontacts = 0;
   T dlb = Lim<T>::max(), rec_dist = Lim<T>::max(), cand_val = Lim<T>::max();
   int fb1 = -1, fb2 = -1;
@@ -173,17 +172,11 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   // of the next level and park this unit.  false: no room in the task table (the unit then simply goes on).
   auto suspend = [&](uint32_t ea, uint32_t eb, int n_extra) -> bool {
     const uint32_t n_child = uint32_t(sp + n_extra);
-    if (WIDE || !split.can_suspend || n_child == 0 || no_room) return false;  // (tasks carry 16-bit node ids)
-    // a table that is full stays full: a plain load first, so that the over-budget lanes of a heavy batch do not queue up
-    // on one atomic per step, and the counter is never pushed far past the capacity (no wrap-around on huge batches)
-    if (__hip_atomic_load(&split.ctr[BVH_CTR_TASKS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= split.cap) {
-      no_room = true;
-      return false;
-    }
+    if (WIDE || !split.can_suspend || n_child == 0) return false;  // (tasks carry 16-bit node ids)
     const uint32_t first = atomicAdd(&split.ctr[BVH_CTR_TASKS], n_child);
     if (first + n_child > split.cap) {  // table full: the slots taken become no-ops for the next level
       for (uint32_t j = first; j < min(first + n_child, split.cap); ++j) split.tasks[j] = BvhTask{0u, 0u, 0xFFFFFFFFu, 0u};
-      no_room = true;  // this lane's units go on to the end from here on
+      steps = 0;  // the unit goes on; it asks again after another budget of steps, not at every step (a full table stays full)
       return false;
     }
     uint32_t my_slot;

@@ -16,6 +16,8 @@ for wl in cfg3 cfg5; do
   timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof_$wl -o $wl -- python bench.py --workload $wl --no-cpu-baseline --no-secondary > $out/prof_$wl.log 2>&1
   db=$(find $out/prof_$wl -name "*.db" | head -1)
   [ -n "$db" ] && python tools/rocprof_summary.py $db > $out/${wl}_kernel_trace_stats.txt
+  # the database behind the summary stays (under gpurun_out/, not committed) so that the figures can be re-aggregated
+  [ -n "$db" ] && cp $db $out/${wl}_results.db
   rm -rf $out/prof_$wl
 done
 timeout 1500 python bench.py > $out/bench_default.json 2> $out/bench_default.err
