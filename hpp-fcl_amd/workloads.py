@@ -443,6 +443,16 @@ def cfg4_mesh_mesh(n=100_000, seed=1, n_variants=8, seg=50, ring=50, half_width=
     return b
 
 
+def cfg4_mesh_mesh_distance(n=100_000, seed=1, n_variants=8, seg=50, ring=50, half_width=2.2):
+    """cfg4's distance() variant ("100 000 mesh-mesh collide() (and distance())"): the same models, poses
+    spread so that about two thirds of the pairs are separated (a distance() on intersecting meshes ends at the first
+    overlapping triangle pair)."""
+    b = cfg4_mesh_mesh(n=n, seed=seed, n_variants=n_variants, seg=seg, ring=ring, half_width=half_width)
+    b.kind = "distance"
+    b.name = "cfg4_mesh_mesh_distance_%dtri" % (2 * seg * ring)
+    return b
+
+
 def make_library(pkg, batch, device=0):
     """engine.Library for a batch (registers the batch's meshes, if any)."""
     lib = pkg.Library(batch.lib, device=device)
