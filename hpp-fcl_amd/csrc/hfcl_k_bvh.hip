@@ -753,16 +753,30 @@ __global__ void __launch_bounds__(64) k_bvh_shape_distance(Work wk, LibView<T> l
 // sqrTriDistance in model 1's frame; the result is seeded with triangle 0 x triangle 0 (preprocess).
 // ---------------------------------------------------------------------------------------
 
+// Two waves per SIMD (256 VGPRs, 36 B per lane of scratch in fp64) with the 20 KB stack: the compiler's own allocation
+// (264 registers) left one.  cfg4's distance() variant, 1M queries: 0.75 -> 1.85 M q/s with the stack and this (profiles/r03_g).
+#ifndef HFCL_WPE_BVH_DISTANCE
+#define HFCL_WPE_BVH_DISTANCE 2
+#endif
 template <typename T, bool WIDE>
-__global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH, 8))) k_bvh_distance(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhSpill spill) {
+__global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH_DISTANCE, 8))) k_bvh_distance(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhSpill spill) {
   typedef BvhEntry<WIDE> EN;
   typedef typename EN::E E;
   constexpr int STACK = WIDE ? (BVHD_STACK * 3) / 4 : BVHD_STACK, HALF = STACK / 2;
   __shared__ E stack_e[STACK][BVHD_BLOCK];
-  __shared__ T stack_d[STACK][BVHD_BLOCK];
+  // The bound travels as a float rounded DOWN: an entry is skipped when its bound cannot beat the current minimum
+  // (canStop), and a bound that is a little too small only means an entry is looked at that the exact bound would have
+  // skipped -- it cannot lower the minimum, and the order of the walk was decided on the exact values when it was pushed.
+  __shared__ float stack_d[STACK][BVHD_BLOCK];
+  auto bound_down = [](T d) -> float {
+    if constexpr (sizeof(T) == 8)
+      return __double2float_rd(d);
+    else
+      return d;
+  };
   // this lane's slab of spilled (entry, bound) records (WIDE only): entries first, bounds behind them
   E* const slab_e = WIDE && spill.slab ? reinterpret_cast<E*>(spill.slab) + size_t(blockIdx.x * BVHD_BLOCK + threadIdx.x) * spill.cap * 2 : nullptr;
-  T* const slab_d = reinterpret_cast<T*>(slab_e + spill.cap);
+  float* const slab_d = reinterpret_cast<float*>(slab_e + spill.cap);
   uint32_t nspill = 0;
   const uint32_t cnt = wk.counts[B_BVH];
   uint32_t* const ticket = &wk.counts[B_COUNT + 2];
@@ -853,13 +867,16 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
           leaf(0u, 0u);  // preprocess()
           sp = 1;
           stack_e[0][tid] = 0u;
-          stack_d[0][tid] = T(-1);
+          stack_d[0][tid] = -1.f;
           live = true;
         }
       }
       if (base + uint32_t(n_need) >= cnt) exhausted = true;
       continue;
     }
+    // (Triangle pairs -- 6 % of the steps -- are evaluated where they are popped.  Parking them until several lanes of the
+    // wave wait, as k_bvh_collide does, loses here: a BV step is two rectangle distances, as heavy as a triangle pair, and
+    // the parked lanes miss them: 8 lanes 0.75, 24 lanes 0.56 against 0.83 M q/s; profiles/r03_g.)
     for (;;) {
       const bool run = live && sp > 0;
       const int n_run = __popcll(__ballot(run || (live && nspill > 0)));
@@ -870,8 +887,8 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
       }
       --sp;
       const E e = stack_e[sp][tid];
-      const T de = stack_d[sp][tid];
-      if (de >= T(0) && de >= mind) continue;  // canStop(d)
+      const float de = stack_d[sp][tid];
+      if (de >= 0.f && T(de) >= mind) continue;  // canStop(d)
       const uint32_t b1 = EN::first(e), b2 = EN::second(e);
       const DNode<T> n1 = bv.nodes[m1.node_off + b1];
       const DNode<T> n2 = bv.nodes[m2.node_off + b2];
@@ -917,10 +934,10 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
       const E ea = EN::pack(a1, a2), ec = EN::pack(c1, c2);
       const bool c_first = d2 < d1;  // visit (c1,c2) first when it is strictly nearer
       stack_e[sp][tid] = c_first ? ea : ec;
-      stack_d[sp][tid] = c_first ? d1 : d2;
+      stack_d[sp][tid] = bound_down(c_first ? d1 : d2);
       ++sp;
       stack_e[sp][tid] = c_first ? ec : ea;
-      stack_d[sp][tid] = c_first ? d2 : d1;
+      stack_d[sp][tid] = bound_down(c_first ? d2 : d1);
       ++sp;
     }
   }
