@@ -384,63 +384,98 @@ HFCL_HD bool in_voronoi(T a, T b, T Anorm_dot_B, T Anorm_dot_T, T A_dot_B, T A_d
 //   A edge: runs along axis ea at coordinate ua*a[oa] on the other axis oa = 1-ea,
 //   B edge: runs along B's axis eb at B-coordinate ub*b[ob], ob = 1-eb,
 // in the reference's order (ea,eb) = (1,1),(1,0),(0,1),(0,0), each with (U,U),(U,L),(L,U),(L,L).
+// Two passes (round 3).  The reference's code tries the 16 pairs one after the other and returns from the first whose
+// Voronoi tests pass; on a wavefront every lane passes in a different block, so all 16 ran nearly empty.  Pass 1
+// evaluates only the cheap entry condition of each block (four comparisons on edge end points) for all 16 and keeps a
+// bit mask; pass 2 takes the candidates of a lane in the reference's order and evaluates ONE parametrised block per trip
+// (the edge-pair indices select the operands), so the lanes of a wave share the code of a trip whatever block each is in:
+// as many trips as the lane with the most candidates needs (1-3 typically) instead of 16 sections.  Every expression is
+// the one of the unrolled form (same operands, same order).
 template <typename T>
 HFCL_HD T rect_distance(const M3<T>& Rab, const V3<T>& Tab, T a0, T a1, T b0, T b1) {
   const T R[3][3] = {{Rab.r0.x, Rab.r0.y, Rab.r0.z}, {Rab.r1.x, Rab.r1.y, Rab.r1.z}, {Rab.r2.x, Rab.r2.y, Rab.r2.z}};
   const T av[2] = {a0, a1}, bv[2] = {b0, b1};
   const V3<T> Tba_v = tmul(Rab, Tab);
   const T Tabv[3] = {Tab.x, Tab.y, Tab.z}, Tba[3] = {Tba_v.x, Tba_v.y, Tba_v.z};
+  // ---- pass 1: which blocks does the reference enter?  bit k = k-th block in its order
+  unsigned mask = 0u;
+  {
+    int k = 0;
 #pragma unroll
-  for (int ea = 1; ea >= 0; --ea) {
-    const int oa = 1 - ea;
+    for (int ea = 1; ea >= 0; --ea) {
+      const int oa = 1 - ea;
 #pragma unroll
-    for (int eb = 1; eb >= 0; --eb) {
-      const int ob = 1 - eb;
-      // B-frame coordinate (along B axis ob) of A's corners: (0,0), (a[ea] along ea), (a[oa] along oa)
-      const T A_ll = -Tba[ob];
-      const T A_e = av[ea] * R[ea][ob];  // step along the A edge direction
-      const T A_o = av[oa] * R[oa][ob];  // step to the "upper" A edge
-      // A-frame coordinate (along A axis oa) of B's corners
-      const T B_ll = Tabv[oa];
-      const T B_e = bv[eb] * R[oa][eb];
-      const T B_o = bv[ob] * R[oa][ob];
+      for (int eb = 1; eb >= 0; --eb) {
+        const int ob = 1 - eb;
+        const T A_ll = -Tba[ob];
+        const T A_e = av[ea] * R[ea][ob];
+        const T A_o = av[oa] * R[oa][ob];
+        const T B_ll = Tabv[oa];
+        const T B_e = bv[eb] * R[oa][eb];
+        const T B_o = bv[ob] * R[oa][ob];
 #pragma unroll
-      for (int ua = 1; ua >= 0; --ua) {
+        for (int ua = 1; ua >= 0; --ua) {
 #pragma unroll
-        for (int ub = 1; ub >= 0; --ub) {
-          const T ea0 = A_ll + (ua ? A_o : T(0)), ea1 = ea0 + A_e;  // A edge end points in B's ob coordinate
-          const T A_l = hmin(ea0, ea1), A_u = hmax(ea0, ea1);
-          const T eb0 = B_ll + (ub ? B_o : T(0)), eb1 = eb0 + B_e;  // B edge end points in A's oa coordinate
-          const T B_l = hmin(eb0, eb1), B_u = hmax(eb0, eb1);
-          const bool pre1 = ub ? (A_u > bv[ob]) : (A_l < T(0));
-          const bool pre2 = ua ? (B_u > av[oa]) : (B_l < T(0));
-          if (!(pre1 && pre2)) continue;
-          const T pa = ua ? av[oa] : T(0), pb = ub ? bv[ob] : T(0);
-          const T A_dot_B = R[ea][eb];
-          const T A_dot_T = Tabv[ea] + pb * R[ea][ob];  // e_ea . (Pb - Pa)
-          const T B_dot_T = Tba[eb] - pa * R[oa][eb];    // B_eb . (Pb - Pa)
-          const bool skip1 = ub ? (A_l > bv[ob]) : (A_u < T(0));
-          const T sgn_b = ub ? T(1) : T(-1);
-          const bool v1 = skip1 || in_voronoi(bv[eb], av[ea], sgn_b * R[ea][ob], sgn_b * (pa * R[oa][ob] - Tba[ob] - pb),
-                                              A_dot_B, pa * R[oa][eb] - Tba[eb], -Tabv[ea] - pb * R[ea][ob]);
-          if (!v1) continue;
-          const bool skip2 = ua ? (B_l > av[oa]) : (B_u < T(0));
-          const T sgn_a = ua ? T(1) : T(-1);
-          const bool v2 = skip2 || in_voronoi(av[ea], bv[eb], sgn_a * R[oa][eb], sgn_a * (Tabv[oa] + pb * R[oa][ob] - pa),
-                                              A_dot_B, A_dot_T, B_dot_T);
-          if (!v2) continue;
-          T t, u;
-          seg_coords(t, u, av[ea], bv[eb], A_dot_B, A_dot_T, B_dot_T);
-          // S = (Pb + u B_eb) - (Pa + t A_ea)
-          T S[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) S[k] = Tabv[k] + R[k][ob] * pb + R[k][eb] * u;
-          S[oa] -= pa;
-          S[ea] -= t;
-          return hsqrt(S[0] * S[0] + S[1] * S[1] + S[2] * S[2]);
+          for (int ub = 1; ub >= 0; --ub) {
+            const T ea0 = A_ll + (ua ? A_o : T(0)), ea1 = ea0 + A_e;
+            const T A_l = hmin(ea0, ea1), A_u = hmax(ea0, ea1);
+            const T eb0 = B_ll + (ub ? B_o : T(0)), eb1 = eb0 + B_e;
+            const T B_l = hmin(eb0, eb1), B_u = hmax(eb0, eb1);
+            const bool pre1 = ub ? (A_u > bv[ob]) : (A_l < T(0));
+            const bool pre2 = ua ? (B_u > av[oa]) : (B_l < T(0));
+            if (pre1 && pre2) mask |= 1u << k;
+            ++k;
+          }
         }
       }
     }
+  }
+  // ---- pass 2: the candidates in order, one parametrised block per trip
+  while (mask) {
+    const int k = __builtin_ctz(mask);
+    mask &= mask - 1u;
+    const bool ea1_ = !(k & 8), eb1_ = !(k & 4), ua = !(k & 2), ub = !(k & 1);  // ea = 1 / eb = 1 / upper A edge / upper B edge
+    // operands selected by the edge-pair indices (ea, oa = 1 - ea index A's axes / rows of R; eb, ob index B's axes / columns)
+    const T Rc_eb[3] = {eb1_ ? R[0][1] : R[0][0], eb1_ ? R[1][1] : R[1][0], eb1_ ? R[2][1] : R[2][0]};  // R[.][eb]
+    const T Rc_ob[3] = {eb1_ ? R[0][0] : R[0][1], eb1_ ? R[1][0] : R[1][1], eb1_ ? R[2][0] : R[2][1]};  // R[.][ob]
+    const T R_ea_eb = ea1_ ? Rc_eb[1] : Rc_eb[0], R_oa_eb = ea1_ ? Rc_eb[0] : Rc_eb[1];
+    const T R_ea_ob = ea1_ ? Rc_ob[1] : Rc_ob[0], R_oa_ob = ea1_ ? Rc_ob[0] : Rc_ob[1];
+    const T av_ea = ea1_ ? av[1] : av[0], av_oa = ea1_ ? av[0] : av[1];
+    const T bv_eb = eb1_ ? bv[1] : bv[0], bv_ob = eb1_ ? bv[0] : bv[1];
+    const T Tab_ea = ea1_ ? Tabv[1] : Tabv[0], Tab_oa = ea1_ ? Tabv[0] : Tabv[1];
+    const T Tba_eb = eb1_ ? Tba[1] : Tba[0], Tba_ob = eb1_ ? Tba[0] : Tba[1];
+    const T A_ll = -Tba_ob;
+    const T A_e = av_ea * R_ea_ob;
+    const T A_o = av_oa * R_oa_ob;
+    const T B_ll = Tab_oa;
+    const T B_e = bv_eb * R_oa_eb;
+    const T B_o = bv_ob * R_oa_ob;
+    const T ea0 = A_ll + (ua ? A_o : T(0)), ea1 = ea0 + A_e;  // A edge end points in B's ob coordinate
+    const T A_l = hmin(ea0, ea1), A_u = hmax(ea0, ea1);
+    const T eb0 = B_ll + (ub ? B_o : T(0)), eb1 = eb0 + B_e;  // B edge end points in A's oa coordinate
+    const T B_l = hmin(eb0, eb1), B_u = hmax(eb0, eb1);
+    const T pa = ua ? av_oa : T(0), pb = ub ? bv_ob : T(0);
+    const T A_dot_B = R_ea_eb;
+    const T A_dot_T = Tab_ea + pb * R_ea_ob;  // e_ea . (Pb - Pa)
+    const T B_dot_T = Tba_eb - pa * R_oa_eb;  // B_eb . (Pb - Pa)
+    const bool skip1 = ub ? (A_l > bv_ob) : (A_u < T(0));
+    const T sgn_b = ub ? T(1) : T(-1);
+    const bool v1 = skip1 || in_voronoi(bv_eb, av_ea, sgn_b * R_ea_ob, sgn_b * (pa * R_oa_ob - Tba_ob - pb), A_dot_B,
+                                        pa * R_oa_eb - Tba_eb, -Tab_ea - pb * R_ea_ob);
+    if (!v1) continue;
+    const bool skip2 = ua ? (B_l > av_oa) : (B_u < T(0));
+    const T sgn_a = ua ? T(1) : T(-1);
+    const bool v2 = skip2 || in_voronoi(av_ea, bv_eb, sgn_a * R_oa_eb, sgn_a * (Tab_oa + pb * R_oa_ob - pa), A_dot_B, A_dot_T, B_dot_T);
+    if (!v2) continue;
+    T t, u;
+    seg_coords(t, u, av_ea, bv_eb, A_dot_B, A_dot_T, B_dot_T);
+    // S = (Pb + u B_eb) - (Pa + t A_ea); component oa loses pa, component ea loses t (third component: neither)
+    T S0 = Tabv[0] + Rc_ob[0] * pb + Rc_eb[0] * u;
+    T S1 = Tabv[1] + Rc_ob[1] * pb + Rc_eb[1] * u;
+    const T S2 = Tabv[2] + Rc_ob[2] * pb + Rc_eb[2] * u;
+    S0 -= ea1_ ? pa : t;  // ea = 1: oa = 0
+    S1 -= ea1_ ? t : pa;
+    return hsqrt(S0 * S0 + S1 * S1 + S2 * S2);
   }
   T sep1, sep2;
   if (Tabv[2] > T(0)) {
