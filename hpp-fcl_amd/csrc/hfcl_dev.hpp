@@ -710,7 +710,7 @@ constexpr int CLS_BLOCK = 1024;  // k_classify
 constexpr int LARGE_W = 16;      // lanes per pair in k_gjk_large
 constexpr int BS_W = 16;         // lanes per query in k_bvh_shape / k_bvh_shape_distance / k_triangle
 constexpr int BS_STACK = 128;
-// LDS stack of k_bvh_distance: (entry, lower bound) per slot; 40 slots x 8 B x 64 lanes = 20 480 B = 16 LDS units per wave:
+// LDS stack of k_bvh_distance: (entry, lower bound in 4 bytes) per slot; 40 slots x 8 B x 64 lanes = 20 480 B = 16 LDS units per wave:
 // eight waves per CU (it was 64 slots x 12 B = 48 KB: three waves per CU).  A traversal holds at most depth1 + depth2 + 2
 // entries: models up to 19 levels deep (5 000 triangles: 16); deeper ones take the wide form with its global slabs.
 constexpr int BVHD_STACK = 40;

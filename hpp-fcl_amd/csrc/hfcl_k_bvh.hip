@@ -764,19 +764,32 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
   typedef typename EN::E E;
   constexpr int STACK = WIDE ? (BVHD_STACK * 3) / 4 : BVHD_STACK, HALF = STACK / 2;
   __shared__ E stack_e[STACK][BVHD_BLOCK];
-  // The bound travels as a float rounded DOWN: an entry is skipped when its bound cannot beat the current minimum
+  // The bound travels in 4 bytes, rounded DOWN: an entry is skipped when its bound cannot beat the current minimum
   // (canStop), and a bound that is a little too small only means an entry is looked at that the exact bound would have
   // skipped -- it cannot lower the minimum, and the order of the walk was decided on the exact values when it was pushed.
-  __shared__ float stack_d[STACK][BVHD_BLOCK];
-  auto bound_down = [](T d) -> float {
+  // fp64: the upper word of the double (sign, exponent, 20 mantissa bits; truncation = rounding down for the bounds, which
+  // are >= 0, and exact for the root's -1): the full exponent range, so scenes of any scale keep their pruning (a float
+  // would flush the bounds of a 1e-40-sized scene to zero and the walk would visit every pair).
+  // Where the truncated bound falls short of the minimum by less than its own resolution (the exact bound may still reach
+  // it: exact ties are what prunes a mesh against a shifted copy of itself, tests/test_gpu_parity.py::
+  // test_bvh_degenerate_deep_tree) the exact bound is evaluated again -- same inputs, same value -- and decides.
+  typedef typename std::conditional<sizeof(T) == 8, uint32_t, float>::type BD;
+  __shared__ BD stack_d[STACK][BVHD_BLOCK];
+  auto bound_down = [](T d) -> BD {
     if constexpr (sizeof(T) == 8)
-      return __double2float_rd(d);
+      return uint32_t(__double2hiint(d));
     else
       return d;
   };
+  auto bound_value = [](BD b) -> T {
+    if constexpr (sizeof(T) == 8)
+      return __hiloint2double(int(b), 0);
+    else
+      return b;
+  };
   // this lane's slab of spilled (entry, bound) records (WIDE only): entries first, bounds behind them
   E* const slab_e = WIDE && spill.slab ? reinterpret_cast<E*>(spill.slab) + size_t(blockIdx.x * BVHD_BLOCK + threadIdx.x) * spill.cap * 2 : nullptr;
-  float* const slab_d = reinterpret_cast<float*>(slab_e + spill.cap);
+  BD* const slab_d = reinterpret_cast<BD*>(slab_e + spill.cap);
   uint32_t nspill = 0;
   const uint32_t cnt = wk.counts[B_BVH];
   uint32_t* const ticket = &wk.counts[B_COUNT + 2];
@@ -867,7 +880,7 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
           leaf(0u, 0u);  // preprocess()
           sp = 1;
           stack_e[0][tid] = 0u;
-          stack_d[0][tid] = -1.f;
+          stack_d[0][tid] = bound_down(T(-1));
           live = true;
         }
       }
@@ -887,9 +900,17 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
       }
       --sp;
       const E e = stack_e[sp][tid];
-      const float de = stack_d[sp][tid];
-      if (de >= 0.f && T(de) >= mind) continue;  // canStop(d)
+      const BD dc = stack_d[sp][tid];
+      const T de = bound_value(dc);
+      if (de >= T(0) && de >= mind) continue;  // canStop(d)
       const uint32_t b1 = EN::first(e), b2 = EN::second(e);
+      if constexpr (sizeof(T) == 8) {
+        if (de >= T(0) && __hiloint2double(int(dc) + 1, 0) > mind) {  // the exact bound may reach the minimum: ask it
+          const T exact = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + b1], bv.rss[m1.node_off + b1], bv.nodes[m2.node_off + b2],
+                                          bv.rss[m2.node_off + b2]);
+          if (exact >= mind) continue;
+        }
+      }
       const DNode<T> n1 = bv.nodes[m1.node_off + b1];
       const DNode<T> n2 = bv.nodes[m2.node_off + b2];
       const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
