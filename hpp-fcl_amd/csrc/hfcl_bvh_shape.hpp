@@ -626,6 +626,148 @@ HFCL_HD void mesh_shape_collide(const DNode<T>* nodes, const T* mverts, const ui
 
 
 // ---------------------------------------------------------------------------------------
+// The same traversals with one query per LANE (k_bvh_shape_lane / k_bvh_shape_distance_lane).
+//
+// The group form above spends a 16-lane group on a walk whose separating-axis tests and (for every solid but a
+// ConvexBase) GJK iterations no lane can share: 100k queries against a 5 000-triangle model ran at 1-6 M q/s, a tenth
+// of what the host's cores reach with the oracle (tools/mesh_solid_bench.py).  Here a lane owns a query: it walks
+// the tree and runs the leaf's closed form / GJK by itself.  What a lane cannot hold is EPA's polytope -- but a leaf
+// that needs EPA ENDS the walk where the fast path applies: collide() with num_max_contacts == 1 and margin,
+// threshold >= 0 (a penetrating triangle is a contact, canStop()), distance() always (every bound left on the stack
+// is >= 0 > the penetration found).  Such a leaf is written to a queue (GJK's final simplex, the triangle, the
+// running bound) and finished by a group kernel that runs EPA and the leaf's epilogue (k_bvh_shape_finish).
+// Same functions, same argument order as the group form: on the host build the two forms produce identical records
+// (tests/test_bvh_shape.py).
+// ---------------------------------------------------------------------------------------
+
+// obb_disjoint(R0, T0, node, bv2) with the node-independent products taken out of the walk: the same operations in
+// the same order (M = R0^T A2, V = R0^T (To2 - T0) are what obb_disjoint computes first)
+template <typename T>
+struct ObbQuery {
+  M3<T> M;
+  V3<T> V, ext;
+};
+template <typename T>
+HFCL_HD ObbQuery<T> make_obb_query(const Pose<T>& tfm, const DNode<T>& bv2) {
+  ObbQuery<T> o;
+  o.M = tmul(tfm.R, bv2.axes);
+  o.V = tmul(tfm.R, bv2.To - tfm.t);
+  o.ext = bv2.extent;
+  return o;
+}
+template <typename T>
+HFCL_HD bool obb_disjoint_q(const ObbQuery<T>& o, const DNode<T>& b1, T security_margin, T break_distance2, T& sq) {
+  const V3<T> Ttemp = o.V - b1.To;
+  const V3<T> Tv = tmul(b1.axes, Ttemp);
+  const M3<T> R = tmul(b1.axes, o.M);
+  return obb_disjoint_lb(R, Tv, b1.extent, o.ext, security_margin, break_distance2, sq);
+}
+
+template <typename T>
+struct ShapeDeferItem {  // a leaf whose GJK ended inside the solid (seed.pair = the query)
+  EpaSeed<T> seed;
+  V3<T> a, b, c;       // the triangle in the solid's frame, as GJK saw it
+  T bound, rec;        // collide(): distance_lower_bound and the recorded distance before this leaf; distance(): min_distance
+  uint32_t prim;
+  int32_t prev_prim;   // distance(): the triangle of the minimum so far
+  uint32_t parent, order;  // collide(): where the unit that met the leaf hangs in the task tree (0xFFFFFFFF: a whole query)
+};
+
+// A leaf on one lane.  Returns true when the leaf must go through EPA (item.seed / a / b / c filled; nothing else
+// changed); otherwise distance / p1 (on the triangle) / p2 (on the solid) / n are the leaf's result and `guess` the
+// solver's cached guess after it.  tfm_of() / tfs_of(): the poses, produced where they are needed.
+template <typename T, class Solid, class PS, class TfM, class TfS>
+HFCL_HD bool mesh_shape_leaf_lane(const V3<T>& ta, const V3<T>& tb, const V3<T>& tc, const MDiff<T>& sMt, const TfM& tfm_of,
+                                  const TfS& tfs_of, const DShape<T>& shape, const Solid& solid, T r1, const QParams<T>& q,
+                                  V3<T>& guess, const PS& ps, T& distance, V3<T>& p1, V3<T>& p2, V3<T>& n,
+                                  ShapeDeferItem<T>& item) {
+  if (shape.kind == K_SPHERE) {
+    const Pose<T> tfm = tfm_of();
+    distance = sphere_triangle(shape, tfs_of(), xform(tfm, ta), xform(tfm, tb), xform(tfm, tc), p2, p1, n);
+    n = -n;
+    return false;
+  }
+  if (kind_is_flat(shape.kind)) {
+    distance = flat_triangle_distance(shape, tfs_of(), ta, tb, tc, tfm_of(), p2, p1, n);
+    n = -n;
+    return false;
+  }
+  const V3<T> guess0 = (q.guess_mode == HFCL_GUESS_CACHED) ? guess : mk<T>(T(1), T(0), T(0));
+  SolidTriSupport<T, Solid> sup;
+  sup.a = mul(sMt.oR1, ta) + sMt.ot1;
+  sup.b = mul(sMt.oR1, tb) + sMt.ot1;
+  sup.c = mul(sMt.oR1, tc) + sMt.ot1;
+  sup.solid = &solid;
+  Gjk<T, typename PS::P> g;
+  gjk_run(g, q.gjk, guess0, r1, false, sup, ps);
+  PairOut<T> o;
+  if (gjk_finish(g, q, tfs_of, r1, T(0), guess0, o, item.seed, ps)) {
+    item.a = sup.a;
+    item.b = sup.b;
+    item.c = sup.c;
+    return true;
+  }
+  p1 = o.p2;
+  p2 = o.p1;
+  n = -o.normal;
+  distance = o.distance;
+  // GJK::Collision without penetration information leaves the solver's cached guess untouched (narrowphase.h:638-656)
+  if (!(o.gjk_status == GJK_COLLISION && !q.compute_penetration)) guess = o.cached_guess;
+  return false;
+}
+
+// The EPA half of a deferred leaf, by a lane group: returns the leaf's distance, p1 (triangle) / p2 (solid) / n and the
+// solver's cached guess after it.
+template <typename T, class Grp, class Solid>
+HFCL_HD T mesh_shape_leaf_finish(const ShapeDeferItem<T>& item, const Pose<T>& tfs, const Solid& solid, T r1, const QParams<T>& q,
+                                 EpaScratch<T, EPA_MAX_ITER>* scratch, V3<T>& p1, V3<T>& p2, V3<T>& n, V3<T>& guess) {
+  SolidTriSupport<T, Solid> sup;
+  sup.a = item.a;
+  sup.b = item.b;
+  sup.c = item.c;
+  sup.solid = &solid;
+  PairOut<T> o;
+  Grp::sync();
+  epa_run<T, Grp, EPA_MAX_ITER>(scratch, item.seed, q, tfs, r1, T(0), sup, o);
+  Grp::sync();
+  p1 = o.p2;
+  p2 = o.p1;
+  n = -o.normal;
+  guess = o.cached_guess;
+  return o.distance;
+}
+
+// updateDistanceLowerBoundFromLeaf + the contact decision of leafCollides (traversal_node_bvh_shape.h:139-186).
+// lowered: the leaf's witness data replace the recorded ones.
+template <typename T>
+HFCL_HD bool mesh_shape_leaf_bound(T distance, const QParams<T>& q, T& dlb, T& rec_dist, bool& lowered) {
+  const T dtc = distance - q.security_margin;
+  lowered = dtc < dlb;
+  if (lowered) {
+    dlb = dtc;
+    rec_dist = distance;
+  }
+  return dtc <= q.collision_distance_threshold;
+}
+// updateDistanceLowerBoundFromBV for a node found disjoint (sq = the squared lower bound of obb_disjoint)
+template <typename T>
+HFCL_HD void mesh_shape_bv_bound(T sq, const QParams<T>& q, T& dlb, T& rec_dist) {
+  if (!(dlb <= T(0))) {
+    const T nd = hsqrt(sq);
+    if (nd < dlb) {
+      dlb = nd;
+      rec_dist = nd + q.security_margin;
+    }
+  }
+}
+// Whether a collide() request may take the one-query-per-lane path (see above).
+template <typename T>
+HFCL_HD bool mesh_shape_lane_request(const QParams<T>& q, uint32_t num_max_contacts) {
+  return num_max_contacts == 1u && q.security_margin >= T(0) && q.collision_distance_threshold >= T(0);
+}
+
+
+// ---------------------------------------------------------------------------------------
 // distance(): MeshShapeDistanceTraversalNodeOBBRSS (traversal_node_bvh_shape.h:276-478) + distanceRecurse
 // (traversal_recurse.cpp:153-203) with a leaf second node, rel_err = abs_err = 0.  stack_n / stack_d: cap
 // entries each of group-shared memory (node id, RSS lower bound of the pending subtree).

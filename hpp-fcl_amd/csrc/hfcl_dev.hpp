@@ -52,7 +52,9 @@ enum { B_CLOSED = 0, B_PRIM = 1, B_CC = 2, B_PC = 3, B_CP = 4, B_BVH = 5, B_UNSU
 // (population in counts[B_CURVED0 + bucket]); a kernel walks the list's bottom part, then its top part (BucketList), and
 // the pairs of a wave are of one class but for one wave per bucket.
 constexpr int B_CURVED0 = B_COUNT + 4;
-constexpr int N_COUNTERS = 2 * B_COUNT + 4;  // bucket populations + the four counters of Work::counts + curved populations
+// + the two counters of the one-query-per-lane mesh x solid form (its ticket, the length of its EPA queue)
+constexpr int CTR_SHAPE_TICKET = 2 * B_COUNT + 4, CTR_SHAPE_DEFER = 2 * B_COUNT + 5;
+constexpr int N_COUNTERS = 2 * B_COUNT + 6;  // bucket populations + the four counters of Work::counts + curved populations + those two
 
 // Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
 // support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
@@ -164,6 +166,8 @@ struct Work {
   void* epa_v0;      // shape-0 support points of the polytopes in flight in the full-capacity EPA kernel
   void* epa_resume;  // saved polytopes (EpaSaved, epa_resume_stride<T> bytes apart) of the first `resume_cap` slots of epa_queue2
   uint32_t resume_cap;
+  void* shape_defer;  // ShapeDeferItem<T>[n]: mesh x solid leaves waiting for EPA (k_bvh_collide<SOLID> -> k_bvh_shape_finish); nullptr: group kernels
+  void* shape_oq;     // ObbQuery<T>[n], by pair: the solid's fitted OBB against the mesh pose (k_shape_obb)
 };
 // a pair with a shape whose support is not a vertex
 __host__ __device__ inline bool curved_pair(int k1, int k2) {
@@ -661,6 +665,7 @@ struct BvhSplit {
   uint32_t budget0;     // ... of the queries themselves (level 0); `budget` is that of the tasks
   uint32_t level, n_levels;
   uint32_t can_suspend;
+  uint32_t leaf_cost;   // SOLID form: steps a GJK leaf counts for (a closed-form leaf: an eighth of it)
 };
 // Step budget per unit (the compile-time default; without HFCL_BVH_* in the environment the host chooses per batch, see
 // hfcl_lib::bvh_auto).  0: units only suspend when their LDS stack is full -- the task mechanism is then the overflow path

@@ -88,6 +88,14 @@ struct hfcl_lib {
   void* d_epa_resume = nullptr;
   void* d_epa_v0 = nullptr;
   size_t resume_cap = 0;
+  void* d_shape_defer = nullptr;  // ShapeDeferItem<double>[shape_defer_capacity]: EPA queue of the one-query-per-lane mesh x solid form
+  void* d_shape_oq = nullptr;     // ObbQuery<double>[shape_defer_capacity]: the solids' OBBs against the mesh poses, by pair
+  size_t shape_defer_capacity = 0;
+  bool bvh_shape_lane = true;     // HFCL_BVH_SHAPE_LANE=0: the group kernels for every request (A/B switch)
+  // step budgets of the one-query-per-lane mesh x solid walk (a unit suspends into tasks when it has taken that many BV-test
+  // equivalents; a GJK leaf counts shape_leaf_cost): the queries themselves / their tasks.  The steps per query have a heavy
+  // tail whatever the batch size (median 1, mean ~60, maximum > 3000 steps with > 1000 leaves), so the walk is always split.
+  uint32_t shape_budget0 = 128, shape_budget = 96, shape_leaf_cost = 32, shape_levels = BVH_MAX_LEVELS;
   // host-call staging: PIPE_SLOTS device buffer sets of `st_capacity` pairs each (a chunk of a host batch), three streams
   // (H2D | kernels | D2H) and per-slot events / pinned counter blocks (host_batch)
   static constexpr int PIPE_SLOTS = 6;  // (three left the feeder waiting for records to leave: profiles/r03_c)
@@ -402,6 +410,11 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_SPLIT")) lib->split = atoi(v) >= 2 ? 2 : (atoi(v) == 1 ? 1 : 0);
   if (const char* v = getenv("HFCL_PIPE_CHUNK")) lib->pipe_chunk = strtoull(v, nullptr, 10);
   if (const char* v = getenv("HFCL_BVH_FILTER")) lib->bvh_filter = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_BVH_SHAPE_LANE")) lib->bvh_shape_lane = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_SHAPE_BUDGET0")) lib->shape_budget0 = uint32_t(atoi(v));
+  if (const char* v = getenv("HFCL_SHAPE_BUDGET")) lib->shape_budget = uint32_t(atoi(v));
+  if (const char* v = getenv("HFCL_SHAPE_LEAF_COST")) lib->shape_leaf_cost = uint32_t(std::max(1, atoi(v)));
+  if (const char* v = getenv("HFCL_SHAPE_LEVELS")) lib->shape_levels = uint32_t(std::min(std::max(1, atoi(v)), int(BVH_MAX_LEVELS)));
   if (const char* v = getenv("HFCL_CLIMB_MIN")) lib->climb_min = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_BUDGET")) lib->bvh_budget = lib->bvh_budget0 = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_BUDGET0")) lib->bvh_budget0 = uint32_t(std::max(0, atoi(v)));
@@ -440,6 +453,8 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_epa_queue2);
   hipFree(lib->d_epa_resume);
   hipFree(lib->d_epa_v0);
+  hipFree(lib->d_shape_defer);
+  hipFree(lib->d_shape_oq);
   if (lib->h_pack) hipHostFree(lib->h_pack);
   if (lib->h_pack_counts) hipHostFree(lib->h_pack_counts);
   hipFree(lib->d_pack);
@@ -638,14 +653,14 @@ static int ensure_workspace(hfcl_lib* lib, size_t n, bool need_epa) {
   return HFCL_OK;
 }
 
-// Tables of a split mesh x mesh traversal for a batch of n queries: room for 8 tasks per query (a long query suspends
-// with a stack of ~20 entries, one query in five is long) -- ~1.2 KB of device memory per query in fp64.
+// Tables of a split traversal (mesh x mesh, mesh x solid) for a batch of n queries: room for 16 tasks per query (a long query suspends
+// with a stack of ~20 entries, one query in five is long; mesh x solid walks are cut finer) -- ~2.4 KB of device memory per query in fp64.
 static int ensure_bvh_split(hfcl_lib* lib, size_t n) {
   if (n <= lib->bvh_split_n) return HFCL_OK;
   hipFree(lib->d_bvh_tasks); hipFree(lib->d_bvh_sums); hipFree(lib->d_bvh_susp);
   lib->d_bvh_tasks = nullptr; lib->d_bvh_sums = nullptr; lib->d_bvh_susp = nullptr;
   lib->bvh_split_n = 0;
-  const size_t nq = n + n / 8 + 1024, cap = 8 * nq + 65536;
+  const size_t nq = n + n / 8 + 1024, cap = 16 * nq + 65536;
   HIP_TRY(hipMalloc(&lib->d_bvh_tasks, cap * sizeof(BvhTask)));
   HIP_TRY(hipMalloc(&lib->d_bvh_sums, (nq + cap) * sizeof(BvhSum<double>)));
   HIP_TRY(hipMalloc(&lib->d_bvh_susp, nq * sizeof(uint32_t)));
@@ -948,6 +963,8 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
   wk.epa_resume = lib->d_epa_resume;
   wk.epa_v0 = lib->d_epa_v0;
   wk.resume_cap = uint32_t(std::min<size_t>(lib->resume_cap, 0xFFFFFFFFu));
+  wk.shape_defer = nullptr;
+  wk.shape_oq = nullptr;
   LibView<T> lv;
   lv.shapes = std::is_same<T, double>::value ? (const DShape<T>*)lib->d_shapes64 : (const DShape<T>*)lib->d_shapes32;
   lv.verts = std::is_same<T, double>::value ? (const T*)lib->d_verts64 : (const T*)lib->d_verts32;
@@ -1032,35 +1049,72 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     BvhSpill spill;
     rc = make_bvh_spill(lib, spill, q.mode != 1);
     if (rc) return rc;
+    // long traversals are cut into tasks when the batch is large enough for the tail to matter and the request keeps no
+    // query-wide contact count (mesh x mesh and the one-query-per-lane form of mesh x solid alike)
+    auto make_split = [&](BvhSplit& split, bool want, bool solid) -> int {
+      memset(&split, 0, sizeof(split));
+      split.leaf_cost = lib->shape_leaf_cost;
+      if (!(want && (solid ? lib->shape_levels : lib->bvh_levels) > 1 && lib->bvh_params.num_max_contacts == 1 && !lib->bvh_params.contacts)) return HFCL_OK;
+      int r = ensure_bvh_split(lib, n);
+      if (r) return r;
+      HIP_TRY(hipMemsetAsync(lib->d_bvh_ctr, 0, BVH_CTR_WORDS * sizeof(uint32_t), st));
+      split.tasks = lib->d_bvh_tasks;
+      split.sums = lib->d_bvh_sums;
+      split.suspended = lib->d_bvh_susp;
+      split.ctr = lib->d_bvh_ctr;
+      split.cap = uint32_t(std::min<size_t>(lib->bvh_split_cap, 0x7FFFFFFFu));
+      split.n_queries = uint32_t(lib->bvh_split_n);
+      split.budget = lib->bvh_budget;
+      split.budget0 = lib->bvh_budget0;
+      split.n_levels = lib->bvh_levels;
+      if (lib->bvh_auto && 2 * n <= 3 * size_t(lib->n_cus) * 512) {  // (8 waves of 64 lanes per CU are resident)
+        split.budget0 = 512;
+        split.budget = 16;
+        split.n_levels = BVH_MAX_LEVELS;
+      }
+      if (solid) {
+        split.budget0 = lib->shape_budget0;
+        split.budget = lib->shape_budget;
+        split.n_levels = lib->shape_levels;
+      }
+      return HFCL_OK;
+    };
+    // mesh x solid: one query per lane (k_bvh_collide's SOLID form) where the request lets a leaf that needs EPA end the
+    // walk (hfcl_bvh_shape.hpp: mesh_shape_lane_request) and the lanes' stacks hold the models; the 16-lane group kernel
+    // otherwise
+    const bool shape_fast = q.mode == 1 && may(B_BVHSHAPE) && lib->bvh_shape_lane && size_t(lib->bvh_max_depth) + 1 <= size_t(BVH_STACK) &&
+                            mesh_shape_lane_request(q, lib->bvh_params.num_max_contacts);
+    if (shape_fast) {
+      if (lib->ws_capacity > lib->shape_defer_capacity) {
+        hipFree(lib->d_shape_defer);
+        hipFree(lib->d_shape_oq);
+        lib->d_shape_defer = lib->d_shape_oq = nullptr;
+        lib->shape_defer_capacity = 0;
+        HIP_TRY(hipMalloc(&lib->d_shape_defer, lib->ws_capacity * sizeof(ShapeDeferItem<double>)));
+        HIP_TRY(hipMalloc(&lib->d_shape_oq, lib->ws_capacity * sizeof(ObbQuery<double>)));
+        lib->shape_defer_capacity = lib->ws_capacity;
+      }
+      wk.shape_defer = lib->d_shape_defer;
+      wk.shape_oq = lib->d_shape_oq;
+    }
     if (q.mode == 1) {
       tbeg("k_bvh_shape");
-      launch_bvh_shape<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance));
+      if (shape_fast) {
+        // tasks re-start the leaf solver from the request's guess: a walk whose leaves hand the cached guess on, or whose
+        // final guess is read, stays in one piece
+        BvhSplit split;
+        rc = make_split(split, n >= 256 && q.guess_mode != HFCL_GUESS_CACHED && !io.gout, true);
+        if (rc) return rc;
+        launch_bvh_shape_fast<T>(blocks_for(n, BVH_BLOCK), blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, lib->bvh_params,
+                                 T(lib->break_distance * lib->break_distance), split, spill);
+      } else {
+        launch_bvh_shape<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance));
+      }
       tend();
       tbeg("k_bvh_collide");
       BvhSplit split;
-      memset(&split, 0, sizeof(split));
-      // long traversals are cut into tasks when the batch is large enough for the tail to matter and the request
-      // keeps no query-wide contact count
-      if (may(B_BVH) && !spill.wide && lib->bvh_levels > 1 && (n >= 256 || 2 * size_t(lib->bvh_max_depth) + 4 > size_t(std::min(BVH_STACK, BVH_STACK_FILT))) &&
-          lib->bvh_params.num_max_contacts == 1 && !lib->bvh_params.contacts) {
-        rc = ensure_bvh_split(lib, n);
-        if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(lib->d_bvh_ctr, 0, BVH_CTR_WORDS * sizeof(uint32_t), st));
-        split.tasks = lib->d_bvh_tasks;
-        split.sums = lib->d_bvh_sums;
-        split.suspended = lib->d_bvh_susp;
-        split.ctr = lib->d_bvh_ctr;
-        split.cap = uint32_t(std::min<size_t>(lib->bvh_split_cap, 0x7FFFFFFFu));
-        split.n_queries = uint32_t(lib->bvh_split_n);
-        split.budget = lib->bvh_budget;
-        split.budget0 = lib->bvh_budget0;
-        split.n_levels = lib->bvh_levels;
-        if (lib->bvh_auto && 2 * n <= 3 * size_t(lib->n_cus) * 512) {  // (8 waves of 64 lanes per CU are resident)
-          split.budget0 = 512;
-          split.budget = 16;
-          split.n_levels = BVH_MAX_LEVELS;
-        }
-      }
+      rc = make_split(split, may(B_BVH) && !spill.wide && (n >= 256 || 2 * size_t(lib->bvh_max_depth) + 4 > size_t(std::min(BVH_STACK, BVH_STACK_FILT))), false);
+      if (rc) return rc;
       launch_bvh_collide<T>(blocks_for(n, BVH_BLOCK), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance), split, spill);
       tend();
     } else {

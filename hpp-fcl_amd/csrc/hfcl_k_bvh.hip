@@ -47,6 +47,65 @@ template <> struct BvhEntry<true> {
   static __device__ __forceinline__ uint32_t second(E e) { return uint32_t(e >> 32); }
 };
 
+// ---------------------------------------------------------------------------------------
+// Mesh x solid with one query per LANE: pieces of the SOLID form of k_bvh_collide (below) and of k_bvh_shape_finish.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct LaneSolid {  // support of the solid in its own frame, by one lane (ConvexBase: serial scan, first maximum wins)
+  DShape<T> s;
+  const T* v;
+  __device__ __forceinline__ V3<T> operator()(const V3<T>& d) const {
+    if (s.kind != K_CONVEX) return prim_support(s, d);
+    uint32_t best = 0;
+    T bd = v[0] * d.x + v[1] * d.y + v[2] * d.z;
+    for (uint32_t i = 1; i < s.num_points; ++i) {
+      const T x = v[3 * size_t(i)] * d.x + v[3 * size_t(i) + 1] * d.y + v[3 * size_t(i) + 2] * d.z;
+      if (x > bd) {
+        bd = x;
+        best = i;
+      }
+    }
+    return mk<T>(v[3 * size_t(best)], v[3 * size_t(best) + 1], v[3 * size_t(best) + 2]);
+  }
+};
+template <typename T>
+__device__ __forceinline__ void emit_shape_contact(const BvhParams& bp, uint32_t pair, bool swapped, int prim, T distance,
+                                                   const V3<T>& p1, const V3<T>& p2, const V3<T>& nn) {
+  if (!bp.contacts) return;
+  const uint32_t slot = atomicAdd(bp.contacts_count, 1u);
+  if (slot >= bp.contacts_cap) return;
+  hfcl_contact c;
+  c.pair = pair;
+  c.b1 = swapped ? -1 : prim;
+  c.b2 = swapped ? prim : -1;
+  c._pad = 0;
+  c.penetration_depth = double(distance);
+  const V3<T> a1 = swapped ? p2 : p1, a2 = swapped ? p1 : p2, an = swapped ? -nn : nn;
+  c.normal[0] = an.x; c.normal[1] = an.y; c.normal[2] = an.z;
+  c.p1[0] = a1.x; c.p1[1] = a1.y; c.p1[2] = a1.z;
+  c.p2[0] = a2.x; c.p2[1] = a2.y; c.p2[2] = a2.z;
+  bp.contacts[slot] = c;
+}
+template <typename T>
+__device__ __forceinline__ void store_unsupported(const IO<T>& io, uint32_t pair) {
+  auto r = io.out[pair];
+  memset(&r, 0, sizeof(r));
+  r.status = 0x80000000u;
+  io.out[pair] = r;
+}
+// Is the work of the task (parent slot p, position o) still needed?  Not if an earlier sibling -- of it or of any of its
+// ancestors -- has found a contact: the sequential walk would have ended there.
+template <typename T>
+__device__ __forceinline__ bool bvh_moot(const BvhSplit& split, uint32_t p, uint32_t o) {
+  for (int hop = 0; hop < BVH_MAX_LEVELS + 1 && p != 0xFFFFFFFFu; ++hop) {
+    const BvhSum<T>* ps = bvh_sum<T>(split, p);
+    if (__hip_atomic_load(&ps->contact_order, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o) return true;
+    o = ps->order;
+    p = ps->parent;
+  }
+  return false;
+}
+
 #ifndef HFCL_BVH_PREFETCH
 #define HFCL_BVH_PREFETCH 1  // cfg4 100k: 7.5 -> 6.7 ms, 1M: 61.6 -> 67.6 M q/s (profiles/r02_r); touching the sibling as well gave nothing more
 #endif
@@ -70,13 +129,70 @@ template <> struct BvhEntry<true> {
 #ifndef HFCL_WPE_BVH_FILT
 #define HFCL_WPE_BVH_FILT 2
 #endif
+// The leaf of the SOLID form as a call: inlined (HFCL_SOLID_LEAF_OUTLINE=0), the leaf's GJK over every support function
+// shares the register allocation of the walk -- 7 % slower on tools/mesh_solid_bench.py (profiles/r03_i).
+#ifndef HFCL_SOLID_LEAF_OUTLINE
+#define HFCL_SOLID_LEAF_OUTLINE 1
+#endif
+template <typename T>
+struct SolidLeafOut {
+  T distance;
+  V3<T> p1, p2, n, guess;
+};
+template <typename T>
+struct SolidLeafIn {
+  const T* mesh_verts;      // of this model
+  const uint32_t* tri;      // the triangle's three vertex ids
+  const DShape<T>* shapes;
+  const T* lib_verts;
+  const decltype(IO<T>::tf1) pose_m;  // pose arrays of the mesh / the solid
+  const decltype(IO<T>::tf1) pose_s;
+  ShapeDeferItem<T>* defer;
+  uint32_t* defer_count;
+  uint32_t pair, solid_id, prim, parent, order;
+};
+template <typename T, class PS>
+__device__ __noinline__ bool solid_leaf_call(const SolidLeafIn<T> in, const QParams<T>* qp, const PS ps, const V3<T> guess_in, SolidLeafOut<T>* out) {
+  const QParams<T> q = *qp;
+  auto vtx = [&](uint32_t i) { return mk<T>(in.mesh_verts[3 * size_t(i)], in.mesh_verts[3 * size_t(i) + 1], in.mesh_verts[3 * size_t(i) + 2]); };
+  const V3<T> ta = vtx(in.tri[0]), tb = vtx(in.tri[1]), tc = vtx(in.tri[2]);
+  LaneSolid<T> solid;
+  solid.s = in.shapes[in.solid_id];
+  solid.v = in.lib_verts + 3 * size_t(solid.s.vertex_offset);
+  auto tfm_of = [&]() { return load_pose(in.pose_m, in.pair); };
+  auto tfs_of = [&]() { return load_pose(in.pose_s, in.pair); };
+  const MDiff<T> sMt = make_mdiff(tfs_of(), tfm_of());
+  V3<T> guess = guess_in;
+  ShapeDeferItem<T> item;
+  const bool to_epa = mesh_shape_leaf_lane(ta, tb, tc, sMt, tfm_of, tfs_of, solid.s, solid, swept_radius(solid.s), q, guess, ps, out->distance,
+                                           out->p1, out->p2, out->n, item);
+  if (to_epa) {
+    item.seed.pair = in.pair;
+    item.prim = in.prim;
+    item.parent = in.parent;
+    item.order = in.order;
+    in.defer[atomicAdd(in.defer_count, 1u)] = item;
+  }
+  out->guess = guess;
+  return to_epa;
+}
+
 #ifndef HFCL_BVH_PARK_MAX
 #define HFCL_BVH_PARK_MAX 32  // lanes waiting for a leaf test or an fp64 re-test that end the BV phase of a wave
 #endif
-template <typename T, bool WIDE, bool FILT = false>
+// SOLID: BVHModel<OBBRSS> x convex solid (bucket B_BVHSHAPE, either operand order) walked by the same machinery, one query
+// per lane.  The second "tree" is the solid's fitted OBB (k_shape_obb wrote its products with the mesh pose, ObbQuery, per
+// query), so an entry is a node of the mesh, every step splits the mesh node (collisionRecurse with a leaf second node) and
+// a leaf is ShapeShapeDistance<TriangleP, S>: closed form or per-lane GJK.  A leaf that needs EPA is a contact on the
+// host's word (mesh_shape_lane_request) and ends the unit like any contact; its numbers come later, from
+// k_bvh_shape_finish.  The 16-lane group kernel this replaces where the request allows walked the long queries of a
+// batch alone (the steps per query have a heavy tail: median 1, mean 60, maximum > 3000 with > 1000 leaf tests on
+// tools/mesh_solid_bench.py's scenes) -- here they suspend into tasks like the long mesh x mesh queries.
+template <typename T, bool WIDE, bool FILT = false, bool SOLID = false>
 __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(FILT ? HFCL_WPE_BVH_FILT : HFCL_WPE_BVH_COLLIDE, 8))) k_bvh_collide(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
                                                           BvhParams bp, T break_distance2, BvhSplit split, BvhSpill spill) {
   static_assert(!FILT || sizeof(T) == 8, "the fp32 filter stands in front of the fp64 test");
+  static_assert(!SOLID || (!WIDE && !FILT), "mesh x solid: 32-bit node ids in the narrow entry, plain tests");
   typedef BvhEntry<WIDE> EN;
   typedef typename EN::E E;
   // the filter form is built for three waves per SIMD: six 128-thread blocks per CU = 20 LDS allocation units (25 600 B) each
@@ -89,8 +205,9 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   uint32_t nspill = 0;
   const uint32_t level = split.level;
   const uint32_t unit0 = level ? split.ctr[BVH_CTR_LEVEL0 + level - 1] : 0u;  // first task of this level
-  const uint32_t cnt = level ? min(split.ctr[BVH_CTR_LEVEL0 + level], split.cap) - min(unit0, split.cap) : wk.counts[B_BVH];
-  uint32_t* const ticket = &wk.counts[B_COUNT + 2];
+  const uint32_t cnt = level ? min(split.ctr[BVH_CTR_LEVEL0 + level], split.cap) - min(unit0, split.cap) : wk.counts[SOLID ? B_BVHSHAPE : B_BVH];
+  uint32_t* const ticket = &wk.counts[SOLID ? CTR_SHAPE_TICKET : B_COUNT + 2];
+  auto ent_first = [](E e) -> uint32_t { return SOLID ? uint32_t(e) : EN::first(e); };  // SOLID: the entry is the mesh node
   const uint32_t budget = split.budget;  // steps a unit may take before it suspends (0: never)
   const int tid = threadIdx.x, lane = tid & 63;
   const T nanv = Lim<T>::nan();
@@ -125,6 +242,10 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   bool have_leaf = false;
   uint32_t lb1 = 0, lb2 = 0;
   uint32_t my_parent = 0xFFFFFFFFu, my_order = 0;  // (tasks) where this unit hangs
+  // SOLID: RT_R / RT_T hold the ObbQuery's M / V, q_ext its extent; the solid, the operand order, the solver's cached guess
+  V3<T> q_ext = mk<T>(T(0), T(0), T(0)), guess = mk<T>(T(1), T(0), T(0));
+  uint32_t solid_id = 0;
+  bool swapped = false;
   auto witness_store = [&](const V3<T>& p1, const V3<T>& p2, const V3<T>& n) {  // the witness of the bound, in place
     if (level) {
       BvhSum<T>* sm = bvh_sum<T>(split, split.n_queries + unit);
@@ -145,20 +266,12 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   auto flush = [&]() {  // the unit this lane finished: a query's record, or a task's summary (the witness is in place)
     if (level)
       write_sum_head(split.n_queries + unit, 0u, 0u, overflow ? BVH_SUM_OVERFLOW : 0u);
-    else
+    else {
       store_bvh_record_head(io, pair, rec_dist, ncontacts, fb1, fb2, overflow);
-  };
-  // Is the work of the task (parent slot p, position o) still needed?  Not if an earlier sibling -- of it or of any of its
-  // ancestors -- has found a contact: the sequential walk would have ended there.
-  auto moot = [&](uint32_t p, uint32_t o) -> bool {
-    for (int hop = 0; hop < BVH_MAX_LEVELS + 1 && p != 0xFFFFFFFFu; ++hop) {
-      const BvhSum<T>* ps = bvh_sum<T>(split, p);
-      if (__hip_atomic_load(&ps->contact_order, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o) return true;
-      o = ps->order;
-      p = ps->parent;
+      if constexpr (SOLID) write_guess<T>(io, pair, guess, 0, 0);
     }
-    return false;
   };
+  auto moot = [&](uint32_t p, uint32_t o) -> bool { return bvh_moot<T>(split, p, o); };
   // a contact in this task ends the walk of every unit above it at this child's position
   auto report_contact = [&](uint32_t p, uint32_t o) {
     for (int hop = 0; hop < BVH_MAX_LEVELS + 1 && p != 0xFFFFFFFFu; ++hop) {
@@ -170,12 +283,19 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   };
   // Turn the `n_extra` entries in `extra` (children about to be pushed: first one on top) and the whole stack into tasks
   // of the next level and park this unit.  false: no room in the task table (the unit then simply goes on).
+  // SOLID: every entry is EXPANDED ONCE on the way out -- its box is tested here, and its two children (or the bound, if the
+  // boxes are disjoint: a child that is already finished) take its place among the tasks.  A suspended stack holds subtrees
+  // of geometrically decreasing size (the bottom entry is the sibling of the walk's first step: half the tree), so plain
+  // suspension halves the longest chain per level at best; with the expansion it is quartered (profiles/r03_i: mesh x solid
+  // 6.2 -> 4.6 ms per 100k sphere queries, nine levels -> six; the same on mesh x mesh stacks LOSES, 4.97 -> 5.28 ms per
+  // 100k cfg4 queries: twice the tasks, and a task costs its set-up).
   auto suspend = [&](uint32_t ea, uint32_t eb, int n_extra) -> bool {
-    const uint32_t n_child = uint32_t(sp + n_extra);
-    if (WIDE || !split.can_suspend || n_child == 0) return false;  // (tasks carry 16-bit node ids)
-    const uint32_t first = atomicAdd(&split.ctr[BVH_CTR_TASKS], n_child);
-    if (first + n_child > split.cap) {  // table full: the slots taken become no-ops for the next level
-      for (uint32_t j = first; j < min(first + n_child, split.cap); ++j) split.tasks[j] = BvhTask{0u, 0u, 0xFFFFFFFFu, 0u};
+    const uint32_t n_ent = uint32_t(sp + n_extra);
+    if (WIDE || !split.can_suspend || n_ent == 0) return false;  // (tasks carry 16-bit node ids)
+    const uint32_t n_slots = SOLID ? 2u * n_ent : n_ent;
+    const uint32_t first = atomicAdd(&split.ctr[BVH_CTR_TASKS], n_slots);
+    if (first + n_slots > split.cap) {  // table full: the slots taken become no-ops for the next level
+      for (uint32_t j = first; j < min(first + n_slots, split.cap); ++j) split.tasks[j] = BvhTask{0u, 0u, 0xFFFFFFFFu, 0u};
       steps = 0;  // the unit goes on; it asks again after another budget of steps, not at every step (a full table stays full)
       return false;
     }
@@ -186,16 +306,52 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
       my_slot = atomicAdd(&split.ctr[BVH_CTR_SUSPENDED], 1u);  // < n_queries: one per query at most
       split.suspended[my_slot] = pair;
     }
-    write_sum_head(my_slot, first, n_child, BVH_SUM_SUSPENDED);  // (before the tasks: they point at it)
+    uint32_t j = first, o = 0;
+    auto as_they_are = [&]() {
+      if (n_extra > 0) split.tasks[j++] = BvhTask{pair, my_slot, ea, o++};
+      if (n_extra > 1) split.tasks[j++] = BvhTask{pair, my_slot, eb, o++};
+      for (int k = sp - 1; k >= 0; --k) split.tasks[j++] = BvhTask{pair, my_slot, uint32_t(stack[k][tid]), o++};  // DFS order: top first
+    };
+    if constexpr (SOLID) {
+      ObbQuery<T> oq;
+      oq.M = RT_R;
+      oq.V = RT_T;
+      oq.ext = q_ext;
+      for (int k = int(n_ent) - 1; k >= 0; --k) {  // DFS order: the children about to be pushed, then the stack from the top
+        const uint32_t e = k >= sp ? (k == int(n_ent) - 1 ? ea : eb) : uint32_t(stack[k][tid]);
+        const DNode<T>* const np = bv.nodes + m1.node_off + e;
+        const int32_t fc = np->first_child;
+        if (fc < 0) {
+          split.tasks[j++] = BvhTask{pair, my_slot, e, o++};
+          continue;
+        }
+        const DNode<T> n1 = *np;
+        T sq;
+        if (obb_disjoint_q(oq, n1, q.security_margin, break_distance2, sq)) {
+          // a child that is finished: its summary is the bound (updateDistanceLowerBoundFromBV, folded in at its place)
+          BvhSum<T>* sm = bvh_sum<T>(split, split.n_queries + j);
+          const T nd = hsqrt(sq);
+          sm->dlb = nd;
+          sm->rec_dist = nd + q.security_margin;
+          sm->cand_val = Lim<T>::max();
+          sm->fb1 = sm->fb2 = -1;
+          sm->ncontacts = 0; sm->first_child = 0; sm->n_child = 0; sm->flags = 0;
+          sm->contact_order = 0xFFFFFFFFu; sm->parent = my_slot; sm->order = o; sm->pad_ = 0;
+          split.tasks[j++] = BvhTask{pair, my_slot, 0xFFFFFFFFu, o++};
+        } else {
+          split.tasks[j++] = BvhTask{pair, my_slot, uint32_t(fc), o++};
+          split.tasks[j++] = BvhTask{pair, my_slot, uint32_t(fc) + 1u, o++};
+        }
+      }
+      for (uint32_t u = j; u < first + n_slots; ++u) split.tasks[u] = BvhTask{0u, 0u, 0xFFFFFFFFu, 0u};  // slots not needed
+    } else {
+      as_they_are();
+    }
+    write_sum_head(my_slot, first, j - first, BVH_SUM_SUSPENDED);
     if (!level) {  // a query's witness so far sits in its record: the summary needs a copy
       BvhSum<T>* sm = bvh_sum<T>(split, my_slot);
       load_witness(io, pair, sm->np1, sm->np2, sm->nn);
     }
-    __threadfence();
-    uint32_t j = first, o = 0;
-    if (n_extra > 0) split.tasks[j++] = BvhTask{pair, my_slot, ea, o++};
-    if (n_extra > 1) split.tasks[j++] = BvhTask{pair, my_slot, eb, o++};
-    for (int k = sp - 1; k >= 0; --k) split.tasks[j++] = BvhTask{pair, my_slot, uint32_t(stack[k][tid]), o++};  // DFS order: top first
     sp = 0;
     live = false;  // nothing to flush: the summary is written
     return true;
@@ -252,13 +408,32 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
               write_sum_head(split.n_queries + unit, 0u, 0u, 0u);
             }
           } else {
-            pair = wk.lists[size_t(B_BVH) * wk.n + it];
+            pair = wk.lists[size_t(SOLID ? B_BVHSHAPE : B_BVH) * wk.n + it];
+          }
+          if constexpr (SOLID) {
+            if (valid) {
+              const uint32_t id1 = wk.shape1[pair], id2 = wk.shape2[pair];
+              swapped = lib.kinds[id1] != uint8_t(K_BVH);  // (shape, BVH): collide(o2, o1) then swapObjects (collision.cpp:93-108)
+              solid_id = swapped ? id1 : id2;
+              m1 = bv.meshes[lib.shapes[swapped ? id2 : id1].bvh_index];
+              const ObbQuery<T> oq = reinterpret_cast<const ObbQuery<T>*>(wk.shape_oq)[pair];
+              if (!(oq.ext.x == oq.ext.x)) {  // k_shape_obb: no OBB for this solid (swept-sphere radius, < 4 bound vertices)
+                valid = false;
+                store_unsupported(io, pair);
+              }
+              RT_R = oq.M;
+              RT_T = oq.V;
+              q_ext = oq.ext;
+              guess = initial_guess<T>(io, q, pair);
+            }
           }
           if (valid) {
+            if constexpr (!SOLID) {
             const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
             m1 = bv.meshes[a.bvh_index];
             m2 = bv.meshes[b.bvh_index];
-            {
+            }
+            if constexpr (!SOLID) {
               const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
               const M3<T> R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
               const V3<T> t = tmul(tf1.R, tf2.t - tf1.t);
@@ -349,7 +524,7 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
         }
         ++steps;
         const E e = stack[--sp][tid];
-        const uint32_t b1 = EN::first(e), b2 = EN::second(e);
+        const uint32_t b1 = ent_first(e), b2 = SOLID ? 0u : EN::second(e);
         if constexpr (FILT) {
           const DNodeF f1 = bv.fnodes[m1.node_off + b1];
           const DNodeF f2 = bv.fnodes[m2.node_off + b2];
@@ -395,6 +570,31 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
               pend = e;
               pend_first = first;
             }
+          }
+        } else if constexpr (SOLID) {
+          const DNode<T>* const np = bv.nodes + m1.node_off + b1;
+          const int32_t fc = np->first_child;
+          if (fc < 0) {
+            have_leaf = true;
+            lb1 = uint32_t(-(fc + 1));
+          } else {
+            const DNode<T> n1 = *np;
+#if HFCL_BVH_PREFETCH
+            const int32_t touched = np[fc - int32_t(b1)].first_child;  // the node popped next if the boxes overlap
+#endif
+            ObbQuery<T> oq;
+            oq.M = RT_R;
+            oq.V = RT_T;
+            oq.ext = q_ext;
+            T sq;
+            const bool disjoint = obb_disjoint_q(oq, n1, q.security_margin, break_distance2, sq);
+#if HFCL_BVH_PREFETCH
+            asm volatile("" ::"v"(touched));
+#endif
+            if (disjoint)
+              on_disjoint(sq);
+            else
+              on_overlap(true, b1, 0u, fc, 0);
           }
         } else {
         const DNode<T> n1 = bv.nodes[m1.node_off + b1];
@@ -456,6 +656,79 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
       }
     }
     // ---- leaf phase (leafCollides, traversal_node_bvhs.h:184-233)
+    if constexpr (SOLID) {
+      if (have_leaf) {
+        have_leaf = false;
+        const uint32_t* t3 = bv.tris + 3 * size_t(m1.tri_off + lb1);
+        const T* mv = bv.verts + 3 * size_t(m1.vert_off);
+        const uint32_t kind = lib.kinds[solid_id];
+        // what the leaf costs in BV tests (the unit of the step budget): a GJK run against the solid, or a closed form
+        steps += (kind == uint32_t(K_SPHERE) || kind_is_flat(int(kind))) ? max(split.leaf_cost / 8u, 1u) : split.leaf_cost;
+        T distance;
+        V3<T> p1, p2, n;
+        bool to_epa;
+#if HFCL_SOLID_LEAF_OUTLINE
+        {
+          SolidLeafIn<T> in{mv, t3, lib.shapes, lib.verts, swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2,
+                            reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer), &wk.counts[CTR_SHAPE_DEFER], pair, solid_id, lb1, my_parent, my_order};
+          SolidLeafOut<T> lo;
+          to_epa = solid_leaf_call<T>(in, &q, leaf_ps, guess, &lo);
+          distance = lo.distance;
+          p1 = lo.p1;
+          p2 = lo.p2;
+          n = lo.n;
+          guess = lo.guess;
+        }
+#else
+        {
+        auto vtx = [&](uint32_t i) { return mk<T>(mv[3 * size_t(i)], mv[3 * size_t(i) + 1], mv[3 * size_t(i) + 2]); };
+        const V3<T> ta = vtx(t3[0]), tb = vtx(t3[1]), tc = vtx(t3[2]);
+        LaneSolid<T> solid;
+        solid.s = lib.shapes[solid_id];
+        solid.v = lib.verts + 3 * size_t(solid.s.vertex_offset);
+        auto tfm_of = [&]() { return load_pose(swapped ? io.tf2 : io.tf1, pair); };
+        auto tfs_of = [&]() { return load_pose(swapped ? io.tf1 : io.tf2, pair); };
+        const MDiff<T> sMt = make_mdiff(tfs_of(), tfm_of());  // Transform3f::inverseTimes: the mesh frame in the solid's frame
+        ShapeDeferItem<T> item;
+        to_epa = mesh_shape_leaf_lane(ta, tb, tc, sMt, tfm_of, tfs_of, solid.s, solid, swept_radius(solid.s), q, guess, leaf_ps,
+                                      distance, p1, p2, n, item);
+        if (to_epa) {
+          item.seed.pair = pair;
+          item.prim = lb1;
+          item.parent = my_parent;
+          item.order = my_order;
+          reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer)[atomicAdd(&wk.counts[CTR_SHAPE_DEFER], 1u)] = item;
+        }
+        }
+#endif
+        bool contact = to_epa;
+        if (!to_epa) {
+          const T dtc = distance - q.security_margin;
+          if (dtc < dlb) {  // updateDistanceLowerBoundFromLeaf
+            dlb = dtc;
+            cand_val = dtc;
+            rec_dist = distance;
+            witness_store(swapped ? p2 : p1, swapped ? p1 : p2, swapped ? -n : n);
+          }
+          contact = dtc <= q.collision_distance_threshold;
+        }
+        if (contact) {
+          if (ncontacts < bp.num_max_contacts) {
+            if (ncontacts == 0) {
+              fb1 = swapped ? -1 : int(lb1);
+              fb2 = swapped ? int(lb1) : -1;
+              if (level) report_contact(my_parent, my_order);
+            }
+            ++ncontacts;
+            if (!to_epa) emit_shape_contact(bp, pair, swapped, int(lb1), distance, p1, p2, n);
+          }
+          if (to_epa || ncontacts >= bp.num_max_contacts) {  // canStop()
+            sp = 0;
+            nspill = 0;
+          }
+        }
+      }
+    } else
     if (have_leaf) {
       have_leaf = false;
       steps += 8;  // a triangle pair costs about as much as eight BV tests
@@ -522,10 +795,10 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
 }
 
 // Between two levels: the tasks made so far are the next level's units; the ticket counter starts over.
-__global__ void k_bvh_level_mark(Work wk, BvhSplit split) {
+__global__ void k_bvh_level_mark(Work wk, BvhSplit split, int ticket) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     split.ctr[BVH_CTR_LEVEL0 + split.level + 1] = split.ctr[BVH_CTR_TASKS];
-    wk.counts[B_COUNT + 2] = 0u;
+    wk.counts[ticket] = 0u;
   }
 }
 
@@ -657,6 +930,74 @@ __global__ void __launch_bounds__(64) k_bvh_shape(Work wk, LibView<T> lib, BvhVi
         store_bvh_record(io, pair, o, st.ncontacts, swapped ? -1 : st.first_prim, swapped ? st.first_prim : -1, st.overflow);
         write_guess<T>(io, pair, st.guess, 0, 0);
       }
+    }
+    LaneGroup<BS_W>::sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Mesh x solid, one query per lane (k_bvh_collide<T, false, false, SOLID>): the two kernels around the walk.
+// k_shape_obb: computeBV<OBBRSS, S>(solid, tf) per query -- the reference's PCA fit of the solid's bound vertices in
+// world frame (Jacobi sweeps; hfcl_bvh_shape.hpp: shape_obb) -- and its products with the mesh pose (ObbQuery), by
+// pair, so that the walk (and every task a long query is cut into) starts from 15 loaded numbers.
+// k_bvh_shape_finish: the leaves that needed EPA, one per BS_W-lane group with the full-capacity polytope in LDS, after
+// the walk and its fold-back: a leaf whose unit was not overtaken by an earlier contact (bvh_moot) is the query's contact;
+// its depth is compared with the bound the record holds (updateDistanceLowerBoundFromLeaf) and patched in.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_shape_obb(Work wk, LibView<T> lib, IO<T> io) {
+  const uint32_t cnt = wk.counts[B_BVHSHAPE];
+  ObbQuery<T>* const table = reinterpret_cast<ObbQuery<T>*>(wk.shape_oq);
+  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
+    const uint32_t pair = wk.lists[size_t(B_BVHSHAPE) * wk.n + it];
+    const uint32_t id1 = wk.shape1[pair], id2 = wk.shape2[pair];
+    const bool swapped = lib.kinds[id1] != uint8_t(K_BVH);
+    const DShape<T> shape = lib.shapes[swapped ? id1 : id2];
+    const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+    DNode<T> bv2;
+    ObbQuery<T> oq;
+    if (shape_obb(shape, lib.verts, swapped ? tf1 : tf2, bv2)) {
+      oq = make_obb_query(swapped ? tf2 : tf1, bv2);
+    } else {
+      const T nanv = Lim<T>::nan();
+      oq.M.r0 = oq.M.r1 = oq.M.r2 = oq.V = oq.ext = mk<T>(nanv, nanv, nanv);
+    }
+    table[pair] = oq;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) k_bvh_shape_finish(Work wk, LibView<T> lib, IO<T> io, QParams<T> q, BvhParams bp, BvhSplit split) {
+  constexpr int G = 64 / BS_W;
+  __shared__ EpaScratch<T, EPA_MAX_ITER> scratch[G];
+  const uint32_t cnt = wk.counts[CTR_SHAPE_DEFER];
+  const ShapeDeferItem<T>* const items = reinterpret_cast<const ShapeDeferItem<T>*>(wk.shape_defer);
+  const int lane = threadIdx.x & 63, grp = lane / BS_W, lig = lane & (BS_W - 1);
+  for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += gridDim.x * G) {
+    const ShapeDeferItem<T> item = items[it];
+    if (split.tasks && bvh_moot<T>(split, item.parent, item.order)) continue;  // (group-uniform) an earlier contact ended the walk
+    const uint32_t pair = item.seed.pair;
+    const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+    const bool swapped = a.kind != K_BVH;
+    GroupSolid<T> solid;
+    solid.s = swapped ? a : b;
+    solid.v = lib.verts + 3 * size_t(solid.s.vertex_offset);
+    solid.lig = lig;
+    if (solid.s.kind == K_CONVEX && solid.s.num_points <= uint32_t(HULL_MAX)) solid.h.load(solid.v, solid.s.num_points, lig);
+    const Pose<T> tfs = load_pose(swapped ? io.tf1 : io.tf2, pair);
+    V3<T> p1, p2, n, guess;
+    const T distance = mesh_shape_leaf_finish<T, LaneGroup<BS_W>>(item, tfs, solid, swept_radius(solid.s), q, &scratch[grp], p1, p2, n, guess);
+    if (lig == 0) {
+      // the record holds the walk's result without this leaf: recorded distance = bound + margin where a leaf set it (the
+      // same subtraction as updateDistanceLowerBoundFromLeaf's), a positive OBB bound otherwise (always above a penetration)
+      auto* r = &io.out[pair];
+      const T dtc = distance - q.security_margin;
+      if (dtc < T(r->distance) - q.security_margin) {
+        r->distance = distance;
+        store_witness(io, pair, swapped ? p2 : p1, swapped ? p1 : p2, swapped ? -n : n);
+      }
+      emit_shape_contact(bp, pair, swapped, int(item.prim), distance, p1, p2, n);
+      write_guess<T>(io, pair, guess, 0, 0);
     }
     LaneGroup<BS_W>::sync();
   }
@@ -972,7 +1313,11 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
 // one launch of the collide kernel in the form the batch asks for: WIDE (32-bit node ids) or not, with the fp32 filter in
 // front of the fp64 test (fp64 batches of a library whose filter records are uploaded, bv.fnodes) or without
 template <typename T>
-static void launch_collide_kernel(bool wide, int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, const BvhSplit& split, const BvhSpill& spill) {
+static void launch_collide_kernel(bool wide, int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, const BvhSplit& split, const BvhSpill& spill, bool solid = false) {
+  if (solid) {  // mesh x solid: the narrow form, 32-bit node ids in the entry
+    hipLaunchKernelGGL((k_bvh_collide<T, false, false, true>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
+    return;
+  }
   if constexpr (sizeof(T) == 8) {
     if (bv.fnodes) {
       if (wide)
@@ -988,8 +1333,8 @@ static void launch_collide_kernel(bool wide, int grid, hipStream_t st, const Wor
     hipLaunchKernelGGL((k_bvh_collide<T, false, false>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
 }
 template <typename T>
-void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill) {
-  if (spill.wide) {  // models with 32-bit node ids: single pass, global spill instead of tasks
+void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill, bool solid) {
+  if (spill.wide && !solid) {  // models with 32-bit node ids: single pass, global spill instead of tasks
     split.tasks = nullptr;
     split.budget = 0;
     split.level = 0;
@@ -1004,7 +1349,7 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
     split.budget = 0;
     split.level = 0;
     split.can_suspend = 0;
-    launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
+    launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill, solid);
     return;
   }
   const uint32_t budget = split.budget;
@@ -1013,8 +1358,8 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
     split.budget = l + 1 < split.n_levels ? (l == 0 ? split.budget0 : budget) : 0u;  // the last level runs to the end
     BvhSplit s = split;
     s.can_suspend = l + 1 < split.n_levels;  // ... and cannot suspend (its stack overflows are flagged)
-    launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s, spill);
-    hipLaunchKernelGGL(k_bvh_level_mark, dim3(1), dim3(64), 0, st, wk, s);
+    launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s, spill, solid);
+    hipLaunchKernelGGL(k_bvh_level_mark, dim3(1), dim3(64), 0, st, wk, s, solid ? int(CTR_SHAPE_TICKET) : int(B_COUNT + 2));
   }
   for (int l = int(split.n_levels) - 2; l >= 0; --l) {
     split.level = uint32_t(l);
@@ -1034,6 +1379,18 @@ template <typename T>
 void launch_bvh_shape(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2) {
   hipLaunchKernelGGL((k_bvh_shape<T>), dim3(grid), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2);
 }
+// mesh x solid collide(), one query per lane: the solids' OBBs, the walk (split as `split` says), the EPA leaves
+template <typename T>
+void launch_bvh_shape_fast(int grid, int grid_finish, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill) {
+  hipLaunchKernelGGL((k_shape_obb<T>), dim3(std::max(1, grid / 2)), dim3(256), 0, st, wk, lv, io);
+  spill.wide = 0;
+  spill.slab = nullptr;
+  const bool splitting = split.tasks && split.n_levels > 1 && bp.num_max_contacts == 1 && !bp.contacts;
+  if (!splitting) split.tasks = nullptr;
+  launch_bvh_collide<T>(grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill, true);
+  split.level = 0;
+  hipLaunchKernelGGL((k_bvh_shape_finish<T>), dim3(grid_finish), dim3(64), 0, st, wk, lv, io, q, bp, split);
+}
 template <typename T>
 void launch_bvh_shape_distance(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q) {
   hipLaunchKernelGGL((k_bvh_shape_distance<T>), dim3(grid), dim3(64), 0, st, wk, lv, bv, io, q);
@@ -1043,10 +1400,11 @@ void launch_triangle(int grid, hipStream_t st, const Work& wk, const LibView<T>&
   hipLaunchKernelGGL((k_triangle<T>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
 }
 #define HFCL_INST(T)                                                                                                             \
-  template void launch_bvh_collide<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill); \
+  template void launch_bvh_collide<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill, bool); \
   template void launch_bvh_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, BvhSpill);                \
   template void launch_bvh_shape<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T);   \
   template void launch_bvh_shape_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&);          \
+  template void launch_bvh_shape_fast<T>(int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill); \
   template void launch_triangle<T>(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&);
 HFCL_INST(float)
 HFCL_INST(double)

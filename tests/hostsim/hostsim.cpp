@@ -482,6 +482,12 @@ int sim_bvh_distance_f64(const hfcl_bvh_node* nodes, size_t n_nodes, const doubl
 }
 
 // BVHModel<OBBRSS> x convex shape (either operand order): the device header's mesh_shape_collide on one lane.
+// nodes popped / triangles tested by each query of the last lane-form batch (tools/mesh_solid_steps.py: the tail of the walks)
+static std::vector<uint32_t> g_steps, g_leaves;
+const uint32_t* sim_shape_walk_steps() { return g_steps.data(); }
+const uint32_t* sim_shape_walk_leaves() { return g_leaves.data(); }
+static int g_shape_lane = 0;  // 1: the one-query-per-lane forms where the request admits them
+void sim_set_shape_lane(int on) { g_shape_lane = on; }
 struct HostSolid {
   DShape<double> s;
   const double* verts;
@@ -540,6 +546,89 @@ int sim_mesh_shape_collide_f64(const hfcl_shape* shapes, size_t n_shapes, const 
       c.p2[0] = a2.x; c.p2[1] = a2.y; c.p2[2] = a2.z;
       cl.push_back(c);
     };
+    if (g_shape_lane && mesh_shape_lane_request(q, creq->num_max_contacts)) {
+      // the one-query-per-lane form (k_bvh_shape_lane + k_bvh_shape_finish), in the order the kernels take the steps
+      const double nanv = Lim<double>::nan();
+      const DNode<double>* nodes1 = dn.data() + mt[0];
+      const double* mverts = verts + 3 * mt[2];
+      const uint32_t* mtris = tris + 3 * mt[3];
+      st.guess = mk<double>(q.guess[0], q.guess[1], q.guess[2]);
+      st.dlb = st.rec_dist = Lim<double>::max();
+      st.np1 = st.np2 = st.nn = mk<double>(nanv, nanv, nanv);
+      st.ncontacts = 0;
+      st.first_prim = -1;
+      st.overflow = st.unsupported = false;
+      DNode<double> bv2;
+      if (!shape_obb(solid, shape_verts, tfs, bv2)) {
+        st.unsupported = true;
+      } else {
+        const ObbQuery<double> oq = make_obb_query(tfm, bv2);
+        const MDiff<double> sMt = make_mdiff(tfs, tfm);
+        const double r1 = swept_radius(solid), bd2 = creq->break_distance * creq->break_distance;
+        int sp = 1;
+        stack[0] = 0;
+        if (g_steps.size() < n) { g_steps.assign(n, 0); g_leaves.assign(n, 0); }
+        g_steps[i] = g_leaves[i] = 0;
+        while (sp > 0) {
+          const DNode<double> n1 = nodes1[stack[--sp]];
+          ++g_steps[i];
+          if (n1.first_child < 0) ++g_leaves[i];
+          if (n1.first_child >= 0) {
+            double sq;
+            if (obb_disjoint_q(oq, n1, q.security_margin, bd2, sq)) {
+              mesh_shape_bv_bound(sq, q, st.dlb, st.rec_dist);
+            } else if (sp + 2 > 128) {
+              st.overflow = true;
+              sp = 0;
+            } else {
+              stack[sp] = uint32_t(n1.first_child + 1);
+              stack[sp + 1] = uint32_t(n1.first_child);
+              sp += 2;
+            }
+            continue;
+          }
+          const uint32_t prim = uint32_t(-(n1.first_child + 1));
+          const uint32_t* t3 = mtris + 3 * size_t(prim);
+          auto vtx = [&](uint32_t k) { return mk<double>(mverts[3 * size_t(k)], mverts[3 * size_t(k) + 1], mverts[3 * size_t(k) + 2]); };
+          auto tfm_of = [&]() { return tfm; };
+          auto tfs_of = [&]() { return tfs; };
+          double distance;
+          V3<double> p1, p2, nn;
+          ShapeDeferItem<double> item;
+          if (mesh_shape_leaf_lane(vtx(t3[0]), vtx(t3[1]), vtx(t3[2]), sMt, tfm_of, tfs_of, solid, hs, r1, q, st.guess, W0Regs<double>(),
+                                   distance, p1, p2, nn, item)) {
+            item.seed.pair = uint32_t(i);
+            item.bound = st.dlb;
+            item.rec = st.rec_dist;
+            item.prim = prim;
+            distance = mesh_shape_leaf_finish<double, SerialGroup<1>>(item, tfs, hs, r1, q, &scratch, p1, p2, nn, st.guess);
+            st.dlb = item.bound;
+            st.rec_dist = item.rec;
+            sp = 0;  // the walk ended at this leaf
+            bool lowered;
+            const bool contact = mesh_shape_leaf_bound(distance, q, st.dlb, st.rec_dist, lowered);
+            if (lowered) { st.np1 = p1; st.np2 = p2; st.nn = nn; }
+            if (contact) {
+              st.ncontacts = 1;
+              st.first_prim = int(prim);
+              on_contact(int(prim), distance, p1, p2, nn);
+            } else {
+              st.overflow = true;
+            }
+          } else {
+            bool lowered;
+            const bool contact = mesh_shape_leaf_bound(distance, q, st.dlb, st.rec_dist, lowered);
+            if (lowered) { st.np1 = p1; st.np2 = p2; st.nn = nn; }
+            if (contact) {
+              st.ncontacts = 1;
+              st.first_prim = int(prim);
+              on_contact(int(prim), distance, p1, p2, nn);
+              sp = 0;
+            }
+          }
+        }
+      }
+    } else
     mesh_shape_collide<double, SerialGroup<1>>(dn.data() + mt[0], verts + 3 * mt[2], tris + 3 * mt[3], tfm, solid, shape_verts, tfs, hs,
                                               q, creq->num_max_contacts, creq->break_distance * creq->break_distance, stack, 128,
                                               &scratch, mk<double>(q.guess[0], q.guess[1], q.guess[2]), on_contact, st);

@@ -150,6 +150,11 @@ def mesh_shape_collide_f64(abi, shapes, verts, meshlib, s1, s2, tf1, tf2, req, m
     return res[0] if len(res) == 1 else tuple(res)
 
 
+def set_shape_lane(on):
+    """1: the mesh x solid sims take the one-query-per-lane forms (k_bvh_shape_lane / _finish) where the request admits them."""
+    lib().sim_set_shape_lane(C.c_int(1 if on else 0))
+
+
 def mesh_shape_distance_f64(abi, shapes, verts, meshlib, s1, s2, tf1, tf2, req, want_guess=False):
     """distance() of BVHModel<OBBRSS> x convex shape pairs through the device header's mesh_shape_distance."""
     shapes = np.ascontiguousarray(shapes)

@@ -129,6 +129,33 @@ def test_device_headers_match_oracle(pkg, oracle, hostsim, nmax, margin, cached)
     assert _same(ggot["gjk_guess"], gref["gjk_guess"], 1e-13)
 
 
+@pytest.mark.parametrize("margin,cached", [(0.0, False), (0.03, False), (0.0, True)])
+def test_lane_form_equals_group_form(pkg, hostsim, margin, cached):
+    """The one-query-per-lane form of the traversal (k_bvh_shape_lane: lane-local walk and GJK, EPA leaves finished by
+    k_bvh_shape_finish from a queue) against the group form, host build of the same headers: every record, contact and
+    cached guess byte for byte (first-contact requests; the others take the group form)."""
+    abi, bb = pkg.abi, pkg.bvh_builder
+    b = _scene(pkg, n=3000, seed=16)
+    ML = bb.MeshLibrary(b.meshes)
+    sel = _mixed_only(pkg, b)
+    req = abi.default_collision_request()
+    req.security_margin = margin
+    if cached:
+        req.q.gjk_initial_guess = abi.CachedGuess
+        req.q.cached_gjk_guess[:] = [0.3, -0.2, 0.9]
+    a = (b.shapes, b.verts, ML, b.s1[sel], b.s2[sel], b.tf1[sel], b.tf2[sel], req)
+    ref, cref, gref = hostsim.mesh_shape_collide_f64(abi, *a, max_contacts=10 ** 6, want_guess=True)
+    hostsim.set_shape_lane(True)
+    try:
+        got, cgot, ggot = hostsim.mesh_shape_collide_f64(abi, *a, max_contacts=10 ** 6, want_guess=True)
+    finally:
+        hostsim.set_shape_lane(False)
+    assert 0.2 < (ref["num_contacts"] > 0).mean() < 0.9
+    assert ref.tobytes() == got.tobytes()
+    assert cref.tobytes() == cgot.tobytes()
+    assert gref.tobytes() == ggot.tobytes()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("nmax,margin", [(1, 0.0), (10 ** 6, 0.0), (3, 0.02)])
 def test_gpu_mesh_vs_shapes(pkg, oracle, nmax, margin):
@@ -192,6 +219,92 @@ def test_gpu_mesh_vs_shapes(pkg, oracle, nmax, margin):
         assert key(cref) == key(cgot)
     frac = (ref["num_contacts"][mixed] > 0).mean()
     assert 0.2 < frac < 0.9, frac
+
+
+def _device_collide(pkg, b, req, env=None, f32=False):
+    """Records of the device-resident entry point for batch b (library created under `env`)."""
+    import os
+    import torch
+    abi, wl = pkg.abi, pkg.workloads
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        lib = wl.make_library(pkg, b)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    dev = torch.device("cuda:0")
+    try:
+        s1 = torch.from_numpy(b.s1.astype(np.int32)).to(dev)
+        s2 = torch.from_numpy(b.s2.astype(np.int32)).to(dev)
+        n = len(b)
+        if f32:
+            p1, p2 = torch.from_numpy(b.pose1_f32).to(dev), torch.from_numpy(b.pose2_f32).to(dev)
+            out = torch.zeros(n * 11, dtype=torch.int32, device=dev)
+            lib.collide_device_f32(s1, s2, p1, p2, n, req, out)
+            torch.cuda.synchronize()
+            return out.cpu().numpy().view(abi.RESULT_F32_DTYPE).copy()
+        p1, p2 = torch.from_numpy(b.tf1).to(dev), torch.from_numpy(b.tf2).to(dev)
+        out = torch.zeros(n * 24, dtype=torch.int32, device=dev)
+        lib.collide_device(s1, s2, p1, p2, n, req, out)
+        torch.cuda.synchronize()
+        return out.cpu().numpy().view(abi.RESULT_DTYPE).copy()
+    finally:
+        lib.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sphere", "box", "capsule", "ellipsoid", "convex32"])
+def test_gpu_mesh_solid_long_walks(pkg, oracle, kind):
+    """Mesh x solid at the size of cfg4's models (5 000 triangles): walks of thousands of steps, which the one-query-per-lane
+    form (k_bvh_collide<SOLID>) cuts into tasks.  (1) Against the oracle: contacts, first-contact triangles, depths.
+    (2) The cut is invisible: tiny step budgets (every long query becomes a deep task tree, entries expanded on the way out,
+    EPA leaves overtaken by earlier contacts) and no budget at all give the same records.  (3) The 16-lane
+    group kernel agrees with both.  (4) The fp32 device path takes the same decisions away from the decision boundary."""
+    abi, bb = pkg.abi, pkg.bvh_builder
+    b = pkg.workloads.mesh_vs_solid(kind, n=6000, seed=3)
+    ML = bb.MeshLibrary(b.meshes)
+    req = abi.default_collision_request()
+    ref, _ = oracle.mixed_collide_batch(b.shapes, b.verts, ML, b.s1, b.s2, b.tf1, b.tf2, req, max_contacts=10 ** 5, n_threads=16)
+    got = _device_collide(pkg, b, req)
+    assert not ((got["status"] >> 30) & 1).any()
+    near = np.abs(ref["distance"]) < 1e-9
+    ok = (got["num_contacts"] == ref["num_contacts"]) | near
+    assert ok.all(), int((~ok).sum())
+    m = ~near
+    assert np.array_equal(got["b1"][m], ref["b1"][m]) and np.array_equal(got["b2"][m], ref["b2"][m])
+    hit = m & (ref["num_contacts"] > 0)
+    assert 0.1 < hit.mean() < 0.5
+    assert np.abs(got["distance"][hit] - ref["distance"][hit]).max() < 4e-6
+    free = m & (ref["num_contacts"] == 0) & (np.abs(ref["distance"]) < 1e300)
+    if kind in ("box", "ellipsoid", "convex32"):  # (solids of revolution: the fitted OBB's orientation is rounding noise)
+        assert np.abs(got["distance"][free] - ref["distance"][free]).max() < 4e-6
+        for f in ("p1", "p2", "normal"):
+            assert np.array_equal(np.isnan(got[f][free]), np.isnan(ref[f][free])), f
+    else:
+        assert (got["distance"][free] > 0).all()
+    tiny = _device_collide(pkg, b, req, env=dict(HFCL_SHAPE_BUDGET0="8", HFCL_SHAPE_BUDGET="8", HFCL_SHAPE_LEAF_COST="8"))
+    whole = _device_collide(pkg, b, req, env=dict(HFCL_SHAPE_LEVELS="1"))
+    for other in (tiny, whole):  # (two inlined copies of the box test may contract their FMAs differently: last-bit room)
+        assert np.array_equal(other["num_contacts"], got["num_contacts"]) and np.array_equal(other["status"], got["status"])
+        assert np.array_equal(other["b1"], got["b1"]) and np.array_equal(other["b2"], got["b2"])
+        for f in ("distance", "p1", "p2", "normal"):
+            assert _same(other[f], got[f], 1e-12), f
+    group = _device_collide(pkg, b, req, env=dict(HFCL_BVH_SHAPE_LANE="0"))
+    assert np.array_equal(group["num_contacts"][m], got["num_contacts"][m])
+    assert np.array_equal(group["b1"], got["b1"]) and np.array_equal(group["b2"], got["b2"])
+    fin = np.abs(got["distance"]) < 1e300
+    assert np.array_equal(fin, np.abs(group["distance"]) < 1e300)
+    cmp = fin if kind in ("box", "ellipsoid", "convex32") else fin & (got["num_contacts"] > 0)  # (round solids: see above)
+    assert np.abs(group["distance"][cmp] - got["distance"][cmp]).max() < 4e-6
+    g32 = _device_collide(pkg, b, req, f32=True)
+    clear = np.abs(ref["distance"]) > 1e-3
+    c32 = (g32["status"] >> 7) & 1
+    assert np.array_equal(c32[clear] != 0, ref["num_contacts"][clear] > 0)
+    assert np.abs(g32["distance"][hit & clear] - ref["distance"][hit & clear]).max() < 2e-4
 
 
 def test_oracle_mesh_shape_distance_equals_brute_force(pkg, oracle):
