@@ -60,13 +60,15 @@ BYTES_PER_QUERY = {
     "cfg3u": 8 + 2 * 28 + 44 + 2 * 32 * 12,  # cfg3 with one hull pair per query: + 2 x 32 fp32 vertices = 876 B
     "cfg2f": 8 + 2 * 28 + 44,  # cfg2's pairs through the fp32 device path (7-float poses, 44-B records)
     "cfg4d": 8 + 2 * 96 + 96,  # cfg4's distance() variant: ids + poses + record (the visited nodes are not counted: no oracle statistic)
+    "cfg4s": 8 + 2 * 96 + 96,  # mesh x solid collide(): ids + poses + record (visited nodes not counted)
 }
 CFG4_BYTES_PER_BV_TEST = 2 * 128
 CFG4_BYTES_PER_LEAF_TEST = 2 * (3 * 24 + 12)
-DEFAULT_PAIRS = {"cfg4": 100_000, "cfg4d": 100_000, "cfg5": 1_250_000, "cfg1": 4_000_000}
+DEFAULT_PAIRS = {"cfg4": 100_000, "cfg4d": 100_000, "cfg4s": 100_000, "cfg5": 1_250_000, "cfg1": 4_000_000}
 BASELINE_CONFIG = {"cfg3": "configs[2]", "cfg2": "configs[1]", "cfg4": "configs[3]", "cfg5": "configs[4]",
                    "cfg1": "configs[0] (shape pair; GPU batch size)", "cfg3u": "configs[2], one hull pair per query",
-                   "cfg2f": "configs[1] through the fp32 device path", "cfg4d": "configs[3], distance() instead of collide()"}
+                   "cfg2f": "configs[1] through the fp32 device path", "cfg4d": "configs[3], distance() instead of collide()",
+                   "cfg4s": "configs[3]'s models against convex solids (SURVEY.md 8 f3: BVH x primitive traversal), six solid kinds mixed"}
 
 # VALU issue peak, MEASURED on the box (tools/valu_peak.hip, profiles/r02_a_valu_issue_peak.txt): the select / compare /
 # fma mix these kernels are made of tops out at 1.00e12 wave64 instructions per second chip-wide with 8 waves per SIMD
@@ -80,7 +82,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=None, choices=["cfg3", "cfg2", "cfg4", "cfg5", "cfg1", "cfg3u", "cfg2f", "cfg4d"],
+    ap.add_argument("--workload", default=None, choices=["cfg3", "cfg2", "cfg4", "cfg5", "cfg1", "cfg3u", "cfg2f", "cfg4d", "cfg4s"],
                     help="run this workload alone as the headline (default: cfg3 + the secondary list)")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default 1M; cfg4: 100k; cfg5: 1.25M = 10M / 8); "
                     "with --scaling strong: pairs of the whole job")
@@ -213,6 +215,8 @@ def make_batch(ctx, workload, n, strong):
         dtype = "f64"
     elif workload == "cfg4d":
         batch, dtype = wl.cfg4_mesh_mesh_distance(n=n, seed=seed), "f64"
+    elif workload == "cfg4s":
+        batch, dtype = wl.mesh_vs_solid("mixed", n=n, seed=seed), "f64"
     else:
         batch, dtype = wl.cfg4_mesh_mesh(n=n, seed=seed), "f64"
     if strong:
@@ -243,6 +247,11 @@ def cpu_baseline(ctx, workload, batch, req, sample, budget_s, all_cores=True):
 
         def run_cpu(lo, hi, threads):
             ob.bvh_distance_batch(MLc, sb.s1[lo:hi], sb.s2[lo:hi], tf1[lo:hi], tf2[lo:hi], n_threads=threads)
+    elif workload == "cfg4s":
+        MLc = ctx.pkg.bvh_builder.MeshLibrary(batch.meshes)
+
+        def run_cpu(lo, hi, threads):
+            ob.mixed_collide_batch(sb.shapes, sb.verts, MLc, sb.s1[lo:hi], sb.s2[lo:hi], tf1[lo:hi], tf2[lo:hi], req, n_threads=threads)
     else:
         fn = ob.distance_batch if sb.kind == "distance" else ob.collide_batch
 
@@ -551,6 +560,7 @@ def main():
         if ctx.world == 1:  # what the drain phases of the headline's kernels cost: the same steps, two batches in flight
             plan += [("cfg3", 0, False, dict(two_streams=True)), ("cfg4", 0, False, dict(two_streams=True))]
             plan.append(("cfg4d", 0, False, {}))  # configs[3]'s distance() variant: ~3 400 RSS tests + 215 triangle pairs per query
+            plan.append(("cfg4s", 0, False, {}))  # configs[3]'s models against convex solids
         if ctx.world > 1:  # the same list with the 24-B exchange format, and the headline without any exchange
             plan += [("cfg5", 10_000_000, True, dict(gather="compact")), ("cfg3", 0, False, dict(gather="none"))]
         for wl_name, pairs, st, kw in plan:

@@ -663,6 +663,14 @@ HFCL_HD bool obb_disjoint_q(const ObbQuery<T>& o, const DNode<T>& b1, T security
   return obb_disjoint_lb(R, Tv, b1.extent, o.ext, security_margin, break_distance2, sq);
 }
 
+// distance(): what rss_lower_bound reads of the solid's fitted OBBRSS (computeBV<OBBRSS, S>, world frame), per query
+template <typename T>
+struct RssQuery {
+  M3<T> axes;
+  V3<T> Tr;
+  T l0, l1, r;
+};
+
 template <typename T>
 struct ShapeDeferItem {  // a leaf whose GJK ended inside the solid (seed.pair = the query)
   EpaSeed<T> seed;

@@ -660,7 +660,9 @@ static int ensure_bvh_split(hfcl_lib* lib, size_t n) {
   hipFree(lib->d_bvh_tasks); hipFree(lib->d_bvh_sums); hipFree(lib->d_bvh_susp);
   lib->d_bvh_tasks = nullptr; lib->d_bvh_sums = nullptr; lib->d_bvh_susp = nullptr;
   lib->bvh_split_n = 0;
-  const size_t nq = n + n / 8 + 1024, cap = 16 * nq + 65536;
+  size_t per_query = 16;
+  if (const char* e = getenv("HFCL_BVH_TASK_SLOTS")) per_query = std::max<size_t>(1, strtoull(e, nullptr, 10));  // test / tuning knob
+  const size_t nq = n + n / 8 + 1024, cap = per_query * nq + 65536;
   HIP_TRY(hipMalloc(&lib->d_bvh_tasks, cap * sizeof(BvhTask)));
   HIP_TRY(hipMalloc(&lib->d_bvh_sums, (nq + cap) * sizeof(BvhSum<double>)));
   HIP_TRY(hipMalloc(&lib->d_bvh_susp, nq * sizeof(uint32_t)));
@@ -1084,14 +1086,16 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     // otherwise
     const bool shape_fast = q.mode == 1 && may(B_BVHSHAPE) && lib->bvh_shape_lane && size_t(lib->bvh_max_depth) + 1 <= size_t(BVH_STACK) &&
                             mesh_shape_lane_request(q, lib->bvh_params.num_max_contacts);
-    if (shape_fast) {
+    // distance(): a leaf that needs EPA always ends the walk; models deeper than the lanes' stacks take the group kernel
+    const bool shape_fast_d = q.mode != 1 && may(B_BVHSHAPE) && lib->bvh_shape_lane && size_t(lib->bvh_max_depth) + 1 <= size_t(BVHD_STACK);
+    if (shape_fast || shape_fast_d) {
       if (lib->ws_capacity > lib->shape_defer_capacity) {
         hipFree(lib->d_shape_defer);
         hipFree(lib->d_shape_oq);
         lib->d_shape_defer = lib->d_shape_oq = nullptr;
         lib->shape_defer_capacity = 0;
         HIP_TRY(hipMalloc(&lib->d_shape_defer, lib->ws_capacity * sizeof(ShapeDeferItem<double>)));
-        HIP_TRY(hipMalloc(&lib->d_shape_oq, lib->ws_capacity * sizeof(ObbQuery<double>)));
+        HIP_TRY(hipMalloc(&lib->d_shape_oq, lib->ws_capacity * std::max(sizeof(ObbQuery<double>), sizeof(RssQuery<double>))));
         lib->shape_defer_capacity = lib->ws_capacity;
       }
       wk.shape_defer = lib->d_shape_defer;
@@ -1119,7 +1123,10 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       tend();
     } else {
       tbeg("k_bvh_shape_distance");
-      launch_bvh_shape_distance<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q);
+      if (shape_fast_d)
+        launch_bvh_shape_distance_fast<T>(blocks_for(n, BVHD_BLOCK), blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q);
+      else
+        launch_bvh_shape_distance<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q);
       tend();
       tbeg("k_bvh_distance");
       launch_bvh_distance<T>(blocks_for(n, BVHD_BLOCK), st, wk, lv, bv, io, q, spill);

@@ -150,6 +150,8 @@ struct SolidLeafIn {
   ShapeDeferItem<T>* defer;
   uint32_t* defer_count;
   uint32_t pair, solid_id, prim, parent, order;
+  T bound;            // distance(): min_distance before this leaf, and the triangle it belongs to
+  int32_t prev_prim;
 };
 template <typename T, class PS>
 __device__ __noinline__ bool solid_leaf_call(const SolidLeafIn<T> in, const QParams<T>* qp, const PS ps, const V3<T> guess_in, SolidLeafOut<T>* out) {
@@ -171,6 +173,8 @@ __device__ __noinline__ bool solid_leaf_call(const SolidLeafIn<T> in, const QPar
     item.prim = in.prim;
     item.parent = in.parent;
     item.order = in.order;
+    item.bound = in.bound;
+    item.prev_prim = in.prev_prim;
     in.defer[atomicAdd(in.defer_count, 1u)] = item;
   }
   out->guess = guess;
@@ -670,7 +674,8 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
 #if HFCL_SOLID_LEAF_OUTLINE
         {
           SolidLeafIn<T> in{mv, t3, lib.shapes, lib.verts, swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2,
-                            reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer), &wk.counts[CTR_SHAPE_DEFER], pair, solid_id, lb1, my_parent, my_order};
+                            reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer), &wk.counts[CTR_SHAPE_DEFER], pair, solid_id, lb1, my_parent, my_order,
+                            T(0), -1};
           SolidLeafOut<T> lo;
           to_epa = solid_leaf_call<T>(in, &q, leaf_ps, guess, &lo);
           distance = lo.distance;
@@ -944,6 +949,35 @@ __global__ void __launch_bounds__(64) k_bvh_shape(Work wk, LibView<T> lib, BvhVi
 // the walk and its fold-back: a leaf whose unit was not overtaken by an earlier contact (bvh_moot) is the query's contact;
 // its depth is compared with the bound the record holds (updateDistanceLowerBoundFromLeaf) and patched in.
 // ---------------------------------------------------------------------------------------
+// distance(): the solid's OBBRSS itself (rss_lower_bound takes the mesh pose as an argument)
+template <typename T>
+__global__ void __launch_bounds__(256) k_shape_obbrss(Work wk, LibView<T> lib, IO<T> io) {
+  const uint32_t cnt = wk.counts[B_BVHSHAPE];
+  RssQuery<T>* const table = reinterpret_cast<RssQuery<T>*>(wk.shape_oq);
+  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
+    const uint32_t pair = wk.lists[size_t(B_BVHSHAPE) * wk.n + it];
+    const uint32_t id1 = wk.shape1[pair], id2 = wk.shape2[pair];
+    const bool swapped = lib.kinds[id1] != uint8_t(K_BVH);
+    const DShape<T> shape = lib.shapes[swapped ? id1 : id2];
+    const Pose<T> tfs = load_pose(swapped ? io.tf1 : io.tf2, pair);
+    DNode<T> bv2;
+    DRss<T> rss2;
+    RssQuery<T> rq;
+    if (shape_obbrss(shape, lib.verts, tfs, bv2, &rss2)) {
+      rq.axes = bv2.axes;
+      rq.Tr = rss2.Tr;
+      rq.l0 = rss2.l0;
+      rq.l1 = rss2.l1;
+      rq.r = rss2.r;
+    } else {
+      const T nanv = Lim<T>::nan();
+      rq.axes.r0 = rq.axes.r1 = rq.axes.r2 = rq.Tr = mk<T>(nanv, nanv, nanv);
+      rq.l0 = rq.l1 = rq.r = nanv;
+    }
+    table[pair] = rq;
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_shape_obb(Work wk, LibView<T> lib, IO<T> io) {
   const uint32_t cnt = wk.counts[B_BVHSHAPE];
@@ -967,7 +1001,7 @@ __global__ void __launch_bounds__(256) k_shape_obb(Work wk, LibView<T> lib, IO<T
 }
 
 template <typename T>
-__global__ void __launch_bounds__(64) k_bvh_shape_finish(Work wk, LibView<T> lib, IO<T> io, QParams<T> q, BvhParams bp, BvhSplit split) {
+__global__ void __launch_bounds__(64) k_bvh_shape_finish(Work wk, LibView<T> lib, IO<T> io, QParams<T> q, BvhParams bp, BvhSplit split, int distance_mode) {
   constexpr int G = 64 / BS_W;
   __shared__ EpaScratch<T, EPA_MAX_ITER> scratch[G];
   const uint32_t cnt = wk.counts[CTR_SHAPE_DEFER];
@@ -987,7 +1021,18 @@ __global__ void __launch_bounds__(64) k_bvh_shape_finish(Work wk, LibView<T> lib
     const Pose<T> tfs = load_pose(swapped ? io.tf1 : io.tf2, pair);
     V3<T> p1, p2, n, guess;
     const T distance = mesh_shape_leaf_finish<T, LaneGroup<BS_W>>(item, tfs, solid, swept_radius(solid.s), q, &scratch[grp], p1, p2, n, guess);
-    if (lig == 0) {
+    if (lig == 0 && distance_mode) {
+      // distance(): the walk ended at this leaf (every bound left on the stack is >= 0); DistanceResult::update
+      T mind = item.bound;
+      int prim = item.prev_prim;
+      if (mind > distance) {
+        mind = distance;
+        prim = int(item.prim);
+        store_witness(io, pair, swapped ? p2 : p1, swapped ? p1 : p2, swapped ? -n : n);
+      }
+      store_bvh_record_head(io, pair, mind, mind <= T(0) ? 0x80000000u : 0u, prim, -1, false);
+      write_guess<T>(io, pair, guess, 0, 0);
+    } else if (lig == 0) {
       // the record holds the walk's result without this leaf: recorded distance = bound + margin where a leaf set it (the
       // same subtraction as updateDistanceLowerBoundFromLeaf's), a positive OBB bound otherwise (always above a penetration)
       auto* r = &io.out[pair];
@@ -1082,6 +1127,182 @@ __global__ void __launch_bounds__(64) k_bvh_shape_distance(Work wk, LibView<T> l
       }
     }
     LaneGroup<BS_W>::sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_bvh_shape_distance_lane: distance() between a mesh and a solid with ONE QUERY PER LANE (the streaming scheme of
+// k_bvh_distance; MeshShapeDistanceTraversalNodeOBBRSS + distanceRecurse as in hfcl_bvh_shape.hpp: mesh_shape_distance).
+// The solid's OBBRSS comes from k_shape_obbrss's table (re-read at every step: 15 numbers that do not wait for the node
+// gather), the leaf is the SOLID collide form's (solid_leaf_call), the witness of the minimum lives in the record.  A leaf
+// that needs EPA ends the walk -- its distance is <= 0 and every bound left on the stack >= 0 -- and is finished by
+// k_bvh_shape_finish.  Bounds travel as in k_bvh_distance (4 bytes, rounded down, exact re-evaluation in the band).
+// ---------------------------------------------------------------------------------------
+#ifndef HFCL_BSD_PARK_MIN
+#define HFCL_BSD_PARK_MIN 16
+#endif
+template <typename T>
+__global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8)))
+k_bvh_shape_distance_lane(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q) {
+  constexpr int STACK = BVHD_STACK;
+  typedef typename std::conditional<sizeof(T) == 8, uint32_t, float>::type BD;
+  __shared__ uint32_t stack_e[STACK][BVHD_BLOCK];
+  __shared__ BD stack_d[STACK][BVHD_BLOCK];
+  __shared__ T w0_slab[W0Lds<T, BVHD_BLOCK>::WORDS];
+  const W0Lds<T, BVHD_BLOCK> leaf_ps{w0_slab + threadIdx.x};
+  auto bound_down = [](T d) -> BD {
+    if constexpr (sizeof(T) == 8)
+      return uint32_t(__double2hiint(d));
+    else
+      return d;
+  };
+  auto bound_value = [](BD b) -> T {
+    if constexpr (sizeof(T) == 8)
+      return __hiloint2double(int(b), 0);
+    else
+      return b;
+  };
+  const uint32_t cnt = wk.counts[B_BVHSHAPE];
+  uint32_t* const ticket = &wk.counts[CTR_SHAPE_TICKET];
+  const RssQuery<T>* const table = reinterpret_cast<const RssQuery<T>*>(wk.shape_oq);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const T nanv = Lim<T>::nan();
+  bool live = false, pending = false, exhausted = false, swapped = false, overflow = false, unsupported = false, deferred = false;
+  bool have_leaf = false;
+  uint32_t pair = 0, solid_id = 0, leaf_prim = 0;
+  DMesh m1 = {0, 0, 0, 0};
+  Pose<T> tfm;
+  tfm.R.r0 = tfm.R.r1 = tfm.R.r2 = tfm.t = mk<T>(T(0), T(0), T(0));
+  T mind = Lim<T>::max();
+  int fb1 = -1, sp = 0;
+  V3<T> guess = mk<T>(T(1), T(0), T(0));
+  // lower bound between the solid's volume and mesh node b (distance(tf1.R, tf1.T, model2_bv, model1.bv(b)))
+  auto bound_of = [&](uint32_t b) -> T {
+    const RssQuery<T> rq = table[pair];
+    DNode<T> n2;
+    n2.axes = rq.axes;
+    DRss<T> r2;
+    r2.Tr = rq.Tr;
+    r2.l0 = rq.l0;
+    r2.l1 = rq.l1;
+    r2.r = rq.r;
+    return rss_lower_bound(tfm.R, tfm.t, n2, r2, bv.nodes[m1.node_off + b], bv.rss[m1.node_off + b]);
+  };
+  auto leaf = [&](uint32_t prim) {
+    SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + prim), lib.shapes, lib.verts,
+                      swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer),
+                      &wk.counts[CTR_SHAPE_DEFER], pair, solid_id, prim, 0xFFFFFFFFu, 0u, mind, fb1};
+    SolidLeafOut<T> lo;
+    if (solid_leaf_call<T>(in, &q, leaf_ps, guess, &lo)) {
+      deferred = true;  // k_bvh_shape_finish writes the record
+      sp = 0;
+      return;
+    }
+    guess = lo.guess;
+    if (mind > lo.distance) {  // DistanceResult::update
+      mind = lo.distance;
+      fb1 = int(prim);
+      store_witness(io, pair, swapped ? lo.p2 : lo.p1, swapped ? lo.p1 : lo.p2, swapped ? -lo.n : lo.n);
+    }
+  };
+  for (;;) {
+    if (live && sp == 0 && !have_leaf) {
+      live = false;
+      pending = !deferred;
+    }
+    const uint64_t live_mask = __ballot(live);
+    const int n_live = __popcll(live_mask);
+    if (exhausted ? n_live == 0 : 64 - n_live >= BVH_REFILL_MIN) {
+      if (pending) {
+        if (unsupported) {
+          store_unsupported(io, pair);
+        } else {
+          // b1 = the triangle, b2 = NONE whatever the operand order (distance.cpp:84-88 swaps o1 / o2 only)
+          store_bvh_record_head(io, pair, mind, mind <= T(0) ? 0x80000000u : 0u, fb1, -1, overflow);
+          write_guess<T>(io, pair, guess, 0, 0);
+        }
+        pending = false;
+      }
+      if (exhausted) break;
+      const int n_need = 64 - n_live;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ticket, uint32_t(n_need));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (!live) {
+        const uint32_t it = base + uint32_t(__popcll(~live_mask & ((uint64_t(1) << lane) - 1)));
+        if (it < cnt) {
+          pair = wk.lists[size_t(B_BVHSHAPE) * wk.n + it];
+          const uint32_t id1 = wk.shape1[pair], id2 = wk.shape2[pair];
+          swapped = lib.kinds[id1] != uint8_t(K_BVH);  // distance.cpp:74-88
+          solid_id = swapped ? id1 : id2;
+          m1 = bv.meshes[lib.shapes[swapped ? id2 : id1].bvh_index];
+          tfm = load_pose(swapped ? io.tf2 : io.tf1, pair);
+          mind = Lim<T>::max();
+          fb1 = -1;
+          overflow = deferred = have_leaf = false;
+          guess = initial_guess<T>(io, q, pair);
+          const T probe = table[pair].r;
+          unsupported = !(probe == probe);
+          sp = 0;
+          if (unsupported) {
+            pending = true;
+          } else {
+            const V3<T> nan3 = mk<T>(nanv, nanv, nanv);
+            store_witness(io, pair, nan3, nan3, nan3);
+            live = true;
+            sp = 1;  // (leaf() of a deferred preprocess() sets it back to 0)
+            stack_e[0][tid] = 0u;
+            stack_d[0][tid] = bound_down(T(-1));
+            leaf(0u);  // preprocess(): triangle 0
+          }
+        }
+      }
+      if (base + uint32_t(n_need) >= cnt) exhausted = true;
+      continue;
+    }
+    // A triangle against the solid is a GJK run: ten times a BV step.  A lane that pops one waits until HFCL_BSD_PARK_MIN
+    // lanes do (or nobody can walk) and the wave runs the leaves together (k_bvh_distance, whose triangle pairs cost what a
+    // BV step costs, evaluates them where they are popped).
+    for (;;) {
+      const bool run = live && sp > 0 && !have_leaf;
+      const int n_run = __popcll(__ballot(run)), n_wait = __popcll(__ballot(have_leaf));
+      if (n_run == 0 || n_wait >= HFCL_BSD_PARK_MIN || (!exhausted && 64 - n_run - n_wait >= BVH_REFILL_MIN)) break;
+      if (!run) continue;
+      --sp;
+      const uint32_t b = stack_e[sp][tid];
+      const BD dc = stack_d[sp][tid];
+      const T de = bound_value(dc);
+      if (de >= T(0) && de >= mind) continue;  // canStop(d)
+      if constexpr (sizeof(T) == 8) {
+        if (de >= T(0) && __hiloint2double(int(dc) + 1, 0) > mind) {  // the exact bound may reach the minimum: ask it
+          if (bound_of(b) >= mind) continue;
+        }
+      }
+      const int32_t fc = bv.nodes[m1.node_off + b].first_child;
+      if (fc < 0) {
+        have_leaf = true;
+        leaf_prim = uint32_t(-(fc + 1));
+        continue;
+      }
+      const uint32_t a1 = uint32_t(fc), c1 = a1 + 1;
+      const T d1 = bound_of(a1), d2 = bound_of(c1);
+      if (sp + 2 > STACK) {
+        overflow = true;
+        sp = 0;
+        continue;
+      }
+      const bool c_first = d2 < d1;  // the nearer child is visited first
+      stack_e[sp][tid] = c_first ? a1 : c1;
+      stack_d[sp][tid] = bound_down(c_first ? d1 : d2);
+      ++sp;
+      stack_e[sp][tid] = c_first ? c1 : a1;
+      stack_d[sp][tid] = bound_down(c_first ? d2 : d1);
+      ++sp;
+    }
+    if (have_leaf) {
+      have_leaf = false;
+      leaf(leaf_prim);
+    }
   }
 }
 
@@ -1379,6 +1600,17 @@ template <typename T>
 void launch_bvh_shape(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2) {
   hipLaunchKernelGGL((k_bvh_shape<T>), dim3(grid), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2);
 }
+// mesh x solid distance(), one query per lane
+template <typename T>
+void launch_bvh_shape_distance_fast(int grid, int grid_finish, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q) {
+  hipLaunchKernelGGL((k_shape_obbrss<T>), dim3(std::max(1, grid / 4)), dim3(256), 0, st, wk, lv, io);
+  hipLaunchKernelGGL((k_bvh_shape_distance_lane<T>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q);
+  BvhSplit none;
+  memset(&none, 0, sizeof(none));
+  BvhParams bp;
+  memset(&bp, 0, sizeof(bp));
+  hipLaunchKernelGGL((k_bvh_shape_finish<T>), dim3(grid_finish), dim3(64), 0, st, wk, lv, io, q, bp, none, 1);
+}
 // mesh x solid collide(), one query per lane: the solids' OBBs, the walk (split as `split` says), the EPA leaves
 template <typename T>
 void launch_bvh_shape_fast(int grid, int grid_finish, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill) {
@@ -1389,7 +1621,7 @@ void launch_bvh_shape_fast(int grid, int grid_finish, hipStream_t st, const Work
   if (!splitting) split.tasks = nullptr;
   launch_bvh_collide<T>(grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill, true);
   split.level = 0;
-  hipLaunchKernelGGL((k_bvh_shape_finish<T>), dim3(grid_finish), dim3(64), 0, st, wk, lv, io, q, bp, split);
+  hipLaunchKernelGGL((k_bvh_shape_finish<T>), dim3(grid_finish), dim3(64), 0, st, wk, lv, io, q, bp, split, 0);
 }
 template <typename T>
 void launch_bvh_shape_distance(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q) {
@@ -1404,6 +1636,7 @@ void launch_triangle(int grid, hipStream_t st, const Work& wk, const LibView<T>&
   template void launch_bvh_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, BvhSpill);                \
   template void launch_bvh_shape<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T);   \
   template void launch_bvh_shape_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&);          \
+  template void launch_bvh_shape_distance_fast<T>(int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&); \
   template void launch_bvh_shape_fast<T>(int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill); \
   template void launch_triangle<T>(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&);
 HFCL_INST(float)

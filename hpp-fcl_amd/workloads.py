@@ -383,37 +383,43 @@ def mesh_vs_shapes(n=20_000, seed=1, seg=14, ring=14, n_variants=3, nper=16, hal
     return b
 
 
+SOLID_KINDS = ("box", "sphere", "capsule", "cylinder", "cone", "ellipsoid", "convex32")
+
+
 def mesh_vs_solid(kind, n=100_000, seed=1, seg=50, nper=64, half_width=1.6):
-    """(mesh, solid) collide() / distance() queries against ONE solid kind, cfg4-size models (seg = ring = 50: 5 000
-    triangles): SURVEY.md 8(f3), the workload of tools/mesh_solid_bench.py and of bench.py's `mesh_solid` line.  The steps
-    per query have a heavy tail (median 1: the boxes at the roots are disjoint; mean ~60; maximum in the thousands)."""
+    """(mesh, solid) collide() / distance() queries, cfg4-size models (seg = ring = 50: 5 000 triangles): SURVEY.md 8(f3),
+    the workload of tools/mesh_solid_bench.py (one solid kind) and of bench.py's `cfg4s` line (kind = "mixed": box, sphere,
+    capsule, cylinder, ellipsoid, convex32 in equal parts).  The steps per query have a heavy tail (median 1: the boxes at
+    the roots are disjoint; mean ~60; maximum in the thousands with hundreds of leaf tests)."""
     rng = _rng(seed, 77)
     meshes = mesh_variants(8, seg, seg)
     lib = geometry.ShapeLibrary()
     for k, m in enumerate(meshes):
         lib.add_bvh(k, len(m.vertices))
     n0 = len(lib)
-    for _ in range(nper):
-        if kind == "box":
-            lib.add_box(*map(float, rng.uniform(0.2, 0.9, 3)))
-        elif kind == "sphere":
-            lib.add_sphere(float(rng.uniform(0.1, 0.6)))
-        elif kind == "capsule":
-            lib.add_capsule(float(rng.uniform(0.1, 0.4)), float(rng.uniform(0.2, 1.0)))
-        elif kind == "cylinder":
-            lib.add_cylinder(float(rng.uniform(0.1, 0.5)), float(rng.uniform(0.2, 1.0)))
-        elif kind == "cone":
-            lib.add_cone(float(rng.uniform(0.1, 0.5)), float(rng.uniform(0.2, 1.0)))
-        elif kind == "ellipsoid":
-            lib.add_ellipsoid(*map(float, rng.uniform(0.1, 0.7, 3)))
-        elif kind == "convex32":
-            lib.add_convex(fibonacci_sphere(32) * rng.uniform(0.1, 0.7, 3))
-        else:
-            raise ValueError(kind)
+    kinds = ("box", "sphere", "capsule", "cylinder", "ellipsoid", "convex32") if kind == "mixed" else tuple(kind.split(","))
+    for kd in kinds:
+        if kd not in SOLID_KINDS:
+            raise ValueError(kd)
+        for _ in range(nper):
+            if kd == "box":
+                lib.add_box(*map(float, rng.uniform(0.2, 0.9, 3)))
+            elif kd == "sphere":
+                lib.add_sphere(float(rng.uniform(0.1, 0.6)))
+            elif kd == "capsule":
+                lib.add_capsule(float(rng.uniform(0.1, 0.4)), float(rng.uniform(0.2, 1.0)))
+            elif kd == "cylinder":
+                lib.add_cylinder(float(rng.uniform(0.1, 0.5)), float(rng.uniform(0.2, 1.0)))
+            elif kd == "cone":
+                lib.add_cone(float(rng.uniform(0.1, 0.5)), float(rng.uniform(0.2, 1.0)))
+            elif kd == "ellipsoid":
+                lib.add_ellipsoid(*map(float, rng.uniform(0.1, 0.7, 3)))
+            else:
+                lib.add_convex(fibonacci_sphere(32) * rng.uniform(0.1, 0.7, 3))
     s1 = rng.integers(0, 8, n)
-    s2 = rng.integers(n0, n0 + nper, n)
+    s2 = rng.integers(n0, n0 + nper * len(kinds), n)
     q1, T1, q2, T2 = _poses(rng, n, half_width)
-    b = Batch("mesh_x_" + kind, lib, s1, s2, q1, T1, q2, T2, "collide")
+    b = Batch("mesh_x_" + kind.replace(",", "_"), lib, s1, s2, q1, T1, q2, T2, "collide")
     b.meshes = meshes
     return b
 

@@ -404,6 +404,47 @@ def test_gpu_mesh_vs_shapes_distance(pkg, oracle):
     assert (got["b2"][mixed] == -1).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sphere", "box", "ellipsoid", "convex32"])
+def test_gpu_mesh_solid_distance_long_walks(pkg, oracle, kind):
+    """distance() between cfg4-size models and a solid: the one-query-per-lane form (k_bvh_shape_distance_lane, EPA leaves
+    finished by k_bvh_shape_finish) against the oracle and against the 16-lane group kernel."""
+    import os
+    abi, wl, bb = pkg.abi, pkg.workloads, pkg.bvh_builder
+    b = wl.mesh_vs_solid(kind, n=3000, seed=5, half_width=2.0)
+    ML = bb.MeshLibrary(b.meshes)
+    req = abi.default_distance_request()
+    ref = oracle.mixed_distance_batch(b.shapes, b.verts, ML, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=16)
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            lib = wl.make_library(pkg, b)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        try:
+            return lib.distance(b.s1, b.s2, b.tf1, b.tf2, req)
+        finally:
+            lib.close()
+
+    got, group = run({}), run(dict(HFCL_BVH_SHAPE_LANE="0"))
+    for r in (got, group):
+        assert not ((r["status"] >> 30) & 1).any()
+        sep = ref["distance"] > 1e-6
+        assert sep.sum() > 1000
+        assert np.abs(r["distance"][sep] - ref["distance"][sep]).max() < 1e-6
+        pen = ref["distance"] <= 0
+        assert pen.sum() > 200 and (r["distance"][pen] <= 1e-9).all()  # which penetrating triangle is met first may differ
+        assert (r["b2"] == -1).all()
+        sg, sr = r["p2"] - r["p1"], ref["p2"] - ref["p1"]
+        err = np.abs(sg[sep] - sr[sep]).max(axis=1)
+        assert err.max() < 2e-3 and np.quantile(err, 0.99) < 1e-6
+    same = (got["b1"] == group["b1"]) | (ref["distance"] <= 1e-6)
+    assert same.mean() > 0.93  # (equidistant triangles at a shared vertex or edge)
+
+
 def test_mesh_vs_flats_headers_match_oracle(pkg, oracle, hostsim):
     """Meshes against Plane / Halfspace: the flats' BVs are unbounded (geometric_shapes_utility.cpp:545-581,
     803-850), so the reference tests every triangle; contacts = triangles reaching into the halfspace."""
