@@ -257,6 +257,38 @@ def _device_collide(pkg, b, req, env=None, f32=False):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cached", [False, True])
+def test_gpu_mesh_solid_guesses(pkg, oracle, cached):
+    """The solver's cached guess through the one-query-per-lane form: a request that reads the guess back (and one whose
+    leaves hand it on: CachedGuess) keeps its walks in one piece; decisions and first-contact triangles are the oracle's,
+    the returned guess is the oracle's where the walk ended on a leaf result that round-off does not move (a contact)."""
+    abi, bb = pkg.abi, pkg.bvh_builder
+    b = pkg.workloads.mesh_vs_solid("box,capsule,convex32", n=4000, seed=11)
+    ML = bb.MeshLibrary(b.meshes)
+    req = abi.default_collision_request()
+    if cached:
+        req.q.gjk_initial_guess = abi.CachedGuess
+        req.q.cached_gjk_guess[:] = [0.3, -0.2, 0.9]
+    ref, _, gref = oracle.mixed_collide_batch(b.shapes, b.verts, ML, b.s1, b.s2, b.tf1, b.tf2, req, max_contacts=10 ** 5,
+                                              n_threads=16, want_guess=True)
+    lib = pkg.workloads.make_library(pkg, b)
+    try:
+        got, ggot = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req, want_guess=True)
+    finally:
+        lib.close()
+    near = np.abs(ref["distance"]) < 1e-9
+    assert ((got["num_contacts"] == ref["num_contacts"]) | near).all()
+    m = ~near
+    assert np.array_equal(got["b1"][m], ref["b1"][m]) and np.array_equal(got["b2"][m], ref["b2"][m])
+    hit = m & (ref["num_contacts"] > 0)
+    assert hit.sum() > 300
+    assert np.isfinite(ggot["gjk_guess"]).all()
+    # (the guess after EPA is -depth * normal: as well conditioned as the contact itself)
+    err = np.abs(ggot["gjk_guess"][hit] - gref["gjk_guess"][hit]).max(axis=1)
+    assert np.quantile(err, 0.99) < 1e-5, float(np.quantile(err, 0.99))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["sphere", "box", "capsule", "ellipsoid", "convex32"])
 def test_gpu_mesh_solid_long_walks(pkg, oracle, kind):
     """Mesh x solid at the size of cfg4's models (5 000 triangles): walks of thousands of steps, which the one-query-per-lane
