@@ -96,6 +96,7 @@ struct hfcl_lib {
   // equivalents; a GJK leaf counts shape_leaf_cost): the queries themselves / their tasks.  The steps per query have a heavy
   // tail whatever the batch size (median 1, mean ~60, maximum > 3000 steps with > 1000 leaves), so the walk is always split.
   uint32_t shape_budget0 = 128, shape_budget = 96, shape_leaf_cost = 32, shape_levels = BVH_MAX_LEVELS;
+  bool shape_coop = true;  // HFCL_SHAPE_COOP=0: suspended queries go through task levels instead of k_bvh_shape_coop
   // host-call staging: PIPE_SLOTS device buffer sets of `st_capacity` pairs each (a chunk of a host batch), three streams
   // (H2D | kernels | D2H) and per-slot events / pinned counter blocks (host_batch)
   static constexpr int PIPE_SLOTS = 6;  // (three left the feeder waiting for records to leave: profiles/r03_c)
@@ -411,6 +412,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_PIPE_CHUNK")) lib->pipe_chunk = strtoull(v, nullptr, 10);
   if (const char* v = getenv("HFCL_BVH_FILTER")) lib->bvh_filter = atoi(v) != 0;
   if (const char* v = getenv("HFCL_BVH_SHAPE_LANE")) lib->bvh_shape_lane = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_SHAPE_COOP")) lib->shape_coop = atoi(v) != 0;
   if (const char* v = getenv("HFCL_SHAPE_BUDGET0")) lib->shape_budget0 = uint32_t(atoi(v));
   if (const char* v = getenv("HFCL_SHAPE_BUDGET")) lib->shape_budget = uint32_t(atoi(v));
   if (const char* v = getenv("HFCL_SHAPE_LEAF_COST")) lib->shape_leaf_cost = uint32_t(std::max(1, atoi(v)));
@@ -1075,6 +1077,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         split.n_levels = BVH_MAX_LEVELS;
       }
       if (solid) {
+        split.coop = lib->shape_coop ? 1u : 0u;
         split.budget0 = lib->shape_budget0;
         split.budget = lib->shape_budget;
         split.n_levels = lib->shape_levels;
@@ -1109,7 +1112,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         BvhSplit split;
         rc = make_split(split, n >= 256 && q.guess_mode != HFCL_GUESS_CACHED && !io.gout, true);
         if (rc) return rc;
-        launch_bvh_shape_fast<T>(blocks_for(n, BVH_BLOCK), blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, lib->bvh_params,
+        launch_bvh_shape_fast<T>(blocks_for(n, BVH_BLOCK), blocks_for(n / 8 + 1, 64 / BS_W), int(std::min<size_t>(n / 4 + 1, size_t(lib->n_cus) * 8)), st, wk, lv, bv, io, q, lib->bvh_params,
                                  T(lib->break_distance * lib->break_distance), split, spill);
       } else {
         launch_bvh_shape<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance));

@@ -154,7 +154,8 @@ struct SolidLeafIn {
   int32_t prev_prim;
 };
 template <typename T, class PS>
-__device__ __noinline__ bool solid_leaf_call(const SolidLeafIn<T> in, const QParams<T>* qp, const PS ps, const V3<T> guess_in, SolidLeafOut<T>* out) {
+__device__ __noinline__ bool solid_leaf_call(const SolidLeafIn<T> in, const QParams<T>* qp, const PS ps, const V3<T> guess_in, SolidLeafOut<T>* out,
+                                             uint32_t* slot_out = nullptr) {
   const QParams<T> q = *qp;
   auto vtx = [&](uint32_t i) { return mk<T>(in.mesh_verts[3 * size_t(i)], in.mesh_verts[3 * size_t(i) + 1], in.mesh_verts[3 * size_t(i) + 2]); };
   const V3<T> ta = vtx(in.tri[0]), tb = vtx(in.tri[1]), tc = vtx(in.tri[2]);
@@ -168,14 +169,16 @@ __device__ __noinline__ bool solid_leaf_call(const SolidLeafIn<T> in, const QPar
   ShapeDeferItem<T> item;
   const bool to_epa = mesh_shape_leaf_lane(ta, tb, tc, sMt, tfm_of, tfs_of, solid.s, solid, swept_radius(solid.s), q, guess, ps, out->distance,
                                            out->p1, out->p2, out->n, item);
-  if (to_epa) {
+  if (to_epa && in.defer) {  // (defer == nullptr: the caller only asks whether the leaf needs EPA)
     item.seed.pair = in.pair;
     item.prim = in.prim;
     item.parent = in.parent;
     item.order = in.order;
     item.bound = in.bound;
     item.prev_prim = in.prev_prim;
-    in.defer[atomicAdd(in.defer_count, 1u)] = item;
+    const uint32_t slot = atomicAdd(in.defer_count, 1u);
+    in.defer[slot] = item;
+    if (slot_out) *slot_out = slot;
   }
   out->guess = guess;
   return to_epa;
@@ -296,7 +299,8 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   auto suspend = [&](uint32_t ea, uint32_t eb, int n_extra) -> bool {
     const uint32_t n_ent = uint32_t(sp + n_extra);
     if (WIDE || !split.can_suspend || n_ent == 0) return false;  // (tasks carry 16-bit node ids)
-    const uint32_t n_slots = SOLID ? 2u * n_ent : n_ent;
+    const bool expand = SOLID && !split.coop;  // (a suspended stack that k_bvh_shape_coop continues stays as it is)
+    const uint32_t n_slots = expand ? 2u * n_ent : n_ent;
     const uint32_t first = atomicAdd(&split.ctr[BVH_CTR_TASKS], n_slots);
     if (first + n_slots > split.cap) {  // table full: the slots taken become no-ops for the next level
       for (uint32_t j = first; j < min(first + n_slots, split.cap); ++j) split.tasks[j] = BvhTask{0u, 0u, 0xFFFFFFFFu, 0u};
@@ -316,7 +320,9 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
       if (n_extra > 1) split.tasks[j++] = BvhTask{pair, my_slot, eb, o++};
       for (int k = sp - 1; k >= 0; --k) split.tasks[j++] = BvhTask{pair, my_slot, uint32_t(stack[k][tid]), o++};  // DFS order: top first
     };
-    if constexpr (SOLID) {
+    if (SOLID && !expand) {
+      as_they_are();
+    } else if constexpr (SOLID) {
       ObbQuery<T> oq;
       oq.M = RT_R;
       oq.V = RT_T;
@@ -1049,6 +1055,232 @@ __global__ void __launch_bounds__(64) k_bvh_shape_finish(Work wk, LibView<T> lib
 }
 
 // ---------------------------------------------------------------------------------------
+// k_bvh_shape_coop: the long walks of a mesh x solid batch, ONE LANE GROUP PER QUERY, COOP_W entries of the stack at a time.
+// k_bvh_collide<SOLID> suspends a query after its step budget and leaves its stack (DFS order) and its state (bounds, witness)
+// behind; here a group of COOP_W lanes takes the query over and goes on with the SAME sequential walk, COOP_W entries wide:
+// the top entries of the (ordered, LDS) stack are popped together, each lane tests its entry's box or runs its triangle's
+// leaf, and the results are applied in stack order by scans over the group --
+//   * the bound after entry i is the minimum of the bound before the window and the values of entries <= i (exclusive
+//     prefix minimum): "this leaf lowered the bound when it was visited" is val_i < that, the witness is the LAST such leaf,
+//     the recorded distance belongs to the FIRST entry that reaches the window's minimum (later ties do not lower it);
+//   * the first entry with a contact ends the walk, entries behind it are void (their EPA items are marked so);
+//   * the children of the overlapping boxes take their parents' places, in order -- and only the entries in FRONT of the
+//     window's first overlapping box are visited in a trip (what the others do to the state depends on that box's subtree).
+// So the walk visits exactly the reference's sequence, up to COOP_W steps per trip instead of one, and ends with the query's
+// record: no task levels, no fold-back.  A step of a lone lane costs ~2 us and a level of tasks its budget times that; a
+// trip of this kernel costs one step's latency for COOP_W of them.  Groups take the next suspended query as they finish.
+// ---------------------------------------------------------------------------------------
+template <typename T, int W>
+__device__ __forceinline__ T group_min_excl_scan(T v, int lig, T identity) {  // exclusive prefix minimum over the lanes of a group
+#pragma unroll
+  for (int d = 1; d < W; d <<= 1) {
+    const T o = __shfl_up(v, d, W);
+    if (lig >= d) v = o < v ? o : v;
+  }
+  const T up = __shfl_up(v, 1, W);
+  return lig == 0 ? identity : up;
+}
+template <typename T, int W>
+__device__ __forceinline__ T group_min_all(T v) {
+#pragma unroll
+  for (int d = W / 2; d >= 1; d >>= 1) {
+    const T o = __shfl_xor(v, d, W);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+// COOP_W lanes per query (a wave walks 64 / COOP_W queries side by side, each with its own stack).  Narrower groups were
+// expected to pay -- the triangles that can be visited in one trip rarely come 64 in a row -- and LOSE: the kernel's time
+// is that of its longest walks, which need more trips the narrower the window (100k ellipsoid queries: 16.5 / 12 / 9.8 /
+// 7.7 ms at 8 / 16 / 32 / 64 lanes, profiles/r03_i).
+#ifndef HFCL_COOP_W
+#define HFCL_COOP_W 64
+#endif
+constexpr int COOP_W = HFCL_COOP_W;
+constexpr int COOP_CAP = 448, COOP_SLACK = 64;  // entries of a query's stack: a full stack narrows the window down to plain DFS, which needs the tree's depth more
+template <typename T>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
+k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhParams bp, T break_distance2, BvhSplit split) {
+  constexpr int W = COOP_W, G = 64 / W;
+  __shared__ uint32_t stacks[G][COOP_CAP + COOP_SLACK];
+  __shared__ T w0_slab[W0Lds<T, 64>::WORDS];
+  const W0Lds<T, 64> leaf_ps{w0_slab + threadIdx.x};
+  const int lane = threadIdx.x, grp = lane / W, lig = lane & (W - 1);
+  uint32_t* const stack = stacks[grp];
+  const uint64_t gbits = W == 64 ? ~uint64_t(0) : ((uint64_t(1) << (W & 63)) - 1);
+  auto gballot = [&](bool x) -> uint64_t { return (__ballot(x) >> (grp * W)) & gbits; };  // the group's lanes, bit 0 = its first lane
+  const uint32_t n_susp = min(split.ctr[BVH_CTR_SUSPENDED], split.n_queries);
+  const T big = Lim<T>::max();
+  // per-group state of the query being walked (uniform over the group's lanes)
+  bool have = false;
+  uint32_t qi = blockIdx.x * G + grp, pair = 0, solid_id = 0, ncontacts = 0;
+  const uint32_t stride = gridDim.x * G;
+  bool swapped = false, overflow = false;
+  DMesh m1 = {0, 0, 0, 0};
+  ObbQuery<T> oq;
+  oq.M.r0 = oq.M.r1 = oq.M.r2 = oq.V = oq.ext = mk<T>(T(0), T(0), T(0));
+  int sp = 0, fb = -1;
+  T dlb = big, rec_dist = big;
+  V3<T> np1 = oq.V, np2 = oq.V, nn = oq.V, guess0 = oq.V;
+  for (;;) {
+    if (!have && qi < n_susp) {
+      const BvhSum<T> s = *bvh_sum<T>(split, qi);
+      pair = split.suspended[qi];
+      qi += stride;
+      const uint32_t id1 = wk.shape1[pair], id2 = wk.shape2[pair];
+      swapped = lib.kinds[id1] != uint8_t(K_BVH);
+      solid_id = swapped ? id1 : id2;
+      m1 = bv.meshes[lib.shapes[swapped ? id2 : id1].bvh_index];
+      oq = reinterpret_cast<const ObbQuery<T>*>(wk.shape_oq)[pair];
+      for (uint32_t j = uint32_t(lig); j < s.n_child; j += uint32_t(W)) stack[s.n_child - 1u - j] = split.tasks[s.first_child + j].entry;  // child 0 on top
+      sp = int(s.n_child);
+      dlb = s.dlb;
+      rec_dist = s.rec_dist;
+      np1 = s.np1;
+      np2 = s.np2;
+      nn = s.nn;
+      fb = -1;
+      ncontacts = 0;
+      overflow = (s.flags & BVH_SUM_OVERFLOW) != 0 || sp > COOP_CAP;
+      if (overflow) sp = 0;
+      guess0 = initial_guess<T>(io, q, pair);  // (walks whose leaves hand a cached guess on are not split)
+      have = true;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!__any(have)) break;
+    bool done = have && sp == 0;
+    if (have && sp > 0) {
+      const int w = min(W, min(sp, max(COOP_CAP - sp, 1)));
+      const bool act = lig < w;
+      const uint32_t e = act ? stack[sp - 1 - lig] : 0u;
+      sp -= w;
+      const DNode<T>* const np = bv.nodes + m1.node_off + e;
+      const int32_t fc = act ? np->first_child : 0;
+      const bool is_leaf = act && fc < 0, is_int = act && fc >= 0;
+      // (1) every box of the window is tested; an overlapping box only refines the stack (its children take its place), at
+      // any position.  What an entry does to the walk's state -- a disjoint box's bound, a triangle's result -- depends on
+      // everything before it in DFS order, which includes the subtrees of overlapping boxes ahead of it: only the entries
+      // in front of the window's FIRST overlapping box are visited in this trip, the others stay for a later one.
+      T val = big, recv = big;  // what this entry would set the bound to, and the recorded distance that goes with it
+      bool overlap = false;
+      if (is_int) {
+        const DNode<T> n1 = *np;
+        T sq;
+        if (obb_disjoint_q(oq, n1, q.security_margin, break_distance2, sq)) {  // updateDistanceLowerBoundFromBV
+          const T nd = hsqrt(sq);
+          val = nd;
+          recv = nd + q.security_margin;
+        } else {
+          overlap = true;
+        }
+      }
+      const uint64_t omask = gballot(overlap);
+      const int f = omask ? __ffsll((unsigned long long)omask) - 1 : W;  // entries [0, f) are visited now
+      bool visit = act && lig < f;
+      // (2) their triangles (no EPA item yet: several triangles of the window may penetrate, only the first in order is the contact)
+      bool contact = false, to_epa = false, leaf_ok = false;
+      SolidLeafOut<T> lo;
+      lo.distance = big;
+      if (is_leaf && visit) {
+        const uint32_t prim = uint32_t(-(fc + 1));
+        SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + prim), lib.shapes, lib.verts,
+                          swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, nullptr, nullptr, pair, solid_id, prim, 0xFFFFFFFFu, 0u, T(0), -1};
+        to_epa = solid_leaf_call<T>(in, &q, leaf_ps, guess0, &lo);
+        if (to_epa) {
+          contact = true;
+        } else {
+          const T dtc = lo.distance - q.security_margin;  // updateDistanceLowerBoundFromLeaf
+          val = dtc;
+          recv = lo.distance;
+          contact = dtc <= q.collision_distance_threshold;
+          leaf_ok = true;
+        }
+      }
+      // (3) the first contact in stack order ends the walk; entries behind it were never visited
+      const uint64_t cmask = gballot(contact);
+      const int c = cmask ? __ffsll((unsigned long long)cmask) - 1 : W;
+      visit = visit && lig <= c;
+      if (!visit) {
+        val = big;
+        leaf_ok = false;
+      }
+      const T before = hmin(dlb, group_min_excl_scan<T, W>(val, lig, big));  // the bound as entry `lig` found it
+      const bool lowered = visit && val < before;
+      const T wmin = group_min_all<T, W>(val);
+      if (gballot(lowered)) {
+        // the bound ends at the minimum of the visited entries, set by the first of them that reaches it
+        const int src = __ffsll((unsigned long long)gballot(visit && val == wmin)) - 1;
+        dlb = wmin;
+        rec_dist = __shfl(recv, src, W);
+      }
+      const uint64_t wmask = gballot(lowered && leaf_ok);  // the witness: the last leaf that lowered the bound on its visit
+      {
+        const int L = wmask ? 63 - __clzll((unsigned long long)wmask) : 0;
+        const V3<T> a1 = swapped ? lo.p2 : lo.p1, a2 = swapped ? lo.p1 : lo.p2, an = swapped ? -lo.n : lo.n;
+        const V3<T> b1 = mk<T>(__shfl(a1.x, L, W), __shfl(a1.y, L, W), __shfl(a1.z, L, W));
+        const V3<T> b2 = mk<T>(__shfl(a2.x, L, W), __shfl(a2.y, L, W), __shfl(a2.z, L, W));
+        const V3<T> bn = mk<T>(__shfl(an.x, L, W), __shfl(an.y, L, W), __shfl(an.z, L, W));
+        if (wmask) {
+          np1 = b1;
+          np2 = b2;
+          nn = bn;
+        }
+      }
+      const int prim_c = __shfl(int(-(fc + 1)), c < W ? c : 0, W);
+      if (c < W) {  // canStop()
+        fb = prim_c;
+        ncontacts = 1;
+        if (lig == c) {
+          if (to_epa) {  // the query's contact: its leaf once more, this time with the EPA item (k_bvh_shape_finish patches the record)
+            SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + uint32_t(prim_c)), lib.shapes, lib.verts,
+                              swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer),
+                              &wk.counts[CTR_SHAPE_DEFER], pair, solid_id, uint32_t(prim_c), 0xFFFFFFFFu, 0u, T(0), -1};
+            solid_leaf_call<T>(in, &q, leaf_ps, guess0, &lo);
+          } else {
+            emit_shape_contact(bp, pair, swapped, prim_c, lo.distance, lo.p1, lo.p2, lo.n);
+          }
+        }
+        sp = 0;
+      } else {
+        // (4) the stack again, in order (entry 0's successors on top): visited entries are gone, an overlapping box is its two
+        // children (left above right), everything else behind the first overlapping box stays as it is
+        const int cnt = !act || lig < f ? 0 : (overlap ? 2 : 1);
+        const uint64_t m2 = gballot(cnt == 2), m1b = gballot(cnt == 1);
+        const uint64_t deeper = ~((uint64_t(2) << lig) - 1);  // window entries behind this one (pushed first)
+        const int pos = sp + 2 * __popcll(m2 & deeper) + __popcll(m1b & deeper);
+        if (cnt == 2) {
+          stack[pos] = uint32_t(fc) + 1u;
+          stack[pos + 1] = uint32_t(fc);
+        } else if (cnt == 1) {
+          stack[pos] = e;
+        }
+        sp += 2 * __popcll(m2) + __popcll(m1b);
+        if (sp > COOP_CAP + COOP_SLACK - 2) {  // a tree deeper than the slack on top of a full stack: flagged, never written past the block
+          overflow = true;
+          sp = 0;
+        }
+      }
+      done = sp == 0;
+    }
+    if (done) {
+      if (lig == 0) {
+        PairOut<T> o;
+        o.distance = rec_dist;
+        o.normal = nn;
+        o.p1 = np1;
+        o.p2 = np2;
+        o.gjk_status = GJK_DID_NOT_RUN;
+        o.epa_status = EPA_DID_NOT_RUN;
+        o.gjk_iters = o.epa_iters = 0;
+        store_bvh_record(io, pair, o, ncontacts, swapped ? -1 : fb, swapped ? fb : -1, overflow);
+      }
+      have = false;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // k_triangle: top-level TriangleP pairs (other than against Plane / Halfspace, which are closed forms):
 // TriangleP x TriangleP (triangle_triangle.cpp:46-105), TriangleP x Sphere (triangle_sphere.cpp:45-68) and
 // TriangleP x {Box, Capsule, Cone, Cylinder, Ellipsoid, ConvexBase} through GJKSolver::shapeDistance's
@@ -1613,12 +1845,25 @@ void launch_bvh_shape_distance_fast(int grid, int grid_finish, hipStream_t st, c
 }
 // mesh x solid collide(), one query per lane: the solids' OBBs, the walk (split as `split` says), the EPA leaves
 template <typename T>
-void launch_bvh_shape_fast(int grid, int grid_finish, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill) {
+void launch_bvh_shape_fast(int grid, int grid_finish, int coop_grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill) {
   hipLaunchKernelGGL((k_shape_obb<T>), dim3(std::max(1, grid / 2)), dim3(256), 0, st, wk, lv, io);
   spill.wide = 0;
   spill.slab = nullptr;
   const bool splitting = split.tasks && split.n_levels > 1 && bp.num_max_contacts == 1 && !bp.contacts;
   if (!splitting) split.tasks = nullptr;
+  if (splitting && split.coop) {
+    // the queries for their step budget, one per lane; then the suspended ones, one per wave and 64 entries at a time
+    BvhSplit s0 = split;
+    s0.level = 0;
+    s0.budget = split.budget0;
+    s0.can_suspend = 1;
+    launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s0, spill, true);
+    hipLaunchKernelGGL((k_bvh_shape_coop<T>), dim3(coop_grid), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2, s0);
+    BvhSplit none = split;
+    none.tasks = nullptr;  // (no task tree: no item is overtaken)
+    hipLaunchKernelGGL((k_bvh_shape_finish<T>), dim3(grid_finish), dim3(64), 0, st, wk, lv, io, q, bp, none, 0);
+    return;
+  }
   launch_bvh_collide<T>(grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill, true);
   split.level = 0;
   hipLaunchKernelGGL((k_bvh_shape_finish<T>), dim3(grid_finish), dim3(64), 0, st, wk, lv, io, q, bp, split, 0);
@@ -1637,7 +1882,7 @@ void launch_triangle(int grid, hipStream_t st, const Work& wk, const LibView<T>&
   template void launch_bvh_shape<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T);   \
   template void launch_bvh_shape_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&);          \
   template void launch_bvh_shape_distance_fast<T>(int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&); \
-  template void launch_bvh_shape_fast<T>(int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill); \
+  template void launch_bvh_shape_fast<T>(int, int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill); \
   template void launch_triangle<T>(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&);
 HFCL_INST(float)
 HFCL_INST(double)
