@@ -666,7 +666,8 @@ struct BvhSplit {
   uint32_t level, n_levels;
   uint32_t can_suspend;
   uint32_t leaf_cost;   // SOLID form: steps a GJK leaf counts for (a closed-form leaf: an eighth of it)
-  uint32_t coop;        // SOLID form: suspended queries are continued by k_bvh_shape_coop (one wave per query) instead of task levels
+  uint32_t coop;        // suspended queries are continued by k_bvh_shape_coop / k_bvh_coop (a lane group per query) instead of task levels
+  uint32_t coop_grid;   // ... blocks of that kernel (0: the launcher's choice)
 };
 // Step budget per unit (the compile-time default; without HFCL_BVH_* in the environment the host chooses per batch, see
 // hfcl_lib::bvh_auto).  0: units only suspend when their LDS stack is full -- the task mechanism is then the overflow path

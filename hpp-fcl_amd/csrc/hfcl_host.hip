@@ -96,7 +96,17 @@ struct hfcl_lib {
   // equivalents; a GJK leaf counts shape_leaf_cost): the queries themselves / their tasks.  The steps per query have a heavy
   // tail whatever the batch size (median 1, mean ~60, maximum > 3000 steps with > 1000 leaves), so the walk is always split.
   uint32_t shape_budget0 = 128, shape_budget = 96, shape_leaf_cost = 32, shape_levels = BVH_MAX_LEVELS;
-  bool shape_coop = true;  // HFCL_SHAPE_COOP=0: suspended queries go through task levels instead of k_bvh_shape_coop
+  // Suspended queries are continued by k_bvh_shape_coop (a wave per query, 64 stack entries per trip) instead of task levels
+  // (HFCL_SHAPE_COOP=0: the levels); the queries' own budget is then 16 steps (100k queries per kind, budgets 8 / 16 / 32 / 128:
+  // sphere 2.0 / 2.0 / 2.4 / 2.6 ms, ellipsoid 7.5 / 8.1 / 8.4 / 8.3, box 1.4 / 1.3 / 1.2 / 1.1; profiles/r03_i)
+  bool shape_coop = true;
+  uint32_t shape_budget0_coop = 16;
+  // Mesh x mesh queries past their step budget are continued by k_bvh_coop (a wave per query, 64 stack entries per trip)
+  // instead of task levels (HFCL_BVH_COOP=0: the levels).  cfg4, budgets 160 / 192 / 256 / 320 / 384: 100k queries 3.82 / 3.53 /
+  // 3.28 / 3.39 / 3.57 ms (levels: 5.03); 1M queries, 256 / 512 / 640 / 1024: 15.1 / 10.95 / 10.86 / 11.9 ms (unsplit stream:
+  // 14.7); 250k: 5.03 ms (8.78); 10k: 2.63 (3.74) -- profiles/r03_k.  HFCL_BVH_BUDGET0_COOP overrides both.
+  bool bvh_coop = true;
+  uint32_t bvh_budget0_coop = 0;  // 0: 256 steps up to 500k queries, 640 beyond
   // host-call staging: PIPE_SLOTS device buffer sets of `st_capacity` pairs each (a chunk of a host batch), three streams
   // (H2D | kernels | D2H) and per-slot events / pinned counter blocks (host_batch)
   static constexpr int PIPE_SLOTS = 6;  // (three left the feeder waiting for records to leave: profiles/r03_c)
@@ -413,7 +423,9 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_BVH_FILTER")) lib->bvh_filter = atoi(v) != 0;
   if (const char* v = getenv("HFCL_BVH_SHAPE_LANE")) lib->bvh_shape_lane = atoi(v) != 0;
   if (const char* v = getenv("HFCL_SHAPE_COOP")) lib->shape_coop = atoi(v) != 0;
-  if (const char* v = getenv("HFCL_SHAPE_BUDGET0")) lib->shape_budget0 = uint32_t(atoi(v));
+  if (const char* v = getenv("HFCL_BVH_COOP")) lib->bvh_coop = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_BVH_BUDGET0_COOP")) lib->bvh_budget0_coop = uint32_t(std::max(1, atoi(v)));
+  if (const char* v = getenv("HFCL_SHAPE_BUDGET0")) lib->shape_budget0 = lib->shape_budget0_coop = uint32_t(atoi(v));
   if (const char* v = getenv("HFCL_SHAPE_BUDGET")) lib->shape_budget = uint32_t(atoi(v));
   if (const char* v = getenv("HFCL_SHAPE_LEAF_COST")) lib->shape_leaf_cost = uint32_t(std::max(1, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_LEVELS")) lib->shape_levels = uint32_t(std::min(std::max(1, atoi(v)), int(BVH_MAX_LEVELS)));
@@ -1076,9 +1088,14 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         split.budget = 16;
         split.n_levels = BVH_MAX_LEVELS;
       }
+      split.coop_grid = uint32_t(lib->n_cus) * 8u;
+      if (!solid && lib->bvh_coop) {
+        split.coop = 1u;
+        split.budget0 = lib->bvh_budget0_coop ? lib->bvh_budget0_coop : (n > 500000 ? 640u : 256u);
+      }
       if (solid) {
         split.coop = lib->shape_coop ? 1u : 0u;
-        split.budget0 = lib->shape_budget0;
+        split.budget0 = lib->shape_coop ? lib->shape_budget0_coop : lib->shape_budget0;
         split.budget = lib->shape_budget;
         split.n_levels = lib->shape_levels;
       }

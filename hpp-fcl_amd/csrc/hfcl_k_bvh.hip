@@ -1281,6 +1281,214 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
 }
 
 // ---------------------------------------------------------------------------------------
+// k_bvh_coop: the same continuation for mesh x mesh walks (BvhSplit::coop on the plain form of k_bvh_collide): a query that
+// used up its step budget is taken over by a lane group that walks COOP_W entries of its (ordered) stack per trip.  An entry
+// is a pair of nodes; a box pair that overlaps is replaced by its two successors (firstOverSecond decides which node is
+// split), a disjoint one by its bound, a pair of leaves by its triangles' distance -- applied in stack order exactly as in
+// k_bvh_shape_coop above (same scans), so the record is the sequential walk's.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct TriLeafOut {
+  T distance;
+  V3<T> p1, p2, n;
+};
+template <typename T, class PS>
+__device__ __noinline__ void tri_leaf_call(const T* v1, const uint32_t* t1, const T* v2, const uint32_t* t2, const decltype(IO<T>::tf1) pose1,
+                                           const decltype(IO<T>::tf1) pose2, uint32_t pair, const QParams<T>* qp, const PS ps, TriLeafOut<T>* out) {
+  const QParams<T> q = *qp;
+  auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
+  TriSupport<T> tri;
+  {
+    const Pose<T> tf1 = load_pose(pose1, pair);
+    tri.p1 = xform(tf1, vtx(v1, t1[0]));
+    tri.p2 = xform(tf1, vtx(v1, t1[1]));
+    tri.p3 = xform(tf1, vtx(v1, t1[2]));
+  }
+  {
+    const Pose<T> tf2 = load_pose(pose2, pair);
+    tri.q1 = xform(tf2, vtx(v2, t2[0]));
+    tri.q2 = xform(tf2, vtx(v2, t2[1]));
+    tri.q3 = xform(tf2, vtx(v2, t2[2]));
+  }
+  int gst, git;
+  out->distance = tri_tri_distance(tri, q.gjk, q.guess_mode == HFCL_GUESS_CACHED, mk<T>(q.guess[0], q.guess[1], q.guess[2]), out->p1, out->p2,
+                                   out->n, gst, git, (V3<T>*)nullptr, ps);
+}
+template <typename T>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
+k_bvh_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhParams bp, T break_distance2, BvhSplit split) {
+  constexpr int W = COOP_W, G = 64 / W;
+  typedef BvhEntry<false> EN;
+  __shared__ uint32_t stacks[G][COOP_CAP + COOP_SLACK];
+  __shared__ T w0_slab[W0Lds<T, 64>::WORDS];
+  const W0Lds<T, 64> leaf_ps{w0_slab + threadIdx.x};
+  const int lane = threadIdx.x, grp = lane / W, lig = lane & (W - 1);
+  uint32_t* const stack = stacks[grp];
+  const uint64_t gbits = W == 64 ? ~uint64_t(0) : ((uint64_t(1) << (W & 63)) - 1);
+  auto gballot = [&](bool x) -> uint64_t { return (__ballot(x) >> (grp * W)) & gbits; };
+  const uint32_t n_susp = min(split.ctr[BVH_CTR_SUSPENDED], split.n_queries);
+  const T big = Lim<T>::max();
+  bool have = false, overflow = false;
+  uint32_t qi = blockIdx.x * G + grp, pair = 0, ncontacts = 0;
+  const uint32_t stride = gridDim.x * G;
+  DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
+  M3<T> RT_R;
+  V3<T> RT_T = mk<T>(T(0), T(0), T(0));
+  RT_R.r0 = RT_R.r1 = RT_R.r2 = RT_T;
+  int sp = 0, fb1 = -1, fb2 = -1;
+  T dlb = big, rec_dist = big;
+  V3<T> np1 = RT_T, np2 = RT_T, nn = RT_T;
+  for (;;) {
+    if (!have && qi < n_susp) {
+      const BvhSum<T> s = *bvh_sum<T>(split, qi);
+      pair = split.suspended[qi];
+      qi += stride;
+      m1 = bv.meshes[lib.shapes[wk.shape1[pair]].bvh_index];
+      m2 = bv.meshes[lib.shapes[wk.shape2[pair]].bvh_index];
+      {
+        const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+        RT_R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
+        RT_T = tmul(tf1.R, tf2.t - tf1.t);
+      }
+      for (uint32_t j = uint32_t(lig); j < s.n_child; j += uint32_t(W)) stack[s.n_child - 1u - j] = split.tasks[s.first_child + j].entry;  // child 0 on top
+      sp = int(s.n_child);
+      dlb = s.dlb;
+      rec_dist = s.rec_dist;
+      np1 = s.np1;
+      np2 = s.np2;
+      nn = s.nn;
+      fb1 = fb2 = -1;
+      ncontacts = 0;
+      overflow = (s.flags & BVH_SUM_OVERFLOW) != 0 || sp > COOP_CAP;
+      if (overflow) sp = 0;
+      have = true;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!__any(have)) break;
+    bool done = have && sp == 0;
+    if (have && sp > 0) {
+      const int w = min(W, min(sp, max(COOP_CAP - sp, 1)));
+      const bool act = lig < w;
+      const uint32_t e = act ? stack[sp - 1 - lig] : 0u;
+      sp -= w;
+      const uint32_t b1 = EN::first(e), b2 = EN::second(e);
+      const DNode<T>* const p1n = bv.nodes + m1.node_off + b1;
+      const DNode<T>* const p2n = bv.nodes + m2.node_off + b2;
+      const int32_t fc1 = act ? p1n->first_child : 0, fc2 = act ? p2n->first_child : 0;
+      const bool l1 = fc1 < 0, l2 = fc2 < 0;
+      const bool is_leaf = act && l1 && l2, is_int = act && !(l1 && l2);
+      T val = big, recv = big;
+      bool overlap = false, first = false;
+      if (is_int) {
+        const DNode<T> n1 = *p1n;
+        const DNode<T> n2 = *p2n;
+        first = l2 || (!l1 && (sqnorm(n1.extent) > sqnorm(n2.extent)));  // firstOverSecond
+        T sq;
+        // argument order of the reference: overlap(RT.R, RT.T, model2.bv(b2), model1.bv(b1))
+        if (obb_disjoint(RT_R, RT_T, n2, n1, q.security_margin, break_distance2, sq)) {  // updateDistanceLowerBoundFromBV
+          const T nd = hsqrt(sq);
+          val = nd;
+          recv = nd + q.security_margin;
+        } else {
+          overlap = true;
+        }
+      }
+      const uint64_t omask = gballot(overlap);
+      const int f = omask ? __ffsll((unsigned long long)omask) - 1 : W;  // entries [0, f) are visited now
+      bool visit = act && lig < f;
+      bool contact = false, leaf_ok = false;
+      TriLeafOut<T> lo;
+      lo.distance = big;
+      const uint32_t lb1 = uint32_t(-(fc1 + 1)), lb2 = uint32_t(-(fc2 + 1));
+      if (is_leaf && visit) {
+        tri_leaf_call<T>(bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + lb1), bv.verts + 3 * size_t(m2.vert_off),
+                         bv.tris + 3 * size_t(m2.tri_off + lb2), io.tf1, io.tf2, pair, &q, leaf_ps, &lo);
+        const T dtc = lo.distance - q.security_margin;  // updateDistanceLowerBoundFromLeaf
+        val = dtc;
+        recv = lo.distance;
+        contact = dtc <= q.collision_distance_threshold;
+        leaf_ok = true;
+      }
+      const uint64_t cmask = gballot(contact);
+      const int c = cmask ? __ffsll((unsigned long long)cmask) - 1 : W;  // the first contact in stack order ends the walk
+      visit = visit && lig <= c;
+      if (!visit) {
+        val = big;
+        leaf_ok = false;
+      }
+      const T before = hmin(dlb, group_min_excl_scan<T, W>(val, lig, big));  // the bound as entry `lig` found it
+      const bool lowered = visit && val < before;
+      const T wmin = group_min_all<T, W>(val);
+      if (gballot(lowered)) {
+        const int src = __ffsll((unsigned long long)gballot(visit && val == wmin)) - 1;
+        dlb = wmin;
+        rec_dist = __shfl(recv, src, W);
+      }
+      const uint64_t wmask = gballot(lowered && leaf_ok);  // the witness: the last leaf that lowered the bound on its visit
+      {
+        const int L = wmask ? 63 - __clzll((unsigned long long)wmask) : 0;
+        const V3<T> c1 = mk<T>(__shfl(lo.p1.x, L, W), __shfl(lo.p1.y, L, W), __shfl(lo.p1.z, L, W));
+        const V3<T> c2 = mk<T>(__shfl(lo.p2.x, L, W), __shfl(lo.p2.y, L, W), __shfl(lo.p2.z, L, W));
+        const V3<T> cn = mk<T>(__shfl(lo.n.x, L, W), __shfl(lo.n.y, L, W), __shfl(lo.n.z, L, W));
+        if (wmask) {
+          np1 = c1;
+          np2 = c2;
+          nn = cn;
+        }
+      }
+      const int cs = c < W ? c : 0;
+      const int cb1 = __shfl(int(lb1), cs, W), cb2 = __shfl(int(lb2), cs, W);
+      if (c < W) {  // canStop() (num_max_contacts == 1: the split forms only)
+        fb1 = cb1;
+        fb2 = cb2;
+        ncontacts = 1;
+        sp = 0;
+      } else {
+        const int cnt = !act || lig < f ? 0 : (overlap ? 2 : 1);
+        const uint64_t mm2 = gballot(cnt == 2), mm1 = gballot(cnt == 1);
+        const uint64_t deeper = ~((uint64_t(2) << lig) - 1);  // window entries behind this one (pushed first)
+        const int pos = sp + 2 * __popcll(mm2 & deeper) + __popcll(mm1 & deeper);
+        if (cnt == 2) {
+          uint32_t ea, eb;
+          if (first) {
+            ea = EN::pack(uint32_t(fc1), b2);
+            eb = EN::pack(uint32_t(fc1) + 1u, b2);
+          } else {
+            ea = EN::pack(b1, uint32_t(fc2));
+            eb = EN::pack(b1, uint32_t(fc2) + 1u);
+          }
+          stack[pos] = eb;      // second child below
+          stack[pos + 1] = ea;  // first child on top
+        } else if (cnt == 1) {
+          stack[pos] = e;
+        }
+        sp += 2 * __popcll(mm2) + __popcll(mm1);
+        if (sp > COOP_CAP + COOP_SLACK - 2) {
+          overflow = true;
+          sp = 0;
+        }
+      }
+      done = sp == 0;
+    }
+    if (done) {
+      if (lig == 0) {
+        PairOut<T> o;
+        o.distance = rec_dist;
+        o.normal = nn;
+        o.p1 = np1;
+        o.p2 = np2;
+        o.gjk_status = GJK_DID_NOT_RUN;
+        o.epa_status = EPA_DID_NOT_RUN;
+        o.gjk_iters = o.epa_iters = 0;
+        store_bvh_record(io, pair, o, ncontacts, fb1, fb2, overflow);
+      }
+      have = false;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // k_triangle: top-level TriangleP pairs (other than against Plane / Halfspace, which are closed forms):
 // TriangleP x TriangleP (triangle_triangle.cpp:46-105), TriangleP x Sphere (triangle_sphere.cpp:45-68) and
 // TriangleP x {Box, Capsule, Cone, Cylinder, Ellipsoid, ConvexBase} through GJKSolver::shapeDistance's
@@ -1803,6 +2011,16 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
     split.level = 0;
     split.can_suspend = 0;
     launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill, solid);
+    return;
+  }
+  if (split.coop && !solid) {
+    // the queries for their step budget, one per lane; then the suspended ones, a lane group each (k_bvh_coop)
+    BvhSplit s0 = split;
+    s0.level = 0;
+    s0.budget = split.budget0;
+    s0.can_suspend = 1;
+    launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s0, spill, false);
+    hipLaunchKernelGGL((k_bvh_coop<T>), dim3(std::max(1, std::min(grid * 2, split.coop_grid ? int(split.coop_grid) : grid * 2))), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2, s0);
     return;
   }
   const uint32_t budget = split.budget;
