@@ -184,6 +184,37 @@ __device__ __noinline__ bool solid_leaf_call(const SolidLeafIn<T> in, const QPar
   return to_epa;
 }
 
+// the triangle pair of a mesh x mesh leaf as a call (k_bvh_coop; k_bvh_collide with HFCL_BVH_LEAF_OUTLINE=1)
+#ifndef HFCL_BVH_LEAF_OUTLINE
+#define HFCL_BVH_LEAF_OUTLINE 0
+#endif
+template <typename T>
+struct TriLeafOut {
+  T distance;
+  V3<T> p1, p2, n;
+};
+template <typename T, class PS>
+__device__ __noinline__ void tri_leaf_call(const T* v1, const uint32_t* t1, const T* v2, const uint32_t* t2, const decltype(IO<T>::tf1) pose1,
+                                           const decltype(IO<T>::tf1) pose2, uint32_t pair, const QParams<T>* qp, const PS ps, TriLeafOut<T>* out) {
+  const QParams<T> q = *qp;
+  auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
+  TriSupport<T> tri;
+  {
+    const Pose<T> tf1 = load_pose(pose1, pair);
+    tri.p1 = xform(tf1, vtx(v1, t1[0]));
+    tri.p2 = xform(tf1, vtx(v1, t1[1]));
+    tri.p3 = xform(tf1, vtx(v1, t1[2]));
+  }
+  {
+    const Pose<T> tf2 = load_pose(pose2, pair);
+    tri.q1 = xform(tf2, vtx(v2, t2[0]));
+    tri.q2 = xform(tf2, vtx(v2, t2[1]));
+    tri.q3 = xform(tf2, vtx(v2, t2[2]));
+  }
+  int gst, git;
+  out->distance = tri_tri_distance(tri, q.gjk, q.guess_mode == HFCL_GUESS_CACHED, mk<T>(q.guess[0], q.guess[1], q.guess[2]), out->p1, out->p2,
+                                   out->n, gst, git, (V3<T>*)nullptr, ps);
+}
 #ifndef HFCL_BVH_PARK_MAX
 #define HFCL_BVH_PARK_MAX 32  // lanes waiting for a leaf test or an fp64 re-test that end the BV phase of a wave
 #endif
@@ -747,6 +778,12 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
       const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + lb2);
       const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
       const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
+#if HFCL_BVH_LEAF_OUTLINE
+      TriLeafOut<T> tlo;
+      tri_leaf_call<T>(v1, t1, v2, t2, io.tf1, io.tf2, pair, &q, leaf_ps, &tlo);
+      const T distance = tlo.distance;
+      const V3<T> p1 = tlo.p1, p2 = tlo.p2, n = tlo.n;
+#else
       auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
       TriSupport<T> tri;
       {
@@ -765,6 +802,7 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
       int gst, git;
       const T distance = tri_tri_distance(tri, q.gjk, q.guess_mode == HFCL_GUESS_CACHED,
                                           mk<T>(q.guess[0], q.guess[1], q.guess[2]), p1, p2, n, gst, git, (V3<T>*)nullptr, leaf_ps);
+#endif
       const T dtc = distance - q.security_margin;
       if (dtc < dlb) {  // updateDistanceLowerBoundFromLeaf
         dlb = dtc;
@@ -1287,33 +1325,6 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
 // split), a disjoint one by its bound, a pair of leaves by its triangles' distance -- applied in stack order exactly as in
 // k_bvh_shape_coop above (same scans), so the record is the sequential walk's.
 // ---------------------------------------------------------------------------------------
-template <typename T>
-struct TriLeafOut {
-  T distance;
-  V3<T> p1, p2, n;
-};
-template <typename T, class PS>
-__device__ __noinline__ void tri_leaf_call(const T* v1, const uint32_t* t1, const T* v2, const uint32_t* t2, const decltype(IO<T>::tf1) pose1,
-                                           const decltype(IO<T>::tf1) pose2, uint32_t pair, const QParams<T>* qp, const PS ps, TriLeafOut<T>* out) {
-  const QParams<T> q = *qp;
-  auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
-  TriSupport<T> tri;
-  {
-    const Pose<T> tf1 = load_pose(pose1, pair);
-    tri.p1 = xform(tf1, vtx(v1, t1[0]));
-    tri.p2 = xform(tf1, vtx(v1, t1[1]));
-    tri.p3 = xform(tf1, vtx(v1, t1[2]));
-  }
-  {
-    const Pose<T> tf2 = load_pose(pose2, pair);
-    tri.q1 = xform(tf2, vtx(v2, t2[0]));
-    tri.q2 = xform(tf2, vtx(v2, t2[1]));
-    tri.q3 = xform(tf2, vtx(v2, t2[2]));
-  }
-  int gst, git;
-  out->distance = tri_tri_distance(tri, q.gjk, q.guess_mode == HFCL_GUESS_CACHED, mk<T>(q.guess[0], q.guess[1], q.guess[2]), out->p1, out->p2,
-                                   out->n, gst, git, (V3<T>*)nullptr, ps);
-}
 template <typename T>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 k_bvh_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhParams bp, T break_distance2, BvhSplit split) {
