@@ -152,6 +152,14 @@ def load_traffic(workload, dominant, n, want="traffic"):
             hit = True
         if base == "k_closed" and "k_closed_staged(" in name:  # the fp64 closed-form kernel (LDS-staged I/O)
             hit = True
+        # the mesh timers stand for a pass of several kernels: the per-lane walk, the continuation of the suspended queries
+        # (k_bvh_coop / k_bvh_shape_coop) and, for mesh x solid, the solids' OBBs and the EPA leaves; the SOLID instantiation of
+        # k_bvh_collide belongs to the mesh x solid pass
+        solid_walk = re.search(r"k_bvh_collide<\w+, false, false, true>", name) is not None
+        if base == "k_bvh_collide":
+            hit = (hit and not solid_walk) or any(x in name for x in ("k_bvh_coop<", "k_bvh_combine<", "k_bvh_level_mark"))
+        if base == "k_bvh_shape":
+            hit = hit or solid_walk or any(x in name for x in ("k_shape_obb", "k_bvh_shape_coop<", "k_bvh_shape_finish<"))
         if not hit:
             continue
         if want == "valu":
