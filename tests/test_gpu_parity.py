@@ -467,10 +467,10 @@ def test_bvh_collide_first_contact(pkg, oracle, seg, n, form, monkeypatch):
 
 @pytest.mark.parametrize("n", [100_000, 250_000])
 def test_bvh_collide_baseline_size(pkg, oracle, n):
-    """BASELINE.json configs[3] at its size: 100k mesh pairs of 5 000-triangle models (the batch form the host picks for
-    it: queries cut at 512 steps, remainders as levels of tasks), and a 250k-query batch (beyond the ~196k queries up to
-    which bvh_auto splits: the unsplit streaming form).  Every record against the oracle: contact counts, first-contact
-    triangle ids in DFS order, depth and witness data."""
+    """BASELINE.json configs[3] at its size: 100k mesh pairs of 5 000-triangle models, and a 250k-query batch (the batch form
+    the host picks for them: one query per lane for 256 steps, then the suspended queries continued by waves that walk 64
+    stack entries per trip, k_bvh_coop).  Every record against the oracle: contact counts, first-contact triangle ids in DFS
+    order, depth and witness data."""
     abi, wl = pkg.abi, pkg.workloads
     b = wl.cfg4_mesh_mesh(n=n)
     assert len(b.meshes) == 8 and all(len(m.triangles) == 5000 for m in b.meshes)
@@ -486,6 +486,45 @@ def test_bvh_collide_baseline_size(pkg, oracle, n):
     ref = oracle.bvh_collide_batch(ML, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=32)
     _check_bvh_records(abi, got, ref, "bvh-cfg4-%d" % n)
     assert 0.2 < (ref["num_contacts"] > 0).mean() < 0.8
+
+
+@pytest.mark.parametrize("form", ["coop", "levels", "whole"])
+def test_bvh_collide_forms_agree(pkg, oracle, form, monkeypatch):
+    """The three forms of a long mesh x mesh walk -- continued 64 entries wide by a wave (with a budget of 24 steps, so that
+    nearly every query is), cut into task levels, and walked in one piece by its lane -- give the oracle's records; and the
+    fp32 device path (its own instantiations of the same kernels) the same decisions away from the decision boundary."""
+    import torch
+    abi, wl = pkg.abi, pkg.workloads
+    if form == "coop":
+        monkeypatch.setenv("HFCL_BVH_BUDGET0_COOP", "24")
+    elif form == "levels":
+        monkeypatch.setenv("HFCL_BVH_COOP", "0")
+    else:
+        monkeypatch.setenv("HFCL_BVH_COOP", "0")
+        monkeypatch.setenv("HFCL_BVH_LEVELS", "1")
+    b = wl.cfg4_mesh_mesh(n=30_000, seed=21)
+    req = wl.make_request(b, abi)
+    ML = pkg.bvh_builder.MeshLibrary(b.meshes)
+    ref = oracle.bvh_collide_batch(ML, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=32)
+    lib = wl.make_library(pkg, b)
+    try:
+        got = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
+        dev = torch.device("cuda:0")
+        d = [torch.from_numpy(x).to(dev) for x in (b.s1.astype(np.int32), b.s2.astype(np.int32), b.pose1_f32, b.pose2_f32)]
+        out = torch.zeros(len(b) * 11, dtype=torch.int32, device=dev)
+        lib.collide_device_f32(*d, len(b), req, out)
+        torch.cuda.synchronize()
+        g32 = out.cpu().numpy().view(abi.RESULT_F32_DTYPE)
+    finally:
+        lib.close()
+    _check_bvh_records(abi, got, ref, "bvh-forms-" + form)
+    clear = np.abs(ref["distance"]) > 1e-3
+    assert np.array_equal(abi.status_contact(g32["status"])[clear] != 0, ref["num_contacts"][clear] > 0)
+    hit = clear & (ref["num_contacts"] > 0)
+    # (fp32 has no triangle ids to compare; where a box test falls the other way in fp32 the walk ends on another contact of the
+    # same pair of meshes, with its own depth: a handful of queries)
+    err = np.abs(g32["distance"][hit] - ref["distance"][hit])
+    assert np.quantile(err, 0.995) < 2e-4 and (err > 2e-4).sum() < 0.005 * hit.sum()
 
 
 def test_bvh_collide_all_contacts(pkg, oracle):
