@@ -54,7 +54,8 @@ enum { B_CLOSED = 0, B_PRIM = 1, B_CC = 2, B_PC = 3, B_CP = 4, B_BVH = 5, B_UNSU
 constexpr int B_CURVED0 = B_COUNT + 4;
 // + the two counters of the one-query-per-lane mesh x solid form (its ticket, the length of its EPA queue)
 constexpr int CTR_SHAPE_TICKET = 2 * B_COUNT + 4, CTR_SHAPE_DEFER = 2 * B_COUNT + 5;
-constexpr int N_COUNTERS = 2 * B_COUNT + 6;  // bucket populations + the four counters of Work::counts + curved populations + those two
+constexpr int CTR_DIST_SUSP = 2 * B_COUNT + 6;  // suspended mesh x mesh distance() walks (DistSusp records)
+constexpr int N_COUNTERS = 2 * B_COUNT + 7;  // bucket populations + the four counters of Work::counts + curved populations + those two
 
 // Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
 // support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
@@ -689,6 +690,11 @@ struct BvhSpill {
   uint32_t cap;         // entries per lane
   uint32_t max_blocks;  // blocks the slab allocation covers
   uint32_t wide;        // 32-bit node ids in the stack entries
+  // distance(), narrow form: a query that has taken `budget` steps leaves its state and its stack in a DistSusp record
+  // (susp[slot], slot from *susp_count) and is continued by k_bvh_distance_coop; budget 0: walks stay with their lanes
+  void* susp;
+  uint32_t* susp_count;
+  uint32_t budget;
 };
 constexpr int BVH_MAX_LEVELS = 12;  // most task levels a batch can be given (HFCL_BVH_LEVELS, the automatic choice)
 #ifndef HFCL_BVH_LEVELS
@@ -722,6 +728,15 @@ constexpr int BS_STACK = 128;
 // entries: models up to 19 levels deep (5 000 triangles: 16); deeper ones take the wide form with its global slabs.
 constexpr int BVHD_STACK = 40;
 constexpr int BVHD_BLOCK = 64;   // k_bvh_distance
+template <typename T>
+struct DistSusp {  // a suspended mesh x mesh distance() walk
+  uint32_t pair, sp;
+  int32_t fb1, fb2;
+  T mind;
+  V3<T> np1, np2;                // witness of the minimum, model-1 frame
+  uint32_t entry[BVHD_STACK];    // stack, bottom first
+  T bound[BVHD_STACK];
+};
 
 // ---------------------------------------------------------------------------------------
 // Witness payload of the GJK simplex parked in LDS (policy of gjk_run / gjk_finish, hfcl_pair.hpp).  The support

@@ -107,6 +107,10 @@ struct hfcl_lib {
   // 14.7); 250k: 5.03 ms (8.78); 10k: 2.63 (3.74) -- profiles/r03_k.  HFCL_BVH_BUDGET0_COOP overrides both.
   bool bvh_coop = true;
   uint32_t bvh_budget0_coop = 0;  // 0: 256 steps up to 500k queries, 640 beyond
+  // distance(): a mesh x mesh walk that has taken this many steps is continued by a wave (k_bvh_distance_coop); 0: never
+  uint32_t bvhd_budget = 1024;    // HFCL_BVHD_BUDGET (cfg4d 100k queries, budgets 0 / 32 / 256 / 1024 / 4096 / 8192: 101.5 / 59.3 / 58.0 / 55.7 / 67.1 / 92.0 ms; profiles/r03_k)
+  void* d_dist_susp = nullptr;    // DistSusp<double>[dist_susp_capacity]
+  size_t dist_susp_capacity = 0;
   // host-call staging: PIPE_SLOTS device buffer sets of `st_capacity` pairs each (a chunk of a host batch), three streams
   // (H2D | kernels | D2H) and per-slot events / pinned counter blocks (host_batch)
   static constexpr int PIPE_SLOTS = 6;  // (three left the feeder waiting for records to leave: profiles/r03_c)
@@ -424,6 +428,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_BVH_SHAPE_LANE")) lib->bvh_shape_lane = atoi(v) != 0;
   if (const char* v = getenv("HFCL_SHAPE_COOP")) lib->shape_coop = atoi(v) != 0;
   if (const char* v = getenv("HFCL_BVH_COOP")) lib->bvh_coop = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_BVHD_BUDGET")) lib->bvhd_budget = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_BUDGET0_COOP")) lib->bvh_budget0_coop = uint32_t(std::max(1, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_BUDGET0")) lib->shape_budget0 = lib->shape_budget0_coop = uint32_t(atoi(v));
   if (const char* v = getenv("HFCL_SHAPE_BUDGET")) lib->shape_budget = uint32_t(atoi(v));
@@ -469,6 +474,7 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_epa_v0);
   hipFree(lib->d_shape_defer);
   hipFree(lib->d_shape_oq);
+  hipFree(lib->d_dist_susp);
   if (lib->h_pack) hipHostFree(lib->h_pack);
   if (lib->h_pack_counts) hipHostFree(lib->h_pack_counts);
   hipFree(lib->d_pack);
@@ -1149,6 +1155,19 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         launch_bvh_shape_distance<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q);
       tend();
       tbeg("k_bvh_distance");
+      if (may(B_BVH) && !spill.wide && lib->bvhd_budget) {
+        if (lib->ws_capacity > lib->dist_susp_capacity) {
+          hipFree(lib->d_dist_susp);
+          lib->d_dist_susp = nullptr;
+          lib->dist_susp_capacity = 0;
+          HIP_TRY(hipMalloc(&lib->d_dist_susp, lib->ws_capacity * sizeof(DistSusp<double>)));
+          lib->dist_susp_capacity = lib->ws_capacity;
+        }
+        spill.susp = lib->d_dist_susp;
+        spill.susp_count = lib->d_counts + CTR_DIST_SUSP;
+        spill.budget = lib->bvhd_budget;
+        spill.max_blocks = uint32_t(lib->n_cus) * 8u;
+      }
       launch_bvh_distance<T>(blocks_for(n, BVHD_BLOCK), st, wk, lv, bv, io, q, spill);
       tend();
     }

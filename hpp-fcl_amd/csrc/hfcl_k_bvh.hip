@@ -1803,7 +1803,7 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
   // this lane's slab of spilled (entry, bound) records (WIDE only): entries first, bounds behind them
   E* const slab_e = WIDE && spill.slab ? reinterpret_cast<E*>(spill.slab) + size_t(blockIdx.x * BVHD_BLOCK + threadIdx.x) * spill.cap * 2 : nullptr;
   BD* const slab_d = reinterpret_cast<BD*>(slab_e + spill.cap);
-  uint32_t nspill = 0;
+  uint32_t nspill = 0, steps = 0;
   const uint32_t cnt = wk.counts[B_BVH];
   uint32_t* const ticket = &wk.counts[B_COUNT + 2];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1890,6 +1890,7 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
           np1 = np2 = mk<T>(nanv, nanv, nanv);
           overflow = false;
           nspill = 0;
+          steps = 0;
           leaf(0u, 0u);  // preprocess()
           sp = 1;
           stack_e[0][tid] = 0u;
@@ -1904,6 +1905,23 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
     // wave wait, as k_bvh_collide does, loses here: a BV step is two rectangle distances, as heavy as a triangle pair, and
     // the parked lanes miss them: 8 lanes 0.75, 24 lanes 0.56 against 0.83 M q/s; profiles/r03_g.)
     for (;;) {
+      if (!WIDE && spill.budget && live && sp > 0 && steps >= spill.budget) {
+        // this walk is a long one: its state and stack go to a record, a wave takes it over (k_bvh_distance_coop)
+        DistSusp<T>* r = reinterpret_cast<DistSusp<T>*>(spill.susp) + atomicAdd(spill.susp_count, 1u);
+        r->pair = pair;
+        r->sp = uint32_t(sp);
+        r->fb1 = fb1;
+        r->fb2 = fb2;
+        r->mind = mind;
+        r->np1 = np1;
+        r->np2 = np2;
+        for (int k = 0; k < sp; ++k) {
+          r->entry[k] = uint32_t(stack_e[k][tid]);
+          r->bound[k] = bound_value(stack_d[k][tid]);
+        }
+        sp = 0;
+        live = false;  // (no record from this lane)
+      }
       const bool run = live && sp > 0;
       const int n_run = __popcll(__ballot(run || (live && nspill > 0)));
       if (n_run == 0 || (!exhausted && 64 - n_run >= BVH_REFILL_MIN)) break;
@@ -1911,6 +1929,7 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
         if (live) reload();
         continue;
       }
+      ++steps;
       --sp;
       const E e = stack_e[sp][tid];
       const BD dc = stack_d[sp][tid];
@@ -1973,6 +1992,146 @@ __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu
       stack_e[sp][tid] = c_first ? ec : ea;
       stack_d[sp][tid] = bound_down(c_first ? d2 : d1);
       ++sp;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_bvh_distance_coop: the long mesh x mesh distance() walks, a wave per query, 64 stack entries per trip (the scheme of
+// k_bvh_coop applied to branch and bound).  Entries of the window whose bound cannot beat the minimum are dropped; box pairs
+// are replaced by their two successors with their bounds (nearer one on top) wherever they stand -- deciding that with the
+// minimum of the moment can only keep a pair the sequential walk would have skipped, never drop one it would have kept; the
+// triangle pairs IN FRONT of the first pair that is split are evaluated together and applied in stack order (the minimum is
+// lowered by strictly smaller distances only, so the first triangle pair in DFS order that attains it is reported, as in
+// distanceRecurse): the same minimum, triangle ids and witness points as the lane's walk.
+// ---------------------------------------------------------------------------------------
+constexpr int COOPD_CAP = 960, COOPD_SLACK = 64;
+template <typename T>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
+k_bvh_distance_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, BvhSpill spill) {
+  typedef BvhEntry<false> EN;
+  __shared__ uint32_t stack_e[COOPD_CAP + COOPD_SLACK];
+  __shared__ T stack_d[COOPD_CAP + COOPD_SLACK];
+  const int lane = threadIdx.x;
+  const uint32_t n_susp = *spill.susp_count;
+  const T big = Lim<T>::max(), nanv = Lim<T>::nan();
+  auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
+  for (uint32_t qi = blockIdx.x; qi < n_susp; qi += gridDim.x) {
+    const DistSusp<T>* const r = reinterpret_cast<const DistSusp<T>*>(spill.susp) + qi;
+    const uint32_t pair = r->pair;
+    const DMesh m1 = bv.meshes[lib.shapes[wk.shape1[pair]].bvh_index], m2 = bv.meshes[lib.shapes[wk.shape2[pair]].bvh_index];
+    const Pose<T> tf1 = load_pose(io.tf1, pair);
+    M3<T> RT_R;
+    V3<T> RT_T;
+    {
+      const Pose<T> tf2 = load_pose(io.tf2, pair);
+      RT_R = tmul(tf1.R, tf2.R);
+      RT_T = tmul(tf1.R, tf2.t - tf1.t);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int sp = int(r->sp);
+    if (lane < sp) {
+      stack_e[lane] = r->entry[lane];
+      stack_d[lane] = r->bound[lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    T mind = r->mind;
+    int fb1 = r->fb1, fb2 = r->fb2;
+    V3<T> np1 = r->np1, np2 = r->np2;
+    bool overflow = false;
+    while (sp > 0) {
+      const int w = min(64, min(sp, max(COOPD_CAP - sp, 1)));
+      const bool act = lane < w;
+      const uint32_t e = act ? stack_e[sp - 1 - lane] : 0u;
+      const T db = act ? stack_d[sp - 1 - lane] : big;
+      sp -= w;
+      const bool alive = act && !(db >= T(0) && db >= mind);  // canStop(d), with the minimum of the moment
+      const uint32_t b1 = EN::first(e), b2 = EN::second(e);
+      const DNode<T>* const p1n = bv.nodes + m1.node_off + b1;
+      const DNode<T>* const p2n = bv.nodes + m2.node_off + b2;
+      const int32_t fc1 = alive ? p1n->first_child : 0, fc2 = alive ? p2n->first_child : 0;
+      const bool l1 = fc1 < 0, l2 = fc2 < 0;
+      const bool is_leaf = alive && l1 && l2, split = alive && !(l1 && l2);
+      uint32_t ea = 0, ec = 0;
+      T d1 = big, d2 = big;
+      if (split) {
+        uint32_t a1, a2, c1, c2;
+        if (l2 || (!l1 && (sqnorm(p1n->extent) > sqnorm(p2n->extent)))) {
+          a1 = uint32_t(fc1);
+          a2 = b2;
+          c1 = a1 + 1;
+          c2 = b2;
+        } else {
+          a1 = b1;
+          a2 = uint32_t(fc2);
+          c1 = b1;
+          c2 = a2 + 1;
+        }
+        d1 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + a1], bv.rss[m1.node_off + a1], bv.nodes[m2.node_off + a2], bv.rss[m2.node_off + a2]);
+        d2 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + c1], bv.rss[m1.node_off + c1], bv.nodes[m2.node_off + c2], bv.rss[m2.node_off + c2]);
+        ea = EN::pack(a1, a2);
+        ec = EN::pack(c1, c2);
+      }
+      const uint64_t smask = __ballot(split);
+      const int f = smask ? __ffsll((unsigned long long)smask) - 1 : 64;  // the triangle pairs in front of it are visited now
+      const bool visit = is_leaf && lane < f;
+      T val = big;
+      V3<T> P = mk<T>(nanv, nanv, nanv), Q = P;
+      const uint32_t lb1 = uint32_t(-(fc1 + 1)), lb2 = uint32_t(-(fc2 + 1));
+      if (visit) {
+        const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
+        const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
+        const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + lb1);
+        const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + lb2);
+        const T dd = sqr_tri_distance(vtx(v1, t1[0]), vtx(v1, t1[1]), vtx(v1, t1[2]), mul(RT_R, vtx(v2, t2[0])) + RT_T,
+                                      mul(RT_R, vtx(v2, t2[1])) + RT_T, mul(RT_R, vtx(v2, t2[2])) + RT_T, P, Q);
+        val = hsqrt(dd);
+      }
+      const T wmin = group_min_all<T, 64>(val);
+      if (wmin < mind) {  // DistanceResult::update: the first triangle pair in order that attains the new minimum
+        const int src = __ffsll((unsigned long long)__ballot(visit && val == wmin)) - 1;
+        mind = wmin;
+        fb1 = __shfl(int(lb1), src);
+        fb2 = __shfl(int(lb2), src);
+        np1 = mk<T>(__shfl(P.x, src), __shfl(P.y, src), __shfl(P.z, src));
+        np2 = mk<T>(__shfl(Q.x, src), __shfl(Q.y, src), __shfl(Q.z, src));
+      }
+      // the stack again, in order: visited triangle pairs and dropped entries are gone, a split pair is its two successors
+      // (the nearer one on top), a triangle pair behind the first split stays
+      const int cnt = split ? 2 : ((is_leaf && lane >= f) ? 1 : 0);
+      const uint64_t m2b = __ballot(cnt == 2), m1b = __ballot(cnt == 1);
+      const uint64_t deeper = ~((uint64_t(2) << lane) - 1);
+      const int pos = sp + 2 * __popcll(m2b & deeper) + __popcll(m1b & deeper);
+      if (cnt == 2) {
+        const bool c_first = d2 < d1;  // visit (c1, c2) first when it is strictly nearer
+        stack_e[pos] = c_first ? ea : ec;
+        stack_d[pos] = c_first ? d1 : d2;
+        stack_e[pos + 1] = c_first ? ec : ea;
+        stack_d[pos + 1] = c_first ? d2 : d1;
+      } else if (cnt == 1) {
+        stack_e[pos] = e;
+        stack_d[pos] = db;
+      }
+      sp += 2 * __popcll(m2b) + __popcll(m1b);
+      if (sp > COOPD_CAP + COOPD_SLACK - 2) {
+        overflow = true;
+        sp = 0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+      PairOut<T> o;
+      o.distance = mind;
+      o.normal = mk<T>(nanv, nanv, nanv);  // not set by the reference on this path (traversal_node_bvhs.h:454,465)
+      o.p1 = xform(tf1, np1);              // postprocess(): model-1 frame -> world
+      o.p2 = xform(tf1, np2);
+      o.gjk_status = GJK_DID_NOT_RUN;
+      o.epa_status = EPA_DID_NOT_RUN;
+      o.gjk_iters = o.epa_iters = 0;
+      store_bvh_record(io, pair, o, mind <= T(0) ? 0x80000000u : 0u, fb1, fb2, overflow);
     }
   }
 }
@@ -2055,6 +2214,7 @@ void launch_bvh_distance(int grid, hipStream_t st, const Work& wk, const LibView
     hipLaunchKernelGGL((k_bvh_distance<T, true>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q, spill);
   } else {
     hipLaunchKernelGGL((k_bvh_distance<T, false>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q, spill);
+    if (spill.budget) hipLaunchKernelGGL((k_bvh_distance_coop<T>), dim3(std::max(1, std::min(grid, int(spill.max_blocks)))), dim3(64), 0, st, wk, lv, bv, io, spill);
   }
 }
 template <typename T>

@@ -588,6 +588,39 @@ def test_bvh_distance(pkg, oracle, seg, n, hw):
     assert np.abs(np.linalg.norm(got["p2"][pos] - got["p1"][pos], axis=1) - got["distance"][pos]).max() < 1e-7
 
 
+def test_bvh_distance_wave_continuation(pkg, oracle, monkeypatch):
+    """distance() walks past their step budget are continued by a wave (k_bvh_distance_coop: 64 stack entries per trip, triangle
+    pairs in front of the first pair that is split visited together and applied in order).  With a budget of 16 steps (every
+    query continues there), the default and "never" the minimum, the triangle ids and the witness points are the same,
+    and the oracle's."""
+    abi, wl, bb = pkg.abi, pkg.workloads, pkg.bvh_builder
+    b = wl.cfg4_mesh_mesh_distance(n=3000, seed=4)
+    ML = bb.MeshLibrary(b.meshes)
+    ref = oracle.bvh_distance_batch(ML, b.s1, b.s2, b.tf1, b.tf2, n_threads=32)
+    res = {}
+    for budget in ("16", "1024", "0"):
+        monkeypatch.setenv("HFCL_BVHD_BUDGET", budget)
+        lib = wl.make_library(pkg, b)
+        try:
+            res[budget] = lib.distance(b.s1, b.s2, b.tf1, b.tf2)
+        finally:
+            lib.close()
+    for budget, got in res.items():
+        assert not np.any((got["status"] >> 30) & 1)
+        assert np.abs(got["distance"] - ref["distance"]).max() < 1e-9, budget
+    base = res["0"]
+    pos = ref["distance"] > 1e-9
+    assert 0.4 < pos.mean() < 0.95
+    for budget in ("16", "1024"):
+        got = res[budget]
+        # (two inlined copies of the triangle-pair distance may contract their FMAs differently: among triangle pairs that share
+        # the nearest vertex or edge another one can come out smaller by an ulp)
+        same = (got["b1"] == base["b1"]) & (got["b2"] == base["b2"])
+        assert same[pos].mean() > 0.97, budget
+        assert np.abs(got["distance"] - base["distance"]).max() < 1e-12
+        assert np.abs(got["p1"][pos] - base["p1"][pos]).max() < 1e-6 and np.abs(got["p2"][pos] - base["p2"][pos]).max() < 1e-6
+
+
 def _mesh_batch(pkg, meshes, n, seed, half_width):
     wl, g = pkg.workloads, pkg.geometry
     rng = np.random.default_rng(seed)
