@@ -55,7 +55,8 @@ constexpr int B_CURVED0 = B_COUNT + 4;
 // + the two counters of the one-query-per-lane mesh x solid form (its ticket, the length of its EPA queue)
 constexpr int CTR_SHAPE_TICKET = 2 * B_COUNT + 4, CTR_SHAPE_DEFER = 2 * B_COUNT + 5;
 constexpr int CTR_DIST_SUSP = 2 * B_COUNT + 6;  // suspended mesh x mesh distance() walks (DistSusp records)
-constexpr int N_COUNTERS = 2 * B_COUNT + 7;  // bucket populations + the four counters of Work::counts + curved populations + those two
+constexpr int CTR_SHAPE_DIST_SUSP = 2 * B_COUNT + 7;  // ... mesh x solid (ShapeDistSusp records)
+constexpr int N_COUNTERS = 2 * B_COUNT + 8;  // bucket populations + the four counters of Work::counts + curved populations + those two
 
 // Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
 // support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
@@ -728,6 +729,14 @@ constexpr int BS_STACK = 128;
 // entries: models up to 19 levels deep (5 000 triangles: 16); deeper ones take the wide form with its global slabs.
 constexpr int BVHD_STACK = 40;
 constexpr int BVHD_BLOCK = 64;   // k_bvh_distance
+template <typename T>
+struct ShapeDistSusp {  // a suspended mesh x solid distance() walk (the witness of the minimum is in the query's record)
+  uint32_t pair, sp;
+  int32_t fb1, pad_;
+  T mind;
+  uint32_t entry[BVHD_STACK];  // mesh nodes, bottom first
+  T bound[BVHD_STACK];
+};
 template <typename T>
 struct DistSusp {  // a suspended mesh x mesh distance() walk
   uint32_t pair, sp;

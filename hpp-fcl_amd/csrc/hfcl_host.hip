@@ -111,6 +111,9 @@ struct hfcl_lib {
   uint32_t bvhd_budget = 1024;    // HFCL_BVHD_BUDGET (cfg4d 100k queries, budgets 0 / 32 / 256 / 1024 / 4096 / 8192: 101.5 / 59.3 / 58.0 / 55.7 / 67.1 / 92.0 ms; profiles/r03_k)
   void* d_dist_susp = nullptr;    // DistSusp<double>[dist_susp_capacity]
   size_t dist_susp_capacity = 0;
+  uint32_t shape_dist_budget = 256;  // HFCL_SHAPE_DIST_BUDGET: the same for mesh x solid (a GJK leaf counts 16 steps; k_bvh_shape_distance_coop)
+  void* d_shape_dist_susp = nullptr;
+  size_t shape_dist_susp_capacity = 0;
   // host-call staging: PIPE_SLOTS device buffer sets of `st_capacity` pairs each (a chunk of a host batch), three streams
   // (H2D | kernels | D2H) and per-slot events / pinned counter blocks (host_batch)
   static constexpr int PIPE_SLOTS = 6;  // (three left the feeder waiting for records to leave: profiles/r03_c)
@@ -429,6 +432,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_SHAPE_COOP")) lib->shape_coop = atoi(v) != 0;
   if (const char* v = getenv("HFCL_BVH_COOP")) lib->bvh_coop = atoi(v) != 0;
   if (const char* v = getenv("HFCL_BVHD_BUDGET")) lib->bvhd_budget = uint32_t(std::max(0, atoi(v)));
+  if (const char* v = getenv("HFCL_SHAPE_DIST_BUDGET")) lib->shape_dist_budget = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_BUDGET0_COOP")) lib->bvh_budget0_coop = uint32_t(std::max(1, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_BUDGET0")) lib->shape_budget0 = lib->shape_budget0_coop = uint32_t(atoi(v));
   if (const char* v = getenv("HFCL_SHAPE_BUDGET")) lib->shape_budget = uint32_t(atoi(v));
@@ -475,6 +479,7 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_shape_defer);
   hipFree(lib->d_shape_oq);
   hipFree(lib->d_dist_susp);
+  hipFree(lib->d_shape_dist_susp);
   if (lib->h_pack) hipHostFree(lib->h_pack);
   if (lib->h_pack_counts) hipHostFree(lib->h_pack_counts);
   hipFree(lib->d_pack);
@@ -1149,8 +1154,25 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       tend();
     } else {
       tbeg("k_bvh_shape_distance");
-      if (shape_fast_d)
-        launch_bvh_shape_distance_fast<T>(blocks_for(n, BVHD_BLOCK), blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q);
+      if (shape_fast_d) {
+        // long walks are handed to waves -- unless their leaves hand a cached guess on, or the final guess is read
+        BvhSpill ss;
+        memset(&ss, 0, sizeof(ss));
+        if (lib->shape_dist_budget && q.guess_mode != HFCL_GUESS_CACHED && !io.gout) {
+          if (lib->ws_capacity > lib->shape_dist_susp_capacity) {
+            hipFree(lib->d_shape_dist_susp);
+            lib->d_shape_dist_susp = nullptr;
+            lib->shape_dist_susp_capacity = 0;
+            HIP_TRY(hipMalloc(&lib->d_shape_dist_susp, lib->ws_capacity * sizeof(ShapeDistSusp<double>)));
+            lib->shape_dist_susp_capacity = lib->ws_capacity;
+          }
+          ss.susp = lib->d_shape_dist_susp;
+          ss.susp_count = lib->d_counts + CTR_SHAPE_DIST_SUSP;
+          ss.budget = lib->shape_dist_budget;
+          ss.max_blocks = uint32_t(lib->n_cus) * 8u;
+        }
+        launch_bvh_shape_distance_fast<T>(blocks_for(n, BVHD_BLOCK), blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, ss);
+      }
       else
         launch_bvh_shape_distance<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q);
       tend();

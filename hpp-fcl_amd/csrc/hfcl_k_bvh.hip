@@ -1594,7 +1594,7 @@ __global__ void __launch_bounds__(64) k_bvh_shape_distance(Work wk, LibView<T> l
 #endif
 template <typename T>
 __global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8)))
-k_bvh_shape_distance_lane(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q) {
+k_bvh_shape_distance_lane(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhSpill spill) {
   constexpr int STACK = BVHD_STACK;
   typedef typename std::conditional<sizeof(T) == 8, uint32_t, float>::type BD;
   __shared__ uint32_t stack_e[STACK][BVHD_BLOCK];
@@ -1620,7 +1620,7 @@ k_bvh_shape_distance_lane(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
   const T nanv = Lim<T>::nan();
   bool live = false, pending = false, exhausted = false, swapped = false, overflow = false, unsupported = false, deferred = false;
   bool have_leaf = false;
-  uint32_t pair = 0, solid_id = 0, leaf_prim = 0;
+  uint32_t pair = 0, solid_id = 0, leaf_prim = 0, steps = 0;
   DMesh m1 = {0, 0, 0, 0};
   Pose<T> tfm;
   tfm.R.r0 = tfm.R.r1 = tfm.R.r2 = tfm.t = mk<T>(T(0), T(0), T(0));
@@ -1691,6 +1691,7 @@ k_bvh_shape_distance_lane(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
           mind = Lim<T>::max();
           fb1 = -1;
           overflow = deferred = have_leaf = false;
+          steps = 0;
           guess = initial_guess<T>(io, q, pair);
           const T probe = table[pair].r;
           unsupported = !(probe == probe);
@@ -1715,10 +1716,26 @@ k_bvh_shape_distance_lane(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
     // lanes do (or nobody can walk) and the wave runs the leaves together (k_bvh_distance, whose triangle pairs cost what a
     // BV step costs, evaluates them where they are popped).
     for (;;) {
+      if (spill.budget && live && sp > 0 && !have_leaf && steps >= spill.budget) {
+        // a long walk: its stack and its minimum go to a record, a wave takes it over (k_bvh_shape_distance_coop)
+        ShapeDistSusp<T>* r = reinterpret_cast<ShapeDistSusp<T>*>(spill.susp) + atomicAdd(spill.susp_count, 1u);
+        r->pair = pair;
+        r->sp = uint32_t(sp);
+        r->fb1 = fb1;
+        r->pad_ = 0;
+        r->mind = mind;
+        for (int k = 0; k < sp; ++k) {
+          r->entry[k] = stack_e[k][tid];
+          r->bound[k] = bound_value(stack_d[k][tid]);
+        }
+        sp = 0;
+        deferred = true;  // (no record from this lane)
+      }
       const bool run = live && sp > 0 && !have_leaf;
       const int n_run = __popcll(__ballot(run)), n_wait = __popcll(__ballot(have_leaf));
       if (n_run == 0 || n_wait >= HFCL_BSD_PARK_MIN || (!exhausted && 64 - n_run - n_wait >= BVH_REFILL_MIN)) break;
       if (!run) continue;
+      ++steps;
       --sp;
       const uint32_t b = stack_e[sp][tid];
       const BD dc = stack_d[sp][tid];
@@ -1732,6 +1749,7 @@ k_bvh_shape_distance_lane(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
       const int32_t fc = bv.nodes[m1.node_off + b].first_child;
       if (fc < 0) {
         have_leaf = true;
+        steps += 15;  // (a GJK leaf counts sixteen steps)
         leaf_prim = uint32_t(-(fc + 1));
         continue;
       }
@@ -1753,6 +1771,160 @@ k_bvh_shape_distance_lane(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
     if (have_leaf) {
       have_leaf = false;
       leaf(leaf_prim);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_bvh_shape_distance_coop: the long mesh x solid distance() walks, a wave per query (the scheme of k_bvh_distance_coop below;
+// the triangles in front of the first node that is split run their leaves -- per-lane GJK -- side by side; a triangle that
+// needs EPA ends the walk as in the lane kernel: only the FIRST such triangle in stack order queues its item).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
+k_bvh_shape_distance_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhSpill spill) {
+  constexpr int CAP = 960, SLACK = 64;
+  __shared__ uint32_t stack_e[CAP + SLACK];
+  __shared__ T stack_d[CAP + SLACK];
+  __shared__ T w0_slab[W0Lds<T, 64>::WORDS];
+  const W0Lds<T, 64> leaf_ps{w0_slab + threadIdx.x};
+  const int lane = threadIdx.x;
+  const uint32_t n_susp = *spill.susp_count;
+  const RssQuery<T>* const table = reinterpret_cast<const RssQuery<T>*>(wk.shape_oq);
+  const T big = Lim<T>::max();
+  for (uint32_t qi = blockIdx.x; qi < n_susp; qi += gridDim.x) {
+    const ShapeDistSusp<T>* const r = reinterpret_cast<const ShapeDistSusp<T>*>(spill.susp) + qi;
+    const uint32_t pair = r->pair;
+    const uint32_t id1 = wk.shape1[pair], id2 = wk.shape2[pair];
+    const bool swapped = lib.kinds[id1] != uint8_t(K_BVH);
+    const uint32_t solid_id = swapped ? id1 : id2;
+    const DMesh m1 = bv.meshes[lib.shapes[swapped ? id2 : id1].bvh_index];
+    const Pose<T> tfm = load_pose(swapped ? io.tf2 : io.tf1, pair);
+    const RssQuery<T> rq = table[pair];
+    DNode<T> n2;
+    n2.axes = rq.axes;
+    DRss<T> r2;
+    r2.Tr = rq.Tr;
+    r2.l0 = rq.l0;
+    r2.l1 = rq.l1;
+    r2.r = rq.r;
+    auto bound_of = [&](uint32_t b) -> T { return rss_lower_bound(tfm.R, tfm.t, n2, r2, bv.nodes[m1.node_off + b], bv.rss[m1.node_off + b]); };
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int sp = int(r->sp);
+    if (lane < sp) {
+      stack_e[lane] = r->entry[lane];
+      stack_d[lane] = r->bound[lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    T mind = r->mind;
+    int fb1 = r->fb1;
+    bool overflow = false, deferred = false;
+    const V3<T> guess0 = initial_guess<T>(io, q, pair);  // (walks whose leaves hand a cached guess on are not suspended)
+    V3<T> guess = guess0;
+    while (sp > 0) {
+      const int w = min(64, min(sp, max(CAP - sp, 1)));
+      const bool act = lane < w;
+      const uint32_t b = act ? stack_e[sp - 1 - lane] : 0u;
+      const T db = act ? stack_d[sp - 1 - lane] : big;
+      sp -= w;
+      const bool alive = act && !(db >= T(0) && db >= mind);  // canStop(d), with the minimum of the moment
+      const int32_t fc = alive ? bv.nodes[m1.node_off + b].first_child : 0;
+      const bool is_leaf = alive && fc < 0, split = alive && fc >= 0;
+      T d1 = big, d2 = big;
+      if (split) {
+        d1 = bound_of(uint32_t(fc));
+        d2 = bound_of(uint32_t(fc) + 1u);
+      }
+      const uint64_t smask = __ballot(split);
+      const int f = smask ? __ffsll((unsigned long long)smask) - 1 : 64;  // the triangles in front of it are visited now
+      const bool visit = is_leaf && lane < f;
+      T val = big;
+      bool to_epa = false;
+      SolidLeafOut<T> lo;
+      lo.distance = big;
+      const uint32_t prim = uint32_t(-(fc + 1));
+      auto run_leaf = [&](bool push, T bound, int prev) -> bool {
+        SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + prim), lib.shapes, lib.verts,
+                          swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, push ? reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer) : nullptr,
+                          push ? &wk.counts[CTR_SHAPE_DEFER] : nullptr, pair, solid_id, prim, 0xFFFFFFFFu, 0u, bound, prev};
+        return solid_leaf_call<T>(in, &q, leaf_ps, guess0, &lo);
+      };
+      if (visit) {
+        to_epa = run_leaf(false, T(0), -1);
+        if (!to_epa) val = lo.distance;
+      }
+      // The evaluated triangles, in stack order, exactly as the lane's walk takes them: a triangle counts only if its bound does
+      // not let it be skipped at ITS turn (canStop with the minimum as it stands then -- a bound is clamped at 0, so after a
+      // penetration every bounded entry is skipped, and the bounds of unbounded solids are NaN and never skip), the minimum is
+      // lowered by strictly smaller distances only, and a counted triangle that needs EPA ends the walk.
+      const uint64_t emask = __ballot(to_epa);
+      int start = 0, src = -1;
+      bool epa_end = false;
+      T run = mind;
+      for (;;) {
+        const uint64_t em = emask & ~((uint64_t(1) << start) - 1);
+        const int c = em ? __ffsll((unsigned long long)em) - 1 : 64;  // the next triangle that needs EPA
+        for (;;) {  // the record-setting triangles in front of it
+          const bool cand = visit && !to_epa && lane >= start && lane < c && !(db >= T(0) && db >= run) && val < run;
+          const uint64_t m = __ballot(cand);
+          if (!m) break;
+          src = __ffsll((unsigned long long)m) - 1;
+          run = __shfl(val, src);
+          start = src + 1;
+        }
+        if (c >= 64) break;
+        const T dbc = __shfl(db, c);
+        if (!(dbc >= T(0) && dbc >= run)) {  // it is visited: the walk ends here
+          epa_end = true;
+          start = c;
+          break;
+        }
+        start = c + 1;  // (skipped like any entry whose bound cannot beat the minimum)
+        if (start >= 64) break;
+      }
+      if (src >= 0) {  // DistanceResult::update
+        mind = run;
+        fb1 = __shfl(int(prim), src);
+        if (lane == src) store_witness(io, pair, swapped ? lo.p2 : lo.p1, swapped ? lo.p1 : lo.p2, swapped ? -lo.n : lo.n);
+        guess = mk<T>(__shfl(lo.guess.x, src), __shfl(lo.guess.y, src), __shfl(lo.guess.z, src));
+      }
+      if (epa_end) {
+        if (lane == start) run_leaf(true, mind, fb1);  // its leaf once more, with the EPA item: k_bvh_shape_finish writes the record
+        deferred = true;
+        sp = 0;
+        break;
+      }
+      // the stack again, in order: visited triangles and dropped entries are gone, a split node is its two children (the
+      // nearer one on top), a triangle behind the first split stays
+      const int cnt = split ? 2 : ((is_leaf && lane >= f) ? 1 : 0);
+      const uint64_t m2b = __ballot(cnt == 2), m1b = __ballot(cnt == 1);
+      const uint64_t deeper = ~((uint64_t(2) << lane) - 1);
+      const int pos = sp + 2 * __popcll(m2b & deeper) + __popcll(m1b & deeper);
+      if (cnt == 2) {
+        const uint32_t a1 = uint32_t(fc), c1 = a1 + 1u;
+        const bool c_first = d2 < d1;  // the nearer child is visited first
+        stack_e[pos] = c_first ? a1 : c1;
+        stack_d[pos] = c_first ? d1 : d2;
+        stack_e[pos + 1] = c_first ? c1 : a1;
+        stack_d[pos + 1] = c_first ? d2 : d1;
+      } else if (cnt == 1) {
+        stack_e[pos] = b;
+        stack_d[pos] = db;
+      }
+      sp += 2 * __popcll(m2b) + __popcll(m1b);
+      if (sp > CAP + SLACK - 2) {
+        overflow = true;
+        sp = 0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && !deferred) {
+      // b1 = the triangle, b2 = NONE whatever the operand order (distance.cpp:84-88 swaps o1 / o2 only)
+      store_bvh_record_head(io, pair, mind, mind <= T(0) ? 0x80000000u : 0u, fb1, -1, overflow);
+      write_guess<T>(io, pair, guess, 0, 0);
     }
   }
 }
@@ -2089,14 +2261,27 @@ k_bvh_distance_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, BvhSpill s
                                       mul(RT_R, vtx(v2, t2[1])) + RT_T, mul(RT_R, vtx(v2, t2[2])) + RT_T, P, Q);
         val = hsqrt(dd);
       }
-      const T wmin = group_min_all<T, 64>(val);
-      if (wmin < mind) {  // DistanceResult::update: the first triangle pair in order that attains the new minimum
-        const int src = __ffsll((unsigned long long)__ballot(visit && val == wmin)) - 1;
-        mind = wmin;
-        fb1 = __shfl(int(lb1), src);
-        fb2 = __shfl(int(lb2), src);
-        np1 = mk<T>(__shfl(P.x, src), __shfl(P.y, src), __shfl(P.z, src));
-        np2 = mk<T>(__shfl(Q.x, src), __shfl(Q.y, src), __shfl(Q.z, src));
+      // The evaluated triangle pairs, in stack order, exactly as the lane's walk takes them: a pair counts only if its bound does
+      // not let it be skipped at ITS turn (canStop with the minimum as it stands then), and the minimum is lowered by strictly
+      // smaller distances only (DistanceResult::update)
+      {
+        int start = 0, src = -1;
+        T run = mind;
+        for (;;) {
+          const bool cand = visit && lane >= start && !(db >= T(0) && db >= run) && val < run;
+          const uint64_t m = __ballot(cand);
+          if (!m) break;
+          src = __ffsll((unsigned long long)m) - 1;
+          run = __shfl(val, src);
+          start = src + 1;
+        }
+        if (src >= 0) {
+          mind = run;
+          fb1 = __shfl(int(lb1), src);
+          fb2 = __shfl(int(lb2), src);
+          np1 = mk<T>(__shfl(P.x, src), __shfl(P.y, src), __shfl(P.z, src));
+          np2 = mk<T>(__shfl(Q.x, src), __shfl(Q.y, src), __shfl(Q.z, src));
+        }
       }
       // the stack again, in order: visited triangle pairs and dropped entries are gone, a split pair is its two successors
       // (the nearer one on top), a triangle pair behind the first split stays
@@ -2223,9 +2408,10 @@ void launch_bvh_shape(int grid, hipStream_t st, const Work& wk, const LibView<T>
 }
 // mesh x solid distance(), one query per lane
 template <typename T>
-void launch_bvh_shape_distance_fast(int grid, int grid_finish, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q) {
+void launch_bvh_shape_distance_fast(int grid, int grid_finish, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, BvhSpill spill) {
   hipLaunchKernelGGL((k_shape_obbrss<T>), dim3(std::max(1, grid / 4)), dim3(256), 0, st, wk, lv, io);
-  hipLaunchKernelGGL((k_bvh_shape_distance_lane<T>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q);
+  hipLaunchKernelGGL((k_bvh_shape_distance_lane<T>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q, spill);
+  if (spill.budget) hipLaunchKernelGGL((k_bvh_shape_distance_coop<T>), dim3(std::max(1, std::min(grid, int(spill.max_blocks)))), dim3(64), 0, st, wk, lv, bv, io, q, spill);
   BvhSplit none;
   memset(&none, 0, sizeof(none));
   BvhParams bp;
@@ -2270,7 +2456,7 @@ void launch_triangle(int grid, hipStream_t st, const Work& wk, const LibView<T>&
   template void launch_bvh_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, BvhSpill);                \
   template void launch_bvh_shape<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T);   \
   template void launch_bvh_shape_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&);          \
-  template void launch_bvh_shape_distance_fast<T>(int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&); \
+  template void launch_bvh_shape_distance_fast<T>(int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, BvhSpill); \
   template void launch_bvh_shape_fast<T>(int, int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill); \
   template void launch_triangle<T>(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&);
 HFCL_INST(float)

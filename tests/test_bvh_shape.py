@@ -462,6 +462,15 @@ def test_gpu_mesh_solid_distance_long_walks(pkg, oracle, kind):
             lib.close()
 
     got, group = run({}), run(dict(HFCL_BVH_SHAPE_LANE="0"))
+    # long walks are continued by waves (k_bvh_shape_distance_coop): with a budget of 16 steps nearly every walk is, with 0 none
+    # -- the same minimum, triangle and witness either way (the continuation applies the triangles in the lane's order)
+    tiny, whole = run(dict(HFCL_SHAPE_DIST_BUDGET="16")), run(dict(HFCL_SHAPE_DIST_BUDGET="0"))
+    for other in (tiny, whole):
+        assert np.array_equal(other["status"], got["status"])
+        sepq = ref["distance"] > 1e-6
+        assert np.abs(other["distance"][sepq] - got["distance"][sepq]).max() < 1e-12
+        assert (other["b1"][sepq] == got["b1"][sepq]).mean() > 0.99  # (two inlined copies of the leaf: an ulp among tied triangles)
+        assert (other["distance"][~sepq] <= 1e-9).all() == (got["distance"][~sepq] <= 1e-9).all()
     for r in (got, group):
         assert not ((r["status"] >> 30) & 1).any()
         sep = ref["distance"] > 1e-6
