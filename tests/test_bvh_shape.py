@@ -289,6 +289,30 @@ def test_gpu_mesh_solid_guesses(pkg, oracle, cached):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["box", "capsule"])
+def test_gpu_mesh_solid_margin_forms_agree(pkg, oracle, kind):
+    """A security margin on the one-query-per-lane path (contacts without penetration: no EPA leaf; bounds shifted by the margin):
+    wave continuation (budget 8), task levels and walks in one piece against the oracle."""
+    abi, bb = pkg.abi, pkg.bvh_builder
+    b = pkg.workloads.mesh_vs_solid(kind, n=4000, seed=8)
+    ML = bb.MeshLibrary(b.meshes)
+    req = abi.default_collision_request()
+    req.security_margin = 0.04
+    ref, _ = oracle.mixed_collide_batch(b.shapes, b.verts, ML, b.s1, b.s2, b.tf1, b.tf2, req, max_contacts=10 ** 5, n_threads=16)
+    near = np.abs(ref["distance"] - 0.04) < 1e-9
+    for env in (dict(HFCL_SHAPE_BUDGET0="8"), dict(HFCL_SHAPE_COOP="0", HFCL_SHAPE_BUDGET0="8", HFCL_SHAPE_BUDGET="8"), dict(HFCL_SHAPE_LEVELS="1")):
+        got = _device_collide(pkg, b, req, env=env)
+        assert ((got["num_contacts"] == ref["num_contacts"]) | near).all(), env
+        m = ~near
+        assert np.array_equal(got["b1"][m], ref["b1"][m]) and np.array_equal(got["b2"][m], ref["b2"][m]), env
+        hit = m & (ref["num_contacts"] > 0)
+        assert hit.sum() > 400 and np.abs(got["distance"][hit] - ref["distance"][hit]).max() < 4e-6, env
+        if kind == "box":
+            free = m & (ref["num_contacts"] == 0) & (np.abs(ref["distance"]) < 1e300)
+            assert np.abs(got["distance"][free] - ref["distance"][free]).max() < 4e-6, env
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["sphere", "box", "capsule", "ellipsoid", "convex32"])
 def test_gpu_mesh_solid_long_walks(pkg, oracle, kind):
     """Mesh x solid at the size of cfg4's models (5 000 triangles): walks of thousands of steps, which the one-query-per-lane
