@@ -18,9 +18,15 @@
 //   k_epa_stream<T,WE,CAP>  tier 1 for fp32: same blocks, but a lane group whose polytope is done starts the
 //                    wave's next item instead of waiting for the slowest of the 8
 //   k_bvh_collide<T> / k_bvh_distance<T>   BVHModel<OBBRSS> x BVHModel<OBBRSS>: one mesh pair per lane,
-//                    explicit DFS stack in LDS (reference order), OBB SAT / RSS bounds, triangle-triangle leaves
-//   k_bvh_shape<T> / k_bvh_shape_distance<T>   BVHModel<OBBRSS> x convex solid or Plane/Halfspace: one query
-//                    per 16-lane group, sequential traversal, leaves = TriangleP-vs-solid GJK + EPA in LDS
+//                    explicit DFS stack in LDS (reference order), OBB SAT / RSS bounds, triangle-triangle leaves;
+//                    a walk past its step budget is continued by a wave, 64 stack entries per trip
+//                    (k_bvh_coop<T> / k_bvh_distance_coop<T>)
+//   k_bvh_collide<T,SOLID> + k_shape_obb<T> + k_bvh_shape_coop<T> + k_bvh_shape_finish<T> (collide, first contact) and
+//   k_bvh_shape_distance_lane<T> + k_shape_obbrss<T> + k_bvh_shape_distance_coop<T> (distance)
+//                    BVHModel<OBBRSS> x convex solid or Plane/Halfspace the same way: one query per lane, per-lane GJK
+//                    leaves, the leaves that need EPA from a queue
+//   k_bvh_shape<T> / k_bvh_shape_distance<T>   ... one query per 16-lane group, sequential traversal, leaves =
+//                    TriangleP-vs-solid GJK + EPA in LDS: requests that keep walking after a contact
 //   k_unsupported<T> flags the pairs of a bucket the engine cannot evaluate (never computed elsewhere)
 #include <algorithm>
 #include <chrono>

@@ -10,8 +10,15 @@
 //                    k_gjk_large<T>   GJK when a hull has more than 32 vertices (scan / hill-climb from memory)
 //                    k_unsupported<T>, k_fill_skipped
 //   hfcl_k_epa.hip   k_epa<T,WE,CAP,TIER>, k_epa_stream<T,WE,CAP>   EPA on the pairs GJK left in `Collision`
-//   hfcl_k_bvh.hip   k_bvh_collide<T> / k_bvh_distance<T>   BVHModel<OBBRSS> x BVHModel<OBBRSS>
-//                    k_bvh_shape<T> / k_bvh_shape_distance<T>   BVHModel<OBBRSS> x convex solid or Plane/Halfspace
+//   hfcl_k_bvh.hip   k_bvh_collide<T> / k_bvh_distance<T>   BVHModel<OBBRSS> x BVHModel<OBBRSS>, one query per lane for a step
+//                                     budget; k_bvh_coop<T> / k_bvh_distance_coop<T>: the queries past it, a wave each,
+//                                     64 stack entries per trip (k_bvh_combine<T>: the task-level alternative)
+//                    k_shape_obb<T>, k_bvh_collide<T, ., ., SOLID>, k_bvh_shape_coop<T>, k_bvh_shape_finish<T>
+//                                     BVHModel<OBBRSS> x convex solid, first-contact collide(): the solids' OBBs, the walk
+//                                     (lane, then wave), the leaves that need EPA
+//                    k_shape_obbrss<T>, k_bvh_shape_distance_lane<T>, k_bvh_shape_distance_coop<T>   ... distance()
+//                    k_bvh_shape<T> / k_bvh_shape_distance<T>   the same rows, one 16-lane group per query: requests that
+//                                     keep walking after a contact, models deeper than the lanes' stacks
 //                    k_triangle<T>    top-level TriangleP pairs
 //
 // Every launcher is asynchronous on `st` and does no error checking of its own (run_batch_one checks hipGetLastError once).

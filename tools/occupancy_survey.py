@@ -18,7 +18,8 @@ CSRC = os.path.join(ROOT, "hpp-fcl_amd", "csrc")
 FLAGS = {"k_gjk": "-fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt",
          "k_epa": "-fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt -ffp-contract=on", "k_bvh": "", "k_util": ""}
 BLOCK = {"k_bvh_collide": 128, "k_bvh_distance": 64, "k_bvh_shape": 64, "k_bvh_shape_distance": 64, "k_triangle": 64, "k_epa": 64,
-         "k_epa_stream": 64, "k_classify": 1024}
+         "k_epa_stream": 64, "k_classify": 1024, "k_bvh_coop": 64, "k_bvh_shape_coop": 64, "k_bvh_distance_coop": 64,
+         "k_bvh_shape_distance_coop": 64, "k_bvh_shape_distance_lane": 64, "k_bvh_shape_finish": 64, "k_bvh_level_mark": 64}
 
 
 def main():
