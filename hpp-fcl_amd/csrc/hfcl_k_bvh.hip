@@ -1136,15 +1136,29 @@ __device__ __forceinline__ T group_min_all(T v) {
 #endif
 constexpr int COOP_W = HFCL_COOP_W;
 constexpr int COOP_CAP = 448, COOP_SLACK = 64;  // entries of a query's stack: a full stack narrows the window down to plain DFS, which needs the tree's depth more
+// What is known about a stack entry travels with it (two bits of the entry word + a value): a box found disjoint keeps its
+// bound, a triangle its distance -- its result does not depend on the walk's state (the leaf solver starts from the
+// request's guess).  A trip with a triangle in it costs a GJK run whatever the number of lanes that have one, so triangles
+// are EVALUATED when HFCL_COOP_LEAF_BATCH lanes of the window hold an unevaluated one or the window has no box left to
+// split, wherever they stand -- and VISITED (applied to the walk's state) later, when everything in front of them is done.
+// 100k queries per kind, batch 16 / 32 / 64: ellipsoid 7.1 / 6.2 / 5.5 ms, convex32 5.3 / 4.5 / 3.9, cylinder 3.6 / 3.2 / 2.7
+// (evaluated where they are visited: 8.1 / 6.2 / 3.8; evaluating whenever the TOP entry is an unevaluated triangle, the first
+// form of this idea, gained nothing: nearly every trip then has one) -- profiles/r03_k.
+#ifndef HFCL_COOP_LEAF_BATCH
+#define HFCL_COOP_LEAF_BATCH 64
+#endif
+constexpr uint32_t COOP_NODE = 0x3FFFFFFFu, COOP_DISJOINT = 1u << 30, COOP_LEAF = 2u << 30, COOP_LEAF_EPA = 3u << 30;
 template <typename T>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhParams bp, T break_distance2, BvhSplit split) {
   constexpr int W = COOP_W, G = 64 / W;
   __shared__ uint32_t stacks[G][COOP_CAP + COOP_SLACK];
+  __shared__ T values[G][COOP_CAP + COOP_SLACK];
   __shared__ T w0_slab[W0Lds<T, 64>::WORDS];
   const W0Lds<T, 64> leaf_ps{w0_slab + threadIdx.x};
   const int lane = threadIdx.x, grp = lane / W, lig = lane & (W - 1);
   uint32_t* const stack = stacks[grp];
+  T* const value = values[grp];
   const uint64_t gbits = W == 64 ? ~uint64_t(0) : ((uint64_t(1) << (W & 63)) - 1);
   auto gballot = [&](bool x) -> uint64_t { return (__ballot(x) >> (grp * W)) & gbits; };  // the group's lanes, bit 0 = its first lane
   const uint32_t n_susp = min(split.ctr[BVH_CTR_SUSPENDED], split.n_queries);
@@ -1160,6 +1174,13 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
   int sp = 0, fb = -1;
   T dlb = big, rec_dist = big;
   V3<T> np1 = oq.V, np2 = oq.V, nn = oq.V, guess0 = oq.V;
+  // a triangle's leaf; push: with the EPA item if it needs one
+  auto run_leaf = [&](uint32_t prim, bool push, SolidLeafOut<T>* lo) -> bool {
+    SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + prim), lib.shapes, lib.verts,
+                      swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, push ? reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer) : nullptr,
+                      push ? &wk.counts[CTR_SHAPE_DEFER] : nullptr, pair, solid_id, prim, 0xFFFFFFFFu, 0u, T(0), -1};
+    return solid_leaf_call<T>(in, &q, leaf_ps, guess0, lo);
+  };
   for (;;) {
     if (!have && qi < n_susp) {
       const BvhSum<T> s = *bvh_sum<T>(split, qi);
@@ -1191,98 +1212,116 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
     if (have && sp > 0) {
       const int w = min(W, min(sp, max(COOP_CAP - sp, 1)));
       const bool act = lig < w;
-      const uint32_t e = act ? stack[sp - 1 - lig] : 0u;
+      const uint32_t ew = act ? stack[sp - 1 - lig] : 0u;
+      T val = act ? value[sp - 1 - lig] : big;  // (meaningful for tagged entries only)
       sp -= w;
+      const uint32_t e = ew & COOP_NODE;
+      uint32_t tag = ew & ~COOP_NODE;
+      // (1) entries nothing is known about yet: a box is tested -- an overlapping one only refines the stack (its children
+      // take its place, at any position), a disjoint one keeps its bound; a triangle waits for the leaf batch
       const DNode<T>* const np = bv.nodes + m1.node_off + e;
-      const int32_t fc = act ? np->first_child : 0;
-      const bool is_leaf = act && fc < 0, is_int = act && fc >= 0;
-      // (1) every box of the window is tested; an overlapping box only refines the stack (its children take its place), at
-      // any position.  What an entry does to the walk's state -- a disjoint box's bound, a triangle's result -- depends on
-      // everything before it in DFS order, which includes the subtrees of overlapping boxes ahead of it: only the entries
-      // in front of the window's FIRST overlapping box are visited in this trip, the others stay for a later one.
-      T val = big, recv = big;  // what this entry would set the bound to, and the recorded distance that goes with it
-      bool overlap = false;
-      if (is_int) {
-        const DNode<T> n1 = *np;
-        T sq;
-        if (obb_disjoint_q(oq, n1, q.security_margin, break_distance2, sq)) {  // updateDistanceLowerBoundFromBV
-          const T nd = hsqrt(sq);
-          val = nd;
-          recv = nd + q.security_margin;
+      int32_t fc = 0;
+      bool overlap = false, pending = false;
+      if (act && tag == 0u) {
+        fc = np->first_child;
+        if (fc >= 0) {
+          const DNode<T> n1 = *np;
+          T sq;
+          if (obb_disjoint_q(oq, n1, q.security_margin, break_distance2, sq)) {
+            val = hsqrt(sq);
+            tag = COOP_DISJOINT;
+          } else {
+            overlap = true;
+          }
         } else {
-          overlap = true;
+          pending = true;
         }
       }
-      const uint64_t omask = gballot(overlap);
-      const int f = omask ? __ffsll((unsigned long long)omask) - 1 : W;  // entries [0, f) are visited now
-      bool visit = act && lig < f;
-      // (2) their triangles (no EPA item yet: several triangles of the window may penetrate, only the first in order is the contact)
-      bool contact = false, to_epa = false, leaf_ok = false;
+      // (2) the triangles, when enough of them wait or the window has nothing left to split
       SolidLeafOut<T> lo;
       lo.distance = big;
-      if (is_leaf && visit) {
-        const uint32_t prim = uint32_t(-(fc + 1));
-        SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + prim), lib.shapes, lib.verts,
-                          swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, nullptr, nullptr, pair, solid_id, prim, 0xFFFFFFFFu, 0u, T(0), -1};
-        to_epa = solid_leaf_call<T>(in, &q, leaf_ps, guess0, &lo);
-        if (to_epa) {
-          contact = true;
-        } else {
-          const T dtc = lo.distance - q.security_margin;  // updateDistanceLowerBoundFromLeaf
-          val = dtc;
-          recv = lo.distance;
-          contact = dtc <= q.collision_distance_threshold;
-          leaf_ok = true;
+      bool fresh = false;  // this lane ran its leaf in this trip (lo holds its witness)
+      {
+        const uint64_t pmask = gballot(pending);
+        if (pmask && (__popcll(pmask) >= HFCL_COOP_LEAF_BATCH || !gballot(overlap))) {
+          if (pending) {
+            const bool to_epa = run_leaf(uint32_t(-(fc + 1)), false, &lo);
+            val = lo.distance;
+            tag = to_epa ? COOP_LEAF_EPA : COOP_LEAF;
+            pending = false;
+            fresh = true;
+          }
         }
       }
-      // (3) the first contact in stack order ends the walk; entries behind it were never visited
-      const uint64_t cmask = gballot(contact);
-      const int c = cmask ? __ffsll((unsigned long long)cmask) - 1 : W;
-      visit = visit && lig <= c;
-      if (!visit) {
-        val = big;
-        leaf_ok = false;
+      // (3) what an entry does to the walk's state depends on everything before it in DFS order -- which includes the subtrees of
+      // overlapping boxes and the triangles still waiting ahead of it: the entries in front of the first of those are visited now
+      const uint64_t block = gballot(overlap || pending);
+      const int f = block ? __ffsll((unsigned long long)block) - 1 : W;
+      bool visit = act && lig < f;
+      const bool is_leaf = tag == COOP_LEAF || tag == COOP_LEAF_EPA;
+      T bnd = big, recv = big;  // what this entry sets the bound to, and the recorded distance that goes with it
+      bool contact = false;
+      if (visit) {
+        if (tag == COOP_DISJOINT) {  // updateDistanceLowerBoundFromBV
+          bnd = val;
+          recv = val + q.security_margin;
+        } else if (tag == COOP_LEAF) {  // updateDistanceLowerBoundFromLeaf
+          bnd = val - q.security_margin;
+          recv = val;
+          contact = bnd <= q.collision_distance_threshold;
+        } else {
+          contact = true;  // (needs EPA: a contact on the host's word)
+        }
       }
-      const T before = hmin(dlb, group_min_excl_scan<T, W>(val, lig, big));  // the bound as entry `lig` found it
-      const bool lowered = visit && val < before;
-      const T wmin = group_min_all<T, W>(val);
+      const uint64_t cmask = gballot(contact);
+      const int c = cmask ? __ffsll((unsigned long long)cmask) - 1 : W;  // the first contact in stack order ends the walk
+      visit = visit && lig <= c;
+      if (!visit) bnd = big;
+      const T before = hmin(dlb, group_min_excl_scan<T, W>(bnd, lig, big));  // the bound as entry `lig` found it
+      const bool lowered = visit && bnd < before;
+      const T wmin = group_min_all<T, W>(bnd);
       if (gballot(lowered)) {
         // the bound ends at the minimum of the visited entries, set by the first of them that reaches it
-        const int src = __ffsll((unsigned long long)gballot(visit && val == wmin)) - 1;
+        const int src = __ffsll((unsigned long long)gballot(visit && bnd == wmin)) - 1;
         dlb = wmin;
         rec_dist = __shfl(recv, src, W);
       }
-      const uint64_t wmask = gballot(lowered && leaf_ok);  // the witness: the last leaf that lowered the bound on its visit
+      // the witness: the last triangle that lowered the bound on its visit (its points, if it was evaluated in an earlier trip,
+      // by running its leaf once more); the contact's points likewise
+      const uint64_t wmask = gballot(lowered && tag == COOP_LEAF);
+      const int L = wmask ? 63 - __clzll((unsigned long long)wmask) : -1;
+      const bool is_contact_lane = c < W && lig == c;
+      if (act && is_leaf && !fresh && ((lig == L) || (is_contact_lane && tag == COOP_LEAF && bp.contacts))) {
+        fc = np->first_child;
+        run_leaf(uint32_t(-(fc + 1)), false, &lo);
+      }
       {
-        const int L = wmask ? 63 - __clzll((unsigned long long)wmask) : 0;
+        const int Ls = L < 0 ? 0 : L;
         const V3<T> a1 = swapped ? lo.p2 : lo.p1, a2 = swapped ? lo.p1 : lo.p2, an = swapped ? -lo.n : lo.n;
-        const V3<T> b1 = mk<T>(__shfl(a1.x, L, W), __shfl(a1.y, L, W), __shfl(a1.z, L, W));
-        const V3<T> b2 = mk<T>(__shfl(a2.x, L, W), __shfl(a2.y, L, W), __shfl(a2.z, L, W));
-        const V3<T> bn = mk<T>(__shfl(an.x, L, W), __shfl(an.y, L, W), __shfl(an.z, L, W));
-        if (wmask) {
+        const V3<T> b1 = mk<T>(__shfl(a1.x, Ls, W), __shfl(a1.y, Ls, W), __shfl(a1.z, Ls, W));
+        const V3<T> b2 = mk<T>(__shfl(a2.x, Ls, W), __shfl(a2.y, Ls, W), __shfl(a2.z, Ls, W));
+        const V3<T> bn = mk<T>(__shfl(an.x, Ls, W), __shfl(an.y, Ls, W), __shfl(an.z, Ls, W));
+        if (L >= 0) {
           np1 = b1;
           np2 = b2;
           nn = bn;
         }
       }
-      const int prim_c = __shfl(int(-(fc + 1)), c < W ? c : 0, W);
       if (c < W) {  // canStop()
+        if (act && is_leaf && fc == 0) fc = np->first_child;
+        const int prim_c = __shfl(int(-(fc + 1)), c, W);
         fb = prim_c;
         ncontacts = 1;
-        if (lig == c) {
-          if (to_epa) {  // the query's contact: its leaf once more, this time with the EPA item (k_bvh_shape_finish patches the record)
-            SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + uint32_t(prim_c)), lib.shapes, lib.verts,
-                              swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer),
-                              &wk.counts[CTR_SHAPE_DEFER], pair, solid_id, uint32_t(prim_c), 0xFFFFFFFFu, 0u, T(0), -1};
-            solid_leaf_call<T>(in, &q, leaf_ps, guess0, &lo);
-          } else {
+        if (is_contact_lane) {
+          if (tag == COOP_LEAF_EPA)  // its leaf once more, this time with the EPA item (k_bvh_shape_finish patches the record)
+            run_leaf(uint32_t(prim_c), true, &lo);
+          else
             emit_shape_contact(bp, pair, swapped, prim_c, lo.distance, lo.p1, lo.p2, lo.n);
-          }
         }
         sp = 0;
       } else {
         // (4) the stack again, in order (entry 0's successors on top): visited entries are gone, an overlapping box is its two
-        // children (left above right), everything else behind the first overlapping box stays as it is
+        // children (left above right), everything else stays with what is known about it
         const int cnt = !act || lig < f ? 0 : (overlap ? 2 : 1);
         const uint64_t m2 = gballot(cnt == 2), m1b = gballot(cnt == 1);
         const uint64_t deeper = ~((uint64_t(2) << lig) - 1);  // window entries behind this one (pushed first)
@@ -1291,7 +1330,8 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
           stack[pos] = uint32_t(fc) + 1u;
           stack[pos + 1] = uint32_t(fc);
         } else if (cnt == 1) {
-          stack[pos] = e;
+          stack[pos] = e | tag;
+          value[pos] = val;
         }
         sp += 2 * __popcll(m2) + __popcll(m1b);
         if (sp > COOP_CAP + COOP_SLACK - 2) {  // a tree deeper than the slack on top of a full stack: flagged, never written past the block
