@@ -654,6 +654,35 @@ def test_bvh_models_beyond_16_bit_node_ids(pkg, oracle):
     assert not np.any((gd["status"] >> 30) & 1)
     assert np.abs(gd["distance"] - rd["distance"]).max() < 1e-9
     lib.close()
+    # the same model against solids: the one-query-per-lane walk and its wave continuation carry 32-bit node ids in their entries
+    g = pkg.geometry
+    rng = np.random.default_rng(5)
+    L = g.ShapeLibrary()
+    L.add_bvh(0, len(big.vertices))
+    for _ in range(8):
+        L.add_box(*map(float, rng.uniform(0.2, 0.8, 3)))
+        L.add_capsule(float(rng.uniform(0.1, 0.3)), float(rng.uniform(0.2, 0.8)))
+    n = 1500
+    q1, T1, q2, T2 = pkg.workloads._poses(rng, n, 1.4)
+    bs = pkg.workloads.Batch("big_mesh_x_solid", L, np.zeros(n, dtype=np.int64), rng.integers(1, 17, n), q1, T1, q2, T2, "collide")
+    bs.meshes = [big]
+    MLs = bb.MeshLibrary(bs.meshes)
+    creq = abi.default_collision_request()
+    refs, _ = oracle.mixed_collide_batch(bs.shapes, bs.verts, MLs, bs.s1, bs.s2, bs.tf1, bs.tf2, creq, max_contacts=10 ** 4, n_threads=16)
+    libs = pkg.workloads.make_library(pkg, bs)
+    try:
+        gots = libs.collide(bs.s1, bs.s2, bs.tf1, bs.tf2, creq)
+        gds = libs.distance(bs.s1, bs.s2, bs.tf1, bs.tf2)
+    finally:
+        libs.close()
+    rds = oracle.mixed_distance_batch(bs.shapes, bs.verts, MLs, bs.s1, bs.s2, bs.tf1, bs.tf2, None, n_threads=16)
+    assert not np.any((gots["status"] >> 30) & 1) and not np.any((gds["status"] >> 30) & 1)
+    near = np.abs(refs["distance"]) < 1e-9
+    assert ((gots["num_contacts"] == refs["num_contacts"]) | near).all()
+    assert np.array_equal(gots["b1"][~near], refs["b1"][~near])
+    assert 0.1 < (refs["num_contacts"] > 0).mean() < 0.9
+    sep = rds["distance"] > 1e-6
+    assert sep.sum() > 300 and np.abs(gds["distance"][sep] - rds["distance"][sep]).max() < 1e-6
 
 
 @pytest.mark.parametrize("force_wide", [False, True])
