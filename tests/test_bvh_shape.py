@@ -257,6 +257,62 @@ def _device_collide(pkg, b, req, env=None, f32=False):
 
 
 @pytest.mark.gpu
+def test_gpu_mesh_solid_ties_forms_agree(pkg, oracle):
+    """Exact ties: a UV sphere (every ring of triangles is the same distance from the axis, mirrored rings from the centre) against
+    boxes ON its axis, identity rotations (a box with three different sides: its fitted OBB is well defined, unlike a solid of
+    revolution's) -- symmetric triangles tie for every bound.  Which of them is reported is decided by
+    the order of the walk (the first that attains the minimum; the last that lowered the bound on its visit), so the wave
+    continuation (budget 2: every query continues there), the task levels and the walk in one piece must report the same
+    triangle and witness -- and the oracle's -- for collide() and distance()."""
+    abi, bb, g, wl = pkg.abi, pkg.bvh_builder, pkg.geometry, pkg.workloads
+    mesh = bb.Mesh(*bb.uv_sphere(24, 24, 1.0))
+    L = g.ShapeLibrary()
+    L.add_bvh(0, len(mesh.vertices))
+    radii = [0.05, 0.2, 0.35, 0.5]
+    for r in radii:
+        L.add_box(r, 0.8 * r, 0.6 * r)
+    zs = np.linspace(-0.25, 0.25, 11)
+    n = len(radii) * len(zs)
+    ident = np.tile(np.array([1.0, 0, 0, 0]), (n, 1))
+    T1 = np.zeros((n, 3))
+    T2 = np.zeros((n, 3))
+    T2[:, 2] = np.repeat(zs, len(radii))
+    s2 = 1 + np.tile(np.arange(len(radii)), len(zs))
+    b = wl.Batch("ties", L, np.zeros(n, dtype=np.int64), s2, ident, T1, ident, T2, "collide")
+    b.meshes = [mesh]
+    ML = bb.MeshLibrary(b.meshes)
+    big = wl.Batch("ties_x", L, np.tile(b.s1, 8), np.tile(b.s2, 8), np.tile(ident, (8, 1)), np.tile(T1, (8, 1)), np.tile(ident, (8, 1)), np.tile(T2, (8, 1)), "collide")
+    big.meshes = [mesh]  # (352 queries: the walks are split from 256 on)
+    creq = abi.default_collision_request()
+    cref, _ = oracle.mixed_collide_batch(big.shapes, big.verts, ML, big.s1, big.s2, big.tf1, big.tf2, creq, max_contacts=10 ** 4, n_threads=8)
+    dref = oracle.mixed_distance_batch(big.shapes, big.verts, ML, big.s1, big.s2, big.tf1, big.tf2, None, n_threads=8)
+    assert (cref["num_contacts"] == 0).all() and (dref["distance"] > 0.01).all()
+    envs = (dict(HFCL_SHAPE_BUDGET0="2", HFCL_SHAPE_DIST_BUDGET="2"), dict(HFCL_SHAPE_COOP="0", HFCL_SHAPE_BUDGET0="2", HFCL_SHAPE_BUDGET="2"),
+            dict(HFCL_SHAPE_LEVELS="1", HFCL_SHAPE_DIST_BUDGET="0"))
+    import os
+    for env in envs:
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            lib = wl.make_library(pkg, big)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        try:
+            cg = lib.collide(big.s1, big.s2, big.tf1, big.tf2, creq)
+            dg = lib.distance(big.s1, big.s2, big.tf1, big.tf2)
+        finally:
+            lib.close()
+        assert np.array_equal(cg["num_contacts"], cref["num_contacts"]), env
+        assert np.abs(cg["distance"] - cref["distance"]).max() < 1e-12, env
+        for f in ("p1", "p2", "normal"):  # the witness of the bound: the LAST triangle that lowered it on its visit
+            assert _same(cg[f], cref[f], 1e-9), (env, f)
+        assert np.abs(dg["distance"] - dref["distance"]).max() < 1e-12, env
+        assert np.array_equal(dg["b1"], dref["b1"]), env  # the FIRST triangle that attains the minimum
+        assert np.abs(dg["p1"] - dref["p1"]).max() < 1e-9 and np.abs(dg["p2"] - dref["p2"]).max() < 1e-9, env
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cached", [False, True])
 def test_gpu_mesh_solid_guesses(pkg, oracle, cached):
     """The solver's cached guess through the one-query-per-lane form: a request that reads the guess back (and one whose
