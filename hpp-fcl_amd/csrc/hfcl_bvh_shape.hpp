@@ -626,11 +626,12 @@ HFCL_HD void mesh_shape_collide(const DNode<T>* nodes, const T* mverts, const ui
 
 
 // ---------------------------------------------------------------------------------------
-// The same traversals with one query per LANE (k_bvh_shape_lane / k_bvh_shape_distance_lane).
+// The same traversals with one query per LANE (hfcl_k_bvh.hip: k_bvh_collide<SOLID>, k_bvh_shape_distance_lane, and the
+// kernels that continue their long walks 64 stack entries at a time).
 //
 // The group form above spends a 16-lane group on a walk whose separating-axis tests and (for every solid but a
-// ConvexBase) GJK iterations no lane can share: 100k queries against a 5 000-triangle model ran at 1-6 M q/s, a tenth
-// of what the host's cores reach with the oracle (tools/mesh_solid_bench.py).  Here a lane owns a query: it walks
+// ConvexBase) GJK iterations no lane can share: 100k queries against a 5 000-triangle model ran at 1-6 M q/s, below
+// what the host's cores reach with the oracle (tools/mesh_solid_bench.py).  Here a lane owns a query: it walks
 // the tree and runs the leaf's closed form / GJK by itself.  What a lane cannot hold is EPA's polytope -- but a leaf
 // that needs EPA ENDS the walk where the fast path applies: collide() with num_max_contacts == 1 and margin,
 // threshold >= 0 (a penetrating triangle is a contact, canStop()), distance() always (every bound left on the stack

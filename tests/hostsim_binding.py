@@ -151,7 +151,7 @@ def mesh_shape_collide_f64(abi, shapes, verts, meshlib, s1, s2, tf1, tf2, req, m
 
 
 def set_shape_lane(on):
-    """1: the mesh x solid sims take the one-query-per-lane forms (k_bvh_shape_lane / _finish) where the request admits them."""
+    """1: the mesh x solid sims take the one-query-per-lane forms (k_bvh_collide<SOLID> / k_bvh_shape_finish) where the request admits them."""
     lib().sim_set_shape_lane(C.c_int(1 if on else 0))
 
 

@@ -131,7 +131,7 @@ def test_device_headers_match_oracle(pkg, oracle, hostsim, nmax, margin, cached)
 
 @pytest.mark.parametrize("margin,cached", [(0.0, False), (0.03, False), (0.0, True)])
 def test_lane_form_equals_group_form(pkg, hostsim, margin, cached):
-    """The one-query-per-lane form of the traversal (k_bvh_shape_lane: lane-local walk and GJK, EPA leaves finished by
+    """The one-query-per-lane form of the traversal (k_bvh_collide<SOLID>: lane-local walk and GJK, EPA leaves finished by
     k_bvh_shape_finish from a queue) against the group form, host build of the same headers: every record, contact and
     cached guess byte for byte (first-contact requests; the others take the group form)."""
     abi, bb = pkg.abi, pkg.bvh_builder
