@@ -24,7 +24,8 @@ are all-gathered over RCCL/xGMI (north_star) on a separate stream, overlapped wi
 byte budget).  `--scaling strong`: one list, rank r owns sharding.shard_range(n, r, world).
 `--backend gloo --device-map 0,0` runs two ranks on one GPU (tests; RCCL refuses duplicate devices).
 
-Prints ONE JSON line on rank 0.
+Rank 0 prints ONE compact JSON line (<= 4 KB: the contract's fields, the headline's `roofline` and `cpu_baseline`, the
+secondary workloads as short rows) as the LAST line of stdout; the full record goes to bench_full.json.
 """
 import argparse
 import hashlib
@@ -183,6 +184,82 @@ def load_traffic(workload, dominant, n, want="traffic"):
 
 class Ctx:
     pass
+
+
+def _r(x, sig=5):
+    """Numbers of the compact line carry `sig` significant digits: the line has a byte budget."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (sig, x))
+    return x
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if d is not None and k in d}
+
+
+COMPACT_LIMIT = 4096  # bytes; the driver keeps the last 8 KB of stdout and parses its last line
+
+
+def compact_line(full):
+    """The LAST stdout line of bench.py: the contract's fields, `roofline` and `cpu_baseline` of the headline, and the
+    secondary workloads as 6-field rows -- at most COMPACT_LIMIT bytes whatever the full record grows to.  The full
+    record (per-kernel durations, SQ counters, notes, bucket counts, the exchange check ...) goes to bench_full.json; nothing in the compact line is computed here, every number is taken from the full record."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                        "vs_baseline", "dtype", "data"))
+    cfg = full.get("config") or {}
+    line["config"] = _pick(cfg, ("workload", "baseline_config", "pairs_per_gpu_per_step", "pairs_per_step_all_gpus",
+                                 "contact_fraction", "request", "gather", "backend", "mean_bv_tests", "mean_leaf_tests"))
+    gc = cfg.get("gather_check")
+    if gc:
+        line["config"]["gather_check"] = {k: (all(v) if isinstance(v, (list, tuple)) else v) for k, v in gc.items()}
+    rf = full.get("roofline") or {}
+    line["roofline"] = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_query",
+                                  "units_per_launch", "kernel_ms", "pipeline_ms", "pipeline_achieved", "hbm_side", "l2_side"))
+    if rf.get("valu_issue"):
+        line["roofline"]["valu_frac"] = _r(rf["valu_issue"]["frac"])
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample"))
+        if cb.get("all_cores"):
+            line["cpu_baseline"]["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+    else:
+        line["cpu_baseline"] = None
+    hb = full.get("host_buffers")
+    if hb:
+        line["host_buffers"] = _pick(hb, ("pairs", "value", "ms_per_call", "frac_of_link_bound"))
+    rows = []
+    for s in full.get("secondary") or []:
+        if "error" in s:
+            rows.append({"workload": s.get("workload"), "error": str(s["error"])[:80]})
+            continue
+        srf, scb = s.get("roofline") or {}, s.get("cpu_baseline") or {}
+        row = {"workload": s.get("tag") or str(s.get("workload"))[:72], "value": _r(s.get("value"), 4), "ms_per_step": _r(s.get("ms_per_step"), 4),
+               "dtype": s.get("dtype"), "frac": _r(srf.get("frac"), 3), "cpu_1thread": _r(scb.get("value"), 4)}
+        if (s.get("config") or {}).get("pairs_per_step_all_gpus"):
+            row["pairs"] = s["config"]["pairs_per_step_all_gpus"]
+        shb = s.get("host_buffers")
+        if shb:
+            row["host_buffers_qps"] = _r(shb.get("value"), 4)
+            row["host_link_frac"] = _r(shb.get("frac_of_link_bound"), 3)
+        if s.get("batches_in_flight", 1) > 1:
+            row["batches_in_flight"] = s["batches_in_flight"]
+        rows.append(row)
+    if rows:
+        line["secondary"] = rows
+    line["full_record"] = "bench_full.json"
+    out = json.dumps(line, separators=(",", ":"))
+    # the budget holds by construction for today's eleven secondary rows (~2.6 KB); if rows are added until it does not,
+    # the rows go first, never the headline
+    while len(out) > COMPACT_LIMIT and line.get("secondary"):
+        line["secondary"] = line["secondary"][:-1]
+        line["secondary_truncated"] = True
+        out = json.dumps(line, separators=(",", ":"))
+    assert len(out) <= COMPACT_LIMIT, len(out)
+    return out
 
 
 def make_batch(ctx, workload, n, strong):
@@ -484,8 +561,17 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
         cpu = None
         if not args.no_cpu_baseline and ctx.world == 1 and cpu_budget_s > 0:  # reported on rank 0 at N=1 only
             cpu = cpu_baseline(ctx, workload, batch, req, cpu_sample, cpu_budget_s)
+        if two_streams:
+            # a throughput-of-two-batches figure: the per-kernel durations above come from the one-stream event pass and do
+            # not describe kernels that overlap another batch's, so this row carries no kernel / roofline figure of its own
+            roofline = {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                        "traffic": None, "bytes_per_query": bpq, "pipeline_achieved": roofline["pipeline_achieved"],
+                        "note": "two batches in flight; see the one-stream row of the same workload for the kernels"}
         result = {
             "workload": batch.name + (" (two batches in flight: even / odd steps on two streams)" if two_streams else ""),
+            "tag": workload + ("/strong" if strong else "") + ("/2streams" if two_streams else "") + (
+                "/gather=" + gather_mode if ctx.dist_on else ""),
+            "batches_in_flight": 2 if two_streams else 1,
             "value": qps, "unit": "queries/s", "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
             "dtype": dtype, "scaling": "strong" if strong else "weak",
             "config": {"workload": batch.name, **extra_cfg, "baseline_config": BASELINE_CONFIG[workload],
@@ -577,7 +663,7 @@ def main():
                                  strong=st, cpu_budget_s=2.5,
                                  cpu_sample=100_000 if wl_name not in ("cfg4", "cfg4d") else (20_000 if wl_name == "cfg4" else 2_000), **kw)
             except Exception as e:  # a secondary must never take the headline down
-                r = {"workload": wl_name + ("_strong" if st else ""), "error": repr(e)} if ctx.rank == 0 else None
+                r = {"workload": wl_name + ("/strong" if st else ""), "error": repr(e)} if ctx.rank == 0 else None
             if r is not None:
                 if st:
                     r["workload"] += " (one %d-pair list sharded over the ranks, gather=%s)" % (pairs, r["config"]["gather"]) \
@@ -608,7 +694,14 @@ def main():
         except Exception:
             pass
         sys.stdout.flush()
-        print(json.dumps(line), flush=True)
+        full = json.dumps(line)
+        try:
+            with open(os.path.join(os.environ.get("HFCL_BENCH_FULL_DIR", ROOT), "bench_full.json"), "w") as f:
+                f.write(full + "\n")
+        except OSError:
+            pass
+        # (not to stderr: the driver's 8 KB tail holds stdout AND stderr)
+        print(compact_line(line), flush=True)  # the last stdout line: <= 4 KB
 
 
 if __name__ == "__main__":

@@ -1,0 +1,79 @@
+"""bench.py's last stdout line must survive the driver's capture: the driver keeps the last 8 KB of stdout (+ stderr) and
+parses the final line.  Round 3's line was 25 KB (profiles/r03_z_bench_default.json is that record) and was lost."""
+import importlib.util
+import io
+import json
+import os
+from contextlib import redirect_stdout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("hfcl_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _full_record():
+    return json.load(open(os.path.join(ROOT, "profiles", "r03_z_bench_default.json")))
+
+
+def test_compact_line_fits_and_carries_the_contract():
+    b = _bench()
+    full = _full_record()
+    assert len(json.dumps(full)) > 20_000  # the record that was lost
+    line = b.compact_line(full)
+    assert "\n" not in line and len(line) < 4096
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["config"]["workload"] == full["config"]["workload"] and "model" not in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_query", "units_per_launch"):
+        assert k in d["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    # numbers are the full record's, to the printed digits
+    assert abs(d["value"] - full["value"]) <= 1e-4 * full["value"]
+    assert abs(d["roofline"]["frac"] - full["roofline"]["frac"]) <= 1e-4 * full["roofline"]["frac"]
+    assert abs(d["roofline"]["achieved"] / d["roofline"]["peak"] - d["roofline"]["frac"]) < 1e-6
+    assert len(d["secondary"]) == len(full["secondary"])
+    for row, s in zip(d["secondary"], full["secondary"]):
+        assert abs(row["value"] - s["value"]) <= 1e-3 * s["value"]
+
+
+def test_last_8000_bytes_of_stdout_parse():
+    """What the driver does: keep the tail of stdout, parse its last line."""
+    b = _bench()
+    full = _full_record()
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        print("RCCL version banner and other library chatter " * 400)  # noise before the line
+        print(b.compact_line(full), flush=True)
+    tail = buf.getvalue()[-8000:]
+    last = tail.rstrip("\n").rsplit("\n", 1)[-1]
+    d = json.loads(last)
+    assert d["metric"] and d["roofline"]["frac"] is not None and d["cpu_baseline"]["value"] > 0
+
+
+def test_compact_line_drops_rows_before_it_overflows():
+    b = _bench()
+    full = _full_record()
+    full["secondary"] = full["secondary"] * 8  # 80 rows
+    line = b.compact_line(full)
+    assert len(line) <= b.COMPACT_LIMIT
+    d = json.loads(line)
+    assert d["secondary_truncated"] and d["roofline"]["kernel"] and d["cpu_baseline"]["value"] > 0
+
+
+def test_two_stream_rows_and_errors():
+    b = _bench()
+    full = _full_record()
+    full["secondary"][0] = {"workload": "cfg2", "error": "RuntimeError('x' * 500)" + "y" * 500}
+    full["secondary"][1]["batches_in_flight"] = 2
+    full["secondary"][1]["roofline"] = {"frac": None, "kernel": None}
+    d = json.loads(b.compact_line(full))
+    assert len(d["secondary"][0]["error"]) <= 80
+    assert d["secondary"][1]["frac"] is None and d["secondary"][1]["batches_in_flight"] == 2
