@@ -60,11 +60,18 @@ BYTES_PER_QUERY = {
     "cfg1": 8 + 2 * 96 + 96,
     "cfg3u": 8 + 2 * 28 + 44 + 2 * 32 * 12,  # cfg3 with one hull pair per query: + 2 x 32 fp32 vertices = 876 B
     "cfg2f": 8 + 2 * 28 + 44,  # cfg2's pairs through the fp32 device path (7-float poses, 44-B records)
-    "cfg4d": 8 + 2 * 96 + 96,  # cfg4's distance() variant: ids + poses + record (the visited nodes are not counted: no oracle statistic)
-    "cfg4s": 8 + 2 * 96 + 96,  # mesh x solid collide(): ids + poses + record (visited nodes not counted)
+    # cfg4's distance() variant and mesh x solid collide(): ids + poses + record, plus what the reference's walk
+    # visits -- num_bv_tests / num_leaf_tests of its traversal node (traversal_node_bvhs.h:126-128,380-381,423,434), measured
+    # with the oracle on a sample as for cfg4
+    "cfg4d": 8 + 2 * 96 + 96,
+    "cfg4s": 8 + 2 * 96 + 96,
 }
+# per BV test / per leaf test of the reference's walk: cfg4 two 128-B OBB node records / two triangles (3 x 24 B vertices + 12 B
+# of indices each); cfg4d two 128-B RSS node records (DNodeD) / two triangles; cfg4s ONE mesh node record (the solid's box is
+# computed from its 56-B shape record, counted once in the 296 B) / one triangle
 CFG4_BYTES_PER_BV_TEST = 2 * 128
 CFG4_BYTES_PER_LEAF_TEST = 2 * (3 * 24 + 12)
+WALK_BYTES = {"cfg4": (CFG4_BYTES_PER_BV_TEST, CFG4_BYTES_PER_LEAF_TEST), "cfg4d": (2 * 128, 2 * (3 * 24 + 12)), "cfg4s": (128, 3 * 24 + 12)}
 DEFAULT_PAIRS = {"cfg4": 100_000, "cfg4d": 100_000, "cfg4s": 100_000, "cfg5": 1_250_000, "cfg1": 4_000_000}
 BASELINE_CONFIG = {"cfg3": "configs[2]", "cfg2": "configs[1]", "cfg4": "configs[3]", "cfg5": "configs[4]",
                    "cfg1": "configs[0] (shape pair; GPU batch size)", "cfg3u": "configs[2], one hull pair per query",
@@ -161,6 +168,8 @@ def load_traffic(workload, dominant, n, want="traffic"):
             hit = (hit and not solid_walk) or any(x in name for x in ("k_bvh_coop<", "k_bvh_combine<", "k_bvh_level_mark"))
         if base == "k_bvh_shape":
             hit = hit or solid_walk or any(x in name for x in ("k_shape_obb", "k_bvh_shape_coop<", "k_bvh_shape_finish<"))
+        if base == "k_bvh_distance":  # the lane walk and its continuation
+            hit = hit or any(x in name for x in ("k_bvh_distance_pool<", "k_bvh_distance_coop<"))
         if not hit:
             continue
         if want == "valu":
@@ -438,7 +447,7 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
         buf = i & 1
         if exchange:
             # double buffering: the kernels of step i overwrite the buffer the exchange of step i-2 read
-            xch.before_launch(buf)
+            xch.before_launch(buf, stream)
         if n and two_streams and buf and not record_times:
             launch2(d_s1, d_s2, d_p1, d_p2, n, req, outs[buf], stream=stream2.cuda_stream)
         elif n:
@@ -519,15 +528,23 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
         avg = {k: float(np.mean(v)) for k, v in kernel_ms.items() if np.mean(v) > 0}
         dominant = max(avg, key=avg.get) if avg else ""
         bpq = BYTES_PER_QUERY[workload]
-        if workload == "cfg4":
+        if workload in WALK_BYTES:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_binding as ob0  # measures N_bv / N_leaf of the reference DFS on a sample
+            import oracle_binding as ob0  # measures N_bv / N_leaf of the reference DFS on a sample (outside the timed region)
             ns0 = min(2000, n)
             ML = pkg.bvh_builder.MeshLibrary(batch.meshes)
-            _, st0 = ob0.bvh_collide_batch(ML, batch.s1[:ns0], batch.s2[:ns0], batch.tf1[:ns0], batch.tf2[:ns0], req,
-                                           n_threads=os.cpu_count() or 1, want_stats=True)
+            sl = slice(0, ns0)
+            if workload == "cfg4":
+                _, st0 = ob0.bvh_collide_batch(ML, batch.s1[sl], batch.s2[sl], batch.tf1[sl], batch.tf2[sl], req,
+                                               n_threads=os.cpu_count() or 1, want_stats=True)
+            elif workload == "cfg4d":
+                _, st0 = ob0.bvh_distance_batch(ML, batch.s1[sl], batch.s2[sl], batch.tf1[sl], batch.tf2[sl],
+                                                n_threads=os.cpu_count() or 1, want_stats=True)
+            else:
+                _, st0 = ob0.mixed_collide_batch(batch.shapes, batch.verts, ML, batch.s1[sl], batch.s2[sl], batch.tf1[sl], batch.tf2[sl], req,
+                                                 n_threads=os.cpu_count() or 1, want_stats=True)
             nbv, nleaf = float(st0[:, 0].mean()), float(st0[:, 1].mean())
-            bpq = bpq + CFG4_BYTES_PER_BV_TEST * nbv + CFG4_BYTES_PER_LEAF_TEST * nleaf
+            bpq = bpq + WALK_BYTES[workload][0] * nbv + WALK_BYTES[workload][1] * nleaf
             extra_cfg.update({"mean_bv_tests": nbv, "mean_leaf_tests": nleaf, "stats_sample": ns0})
         # units the dominant kernel processes in one launch
         if dominant.startswith("k_epa<fast"):
@@ -558,6 +575,14 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
             "pipeline_ms": pipeline_ms, "pipeline_achieved": (n * bpq) / (ms_per_step * 1e-3) / 1e9,
             "kernels_ms": avg, "valu_issue": valu,
         }
+        if workload in WALK_BYTES and achieved:
+            # The walks read node records that live in L2 / MALL (8 models x 1.28 MB here): the "algorithmic" rate above is what the
+            # LANES consume (an L2-side figure), the HBM-side figure is what the PMC pass saw leave the memory controllers.  Both
+            # against the HBM peak, both stated -- the single `frac` of earlier rounds mixed them.
+            roofline["l2_side"] = {"GBps": _r(achieved, 4), "frac_of_hbm_peak": _r(achieved / HBM_PEAK_GBS, 3),
+                                   "note": "visited node / triangle records x record size / kernel time"}
+            roofline["hbm_side"] = ({"GBps": _r(traffic / (dom_ms * 1e-3) / 1e9, 4), "frac_of_hbm_peak": _r(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                                     "note": "PMC bytes (2 x FETCH_SIZE + WRITE_SIZE) / kernel time"} if traffic else None)
         cpu = None
         if not args.no_cpu_baseline and ctx.world == 1 and cpu_budget_s > 0:  # reported on rank 0 at N=1 only
             cpu = cpu_baseline(ctx, workload, batch, req, cpu_sample, cpu_budget_s)

@@ -219,22 +219,24 @@ class Convex(ShapeBase):
         self.polygons = list(polygons) if polygons is not None else []
 
     def neighbors(self):
-        """ConvexBase::neighbors as CSR (offsets[num_points + 1], ids), or None without facets.  Built once per object."""
+        """ConvexBase::neighbors as CSR (offsets[num_points + 1], ids), or None without facets.  Cached per object, keyed on the facets' indices."""
         if not self.polygons:
             return None
-        if getattr(self, "_nb_cache", None) is not None and self._nb_cache[0] == (self.num_points, len(self.polygons)):
+        polys = [tuple(int(poly[k]) for k in range(3)) if isinstance(poly, Triangle) else tuple(int(k) for k in poly) for poly in self.polygons]
+        key = (len(self.points), hash(tuple(polys)))  # the facets themselves: an edit in place must not leave a stale adjacency behind
+        if getattr(self, "_nb_cache", None) is not None and self._nb_cache[0] == key:
             return self._nb_cache[1]
-        nb = [set() for _ in range(self.num_points)]
-        for poly in self.polygons:
-            idx = [int(poly[k]) for k in range(3)] if isinstance(poly, Triangle) else [int(k) for k in poly]
+        npts = len(self.points)
+        nb = [set() for _ in range(npts)]
+        for idx in polys:
             n = len(idx)
             for j in range(n):
                 nb[idx[j]].add(idx[j - 1])
                 nb[idx[j]].add(idx[(j + 1) % n])
-        offs = np.zeros(self.num_points + 1, dtype=np.uint32)
+        offs = np.zeros(npts + 1, dtype=np.uint32)
         offs[1:] = np.cumsum([len(x) for x in nb])
         out = (offs, np.array([v for x in nb for v in sorted(x)], dtype=np.uint32))
-        self._nb_cache = ((self.num_points, len(self.polygons)), out)
+        self._nb_cache = (key, out)
         return out
 
     def _register(self, L):
@@ -463,9 +465,9 @@ class _Context:
             self.lib = engine.Library(self.L, device=self.device)
             for m in self.meshes:
                 self.lib.add_bvh(m)
-            # large hulls with facets: the adjacency the device climbs.  Only hulls the engine will climb (HFCL_CLIMB_MIN
-            # vertices, default 512: below that the scan is faster) pay the host loop and the device copy.
-            climb_min = int(os.environ.get("HFCL_CLIMB_MIN", "512"))
+            # large hulls with facets: the adjacency the device climbs.  Only hulls the engine will climb (its own threshold,
+            # hfcl_lib_climb_min: below that the scan is faster) pay the host loop and the device copy.
+            climb_min = self.lib.climb_min()
             for g in self.keep:
                 if isinstance(g, Convex) and g.num_points >= max(33, climb_min):
                     nb = g.neighbors()

@@ -35,6 +35,20 @@ struct DNode {
   V3<T> extent;
 };
 
+// What the distance() walk reads of a node, in ONE record (fp64: 128 B = one cache line, against a 128-B DNode of which it
+// uses the axes and the child link plus a 48-B DRss from another array): the axes (RSS axes = OBB axes), the RSS origin,
+// side lengths and radius, the child link, and the rank of obb.extent.squaredNorm() among all nodes of the library
+// (obbf_size_ranks: equal sizes share a rank, so rank1 > rank2 <=> size1 > size2 -- the descent rule of distanceRecurse,
+// traversal_recurse.cpp:165-166 via firstOverSecond, as an integer compare on values formed without contraction).
+template <typename T>
+struct alignas(16) DNodeD {
+  M3<T> axes;
+  V3<T> Tr;
+  T l0, l1, r;
+  int32_t first_child;
+  uint32_t rank;
+};
+
 // obbDisjointAndLowerBoundDistance: B, T = pose of OBB 2 in the frame of OBB 1; a, b = extents.
 template <typename T>
 HFCL_HD bool obb_disjoint_lb(const M3<T>& B, const V3<T>& Tv, const V3<T>& a_, const V3<T>& b_, T security_margin,
@@ -155,6 +169,7 @@ inline DNodeF pack_fnode(const hfcl_bvh_node& n, uint32_t rank) {
   for (int k = 0; k < 9; ++k) safe = safe && fabs(a[k]) <= 1.0 + 1e-9;
   const double l0 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], l1 = a[3] * a[3] + a[4] * a[4] + a[5] * a[5];
   safe = safe && fabs(l0 - 1.0) <= 1e-9 && fabs(l1 - 1.0) <= 1e-9 && fabs(a[0] * a[3] + a[1] * a[4] + a[2] * a[5]) <= 1e-9;
+  for (int k = 0; k < 3; ++k) safe = safe && n.obb_extent[k] >= 0;  // (the error bound was derived for non-negative extents)
   f.rank = (rank & OBBF_RANK_MASK) | (sgn < 0 ? OBBF_LEFT : 0u) | (safe ? 0u : OBBF_UNSAFE);
   double mag = 0;
   for (int k = 0; k < 3; ++k) {
@@ -163,7 +178,6 @@ inline DNodeF pack_fnode(const hfcl_bvh_node& n, uint32_t rank) {
     f.To[k] = float(n.obb_To[k]);
     f.extent[k] = float(n.obb_extent[k]);
     mag += fabs(n.obb_To[k]) + fabs(n.obb_extent[k]);
-    safe = safe && n.obb_extent[k] >= 0;
   }
   if (!(mag < 1e30)) f.rank |= OBBF_UNSAFE;  // NaN / huge: the fp64 test decides
   f.mag = float(mag) * (1.f + 4.f * OBBF_U) + 1e-37f;
@@ -508,6 +522,15 @@ HFCL_HD T rss_lower_bound(const M3<T>& R0, const V3<T>& T0, const DNode<T>& n1, 
   const V3<T> Ttemp = mul(R0, r2.Tr) + T0 - r1.Tr;
   const V3<T> Tv = tmul(n1.axes, Ttemp);
   const T d = rect_distance(R, Tv, r1.l0, r1.l1, r2.l0, r2.l1) - (r1.r + r2.r);
+  return d < T(0) ? T(0) : d;
+}
+
+template <typename T>
+HFCL_HD T rss_lower_bound(const M3<T>& R0, const V3<T>& T0, const DNodeD<T>& n1, const DNodeD<T>& n2) {
+  const M3<T> R = tmul(n1.axes, mmul(R0, n2.axes));
+  const V3<T> Ttemp = mul(R0, n2.Tr) + T0 - n1.Tr;
+  const V3<T> Tv = tmul(n1.axes, Ttemp);
+  const T d = rect_distance(R, Tv, n1.l0, n1.l1, n2.l0, n2.l1) - (n1.r + n2.r);
   return d < T(0) ? T(0) : d;
 }
 

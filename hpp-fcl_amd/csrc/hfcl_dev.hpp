@@ -56,7 +56,8 @@ constexpr int B_CURVED0 = B_COUNT + 4;
 constexpr int CTR_SHAPE_TICKET = 2 * B_COUNT + 4, CTR_SHAPE_DEFER = 2 * B_COUNT + 5;
 constexpr int CTR_DIST_SUSP = 2 * B_COUNT + 6;  // suspended mesh x mesh distance() walks (DistSusp records)
 constexpr int CTR_SHAPE_DIST_SUSP = 2 * B_COUNT + 7;  // ... mesh x solid (ShapeDistSusp records)
-constexpr int N_COUNTERS = 2 * B_COUNT + 8;  // bucket populations + the four counters of Work::counts + curved populations + those two
+constexpr int CTR_DIST_TICKET = 2 * B_COUNT + 8;  // ticket of k_bvh_distance_pool: next DistSusp record to take
+constexpr int N_COUNTERS = 2 * B_COUNT + 9;  // bucket populations + the four counters of Work::counts + curved populations + those
 
 // Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
 // support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
@@ -168,7 +169,8 @@ struct Work {
   void* epa_v0;      // shape-0 support points of the polytopes in flight in the full-capacity EPA kernel
   void* epa_resume;  // saved polytopes (EpaSaved, epa_resume_stride<T> bytes apart) of the first `resume_cap` slots of epa_queue2
   uint32_t resume_cap;
-  void* shape_defer;  // ShapeDeferItem<T>[n]: mesh x solid leaves waiting for EPA (k_bvh_collide<SOLID> -> k_bvh_shape_finish); nullptr: group kernels
+  void* shape_defer;  // ShapeDeferItem<T>[shape_defer_cap]: mesh x solid leaves waiting for EPA (k_bvh_collide<SOLID> -> k_bvh_shape_finish); nullptr: group kernels
+  uint32_t shape_defer_cap;  // a unit (query, or task of a split walk) queues at most one item: sized by the host for every unit a batch can make
   void* shape_oq;     // ObbQuery<T>[n], by pair: the solid's fitted OBB against the mesh pose (k_shape_obb)
 };
 // a pair with a shape whose support is not a vertex
@@ -624,6 +626,7 @@ struct BvhView {
   const DNode<T>* nodes;
   const DNodeF* fnodes;  // filter records of the same nodes (hfcl_bvh.hpp: obb_filter); nullptr: plain fp64 tests
   const DRss<T>* rss;
+  const DNodeD<T>* dnodes;  // the distance() walk's packed node records (hfcl_bvh.hpp)
   const T* verts;        // xyz
   const uint32_t* tris;  // 3 local vertex ids per triangle
   const DMesh* meshes;
@@ -696,6 +699,10 @@ struct BvhSpill {
   void* susp;
   uint32_t* susp_count;
   uint32_t budget;
+  // ... or, pool != 0, by k_bvh_distance_pool (hfcl_k_bvhd.hip): several walks per wave, their box and triangle tests pooled
+  uint32_t pool;
+  uint32_t* pool_ticket;
+  uint32_t pool_leaf_min, pool_starve;  // its two scheduling knobs
 };
 constexpr int BVH_MAX_LEVELS = 12;  // most task levels a batch can be given (HFCL_BVH_LEVELS, the automatic choice)
 #ifndef HFCL_BVH_LEVELS
@@ -709,6 +716,27 @@ constexpr int BVH_MAX_LEVELS = 12;  // most task levels a batch can be given (HF
 #define HFCL_BVH_STACK 48
 #endif
 constexpr int BVH_STACK = HFCL_BVH_STACK;
+
+// WIDE: models of more than 65535 BV nodes.  A stack entry is then two 32-bit node ids (the LDS stack holds half as
+// many), and a lane whose LDS stack is full moves its lower half to a slab of its own in global memory (BvhSpill) and
+// takes it back when the LDS part runs empty: the reference's stack is a growable std::vector
+// (traversal_recurse.cpp:95), a traversal here is bounded by the slab the host sized from the depths of the models.
+template <bool WIDE> struct BvhEntry;
+template <> struct BvhEntry<false> {
+  typedef uint32_t E;
+  static constexpr int STACK = BVH_STACK;
+  static __device__ __forceinline__ E pack(uint32_t b1, uint32_t b2) { return b1 | (b2 << 16); }
+  static __device__ __forceinline__ uint32_t first(E e) { return e & 0xFFFFu; }
+  static __device__ __forceinline__ uint32_t second(E e) { return e >> 16; }
+};
+template <> struct BvhEntry<true> {
+  typedef uint64_t E;
+  static constexpr int STACK = BVH_STACK / 2;
+  static __device__ __forceinline__ E pack(uint32_t b1, uint32_t b2) { return uint64_t(b1) | (uint64_t(b2) << 32); }
+  static __device__ __forceinline__ uint32_t first(E e) { return uint32_t(e); }
+  static __device__ __forceinline__ uint32_t second(E e) { return uint32_t(e >> 32); }
+};
+
 #ifndef HFCL_BVH_STACK_FILT
 #define HFCL_BVH_STACK_FILT 26  // 26 x 4 B x 128 lanes + the 12 KB witness slab = 25 600 B = 20 LDS units: six blocks per CU
 #endif

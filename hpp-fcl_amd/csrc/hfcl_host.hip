@@ -80,6 +80,9 @@ struct hfcl_lib {
   std::map<uint32_t, HostGraph> h_graphs;
   bool graph_dirty = false;
   uint32_t* d_graph_base = nullptr;
+  std::vector<void*> graph_retired;   // adjacency images replaced by a later registration: batches in flight on other streams may still read
+                                      // them, so they are freed where the library waits for the device anyway (set_shapes, destroy)
+  hipStream_t upload_stream = nullptr;  // non-blocking stream of the adjacency upload (the host waits for it alone)
   uint32_t* d_graph_off = nullptr;
   NbrEntry<float>* d_graph_ent32 = nullptr;
   NbrEntry<double>* d_graph_ent64 = nullptr;
@@ -114,7 +117,9 @@ struct hfcl_lib {
   bool bvh_coop = true;
   uint32_t bvh_budget0_coop = 0;  // 0: 256 steps up to 500k queries, 640 beyond
   // distance(): a mesh x mesh walk that has taken this many steps is continued by a wave (k_bvh_distance_coop); 0: never
-  uint32_t bvhd_budget = 1024;    // HFCL_BVHD_BUDGET (cfg4d 100k queries, budgets 0 / 32 / 256 / 1024 / 4096 / 8192: 101.5 / 59.3 / 58.0 / 55.7 / 67.1 / 92.0 ms; profiles/r03_k)
+  uint32_t bvhd_budget = 64;      // HFCL_BVHD_BUDGET: steps a lane walks before its walk goes to k_bvh_distance_pool (cfg4d 100k queries, budgets 16 / 64 / 256: 34.4 / 33.2 / 34.1 ms, profiles/r04_c; with the wave-per-walk form of round 3, HFCL_BVHD_POOL=0, 1024 was best: 55.7 ms)
+  uint32_t bvhd_pool = 1;         // HFCL_BVHD_POOL: the walks past the budget are continued by k_bvh_distance_pool (0: k_bvh_distance_coop)
+  uint32_t bvhd_pool_leaf_min = 24, bvhd_pool_starve = 32;  // HFCL_BVHD_LEAF_MIN / HFCL_BVHD_STARVE
   void* d_dist_susp = nullptr;    // DistSusp<double>[dist_susp_capacity]
   size_t dist_susp_capacity = 0;
   uint32_t shape_dist_budget = 256;  // HFCL_SHAPE_DIST_BUDGET: the same for mesh x solid (a GJK leaf counts 16 steps; k_bvh_shape_distance_coop)
@@ -181,6 +186,8 @@ struct hfcl_lib {
   bool bvh_filter = false;     // HFCL_BVH_FILTER=1: the fp32 filter form of k_bvh_collide (exact, measured slower: profiles/r03_b)
   DRss<double>* d_rss64 = nullptr;
   DRss<float>* d_rss32 = nullptr;
+  DNodeD<double>* d_dnodes64 = nullptr;  // the distance() walk's packed node records
+  DNodeD<float>* d_dnodes32 = nullptr;
   double* d_bverts64 = nullptr;
   float* d_bverts32 = nullptr;
   uint32_t* d_btris = nullptr;
@@ -212,6 +219,7 @@ struct hfcl_lib {
 };
 
 static void share_tables(hfcl_lib* h, const hfcl_lib* lib);
+static void free_retired_graphs(hfcl_lib* lib);
 
 // bucket population i of the last batch (both halves of a split batch)
 static uint32_t one_count(const uint32_t* c, int i) {
@@ -438,6 +446,9 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_SHAPE_COOP")) lib->shape_coop = atoi(v) != 0;
   if (const char* v = getenv("HFCL_BVH_COOP")) lib->bvh_coop = atoi(v) != 0;
   if (const char* v = getenv("HFCL_BVHD_BUDGET")) lib->bvhd_budget = uint32_t(std::max(0, atoi(v)));
+  if (const char* v = getenv("HFCL_BVHD_POOL")) lib->bvhd_pool = uint32_t(std::max(0, atoi(v)));
+  if (const char* v = getenv("HFCL_BVHD_LEAF_MIN")) lib->bvhd_pool_leaf_min = uint32_t(std::max(1, atoi(v)));
+  if (const char* v = getenv("HFCL_BVHD_STARVE")) lib->bvhd_pool_starve = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_DIST_BUDGET")) lib->shape_dist_budget = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_BUDGET0_COOP")) lib->bvh_budget0_coop = uint32_t(std::max(1, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_BUDGET0")) lib->shape_budget0 = lib->shape_budget0_coop = uint32_t(atoi(v));
@@ -461,6 +472,8 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipSetDevice(lib->device);
   hipDeviceSynchronize();
   if (lib->helper) hfcl_lib_destroy(lib->helper);
+  if (!lib->is_helper) free_retired_graphs(lib);
+  if (lib->upload_stream) hipStreamDestroy(lib->upload_stream);
   if (lib->side) hipStreamDestroy(lib->side);
   if (lib->ev_fork) hipEventDestroy(lib->ev_fork);
   if (lib->ev_join) hipEventDestroy(lib->ev_join);
@@ -514,6 +527,8 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_fnodes);
   hipFree(lib->d_rss64);
   hipFree(lib->d_rss32);
+  hipFree(lib->d_dnodes64);
+  hipFree(lib->d_dnodes32);
   hipFree(lib->d_bverts64);
   hipFree(lib->d_bverts32);
   hipFree(lib->d_btris);
@@ -541,6 +556,7 @@ int hfcl_lib_set_shapes(hfcl_lib* lib, const hfcl_shape* shapes, size_t n_shapes
   if (!validate_shapes("hfcl_lib_set_shapes", shapes, n_shapes, vertices, n_vertices)) return HFCL_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(lib->device));
   HIP_TRY(hipDeviceSynchronize());  // nothing of this library may still be reading the old tables
+  free_retired_graphs(lib);
   if (!upload_shapes(lib, shapes, n_shapes, vertices, n_vertices)) {
     set_error("hfcl_lib_set_shapes: HIP allocation/copy failed");
     return HFCL_ERR_HIP;
@@ -589,6 +605,7 @@ int hfcl_lib_set_convex_neighbors(hfcl_lib* lib, uint32_t shape_id, const uint32
 }
 size_t hfcl_lib_num_shapes(const hfcl_lib* lib) { return lib ? lib->n_shapes : 0; }
 int hfcl_lib_device(const hfcl_lib* lib) { return lib ? lib->device : -1; }
+uint32_t hfcl_lib_climb_min(const hfcl_lib* lib) { return lib ? lib->climb_min : 0u; }
 
 int hfcl_lib_add_bvh(hfcl_lib* lib, const hfcl_bvh_node* nodes, size_t n_nodes, const double* vertices,
                      size_t n_vertices, const uint32_t* triangles, size_t n_tris) {
@@ -749,11 +766,18 @@ static DNode<T> pack_node(const hfcl_bvh_node& n) {
 // d_graph_off, the neighbours with their coordinates inline in d_graph_ent32/64 (one fetch per hop instead of two).
 // The warm-start vertices are the support vertices along the 14 directions of ConvexBase::buildSupportWarmStart
 // (src/shape/geometric_shapes.cpp: the six axis directions and the eight cube diagonals).
+static void free_retired_graphs(hfcl_lib* lib) {  // (the caller has waited for the device)
+  for (void* p : lib->graph_retired) hipFree(p);
+  lib->graph_retired.clear();
+}
+// No device-wide wait (round 4): the previous image is retired, not freed, the new one is copied on a non-blocking stream
+// of its own and the host waits for that stream only -- hipFree and the null-stream hipMemcpy the first version used both
+// stall every stream of the device, inside an entry point documented as asynchronous.
 static int upload_graph(hfcl_lib* lib) {
   if (!lib->graph_dirty) return HFCL_OK;
   HIP_TRY(hipSetDevice(lib->device));
-  HIP_TRY(hipDeviceSynchronize());
-  hipFree(lib->d_graph_base); hipFree(lib->d_graph_off); hipFree(lib->d_graph_ent32); hipFree(lib->d_graph_ent64);
+  for (void* p : {(void*)lib->d_graph_base, (void*)lib->d_graph_off, (void*)lib->d_graph_ent32, (void*)lib->d_graph_ent64})
+    if (p) lib->graph_retired.push_back(p);
   lib->d_graph_base = nullptr; lib->d_graph_off = nullptr; lib->d_graph_ent32 = nullptr; lib->d_graph_ent64 = nullptr;
   lib->graph_dirty = false;
   if (lib->h_graphs.empty()) {
@@ -803,10 +827,13 @@ static int upload_graph(hfcl_lib* lib) {
   ok = ok && hipMalloc(&lib->d_graph_off, off.size() * sizeof(uint32_t)) == hipSuccess;
   ok = ok && hipMalloc(&lib->d_graph_ent32, (e32.size() + 1) * sizeof(NbrEntry<float>)) == hipSuccess;
   ok = ok && hipMalloc(&lib->d_graph_ent64, (e64.size() + 1) * sizeof(NbrEntry<double>)) == hipSuccess;
-  ok = ok && hipMemcpy(lib->d_graph_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && hipMemcpy(lib->d_graph_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && (e32.empty() || hipMemcpy(lib->d_graph_ent32, e32.data(), e32.size() * sizeof(NbrEntry<float>), hipMemcpyHostToDevice) == hipSuccess);
-  ok = ok && (e64.empty() || hipMemcpy(lib->d_graph_ent64, e64.data(), e64.size() * sizeof(NbrEntry<double>), hipMemcpyHostToDevice) == hipSuccess);
+  if (!lib->upload_stream) ok = ok && hipStreamCreateWithFlags(&lib->upload_stream, hipStreamNonBlocking) == hipSuccess;
+  hipStream_t us = lib->upload_stream;
+  ok = ok && hipMemcpyAsync(lib->d_graph_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice, us) == hipSuccess;
+  ok = ok && hipMemcpyAsync(lib->d_graph_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, us) == hipSuccess;
+  ok = ok && (e32.empty() || hipMemcpyAsync(lib->d_graph_ent32, e32.data(), e32.size() * sizeof(NbrEntry<float>), hipMemcpyHostToDevice, us) == hipSuccess);
+  ok = ok && (e64.empty() || hipMemcpyAsync(lib->d_graph_ent64, e64.data(), e64.size() * sizeof(NbrEntry<double>), hipMemcpyHostToDevice, us) == hipSuccess);
+  ok = ok && hipStreamSynchronize(us) == hipSuccess;  // the host vectors go out of scope; kernels launched after this see the image
   if (!ok) {  // nothing half-built stays behind: the next batch retries the upload from the host copies
     hipFree(lib->d_graph_base); hipFree(lib->d_graph_off); hipFree(lib->d_graph_ent32); hipFree(lib->d_graph_ent64);
     lib->d_graph_base = nullptr; lib->d_graph_off = nullptr; lib->d_graph_ent32 = nullptr; lib->d_graph_ent64 = nullptr;
@@ -823,6 +850,8 @@ static int upload_bvh(hfcl_lib* lib) {
   if (!lib->bvh_dirty) return HFCL_OK;
   hipFree(lib->d_nodes64); hipFree(lib->d_nodes32); hipFree(lib->d_bverts64); hipFree(lib->d_bverts32);
   hipFree(lib->d_btris); hipFree(lib->d_meshes); hipFree(lib->d_rss64); hipFree(lib->d_rss32); hipFree(lib->d_fnodes);
+  hipFree(lib->d_dnodes64); hipFree(lib->d_dnodes32);
+  lib->d_dnodes64 = nullptr; lib->d_dnodes32 = nullptr;
   lib->d_rss64 = nullptr; lib->d_rss32 = nullptr; lib->d_fnodes = nullptr;
   lib->d_nodes64 = nullptr; lib->d_nodes32 = nullptr; lib->d_bverts64 = nullptr; lib->d_bverts32 = nullptr;
   lib->d_btris = nullptr; lib->d_meshes = nullptr;
@@ -854,6 +883,19 @@ static int upload_bvh(hfcl_lib* lib) {
     for (size_t i = 0; i < nn; ++i) fn[i] = pack_fnode(lib->h_bvh_nodes[i], rank[i]);
     HIP_TRY(hipMalloc(&lib->d_fnodes, nn * sizeof(DNodeF)));
     HIP_TRY(hipMemcpy(lib->d_fnodes, fn.data(), nn * sizeof(DNodeF), hipMemcpyHostToDevice));
+    // the distance() walk's records: axes + RSS + child link + the same ranks
+    std::vector<DNodeD<double>> d64(nn);
+    std::vector<DNodeD<float>> d32(nn);
+    for (size_t i = 0; i < nn; ++i) {
+      d64[i].axes = n64[i].axes; d64[i].Tr = r64[i].Tr; d64[i].l0 = r64[i].l0; d64[i].l1 = r64[i].l1; d64[i].r = r64[i].r;
+      d64[i].first_child = n64[i].first_child; d64[i].rank = rank[i];
+      d32[i].axes = n32[i].axes; d32[i].Tr = r32[i].Tr; d32[i].l0 = r32[i].l0; d32[i].l1 = r32[i].l1; d32[i].r = r32[i].r;
+      d32[i].first_child = n32[i].first_child; d32[i].rank = rank[i];
+    }
+    HIP_TRY(hipMalloc(&lib->d_dnodes64, nn * sizeof(DNodeD<double>)));
+    HIP_TRY(hipMalloc(&lib->d_dnodes32, nn * sizeof(DNodeD<float>)));
+    HIP_TRY(hipMemcpy(lib->d_dnodes64, d64.data(), nn * sizeof(DNodeD<double>), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(lib->d_dnodes32, d32.data(), nn * sizeof(DNodeD<float>), hipMemcpyHostToDevice));
   }
   HIP_TRY(hipMalloc(&lib->d_nodes64, nn * sizeof(DNode<double>)));
   HIP_TRY(hipMalloc(&lib->d_nodes32, nn * sizeof(DNode<float>)));
@@ -997,6 +1039,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
   wk.epa_v0 = lib->d_epa_v0;
   wk.resume_cap = uint32_t(std::min<size_t>(lib->resume_cap, 0xFFFFFFFFu));
   wk.shape_defer = nullptr;
+  wk.shape_defer_cap = 0;
   wk.shape_oq = nullptr;
   LibView<T> lv;
   lv.shapes = std::is_same<T, double>::value ? (const DShape<T>*)lib->d_shapes64 : (const DShape<T>*)lib->d_shapes32;
@@ -1075,6 +1118,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     bv.nodes = std::is_same<T, double>::value ? (const DNode<T>*)lib->d_nodes64 : (const DNode<T>*)lib->d_nodes32;
     bv.fnodes = (std::is_same<T, double>::value && lib->bvh_filter) ? lib->d_fnodes : nullptr;
     bv.rss = std::is_same<T, double>::value ? (const DRss<T>*)lib->d_rss64 : (const DRss<T>*)lib->d_rss32;
+    bv.dnodes = std::is_same<T, double>::value ? (const DNodeD<T>*)lib->d_dnodes64 : (const DNodeD<T>*)lib->d_dnodes32;
     bv.verts = std::is_same<T, double>::value ? (const T*)lib->d_bverts64 : (const T*)lib->d_bverts32;
     bv.tris = lib->d_btris;
     bv.meshes = lib->d_meshes;
@@ -1126,16 +1170,25 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     // distance(): a leaf that needs EPA always ends the walk; models deeper than the lanes' stacks take the group kernel
     const bool shape_fast_d = q.mode != 1 && may(B_BVHSHAPE) && lib->bvh_shape_lane && size_t(lib->bvh_max_depth) + 1 <= size_t(BVHD_STACK);
     if (shape_fast || shape_fast_d) {
-      if (lib->ws_capacity > lib->shape_defer_capacity) {
+      // one EPA item per unit at most (a contact ends the unit): a query, or -- when suspended walks are cut into task levels
+      // instead of being continued by a wave (HFCL_SHAPE_COOP=0) -- every task of the split's table as well
+      size_t need = lib->ws_capacity;
+      if (shape_fast && !lib->shape_coop && n >= 256) {
+        rc = ensure_bvh_split(lib, n);
+        if (rc) return rc;
+        need = std::max(need, n + lib->bvh_split_cap);
+      }
+      if (need > lib->shape_defer_capacity) {
         hipFree(lib->d_shape_defer);
         hipFree(lib->d_shape_oq);
         lib->d_shape_defer = lib->d_shape_oq = nullptr;
         lib->shape_defer_capacity = 0;
-        HIP_TRY(hipMalloc(&lib->d_shape_defer, lib->ws_capacity * sizeof(ShapeDeferItem<double>)));
-        HIP_TRY(hipMalloc(&lib->d_shape_oq, lib->ws_capacity * std::max(sizeof(ObbQuery<double>), sizeof(RssQuery<double>))));
-        lib->shape_defer_capacity = lib->ws_capacity;
+        HIP_TRY(hipMalloc(&lib->d_shape_defer, need * sizeof(ShapeDeferItem<double>)));
+        HIP_TRY(hipMalloc(&lib->d_shape_oq, need * std::max(sizeof(ObbQuery<double>), sizeof(RssQuery<double>))));
+        lib->shape_defer_capacity = need;
       }
       wk.shape_defer = lib->d_shape_defer;
+      wk.shape_defer_cap = uint32_t(std::min<size_t>(lib->shape_defer_capacity, 0xFFFFFFFFu));
       wk.shape_oq = lib->d_shape_oq;
     }
     if (q.mode == 1) {
@@ -1195,6 +1248,10 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         spill.susp_count = lib->d_counts + CTR_DIST_SUSP;
         spill.budget = lib->bvhd_budget;
         spill.max_blocks = uint32_t(lib->n_cus) * 8u;
+        spill.pool = lib->bvhd_pool;
+        spill.pool_ticket = lib->d_counts + CTR_DIST_TICKET;
+        spill.pool_leaf_min = lib->bvhd_pool_leaf_min;
+        spill.pool_starve = lib->bvhd_pool_starve;
       }
       launch_bvh_distance<T>(blocks_for(n, BVHD_BLOCK), st, wk, lv, bv, io, q, spill);
       tend();

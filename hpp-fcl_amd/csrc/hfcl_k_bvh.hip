@@ -27,26 +27,6 @@
 template <typename T>
 __device__ __forceinline__ BvhSum<T>* bvh_sum(const BvhSplit& sp, uint32_t slot) { return reinterpret_cast<BvhSum<T>*>(sp.sums) + slot; }
 
-// WIDE: models of more than 65535 BV nodes.  A stack entry is then two 32-bit node ids (the LDS stack holds half as
-// many), and a lane whose LDS stack is full moves its lower half to a slab of its own in global memory (BvhSpill) and
-// takes it back when the LDS part runs empty: the reference's stack is a growable std::vector
-// (traversal_recurse.cpp:95), a traversal here is bounded by the slab the host sized from the depths of the models.
-template <bool WIDE> struct BvhEntry;
-template <> struct BvhEntry<false> {
-  typedef uint32_t E;
-  static constexpr int STACK = BVH_STACK;
-  static __device__ __forceinline__ E pack(uint32_t b1, uint32_t b2) { return b1 | (b2 << 16); }
-  static __device__ __forceinline__ uint32_t first(E e) { return e & 0xFFFFu; }
-  static __device__ __forceinline__ uint32_t second(E e) { return e >> 16; }
-};
-template <> struct BvhEntry<true> {
-  typedef uint64_t E;
-  static constexpr int STACK = BVH_STACK / 2;
-  static __device__ __forceinline__ E pack(uint32_t b1, uint32_t b2) { return uint64_t(b1) | (uint64_t(b2) << 32); }
-  static __device__ __forceinline__ uint32_t first(E e) { return uint32_t(e); }
-  static __device__ __forceinline__ uint32_t second(E e) { return uint32_t(e >> 32); }
-};
-
 // ---------------------------------------------------------------------------------------
 // Mesh x solid with one query per LANE: pieces of the SOLID form of k_bvh_collide (below) and of k_bvh_shape_finish.
 // ---------------------------------------------------------------------------------------
@@ -149,6 +129,7 @@ struct SolidLeafIn {
   const decltype(IO<T>::tf1) pose_s;
   ShapeDeferItem<T>* defer;
   uint32_t* defer_count;
+  uint32_t defer_cap;
   uint32_t pair, solid_id, prim, parent, order;
   T bound;            // distance(): min_distance before this leaf, and the triangle it belongs to
   int32_t prev_prim;
@@ -177,7 +158,7 @@ __device__ __noinline__ bool solid_leaf_call(const SolidLeafIn<T> in, const QPar
     item.bound = in.bound;
     item.prev_prim = in.prev_prim;
     const uint32_t slot = atomicAdd(in.defer_count, 1u);
-    in.defer[slot] = item;
+    if (slot < in.defer_cap) in.defer[slot] = item;  // (the host sizes the queue for one item per unit of the batch; never past its end)
     if (slot_out) *slot_out = slot;
   }
   out->guess = guess;
@@ -711,7 +692,7 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
 #if HFCL_SOLID_LEAF_OUTLINE
         {
           SolidLeafIn<T> in{mv, t3, lib.shapes, lib.verts, swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2,
-                            reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer), &wk.counts[CTR_SHAPE_DEFER], pair, solid_id, lb1, my_parent, my_order,
+                            reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer), &wk.counts[CTR_SHAPE_DEFER], wk.shape_defer_cap, pair, solid_id, lb1, my_parent, my_order,
                             T(0), -1};
           SolidLeafOut<T> lo;
           to_epa = solid_leaf_call<T>(in, &q, leaf_ps, guess, &lo);
@@ -739,7 +720,8 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
           item.prim = lb1;
           item.parent = my_parent;
           item.order = my_order;
-          reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer)[atomicAdd(&wk.counts[CTR_SHAPE_DEFER], 1u)] = item;
+          const uint32_t slot = atomicAdd(&wk.counts[CTR_SHAPE_DEFER], 1u);
+          if (slot < wk.shape_defer_cap) reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer)[slot] = item;
         }
         }
 #endif
@@ -1048,7 +1030,7 @@ template <typename T>
 __global__ void __launch_bounds__(64) k_bvh_shape_finish(Work wk, LibView<T> lib, IO<T> io, QParams<T> q, BvhParams bp, BvhSplit split, int distance_mode) {
   constexpr int G = 64 / BS_W;
   __shared__ EpaScratch<T, EPA_MAX_ITER> scratch[G];
-  const uint32_t cnt = wk.counts[CTR_SHAPE_DEFER];
+  const uint32_t cnt = min(wk.counts[CTR_SHAPE_DEFER], wk.shape_defer_cap);
   const ShapeDeferItem<T>* const items = reinterpret_cast<const ShapeDeferItem<T>*>(wk.shape_defer);
   const int lane = threadIdx.x & 63, grp = lane / BS_W, lig = lane & (BS_W - 1);
   for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += gridDim.x * G) {
@@ -1178,7 +1160,7 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
   auto run_leaf = [&](uint32_t prim, bool push, SolidLeafOut<T>* lo) -> bool {
     SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + prim), lib.shapes, lib.verts,
                       swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, push ? reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer) : nullptr,
-                      push ? &wk.counts[CTR_SHAPE_DEFER] : nullptr, pair, solid_id, prim, 0xFFFFFFFFu, 0u, T(0), -1};
+                      push ? &wk.counts[CTR_SHAPE_DEFER] : nullptr, wk.shape_defer_cap, pair, solid_id, prim, 0xFFFFFFFFu, 0u, T(0), -1};
     return solid_leaf_call<T>(in, &q, leaf_ps, guess0, lo);
   };
   for (;;) {
@@ -1682,7 +1664,7 @@ k_bvh_shape_distance_lane(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
   auto leaf = [&](uint32_t prim) {
     SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + prim), lib.shapes, lib.verts,
                       swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer),
-                      &wk.counts[CTR_SHAPE_DEFER], pair, solid_id, prim, 0xFFFFFFFFu, 0u, mind, fb1};
+                      &wk.counts[CTR_SHAPE_DEFER], wk.shape_defer_cap, pair, solid_id, prim, 0xFFFFFFFFu, 0u, mind, fb1};
     SolidLeafOut<T> lo;
     if (solid_leaf_call<T>(in, &q, leaf_ps, guess, &lo)) {
       deferred = true;  // k_bvh_shape_finish writes the record
@@ -1888,7 +1870,7 @@ k_bvh_shape_distance_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
       auto run_leaf = [&](bool push, T bound, int prev) -> bool {
         SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + prim), lib.shapes, lib.verts,
                           swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, push ? reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer) : nullptr,
-                          push ? &wk.counts[CTR_SHAPE_DEFER] : nullptr, pair, solid_id, prim, 0xFFFFFFFFu, 0u, bound, prev};
+                          push ? &wk.counts[CTR_SHAPE_DEFER] : nullptr, wk.shape_defer_cap, pair, solid_id, prim, 0xFFFFFFFFu, 0u, bound, prev};
         return solid_leaf_call<T>(in, &q, leaf_ps, guess0, &lo);
       };
       if (visit) {
@@ -1969,398 +1951,6 @@ k_bvh_shape_distance_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// k_bvh_distance: BVHModel<OBBRSS> x BVHModel<OBBRSS> distance().  distanceRecurse
-// (src/traversal/traversal_recurse.cpp:153-203) flattened: both child pairs get their RSS lower
-// bound, the farther one is pushed first (with its bound), the nearer one on top; a popped entry is
-// skipped when its bound can no longer beat the current minimum (canStop, rel_err = abs_err = 0 as
-// latched by the reference's traversal node, traversal_node_bvhs.h:409-410).  Leaves =
-// sqrTriDistance in model 1's frame; the result is seeded with triangle 0 x triangle 0 (preprocess).
-// ---------------------------------------------------------------------------------------
-
-// Two waves per SIMD (256 VGPRs, 36 B per lane of scratch in fp64) with the 20 KB stack: the compiler's own allocation
-// (264 registers) left one.  cfg4's distance() variant, 1M queries: 0.75 -> 1.85 M q/s with the stack and this (profiles/r03_g).
-#ifndef HFCL_WPE_BVH_DISTANCE
-#define HFCL_WPE_BVH_DISTANCE 2
-#endif
-template <typename T, bool WIDE>
-__global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH_DISTANCE, 8))) k_bvh_distance(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhSpill spill) {
-  typedef BvhEntry<WIDE> EN;
-  typedef typename EN::E E;
-  constexpr int STACK = WIDE ? (BVHD_STACK * 3) / 4 : BVHD_STACK, HALF = STACK / 2;
-  __shared__ E stack_e[STACK][BVHD_BLOCK];
-  // The bound travels in 4 bytes, rounded DOWN: an entry is skipped when its bound cannot beat the current minimum
-  // (canStop), and a bound that is a little too small only means an entry is looked at that the exact bound would have
-  // skipped -- it cannot lower the minimum, and the order of the walk was decided on the exact values when it was pushed.
-  // fp64: the upper word of the double (sign, exponent, 20 mantissa bits; truncation = rounding down for the bounds, which
-  // are >= 0, and exact for the root's -1): the full exponent range, so scenes of any scale keep their pruning (a float
-  // would flush the bounds of a 1e-40-sized scene to zero and the walk would visit every pair).
-  // Where the truncated bound falls short of the minimum by less than its own resolution (the exact bound may still reach
-  // it: exact ties are what prunes a mesh against a shifted copy of itself, tests/test_gpu_parity.py::
-  // test_bvh_degenerate_deep_tree) the exact bound is evaluated again -- same inputs, same value -- and decides.
-  typedef typename std::conditional<sizeof(T) == 8, uint32_t, float>::type BD;
-  __shared__ BD stack_d[STACK][BVHD_BLOCK];
-  auto bound_down = [](T d) -> BD {
-    if constexpr (sizeof(T) == 8)
-      return uint32_t(__double2hiint(d));
-    else
-      return d;
-  };
-  auto bound_value = [](BD b) -> T {
-    if constexpr (sizeof(T) == 8)
-      return __hiloint2double(int(b), 0);
-    else
-      return b;
-  };
-  // this lane's slab of spilled (entry, bound) records (WIDE only): entries first, bounds behind them
-  E* const slab_e = WIDE && spill.slab ? reinterpret_cast<E*>(spill.slab) + size_t(blockIdx.x * BVHD_BLOCK + threadIdx.x) * spill.cap * 2 : nullptr;
-  BD* const slab_d = reinterpret_cast<BD*>(slab_e + spill.cap);
-  uint32_t nspill = 0, steps = 0;
-  const uint32_t cnt = wk.counts[B_BVH];
-  uint32_t* const ticket = &wk.counts[B_COUNT + 2];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const T nanv = Lim<T>::nan();
-  // streaming as in k_bvh_collide: per-lane query state, refill once BVH_REFILL_MIN lanes are idle
-  bool live = false, pending = false, exhausted = false;  // exhausted is wave-uniform
-  uint32_t pair = 0;
-  DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
-  Pose<T> tf1;
-  M3<T> RT_R;
-  V3<T> RT_T;
-  T mind = Lim<T>::max();
-  int fb1 = -1, fb2 = -1;
-  V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1;
-  bool overflow = false;
-  int sp = 0;
-  auto reload = [&]() {  // the LDS part ran empty: take spilled records back (WIDE)
-    if (!WIDE || nspill == 0) return;
-    const uint32_t m = min(nspill, uint32_t(HALF));
-    for (uint32_t k = 0; k < m; ++k) {
-      stack_e[k][tid] = slab_e[nspill - m + k];
-      stack_d[k][tid] = slab_d[nspill - m + k];
-    }
-    nspill -= m;
-    sp = int(m);
-  };
-  auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
-  auto leaf = [&](uint32_t p1i, uint32_t p2i) {
-    const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
-    const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
-    const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + p1i);
-    const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + p2i);
-    V3<T> P, Q;
-    const T d2 = sqr_tri_distance(vtx(v1, t1[0]), vtx(v1, t1[1]), vtx(v1, t1[2]), mul(RT_R, vtx(v2, t2[0])) + RT_T,
-                                  mul(RT_R, vtx(v2, t2[1])) + RT_T, mul(RT_R, vtx(v2, t2[2])) + RT_T, P, Q);
-    const T d = hsqrt(d2);
-    if (mind > d) {  // DistanceResult::update
-      mind = d;
-      fb1 = int(p1i);
-      fb2 = int(p2i);
-      np1 = P;
-      np2 = Q;
-    }
-  };
-  for (;;) {
-    if (live && sp == 0) reload();
-    if (live && sp == 0) {
-      live = false;
-      pending = true;
-    }
-    const uint64_t live_mask = __ballot(live);
-    const int n_live = __popcll(live_mask);
-    if (exhausted ? n_live == 0 : 64 - n_live >= BVH_REFILL_MIN) {
-      if (pending) {
-        PairOut<T> o;
-        o.distance = mind;
-        o.normal = mk<T>(nanv, nanv, nanv);  // not set by the reference on this path (traversal_node_bvhs.h:454,465)
-        o.p1 = xform(tf1, np1);              // postprocess(): model-1 frame -> world
-        o.p2 = xform(tf1, np2);
-        o.gjk_status = GJK_DID_NOT_RUN;
-        o.epa_status = EPA_DID_NOT_RUN;
-        o.gjk_iters = o.epa_iters = 0;
-        store_bvh_record(io, pair, o, mind <= T(0) ? 0x80000000u : 0u, fb1, fb2, overflow);
-        pending = false;
-      }
-      if (exhausted) break;
-      const int n_need = 64 - n_live;
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(ticket, uint32_t(n_need));
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (!live) {
-        const uint32_t it = base + uint32_t(__popcll(~live_mask & ((uint64_t(1) << lane) - 1)));
-        if (it < cnt) {
-          pair = wk.lists[size_t(B_BVH) * wk.n + it];
-          const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
-          m1 = bv.meshes[a.bvh_index];
-          m2 = bv.meshes[b.bvh_index];
-          tf1 = load_pose(io.tf1, pair);
-          const Pose<T> tf2 = load_pose(io.tf2, pair);
-          RT_R = tmul(tf1.R, tf2.R);
-          RT_T = tmul(tf1.R, tf2.t - tf1.t);
-          mind = Lim<T>::max();
-          fb1 = fb2 = -1;
-          np1 = np2 = mk<T>(nanv, nanv, nanv);
-          overflow = false;
-          nspill = 0;
-          steps = 0;
-          leaf(0u, 0u);  // preprocess()
-          sp = 1;
-          stack_e[0][tid] = 0u;
-          stack_d[0][tid] = bound_down(T(-1));
-          live = true;
-        }
-      }
-      if (base + uint32_t(n_need) >= cnt) exhausted = true;
-      continue;
-    }
-    // (Triangle pairs -- 6 % of the steps -- are evaluated where they are popped.  Parking them until several lanes of the
-    // wave wait, as k_bvh_collide does, loses here: a BV step is two rectangle distances, as heavy as a triangle pair, and
-    // the parked lanes miss them: 8 lanes 0.75, 24 lanes 0.56 against 0.83 M q/s; profiles/r03_g.)
-    for (;;) {
-      if (!WIDE && spill.budget && live && sp > 0 && steps >= spill.budget) {
-        // this walk is a long one: its state and stack go to a record, a wave takes it over (k_bvh_distance_coop)
-        DistSusp<T>* r = reinterpret_cast<DistSusp<T>*>(spill.susp) + atomicAdd(spill.susp_count, 1u);
-        r->pair = pair;
-        r->sp = uint32_t(sp);
-        r->fb1 = fb1;
-        r->fb2 = fb2;
-        r->mind = mind;
-        r->np1 = np1;
-        r->np2 = np2;
-        for (int k = 0; k < sp; ++k) {
-          r->entry[k] = uint32_t(stack_e[k][tid]);
-          r->bound[k] = bound_value(stack_d[k][tid]);
-        }
-        sp = 0;
-        live = false;  // (no record from this lane)
-      }
-      const bool run = live && sp > 0;
-      const int n_run = __popcll(__ballot(run || (live && nspill > 0)));
-      if (n_run == 0 || (!exhausted && 64 - n_run >= BVH_REFILL_MIN)) break;
-      if (!run) {
-        if (live) reload();
-        continue;
-      }
-      ++steps;
-      --sp;
-      const E e = stack_e[sp][tid];
-      const BD dc = stack_d[sp][tid];
-      const T de = bound_value(dc);
-      if (de >= T(0) && de >= mind) continue;  // canStop(d)
-      const uint32_t b1 = EN::first(e), b2 = EN::second(e);
-      if constexpr (sizeof(T) == 8) {
-        if (de >= T(0) && __hiloint2double(int(dc) + 1, 0) > mind) {  // the exact bound may reach the minimum: ask it
-          const T exact = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + b1], bv.rss[m1.node_off + b1], bv.nodes[m2.node_off + b2],
-                                          bv.rss[m2.node_off + b2]);
-          if (exact >= mind) continue;
-        }
-      }
-      const DNode<T> n1 = bv.nodes[m1.node_off + b1];
-      const DNode<T> n2 = bv.nodes[m2.node_off + b2];
-      const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
-      if (l1 && l2) {
-        leaf(uint32_t(-(n1.first_child + 1)), uint32_t(-(n2.first_child + 1)));
-        continue;
-      }
-      uint32_t a1, a2, c1, c2;
-      if (l2 || (!l1 && (sqnorm(n1.extent) > sqnorm(n2.extent)))) {
-        a1 = uint32_t(n1.first_child);
-        a2 = b2;
-        c1 = a1 + 1;
-        c2 = b2;
-      } else {
-        a1 = b1;
-        a2 = uint32_t(n2.first_child);
-        c1 = b1;
-        c2 = a2 + 1;
-      }
-      const T d1 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + a1], bv.rss[m1.node_off + a1],
-                                   bv.nodes[m2.node_off + a2], bv.rss[m2.node_off + a2]);
-      const T d2 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + c1], bv.rss[m1.node_off + c1],
-                                   bv.nodes[m2.node_off + c2], bv.rss[m2.node_off + c2]);
-      if (WIDE && sp + 2 > STACK && slab_e && nspill + uint32_t(HALF) <= spill.cap) {  // lower half -> the lane's slab
-        for (int k = 0; k < HALF; ++k) {
-          slab_e[nspill + k] = stack_e[k][tid];
-          slab_d[nspill + k] = stack_d[k][tid];
-        }
-        nspill += uint32_t(HALF);
-        for (int k = HALF; k < sp; ++k) {
-          stack_e[k - HALF][tid] = stack_e[k][tid];
-          stack_d[k - HALF][tid] = stack_d[k][tid];
-        }
-        sp -= HALF;
-      }
-      if (sp + 2 > STACK) {
-        overflow = true;
-        sp = 0;
-        nspill = 0;
-        continue;
-      }
-      const E ea = EN::pack(a1, a2), ec = EN::pack(c1, c2);
-      const bool c_first = d2 < d1;  // visit (c1,c2) first when it is strictly nearer
-      stack_e[sp][tid] = c_first ? ea : ec;
-      stack_d[sp][tid] = bound_down(c_first ? d1 : d2);
-      ++sp;
-      stack_e[sp][tid] = c_first ? ec : ea;
-      stack_d[sp][tid] = bound_down(c_first ? d2 : d1);
-      ++sp;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// k_bvh_distance_coop: the long mesh x mesh distance() walks, a wave per query, 64 stack entries per trip (the scheme of
-// k_bvh_coop applied to branch and bound).  Entries of the window whose bound cannot beat the minimum are dropped; box pairs
-// are replaced by their two successors with their bounds (nearer one on top) wherever they stand -- deciding that with the
-// minimum of the moment can only keep a pair the sequential walk would have skipped, never drop one it would have kept; the
-// triangle pairs IN FRONT of the first pair that is split are evaluated together and applied in stack order (the minimum is
-// lowered by strictly smaller distances only, so the first triangle pair in DFS order that attains it is reported, as in
-// distanceRecurse): the same minimum, triangle ids and witness points as the lane's walk.
-// ---------------------------------------------------------------------------------------
-constexpr int COOPD_CAP = 960, COOPD_SLACK = 64;
-template <typename T>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
-k_bvh_distance_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, BvhSpill spill) {
-  typedef BvhEntry<false> EN;
-  __shared__ uint32_t stack_e[COOPD_CAP + COOPD_SLACK];
-  __shared__ T stack_d[COOPD_CAP + COOPD_SLACK];
-  const int lane = threadIdx.x;
-  const uint32_t n_susp = *spill.susp_count;
-  const T big = Lim<T>::max(), nanv = Lim<T>::nan();
-  auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
-  for (uint32_t qi = blockIdx.x; qi < n_susp; qi += gridDim.x) {
-    const DistSusp<T>* const r = reinterpret_cast<const DistSusp<T>*>(spill.susp) + qi;
-    const uint32_t pair = r->pair;
-    const DMesh m1 = bv.meshes[lib.shapes[wk.shape1[pair]].bvh_index], m2 = bv.meshes[lib.shapes[wk.shape2[pair]].bvh_index];
-    const Pose<T> tf1 = load_pose(io.tf1, pair);
-    M3<T> RT_R;
-    V3<T> RT_T;
-    {
-      const Pose<T> tf2 = load_pose(io.tf2, pair);
-      RT_R = tmul(tf1.R, tf2.R);
-      RT_T = tmul(tf1.R, tf2.t - tf1.t);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    int sp = int(r->sp);
-    if (lane < sp) {
-      stack_e[lane] = r->entry[lane];
-      stack_d[lane] = r->bound[lane];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    T mind = r->mind;
-    int fb1 = r->fb1, fb2 = r->fb2;
-    V3<T> np1 = r->np1, np2 = r->np2;
-    bool overflow = false;
-    while (sp > 0) {
-      const int w = min(64, min(sp, max(COOPD_CAP - sp, 1)));
-      const bool act = lane < w;
-      const uint32_t e = act ? stack_e[sp - 1 - lane] : 0u;
-      const T db = act ? stack_d[sp - 1 - lane] : big;
-      sp -= w;
-      const bool alive = act && !(db >= T(0) && db >= mind);  // canStop(d), with the minimum of the moment
-      const uint32_t b1 = EN::first(e), b2 = EN::second(e);
-      const DNode<T>* const p1n = bv.nodes + m1.node_off + b1;
-      const DNode<T>* const p2n = bv.nodes + m2.node_off + b2;
-      const int32_t fc1 = alive ? p1n->first_child : 0, fc2 = alive ? p2n->first_child : 0;
-      const bool l1 = fc1 < 0, l2 = fc2 < 0;
-      const bool is_leaf = alive && l1 && l2, split = alive && !(l1 && l2);
-      uint32_t ea = 0, ec = 0;
-      T d1 = big, d2 = big;
-      if (split) {
-        uint32_t a1, a2, c1, c2;
-        if (l2 || (!l1 && (sqnorm(p1n->extent) > sqnorm(p2n->extent)))) {
-          a1 = uint32_t(fc1);
-          a2 = b2;
-          c1 = a1 + 1;
-          c2 = b2;
-        } else {
-          a1 = b1;
-          a2 = uint32_t(fc2);
-          c1 = b1;
-          c2 = a2 + 1;
-        }
-        d1 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + a1], bv.rss[m1.node_off + a1], bv.nodes[m2.node_off + a2], bv.rss[m2.node_off + a2]);
-        d2 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + c1], bv.rss[m1.node_off + c1], bv.nodes[m2.node_off + c2], bv.rss[m2.node_off + c2]);
-        ea = EN::pack(a1, a2);
-        ec = EN::pack(c1, c2);
-      }
-      const uint64_t smask = __ballot(split);
-      const int f = smask ? __ffsll((unsigned long long)smask) - 1 : 64;  // the triangle pairs in front of it are visited now
-      const bool visit = is_leaf && lane < f;
-      T val = big;
-      V3<T> P = mk<T>(nanv, nanv, nanv), Q = P;
-      const uint32_t lb1 = uint32_t(-(fc1 + 1)), lb2 = uint32_t(-(fc2 + 1));
-      if (visit) {
-        const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
-        const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
-        const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + lb1);
-        const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + lb2);
-        const T dd = sqr_tri_distance(vtx(v1, t1[0]), vtx(v1, t1[1]), vtx(v1, t1[2]), mul(RT_R, vtx(v2, t2[0])) + RT_T,
-                                      mul(RT_R, vtx(v2, t2[1])) + RT_T, mul(RT_R, vtx(v2, t2[2])) + RT_T, P, Q);
-        val = hsqrt(dd);
-      }
-      // The evaluated triangle pairs, in stack order, exactly as the lane's walk takes them: a pair counts only if its bound does
-      // not let it be skipped at ITS turn (canStop with the minimum as it stands then), and the minimum is lowered by strictly
-      // smaller distances only (DistanceResult::update)
-      {
-        int start = 0, src = -1;
-        T run = mind;
-        for (;;) {
-          const bool cand = visit && lane >= start && !(db >= T(0) && db >= run) && val < run;
-          const uint64_t m = __ballot(cand);
-          if (!m) break;
-          src = __ffsll((unsigned long long)m) - 1;
-          run = __shfl(val, src);
-          start = src + 1;
-        }
-        if (src >= 0) {
-          mind = run;
-          fb1 = __shfl(int(lb1), src);
-          fb2 = __shfl(int(lb2), src);
-          np1 = mk<T>(__shfl(P.x, src), __shfl(P.y, src), __shfl(P.z, src));
-          np2 = mk<T>(__shfl(Q.x, src), __shfl(Q.y, src), __shfl(Q.z, src));
-        }
-      }
-      // the stack again, in order: visited triangle pairs and dropped entries are gone, a split pair is its two successors
-      // (the nearer one on top), a triangle pair behind the first split stays
-      const int cnt = split ? 2 : ((is_leaf && lane >= f) ? 1 : 0);
-      const uint64_t m2b = __ballot(cnt == 2), m1b = __ballot(cnt == 1);
-      const uint64_t deeper = ~((uint64_t(2) << lane) - 1);
-      const int pos = sp + 2 * __popcll(m2b & deeper) + __popcll(m1b & deeper);
-      if (cnt == 2) {
-        const bool c_first = d2 < d1;  // visit (c1, c2) first when it is strictly nearer
-        stack_e[pos] = c_first ? ea : ec;
-        stack_d[pos] = c_first ? d1 : d2;
-        stack_e[pos + 1] = c_first ? ec : ea;
-        stack_d[pos + 1] = c_first ? d2 : d1;
-      } else if (cnt == 1) {
-        stack_e[pos] = e;
-        stack_d[pos] = db;
-      }
-      sp += 2 * __popcll(m2b) + __popcll(m1b);
-      if (sp > COOPD_CAP + COOPD_SLACK - 2) {
-        overflow = true;
-        sp = 0;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (lane == 0) {
-      PairOut<T> o;
-      o.distance = mind;
-      o.normal = mk<T>(nanv, nanv, nanv);  // not set by the reference on this path (traversal_node_bvhs.h:454,465)
-      o.p1 = xform(tf1, np1);              // postprocess(): model-1 frame -> world
-      o.p2 = xform(tf1, np2);
-      o.gjk_status = GJK_DID_NOT_RUN;
-      o.epa_status = EPA_DID_NOT_RUN;
-      o.gjk_iters = o.epa_iters = 0;
-      store_bvh_record(io, pair, o, mind <= T(0) ? 0x80000000u : 0u, fb1, fb2, overflow);
-    }
-  }
-}
-
 // =======================================================================================
 // launchers (hfcl_launch.hpp)
 // =======================================================================================
@@ -2433,16 +2023,6 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
   }
 }
 template <typename T>
-void launch_bvh_distance(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, BvhSpill spill) {
-  if (spill.wide) {
-    if (spill.slab) grid = std::min(grid, int(spill.max_blocks) * (BVH_BLOCK / BVHD_BLOCK));
-    hipLaunchKernelGGL((k_bvh_distance<T, true>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q, spill);
-  } else {
-    hipLaunchKernelGGL((k_bvh_distance<T, false>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q, spill);
-    if (spill.budget) hipLaunchKernelGGL((k_bvh_distance_coop<T>), dim3(std::max(1, std::min(grid, int(spill.max_blocks)))), dim3(64), 0, st, wk, lv, bv, io, spill);
-  }
-}
-template <typename T>
 void launch_bvh_shape(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2) {
   hipLaunchKernelGGL((k_bvh_shape<T>), dim3(grid), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2);
 }
@@ -2493,7 +2073,6 @@ void launch_triangle(int grid, hipStream_t st, const Work& wk, const LibView<T>&
 }
 #define HFCL_INST(T)                                                                                                             \
   template void launch_bvh_collide<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill, bool); \
-  template void launch_bvh_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, BvhSpill);                \
   template void launch_bvh_shape<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T);   \
   template void launch_bvh_shape_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&);          \
   template void launch_bvh_shape_distance_fast<T>(int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, BvhSpill); \

@@ -1,0 +1,699 @@
+// hfcl_k_bvhd.hip -- BVHModel<OBBRSS> x BVHModel<OBBRSS> distance(): the lane walk (k_bvh_distance), its continuations
+// (k_bvh_distance_pool; k_bvh_distance_coop, the ordered wave-per-walk form of round 3) and their launcher.
+//
+// This unit is compiled with -ffp-contract=off (Makefile: FLAGS_k_bvhd): rectDistance, sqrTriDistance and the products in
+// front of them are then the reference's operations one for one (its default build does not contract either, and the
+// oracle is built the same way), so which of several triangle pairs at the minimal distance is reported -- decided by
+// comparisons between values that agree to the last bit or differ in it -- is the reference's choice
+// (tests/test_gpu_parity.py::test_bvh_distance*: triangle ids equal to the oracle's).
+#include <algorithm>
+
+#include "hfcl_dev.hpp"
+#include "hfcl_launch.hpp"
+
+// ---------------------------------------------------------------------------------------
+// k_bvh_distance: BVHModel<OBBRSS> x BVHModel<OBBRSS> distance().  distanceRecurse
+// (src/traversal/traversal_recurse.cpp:153-203) flattened: both child pairs get their RSS lower
+// bound, the farther one is pushed first (with its bound), the nearer one on top; a popped entry is
+// skipped when its bound can no longer beat the current minimum (canStop, rel_err = abs_err = 0 as
+// latched by the reference's traversal node, traversal_node_bvhs.h:409-410).  Leaves =
+// sqrTriDistance in model 1's frame; the result is seeded with triangle 0 x triangle 0 (preprocess).
+// ---------------------------------------------------------------------------------------
+
+
+// Two waves per SIMD (256 VGPRs, 36 B per lane of scratch in fp64) with the 20 KB stack: the compiler's own allocation
+// (264 registers) left one.  cfg4's distance() variant, 1M queries: 0.75 -> 1.85 M q/s with the stack and this (profiles/r03_g).
+#ifndef HFCL_WPE_BVH_DISTANCE
+#define HFCL_WPE_BVH_DISTANCE 2
+#endif
+template <typename T, bool WIDE>
+__global__ void __launch_bounds__(BVHD_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH_DISTANCE, 8))) k_bvh_distance(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhSpill spill) {
+  typedef BvhEntry<WIDE> EN;
+  typedef typename EN::E E;
+  constexpr int STACK = WIDE ? (BVHD_STACK * 3) / 4 : BVHD_STACK, HALF = STACK / 2;
+  __shared__ E stack_e[STACK][BVHD_BLOCK];
+  // The bound travels in 4 bytes, rounded DOWN: an entry is skipped when its bound cannot beat the current minimum
+  // (canStop), and a bound that is a little too small only means an entry is looked at that the exact bound would have
+  // skipped -- it cannot lower the minimum, and the order of the walk was decided on the exact values when it was pushed.
+  // fp64: the upper word of the double (sign, exponent, 20 mantissa bits; truncation = rounding down for the bounds, which
+  // are >= 0, and exact for the root's -1): the full exponent range, so scenes of any scale keep their pruning (a float
+  // would flush the bounds of a 1e-40-sized scene to zero and the walk would visit every pair).
+  // Where the truncated bound falls short of the minimum by less than its own resolution (the exact bound may still reach
+  // it: exact ties are what prunes a mesh against a shifted copy of itself, tests/test_gpu_parity.py::
+  // test_bvh_degenerate_deep_tree) the exact bound is evaluated again -- same inputs, same value -- and decides.
+  typedef typename std::conditional<sizeof(T) == 8, uint32_t, float>::type BD;
+  __shared__ BD stack_d[STACK][BVHD_BLOCK];
+  auto bound_down = [](T d) -> BD {
+    if constexpr (sizeof(T) == 8)
+      return uint32_t(__double2hiint(d));
+    else
+      return d;
+  };
+  auto bound_value = [](BD b) -> T {
+    if constexpr (sizeof(T) == 8)
+      return __hiloint2double(int(b), 0);
+    else
+      return b;
+  };
+  // this lane's slab of spilled (entry, bound) records (WIDE only): entries first, bounds behind them
+  E* const slab_e = WIDE && spill.slab ? reinterpret_cast<E*>(spill.slab) + size_t(blockIdx.x * BVHD_BLOCK + threadIdx.x) * spill.cap * 2 : nullptr;
+  BD* const slab_d = reinterpret_cast<BD*>(slab_e + spill.cap);
+  uint32_t nspill = 0, steps = 0;
+  const uint32_t cnt = wk.counts[B_BVH];
+  uint32_t* const ticket = &wk.counts[B_COUNT + 2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const T nanv = Lim<T>::nan();
+  // streaming as in k_bvh_collide: per-lane query state, refill once BVH_REFILL_MIN lanes are idle
+  bool live = false, pending = false, exhausted = false;  // exhausted is wave-uniform
+  uint32_t pair = 0;
+  DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
+  Pose<T> tf1;
+  M3<T> RT_R;
+  V3<T> RT_T;
+  T mind = Lim<T>::max();
+  int fb1 = -1, fb2 = -1;
+  V3<T> np1 = mk<T>(nanv, nanv, nanv), np2 = np1;
+  bool overflow = false;
+  int sp = 0;
+  auto reload = [&]() {  // the LDS part ran empty: take spilled records back (WIDE)
+    if (!WIDE || nspill == 0) return;
+    const uint32_t m = min(nspill, uint32_t(HALF));
+    for (uint32_t k = 0; k < m; ++k) {
+      stack_e[k][tid] = slab_e[nspill - m + k];
+      stack_d[k][tid] = slab_d[nspill - m + k];
+    }
+    nspill -= m;
+    sp = int(m);
+  };
+  auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
+  auto leaf = [&](uint32_t p1i, uint32_t p2i) {
+    const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
+    const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
+    const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + p1i);
+    const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + p2i);
+    V3<T> P, Q;
+    const T d2 = sqr_tri_distance(vtx(v1, t1[0]), vtx(v1, t1[1]), vtx(v1, t1[2]), mul(RT_R, vtx(v2, t2[0])) + RT_T,
+                                  mul(RT_R, vtx(v2, t2[1])) + RT_T, mul(RT_R, vtx(v2, t2[2])) + RT_T, P, Q);
+    const T d = hsqrt(d2);
+    if (mind > d) {  // DistanceResult::update
+      mind = d;
+      fb1 = int(p1i);
+      fb2 = int(p2i);
+      np1 = P;
+      np2 = Q;
+    }
+  };
+  for (;;) {
+    if (live && sp == 0) reload();
+    if (live && sp == 0) {
+      live = false;
+      pending = true;
+    }
+    const uint64_t live_mask = __ballot(live);
+    const int n_live = __popcll(live_mask);
+    if (exhausted ? n_live == 0 : 64 - n_live >= BVH_REFILL_MIN) {
+      if (pending) {
+        PairOut<T> o;
+        o.distance = mind;
+        o.normal = mk<T>(nanv, nanv, nanv);  // not set by the reference on this path (traversal_node_bvhs.h:454,465)
+        o.p1 = xform(tf1, np1);              // postprocess(): model-1 frame -> world
+        o.p2 = xform(tf1, np2);
+        o.gjk_status = GJK_DID_NOT_RUN;
+        o.epa_status = EPA_DID_NOT_RUN;
+        o.gjk_iters = o.epa_iters = 0;
+        store_bvh_record(io, pair, o, mind <= T(0) ? 0x80000000u : 0u, fb1, fb2, overflow);
+        pending = false;
+      }
+      if (exhausted) break;
+      const int n_need = 64 - n_live;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ticket, uint32_t(n_need));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (!live) {
+        const uint32_t it = base + uint32_t(__popcll(~live_mask & ((uint64_t(1) << lane) - 1)));
+        if (it < cnt) {
+          pair = wk.lists[size_t(B_BVH) * wk.n + it];
+          const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+          m1 = bv.meshes[a.bvh_index];
+          m2 = bv.meshes[b.bvh_index];
+          tf1 = load_pose(io.tf1, pair);
+          const Pose<T> tf2 = load_pose(io.tf2, pair);
+          RT_R = tmul(tf1.R, tf2.R);
+          RT_T = tmul(tf1.R, tf2.t - tf1.t);
+          mind = Lim<T>::max();
+          fb1 = fb2 = -1;
+          np1 = np2 = mk<T>(nanv, nanv, nanv);
+          overflow = false;
+          nspill = 0;
+          steps = 0;
+          leaf(0u, 0u);  // preprocess()
+          sp = 1;
+          stack_e[0][tid] = 0u;
+          stack_d[0][tid] = bound_down(T(-1));
+          live = true;
+        }
+      }
+      if (base + uint32_t(n_need) >= cnt) exhausted = true;
+      continue;
+    }
+    // (Triangle pairs -- 6 % of the steps -- are evaluated where they are popped.  Parking them until several lanes of the
+    // wave wait, as k_bvh_collide does, loses here: a BV step is two rectangle distances, as heavy as a triangle pair, and
+    // the parked lanes miss them: 8 lanes 0.75, 24 lanes 0.56 against 0.83 M q/s; profiles/r03_g.)
+    for (;;) {
+      if (!WIDE && spill.budget && live && sp > 0 && steps >= spill.budget) {
+        // this walk is a long one: its state and stack go to a record, a wave takes it over (k_bvh_distance_coop)
+        DistSusp<T>* r = reinterpret_cast<DistSusp<T>*>(spill.susp) + atomicAdd(spill.susp_count, 1u);
+        r->pair = pair;
+        r->sp = uint32_t(sp);
+        r->fb1 = fb1;
+        r->fb2 = fb2;
+        r->mind = mind;
+        r->np1 = np1;
+        r->np2 = np2;
+        for (int k = 0; k < sp; ++k) {
+          r->entry[k] = uint32_t(stack_e[k][tid]);
+          r->bound[k] = bound_value(stack_d[k][tid]);
+        }
+        sp = 0;
+        live = false;  // (no record from this lane)
+      }
+      const bool run = live && sp > 0;
+      const int n_run = __popcll(__ballot(run || (live && nspill > 0)));
+      if (n_run == 0 || (!exhausted && 64 - n_run >= BVH_REFILL_MIN)) break;
+      if (!run) {
+        if (live) reload();
+        continue;
+      }
+      ++steps;
+      --sp;
+      const E e = stack_e[sp][tid];
+      const BD dc = stack_d[sp][tid];
+      const T de = bound_value(dc);
+      if (de >= T(0) && de >= mind) continue;  // canStop(d)
+      const uint32_t b1 = EN::first(e), b2 = EN::second(e);
+      if constexpr (sizeof(T) == 8) {
+        if (de >= T(0) && __hiloint2double(int(dc) + 1, 0) > mind) {  // the exact bound may reach the minimum: ask it
+          const T exact = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + b1], bv.rss[m1.node_off + b1], bv.nodes[m2.node_off + b2],
+                                          bv.rss[m2.node_off + b2]);
+          if (exact >= mind) continue;
+        }
+      }
+      const DNode<T> n1 = bv.nodes[m1.node_off + b1];
+      const DNode<T> n2 = bv.nodes[m2.node_off + b2];
+      const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
+      if (l1 && l2) {
+        leaf(uint32_t(-(n1.first_child + 1)), uint32_t(-(n2.first_child + 1)));
+        continue;
+      }
+      uint32_t a1, a2, c1, c2;
+      if (l2 || (!l1 && (sqnorm(n1.extent) > sqnorm(n2.extent)))) {
+        a1 = uint32_t(n1.first_child);
+        a2 = b2;
+        c1 = a1 + 1;
+        c2 = b2;
+      } else {
+        a1 = b1;
+        a2 = uint32_t(n2.first_child);
+        c1 = b1;
+        c2 = a2 + 1;
+      }
+      const T d1 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + a1], bv.rss[m1.node_off + a1],
+                                   bv.nodes[m2.node_off + a2], bv.rss[m2.node_off + a2]);
+      const T d2 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + c1], bv.rss[m1.node_off + c1],
+                                   bv.nodes[m2.node_off + c2], bv.rss[m2.node_off + c2]);
+      if (WIDE && sp + 2 > STACK && slab_e && nspill + uint32_t(HALF) <= spill.cap) {  // lower half -> the lane's slab
+        for (int k = 0; k < HALF; ++k) {
+          slab_e[nspill + k] = stack_e[k][tid];
+          slab_d[nspill + k] = stack_d[k][tid];
+        }
+        nspill += uint32_t(HALF);
+        for (int k = HALF; k < sp; ++k) {
+          stack_e[k - HALF][tid] = stack_e[k][tid];
+          stack_d[k - HALF][tid] = stack_d[k][tid];
+        }
+        sp -= HALF;
+      }
+      if (sp + 2 > STACK) {
+        overflow = true;
+        sp = 0;
+        nspill = 0;
+        continue;
+      }
+      const E ea = EN::pack(a1, a2), ec = EN::pack(c1, c2);
+      const bool c_first = d2 < d1;  // visit (c1,c2) first when it is strictly nearer
+      stack_e[sp][tid] = c_first ? ea : ec;
+      stack_d[sp][tid] = bound_down(c_first ? d1 : d2);
+      ++sp;
+      stack_e[sp][tid] = c_first ? ec : ea;
+      stack_d[sp][tid] = bound_down(c_first ? d2 : d1);
+      ++sp;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_bvh_distance_coop: the long mesh x mesh distance() walks, a wave per query, 64 stack entries per trip (the scheme of
+// k_bvh_coop applied to branch and bound).  Entries of the window whose bound cannot beat the minimum are dropped; box pairs
+// are replaced by their two successors with their bounds (nearer one on top) wherever they stand -- deciding that with the
+// minimum of the moment can only keep a pair the sequential walk would have skipped, never drop one it would have kept; the
+// triangle pairs IN FRONT of the first pair that is split are evaluated together and applied in stack order (the minimum is
+// lowered by strictly smaller distances only, so the first triangle pair in DFS order that attains it is reported, as in
+// distanceRecurse): the same minimum, triangle ids and witness points as the lane's walk.
+// ---------------------------------------------------------------------------------------
+constexpr int COOPD_CAP = 960, COOPD_SLACK = 64;
+template <typename T>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
+k_bvh_distance_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, BvhSpill spill) {
+  typedef BvhEntry<false> EN;
+  __shared__ uint32_t stack_e[COOPD_CAP + COOPD_SLACK];
+  __shared__ T stack_d[COOPD_CAP + COOPD_SLACK];
+  const int lane = threadIdx.x;
+  const uint32_t n_susp = *spill.susp_count;
+  const T big = Lim<T>::max(), nanv = Lim<T>::nan();
+  auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
+  for (uint32_t qi = blockIdx.x; qi < n_susp; qi += gridDim.x) {
+    const DistSusp<T>* const r = reinterpret_cast<const DistSusp<T>*>(spill.susp) + qi;
+    const uint32_t pair = r->pair;
+    const DMesh m1 = bv.meshes[lib.shapes[wk.shape1[pair]].bvh_index], m2 = bv.meshes[lib.shapes[wk.shape2[pair]].bvh_index];
+    const Pose<T> tf1 = load_pose(io.tf1, pair);
+    M3<T> RT_R;
+    V3<T> RT_T;
+    {
+      const Pose<T> tf2 = load_pose(io.tf2, pair);
+      RT_R = tmul(tf1.R, tf2.R);
+      RT_T = tmul(tf1.R, tf2.t - tf1.t);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int sp = int(r->sp);
+    if (lane < sp) {
+      stack_e[lane] = r->entry[lane];
+      stack_d[lane] = r->bound[lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    T mind = r->mind;
+    int fb1 = r->fb1, fb2 = r->fb2;
+    V3<T> np1 = r->np1, np2 = r->np2;
+    bool overflow = false;
+    while (sp > 0) {
+      const int w = min(64, min(sp, max(COOPD_CAP - sp, 1)));
+      const bool act = lane < w;
+      const uint32_t e = act ? stack_e[sp - 1 - lane] : 0u;
+      const T db = act ? stack_d[sp - 1 - lane] : big;
+      sp -= w;
+      const bool alive = act && !(db >= T(0) && db >= mind);  // canStop(d), with the minimum of the moment
+      const uint32_t b1 = EN::first(e), b2 = EN::second(e);
+      const DNode<T>* const p1n = bv.nodes + m1.node_off + b1;
+      const DNode<T>* const p2n = bv.nodes + m2.node_off + b2;
+      const int32_t fc1 = alive ? p1n->first_child : 0, fc2 = alive ? p2n->first_child : 0;
+      const bool l1 = fc1 < 0, l2 = fc2 < 0;
+      const bool is_leaf = alive && l1 && l2, split = alive && !(l1 && l2);
+      uint32_t ea = 0, ec = 0;
+      T d1 = big, d2 = big;
+      if (split) {
+        uint32_t a1, a2, c1, c2;
+        if (l2 || (!l1 && (sqnorm(p1n->extent) > sqnorm(p2n->extent)))) {
+          a1 = uint32_t(fc1);
+          a2 = b2;
+          c1 = a1 + 1;
+          c2 = b2;
+        } else {
+          a1 = b1;
+          a2 = uint32_t(fc2);
+          c1 = b1;
+          c2 = a2 + 1;
+        }
+        d1 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + a1], bv.rss[m1.node_off + a1], bv.nodes[m2.node_off + a2], bv.rss[m2.node_off + a2]);
+        d2 = rss_lower_bound(RT_R, RT_T, bv.nodes[m1.node_off + c1], bv.rss[m1.node_off + c1], bv.nodes[m2.node_off + c2], bv.rss[m2.node_off + c2]);
+        ea = EN::pack(a1, a2);
+        ec = EN::pack(c1, c2);
+      }
+      const uint64_t smask = __ballot(split);
+      const int f = smask ? __ffsll((unsigned long long)smask) - 1 : 64;  // the triangle pairs in front of it are visited now
+      const bool visit = is_leaf && lane < f;
+      T val = big;
+      V3<T> P = mk<T>(nanv, nanv, nanv), Q = P;
+      const uint32_t lb1 = uint32_t(-(fc1 + 1)), lb2 = uint32_t(-(fc2 + 1));
+      if (visit) {
+        const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
+        const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
+        const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + lb1);
+        const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + lb2);
+        const T dd = sqr_tri_distance(vtx(v1, t1[0]), vtx(v1, t1[1]), vtx(v1, t1[2]), mul(RT_R, vtx(v2, t2[0])) + RT_T,
+                                      mul(RT_R, vtx(v2, t2[1])) + RT_T, mul(RT_R, vtx(v2, t2[2])) + RT_T, P, Q);
+        val = hsqrt(dd);
+      }
+      // The evaluated triangle pairs, in stack order, exactly as the lane's walk takes them: a pair counts only if its bound does
+      // not let it be skipped at ITS turn (canStop with the minimum as it stands then), and the minimum is lowered by strictly
+      // smaller distances only (DistanceResult::update)
+      {
+        int start = 0, src = -1;
+        T run = mind;
+        for (;;) {
+          const bool cand = visit && lane >= start && !(db >= T(0) && db >= run) && val < run;
+          const uint64_t m = __ballot(cand);
+          if (!m) break;
+          src = __ffsll((unsigned long long)m) - 1;
+          run = __shfl(val, src);
+          start = src + 1;
+        }
+        if (src >= 0) {
+          mind = run;
+          fb1 = __shfl(int(lb1), src);
+          fb2 = __shfl(int(lb2), src);
+          np1 = mk<T>(__shfl(P.x, src), __shfl(P.y, src), __shfl(P.z, src));
+          np2 = mk<T>(__shfl(Q.x, src), __shfl(Q.y, src), __shfl(Q.z, src));
+        }
+      }
+      // the stack again, in order: visited triangle pairs and dropped entries are gone, a split pair is its two successors
+      // (the nearer one on top), a triangle pair behind the first split stays
+      const int cnt = split ? 2 : ((is_leaf && lane >= f) ? 1 : 0);
+      const uint64_t m2b = __ballot(cnt == 2), m1b = __ballot(cnt == 1);
+      const uint64_t deeper = ~((uint64_t(2) << lane) - 1);
+      const int pos = sp + 2 * __popcll(m2b & deeper) + __popcll(m1b & deeper);
+      if (cnt == 2) {
+        const bool c_first = d2 < d1;  // visit (c1, c2) first when it is strictly nearer
+        stack_e[pos] = c_first ? ea : ec;
+        stack_d[pos] = c_first ? d1 : d2;
+        stack_e[pos + 1] = c_first ? ec : ea;
+        stack_d[pos + 1] = c_first ? d2 : d1;
+      } else if (cnt == 1) {
+        stack_e[pos] = e;
+        stack_d[pos] = db;
+      }
+      sp += 2 * __popcll(m2b) + __popcll(m1b);
+      if (sp > COOPD_CAP + COOPD_SLACK - 2) {
+        overflow = true;
+        sp = 0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+      PairOut<T> o;
+      o.distance = mind;
+      o.normal = mk<T>(nanv, nanv, nanv);  // not set by the reference on this path (traversal_node_bvhs.h:454,465)
+      o.p1 = xform(tf1, np1);              // postprocess(): model-1 frame -> world
+      o.p2 = xform(tf1, np2);
+      o.gjk_status = GJK_DID_NOT_RUN;
+      o.epa_status = EPA_DID_NOT_RUN;
+      o.gjk_iters = o.epa_iters = 0;
+      store_bvh_record(io, pair, o, mind <= T(0) ? 0x80000000u : 0u, fb1, fb2, overflow);
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// k_bvh_distance_pool: the mesh x mesh distance() walks past the lanes' step budget, POOL_Q walks per wave with their tests
+// pooled (round 4; replaces k_bvh_distance_coop as the default continuation).
+//
+// What the measurements of the wave-per-walk form said (profiles/r04_b): 0.47 of the fp64 issue peak with 16 of 64 lanes
+// active on average -- a walk's window holds 10-20 box pairs to split and each of their lanes ran both children's rectangle
+// distances one after the other while the rest idled, and triangle pairs were evaluated a handful at a time.  Here
+//   * a wave owns POOL_Q walks (slots), each with its stack in LDS, in DFS order (top = next in the reference's order);
+//   * every trip, each slot offers the top POOL_SEG entries of its stack; entries whose bound cannot beat the slot's
+//     minimum are dropped, box pairs to split put their TWO child tests into one list for the whole wave, and the list is
+//     worked off 64 tests at a time, one rss_lower_bound per lane (the packed 128-B DNodeD records: one line per node);
+//   * triangle pairs stay on the stack until the wave holds `leaf_min` of them in its windows (or has too few box tests
+//     to fill half of its lanes), then all of them are evaluated together, one per lane;
+//   * the window is written back in order: a split pair becomes its two children (nearer one on top, the reference's
+//     `d2 < d1` rule), a deferred triangle pair stays, everything else is gone.
+// An entry carries what the next trip needs to know about it (triangle ids, or which node is split and its first child),
+// filled in by the lane that tested it from the records it had loaded anyway: a trip has no dependent gather before its tests.
+//
+// Order.  The reference visits triangle pairs in DFS order and keeps the FIRST one that attains the minimum
+// (DistanceResult::update lowers on `<` only), and it skips an entry when its bound is >= the minimum of that moment.  The
+// minimum itself does not depend on the order of the visits; the reported pair is the first in DFS order among the visited
+// ones that attain it.  So each slot keeps, with its minimum, a marker `p` = how many entries of its (DFS-ordered) stack
+// come AFTER the pair that set it: a triangle pair replaces the minimum when it is strictly smaller, or equal and in front
+// of it (index >= p); an entry is dropped when its bound exceeds the minimum, or equals it and stands behind it (index < p:
+// the sequential walk would already hold that minimum at the entry's turn) -- an entry in front of it with an equal bound
+// is kept, as the sequential walk (whose minimum was still larger there) would have.  Writing the window back updates `p`
+// by counting what the entries behind the marker became.  The lane phase hands a walk over with everything on its stack
+// behind its minimum (p = sp).  Measured against the sequential walk on the host (tools/order_free_probe.py, 100 000 cfg4d
+// queries): the same distance, triangle ids and witness points in every query; 95 % of the separated queries have several
+// triangle pairs at exactly the minimal distance (shared vertices), so the marker is what decides the reported ids.
+// ---------------------------------------------------------------------------------------
+#ifndef HFCL_POOL_Q
+#define HFCL_POOL_Q 4
+#endif
+constexpr int POOL_Q = HFCL_POOL_Q, POOL_SEG = 64 / POOL_Q;
+// a slot's stack: windows narrow once POOL_CAPW entries are in use, down to plain DFS, which adds at most the lanes'
+// stack depth (BVHD_STACK >= depth1 + depth2 + 2, make_bvh_spill) on top
+constexpr int POOL_CAPW = 640 / POOL_Q, POOL_CAP = POOL_CAPW + BVHD_STACK + 8;
+
+// what the next trip needs to know about the node pair (n1, n2): bit 31 = two leaves -> triangle ids (15 bits each; a
+// narrow-form model has < 32 768 triangles); else bit 30 = node 1 is the one to split (distanceRecurse's descent rule:
+// node 2 a leaf, or node 1 not a leaf and larger) and bits 0-15 = the first child of the node that is split
+__device__ __forceinline__ uint32_t pool_entry_info(int32_t fc1, uint32_t rk1, int32_t fc2, uint32_t rk2) {
+  const bool l1 = fc1 < 0, l2 = fc2 < 0;
+  if (l1 && l2) return 0x80000000u | uint32_t(-(fc1 + 1)) | (uint32_t(-(fc2 + 1)) << 15);
+  const bool side1 = l2 || (!l1 && rk1 > rk2);
+  return side1 ? (0x40000000u | uint32_t(fc1)) : uint32_t(fc2);
+}
+
+#ifndef HFCL_WPE_BVHD_POOL
+#define HFCL_WPE_BVHD_POOL 2
+#endif
+template <typename T>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVHD_POOL, 8))) k_bvh_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, BvhSpill spill) {
+  constexpr int Q = POOL_Q, SEG = POOL_SEG;
+  __shared__ uint32_t st_e[Q][POOL_CAP], st_x[Q][POOL_CAP];
+  __shared__ T st_d[Q][POOL_CAP];
+  __shared__ T q_rt[Q][12];   // RT_R (row-major), RT_T of the slot's query
+  __shared__ T q_wit[Q][6];   // witness points of the slot's minimum, model-1 frame
+  __shared__ int q_fb[Q][2];
+  __shared__ uint32_t t_n1[128], t_n2[128], t_q[128], t_x[128];
+  __shared__ T t_res[128];
+  const int lane = threadIdx.x, q = lane / SEG, j = lane % SEG;
+  const uint64_t lt_mask = (uint64_t(1) << lane) - 1;
+  const uint64_t segm = (SEG == 64 ? ~uint64_t(0) : ((uint64_t(1) << SEG) - 1)) << (q * SEG);
+  const uint64_t deeper = segm & ~((uint64_t(2) << lane) - 1);  // the lanes of my slot that hold entries further down
+  const uint32_t n_susp = *spill.susp_count;
+  const int leaf_min = int(spill.pool_leaf_min), starve = int(spill.pool_starve);
+  const T big = Lim<T>::max(), nanv = Lim<T>::nan();
+  auto sync = []() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
+  // slot state, identical in the SEG lanes of a slot
+  bool active = false, exhausted = false;
+  int sp = 0, p = 0;
+  T mind = big;
+  uint32_t pair = 0, off1 = 0, off2 = 0;
+  DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
+  for (;;) {
+    // ---- slots without a walk take the next suspended ones
+    const uint64_t idle = __ballot(!active && j == 0);
+    if (idle && !exhausted) {
+      const int n_need = __popcll(idle);
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(spill.pool_ticket, uint32_t(n_need));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base + uint32_t(n_need) >= n_susp) exhausted = true;
+      const uint32_t it = base + uint32_t(__popcll(idle & ((uint64_t(1) << (q * SEG)) - 1)));  // (bits of idle sit at the slots' first lanes)
+      if (!active && it < n_susp) {
+        const DistSusp<T>* const r = reinterpret_cast<const DistSusp<T>*>(spill.susp) + it;
+        pair = r->pair;
+        m1 = bv.meshes[lib.shapes[wk.shape1[pair]].bvh_index];
+        m2 = bv.meshes[lib.shapes[wk.shape2[pair]].bvh_index];
+        off1 = m1.node_off;
+        off2 = m2.node_off;
+        sp = int(r->sp);
+        p = sp;  // everything on the stack comes after what the lane has visited
+        mind = r->mind;
+        for (int k = j; k < sp; k += SEG) {
+          const uint32_t e = r->entry[k];
+          const DNodeD<T>* const a = bv.dnodes + off1 + (e & 0xFFFFu);
+          const DNodeD<T>* const b = bv.dnodes + off2 + (e >> 16);
+          st_e[q][k] = e;
+          st_x[q][k] = pool_entry_info(a->first_child, a->rank, b->first_child, b->rank);
+          st_d[q][k] = r->bound[k];
+        }
+        if (j == 0) {
+          const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+          const M3<T> R = tmul(tf1.R, tf2.R);
+          const V3<T> t = tmul(tf1.R, tf2.t - tf1.t);
+          T* o = q_rt[q];
+          o[0] = R.r0.x; o[1] = R.r0.y; o[2] = R.r0.z; o[3] = R.r1.x; o[4] = R.r1.y; o[5] = R.r1.z;
+          o[6] = R.r2.x; o[7] = R.r2.y; o[8] = R.r2.z; o[9] = t.x; o[10] = t.y; o[11] = t.z;
+          q_fb[q][0] = r->fb1;
+          q_fb[q][1] = r->fb2;
+          T* w6 = q_wit[q];
+          w6[0] = r->np1.x; w6[1] = r->np1.y; w6[2] = r->np1.z; w6[3] = r->np2.x; w6[4] = r->np2.y; w6[5] = r->np2.z;
+        }
+        active = true;
+      }
+      sync();
+    }
+    if (__ballot(active) == 0) break;  // (only once the records have run out)
+    // ---- the windows
+    const int w = active ? min(SEG, min(sp, max(POOL_CAPW - sp, 1))) : 0;
+    const bool act = j < w;
+    const int i = sp - 1 - j;
+    uint32_t e = 0, x = 0;
+    T db = big;
+    if (act) {
+      e = st_e[q][i];
+      x = st_x[q][i];
+      db = st_d[q][i];
+    }
+    // canStop(bound) with the slot's minimum.  Behind the pair that set the minimum (i < p) this is the sequential walk's
+    // test at the entry's turn.  In front of it the sequential walk held a larger minimum at the entry's turn, and a bound
+    // can exceed a distance below it by an ulp (a leaf pair's rectangles against its triangles): such an entry may hold
+    // the first pair at the minimal distance, so entries in front are only dropped when their bound is clear of the minimum
+    const bool alive = act && !(db >= T(0) && (i < p ? db >= mind : db > mind * (T(1) + T(64) * Lim<T>::eps())));
+    const bool is_leaf = alive && (x >> 31) != 0u, split = alive && (x >> 31) == 0u;
+    // ---- the children's tests of every split pair of the wave in one list
+    const uint64_t smask = __ballot(split);
+    const int ns = __popcll(smask), k2 = 2 * __popcll(smask & lt_mask);
+    uint32_t ea = 0, ec = 0;
+    if (split) {
+      const uint32_t b1 = e & 0xFFFFu, b2 = e >> 16, fc = x & 0xFFFFu;
+      const bool side1 = (x & 0x40000000u) != 0u;
+      const uint32_t a1 = side1 ? fc : b1, a2 = side1 ? b2 : fc, c1 = side1 ? fc + 1 : b1, c2 = side1 ? b2 : fc + 1;
+      ea = a1 | (a2 << 16);
+      ec = c1 | (c2 << 16);
+      t_n1[k2] = off1 + a1;
+      t_n2[k2] = off2 + a2;
+      t_q[k2] = uint32_t(q);
+      t_n1[k2 + 1] = off1 + c1;
+      t_n2[k2 + 1] = off2 + c2;
+      t_q[k2 + 1] = uint32_t(q);
+    }
+    sync();
+    for (int tb = 0; tb < 2 * ns; tb += 64) {
+      const int t = tb + lane;
+      if (t < 2 * ns) {
+        const T* const rt = q_rt[t_q[t]];
+        M3<T> R0;
+        R0.r0 = mk<T>(rt[0], rt[1], rt[2]);
+        R0.r1 = mk<T>(rt[3], rt[4], rt[5]);
+        R0.r2 = mk<T>(rt[6], rt[7], rt[8]);
+        const V3<T> T0 = mk<T>(rt[9], rt[10], rt[11]);
+        const DNodeD<T> A = bv.dnodes[t_n1[t]], B = bv.dnodes[t_n2[t]];
+        t_res[t] = rss_lower_bound(R0, T0, A, B);
+        t_x[t] = pool_entry_info(A.first_child, A.rank, B.first_child, B.rank);
+      }
+    }
+    sync();
+    T d1 = big, d2 = big;
+    uint32_t xa = 0, xc = 0;
+    if (split) {
+      d1 = t_res[k2];
+      d2 = t_res[k2 + 1];
+      xa = t_x[k2];
+      xc = t_x[k2 + 1];
+    }
+    // ---- the triangle pairs, once they are worth a pass
+    const int nl = __popcll(__ballot(is_leaf));
+    const bool do_leaves = nl > 0 && (nl >= leaf_min || 2 * ns < starve);
+    int jw = -1;  // the window entry that set a new minimum in this trip (slot-uniform)
+    if (do_leaves) {
+      T val = big;
+      V3<T> P = mk<T>(nanv, nanv, nanv), Qp = P;
+      const uint32_t lb1 = x & 0x7FFFu, lb2 = (x >> 15) & 0x7FFFu;
+      if (is_leaf) {
+        const T* const rt = q_rt[q];
+        M3<T> R0;
+        R0.r0 = mk<T>(rt[0], rt[1], rt[2]);
+        R0.r1 = mk<T>(rt[3], rt[4], rt[5]);
+        R0.r2 = mk<T>(rt[6], rt[7], rt[8]);
+        const V3<T> T0 = mk<T>(rt[9], rt[10], rt[11]);
+        const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
+        const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
+        const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + lb1);
+        const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + lb2);
+        const T dd = sqr_tri_distance(vtx(v1, t1[0]), vtx(v1, t1[1]), vtx(v1, t1[2]), mul(R0, vtx(v2, t2[0])) + T0,
+                                      mul(R0, vtx(v2, t2[1])) + T0, mul(R0, vtx(v2, t2[2])) + T0, P, Qp);
+        val = hsqrt(dd);
+      }
+      // DistanceResult::update over the slot's evaluated pairs: the smallest value, the first in DFS order among equals
+      // (j = 0 is the top of the stack), and against the standing minimum a tie wins only in front of it
+      const bool cand = is_leaf && (val < mind || (val == mind && i >= p));
+      T bestv = cand ? val : big;
+      int bj = cand ? j : 64;
+#pragma unroll
+      for (int m = 1; m < SEG; m <<= 1) {
+        const T ov = __shfl_xor(bestv, m);
+        const int oj = __shfl_xor(bj, m);
+        if (oj < 64 && (bj == 64 || ov < bestv || (ov == bestv && oj < bj))) {
+          bestv = ov;
+          bj = oj;
+        }
+      }
+      if (bj < 64) {
+        jw = bj;
+        mind = bestv;
+        if (j == bj) {
+          q_fb[q][0] = int(lb1);
+          q_fb[q][1] = int(lb2);
+          T* w6 = q_wit[q];
+          w6[0] = P.x; w6[1] = P.y; w6[2] = P.z; w6[3] = Qp.x; w6[4] = Qp.y; w6[5] = Qp.z;
+        }
+      }
+    }
+    // ---- the windows written back, in order
+    const int cnt = split ? 2 : ((is_leaf && !do_leaves) ? 1 : 0);
+    const uint64_t m2b = __ballot(cnt == 2), m1b = __ballot(cnt == 1);
+    const int base_i = sp - w;
+    const int pos = base_i + 2 * __popcll(m2b & deeper) + __popcll(m1b & deeper);
+    if (cnt == 2) {
+      const bool c_first = d2 < d1;  // visit (c1, c2) first when it is strictly nearer
+      st_e[q][pos] = c_first ? ea : ec;
+      st_x[q][pos] = c_first ? xa : xc;
+      st_d[q][pos] = c_first ? d1 : d2;
+      st_e[q][pos + 1] = c_first ? ec : ea;
+      st_x[q][pos + 1] = c_first ? xc : xa;
+      st_d[q][pos + 1] = c_first ? d2 : d1;
+    } else if (cnt == 1) {
+      st_e[q][pos] = e;
+      st_x[q][pos] = x;
+      st_d[q][pos] = db;
+    }
+    // the marker: what stands behind the pair of the minimum now
+    const uint64_t later_m = __ballot(act && (jw >= 0 ? j > jw : i < p)) & segm;
+    p = (jw >= 0 ? base_i : min(p, base_i)) + 2 * __popcll(m2b & later_m) + __popcll(m1b & later_m);
+    sp = base_i + 2 * __popcll(m2b & segm) + __popcll(m1b & segm);
+    sync();
+    if (active && sp == 0) {  // this walk is over
+      if (j == 0) {
+        const Pose<T> tf1 = load_pose(io.tf1, pair);
+        const T* w6 = q_wit[q];
+        PairOut<T> o;
+        o.distance = mind;
+        o.normal = mk<T>(nanv, nanv, nanv);  // not set by the reference on this path (traversal_node_bvhs.h:454,465)
+        o.p1 = xform(tf1, mk<T>(w6[0], w6[1], w6[2]));  // postprocess(): model-1 frame -> world
+        o.p2 = xform(tf1, mk<T>(w6[3], w6[4], w6[5]));
+        o.gjk_status = GJK_DID_NOT_RUN;
+        o.epa_status = EPA_DID_NOT_RUN;
+        o.gjk_iters = o.epa_iters = 0;
+        store_bvh_record(io, pair, o, mind <= T(0) ? 0x80000000u : 0u, q_fb[q][0], q_fb[q][1], false);
+      }
+      active = false;
+    }
+  }
+}
+
+// =======================================================================================
+// launcher (hfcl_launch.hpp)
+// =======================================================================================
+template <typename T>
+void launch_bvh_distance(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, BvhSpill spill) {
+  if (spill.wide) {
+    if (spill.slab) grid = std::min(grid, int(spill.max_blocks) * (BVH_BLOCK / BVHD_BLOCK));
+    hipLaunchKernelGGL((k_bvh_distance<T, true>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q, spill);
+  } else {
+    hipLaunchKernelGGL((k_bvh_distance<T, false>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q, spill);
+    const int cgrid = std::max(1, std::min(grid, int(spill.max_blocks)));
+    if (spill.budget && spill.pool)
+      hipLaunchKernelGGL((k_bvh_distance_pool<T>), dim3(cgrid), dim3(64), 0, st, wk, lv, bv, io, spill);
+    else if (spill.budget)
+      hipLaunchKernelGGL((k_bvh_distance_coop<T>), dim3(cgrid), dim3(64), 0, st, wk, lv, bv, io, spill);
+  }
+}
+template void launch_bvh_distance<float>(int, hipStream_t, const Work&, const LibView<float>&, const BvhView<float>&, const IO<float>&, const QParams<float>&, BvhSpill);
+template void launch_bvh_distance<double>(int, hipStream_t, const Work&, const LibView<double>&, const BvhView<double>&, const IO<double>&, const QParams<double>&, BvhSpill);

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("HFCL_LIB_PATH", os.path.join(_CSRC, "libhppfcl_amd.so
 
 EXPORTED_SYMBOLS = [
     "hfcl_abi_version", "hfcl_device_count", "hfcl_last_error", "hfcl_collision_request_init",
-    "hfcl_distance_request_init", "hfcl_lib_create", "hfcl_lib_destroy", "hfcl_lib_num_shapes", "hfcl_lib_device",
+    "hfcl_distance_request_init", "hfcl_lib_create", "hfcl_lib_destroy", "hfcl_lib_num_shapes", "hfcl_lib_device", "hfcl_lib_climb_min",
     "hfcl_lib_add_bvh", "hfcl_collide_batch", "hfcl_distance_batch", "hfcl_collide_batch_device",
     "hfcl_distance_batch_device", "hfcl_distance_batch_device_f32", "hfcl_collide_batch_device_f32",
     "hfcl_collide_batch_contacts", "hfcl_last_kernel_ms", "hfcl_last_kernel_name", "hfcl_bvh_build",
@@ -62,6 +62,7 @@ def dll():
         d.hfcl_last_error.restype = C.c_char_p
         d.hfcl_lib_create.restype = C.c_void_p
         d.hfcl_lib_num_shapes.restype = C.c_size_t
+        d.hfcl_lib_climb_min.restype = C.c_uint32
         d.hfcl_last_kernel_ms.restype = C.c_double
         d.hfcl_last_kernel_name.restype = C.c_char_p
         d.hfcl_broadphase_self_pairs.restype = C.c_void_p
@@ -240,6 +241,10 @@ class Library:
         ids = np.ascontiguousarray(neighbors, dtype=np.uint32)
         _check(dll().hfcl_lib_set_convex_neighbors(self._h, C.c_uint32(int(shape_id)), C.c_void_p(off.ctypes.data),
                                                    C.c_void_p(ids.ctypes.data)))
+
+    def climb_min(self):
+        """Smallest hull (vertices) this library answers by hill-climbing a registered adjacency (hfcl_lib_climb_min)."""
+        return int(dll().hfcl_lib_climb_min(self._h))
 
     def set_host_chunk(self, pairs):
         """Pairs per chunk of the host-buffer pipeline (0 = automatic)."""

@@ -101,11 +101,18 @@ class RecordExchange:
         b = self.per * self.words * 4
         return b, b * (self.world - 1)
 
-    def before_launch(self, buf):
-        """The kernels of this step overwrite the buffer the exchange of two steps ago read: order them after it
-        (stream-side wait, the host does not block)."""
+    def before_launch(self, buf, stream=None):
+        """The kernels of this step overwrite the buffer the exchange of two steps ago read: order them after it.  `stream`:
+        the torch stream the kernels of this step are launched on (None: torch's current stream).  Work.wait() of an RCCL
+        collective makes the CURRENT stream wait for it (the host does not block), so the wait is issued with the launch
+        stream current -- a caller that launches on another stream than torch's current one is ordered as well."""
         h = self.inflight.pop(buf, None)
-        if h is not None:
+        if h is None:
+            return
+        if stream is not None and not self.on_cpu and not self.staged:
+            with self.torch.cuda.stream(stream):
+                h.wait()
+        else:
             h.wait()
 
     def after_launch(self, buf, records, n_valid, stream):
@@ -117,6 +124,12 @@ class RecordExchange:
             send = self.packed[buf]
             if n_valid:
                 self.lib.compact_results_device(records, n_valid, send, f32=self.dtype == "f32", stream=stream.cuda_stream)
+            if n_valid < self.per:  # rows past this rank's shard travel as zeros, never as the rows of an earlier, longer step
+                if self.on_cpu:
+                    send[n_valid * self.words:].zero_()
+                else:
+                    with torch.cuda.stream(stream):
+                        send[n_valid * self.words:].zero_()
         if self.dist is None:
             return send
         if self.on_cpu:

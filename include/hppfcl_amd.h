@@ -155,7 +155,9 @@ typedef struct hfcl_result {
   int32_t  num_contacts;    /* collide only                                            */
 } hfcl_result;              /* 96 bytes                                                */
 
-/* Compact fp32 record for the fp32 device-resident path: 44 bytes. */
+/* Compact fp32 record for the fp32 device-resident path: 44 bytes.  It has NO b1 / b2: a BVHModel pair run through the
+ * fp32 entry points reports its contact flag, distance, witness points and normal, not the triangle ids (Contact::b1 / b2,
+ * DistanceResult::b1 / b2) -- callers that need the primitive ids of mesh pairs use the fp64 entry points. */
 typedef struct hfcl_result_f32 {
   float    distance;
   float    p1[3];
@@ -239,13 +241,16 @@ int hfcl_lib_set_shapes(hfcl_lib* lib, const hfcl_shape* shapes, size_t n_shapes
  * that has one answers GJK / EPA support queries by neighbour hill-climbing from the previous answer, as
  * getShapeSupportLog does (src/narrowphase/support_functions.cpp:323-397), instead of scanning every vertex; smaller
  * hulls and hulls without adjacency are unaffected.  hfcl_lib_set_shapes drops all registered adjacencies.
- * The device image is (re)built by the first batch after a registration; that batch waits for the device once (batches
- * of other streams may still be reading the previous image). */
+ * The device image is (re)built by the first batch after a registration: the calling thread waits for that upload (a copy
+ * stream of the library's own), nothing else on the device is synchronised; the previous image stays allocated until
+ * hfcl_lib_set_shapes / hfcl_lib_destroy (batches in flight on other streams may still be reading it). */
 int hfcl_lib_set_convex_neighbors(hfcl_lib* lib, uint32_t shape_id, const uint32_t* offsets,
                                   const uint32_t* neighbors);
 void      hfcl_lib_destroy(hfcl_lib* lib);
 size_t    hfcl_lib_num_shapes(const hfcl_lib* lib);
 int       hfcl_lib_device(const hfcl_lib* lib);
+/* Smallest hull (vertices) that answers support queries by hill-climbing a registered adjacency (HFCL_CLIMB_MIN, default 512). */
+uint32_t  hfcl_lib_climb_min(const hfcl_lib* lib);
 
 /* Register a BVHModel<OBBRSS> (include/hpp/fcl/BVH/BVH_model.h:66-360, BV_node.h:52-148):
  * nodes: n_nodes records of 32 doubles in the reference's field order
@@ -351,7 +356,11 @@ int hfcl_distance_batch_device(hfcl_lib* lib, const uint32_t* d_shape1, const ui
 
 /* fp32 compute path (the reference has no fp32; parity = fp32 result vs fp64 oracle within
  * the tolerance stated in tests/).  Poses are 7-float (quat wxyz + translation) records,
- * results are 44-byte hfcl_result_f32 records.  Device-resident only. */
+ * results are 44-byte hfcl_result_f32 records (no primitive ids: see hfcl_result_f32).  Device-resident only.
+ * EPA statuses and iteration counts of this path are not the reference's step for step: the fp32 convex x convex fast tier finds
+ * an expansion's horizon without the reference's walk (every face the new vertex is above is removed, connected to the
+ * closest face or not; csrc/hfcl_epa.hpp: silhouette_parallel), the depth converges to the same value
+ * (tests/test_epa_ground_truth.py). */
 int hfcl_distance_batch_device_f32(hfcl_lib* lib, const uint32_t* d_shape1, const uint32_t* d_shape2,
                                    const float* d_pose1, const float* d_pose2, size_t n,
                                    const hfcl_distance_request* req, hfcl_result_f32* d_out,

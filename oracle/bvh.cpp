@@ -666,6 +666,13 @@ struct DistTraversal {
 };
 }  // namespace
 
+// the distance leafComputeDistance assigns to the triangle pair (pid1, pid2) of this query (for tests that enumerate ties)
+double bvh_leaf_distance(const MeshView& m1, const Tf& tf1, const MeshView& m2, const Tf& tf2, int pid1, int pid2) {
+  DistTraversal t(m1, tf1, m2, tf2);
+  t.leaf(pid1, pid2);
+  return t.min_distance;
+}
+
 int bvh_distance_pair(const MeshView& m1, const Tf& tf1, const MeshView& m2, const Tf& tf2, hfcl_result& out,
                       BvhStats* stats) {
   DistTraversal t(m1, tf1, m2, tf2);

@@ -58,4 +58,5 @@ double rss_distance(const M3& R0, const V3& T0, const hfcl_bvh_node& b1, const h
 double sqr_tri_distance(const V3 S[3], const V3 T[3], V3& P, V3& Q);
 int bvh_distance_pair(const MeshView& m1, const Tf& tf1, const MeshView& m2, const Tf& tf2, hfcl_result& out,
                       BvhStats* stats);
+double bvh_leaf_distance(const MeshView& m1, const Tf& tf1, const MeshView& m2, const Tf& tf2, int pid1, int pid2);
 }  // namespace orc

@@ -236,11 +236,14 @@ int orc_bvh_collide_batch(const hfcl_bvh_node* nodes, const double* verts, const
 // collide() over one shape table that may hold BVHModel<OBBRSS> entries (type HFCL_BV_OBBRSS, bvh_index into
 // the mesh table) next to convex shapes: mesh x mesh, mesh x shape, shape x mesh (operand swap of
 // src/collision.cpp:93-108) and shape x shape, dispatched like the reference's collision matrix.
-int orc_mixed_collide_batch(const hfcl_shape* shapes, size_t n_shapes, const double* shape_verts, const hfcl_bvh_node* nodes,
-                            const double* mesh_verts, const uint32_t* tris, const uint64_t* mesh_table, size_t n_meshes,
-                            const uint32_t* s1, const uint32_t* s2, const double* tf1, const double* tf2, size_t n,
-                            const hfcl_collision_request* req, hfcl_result* out, hfcl_guess* guess_out,
-                            hfcl_contact* contacts, size_t max_contacts, size_t* n_contacts, int n_threads) {
+// out_stats (nullable): 2 x uint32 per pair -- num_bv_tests, num_leaf_tests of the traversal node
+// (traversal_node_bvhs.h:126-128 / traversal_node_bvh_shape.h: the counters the reference keeps), 0 for shape x shape pairs.
+int orc_mixed_collide_batch_stats(const hfcl_shape* shapes, size_t n_shapes, const double* shape_verts, const hfcl_bvh_node* nodes,
+                                  const double* mesh_verts, const uint32_t* tris, const uint64_t* mesh_table, size_t n_meshes,
+                                  const uint32_t* s1, const uint32_t* s2, const double* tf1, const double* tf2, size_t n,
+                                  const hfcl_collision_request* req, hfcl_result* out, hfcl_guess* guess_out,
+                                  hfcl_contact* contacts, size_t max_contacts, size_t* n_contacts, int n_threads,
+                                  uint32_t* out_stats) {
   std::vector<MeshView> meshes(n_meshes);
   for (size_t i = 0; i < n_meshes; ++i) {
     meshes[i].nodes = nodes + mesh_table[4 * i];
@@ -261,19 +264,24 @@ int orc_mixed_collide_batch(const hfcl_shape* shapes, size_t n_shapes, const dou
       const Tf t1 = tf_from_abi(tf1 + 12 * i), t2 = tf_from_abi(tf2 + 12 * i);
       hfcl_guess* go = guess_out ? guess_out + i : nullptr;
       int rc;
+      BvhStats st;
       if (ma && mc) {
         rc = bvh_collide_pair(meshes[a.bvh_index], t1, meshes[c.bvh_index], t2, *req, out[i], contacts ? &cl : nullptr,
-                              uint32_t(i), nullptr);
+                              uint32_t(i), &st);
         if (go) *go = hfcl_guess{{req->q.cached_gjk_guess[0], req->q.cached_gjk_guess[1], req->q.cached_gjk_guess[2]},
                                  {req->q.cached_support_func_guess[0], req->q.cached_support_func_guess[1]}};
       } else if (ma) {
         rc = bvh_shape_collide_pair(meshes[a.bvh_index], t1, lib[s2[i]], t2, *req, false, out[i], contacts ? &cl : nullptr,
-                                    uint32_t(i), go, nullptr);
+                                    uint32_t(i), go, &st);
       } else if (mc) {
         rc = bvh_shape_collide_pair(meshes[c.bvh_index], t2, lib[s1[i]], t1, *req, true, out[i], contacts ? &cl : nullptr,
-                                    uint32_t(i), go, nullptr);
+                                    uint32_t(i), go, &st);
       } else {
         rc = collide_pair(lib[s1[i]], t1, lib[s2[i]], t2, *req, nullptr, out[i], go);
+      }
+      if (out_stats) {
+        out_stats[2 * i] = st.num_bv_tests;
+        out_stats[2 * i + 1] = st.num_leaf_tests;
       }
       if (rc) err = rc;
     }
@@ -286,6 +294,15 @@ int orc_mixed_collide_batch(const hfcl_shape* shapes, size_t n_shapes, const dou
     if (n_contacts) *n_contacts = k;
   }
   return err;
+}
+
+int orc_mixed_collide_batch(const hfcl_shape* shapes, size_t n_shapes, const double* shape_verts, const hfcl_bvh_node* nodes,
+                            const double* mesh_verts, const uint32_t* tris, const uint64_t* mesh_table, size_t n_meshes,
+                            const uint32_t* s1, const uint32_t* s2, const double* tf1, const double* tf2, size_t n,
+                            const hfcl_collision_request* req, hfcl_result* out, hfcl_guess* guess_out,
+                            hfcl_contact* contacts, size_t max_contacts, size_t* n_contacts, int n_threads) {
+  return orc_mixed_collide_batch_stats(shapes, n_shapes, shape_verts, nodes, mesh_verts, tris, mesh_table, n_meshes, s1, s2, tf1, tf2, n,
+                                       req, out, guess_out, contacts, max_contacts, n_contacts, n_threads, nullptr);
 }
 
 // distance() counterpart of orc_mixed_collide_batch.
@@ -347,6 +364,19 @@ int orc_bvh_distance_batch(const hfcl_bvh_node* nodes, const double* verts, cons
     }
   });
   return 0;
+}
+
+// distance of ONE triangle pair of a mesh x mesh query, as the traversal's leaf computes it (model-1 frame)
+double orc_bvh_leaf_distance(const hfcl_bvh_node* nodes, const double* verts, const uint32_t* tris, const uint64_t* mesh_table,
+                             size_t n_meshes, uint32_t m1, uint32_t m2, const double* tf1, const double* tf2, int pid1, int pid2) {
+  std::vector<MeshView> meshes(n_meshes);
+  for (size_t i = 0; i < n_meshes; ++i) {
+    meshes[i].nodes = nodes + mesh_table[4 * i];
+    meshes[i].n_nodes = mesh_table[4 * i + 1];
+    meshes[i].verts = verts + 3 * mesh_table[4 * i + 2];
+    meshes[i].tris = tris + 3 * mesh_table[4 * i + 3];
+  }
+  return bvh_leaf_distance(meshes[m1], tf_from_abi(tf1), meshes[m2], tf_from_abi(tf2), pid1, pid2);
 }
 
 // rectDistance on raw inputs (unit tests): Rab row-major 9, Tab 3, a 2, b 2

@@ -172,6 +172,18 @@ def bvh_distance_batch(meshlib, m1, m2, tf1, tf2, n_threads=1, want_stats=False)
     return (out, stats) if want_stats else out
 
 
+def bvh_leaf_distance(meshlib, m1, m2, tf1, tf2, pid1, pid2):
+    """The distance the oracle's traversal assigns to triangle pair (pid1, pid2) of the query (mesh m1 at tf1, mesh m2 at tf2)."""
+    abi = _pkg().abi
+    f = lib().orc_bvh_leaf_distance
+    f.restype = C.c_double
+    nodes = np.ascontiguousarray(meshlib.nodes)
+    t1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(12)
+    t2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(12)
+    return f(abi.ptr(nodes), abi.ptr(meshlib.verts), abi.ptr(meshlib.tris), abi.ptr(meshlib.table), C.c_size_t(len(meshlib.table)),
+             C.c_uint32(int(m1)), C.c_uint32(int(m2)), abi.ptr(t1), abi.ptr(t2), C.c_int(int(pid1)), C.c_int(int(pid2)))
+
+
 def rect_distance(Rab, Tab, a, b):
     abi = _pkg().abi
     L = lib()
@@ -267,7 +279,8 @@ def register_hull_neighbors(shapes, verts, graphs=None):
     return len(keep)
 
 
-def mixed_collide_batch(shapes, verts, meshlib, s1, s2, tf1, tf2, req=None, max_contacts=0, n_threads=1, want_guess=False):
+def mixed_collide_batch(shapes, verts, meshlib, s1, s2, tf1, tf2, req=None, max_contacts=0, n_threads=1, want_guess=False,
+                        want_stats=False):
     """collide() over a shape table that mixes BVHModel<OBBRSS> entries (bvh_index -> meshlib) and convex
     shapes: mesh x mesh, mesh x shape, shape x mesh, shape x shape (oracle/capi.cpp orc_mixed_collide_batch)."""
     abi = _pkg().abi
@@ -284,12 +297,13 @@ def mixed_collide_batch(shapes, verts, meshlib, s1, s2, tf1, tf2, req=None, max_
     contacts = np.zeros(max(1, max_contacts), dtype=abi.CONTACT_DTYPE)
     nc = C.c_size_t(0)
     nodes = np.ascontiguousarray(meshlib.nodes)
-    rc = lib().orc_mixed_collide_batch(abi.ptr(shapes), C.c_size_t(len(shapes)), abi.ptr(verts), abi.ptr(nodes),
-                                       abi.ptr(meshlib.verts), abi.ptr(meshlib.tris), abi.ptr(meshlib.table),
-                                       C.c_size_t(len(meshlib.table)), abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1), abi.ptr(tf2),
-                                       C.c_size_t(n), C.byref(req), abi.ptr(out), abi.ptr(gout),
-                                       abi.ptr(contacts) if max_contacts else None, C.c_size_t(max_contacts), C.byref(nc),
-                                       C.c_int(n_threads))
+    stats = np.zeros((n, 2), dtype=np.uint32) if want_stats else None  # (num_bv_tests, num_leaf_tests) per pair
+    rc = lib().orc_mixed_collide_batch_stats(abi.ptr(shapes), C.c_size_t(len(shapes)), abi.ptr(verts), abi.ptr(nodes),
+                                             abi.ptr(meshlib.verts), abi.ptr(meshlib.tris), abi.ptr(meshlib.table),
+                                             C.c_size_t(len(meshlib.table)), abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1), abi.ptr(tf2),
+                                             C.c_size_t(n), C.byref(req), abi.ptr(out), abi.ptr(gout),
+                                             abi.ptr(contacts) if max_contacts else None, C.c_size_t(max_contacts), C.byref(nc),
+                                             C.c_int(n_threads), abi.ptr(stats))
     if rc:
         raise ValueError("oracle mixed collide: error %d" % rc)
     res = [out]
@@ -297,6 +311,8 @@ def mixed_collide_batch(shapes, verts, meshlib, s1, s2, tf1, tf2, req=None, max_
         res.append(contacts[:nc.value])
     if want_guess:
         res.append(gout)
+    if want_stats:
+        res.append(stats)
     return res[0] if len(res) == 1 else tuple(res)
 
 

@@ -55,14 +55,21 @@ def test_bench_refuses_missing_gpus_instead_of_hanging():
 
 
 def _bench(args, timeout=900):
+    """Run bench.py; returns its FULL record (bench_full.json) after checking that the last stdout line is the compact form of it."""
+    import tempfile
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
-    assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as d:
+        env["HFCL_BENCH_FULL_DIR"] = d
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and len(lines[0]) <= 4096, p.stdout[-2000:]
+        compact = json.loads(lines[0])
+        full = json.load(open(os.path.join(d, "bench_full.json")))
+    assert abs(compact["value"] - full["value"]) <= 1e-4 * full["value"] and compact["n_gpus"] == full["n_gpus"]
+    return full
 
 
 @pytest.mark.gpu
@@ -92,6 +99,23 @@ def test_two_ranks_on_one_gpu_weak_cfg3(torch_cuda):
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and cfg["pairs_per_step_all_gpus"] == 2 * 65537
     assert cfg["gather_check"]["block_checksums"] is True
     assert cfg["gather_bytes_per_rank_per_step"]["received"] == 65537 * 44
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gather", ["full", "compact"])
+def test_rccl_exchange_branch_with_one_rank(torch_cuda, gather, monkeypatch):
+    """The branch a driver meets with 8 ranks -- process group "nccl" (= RCCL), records all-gathered with async_op on the
+    communication stream behind an event of the launch stream, Work.wait() on the launch stream two steps later -- executed
+    on this box with a world of one (HFCL_BENCH_FORCE_DIST=1: every N > 1 code path of bench.py, one rank)."""
+    monkeypatch.setenv("HFCL_BENCH_FORCE_DIST", "1")
+    monkeypatch.setenv("MASTER_PORT", "29577")
+    line = _bench(["--workload", "cfg3", "--pairs", "65537", "--steps", "5", "--warmup", "1", "--backend", "nccl", "--gather", gather,
+                   "--no-cpu-baseline"])
+    cfg = line["config"]
+    assert cfg["backend"] == "nccl" and cfg["all_gather_results"] is True and cfg["gather"] == gather
+    assert cfg["gather_check"]["block_checksums"] is True
+    assert cfg["gather_bytes_per_rank_per_step"]["sent"] == 65537 * (8 if gather == "compact" else 44)
+    assert line["value"] > 0
 
 
 @pytest.mark.gpu

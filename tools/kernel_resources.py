@@ -1,22 +1,23 @@
 #!/usr/bin/env python
 """Compact per-kernel resource table (VGPR / AGPR / scratch / LDS / occupancy) from hipcc's
 -Rpass-analysis=kernel-resource-usage.
-usage: tools/kernel_resources.py [gjk|epa|bvh ...] [extra hipcc flags]   (default: all three kernel translation units)"""
+usage: tools/kernel_resources.py [gjk|epa|bvh|bvhd ...] [extra hipcc flags]   (default: all three kernel translation units)"""
 import os
 import re
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-units = [a for a in sys.argv[1:] if a in ("gjk", "epa", "bvh")] or ["gjk", "epa", "bvh"]
-flags = [a for a in sys.argv[1:] if a not in ("gjk", "epa", "bvh")]
+UNITS = ("gjk", "epa", "bvh", "bvhd")
+units = [a for a in sys.argv[1:] if a in UNITS] or list(UNITS)
+flags = [a for a in sys.argv[1:] if a not in UNITS]
 procs = []
 for u in units:  # the translation units compile side by side
     src = os.path.join(ROOT, "hpp-fcl_amd", "csrc", "hfcl_k_%s.hip" % u)
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-value", "-Wno-pass-failed",
            "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", src] + \
         (["-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt"] if u in ("gjk", "epa") else []) + \
-        (["-ffp-contract=on"] if u == "epa" else []) + flags  # (the Makefile's per-unit flags)
+        (["-ffp-contract=on"] if u == "epa" else []) + (["-ffp-contract=off"] if u == "bvhd" else []) + flags  # (the Makefile's per-unit flags)
     procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
 err = "".join(p.communicate()[1] for p in procs)
 rows, cur = [], {}
