@@ -405,82 +405,117 @@ HFCL_HD bool in_voronoi(T a, T b, T Anorm_dot_B, T Anorm_dot_T, T A_dot_B, T A_d
 // (the edge-pair indices select the operands), so the lanes of a wave share the code of a trip whatever block each is in:
 // as many trips as the lane with the most candidates needs (1-3 typically) instead of 16 sections.  Every expression is
 // the one of the unrolled form (same operands, same order).
+// The pieces of rectDistance as a state + steps, so that a kernel can run ONE candidate per lane and round
+// (the candidates a lane still has to try travel as a mask: profiles/r04_f); rect_distance() below is their sequence.
 template <typename T>
-HFCL_HD T rect_distance(const M3<T>& Rab, const V3<T>& Tab, T a0, T a1, T b0, T b1) {
-  const T R[3][3] = {{Rab.r0.x, Rab.r0.y, Rab.r0.z}, {Rab.r1.x, Rab.r1.y, Rab.r1.z}, {Rab.r2.x, Rab.r2.y, Rab.r2.z}};
-  const T av[2] = {a0, a1}, bv[2] = {b0, b1};
-  const V3<T> Tba_v = tmul(Rab, Tab);
-  const T Tabv[3] = {Tab.x, Tab.y, Tab.z}, Tba[3] = {Tba_v.x, Tba_v.y, Tba_v.z};
-  // ---- pass 1: which blocks does the reference enter?  bit k = k-th block in its order
-  unsigned mask = 0u;
-  {
-    int k = 0;
+struct RectTest {
+  T R[3][3], av[2], bv[2], Tabv[3], Tba[3];
+  HFCL_HD void init(const M3<T>& Rab, const V3<T>& Tab, T a0, T a1, T b0, T b1) {
+    R[0][0] = Rab.r0.x; R[0][1] = Rab.r0.y; R[0][2] = Rab.r0.z;
+    R[1][0] = Rab.r1.x; R[1][1] = Rab.r1.y; R[1][2] = Rab.r1.z;
+    R[2][0] = Rab.r2.x; R[2][1] = Rab.r2.y; R[2][2] = Rab.r2.z;
+    av[0] = a0; av[1] = a1; bv[0] = b0; bv[1] = b1;
+    const V3<T> Tba_v = tmul(Rab, Tab);
+    Tabv[0] = Tab.x; Tabv[1] = Tab.y; Tabv[2] = Tab.z;
+    Tba[0] = Tba_v.x; Tba[1] = Tba_v.y; Tba[2] = Tba_v.z;
+  }
+  // which blocks does the reference enter?  bit k = k-th block in its order
+  HFCL_HD unsigned pass1() const {
+    unsigned mask = 0u;
+    {
+      int k = 0;
 #pragma unroll
-    for (int ea = 1; ea >= 0; --ea) {
-      const int oa = 1 - ea;
+      for (int ea = 1; ea >= 0; --ea) {
+        const int oa = 1 - ea;
 #pragma unroll
-      for (int eb = 1; eb >= 0; --eb) {
-        const int ob = 1 - eb;
-        const T A_ll = -Tba[ob];
-        const T A_e = av[ea] * R[ea][ob];
-        const T A_o = av[oa] * R[oa][ob];
-        const T B_ll = Tabv[oa];
-        const T B_e = bv[eb] * R[oa][eb];
-        const T B_o = bv[ob] * R[oa][ob];
+        for (int eb = 1; eb >= 0; --eb) {
+          const int ob = 1 - eb;
+          const T A_ll = -Tba[ob];
+          const T A_e = av[ea] * R[ea][ob];
+          const T A_o = av[oa] * R[oa][ob];
+          const T B_ll = Tabv[oa];
+          const T B_e = bv[eb] * R[oa][eb];
+          const T B_o = bv[ob] * R[oa][ob];
 #pragma unroll
-        for (int ua = 1; ua >= 0; --ua) {
+          for (int ua = 1; ua >= 0; --ua) {
 #pragma unroll
-          for (int ub = 1; ub >= 0; --ub) {
-            const T ea0 = A_ll + (ua ? A_o : T(0)), ea1 = ea0 + A_e;
-            const T A_l = hmin(ea0, ea1), A_u = hmax(ea0, ea1);
-            const T eb0 = B_ll + (ub ? B_o : T(0)), eb1 = eb0 + B_e;
-            const T B_l = hmin(eb0, eb1), B_u = hmax(eb0, eb1);
-            const bool pre1 = ub ? (A_u > bv[ob]) : (A_l < T(0));
-            const bool pre2 = ua ? (B_u > av[oa]) : (B_l < T(0));
-            if (pre1 && pre2) mask |= 1u << k;
-            ++k;
+            for (int ub = 1; ub >= 0; --ub) {
+              const T ea0 = A_ll + (ua ? A_o : T(0)), ea1 = ea0 + A_e;
+              const T A_l = hmin(ea0, ea1), A_u = hmax(ea0, ea1);
+              const T eb0 = B_ll + (ub ? B_o : T(0)), eb1 = eb0 + B_e;
+              const T B_l = hmin(eb0, eb1), B_u = hmax(eb0, eb1);
+              const bool pre1 = ub ? (A_u > bv[ob]) : (A_l < T(0));
+              const bool pre2 = ua ? (B_u > av[oa]) : (B_l < T(0));
+              if (pre1 && pre2) mask |= 1u << k;
+              ++k;
+            }
           }
         }
       }
     }
+    return mask;
   }
-  // ---- pass 2: the candidates in order, one parametrised block per trip
-  while (mask) {
-    const int k = __builtin_ctz(mask);
-    mask &= mask - 1u;
-    const bool ea1_ = !(k & 8), eb1_ = !(k & 4), ua = !(k & 2), ub = !(k & 1);  // ea = 1 / eb = 1 / upper A edge / upper B edge
-    // operands selected by the edge-pair indices (ea, oa = 1 - ea index A's axes / rows of R; eb, ob index B's axes / columns)
-    const T Rc_eb[3] = {eb1_ ? R[0][1] : R[0][0], eb1_ ? R[1][1] : R[1][0], eb1_ ? R[2][1] : R[2][0]};  // R[.][eb]
-    const T Rc_ob[3] = {eb1_ ? R[0][0] : R[0][1], eb1_ ? R[1][0] : R[1][1], eb1_ ? R[2][0] : R[2][1]};  // R[.][ob]
-    const T R_ea_eb = ea1_ ? Rc_eb[1] : Rc_eb[0], R_oa_eb = ea1_ ? Rc_eb[0] : Rc_eb[1];
-    const T R_ea_ob = ea1_ ? Rc_ob[1] : Rc_ob[0], R_oa_ob = ea1_ ? Rc_ob[0] : Rc_ob[1];
-    const T av_ea = ea1_ ? av[1] : av[0], av_oa = ea1_ ? av[0] : av[1];
-    const T bv_eb = eb1_ ? bv[1] : bv[0], bv_ob = eb1_ ? bv[0] : bv[1];
-    const T Tab_ea = ea1_ ? Tabv[1] : Tabv[0], Tab_oa = ea1_ ? Tabv[0] : Tabv[1];
-    const T Tba_eb = eb1_ ? Tba[1] : Tba[0], Tba_ob = eb1_ ? Tba[0] : Tba[1];
-    const T A_ll = -Tba_ob;
-    const T A_e = av_ea * R_ea_ob;
-    const T A_o = av_oa * R_oa_ob;
-    const T B_ll = Tab_oa;
-    const T B_e = bv_eb * R_oa_eb;
-    const T B_o = bv_ob * R_oa_ob;
-    const T ea0 = A_ll + (ua ? A_o : T(0)), ea1 = ea0 + A_e;  // A edge end points in B's ob coordinate
-    const T A_l = hmin(ea0, ea1), A_u = hmax(ea0, ea1);
-    const T eb0 = B_ll + (ub ? B_o : T(0)), eb1 = eb0 + B_e;  // B edge end points in A's oa coordinate
-    const T B_l = hmin(eb0, eb1), B_u = hmax(eb0, eb1);
-    const T pa = ua ? av_oa : T(0), pb = ub ? bv_ob : T(0);
-    const T A_dot_B = R_ea_eb;
-    const T A_dot_T = Tab_ea + pb * R_ea_ob;  // e_ea . (Pb - Pa)
-    const T B_dot_T = Tba_eb - pa * R_oa_eb;  // B_eb . (Pb - Pa)
-    const bool skip1 = ub ? (A_l > bv_ob) : (A_u < T(0));
-    const T sgn_b = ub ? T(1) : T(-1);
-    const bool v1 = skip1 || in_voronoi(bv_eb, av_ea, sgn_b * R_ea_ob, sgn_b * (pa * R_oa_ob - Tba_ob - pb), A_dot_B,
-                                        pa * R_oa_eb - Tba_eb, -Tab_ea - pb * R_ea_ob);
-    if (!v1) continue;
-    const bool skip2 = ua ? (B_l > av_oa) : (B_u < T(0));
-    const T sgn_a = ua ? T(1) : T(-1);
-    const bool v2 = skip2 || in_voronoi(av_ea, bv_eb, sgn_a * R_oa_eb, sgn_a * (Tab_oa + pb * R_oa_ob - pa), A_dot_B, A_dot_T, B_dot_T);
-    if (!v2) continue;
+  // what the block of a candidate selects of the state for its closest-point computation
+  struct Sel {
+    bool ea1_;
+    T av_ea, bv_eb, A_dot_B, A_dot_T, B_dot_T, pa, pb;
+    T Rc_eb[3], Rc_ob[3];
+  };
+  // the first candidate of `mask` (removed from it): true when both of its Voronoi tests pass (two divisions); its operands in `s`
+  HFCL_HD bool decide(unsigned& mask, Sel& s) const {
+    bool& ea1_ = s.ea1_;
+    T &av_ea = s.av_ea, &bv_eb = s.bv_eb, &A_dot_B = s.A_dot_B, &A_dot_T = s.A_dot_T, &B_dot_T = s.B_dot_T, &pa = s.pa, &pb = s.pb;
+    T* const Rc_eb = s.Rc_eb;
+    T* const Rc_ob = s.Rc_ob;
+    {
+      const int k = __builtin_ctz(mask);
+      mask &= mask - 1u;
+      const bool eb1_ = !(k & 4), ua = !(k & 2), ub = !(k & 1);  // eb = 1 / upper A edge / upper B edge
+      ea1_ = !(k & 8);                                            // ea = 1
+      // operands selected by the edge-pair indices (ea, oa = 1 - ea index A's axes / rows of R; eb, ob index B's axes / columns)
+      Rc_eb[0] = eb1_ ? R[0][1] : R[0][0]; Rc_eb[1] = eb1_ ? R[1][1] : R[1][0]; Rc_eb[2] = eb1_ ? R[2][1] : R[2][0];  // R[.][eb]
+      Rc_ob[0] = eb1_ ? R[0][0] : R[0][1]; Rc_ob[1] = eb1_ ? R[1][0] : R[1][1]; Rc_ob[2] = eb1_ ? R[2][0] : R[2][1];  // R[.][ob]
+      const T R_ea_eb = ea1_ ? Rc_eb[1] : Rc_eb[0], R_oa_eb = ea1_ ? Rc_eb[0] : Rc_eb[1];
+      const T R_ea_ob = ea1_ ? Rc_ob[1] : Rc_ob[0], R_oa_ob = ea1_ ? Rc_ob[0] : Rc_ob[1];
+      av_ea = ea1_ ? av[1] : av[0];
+      const T av_oa = ea1_ ? av[0] : av[1];
+      bv_eb = eb1_ ? bv[1] : bv[0];
+      const T bv_ob = eb1_ ? bv[0] : bv[1];
+      const T Tab_ea = ea1_ ? Tabv[1] : Tabv[0], Tab_oa = ea1_ ? Tabv[0] : Tabv[1];
+      const T Tba_eb = eb1_ ? Tba[1] : Tba[0], Tba_ob = eb1_ ? Tba[0] : Tba[1];
+      const T A_ll = -Tba_ob;
+      const T A_e = av_ea * R_ea_ob;
+      const T A_o = av_oa * R_oa_ob;
+      const T B_ll = Tab_oa;
+      const T B_e = bv_eb * R_oa_eb;
+      const T B_o = bv_ob * R_oa_ob;
+      const T ea0 = A_ll + (ua ? A_o : T(0)), ea1 = ea0 + A_e;  // A edge end points in B's ob coordinate
+      const T A_l = hmin(ea0, ea1), A_u = hmax(ea0, ea1);
+      const T eb0 = B_ll + (ub ? B_o : T(0)), eb1 = eb0 + B_e;  // B edge end points in A's oa coordinate
+      const T B_l = hmin(eb0, eb1), B_u = hmax(eb0, eb1);
+      pa = ua ? av_oa : T(0);
+      pb = ub ? bv_ob : T(0);
+      A_dot_B = R_ea_eb;
+      A_dot_T = Tab_ea + pb * R_ea_ob;  // e_ea . (Pb - Pa)
+      B_dot_T = Tba_eb - pa * R_oa_eb;  // B_eb . (Pb - Pa)
+      const bool skip1 = ub ? (A_l > bv_ob) : (A_u < T(0));
+      const T sgn_b = ub ? T(1) : T(-1);
+      const bool v1 = skip1 || in_voronoi(bv_eb, av_ea, sgn_b * R_ea_ob, sgn_b * (pa * R_oa_ob - Tba_ob - pb), A_dot_B,
+                                          pa * R_oa_eb - Tba_eb, -Tab_ea - pb * R_ea_ob);
+      if (!v1) return false;
+      const bool skip2 = ua ? (B_l > av_oa) : (B_u < T(0));
+      const T sgn_a = ua ? T(1) : T(-1);
+      const bool v2 = skip2 || in_voronoi(av_ea, bv_eb, sgn_a * R_oa_eb, sgn_a * (Tab_oa + pb * R_oa_ob - pa), A_dot_B, A_dot_T, B_dot_T);
+      if (!v2) return false;
+    }
+    return true;
+  }
+  // the distance of the edge pair that passed: seg_coords (a third division) and the closest points
+  HFCL_HD T finish(const Sel& s) const {
+    const bool ea1_ = s.ea1_;
+    const T av_ea = s.av_ea, bv_eb = s.bv_eb, A_dot_B = s.A_dot_B, A_dot_T = s.A_dot_T, B_dot_T = s.B_dot_T, pa = s.pa, pb = s.pb;
+    const T* const Rc_eb = s.Rc_eb;
+    const T* const Rc_ob = s.Rc_ob;
     T t, u;
     seg_coords(t, u, av_ea, bv_eb, A_dot_B, A_dot_T, B_dot_T);
     // S = (Pb + u B_eb) - (Pa + t A_ea); component oa loses pa, component ea loses t (third component: neither)
@@ -491,27 +526,59 @@ HFCL_HD T rect_distance(const M3<T>& Rab, const V3<T>& Tab, T a0, T a1, T b0, T 
     S1 -= ea1_ ? t : pa;
     return hsqrt(S0 * S0 + S1 * S1 + S2 * S2);
   }
-  T sep1, sep2;
-  if (Tabv[2] > T(0)) {
-    sep1 = Tabv[2];
-    if (R[2][0] < T(0)) sep1 += b0 * R[2][0];
-    if (R[2][1] < T(0)) sep1 += b1 * R[2][1];
-  } else {
-    sep1 = -Tabv[2];
-    if (R[2][0] > T(0)) sep1 -= b0 * R[2][0];
-    if (R[2][1] > T(0)) sep1 -= b1 * R[2][1];
+  // no edge pair passed: the two face separations
+  HFCL_HD T faces() const {
+    const T a0 = av[0], a1 = av[1], b0 = bv[0], b1 = bv[1];
+    T sep1, sep2;
+    if (Tabv[2] > T(0)) {
+      sep1 = Tabv[2];
+      if (R[2][0] < T(0)) sep1 += b0 * R[2][0];
+      if (R[2][1] < T(0)) sep1 += b1 * R[2][1];
+    } else {
+      sep1 = -Tabv[2];
+      if (R[2][0] > T(0)) sep1 -= b0 * R[2][0];
+      if (R[2][1] > T(0)) sep1 -= b1 * R[2][1];
+    }
+    if (Tba[2] < T(0)) {
+      sep2 = -Tba[2];
+      if (R[0][2] < T(0)) sep2 += a0 * R[0][2];
+      if (R[1][2] < T(0)) sep2 += a1 * R[1][2];
+    } else {
+      sep2 = Tba[2];
+      if (R[0][2] > T(0)) sep2 -= a0 * R[0][2];
+      if (R[1][2] > T(0)) sep2 -= a1 * R[1][2];
+    }
+    const T sep = sep1 > sep2 ? sep1 : sep2;
+    return sep > T(0) ? sep : T(0);
   }
-  if (Tba[2] < T(0)) {
-    sep2 = -Tba[2];
-    if (R[0][2] < T(0)) sep2 += a0 * R[0][2];
-    if (R[1][2] < T(0)) sep2 += a1 * R[1][2];
-  } else {
-    sep2 = Tba[2];
-    if (R[0][2] > T(0)) sep2 -= a0 * R[0][2];
-    if (R[1][2] > T(0)) sep2 -= a1 * R[1][2];
-  }
-  const T sep = sep1 > sep2 ? sep1 : sep2;
-  return sep > T(0) ? sep : T(0);
+};
+
+template <typename T>
+HFCL_HD T rect_distance(const M3<T>& Rab, const V3<T>& Tab, T a0, T a1, T b0, T b1) {
+  RectTest<T> rt;
+  rt.init(Rab, Tab, a0, a1, b0, b1);
+  unsigned mask = rt.pass1();
+  // The candidates in order, one parametrised block per trip.  The loop only DECIDES; the closest points of the edge pair that
+  // passes are computed once behind it: on a wavefront the loop runs as many trips as its slowest lane needs (3-4 of 64
+  // lanes' 1.2 on average), so what every trip carries is paid 3-4 times (round 4).
+  typename RectTest<T>::Sel sel;
+  bool found = false;
+  while (mask)
+    if (rt.decide(mask, sel)) {
+      found = true;
+      break;
+    }
+  return found ? rt.finish(sel) : rt.faces();
+}
+
+// the operands of distance(R0, T0, rss1, rss2) for RectTest, and the radii that come off the rectangle distance
+template <typename T>
+HFCL_HD T rss_rect_setup(RectTest<T>& rt, const M3<T>& R0, const V3<T>& T0, const DNodeD<T>& n1, const DNodeD<T>& n2) {
+  const M3<T> R = tmul(n1.axes, mmul(R0, n2.axes));
+  const V3<T> Ttemp = mul(R0, n2.Tr) + T0 - n1.Tr;
+  const V3<T> Tv = tmul(n1.axes, Ttemp);
+  rt.init(R, Tv, n1.l0, n1.l1, n2.l0, n2.l1);
+  return n1.r + n2.r;
 }
 
 // distance(R0, T0, b1.rss, b2.rss): lower bound of the distance between the two node volumes

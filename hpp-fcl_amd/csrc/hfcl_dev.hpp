@@ -702,7 +702,7 @@ struct BvhSpill {
   // ... or, pool != 0, by k_bvh_distance_pool (hfcl_k_bvhd.hip): several walks per wave, their box and triangle tests pooled
   uint32_t pool;
   uint32_t* pool_ticket;
-  uint32_t pool_leaf_min, pool_starve;  // its two scheduling knobs
+  uint32_t pool_leaf_min, pool_starve, pool_part_min;  // its scheduling knobs
 };
 constexpr int BVH_MAX_LEVELS = 12;  // most task levels a batch can be given (HFCL_BVH_LEVELS, the automatic choice)
 #ifndef HFCL_BVH_LEVELS

@@ -119,7 +119,7 @@ struct hfcl_lib {
   // distance(): a mesh x mesh walk that has taken this many steps is continued by a wave (k_bvh_distance_coop); 0: never
   uint32_t bvhd_budget = 64;      // HFCL_BVHD_BUDGET: steps a lane walks before its walk goes to k_bvh_distance_pool (cfg4d 100k queries, budgets 16 / 64 / 256: 34.4 / 33.2 / 34.1 ms, profiles/r04_c; with the wave-per-walk form of round 3, HFCL_BVHD_POOL=0, 1024 was best: 55.7 ms)
   uint32_t bvhd_pool = 1;         // HFCL_BVHD_POOL: the walks past the budget are continued by k_bvh_distance_pool (0: k_bvh_distance_coop)
-  uint32_t bvhd_pool_leaf_min = 24, bvhd_pool_starve = 32;  // HFCL_BVHD_LEAF_MIN / HFCL_BVHD_STARVE
+  uint32_t bvhd_pool_leaf_min = 24, bvhd_pool_starve = 32, bvhd_pool_part_min = 48;  // HFCL_BVHD_LEAF_MIN / HFCL_BVHD_STARVE / HFCL_BVHD_PART_MIN
   void* d_dist_susp = nullptr;    // DistSusp<double>[dist_susp_capacity]
   size_t dist_susp_capacity = 0;
   uint32_t shape_dist_budget = 256;  // HFCL_SHAPE_DIST_BUDGET: the same for mesh x solid (a GJK leaf counts 16 steps; k_bvh_shape_distance_coop)
@@ -449,6 +449,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_BVHD_POOL")) lib->bvhd_pool = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVHD_LEAF_MIN")) lib->bvhd_pool_leaf_min = uint32_t(std::max(1, atoi(v)));
   if (const char* v = getenv("HFCL_BVHD_STARVE")) lib->bvhd_pool_starve = uint32_t(std::max(0, atoi(v)));
+  if (const char* v = getenv("HFCL_BVHD_PART_MIN")) lib->bvhd_pool_part_min = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_DIST_BUDGET")) lib->shape_dist_budget = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_BUDGET0_COOP")) lib->bvh_budget0_coop = uint32_t(std::max(1, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_BUDGET0")) lib->shape_budget0 = lib->shape_budget0_coop = uint32_t(atoi(v));
@@ -1252,6 +1253,8 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         spill.pool_ticket = lib->d_counts + CTR_DIST_TICKET;
         spill.pool_leaf_min = lib->bvhd_pool_leaf_min;
         spill.pool_starve = lib->bvhd_pool_starve;
+        spill.pool_part_min = lib->bvhd_pool_part_min;
+        if (lib->bvh_max_nodes > 32767) spill.pool = 0;  // 15-bit node ids in the pool's entry word (POOL_MAX_NODES)
       }
       launch_bvh_distance<T>(blocks_for(n, BVHD_BLOCK), st, wk, lv, bv, io, q, spill);
       tend();

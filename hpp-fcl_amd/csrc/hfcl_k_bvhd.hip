@@ -409,19 +409,28 @@ k_bvh_distance_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, BvhSpill s
 // k_bvh_distance_pool: the mesh x mesh distance() walks past the lanes' step budget, POOL_Q walks per wave with their tests
 // pooled (round 4; replaces k_bvh_distance_coop as the default continuation).
 //
-// What the measurements of the wave-per-walk form said (profiles/r04_b): 0.47 of the fp64 issue peak with 16 of 64 lanes
+// What the measurements of the wave-per-walk form said (profiles/r04_b_mesh_pmc.txt): 0.47 of the fp64 issue peak with 16 of 64 lanes
 // active on average -- a walk's window holds 10-20 box pairs to split and each of their lanes ran both children's rectangle
 // distances one after the other while the rest idled, and triangle pairs were evaluated a handful at a time.  Here
 //   * a wave owns POOL_Q walks (slots), each with its stack in LDS, in DFS order (top = next in the reference's order);
-//   * every trip, each slot offers the top POOL_SEG entries of its stack; entries whose bound cannot beat the slot's
+//   * every trip, each slot offers the top POOL_SEG * POOL_E entries of its stack; entries whose bound cannot beat the slot's
 //     minimum are dropped, box pairs to split put their TWO child tests into one list for the whole wave, and the list is
-//     worked off 64 tests at a time, one rss_lower_bound per lane (the packed 128-B DNodeD records: one line per node);
+//     worked off 64 tests at a time, one rss_lower_bound per lane (the packed 128-B DNodeD records: one line per node).  Full
+//     rounds only, plus a last partial one when it is the only one or fills `part_min` lanes: what is left over stays on its
+//     stack and is offered again;
 //   * triangle pairs stay on the stack until the wave holds `leaf_min` of them in its windows (or has too few box tests
-//     to fill half of its lanes), then all of them are evaluated together, one per lane;
+//     to fill half of its lanes), then up to 64 of them are evaluated together, one per lane, whichever slot they belong to;
 //   * the window is written back in order: a split pair becomes its two children (nearer one on top, the reference's
-//     `d2 < d1` rule), a deferred triangle pair stays, everything else is gone.
-// An entry carries what the next trip needs to know about it (triangle ids, or which node is split and its first child),
-// filled in by the lane that tested it from the records it had loaded anyway: a trip has no dependent gather before its tests.
+//     `d2 < d1` rule), a deferred triangle pair or box pair stays, everything else is gone.
+// An entry is one 32-bit word and its bound: what the next trip needs to know about it (triangle ids, or which node is split
+// and its first child), filled in by the lane that tested it from the records it had loaded anyway: a trip has no dependent
+// gather before its tests.
+// What bounds it now (profiles/r04_d): a walk's frontier is ~6 box pairs per trip however wide the window, so a wave of four
+// walks fills 42 of 64 lanes per round; a round runs as many candidate blocks of rectDistance as its slowest lane needs (3-4
+// against 1.2 on average); more walks per wave fill the rounds but lengthen every walk, and the batch ends with its longest
+// walks (18 600 box tests against 3 400 on average).  Decoupling the tests from the trips (queues of tests and an "in flight"
+// state for the entries that wait for them) was built and measured 3-5x slower (profiles/r04_f): every level of the
+// trees then takes two trips.
 //
 // Order.  The reference visits triangle pairs in DFS order and keeps the FIRST one that attains the minimum
 // (DistanceResult::update lowers on `<` only), and it skips an entry when its bound is >= the minimum of that moment.  The
@@ -432,47 +441,95 @@ k_bvh_distance_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, BvhSpill s
 // the sequential walk would already hold that minimum at the entry's turn) -- an entry in front of it with an equal bound
 // is kept, as the sequential walk (whose minimum was still larger there) would have.  Writing the window back updates `p`
 // by counting what the entries behind the marker became.  The lane phase hands a walk over with everything on its stack
-// behind its minimum (p = sp).  Measured against the sequential walk on the host (tools/order_free_probe.py, 100 000 cfg4d
-// queries): the same distance, triangle ids and witness points in every query; 95 % of the separated queries have several
-// triangle pairs at exactly the minimal distance (shared vertices), so the marker is what decides the reported ids.
+// behind its minimum (p = sp).  Measured (profiles/r04_c): the oracle's distance, triangle ids and witness points, bit for bit,
+// in 100 000 of 100 000 cfg4d queries; 95 % of the separated queries have several triangle pairs at exactly the minimal
+// distance (shared vertices), so the marker is what decides the reported ids.  What the rule cannot reproduce is a walk whose
+// choice hangs on a bound that exceeds a distance below it by an ulp AND on the order of the visits (one query in 20 000
+// before entries in front of the minimum were given their margin, see the window scan; none since).
 // ---------------------------------------------------------------------------------------
 #ifndef HFCL_POOL_Q
 #define HFCL_POOL_Q 4
 #endif
-constexpr int POOL_Q = HFCL_POOL_Q, POOL_SEG = 64 / POOL_Q;
+#ifndef HFCL_POOL_E
+#define HFCL_POOL_E 1
+#endif
+// POOL_Q slots per wave, POOL_SEG lanes per slot, POOL_E window entries per lane: a slot offers POOL_SEG * POOL_E entries a trip
+constexpr int POOL_Q = HFCL_POOL_Q, POOL_SEG = 64 / POOL_Q, POOL_E = HFCL_POOL_E, POOL_WIN = POOL_SEG * POOL_E;
+static_assert(POOL_E >= 1 && POOL_E <= 3, "per-lane counts travel as three ballots (values up to 2 * POOL_E <= 7)");
 // a slot's stack: windows narrow once POOL_CAPW entries are in use, down to plain DFS, which adds at most the lanes'
 // stack depth (BVHD_STACK >= depth1 + depth2 + 2, make_bvh_spill) on top
-constexpr int POOL_CAPW = 640 / POOL_Q, POOL_CAP = POOL_CAPW + BVHD_STACK + 8;
+#ifndef HFCL_POOL_CAPW
+#define HFCL_POOL_CAPW (640 / HFCL_POOL_Q)
+#endif
+constexpr int POOL_CAPW = HFCL_POOL_CAPW, POOL_CAP = POOL_CAPW + BVHD_STACK + 8;
+#ifndef HFCL_POOL_ROUNDS
+#define HFCL_POOL_ROUNDS 2
+#endif
+constexpr int POOL_ROUNDS = HFCL_POOL_ROUNDS, POOL_TESTS = 64 * POOL_ROUNDS;  // child tests of a trip: full rounds of 64
+constexpr uint32_t POOL_MAX_NODES = 32767;
 
-// what the next trip needs to know about the node pair (n1, n2): bit 31 = two leaves -> triangle ids (15 bits each; a
-// narrow-form model has < 32 768 triangles); else bit 30 = node 1 is the one to split (distanceRecurse's descent rule:
-// node 2 a leaf, or node 1 not a leaf and larger) and bits 0-15 = the first child of the node that is split
-__device__ __forceinline__ uint32_t pool_entry_info(int32_t fc1, uint32_t rk1, int32_t fc2, uint32_t rk2) {
+// A stack entry is ONE 32-bit word next to its bound -- what the next trip needs to know about the node pair (n1, n2):
+// bit 31 = two leaves -> bits 0-14 / 15-29 the triangle ids; else bit 30 = node 1 is the one to split (distanceRecurse's descent
+// rule: node 2 a leaf, or node 1 not a leaf and larger), bits 0-14 = the node that is kept, bits 15-29 = the first child of the
+// node that is split.  15-bit ids: models of up to POOL_MAX_NODES nodes (larger narrow-form models take k_bvh_distance_coop).
+__device__ __forceinline__ uint32_t pool_entry_info(uint32_t n1, int32_t fc1, uint32_t rk1, uint32_t n2, int32_t fc2, uint32_t rk2) {
   const bool l1 = fc1 < 0, l2 = fc2 < 0;
   if (l1 && l2) return 0x80000000u | uint32_t(-(fc1 + 1)) | (uint32_t(-(fc2 + 1)) << 15);
   const bool side1 = l2 || (!l1 && rk1 > rk2);
-  return side1 ? (0x40000000u | uint32_t(fc1)) : uint32_t(fc2);
+  return side1 ? (0x40000000u | n2 | (uint32_t(fc1) << 15)) : (n1 | (uint32_t(fc2) << 15));
 }
 
 #ifndef HFCL_WPE_BVHD_POOL
 #define HFCL_WPE_BVHD_POOL 2
 #endif
+// HFCL_POOL_PROF (variant builds only, tools/build_variant.sh): wave clocks per phase and event counts into pool_prof[16]
+// (0 scan / 1 box tests / 2 triangle tests / 3 write-back / 4 refill clocks; 8 trips, 9 box rounds, 10 box tests, 11 triangle
+// passes, 12 triangle tests, 13 walks), read back by tools/pool_prof.py through hfcl_debug_pool_prof
+#ifdef HFCL_POOL_PROF
+__device__ unsigned long long pool_prof[16];
+#define POOL_T0() const unsigned long long t0_ = __builtin_readcyclecounter()
+#define POOL_T(i)                                                                      \
+  do {                                                                                 \
+    if (lane == 0) atomicAdd(&pool_prof[i], __builtin_readcyclecounter() - tq_);       \
+    tq_ = __builtin_readcyclecounter();                                                \
+  } while (0)
+#define POOL_C(i, v)                                                  \
+  do {                                                                \
+    if (lane == 0) atomicAdd(&pool_prof[i], (unsigned long long)(v)); \
+  } while (0)
+#else
+#define POOL_T(i)
+#define POOL_C(i, v)
+#endif
 template <typename T>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVHD_POOL, 8))) k_bvh_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, BvhSpill spill) {
   constexpr int Q = POOL_Q, SEG = POOL_SEG;
-  __shared__ uint32_t st_e[Q][POOL_CAP], st_x[Q][POOL_CAP];
+  __shared__ uint32_t st_x[Q][POOL_CAP];
   __shared__ T st_d[Q][POOL_CAP];
   __shared__ T q_rt[Q][12];   // RT_R (row-major), RT_T of the slot's query
   __shared__ T q_wit[Q][6];   // witness points of the slot's minimum, model-1 frame
   __shared__ int q_fb[Q][2];
-  __shared__ uint32_t t_n1[128], t_n2[128], t_q[128], t_x[128];
-  __shared__ T t_res[128];
+  __shared__ uint32_t q_noff[Q][2];  // node_off of the slot's two models
+  __shared__ uint32_t q_off[Q][4];  // vert_off, tri_off of the slot's two models (the lane that evaluates a triangle pair may belong to another slot)
+  __shared__ int q_win[Q];          // index in the triangle list of the pair that set the slot's minimum in this trip (-1: none)
+  __shared__ uint32_t t_n1[POOL_TESTS], t_n2[POOL_TESTS], t_x[POOL_TESTS];
+  __shared__ uint8_t t_q[POOL_TESTS];
+  __shared__ T t_res[POOL_TESTS];
+  __shared__ uint32_t l_x[64];  // the triangle pairs evaluated in this trip (at most one per lane): the entry's info word ...
+  __shared__ uint8_t l_q[64];   // ... and its slot
+  __shared__ T l_val[64];
+  constexpr int E = POOL_E, WIN = POOL_WIN;
   const int lane = threadIdx.x, q = lane / SEG, j = lane % SEG;
   const uint64_t lt_mask = (uint64_t(1) << lane) - 1;
   const uint64_t segm = (SEG == 64 ? ~uint64_t(0) : ((uint64_t(1) << SEG) - 1)) << (q * SEG);
   const uint64_t deeper = segm & ~((uint64_t(2) << lane) - 1);  // the lanes of my slot that hold entries further down
+  // sum of a small per-lane count c (0 ... 7) over the lanes of mask m
+  auto lane_sum = [](int c, uint64_t m) -> int {
+    return __popcll(__ballot((c & 1) != 0) & m) + 2 * __popcll(__ballot((c & 2) != 0) & m) + 4 * __popcll(__ballot((c & 4) != 0) & m);
+  };
   const uint32_t n_susp = *spill.susp_count;
-  const int leaf_min = int(spill.pool_leaf_min), starve = int(spill.pool_starve);
+  const int leaf_min = int(spill.pool_leaf_min), starve = int(spill.pool_starve), part_min = int(spill.pool_part_min);
+  uint32_t trip = 0;
   const T big = Lim<T>::max(), nanv = Lim<T>::nan();
   auto sync = []() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -485,6 +542,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
   T mind = big;
   uint32_t pair = 0, off1 = 0, off2 = 0;
   DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
+#ifdef HFCL_POOL_PROF
+  unsigned long long tq_ = __builtin_readcyclecounter();
+#endif
   for (;;) {
     // ---- slots without a walk take the next suspended ones
     const uint64_t idle = __ballot(!active && j == 0);
@@ -509,8 +569,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
           const uint32_t e = r->entry[k];
           const DNodeD<T>* const a = bv.dnodes + off1 + (e & 0xFFFFu);
           const DNodeD<T>* const b = bv.dnodes + off2 + (e >> 16);
-          st_e[q][k] = e;
-          st_x[q][k] = pool_entry_info(a->first_child, a->rank, b->first_child, b->rank);
+          st_x[q][k] = pool_entry_info(e & 0xFFFFu, a->first_child, a->rank, e >> 16, b->first_child, b->rank);
           st_d[q][k] = r->bound[k];
         }
         if (j == 0) {
@@ -522,6 +581,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
           o[6] = R.r2.x; o[7] = R.r2.y; o[8] = R.r2.z; o[9] = t.x; o[10] = t.y; o[11] = t.z;
           q_fb[q][0] = r->fb1;
           q_fb[q][1] = r->fb2;
+          q_noff[q][0] = m1.node_off; q_noff[q][1] = m2.node_off;
+          q_off[q][0] = m1.vert_off; q_off[q][1] = m1.tri_off; q_off[q][2] = m2.vert_off; q_off[q][3] = m2.tri_off;
           T* w6 = q_wit[q];
           w6[0] = r->np1.x; w6[1] = r->np1.y; w6[2] = r->np1.z; w6[3] = r->np2.x; w6[4] = r->np2.y; w6[5] = r->np2.z;
         }
@@ -530,137 +591,238 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
       sync();
     }
     if (__ballot(active) == 0) break;  // (only once the records have run out)
-    // ---- the windows
-    const int w = active ? min(SEG, min(sp, max(POOL_CAPW - sp, 1))) : 0;
-    const bool act = j < w;
-    const int i = sp - 1 - j;
-    uint32_t e = 0, x = 0;
-    T db = big;
-    if (act) {
-      e = st_e[q][i];
-      x = st_x[q][i];
-      db = st_d[q][i];
+    POOL_T(4);
+    // ---- the windows: lane j of a slot holds entries j * E ... j * E + E - 1 from the top of the slot's stack
+    const int w = active ? min(WIN, min(sp, max(POOL_CAPW - sp, 1))) : 0;
+    const int base_i = sp - w;
+    uint32_t x[E];
+    T db[E];
+    int idx[E];
+    bool is_leaf[E], split[E], held[E];
+    int ns_l = 0, nl_l = 0;
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+      const int wj = j * E + u;
+      const bool act = wj < w;
+      idx[u] = sp - 1 - wj;
+      x[u] = 0u;
+      db[u] = big;
+      if (act) {
+        x[u] = st_x[q][idx[u]];
+        db[u] = st_d[q][idx[u]];
+      }
+      // canStop(bound) with the slot's minimum.  Behind the pair that set the minimum (idx < p) this is the sequential walk's
+      // test at the entry's turn.  In front of it the sequential walk held a larger minimum at the entry's turn, and a bound
+      // can exceed a distance below it by an ulp (a leaf pair's rectangles against its triangles): such an entry may hold
+      // the first pair at the minimal distance, so entries in front are only dropped when their bound is clear of the minimum
+      const bool alive = act && !(db[u] >= T(0) && (idx[u] < p ? db[u] >= mind : db[u] > mind * (T(1) + T(64) * Lim<T>::eps())));
+      held[u] = false;
+      is_leaf[u] = alive && (x[u] >> 31) != 0u;
+      split[u] = alive && (x[u] >> 31) == 0u;
+      ns_l += split[u] ? 1 : 0;
+      nl_l += is_leaf[u] ? 1 : 0;
     }
-    // canStop(bound) with the slot's minimum.  Behind the pair that set the minimum (i < p) this is the sequential walk's
-    // test at the entry's turn.  In front of it the sequential walk held a larger minimum at the entry's turn, and a bound
-    // can exceed a distance below it by an ulp (a leaf pair's rectangles against its triangles): such an entry may hold
-    // the first pair at the minimal distance, so entries in front are only dropped when their bound is clear of the minimum
-    const bool alive = act && !(db >= T(0) && (i < p ? db >= mind : db > mind * (T(1) + T(64) * Lim<T>::eps())));
-    const bool is_leaf = alive && (x >> 31) != 0u, split = alive && (x >> 31) == 0u;
     // ---- the children's tests of every split pair of the wave in one list
-    const uint64_t smask = __ballot(split);
-    const int ns = __popcll(smask), k2 = 2 * __popcll(smask & lt_mask);
-    uint32_t ea = 0, ec = 0;
-    if (split) {
-      const uint32_t b1 = e & 0xFFFFu, b2 = e >> 16, fc = x & 0xFFFFu;
-      const bool side1 = (x & 0x40000000u) != 0u;
-      const uint32_t a1 = side1 ? fc : b1, a2 = side1 ? b2 : fc, c1 = side1 ? fc + 1 : b1, c2 = side1 ? b2 : fc + 1;
-      ea = a1 | (a2 << 16);
-      ec = c1 | (c2 << 16);
-      t_n1[k2] = off1 + a1;
-      t_n2[k2] = off2 + a2;
-      t_q[k2] = uint32_t(q);
-      t_n1[k2 + 1] = off1 + c1;
-      t_n2[k2 + 1] = off2 + c2;
-      t_q[k2 + 1] = uint32_t(q);
-    }
-    sync();
-    for (int tb = 0; tb < 2 * ns; tb += 64) {
-      const int t = tb + lane;
-      if (t < 2 * ns) {
-        const T* const rt = q_rt[t_q[t]];
-        M3<T> R0;
-        R0.r0 = mk<T>(rt[0], rt[1], rt[2]);
-        R0.r1 = mk<T>(rt[3], rt[4], rt[5]);
-        R0.r2 = mk<T>(rt[6], rt[7], rt[8]);
-        const V3<T> T0 = mk<T>(rt[9], rt[10], rt[11]);
-        const DNodeD<T> A = bv.dnodes[t_n1[t]], B = bv.dnodes[t_n2[t]];
-        t_res[t] = rss_lower_bound(R0, T0, A, B);
-        t_x[t] = pool_entry_info(A.first_child, A.rank, B.first_child, B.rank);
+    const int ns = lane_sum(ns_l, ~uint64_t(0));
+    // Only full rounds of 64 tests are run (at most POOL_ROUNDS of them), and a last partial one when nothing else would run or
+    // it fills `part_min` lanes: the split pairs beyond stay as they are and are offered again in the next trip, together with
+    // the children of the pairs that were split -- a round costs the same with 3 lanes as with 64 (profiles/r04_d: 42 of 64
+    // lanes per round before).  Which end of the wave's windows is served first alternates, so no slot waits for long.
+    const bool up = (trip & 1u) == 0u;
+    ++trip;
+    const int t_all = 2 * ns;
+    int t_run = min(t_all, 64 * POOL_ROUNDS);
+    if (t_run > 64 && (t_run & 63) != 0 && (t_run & 63) < part_min) t_run &= ~63;
+    int k2[E];
+    {
+      int k = lane_sum(ns_l, up ? lt_mask : ~((uint64_t(2) << lane) - 1));
+#pragma unroll
+      for (int uu = 0; uu < E; ++uu) {
+        const int u = up ? uu : E - 1 - uu;
+        k2[u] = 2 * k;
+        if (split[u]) {
+          if (2 * k < t_run) {
+            const uint32_t keep = x[u] & 0x7FFFu, fc = (x[u] >> 15) & 0x7FFFu;
+            const bool side1 = (x[u] & 0x40000000u) != 0u;
+            const uint32_t a1 = side1 ? fc : keep, a2 = side1 ? keep : fc, c1 = side1 ? fc + 1 : keep, c2 = side1 ? keep : fc + 1;
+            t_n1[2 * k] = a1;
+            t_n2[2 * k] = a2;
+            t_q[2 * k] = uint8_t(q);
+            t_n1[2 * k + 1] = c1;
+            t_n2[2 * k + 1] = c2;
+            t_q[2 * k + 1] = uint8_t(q);
+          } else {
+            split[u] = false;  // not in this trip: the entry stays as it is
+            held[u] = true;
+          }
+          ++k;
+        }
       }
     }
     sync();
-    T d1 = big, d2 = big;
-    uint32_t xa = 0, xc = 0;
-    if (split) {
-      d1 = t_res[k2];
-      d2 = t_res[k2 + 1];
-      xa = t_x[k2];
-      xc = t_x[k2 + 1];
-    }
-    // ---- the triangle pairs, once they are worth a pass
-    const int nl = __popcll(__ballot(is_leaf));
-    const bool do_leaves = nl > 0 && (nl >= leaf_min || 2 * ns < starve);
-    int jw = -1;  // the window entry that set a new minimum in this trip (slot-uniform)
-    if (do_leaves) {
-      T val = big;
-      V3<T> P = mk<T>(nanv, nanv, nanv), Qp = P;
-      const uint32_t lb1 = x & 0x7FFFu, lb2 = (x >> 15) & 0x7FFFu;
-      if (is_leaf) {
-        const T* const rt = q_rt[q];
+    POOL_T(0);
+    POOL_C(8, 1);
+    POOL_C(10, t_run);
+    for (int tb = 0; tb < t_run; tb += 64) {
+      POOL_C(9, 1);
+      const int t = tb + lane;
+      if (t < t_run) {
+        const uint32_t ts = t_q[t];
+        const T* const rt = q_rt[ts];
         M3<T> R0;
         R0.r0 = mk<T>(rt[0], rt[1], rt[2]);
         R0.r1 = mk<T>(rt[3], rt[4], rt[5]);
         R0.r2 = mk<T>(rt[6], rt[7], rt[8]);
         const V3<T> T0 = mk<T>(rt[9], rt[10], rt[11]);
-        const T* v1 = bv.verts + 3 * size_t(m1.vert_off);
-        const T* v2 = bv.verts + 3 * size_t(m2.vert_off);
-        const uint32_t* t1 = bv.tris + 3 * size_t(m1.tri_off + lb1);
-        const uint32_t* t2 = bv.tris + 3 * size_t(m2.tri_off + lb2);
+        const uint32_t n1 = t_n1[t], n2 = t_n2[t];
+        const DNodeD<T> A = bv.dnodes[q_noff[ts][0] + n1], B = bv.dnodes[q_noff[ts][1] + n2];
+        t_res[t] = rss_lower_bound(R0, T0, A, B);
+        t_x[t] = pool_entry_info(n1, A.first_child, A.rank, n2, B.first_child, B.rank);
+      }
+    }
+    sync();
+    T d1[E], d2[E];
+    uint32_t xa[E], xc[E];
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+      d1[u] = d2[u] = big;
+      xa[u] = xc[u] = 0u;
+      if (split[u]) {
+        d1[u] = t_res[k2[u]];
+        d2[u] = t_res[k2[u] + 1];
+        xa[u] = t_x[k2[u]];
+        xc[u] = t_x[k2[u] + 1];
+      }
+    }
+    POOL_T(1);
+    // ---- the triangle pairs, once they are worth a pass: the first 64 of the wave's windows, one per lane
+    const int nl = lane_sum(nl_l, ~uint64_t(0));
+    const bool do_leaves = nl > 0 && (nl >= leaf_min || 2 * ns < starve);
+    int jw = -1;  // the window entry (j * E + u) that set a new minimum in this trip (slot-uniform)
+    bool leaf_eval[E];
+#pragma unroll
+    for (int u = 0; u < E; ++u) leaf_eval[u] = false;
+    if (do_leaves) {
+      int li[E];
+      {
+        int l = lane_sum(nl_l, lt_mask);
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+          li[u] = l;
+          if (is_leaf[u]) {
+            if (l < 64) {
+              leaf_eval[u] = true;
+              l_x[l] = x[u];
+              l_q[l] = uint8_t(q);
+            }
+            ++l;
+          }
+        }
+      }
+      if (j == 0) q_win[q] = -1;
+      sync();
+      const int nle = min(nl, 64);
+      T val = big;
+      V3<T> P = mk<T>(nanv, nanv, nanv), Qp = P;
+      uint32_t my_slot = 0u, lb1 = 0u, lb2 = 0u;
+      if (lane < nle) {
+        my_slot = l_q[lane];
+        lb1 = l_x[lane] & 0x7FFFu;
+        lb2 = (l_x[lane] >> 15) & 0x7FFFu;
+        const T* const rt = q_rt[my_slot];
+        M3<T> R0;
+        R0.r0 = mk<T>(rt[0], rt[1], rt[2]);
+        R0.r1 = mk<T>(rt[3], rt[4], rt[5]);
+        R0.r2 = mk<T>(rt[6], rt[7], rt[8]);
+        const V3<T> T0 = mk<T>(rt[9], rt[10], rt[11]);
+        const T* v1 = bv.verts + 3 * size_t(q_off[my_slot][0]);
+        const T* v2 = bv.verts + 3 * size_t(q_off[my_slot][2]);
+        const uint32_t* t1 = bv.tris + 3 * size_t(q_off[my_slot][1] + lb1);
+        const uint32_t* t2 = bv.tris + 3 * size_t(q_off[my_slot][3] + lb2);
         const T dd = sqr_tri_distance(vtx(v1, t1[0]), vtx(v1, t1[1]), vtx(v1, t1[2]), mul(R0, vtx(v2, t2[0])) + T0,
                                       mul(R0, vtx(v2, t2[1])) + T0, mul(R0, vtx(v2, t2[2])) + T0, P, Qp);
         val = hsqrt(dd);
+        l_val[lane] = val;
       }
-      // DistanceResult::update over the slot's evaluated pairs: the smallest value, the first in DFS order among equals
-      // (j = 0 is the top of the stack), and against the standing minimum a tie wins only in front of it
-      const bool cand = is_leaf && (val < mind || (val == mind && i >= p));
-      T bestv = cand ? val : big;
-      int bj = cand ? j : 64;
+      sync();
+      // DistanceResult::update over the slot's evaluated pairs: the smallest value, the first in DFS order among equals (window
+      // index 0 is the top of the stack), and against the standing minimum a tie wins only in front of it
+      T bestv = big;
+      int bw = 64 * E, bl = -1;  // window index and list index of the lane's / the slot's best candidate
+#pragma unroll
+      for (int u = 0; u < E; ++u) {
+        if (leaf_eval[u]) {
+          const T v = l_val[li[u]];
+          const bool cand = v < mind || (v == mind && idx[u] >= p);
+          if (cand && (bl < 0 || v < bestv)) {  // (u ascending = DFS order: a later equal value does not replace)
+            bestv = v;
+            bw = j * E + u;
+            bl = li[u];
+          }
+        }
+      }
 #pragma unroll
       for (int m = 1; m < SEG; m <<= 1) {
         const T ov = __shfl_xor(bestv, m);
-        const int oj = __shfl_xor(bj, m);
-        if (oj < 64 && (bj == 64 || ov < bestv || (ov == bestv && oj < bj))) {
+        const int ow = __shfl_xor(bw, m), ol = __shfl_xor(bl, m);
+        if (ol >= 0 && (bl < 0 || ov < bestv || (ov == bestv && ow < bw))) {
           bestv = ov;
-          bj = oj;
+          bw = ow;
+          bl = ol;
         }
       }
-      if (bj < 64) {
-        jw = bj;
+      if (bl >= 0) {
+        jw = bw;
         mind = bestv;
-        if (j == bj) {
-          q_fb[q][0] = int(lb1);
-          q_fb[q][1] = int(lb2);
-          T* w6 = q_wit[q];
-          w6[0] = P.x; w6[1] = P.y; w6[2] = P.z; w6[3] = Qp.x; w6[4] = Qp.y; w6[5] = Qp.z;
-        }
+        if (j == 0) q_win[q] = bl;
       }
+      sync();
+      if (lane < nle && q_win[my_slot] == lane) {  // the lane that evaluated the new minimum's pair still holds its witness
+        q_fb[my_slot][0] = int(lb1);
+        q_fb[my_slot][1] = int(lb2);
+        T* w6 = q_wit[my_slot];
+        w6[0] = P.x; w6[1] = P.y; w6[2] = P.z; w6[3] = Qp.x; w6[4] = Qp.y; w6[5] = Qp.z;
+      }
+      POOL_C(11, 1);
+      POOL_C(12, nle);
     }
-    // ---- the windows written back, in order
-    const int cnt = split ? 2 : ((is_leaf && !do_leaves) ? 1 : 0);
-    const uint64_t m2b = __ballot(cnt == 2), m1b = __ballot(cnt == 1);
-    const int base_i = sp - w;
-    const int pos = base_i + 2 * __popcll(m2b & deeper) + __popcll(m1b & deeper);
-    if (cnt == 2) {
-      const bool c_first = d2 < d1;  // visit (c1, c2) first when it is strictly nearer
-      st_e[q][pos] = c_first ? ea : ec;
-      st_x[q][pos] = c_first ? xa : xc;
-      st_d[q][pos] = c_first ? d1 : d2;
-      st_e[q][pos + 1] = c_first ? ec : ea;
-      st_x[q][pos + 1] = c_first ? xc : xa;
-      st_d[q][pos + 1] = c_first ? d2 : d1;
-    } else if (cnt == 1) {
-      st_e[q][pos] = e;
-      st_x[q][pos] = x;
-      st_d[q][pos] = db;
+    POOL_T(2);
+    // ---- the windows written back, in order: deeper entries first, a split pair as its two children (nearer one on top)
+    int cnt[E], cnt_l = 0, later_l = 0;
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+      cnt[u] = split[u] ? 2 : (((is_leaf[u] && !leaf_eval[u]) || held[u]) ? 1 : 0);
+      cnt_l += cnt[u];
+      const bool later = (j * E + u) < w && (jw >= 0 ? (j * E + u) > jw : idx[u] < p);  // stands behind the pair of the minimum
+      later_l += later ? cnt[u] : 0;
+    }
+    {
+      int pos = base_i + lane_sum(cnt_l, deeper);
+#pragma unroll
+      for (int u = E - 1; u >= 0; --u) {
+        if (cnt[u] == 2) {
+          const bool c_first = d2[u] < d1[u];  // visit (c1, c2) first when it is strictly nearer
+          st_x[q][pos] = c_first ? xa[u] : xc[u];
+          st_d[q][pos] = c_first ? d1[u] : d2[u];
+          st_x[q][pos + 1] = c_first ? xc[u] : xa[u];
+          st_d[q][pos + 1] = c_first ? d2[u] : d1[u];
+        } else if (cnt[u] == 1) {
+          st_x[q][pos] = x[u];
+          st_d[q][pos] = db[u];
+        }
+        pos += cnt[u];
+      }
     }
     // the marker: what stands behind the pair of the minimum now
-    const uint64_t later_m = __ballot(act && (jw >= 0 ? j > jw : i < p)) & segm;
-    p = (jw >= 0 ? base_i : min(p, base_i)) + 2 * __popcll(m2b & later_m) + __popcll(m1b & later_m);
-    sp = base_i + 2 * __popcll(m2b & segm) + __popcll(m1b & segm);
+    p = (jw >= 0 ? base_i : min(p, base_i)) + lane_sum(later_l, segm);
+    sp = base_i + lane_sum(cnt_l, segm);
     sync();
+    POOL_T(3);
     if (active && sp == 0) {  // this walk is over
       if (j == 0) {
+#ifdef HFCL_POOL_PROF
+        atomicAdd(&pool_prof[13], 1ull);
+#endif
         const Pose<T> tf1 = load_pose(io.tf1, pair);
         const T* w6 = q_wit[q];
         PairOut<T> o;
@@ -695,5 +857,13 @@ void launch_bvh_distance(int grid, hipStream_t st, const Work& wk, const LibView
       hipLaunchKernelGGL((k_bvh_distance_coop<T>), dim3(cgrid), dim3(64), 0, st, wk, lv, bv, io, spill);
   }
 }
+#ifdef HFCL_POOL_PROF
+extern "C" int hfcl_debug_pool_prof(unsigned long long* out16, int reset) {
+  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pool_prof), sizeof(z)) != hipSuccess) return -1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(pool_prof), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 template void launch_bvh_distance<float>(int, hipStream_t, const Work&, const LibView<float>&, const BvhView<float>&, const IO<float>&, const QParams<float>&, BvhSpill);
 template void launch_bvh_distance<double>(int, hipStream_t, const Work&, const LibView<double>&, const BvhView<double>&, const IO<double>&, const QParams<double>&, BvhSpill);
