@@ -83,15 +83,20 @@ def test_cfg5_scene_statistics(pkg):
 
 
 @pytest.mark.gpu
-def test_gpu_narrowphase_on_broadphase_pairs(pkg, oracle):
-    """cfg5 end to end: host broadphase -> device collide() on the candidate pairs == oracle."""
+@pytest.mark.parametrize("n_objects,pairs", [(60000, 300000), (125000, 1250000)])
+def test_gpu_narrowphase_on_broadphase_pairs(pkg, oracle, n_objects, pairs):
+    """cfg5 end to end: host broadphase -> device collide() on the candidate pairs == oracle; the second case is BASELINE.json
+    configs[4]'s per-GPU share (10M / 8 = 1.25M pairs from a scene of 125 000 objects), every record against the oracle."""
     import compare
+    import os
     abi, wl = pkg.abi, pkg.workloads
-    b = _scene(pkg, 60000, 300000)
+    b = _scene(pkg, n_objects, int(1.15 * pairs))  # (the scene's side is chosen for ABOUT that many overlapping boxes)
+    assert len(b) >= pairs, len(b)
+    b = b.slice(0, pairs)
     req = wl.make_request(b, abi)
     lib = wl.make_library(pkg, b)
     got = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
-    ref = oracle.collide_batch(b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=32)
+    ref = oracle.collide_batch(b.shapes, b.verts, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=min(64, os.cpu_count() or 8))
     compare.check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name="cfg5-broadphase")
     assert 0.05 < (ref["num_contacts"] > 0).mean() < 0.9
     lib.close()

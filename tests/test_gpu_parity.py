@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 def _oracle(oracle, b, req, tf1=None, tf2=None):
     fn = oracle.distance_batch if b.kind == "distance" else oracle.collide_batch
     return fn(b.shapes, b.verts, b.s1, b.s2, b.tf1 if tf1 is None else tf1, b.tf2 if tf2 is None else tf2, req,
-              n_threads=8)
+              n_threads=min(64, max(8, os.cpu_count() or 8)))
 
 
 def _engine(pkg, b, req):
@@ -233,10 +233,11 @@ def test_edge_cases(pkg, oracle):
 @pytest.mark.parametrize("case", ["cfg2_box_capsule", "cfg3_convex_convex", "cfg3_unique_hulls"])
 def test_fp32_device_path(pkg, oracle, torch_cuda, case):
     """fp32 device-resident path (7-float poses, 44-byte records) vs the fp64 oracle fed with the
-    fp32-rounded poses.  Envelope |dd| <= 1e-4*(1+|d|); flags may differ only if |d| <= 1e-4."""
+    fp32-rounded poses.  Envelope |dd| <= 1e-4*(1+|d|); flags may differ only if |d| <= 1e-4.  cfg3_convex_convex is the
+    headline configuration (BASELINE.json configs[2]) at its size: 1 000 000 pairs, every record against the oracle."""
     torch = torch_cuda
     abi, wl = pkg.abi, pkg.workloads
-    b = getattr(wl, case)(n=100000 if case == "cfg3_unique_hulls" else 200000)
+    b = getattr(wl, case)(n={"cfg3_unique_hulls": 100000, "cfg3_convex_convex": 1000000}.get(case, 200000))
     req = wl.make_request(b, abi)
     tf1, tf2 = b.tf_from_f32()
     ref = _oracle(oracle, b, req, tf1, tf2)
