@@ -11,5 +11,6 @@ for wl in cfg3 cfg5 cfg4 cfg4d cfg4s; do
     echo "# source_sha $sha); the database is kept as gpurun_out/$t1/${wl}_results.db (scratch, not committed)"
     cat gpurun_out/$t1/${wl}_kernel_trace_stats.txt; } > profiles/${pre}_${wl}_kernel_trace_stats.txt
 done
-grep '^{' gpurun_out/$t2/bench_default.json | tail -1 > profiles/${pre}_bench_default.json
+grep '^{' gpurun_out/$t2/bench_default.json | tail -1 > profiles/${pre}_bench_line.json   # the compact line (what the driver parses)
+cp gpurun_out/$t2/bench_full.json profiles/${pre}_bench_default.json                      # the full record
 echo "source_sha $sha -> profiles/${pre}_*"
