@@ -2005,7 +2005,9 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
     s0.budget = split.budget0;
     s0.can_suspend = 1;
     launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s0, spill, false);
-    hipLaunchKernelGGL((k_bvh_coop<T>), dim3(std::max(1, std::min(grid * 2, split.coop_grid ? int(split.coop_grid) : grid * 2))), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2, s0);
+    // a wave per suspended query, up to what the chip holds (`grid` blocks of BVH_BLOCK queries: `grid * 2` waves left a quarter of the
+    // wave slots empty at 100k queries, profiles/r04_h)
+    hipLaunchKernelGGL((k_bvh_coop<T>), dim3(std::max(1, std::min(grid * BVH_BLOCK, split.coop_grid ? int(split.coop_grid) : grid * 2))), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2, s0);
     return;
   }
   const uint32_t budget = split.budget;
@@ -2031,7 +2033,7 @@ template <typename T>
 void launch_bvh_shape_distance_fast(int grid, int grid_finish, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, BvhSpill spill) {
   hipLaunchKernelGGL((k_shape_obbrss<T>), dim3(std::max(1, grid / 4)), dim3(256), 0, st, wk, lv, io);
   hipLaunchKernelGGL((k_bvh_shape_distance_lane<T>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q, spill);
-  if (spill.budget) hipLaunchKernelGGL((k_bvh_shape_distance_coop<T>), dim3(std::max(1, std::min(grid, int(spill.max_blocks)))), dim3(64), 0, st, wk, lv, bv, io, q, spill);
+  if (spill.budget) hipLaunchKernelGGL((k_bvh_shape_distance_coop<T>), dim3(std::max(1, std::min(grid * BVHD_BLOCK, int(spill.max_blocks)))), dim3(64), 0, st, wk, lv, bv, io, q, spill);
   BvhSplit none;
   memset(&none, 0, sizeof(none));
   BvhParams bp;
