@@ -252,21 +252,23 @@ def test_fp32_device_path(pkg, oracle, torch_cuda, case):
     fn(d_s1, d_s2, d_p1, d_p2, len(b), req, d_out, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     got = d_out.cpu().numpy().view(abi.RESULT_F32_DTYPE)
-    # No blanket allowance.  One class of records is excused, enumerated and checked for its stated reason: a polytope
-    # with two near-equidistant closest faces, where fp32 EPA ends on the other one.  Depth and flags must still be inside
-    # the envelope; only the separation DIRECTION may differ, and it must be one that realises the same penetration depth
-    # (overlap of the two shapes along the GPU's normal, evaluated in fp64 from the shapes, within the envelope of the
-    # oracle's depth).  At most 4 such records in a batch (the 2M-pair soak finds 1 per million).
+    # No blanket allowance.  One class of records is excused, enumerated and checked for its stated reason: the separation
+    # DIRECTION differs from the oracle's by more than the envelope while depth / distance and flags are inside it -- a polytope
+    # with two near-equidistant closest faces where fp32 EPA ends on the other one, or (one separated pair per million, met at
+    # BASELINE size) a GJK run whose fp32 iterates stop on another point of a nearly flat minimum: the solvers' stopping rules
+    # bound the distance to `tol`, the direction only to ~sqrt(2 tol).  Such a record must still be RIGHT: along the GPU's
+    # normal the two shapes, evaluated in fp64 from the shape table, overlap by the oracle's depth (penetration) or are apart by
+    # the oracle's distance (separation), within the envelope -- i.e. the direction realises the same signed distance.
+    # At most 4 such records in a batch (the 2M-pair soak finds 1 per million).
     bad = check_parity(abi, got, ref, dist_tol=1e-4, point_tol=5e-4, flag_band=1e-4, name=case + "-f32", fp32=True,
                        collect_only=True)
     excused = bad["sep_bad_mask"] & ~bad["flag_bad_mask"] & ~bad["dist_bad_mask"] & ~bad["nan_bad_mask"]
     assert excused.sum() <= 4, "%s: %d records outside the fp32 envelope: %s" % (case, excused.sum(), np.flatnonzero(excused)[:20])
     for k in np.flatnonzero(excused):
-        assert abi.status_contact(ref["status"][k]) == 1, "only penetrating pairs (EPA) are excused"
         nrm = got["normal"][k].astype(np.float64)
-        ext = _overlap_extent(abi, b, k, tf1[k], tf2[k], nrm / np.linalg.norm(nrm))
-        d = abs(float(ref["distance"][k]))
-        assert abs(ext - d) <= 1e-4 * (1 + d), "record %d: the GPU's normal does not realise the oracle's depth (%g vs %g)" % (k, ext, d)
+        ext = _overlap_extent(abi, b, k, tf1[k], tf2[k], nrm / np.linalg.norm(nrm))  # > 0: overlap along the normal, < 0: a gap
+        d = float(ref["distance"][k])  # signed: -depth for a penetrating pair
+        assert abs(ext + d) <= 1e-4 * (1 + abs(d)), "record %d: the GPU's normal does not realise the oracle's signed distance (%g vs %g)" % (k, -ext, d)
     check_parity(abi, got[~excused], ref[~excused], dist_tol=1e-4, point_tol=5e-4, flag_band=1e-4, name=case + "-f32", fp32=True)
     check_properties(abi, got, tol=2e-4, name=case + "-f32")
     lib.close()
