@@ -461,7 +461,8 @@ static_assert(POOL_E >= 1 && POOL_E <= 3, "per-lane counts travel as three ballo
 #ifndef HFCL_POOL_CAPW
 #define HFCL_POOL_CAPW (640 / HFCL_POOL_Q)
 #endif
-constexpr int POOL_CAPW = HFCL_POOL_CAPW, POOL_CAP = POOL_CAPW + BVHD_STACK + 8;
+constexpr int POOL_CAPW = HFCL_POOL_CAPW;
+constexpr int POOL_BIG_BATCH = 400000;  // queries from which a wave takes 8 walks instead of POOL_Q
 #ifndef HFCL_POOL_ROUNDS
 #define HFCL_POOL_ROUNDS 2
 #endif
@@ -501,11 +502,14 @@ __device__ unsigned long long pool_prof[16];
 #define POOL_T(i)
 #define POOL_C(i, v)
 #endif
-template <typename T>
+// PQ: walks per wave.  POOL_Q (4) for batches up to POOL_BIG_BATCH queries; 8 (8-entry windows, shorter stacks) beyond: fuller rounds,
+// and the longer life of every walk no longer shows at the end of the batch (1M queries: 224 -> 215 ms; 100k: 25.9 -> 27.3 ms)
+template <typename T, int PQ>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVHD_POOL, 8))) k_bvh_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, BvhSpill spill) {
-  constexpr int Q = POOL_Q, SEG = POOL_SEG;
-  __shared__ uint32_t st_x[Q][POOL_CAP];
-  __shared__ T st_d[Q][POOL_CAP];
+  constexpr int Q = PQ, SEG = 64 / PQ;
+  constexpr int CAPW = PQ == POOL_Q ? POOL_CAPW : 832 / PQ, CAP = CAPW + BVHD_STACK + 8;
+  __shared__ uint32_t st_x[Q][CAP];
+  __shared__ T st_d[Q][CAP];
   __shared__ T q_rt[Q][12];   // RT_R (row-major), RT_T of the slot's query
   __shared__ T q_wit[Q][6];   // witness points of the slot's minimum, model-1 frame
   __shared__ int q_fb[Q][2];
@@ -518,7 +522,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
   __shared__ uint32_t l_x[64];  // the triangle pairs evaluated in this trip (at most one per lane): the entry's info word ...
   __shared__ uint8_t l_q[64];   // ... and its slot
   __shared__ T l_val[64];
-  constexpr int E = POOL_E, WIN = POOL_WIN;
+  constexpr int E = POOL_E, WIN = SEG * E;
   const int lane = threadIdx.x, q = lane / SEG, j = lane % SEG;
   const uint64_t lt_mask = (uint64_t(1) << lane) - 1;
   const uint64_t segm = (SEG == 64 ? ~uint64_t(0) : ((uint64_t(1) << SEG) - 1)) << (q * SEG);
@@ -593,7 +597,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
     if (__ballot(active) == 0) break;  // (only once the records have run out)
     POOL_T(4);
     // ---- the windows: lane j of a slot holds entries j * E ... j * E + E - 1 from the top of the slot's stack
-    const int w = active ? min(WIN, min(sp, max(POOL_CAPW - sp, 1))) : 0;
+    const int w = active ? min(WIN, min(sp, max(CAPW - sp, 1))) : 0;
     const int base_i = sp - w;
     uint32_t x[E];
     T db[E];
@@ -850,12 +854,14 @@ void launch_bvh_distance(int grid, hipStream_t st, const Work& wk, const LibView
     hipLaunchKernelGGL((k_bvh_distance<T, true>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q, spill);
   } else {
     hipLaunchKernelGGL((k_bvh_distance<T, false>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q, spill);
-    const int cgrid = std::max(1, std::min(grid * BVHD_BLOCK, int(spill.max_blocks)));  // a wave per suspended walk, up to what the chip holds
+    const int cgrid = std::max(1, int(std::min<uint32_t>(wk.n, spill.max_blocks)));  // a wave per suspended walk, up to what the chip holds
     // the pool: a wave per POOL_Q walks, up to what the chip holds (`grid` is the lanes' grid, a block of BVHD_BLOCK queries each:
     // with it a 100k-query batch started 1 563 of the 2 048 waves the chip holds -- 30.5 ms instead of 25.4, profiles/r04_h)
-    const int pgrid = std::max(1, std::min((grid * BVHD_BLOCK + POOL_Q - 1) / POOL_Q, int(spill.max_blocks)));
-    if (spill.budget && spill.pool)
-      hipLaunchKernelGGL((k_bvh_distance_pool<T>), dim3(pgrid), dim3(64), 0, st, wk, lv, bv, io, spill);
+    const int n_est = int(std::min<uint32_t>(wk.n, 0x7FFFFFFFu));  // pairs of the batch (the lanes' grid is capped, hfcl_host.hip: blocks_for)
+    if (spill.budget && spill.pool && n_est > POOL_BIG_BATCH)
+      hipLaunchKernelGGL((k_bvh_distance_pool<T, 8>), dim3(std::max(1, std::min((n_est + 7) / 8, int(spill.max_blocks)))), dim3(64), 0, st, wk, lv, bv, io, spill);
+    else if (spill.budget && spill.pool)
+      hipLaunchKernelGGL((k_bvh_distance_pool<T, POOL_Q>), dim3(std::max(1, std::min((n_est + POOL_Q - 1) / POOL_Q, int(spill.max_blocks)))), dim3(64), 0, st, wk, lv, bv, io, spill);
     else if (spill.budget)
       hipLaunchKernelGGL((k_bvh_distance_coop<T>), dim3(cgrid), dim3(64), 0, st, wk, lv, bv, io, spill);
   }
