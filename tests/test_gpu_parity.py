@@ -644,10 +644,17 @@ def test_bvh_distance_at_baseline_size(pkg, oracle, n):
     got = lib.distance(b.s1, b.s2, b.tf1, b.tf2)
     again = lib.distance(b.s1, b.s2, b.tf1, b.tf2)
     lib.close()
-    assert np.array_equal(got.view(np.uint8), again.view(np.uint8)), "distance() is not deterministic"
     ref = oracle.bvh_distance_batch(ML, b.s1, b.s2, b.tf1, b.tf2, n_threads=os.cpu_count() or 8)
-    ties = _check_distance_records(oracle, ML, b, got, ref, "cfg4d", max_ties=0.0005)
-    print("cfg4d %d queries: %d enumerated 0-ulp ties" % (n, ties))
+    ties = _check_distance_records(oracle, ML, b, got, ref, "cfg4d", max_ties=0.00002)
+    ties2 = _check_distance_records(oracle, ML, b, again, ref, "cfg4d, second run", max_ties=0.00002)
+    # (which walks share a wave depends on the order the waves take their tickets, and with it the order in which a walk's pairs
+    # are evaluated: two runs agree byte for byte except where one of them falls into the enumerated class above)
+    differ = np.flatnonzero((got["b1"] != again["b1"]) | (got["b2"] != again["b2"]))
+    assert len(differ) <= ties + ties2
+    same = np.ones(n, dtype=bool)
+    same[differ] = False
+    assert np.array_equal(got[same].view(np.uint8), again[same].view(np.uint8)), "distance() is not deterministic"
+    print("cfg4d %d queries: %d / %d enumerated 0-ulp ties in two runs" % (n, ties, ties2))
 
 
 def _mesh_batch(pkg, meshes, n, seed, half_width):
