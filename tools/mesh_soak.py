@@ -31,7 +31,7 @@ def run(pkg, b, kind, env):
         lib.close()
 
 
-def compare(a, c, kind):
+def compare(a, c, kind, exact=False):
     """-> (queries whose decision / triangle ids differ, max |distance difference|, queries with another triangle at the same distance)"""
     fin = (np.abs(a["distance"]) < 1e300) & (np.abs(c["distance"]) < 1e300)
     dd = float(np.abs(a["distance"][fin] - c["distance"][fin]).max()) if fin.any() else 0.0
@@ -39,7 +39,12 @@ def compare(a, c, kind):
     ids = (a["b1"] != c["b1"]) | (a["b2"] != c["b2"])
     if kind == "collide":
         return int((hard | ids).sum()), dd, 0
-    tie = ids & (np.abs(a["distance"] - c["distance"]) < 1e-12)  # distance(): tied triangles, an ulp apart between two inlined leaves
+    if exact:
+        # mesh x mesh distance() (round 4: its unit is built without contraction): the distances of the two forms agree to 0 ulp; another
+        # triangle pair may be reported only AT that distance (the enumerated class of tests/test_gpu_parity.py: _check_distance_records)
+        tie = ids & (a["distance"] == c["distance"])
+        return int((hard | (ids & ~tie) | (a["distance"] != c["distance"])).sum()), dd, int(tie.sum())
+    tie = ids & (np.abs(a["distance"] - c["distance"]) < 1e-12)  # mesh x solid distance(): tied triangles, an ulp apart between two inlined leaves
     return int((hard | (ids & ~tie)).sum()), dd, int(tie.sum())
 
 
@@ -64,7 +69,7 @@ def main():
         for s in range(a.seeds):
             b = gen(s)
             r0, r1 = run(pkg, b, kind, {}), run(pkg, b, kind, env)
-            nb, dd, nt = compare(r0, r1, kind)
+            nb, dd, nt = compare(r0, r1, kind, exact=name == "mesh x mesh distance")
             tot += len(b)
             bad += nb
             ties += nt
