@@ -122,7 +122,9 @@ struct hfcl_lib {
   uint32_t bvhd_pool_leaf_min = 24, bvhd_pool_starve = 32, bvhd_pool_part_min = 48;  // HFCL_BVHD_LEAF_MIN / HFCL_BVHD_STARVE / HFCL_BVHD_PART_MIN
   void* d_dist_susp = nullptr;    // DistSusp<double>[dist_susp_capacity]
   size_t dist_susp_capacity = 0;
-  uint32_t shape_dist_budget = 256;  // HFCL_SHAPE_DIST_BUDGET: the same for mesh x solid (a GJK leaf counts 16 steps; k_bvh_shape_distance_coop)
+  uint32_t shape_dist_pool = 1;     // HFCL_SHAPE_DIST_POOL: mesh x solid distance() walks past the budget continue in k_bvh_shape_distance_pool (0: k_bvh_shape_distance_coop)
+  uint32_t shape_dist_leaf_min = 48, shape_dist_starve = 16;  // HFCL_SHAPE_DIST_LEAF_MIN / HFCL_SHAPE_DIST_STARVE (a GJK pass is worth waiting for: profiles/r04_i)
+  uint32_t shape_dist_budget = 64;  // HFCL_SHAPE_DIST_BUDGET: the same for mesh x solid (a GJK leaf counts 16 steps; k_bvh_shape_distance_coop)
   void* d_shape_dist_susp = nullptr;
   size_t shape_dist_susp_capacity = 0;
   // host-call staging: PIPE_SLOTS device buffer sets of `st_capacity` pairs each (a chunk of a host batch), three streams
@@ -166,6 +168,8 @@ struct hfcl_lib {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool kernel_timing = true;         // HIP events around every kernel (hfcl_lib_set_kernel_timing)
   uint32_t possible_buckets = ~0u;   // bit b: some pair of this library's shape kinds classifies into bucket b
+  bool has_flats = true;             // some shape is a Plane / Halfspace: their "very rough" volumes are no lower bounds, so what a mesh walk
+                                     // against them reports depends on the ORDER of its visits -- the ordered continuation, not the pool
   bool has_curved = true;            // some shape is an Ellipsoid / Cone / Cylinder: the curved class of the fp64 EPA tiers can occur
   int cvx_w = 0;  // 0 = per kernel (auto_cvx_w); HFCL_CVX_W forces one width for all
   bool closed_staged = true;  // HFCL_CLOSED_STAGED=0: A/B switch back to the direct-access k_closed<double>
@@ -391,6 +395,7 @@ static bool upload_shapes(hfcl_lib* lib, const hfcl_shape* shapes, size_t n_shap
           if (present[b]) mask |= 1u << bucket_of(a, b);
     lib->possible_buckets = mask;
     lib->has_curved = present[K_ELLIPSOID] || present[K_CONE] || present[K_CYLINDER];
+    lib->has_flats = present[K_PLANE] || present[K_HALFSPACE];
   }
   lib->h_kinds = kinds;
   std::vector<float> v32(3 * n_vertices + 3);
@@ -447,6 +452,9 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_BVH_COOP")) lib->bvh_coop = atoi(v) != 0;
   if (const char* v = getenv("HFCL_BVHD_BUDGET")) lib->bvhd_budget = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVHD_POOL")) lib->bvhd_pool = uint32_t(std::max(0, atoi(v)));
+  if (const char* v = getenv("HFCL_SHAPE_DIST_POOL")) lib->shape_dist_pool = uint32_t(std::max(0, atoi(v)));
+  if (const char* v = getenv("HFCL_SHAPE_DIST_LEAF_MIN")) lib->shape_dist_leaf_min = uint32_t(std::max(1, atoi(v)));
+  if (const char* v = getenv("HFCL_SHAPE_DIST_STARVE")) lib->shape_dist_starve = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVHD_LEAF_MIN")) lib->bvhd_pool_leaf_min = uint32_t(std::max(1, atoi(v)));
   if (const char* v = getenv("HFCL_BVHD_STARVE")) lib->bvhd_pool_starve = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVHD_PART_MIN")) lib->bvhd_pool_part_min = uint32_t(std::max(0, atoi(v)));
@@ -1230,6 +1238,10 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
           ss.susp_count = lib->d_counts + CTR_SHAPE_DIST_SUSP;
           ss.budget = lib->shape_dist_budget;
           ss.max_blocks = uint32_t(lib->n_cus) * 8u;
+          ss.pool = lib->has_flats ? 0u : lib->shape_dist_pool;
+          ss.pool_ticket = lib->d_counts + CTR_SHAPE_DIST_TICKET;
+          ss.pool_leaf_min = lib->shape_dist_leaf_min;
+          ss.pool_starve = lib->shape_dist_starve;
         }
         launch_bvh_shape_distance_fast<T>(blocks_for(n, BVHD_BLOCK), blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, ss);
       }
@@ -1296,6 +1308,7 @@ static void share_tables(hfcl_lib* h, const hfcl_lib* lib) {
   h->d_kinds = lib->d_kinds;
   h->possible_buckets = lib->possible_buckets;
   h->has_curved = lib->has_curved;
+  h->has_flats = lib->has_flats;
   h->d_graph_base = lib->d_graph_base;
   h->d_graph_off = lib->d_graph_off;
   h->d_graph_ent32 = lib->d_graph_ent32;

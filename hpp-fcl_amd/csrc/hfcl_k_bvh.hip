@@ -1951,6 +1951,258 @@ k_bvh_shape_distance_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_bvh_shape_distance_pool: the long mesh x solid distance() walks with the scheme of k_bvh_distance_pool (hfcl_k_bvhd.hip, round 4):
+// SDP_Q walks per wave, each with its stack in LDS in DFS order; the child tests of every mesh node that is split go into one list for
+// the wave, worked off 64 at a time (one rss_lower_bound per lane against the walk's solid, on the packed DNodeD records); the
+// triangles of the wave's windows are evaluated together, one GJK run per lane, whichever walk they belong to; a marker per walk
+// (entries that stand behind the triangle of the minimum) keeps the reference's choice among equal distances whatever the order of
+// the evaluations.  What this row adds to the mesh x mesh form: a triangle inside the solid (its leaf asks for EPA) ends the walk at
+// its turn, so the FIRST such triangle in DFS order is the walk's result -- it ranks below every distance, ties by DFS order --, the
+// entries behind it are dropped, the ones in front are finished (they may hold an earlier one), and when the stack is empty its
+// lane runs the leaf once more to queue the EPA item (k_bvh_shape_finish writes the record), as k_bvh_shape_distance_coop does.
+// Suspended walks never hand a cached guess on and their final guess is not read (the host does not suspend those).
+// ---------------------------------------------------------------------------------------
+constexpr int SDP_Q = 4, SDP_SEG = 64 / SDP_Q, SDP_CAPW = 160, SDP_CAP = SDP_CAPW + BVHD_STACK + 8;
+template <typename T>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
+k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhSpill spill) {
+  constexpr int Q = SDP_Q, SEG = SDP_SEG;
+  __shared__ uint32_t st_x[Q][SDP_CAP];  // bit 31: a triangle (bits 0-30 its id); else a mesh node whose first child is bits 0-30
+  __shared__ T st_d[Q][SDP_CAP];
+  __shared__ T q_tf[Q][12];    // pose of the mesh (R rows, t): the R0, T0 of the bound
+  __shared__ T q_rss[Q][15];   // the solid's RSS in the mesh frame's terms (RssQuery): axes, Tr, l0, l1, r
+  __shared__ uint32_t q_ids[Q][6];  // pair, solid id, swapped, vert_off, tri_off, node_off
+  __shared__ uint32_t t_node[128], t_x[128];
+  __shared__ uint8_t t_q[128];
+  __shared__ T t_res[128];
+  __shared__ T w0_slab[W0Lds<T, 64>::WORDS];
+  const W0Lds<T, 64> leaf_ps{w0_slab + threadIdx.x};
+  const int lane = threadIdx.x, qs = lane / SEG, j = lane % SEG;
+  const uint64_t lt_mask = (uint64_t(1) << lane) - 1;
+  const uint64_t segm = ((uint64_t(1) << SEG) - 1) << (qs * SEG);
+  const uint64_t deeper = segm & ~((uint64_t(2) << lane) - 1);
+  const uint32_t n_susp = *spill.susp_count;
+  const RssQuery<T>* const table = reinterpret_cast<const RssQuery<T>*>(wk.shape_oq);
+  const int leaf_min = int(spill.pool_leaf_min), starve = int(spill.pool_starve);
+  const T big = Lim<T>::max();
+  auto sync = []() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  // slot state, identical in the SEG lanes of a slot
+  // `ended`: a triangle that ENDS the sequential walk at its turn has been found (p marks it): it asks for EPA (ended_epa), or its
+  // leaf reported a negative distance without EPA (a closed form) while its bound is a number -- bounds are clamped at 0, so behind
+  // such a triangle every bounded entry is skipped: the walk's result is the FIRST such triangle in DFS order, not the smallest value
+  bool active = false, exhausted = false, ended = false, ended_epa = false, overflow = false;
+  int sp = 0, p = 0, fb1 = -1, end_prim = -1;
+  T mind = big, end_val = T(0);
+  uint32_t pair = 0;
+  for (;;) {
+    const uint64_t idle = __ballot(!active && j == 0);
+    if (idle && !exhausted) {
+      const int n_need = __popcll(idle);
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(spill.pool_ticket, uint32_t(n_need));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base + uint32_t(n_need) >= n_susp) exhausted = true;
+      const uint32_t it = base + uint32_t(__popcll(idle & ((uint64_t(1) << (qs * SEG)) - 1)));
+      if (!active && it < n_susp) {
+        const ShapeDistSusp<T>* const r = reinterpret_cast<const ShapeDistSusp<T>*>(spill.susp) + it;
+        pair = r->pair;
+        const uint32_t id1 = wk.shape1[pair], id2 = wk.shape2[pair];
+        const bool swapped = lib.kinds[id1] != uint8_t(K_BVH);
+        const DMesh m1 = bv.meshes[lib.shapes[swapped ? id2 : id1].bvh_index];
+        sp = int(r->sp);
+        p = sp;  // everything on the stack comes after what the lane has visited
+        mind = r->mind;
+        fb1 = r->fb1;
+        ended = ended_epa = false;
+        end_prim = -1;
+        overflow = false;
+        // (not vectorised: hipcc 7.2's instruction selection dies on the masked gather the loop vectoriser makes of this loop)
+#pragma clang loop vectorize(disable) interleave(disable)
+        for (int k = j; k < sp; k += SEG) {
+          const uint32_t b = r->entry[k];
+          const int32_t fc = bv.dnodes[m1.node_off + b].first_child;
+          st_x[qs][k] = fc < 0 ? (0x80000000u | uint32_t(-(fc + 1))) : uint32_t(fc);
+          st_d[qs][k] = r->bound[k];
+        }
+        if (j == 0) {
+          const Pose<T> tfm = load_pose(swapped ? io.tf2 : io.tf1, pair);
+          T* o = q_tf[qs];
+          o[0] = tfm.R.r0.x; o[1] = tfm.R.r0.y; o[2] = tfm.R.r0.z; o[3] = tfm.R.r1.x; o[4] = tfm.R.r1.y; o[5] = tfm.R.r1.z;
+          o[6] = tfm.R.r2.x; o[7] = tfm.R.r2.y; o[8] = tfm.R.r2.z; o[9] = tfm.t.x; o[10] = tfm.t.y; o[11] = tfm.t.z;
+          const RssQuery<T> rq = table[pair];
+          T* g = q_rss[qs];
+          g[0] = rq.axes.r0.x; g[1] = rq.axes.r0.y; g[2] = rq.axes.r0.z; g[3] = rq.axes.r1.x; g[4] = rq.axes.r1.y; g[5] = rq.axes.r1.z;
+          g[6] = rq.axes.r2.x; g[7] = rq.axes.r2.y; g[8] = rq.axes.r2.z; g[9] = rq.Tr.x; g[10] = rq.Tr.y; g[11] = rq.Tr.z;
+          g[12] = rq.l0; g[13] = rq.l1; g[14] = rq.r;
+          uint32_t* c = q_ids[qs];
+          c[0] = pair; c[1] = swapped ? id1 : id2; c[2] = swapped ? 1u : 0u; c[3] = m1.vert_off; c[4] = m1.tri_off; c[5] = m1.node_off;
+        }
+        active = true;
+      }
+      sync();
+    }
+    if (__ballot(active) == 0) break;
+    // ---- the windows
+    const int w = active ? min(SEG, min(sp, max(SDP_CAPW - sp, 1))) : 0;
+    const int base_i = sp - w;
+    const bool act = j < w;
+    const int idx = sp - 1 - j;
+    uint32_t x = 0u;
+    T db = big;
+    if (act) {
+      x = st_x[qs][idx];
+      db = st_d[qs][idx];
+    }
+    // behind a triangle that ends the walk nothing is visited; else canStop(bound) with the slot's minimum: behind the triangle of
+    // the minimum the sequential walk's test, in front of it a tie is kept (k_bvh_distance_pool; NaN bounds never skip)
+    const bool alive = act && !(ended && idx < p) && !(db >= T(0) && (idx < p && !ended ? db >= mind : db > mind));
+    const bool is_leaf = alive && (x >> 31) != 0u, split = alive && (x >> 31) == 0u;
+    // ---- the children's bounds of every split node of the wave in one list
+    const uint64_t smask = __ballot(split);
+    const int ns = __popcll(smask), k2 = 2 * __popcll(smask & lt_mask);
+    if (split) {
+      t_node[k2] = x;
+      t_node[k2 + 1] = x + 1u;
+      t_q[k2] = uint8_t(qs);
+      t_q[k2 + 1] = uint8_t(qs);
+    }
+    sync();
+    for (int tb = 0; tb < 2 * ns; tb += 64) {
+      const int t = tb + lane;
+      if (t < 2 * ns) {
+        const uint32_t ts = t_q[t];
+        const T* const f = q_tf[ts];
+        const T* const g = q_rss[ts];
+        M3<T> R0;
+        R0.r0 = mk<T>(f[0], f[1], f[2]);
+        R0.r1 = mk<T>(f[3], f[4], f[5]);
+        R0.r2 = mk<T>(f[6], f[7], f[8]);
+        const V3<T> T0 = mk<T>(f[9], f[10], f[11]);
+        DNodeD<T> S;
+        S.axes.r0 = mk<T>(g[0], g[1], g[2]);
+        S.axes.r1 = mk<T>(g[3], g[4], g[5]);
+        S.axes.r2 = mk<T>(g[6], g[7], g[8]);
+        S.Tr = mk<T>(g[9], g[10], g[11]);
+        S.l0 = g[12];
+        S.l1 = g[13];
+        S.r = g[14];
+        const DNodeD<T> M = bv.dnodes[q_ids[ts][5] + t_node[t]];
+        t_res[t] = rss_lower_bound(R0, T0, S, M);
+        t_x[t] = M.first_child < 0 ? (0x80000000u | uint32_t(-(M.first_child + 1))) : uint32_t(M.first_child);
+      }
+    }
+    sync();
+    T d1 = big, d2 = big;
+    uint32_t xa = 0u, xc = 0u;
+    if (split) {
+      d1 = t_res[k2];
+      d2 = t_res[k2 + 1];
+      xa = t_x[k2];
+      xc = t_x[k2 + 1];
+    }
+    // ---- the triangles, once they are worth a pass (one GJK run per lane)
+    const int nl = __popcll(__ballot(is_leaf));
+    const bool do_leaves = nl > 0 && (nl >= leaf_min || 2 * ns < starve);
+    int jw = -1;
+    if (do_leaves) {
+      T val = big;
+      bool to_epa = false;
+      SolidLeafOut<T> lo;
+      lo.distance = big;
+      const uint32_t prim = x & 0x7FFFFFFFu;
+      if (is_leaf) {
+        const uint32_t* c = q_ids[qs];
+        const bool swapped = c[2] != 0u;
+        SolidLeafIn<T> in{bv.verts + 3 * size_t(c[3]), bv.tris + 3 * size_t(c[4] + prim), lib.shapes, lib.verts,
+                          swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, nullptr, nullptr, 0u, pair, c[1], prim, 0xFFFFFFFFu, 0u, T(0), -1};
+        to_epa = solid_leaf_call<T>(in, &q, leaf_ps, initial_guess<T>(io, q, pair), &lo);
+        if (!to_epa) val = lo.distance;
+      }
+      // the slot's best candidate: a triangle that ends the walk before any distance (the first of them in DFS order), else the
+      // smaller distance, the first in DFS order among equals; against the standing result a tie wins only in front of it
+      const bool ends = is_leaf && (to_epa || (val < T(0) && db >= T(0)));
+      const bool cand = is_leaf && (ends ? (!ended || idx >= p) : (!ended && (val < mind || (val == mind && idx >= p))));
+      T bestv = cand ? (ends ? -big : val) : big;
+      int bj = cand ? j : 64;
+#pragma unroll
+      for (int m = 1; m < SEG; m <<= 1) {
+        const T ov = __shfl_xor(bestv, m);
+        const int oj = __shfl_xor(bj, m);
+        if (oj < 64 && (bj == 64 || ov < bestv || (ov == bestv && oj < bj))) {
+          bestv = ov;
+          bj = oj;
+        }
+      }
+      if (bj < 64) {
+        jw = bj;
+        const int src = qs * SEG + bj;
+        const bool w_ends = __shfl(int(ends), src) != 0, w_epa = __shfl(int(to_epa), src) != 0;
+        const int w_prim = __shfl(int(prim), src);
+        const bool swapped = q_ids[qs][2] != 0u;
+        if (w_ends) {
+          ended = true;
+          ended_epa = w_epa;
+          end_prim = w_prim;
+          if (!w_epa) {
+            end_val = __shfl(val, src);
+            if (j == bj) store_witness(io, pair, swapped ? lo.p2 : lo.p1, swapped ? lo.p1 : lo.p2, swapped ? -lo.n : lo.n);
+          }
+        } else {
+          mind = bestv;
+          fb1 = w_prim;
+          if (j == bj) store_witness(io, pair, swapped ? lo.p2 : lo.p1, swapped ? lo.p1 : lo.p2, swapped ? -lo.n : lo.n);
+        }
+      }
+    }
+    // ---- the windows written back, in order
+    const int cnt = split ? 2 : ((is_leaf && !do_leaves) ? 1 : 0);
+    const uint64_t m2b = __ballot(cnt == 2), m1b = __ballot(cnt == 1);
+    const int pos = base_i + 2 * __popcll(m2b & deeper) + __popcll(m1b & deeper);
+    if (cnt == 2) {
+      const bool c_first = d2 < d1;  // the nearer child is visited first
+      st_x[qs][pos] = c_first ? xa : xc;
+      st_d[qs][pos] = c_first ? d1 : d2;
+      st_x[qs][pos + 1] = c_first ? xc : xa;
+      st_d[qs][pos + 1] = c_first ? d2 : d1;
+    } else if (cnt == 1) {
+      st_x[qs][pos] = x;
+      st_d[qs][pos] = db;
+    }
+    const uint64_t later_m = __ballot(act && (jw >= 0 ? j > jw : idx < p)) & segm;
+    p = (jw >= 0 ? base_i : min(p, base_i)) + 2 * __popcll(m2b & later_m) + __popcll(m1b & later_m);
+    sp = base_i + 2 * __popcll(m2b & segm) + __popcll(m1b & segm);
+    if (sp > SDP_CAP - 2) {
+      overflow = true;
+      sp = 0;
+    }
+    sync();
+    if (active && sp == 0) {  // this walk is over
+      if (j == 0) {
+        if (ended && ended_epa && !overflow) {
+          // the triangle that ended the walk: its leaf once more, with the EPA item (k_bvh_shape_finish writes the record)
+          const uint32_t* c = q_ids[qs];
+          const bool swapped = c[2] != 0u;
+          SolidLeafIn<T> in{bv.verts + 3 * size_t(c[3]), bv.tris + 3 * size_t(c[4] + uint32_t(end_prim)), lib.shapes, lib.verts,
+                            swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer),
+                            &wk.counts[CTR_SHAPE_DEFER], wk.shape_defer_cap, pair, c[1], uint32_t(end_prim), 0xFFFFFFFFu, 0u, mind, fb1};
+          SolidLeafOut<T> lo;
+          solid_leaf_call<T>(in, &q, leaf_ps, initial_guess<T>(io, q, pair), &lo);
+        } else {
+          // b1 = the triangle, b2 = NONE whatever the operand order (distance.cpp:84-88 swaps o1 / o2 only)
+          const T dist = ended && !overflow ? end_val : mind;
+          store_bvh_record_head(io, pair, dist, dist <= T(0) ? 0x80000000u : 0u, ended && !overflow ? end_prim : fb1, -1, overflow);
+          write_guess<T>(io, pair, initial_guess<T>(io, q, pair), 0, 0);
+        }
+      }
+      active = false;
+    }
+  }
+}
+
 // =======================================================================================
 // launchers (hfcl_launch.hpp)
 // =======================================================================================
@@ -2033,7 +2285,11 @@ template <typename T>
 void launch_bvh_shape_distance_fast(int grid, int grid_finish, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, BvhSpill spill) {
   hipLaunchKernelGGL((k_shape_obbrss<T>), dim3(std::max(1, grid / 4)), dim3(256), 0, st, wk, lv, io);
   hipLaunchKernelGGL((k_bvh_shape_distance_lane<T>), dim3(grid), dim3(BVHD_BLOCK), 0, st, wk, lv, bv, io, q, spill);
-  if (spill.budget) hipLaunchKernelGGL((k_bvh_shape_distance_coop<T>), dim3(std::max(1, std::min(grid * BVHD_BLOCK, int(spill.max_blocks)))), dim3(64), 0, st, wk, lv, bv, io, q, spill);
+  const int n_est = int(std::min<uint32_t>(wk.n, 0x7FFFFFFFu));
+  if (spill.budget && spill.pool)
+    hipLaunchKernelGGL((k_bvh_shape_distance_pool<T>), dim3(std::max(1, std::min((n_est + SDP_Q - 1) / SDP_Q, int(spill.max_blocks)))), dim3(64), 0, st, wk, lv, bv, io, q, spill);
+  else if (spill.budget)
+    hipLaunchKernelGGL((k_bvh_shape_distance_coop<T>), dim3(std::max(1, std::min(n_est, int(spill.max_blocks)))), dim3(64), 0, st, wk, lv, bv, io, q, spill);
   BvhSplit none;
   memset(&none, 0, sizeof(none));
   BvhParams bp;
