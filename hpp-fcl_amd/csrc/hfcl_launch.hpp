@@ -10,13 +10,18 @@
 //                    k_gjk_large<T>   GJK when a hull has more than 32 vertices (scan / hill-climb from memory)
 //                    k_unsupported<T>, k_fill_skipped
 //   hfcl_k_epa.hip   k_epa<T,WE,CAP,TIER>, k_epa_stream<T,WE,CAP>   EPA on the pairs GJK left in `Collision`
-//   hfcl_k_bvh.hip   k_bvh_collide<T> / k_bvh_distance<T>   BVHModel<OBBRSS> x BVHModel<OBBRSS>, one query per lane for a step
-//                                     budget; k_bvh_coop<T> / k_bvh_distance_coop<T>: the queries past it, a wave each,
-//                                     64 stack entries per trip (k_bvh_combine<T>: the task-level alternative)
+//   hfcl_k_bvh.hip   k_bvh_collide<T>   BVHModel<OBBRSS> x BVHModel<OBBRSS> collide(), one query per lane for a step budget;
+//                                     k_bvh_coop<T>: the queries past it, a wave each, 64 stack entries per trip
+//                                     (k_bvh_combine<T>: the task-level alternative)
+//   hfcl_k_bvhd.hip  k_bvh_distance<T>  ... distance(), one query per lane for a step budget (this unit is built without
+//                                     contraction: triangle ids equal to the reference's); k_bvh_distance_pool<T, PQ>: the walks past
+//                                     it, PQ per wave, their box and triangle tests pooled, DFS order kept by a marker
+//                                     (k_bvh_distance_coop<T>: the ordered wave-per-walk form)
 //                    k_shape_obb<T>, k_bvh_collide<T, ., ., SOLID>, k_bvh_shape_coop<T>, k_bvh_shape_finish<T>
 //                                     BVHModel<OBBRSS> x convex solid, first-contact collide(): the solids' OBBs, the walk
 //                                     (lane, then wave), the leaves that need EPA
-//                    k_shape_obbrss<T>, k_bvh_shape_distance_lane<T>, k_bvh_shape_distance_coop<T>   ... distance()
+//                    k_shape_obbrss<T>, k_bvh_shape_distance_lane<T>, k_bvh_shape_distance_pool<T>   ... distance()
+//                                     (k_bvh_shape_distance_coop<T>: the ordered form, libraries with a Plane / Halfspace)
 //                    k_bvh_shape<T> / k_bvh_shape_distance<T>   the same rows, one 16-lane group per query: requests that
 //                                     keep walking after a contact, models deeper than the lanes' stacks
 //                    k_triangle<T>    top-level TriangleP pairs
