@@ -660,7 +660,7 @@ struct BvhSum {  // what a unit (query or task) knows when it ends or suspends
   uint32_t contact_order, parent, order, pad_;
 };
 // counters of a split traversal (device words)
-enum { BVH_CTR_TASKS = 0, BVH_CTR_SUSPENDED = 1, BVH_CTR_LEVEL0 = 2 /* [2 + k] = number of tasks made before level k ended */, BVH_CTR_WORDS = 16 };
+enum { BVH_CTR_TASKS = 0, BVH_CTR_SUSPENDED = 1, BVH_CTR_LEVEL0 = 2 /* [2 + k] = number of tasks made before level k ended */, BVH_CTR_CUT = 15 /* words of BvhSplit::cut_words in use */, BVH_CTR_WORDS = 16 };
 struct BvhSplit {
   BvhTask* tasks;       // task table (cap entries)
   void* sums;           // BvhSum<T>[n_queries + cap]: suspended queries first, then one per task
@@ -674,7 +674,16 @@ struct BvhSplit {
   uint32_t leaf_cost;   // SOLID form: steps a GJK leaf counts for (a closed-form leaf: an eighth of it)
   uint32_t coop;        // suspended queries are continued by k_bvh_shape_coop / k_bvh_coop (a lane group per query) instead of task levels
   uint32_t coop_grid;   // ... blocks of that kernel (0: the launcher's choice)
+  // A walk one of those kernels has worked on for `cut_ticks` clock ticks is CUT: its stack, in chunks of COOP_CHUNK entries, becomes
+  // tasks for the next launch of the same kernel (a chunk task's `entry` is the index of its first word in cut_words, its `order`
+  // carries the number of its entries in the high half), its state a summary, and k_bvh_combine folds the chunks' summaries back in
+  // DFS order as it does for k_bvh_collide's task levels.  0: never (the walk stays with its wave to the end).
+  uint32_t cut_ticks;
+  uint32_t cut_cap;     // words of cut_words (and values of cut_vals)
+  uint32_t* cut_words;  // stack entries of the cut walks
+  void* cut_vals;       // T[cut_cap]: what is known about them (k_bvh_shape_coop's tagged entries: a box's bound, a triangle's distance)
 };
+constexpr int COOP_CHUNK = 16;
 // Step budget per unit (the compile-time default; without HFCL_BVH_* in the environment the host chooses per batch, see
 // hfcl_lib::bvh_auto).  0: units only suspend when their LDS stack is full -- the task mechanism is then the overflow path
 // of deep traversals and costs nothing otherwise.  One budget for all levels does not pay (profiles/r02_k: cfg4 7.3 ms

@@ -109,6 +109,13 @@ struct hfcl_lib {
   // (HFCL_SHAPE_COOP=0: the levels); the queries' own budget is then 16 steps (100k queries per kind, budgets 8 / 16 / 32 / 128:
   // sphere 2.0 / 2.0 / 2.4 / 2.6 ms, ellipsoid 7.5 / 8.1 / 8.4 / 8.3, box 1.4 / 1.3 / 1.2 / 1.1; profiles/r03_i)
   bool shape_coop = true;
+  // ... and a walk such a kernel has worked on for this many clock ticks is cut into chunk tasks for its next launch (BvhSplit::cut_ticks;
+  // HFCL_BVH_CUT_TICKS / HFCL_SHAPE_CUT_TICKS; 0: never).  The records equal the uncut walks' in every field wherever the cuts fall
+  // (tools/cut_check.py).  mesh x solid, 600 000 ticks (~2.3x the mean walk): 100k mixed queries 4.4 -> 3.7 ms on one box, the single
+  // kinds within +-5 %; shorter budgets lose (200 000: 3.5 against 3.3 at 400 000, 100 000: 6.8 ms -- every cut walks the chunks
+  // behind a contact for nothing and pays three launches).  mesh x mesh: off -- its waves are busy 79 % of the kernel's time already
+  // and cfg4 went 2.97 -> 3.18 ms (profiles/r04_j)
+  uint32_t bvh_cut_ticks = 0, shape_cut_ticks = 600000;
   uint32_t shape_budget0_coop = 16;
   // Mesh x mesh queries past their step budget are continued by k_bvh_coop (a wave per query, 64 stack entries per trip)
   // instead of task levels (HFCL_BVH_COOP=0: the levels).  cfg4, budgets 160 / 192 / 256 / 320 / 384: 100k queries 3.82 / 3.53 /
@@ -203,6 +210,8 @@ struct hfcl_lib {
   size_t bvh_slab_bytes = 0;
   // split mesh x mesh traversals (BvhSplit): task table, unit summaries, suspended-query list, counters
   BvhTask* d_bvh_tasks = nullptr;
+  uint32_t* d_bvh_cut_words = nullptr;  // BvhSplit::cut_words / cut_vals (bvh_split_cap entries each)
+  double* d_bvh_cut_vals = nullptr;
   void* d_bvh_sums = nullptr;
   uint32_t* d_bvh_susp = nullptr;
   uint32_t* d_bvh_ctr = nullptr;
@@ -449,6 +458,8 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_BVH_FILTER")) lib->bvh_filter = atoi(v) != 0;
   if (const char* v = getenv("HFCL_BVH_SHAPE_LANE")) lib->bvh_shape_lane = atoi(v) != 0;
   if (const char* v = getenv("HFCL_SHAPE_COOP")) lib->shape_coop = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_BVH_CUT_TICKS")) lib->bvh_cut_ticks = uint32_t(strtoul(v, nullptr, 10));
+  if (const char* v = getenv("HFCL_SHAPE_CUT_TICKS")) lib->shape_cut_ticks = uint32_t(strtoul(v, nullptr, 10));
   if (const char* v = getenv("HFCL_BVH_COOP")) lib->bvh_coop = atoi(v) != 0;
   if (const char* v = getenv("HFCL_BVHD_BUDGET")) lib->bvhd_budget = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVHD_POOL")) lib->bvhd_pool = uint32_t(std::max(0, atoi(v)));
@@ -545,6 +556,8 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_contacts);
   hipFree(lib->d_contacts_count);
   hipFree(lib->d_bvh_tasks);
+  hipFree(lib->d_bvh_cut_words);
+  hipFree(lib->d_bvh_cut_vals);
   hipFree(lib->d_bvh_slab);
   hipFree(lib->d_bvh_sums);
   hipFree(lib->d_bvh_susp);
@@ -714,14 +727,16 @@ static int ensure_workspace(hfcl_lib* lib, size_t n, bool need_epa) {
 // with a stack of ~20 entries, one query in five is long; mesh x solid walks are cut finer) -- ~2.4 KB of device memory per query in fp64.
 static int ensure_bvh_split(hfcl_lib* lib, size_t n) {
   if (n <= lib->bvh_split_n) return HFCL_OK;
-  hipFree(lib->d_bvh_tasks); hipFree(lib->d_bvh_sums); hipFree(lib->d_bvh_susp);
-  lib->d_bvh_tasks = nullptr; lib->d_bvh_sums = nullptr; lib->d_bvh_susp = nullptr;
+  hipFree(lib->d_bvh_tasks); hipFree(lib->d_bvh_sums); hipFree(lib->d_bvh_susp); hipFree(lib->d_bvh_cut_words); hipFree(lib->d_bvh_cut_vals);
+  lib->d_bvh_tasks = nullptr; lib->d_bvh_sums = nullptr; lib->d_bvh_susp = nullptr; lib->d_bvh_cut_words = nullptr; lib->d_bvh_cut_vals = nullptr;
   lib->bvh_split_n = 0;
   size_t per_query = 16;
   if (const char* e = getenv("HFCL_BVH_TASK_SLOTS")) per_query = std::max<size_t>(1, strtoull(e, nullptr, 10));  // test / tuning knob
   const size_t nq = n + n / 8 + 1024, cap = per_query * nq + 65536;
   HIP_TRY(hipMalloc(&lib->d_bvh_tasks, cap * sizeof(BvhTask)));
   HIP_TRY(hipMalloc(&lib->d_bvh_sums, (nq + cap) * sizeof(BvhSum<double>)));
+  HIP_TRY(hipMalloc(&lib->d_bvh_cut_words, cap * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&lib->d_bvh_cut_vals, cap * sizeof(double)));
   HIP_TRY(hipMalloc(&lib->d_bvh_susp, nq * sizeof(uint32_t)));
   if (!lib->d_bvh_ctr) HIP_TRY(hipMalloc(&lib->d_bvh_ctr, BVH_CTR_WORDS * sizeof(uint32_t)));
   lib->bvh_split_n = nq;
@@ -1159,6 +1174,10 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         split.n_levels = BVH_MAX_LEVELS;
       }
       split.coop_grid = uint32_t(lib->n_cus) * 8u;
+      split.cut_ticks = solid ? lib->shape_cut_ticks : lib->bvh_cut_ticks;
+      split.cut_cap = split.cap;
+      split.cut_words = lib->d_bvh_cut_words;
+      split.cut_vals = lib->d_bvh_cut_vals;
       if (!solid && lib->bvh_coop) {
         split.coop = 1u;
         split.budget0 = lib->bvh_budget0_coop ? lib->bvh_budget0_coop : (n > 500000 ? 640u : 256u);
@@ -1182,6 +1201,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       // one EPA item per unit at most (a contact ends the unit): a query, or -- when suspended walks are cut into task levels
       // instead of being continued by a wave (HFCL_SHAPE_COOP=0) -- every task of the split's table as well
       size_t need = lib->ws_capacity;
+      if (shape_fast && lib->shape_coop && lib->shape_cut_ticks) need = std::max(need, n + n / 2 + 4096);  // (the chunks of a cut walk are units too)
       if (shape_fast && !lib->shape_coop && n >= 256) {
         rc = ensure_bvh_split(lib, n);
         if (rc) return rc;

@@ -842,7 +842,7 @@ __global__ void __launch_bounds__(256) k_bvh_combine(Work wk, IO<T> io, BvhSplit
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
     const uint32_t slot = level ? split.n_queries + unit0 + i : i;
     BvhSum<T> s = *bvh_sum<T>(split, slot);
-    if (level && !(s.flags & BVH_SUM_SUSPENDED)) continue;  // (level 0: the suspended list holds nothing else)
+    if (!(s.flags & BVH_SUM_SUSPENDED)) continue;  // (level 0: a suspended query that k_bvh_coop / k_bvh_shape_coop walked to its end)
     if (level && split.tasks[unit0 + i].entry == 0xFFFFFFFFu) continue;
     bool overflow = (s.flags & BVH_SUM_OVERFLOW) != 0;
     for (uint32_t j = 0; j < s.n_child; ++j) {
@@ -1130,6 +1130,83 @@ constexpr int COOP_CAP = 448, COOP_SLACK = 64;  // entries of a query's stack: a
 #define HFCL_COOP_LEAF_BATCH 64
 #endif
 constexpr uint32_t COOP_NODE = 0x3FFFFFFFu, COOP_DISJOINT = 1u << 30, COOP_LEAF = 2u << 30, COOP_LEAF_EPA = 3u << 30;
+// HFCL_COOP_PROF (variant builds only, tools/build_variant.sh ... k_bvh -DHFCL_COOP_PROF): how long the walks of k_bvh_shape_coop /
+// k_bvh_coop and their waves live, in clock ticks -- [0] longest walk, [1] sum over the walks, [2] walks, [3] longest wave, [4] sum over
+// the waves that had a walk, [5] their number, [6] walks cut -- read back by tools/coop_prof.py through hfcl_debug_coop_prof
+#ifdef HFCL_COOP_PROF
+__device__ unsigned long long coop_prof[16];
+#define COOP_WALK_END(first_lane, t_begin)                                                         \
+  do {                                                                                             \
+    if (first_lane) {                                                                              \
+      const unsigned long long dt_ = __builtin_readcyclecounter() - (t_begin);                     \
+      atomicMax(&coop_prof[0], dt_);                                                               \
+      atomicAdd(&coop_prof[1], dt_);                                                               \
+      atomicAdd(&coop_prof[2], 1ull);                                                              \
+    }                                                                                              \
+  } while (0)
+#define COOP_WAVE_END(t_begin, n_walks)                                                            \
+  do {                                                                                             \
+    if (threadIdx.x == 0 && (n_walks) > 0) {                                                       \
+      const unsigned long long dt_ = __builtin_readcyclecounter() - (t_begin);                     \
+      atomicMax(&coop_prof[3], dt_);                                                               \
+      atomicAdd(&coop_prof[4], dt_);                                                               \
+      atomicAdd(&coop_prof[5], 1ull);                                                              \
+    }                                                                                              \
+  } while (0)
+#define COOP_CUT_COUNT(first_lane)                      \
+  do {                                                  \
+    if (first_lane) atomicAdd(&coop_prof[6], 1ull);     \
+  } while (0)
+extern "C" int hfcl_debug_coop_prof(unsigned long long* out16, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(coop_prof), sizeof(coop_prof)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(coop_prof), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#else
+#define COOP_WALK_END(first_lane, t_begin)
+#define COOP_WAVE_END(t_begin, n_walks)
+#define COOP_CUT_COUNT(first_lane)
+#endif
+// Cutting a long walk (BvhSplit::cut_ticks).  A batch of 100 000 queries used to end with one wave on its longest walk (mesh x solid:
+// 1.7 of the kernel's 2.9 ms, the waves busy 54 % of the time; mesh x mesh: 79 %; profiles/r04_j).  A walk that has had its time is
+// therefore cut: its stack (DFS order, top first) goes to BvhSplit::cut_words / cut_vals as it is -- tags and values included -- in
+// chunks of COOP_CHUNK entries, each chunk a BvhTask of the next launch of the same kernel, whose unit starts from those entries with an
+// empty state and ends with a summary (BvhSum) instead of a record; the cut walk's own state is the summary its chunks hang under, and
+// k_bvh_combine folds them back in DFS order exactly as it folds k_bvh_collide's task levels (bound: a minimum; witness: the last
+// triangle of a chunk that lowered the chunk's own bound, if it also lies below the bound as it stood before the chunk; a contact ends
+// the fold).  A chunk can be cut again (two more launches); where it is cut never changes a record, only when its parts are walked.
+// coop_take_units: the group's next unit -- a suspended query (level 0: its index) or a chunk task of the level.
+template <int W>
+__device__ __forceinline__ uint32_t coop_next_unit(uint32_t* ticket, int lig, int grp) {
+  uint32_t u = 0;
+  if (lig == 0) u = atomicAdd(ticket, 1u);
+  return uint32_t(__shfl(int(u), grp * W));
+}
+// a contact in a chunk ends the walk of every unit above it at that chunk's position (k_bvh_collide: report_contact)
+template <typename T>
+__device__ __forceinline__ void coop_report_contact(const BvhSplit& split, uint32_t p, uint32_t o) {
+  for (int hop = 0; hop < BVH_MAX_LEVELS + 1 && p != 0xFFFFFFFFu; ++hop) {
+    BvhSum<T>* ps = bvh_sum<T>(split, p);
+    atomicMin(&ps->contact_order, o);
+    o = ps->order;
+    p = ps->parent;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void coop_write_sum(const BvhSplit& split, uint32_t slot, T dlb, T rec_dist, T cand_val, const V3<T>& np1, const V3<T>& np2,
+                                               const V3<T>& nn, int fb1, int fb2, uint32_t ncontacts, uint32_t first_child, uint32_t n_child,
+                                               uint32_t flags, uint32_t parent, uint32_t order) {
+  BvhSum<T>* sm = bvh_sum<T>(split, slot);
+  sm->dlb = dlb; sm->rec_dist = rec_dist; sm->cand_val = cand_val;
+  sm->np1 = np1; sm->np2 = np2; sm->nn = nn;
+  sm->fb1 = fb1; sm->fb2 = fb2;
+  sm->ncontacts = ncontacts; sm->first_child = first_child; sm->n_child = n_child; sm->flags = flags;
+  sm->contact_order = 0xFFFFFFFFu; sm->parent = parent; sm->order = order; sm->pad_ = 0;
+}
 template <typename T>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhParams bp, T break_distance2, BvhSplit split) {
@@ -1143,40 +1220,84 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
   T* const value = values[grp];
   const uint64_t gbits = W == 64 ? ~uint64_t(0) : ((uint64_t(1) << (W & 63)) - 1);
   auto gballot = [&](bool x) -> uint64_t { return (__ballot(x) >> (grp * W)) & gbits; };  // the group's lanes, bit 0 = its first lane
-  const uint32_t n_susp = min(split.ctr[BVH_CTR_SUSPENDED], split.n_queries);
+  // the units of this launch: the suspended queries (level 0), or the chunks the launch before cut its long walks into
+  const uint32_t level = split.level;
+  const uint32_t unit0 = level ? min(split.ctr[BVH_CTR_LEVEL0 + level - 1], split.cap) : 0u;
+  const uint32_t n_units = level ? min(split.ctr[BVH_CTR_LEVEL0 + level], split.cap) - unit0 : min(split.ctr[BVH_CTR_SUSPENDED], split.n_queries);
+  const unsigned long long cut_ticks = split.can_suspend ? split.cut_ticks : 0u;
+  uint32_t* const ticket = &wk.counts[CTR_SHAPE_TICKET];  // (k_bvh_collide<SOLID> is through with it; k_bvh_level_mark has reset it)
+  T* const cut_vals = reinterpret_cast<T*>(split.cut_vals);
   const T big = Lim<T>::max();
   // per-group state of the query being walked (uniform over the group's lanes)
-  bool have = false;
-  uint32_t qi = blockIdx.x * G + grp, pair = 0, solid_id = 0, ncontacts = 0;
-  const uint32_t stride = gridDim.x * G;
+  bool have = false, exhausted = false;
+  uint32_t pair = 0, solid_id = 0, ncontacts = 0;
+  uint32_t unit = 0, my_parent = 0xFFFFFFFFu, my_order = 0;  // where the unit hangs (a chunk: the cut walk's summary slot, its place among the chunks)
+  unsigned long long t_begin = 0, t_wave = __builtin_readcyclecounter();
+  unsigned n_walks = 0, trip_no = 0;
+  (void)t_wave; (void)n_walks;
   bool swapped = false, overflow = false;
   DMesh m1 = {0, 0, 0, 0};
   ObbQuery<T> oq;
   oq.M.r0 = oq.M.r1 = oq.M.r2 = oq.V = oq.ext = mk<T>(T(0), T(0), T(0));
   int sp = 0, fb = -1;
-  T dlb = big, rec_dist = big;
+  T dlb = big, rec_dist = big, cand_val = big;
   V3<T> np1 = oq.V, np2 = oq.V, nn = oq.V, guess0 = oq.V;
   // a triangle's leaf; push: with the EPA item if it needs one
   auto run_leaf = [&](uint32_t prim, bool push, SolidLeafOut<T>* lo) -> bool {
     SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + prim), lib.shapes, lib.verts,
                       swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, push ? reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer) : nullptr,
-                      push ? &wk.counts[CTR_SHAPE_DEFER] : nullptr, wk.shape_defer_cap, pair, solid_id, prim, 0xFFFFFFFFu, 0u, T(0), -1};
+                      push ? &wk.counts[CTR_SHAPE_DEFER] : nullptr, wk.shape_defer_cap, pair, solid_id, prim, my_parent, my_order, T(0), -1};
     return solid_leaf_call<T>(in, &q, leaf_ps, guess0, lo);
   };
   for (;;) {
-    if (!have && qi < n_susp) {
-      const BvhSum<T> s = *bvh_sum<T>(split, qi);
-      pair = split.suspended[qi];
-      qi += stride;
+    if (!have && !exhausted) {
+      const uint32_t qi = coop_next_unit<W>(ticket, lig, grp);
+      exhausted = qi >= n_units;
+      bool take = !exhausted;
+      BvhTask task = {0u, 0xFFFFFFFFu, 0u, 0u};
+      if (take && level) {
+        task = split.tasks[unit0 + qi];
+        take = task.entry != 0xFFFFFFFFu;  // (a slot of a table that was full)
+        if (take && bvh_moot<T>(split, task.parent, task.order & 0xFFFFu)) {  // it stands behind a contact: nobody reads its summary
+          if (lig == 0) bvh_sum<T>(split, split.n_queries + unit0 + qi)->flags = 0u;
+          take = false;
+        }
+      }
+      if (take) {
+      BvhSum<T> s;
+      if (level) {
+        s.dlb = s.rec_dist = s.cand_val = big;
+        s.np1 = s.np2 = s.nn = mk<T>(Lim<T>::nan(), Lim<T>::nan(), Lim<T>::nan());
+        s.flags = 0u;
+        s.first_child = task.entry;
+        s.n_child = task.order >> 16;
+        pair = task.pair;
+      } else {
+        s = *bvh_sum<T>(split, qi);
+        pair = split.suspended[qi];
+      }
+      unit = qi;
+      my_parent = task.parent;
+      my_order = task.order & 0xFFFFu;
       const uint32_t id1 = wk.shape1[pair], id2 = wk.shape2[pair];
       swapped = lib.kinds[id1] != uint8_t(K_BVH);
       solid_id = swapped ? id1 : id2;
       m1 = bv.meshes[lib.shapes[swapped ? id2 : id1].bvh_index];
       oq = reinterpret_cast<const ObbQuery<T>*>(wk.shape_oq)[pair];
-      for (uint32_t j = uint32_t(lig); j < s.n_child; j += uint32_t(W)) stack[s.n_child - 1u - j] = split.tasks[s.first_child + j].entry;  // child 0 on top
+      if (level) {  // the chunk's entries, with what is known about them
+        for (uint32_t j = uint32_t(lig); j < s.n_child; j += uint32_t(W)) {
+          stack[s.n_child - 1u - j] = split.cut_words[s.first_child + j];
+          value[s.n_child - 1u - j] = cut_vals[s.first_child + j];
+        }
+      } else {
+        for (uint32_t j = uint32_t(lig); j < s.n_child; j += uint32_t(W)) stack[s.n_child - 1u - j] = split.tasks[s.first_child + j].entry;  // child 0 on top
+      }
       sp = int(s.n_child);
       dlb = s.dlb;
       rec_dist = s.rec_dist;
+      cand_val = s.cand_val;
+      t_begin = __builtin_readcyclecounter();
+      ++n_walks;
       np1 = s.np1;
       np2 = s.np2;
       nn = s.nn;
@@ -1186,10 +1307,22 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       if (overflow) sp = 0;
       guess0 = initial_guess<T>(io, q, pair);  // (walks whose leaves hand a cached guess on are not split)
       have = true;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (!__any(have)) break;
+    if (!__any(have)) {
+      if (__all(exhausted)) break;
+      continue;  // (the units drawn were chunks nobody needs)
+    }
+    if (have && level && (++trip_no & 15u) == 0u && bvh_moot<T>(split, my_parent, my_order)) {
+      // (every 16th trip: the look costs a dependent load per level, every trip 3.3 -> 3.75 ms on cfg4s) a chunk in front of this one
+      // has found a contact meanwhile: the sequential walk ended there, nobody reads this summary
+      if (lig == 0) bvh_sum<T>(split, split.n_queries + unit0 + unit)->flags = 0u;
+      COOP_WALK_END(lig == 0, t_begin);
+      have = false;
+      continue;
+    }
     bool done = have && sp == 0;
     if (have && sp > 0) {
       const int w = min(W, min(sp, max(COOP_CAP - sp, 1)));
@@ -1272,6 +1405,7 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       // by running its leaf once more); the contact's points likewise
       const uint64_t wmask = gballot(lowered && tag == COOP_LEAF);
       const int L = wmask ? 63 - __clzll((unsigned long long)wmask) : -1;
+      if (L >= 0) cand_val = __shfl(bnd, L, W);
       const bool is_contact_lane = c < W && lig == c;
       if (act && is_leaf && !fresh && ((lig == L) || (is_contact_lane && tag == COOP_LEAF && bp.contacts))) {
         fc = np->first_child;
@@ -1322,9 +1456,53 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
         }
       }
       done = sp == 0;
+      if (cut_ticks && sp > COOP_CHUNK && __builtin_readcyclecounter() - t_begin > cut_ticks) {
+        // ---- cut: the stack, top first, as chunks for the next launch; this unit's state as the summary they hang under
+        const uint32_t n_ent = uint32_t(sp), n_chunks = (n_ent + COOP_CHUNK - 1u) / COOP_CHUNK;
+        uint32_t first_task = 0, first_word = 0;
+        if (lig == 0) {
+          first_task = atomicAdd(&split.ctr[BVH_CTR_TASKS], n_chunks);
+          first_word = atomicAdd(&split.ctr[BVH_CTR_CUT], n_ent);
+        }
+        first_task = uint32_t(__shfl(int(first_task), 0, W));
+        first_word = uint32_t(__shfl(int(first_word), 0, W));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (first_task + n_chunks > split.cap || first_word + n_ent > split.cut_cap) {  // no room: the slots taken are no-ops, the walk goes on
+          for (uint32_t c = first_task + uint32_t(lig); c < min(first_task + n_chunks, split.cap); c += uint32_t(W)) split.tasks[c] = BvhTask{0u, 0u, 0xFFFFFFFFu, 0u};
+          t_begin = __builtin_readcyclecounter();
+        } else {
+          const uint32_t my_slot = level ? split.n_queries + unit0 + unit : unit;
+          for (uint32_t k = uint32_t(lig); k < n_ent; k += uint32_t(W)) {
+            split.cut_words[first_word + k] = stack[sp - 1 - int(k)];
+            cut_vals[first_word + k] = value[sp - 1 - int(k)];
+          }
+          for (uint32_t c = uint32_t(lig); c < n_chunks; c += uint32_t(W))
+            split.tasks[first_task + c] = BvhTask{pair, my_slot, first_word + c * COOP_CHUNK, c | (min(uint32_t(COOP_CHUNK), n_ent - c * COOP_CHUNK) << 16)};
+          if (lig == 0)
+            coop_write_sum<T>(split, my_slot, dlb, rec_dist, cand_val, np1, np2, nn, -1, -1, 0u, first_task, n_chunks,
+                              BVH_SUM_SUSPENDED | (overflow ? BVH_SUM_OVERFLOW : 0u), my_parent, my_order);
+          COOP_CUT_COUNT(lig == 0);
+          COOP_WALK_END(lig == 0, t_begin);
+          have = false;
+          sp = 0;
+        }
+      }
+    }
+    if (done && level) {
+      // ---- a chunk's summary (k_bvh_combine folds it into the walk it was cut from)
+      if (lig == 0) {
+        coop_write_sum<T>(split, split.n_queries + unit0 + unit, dlb, rec_dist, cand_val, np1, np2, nn, swapped ? -1 : fb, swapped ? fb : -1, ncontacts, 0u, 0u,
+                          overflow ? BVH_SUM_OVERFLOW : 0u, my_parent, my_order);
+        if (ncontacts) coop_report_contact<T>(split, my_parent, my_order);
+      }
+      COOP_WALK_END(lig == 0, t_begin);
+      have = false;
+      done = false;
     }
     if (done) {
       if (lig == 0) {
+        bvh_sum<T>(split, unit)->flags = 0u;  // (not cut: k_bvh_combine has nothing to fold for this query)
         PairOut<T> o;
         o.distance = rec_dist;
         o.normal = nn;
@@ -1335,9 +1513,11 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
         o.gjk_iters = o.epa_iters = 0;
         store_bvh_record(io, pair, o, ncontacts, swapped ? -1 : fb, swapped ? fb : -1, overflow);
       }
+      COOP_WALK_END(lig == 0, t_begin);
       have = false;
     }
   }
+  COOP_WAVE_END(t_wave, n_walks);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1359,23 +1539,56 @@ k_bvh_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhPa
   uint32_t* const stack = stacks[grp];
   const uint64_t gbits = W == 64 ? ~uint64_t(0) : ((uint64_t(1) << (W & 63)) - 1);
   auto gballot = [&](bool x) -> uint64_t { return (__ballot(x) >> (grp * W)) & gbits; };
-  const uint32_t n_susp = min(split.ctr[BVH_CTR_SUSPENDED], split.n_queries);
+  // the units of this launch: the suspended queries (level 0), or the chunks the launch before cut its long walks into (see above)
+  const uint32_t level = split.level;
+  const uint32_t unit0 = level ? min(split.ctr[BVH_CTR_LEVEL0 + level - 1], split.cap) : 0u;
+  const uint32_t n_units = level ? min(split.ctr[BVH_CTR_LEVEL0 + level], split.cap) - unit0 : min(split.ctr[BVH_CTR_SUSPENDED], split.n_queries);
+  const unsigned long long cut_ticks = split.can_suspend ? split.cut_ticks : 0u;
+  uint32_t* const ticket = &wk.counts[B_COUNT + 2];  // (k_bvh_collide is through with it; k_bvh_level_mark has reset it)
   const T big = Lim<T>::max();
-  bool have = false, overflow = false;
-  uint32_t qi = blockIdx.x * G + grp, pair = 0, ncontacts = 0;
-  const uint32_t stride = gridDim.x * G;
+  bool have = false, overflow = false, exhausted = false;
+  uint32_t pair = 0, ncontacts = 0;
+  uint32_t unit = 0, my_parent = 0xFFFFFFFFu, my_order = 0;
+  unsigned long long t_begin = 0, t_wave = __builtin_readcyclecounter();
+  unsigned n_walks = 0, trip_no = 0;
+  (void)t_wave; (void)n_walks;
   DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
   M3<T> RT_R;
   V3<T> RT_T = mk<T>(T(0), T(0), T(0));
   RT_R.r0 = RT_R.r1 = RT_R.r2 = RT_T;
   int sp = 0, fb1 = -1, fb2 = -1;
-  T dlb = big, rec_dist = big;
+  T dlb = big, rec_dist = big, cand_val = big;
   V3<T> np1 = RT_T, np2 = RT_T, nn = RT_T;
   for (;;) {
-    if (!have && qi < n_susp) {
-      const BvhSum<T> s = *bvh_sum<T>(split, qi);
-      pair = split.suspended[qi];
-      qi += stride;
+    if (!have && !exhausted) {
+      const uint32_t qi = coop_next_unit<W>(ticket, lig, grp);
+      exhausted = qi >= n_units;
+      bool take = !exhausted;
+      BvhTask task = {0u, 0xFFFFFFFFu, 0u, 0u};
+      if (take && level) {
+        task = split.tasks[unit0 + qi];
+        take = task.entry != 0xFFFFFFFFu;  // (a slot of a table that was full)
+        if (take && bvh_moot<T>(split, task.parent, task.order & 0xFFFFu)) {  // it stands behind a contact: nobody reads its summary
+          if (lig == 0) bvh_sum<T>(split, split.n_queries + unit0 + qi)->flags = 0u;
+          take = false;
+        }
+      }
+      if (take) {
+      BvhSum<T> s;
+      if (level) {
+        s.dlb = s.rec_dist = s.cand_val = big;
+        s.np1 = s.np2 = s.nn = mk<T>(Lim<T>::nan(), Lim<T>::nan(), Lim<T>::nan());
+        s.flags = 0u;
+        s.first_child = task.entry;
+        s.n_child = task.order >> 16;
+        pair = task.pair;
+      } else {
+        s = *bvh_sum<T>(split, qi);
+        pair = split.suspended[qi];
+      }
+      unit = qi;
+      my_parent = task.parent;
+      my_order = task.order & 0xFFFFu;
       m1 = bv.meshes[lib.shapes[wk.shape1[pair]].bvh_index];
       m2 = bv.meshes[lib.shapes[wk.shape2[pair]].bvh_index];
       {
@@ -1383,10 +1596,17 @@ k_bvh_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhPa
         RT_R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
         RT_T = tmul(tf1.R, tf2.t - tf1.t);
       }
-      for (uint32_t j = uint32_t(lig); j < s.n_child; j += uint32_t(W)) stack[s.n_child - 1u - j] = split.tasks[s.first_child + j].entry;  // child 0 on top
+      if (level) {
+        for (uint32_t j = uint32_t(lig); j < s.n_child; j += uint32_t(W)) stack[s.n_child - 1u - j] = split.cut_words[s.first_child + j];  // the chunk's entries
+      } else {
+        for (uint32_t j = uint32_t(lig); j < s.n_child; j += uint32_t(W)) stack[s.n_child - 1u - j] = split.tasks[s.first_child + j].entry;  // child 0 on top
+      }
       sp = int(s.n_child);
       dlb = s.dlb;
       rec_dist = s.rec_dist;
+      cand_val = s.cand_val;
+      t_begin = __builtin_readcyclecounter();
+      ++n_walks;
       np1 = s.np1;
       np2 = s.np2;
       nn = s.nn;
@@ -1395,10 +1615,22 @@ k_bvh_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhPa
       overflow = (s.flags & BVH_SUM_OVERFLOW) != 0 || sp > COOP_CAP;
       if (overflow) sp = 0;
       have = true;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (!__any(have)) break;
+    if (!__any(have)) {
+      if (__all(exhausted)) break;
+      continue;  // (the units drawn were chunks nobody needs)
+    }
+    if (have && level && (++trip_no & 15u) == 0u && bvh_moot<T>(split, my_parent, my_order)) {
+      // (every 16th trip: the look costs a dependent load per level, every trip 3.3 -> 3.75 ms on cfg4s) a chunk in front of this one
+      // has found a contact meanwhile: the sequential walk ended there, nobody reads this summary
+      if (lig == 0) bvh_sum<T>(split, split.n_queries + unit0 + unit)->flags = 0u;
+      COOP_WALK_END(lig == 0, t_begin);
+      have = false;
+      continue;
+    }
     bool done = have && sp == 0;
     if (have && sp > 0) {
       const int w = min(W, min(sp, max(COOP_CAP - sp, 1)));
@@ -1468,6 +1700,7 @@ k_bvh_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhPa
           np1 = c1;
           np2 = c2;
           nn = cn;
+          cand_val = __shfl(val, L, W);
         }
       }
       const int cs = c < W ? c : 0;
@@ -1503,9 +1736,50 @@ k_bvh_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhPa
         }
       }
       done = sp == 0;
+      if (cut_ticks && sp > COOP_CHUNK && __builtin_readcyclecounter() - t_begin > cut_ticks) {
+        // ---- cut: the stack, top first, as chunks for the next launch; this unit's state as the summary they hang under
+        const uint32_t n_ent = uint32_t(sp), n_chunks = (n_ent + COOP_CHUNK - 1u) / COOP_CHUNK;
+        uint32_t first_task = 0, first_word = 0;
+        if (lig == 0) {
+          first_task = atomicAdd(&split.ctr[BVH_CTR_TASKS], n_chunks);
+          first_word = atomicAdd(&split.ctr[BVH_CTR_CUT], n_ent);
+        }
+        first_task = uint32_t(__shfl(int(first_task), 0, W));
+        first_word = uint32_t(__shfl(int(first_word), 0, W));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (first_task + n_chunks > split.cap || first_word + n_ent > split.cut_cap) {  // no room: the slots taken are no-ops, the walk goes on
+          for (uint32_t c = first_task + uint32_t(lig); c < min(first_task + n_chunks, split.cap); c += uint32_t(W)) split.tasks[c] = BvhTask{0u, 0u, 0xFFFFFFFFu, 0u};
+          t_begin = __builtin_readcyclecounter();
+        } else {
+          const uint32_t my_slot = level ? split.n_queries + unit0 + unit : unit;
+          for (uint32_t k = uint32_t(lig); k < n_ent; k += uint32_t(W)) split.cut_words[first_word + k] = stack[sp - 1 - int(k)];
+          for (uint32_t c = uint32_t(lig); c < n_chunks; c += uint32_t(W))
+            split.tasks[first_task + c] = BvhTask{pair, my_slot, first_word + c * COOP_CHUNK, c | (min(uint32_t(COOP_CHUNK), n_ent - c * COOP_CHUNK) << 16)};
+          if (lig == 0)
+            coop_write_sum<T>(split, my_slot, dlb, rec_dist, cand_val, np1, np2, nn, -1, -1, 0u, first_task, n_chunks,
+                              BVH_SUM_SUSPENDED | (overflow ? BVH_SUM_OVERFLOW : 0u), my_parent, my_order);
+          COOP_CUT_COUNT(lig == 0);
+          COOP_WALK_END(lig == 0, t_begin);
+          have = false;
+          sp = 0;
+        }
+      }
+    }
+    if (done && level) {
+      // ---- a chunk's summary (k_bvh_combine folds it into the walk it was cut from)
+      if (lig == 0) {
+        coop_write_sum<T>(split, split.n_queries + unit0 + unit, dlb, rec_dist, cand_val, np1, np2, nn, fb1, fb2, ncontacts, 0u, 0u,
+                          overflow ? BVH_SUM_OVERFLOW : 0u, my_parent, my_order);
+        if (ncontacts) coop_report_contact<T>(split, my_parent, my_order);
+      }
+      COOP_WALK_END(lig == 0, t_begin);
+      have = false;
+      done = false;
     }
     if (done) {
       if (lig == 0) {
+        bvh_sum<T>(split, unit)->flags = 0u;  // (not cut: k_bvh_combine has nothing to fold for this query)
         PairOut<T> o;
         o.distance = rec_dist;
         o.normal = nn;
@@ -1516,9 +1790,11 @@ k_bvh_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhPa
         o.gjk_iters = o.epa_iters = 0;
         store_bvh_record(io, pair, o, ncontacts, fb1, fb2, overflow);
       }
+      COOP_WALK_END(lig == 0, t_begin);
       have = false;
     }
   }
+  COOP_WAVE_END(t_wave, n_walks);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2230,6 +2506,27 @@ static void launch_collide_kernel(bool wide, int grid, hipStream_t st, const Wor
   else
     hipLaunchKernelGGL((k_bvh_collide<T, false, false>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
 }
+// The continuation of the suspended queries by k_bvh_coop / k_bvh_shape_coop: one launch, or -- BvhSplit::cut_ticks -- three, the second and
+// third walking the chunks the launch before cut its long walks into (levels 2 and 3 of the task table: k_bvh_level_mark files the
+// tasks made so far under ctr[LEVEL0 + level + 1] and resets the ticket), and the fold-back of the chunks' summaries.
+template <typename T, class Launch>
+static void launch_coop_levels(int grid, hipStream_t st, const Work& wk, const IO<T>& io, BvhSplit s, int ticket, Launch&& launch) {
+  const bool cutting = s.cut_ticks != 0 && s.cut_words != nullptr;
+  s.level = 0;
+  for (uint32_t l = 0; l < (cutting ? 3u : 1u); ++l) {
+    hipLaunchKernelGGL(k_bvh_level_mark, dim3(1), dim3(64), 0, st, wk, s, ticket);
+    s.level = l ? l + 1 : 0u;  // launch 0: the suspended queries; launches 1, 2: the chunks of the launch before
+    s.can_suspend = cutting && l < 2 ? 1u : 0u;
+    launch(s);
+    s.level = l + 1;  // (what the next mark files the tasks under)
+  }
+  if (cutting) {
+    s.level = 2;
+    hipLaunchKernelGGL((k_bvh_combine<T>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, io, s);
+    s.level = 0;
+    hipLaunchKernelGGL((k_bvh_combine<T>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, io, s);
+  }
+}
 template <typename T>
 void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill, bool solid) {
   if (spill.wide && !solid) {  // models with 32-bit node ids: single pass, global spill instead of tasks
@@ -2259,7 +2556,10 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
     launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s0, spill, false);
     // a wave per suspended query, up to what the chip holds (`grid` blocks of BVH_BLOCK queries: `grid * 2` waves left a quarter of the
     // wave slots empty at 100k queries, profiles/r04_h)
-    hipLaunchKernelGGL((k_bvh_coop<T>), dim3(std::max(1, std::min(grid * BVH_BLOCK, split.coop_grid ? int(split.coop_grid) : grid * 2))), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2, s0);
+    const int coop_grid = std::max(1, std::min(grid * BVH_BLOCK, split.coop_grid ? int(split.coop_grid) : grid * 2));
+    launch_coop_levels<T>(grid, st, wk, io, s0, int(B_COUNT + 2), [&](const BvhSplit& s) {
+      hipLaunchKernelGGL((k_bvh_coop<T>), dim3(coop_grid), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2, s);
+    });
     return;
   }
   const uint32_t budget = split.budget;
@@ -2311,10 +2611,14 @@ void launch_bvh_shape_fast(int grid, int grid_finish, int coop_grid, hipStream_t
     s0.budget = split.budget0;
     s0.can_suspend = 1;
     launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s0, spill, true);
-    hipLaunchKernelGGL((k_bvh_shape_coop<T>), dim3(coop_grid), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2, s0);
-    BvhSplit none = split;
-    none.tasks = nullptr;  // (no task tree: no item is overtaken)
-    hipLaunchKernelGGL((k_bvh_shape_finish<T>), dim3(grid_finish), dim3(64), 0, st, wk, lv, io, q, bp, none, 0);
+    launch_coop_levels<T>(grid, st, wk, io, s0, int(CTR_SHAPE_TICKET), [&](const BvhSplit& s) {
+      hipLaunchKernelGGL((k_bvh_shape_coop<T>), dim3(coop_grid), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2, s);
+    });
+    // (the EPA item of a chunk that stands behind another chunk's contact is skipped: bvh_moot over the summaries; items of whole walks
+    // hang under no summary)
+    BvhSplit fin = s0;
+    fin.level = 0;
+    hipLaunchKernelGGL((k_bvh_shape_finish<T>), dim3(grid_finish), dim3(64), 0, st, wk, lv, io, q, bp, fin, 0);
     return;
   }
   launch_bvh_collide<T>(grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill, true);

@@ -12,6 +12,8 @@
 //   hfcl_k_epa.hip   k_epa<T,WE,CAP,TIER>, k_epa_stream<T,WE,CAP>   EPA on the pairs GJK left in `Collision`
 //   hfcl_k_bvh.hip   k_bvh_collide<T>   BVHModel<OBBRSS> x BVHModel<OBBRSS> collide(), one query per lane for a step budget;
 //                                     k_bvh_coop<T>: the queries past it, a wave each, 64 stack entries per trip
+//                                     (BvhSplit::cut_ticks: a walk a wave has had for that long is cut into chunk tasks for the kernel's next
+//                                     launch, k_bvh_combine folds them back; on for mesh x solid, k_bvh_shape_coop)
 //                                     (k_bvh_combine<T>: the task-level alternative)
 //   hfcl_k_bvhd.hip  k_bvh_distance<T>  ... distance(), one query per lane for a step budget (this unit is built without
 //                                     contraction: triangle ids equal to the reference's); k_bvh_distance_pool<T, PQ>: the walks past

@@ -405,6 +405,14 @@ def test_gpu_mesh_solid_long_walks(pkg, oracle, kind):
         assert np.array_equal(other["b1"], got["b1"]) and np.array_equal(other["b2"], got["b2"])
         for f in ("distance", "p1", "p2", "normal"):
             assert _same(other[f], got[f], 1e-12), f
+    # (2b) the waves' own long walks cut into chunks for later launches (BvhSplit::cut_ticks; here after 15 000 clock ticks, with
+    # the lanes handing over after 8 steps): the same kernel on the same entries -- every field of every record, bit for bit
+    cut = _device_collide(pkg, b, req, env=dict(HFCL_SHAPE_CUT_TICKS="15000", HFCL_SHAPE_BUDGET0="8"))
+    uncut = _device_collide(pkg, b, req, env=dict(HFCL_SHAPE_BUDGET0="8"))
+    for f in cut.dtype.names:
+        assert _same(cut[f], uncut[f], 0.0) if cut[f].dtype.kind == "f" else np.array_equal(cut[f], uncut[f]), f
+    for f in ("num_contacts", "status", "b1", "b2"):
+        assert np.array_equal(cut[f], got[f]), f
     group = _device_collide(pkg, b, req, env=dict(HFCL_BVH_SHAPE_LANE="0"))
     assert np.array_equal(group["num_contacts"][m], got["num_contacts"][m])
     assert np.array_equal(group["b1"], got["b1"]) and np.array_equal(group["b2"], got["b2"])

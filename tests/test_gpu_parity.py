@@ -493,15 +493,20 @@ def test_bvh_collide_baseline_size(pkg, oracle, n):
     assert 0.2 < (ref["num_contacts"] > 0).mean() < 0.8
 
 
-@pytest.mark.parametrize("form", ["coop", "levels", "whole"])
+@pytest.mark.parametrize("form", ["coop", "cut", "levels", "whole"])
 def test_bvh_collide_forms_agree(pkg, oracle, form, monkeypatch):
-    """The three forms of a long mesh x mesh walk -- continued 64 entries wide by a wave (with a budget of 24 steps, so that
-    nearly every query is), cut into task levels, and walked in one piece by its lane -- give the oracle's records; and the
-    fp32 device path (its own instantiations of the same kernels) the same decisions away from the decision boundary."""
+    """The forms of a long mesh x mesh walk -- continued 64 entries wide by a wave (with a budget of 24 steps, so that
+    nearly every query is), the same with the waves' long walks cut into chunks that later launches walk and k_bvh_combine folds
+    back (BvhSplit::cut_ticks, here after 15 000 clock ticks: thousands of cuts, chunks cut again, chunks behind a contact), cut into
+    task levels by the lanes, and walked in one piece by its lane -- give the oracle's records; and the fp32 device path (its own
+    instantiations of the same kernels) the same decisions away from the decision boundary."""
     import torch
     abi, wl = pkg.abi, pkg.workloads
     if form == "coop":
         monkeypatch.setenv("HFCL_BVH_BUDGET0_COOP", "24")
+    elif form == "cut":
+        monkeypatch.setenv("HFCL_BVH_BUDGET0_COOP", "24")
+        monkeypatch.setenv("HFCL_BVH_CUT_TICKS", "15000")
     elif form == "levels":
         monkeypatch.setenv("HFCL_BVH_COOP", "0")
     else:
