@@ -12,6 +12,7 @@ from __graft_entry__ import load_pkg  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+only = sys.argv[3].split(",") if len(sys.argv) > 3 else None  # e.g. mesh,mixed,ellipsoid
 pkg = load_pkg()
 abi, wl = pkg.abi, pkg.workloads
 
@@ -43,11 +44,13 @@ bad_total = 0
 cases = [("mesh x mesh", lambda s: wl.cfg4_mesh_mesh(n=n, seed=400 + s), "HFCL_BVH_CUT_TICKS")]
 for kind in ("mixed", "sphere", "box", "capsule", "cylinder", "ellipsoid", "convex32", "cone"):
     cases.append(("mesh x " + kind, (lambda kd: lambda s: wl.mesh_vs_solid(kd, n=n, seed=300 + s))(kind), "HFCL_SHAPE_CUT_TICKS"))
+if only:
+    cases = [c for c in cases if c[0].split(" x ")[-1] in only]
 for name, make, knob in cases:
     for s in range(seeds):
         b = make(s)
         ref = run(b, {knob: "0"})
-        for ticks in ("400000", "100000", "15000"):
+        for ticks in ("600000", "100000", "15000"):
             got = run(b, {knob: ticks})
             diff = differing(got, ref)
             bad_total += int(diff.sum())
