@@ -1243,11 +1243,11 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
   T dlb = big, rec_dist = big, cand_val = big;
   V3<T> np1 = oq.V, np2 = oq.V, nn = oq.V, guess0 = oq.V;
   // a triangle's leaf; push: with the EPA item if it needs one
-  auto run_leaf = [&](uint32_t prim, bool push, SolidLeafOut<T>* lo) -> bool {
+  auto run_leaf = [&](uint32_t prim, bool push, SolidLeafOut<T>* lo, uint32_t* slot = nullptr) -> bool {
     SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + prim), lib.shapes, lib.verts,
                       swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, push ? reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer) : nullptr,
                       push ? &wk.counts[CTR_SHAPE_DEFER] : nullptr, wk.shape_defer_cap, pair, solid_id, prim, my_parent, my_order, T(0), -1};
-    return solid_leaf_call<T>(in, &q, leaf_ps, guess0, lo);
+    return solid_leaf_call<T>(in, &q, leaf_ps, guess0, lo, slot);
   };
   for (;;) {
     if (!have && !exhausted) {
@@ -1428,12 +1428,19 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
         const int prim_c = __shfl(int(-(fc + 1)), c, W);
         fb = prim_c;
         ncontacts = 1;
+        bool lost = false;
         if (is_contact_lane) {
-          if (tag == COOP_LEAF_EPA)  // its leaf once more, this time with the EPA item (k_bvh_shape_finish patches the record)
-            run_leaf(uint32_t(prim_c), true, &lo);
-          else
+          if (tag == COOP_LEAF_EPA) {  // its leaf once more, this time with the EPA item (k_bvh_shape_finish patches the record)
+            uint32_t slot = 0u;
+            run_leaf(uint32_t(prim_c), true, &lo, &slot);
+            lost = slot >= wk.shape_defer_cap;
+          } else {
             emit_shape_contact(bp, pair, swapped, prim_c, lo.distance, lo.p1, lo.p2, lo.n);
+          }
         }
+        // (the host sizes the queue of EPA items for the units it expects -- one and a half per query once walks are cut into chunks --;
+        // a contact whose item found it full says so in its record instead of keeping a depth nobody computed)
+        if (gballot(lost)) overflow = true;
         sp = 0;
       } else {
         // (4) the stack again, in order (entry 0's successors on top): visited entries are gone, an overlapping box is its two
