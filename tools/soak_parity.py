@@ -100,6 +100,27 @@ def main():
         print("cfg4_mesh_mesh seed %d      n=%8d  collide: contact counts / first-contact ids identical (%d near-zero skipped), "
               "max|dd| %.1e, contacts %.3f;  distance: max|dd| %.1e" %
               (seed, len(b), int(near.sum()), dd, float((ref["num_contacts"] > 0).mean()), ddist), flush=True)
+    # ---- meshes against solids (cfg4s: six solid kinds mixed, first-contact collide; the waves' long walks cut into chunks, DESIGN.md
+    # section 3 item 6e) and their distance(): contact counts / first-contact triangles identical, depths and distances to 4e-6
+    for seed in (51, 52, 53):
+        b = wl.mesh_vs_solid("mixed", n=nm, seed=seed)
+        ML = bb.MeshLibrary(b.meshes)
+        req = abi.default_collision_request()
+        lib = wl.make_library(pkg, b)
+        got = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
+        lib.close()
+        ref, _ = ob.mixed_collide_batch(b.shapes, b.verts, ML, b.s1, b.s2, b.tf1, b.tf2, req, max_contacts=10 ** 5, n_threads=threads)
+        assert not np.any((got["status"] >> 30) & 1), "traversal stack overflow"
+        near = np.abs(ref["distance"]) < 1e-9
+        same = got["num_contacts"] == ref["num_contacts"]
+        ok = same & ~near
+        ids = (got["b1"][ok] == ref["b1"][ok]) & (got["b2"][ok] == ref["b2"][ok])
+        hit = ok & (ref["num_contacts"] > 0)
+        dd = np.abs(got["distance"][hit] - ref["distance"][hit]).max()
+        assert np.all(same | near) and ids.all() and dd < 4e-6, (same.mean(), ids.mean(), dd)
+        total += len(b)
+        print("mesh_x_solid (mixed) seed %d n=%8d  collide: contact counts / first-contact triangles identical (%d near-zero skipped), "
+              "max|dd| of the depths %.1e, contacts %.3f" % (seed, len(b), int(near.sum()), dd, float((ref["num_contacts"] > 0).mean())), flush=True)
     # ---- fp32 device-resident path (cfg3, the bench configuration): envelope of DESIGN.md "fp32 path"
     import torch
     dev = torch.device("cuda:0")
