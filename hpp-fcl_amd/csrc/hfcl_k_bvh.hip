@@ -1179,12 +1179,41 @@ extern "C" int hfcl_debug_coop_prof(unsigned long long* out16, int reset) {
 // k_bvh_combine folds them back in DFS order exactly as it folds k_bvh_collide's task levels (bound: a minimum; witness: the last
 // triangle of a chunk that lowered the chunk's own bound, if it also lies below the bound as it stood before the chunk; a contact ends
 // the fold).  A chunk can be cut again (two more launches); where it is cut never changes a record, only when its parts are walked.
-// coop_take_units: the group's next unit -- a suspended query (level 0: its index) or a chunk task of the level.
-template <int W>
-__device__ __forceinline__ uint32_t coop_next_unit(uint32_t* ticket, int lig, int grp) {
-  uint32_t u = 0;
-  if (lig == 0) u = atomicAdd(ticket, 1u);
-  return uint32_t(__shfl(int(u), grp * W));
+// What a lane group draws from the launch's ticket: a suspended query (level 0) or a chunk of a cut walk.
+struct CoopUnit {
+  bool take;       // there is a unit to walk (not: the ticket ran out, a slot of a table that was full, a chunk behind a contact)
+  bool exhausted;  // the ticket has run past the launch's units
+  uint32_t index;  // of the unit among the launch's units
+  uint32_t pair, parent, order;  // the query; (chunks) the summary slot of the walk it was cut from and its place among that walk's chunks
+  uint32_t first, count;         // chunks: its entries are cut_words / cut_vals [first, first + count)
+};
+template <typename T, int W>
+__device__ __forceinline__ CoopUnit coop_draw(const BvhSplit& split, uint32_t* ticket, uint32_t level, uint32_t unit0, uint32_t n_units, int lig, int grp) {
+  CoopUnit u = {false, false, 0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u};
+  uint32_t qi = 0;
+  if (lig == 0) qi = atomicAdd(ticket, 1u);
+  qi = uint32_t(__shfl(int(qi), grp * W));
+  u.index = qi;
+  u.exhausted = qi >= n_units;
+  if (u.exhausted) return u;
+  if (!level) {
+    u.pair = split.suspended[qi];
+    u.take = true;
+    return u;
+  }
+  const BvhTask task = split.tasks[unit0 + qi];
+  if (task.entry == 0xFFFFFFFFu) return u;  // (a slot of a table that was full)
+  if (bvh_moot<T>(split, task.parent, task.order & 0xFFFFu)) {  // it stands behind a contact: nobody reads its summary
+    if (lig == 0) bvh_sum<T>(split, split.n_queries + unit0 + qi)->flags = 0u;
+    return u;
+  }
+  u.pair = task.pair;
+  u.parent = task.parent;
+  u.order = task.order & 0xFFFFu;
+  u.first = task.entry;
+  u.count = task.order >> 16;
+  u.take = true;
+  return u;
 }
 // a contact in a chunk ends the walk of every unit above it at that chunk's position (k_bvh_collide: report_contact)
 template <typename T>
@@ -1206,6 +1235,39 @@ __device__ __forceinline__ void coop_write_sum(const BvhSplit& split, uint32_t s
   sm->fb1 = fb1; sm->fb2 = fb2;
   sm->ncontacts = ncontacts; sm->first_child = first_child; sm->n_child = n_child; sm->flags = flags;
   sm->contact_order = 0xFFFFFFFFu; sm->parent = parent; sm->order = order; sm->pad_ = 0;
+}
+// The cut itself, by the lanes of the unit's group: the stack (sp entries, top first; `value`: what is known about them, or nullptr) to
+// cut_words / cut_vals in chunks of COOP_CHUNK, a BvhTask per chunk, the unit's state as the summary they hang under.  false: the tables
+// have no room (the slots taken are no-ops): the walk goes on.
+template <typename T, int W>
+__device__ __forceinline__ bool coop_cut(const BvhSplit& split, uint32_t my_slot, uint32_t pair, uint32_t my_parent, uint32_t my_order, const uint32_t* stack,
+                                         const T* value, int sp, int lig, T dlb, T rec_dist, T cand_val, const V3<T>& np1, const V3<T>& np2, const V3<T>& nn,
+                                         bool overflow) {
+  const uint32_t n_ent = uint32_t(sp), n_chunks = (n_ent + COOP_CHUNK - 1u) / COOP_CHUNK;
+  uint32_t first_task = 0, first_word = 0;
+  if (lig == 0) {
+    first_task = atomicAdd(&split.ctr[BVH_CTR_TASKS], n_chunks);
+    first_word = atomicAdd(&split.ctr[BVH_CTR_CUT], n_ent);
+  }
+  first_task = uint32_t(__shfl(int(first_task), 0, W));
+  first_word = uint32_t(__shfl(int(first_word), 0, W));
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the stack was written back by the lanes of this trip)
+  __builtin_amdgcn_wave_barrier();
+  if (first_task + n_chunks > split.cap || first_word + n_ent > split.cut_cap) {
+    for (uint32_t c = first_task + uint32_t(lig); c < min(first_task + n_chunks, split.cap); c += uint32_t(W)) split.tasks[c] = BvhTask{0u, 0u, 0xFFFFFFFFu, 0u};
+    return false;
+  }
+  T* const cut_vals = reinterpret_cast<T*>(split.cut_vals);
+  for (uint32_t k = uint32_t(lig); k < n_ent; k += uint32_t(W)) {
+    split.cut_words[first_word + k] = stack[sp - 1 - int(k)];
+    if (value) cut_vals[first_word + k] = value[sp - 1 - int(k)];
+  }
+  for (uint32_t c = uint32_t(lig); c < n_chunks; c += uint32_t(W))
+    split.tasks[first_task + c] = BvhTask{pair, my_slot, first_word + c * COOP_CHUNK, c | (min(uint32_t(COOP_CHUNK), n_ent - c * COOP_CHUNK) << 16)};
+  if (lig == 0)
+    coop_write_sum<T>(split, my_slot, dlb, rec_dist, cand_val, np1, np2, nn, -1, -1, 0u, first_task, n_chunks,
+                      BVH_SUM_SUSPENDED | (overflow ? BVH_SUM_OVERFLOW : 0u), my_parent, my_order);
+  return true;
 }
 template <typename T>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
@@ -1251,34 +1313,23 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
   };
   for (;;) {
     if (!have && !exhausted) {
-      const uint32_t qi = coop_next_unit<W>(ticket, lig, grp);
-      exhausted = qi >= n_units;
-      bool take = !exhausted;
-      BvhTask task = {0u, 0xFFFFFFFFu, 0u, 0u};
-      if (take && level) {
-        task = split.tasks[unit0 + qi];
-        take = task.entry != 0xFFFFFFFFu;  // (a slot of a table that was full)
-        if (take && bvh_moot<T>(split, task.parent, task.order & 0xFFFFu)) {  // it stands behind a contact: nobody reads its summary
-          if (lig == 0) bvh_sum<T>(split, split.n_queries + unit0 + qi)->flags = 0u;
-          take = false;
-        }
-      }
-      if (take) {
+      const CoopUnit u = coop_draw<T, W>(split, ticket, level, unit0, n_units, lig, grp);
+      exhausted = u.exhausted;
+      if (u.take) {
       BvhSum<T> s;
-      if (level) {
+      if (level) {  // a chunk starts from an empty state
         s.dlb = s.rec_dist = s.cand_val = big;
         s.np1 = s.np2 = s.nn = mk<T>(Lim<T>::nan(), Lim<T>::nan(), Lim<T>::nan());
         s.flags = 0u;
-        s.first_child = task.entry;
-        s.n_child = task.order >> 16;
-        pair = task.pair;
+        s.first_child = u.first;
+        s.n_child = u.count;
       } else {
-        s = *bvh_sum<T>(split, qi);
-        pair = split.suspended[qi];
+        s = *bvh_sum<T>(split, u.index);
       }
-      unit = qi;
-      my_parent = task.parent;
-      my_order = task.order & 0xFFFFu;
+      pair = u.pair;
+      unit = u.index;
+      my_parent = u.parent;
+      my_order = u.order;
       const uint32_t id1 = wk.shape1[pair], id2 = wk.shape2[pair];
       swapped = lib.kinds[id1] != uint8_t(K_BVH);
       solid_id = swapped ? id1 : id2;
@@ -1464,35 +1515,15 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       }
       done = sp == 0;
       if (cut_ticks && sp > COOP_CHUNK && __builtin_readcyclecounter() - t_begin > cut_ticks) {
-        // ---- cut: the stack, top first, as chunks for the next launch; this unit's state as the summary they hang under
-        const uint32_t n_ent = uint32_t(sp), n_chunks = (n_ent + COOP_CHUNK - 1u) / COOP_CHUNK;
-        uint32_t first_task = 0, first_word = 0;
-        if (lig == 0) {
-          first_task = atomicAdd(&split.ctr[BVH_CTR_TASKS], n_chunks);
-          first_word = atomicAdd(&split.ctr[BVH_CTR_CUT], n_ent);
-        }
-        first_task = uint32_t(__shfl(int(first_task), 0, W));
-        first_word = uint32_t(__shfl(int(first_word), 0, W));
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (first_task + n_chunks > split.cap || first_word + n_ent > split.cut_cap) {  // no room: the slots taken are no-ops, the walk goes on
-          for (uint32_t c = first_task + uint32_t(lig); c < min(first_task + n_chunks, split.cap); c += uint32_t(W)) split.tasks[c] = BvhTask{0u, 0u, 0xFFFFFFFFu, 0u};
-          t_begin = __builtin_readcyclecounter();
-        } else {
-          const uint32_t my_slot = level ? split.n_queries + unit0 + unit : unit;
-          for (uint32_t k = uint32_t(lig); k < n_ent; k += uint32_t(W)) {
-            split.cut_words[first_word + k] = stack[sp - 1 - int(k)];
-            cut_vals[first_word + k] = value[sp - 1 - int(k)];
-          }
-          for (uint32_t c = uint32_t(lig); c < n_chunks; c += uint32_t(W))
-            split.tasks[first_task + c] = BvhTask{pair, my_slot, first_word + c * COOP_CHUNK, c | (min(uint32_t(COOP_CHUNK), n_ent - c * COOP_CHUNK) << 16)};
-          if (lig == 0)
-            coop_write_sum<T>(split, my_slot, dlb, rec_dist, cand_val, np1, np2, nn, -1, -1, 0u, first_task, n_chunks,
-                              BVH_SUM_SUSPENDED | (overflow ? BVH_SUM_OVERFLOW : 0u), my_parent, my_order);
+        // ---- the walk has had its time: what is left of it becomes chunks for the next launch (coop_cut)
+        if (coop_cut<T, W>(split, level ? split.n_queries + unit0 + unit : unit, pair, my_parent, my_order, stack, value, sp, lig, dlb, rec_dist, cand_val,
+                           np1, np2, nn, overflow)) {
           COOP_CUT_COUNT(lig == 0);
           COOP_WALK_END(lig == 0, t_begin);
           have = false;
           sp = 0;
+        } else {
+          t_begin = __builtin_readcyclecounter();  // (no room: the walk goes on and asks again after another budget)
         }
       }
     }
@@ -1568,34 +1599,23 @@ k_bvh_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhPa
   V3<T> np1 = RT_T, np2 = RT_T, nn = RT_T;
   for (;;) {
     if (!have && !exhausted) {
-      const uint32_t qi = coop_next_unit<W>(ticket, lig, grp);
-      exhausted = qi >= n_units;
-      bool take = !exhausted;
-      BvhTask task = {0u, 0xFFFFFFFFu, 0u, 0u};
-      if (take && level) {
-        task = split.tasks[unit0 + qi];
-        take = task.entry != 0xFFFFFFFFu;  // (a slot of a table that was full)
-        if (take && bvh_moot<T>(split, task.parent, task.order & 0xFFFFu)) {  // it stands behind a contact: nobody reads its summary
-          if (lig == 0) bvh_sum<T>(split, split.n_queries + unit0 + qi)->flags = 0u;
-          take = false;
-        }
-      }
-      if (take) {
+      const CoopUnit u = coop_draw<T, W>(split, ticket, level, unit0, n_units, lig, grp);
+      exhausted = u.exhausted;
+      if (u.take) {
       BvhSum<T> s;
-      if (level) {
+      if (level) {  // a chunk starts from an empty state
         s.dlb = s.rec_dist = s.cand_val = big;
         s.np1 = s.np2 = s.nn = mk<T>(Lim<T>::nan(), Lim<T>::nan(), Lim<T>::nan());
         s.flags = 0u;
-        s.first_child = task.entry;
-        s.n_child = task.order >> 16;
-        pair = task.pair;
+        s.first_child = u.first;
+        s.n_child = u.count;
       } else {
-        s = *bvh_sum<T>(split, qi);
-        pair = split.suspended[qi];
+        s = *bvh_sum<T>(split, u.index);
       }
-      unit = qi;
-      my_parent = task.parent;
-      my_order = task.order & 0xFFFFu;
+      pair = u.pair;
+      unit = u.index;
+      my_parent = u.parent;
+      my_order = u.order;
       m1 = bv.meshes[lib.shapes[wk.shape1[pair]].bvh_index];
       m2 = bv.meshes[lib.shapes[wk.shape2[pair]].bvh_index];
       {
@@ -1744,32 +1764,15 @@ k_bvh_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhPa
       }
       done = sp == 0;
       if (cut_ticks && sp > COOP_CHUNK && __builtin_readcyclecounter() - t_begin > cut_ticks) {
-        // ---- cut: the stack, top first, as chunks for the next launch; this unit's state as the summary they hang under
-        const uint32_t n_ent = uint32_t(sp), n_chunks = (n_ent + COOP_CHUNK - 1u) / COOP_CHUNK;
-        uint32_t first_task = 0, first_word = 0;
-        if (lig == 0) {
-          first_task = atomicAdd(&split.ctr[BVH_CTR_TASKS], n_chunks);
-          first_word = atomicAdd(&split.ctr[BVH_CTR_CUT], n_ent);
-        }
-        first_task = uint32_t(__shfl(int(first_task), 0, W));
-        first_word = uint32_t(__shfl(int(first_word), 0, W));
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (first_task + n_chunks > split.cap || first_word + n_ent > split.cut_cap) {  // no room: the slots taken are no-ops, the walk goes on
-          for (uint32_t c = first_task + uint32_t(lig); c < min(first_task + n_chunks, split.cap); c += uint32_t(W)) split.tasks[c] = BvhTask{0u, 0u, 0xFFFFFFFFu, 0u};
-          t_begin = __builtin_readcyclecounter();
-        } else {
-          const uint32_t my_slot = level ? split.n_queries + unit0 + unit : unit;
-          for (uint32_t k = uint32_t(lig); k < n_ent; k += uint32_t(W)) split.cut_words[first_word + k] = stack[sp - 1 - int(k)];
-          for (uint32_t c = uint32_t(lig); c < n_chunks; c += uint32_t(W))
-            split.tasks[first_task + c] = BvhTask{pair, my_slot, first_word + c * COOP_CHUNK, c | (min(uint32_t(COOP_CHUNK), n_ent - c * COOP_CHUNK) << 16)};
-          if (lig == 0)
-            coop_write_sum<T>(split, my_slot, dlb, rec_dist, cand_val, np1, np2, nn, -1, -1, 0u, first_task, n_chunks,
-                              BVH_SUM_SUSPENDED | (overflow ? BVH_SUM_OVERFLOW : 0u), my_parent, my_order);
+        // ---- the walk has had its time: what is left of it becomes chunks for the next launch (coop_cut)
+        if (coop_cut<T, W>(split, level ? split.n_queries + unit0 + unit : unit, pair, my_parent, my_order, stack, static_cast<const T*>(nullptr), sp, lig, dlb, rec_dist, cand_val,
+                           np1, np2, nn, overflow)) {
           COOP_CUT_COUNT(lig == 0);
           COOP_WALK_END(lig == 0, t_begin);
           have = false;
           sp = 0;
+        } else {
+          t_begin = __builtin_readcyclecounter();  // (no room: the walk goes on and asks again after another budget)
         }
       }
     }
