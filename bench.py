@@ -156,7 +156,7 @@ def load_traffic(workload, dominant, n, want="traffic"):
     found = False
     for name, v in t["kernels"].items():
         hit = any(base + suffix in name for suffix in ("<", "64<", "(")) and re.search(sel, name) is not None
-        if tag == "fast" and "k_epa_stream<" in name:  # the fp32 fast tier is the streaming form of the same kernel
+        if tag == "fast" and ("k_epa_stream<" in name or "k_epa_loop<" in name):  # the fp32 fast tier: the streaming forms of the same kernel
             hit = True
         if base == "k_closed" and "k_closed_staged(" in name:  # the fp64 closed-form kernel (LDS-staged I/O)
             hit = True

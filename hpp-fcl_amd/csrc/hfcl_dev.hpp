@@ -58,7 +58,8 @@ constexpr int CTR_DIST_SUSP = 2 * B_COUNT + 6;  // suspended mesh x mesh distanc
 constexpr int CTR_SHAPE_DIST_SUSP = 2 * B_COUNT + 7;  // ... mesh x solid (ShapeDistSusp records)
 constexpr int CTR_DIST_TICKET = 2 * B_COUNT + 8;  // ticket of k_bvh_distance_pool: next DistSusp record to take
 constexpr int CTR_SHAPE_DIST_TICKET = 2 * B_COUNT + 9;  // ticket of k_bvh_shape_distance_pool
-constexpr int N_COUNTERS = 2 * B_COUNT + 10;  // bucket populations + the four counters of Work::counts + curved populations + those
+constexpr int CTR_EPA_READY = 2 * B_COUNT + 10;  // blocks k_epa_prepare handed to k_epa_loop (EpaReady records)
+constexpr int N_COUNTERS = 2 * B_COUNT + 11;  // bucket populations + the four counters of Work::counts + curved populations + those
 
 // Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
 // support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
@@ -173,6 +174,7 @@ struct Work {
   void* shape_defer;  // ShapeDeferItem<T>[shape_defer_cap]: mesh x solid leaves waiting for EPA (k_bvh_collide<SOLID> -> k_bvh_shape_finish); nullptr: group kernels
   uint32_t shape_defer_cap;  // a unit (query, or task of a split walk) queues at most one item: sized by the host for every unit a batch can make
   void* shape_oq;     // ObbQuery<T>[n], by pair: the solid's fitted OBB against the mesh pose (k_shape_obb)
+  void* epa_ready;    // EpaReady<T>[n]: convex x convex polytopes between k_epa_prepare, k_epa_loop and k_epa_records (nullptr: the one-kernel form)
 };
 // a pair with a shape whose support is not a vertex
 __host__ __device__ inline bool curved_pair(int k1, int k2) {

@@ -181,6 +181,133 @@ HFCL_HD void epa_support(Sup& sup, const V3<T>& dir, V3<T>& w, V3<T>& w0, int& t
   }
 }
 
+// The plane of a polytope face (a, b, c): the arithmetic of newFace (:1081-1137) on its own, so that every place that
+// builds a face -- Epa::face_geometry in a scratch block, epa_prepare_tetrahedron in registers -- rounds the same way.
+// Returns 0 when the face is kept, else the status newFace sets (NonConvex / Degenerated); flag: 1 in hull, 3 in hull + ignore.
+template <typename T>
+HFCL_HD int epa_face_plane(const V3<T>& a, const V3<T>& b, const V3<T>& c, T tolerance, bool force, V3<T>& n, T& dist, int& flag) {
+  n = cross(b - a, c - a);
+  int fail = 0;
+  flag = 1;
+  dist = T(0);
+  if (norm(n) > Lim<T>::eps()) {
+    n = normalized(n);
+    const T a_dot_nab = dot(a, cross(b - a, n));
+    const T b_dot_nbc = dot(b, cross(c - b, n));
+    const T c_dot_nca = dot(c, cross(a - c, n));
+    T d;
+    if (a_dot_nab >= -tolerance && b_dot_nbc >= -tolerance && c_dot_nca >= -tolerance) {
+      d = dot(a, n);
+    } else {
+      d = Lim<T>::max();
+      flag = 3;  // in hull + ignore
+    }
+    dist = d;
+    if (!(d >= -tolerance || force)) fail = EPA_NON_CONVEX;
+  } else {
+    fail = EPA_DEGENERATED;
+  }
+  return fail;
+}
+
+// ---------------------------------------------------------------------------------------
+// The convex x convex fast tier in three stages (hfcl_k_epa.hip: k_epa_prepare / k_epa_loop / k_epa_records).
+// What EPA::evaluate does before its loop for a seed of rank 4 -- orientation, the first tetrahedron, its closest face
+// (:1188-1230) -- and after it -- witness points, the record (narrowphase.h:658-711) -- is serial work per polytope; inside
+// the streaming kernel an 8-lane group executes it redundantly while the live groups of the wave wait.  Here one LANE per
+// polytope does it, in kernels of their own around the loop kernel, and the two hand each other a block per polytope:
+//   prepare -> loop : EpaReady   the oriented tetrahedron (vertex records with their tags, face planes, ignore flags, the first
+//                                closest face) and what a group needs to evaluate supports (hull offsets, relative pose);
+//   loop -> records : the same block, its pose / vertex area overwritten with the loop's result (EpaLoopOut) and `state` set.
+// ---------------------------------------------------------------------------------------
+enum { EPA_READY_PENDING = 0u, EPA_READY_DONE = 1u, EPA_READY_HANDED_OVER = 2u };
+template <typename T>
+struct alignas(16) EpaReady {
+  uint32_t seed;            // slot of the polytope's seed in the convex x convex queue (item `seed` of that queue)
+  uint32_t voff_a, voff_b;  // first vertex of the two hulls in the library's vertex table
+  // bits 0-5 / 6-11: vertices of hull a / b; 12-13: first closest face; 14-17: ignore flag of face 0..3; 18: relative pose is the identity
+  uint32_t packed;
+  T md[12];                 // MDiff: oR1 rows, ot1
+  Quad<T> vw[4];            // vertex records of the oriented tetrahedron (w: tag)
+  Quad<T> fn[4];            // face planes
+  uint32_t state;           // EPA_READY_*
+  uint32_t pad_[3];
+};
+template <typename T>
+struct __attribute__((may_alias)) EpaLoopOut {  // overlays EpaReady::md .. (the loop is over: the block's pose and vertices are no longer needed)
+  int32_t status, iterations;
+  T nx, ny, nz, depth;       // the last valid `outer` face: normal and distance (EpaLoop::outer_n / outer_d)
+  T rw[9];                   // w of its three vertices
+  int32_t tag[3];            // ... and their tags
+};
+static_assert(sizeof(EpaLoopOut<float>) <= sizeof(float) * 12 + sizeof(Quad<float>) * 4, "the result overlays the pose and vertex area");
+// connectivity of the first tetrahedron as Epa::begin binds it (faces (0,1,2) (1,0,3) (2,1,3) (0,2,3), stamps 0..3)
+struct EpaTetraTopo {
+  uint32_t vf[4], ap[4], ae[4];
+};
+constexpr EpaTetraTopo epa_tetra_topo() {
+  EpaTetraTopo t{{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  const int corner[4][3] = {{0, 1, 2}, {1, 0, 3}, {2, 1, 3}, {0, 2, 3}};
+  int adj[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, adje[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  const int binds[6][4] = {{0, 0, 1, 0}, {0, 1, 2, 0}, {0, 2, 3, 0}, {1, 1, 3, 2}, {1, 2, 2, 1}, {2, 2, 3, 1}};  // (fa, ea, fb, eb), :1222-1227
+  for (int k = 0; k < 6; ++k) {
+    adj[binds[k][0]][binds[k][1]] = binds[k][2];
+    adje[binds[k][0]][binds[k][1]] = binds[k][3];
+    adj[binds[k][2]][binds[k][3]] = binds[k][0];
+    adje[binds[k][2]][binds[k][3]] = binds[k][1];
+  }
+  for (int f = 0; f < 4; ++f) {
+    t.vf[f] = uint32_t(corner[f][0]) | (uint32_t(corner[f][1]) << 8) | (uint32_t(corner[f][2]) << 16);
+    t.ap[f] = uint32_t(adj[f][0]) | (uint32_t(adj[f][1]) << 8) | (uint32_t(adj[f][2]) << 16);
+    t.ae[f] = uint32_t(adje[f][0]) | (uint32_t(adje[f][1]) << 8) | (uint32_t(adje[f][2]) << 16) | (uint32_t(f) << 24);
+  }
+  return t;
+}
+// Epa::begin for a seed of rank 4 (w[i] with tag -1-i), by one lane, nothing but registers.  Returns false when the
+// reference falls back (origin not enclosed, degenerate face: :1299-1315); otherwise vw / fn / flags / closest describe the
+// block Epa::begin would have left.
+template <typename T>
+HFCL_HD bool epa_prepare_tetrahedron(const V3<T>* w, T tolerance, Quad<T>* vw, Quad<T>* fn, int* flags, int& closest) {
+  // GJK::encloseOrigin, rank 4 (:483-488)
+  if (!(habs(triple(w[0] - w[3], w[1] - w[3], w[2] - w[3])) > T(0))) return false;
+  const bool swap01 = dot(w[0] - w[3], cross(w[1] - w[3], w[2] - w[3])) < T(0);  // :1196-1201
+  const V3<T> v0 = swap01 ? w[1] : w[0], v1 = swap01 ? w[0] : w[1];
+  vw[0] = Quad<T>{v0.x, v0.y, v0.z, T(swap01 ? -2 : -1)};
+  vw[1] = Quad<T>{v1.x, v1.y, v1.z, T(swap01 ? -1 : -2)};
+  vw[2] = Quad<T>{w[2].x, w[2].y, w[2].z, T(-3)};
+  vw[3] = Quad<T>{w[3].x, w[3].y, w[3].z, T(-4)};
+  const V3<T> p[4] = {v0, v1, w[2], w[3]};
+  const int corner[4][3] = {{0, 1, 2}, {1, 0, 3}, {2, 1, 3}, {0, 2, 3}};
+  bool ok = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int f = 0; f < 4; ++f) {
+    V3<T> n;
+    T d;
+    const int fail = epa_face_plane(p[corner[f][0]], p[corner[f][1]], p[corner[f][2]], tolerance, true, n, d, flags[f]);
+    fn[f] = Quad<T>{n.x, n.y, n.z, d};
+    ok = ok && fail == 0;
+  }
+  if (!ok) return false;  // hull_count != 4
+  // findClosestFace over the four faces (stamps 0..3: the later face wins a tie; all ignored: the list head, face 3)
+  T best = Lim<T>::max();
+  int best_f = EPA_NULL;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int f = 0; f < 4; ++f) {
+    if (flags[f] & 2) continue;
+    const T sq = fn[f].w * fn[f].w;
+    if (sq < best || (sq == best && best_f != EPA_NULL)) {
+      best = sq;
+      best_f = f;
+    }
+  }
+  closest = best_f != EPA_NULL ? best_f : 3;
+  return true;
+}
+
 // HFCL_EPA_PAR_HZ: 1 = the fp32 convex x convex fast tier (the V0_TAG blocks) finds the horizon of an expansion with all
 // lanes at once (Epa::silhouette_parallel) instead of walking it; 2 = every fp32 polytope (validation builds); 0 = never.
 // fp64 always walks: its statuses and iteration counts are the reference's to the letter.  (The full-capacity fp32 tier walks
@@ -298,28 +425,10 @@ struct Epa {
   // Geometry part of newFace (:1081-1137) for the triangle (ia, ib, ic) stored in slot f.
   // Returns 0 when the face is kept, else the status newFace sets (NonConvex / Degenerated).
   HFCL_HD int face_geometry(int f, int ia, int ib, int ic, bool force, int face_stamp) {
-    const V3<T> a = vw(ia), b = vw(ib), c = vw(ic);
-    V3<T> n = cross(b - a, c - a);
-    int fail = 0;
-    int flag = 1;
-    T dist = T(0);
-    if (norm(n) > Lim<T>::eps()) {
-      n = normalized(n);
-      const T a_dot_nab = dot(a, cross(b - a, n));
-      const T b_dot_nbc = dot(b, cross(c - b, n));
-      const T c_dot_nca = dot(c, cross(a - c, n));
-      T d;
-      if (a_dot_nab >= -tolerance && b_dot_nbc >= -tolerance && c_dot_nca >= -tolerance) {
-        d = dot(a, n);
-      } else {
-        d = Lim<T>::max();
-        flag = 3;  // in hull + ignore
-      }
-      dist = d;
-      if (!(d >= -tolerance || force)) fail = EPA_NON_CONVEX;
-    } else {
-      fail = EPA_DEGENERATED;
-    }
+    V3<T> n;
+    T dist;
+    int flag;
+    const int fail = epa_face_plane(vw(ia), vw(ib), vw(ic), tolerance, force, n, dist, flag);
     m->fn[f] = Quad<T>{n.x, n.y, n.z, dist};
     // corners + flags + high stamp bits in one word; the pass mark is cleared; adjacency bytes are written by the binds
     m->ft[f].vf = uint32_t(ia) | (uint32_t(ib) << 8) | (uint32_t(ic) << 16) | (uint32_t(flag) << 24) |
@@ -724,6 +833,44 @@ struct Epa {
       return false;
     }
     return hz_count >= 3;
+  }
+
+  // Take over the tetrahedron epa_prepare_tetrahedron described: the state begin() leaves behind for a seed of rank 4.
+  // Call after reset(); ends with a sync.  Returns the first closest face.
+  HFCL_HD int install(const EpaReady<T>* rb, uint32_t packed) {
+    constexpr EpaTetraTopo topo = epa_tetra_topo();
+    for (int i = Grp::lane(); i < 8; i += Grp::W) {
+      if (i < 4) {
+        m->vw[i] = rb->vw[i];
+      } else {
+        const int f = i - 4;
+        m->fn[f] = rb->fn[f];
+        const uint32_t flag = 1u | (((packed >> (14 + f)) & 1u) << 1);
+        m->ft[f].vf = (f == 0 ? topo.vf[0] : (f == 1 ? topo.vf[1] : (f == 2 ? topo.vf[2] : topo.vf[3]))) | (flag << 24);
+        m->ft[f].ap = f == 0 ? topo.ap[0] : (f == 1 ? topo.ap[1] : (f == 2 ? topo.ap[2] : topo.ap[3]));
+        m->ft[f].ae = f == 0 ? topo.ae[0] : (f == 1 ? topo.ae[1] : (f == 2 ? topo.ae[2] : topo.ae[3]));
+      }
+    }
+    status = EPA_VALID;
+    num_vertices = 4;
+    hull_count = 4;
+    stock_top -= 4;
+    stamp = 4;
+    hw = 4;
+    Grp::sync();
+    return int((packed >> 12) & 3u);
+  }
+  // The loop's result with tags instead of shape-0 support points (V0_TAG blocks; resolved by whoever writes the record).
+  HFCL_HD void loop_out(const EpaLoop<T>& L, EpaLoopOut<T>& o) const {
+    o.status = status;
+    o.iterations = L.iterations;
+    o.nx = L.outer_n.x; o.ny = L.outer_n.y; o.nz = L.outer_n.z;
+    o.depth = L.outer_d;
+    const Quad<T> a = m->vw[L.o0], b = m->vw[L.o1], c = m->vw[L.o2];
+    o.rw[0] = a.x; o.rw[1] = a.y; o.rw[2] = a.z;
+    o.rw[3] = b.x; o.rw[4] = b.y; o.rw[5] = b.z;
+    o.rw[6] = c.x; o.rw[7] = c.y; o.rw[8] = c.z;
+    o.tag[0] = int(a.w); o.tag[1] = int(b.w); o.tag[2] = int(c.w);
   }
 
   // GJK::encloseOrigin :437-492 on verts[0..rank) (reference order).  sup(dir) -> (w, w0).

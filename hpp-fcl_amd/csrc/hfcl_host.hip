@@ -94,6 +94,10 @@ struct hfcl_lib {
   uint32_t* d_counts = nullptr;
   void* d_epa_queue = nullptr;
   void* d_epa_queue2 = nullptr;
+  void* d_epa_ready = nullptr;   // EpaReady<float>[epa_ready_capacity]: the staged convex x convex fast tier (k_epa_prepare / k_epa_loop / k_epa_records)
+  size_t epa_ready_capacity = 0;
+  bool epa_cc_staged = true;     // HFCL_EPA_CC_STAGED=0: the one-kernel form (k_epa_stream<.., CC>)
+  size_t epa_cc_staged_min = 32768;  // ... which batches below this many pairs keep (two launches less); HFCL_EPA_CC_STAGED_MIN
   void* d_epa_resume = nullptr;
   void* d_epa_v0 = nullptr;
   size_t resume_cap = 0;
@@ -454,6 +458,8 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   }
   if (const char* v = getenv("HFCL_CLOSED_STAGED")) lib->closed_staged = atoi(v) != 0;
   if (const char* v = getenv("HFCL_SPLIT")) lib->split = atoi(v) >= 2 ? 2 : (atoi(v) == 1 ? 1 : 0);
+  if (const char* v = getenv("HFCL_EPA_CC_STAGED")) lib->epa_cc_staged = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_EPA_CC_STAGED_MIN")) lib->epa_cc_staged_min = size_t(std::max(0ll, atoll(v)));
   if (const char* v = getenv("HFCL_PIPE_CHUNK")) lib->pipe_chunk = strtoull(v, nullptr, 10);
   if (const char* v = getenv("HFCL_BVH_FILTER")) lib->bvh_filter = atoi(v) != 0;
   if (const char* v = getenv("HFCL_BVH_SHAPE_LANE")) lib->bvh_shape_lane = atoi(v) != 0;
@@ -513,6 +519,7 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_lists);
   hipFree(lib->d_epa_queue);
   hipFree(lib->d_epa_queue2);
+  hipFree(lib->d_epa_ready);
   hipFree(lib->d_epa_resume);
   hipFree(lib->d_epa_v0);
   hipFree(lib->d_shape_defer);
@@ -1065,6 +1072,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
   wk.shape_defer = nullptr;
   wk.shape_defer_cap = 0;
   wk.shape_oq = nullptr;
+  wk.epa_ready = nullptr;
   LibView<T> lv;
   lv.shapes = std::is_same<T, double>::value ? (const DShape<T>*)lib->d_shapes64 : (const DShape<T>*)lib->d_shapes32;
   lv.verts = std::is_same<T, double>::value ? (const T*)lib->d_verts64 : (const T*)lib->d_verts32;
@@ -1294,11 +1302,39 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
   }
 
   if (q.compute_penetration && any_gjk) {
+    // fp32 convex x convex pairs: the fast tier in three stages (hfcl_k_epa.hip) for batches large enough to pay for two more launches
+    bool cc_staged = false;
+    if constexpr (std::is_same<T, float>::value) {
+      cc_staged = may(B_CC) && lib->epa_cc_staged && n >= lib->epa_cc_staged_min;
+      if (cc_staged) {
+        if (lib->ws_capacity > lib->epa_ready_capacity) {
+          hipFree(lib->d_epa_ready);
+          lib->d_epa_ready = nullptr;
+          lib->epa_ready_capacity = 0;
+          HIP_TRY(hipMalloc(&lib->d_epa_ready, lib->ws_capacity * sizeof(EpaReady<float>)));
+          lib->epa_ready_capacity = lib->ws_capacity;
+        }
+        wk.epa_ready = lib->d_epa_ready;
+        tbeg("k_epa_prepare");
+        launch_epa_prepare(blocks_for(n / 4 + 1, 256), st, wk, lv, io, q);
+        tend();
+      }
+    }
+    const int epa_batches = int(std::min<size_t>((n + 64 / EPA_WE - 1) / (64 / EPA_WE), size_t(1) << 22));
     tbeg("k_epa<fast>");
     // (the launcher sizes the grid of the persistent forms itself: here only the number of wave-sized batches)
-    launch_epa_fast<T>(int(std::min<size_t>((n + 64 / EPA_WE - 1) / (64 / EPA_WE), size_t(1) << 22)), st, wk, lv, io, q, may(B_CC),
-                       may(B_PRIM) || may(B_PC) || may(B_CP), lib->n_cus, lib->has_curved);
+    if constexpr (std::is_same<T, float>::value) {
+      if (cc_staged) launch_epa_loop(epa_batches, st, wk, lv, q, lib->n_cus);
+    }
+    launch_epa_fast<T>(epa_batches, st, wk, lv, io, q, may(B_CC) && !cc_staged, may(B_PRIM) || may(B_PC) || may(B_CP), lib->n_cus, lib->has_curved);
     tend();
+    if constexpr (std::is_same<T, float>::value) {
+      if (cc_staged) {
+        tbeg("k_epa_records");
+        launch_epa_records(blocks_for(n / 4 + 1, 256), st, wk, lv, io, q);
+        tend();
+      }
+    }
     tbeg("k_epa<full>");
     launch_epa_full<T>(blocks_for(n / 16 + 1, 64 / epa_we2<T>), st, wk, lv, io, q);
     tend();
@@ -1342,6 +1378,8 @@ static hfcl_lib* make_helper(hfcl_lib* lib) {
   share_tables(h, lib);
   h->cvx_w = lib->cvx_w;
   h->closed_staged = lib->closed_staged;
+  h->epa_cc_staged = lib->epa_cc_staged;
+  h->epa_cc_staged_min = lib->epa_cc_staged_min;
   h->n_cus = lib->n_cus;
   bool ok = hipMalloc(&h->d_counts, N_COUNTERS * sizeof(uint32_t)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&h->h_counts, N_COUNTERS * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;

@@ -321,6 +321,199 @@ k_epa_stream(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
 }
 
 // =======================================================================================
+// The convex x convex fast tier in three stages (hfcl_epa.hpp: EpaReady).  k_epa_stream<.., CC> spends a quarter of its
+// instructions in its refills -- seed, poses, encloseOrigin, first tetrahedron, closest face; witness points and the record of
+// the polytope that ended -- with three or four of a wave's eight groups taking part and every lane of a group doing the same
+// serial work (profiles/r05_a).  Here that work is done by one lane per polytope in two kernels around the loop:
+//   k_epa_prepare  item of the convex x convex queue -> EpaReady block (compacted: fall-backs get their record here, the
+//                  two-in-a-hundred-thousand seeds of rank < 4 go to the full-capacity tier, which starts from any seed);
+//   k_epa_loop     the expansion loop alone: a refill is a block copied into LDS and two hulls;
+//   k_epa_records  EpaLoopOut -> witness points, normal, record (EPAExtractWitnessPointsAndNormal, narrowphase.h:658-711).
+// =======================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) k_epa_prepare(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  const uint32_t cnt = wk.counts[B_COUNT + 3];
+  const EpaItem<T>* const queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
+  EpaReady<T>* const ready = reinterpret_cast<EpaReady<T>*>(wk.epa_ready);
+  const int lane = threadIdx.x & 63;
+  // (whole waves walk the queue so that the slots of a wave's blocks are reserved with one atomic)
+  for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; base < cnt; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + uint32_t(lane);
+    bool live = false;
+    EpaReady<T> rb;
+    if (i < cnt) {
+      const EpaItem<T>* ip = queue + (wk.n - 1u - i);
+      const int rank = ip->rank;
+      if (rank != 4) {
+        // encloseOrigin has supports to evaluate: the full-capacity tier starts from the seed
+        const uint32_t slot = atomicAdd(&wk.counts[B_COUNT + 1], 1u);
+        reinterpret_cast<EpaItem<T>*>(wk.epa_queue2)[slot] = *ip;
+      } else {
+        const V3<T> w[4] = {ip->w[0], ip->w[1], ip->w[2], ip->w[3]};
+        int flags[4], closest = 0;
+        live = epa_prepare_tetrahedron(w, q.epa_tolerance, rb.vw, rb.fn, flags, closest);
+        const uint32_t pair = ip->pair;
+        if (live) {
+          const DShape<T> a = lib.shapes[wk.shape1[pair]], b = lib.shapes[wk.shape2[pair]];
+          const MDiff<T> md = make_mdiff(load_pose(io.tf1, pair), load_pose(io.tf2, pair));
+          rb.seed = i;
+          rb.voff_a = a.vertex_offset;
+          rb.voff_b = b.vertex_offset;
+          rb.packed = (a.num_points & 63u) | ((b.num_points & 63u) << 6) | (uint32_t(closest) << 12) | (uint32_t((flags[0] >> 1) & 1) << 14) |
+                      (uint32_t((flags[1] >> 1) & 1) << 15) | (uint32_t((flags[2] >> 1) & 1) << 16) | (uint32_t((flags[3] >> 1) & 1) << 17) |
+                      (md.identity ? 1u << 18 : 0u);
+          rb.md[0] = md.oR1.r0.x; rb.md[1] = md.oR1.r0.y; rb.md[2] = md.oR1.r0.z;
+          rb.md[3] = md.oR1.r1.x; rb.md[4] = md.oR1.r1.y; rb.md[5] = md.oR1.r1.z;
+          rb.md[6] = md.oR1.r2.x; rb.md[7] = md.oR1.r2.y; rb.md[8] = md.oR1.r2.z;
+          rb.md[9] = md.ot1.x; rb.md[10] = md.ot1.y; rb.md[11] = md.ot1.z;
+          rb.state = EPA_READY_PENDING;
+          rb.pad_[0] = rb.pad_[1] = rb.pad_[2] = 0u;
+        } else {  // FallBack (:1299-1315): final without a loop
+          EpaResult<T> res;
+          res.status = EPA_FALLBACK;
+          res.iterations = 0;
+          PairOut<T> o;
+          epa_finish(res, ip->gjk_iters, load_pose(io.tf1, pair), T(0), T(0), o);
+          write_out<T>(io, q, pair, o);
+          write_guess<T>(io, pair, o.cached_guess, 0, 0);
+        }
+      }
+    }
+    const uint64_t m = __ballot(live);
+    uint32_t slot0 = 0;
+    if (lane == 0 && m) slot0 = atomicAdd(&wk.counts[CTR_EPA_READY], uint32_t(__popcll(m)));
+    slot0 = __shfl(slot0, 0, 64);
+    if (live) ready[slot0 + uint32_t(__popcll(m & ((uint64_t(1) << lane) - 1u)))] = rb;
+  }
+}
+
+#ifndef HFCL_EPA_LOOP_REFILL_MIN
+#define HFCL_EPA_LOOP_REFILL_MIN 2  // a refill is cheap here: idle groups wait for fewer companions than in k_epa_stream
+#endif
+#ifndef HFCL_EPA_LOOP_TICKETS
+#define HFCL_EPA_LOOP_TICKETS 0  // 1: waves draw their blocks from a ticket counter instead of a static share (A/B)
+#endif
+template <typename T, int WE, int CAP>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_EPA32_CC, 8)))
+k_epa_loop(Work wk, LibView<T> lib, QParams<T> q) {
+  constexpr int G = 64 / WE;
+  static_assert(WE >= 8, "a group's lanes copy the eight records of a block");
+  typedef LaneGroup<WE> Grp;
+  __shared__ EpaScratch<T, CAP, V0_TAG> scratch[G];
+  const uint32_t cnt = wk.counts[CTR_EPA_READY];
+  const int lane = threadIdx.x & 63, grp = lane / WE, lig = lane & (WE - 1);
+  EpaReady<T>* const ready = reinterpret_cast<EpaReady<T>*>(wk.epa_ready);
+  const EpaItem<T>* const queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
+  enum { IDLE = 0, LIVE = 1, DONE = 2, HANDOVER = 3 };
+  int state = IDLE;
+  uint32_t it = 0;             // block of this group's polytope
+  uint32_t voff_a = 0;         // ... and what its hand-over needs: hull a's vertices, its seed
+  uint32_t seed_slot = 0;
+  uint32_t next = blockIdx.x;  // wave-uniform: the wave's blocks are next, next + gridDim.x, ...
+  EpaSupportCC<T, WE> sup;
+  sup.lig = lig;
+  Epa<T, Grp, CAP, V0_TAG> epa;
+  EpaLoop<T> L;
+  while (true) {
+    const uint64_t live = __ballot(state == LIVE);
+    const int n_live = __popcll(live) / WE;
+    const bool more = next < cnt;
+    if (n_live == 0 || (more && G - n_live >= HFCL_EPA_LOOP_REFILL_MIN)) {
+      // ---- refill phase (uniform decision; groups with a live polytope sit it out) ----
+      if (state != LIVE) {
+        if (state != IDLE) {
+          EpaReady<T>* rb = ready + it;
+          if (state == DONE) {
+            EpaLoopOut<T> o;
+            epa.loop_out(L, o);
+            if (lig == 0) {
+              *reinterpret_cast<EpaLoopOut<T>*>(rb->md) = o;
+              rb->state = EPA_READY_DONE;
+            }
+          } else {  // hand over to the full-capacity tier: the seed and, room permitting, the polytope itself
+            const EpaItem<T>* ip = queue + (wk.n - 1u - seed_slot);
+            uint32_t slot = 0;
+            if (lig == 0) slot = atomicAdd(&wk.counts[B_COUNT + 1], 1u);
+            slot = __shfl(slot, 0, WE);
+            const bool save = epa.resumable && slot < wk.resume_cap;
+            if (save) epa_save_block<T, Grp, CAP>(&scratch[grp], resume_slot<T, CAP>(wk, slot), SeedTags<T>{lib.verts + 3 * size_t(voff_a), ip});
+            if (lig == 0) {  // queue to queue, no local copy
+              EpaItem<T>* dst = reinterpret_cast<EpaItem<T>*>(wk.epa_queue2) + slot;
+              *dst = *ip;
+              if (save) dst->rank = ip->rank | EPA_RESUME_FLAG | (CAP != epa_fast_cap<T> ? EPA_RESUME_SMALL : 0);
+              rb->state = EPA_READY_HANDED_OVER;
+            }
+          }
+          Grp::sync();
+          state = IDLE;
+        }
+        // rank of this group among the groups taking part, in lane order
+        const uint64_t lower = live | ~((uint64_t(1) << (grp * WE)) - 1);  // live lanes and lanes >= mine do not count
+        const uint32_t rank = uint32_t(__popcll(~lower)) / WE;
+        it = next + rank * gridDim.x;
+        if (it < cnt) {
+          const EpaReady<T>* rb = ready + it;
+          const uint32_t packed = rb->packed;
+          seed_slot = rb->seed;
+          voff_a = rb->voff_a;
+          sup.h0.load(lib.verts + 3 * size_t(voff_a), packed & 63u, lig);
+          sup.h1.load(lib.verts + 3 * size_t(rb->voff_b), (packed >> 6) & 63u, lig);
+          sup.md.oR1.r0 = mk<T>(rb->md[0], rb->md[1], rb->md[2]);
+          sup.md.oR1.r1 = mk<T>(rb->md[3], rb->md[4], rb->md[5]);
+          sup.md.oR1.r2 = mk<T>(rb->md[6], rb->md[7], rb->md[8]);
+          sup.md.ot1 = mk<T>(rb->md[9], rb->md[10], rb->md[11]);
+          sup.md.identity = (packed >> 18) & 1u;
+          epa.reset(&scratch[grp], q.epa_max_iterations, q.epa_tolerance);
+          epa.loop_enter(L, epa.install(rb, packed), 0, 0);
+          state = LIVE;
+        }
+      }
+      next += uint32_t(G - n_live) * gridDim.x;
+      if (n_live == 0 && !more) {
+        if (__ballot(state == LIVE) == 0) break;
+      }
+      continue;
+    }
+    // ---- trip ----
+    if (state == LIVE) {
+      const int r = epa.step(L, sup);
+      if (r != 0) state = r == 1 ? DONE : HANDOVER;
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_epa_records(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  const uint32_t cnt = wk.counts[CTR_EPA_READY];
+  const EpaReady<T>* const ready = reinterpret_cast<const EpaReady<T>*>(wk.epa_ready);
+  const EpaItem<T>* const queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+    const EpaReady<T>* rb = ready + i;
+    if (rb->state != EPA_READY_DONE) continue;  // handed over: the full-capacity tier writes the record
+    const EpaLoopOut<T>* lo = reinterpret_cast<const EpaLoopOut<T>*>(rb->md);
+    const EpaItem<T>* ip = queue + (wk.n - 1u - rb->seed);
+    const uint32_t pair = ip->pair;
+    const SeedTags<T> tags{lib.verts + 3 * size_t(rb->voff_a), ip};
+    const T r0 = swept_radius(lib.shapes[wk.shape1[pair]]), r1 = swept_radius(lib.shapes[wk.shape2[pair]]);
+    EpaResult<T> res;
+    res.status = lo->status;
+    res.iterations = lo->iterations;
+    res.normal = mk<T>(lo->nx, lo->ny, lo->nz);
+    res.depth = lo->depth + (r0 + r1);
+    res.rw0_ = mk<T>(lo->rw[0], lo->rw[1], lo->rw[2]);
+    res.rw1_ = mk<T>(lo->rw[3], lo->rw[4], lo->rw[5]);
+    res.rw2_ = mk<T>(lo->rw[6], lo->rw[7], lo->rw[8]);
+    res.r00 = tags(lo->tag[0]);
+    res.r01 = tags(lo->tag[1]);
+    res.r02 = tags(lo->tag[2]);
+    PairOut<T> o;
+    epa_finish(res, ip->gjk_iters, load_pose(io.tf1, pair), r0, r1, o);
+    write_out<T>(io, q, pair, o);
+    write_guess<T>(io, pair, o.cached_guess, 0, 0);
+  }
+}
+
+// =======================================================================================
 // launchers (hfcl_launch.hpp)
 // =======================================================================================
 // fp32 streams (two or three waves per SIMD hide the refill's global loads: k_epa<fast> 1.87 -> 1.76 ms on cfg3);
@@ -376,6 +569,17 @@ void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>&
 }
 template void launch_epa_fast<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&, bool, bool, int, bool);
 template void launch_epa_fast<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&, bool, bool, int, bool);
+
+void launch_epa_prepare(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q) {
+  hipLaunchKernelGGL((k_epa_prepare<float>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+}
+void launch_epa_loop(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const QParams<float>& q, int n_cus) {
+  static const int per_cu = resident_blocks_per_cu(k_epa_loop<float, EPA_WE, EPA_FAST_CAP>);
+  hipLaunchKernelGGL((k_epa_loop<float, EPA_WE, EPA_FAST_CAP>), dim3(std::min(grid, n_cus * per_cu * HFCL_EPA_GRID_ROUNDS)), dim3(64), 0, st, wk, lv, q);
+}
+void launch_epa_records(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q) {
+  hipLaunchKernelGGL((k_epa_records<float>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
+}
 
 template <typename T>
 void launch_epa_full(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {

@@ -10,6 +10,7 @@
 //                    k_gjk_large<T>   GJK when a hull has more than 32 vertices (scan / hill-climb from memory)
 //                    k_unsupported<T>, k_fill_skipped
 //   hfcl_k_epa.hip   k_epa<T,WE,CAP,TIER>, k_epa_stream<T,WE,CAP>   EPA on the pairs GJK left in `Collision`
+//                    k_epa_prepare / k_epa_loop / k_epa_records   the fp32 convex x convex fast tier in three stages
 //   hfcl_k_bvh.hip   k_bvh_collide<T>   BVHModel<OBBRSS> x BVHModel<OBBRSS> collide(), one query per lane for a step budget;
 //                                     k_bvh_coop<T>: the queries past it, a wave each, 64 stack entries per trip
 //                                     (BvhSplit::cut_ticks: a walk a wave has had for that long is cut into chunk tasks for the kernel's next
@@ -52,6 +53,10 @@ void launch_compact_records(hipStream_t st, const hfcl_result_f32* in, hfcl_resu
 // queue and a kernel of their own); curved_class (fp64): the library has a shape whose support is not a vertex, i.e. the
 // curved class of pairs -- a queue and a fast-tier kernel of its own -- can occur
 template <typename T> void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool cc_queue, bool general_queue, int n_cus, bool curved_class = true);
+// the fp32 convex x convex fast tier in three stages (Work::epa_ready set): one lane per polytope before and after the loop kernel
+void launch_epa_prepare(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q);
+void launch_epa_loop(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const QParams<float>& q, int n_cus);
+void launch_epa_records(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q);
 template <typename T> void launch_epa_full(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q);
 
 // split: the task tables of a split traversal (tasks == nullptr: single pass)

@@ -235,6 +235,85 @@ int sim_batch_f32(const hfcl_shape* shapes, size_t n_shapes, const double* verti
   return 0;
 }
 
+// The staged convex x convex fast tier (hfcl_epa.hpp: EpaReady): for every pair whose GJK ends in a seed of rank 4,
+// epa_prepare_tetrahedron + Epa::install must leave the scratch block and the solver fields exactly as Epa::begin does
+// (or both fall back).  Returns the number of seeds checked; *mismatches counts the ones that differ in any byte.
+namespace {
+struct NoSupportTagged {  // encloseOrigin evaluates no support for a seed of rank 4
+  void operator()(const V3<float>&, V3<float>&, V3<float>&, int&) const {}
+};
+struct ZeroTags {
+  V3<float> operator()(int) const { return mk<float>(0.f, 0.f, 0.f); }
+};
+}  // namespace
+long sim_epa_prepare_selftest(const hfcl_shape* shapes, size_t n_shapes, const double* vertices, size_t n_vertices, const uint32_t* s1,
+                              const uint32_t* s2, const float* pose1, const float* pose2, size_t n, const hfcl_distance_request* dreq,
+                              long* mismatches, long* fallbacks) {
+  std::vector<DShape<float>> lib(n_shapes);
+  for (size_t i = 0; i < n_shapes; ++i) lib[i] = to_dshape<float>(shapes[i]);
+  std::vector<float> v32(3 * n_vertices + 3);
+  for (size_t i = 0; i < 3 * n_vertices; ++i) v32[i] = float(vertices[i]);
+  QParams<float> q;
+  fill_q(q, dreq->q);
+  q.mode = 0;
+  q.compute_penetration = 1;
+  q.security_margin = 0;
+  q.gjk.distance_upper_bound = Lim<float>::max();
+  long checked = 0;
+  *mismatches = 0;
+  *fallbacks = 0;
+  constexpr int CAP = 17;
+  typedef Epa<float, SerialGroup<1>, CAP, V0_TAG> E;
+  static EpaScratch<float, CAP, V0_TAG> blk_a, blk_b;
+  for (size_t i = 0; i < n; ++i) {
+    const DShape<float>&a = lib[s1[i]], &b = lib[s2[i]];
+    SerialSupport<float> sup;
+    sup.a = a;
+    sup.b = b;
+    sup.va = v32.data() + 3 * size_t(a.vertex_offset);
+    sup.vb = v32.data() + 3 * size_t(b.vertex_offset);
+    const Pose<float> tf1 = pose_from_quat<float>(pose1 + 7 * i), tf2 = pose_from_quat<float>(pose2 + 7 * i);
+    sup.md = make_mdiff(tf1, tf2);
+    const V3<float> g0 = mk<float>(1, 0, 0);
+    Gjk<float, PW0<float>> g;
+    gjk_run(g, q.gjk, g0, 0.f, true, sup);
+    PairOut<float> o;
+    EpaSeed<float> seed;
+    if (!gjk_finish(g, q, tf1, 0.f, 0.f, g0, o, seed) || seed.rank != 4) continue;
+    ++checked;
+    std::memset(&blk_a, 0xA5, sizeof(blk_a));
+    std::memset(&blk_b, 0xA5, sizeof(blk_b));
+    E ea;
+    ea.reset(&blk_a, q.epa_max_iterations, q.epa_tolerance);
+    for (int k = 0; k < 4; ++k) ea.set_vert(k, seed.w[k], seed.w0[k], -1 - k);
+    NoSupportTagged ns;
+    EpaResult<float> res;
+    const int closest_a = ea.begin(seed.rank, -seed.guess, ns, res, ZeroTags());
+    EpaReady<float> rb;
+    int flags[4], closest_b = 0;
+    const bool live = epa_prepare_tetrahedron(seed.w, q.epa_tolerance, rb.vw, rb.fn, flags, closest_b);
+    if (!live || closest_a == EPA_NULL) {
+      ++*fallbacks;
+      if (live != (closest_a != EPA_NULL)) ++*mismatches;
+      continue;
+    }
+    rb.packed = uint32_t(closest_b) << 12;
+    for (int f = 0; f < 4; ++f) rb.packed |= uint32_t((flags[f] >> 1) & 1) << (14 + f);
+    E eb;
+    eb.reset(&blk_b, q.epa_max_iterations, q.epa_tolerance);
+    const int closest_i = eb.install(&rb, rb.packed);
+    bool same = closest_i == closest_a && ea.status == eb.status && ea.num_vertices == eb.num_vertices && ea.hull_count == eb.hull_count &&
+                ea.stock_top == eb.stock_top && ea.stamp == eb.stamp && ea.hw == eb.hw && ea.pending_release == eb.pending_release;
+    same = same && std::memcmp(blk_a.vw, blk_b.vw, 4 * sizeof(Quad<float>)) == 0 && std::memcmp(blk_a.fn, blk_b.fn, 4 * sizeof(Quad<float>)) == 0 &&
+           std::memcmp(blk_a.ft, blk_b.ft, 4 * sizeof(FaceTopo)) == 0;
+    // the part of the stock that is still in use, and the flags of the unused faces
+    same = same && std::memcmp(blk_a.stock, blk_b.stock, size_t(ea.stock_top)) == 0;
+    for (int f = 4; f < 2 * CAP + 4; ++f) same = same && blk_a.ft[f].flag() == blk_b.ft[f].flag();
+    if (!same) ++*mismatches;
+  }
+  return checked;
+}
+
 }  // extern "C"
 
 // BVHModel<OBBRSS> collide through the device headers' BV test / leaf test with a serial DFS
