@@ -59,7 +59,8 @@ constexpr int CTR_SHAPE_DIST_SUSP = 2 * B_COUNT + 7;  // ... mesh x solid (Shape
 constexpr int CTR_DIST_TICKET = 2 * B_COUNT + 8;  // ticket of k_bvh_distance_pool: next DistSusp record to take
 constexpr int CTR_SHAPE_DIST_TICKET = 2 * B_COUNT + 9;  // ticket of k_bvh_shape_distance_pool
 constexpr int CTR_EPA_READY = 2 * B_COUNT + 10;  // blocks k_epa_prepare handed to k_epa_loop (EpaReady records)
-constexpr int N_COUNTERS = 2 * B_COUNT + 11;  // bucket populations + the four counters of Work::counts + curved populations + those
+constexpr int CTR_EPA_CC_OVER = 2 * B_COUNT + 11;  // ... and those of them k_epa_loop saved for k_epa_resume_cc
+constexpr int N_COUNTERS = 2 * B_COUNT + 12;  // bucket populations + the four counters of Work::counts + curved populations + those
 
 // Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
 // support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
@@ -175,6 +176,8 @@ struct Work {
   uint32_t shape_defer_cap;  // a unit (query, or task of a split walk) queues at most one item: sized by the host for every unit a batch can make
   void* shape_oq;     // ObbQuery<T>[n], by pair: the solid's fitted OBB against the mesh pose (k_shape_obb)
   void* epa_ready;    // EpaReady<T>[n]: convex x convex polytopes between k_epa_prepare, k_epa_loop and k_epa_records (nullptr: the one-kernel form)
+  uint32_t* epa_cc_over;  // blocks of epa_ready whose polytope k_epa_loop saved for k_epa_resume_cc, slot i <-> slot cc_resume_base + i of epa_resume
+  uint32_t cc_resume_base, cc_resume_cap;
 };
 // a pair with a shape whose support is not a vertex
 __host__ __device__ inline bool curved_pair(int k1, int k2) {
@@ -579,6 +582,19 @@ struct LaneGroup {
     __builtin_amdgcn_wave_barrier();
   }
   static __device__ __forceinline__ uint32_t atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }  // LDS (ds_add_rtn)
+  // the lanes of this group for which `pred` holds, as bits of the wave's ballot ...
+  static __device__ __forceinline__ uint64_t group_bits(bool pred) {
+    const uint64_t mine = (W_ == 64 ? ~uint64_t(0) : ((uint64_t(1) << (W_ & 63)) - 1u)) << ((threadIdx.x & 63) & ~(W_ - 1));
+    return __ballot(pred) & mine;
+  }
+  // ... as a mask of the group (bit = lane in group) ...
+  static __device__ __forceinline__ uint64_t ballot(bool pred) { return group_bits(pred) >> ((threadIdx.x & 63) & ~(W_ - 1)); }
+  // ... and counted: below the calling lane, in the whole group
+  static __device__ __forceinline__ void count(bool pred, int& below, int& total) {
+    const uint64_t b = group_bits(pred);
+    below = int(__builtin_amdgcn_mbcnt_hi(uint32_t(b >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(b), 0u)));
+    total = __popcll(b);
+  }
 };
 
 // Capacity (iterations) of the fast tier's block.  fp32: 17 -- the convex x convex form (k_epa_stream<.., CC>) then has
@@ -614,6 +630,9 @@ constexpr int EPA_WE2 = HFCL_EPA_WE2;  // lanes per polytope in the full-capacit
 #define HFCL_EPA_WE2_64 32  // fp64: 2 polytopes x 8.6 KB per wave = two waves per SIMD (16 lanes: 4 polytopes, 34 KB, one wave); cfg5 k_epa<full> 0.445 -> 0.35 ms
 #endif
 template <typename T> constexpr int epa_we2 = sizeof(T) == 4 ? HFCL_EPA_WE2 : HFCL_EPA_WE2_64;
+#ifndef HFCL_EPA_CC_RESUME_WE
+#define HFCL_EPA_CC_RESUME_WE 32  // lanes per polytope of k_epa_resume_cc (hfcl_k_epa.hip)
+#endif
 
 // ---------------------------------------------------------------------------------------
 // k_bvh_collide: BVHModel<OBBRSS> x BVHModel<OBBRSS> collide().

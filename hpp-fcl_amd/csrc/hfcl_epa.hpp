@@ -146,6 +146,12 @@ struct SerialGroup {
   template <int M, class X> static HFCL_HD X exchange(X v) { return v; }
   static HFCL_HD void sync() {}
   static HFCL_HD uint32_t atomic_inc(uint32_t* p) { return (*p)++; }
+  // the lanes of the group for which `pred` holds: as a mask (bit = lane in group), and counted (below the caller / in all)
+  static HFCL_HD uint64_t ballot(bool pred) { return pred ? 1u : 0u; }
+  static HFCL_HD void count(bool pred, int& below, int& total) {
+    below = 0;
+    total = pred ? 1 : 0;
+  }
 };
 
 template <typename T>
@@ -231,7 +237,9 @@ struct alignas(16) EpaReady {
   Quad<T> vw[4];            // vertex records of the oriented tetrahedron (w: tag)
   Quad<T> fn[4];            // face planes
   uint32_t state;           // EPA_READY_*
-  uint32_t pad_[3];
+  uint32_t pair;            // the query ...
+  uint32_t gjk_iters;       // ... and what its record says about GJK
+  uint32_t pad_;
 };
 template <typename T>
 struct __attribute__((may_alias)) EpaLoopOut {  // overlays EpaReady::md .. (the loop is over: the block's pose and vertices are no longer needed)
@@ -315,11 +323,16 @@ HFCL_HD bool epa_prepare_tetrahedron(const V3<T>* w, T tolerance, Quad<T>* vw, Q
 #ifndef HFCL_EPA_PAR_HZ
 #define HFCL_EPA_PAR_HZ 1
 #endif
+#ifndef HFCL_EPA_FLAT
+#define HFCL_EPA_FLAT 1  // find_closest_face_flat in the fp32 convex x convex fast tier (k_epa_loop 0.975 -> 0.961 ms; the horizon search built the same way -- ballots instead of pass marks and LDS atomics -- is 3 % slower: profiles/r05_b)
+#endif
 template <typename T, class Grp, int CAP = EPA_MAX_ITER, int V0M = V0_BLOCK>
 struct Epa {
   static constexpr bool TAGGED = V0M == V0_TAG;
   static constexpr bool PARALLEL_HORIZON = sizeof(T) == 4 && (HFCL_EPA_PAR_HZ >= 2 || (HFCL_EPA_PAR_HZ == 1 && V0M == V0_TAG));
   typedef EpaScratch<T, CAP, V0M> Block;
+  // The branch-free form of the closest-face scan (find_closest_face_flat): the small blocks of the fp32 convex x convex fast tier.
+  static constexpr bool FLAT_CF = PARALLEL_HORIZON && HFCL_EPA_FLAT && EpaScratch<T, CAP, V0M>::NF <= 64;
   Block* m;
   Quad<T>* v0p;  // m->v0, or the caller's array (V0_EXTERN); unused with tags
   T tolerance;
@@ -460,7 +473,76 @@ struct Epa {
   // The same scan also releases the faces the last expansion made obsolete (pending_release = their pass
   // mark): they go back to the stock through a group-shared counter, in no particular order (slot
   // numbers never influence a result, ties are decided by the stamps).
+  // The same scan without a branch or an LDS atomic: every lane loads its share of the block's slots at once (the trip count
+  // of the loop above differs from group to group of a wave and each trip is two dependent LDS round trips), decides with
+  // selects, and the released faces find their stock slots by counting (Grp::count) -- in the order the atomic hands them
+  // out, slot j * W + lane ascending.  A lane without a face to release stores into a byte of the walk stack nobody reads.
+  HFCL_HD int find_closest_face_flat() {
+    const int rel = pending_release;
+    pending_release = -1;
+    Grp::sync();
+    const int nf = hw;
+    constexpr int PER_LANE = (Block::NF + Grp::W - 1) / Grp::W;
+    uint8_t* const dummy = reinterpret_cast<uint8_t*>(m->stack) + Grp::lane();
+    FaceTopo t[PER_LANE];
+    T dist[PER_LANE];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < PER_LANE; ++j) {
+      const int f = Grp::lane() + j * Grp::W;
+      const int fc = f < nf ? f : 0;
+      t[j] = m->ft[fc];
+      dist[j] = m->fn[fc].w;
+    }
+    T best = Lim<T>::max();
+    int best_stamp = -1, best_f = EPA_NULL;
+    int head_stamp = -1, head_f = EPA_NULL;
+    int released = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < PER_LANE; ++j) {
+      const int f = Grp::lane() + j * Grp::W;
+      const int fl = t[j].flag();
+      const bool in_hull = f < nf && (fl & 1);
+      const bool release = in_hull && rel >= 0 && t[j].pass() == rel;
+      int below, total;
+      Grp::count(release, below, total);
+      *(release ? topo_bytes(m->ft[f], 0) + 3 : dummy) = uint8_t(0);  // set_flag(f, 0)
+      *(release ? &m->stock[stock_top + released + below] : dummy) = uint8_t(f);
+      released += total;
+      const bool cand = in_hull && !release;
+      const int st = t[j].stamp();
+      const bool th = cand && st > head_stamp;
+      head_stamp = th ? st : head_stamp;
+      head_f = th ? f : head_f;
+      const T sq = dist[j] * dist[j];
+      const bool take = cand && !(fl & 2) && (sq < best || (sq == best && st > best_stamp && best_f != EPA_NULL));
+      best = take ? sq : best;
+      best_stamp = take ? st : best_stamp;
+      best_f = take ? f : best_f;
+    }
+    butterfly_stages<Grp::W>([&](auto stage) {
+      constexpr int M = decltype(stage)::value;
+      const T ob = Grp::template exchange<M>(best);
+      const int os = Grp::template exchange<M>(best_stamp), of = Grp::template exchange<M>(best_f);
+      const int ohs = Grp::template exchange<M>(head_stamp), ohf = Grp::template exchange<M>(head_f);
+      const bool take = (of != EPA_NULL) && (best_f == EPA_NULL || ob < best || (ob == best && os > best_stamp));
+      best = take ? ob : best;
+      best_stamp = take ? os : best_stamp;
+      best_f = take ? of : best_f;
+      const bool th = ohs > head_stamp;
+      head_stamp = th ? ohs : head_stamp;
+      head_f = th ? ohf : head_f;
+    });
+    stock_top += released;
+    hull_count -= released;
+    return best_f != EPA_NULL ? best_f : head_f;
+  }
+
   HFCL_HD int find_closest_face() {
+    if constexpr (FLAT_CF) return find_closest_face_flat();
     const int rel = pending_release;
     pending_release = -1;
     if (rel >= 0 && Grp::lane() == 0) m->top = uint32_t(stock_top);
@@ -1097,9 +1179,9 @@ struct Epa {
 
   // Continue a polytope saved by a tier with capacity CAP_SRC in this (already reset()) block: vertices and
   // faces keep their indices, the extra faces of the larger block join the stock.
+  // (a V0_TAG block continues a V0_TAG block: the vertex records keep their tags and the saved coordinates are not read)
   template <int CAP_SRC>
   HFCL_HD EpaHeader load(const EpaSaved<T, CAP_SRC>* saved) {
-    static_assert(V0M != V0_TAG, "a continued polytope keeps its support points as coordinates");
     typedef EpaScratch<T, CAP_SRC, V0_TAG> Src;
     const Src* src = &saved->blk;
     const EpaHeader h = src->hdr;
@@ -1108,8 +1190,12 @@ struct Epa {
 #endif
     for (int i = Grp::lane(); i < h.num_vertices; i += Grp::W) {
       const Quad<T> q = src->vw[i];
-      m->vw[i] = Quad<T>{q.x, q.y, q.z, T(0)};
-      v0p[i] = saved->v0[i];
+      if constexpr (V0M == V0_TAG) {
+        m->vw[i] = q;
+      } else {
+        m->vw[i] = Quad<T>{q.x, q.y, q.z, T(0)};
+        v0p[i] = saved->v0[i];
+      }
     }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
@@ -1136,7 +1222,8 @@ struct Epa {
 
 // Group-cooperative copy of a resumable polytope (scratch block incl. its header) to `dst`, with the shape-0 support
 // points of its vertices written out as coordinates (`tags`: int -> V3, V0_TAG blocks only; V0_BLOCK blocks carry them).
-template <typename T, class Grp, int CAP, int V0M, class Tags = NoTags>
+// KEEP_TAGS (V0_TAG blocks): the continuing tier works with tags as well -- nothing but the block is written.
+template <typename T, class Grp, int CAP, int V0M, class Tags = NoTags, bool KEEP_TAGS = false>
 HFCL_HD void epa_save_block(const EpaScratch<T, CAP, V0M>* block, EpaSaved<T, CAP>* dst, const Tags& tags = Tags()) {
   static_assert(V0M != V0_EXTERN, "only the fast tiers hand polytopes over");
   Grp::sync();
@@ -1151,16 +1238,18 @@ HFCL_HD void epa_save_block(const EpaScratch<T, CAP, V0M>* block, EpaSaved<T, CA
 #pragma unroll 1
 #endif
   for (int i = Grp::lane(); i < int(sizeof(Tail) / 4); i += Grp::W) d[i] = src[i];
-  const int nv = block->hdr.num_vertices;  // the records beyond hold whatever the LDS held before: no tags to resolve
+  if constexpr (!KEEP_TAGS) {
+    const int nv = block->hdr.num_vertices;  // the records beyond hold whatever the LDS held before: no tags to resolve
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-  for (int i = Grp::lane(); i < nv; i += Grp::W) {
-    if constexpr (V0M == V0_TAG) {
-      const V3<T> p = tags(int(block->vw[i].w));
-      dst->v0[i] = Quad<T>{p.x, p.y, p.z, T(0)};
-    } else {
-      dst->v0[i] = block->v0[i];
+    for (int i = Grp::lane(); i < nv; i += Grp::W) {
+      if constexpr (V0M == V0_TAG) {
+        const V3<T> p = tags(int(block->vw[i].w));
+        dst->v0[i] = Quad<T>{p.x, p.y, p.z, T(0)};
+      } else {
+        dst->v0[i] = block->v0[i];
+      }
     }
   }
 }

@@ -94,8 +94,12 @@ struct hfcl_lib {
   uint32_t* d_counts = nullptr;
   void* d_epa_queue = nullptr;
   void* d_epa_queue2 = nullptr;
+  uint32_t* d_epa_cc_over = nullptr;  // Work::epa_cc_over (resume_cap entries)
+  hipStream_t aux = nullptr;     // k_epa_records runs here, beside the tiers that continue the handed-over polytopes
+  hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr;
   void* d_epa_ready = nullptr;   // EpaReady<float>[epa_ready_capacity]: the staged convex x convex fast tier (k_epa_prepare / k_epa_loop / k_epa_records)
   size_t epa_ready_capacity = 0;
+  bool records_aside = true;     // HFCL_EPA_RECORDS_ASIDE=0: k_epa_records on the batch's stream
   bool epa_cc_staged = true;     // HFCL_EPA_CC_STAGED=0: the one-kernel form (k_epa_stream<.., CC>)
   size_t epa_cc_staged_min = 32768;  // ... which batches below this many pairs keep (two launches less); HFCL_EPA_CC_STAGED_MIN
   void* d_epa_resume = nullptr;
@@ -459,6 +463,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_CLOSED_STAGED")) lib->closed_staged = atoi(v) != 0;
   if (const char* v = getenv("HFCL_SPLIT")) lib->split = atoi(v) >= 2 ? 2 : (atoi(v) == 1 ? 1 : 0);
   if (const char* v = getenv("HFCL_EPA_CC_STAGED")) lib->epa_cc_staged = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_EPA_RECORDS_ASIDE")) lib->records_aside = atoi(v) != 0;
   if (const char* v = getenv("HFCL_EPA_CC_STAGED_MIN")) lib->epa_cc_staged_min = size_t(std::max(0ll, atoll(v)));
   if (const char* v = getenv("HFCL_PIPE_CHUNK")) lib->pipe_chunk = strtoull(v, nullptr, 10);
   if (const char* v = getenv("HFCL_BVH_FILTER")) lib->bvh_filter = atoi(v) != 0;
@@ -520,6 +525,10 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_epa_queue);
   hipFree(lib->d_epa_queue2);
   hipFree(lib->d_epa_ready);
+  hipFree(lib->d_epa_cc_over);
+  if (lib->aux) hipStreamDestroy(lib->aux);
+  if (lib->ev_aux0) hipEventDestroy(lib->ev_aux0);
+  if (lib->ev_aux1) hipEventDestroy(lib->ev_aux1);
   hipFree(lib->d_epa_resume);
   hipFree(lib->d_epa_v0);
   hipFree(lib->d_shape_defer);
@@ -711,9 +720,11 @@ static int ensure_workspace(hfcl_lib* lib, size_t n, bool need_epa) {
     hipFree(lib->d_epa_queue);
     hipFree(lib->d_epa_queue2);
     hipFree(lib->d_epa_resume);
+    hipFree(lib->d_epa_cc_over);
     lib->d_epa_queue = nullptr;
     lib->d_epa_queue2 = nullptr;
     lib->d_epa_resume = nullptr;
+    lib->d_epa_cc_over = nullptr;
     lib->resume_cap = 0;
     lib->epa_capacity = 0;
     const size_t cap = lib->ws_capacity;
@@ -724,6 +735,7 @@ static int ensure_workspace(hfcl_lib* lib, size_t n, bool need_epa) {
     size_t rcap = std::min(cap, std::max<size_t>(65536, cap / 8));
     if (const char* e = getenv("HFCL_EPA_RESUME_SLOTS")) rcap = std::max<size_t>(1, std::min<size_t>(cap, strtoull(e, nullptr, 10)));  // test knob
     HIP_TRY(hipMalloc(&lib->d_epa_resume, rcap * std::max(epa_resume_stride<double>, epa_resume_stride<float>)));
+    HIP_TRY(hipMalloc((void**)&lib->d_epa_cc_over, rcap * sizeof(uint32_t)));
     lib->resume_cap = rcap;
     lib->epa_capacity = cap;
   }
@@ -1073,6 +1085,13 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
   wk.shape_defer_cap = 0;
   wk.shape_oq = nullptr;
   wk.epa_ready = nullptr;
+  wk.epa_cc_over = lib->d_epa_cc_over;
+  // fp32 slots are shorter than the area's stride (the fp64 slot): the slots past resume_cap are the convex x convex tier's own
+  wk.cc_resume_base = wk.resume_cap;
+  {
+    const size_t fslots = lib->resume_cap * std::max(epa_resume_stride<double>, epa_resume_stride<float>) / epa_resume_stride<float>;
+    wk.cc_resume_cap = std::is_same<T, float>::value && fslots > lib->resume_cap ? uint32_t(std::min<size_t>(fslots - lib->resume_cap, lib->resume_cap)) : 0u;
+  }
   LibView<T> lv;
   lv.shapes = std::is_same<T, double>::value ? (const DShape<T>*)lib->d_shapes64 : (const DShape<T>*)lib->d_shapes32;
   lv.verts = std::is_same<T, double>::value ? (const T*)lib->d_verts64 : (const T*)lib->d_verts32;
@@ -1328,16 +1347,49 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     }
     launch_epa_fast<T>(epa_batches, st, wk, lv, io, q, may(B_CC) && !cc_staged, may(B_PRIM) || may(B_PC) || may(B_CP), lib->n_cus, lib->has_curved);
     tend();
+    bool tail_done = false;
     if constexpr (std::is_same<T, float>::value) {
       if (cc_staged) {
-        tbeg("k_epa_records");
-        launch_epa_records(blocks_for(n / 4 + 1, 256), st, wk, lv, io, q);
+        // Three kernels end the batch: the records of the finished polytopes (bound by memory), the continuation of the handed-over ones
+        // and the general full-capacity tier (each as long as its longest chain of iterations, with a few thousand waves).  The first and
+        // the last run on a stream of their own beside the second.
+        if (!lib->aux && lib->records_aside) {
+          HIP_TRY(hipStreamCreateWithFlags(&lib->aux, hipStreamNonBlocking));
+          HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux0, hipEventDisableTiming));
+          HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux1, hipEventDisableTiming));
+        }
+        hipStream_t rs = lib->records_aside ? lib->aux : st;
+        if (lib->records_aside) {
+          HIP_TRY(hipEventRecord(lib->ev_aux0, st));
+          HIP_TRY(hipStreamWaitEvent(rs, lib->ev_aux0, 0));
+        }
+        auto tbeg_on = [&](const char* name, hipStream_t s) {
+          if (!lib->kernel_timing) return;
+          t = timer_slot(lib, ti++, name);
+          hipEventRecord(t->e0, s);
+        };
+        auto tend_on = [&](hipStream_t s) {
+          if (lib->kernel_timing) hipEventRecord(t->e1, s);
+        };
+        tbeg_on("k_epa_records", rs);
+        launch_epa_records(blocks_for(n / 4 + 1, 256), rs, wk, lv, io, q);
+        tend_on(rs);
+        tbeg_on("k_epa<full>", rs);
+        launch_epa_full<T>(blocks_for(n / 16 + 1, 64 / epa_we2<T>), rs, wk, lv, io, q);
+        tend_on(rs);
+        if (lib->records_aside) HIP_TRY(hipEventRecord(lib->ev_aux1, rs));
+        tbeg("k_epa_resume_cc");
+        launch_epa_resume_cc(blocks_for(n / 16 + 1, 64 / HFCL_EPA_CC_RESUME_WE), st, wk, lv, io, q);
         tend();
+        if (lib->records_aside) HIP_TRY(hipStreamWaitEvent(st, lib->ev_aux1, 0));
+        tail_done = true;
       }
     }
-    tbeg("k_epa<full>");
-    launch_epa_full<T>(blocks_for(n / 16 + 1, 64 / epa_we2<T>), st, wk, lv, io, q);
-    tend();
+    if (!tail_done) {
+      tbeg("k_epa<full>");
+      launch_epa_full<T>(blocks_for(n / 16 + 1, 64 / epa_we2<T>), st, wk, lv, io, q);
+      tend();
+    }
   }
   // last: a launch of a few waves that, between the GJK and the EPA kernels, only waited for a free CU while the other
   // half of a split batch had the chip (0.2 ms of this stream's timeline on cfg5)
@@ -1379,6 +1431,7 @@ static hfcl_lib* make_helper(hfcl_lib* lib) {
   h->cvx_w = lib->cvx_w;
   h->closed_staged = lib->closed_staged;
   h->epa_cc_staged = lib->epa_cc_staged;
+  h->records_aside = lib->records_aside;
   h->epa_cc_staged_min = lib->epa_cc_staged_min;
   h->n_cus = lib->n_cus;
   bool ok = hipMalloc(&h->d_counts, N_COUNTERS * sizeof(uint32_t)) == hipSuccess;

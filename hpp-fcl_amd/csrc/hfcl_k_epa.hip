@@ -367,7 +367,9 @@ __global__ void __launch_bounds__(256) k_epa_prepare(Work wk, LibView<T> lib, IO
           rb.md[6] = md.oR1.r2.x; rb.md[7] = md.oR1.r2.y; rb.md[8] = md.oR1.r2.z;
           rb.md[9] = md.ot1.x; rb.md[10] = md.ot1.y; rb.md[11] = md.ot1.z;
           rb.state = EPA_READY_PENDING;
-          rb.pad_[0] = rb.pad_[1] = rb.pad_[2] = 0u;
+          rb.pair = pair;
+          rb.gjk_iters = ip->gjk_iters;
+          rb.pad_ = 0u;
         } else {  // FallBack (:1299-1315): final without a loop
           EpaResult<T> res;
           res.status = EPA_FALLBACK;
@@ -388,11 +390,19 @@ __global__ void __launch_bounds__(256) k_epa_prepare(Work wk, LibView<T> lib, IO
 }
 
 #ifndef HFCL_EPA_LOOP_REFILL_MIN
-#define HFCL_EPA_LOOP_REFILL_MIN 2  // a refill is cheap here: idle groups wait for fewer companions than in k_epa_stream
+#define HFCL_EPA_LOOP_REFILL_MIN 2  // a refill is cheap here: idle groups wait for fewer companions than in k_epa_stream (1: the same, 3: 4 % slower; profiles/r05_a)
 #endif
-#ifndef HFCL_EPA_LOOP_TICKETS
-#define HFCL_EPA_LOOP_TICKETS 0  // 1: waves draw their blocks from a ticket counter instead of a static share (A/B)
+#ifndef HFCL_EPA_LOOP_ROUNDS
+#define HFCL_EPA_LOOP_ROUNDS 1  // persistent grid = this many times the resident waves (1 / 2 / 3: 0.979 / 0.994 / 1.016 ms; profiles/r05_a)
 #endif
+#ifndef HFCL_EPA_CC_RESUME
+#define HFCL_EPA_CC_RESUME 1  // polytopes that outgrow the block are continued by k_epa_resume_cc (0: by the general full-capacity tier)
+#endif
+// the part of the hand-over area the convex x convex polytopes of k_epa_loop are saved in (EpaSaved<T, EPA_FAST_CAP> blocks, tags kept)
+template <typename T>
+__device__ __forceinline__ EpaSaved<T, EPA_FAST_CAP>* cc_resume_slot(const Work& wk, uint32_t slot) {
+  return resume_slot<T, EPA_FAST_CAP>(wk, wk.cc_resume_base + slot);
+}
 template <typename T, int WE, int CAP>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_EPA32_CC, 8)))
 k_epa_loop(Work wk, LibView<T> lib, QParams<T> q) {
@@ -407,8 +417,6 @@ k_epa_loop(Work wk, LibView<T> lib, QParams<T> q) {
   enum { IDLE = 0, LIVE = 1, DONE = 2, HANDOVER = 3 };
   int state = IDLE;
   uint32_t it = 0;             // block of this group's polytope
-  uint32_t voff_a = 0;         // ... and what its hand-over needs: hull a's vertices, its seed
-  uint32_t seed_slot = 0;
   uint32_t next = blockIdx.x;  // wave-uniform: the wave's blocks are next, next + gridDim.x, ...
   EpaSupportCC<T, WE> sup;
   sup.lig = lig;
@@ -430,19 +438,25 @@ k_epa_loop(Work wk, LibView<T> lib, QParams<T> q) {
               *reinterpret_cast<EpaLoopOut<T>*>(rb->md) = o;
               rb->state = EPA_READY_DONE;
             }
-          } else {  // hand over to the full-capacity tier: the seed and, room permitting, the polytope itself
-            const EpaItem<T>* ip = queue + (wk.n - 1u - seed_slot);
-            uint32_t slot = 0;
-            if (lig == 0) slot = atomicAdd(&wk.counts[B_COUNT + 1], 1u);
-            slot = __shfl(slot, 0, WE);
-            const bool save = epa.resumable && slot < wk.resume_cap;
-            if (save) epa_save_block<T, Grp, CAP>(&scratch[grp], resume_slot<T, CAP>(wk, slot), SeedTags<T>{lib.verts + 3 * size_t(voff_a), ip});
-            if (lig == 0) {  // queue to queue, no local copy
-              EpaItem<T>* dst = reinterpret_cast<EpaItem<T>*>(wk.epa_queue2) + slot;
-              *dst = *ip;
-              if (save) dst->rank = ip->rank | EPA_RESUME_FLAG | (CAP != epa_fast_cap<T> ? EPA_RESUME_SMALL : 0);
-              rb->state = EPA_READY_HANDED_OVER;
+          } else {
+            // the polytope outgrew the block: saved as it is (tags kept) for k_epa_resume_cc; without room in the hand-over area,
+            // or when it cannot be continued, its seed goes to the general full-capacity tier
+            uint32_t slot = 0xFFFFFFFFu;
+            if (HFCL_EPA_CC_RESUME && epa.resumable) {
+              if (lig == 0) slot = atomicAdd(&wk.counts[CTR_EPA_CC_OVER], 1u);
+              slot = __shfl(slot, 0, WE);
             }
+            if (slot < wk.cc_resume_cap) {  // (slots past the area are never read: k_epa_resume_cc clamps the count)
+              epa_save_block<T, Grp, CAP, V0_TAG, NoTags, true>(&scratch[grp], cc_resume_slot<T>(wk, slot));
+              if (lig == 0) wk.epa_cc_over[slot] = it;
+            } else {
+              if (lig == 0) {  // queue to queue, no local copy
+                const EpaItem<T>* ip = queue + (wk.n - 1u - rb->seed);
+                const uint32_t s2 = atomicAdd(&wk.counts[B_COUNT + 1], 1u);
+                reinterpret_cast<EpaItem<T>*>(wk.epa_queue2)[s2] = *ip;
+              }
+            }
+            if (lig == 0) rb->state = EPA_READY_HANDED_OVER;
           }
           Grp::sync();
           state = IDLE;
@@ -454,9 +468,7 @@ k_epa_loop(Work wk, LibView<T> lib, QParams<T> q) {
         if (it < cnt) {
           const EpaReady<T>* rb = ready + it;
           const uint32_t packed = rb->packed;
-          seed_slot = rb->seed;
-          voff_a = rb->voff_a;
-          sup.h0.load(lib.verts + 3 * size_t(voff_a), packed & 63u, lig);
+          sup.h0.load(lib.verts + 3 * size_t(rb->voff_a), packed & 63u, lig);
           sup.h1.load(lib.verts + 3 * size_t(rb->voff_b), (packed >> 6) & 63u, lig);
           sup.md.oR1.r0 = mk<T>(rb->md[0], rb->md[1], rb->md[2]);
           sup.md.oR1.r1 = mk<T>(rb->md[3], rb->md[4], rb->md[5]);
@@ -482,6 +494,51 @@ k_epa_loop(Work wk, LibView<T> lib, QParams<T> q) {
   }
 }
 
+// The polytopes k_epa_loop saved, continued in blocks of the reference's capacity by the same code -- tags, register hulls, the
+// parallel horizon --, WE lanes each (the general full-capacity tier, k_epa<.., 2>, is built for any pair of kinds, walks the
+// silhouette and steps four polytopes of 16 lanes in lockstep: 8 us per iteration where this one takes ~3; the hand-overs are two
+// polytopes in a hundred and their kernel is as long as its longest chain of iterations).
+template <typename T, int WE>
+__global__ void __launch_bounds__(64) k_epa_resume_cc(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
+  constexpr int G = 64 / WE, CAP = EPA_MAX_ITER;
+  typedef LaneGroup<WE> Grp;
+  __shared__ EpaScratch<T, CAP, V0_TAG> scratch[G];
+  const uint32_t cnt = min(wk.counts[CTR_EPA_CC_OVER], wk.cc_resume_cap);
+  const int lane = threadIdx.x & 63, grp = lane / WE, lig = lane & (WE - 1);
+  const EpaReady<T>* const ready = reinterpret_cast<const EpaReady<T>*>(wk.epa_ready);
+  const EpaItem<T>* const queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
+  for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += gridDim.x * G) {
+    const uint32_t idx = wk.epa_cc_over[it];
+    if (idx == 0xFFFFFFFFu) continue;
+    const EpaReady<T>* rb = ready + idx;
+    const uint32_t packed = rb->packed, pair = rb->pair;
+    EpaSupportCC<T, WE> sup;
+    sup.lig = lig;
+    const T* va = lib.verts + 3 * size_t(rb->voff_a);
+    sup.h0.load(va, packed & 63u, lig);
+    sup.h1.load(lib.verts + 3 * size_t(rb->voff_b), (packed >> 6) & 63u, lig);
+    sup.md.oR1.r0 = mk<T>(rb->md[0], rb->md[1], rb->md[2]);
+    sup.md.oR1.r1 = mk<T>(rb->md[3], rb->md[4], rb->md[5]);
+    sup.md.oR1.r2 = mk<T>(rb->md[6], rb->md[7], rb->md[8]);
+    sup.md.ot1 = mk<T>(rb->md[9], rb->md[10], rb->md[11]);
+    sup.md.identity = (packed >> 18) & 1u;
+    const SeedTags<T> tags{va, queue + (wk.n - 1u - rb->seed)};
+    const T r0 = swept_radius(lib.shapes[wk.shape1[pair]]), r1 = swept_radius(lib.shapes[wk.shape2[pair]]);
+    Epa<T, Grp, CAP, V0_TAG> epa;
+    epa.reset(&scratch[grp], q.epa_max_iterations, q.epa_tolerance);
+    const EpaHeader h = epa.template load<EPA_FAST_CAP>(cc_resume_slot<T>(wk, it));
+    EpaResult<T> res;
+    epa.run_loop(h.closest, h.iterations, h.pass, r0 + r1, sup, res, tags);
+    PairOut<T> o;
+    epa_finish(res, rb->gjk_iters, load_pose(io.tf1, pair), r0, r1, o);
+    if (lig == 0) {
+      write_out<T>(io, q, pair, o);
+      write_guess<T>(io, pair, o.cached_guess, 0, 0);
+    }
+    Grp::sync();
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_epa_records(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
   const uint32_t cnt = wk.counts[CTR_EPA_READY];
@@ -489,11 +546,10 @@ __global__ void __launch_bounds__(256) k_epa_records(Work wk, LibView<T> lib, IO
   const EpaItem<T>* const queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
     const EpaReady<T>* rb = ready + i;
-    if (rb->state != EPA_READY_DONE) continue;  // handed over: the full-capacity tier writes the record
+    if (rb->state != EPA_READY_DONE) continue;  // handed over: the tier that continues the polytope writes the record
     const EpaLoopOut<T>* lo = reinterpret_cast<const EpaLoopOut<T>*>(rb->md);
-    const EpaItem<T>* ip = queue + (wk.n - 1u - rb->seed);
-    const uint32_t pair = ip->pair;
-    const SeedTags<T> tags{lib.verts + 3 * size_t(rb->voff_a), ip};
+    const uint32_t pair = rb->pair;
+    const SeedTags<T> tags{lib.verts + 3 * size_t(rb->voff_a), queue + (wk.n - 1u - rb->seed)};
     const T r0 = swept_radius(lib.shapes[wk.shape1[pair]]), r1 = swept_radius(lib.shapes[wk.shape2[pair]]);
     EpaResult<T> res;
     res.status = lo->status;
@@ -507,7 +563,7 @@ __global__ void __launch_bounds__(256) k_epa_records(Work wk, LibView<T> lib, IO
     res.r01 = tags(lo->tag[1]);
     res.r02 = tags(lo->tag[2]);
     PairOut<T> o;
-    epa_finish(res, ip->gjk_iters, load_pose(io.tf1, pair), r0, r1, o);
+    epa_finish(res, rb->gjk_iters, load_pose(io.tf1, pair), r0, r1, o);
     write_out<T>(io, q, pair, o);
     write_guess<T>(io, pair, o.cached_guess, 0, 0);
   }
@@ -575,7 +631,10 @@ void launch_epa_prepare(int grid, hipStream_t st, const Work& wk, const LibView<
 }
 void launch_epa_loop(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const QParams<float>& q, int n_cus) {
   static const int per_cu = resident_blocks_per_cu(k_epa_loop<float, EPA_WE, EPA_FAST_CAP>);
-  hipLaunchKernelGGL((k_epa_loop<float, EPA_WE, EPA_FAST_CAP>), dim3(std::min(grid, n_cus * per_cu * HFCL_EPA_GRID_ROUNDS)), dim3(64), 0, st, wk, lv, q);
+  hipLaunchKernelGGL((k_epa_loop<float, EPA_WE, EPA_FAST_CAP>), dim3(std::min(grid, n_cus * per_cu * HFCL_EPA_LOOP_ROUNDS)), dim3(64), 0, st, wk, lv, q);
+}
+void launch_epa_resume_cc(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q) {
+  hipLaunchKernelGGL((k_epa_resume_cc<float, HFCL_EPA_CC_RESUME_WE>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
 }
 void launch_epa_records(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q) {
   hipLaunchKernelGGL((k_epa_records<float>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);

@@ -56,6 +56,7 @@ template <typename T> void launch_epa_fast(int grid, hipStream_t st, const Work&
 // the fp32 convex x convex fast tier in three stages (Work::epa_ready set): one lane per polytope before and after the loop kernel
 void launch_epa_prepare(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q);
 void launch_epa_loop(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const QParams<float>& q, int n_cus);
+void launch_epa_resume_cc(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q);
 void launch_epa_records(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q);
 template <typename T> void launch_epa_full(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q);
 

@@ -246,9 +246,59 @@ struct ZeroTags {
   V3<float> operator()(int) const { return mk<float>(0.f, 0.f, 0.f); }
 };
 }  // namespace
+static bool epa_prepare_check_one(const EpaSeed<float>& seed, const QParams<float>& q, long* fallbacks, float* feat) {
+  constexpr int CAP = 17;
+  typedef Epa<float, SerialGroup<1>, CAP, V0_TAG> E;
+  static EpaScratch<float, CAP, V0_TAG> blk_a, blk_b;
+  std::memset(&blk_a, 0xA5, sizeof(blk_a));
+  std::memset(&blk_b, 0xA5, sizeof(blk_b));
+  E ea;
+  ea.reset(&blk_a, q.epa_max_iterations, q.epa_tolerance);
+  for (int k = 0; k < 4; ++k) ea.set_vert(k, seed.w[k], seed.w0[k], -1 - k);
+  NoSupportTagged ns;
+  EpaResult<float> res;
+  const int closest_a = ea.begin(seed.rank, -seed.guess, ns, res, ZeroTags());
+  EpaReady<float> rb;
+  int flags[4], closest_b = 0;
+  const bool live = epa_prepare_tetrahedron(seed.w, q.epa_tolerance, rb.vw, rb.fn, flags, closest_b);
+  if (!live || closest_a == EPA_NULL) {
+    ++*fallbacks;
+    return live == (closest_a != EPA_NULL);
+  }
+  if (feat) {  // what k_epa_prepare knows about the polytope before its loop (tools: predictors of the length of the loop)
+    float dmin = Lim<float>::max(), dmax = 0.f;
+    for (int f = 0; f < 4; ++f)
+      if (!(flags[f] & 2)) {
+        dmin = std::min(dmin, rb.fn[f].w);
+        dmax = std::max(dmax, rb.fn[f].w);
+      }
+    feat[0] = dmin;
+    feat[1] = dmax;
+    feat[2] = habs(triple(seed.w[0] - seed.w[3], seed.w[1] - seed.w[3], seed.w[2] - seed.w[3]));
+    feat[3] = float(seed.gjk_iters);
+    float e = 0.f;
+    for (int a2 = 0; a2 < 4; ++a2)
+      for (int b2 = a2 + 1; b2 < 4; ++b2) e = std::max(e, norm(seed.w[a2] - seed.w[b2]));
+    feat[4] = e;
+    feat[5] = float((flags[0] >> 1) + (flags[1] >> 1) + (flags[2] >> 1) + (flags[3] >> 1));
+  }
+  rb.packed = uint32_t(closest_b) << 12;
+  for (int f = 0; f < 4; ++f) rb.packed |= uint32_t((flags[f] >> 1) & 1) << (14 + f);
+  E eb;
+  eb.reset(&blk_b, q.epa_max_iterations, q.epa_tolerance);
+  const int closest_i = eb.install(&rb, rb.packed);
+  bool same = closest_i == closest_a && ea.status == eb.status && ea.num_vertices == eb.num_vertices && ea.hull_count == eb.hull_count &&
+              ea.stock_top == eb.stock_top && ea.stamp == eb.stamp && ea.hw == eb.hw && ea.pending_release == eb.pending_release;
+  same = same && std::memcmp(blk_a.vw, blk_b.vw, 4 * sizeof(Quad<float>)) == 0 && std::memcmp(blk_a.fn, blk_b.fn, 4 * sizeof(Quad<float>)) == 0 &&
+         std::memcmp(blk_a.ft, blk_b.ft, 4 * sizeof(FaceTopo)) == 0;
+  // the part of the stock that is still in use, and the flags of the unused faces
+  same = same && std::memcmp(blk_a.stock, blk_b.stock, size_t(ea.stock_top)) == 0;
+  for (int f = 4; f < 2 * CAP + 4; ++f) same = same && blk_a.ft[f].flag() == blk_b.ft[f].flag();
+  return same;
+}
 long sim_epa_prepare_selftest(const hfcl_shape* shapes, size_t n_shapes, const double* vertices, size_t n_vertices, const uint32_t* s1,
                               const uint32_t* s2, const float* pose1, const float* pose2, size_t n, const hfcl_distance_request* dreq,
-                              long* mismatches, long* fallbacks) {
+                              long* mismatches, long* fallbacks, float* features /* optional: 6 per pair */) {
   std::vector<DShape<float>> lib(n_shapes);
   for (size_t i = 0; i < n_shapes; ++i) lib[i] = to_dshape<float>(shapes[i]);
   std::vector<float> v32(3 * n_vertices + 3);
@@ -262,9 +312,6 @@ long sim_epa_prepare_selftest(const hfcl_shape* shapes, size_t n_shapes, const d
   long checked = 0;
   *mismatches = 0;
   *fallbacks = 0;
-  constexpr int CAP = 17;
-  typedef Epa<float, SerialGroup<1>, CAP, V0_TAG> E;
-  static EpaScratch<float, CAP, V0_TAG> blk_a, blk_b;
   for (size_t i = 0; i < n; ++i) {
     const DShape<float>&a = lib[s1[i]], &b = lib[s2[i]];
     SerialSupport<float> sup;
@@ -279,39 +326,35 @@ long sim_epa_prepare_selftest(const hfcl_shape* shapes, size_t n_shapes, const d
     gjk_run(g, q.gjk, g0, 0.f, true, sup);
     PairOut<float> o;
     EpaSeed<float> seed;
+    if (features)
+      for (int k = 0; k < 6; ++k) features[6 * i + k] = Lim<float>::nan();
     if (!gjk_finish(g, q, tf1, 0.f, 0.f, g0, o, seed) || seed.rank != 4) continue;
     ++checked;
-    std::memset(&blk_a, 0xA5, sizeof(blk_a));
-    std::memset(&blk_b, 0xA5, sizeof(blk_b));
-    E ea;
-    ea.reset(&blk_a, q.epa_max_iterations, q.epa_tolerance);
-    for (int k = 0; k < 4; ++k) ea.set_vert(k, seed.w[k], seed.w0[k], -1 - k);
-    NoSupportTagged ns;
-    EpaResult<float> res;
-    const int closest_a = ea.begin(seed.rank, -seed.guess, ns, res, ZeroTags());
-    EpaReady<float> rb;
-    int flags[4], closest_b = 0;
-    const bool live = epa_prepare_tetrahedron(seed.w, q.epa_tolerance, rb.vw, rb.fn, flags, closest_b);
-    if (!live || closest_a == EPA_NULL) {
-      ++*fallbacks;
-      if (live != (closest_a != EPA_NULL)) ++*mismatches;
-      continue;
-    }
-    rb.packed = uint32_t(closest_b) << 12;
-    for (int f = 0; f < 4; ++f) rb.packed |= uint32_t((flags[f] >> 1) & 1) << (14 + f);
-    E eb;
-    eb.reset(&blk_b, q.epa_max_iterations, q.epa_tolerance);
-    const int closest_i = eb.install(&rb, rb.packed);
-    bool same = closest_i == closest_a && ea.status == eb.status && ea.num_vertices == eb.num_vertices && ea.hull_count == eb.hull_count &&
-                ea.stock_top == eb.stock_top && ea.stamp == eb.stamp && ea.hw == eb.hw && ea.pending_release == eb.pending_release;
-    same = same && std::memcmp(blk_a.vw, blk_b.vw, 4 * sizeof(Quad<float>)) == 0 && std::memcmp(blk_a.fn, blk_b.fn, 4 * sizeof(Quad<float>)) == 0 &&
-           std::memcmp(blk_a.ft, blk_b.ft, 4 * sizeof(FaceTopo)) == 0;
-    // the part of the stock that is still in use, and the flags of the unused faces
-    same = same && std::memcmp(blk_a.stock, blk_b.stock, size_t(ea.stock_top)) == 0;
-    for (int f = 4; f < 2 * CAP + 4; ++f) same = same && blk_a.ft[f].flag() == blk_b.ft[f].flag();
-    if (!same) ++*mismatches;
+    if (!epa_prepare_check_one(seed, q, fallbacks, features ? features + 6 * i : nullptr)) ++*mismatches;
   }
   return checked;
+}
+// ... on tetrahedra given as they are (w: 12 floats each): flat, inverted, origin outside -- what GJK's seeds rarely are
+long sim_epa_prepare_selftest_tetrahedra(const float* w, size_t n, float tolerance, long* mismatches, long* fallbacks) {
+  QParams<float> q;
+  std::memset(&q, 0, sizeof(q));
+  q.epa_tolerance = tolerance;
+  q.epa_max_iterations = 64;
+  *mismatches = 0;
+  *fallbacks = 0;
+  for (size_t i = 0; i < n; ++i) {
+    EpaSeed<float> seed;
+    seed.pair = uint32_t(i);
+    seed.rank = 4;
+    for (int k = 0; k < 4; ++k) {
+      seed.w[k] = mk<float>(w[12 * i + 3 * k], w[12 * i + 3 * k + 1], w[12 * i + 3 * k + 2]);
+      seed.w0[k] = seed.w[k];
+    }
+    seed.guess = mk<float>(1.f, 0.f, 0.f);
+    seed.gjk_iters = 0;
+    if (!epa_prepare_check_one(seed, q, fallbacks, nullptr)) ++*mismatches;
+  }
+  return long(n);
 }
 
 }  // extern "C"

@@ -274,6 +274,41 @@ def test_fp32_device_path(pkg, oracle, torch_cuda, case):
     lib.close()
 
 
+@pytest.mark.parametrize("case,n", [("cfg3_convex_convex", 300000), ("cfg3_unique_hulls", 60000), ("cfg5_mixed", 120000)])
+def test_fp32_staged_epa_equals_one_kernel_form(pkg, torch_cuda, monkeypatch, case, n):
+    """The convex x convex EPA fast tier in three stages (k_epa_prepare: one lane per polytope builds the first tetrahedron;
+    k_epa_loop: the expansion loop; k_epa_records: one lane per polytope writes the record; k_epa_resume_cc continues the
+    polytopes that outgrow the block) against the one-kernel streaming form on the same batch: every record byte for byte
+    (the same arithmetic in other kernels).  cfg5_mixed: convex x convex pairs beside the general queue of the same batch."""
+    torch = torch_cuda
+    abi, wl = pkg.abi, pkg.workloads
+    b = getattr(wl, case)(n=n, seed=3)
+    req = wl.make_request(b, abi)
+    dev = torch.device("cuda:0")
+    d_s1 = torch.from_numpy(b.s1.astype(np.int32)).to(dev)
+    d_s2 = torch.from_numpy(b.s2.astype(np.int32)).to(dev)
+    d_p1 = torch.from_numpy(b.pose1_f32).to(dev)
+    d_p2 = torch.from_numpy(b.pose2_f32).to(dev)
+    recs, queues = {}, {}
+    monkeypatch.setenv("HFCL_EPA_CC_STAGED_MIN", "0")
+    for staged in ("0", "1"):
+        monkeypatch.setenv("HFCL_EPA_CC_STAGED", staged)
+        lib = pkg.Library(b.lib)
+        d_out = torch.zeros(len(b) * 11, dtype=torch.int32, device=dev)
+        fn = lib.distance_device_f32 if b.kind == "distance" else lib.collide_device_f32
+        for _ in range(2):  # (the second call runs on a warm workspace)
+            fn(d_s1, d_s2, d_p1, d_p2, len(b), req, d_out, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        recs[staged] = d_out.cpu().numpy().reshape(len(b), 11).copy()
+        queues[staged] = lib.last_bucket_counts()
+        names = [k for k, _ in lib.last_kernel_breakdown()]
+        assert ("k_epa_prepare" in names) == (staged == "1"), names
+        lib.close()
+    assert queues["0"]["epa_queue"] == queues["1"]["epa_queue"] > 0
+    differ = np.flatnonzero((recs["0"] != recs["1"]).any(axis=1))
+    assert differ.size == 0, "%d records differ, first %s" % (differ.size, differ[:10])
+
+
 def _support(abi, b, shape_id, R, T, n):
     """max over the posed shape of x . n (fp64, from the shape table): Box / Capsule / Convex."""
     sh = b.shapes[shape_id]
