@@ -8,5 +8,5 @@ This module holds plumbing only.  All compute happens in csrc/libhppfcl_amd.so (
 gfx950).  There is no CPU fallback: without the built library or without a GPU every compute
 call raises."""
 from . import abi, bvh_builder, compat, engine, geometry, multigpu, sharding, workloads  # noqa: F401
-from .engine import EngineError, Library  # noqa: F401
+from .engine import EngineError, Library, MultiLibrary  # noqa: F401
 from .geometry import ShapeLibrary, make_pose, quat_to_matrix  # noqa: F401

@@ -48,6 +48,7 @@
 // =======================================================================================
 static thread_local std::string g_last_error;
 static void set_error(const std::string& s) { g_last_error = s; }
+void hfcl_internal_set_error(const char* msg) { g_last_error = msg ? msg : ""; }  // hfcl_multi.hip: a worker thread's message handed to the caller's
 
 #define HIP_TRY(expr)                                                                         \
   do {                                                                                        \
@@ -476,9 +477,9 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_BVHD_POOL")) lib->bvhd_pool = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_DIST_POOL")) lib->shape_dist_pool = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_DIST_LEAF_MIN")) lib->shape_dist_leaf_min = uint32_t(std::max(1, atoi(v)));
-  if (const char* v = getenv("HFCL_SHAPE_DIST_STARVE")) lib->shape_dist_starve = uint32_t(std::max(0, atoi(v)));
+  if (const char* v = getenv("HFCL_SHAPE_DIST_STARVE")) lib->shape_dist_starve = uint32_t(std::max(1, atoi(v)));  // (>= 1: a window of triangles alone must always run)
   if (const char* v = getenv("HFCL_BVHD_LEAF_MIN")) lib->bvhd_pool_leaf_min = uint32_t(std::max(1, atoi(v)));
-  if (const char* v = getenv("HFCL_BVHD_STARVE")) lib->bvhd_pool_starve = uint32_t(std::max(0, atoi(v)));
+  if (const char* v = getenv("HFCL_BVHD_STARVE")) lib->bvhd_pool_starve = uint32_t(std::max(1, atoi(v)));
   if (const char* v = getenv("HFCL_BVHD_PART_MIN")) lib->bvhd_pool_part_min = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_DIST_BUDGET")) lib->shape_dist_budget = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVH_BUDGET0_COOP")) lib->bvh_budget0_coop = uint32_t(std::max(1, atoi(v)));

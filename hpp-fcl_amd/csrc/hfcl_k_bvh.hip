@@ -4,6 +4,18 @@
 #include "hfcl_dev.hpp"
 #include "hfcl_launch.hpp"
 
+// This file is compiled twice (Makefile): hfcl_k_bvh.o, HFCL_BVH_PART = 1 -- the collide() kernels and their launchers -- and
+// hfcl_k_bvhs.o, HFCL_BVH_PART = 2 -- mesh x solid distance() -- WITHOUT contraction of a*b+c: the reported triangle hangs on
+// comparisons of distances that are equal or an ulp apart (triangles that share the closest vertex or edge), and with the
+// reference's arithmetic the ids, distances and witness points are the oracle's (profiles/r05_c: ids 77-93 % -> 100 % equal,
+// distances 29-71 % -> 100 % bit-equal), as for mesh x mesh (hfcl_k_bvhd.hip).  Kernels both parts launch carry the part as a
+// template argument (one host stub per object).  0: everything in one object (tools).
+#ifndef HFCL_BVH_PART
+#define HFCL_BVH_PART 0
+#endif
+#define HFCL_BVH_COLLIDE_PART (HFCL_BVH_PART != 2)
+#define HFCL_BVH_DISTANCE_PART (HFCL_BVH_PART != 1)
+
 // ---------------------------------------------------------------------------------------
 // k_bvh_collide: BVHModel<OBBRSS> x BVHModel<OBBRSS> collide().
 // Traversal = collisionRecurse (src/traversal/traversal_recurse.cpp:44-85) with the recursion
@@ -826,12 +838,14 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
 }
 
 // Between two levels: the tasks made so far are the next level's units; the ticket counter starts over.
+#if HFCL_BVH_COLLIDE_PART
 __global__ void k_bvh_level_mark(Work wk, BvhSplit split, int ticket) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     split.ctr[BVH_CTR_LEVEL0 + split.level + 1] = split.ctr[BVH_CTR_TASKS];
     wk.counts[ticket] = 0u;
   }
 }
+#endif
 
 // Fold the children of the suspended units of level `split.level` back (the children's own children are folded already).
 template <typename T>
@@ -1026,7 +1040,7 @@ __global__ void __launch_bounds__(256) k_shape_obb(Work wk, LibView<T> lib, IO<T
   }
 }
 
-template <typename T>
+template <typename T, int PART = HFCL_BVH_PART>
 __global__ void __launch_bounds__(64) k_bvh_shape_finish(Work wk, LibView<T> lib, IO<T> io, QParams<T> q, BvhParams bp, BvhSplit split, int distance_mode) {
   constexpr int G = 64 / BS_W;
   __shared__ EpaScratch<T, EPA_MAX_ITER> scratch[G];
@@ -2282,7 +2296,7 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
   // such a triangle every bounded entry is skipped: the walk's result is the FIRST such triangle in DFS order, not the smallest value
   bool active = false, exhausted = false, ended = false, ended_epa = false, overflow = false;
   int sp = 0, p = 0, fb1 = -1, end_prim = -1;
-  T mind = big, end_val = T(0);
+  T mind = big, end_val = T(0), margin = T(0);
   uint32_t pair = 0;
   for (;;) {
     const uint64_t idle = __ballot(!active && j == 0);
@@ -2313,6 +2327,15 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
           const int32_t fc = bv.dnodes[m1.node_off + b].first_child;
           st_x[qs][k] = fc < 0 ? (0x80000000u | uint32_t(-(fc + 1))) : uint32_t(fc);
           st_d[qs][k] = r->bound[k];
+        }
+        {
+          // what a bound may exceed a distance beneath it by: a few ulps of the scene's size (the solid's volume in the mesh's frame and
+          // the mesh's root volume), as in k_bvh_distance_pool -- an entry IN FRONT of the minimum is kept within that margin
+          const RssQuery<T> rq0 = table[pair];
+          const DNodeD<T>* const root = bv.dnodes + m1.node_off;
+          const T scale = habs(rq0.Tr.x) + habs(rq0.Tr.y) + habs(rq0.Tr.z) + rq0.l0 + rq0.l1 + T(2) * rq0.r + habs(root->Tr.x) + habs(root->Tr.y) +
+                          habs(root->Tr.z) + root->l0 + root->l1 + T(2) * root->r;
+          margin = T(4) * Lim<T>::eps() * scale;
         }
         if (j == 0) {
           const Pose<T> tfm = load_pose(swapped ? io.tf2 : io.tf1, pair);
@@ -2345,7 +2368,7 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
     }
     // behind a triangle that ends the walk nothing is visited; else canStop(bound) with the slot's minimum: behind the triangle of
     // the minimum the sequential walk's test, in front of it a tie is kept (k_bvh_distance_pool; NaN bounds never skip)
-    const bool alive = act && !(ended && idx < p) && !(db >= T(0) && (idx < p && !ended ? db >= mind : db > mind));
+    const bool alive = act && !(ended && idx < p) && !(db >= T(0) && (idx < p && !ended ? db >= mind : db > mind + margin));
     const bool is_leaf = alive && (x >> 31) != 0u, split = alive && (x >> 31) == 0u;
     // ---- the children's bounds of every split node of the wave in one list
     const uint64_t smask = __ballot(split);
@@ -2392,8 +2415,10 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
     }
     // ---- the triangles, once they are worth a pass (one GJK run per lane)
     const int nl = __popcll(__ballot(is_leaf));
-    const bool do_leaves = nl > 0 && (nl >= leaf_min || 2 * ns < starve);
+    const bool do_leaves = nl > 0 && (nl >= leaf_min || 2 * ns < starve || ns == 0);  // (nothing but triangles in the windows: they run, whatever the knobs say)
     int jw = -1;
+    T run_at = mind;  // the slot's minimum as of this lane's own turn in the pass, and whether the pass had set one / ended the walk by then
+    bool upd_at = false, stop_at = false;
     if (do_leaves) {
       T val = big;
       bool to_epa = false;
@@ -2408,44 +2433,65 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
         to_epa = solid_leaf_call<T>(in, &q, leaf_ps, initial_guess<T>(io, q, pair), &lo);
         if (!to_epa) val = lo.distance;
       }
-      // the slot's best candidate: a triangle that ends the walk before any distance (the first of them in DFS order), else the
-      // smaller distance, the first in DFS order among equals; against the standing result a tie wins only in front of it
+      // DistanceResult::update over the slot's evaluated triangles IN THE ORDER OF THEIR VISITS (window index 0 = the top of the stack
+      // = visited first).  The sequential walk tests an entry against the minimum of ITS turn: a triangle behind a minimum that an
+      // earlier triangle of this very pass has set is visited only if its bound is below that minimum -- evaluated together, a
+      // triangle whose bound exceeds its own distance by an ulp would otherwise lower a minimum the reference never lowers (two
+      // records in 20 000 box queries, profiles/r05_c).  A triangle that ends the walk (asks for EPA, or a negative closed-form
+      // distance behind a bound) is the result if the walk reaches it; against the standing result a tie wins only in front of it.
       const bool ends = is_leaf && (to_epa || (val < T(0) && db >= T(0)));
-      const bool cand = is_leaf && (ends ? (!ended || idx >= p) : (!ended && (val < mind || (val == mind && idx >= p))));
-      T bestv = cand ? (ends ? -big : val) : big;
-      int bj = cand ? j : 64;
-#pragma unroll
-      for (int m = 1; m < SEG; m <<= 1) {
-        const T ov = __shfl_xor(bestv, m);
-        const int oj = __shfl_xor(bj, m);
-        if (oj < 64 && (bj == 64 || ov < bestv || (ov == bestv && oj < bj))) {
-          bestv = ov;
-          bj = oj;
+      T run = mind;
+      bool upd = false, stop = false;
+      int win_min = -1, win_end = -1;
+#pragma unroll 4
+      for (int s = 0; s < SEG; ++s) {
+        const int src = qs * SEG + s;
+        if (j == s) {
+          run_at = run;
+          upd_at = upd;
+          stop_at = stop;
+        }
+        const bool leaf_s = __shfl(int(is_leaf), src) != 0, ends_s = __shfl(int(ends), src) != 0;
+        const T db_s = __shfl(db, src), val_s = __shfl(val, src);
+        const int idx_s = sp - 1 - s;
+        const bool visited = leaf_s && !stop && !(upd && db_s >= T(0) && db_s >= run);
+        const bool take_end = visited && ends_s && (!ended || idx_s >= p);
+        const bool take_min = visited && !ends_s && !ended && (val_s < run || (val_s == run && !upd && idx_s >= p));
+        if (take_min) {
+          run = val_s;
+          win_min = s;
+          upd = true;
+        }
+        if (take_end) {
+          win_end = s;
+          stop = true;
         }
       }
-      if (bj < 64) {
-        jw = bj;
-        const int src = qs * SEG + bj;
-        const bool w_ends = __shfl(int(ends), src) != 0, w_epa = __shfl(int(to_epa), src) != 0;
-        const int w_prim = __shfl(int(prim), src);
-        const bool swapped = q_ids[qs][2] != 0u;
-        if (w_ends) {
-          ended = true;
-          ended_epa = w_epa;
-          end_prim = w_prim;
-          if (!w_epa) {
-            end_val = __shfl(val, src);
-            if (j == bj) store_witness(io, pair, swapped ? lo.p2 : lo.p1, swapped ? lo.p1 : lo.p2, swapped ? -lo.n : lo.n);
-          }
-        } else {
-          mind = bestv;
-          fb1 = w_prim;
-          if (j == bj) store_witness(io, pair, swapped ? lo.p2 : lo.p1, swapped ? lo.p1 : lo.p2, swapped ? -lo.n : lo.n);
-        }
+      const bool swapped = q_ids[qs][2] != 0u;
+      bool w_epa = false;
+      if (win_min >= 0) {
+        mind = run;
+        fb1 = __shfl(int(prim), qs * SEG + win_min);
+        jw = win_min;
       }
+      if (win_end >= 0) {
+        const int src = qs * SEG + win_end;
+        w_epa = __shfl(int(to_epa), src) != 0;
+        ended = true;
+        ended_epa = w_epa;
+        end_prim = __shfl(int(prim), src);
+        if (!w_epa) end_val = __shfl(val, src);
+        jw = win_end;
+      }
+      // the witness of the record: the ending triangle's when it carries a distance, else the minimum's (an EPA item falls back to it)
+      const int w_lane = (win_end >= 0 && !w_epa) ? win_end : win_min;
+      if (w_lane >= 0 && j == w_lane && (w_lane == win_end || win_min >= 0))
+        store_witness(io, pair, swapped ? lo.p2 : lo.p1, swapped ? lo.p1 : lo.p2, swapped ? -lo.n : lo.n);
     }
-    // ---- the windows written back, in order
-    const int cnt = split ? 2 : ((is_leaf && !do_leaves) ? 1 : 0);
+    // ---- the windows written back, in order (a node behind a minimum of this pass that its bound does not beat, or behind a triangle
+    // that ended the walk in this pass, is not split: the sequential walk skips it at its turn)
+    const bool unsplit = split && (stop_at || (upd_at && db >= T(0) && db >= run_at));
+    const int cnt = (split && !unsplit) ? 2 : ((is_leaf && !do_leaves) ? 1 : 0);
     const uint64_t m2b = __ballot(cnt == 2), m1b = __ballot(cnt == 1);
     const int pos = base_i + 2 * __popcll(m2b & deeper) + __popcll(m1b & deeper);
     if (cnt == 2) {
@@ -2496,6 +2542,7 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
 // split.tasks == nullptr (or split.n_levels <= 1): the plain single-pass traversal.
 // one launch of the collide kernel in the form the batch asks for: WIDE (32-bit node ids) or not, with the fp32 filter in
 // front of the fp64 test (fp64 batches of a library whose filter records are uploaded, bv.fnodes) or without
+#if HFCL_BVH_COLLIDE_PART
 template <typename T>
 static void launch_collide_kernel(bool wide, int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, const BvhSplit& split, const BvhSpill& spill, bool solid = false) {
   if (solid) {  // mesh x solid: the narrow form, 32-bit node ids in the entry
@@ -2590,6 +2637,8 @@ template <typename T>
 void launch_bvh_shape(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2) {
   hipLaunchKernelGGL((k_bvh_shape<T>), dim3(grid), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2);
 }
+#endif
+#if HFCL_BVH_DISTANCE_PART
 // mesh x solid distance(), one query per lane
 template <typename T>
 void launch_bvh_shape_distance_fast(int grid, int grid_finish, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, BvhSpill spill) {
@@ -2606,6 +2655,8 @@ void launch_bvh_shape_distance_fast(int grid, int grid_finish, hipStream_t st, c
   memset(&bp, 0, sizeof(bp));
   hipLaunchKernelGGL((k_bvh_shape_finish<T>), dim3(grid_finish), dim3(64), 0, st, wk, lv, io, q, bp, none, 1);
 }
+#endif
+#if HFCL_BVH_COLLIDE_PART
 // mesh x solid collide(), one query per lane: the solids' OBBs, the walk (split as `split` says), the EPA leaves
 template <typename T>
 void launch_bvh_shape_fast(int grid, int grid_finish, int coop_grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill) {
@@ -2635,21 +2686,34 @@ void launch_bvh_shape_fast(int grid, int grid_finish, int coop_grid, hipStream_t
   split.level = 0;
   hipLaunchKernelGGL((k_bvh_shape_finish<T>), dim3(grid_finish), dim3(64), 0, st, wk, lv, io, q, bp, split, 0);
 }
+#endif
+#if HFCL_BVH_DISTANCE_PART
 template <typename T>
 void launch_bvh_shape_distance(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q) {
   hipLaunchKernelGGL((k_bvh_shape_distance<T>), dim3(grid), dim3(64), 0, st, wk, lv, bv, io, q);
 }
+#endif
+#if HFCL_BVH_COLLIDE_PART
 template <typename T>
 void launch_triangle(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {
   hipLaunchKernelGGL((k_triangle<T>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
 }
+#endif
+#if HFCL_BVH_COLLIDE_PART
 #define HFCL_INST(T)                                                                                                             \
   template void launch_bvh_collide<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill, bool); \
   template void launch_bvh_shape<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T);   \
-  template void launch_bvh_shape_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&);          \
-  template void launch_bvh_shape_distance_fast<T>(int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, BvhSpill); \
   template void launch_bvh_shape_fast<T>(int, int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill); \
   template void launch_triangle<T>(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&);
 HFCL_INST(float)
 HFCL_INST(double)
 #undef HFCL_INST
+#endif
+#if HFCL_BVH_DISTANCE_PART
+#define HFCL_INST(T)                                                                                                             \
+  template void launch_bvh_shape_distance<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&);          \
+  template void launch_bvh_shape_distance_fast<T>(int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, BvhSpill);
+HFCL_INST(float)
+HFCL_INST(double)
+#undef HFCL_INST
+#endif

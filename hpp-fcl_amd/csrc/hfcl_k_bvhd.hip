@@ -722,7 +722,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
     POOL_T(1);
     // ---- the triangle pairs, once they are worth a pass: the first 64 of the wave's windows, one per lane
     const int nl = lane_sum(nl_l, ~uint64_t(0));
-    const bool do_leaves = nl > 0 && (nl >= leaf_min || 2 * ns < starve);
+    const bool do_leaves = nl > 0 && (nl >= leaf_min || 2 * ns < starve || ns == 0);  // (nothing but triangles in the windows: they run, whatever the knobs say)
     int jw = -1;  // the window entry (j * E + u) that set a new minimum in this trip (slot-uniform)
     bool leaf_eval[E];
 #pragma unroll

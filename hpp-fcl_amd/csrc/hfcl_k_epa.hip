@@ -11,6 +11,15 @@
 #include "hfcl_dev.hpp"
 #include "hfcl_launch.hpp"
 
+// Compiled twice, per precision (hfcl_k_epa32.o / hfcl_k_epa64.o; see hfcl_k_gjk.hip): the fp64 tiers without contraction
+// (the reference's arithmetic: iteration counts and statuses are the oracle's in every record), the fp32 tiers with the
+// contraction the source spells out (-ffp-contract=on).
+#ifndef HFCL_UNIT_PRECISION
+#define HFCL_UNIT_PRECISION 0
+#endif
+#define HFCL_UNIT_F32 (HFCL_UNIT_PRECISION != 64)
+#define HFCL_UNIT_F64 (HFCL_UNIT_PRECISION != 32)
+
 // LARGE: hulls of more than HULL_MAX vertices may occur (scanned from memory); only the
 // full-capacity tier is built that way, so the fast tier keeps its register budget.
 template <typename T, int WE, bool LARGE>
@@ -623,9 +632,14 @@ void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>&
 #endif
   }
 }
+#if HFCL_UNIT_F32
 template void launch_epa_fast<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&, bool, bool, int, bool);
+#endif
+#if HFCL_UNIT_F64
 template void launch_epa_fast<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&, bool, bool, int, bool);
+#endif
 
+#if HFCL_UNIT_F32
 void launch_epa_prepare(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q) {
   hipLaunchKernelGGL((k_epa_prepare<float>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
 }
@@ -640,9 +654,15 @@ void launch_epa_records(int grid, hipStream_t st, const Work& wk, const LibView<
   hipLaunchKernelGGL((k_epa_records<float>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
 }
 
+#endif
+
 template <typename T>
 void launch_epa_full(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {
   hipLaunchKernelGGL((k_epa<T, epa_we2<T>, EPA_MAX_ITER, 2>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
 }
+#if HFCL_UNIT_F32
 template void launch_epa_full<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&);
+#endif
+#if HFCL_UNIT_F64
 template void launch_epa_full<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&);
+#endif

@@ -2,12 +2,24 @@
 #include "hfcl_dev.hpp"
 #include "hfcl_launch.hpp"
 
+// This file is compiled twice (Makefile: hfcl_k_gjk32.o / hfcl_k_gjk64.o, HFCL_UNIT_PRECISION = 32 / 64): the fp64 kernels -- the
+// reference's precision, everything the oracle is compared with digit for digit -- without contraction of a*b+c (-ffp-contract=off:
+// iteration counts, statuses and distances of the GJK / EPA kernels then equal the oracle's in every record; profiles/r05_c),
+// the fp32 kernels with it (specified by an envelope; 5 % faster that way).  The kernels without a precision (k_classify,
+// k_expand_poses, ...) belong to the fp64 object.  0: one object with everything (tools).
+#ifndef HFCL_UNIT_PRECISION
+#define HFCL_UNIT_PRECISION 0
+#endif
+#define HFCL_UNIT_F32 (HFCL_UNIT_PRECISION != 64)
+#define HFCL_UNIT_F64 (HFCL_UNIT_PRECISION != 32)
+
 // ---------------------------------------------------------------------------------------
 // k_classify: bucket every pair by (kind1, kind2).  Wave-aggregated list append.
 // ---------------------------------------------------------------------------------------
 // One global atomic per (block trip, bucket) reserves the block's range in the bucket list: these same-address
 // atomics serialise (~20 ns each), so the trips are made large -- 1024 threads x 8 pairs (4M pairs: 39 us at
 // 2048 pairs per trip).
+#if HFCL_UNIT_F64
 __global__ void __launch_bounds__(CLS_BLOCK) k_classify(Work wk, const uint8_t* kinds, uint32_t n_shapes, bool distance_mode) {
   // Each block handles CHUNK consecutive pairs per trip: per-bucket counts are built in LDS, one
   // global atomic per (block, bucket) reserves a range, then every lane writes its pair index.
@@ -70,6 +82,7 @@ __global__ void __launch_bounds__(CLS_BLOCK) k_classify(Work wk, const uint8_t* 
   }
 }
 
+#endif
 // pairs the engine cannot evaluate: flagged, never silently computed elsewhere
 template <typename T>
 __global__ void __launch_bounds__(256) k_unsupported(Work wk, IO<T> io, int bucket) {
@@ -109,6 +122,7 @@ __global__ void __launch_bounds__(256) k_closed(Work wk, LibView<T> lib, IO<T> i
 // cache merging (non-temporal accesses: 2.5x slower, profiles/); here the block's 256 poses are fetched as
 // 1536 consecutive 16-byte pieces (lane-contiguous when the bucket list is in input order, as it is up to the
 // interleaving of blocks in k_classify), handed over in LDS, and the records leave the same way.
+#if HFCL_UNIT_F64
 typedef double hfcl_d2 __attribute__((ext_vector_type(2)));
 #ifndef HFCL_WPE_CLOSED
 #define HFCL_WPE_CLOSED 2
@@ -157,6 +171,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_W
   }
 }
 
+#endif
 // ---------------------------------------------------------------------------------------
 // Shared GJK epilogue: final record, or hand-off to k_epa through the device queue.
 // ---------------------------------------------------------------------------------------
@@ -432,6 +447,7 @@ __global__ void k_fill_skipped(R* out, uint32_t n) {
     out[i] = r;
   }
 }
+#if HFCL_UNIT_F64
 template <>
 __global__ void k_fill_skipped<hfcl_result>(hfcl_result* out, uint32_t n) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -446,10 +462,12 @@ __global__ void k_fill_skipped<hfcl_result>(hfcl_result* out, uint32_t n) {
   }
 }
 
+#endif
 // ---------------------------------------------------------------------------------------
 // compact host poses (quaternion w,x,y,z + translation, 7 doubles) -> the 12-double Transform3f image the fp64
 // kernels read (column-major R, then T).  Runs on the device so that only 56 bytes per pose cross the host link.
 // ---------------------------------------------------------------------------------------
+#if HFCL_UNIT_F64
 __global__ void __launch_bounds__(256) k_expand_poses(const double* qt, double* tf, uint32_t n) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const Pose<double> p = pose_from_quat<double, double>(qt + 7 * size_t(i));
@@ -460,35 +478,50 @@ __global__ void __launch_bounds__(256) k_expand_poses(const double* qt, double* 
     o[9] = p.t.x; o[10] = p.t.y; o[11] = p.t.z;
   }
 }
+#endif
+#if HFCL_UNIT_F64
 void launch_expand_poses(hipStream_t st, const double* qt, double* tf, uint32_t n) {
   hipLaunchKernelGGL(k_expand_poses, dim3(1024), dim3(256), 0, st, qt, tf, n);
 }
+#endif
 
 // =======================================================================================
 // launchers (hfcl_launch.hpp)
 // =======================================================================================
+#if HFCL_UNIT_F64
 void launch_classify(int grid, hipStream_t st, const Work& wk, const uint8_t* kinds, uint32_t n_shapes, bool distance_mode) {
   hipLaunchKernelGGL(k_classify, dim3(grid), dim3(CLS_BLOCK), 0, st, wk, kinds, n_shapes, distance_mode);
 }
+#endif
 template <typename T>
 void launch_unsupported(int grid, hipStream_t st, const Work& wk, const IO<T>& io, int bucket) {
   hipLaunchKernelGGL((k_unsupported<T>), dim3(grid), dim3(256), 0, st, wk, io, bucket);
 }
+#if HFCL_UNIT_F32
 template void launch_unsupported<float>(int, hipStream_t, const Work&, const IO<float>&, int);
+#endif
+#if HFCL_UNIT_F64
 template void launch_unsupported<double>(int, hipStream_t, const Work&, const IO<double>&, int);
+#endif
 
 template <typename T>
 void launch_closed(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool staged) {
+#if HFCL_UNIT_F64
   if constexpr (sizeof(T) == 8) {
     if (staged) {
       hipLaunchKernelGGL(k_closed_staged, dim3(grid), dim3(256), 0, st, wk, lv, io, q);
       return;
     }
   }
+#endif
   hipLaunchKernelGGL((k_closed<T>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
 }
+#if HFCL_UNIT_F32
 template void launch_closed<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&, bool);
+#endif
+#if HFCL_UNIT_F64
 template void launch_closed<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&, bool);
+#endif
 
 template <typename T>
 void launch_gjk_prim(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool bvg) {
@@ -497,8 +530,12 @@ void launch_gjk_prim(int grid, hipStream_t st, const Work& wk, const LibView<T>&
   else
     hipLaunchKernelGGL((k_gjk_prim<T, false>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
 }
+#if HFCL_UNIT_F32
 template void launch_gjk_prim<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&, bool);
+#endif
+#if HFCL_UNIT_F64
 template void launch_gjk_prim<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&, bool);
+#endif
 
 template <typename T, int M>
 static void launch_gjk_cvx_m(int w, bool bvg, int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {
@@ -522,8 +559,12 @@ void launch_gjk_cvx(int m, int w, bool bvg, int grid, hipStream_t st, const Work
   else if (m == 1) launch_gjk_cvx_m<T, 1>(w, bvg, grid, st, wk, lv, io, q);
   else launch_gjk_cvx_m<T, 2>(w, bvg, grid, st, wk, lv, io, q);
 }
+#if HFCL_UNIT_F32
 template void launch_gjk_cvx<float>(int, int, bool, int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&);
+#endif
+#if HFCL_UNIT_F64
 template void launch_gjk_cvx<double>(int, int, bool, int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&);
+#endif
 
 template <typename T>
 void launch_gjk_large(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool bvg) {
@@ -532,12 +573,20 @@ void launch_gjk_large(int grid, hipStream_t st, const Work& wk, const LibView<T>
   else
     hipLaunchKernelGGL((k_gjk_large<T, false>), dim3(grid), dim3(256), 0, st, wk, lv, io, q);
 }
+#if HFCL_UNIT_F32
 template void launch_gjk_large<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&, bool);
+#endif
+#if HFCL_UNIT_F64
 template void launch_gjk_large<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&, bool);
+#endif
 
+#if HFCL_UNIT_F64
 void launch_fill_skipped(hipStream_t st, hfcl_result* out, uint32_t n) {
   hipLaunchKernelGGL((k_fill_skipped<hfcl_result>), dim3(1024), dim3(256), 0, st, out, n);
 }
+#endif
+#if HFCL_UNIT_F32
 void launch_fill_skipped(hipStream_t st, hfcl_result_f32* out, uint32_t n) {
   hipLaunchKernelGGL((k_fill_skipped<hfcl_result_f32>), dim3(1024), dim3(256), 0, st, out, n);
 }
+#endif

@@ -24,6 +24,9 @@ EXPORTED_SYMBOLS = [
     "hfcl_pairlist_data", "hfcl_pairlist_free", "hfcl_lib_set_kernel_timing", "hfcl_pair_supported", "hfcl_last_kernel_breakdown", "hfcl_last_bucket_counts", "hfcl_lib_set_split", "hfcl_lib_get_split", "hfcl_lib_last_split_parts",
     "hfcl_collide_batch_qt", "hfcl_distance_batch_qt", "hfcl_lib_set_host_chunk", "hfcl_lib_set_shapes",
     "hfcl_lib_set_convex_neighbors", "hfcl_compact_results_device", "hfcl_compact_results_device_f32",
+ "hfcl_shard_range", "hfcl_multi_create", "hfcl_multi_destroy", "hfcl_multi_size", "hfcl_multi_replica",
+    "hfcl_multi_set_shapes", "hfcl_multi_set_convex_neighbors", "hfcl_multi_add_bvh", "hfcl_collide_batch_multi", "hfcl_distance_batch_multi",
+    "hfcl_collide_batch_multi_device", "hfcl_distance_batch_multi_device",
 ]
 
 
@@ -309,3 +312,73 @@ class Library:
         dll().hfcl_last_bucket_counts(self._h, out)
         keys = ["closed", "prim", "cc", "pc", "cp", "bvh", "unsupported", "large", "bvh_shape", "tri", "epa_queue", "epa_overflow"]
         return dict(zip(keys, [int(v) for v in out]))
+
+
+def shard_range(n, rank, world):
+    """hfcl_shard_range of the C ABI (= sharding.shard_range)."""
+    lo, hi = C.c_size_t(0), C.c_size_t(0)
+    dll().hfcl_shard_range(C.c_size_t(int(n)), C.c_int(int(rank)), C.c_int(int(world)), C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+class MultiLibrary:
+    """hfcl_multi: replicas of a shape library on several devices of this process (include/hppfcl_amd.h); a batch is cut
+    into contiguous shards, one per replica.  `devices` may list a device more than once (host-buffer entry points)."""
+
+    def __init__(self, shape_library, devices=(0,)):
+        d = dll()
+        self._shapes = np.ascontiguousarray(shape_library.shapes_array())
+        self._verts = np.ascontiguousarray(shape_library.vertices_array(), dtype=np.float64)
+        self.devices = [int(x) for x in devices]
+        dev = (C.c_int * len(self.devices))(*self.devices)
+        d.hfcl_multi_create.restype = C.c_void_p
+        h = d.hfcl_multi_create(dev, C.c_int(len(self.devices)), abi.ptr(self._shapes), C.c_size_t(len(self._shapes)), abi.ptr(self._verts),
+                                C.c_size_t(len(self._verts)))
+        if not h:
+            raise EngineError(abi.ERR_NO_DEVICE, last_error())
+        self._h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            dll().hfcl_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(dll().hfcl_multi_size(self._h))
+
+    def add_bvh(self, mesh):
+        nodes = np.ascontiguousarray(mesh.nodes)
+        verts = np.ascontiguousarray(mesh.vertices, dtype=np.float64)
+        tris = np.ascontiguousarray(mesh.triangles, dtype=np.uint32)
+        idx = dll().hfcl_multi_add_bvh(self._h, abi.ptr(nodes), C.c_size_t(len(nodes)), abi.ptr(verts), C.c_size_t(len(verts)), abi.ptr(tris),
+                                       C.c_size_t(len(tris)))
+        if idx < 0:
+            raise EngineError(abi.ERR_INVALID_ARGUMENT, last_error())
+        return idx
+
+    _host = Library._host
+
+    def collide(self, s1, s2, tf1, tf2, req=None, guess_in=None, want_guess=False):
+        return self._host(dll().hfcl_collide_batch_multi, s1, s2, tf1, tf2, req or abi.default_collision_request(), guess_in, want_guess)
+
+    def distance(self, s1, s2, tf1, tf2, req=None, guess_in=None, want_guess=False):
+        return self._host(dll().hfcl_distance_batch_multi, s1, s2, tf1, tf2, req or abi.default_distance_request(), guess_in, want_guess)
+
+    def _gathered(self, fn, d_s1, d_s2, d_tf1, d_tf2, n, req, d_gathered, streams=None):
+        """Per-replica lists of device buffers (torch tensors or raw pointers); d_gathered[g]: len(self) * ceil(n / len(self)) records."""
+        G = len(self)
+        arr = lambda xs: (C.c_void_p * G)(*[_dptr(x) for x in xs])  # noqa: E731
+        st = (C.c_void_p * G)(*[C.c_void_p(int(x)) for x in streams]) if streams is not None else None
+        _check(fn(self._h, arr(d_s1), arr(d_s2), arr(d_tf1), arr(d_tf2), C.c_size_t(int(n)), C.byref(req), arr(d_gathered), st))
+
+    def collide_device_gathered(self, d_s1, d_s2, d_tf1, d_tf2, n, req, d_gathered, streams=None):
+        self._gathered(dll().hfcl_collide_batch_multi_device, d_s1, d_s2, d_tf1, d_tf2, n, req, d_gathered, streams)
+
+    def distance_device_gathered(self, d_s1, d_s2, d_tf1, d_tf2, n, req, d_gathered, streams=None):
+        self._gathered(dll().hfcl_distance_batch_multi_device, d_s1, d_s2, d_tf1, d_tf2, n, req, d_gathered, streams)

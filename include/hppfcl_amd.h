@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HFCL_ABI_VERSION 3
+#define HFCL_ABI_VERSION 4  /* 4: the hfcl_multi_* entry points (several devices in one process) */
 
 /* ---- geometry kinds: numeric values are hpp-fcl's NODE_TYPE
  *      (include/hpp/fcl/collision_object.h:65-89) so a caller can pass
@@ -409,6 +409,48 @@ int  hfcl_lib_last_split_parts(const hfcl_lib* lib);  /* 1 or 2: how the last ba
 /* Per-kernel HIP events are recorded by default; a caller that does not read them can switch
  * them off (on = 0) and save two stream markers per kernel launch. */
 void hfcl_lib_set_kernel_timing(hfcl_lib* lib, int on);
+
+/* ---- several devices in one process ("one process, G streams") ---------------------------------------
+ * The queries of a batch are independent: a batch over G devices is G contiguous shards of the pair list, one per replica
+ * of the library, with no exchange between them -- replica g owns the pairs [lo_g, hi_g) of hfcl_shard_range (ceil(n / G)
+ * pairs each, the last ones possibly short or empty).  What the reference offers for this is the collector that hands a
+ * caller the broadphase's pair list (CollisionCallBackCollect, src/broadphase/default_broadphase_callbacks.cpp:91-123);
+ * the narrow phase over that list is what is sharded here.
+ * hfcl_multi_create: one replica of the library per entry of `devices` (a device may be listed more than once: two
+ * replicas then share it); every hfcl_multi_* registration call is the hfcl_lib_* call of the same name on every replica
+ * (same shape ids and bvh indices everywhere).  NULL + hfcl_last_error() on failure. */
+typedef struct hfcl_multi hfcl_multi;
+void hfcl_shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi);
+hfcl_multi* hfcl_multi_create(const int* devices, int n_devices, const hfcl_shape* shapes, size_t n_shapes,
+                              const double* vertices, size_t n_vertices);
+void      hfcl_multi_destroy(hfcl_multi* m);
+int       hfcl_multi_size(const hfcl_multi* m);
+hfcl_lib* hfcl_multi_replica(hfcl_multi* m, int i);
+int hfcl_multi_set_shapes(hfcl_multi* m, const hfcl_shape* shapes, size_t n_shapes, const double* vertices, size_t n_vertices);
+int hfcl_multi_set_convex_neighbors(hfcl_multi* m, uint32_t shape_id, const uint32_t* offsets, const uint32_t* neighbors);
+int hfcl_multi_add_bvh(hfcl_multi* m, const hfcl_bvh_node* nodes, size_t n_nodes, const double* vertices, size_t n_vertices,
+                       const uint32_t* triangles, size_t n_tris);
+/* Host buffers: hfcl_collide_batch / hfcl_distance_batch with the pair list cut into the replicas' shards, every shard
+ * through its replica's own pipeline (a host thread each), the records straight into the caller's `out` (the host form
+ * needs no collective).  The records equal the single-library call's byte for byte. */
+int hfcl_collide_batch_multi(hfcl_multi* m, const uint32_t* shape1, const uint32_t* shape2, const double* tf1,
+                             const double* tf2, size_t n, const hfcl_collision_request* req, hfcl_result* out,
+                             const hfcl_guess* guess_in, hfcl_guess* guess_out);
+int hfcl_distance_batch_multi(hfcl_multi* m, const uint32_t* shape1, const uint32_t* shape2, const double* tf1,
+                              const double* tf2, size_t n, const hfcl_distance_request* req, hfcl_result* out,
+                              const hfcl_guess* guess_in, hfcl_guess* guess_out);
+/* Device-resident buffers: replica g finds the inputs of ITS shard on its device (d_shape1[g] ... : hi_g - lo_g entries)
+ * and writes into d_gathered[g], a buffer of G * ceil(n / G) records on the same device: its own shard at slot g, then the
+ * other replicas' shards arrive by an in-place all-gather of the fixed-size records (ncclAllGather of librccl.so -- RCCL
+ * over xGMI --, loaded on first use; every device then holds the whole batch's records, north_star's exchange).
+ * Asynchronous on streams[g] (hipStream_t as void*; NULL array: the null streams).  With one replica there is nothing to
+ * gather.  HFCL_ERR_INVALID_ARGUMENT when a device is listed twice (one communicator rank per device) ; HFCL_ERR_HIP when librccl.so cannot be loaded. */
+int hfcl_collide_batch_multi_device(hfcl_multi* m, const uint32_t* const* d_shape1, const uint32_t* const* d_shape2,
+                                    const double* const* d_tf1, const double* const* d_tf2, size_t n,
+                                    const hfcl_collision_request* req, hfcl_result* const* d_gathered, void* const* streams);
+int hfcl_distance_batch_multi_device(hfcl_multi* m, const uint32_t* const* d_shape1, const uint32_t* const* d_shape2,
+                                     const double* const* d_tf1, const double* const* d_tf2, size_t n,
+                                     const hfcl_distance_request* req, hfcl_result* const* d_gathered, void* const* streams);
 
 #ifdef __cplusplus
 }

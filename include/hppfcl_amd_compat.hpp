@@ -472,15 +472,19 @@ inline hfcl_distance_request to_abi(const DistanceRequest& r) {
 // the CollisionCallBackCollect hand-off (collect pairs on the host, evaluate them in one call).
 class BatchQueries {
  public:
-  explicit BatchQueries(int device = 0) : device_(device) {}
-  ~BatchQueries() { hfcl_lib_destroy(lib_); }
+  explicit BatchQueries(int device = 0) : devices_(1, device) {}
+  /// Several devices of this process: the library is replicated on each and every batch is cut into contiguous shards, one per
+  /// device (hfcl_multi_*, include/hppfcl_amd.h); the results are the single-device ones.  A device may be listed more than once.
+  explicit BatchQueries(const std::vector<int>& devices) : devices_(devices.empty() ? std::vector<int>(1, 0) : devices) {}
+  ~BatchQueries() { hfcl_multi_destroy(lib_); }
+  size_t numDevices() const { return devices_.size(); }
   BatchQueries(const BatchQueries&) = delete;
   BatchQueries& operator=(const BatchQueries&) = delete;
 
   /// Forget every registered geometry (and free the device library): a long-lived context that has seen many temporary
   /// geometries -- the thread's default one behind collide() / distance() -- is pruned this way.
   void reset() {
-    hfcl_lib_destroy(lib_);
+    hfcl_multi_destroy(lib_);
     lib_ = nullptr;
     shapes_.clear();
     verts_.clear();
@@ -655,16 +659,16 @@ class BatchQueries {
            const std::vector<Transform3f>& tf2, const CollisionRequest* creq, const DistanceRequest* dreq) {
     if (tf1.size() != pairs.size() || tf2.size() != pairs.size()) throw std::invalid_argument("pairs/poses size mismatch");
     if (!lib_) {
-      lib_ = hfcl_lib_create(shapes_.data(), shapes_.size(), verts_.data(), verts_.size() / 3, device_);
+      lib_ = hfcl_multi_create(devices_.data(), static_cast<int>(devices_.size()), shapes_.data(), shapes_.size(), verts_.data(), verts_.size() / 3);
       if (!lib_) throw std::runtime_error(hfcl_last_error());
       meshes_uploaded_ = 0;
     } else if (shapes_dirty_) {  // geometries were added since the last query: new shape tables, everything else stays
-      const int rc = hfcl_lib_set_shapes(lib_, shapes_.data(), shapes_.size(), verts_.data(), verts_.size() / 3);
+      const int rc = hfcl_multi_set_shapes(lib_, shapes_.data(), shapes_.size(), verts_.data(), verts_.size() / 3);
       if (rc) throw_for(rc);
     }
     if (shapes_dirty_ || adjacency_pending_) {  // (hfcl_lib_set_shapes dropped the adjacencies of the old table)
       for (const auto& kv : adjacency_) {
-        const int rc = hfcl_lib_set_convex_neighbors(lib_, kv.first, kv.second.first.data(), kv.second.second.data());
+        const int rc = hfcl_multi_set_convex_neighbors(lib_, kv.first, kv.second.first.data(), kv.second.second.data());
         if (rc) throw_for(rc);
       }
       adjacency_pending_ = false;
@@ -672,8 +676,8 @@ class BatchQueries {
     shapes_dirty_ = false;
     for (; meshes_uploaded_ < meshes_.size(); ++meshes_uploaded_) {  // bvh_index = registration order
       const MeshRef& r = meshes_[meshes_uploaded_];
-      if (hfcl_lib_add_bvh(lib_, r.nodes.data(), r.nodes.size(), r.verts.data(), r.verts.size() / 3, r.tris.data(),
-                           r.tris.size() / 3) < 0)
+      if (hfcl_multi_add_bvh(lib_, r.nodes.data(), r.nodes.size(), r.verts.data(), r.verts.size() / 3, r.tris.data(),
+                             r.tris.size() / 3) < 0)
         throw std::runtime_error(hfcl_last_error());
     }
     std::vector<uint32_t> s1(pairs.size()), s2(pairs.size());
@@ -691,7 +695,8 @@ class BatchQueries {
       size_t cap = std::max<size_t>(1024, 64 * pairs.size()), produced = 0;
       for (int attempt = 0; attempt < 2; ++attempt) {
         contacts_.resize(cap);
-        rc = hfcl_collide_batch_contacts(lib_, s1.data(), s2.data(), reinterpret_cast<const double*>(tf1.data()),
+        // (contact lists are appended through one device counter: the first replica takes the whole batch)
+        rc = hfcl_collide_batch_contacts(hfcl_multi_replica(lib_, 0), s1.data(), s2.data(), reinterpret_cast<const double*>(tf1.data()),
                                          reinterpret_cast<const double*>(tf2.data()), pairs.size(), &a, rec_.data(),
                                          contacts_.data(), cap, &produced);
         if (rc || produced <= cap) break;
@@ -705,19 +710,19 @@ class BatchQueries {
       for (auto& g : guess_) g = hfcl_guess{{1, 0, 0}, {0, 0}};
     } else if (creq) {
       const hfcl_collision_request a = to_abi(*creq);
-      rc = hfcl_collide_batch(lib_, s1.data(), s2.data(), reinterpret_cast<const double*>(tf1.data()),
-                              reinterpret_cast<const double*>(tf2.data()), pairs.size(), &a, rec_.data(), nullptr, guess_.data());
+      rc = hfcl_collide_batch_multi(lib_, s1.data(), s2.data(), reinterpret_cast<const double*>(tf1.data()),
+                                    reinterpret_cast<const double*>(tf2.data()), pairs.size(), &a, rec_.data(), nullptr, guess_.data());
     } else {
       const hfcl_distance_request a = to_abi(*dreq);
-      rc = hfcl_distance_batch(lib_, s1.data(), s2.data(), reinterpret_cast<const double*>(tf1.data()),
-                               reinterpret_cast<const double*>(tf2.data()), pairs.size(), &a, rec_.data(), nullptr, guess_.data());
+      rc = hfcl_distance_batch_multi(lib_, s1.data(), s2.data(), reinterpret_cast<const double*>(tf1.data()),
+                                     reinterpret_cast<const double*>(tf2.data()), pairs.size(), &a, rec_.data(), nullptr, guess_.data());
     }
     if (rc) throw_for(rc);
   }
 
  private:
-  int device_;
-  hfcl_lib* lib_ = nullptr;
+  std::vector<int> devices_;
+  hfcl_multi* lib_ = nullptr;  // one replica of the library per device (one device: a single library behind the same calls)
   std::vector<hfcl_shape> shapes_;
   std::vector<double> verts_;
   std::vector<const CollisionGeometry*> geoms_;

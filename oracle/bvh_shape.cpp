@@ -481,6 +481,14 @@ struct MeshShapeDistTraversal {
 };
 }  // namespace
 
+// distance of ONE triangle of a mesh x solid query, as the traversal's leaf computes it with the request's solver settings
+// (default guess: the value does not depend on the leaves visited before) -- test infrastructure for enumerated ties
+double bvh_shape_leaf_distance(const MeshView& m1, const Tf& tf1, const Shape& s2, const Tf& tf2, const hfcl_distance_request& req, int pid) {
+  MeshShapeDistTraversal t(m1, tf1, s2, tf2, req);
+  t.leaf(pid);
+  return t.ok ? t.min_distance : std::numeric_limits<double>::quiet_NaN();
+}
+
 int bvh_shape_distance_pair(const MeshView& m1, const Tf& tf1, const Shape& s2, const Tf& tf2, const hfcl_distance_request& req,
                             bool swapped, hfcl_result& out, hfcl_guess* guess_out) {
   MeshShapeDistTraversal t(m1, tf1, s2, tf2, req);

@@ -4,6 +4,7 @@
 // Exit code 0 = all checks passed; 3 = no GPU (the shim has no CPU fallback).
 #include <chrono>
 #include <cmath>
+#include <cstring>
 #include <memory>
 #include <vector>
 #include <cstdio>
@@ -96,6 +97,49 @@ int main() {
     DistanceRequest rq; std::vector<DistanceResult> res;
     batch.distance(pairs, tf1, tf2, rq, res);
     for (int k = 0; k < 100; ++k) CHECK(std::fabs(res[k].min_distance - (1.5 + 0.02 * k - 2.0)) < 1e-6);
+  }
+  {  // the same hand-off over two replicas of the library (hfcl_multi_*; both on device 0 here): a 100 001-pair list cut into two shards
+     // equals the single-library batch record for record (the collector that feeds it: default_broadphase_callbacks.cpp:93-123)
+    STAGE("multi-device batch");
+    auto pts = std::make_shared<std::vector<Vec3f>>();
+    for (int i = 0; i < 8; ++i) pts->push_back(Vec3f((i & 1) ? 1 : -1, (i & 2) ? 1 : -1, (i & 4) ? 1 : -1));
+    ConvexBase cube(pts);
+    Box box(2, 2, 2);
+    Capsule cap(0.4, 1.2);
+    Sphere ball(0.7);
+    amd::BatchQueries one, two(std::vector<int>{0, 0});
+    CHECK(two.numDevices() == 2);
+    const CollisionGeometry* geoms[4] = {&cube, &box, &cap, &ball};
+    uint32_t id1[4], id2[4];
+    for (int k = 0; k < 4; ++k) { id1[k] = one.add(geoms[k]); id2[k] = two.add(geoms[k]); CHECK(id1[k] == id2[k]); }
+    const size_t n = 100001;
+    std::vector<std::pair<uint32_t, uint32_t>> pairs(n);
+    std::vector<Transform3f> tf1(n), tf2(n);
+    uint64_t rng = 12345;
+    auto uni = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return double(rng >> 11) / double(1ull << 53); };
+    for (size_t k = 0; k < n; ++k) {
+      pairs[k] = {id1[k % 4], id1[(k / 4 + k) % 4]};
+      auto unit = [](double w, double x, double y, double z) { const double s = 1.0 / std::sqrt(w * w + x * x + y * y + z * z); return makeQuat(w * s, x * s, y * s, z * s); };
+      tf1[k] = Transform3f(unit(1, 0.3 * uni(), 0.2 * uni(), 0.1 * uni()), Vec3f(0.3 * uni(), 0.3 * uni(), 0.3 * uni()));
+      tf2[k] = Transform3f(unit(1, 0.5 * uni(), 0.4 * uni(), 0.3 * uni()), Vec3f(3.0 * uni() - 0.5, 0.8 * uni(), 0.8 * uni()));
+    }
+    DistanceRequest dq; std::vector<DistanceResult> r1, r2;
+    one.distance(pairs, tf1, tf2, dq, r1);
+    two.distance(pairs, tf1, tf2, dq, r2);
+    CHECK(r1.size() == n && r2.size() == n);
+    size_t differ = 0, penetrating = 0;
+    for (size_t k = 0; k < n; ++k) {
+      differ += std::memcmp(&one.records()[k], &two.records()[k], sizeof(hfcl_result)) != 0;
+      penetrating += r1[k].min_distance <= 0;
+    }
+    CHECK(differ == 0);
+    CHECK(penetrating > n / 20 && penetrating < n - n / 20);
+    CollisionRequest cq; std::vector<CollisionResult> c1, c2;
+    one.collide(pairs, tf1, tf2, cq, c1);
+    two.collide(pairs, tf1, tf2, cq, c2);
+    differ = 0;
+    for (size_t k = 0; k < n; ++k) differ += std::memcmp(&one.records()[k], &two.records()[k], sizeof(hfcl_result)) != 0 || c1[k].numContacts() != c2[k].numContacts();
+    CHECK(differ == 0);
   }
   {  // BVHModel<OBBRSS>: two box meshes as in test/collision.cpp / geometric_shape_to_BVH_model.h (12 triangles each)
     auto make_box_mesh = [](BVHModel<OBBRSS>& m, double hx, double hy, double hz) {

@@ -184,6 +184,23 @@ def bvh_leaf_distance(meshlib, m1, m2, tf1, tf2, pid1, pid2):
              C.c_uint32(int(m1)), C.c_uint32(int(m2)), abi.ptr(t1), abi.ptr(t2), C.c_int(int(pid1)), C.c_int(int(pid2)))
 
 
+def mixed_leaf_distance(shapes, verts, meshlib, s1, s2, tf1, tf2, pid, req=None):
+    """The distance the oracle's mesh x solid traversal assigns to triangle `pid` of the query (shape s1 at tf1, shape s2 at tf2; one of
+    them a mesh), with the request's solver settings and the default guess."""
+    abi = _pkg().abi
+    req = req or abi.default_distance_request()
+    f = lib().orc_mixed_leaf_distance
+    f.restype = C.c_double
+    shapes = np.ascontiguousarray(shapes)
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    nodes = np.ascontiguousarray(meshlib.nodes)
+    t1 = np.ascontiguousarray(tf1, dtype=np.float64).reshape(12)
+    t2 = np.ascontiguousarray(tf2, dtype=np.float64).reshape(12)
+    return f(abi.ptr(shapes), C.c_size_t(len(shapes)), abi.ptr(verts), abi.ptr(nodes), abi.ptr(meshlib.verts), abi.ptr(meshlib.tris),
+             abi.ptr(meshlib.table), C.c_size_t(len(meshlib.table)), C.c_uint32(int(s1)), C.c_uint32(int(s2)), abi.ptr(t1), abi.ptr(t2),
+             C.byref(req), C.c_int(int(pid)))
+
+
 def rect_distance(Rab, Tab, a, b):
     abi = _pkg().abi
     L = lib()

@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(declared) >= 19
     for sym in sorted(declared):
         assert hasattr(lib, sym), "missing export: " + sym
-    assert lib.hfcl_abi_version() == 3
+    assert lib.hfcl_abi_version() == 4
     assert set(pkg.engine.EXPORTED_SYMBOLS) <= declared
 
 

@@ -26,31 +26,35 @@ def _engine(pkg, b, req):
         lib.close()
 
 
+def _check_exact(abi, got, ref, name):
+    """The fp64 GJK / EPA kernels are built without contraction (hfcl_k_gjk64.o / hfcl_k_epa64.o): every integer output -- GJK and EPA
+    status, both iteration counts, the contact flag, the contact count -- and every distance equal the oracle's, record for record."""
+    assert np.array_equal(got["status"], ref["status"]), "%s: %d status words differ" % (name, int((got["status"] != ref["status"]).sum()))
+    assert np.array_equal(got["num_contacts"], ref["num_contacts"]), name
+    d_eq = (got["distance"] == ref["distance"]) | (np.isnan(got["distance"]) & np.isnan(ref["distance"]))
+    assert d_eq.all(), "%s: %d distances differ in their last bits, max %g" % (
+        name, int((~d_eq).sum()), np.nanmax(np.abs(got["distance"][~d_eq] - ref["distance"][~d_eq])))
+
+
 def test_native_library_is_loaded(pkg):
     assert pkg.engine.device_count() >= 1
-    assert pkg.engine.dll().hfcl_abi_version() == 3
+    assert pkg.engine.dll().hfcl_abi_version() == 4
 
 
 @pytest.mark.parametrize("case,n", [("cfg1_sphere_sphere", 1000), ("cfg2_box_capsule", 100000),
                                     ("cfg3_convex_convex", 100000), ("cfg5_mixed", 100000),
                                     ("all_primitives", 100000)])
 def test_fp64_parity(pkg, oracle, case, n):
-    """fp64 kernels vs oracle: flags/statuses exact (outside a 1e-9 decision band), distances and
-    separation vectors to the solver tolerance 1e-6 (narrowphase_defaults.h:48,61)."""
+    """fp64 kernels vs oracle: statuses, iteration counts, flags and distances EQUAL in every record (no decision band: the kernels
+    do the reference's arithmetic, no contraction), witness points and normals to 1e-9 (their last step -- closest_points, the
+    transform to the world frame -- is summed in another order than the oracle's)."""
     abi, wl = pkg.abi, pkg.workloads
     b = getattr(wl, case)(n=n)
     req = wl.make_request(b, abi)
     ref = _oracle(oracle, b, req)
     got, buckets = _engine(pkg, b, req)
-    # Smooth shapes (cone / cylinder mantle): EPA stops on its tolerance (1e-6 * (1 + |w|)), not on an exact
-    # face, so FMA contraction moves the depth by ~tolerance and the normal by ~sqrt(tolerance); polytopes
-    # and the other kinds terminate exactly and agree to ~1e-12.
-    smooth = case == "all_primitives"
-    st = check_parity(abi, got, ref, dist_tol=4e-6 if smooth else 1e-6, point_tol=2e-3 if smooth else 1e-5,
-                      flag_band=1e-9, name=case)
-    # FMA contraction is the only arithmetic difference: ~1e-12 on all but a few ill-conditioned pairs
-    # (EPA picking the other of two near-equidistant faces: still inside the solver tolerance)
-    assert st["p999_dd"] < (1e-6 if smooth else 1e-9) and st["max_dd"] < (4e-6 if smooth else 1e-6), st
+    _check_exact(abi, got, ref, case)
+    check_parity(abi, got, ref, dist_tol=1e-15, point_tol=1e-9, flag_band=0.0, name=case)
     check_properties(abi, got, tol=1e-6, name=case)
     assert buckets["unsupported"] == 0
 
@@ -79,7 +83,8 @@ def test_fp64_gjk_variants(pkg, oracle, variant):
     req.q.gjk_variant = variant
     ref = _oracle(oracle, b, req)
     got, _ = _engine(pkg, b, req)
-    check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name="variant%d" % variant)
+    _check_exact(abi, got, ref, "variant%d" % variant)
+    check_parity(abi, got, ref, dist_tol=1e-15, point_tol=1e-9, flag_band=0.0, name="variant%d" % variant)
 
 
 @pytest.mark.parametrize("crit", [(0, 0), (1, 0), (1, 1), (2, 0), (2, 1)])
@@ -96,21 +101,10 @@ def test_fp64_convergence_criteria(pkg, oracle, variant, crit):
     ref = _oracle(oracle, b, req)
     got, _ = _engine(pkg, b, req)
     name = "crit%d%d-v%d" % (crit + (variant,))
-    # The *relative* form of the duality-gap and hybrid tests asks diff <= tol^2 = 1e-12 with diff = 2 ray.(ray - w) or
-    # |ray|^2 - alpha^2 (the reference's formula, gjk.cpp:405-422): on a strictly convex shape (Ellipsoid) GJK then runs
-    # 25-40 iterations until that difference of nearly equal numbers falls below 1e-12 by cancellation, i.e. round-off
-    # decides the last iterations (the device contracts a*b+c, the oracle does not; the reference itself would move with
-    # its compiler flags).  Those pairs are held to the solver's accuracy instead of to the oracle's last digits;
-    # everything else matches as usual.
-    smooth = (crit in ((1, 0), (2, 0))) & ((b.shapes["type"][b.s1] == abi.GEOM_ELLIPSOID) | (b.shapes["type"][b.s2] == abi.GEOM_ELLIPSOID))
-    check_parity(abi, got[~smooth], ref[~smooth], dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name=name)
-    if smooth.any():
-        dd = np.abs(got["distance"][smooth] - ref["distance"][smooth])
-        assert np.array_equal(abi.status_contact(got["status"][smooth]), abi.status_contact(ref["status"][smooth])) or \
-            np.all(np.abs(ref["distance"][smooth][abi.status_contact(got["status"][smooth]) != abi.status_contact(ref["status"][smooth])]) < 1e-4)
-        assert (dd > 1e-4 * (1 + np.abs(ref["distance"][smooth]))).mean() < 2e-3, name
-    same_it = abi.status_gjk_iters(got["status"][~smooth]) == abi.status_gjk_iters(ref["status"][~smooth])
-    assert same_it.mean() > 0.99, same_it.mean()
+    # (The *relative* duality-gap and hybrid tests ask diff <= tol^2 = 1e-12 of a difference of nearly equal numbers, gjk.cpp:405-422: on
+    # an Ellipsoid round-off decides GJK's last iterations.  With the kernels' arithmetic equal to the oracle's that is no exception any more.)
+    _check_exact(abi, got, ref, name)
+    check_parity(abi, got, ref, dist_tol=1e-15, point_tol=1e-9, flag_band=0.0, name=name)
 
 
 @pytest.mark.parametrize("case", ["cfg5_mixed", "cfg3_convex_convex"])
@@ -122,10 +116,8 @@ def test_fp64_bounding_volume_guess(pkg, oracle, case):
     req.q.gjk_initial_guess = abi.BoundingVolumeGuess
     ref = _oracle(oracle, b, req)
     got, _ = _engine(pkg, b, req)
-    check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name=case + "-bvguess")
-    # the guess itself is computed with FMA contraction on the device (last-bit differences), which moves the trip
-    # count of ~1 % of the Nesterov runs by one; results agree to the solver tolerance (check_parity above)
-    assert (abi.status_gjk_iters(got["status"]) == abi.status_gjk_iters(ref["status"])).mean() > 0.97
+    _check_exact(abi, got, ref, case + "-bvguess")
+    check_parity(abi, got, ref, dist_tol=1e-15, point_tol=1e-9, flag_band=0.0, name=case + "-bvguess")
 
 
 def test_fp64_collide_options(pkg, oracle):
@@ -136,7 +128,8 @@ def test_fp64_collide_options(pkg, oracle):
         req.security_margin, req.distance_upper_bound, req.enable_contact = margin, dub, contact
         ref = _oracle(oracle, b, req)
         got, _ = _engine(pkg, b, req)
-        check_parity(abi, got, ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name="opts%s" % ((margin, dub),))
+        _check_exact(abi, got, ref, "opts%s" % ((margin, dub),))
+        check_parity(abi, got, ref, dist_tol=1e-15, point_tol=1e-9, flag_band=0.0, name="opts%s" % ((margin, dub),))
         assert np.array_equal(got["num_contacts"] > 0, abi.status_contact(got["status"]) > 0)
     req = abi.default_collision_request()
     req.security_margin = -np.inf
@@ -353,7 +346,8 @@ def test_full_size_properties(pkg, oracle, torch_cuda, case):
     sub = b.slice(0, len(b))
     ofn = oracle.distance_batch if b.kind == "distance" else oracle.collide_batch
     ref = ofn(b.shapes, b.verts, b.s1[idx], b.s2[idx], b.tf1[idx], b.tf2[idx], req, n_threads=8)
-    check_parity(abi, got[idx], ref, dist_tol=1e-6, point_tol=1e-5, flag_band=1e-9, name=case + "-1M-sample")
+    _check_exact(abi, got[idx], ref, case + "-1M-sample")
+    check_parity(abi, got[idx], ref, dist_tol=1e-15, point_tol=1e-9, flag_band=0.0, name=case + "-1M-sample")
     frac = abi.status_contact(got["status"]).mean()
     assert 0.2 < frac < 0.45, frac
     lib.close()

@@ -44,6 +44,7 @@ for case, kw, mode in cases:
     fl_eq = abi.status_contact(got["status"]) == abi.status_contact(ref["status"])
     w_eq = nanok(got["p1"], ref["p1"]).all(axis=1) & nanok(got["p2"], ref["p2"]).all(axis=1) & nanok(got["normal"], ref["normal"]).all(axis=1)
     dd = np.abs(got["distance"] - ref["distance"])
+    dw = max(np.nanmax(np.abs(got[f] - ref[f])) for f in ("p1", "p2", "normal"))
     print("%-20s %-8s n=%d | status equal %.6f | gjk iters equal %.6f | epa iters equal %.6f | contact flags differ %d | distance bit-equal %.6f | "
-          "witness+normal bit-equal %.6f | max|dd| %.3g" % (case, mode or "", len(got), st_eq.mean(), gi_eq.mean(), ei_eq.mean(), int((~fl_eq).sum()),
-                                                              d_eq.mean(), w_eq.mean(), np.nanmax(dd)))
+          "witness+normal bit-equal %.6f | max|dd| %.3g | max witness/normal diff %.3g" % (case, mode or "", len(got), st_eq.mean(), gi_eq.mean(), ei_eq.mean(), int((~fl_eq).sum()),
+                                                              d_eq.mean(), w_eq.mean(), np.nanmax(dd), dw))

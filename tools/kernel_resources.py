@@ -8,16 +8,18 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-UNITS = ("gjk", "epa", "bvh", "bvhd")
-units = [a for a in sys.argv[1:] if a in UNITS] or list(UNITS)
-flags = [a for a in sys.argv[1:] if a not in UNITS]
+UNITS = ("gjk32", "gjk64", "epa32", "epa64", "bvh", "bvhs", "bvhd")  # as the Makefile builds them (gjk / epa: both precisions)
+ALIAS = {"gjk": ["gjk32", "gjk64"], "epa": ["epa32", "epa64"]}
+units = [u for a in sys.argv[1:] for u in ALIAS.get(a, [a] if a in UNITS else [])] or list(UNITS)
+flags = [a for a in sys.argv[1:] if a not in UNITS and a not in ALIAS]
 procs = []
 for u in units:  # the translation units compile side by side
-    src = os.path.join(ROOT, "hpp-fcl_amd", "csrc", "hfcl_k_%s.hip" % u)
+    src = os.path.join(ROOT, "hpp-fcl_amd", "csrc", "hfcl_k_%s.hip" % ("bvh" if u == "bvhs" else u.rstrip("0123456789")))
+    mk = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "hpp-fcl_amd", "csrc"), "-pn"], capture_output=True, text=True).stdout
+    m = re.search(r"^FLAGS_k_%s = (.*)$" % u, mk, re.M)  # the Makefile's per-unit flags
+    unit_flags = (m.group(1).split() if m else []) + (["-DHFCL_UNIT_PRECISION=" + u[-2:]] if u[-2:] in ("32", "64") else [])
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-value", "-Wno-pass-failed",
-           "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", src] + \
-        (["-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt"] if u in ("gjk", "epa") else []) + \
-        (["-ffp-contract=on"] if u == "epa" else []) + (["-ffp-contract=off"] if u == "bvhd" else []) + flags  # (the Makefile's per-unit flags)
+           "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", src] + unit_flags + flags
     procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
 err = "".join(p.communicate()[1] for p in procs)
 rows, cur = [], {}

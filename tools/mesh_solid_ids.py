@@ -42,6 +42,16 @@ for kind in kinds:
               kind, n, int(mixed.sum()), sep.sum() / max(1, mixed.sum()), same[mixed].mean(), same[sep].mean(), int((~same[sep]).sum()),
               eq_d[mixed].mean(), eq_d[sep].mean(), eq_w[sep].mean(), eq_s[mixed].mean(),
               np.nanmax(np.abs(got["distance"][mixed] - ref["distance"][mixed])), [(a, round(v, 2)) for a, v in kb if v > 0.05]))
+    bad = np.flatnonzero(mixed & ~same)
+    nt = 0
+    for k in bad[:40]:
+        dg = ob.mixed_leaf_distance(b.shapes, b.verts, ML, b.s1[k], b.s2[k], b.tf1[k], b.tf2[k], got["b1"][k], req)
+        nt += dg == ref["distance"][k]
+        if k in bad[:6] or dg != ref["distance"][k]:
+            print("           record %d: device triangle %d (oracle leaf value %.17g, device distance %.17g), oracle triangle %d at %.17g" % (
+                k, got["b1"][k], dg, got["distance"][k], ref["b1"][k], ref["distance"][k]))
+    if len(bad):
+        print("           %d of the first %d differing records report a triangle at exactly the oracle's distance (0-ulp ties)" % (nt, min(40, len(bad))))
     pen = mixed & ~sep
     if pen.any():
         print("           penetrating: ids equal %.5f  distance bit-equal %.5f  max|dd| %.3g" % (
