@@ -102,7 +102,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo "
                     "stages the records through host memory and allows several ranks per device)")
     ap.add_argument("--device-map", default="", help="comma list: device of each local rank (default: rank r -> device r)")
-    ap.add_argument("--verify-gather", action="store_true", help="after the timed region check what the exchange "
+    ap.add_argument("--no-verify-gather", dest="verify_gather", action="store_false", default=None, help="skip the check below")
+    ap.add_argument("--verify-gather", action="store_true", default=None, help="(default when WORLD_SIZE > 1) after the timed region check what the exchange "
                     "delivered: block checksums of every rank; --scaling strong: bytes equal to the whole list run on rank 0")
     ap.add_argument("--split", type=int, default=0, help="0: the library decides (two half-batches on two streams for "
                     "mixed libraries); 1: one stream; 2: always split")
@@ -246,8 +247,13 @@ def compact_line(full):
             rows.append({"workload": s.get("workload"), "error": str(s["error"])[:80]})
             continue
         srf, scb = s.get("roofline") or {}, s.get("cpu_baseline") or {}
+        # two fractions of the HBM peak per row, each with ONE meaning on every row: l2_frac = what the lanes consume (the algorithmic
+        # bytes of the row: visited node / triangle records for the mesh rows, which live in L2 / MALL) / kernel time; hbm_frac = what the
+        # memory controllers moved (PMC bytes of the committed pass of this device code) / kernel time, null without such a pass
+        kms = srf.get("kernel_ms")
+        hbm_frac = (srf["traffic"] / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (srf.get("traffic") and kms and kms == kms and kms > 0) else None
         row = {"workload": s.get("tag") or str(s.get("workload"))[:72], "value": _r(s.get("value"), 4), "ms_per_step": _r(s.get("ms_per_step"), 4),
-               "dtype": s.get("dtype"), "frac": _r(srf.get("frac"), 3), "cpu_1thread": _r(scb.get("value"), 4)}
+               "dtype": s.get("dtype"), "l2_frac": _r(srf.get("frac"), 3), "hbm_frac": _r(hbm_frac, 3), "cpu_1thread": _r(scb.get("value"), 4)}
         if (s.get("config") or {}).get("pairs_per_step_all_gpus"):
             row["pairs"] = s["config"]["pairs_per_step_all_gpus"]
         shb = s.get("host_buffers")
@@ -267,7 +273,12 @@ def compact_line(full):
         line["secondary"] = line["secondary"][:-1]
         line["secondary_truncated"] = True
         out = json.dumps(line, separators=(",", ":"))
-    assert len(out) <= COMPACT_LIMIT, len(out)
+    for optional in ("host_buffers", "cpu_baseline", "roofline"):  # (cannot happen with today's fields; a line is printed whatever happens)
+        if len(out) <= COMPACT_LIMIT:
+            break
+        line[optional] = None
+        line["truncated"] = True
+        out = json.dumps(line, separators=(",", ":"))
     return out
 
 
@@ -359,7 +370,8 @@ def cpu_baseline(ctx, workload, batch, req, sample, budget_s, all_cores=True):
         t_cpu += time.perf_counter() - t1
         reps += 1
     out = {"value": reps * ns / t_cpu, "unit": "queries/s", "cores": 1, "kind": "port",
-           "sample": "%d pairs of the same workload x %d repeats, fp64 CPU oracle (oracle/), 1 thread" % (ns, reps)}
+           "sample": "%d pairs of the same workload x %d repeats, fp64 CPU oracle (oracle/: g++ -O3 -march=x86-64-v2, no FMA -- the reference's default "
+                     "arithmetic, not -march=native), 1 thread" % (ns, reps)}
     if all_cores:
         cores_all = os.cpu_count() or 1
         t1 = time.perf_counter()
@@ -491,7 +503,35 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
     gather_check = None
     if gather and steps > 0:
         gather_check = {"block_checksums": xch.verify(last, sent[last], ctx.rank)}
-        if args.verify_gather and strong:
+        verify = args.verify_gather if args.verify_gather is not None else ctx.world > 1  # (on by default for every real multi-rank run)
+        if verify and not strong and workload in WALK_BYTES:
+            verify = False  # (weak scaling regenerates every rank's batch on rank 0: done for the pair-list workloads, not for the mesh scenes)
+        if verify and not strong:
+            # weak scaling: every rank ran its own list (seed 1 + rank).  Rank 0 regenerates each of them, runs it through the same entry
+            # point alone, and compares with the rank's block of the gathered buffer: bytes equal to single-rank runs
+            ok = None
+            if ctx.rank == 0:
+                ok = True
+                per_words = xch.gathered[last].numel() // ctx.world
+                for r in range(ctx.world):
+                    c2 = Ctx()
+                    c2.__dict__.update(ctx.__dict__)
+                    c2.rank, c2.batch_cache = r, None
+                    b_r = make_batch(c2, workload, n, False)[0]
+                    f_s1 = torch.from_numpy(b_r.s1.astype(np.int32)).to(dev)
+                    f_s2 = torch.from_numpy(b_r.s2.astype(np.int32)).to(dev)
+                    f_p1 = torch.from_numpy(b_r.pose1_f32 if dtype == "f32" else b_r.tf1).to(dev)
+                    f_p2 = torch.from_numpy(b_r.pose2_f32 if dtype == "f32" else b_r.tf2).to(dev)
+                    f_out = torch.zeros(n * rec_words, dtype=torch.int32, device=dev)
+                    launch(f_s1, f_s2, f_p1, f_p2, n, req, f_out, stream=stream.cuda_stream)
+                    torch.cuda.synchronize()
+                    rec = f_out.cpu().numpy().view(abi.RESULT_F32_DTYPE if dtype == "f32" else abi.RESULT_DTYPE)
+                    want = pkg.multigpu.expected_exchange(rec, dtype, gather_mode)
+                    got = xch.gathered[last][r * per_words:r * per_words + want.size].cpu().numpy()
+                    ok = ok and bool(np.array_equal(got, want))
+                    del f_s1, f_s2, f_p1, f_p2, f_out
+            gather_check["equals_single_rank_run"] = ok
+        if verify and strong:
             # the whole list on ONE rank, through the same entry point: the gathered buffer must hold exactly these bytes
             ok = None
             if ctx.rank == 0:

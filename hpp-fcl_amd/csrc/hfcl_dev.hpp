@@ -701,6 +701,8 @@ struct BvhSplit {
   // DFS order as it does for k_bvh_collide's task levels.  0: never (the walk stays with its wave to the end).
   uint32_t cut_ticks;
   uint32_t cut_cap;     // words of cut_words (and values of cut_vals)
+  uint32_t cut_task_cap;  // chunk tasks the cuts of a batch may make in all (mesh x solid: every chunk is a unit that can queue one EPA item, and
+                          // the host sized that queue for n queries + this many chunks; a walk that would exceed it is not cut)
   uint32_t* cut_words;  // stack entries of the cut walks
   void* cut_vals;       // T[cut_cap]: what is known about them (k_bvh_shape_coop's tagged entries: a box's bound, a triangle's distance)
 };

@@ -820,6 +820,12 @@ static void free_retired_graphs(hfcl_lib* lib) {  // (the caller has waited for 
 static int upload_graph(hfcl_lib* lib) {
   if (!lib->graph_dirty) return HFCL_OK;
   HIP_TRY(hipSetDevice(lib->device));
+  // (an application that re-registers neighbours between batches must not grow device memory without bound: after four retired
+  // images the device is waited for once and they are freed)
+  if (lib->graph_retired.size() >= 16) {
+    HIP_TRY(hipDeviceSynchronize());
+    free_retired_graphs(lib);
+  }
   for (void* p : {(void*)lib->d_graph_base, (void*)lib->d_graph_off, (void*)lib->d_graph_ent32, (void*)lib->d_graph_ent64})
     if (p) lib->graph_retired.push_back(p);
   lib->d_graph_base = nullptr; lib->d_graph_off = nullptr; lib->d_graph_ent32 = nullptr; lib->d_graph_ent64 = nullptr;
@@ -1204,6 +1210,8 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       split.coop_grid = uint32_t(lib->n_cus) * 8u;
       split.cut_ticks = solid ? lib->shape_cut_ticks : lib->bvh_cut_ticks;
       split.cut_cap = split.cap;
+      // (mesh x solid: the EPA queue has room for one item per query and per chunk -- shape_defer_cap entries, sized before the walk)
+      split.cut_task_cap = solid ? (wk.shape_defer_cap > n ? uint32_t(std::min<size_t>(wk.shape_defer_cap - n, split.cap)) : 0u) : split.cap;
       split.cut_words = lib->d_bvh_cut_words;
       split.cut_vals = lib->d_bvh_cut_vals;
       if (!solid && lib->bvh_coop) {

@@ -1267,7 +1267,7 @@ __device__ __forceinline__ bool coop_cut(const BvhSplit& split, uint32_t my_slot
   first_word = uint32_t(__shfl(int(first_word), 0, W));
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the stack was written back by the lanes of this trip)
   __builtin_amdgcn_wave_barrier();
-  if (first_task + n_chunks > split.cap || first_word + n_ent > split.cut_cap) {
+  if (first_task + n_chunks > min(split.cap, split.cut_task_cap) || first_word + n_ent > split.cut_cap) {
     for (uint32_t c = first_task + uint32_t(lig); c < min(first_task + n_chunks, split.cap); c += uint32_t(W)) split.tasks[c] = BvhTask{0u, 0u, 0xFFFFFFFFu, 0u};
     return false;
   }

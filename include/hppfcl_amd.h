@@ -96,7 +96,9 @@ typedef struct hfcl_query_request {
   int32_t  gjk_convergence_criterion;       /* Default (VDB)                          */
   int32_t  gjk_convergence_criterion_type;  /* Relative                               */
   uint32_t gjk_max_iterations;              /* 128  narrowphase_defaults.h:47         */
-  uint32_t epa_max_iterations;              /* 64   narrowphase_defaults.h:60 (device limit: <= 64) */
+  uint32_t epa_max_iterations;              /* 64   narrowphase_defaults.h:60.  DEVICE LIMIT: <= 64 -- the polytope blocks in LDS hold the
+                                             * reference's default capacity (68 vertices, 132 faces; 8-bit indices); a larger value is refused with
+                                             * HFCL_ERR_LIMIT, never clamped silently (the reference takes any value, collision_data.h:171-237) */
   double   gjk_tolerance;                   /* 1e-6                                   */
   double   epa_tolerance;                   /* 1e-6                                   */
   double   collision_distance_threshold;    /* Eigen dummy_precision<double> = 1e-12, collision_data.h:236 */
@@ -154,6 +156,14 @@ typedef struct hfcl_result {
   uint32_t status;          /* packed, see above                                       */
   int32_t  num_contacts;    /* collide only                                            */
 } hfcl_result;              /* 96 bytes                                                */
+/* b1 / b2 of a mesh distance() record and ties.  Triangles that share the closest vertex or edge are at the minimal distance
+ * bit for bit, and DistanceResult::update (collision_data.h:1099-1125) keeps the first the reference's walk meets.  The default
+ * continuation kernels of long walks (several walks per wave, their tests pooled) reproduce that choice through a marker rule;
+ * where the choice hangs on a bound that exceeds a distance beneath it by an ulp, they may report ANOTHER triangle (pair) at exactly
+ * the same distance -- measured: 0 records in 2.1 M mesh x mesh queries, 4 in 300 000 mesh x solid queries -- and, mesh x mesh, which
+ * one can differ between two runs (which walks share a wave depends on the order they are drawn in).  distance, status and the
+ * witness points of records with equal ids do not depend on it.  HFCL_BVHD_POOL=0 / HFCL_SHAPE_DIST_POOL=0 select the ordered
+ * continuation kernels, which have no such records (1.5-2x slower on long walks). */
 
 /* Compact fp32 record for the fp32 device-resident path: 44 bytes.  It has NO b1 / b2: a BVHModel pair run through the
  * fp32 entry points reports its contact flag, distance, witness points and normal, not the triangle ids (Contact::b1 / b2,

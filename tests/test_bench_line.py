@@ -76,4 +76,4 @@ def test_two_stream_rows_and_errors():
     full["secondary"][1]["roofline"] = {"frac": None, "kernel": None}
     d = json.loads(b.compact_line(full))
     assert len(d["secondary"][0]["error"]) <= 80
-    assert d["secondary"][1]["frac"] is None and d["secondary"][1]["batches_in_flight"] == 2
+    assert d["secondary"][1]["l2_frac"] is None and d["secondary"][1]["hbm_frac"] is None and d["secondary"][1]["batches_in_flight"] == 2

@@ -92,12 +92,13 @@ def test_two_ranks_on_one_gpu_strong_cfg5(torch_cuda, gather):
 
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_weak_cfg3(torch_cuda):
-    """The headline's N > 1 form: own batch per rank, fp32 records all-gathered; block checksums of both ranks agree."""
+    """The headline's N > 1 form as a driver launches it (no extra flag): own batch per rank, fp32 records all-gathered; block checksums
+    of both ranks agree, and every rank's block equals that rank's batch run alone on rank 0, byte for byte."""
     line = _bench(["--gpus", "2", "--backend", "gloo", "--device-map", "0,0", "--workload", "cfg3", "--pairs", "65537",
                    "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
     cfg = line["config"]
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and cfg["pairs_per_step_all_gpus"] == 2 * 65537
-    assert cfg["gather_check"]["block_checksums"] is True
+    assert cfg["gather_check"] == {"block_checksums": True, "equals_single_rank_run": True}
     assert cfg["gather_bytes_per_rank_per_step"]["received"] == 65537 * 44
 
 
