@@ -518,17 +518,21 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
                     c2.__dict__.update(ctx.__dict__)
                     c2.rank, c2.batch_cache = r, None
                     b_r = make_batch(c2, workload, n, False)[0]
+                    lib_r = wl.make_library(pkg, b_r, device=ctx.device_index)  # (the rank's own shape library: its seed makes the hulls too)
+                    name = ("distance" if b_r.kind == "distance" else "collide") + ("_device_f32" if dtype == "f32" else "_device")
+                    launch_r = getattr(lib_r, name)
                     f_s1 = torch.from_numpy(b_r.s1.astype(np.int32)).to(dev)
                     f_s2 = torch.from_numpy(b_r.s2.astype(np.int32)).to(dev)
                     f_p1 = torch.from_numpy(b_r.pose1_f32 if dtype == "f32" else b_r.tf1).to(dev)
                     f_p2 = torch.from_numpy(b_r.pose2_f32 if dtype == "f32" else b_r.tf2).to(dev)
                     f_out = torch.zeros(n * rec_words, dtype=torch.int32, device=dev)
-                    launch(f_s1, f_s2, f_p1, f_p2, n, req, f_out, stream=stream.cuda_stream)
+                    launch_r(f_s1, f_s2, f_p1, f_p2, n, req, f_out, stream=stream.cuda_stream)
                     torch.cuda.synchronize()
                     rec = f_out.cpu().numpy().view(abi.RESULT_F32_DTYPE if dtype == "f32" else abi.RESULT_DTYPE)
                     want = pkg.multigpu.expected_exchange(rec, dtype, gather_mode)
                     got = xch.gathered[last][r * per_words:r * per_words + want.size].cpu().numpy()
                     ok = ok and bool(np.array_equal(got, want))
+                    lib_r.close()
                     del f_s1, f_s2, f_p1, f_p2, f_out
             gather_check["equals_single_rank_run"] = ok
         if verify and strong:

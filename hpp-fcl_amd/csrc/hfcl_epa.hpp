@@ -226,7 +226,7 @@ HFCL_HD int epa_face_plane(const V3<T>& a, const V3<T>& b, const V3<T>& c, T tol
 //                                closest face) and what a group needs to evaluate supports (hull offsets, relative pose);
 //   loop -> records : the same block, its pose / vertex area overwritten with the loop's result (EpaLoopOut) and `state` set.
 // ---------------------------------------------------------------------------------------
-enum { EPA_READY_PENDING = 0u, EPA_READY_DONE = 1u, EPA_READY_HANDED_OVER = 2u };
+enum { EPA_READY_PENDING = 0u, EPA_READY_DONE = 1u, EPA_READY_HANDED_OVER = 2u, EPA_READY_NONE = 3u };
 template <typename T>
 struct alignas(16) EpaReady {
   uint32_t seed;            // slot of the polytope's seed in the convex x convex queue (item `seed` of that queue)

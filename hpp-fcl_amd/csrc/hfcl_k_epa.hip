@@ -344,13 +344,13 @@ __global__ void __launch_bounds__(256) k_epa_prepare(Work wk, LibView<T> lib, IO
   const uint32_t cnt = wk.counts[B_COUNT + 3];
   const EpaItem<T>* const queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
   EpaReady<T>* const ready = reinterpret_cast<EpaReady<T>*>(wk.epa_ready);
-  const int lane = threadIdx.x & 63;
-  // (whole waves walk the queue so that the slots of a wave's blocks are reserved with one atomic)
-  for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; base < cnt; base += gridDim.x * blockDim.x) {
-    const uint32_t i = base + uint32_t(lane);
+  // Block i belongs to item i of the queue: no compaction (reserving a wave's slots with an atomicAdd on one counter is ~20 ns per wave
+  // and trip, one after the other: 4 600 of them were 0.05 of this kernel's 0.07 ms, profiles/r05_b).  The few items without a loop --
+  // fall-backs, seeds of rank < 4: a few in 100 000 -- leave a block marked EPA_READY_NONE that k_epa_loop passes over.
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
     bool live = false;
     EpaReady<T> rb;
-    if (i < cnt) {
+    {
       const EpaItem<T>* ip = queue + (wk.n - 1u - i);
       const int rank = ip->rank;
       if (rank != 4) {
@@ -390,11 +390,12 @@ __global__ void __launch_bounds__(256) k_epa_prepare(Work wk, LibView<T> lib, IO
         }
       }
     }
-    const uint64_t m = __ballot(live);
-    uint32_t slot0 = 0;
-    if (lane == 0 && m) slot0 = atomicAdd(&wk.counts[CTR_EPA_READY], uint32_t(__popcll(m)));
-    slot0 = __shfl(slot0, 0, 64);
-    if (live) ready[slot0 + uint32_t(__popcll(m & ((uint64_t(1) << lane) - 1u)))] = rb;
+    if (live) {
+      ready[i] = rb;
+    } else {
+      ready[i].packed = 0u;  // (no vertices: never a live block)
+      ready[i].state = EPA_READY_NONE;
+    }
   }
 }
 
@@ -419,7 +420,7 @@ k_epa_loop(Work wk, LibView<T> lib, QParams<T> q) {
   static_assert(WE >= 8, "a group's lanes copy the eight records of a block");
   typedef LaneGroup<WE> Grp;
   __shared__ EpaScratch<T, CAP, V0_TAG> scratch[G];
-  const uint32_t cnt = wk.counts[CTR_EPA_READY];
+  const uint32_t cnt = wk.counts[B_COUNT + 3];  // one block per item of the convex x convex queue
   const int lane = threadIdx.x & 63, grp = lane / WE, lig = lane & (WE - 1);
   EpaReady<T>* const ready = reinterpret_cast<EpaReady<T>*>(wk.epa_ready);
   const EpaItem<T>* const queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
@@ -477,6 +478,7 @@ k_epa_loop(Work wk, LibView<T> lib, QParams<T> q) {
         if (it < cnt) {
           const EpaReady<T>* rb = ready + it;
           const uint32_t packed = rb->packed;
+          if ((packed & 63u) != 0u) {  // (0 vertices: EPA_READY_NONE, k_epa_prepare wrote the record or queued the seed elsewhere)
           sup.h0.load(lib.verts + 3 * size_t(rb->voff_a), packed & 63u, lig);
           sup.h1.load(lib.verts + 3 * size_t(rb->voff_b), (packed >> 6) & 63u, lig);
           sup.md.oR1.r0 = mk<T>(rb->md[0], rb->md[1], rb->md[2]);
@@ -487,6 +489,7 @@ k_epa_loop(Work wk, LibView<T> lib, QParams<T> q) {
           epa.reset(&scratch[grp], q.epa_max_iterations, q.epa_tolerance);
           epa.loop_enter(L, epa.install(rb, packed), 0, 0);
           state = LIVE;
+          }
         }
       }
       next += uint32_t(G - n_live) * gridDim.x;
@@ -550,7 +553,7 @@ __global__ void __launch_bounds__(64) k_epa_resume_cc(Work wk, LibView<T> lib, I
 
 template <typename T>
 __global__ void __launch_bounds__(256) k_epa_records(Work wk, LibView<T> lib, IO<T> io, QParams<T> q) {
-  const uint32_t cnt = wk.counts[CTR_EPA_READY];
+  const uint32_t cnt = wk.counts[B_COUNT + 3];
   const EpaReady<T>* const ready = reinterpret_cast<const EpaReady<T>*>(wk.epa_ready);
   const EpaItem<T>* const queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {

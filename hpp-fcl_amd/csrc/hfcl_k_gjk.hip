@@ -193,7 +193,11 @@ __device__ __forceinline__ void finish_gjk(const Gjk<T, P>& g, const Work& wk, c
     if (cc_queue) {
       // fp32 convex x convex pairs have a fast tier of their own (k_epa_stream<.., CC>): its queue is the top end of
       // epa_queue, filled downwards from slot n-1 (the two queues of a batch hold at most n items together)
+#ifdef HFCL_EXPERIMENT_NO_QUEUE_ATOMIC  // timing experiment only (the EPA kernels then see an empty queue): what does the counter cost?
+      const uint32_t slot = pair;
+#else
       const uint32_t slot = atomicAdd(&wk.counts[B_COUNT + 3], 1u);
+#endif
       reinterpret_cast<EpaSeed<T>*>(wk.epa_queue)[wk.n - 1u - slot] = seed;
     } else {
       // full_tier: straight to the full-capacity EPA queue (pairs with a large hull: only that tier
