@@ -1283,8 +1283,11 @@ __device__ __forceinline__ bool coop_cut(const BvhSplit& split, uint32_t my_slot
                       BVH_SUM_SUSPENDED | (overflow ? BVH_SUM_OVERFLOW : 0u), my_parent, my_order);
   return true;
 }
+#ifndef HFCL_WPE_SHAPE_COOP
+#define HFCL_WPE_SHAPE_COOP 2
+#endif
 template <typename T>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_SHAPE_COOP, 8)))
 k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhParams bp, T break_distance2, BvhSplit split) {
   constexpr int W = COOP_W, G = 64 / W;
   __shared__ uint32_t stacks[G][COOP_CAP + COOP_SLACK];
