@@ -1237,7 +1237,10 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       // one EPA item per unit at most (a contact ends the unit): a query, or -- when suspended walks are cut into task levels
       // instead of being continued by a wave (HFCL_SHAPE_COOP=0) -- every task of the split's table as well
       size_t need = lib->ws_capacity;
-      if (shape_fast && lib->shape_coop && lib->shape_cut_ticks) need = std::max(need, n + n / 2 + 4096);  // (the chunks of a cut walk are units too)
+      // (the chunks of a cut walk are units too, and every unit can queue one item: room for four chunks per query -- 336 B each --; a walk
+      // whose chunks would not fit is not cut, BvhSplit::cut_task_cap.  cfg4s makes ~0.6 chunks per query; n / 2 was too tight: cuts refused,
+      // 3.5 -> 4.4 ms)
+      if (shape_fast && lib->shape_coop && lib->shape_cut_ticks) need = std::max(need, n + 4 * n + 4096);
       if (shape_fast && !lib->shape_coop && n >= 256) {
         rc = ensure_bvh_split(lib, n);
         if (rc) return rc;
