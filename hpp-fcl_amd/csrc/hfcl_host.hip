@@ -101,6 +101,7 @@ struct hfcl_lib {
   void* d_epa_ready = nullptr;   // EpaReady<float>[epa_ready_capacity]: the staged convex x convex fast tier (k_epa_prepare / k_epa_loop / k_epa_records)
   size_t epa_ready_capacity = 0;
   bool records_aside = true;     // HFCL_EPA_RECORDS_ASIDE=0: k_epa_records on the batch's stream
+  bool epa64_two_streams = true; // HFCL_EPA64_TWO_STREAMS=0: the two fp64 fast-tier kernels one after the other
   bool epa_cc_staged = true;     // HFCL_EPA_CC_STAGED=0: the one-kernel form (k_epa_stream<.., CC>)
   size_t epa_cc_staged_min = 32768;  // ... which batches below this many pairs keep (two launches less); HFCL_EPA_CC_STAGED_MIN
   void* d_epa_resume = nullptr;
@@ -465,6 +466,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_SPLIT")) lib->split = atoi(v) >= 2 ? 2 : (atoi(v) == 1 ? 1 : 0);
   if (const char* v = getenv("HFCL_EPA_CC_STAGED")) lib->epa_cc_staged = atoi(v) != 0;
   if (const char* v = getenv("HFCL_EPA_RECORDS_ASIDE")) lib->records_aside = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_EPA64_TWO_STREAMS")) lib->epa64_two_streams = atoi(v) != 0;
   if (const char* v = getenv("HFCL_EPA_CC_STAGED_MIN")) lib->epa_cc_staged_min = size_t(std::max(0ll, atoll(v)));
   if (const char* v = getenv("HFCL_PIPE_CHUNK")) lib->pipe_chunk = strtoull(v, nullptr, 10);
   if (const char* v = getenv("HFCL_BVH_FILTER")) lib->bvh_filter = atoi(v) != 0;
@@ -1357,7 +1359,25 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     if constexpr (std::is_same<T, float>::value) {
       if (cc_staged) launch_epa_loop(epa_batches, st, wk, lv, q, lib->n_cus);
     }
-    launch_epa_fast<T>(epa_batches, st, wk, lv, io, q, may(B_CC) && !cc_staged, may(B_PRIM) || may(B_PC) || may(B_CP), lib->n_cus, lib->has_curved);
+    // fp64 with both classes of pairs: their fast-tier kernels on two streams (each one's tail under the other's body)
+    hipStream_t st2 = nullptr;
+    if constexpr (std::is_same<T, double>::value) {
+      if (lib->epa64_two_streams && lib->has_curved && (may(B_PRIM) || may(B_PC) || may(B_CP) || may(B_CC))) {
+        if (!lib->aux) {
+          HIP_TRY(hipStreamCreateWithFlags(&lib->aux, hipStreamNonBlocking));
+          HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux0, hipEventDisableTiming));
+          HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux1, hipEventDisableTiming));
+        }
+        st2 = lib->aux;
+        HIP_TRY(hipEventRecord(lib->ev_aux0, st));
+        HIP_TRY(hipStreamWaitEvent(st2, lib->ev_aux0, 0));
+      }
+    }
+    launch_epa_fast<T>(epa_batches, st, wk, lv, io, q, may(B_CC) && !cc_staged, may(B_PRIM) || may(B_PC) || may(B_CP), lib->n_cus, lib->has_curved, st2);
+    if (st2) {
+      HIP_TRY(hipEventRecord(lib->ev_aux1, st2));
+      HIP_TRY(hipStreamWaitEvent(st, lib->ev_aux1, 0));
+    }
     tend();
     bool tail_done = false;
     if constexpr (std::is_same<T, float>::value) {
@@ -1444,6 +1464,7 @@ static hfcl_lib* make_helper(hfcl_lib* lib) {
   h->closed_staged = lib->closed_staged;
   h->epa_cc_staged = lib->epa_cc_staged;
   h->records_aside = lib->records_aside;
+  h->epa64_two_streams = lib->epa64_two_streams;
   h->epa_cc_staged_min = lib->epa_cc_staged_min;
   h->n_cus = lib->n_cus;
   bool ok = hipMalloc(&h->d_counts, N_COUNTERS * sizeof(uint32_t)) == hipSuccess;

@@ -612,7 +612,7 @@ static int resident_blocks_per_cu(K kernel) {
   return std::max(nb, 1);
 }
 template <typename T>
-void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool cc_queue, bool general_queue, int n_cus, bool curved_class) {
+void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool cc_queue, bool general_queue, int n_cus, bool curved_class, hipStream_t st2) {
   if constexpr (sizeof(T) == 4) {
     static const int per_cu_cc = resident_blocks_per_cu(k_epa_stream<T, EPA_WE, EPA_FAST_CAP, true>);
     static const int per_cu_gen = resident_blocks_per_cu(k_epa_stream<T, EPA_WE, EPA_FAST_CAP, false>);
@@ -631,15 +631,16 @@ void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>&
     // iterations (8 per wave) -- profiles/r02_u
     if (curved_class)
       hipLaunchKernelGGL((k_epa<T, HFCL_EPA64_CURVED_WE, epa_fast_cap<T>, 1, 2>), dim3(std::min(grid * (HFCL_EPA64_CURVED_WE / EPA_WE), n_cus * 16)), dim3(64), 0, st, wk, lv, io, q);
-    hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_small_cap<T>, 1, 1>), dim3(std::min(grid, n_cus * 32)), dim3(64), 0, st, wk, lv, io, q);
+    // (st2: the two classes side by side on two streams -- each kernel's tail is the other's body; the caller forks and joins)
+    hipLaunchKernelGGL((k_epa<T, EPA_WE, epa_small_cap<T>, 1, 1>), dim3(std::min(grid, n_cus * 32)), dim3(64), 0, (curved_class && st2) ? st2 : st, wk, lv, io, q);
 #endif
   }
 }
 #if HFCL_UNIT_F32
-template void launch_epa_fast<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&, bool, bool, int, bool);
+template void launch_epa_fast<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&, bool, bool, int, bool, hipStream_t);
 #endif
 #if HFCL_UNIT_F64
-template void launch_epa_fast<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&, bool, bool, int, bool);
+template void launch_epa_fast<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&, bool, bool, int, bool, hipStream_t);
 #endif
 
 #if HFCL_UNIT_F32

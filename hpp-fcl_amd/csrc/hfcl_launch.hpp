@@ -52,7 +52,8 @@ void launch_compact_records(hipStream_t st, const hfcl_result_f32* in, hfcl_resu
 // cc_queue / general_queue (fp32): which of the two streaming forms have anything to do (convex x convex pairs have a
 // queue and a kernel of their own); curved_class (fp64): the library has a shape whose support is not a vertex, i.e. the
 // curved class of pairs -- a queue and a fast-tier kernel of its own -- can occur
-template <typename T> void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool cc_queue, bool general_queue, int n_cus, bool curved_class = true);
+// st2 (fp64, both classes present): the polytope-class kernel goes there, beside the curved-class kernel on st (the caller forks and joins)
+template <typename T> void launch_epa_fast(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool cc_queue, bool general_queue, int n_cus, bool curved_class = true, hipStream_t st2 = nullptr);
 // the fp32 convex x convex fast tier in three stages (Work::epa_ready set): one lane per polytope before and after the loop kernel
 void launch_epa_prepare(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q);
 void launch_epa_loop(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const QParams<float>& q, int n_cus);
