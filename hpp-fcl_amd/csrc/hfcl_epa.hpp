@@ -323,13 +323,18 @@ HFCL_HD bool epa_prepare_tetrahedron(const V3<T>* w, T tolerance, Quad<T>* vw, Q
 #ifndef HFCL_EPA_PAR_HZ
 #define HFCL_EPA_PAR_HZ 1
 #endif
+#ifndef HFCL_EPA_RESUME_PAR_HZ
+#define HFCL_EPA_RESUME_PAR_HZ 0  // 1: k_epa_resume_cc finds horizons with all lanes as well (A/B)
+#endif
 #ifndef HFCL_EPA_FLAT
 #define HFCL_EPA_FLAT 1  // find_closest_face_flat in the fp32 convex x convex fast tier (k_epa_loop 0.975 -> 0.961 ms; the horizon search built the same way -- ballots instead of pass marks and LDS atomics -- is 3 % slower: profiles/r05_b)
 #endif
 template <typename T, class Grp, int CAP = EPA_MAX_ITER, int V0M = V0_BLOCK>
 struct Epa {
   static constexpr bool TAGGED = V0M == V0_TAG;
-  static constexpr bool PARALLEL_HORIZON = sizeof(T) == 4 && (HFCL_EPA_PAR_HZ >= 2 || (HFCL_EPA_PAR_HZ == 1 && V0M == V0_TAG));
+  // (blocks of the reference's capacity walk: the tier that continues a handed-over convex x convex polytope does what the general
+  // full-capacity tier does, so that a record does not depend on which of the two continued it -- i.e. on the size of its batch)
+  static constexpr bool PARALLEL_HORIZON = sizeof(T) == 4 && (HFCL_EPA_PAR_HZ >= 2 || (HFCL_EPA_PAR_HZ == 1 && V0M == V0_TAG && (CAP < EPA_MAX_ITER || HFCL_EPA_RESUME_PAR_HZ)));
   typedef EpaScratch<T, CAP, V0M> Block;
   // The branch-free form of the closest-face scan (find_closest_face_flat): the small blocks of the fp32 convex x convex fast tier.
   static constexpr bool FLAT_CF = PARALLEL_HORIZON && HFCL_EPA_FLAT && EpaScratch<T, CAP, V0M>::NF <= 64;
