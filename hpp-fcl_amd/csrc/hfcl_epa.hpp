@@ -818,6 +818,14 @@ struct Epa {
     int hz_count = 0, stop_kind = 0, stop_at = 0;
     bool by_tables = false;  // the new faces find their neighbours through the vertex tables (no order on the horizon)
     if constexpr (PARALLEL_HORIZON) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(HFCL_EPA_PHASE_TWICE) && HFCL_EPA_PHASE_TWICE == 2  // ... the horizon search once more (idempotent)
+      {
+        int hz2 = 0;
+        const bool bt2 = silhouette_parallel(pass, closest, dummy_precision, ww, hz2);
+        asm volatile("" ::"v"(hz2), "v"(int(bt2)));
+        Grp::sync();
+      }
+#endif
       by_tables = silhouette_parallel(pass, closest, dummy_precision, ww, hz_count);
       if (!by_tables) {  // not a horizon of simple loops: marks undone, the walk decides
         const int nfu = hw;
@@ -1132,6 +1140,15 @@ struct Epa {
     V3<T> w, w0;
     int tag;
     epa_support<TAGGED>(sup, cn, w, w0, tag);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(HFCL_EPA_PHASE_TWICE) && HFCL_EPA_PHASE_TWICE == 1  // phase-cost experiment (tools/epa_phase_costs.sh): the support once more
+    {
+      V3<T> cn2 = cn, w2, w02;
+      int tag2;
+      asm volatile("" : "+v"(cn2.x));
+      epa_support<TAGGED>(sup, cn2, w2, w02, tag2);
+      asm volatile("" ::"v"(w2.x), "v"(w2.y), "v"(w2.z), "v"(tag2));
+    }
+#endif
     Grp::sync();
     set_vert(iw, w, w0, tag);
     Grp::sync();
@@ -1158,6 +1175,16 @@ struct Epa {
       }
       return 1;
     }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(HFCL_EPA_PHASE_TWICE) && HFCL_EPA_PHASE_TWICE == 4  // ... the closest-face scan once more (the second without releases)
+    {
+      const int c2 = find_closest_face();
+      asm volatile("" ::"v"(c2));
+      pending_release = -1;
+      const int c3 = find_closest_face();
+      loop_enter(L, c2 == c3 ? c2 : c3, L.iterations + 1, L.pass);
+      return 0;
+    }
+#endif
     loop_enter(L, find_closest_face(), L.iterations + 1, L.pass);
     return 0;
   }
