@@ -58,9 +58,8 @@ constexpr int CTR_DIST_SUSP = 2 * B_COUNT + 6;  // suspended mesh x mesh distanc
 constexpr int CTR_SHAPE_DIST_SUSP = 2 * B_COUNT + 7;  // ... mesh x solid (ShapeDistSusp records)
 constexpr int CTR_DIST_TICKET = 2 * B_COUNT + 8;  // ticket of k_bvh_distance_pool: next DistSusp record to take
 constexpr int CTR_SHAPE_DIST_TICKET = 2 * B_COUNT + 9;  // ticket of k_bvh_shape_distance_pool
-constexpr int CTR_EPA_READY = 2 * B_COUNT + 10;  // (unused: k_epa_prepare no longer compacts its blocks)
-constexpr int CTR_EPA_CC_OVER = 2 * B_COUNT + 11;  // ... and those of them k_epa_loop saved for k_epa_resume_cc
-constexpr int N_COUNTERS = 2 * B_COUNT + 12;  // bucket populations + the four counters of Work::counts + curved populations + those
+constexpr int CTR_EPA_CC_OVER = 2 * B_COUNT + 10;  // convex x convex polytopes k_epa_loop saved for k_epa_resume_cc
+constexpr int N_COUNTERS = 2 * B_COUNT + 11;  // bucket populations + the four counters of Work::counts + curved populations + those
 
 // Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
 // support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
