@@ -175,6 +175,7 @@ struct Work {
   uint32_t shape_defer_cap;  // a unit (query, or task of a split walk) queues at most one item: sized by the host for every unit a batch can make
   void* shape_oq;     // ObbQuery<T>[n], by pair: the solid's fitted OBB against the mesh pose (k_shape_obb)
   void* epa_ready;    // EpaReady<T>[n]: convex x convex polytopes between k_epa_prepare, k_epa_loop and k_epa_records (nullptr: the one-kernel form)
+  void* epa_ready_g;  // EpaReadyG<T>[n]: polytopes of any pair kinds between k_epa_prepare_general / k_epa_loop_general / k_epa_records_general (nullptr: the lockstep tiers)
   uint32_t* epa_cc_over;  // blocks of epa_ready whose polytope k_epa_loop saved for k_epa_resume_cc, slot i <-> slot cc_resume_base + i of epa_resume
   uint32_t cc_resume_base, cc_resume_cap;
 };

@@ -329,6 +329,168 @@ HFCL_HD bool epa_prepare_tetrahedron(const V3<T>* w, T tolerance, Quad<T>* vw, Q
 #ifndef HFCL_EPA_FLAT
 #define HFCL_EPA_FLAT 1  // find_closest_face_flat in the fp32 convex x convex fast tier (k_epa_loop 0.975 -> 0.961 ms; the horizon search built the same way -- ballots instead of pass marks and LDS atomics -- is 3 % slower: profiles/r05_b)
 #endif
+// GJK::encloseOrigin :437-492 on the vertices 0..rank-1 of a store (reference order): st.vw(i) reads vertex i, st.eo_support(sup, dir, ...)
+// evaluates a support point, st.eo_put(i, w, w0, tag) stores vertex i.  One function for the polytope block in LDS (Epa) and for the
+// registers of a lane that prepares a polytope on its own (EpaRegStore): the same operations in the same order.
+template <typename T, class Store, class Sup>
+HFCL_HD bool epa_enclose_origin(Store& st, int& rank, Sup& sup) {
+  const int base = rank;
+  int c1 = 0, c2 = 0, c3 = 0;  // candidate counters of the rank-1/2/3 levels (no arrays: registers)
+  bool entering = true;
+  for (;;) {
+    if (entering) {
+      if (rank == 4) {
+        if (habs(triple(st.vw(0) - st.vw(3), st.vw(1) - st.vw(3), st.vw(2) - st.vw(3))) > T(0)) return true;
+        if (base == 4) return false;
+        --rank;  // parent removes the vertex
+        entering = false;
+        continue;
+      }
+      if (rank == 1) c1 = 0;
+      if (rank == 2) c2 = 0;
+      if (rank == 3) c3 = 0;
+    }
+    // try the next candidate direction at this level
+    V3<T> dir = mk<T>(T(0), T(0), T(0));
+    bool have = false;
+    while (!have) {
+      const int c = (rank == 1) ? c1 : ((rank == 2) ? c2 : c3);
+      if (rank == 1) {
+        if (c >= 6) break;
+        const int i = c >> 1;  // both the "+" and the "-" attempt use +e_i (reference quirk :443-448)
+        dir = mk<T>(i == 0 ? T(1) : T(0), i == 1 ? T(1) : T(0), i == 2 ? T(1) : T(0));
+        have = true;
+      } else if (rank == 2) {
+        if (c >= 6) break;
+        const int i = c >> 1;
+        const V3<T> d = st.vw(1) - st.vw(0);
+        const V3<T> axis = mk<T>(i == 0 ? T(1) : T(0), i == 1 ? T(1) : T(0), i == 2 ? T(1) : T(0));
+        const V3<T> p = cross(d, axis);
+        if (is_zero(p)) {
+          c2 = (i + 1) * 2;
+          continue;
+        }
+        dir = (c & 1) ? -p : p;
+        have = true;
+      } else {  // rank 3
+        if (c >= 2) break;
+        const V3<T> axis = cross(st.vw(1) - st.vw(0), st.vw(2) - st.vw(0));
+        if (is_zero(axis)) {
+          c3 = 2;
+          continue;
+        }
+        dir = (c & 1) ? -axis : axis;
+        have = true;
+      }
+    }
+    if (!have) {
+      if (rank == base) return false;
+      --rank;
+      entering = false;
+      continue;
+    }
+    if (rank == 1) ++c1;
+    if (rank == 2) ++c2;
+    if (rank == 3) ++c3;
+    V3<T> w, w0;
+    int tag;
+    st.eo_support(sup, dir, w, w0, tag);
+    st.eo_put(rank, w, w0, tag);
+    ++rank;
+    entering = true;
+  }
+}
+// the four vertices of a polytope-to-be in the registers of one lane (k_epa_prepare_general)
+template <typename T>
+struct EpaRegStore {
+  V3<T> w[4], w0[4];
+  HFCL_HD const V3<T>& vw(int i) const { return w[i]; }
+  template <class Sup>
+  HFCL_HD void eo_support(Sup& sup, const V3<T>& dir, V3<T>& ws, V3<T>& w0s, int& tag) const {
+    sup(dir, ws, w0s);
+    tag = 0;
+  }
+  HFCL_HD void eo_put(int i, const V3<T>& ws, const V3<T>& w0s, int) {  // (i = 1, 2 or 3; constant indices keep the arrays in registers)
+    if (i == 1) { w[1] = ws; w0[1] = w0s; }
+    if (i == 2) { w[2] = ws; w0[2] = w0s; }
+    if (i == 3) { w[3] = ws; w0[3] = w0s; }
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// The same three stages for pairs of any convex kinds (V0_BLOCK blocks: supports are coordinates, not vertex tags; seeds of any rank:
+// encloseOrigin runs in the preparing lane with the pair's support functions; fp64 as well: k_epa_prepare_general / k_epa_loop_general /
+// k_epa_records_general in hfcl_k_epa.hip).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct alignas(16) EpaReadyG {
+  uint32_t seed;            // slot of the seed in its queue (bit 31: the queue at the top end of epa_queue)
+  uint32_t pair;
+  uint32_t sid1, sid2;      // the two shapes
+  uint32_t packed;          // bits 0-1: first closest face; 2-5: ignore flag of face 0..3; 6: relative pose is the identity
+  uint32_t gjk_iters;
+  uint32_t state;           // EPA_READY_*
+  uint32_t pad_;
+  T md[12];                 // MDiff: oR1 rows, ot1
+  Quad<T> vw[4];            // vertex records of the oriented tetrahedron
+  Quad<T> v0[4];            // ... their support points on shape 0
+  Quad<T> fn[4];            // face planes
+};
+template <typename T>
+struct __attribute__((may_alias)) EpaLoopOutG {  // overlays EpaReadyG::md .. once the loop is over
+  int32_t status, iterations;
+  T nx, ny, nz, depth;       // the last valid `outer` face: normal and distance
+  T rw[9];                   // w of its three vertices
+  T r0[9];                   // ... and their support points on shape 0
+};
+static_assert(sizeof(EpaLoopOutG<float>) <= sizeof(float) * 12 + 2 * sizeof(Quad<float>) * 4 && sizeof(EpaLoopOutG<double>) <= sizeof(double) * 12 + 2 * sizeof(Quad<double>) * 4,
+              "the result overlays the pose and vertex area");
+// Epa::begin for a seed of any rank, by one lane: st holds the seed's vertices (reference order), `sup` evaluates the pair's supports.
+// Returns false when the reference falls back (:1299-1315); otherwise vw / v0 / fn / flags / closest describe the block begin() leaves.
+template <typename T, class Sup>
+HFCL_HD bool epa_prepare_general(EpaRegStore<T>& st, int rank, T tolerance, Sup& sup, Quad<T>* vw, Quad<T>* v0, Quad<T>* fn, int* flags, int& closest) {
+  const bool enclosed = epa_enclose_origin<T>(st, rank, sup);
+  if (!(rank > 1 && enclosed)) return false;
+  const bool swap01 = dot(st.w[0] - st.w[3], cross(st.w[1] - st.w[3], st.w[2] - st.w[3])) < T(0);  // :1196-1201
+  const V3<T> p[4] = {swap01 ? st.w[1] : st.w[0], swap01 ? st.w[0] : st.w[1], st.w[2], st.w[3]};
+  const V3<T> p0[4] = {swap01 ? st.w0[1] : st.w0[0], swap01 ? st.w0[0] : st.w0[1], st.w0[2], st.w0[3]};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int i = 0; i < 4; ++i) {
+    vw[i] = Quad<T>{p[i].x, p[i].y, p[i].z, T(0)};
+    v0[i] = Quad<T>{p0[i].x, p0[i].y, p0[i].z, T(0)};
+  }
+  const int corner[4][3] = {{0, 1, 2}, {1, 0, 3}, {2, 1, 3}, {0, 2, 3}};
+  bool ok = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int f = 0; f < 4; ++f) {
+    V3<T> n;
+    T d;
+    const int fail = epa_face_plane(p[corner[f][0]], p[corner[f][1]], p[corner[f][2]], tolerance, true, n, d, flags[f]);
+    fn[f] = Quad<T>{n.x, n.y, n.z, d};
+    ok = ok && fail == 0;
+  }
+  if (!ok) return false;  // hull_count != 4
+  T best = Lim<T>::max();
+  int best_f = EPA_NULL;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int f = 0; f < 4; ++f) {
+    if (flags[f] & 2) continue;
+    const T sq = fn[f].w * fn[f].w;
+    if (sq < best || (sq == best && best_f != EPA_NULL)) {
+      best = sq;
+      best_f = f;
+    }
+  }
+  closest = best_f != EPA_NULL ? best_f : 3;
+  return true;
+}
+
 template <typename T, class Grp, int CAP = EPA_MAX_ITER, int V0M = V0_BLOCK>
 struct Epa {
   static constexpr bool TAGGED = V0M == V0_TAG;
@@ -955,6 +1117,42 @@ struct Epa {
     Grp::sync();
     return int((packed >> 12) & 3u);
   }
+  // ... of a general pair (V0_BLOCK): twelve records -- vertices, their shape-0 support points, face planes
+  HFCL_HD int install(const EpaReadyG<T>* rb, uint32_t packed) {
+    static_assert(V0M == V0_BLOCK, "general pairs keep their support points in the block");
+    constexpr EpaTetraTopo topo = epa_tetra_topo();
+    for (int i = Grp::lane(); i < 12; i += Grp::W) {
+      if (i < 4) {
+        m->vw[i] = rb->vw[i];
+      } else if (i < 8) {
+        v0p[i - 4] = rb->v0[i - 4];
+      } else {
+        const int f = i - 8;
+        m->fn[f] = rb->fn[f];
+        const uint32_t flag = 1u | (((packed >> (2 + f)) & 1u) << 1);
+        m->ft[f].vf = (f == 0 ? topo.vf[0] : (f == 1 ? topo.vf[1] : (f == 2 ? topo.vf[2] : topo.vf[3]))) | (flag << 24);
+        m->ft[f].ap = f == 0 ? topo.ap[0] : (f == 1 ? topo.ap[1] : (f == 2 ? topo.ap[2] : topo.ap[3]));
+        m->ft[f].ae = f == 0 ? topo.ae[0] : (f == 1 ? topo.ae[1] : (f == 2 ? topo.ae[2] : topo.ae[3]));
+      }
+    }
+    status = EPA_VALID;
+    num_vertices = 4;
+    hull_count = 4;
+    stock_top -= 4;
+    stamp = 4;
+    hw = 4;
+    Grp::sync();
+    return int(packed & 3u);
+  }
+  HFCL_HD void loop_out(const EpaLoop<T>& L, EpaLoopOutG<T>& o) const {
+    o.status = status;
+    o.iterations = L.iterations;
+    o.nx = L.outer_n.x; o.ny = L.outer_n.y; o.nz = L.outer_n.z;
+    o.depth = L.outer_d;
+    const V3<T> a = vw(L.o0), b = vw(L.o1), c = vw(L.o2), a0 = v0(L.o0), b0 = v0(L.o1), c0 = v0(L.o2);
+    o.rw[0] = a.x; o.rw[1] = a.y; o.rw[2] = a.z; o.rw[3] = b.x; o.rw[4] = b.y; o.rw[5] = b.z; o.rw[6] = c.x; o.rw[7] = c.y; o.rw[8] = c.z;
+    o.r0[0] = a0.x; o.r0[1] = a0.y; o.r0[2] = a0.z; o.r0[3] = b0.x; o.r0[4] = b0.y; o.r0[5] = b0.z; o.r0[6] = c0.x; o.r0[7] = c0.y; o.r0[8] = c0.z;
+  }
   // The loop's result with tags instead of shape-0 support points (V0_TAG blocks; resolved by whoever writes the record).
   HFCL_HD void loop_out(const EpaLoop<T>& L, EpaLoopOut<T>& o) const {
     o.status = status;
@@ -968,76 +1166,19 @@ struct Epa {
     o.tag[0] = int(a.w); o.tag[1] = int(b.w); o.tag[2] = int(c.w);
   }
 
-  // GJK::encloseOrigin :437-492 on verts[0..rank) (reference order).  sup(dir) -> (w, w0).
+  // GJK::encloseOrigin :437-492 on verts[0..rank) (reference order).  sup(dir) -> (w, w0).  (epa_enclose_origin, below the class, over
+  // this block's vertex records.)
   template <class Sup>
   HFCL_HD bool enclose_origin(int& rank, Sup& sup) {
-    const int base = rank;
-    int c1 = 0, c2 = 0, c3 = 0;  // candidate counters of the rank-1/2/3 levels (no arrays: registers)
-    bool entering = true;
-    for (;;) {
-      if (entering) {
-        if (rank == 4) {
-          if (habs(triple(vw(0) - vw(3), vw(1) - vw(3), vw(2) - vw(3))) > T(0)) return true;
-          if (base == 4) return false;
-          --rank;  // parent removes the vertex
-          entering = false;
-          continue;
-        }
-        if (rank == 1) c1 = 0;
-        if (rank == 2) c2 = 0;
-        if (rank == 3) c3 = 0;
-      }
-      // try the next candidate direction at this level
-      V3<T> dir = mk<T>(T(0), T(0), T(0));
-      bool have = false;
-      while (!have) {
-        const int c = (rank == 1) ? c1 : ((rank == 2) ? c2 : c3);
-        if (rank == 1) {
-          if (c >= 6) break;
-          const int i = c >> 1;  // both the "+" and the "-" attempt use +e_i (reference quirk :443-448)
-          dir = mk<T>(i == 0 ? T(1) : T(0), i == 1 ? T(1) : T(0), i == 2 ? T(1) : T(0));
-          have = true;
-        } else if (rank == 2) {
-          if (c >= 6) break;
-          const int i = c >> 1;
-          const V3<T> d = vw(1) - vw(0);
-          const V3<T> axis = mk<T>(i == 0 ? T(1) : T(0), i == 1 ? T(1) : T(0), i == 2 ? T(1) : T(0));
-          const V3<T> p = cross(d, axis);
-          if (is_zero(p)) {
-            c2 = (i + 1) * 2;
-            continue;
-          }
-          dir = (c & 1) ? -p : p;
-          have = true;
-        } else {  // rank 3
-          if (c >= 2) break;
-          const V3<T> axis = cross(vw(1) - vw(0), vw(2) - vw(0));
-          if (is_zero(axis)) {
-            c3 = 2;
-            continue;
-          }
-          dir = (c & 1) ? -axis : axis;
-          have = true;
-        }
-      }
-      if (!have) {
-        if (rank == base) return false;
-        --rank;
-        entering = false;
-        continue;
-      }
-      if (rank == 1) ++c1;
-      if (rank == 2) ++c2;
-      if (rank == 3) ++c3;
-      V3<T> w, w0;
-      int tag;
-      epa_support<TAGGED>(sup, dir, w, w0, tag);
-      Grp::sync();
-      set_vert(rank, w, w0, tag);
-      Grp::sync();
-      ++rank;
-      entering = true;
-    }
+    return epa_enclose_origin<T>(*this, rank, sup);
+  }
+  // the vertex store epa_enclose_origin works on
+  template <class Sup>
+  HFCL_HD void eo_support(Sup& sup, const V3<T>& dir, V3<T>& w, V3<T>& w0, int& tag) const { epa_support<TAGGED>(sup, dir, w, w0, tag); }
+  HFCL_HD void eo_put(int i, const V3<T>& w, const V3<T>& w0, int tag) {
+    Grp::sync();
+    set_vert(i, w, w0, tag);
+    Grp::sync();
   }
 
   // EPA::evaluate :1156-1316.  verts[0..rank) must already hold GJK's final simplex in the

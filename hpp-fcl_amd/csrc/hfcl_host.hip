@@ -100,6 +100,12 @@ struct hfcl_lib {
   hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr;
   void* d_epa_ready = nullptr;   // EpaReady<float>[epa_ready_capacity]: the staged convex x convex fast tier (k_epa_prepare / k_epa_loop / k_epa_records)
   size_t epa_ready_capacity = 0;
+  void* d_epa_ready_g = nullptr; // EpaReadyG<T>[ws_capacity]: the staged fast tier of the general queues (both precisions)
+  size_t epa_ready_g_bytes = 0;
+  bool epa_general_staged = false;       // HFCL_EPA_GENERAL_STAGED=1: prepare / loop / records for the general queues too.  Byte-identical
+                                         // records; measured slower in wall-clock on cfg2 (0.416 -> 0.479 ms) and cfg5 unsplit (4.77 -> 5.30 ms
+                                         // per 1M mixed pairs), faster only on cfg5 split (5.34 -> 5.13): profiles/r05_e_general_staged.md
+  size_t epa_general_staged_min = 32768; // HFCL_EPA_GENERAL_STAGED_MIN
   bool records_aside = true;     // HFCL_EPA_RECORDS_ASIDE=0: k_epa_records on the batch's stream
   bool epa64_two_streams = true; // HFCL_EPA64_TWO_STREAMS=0: the two fp64 fast-tier kernels one after the other
   bool epa_cc_staged = true;     // HFCL_EPA_CC_STAGED=0: the one-kernel form (k_epa_stream<.., CC>)
@@ -466,6 +472,8 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_SPLIT")) lib->split = atoi(v) >= 2 ? 2 : (atoi(v) == 1 ? 1 : 0);
   if (const char* v = getenv("HFCL_EPA_CC_STAGED")) lib->epa_cc_staged = atoi(v) != 0;
   if (const char* v = getenv("HFCL_EPA_RECORDS_ASIDE")) lib->records_aside = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_EPA_GENERAL_STAGED")) lib->epa_general_staged = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_EPA_GENERAL_STAGED_MIN")) lib->epa_general_staged_min = size_t(std::max(0ll, atoll(v)));
   if (const char* v = getenv("HFCL_EPA64_TWO_STREAMS")) lib->epa64_two_streams = atoi(v) != 0;
   if (const char* v = getenv("HFCL_EPA_CC_STAGED_MIN")) lib->epa_cc_staged_min = size_t(std::max(0ll, atoll(v)));
   if (const char* v = getenv("HFCL_PIPE_CHUNK")) lib->pipe_chunk = strtoull(v, nullptr, 10);
@@ -528,6 +536,7 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_epa_queue);
   hipFree(lib->d_epa_queue2);
   hipFree(lib->d_epa_ready);
+  hipFree(lib->d_epa_ready_g);
   hipFree(lib->d_epa_cc_over);
   if (lib->aux) hipStreamDestroy(lib->aux);
   if (lib->ev_aux0) hipEventDestroy(lib->ev_aux0);
@@ -1094,6 +1103,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
   wk.shape_defer_cap = 0;
   wk.shape_oq = nullptr;
   wk.epa_ready = nullptr;
+  wk.epa_ready_g = nullptr;
   wk.epa_cc_over = lib->d_epa_cc_over;
   // fp32 slots are shorter than the area's stride (the fp64 slot): the slots past resume_cap are the convex x convex tier's own
   wk.cc_resume_base = wk.resume_cap;
@@ -1335,89 +1345,119 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
   }
 
   if (q.compute_penetration && any_gjk) {
-    // fp32 convex x convex pairs: the fast tier in three stages (hfcl_k_epa.hip) for batches large enough to pay for two more launches
+    // ---- EPA.  Fast tiers in three stages (hfcl_k_epa.hip) for batches large enough to pay for the extra launches: one lane per polytope
+    // prepares it (encloseOrigin, first tetrahedron) and writes its record; the loop kernels between them do nothing but expand.
+    //   fp32 convex x convex (the top queue): k_epa_prepare / k_epa_loop / k_epa_records, k_epa_resume_cc for the polytopes that outgrow the block
+    //   every other queue, both precisions:    k_epa_prepare_general / k_epa_loop_general / k_epa_records_general, the full-capacity tier behind them
+    // Otherwise the one-kernel forms (launch_epa_fast: fp32 streams, fp64 lockstep kernels).
+    constexpr bool F32 = std::is_same<T, float>::value;
+    const bool general_q = may(B_PRIM) || may(B_PC) || may(B_CP) || (!F32 && may(B_CC));
     bool cc_staged = false;
-    if constexpr (std::is_same<T, float>::value) {
-      cc_staged = may(B_CC) && lib->epa_cc_staged && n >= lib->epa_cc_staged_min;
+    if constexpr (F32) cc_staged = may(B_CC) && lib->epa_cc_staged && n >= lib->epa_cc_staged_min;
+    const bool gen_staged = general_q && lib->epa_general_staged && n >= lib->epa_general_staged_min;
+    auto need_aux = [&]() -> int {
+      if (lib->aux) return HFCL_OK;
+      HIP_TRY(hipStreamCreateWithFlags(&lib->aux, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux0, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux1, hipEventDisableTiming));
+      return HFCL_OK;
+    };
+    auto tbeg_on = [&](const char* name, hipStream_t s) {
+      if (!lib->kernel_timing) return;
+      t = timer_slot(lib, ti++, name);
+      hipEventRecord(t->e0, s);
+    };
+    auto tend_on = [&](hipStream_t s) {
+      if (lib->kernel_timing) hipEventRecord(t->e1, s);
+    };
+    if (cc_staged) {
+      if (lib->ws_capacity > lib->epa_ready_capacity) {
+        hipFree(lib->d_epa_ready);
+        lib->d_epa_ready = nullptr;
+        lib->epa_ready_capacity = 0;
+        HIP_TRY(hipMalloc(&lib->d_epa_ready, lib->ws_capacity * sizeof(EpaReady<float>)));
+        lib->epa_ready_capacity = lib->ws_capacity;
+      }
+      wk.epa_ready = lib->d_epa_ready;
+    }
+    if (gen_staged) {
+      if (lib->ws_capacity * sizeof(EpaReadyG<T>) > lib->epa_ready_g_bytes) {
+        hipFree(lib->d_epa_ready_g);
+        lib->d_epa_ready_g = nullptr;
+        lib->epa_ready_g_bytes = 0;
+        HIP_TRY(hipMalloc(&lib->d_epa_ready_g, lib->ws_capacity * sizeof(EpaReadyG<T>)));
+        lib->epa_ready_g_bytes = lib->ws_capacity * sizeof(EpaReadyG<T>);
+      }
+      wk.epa_ready_g = lib->d_epa_ready_g;
+    }
+    if constexpr (F32) {
       if (cc_staged) {
-        if (lib->ws_capacity > lib->epa_ready_capacity) {
-          hipFree(lib->d_epa_ready);
-          lib->d_epa_ready = nullptr;
-          lib->epa_ready_capacity = 0;
-          HIP_TRY(hipMalloc(&lib->d_epa_ready, lib->ws_capacity * sizeof(EpaReady<float>)));
-          lib->epa_ready_capacity = lib->ws_capacity;
-        }
-        wk.epa_ready = lib->d_epa_ready;
         tbeg("k_epa_prepare");
         launch_epa_prepare(blocks_for(n / 4 + 1, 256), st, wk, lv, io, q);
         tend();
       }
     }
+    if (gen_staged) {
+      tbeg("k_epa_prepare_general");
+      launch_epa_prepare_general<T>(blocks_for(n / 4 + 1, 256), st, wk, lv, io, q, F32);
+      tend();
+    }
     const int epa_batches = int(std::min<size_t>((n + 64 / EPA_WE - 1) / (64 / EPA_WE), size_t(1) << 22));
     tbeg("k_epa<fast>");
-    // (the launcher sizes the grid of the persistent forms itself: here only the number of wave-sized batches)
-    if constexpr (std::is_same<T, float>::value) {
-      if (cc_staged) launch_epa_loop(epa_batches, st, wk, lv, q, lib->n_cus);
-    }
     // fp64 with both classes of pairs: their fast-tier kernels on two streams (each one's tail under the other's body)
     hipStream_t st2 = nullptr;
-    if constexpr (std::is_same<T, double>::value) {
-      if (lib->epa64_two_streams && lib->has_curved && (may(B_PRIM) || may(B_PC) || may(B_CP) || may(B_CC))) {
-        if (!lib->aux) {
-          HIP_TRY(hipStreamCreateWithFlags(&lib->aux, hipStreamNonBlocking));
-          HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux0, hipEventDisableTiming));
-          HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux1, hipEventDisableTiming));
-        }
+    if constexpr (!F32) {
+      if (lib->epa64_two_streams && lib->has_curved && general_q) {
+        if (int rc2 = need_aux()) return rc2;
         st2 = lib->aux;
         HIP_TRY(hipEventRecord(lib->ev_aux0, st));
         HIP_TRY(hipStreamWaitEvent(st2, lib->ev_aux0, 0));
       }
     }
-    launch_epa_fast<T>(epa_batches, st, wk, lv, io, q, may(B_CC) && !cc_staged, may(B_PRIM) || may(B_PC) || may(B_CP), lib->n_cus, lib->has_curved, st2);
+    // (the launchers size the grids of the persistent forms themselves: here only the number of wave-sized batches)
+    if constexpr (F32) {
+      if (cc_staged) launch_epa_loop(epa_batches, st, wk, lv, q, lib->n_cus);
+    }
+    if (gen_staged) launch_epa_loop_general<T>(epa_batches, st, st2, wk, lv, q, lib->n_cus, lib->has_curved);
+    if ((F32 && may(B_CC) && !cc_staged) || (general_q && !gen_staged))
+      launch_epa_fast<T>(epa_batches, st, wk, lv, io, q, may(B_CC) && !cc_staged, general_q && !gen_staged, lib->n_cus, lib->has_curved, st2);
     if (st2) {
       HIP_TRY(hipEventRecord(lib->ev_aux1, st2));
       HIP_TRY(hipStreamWaitEvent(st, lib->ev_aux1, 0));
     }
     tend();
-    bool tail_done = false;
-    if constexpr (std::is_same<T, float>::value) {
-      if (cc_staged) {
-        // Three kernels end the batch: the records of the finished polytopes (bound by memory), the continuation of the handed-over ones
-        // and the general full-capacity tier (each as long as its longest chain of iterations, with a few thousand waves).  The first and
-        // the last run on a stream of their own beside the second.
-        if (!lib->aux && lib->records_aside) {
-          HIP_TRY(hipStreamCreateWithFlags(&lib->aux, hipStreamNonBlocking));
-          HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux0, hipEventDisableTiming));
-          HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux1, hipEventDisableTiming));
-        }
-        hipStream_t rs = lib->records_aside ? lib->aux : st;
-        if (lib->records_aside) {
-          HIP_TRY(hipEventRecord(lib->ev_aux0, st));
-          HIP_TRY(hipStreamWaitEvent(rs, lib->ev_aux0, 0));
-        }
-        auto tbeg_on = [&](const char* name, hipStream_t s) {
-          if (!lib->kernel_timing) return;
-          t = timer_slot(lib, ti++, name);
-          hipEventRecord(t->e0, s);
-        };
-        auto tend_on = [&](hipStream_t s) {
-          if (lib->kernel_timing) hipEventRecord(t->e1, s);
-        };
-        tbeg_on("k_epa_records", rs);
-        launch_epa_records(blocks_for(n / 4 + 1, 256), rs, wk, lv, io, q);
-        tend_on(rs);
-        tbeg_on("k_epa<full>", rs);
-        launch_epa_full<T>(blocks_for(n / 16 + 1, 64 / epa_we2<T>), rs, wk, lv, io, q);
-        tend_on(rs);
-        if (lib->records_aside) HIP_TRY(hipEventRecord(lib->ev_aux1, rs));
-        tbeg("k_epa_resume_cc");
-        launch_epa_resume_cc(blocks_for(n / 16 + 1, 64 / HFCL_EPA_CC_RESUME_WE), st, wk, lv, io, q);
-        tend();
-        if (lib->records_aside) HIP_TRY(hipStreamWaitEvent(st, lib->ev_aux1, 0));
-        tail_done = true;
+    if (cc_staged || gen_staged) {
+      // What ends the batch: the records of the finished polytopes (bound by memory), the continuation of the handed-over ones
+      // (k_epa_resume_cc; as long as its longest chain of iterations) and the full-capacity tier (likewise).  The records run on a stream of
+      // their own beside the latter two (with a convex x convex tier the full-capacity tier joins them there, beside the continuation).
+      const bool aside = lib->records_aside;
+      if (aside) {
+        if (int rc2 = need_aux()) return rc2;
+        HIP_TRY(hipEventRecord(lib->ev_aux0, st));
+        HIP_TRY(hipStreamWaitEvent(lib->aux, lib->ev_aux0, 0));
       }
-    }
-    if (!tail_done) {
+      hipStream_t rs = aside ? lib->aux : st;
+      tbeg_on("k_epa_records", rs);
+      if constexpr (F32) {
+        if (cc_staged) launch_epa_records(blocks_for(n / 4 + 1, 256), rs, wk, lv, io, q);
+      }
+      if (gen_staged) launch_epa_records_general<T>(blocks_for(n / 4 + 1, 256), rs, wk, lv, io, q, F32);
+      tend_on(rs);
+      // (without a continuation kernel of its own the batch's stream takes the full-capacity tier)
+      hipStream_t fs = cc_staged ? rs : st;
+      tbeg_on("k_epa<full>", fs);
+      launch_epa_full<T>(blocks_for(n / 16 + 1, 64 / epa_we2<T>), fs, wk, lv, io, q);
+      tend_on(fs);
+      if (aside) HIP_TRY(hipEventRecord(lib->ev_aux1, rs));
+      if constexpr (F32) {
+        if (cc_staged) {
+          tbeg("k_epa_resume_cc");
+          launch_epa_resume_cc(blocks_for(n / 16 + 1, 64 / HFCL_EPA_CC_RESUME_WE), st, wk, lv, io, q);
+          tend();
+        }
+      }
+      if (aside) HIP_TRY(hipStreamWaitEvent(st, lib->ev_aux1, 0));
+    } else {
       tbeg("k_epa<full>");
       launch_epa_full<T>(blocks_for(n / 16 + 1, 64 / epa_we2<T>), st, wk, lv, io, q);
       tend();
@@ -1464,6 +1504,8 @@ static hfcl_lib* make_helper(hfcl_lib* lib) {
   h->closed_staged = lib->closed_staged;
   h->epa_cc_staged = lib->epa_cc_staged;
   h->records_aside = lib->records_aside;
+  h->epa_general_staged = lib->epa_general_staged;
+  h->epa_general_staged_min = lib->epa_general_staged_min;
   h->epa64_two_streams = lib->epa64_two_streams;
   h->epa_cc_staged_min = lib->epa_cc_staged_min;
   h->n_cus = lib->n_cus;

@@ -582,6 +582,200 @@ __global__ void __launch_bounds__(256) k_epa_records(Work wk, LibView<T> lib, IO
 }
 
 // =======================================================================================
+// The same three stages for pairs of any convex kinds and for both precisions (hfcl_epa.hpp: EpaReadyG).  The lockstep fast tiers
+// (k_epa<.., 1, QSEL>) step the 4 or 8 polytopes of a wave until the last of them is through: on cfg5 the curved class runs 24 iterations on
+// average and 36 for the slowest of four (66 % useful trips; 77 % with the hand-over at 29), the polytope class 5.7 and 11.2 for the
+// slowest of eight (53 %).  The streaming form lost in fp64 because a refill -- seed, shape records, encloseOrigin, tetrahedron; witness
+// points and record -- cost more than the idle groups (profiles/r02_q, r02_u, r03_l); here a refill is twelve records copied into LDS.
+//   k_epa_prepare_general  both queues of epa_queue (bottom: 0 .. counts[B_COUNT]; top: slots n-1 downwards, counts[B_COUNT + 3]) ->
+//                          block i / block n-1-i of epa_ready_g; encloseOrigin (any rank) with the pair's supports, one lane per seed
+//   k_epa_loop_general     one queue (QTOP), WE lanes per polytope, blocks for CAP iterations; hands over to the full-capacity tier as
+//                          the lockstep kernels do (epa_save_block, queue 2)
+//   k_epa_records_general  both queues
+// fp64 arithmetic is the reference's (the unit is built without contraction) in every stage: the records are the lockstep form's, byte for byte.
+// =======================================================================================
+template <typename T>
+__device__ __forceinline__ EpaReadyG<T>* ready_g(const Work& wk, bool top, uint32_t i) {
+  return reinterpret_cast<EpaReadyG<T>*>(wk.epa_ready_g) + (top ? wk.n - 1u - i : i);
+}
+// (seeds of rank < 4 -- encloseOrigin would evaluate supports: none in 60 000 polytopes of cfg5 / cfg2 -- go to the full-capacity tier, which
+// starts from any seed and reproduces the fast tier's record bit for bit (test_epa_hand_over_equals_restart); the kernel then needs no support
+// function and nothing but a seed's eight points in registers)
+struct NoSupportNeeded {
+  template <typename T>
+  __device__ __forceinline__ void operator()(const V3<T>&, V3<T>& w, V3<T>& w0) const {
+    w = w0 = mk<T>(T(0), T(0), T(0));
+  }
+};
+template <typename T>
+__global__ void __launch_bounds__(256) k_epa_prepare_general(Work wk, LibView<T> lib, IO<T> io, QParams<T> q, int skip_top) {
+  const uint32_t cnt0 = wk.counts[B_COUNT], cnt = cnt0 + (skip_top ? 0u : wk.counts[B_COUNT + 3]);
+  const EpaItem<T>* const queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
+  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
+    const bool top = it >= cnt0;
+    const uint32_t i = top ? it - cnt0 : it;
+    const EpaItem<T>* ip = top ? queue + (wk.n - 1u - i) : queue + i;
+    EpaReadyG<T>* const rbp = ready_g<T>(wk, top, i);
+    if (ip->rank != 4) {
+      const uint32_t slot = atomicAdd(&wk.counts[B_COUNT + 1], 1u);
+      reinterpret_cast<EpaItem<T>*>(wk.epa_queue2)[slot] = *ip;
+      rbp->state = EPA_READY_NONE;
+      continue;
+    }
+    const uint32_t pair = ip->pair;
+    EpaRegStore<T> st;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      st.w[k] = ip->w[k];
+      st.w0[k] = ip->w0[k];
+    }
+    int flags[4], closest = 0;
+    NoSupportNeeded ns;
+    // (the records go straight to the block: held in registers until the end they are 100 of them in fp64)
+    if (epa_prepare_general(st, 4, q.epa_tolerance, ns, rbp->vw, rbp->v0, rbp->fn, flags, closest)) {
+      const uint32_t sid1 = wk.shape1[pair], sid2 = wk.shape2[pair];
+      const MDiff<T> md = make_mdiff(load_pose(io.tf1, pair), load_pose(io.tf2, pair));
+      rbp->seed = i | (top ? 0x80000000u : 0u);
+      rbp->pair = pair;
+      rbp->sid1 = sid1;
+      rbp->sid2 = sid2;
+      rbp->packed = uint32_t(closest) | (uint32_t((flags[0] >> 1) & 1) << 2) | (uint32_t((flags[1] >> 1) & 1) << 3) | (uint32_t((flags[2] >> 1) & 1) << 4) |
+                    (uint32_t((flags[3] >> 1) & 1) << 5) | (md.identity ? 1u << 6 : 0u);
+      rbp->gjk_iters = ip->gjk_iters;
+      rbp->state = EPA_READY_PENDING;
+      rbp->md[0] = md.oR1.r0.x; rbp->md[1] = md.oR1.r0.y; rbp->md[2] = md.oR1.r0.z;
+      rbp->md[3] = md.oR1.r1.x; rbp->md[4] = md.oR1.r1.y; rbp->md[5] = md.oR1.r1.z;
+      rbp->md[6] = md.oR1.r2.x; rbp->md[7] = md.oR1.r2.y; rbp->md[8] = md.oR1.r2.z;
+      rbp->md[9] = md.ot1.x; rbp->md[10] = md.ot1.y; rbp->md[11] = md.ot1.z;
+    } else {  // FallBack (:1299-1315): final without a loop
+      EpaResult<T> res;
+      res.status = EPA_FALLBACK;
+      res.iterations = 0;
+      PairOut<T> o;
+      epa_finish(res, ip->gjk_iters, load_pose(io.tf1, pair), swept_radius(lib.shapes[wk.shape1[pair]]), swept_radius(lib.shapes[wk.shape2[pair]]), o);
+      write_out<T>(io, q, pair, o);
+      write_guess<T>(io, pair, o.cached_guess, 0, 0);
+      rbp->state = EPA_READY_NONE;
+    }
+  }
+}
+
+#ifndef HFCL_EPA_LOOPG_REFILL_MIN
+#define HFCL_EPA_LOOPG_REFILL_MIN 1
+#endif
+template <typename T, int WE, int CAP, bool QTOP>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? epa_waves_per_simd<T, WE, CAP, 1> : HFCL_WPE_EPA32, 8)))
+k_epa_loop_general(Work wk, LibView<T> lib, QParams<T> q) {
+  constexpr int G = 64 / WE;
+  typedef LaneGroup<WE> Grp;
+  __shared__ EpaScratch<T, CAP, V0_BLOCK> scratch[G];
+  const uint32_t cnt = wk.counts[QTOP ? B_COUNT + 3 : B_COUNT];
+  const int lane = threadIdx.x & 63, grp = lane / WE, lig = lane & (WE - 1);
+  const EpaItem<T>* const queue = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
+  enum { IDLE = 0, LIVE = 1, DONE = 2, HANDOVER = 3 };
+  int state = IDLE;
+  uint32_t it = 0;             // item of this group's polytope
+  uint32_t next = blockIdx.x;  // wave-uniform: the wave's items are next, next + gridDim.x, ...
+  EpaSupport<T, WE, false> sup;
+  sup.lig = lig;
+  Epa<T, Grp, CAP, V0_BLOCK> epa;
+  EpaLoop<T> L;
+  while (true) {
+    const uint64_t live = __ballot(state == LIVE);
+    const int n_live = __popcll(live) / WE;
+    const bool more = next < cnt;
+    if (n_live == 0 || (more && G - n_live >= HFCL_EPA_LOOPG_REFILL_MIN)) {
+      if (state != LIVE) {
+        if (state != IDLE) {
+          EpaReadyG<T>* rb = ready_g<T>(wk, QTOP, it);
+          if (state == DONE) {
+            EpaLoopOutG<T> o;
+            epa.loop_out(L, o);
+            if (lig == 0) {
+              *reinterpret_cast<EpaLoopOutG<T>*>(rb->md) = o;
+              rb->state = EPA_READY_DONE;
+            }
+          } else {  // hand over to the full-capacity tier: the seed and, room permitting, the polytope itself
+            const EpaItem<T>* ip = QTOP ? queue + (wk.n - 1u - it) : queue + it;
+            uint32_t slot = 0;
+            if (lig == 0) slot = atomicAdd(&wk.counts[B_COUNT + 1], 1u);
+            slot = __shfl(slot, 0, WE);
+            const bool save = epa.resumable && slot < wk.resume_cap;
+            if (save) epa_save_block<T, Grp, CAP>(&scratch[grp], resume_slot<T, CAP>(wk, slot));
+            if (lig == 0) {  // queue to queue, no local copy
+              EpaItem<T>* dst = reinterpret_cast<EpaItem<T>*>(wk.epa_queue2) + slot;
+              *dst = *ip;
+              if (save) dst->rank = ip->rank | EPA_RESUME_FLAG | (CAP != epa_fast_cap<T> ? EPA_RESUME_SMALL : 0);
+              rb->state = EPA_READY_HANDED_OVER;
+            }
+          }
+          Grp::sync();
+          state = IDLE;
+        }
+        const uint64_t lower = live | ~((uint64_t(1) << (grp * WE)) - 1);  // live lanes and lanes >= mine do not count
+        const uint32_t rank = uint32_t(__popcll(~lower)) / WE;
+        it = next + rank * gridDim.x;
+        if (it < cnt) {
+          const EpaReadyG<T>* rb = ready_g<T>(wk, QTOP, it);
+          if (rb->state == EPA_READY_PENDING) {  // (EPA_READY_NONE: k_epa_prepare_general wrote the record)
+            const uint32_t packed = rb->packed;
+            sup.a = lib.shapes[rb->sid1];
+            sup.b = lib.shapes[rb->sid2];
+            if (sup.a.kind == K_CONVEX) sup.h0.load(lib.verts + 3 * size_t(sup.a.vertex_offset), sup.a.num_points, lig);
+            if (sup.b.kind == K_CONVEX) sup.h1.load(lib.verts + 3 * size_t(sup.b.vertex_offset), sup.b.num_points, lig);
+            sup.md.oR1.r0 = mk<T>(rb->md[0], rb->md[1], rb->md[2]);
+            sup.md.oR1.r1 = mk<T>(rb->md[3], rb->md[4], rb->md[5]);
+            sup.md.oR1.r2 = mk<T>(rb->md[6], rb->md[7], rb->md[8]);
+            sup.md.ot1 = mk<T>(rb->md[9], rb->md[10], rb->md[11]);
+            sup.md.identity = (packed >> 6) & 1u;
+            epa.reset(&scratch[grp], q.epa_max_iterations, q.epa_tolerance);
+            epa.loop_enter(L, epa.install(rb, packed), 0, 0);
+            state = LIVE;
+          }
+        }
+      }
+      next += uint32_t(G - n_live) * gridDim.x;
+      if (n_live == 0 && !more) {
+        if (__ballot(state == LIVE) == 0) break;
+      }
+      continue;
+    }
+    if (state == LIVE) {
+      const int r = epa.step(L, sup);
+      if (r != 0) state = r == 1 ? DONE : HANDOVER;
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_epa_records_general(Work wk, LibView<T> lib, IO<T> io, QParams<T> q, int skip_top) {
+  const uint32_t cnt0 = wk.counts[B_COUNT], cnt = cnt0 + (skip_top ? 0u : wk.counts[B_COUNT + 3]);
+  for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < cnt; it += gridDim.x * blockDim.x) {
+    const bool top = it >= cnt0;
+    const EpaReadyG<T>* rb = ready_g<T>(wk, top, top ? it - cnt0 : it);
+    if (rb->state != EPA_READY_DONE) continue;  // handed over (the full-capacity tier writes the record) or final already
+    const EpaLoopOutG<T>* lo = reinterpret_cast<const EpaLoopOutG<T>*>(rb->md);
+    const uint32_t pair = rb->pair;
+    const T r0 = swept_radius(lib.shapes[rb->sid1]), r1 = swept_radius(lib.shapes[rb->sid2]);
+    EpaResult<T> res;
+    res.status = lo->status;
+    res.iterations = lo->iterations;
+    res.normal = mk<T>(lo->nx, lo->ny, lo->nz);
+    res.depth = lo->depth + (r0 + r1);
+    res.rw0_ = mk<T>(lo->rw[0], lo->rw[1], lo->rw[2]);
+    res.rw1_ = mk<T>(lo->rw[3], lo->rw[4], lo->rw[5]);
+    res.rw2_ = mk<T>(lo->rw[6], lo->rw[7], lo->rw[8]);
+    res.r00 = mk<T>(lo->r0[0], lo->r0[1], lo->r0[2]);
+    res.r01 = mk<T>(lo->r0[3], lo->r0[4], lo->r0[5]);
+    res.r02 = mk<T>(lo->r0[6], lo->r0[7], lo->r0[8]);
+    PairOut<T> o;
+    epa_finish(res, rb->gjk_iters, load_pose(io.tf1, pair), r0, r1, o);
+    write_out<T>(io, q, pair, o);
+    write_guess<T>(io, pair, o.cached_guess, 0, 0);
+  }
+}
+
+// =======================================================================================
 // launchers (hfcl_launch.hpp)
 // =======================================================================================
 // fp32 streams (two or three waves per SIMD hide the refill's global loads: k_epa<fast> 1.87 -> 1.76 ms on cfg3);
@@ -659,6 +853,44 @@ void launch_epa_records(int grid, hipStream_t st, const Work& wk, const LibView<
 }
 
 #endif
+
+// the general three-stage fast tier (fp64: the polytope class from the bottom queue on st, the curved class from the top queue on st2 when
+// given; fp32: the bottom queue -- the top one is the convex x convex tier's)
+template <typename T>
+void launch_epa_prepare_general(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool skip_top) {
+  hipLaunchKernelGGL((k_epa_prepare_general<T>), dim3(grid), dim3(256), 0, st, wk, lv, io, q, skip_top ? 1 : 0);
+}
+template <typename T>
+void launch_epa_records_general(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool skip_top) {
+  hipLaunchKernelGGL((k_epa_records_general<T>), dim3(grid), dim3(256), 0, st, wk, lv, io, q, skip_top ? 1 : 0);
+}
+#ifndef HFCL_EPA_LOOPG_ROUNDS
+#define HFCL_EPA_LOOPG_ROUNDS 1
+#endif
+template <typename T>
+void launch_epa_loop_general(int grid, hipStream_t st, hipStream_t st2, const Work& wk, const LibView<T>& lv, const QParams<T>& q, int n_cus, bool curved_class) {
+  if constexpr (sizeof(T) == 4) {
+    static const int per_cu = resident_blocks_per_cu(k_epa_loop_general<T, EPA_WE, EPA_FAST_CAP, false>);
+    hipLaunchKernelGGL((k_epa_loop_general<T, EPA_WE, EPA_FAST_CAP, false>), dim3(std::min(grid, n_cus * per_cu * HFCL_EPA_LOOPG_ROUNDS)), dim3(64), 0, st, wk, lv, q);
+  } else {
+    static const int per_cu_c = resident_blocks_per_cu(k_epa_loop_general<T, HFCL_EPA64_CURVED_WE, epa_fast_cap<T>, true>);
+    static const int per_cu_p = resident_blocks_per_cu(k_epa_loop_general<T, EPA_WE, epa_small_cap<T>, false>);
+    if (curved_class)
+      hipLaunchKernelGGL((k_epa_loop_general<T, HFCL_EPA64_CURVED_WE, epa_fast_cap<T>, true>), dim3(std::min(grid * (HFCL_EPA64_CURVED_WE / EPA_WE), n_cus * per_cu_c * HFCL_EPA_LOOPG_ROUNDS)), dim3(64), 0, st, wk, lv, q);
+    hipLaunchKernelGGL((k_epa_loop_general<T, EPA_WE, epa_small_cap<T>, false>), dim3(std::min(grid, n_cus * per_cu_p * HFCL_EPA_LOOPG_ROUNDS)), dim3(64), 0, (curved_class && st2) ? st2 : st, wk, lv, q);
+  }
+}
+#define HFCL_INST_G(T)                                                                                                                                     \
+  template void launch_epa_prepare_general<T>(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&, bool);                   \
+  template void launch_epa_records_general<T>(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&, bool);                   \
+  template void launch_epa_loop_general<T>(int, hipStream_t, hipStream_t, const Work&, const LibView<T>&, const QParams<T>&, int, bool);
+#if HFCL_UNIT_F32
+HFCL_INST_G(float)
+#endif
+#if HFCL_UNIT_F64
+HFCL_INST_G(double)
+#endif
+#undef HFCL_INST_G
 
 template <typename T>
 void launch_epa_full(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {

@@ -59,6 +59,10 @@ void launch_epa_prepare(int grid, hipStream_t st, const Work& wk, const LibView<
 void launch_epa_loop(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const QParams<float>& q, int n_cus);
 void launch_epa_resume_cc(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q);
 void launch_epa_records(int grid, hipStream_t st, const Work& wk, const LibView<float>& lv, const IO<float>& io, const QParams<float>& q);
+// ... and for pairs of any convex kinds, both precisions (Work::epa_ready_g set)
+template <typename T> void launch_epa_prepare_general(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool skip_top);
+template <typename T> void launch_epa_loop_general(int grid, hipStream_t st, hipStream_t st2, const Work& wk, const LibView<T>& lv, const QParams<T>& q, int n_cus, bool curved_class);
+template <typename T> void launch_epa_records_general(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool skip_top);
 template <typename T> void launch_epa_full(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q);
 
 // split: the task tables of a split traversal (tasks == nullptr: single pass)

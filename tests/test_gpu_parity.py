@@ -302,6 +302,42 @@ def test_fp32_staged_epa_equals_one_kernel_form(pkg, torch_cuda, monkeypatch, ca
     assert differ.size == 0, "%d records differ, first %s" % (differ.size, differ[:10])
 
 
+@pytest.mark.parametrize("case,n,precision", [("cfg5_mixed", 120000, "f64"), ("all_primitives", 60000, "f64"), ("cfg2_box_capsule", 120000, "f64"),
+                                              ("cfg5_mixed", 120000, "f32"), ("cfg2_box_capsule", 120000, "f32")])
+def test_general_staged_epa_equals_one_kernel_form(pkg, torch_cuda, monkeypatch, case, n, precision):
+    """HFCL_EPA_GENERAL_STAGED=1 (k_epa_prepare_general / k_epa_loop_general / k_epa_records_general for the general EPA queues; off by
+    default, profiles/r05_e_general_staged.md) against the default one-kernel forms on the same batch: records and cached guesses byte for
+    byte."""
+    torch = torch_cuda
+    abi, wl = pkg.abi, pkg.workloads
+    b = getattr(wl, case)(n=n, seed=5)
+    req = wl.make_request(b, abi)
+    dev = torch.device("cuda:0")
+    d_s1 = torch.from_numpy(b.s1.astype(np.int32)).to(dev)
+    d_s2 = torch.from_numpy(b.s2.astype(np.int32)).to(dev)
+    f32 = precision == "f32"
+    d_p1 = torch.from_numpy(b.pose1_f32 if f32 else b.tf1).to(dev)
+    d_p2 = torch.from_numpy(b.pose2_f32 if f32 else b.tf2).to(dev)
+    words = 11 if f32 else 24
+    recs = {}
+    monkeypatch.setenv("HFCL_EPA_GENERAL_STAGED_MIN", "0")
+    for staged in ("0", "1"):
+        monkeypatch.setenv("HFCL_EPA_GENERAL_STAGED", staged)
+        lib = pkg.Library(b.lib)
+        d_out = torch.zeros(len(b) * words, dtype=torch.int32, device=dev)
+        name = ("distance" if b.kind == "distance" else "collide") + ("_device_f32" if f32 else "_device")
+        for _ in range(2):
+            getattr(lib, name)(d_s1, d_s2, d_p1, d_p2, len(b), req, d_out, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        recs[staged] = d_out.cpu().numpy().reshape(len(b), words).copy()
+        names = [k for k, _ in lib.last_kernel_breakdown()]
+        assert ("k_epa_prepare_general" in names) == (staged == "1"), names
+        assert lib.last_bucket_counts()["epa_queue"] > 0
+        lib.close()
+    differ = np.flatnonzero((recs["0"] != recs["1"]).any(axis=1))
+    assert differ.size == 0, "%d records differ, first %s" % (differ.size, differ[:10])
+
+
 def _support(abi, b, shape_id, R, T, n):
     """max over the posed shape of x . n (fp64, from the shape table): Box / Capsule / Convex."""
     sh = b.shapes[shape_id]
