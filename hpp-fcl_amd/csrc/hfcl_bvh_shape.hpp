@@ -727,9 +727,10 @@ HFCL_HD bool mesh_shape_leaf_lane(const V3<T>& ta, const V3<T>& tb, const V3<T>&
 
 // The EPA half of a deferred leaf, by a lane group: returns the leaf's distance, p1 (triangle) / p2 (solid) / n and the
 // solver's cached guess after it.
-template <typename T, class Grp, class Solid>
+// done (optional): false when the polytope outgrew the CAP-sized block (nothing else is meaningful then: the full-capacity tier redoes it).
+template <typename T, class Grp, class Solid, int CAP = EPA_MAX_ITER>
 HFCL_HD T mesh_shape_leaf_finish(const ShapeDeferItem<T>& item, const Pose<T>& tfs, const Solid& solid, T r1, const QParams<T>& q,
-                                 EpaScratch<T, EPA_MAX_ITER>* scratch, V3<T>& p1, V3<T>& p2, V3<T>& n, V3<T>& guess) {
+                                 EpaScratch<T, CAP>* scratch, V3<T>& p1, V3<T>& p2, V3<T>& n, V3<T>& guess, bool* done = nullptr) {
   SolidTriSupport<T, Solid> sup;
   sup.a = item.a;
   sup.b = item.b;
@@ -737,8 +738,9 @@ HFCL_HD T mesh_shape_leaf_finish(const ShapeDeferItem<T>& item, const Pose<T>& t
   sup.solid = &solid;
   PairOut<T> o;
   Grp::sync();
-  epa_run<T, Grp, EPA_MAX_ITER>(scratch, item.seed, q, tfs, r1, T(0), sup, o);
+  const int rc = epa_run<T, Grp, CAP>(scratch, item.seed, q, tfs, r1, T(0), sup, o);
   Grp::sync();
+  if (done) *done = rc == 1;
   p1 = o.p2;
   p2 = o.p1;
   n = -o.normal;

@@ -59,7 +59,9 @@ constexpr int CTR_SHAPE_DIST_SUSP = 2 * B_COUNT + 7;  // ... mesh x solid (Shape
 constexpr int CTR_DIST_TICKET = 2 * B_COUNT + 8;  // ticket of k_bvh_distance_pool: next DistSusp record to take
 constexpr int CTR_SHAPE_DIST_TICKET = 2 * B_COUNT + 9;  // ticket of k_bvh_shape_distance_pool
 constexpr int CTR_EPA_CC_OVER = 2 * B_COUNT + 10;  // convex x convex polytopes k_epa_loop saved for k_epa_resume_cc
-constexpr int N_COUNTERS = 2 * B_COUNT + 11;  // bucket populations + the four counters of Work::counts + curved populations + those
+constexpr int CTR_SHAPE_FINISH_OVER = 2 * B_COUNT + 11;  // [+0, +1] mesh x solid EPA leaves that outgrew k_bvh_shape_finish's fast block (the two halves of Work::shape_finish_over)
+constexpr int CTR_SHAPE_DEFER_MARK = 2 * B_COUNT + 13;   // CTR_SHAPE_DEFER as the first launch of k_bvh_shape_coop left it: the items of whole walks (k_bvh_level_mark)
+constexpr int N_COUNTERS = 2 * B_COUNT + 14;  // bucket populations + the four counters of Work::counts + curved populations + those
 
 // Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
 // support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
@@ -173,6 +175,7 @@ struct Work {
   uint32_t resume_cap;
   void* shape_defer;  // ShapeDeferItem<T>[shape_defer_cap]: mesh x solid leaves waiting for EPA (k_bvh_collide<SOLID> -> k_bvh_shape_finish); nullptr: group kernels
   uint32_t shape_defer_cap;  // a unit (query, or task of a split walk) queues at most one item: sized by the host for every unit a batch can make
+  uint32_t* shape_finish_over;  // [2 * shape_defer_cap] indices of shape_defer: the items whose polytope outgrew the fast block of k_bvh_shape_finish (nullptr: one tier)
   void* shape_oq;     // ObbQuery<T>[n], by pair: the solid's fitted OBB against the mesh pose (k_shape_obb)
   void* epa_ready;    // EpaReady<T>[n]: convex x convex polytopes between k_epa_prepare, k_epa_loop and k_epa_records (nullptr: the one-kernel form)
   void* epa_ready_g;  // EpaReadyG<T>[n]: polytopes of any pair kinds between k_epa_prepare_general / k_epa_loop_general / k_epa_records_general (nullptr: the lockstep tiers)

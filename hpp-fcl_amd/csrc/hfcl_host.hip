@@ -97,7 +97,7 @@ struct hfcl_lib {
   void* d_epa_queue2 = nullptr;
   uint32_t* d_epa_cc_over = nullptr;  // Work::epa_cc_over (resume_cap entries)
   hipStream_t aux = nullptr;     // k_epa_records runs here, beside the tiers that continue the handed-over polytopes
-  hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr;
+  hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr, ev_aux2 = nullptr, ev_aux3 = nullptr;  // fork / join of the EPA tail; of k_bvh_shape_finish's first half
   void* d_epa_ready = nullptr;   // EpaReady<float>[epa_ready_capacity]: the staged convex x convex fast tier (k_epa_prepare / k_epa_loop / k_epa_records)
   size_t epa_ready_capacity = 0;
   void* d_epa_ready_g = nullptr; // EpaReadyG<T>[ws_capacity]: the staged fast tier of the general queues (both precisions)
@@ -113,6 +113,8 @@ struct hfcl_lib {
   void* d_epa_resume = nullptr;
   void* d_epa_v0 = nullptr;
   size_t resume_cap = 0;
+  bool shape_finish_tiers = true;  // HFCL_SHAPE_FINISH_TIERS=0: k_bvh_shape_finish in one launch at full capacity
+  bool shape_finish_aside = true;  // HFCL_SHAPE_FINISH_ASIDE=0: all of k_bvh_shape_finish behind the last launch of k_bvh_shape_coop
   void* d_shape_defer = nullptr;  // ShapeDeferItem<double>[shape_defer_capacity]: EPA queue of the one-query-per-lane mesh x solid form
   void* d_shape_oq = nullptr;     // ObbQuery<double>[shape_defer_capacity]: the solids' OBBs against the mesh poses, by pair
   size_t shape_defer_capacity = 0;
@@ -473,6 +475,8 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_EPA_CC_STAGED")) lib->epa_cc_staged = atoi(v) != 0;
   if (const char* v = getenv("HFCL_EPA_RECORDS_ASIDE")) lib->records_aside = atoi(v) != 0;
   if (const char* v = getenv("HFCL_EPA_GENERAL_STAGED")) lib->epa_general_staged = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_SHAPE_FINISH_TIERS")) lib->shape_finish_tiers = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_SHAPE_FINISH_ASIDE")) lib->shape_finish_aside = atoi(v) != 0;
   if (const char* v = getenv("HFCL_EPA_GENERAL_STAGED_MIN")) lib->epa_general_staged_min = size_t(std::max(0ll, atoll(v)));
   if (const char* v = getenv("HFCL_EPA64_TWO_STREAMS")) lib->epa64_two_streams = atoi(v) != 0;
   if (const char* v = getenv("HFCL_EPA_CC_STAGED_MIN")) lib->epa_cc_staged_min = size_t(std::max(0ll, atoll(v)));
@@ -541,6 +545,8 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   if (lib->aux) hipStreamDestroy(lib->aux);
   if (lib->ev_aux0) hipEventDestroy(lib->ev_aux0);
   if (lib->ev_aux1) hipEventDestroy(lib->ev_aux1);
+  if (lib->ev_aux2) hipEventDestroy(lib->ev_aux2);
+  if (lib->ev_aux3) hipEventDestroy(lib->ev_aux3);
   hipFree(lib->d_epa_resume);
   hipFree(lib->d_epa_v0);
   hipFree(lib->d_shape_defer);
@@ -1032,6 +1038,16 @@ static int validate_query(const hfcl_query_request& q) {
 // Lane-group width of the convex GJK kernels.  A/B on cfg3 / cfg5 (profiles/r01_k_gjk_lane_group_w2.txt): 2-lane
 // groups (16 vertices of each hull per lane, 32 pairs per wave: half the redundancy of the serial simplex code)
 // beat 4-lane groups wherever their 96 / 192 vertex registers fit -- everywhere but fp64 convex x convex.
+// the helper stream of a library (tail kernels beside the main ones) and its fork / join events, made on first use
+static int ensure_aux(hfcl_lib* lib) {
+  if (lib->aux) return HFCL_OK;
+  HIP_TRY(hipStreamCreateWithFlags(&lib->aux, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux0, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux1, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux2, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux3, hipEventDisableTiming));
+  return HFCL_OK;
+}
 template <typename T, int M>
 static int auto_cvx_w() {
   return (sizeof(T) == 8 && M == 0) ? 4 : 2;
@@ -1101,6 +1117,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
   wk.resume_cap = uint32_t(std::min<size_t>(lib->resume_cap, 0xFFFFFFFFu));
   wk.shape_defer = nullptr;
   wk.shape_defer_cap = 0;
+  wk.shape_finish_over = nullptr;
   wk.shape_oq = nullptr;
   wk.epa_ready = nullptr;
   wk.epa_ready_g = nullptr;
@@ -1263,12 +1280,13 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         hipFree(lib->d_shape_oq);
         lib->d_shape_defer = lib->d_shape_oq = nullptr;
         lib->shape_defer_capacity = 0;
-        HIP_TRY(hipMalloc(&lib->d_shape_defer, need * sizeof(ShapeDeferItem<double>)));
+        HIP_TRY(hipMalloc(&lib->d_shape_defer, need * (sizeof(ShapeDeferItem<double>) + 2 * sizeof(uint32_t))));  // (+ the two lists of k_bvh_shape_finish's second tier)
         HIP_TRY(hipMalloc(&lib->d_shape_oq, need * std::max(sizeof(ObbQuery<double>), sizeof(RssQuery<double>))));
         lib->shape_defer_capacity = need;
       }
       wk.shape_defer = lib->d_shape_defer;
       wk.shape_defer_cap = uint32_t(std::min<size_t>(lib->shape_defer_capacity, 0xFFFFFFFFu));
+      wk.shape_finish_over = lib->shape_finish_tiers ? reinterpret_cast<uint32_t*>(static_cast<char*>(lib->d_shape_defer) + lib->shape_defer_capacity * sizeof(ShapeDeferItem<double>)) : nullptr;
       wk.shape_oq = lib->d_shape_oq;
     }
     if (q.mode == 1) {
@@ -1279,8 +1297,14 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         BvhSplit split;
         rc = make_split(split, n >= 256 && q.guess_mode != HFCL_GUESS_CACHED && !io.gout, true);
         if (rc) return rc;
+        AsideStream aside = {nullptr, nullptr, nullptr};
+        if (lib->shape_finish_aside && wk.shape_finish_over && split.tasks && split.coop && split.cut_ticks) {
+          rc = ensure_aux(lib);
+          if (rc) return rc;
+          aside = AsideStream{lib->aux, lib->ev_aux2, lib->ev_aux3};
+        }
         launch_bvh_shape_fast<T>(blocks_for(n, BVH_BLOCK), blocks_for(n / 8 + 1, 64 / BS_W), int(std::min<size_t>(n / 4 + 1, size_t(lib->n_cus) * 8)), st, wk, lv, bv, io, q, lib->bvh_params,
-                                 T(lib->break_distance * lib->break_distance), split, spill);
+                                 T(lib->break_distance * lib->break_distance), split, spill, aside.stream ? &aside : nullptr);
       } else {
         launch_bvh_shape<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance));
       }
@@ -1355,13 +1379,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     bool cc_staged = false;
     if constexpr (F32) cc_staged = may(B_CC) && lib->epa_cc_staged && n >= lib->epa_cc_staged_min;
     const bool gen_staged = general_q && lib->epa_general_staged && n >= lib->epa_general_staged_min;
-    auto need_aux = [&]() -> int {
-      if (lib->aux) return HFCL_OK;
-      HIP_TRY(hipStreamCreateWithFlags(&lib->aux, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux0, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux1, hipEventDisableTiming));
-      return HFCL_OK;
-    };
+    auto need_aux = [&]() -> int { return ensure_aux(lib); };
     auto tbeg_on = [&](const char* name, hipStream_t s) {
       if (!lib->kernel_timing) return;
       t = timer_slot(lib, ti++, name);
@@ -1505,6 +1523,9 @@ static hfcl_lib* make_helper(hfcl_lib* lib) {
   h->epa_cc_staged = lib->epa_cc_staged;
   h->records_aside = lib->records_aside;
   h->epa_general_staged = lib->epa_general_staged;
+  h->shape_finish_tiers = lib->shape_finish_tiers;
+  h->shape_finish_aside = lib->shape_finish_aside;
+  h->shape_cut_ticks = lib->shape_cut_ticks;
   h->epa_general_staged_min = lib->epa_general_staged_min;
   h->epa64_two_streams = lib->epa64_two_streams;
   h->epa_cc_staged_min = lib->epa_cc_staged_min;

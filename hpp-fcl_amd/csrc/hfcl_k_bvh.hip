@@ -843,6 +843,7 @@ __global__ void k_bvh_level_mark(Work wk, BvhSplit split, int ticket) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     split.ctr[BVH_CTR_LEVEL0 + split.level + 1] = split.ctr[BVH_CTR_TASKS];
     wk.counts[ticket] = 0u;
+    if (ticket == CTR_SHAPE_TICKET && split.level == 1) wk.counts[CTR_SHAPE_DEFER_MARK] = min(wk.counts[CTR_SHAPE_DEFER], wk.shape_defer_cap);  // (the first launch of k_bvh_shape_coop is over)
   }
 }
 #endif
@@ -1040,14 +1041,30 @@ __global__ void __launch_bounds__(256) k_shape_obb(Work wk, LibView<T> lib, IO<T
   }
 }
 
-template <typename T, int PART = HFCL_BVH_PART>
-__global__ void __launch_bounds__(64) k_bvh_shape_finish(Work wk, LibView<T> lib, IO<T> io, QParams<T> q, BvhParams bp, BvhSplit split, int distance_mode) {
+// Two tiers (HFCL_SHAPE_FINISH_TIERS, default on), as k_epa's: CAP = SHAPE_FINISH_FAST_CAP first -- a block a third the size, two waves
+// per SIMD where the full-capacity block admits one -- and the polytopes that outgrow it listed in Work::shape_finish_over for a second
+// launch at EPA_MAX_ITER that starts them again (tier: 0 the only launch, 1 the fast one, 2 the one over the list).  What a polytope that
+// fits computes does not depend on the block's capacity (tests/test_gpu_parity.py: test_epa_hand_over_equals_restart is the same property of
+// k_epa's tiers), so the records are those of the one-tier form.
+#ifndef HFCL_SHAPE_FINISH_FAST_CAP
+#define HFCL_SHAPE_FINISH_FAST_CAP 21
+#endif
+constexpr int SHAPE_FINISH_FAST_CAP = HFCL_SHAPE_FINISH_FAST_CAP;
+template <typename T, int PART = HFCL_BVH_PART, int CAP = EPA_MAX_ITER>
+// range: 0 every item; 1 the items in front of CTR_SHAPE_DEFER_MARK (whole walks: final once the first launch of k_bvh_shape_coop is over); 2 the
+// items behind it (those of chunks).  Ranges 1 and 2 run on two streams and list their second tier in the two halves of shape_finish_over.
+__global__ void __launch_bounds__(64) k_bvh_shape_finish(Work wk, LibView<T> lib, IO<T> io, QParams<T> q, BvhParams bp, BvhSplit split, int distance_mode, int tier, int range) {
   constexpr int G = 64 / BS_W;
-  __shared__ EpaScratch<T, EPA_MAX_ITER> scratch[G];
-  const uint32_t cnt = min(wk.counts[CTR_SHAPE_DEFER], wk.shape_defer_cap);
+  __shared__ EpaScratch<T, CAP> scratch[G];
+  const int half = range == 2 ? 1 : 0;
+  uint32_t* const over = wk.shape_finish_over + size_t(half) * wk.shape_defer_cap;
+  const uint32_t first = tier != 2 && range == 2 ? wk.counts[CTR_SHAPE_DEFER_MARK] : 0u;
+  const uint32_t cnt = tier == 2 ? min(wk.counts[CTR_SHAPE_FINISH_OVER + half], wk.shape_defer_cap)
+                                 : (range == 1 ? wk.counts[CTR_SHAPE_DEFER_MARK] : min(wk.counts[CTR_SHAPE_DEFER], wk.shape_defer_cap));
   const ShapeDeferItem<T>* const items = reinterpret_cast<const ShapeDeferItem<T>*>(wk.shape_defer);
   const int lane = threadIdx.x & 63, grp = lane / BS_W, lig = lane & (BS_W - 1);
-  for (uint32_t it = blockIdx.x * G + grp; it < cnt; it += gridDim.x * G) {
+  for (uint32_t k = first + blockIdx.x * G + grp; k < cnt; k += gridDim.x * G) {
+    const uint32_t it = tier == 2 ? over[k] : k;
     const ShapeDeferItem<T> item = items[it];
     if (split.tasks && bvh_moot<T>(split, item.parent, item.order)) continue;  // (group-uniform) an earlier contact ended the walk
     const uint32_t pair = item.seed.pair;
@@ -1060,7 +1077,13 @@ __global__ void __launch_bounds__(64) k_bvh_shape_finish(Work wk, LibView<T> lib
     if (solid.s.kind == K_CONVEX && solid.s.num_points <= uint32_t(HULL_MAX)) solid.h.load(solid.v, solid.s.num_points, lig);
     const Pose<T> tfs = load_pose(swapped ? io.tf1 : io.tf2, pair);
     V3<T> p1, p2, n, guess;
-    const T distance = mesh_shape_leaf_finish<T, LaneGroup<BS_W>>(item, tfs, solid, swept_radius(solid.s), q, &scratch[grp], p1, p2, n, guess);
+    bool done = true;
+    const T distance = mesh_shape_leaf_finish<T, LaneGroup<BS_W>, GroupSolid<T>, CAP>(item, tfs, solid, swept_radius(solid.s), q, &scratch[grp], p1, p2, n, guess, &done);
+    if (CAP != EPA_MAX_ITER && !done) {  // (group-uniform) to the full-capacity launch
+      if (lig == 0) over[atomicAdd(&wk.counts[CTR_SHAPE_FINISH_OVER + half], 1u)] = it;
+      LaneGroup<BS_W>::sync();
+      continue;
+    }
     if (lig == 0 && distance_mode) {
       // distance(): the walk ended at this leaf (every bound left on the stack is >= 0); DistanceResult::update
       T mind = item.bound;
@@ -1088,6 +1111,17 @@ __global__ void __launch_bounds__(64) k_bvh_shape_finish(Work wk, LibView<T> lib
   }
 }
 
+template <typename T>
+static void launch_shape_finish(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, const BvhSplit& split,
+                                int distance_mode, int range = 0) {
+  if (wk.shape_finish_over && q.epa_max_iterations > SHAPE_FINISH_FAST_CAP) {
+    hipLaunchKernelGGL((k_bvh_shape_finish<T, HFCL_BVH_PART, SHAPE_FINISH_FAST_CAP>), dim3(grid), dim3(64), 0, st, wk, lv, io, q, bp, split, distance_mode, 1, range);
+    hipLaunchKernelGGL((k_bvh_shape_finish<T, HFCL_BVH_PART, EPA_MAX_ITER>), dim3(std::max(1, grid / 4)), dim3(64), 0, st, wk, lv, io, q, bp, split, distance_mode, 2, range);
+  } else {
+    hipLaunchKernelGGL((k_bvh_shape_finish<T, HFCL_BVH_PART, EPA_MAX_ITER>), dim3(grid), dim3(64), 0, st, wk, lv, io, q, bp, split, distance_mode, 0, range);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // k_bvh_shape_coop: the long walks of a mesh x solid batch, ONE LANE GROUP PER QUERY, COOP_W entries of the stack at a time.
 // k_bvh_collide<SOLID> suspends a query after its step budget and leaves its stack (DFS order) and its state (bounds, witness)
@@ -1104,6 +1138,33 @@ __global__ void __launch_bounds__(64) k_bvh_shape_finish(Work wk, LibView<T> lib
 // record: no task levels, no fold-back.  A step of a lone lane costs ~2 us and a level of tasks its budget times that; a
 // trip of this kernel costs one step's latency for COOP_W of them.  Groups take the next suspended query as they finish.
 // ---------------------------------------------------------------------------------------
+// A walk's state is the same in every lane of its group; when the group is the wave (W == 64) it belongs in SGPRs, not in 64 copies
+// that stay live across the leaf's GJK (k_bvh_shape_coop<double>: 624 B/lane of scratch before, profiles/r05_f): wave_uniform() says so
+// to the compiler (v_readfirstlane), a no-op for narrower groups.
+template <int W>
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t x) {
+  if constexpr (W == 64) return uint32_t(__builtin_amdgcn_readfirstlane(int(x)));
+  return x;
+}
+template <int W>
+__device__ __forceinline__ int wave_uniform(int x) {
+  if constexpr (W == 64) return __builtin_amdgcn_readfirstlane(x);
+  return x;
+}
+template <int W>
+__device__ __forceinline__ float wave_uniform(float x) {
+  if constexpr (W == 64) return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+  return x;
+}
+template <int W>
+__device__ __forceinline__ double wave_uniform(double x) {
+  if constexpr (W == 64) return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+  return x;
+}
+template <int W, typename T>
+__device__ __forceinline__ V3<T> wave_uniform(const V3<T>& v) {
+  return mk<T>(wave_uniform<W>(v.x), wave_uniform<W>(v.y), wave_uniform<W>(v.z));
+}
 template <typename T, int W>
 __device__ __forceinline__ T group_min_excl_scan(T v, int lig, T identity) {  // exclusive prefix minimum over the lanes of a group
 #pragma unroll
@@ -1131,7 +1192,10 @@ __device__ __forceinline__ T group_min_all(T v) {
 #define HFCL_COOP_W 64
 #endif
 constexpr int COOP_W = HFCL_COOP_W;
-constexpr int COOP_CAP = 448, COOP_SLACK = 64;  // entries of a query's stack: a full stack narrows the window down to plain DFS, which needs the tree's depth more
+#ifndef HFCL_COOP_CAP
+#define HFCL_COOP_CAP 448
+#endif
+constexpr int COOP_CAP = HFCL_COOP_CAP, COOP_SLACK = 64;  // entries of a query's stack: a full stack narrows the window down to plain DFS, which needs the tree's depth more
 // What is known about a stack entry travels with it (two bits of the entry word + a value): a box found disjoint keeps its
 // bound, a triangle its distance -- its result does not depend on the walk's state (the leaf solver starts from the
 // request's guess).  A trip with a triangle in it costs a GJK run whatever the number of lanes that have one, so triangles
@@ -1148,7 +1212,7 @@ constexpr uint32_t COOP_NODE = 0x3FFFFFFFu, COOP_DISJOINT = 1u << 30, COOP_LEAF 
 // k_bvh_coop and their waves live, in clock ticks -- [0] longest walk, [1] sum over the walks, [2] walks, [3] longest wave, [4] sum over
 // the waves that had a walk, [5] their number, [6] walks cut -- read back by tools/coop_prof.py through hfcl_debug_coop_prof
 #ifdef HFCL_COOP_PROF
-__device__ unsigned long long coop_prof[16];
+__device__ unsigned long long coop_prof[24];
 #define COOP_WALK_END(first_lane, t_begin)                                                         \
   do {                                                                                             \
     if (first_lane) {                                                                              \
@@ -1175,15 +1239,29 @@ extern "C" int hfcl_debug_coop_prof(unsigned long long* out16, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(coop_prof), sizeof(coop_prof)) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[24] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(coop_prof), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;
 }
+#define COOP_PROF_DECL unsigned long long pf_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_ = 0
+#define COOP_PROF_T0 (pt_ = __builtin_readcyclecounter())
+#define COOP_PROF_ADD(k, x) (pf_[k] += (unsigned long long)(x))
+#define COOP_PROF_DT(k) (pf_[k] += __builtin_readcyclecounter() - pt_)
+#define COOP_PROF_FLUSH                                                 \
+  do {                                                                  \
+    if (threadIdx.x == 0)                                               \
+      for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&coop_prof[7 + k_], pf_[k_]); \
+  } while (0)
 #else
 #define COOP_WALK_END(first_lane, t_begin)
 #define COOP_WAVE_END(t_begin, n_walks)
 #define COOP_CUT_COUNT(first_lane)
+#define COOP_PROF_DECL
+#define COOP_PROF_T0
+#define COOP_PROF_ADD(k, x)
+#define COOP_PROF_DT(k)
+#define COOP_PROF_FLUSH
 #endif
 // Cutting a long walk (BvhSplit::cut_ticks).  A batch of 100 000 queries used to end with one wave on its longest walk (mesh x solid:
 // 1.7 of the kernel's 2.9 ms, the waves busy 54 % of the time; mesh x mesh: 79 %; profiles/r04_j).  A walk that has had its time is
@@ -1315,6 +1393,7 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
   unsigned n_walks = 0, trip_no = 0;
   (void)t_wave; (void)n_walks;
   bool swapped = false, overflow = false;
+  COOP_PROF_DECL;  // [0] trips [1] box-test ticks [2] boxes tested [3] leaf batches [4] their ticks [5] their lanes [6] ticks from the scans to the end of a trip that ends in a contact [7] ticks drawing and loading units
   DMesh m1 = {0, 0, 0, 0};
   ObbQuery<T> oq;
   oq.M.r0 = oq.M.r1 = oq.M.r2 = oq.V = oq.ext = mk<T>(T(0), T(0), T(0));
@@ -1330,6 +1409,7 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
   };
   for (;;) {
     if (!have && !exhausted) {
+      COOP_PROF_T0;
       const CoopUnit u = coop_draw<T, W>(split, ticket, level, unit0, n_units, lig, grp);
       exhausted = u.exhausted;
       if (u.take) {
@@ -1343,15 +1423,26 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       } else {
         s = *bvh_sum<T>(split, u.index);
       }
-      pair = u.pair;
-      unit = u.index;
-      my_parent = u.parent;
-      my_order = u.order;
-      const uint32_t id1 = wk.shape1[pair], id2 = wk.shape2[pair];
-      swapped = lib.kinds[id1] != uint8_t(K_BVH);
+      pair = wave_uniform<W>(u.pair);
+      unit = wave_uniform<W>(u.index);
+      my_parent = wave_uniform<W>(u.parent);
+      my_order = wave_uniform<W>(u.order);
+      const uint32_t id1 = wave_uniform<W>(wk.shape1[pair]), id2 = wave_uniform<W>(wk.shape2[pair]);
+      swapped = wave_uniform<W>(int(lib.kinds[id1] != uint8_t(K_BVH))) != 0;
       solid_id = swapped ? id1 : id2;
-      m1 = bv.meshes[lib.shapes[swapped ? id2 : id1].bvh_index];
-      oq = reinterpret_cast<const ObbQuery<T>*>(wk.shape_oq)[pair];
+      {
+        const DMesh mm = bv.meshes[wave_uniform<W>(lib.shapes[swapped ? id2 : id1].bvh_index)];
+        m1.node_off = wave_uniform<W>(mm.node_off);
+        m1.vert_off = wave_uniform<W>(mm.vert_off);
+        m1.tri_off = wave_uniform<W>(mm.tri_off);
+        m1.n_nodes = wave_uniform<W>(mm.n_nodes);
+        const ObbQuery<T> o = reinterpret_cast<const ObbQuery<T>*>(wk.shape_oq)[pair];
+        oq.M.r0 = wave_uniform<W>(o.M.r0);
+        oq.M.r1 = wave_uniform<W>(o.M.r1);
+        oq.M.r2 = wave_uniform<W>(o.M.r2);
+        oq.V = wave_uniform<W>(o.V);
+        oq.ext = wave_uniform<W>(o.ext);
+      }
       if (level) {  // the chunk's entries, with what is known about them
         for (uint32_t j = uint32_t(lig); j < s.n_child; j += uint32_t(W)) {
           stack[s.n_child - 1u - j] = split.cut_words[s.first_child + j];
@@ -1360,22 +1451,23 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       } else {
         for (uint32_t j = uint32_t(lig); j < s.n_child; j += uint32_t(W)) stack[s.n_child - 1u - j] = split.tasks[s.first_child + j].entry;  // child 0 on top
       }
-      sp = int(s.n_child);
-      dlb = s.dlb;
-      rec_dist = s.rec_dist;
-      cand_val = s.cand_val;
+      sp = wave_uniform<W>(int(s.n_child));
+      dlb = wave_uniform<W>(s.dlb);
+      rec_dist = wave_uniform<W>(s.rec_dist);
+      cand_val = wave_uniform<W>(s.cand_val);
       t_begin = __builtin_readcyclecounter();
       ++n_walks;
-      np1 = s.np1;
-      np2 = s.np2;
-      nn = s.nn;
+      np1 = wave_uniform<W>(s.np1);
+      np2 = wave_uniform<W>(s.np2);
+      nn = wave_uniform<W>(s.nn);
       fb = -1;
       ncontacts = 0;
-      overflow = (s.flags & BVH_SUM_OVERFLOW) != 0 || sp > COOP_CAP;
+      overflow = wave_uniform<W>(int((s.flags & BVH_SUM_OVERFLOW) != 0)) != 0 || sp > COOP_CAP;
       if (overflow) sp = 0;
-      guess0 = initial_guess<T>(io, q, pair);  // (walks whose leaves hand a cached guess on are not split)
+      guess0 = wave_uniform<W>(initial_guess<T>(io, q, pair));  // (walks whose leaves hand a cached guess on are not split)
       have = true;
       }
+      COOP_PROF_DT(7);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1405,10 +1497,13 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       const DNode<T>* const np = bv.nodes + m1.node_off + e;
       int32_t fc = 0;
       bool overlap = false, pending = false;
+      COOP_PROF_ADD(0, 1);
+      COOP_PROF_ADD(2, __popcll(__ballot(act && tag == 0u)));
+      COOP_PROF_T0;
       if (act && tag == 0u) {
-        fc = np->first_child;
+        const DNode<T> n1 = *np;  // (the whole record at once: a leaf's box is read for nothing, an inner node's not a latency later)
+        fc = n1.first_child;
         if (fc >= 0) {
-          const DNode<T> n1 = *np;
           T sq;
           if (obb_disjoint_q(oq, n1, q.security_margin, break_distance2, sq)) {
             val = hsqrt(sq);
@@ -1420,6 +1515,7 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
           pending = true;
         }
       }
+      COOP_PROF_DT(1);
       // (2) the triangles, when enough of them wait or the window has nothing left to split
       SolidLeafOut<T> lo;
       lo.distance = big;
@@ -1427,6 +1523,9 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       {
         const uint64_t pmask = gballot(pending);
         if (pmask && (__popcll(pmask) >= HFCL_COOP_LEAF_BATCH || !gballot(overlap))) {
+          COOP_PROF_ADD(3, 1);
+          COOP_PROF_ADD(5, __popcll(pmask));
+          COOP_PROF_T0;
           if (pending) {
             const bool to_epa = run_leaf(uint32_t(-(fc + 1)), false, &lo);
             val = lo.distance;
@@ -1434,10 +1533,12 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
             pending = false;
             fresh = true;
           }
+          COOP_PROF_DT(4);
         }
       }
       // (3) what an entry does to the walk's state depends on everything before it in DFS order -- which includes the subtrees of
       // overlapping boxes and the triangles still waiting ahead of it: the entries in front of the first of those are visited now
+      COOP_PROF_T0;
       const uint64_t block = gballot(overlap || pending);
       const int f = block ? __ffsll((unsigned long long)block) - 1 : W;
       bool visit = act && lig < f;
@@ -1466,15 +1567,17 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       if (gballot(lowered)) {
         // the bound ends at the minimum of the visited entries, set by the first of them that reaches it
         const int src = __ffsll((unsigned long long)gballot(visit && bnd == wmin)) - 1;
-        dlb = wmin;
-        rec_dist = __shfl(recv, src, W);
+        dlb = wave_uniform<W>(wmin);
+        rec_dist = wave_uniform<W>(__shfl(recv, src, W));
       }
       // the witness: the last triangle that lowered the bound on its visit (its points, if it was evaluated in an earlier trip,
       // by running its leaf once more); the contact's points likewise
       const uint64_t wmask = gballot(lowered && tag == COOP_LEAF);
       const int L = wmask ? 63 - __clzll((unsigned long long)wmask) : -1;
-      if (L >= 0) cand_val = __shfl(bnd, L, W);
+      if (L >= 0) cand_val = wave_uniform<W>(__shfl(bnd, L, W));
       const bool is_contact_lane = c < W && lig == c;
+      COOP_PROF_DT(8);
+      COOP_PROF_T0;
       if (act && is_leaf && !fresh && ((lig == L) || (is_contact_lane && tag == COOP_LEAF && bp.contacts))) {
         fc = np->first_child;
         run_leaf(uint32_t(-(fc + 1)), false, &lo);
@@ -1486,14 +1589,14 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
         const V3<T> b2 = mk<T>(__shfl(a2.x, Ls, W), __shfl(a2.y, Ls, W), __shfl(a2.z, Ls, W));
         const V3<T> bn = mk<T>(__shfl(an.x, Ls, W), __shfl(an.y, Ls, W), __shfl(an.z, Ls, W));
         if (L >= 0) {
-          np1 = b1;
-          np2 = b2;
-          nn = bn;
+          np1 = wave_uniform<W>(b1);
+          np2 = wave_uniform<W>(b2);
+          nn = wave_uniform<W>(bn);
         }
       }
       if (c < W) {  // canStop()
         if (act && is_leaf && fc == 0) fc = np->first_child;
-        const int prim_c = __shfl(int(-(fc + 1)), c, W);
+        const int prim_c = wave_uniform<W>(__shfl(int(-(fc + 1)), c, W));
         fb = prim_c;
         ncontacts = 1;
         bool lost = false;
@@ -1510,9 +1613,12 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
         // a contact whose item found it full says so in its record instead of keeping a depth nobody computed)
         if (gballot(lost)) overflow = true;
         sp = 0;
+        COOP_PROF_DT(6);
       } else {
         // (4) the stack again, in order (entry 0's successors on top): visited entries are gone, an overlapping box is its two
         // children (left above right), everything else stays with what is known about it
+        COOP_PROF_DT(9);  // (the witness part of a trip without a contact)
+        COOP_PROF_T0;
         const int cnt = !act || lig < f ? 0 : (overlap ? 2 : 1);
         const uint64_t m2 = gballot(cnt == 2), m1b = gballot(cnt == 1);
         const uint64_t deeper = ~((uint64_t(2) << lig) - 1);  // window entries behind this one (pushed first)
@@ -1531,6 +1637,9 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
         }
       }
       done = sp == 0;
+      if (done) COOP_PROF_T0; else COOP_PROF_DT(10);
+      // (cutting sooner once the launch's ticket has run out -- nothing left to draw, idle slots waiting -- was measured: 3.10 -> 5.9 / 7.2 / 8.0 ms
+      // with 150k / 80k / 40k ticks: the three launches are all the levels there are, and what the early cuts leave for the last one is long)
       if (cut_ticks && sp > COOP_CHUNK && __builtin_readcyclecounter() - t_begin > cut_ticks) {
         // ---- the walk has had its time: what is left of it becomes chunks for the next launch (coop_cut)
         if (coop_cut<T, W>(split, level ? split.n_queries + unit0 + unit : unit, pair, my_parent, my_order, stack, value, sp, lig, dlb, rec_dist, cand_val,
@@ -1570,8 +1679,10 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       }
       COOP_WALK_END(lig == 0, t_begin);
       have = false;
+      COOP_PROF_DT(11);
     }
   }
+  COOP_PROF_FLUSH;
   COOP_WAVE_END(t_wave, n_walks);
 }
 
@@ -2569,12 +2680,14 @@ static void launch_collide_kernel(bool wide, int grid, hipStream_t st, const Wor
 // The continuation of the suspended queries by k_bvh_coop / k_bvh_shape_coop: one launch, or -- BvhSplit::cut_ticks -- three, the second and
 // third walking the chunks the launch before cut its long walks into (levels 2 and 3 of the task table: k_bvh_level_mark files the
 // tasks made so far under ctr[LEVEL0 + level + 1] and resets the ticket), and the fold-back of the chunks' summaries.
-template <typename T, class Launch>
-static void launch_coop_levels(int grid, hipStream_t st, const Work& wk, const IO<T>& io, BvhSplit s, int ticket, Launch&& launch) {
+// after_first (optional): called once the mark behind the first launch is in the stream -- returns false when there is no such mark (no cutting)
+template <typename T, class Launch, class AfterFirst>
+static bool launch_coop_levels(int grid, hipStream_t st, const Work& wk, const IO<T>& io, BvhSplit s, int ticket, Launch&& launch, AfterFirst&& after_first) {
   const bool cutting = s.cut_ticks != 0 && s.cut_words != nullptr;
   s.level = 0;
   for (uint32_t l = 0; l < (cutting ? 3u : 1u); ++l) {
     hipLaunchKernelGGL(k_bvh_level_mark, dim3(1), dim3(64), 0, st, wk, s, ticket);
+    if (l == 1) after_first();
     s.level = l ? l + 1 : 0u;  // launch 0: the suspended queries; launches 1, 2: the chunks of the launch before
     s.can_suspend = cutting && l < 2 ? 1u : 0u;
     launch(s);
@@ -2586,6 +2699,11 @@ static void launch_coop_levels(int grid, hipStream_t st, const Work& wk, const I
     s.level = 0;
     hipLaunchKernelGGL((k_bvh_combine<T>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, io, s);
   }
+  return cutting;
+}
+template <typename T, class Launch>
+static void launch_coop_levels(int grid, hipStream_t st, const Work& wk, const IO<T>& io, BvhSplit s, int ticket, Launch&& launch) {
+  launch_coop_levels<T>(grid, st, wk, io, s, ticket, launch, [] {});
 }
 template <typename T>
 void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill, bool solid) {
@@ -2656,13 +2774,13 @@ void launch_bvh_shape_distance_fast(int grid, int grid_finish, hipStream_t st, c
   memset(&none, 0, sizeof(none));
   BvhParams bp;
   memset(&bp, 0, sizeof(bp));
-  hipLaunchKernelGGL((k_bvh_shape_finish<T>), dim3(grid_finish), dim3(64), 0, st, wk, lv, io, q, bp, none, 1);
+  launch_shape_finish<T>(grid_finish, st, wk, lv, io, q, bp, none, 1);
 }
 #endif
 #if HFCL_BVH_COLLIDE_PART
 // mesh x solid collide(), one query per lane: the solids' OBBs, the walk (split as `split` says), the EPA leaves
 template <typename T>
-void launch_bvh_shape_fast(int grid, int grid_finish, int coop_grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill) {
+void launch_bvh_shape_fast(int grid, int grid_finish, int coop_grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill, const AsideStream* aside) {
   hipLaunchKernelGGL((k_shape_obb<T>), dim3(std::max(1, grid / 2)), dim3(256), 0, st, wk, lv, io);
   spill.wide = 0;
   spill.slab = nullptr;
@@ -2675,19 +2793,30 @@ void launch_bvh_shape_fast(int grid, int grid_finish, int coop_grid, hipStream_t
     s0.budget = split.budget0;
     s0.can_suspend = 1;
     launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s0, spill, true);
-    launch_coop_levels<T>(grid, st, wk, io, s0, int(CTR_SHAPE_TICKET), [&](const BvhSplit& s) {
-      hipLaunchKernelGGL((k_bvh_shape_coop<T>), dim3(coop_grid), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2, s);
-    });
     // (the EPA item of a chunk that stands behind another chunk's contact is skipped: bvh_moot over the summaries; items of whole walks
     // hang under no summary)
     BvhSplit fin = s0;
     fin.level = 0;
-    hipLaunchKernelGGL((k_bvh_shape_finish<T>), dim3(grid_finish), dim3(64), 0, st, wk, lv, io, q, bp, fin, 0);
+    // The items of whole walks -- all that k_bvh_collide<SOLID> and the first launch of k_bvh_shape_coop queue -- are final when that launch
+    // ends: their EPA runs on the helper stream beside the two launches that walk the chunks (few waves, as long as their longest chains:
+    // 0.54 ms of cfg4s's 3.45, and k_bvh_shape_finish another 0.52 behind them before; profiles/r05_f).
+    bool forked = false;
+    const bool cut = launch_coop_levels<T>(grid, st, wk, io, s0, int(CTR_SHAPE_TICKET), [&](const BvhSplit& s) {
+      hipLaunchKernelGGL((k_bvh_shape_coop<T>), dim3(coop_grid), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2, s);
+    }, [&] {
+      if (!aside || !wk.shape_finish_over) return;
+      if (hipEventRecord(aside->fork, st) != hipSuccess || hipStreamWaitEvent(aside->stream, aside->fork, 0) != hipSuccess) return;
+      launch_shape_finish<T>(grid_finish, aside->stream, wk, lv, io, q, bp, fin, 0, 1);
+      forked = hipEventRecord(aside->join, aside->stream) == hipSuccess;
+    });
+    (void)cut;
+    launch_shape_finish<T>(grid_finish, st, wk, lv, io, q, bp, fin, 0, forked ? 2 : 0);
+    if (forked) hipStreamWaitEvent(st, aside->join, 0);
     return;
   }
   launch_bvh_collide<T>(grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill, true);
   split.level = 0;
-  hipLaunchKernelGGL((k_bvh_shape_finish<T>), dim3(grid_finish), dim3(64), 0, st, wk, lv, io, q, bp, split, 0);
+  launch_shape_finish<T>(grid_finish, st, wk, lv, io, q, bp, split, 0);
 }
 #endif
 #if HFCL_BVH_DISTANCE_PART
@@ -2706,7 +2835,7 @@ void launch_triangle(int grid, hipStream_t st, const Work& wk, const LibView<T>&
 #define HFCL_INST(T)                                                                                                             \
   template void launch_bvh_collide<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill, bool); \
   template void launch_bvh_shape<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T);   \
-  template void launch_bvh_shape_fast<T>(int, int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill); \
+  template void launch_bvh_shape_fast<T>(int, int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill, const AsideStream*); \
   template void launch_triangle<T>(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&);
 HFCL_INST(float)
 HFCL_INST(double)
