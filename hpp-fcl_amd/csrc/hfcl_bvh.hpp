@@ -592,6 +592,33 @@ HFCL_HD T rss_lower_bound(const M3<T>& R0, const V3<T>& T0, const DNode<T>& n1, 
   return d < T(0) ? T(0) : d;
 }
 
+// A cheap lower bound of rss_lower_bound(): the separation of the two swept rectangles along three directions -- the normal of rectangle 1, the
+// normal of rectangle 2, the line through the two centres -- in the frame of rectangle 1 (R, Tv as rect_distance takes them: rectangle 1 spans
+// [0, l0] x [0, l1] in the plane z = 0, rectangle 2 has its corner at Tv and its sides m0, m1 along the columns 0 and 1 of R), less a slack
+// of 1e-9 of the lengths involved (fp64: seven orders above the rounding of either computation).  The distance of two convex sets is at least their
+// separation along any direction, so a pair whose bound already exceeds the walk's minimum is one the reference prunes too (canStop), whatever
+// the exact value: its rectDistance need not run.  On cfg4d's walks this decides 30 % of all tests, 70 % of those the exact value prunes at
+// that moment, and never exceeds the exact distance (13 M tests, tools/bound_probe.cpp).
+template <typename T>
+HFCL_HD T rss_cheap_bound(const M3<T>& R, const V3<T>& Tv, T l0, T l1, T m0, T m1, T rsum) {
+  const T h0 = T(0.5) * l0, h1 = T(0.5) * l1, g0 = T(0.5) * m0, g1 = T(0.5) * m1;
+  const T cx = Tv.x + R.r0.x * g0 + R.r0.y * g1 - h0, cy = Tv.y + R.r1.x * g0 + R.r1.y * g1 - h1, cz = Tv.z + R.r2.x * g0 + R.r2.y * g1;
+  const T gap1 = habs(cz) - (g0 * habs(R.r2.x) + g1 * habs(R.r2.y));
+  const T gap2 = habs(cx * R.r0.z + cy * R.r1.z + cz * R.r2.z) - (h0 * habs(R.r0.z) + h1 * habs(R.r1.z));
+  const T L2 = cx * cx + cy * cy + cz * cz;
+  const T L = hsqrt(L2);
+  const T e = h0 * habs(cx) + h1 * habs(cy) + g0 * habs(R.r0.x * cx + R.r1.x * cy + R.r2.x * cz) + g1 * habs(R.r0.y * cx + R.r1.y * cy + R.r2.y * cz);
+  const T gap3 = L > T(0) ? L - e / L : T(-1);
+  const T lb = hmax(gap1, hmax(gap2, gap3)) - rsum;
+  return lb - T(sizeof(T) == 4 ? 1e-5 : 1e-9) * (L + h0 + h1 + g0 + g1 + rsum);  // (fp32: two orders above ITS rounding)
+}
+template <typename T>
+HFCL_HD T rss_cheap_bound(const M3<T>& R0, const V3<T>& T0, const DNodeD<T>& n1, const DNodeD<T>& n2) {
+  const M3<T> R = tmul(n1.axes, mmul(R0, n2.axes));
+  const V3<T> Tv = tmul(n1.axes, mul(R0, n2.Tr) + T0 - n1.Tr);
+  return rss_cheap_bound(R, Tv, n1.l0, n1.l1, n2.l0, n2.l1, n1.r + n2.r);
+}
+
 template <typename T>
 HFCL_HD T rss_lower_bound(const M3<T>& R0, const V3<T>& T0, const DNodeD<T>& n1, const DNodeD<T>& n2) {
   const M3<T> R = tmul(n1.axes, mmul(R0, n2.axes));

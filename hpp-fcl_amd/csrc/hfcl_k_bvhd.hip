@@ -471,6 +471,18 @@ constexpr int POOL_BIG_BATCH = 400000;  // queries from which a wave takes 8 wal
 #define HFCL_POOL_ROUNDS 2
 #endif
 constexpr int POOL_ROUNDS = HFCL_POOL_ROUNDS, POOL_TESTS = 64 * POOL_ROUNDS;  // child tests of a trip: full rounds of 64
+// HFCL_POOL_CHEAP (variant builds; default 0): a trip first puts rss_cheap_bound() to its candidate tests -- up to POOL_CAND of them, a round more
+// than it runs exactly -- and only those the bound does not decide go through rectDistance, packed into full rounds again (hfcl_bvh.hpp: the pairs
+// it decides are pairs the exact value would drop as well, so the walk is the same).  Exact, and decides 30 % of the tests, but the pass that
+// forms the bounds reads both nodes and multiplies the frames as the exact test does: cfg4d 25.4 -> 30.9 ms alone, 21.5 -> 25.6 ms on top of
+// HFCL_POOL_DROP_DEAD (profiles/r05_g).
+#ifndef HFCL_POOL_CHEAP
+#define HFCL_POOL_CHEAP 0
+#endif
+constexpr int POOL_CAND = HFCL_POOL_CHEAP ? 64 * (POOL_ROUNDS + 1) : POOL_TESTS;
+#ifndef HFCL_POOL_DROP_DEAD
+#define HFCL_POOL_DROP_DEAD 1
+#endif
 constexpr uint32_t POOL_MAX_NODES = 32767;
 
 // A stack entry is ONE 32-bit word next to its bound -- what the next trip needs to know about the node pair (n1, n2):
@@ -520,9 +532,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
   __shared__ uint32_t q_noff[Q][2];  // node_off of the slot's two models
   __shared__ uint32_t q_off[Q][4];  // vert_off, tri_off of the slot's two models (the lane that evaluates a triangle pair may belong to another slot)
   __shared__ int q_win[Q];          // index in the triangle list of the pair that set the slot's minimum in this trip (-1: none)
-  __shared__ uint32_t t_n1[POOL_TESTS], t_n2[POOL_TESTS], t_x[POOL_TESTS];
-  __shared__ uint8_t t_q[POOL_TESTS];
-  __shared__ T t_res[POOL_TESTS];
+  __shared__ uint32_t t_n1[POOL_CAND], t_n2[POOL_CAND], t_x[POOL_CAND];
+  __shared__ uint8_t t_q[POOL_CAND];
+  __shared__ uint8_t t_live[POOL_CAND];  // the candidates rss_cheap_bound left undecided, in order
+  __shared__ T t_res[POOL_CAND];
+  __shared__ T q_bar[Q];  // what a bound must exceed to be dropped wherever its entry stands: the slot's minimum + margin
   __shared__ uint32_t l_x[64];  // the triangle pairs evaluated in this trip (at most one per lane): the entry's info word ...
   __shared__ uint8_t l_q[64];   // ... and its slot
   __shared__ T l_val[64];
@@ -656,8 +670,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
     const bool up = (trip & 1u) == 0u;
     ++trip;
     const int t_all = 2 * ns;
-    int t_run = min(t_all, 64 * POOL_ROUNDS);
-    if (t_run > 64 && (t_run & 63) != 0 && (t_run & 63) < part_min) t_run &= ~63;
+    int t_run = min(t_all, POOL_CAND);
+    if (!HFCL_POOL_CHEAP && t_run > 64 && (t_run & 63) != 0 && (t_run & 63) < part_min) t_run &= ~63;
+    if (HFCL_POOL_CHEAP && j == 0) q_bar[q] = mind + margin;
     int k2[E];
     {
       int k = lane_sum(ns_l, up ? lt_mask : ~((uint64_t(2) << lane) - 1));
@@ -687,11 +702,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
     sync();
     POOL_T(0);
     POOL_C(8, 1);
-    POOL_C(10, t_run);
-    for (int tb = 0; tb < t_run; tb += 64) {
+        int n_live = t_run;
+    if constexpr (HFCL_POOL_CHEAP != 0) {
+      // the cheap bound on every candidate; the undecided ones listed in order (t_live), marked -1 until their exact value is there
+      n_live = 0;
+      for (int tb = 0; tb < t_run; tb += 64) {
+        const int t = tb + lane;
+        bool live = false;
+        if (t < t_run) {
+          const uint32_t ts = t_q[t];
+          const T* const rt = q_rt[ts];
+          M3<T> R0;
+          R0.r0 = mk<T>(rt[0], rt[1], rt[2]);
+          R0.r1 = mk<T>(rt[3], rt[4], rt[5]);
+          R0.r2 = mk<T>(rt[6], rt[7], rt[8]);
+          const V3<T> T0 = mk<T>(rt[9], rt[10], rt[11]);
+          const DNodeD<T> A = bv.dnodes[q_noff[ts][0] + t_n1[t]], B = bv.dnodes[q_noff[ts][1] + t_n2[t]];
+          live = !(rss_cheap_bound(R0, T0, A, B) > q_bar[ts]);
+          t_res[t] = live ? T(-1) : big;  // (a bound of `big` is dropped wherever the entry stands)
+          t_x[t] = 0u;
+        }
+        const uint64_t lm = __ballot(live);
+        if (live) t_live[n_live + __popcll(lm & lt_mask)] = uint8_t(t);
+        n_live += __popcll(lm);
+      }
+      POOL_C(14, t_run - n_live);
+      sync();
+      // full rounds of the undecided ones (and a last partial one when it is the only one or fills `part_min` lanes); the rest keep their mark
+      if (n_live > 64 * POOL_ROUNDS) n_live = 64 * POOL_ROUNDS;
+      if (n_live > 64 && (n_live & 63) != 0 && (n_live & 63) < part_min) n_live &= ~63;
+    }
+    POOL_C(10, n_live);
+    for (int tb = 0; tb < n_live; tb += 64) {
       POOL_C(9, 1);
-      const int t = tb + lane;
-      if (t < t_run) {
+      if (tb + lane < n_live) {
+        const int t = HFCL_POOL_CHEAP ? int(t_live[tb + lane]) : tb + lane;
         const uint32_t ts = t_q[t];
         const T* const rt = q_rt[ts];
         M3<T> R0;
@@ -717,6 +762,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
         d2[u] = t_res[k2[u] + 1];
         xa[u] = t_x[k2[u]];
         xc[u] = t_x[k2[u] + 1];
+        if (HFCL_POOL_CHEAP && (d1[u] < T(0) || d2[u] < T(0))) {  // a child's exact test did not fit into this trip's rounds: the entry stays as it is
+          split[u] = false;
+          held[u] = true;
+        }
       }
     }
     POOL_T(1);
@@ -813,24 +862,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
     }
     POOL_T(2);
     // ---- the windows written back, in order: deeper entries first, a split pair as its two children (nearer one on top)
+    // (HFCL_POOL_DROP_DEAD, default 1) A child whose bound cannot beat the minimum any more is not written at all: the test is the one the
+    // next trip would put to it at the head of its window -- with this trip's minimum, and behind the pair of the minimum exactly when its
+    // parent is --, so the walk is the same and the windows hold live entries only.
     int cnt[E], cnt_l = 0, later_l = 0;
+    bool keep_a[E], keep_c[E];
 #pragma unroll
     for (int u = 0; u < E; ++u) {
-      cnt[u] = split[u] ? 2 : (((is_leaf[u] && !leaf_eval[u]) || held[u]) ? 1 : 0);
-      cnt_l += cnt[u];
       const bool later = (j * E + u) < w && (jw >= 0 ? (j * E + u) > jw : idx[u] < p);  // stands behind the pair of the minimum
+      keep_a[u] = keep_c[u] = split[u];
+#if HFCL_POOL_DROP_DEAD
+      if (split[u]) {
+        keep_a[u] = !(later ? d1[u] >= mind : d1[u] > mind + margin);
+        keep_c[u] = !(later ? d2[u] >= mind : d2[u] > mind + margin);
+      }
+#endif
+      cnt[u] = split[u] ? (keep_a[u] ? 1 : 0) + (keep_c[u] ? 1 : 0) : (((is_leaf[u] && !leaf_eval[u]) || held[u]) ? 1 : 0);
+      cnt_l += cnt[u];
       later_l += later ? cnt[u] : 0;
     }
     {
       int pos = base_i + lane_sum(cnt_l, deeper);
 #pragma unroll
       for (int u = E - 1; u >= 0; --u) {
-        if (cnt[u] == 2) {
-          const bool c_first = d2[u] < d1[u];  // visit (c1, c2) first when it is strictly nearer
-          st_x[q][pos] = c_first ? xa[u] : xc[u];
-          st_d[q][pos] = c_first ? d1[u] : d2[u];
-          st_x[q][pos + 1] = c_first ? xc[u] : xa[u];
-          st_d[q][pos + 1] = c_first ? d2[u] : d1[u];
+        if (split[u]) {
+          const bool c_first = d2[u] < d1[u];  // visit (c1, c2) first when it is strictly nearer: the other one lies deeper
+          int at = pos;
+          if (c_first ? keep_a[u] : keep_c[u]) {
+            st_x[q][at] = c_first ? xa[u] : xc[u];
+            st_d[q][at] = c_first ? d1[u] : d2[u];
+            ++at;
+          }
+          if (c_first ? keep_c[u] : keep_a[u]) {
+            st_x[q][at] = c_first ? xc[u] : xa[u];
+            st_d[q][at] = c_first ? d2[u] : d1[u];
+          }
         } else if (cnt[u] == 1) {
           st_x[q][pos] = x[u];
           st_d[q][pos] = db[u];
