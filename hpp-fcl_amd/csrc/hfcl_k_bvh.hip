@@ -1212,7 +1212,7 @@ constexpr uint32_t COOP_NODE = 0x3FFFFFFFu, COOP_DISJOINT = 1u << 30, COOP_LEAF 
 // k_bvh_coop and their waves live, in clock ticks -- [0] longest walk, [1] sum over the walks, [2] walks, [3] longest wave, [4] sum over
 // the waves that had a walk, [5] their number, [6] walks cut -- read back by tools/coop_prof.py through hfcl_debug_coop_prof
 #ifdef HFCL_COOP_PROF
-__device__ unsigned long long coop_prof[24];
+__device__ unsigned long long coop_prof[32];
 #define COOP_WALK_END(first_lane, t_begin)                                                         \
   do {                                                                                             \
     if (first_lane) {                                                                              \
@@ -1239,19 +1239,19 @@ extern "C" int hfcl_debug_coop_prof(unsigned long long* out16, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(coop_prof), sizeof(coop_prof)) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[24] = {0};
+    unsigned long long z[32] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(coop_prof), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;
 }
-#define COOP_PROF_DECL unsigned long long pf_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_ = 0
+#define COOP_PROF_DECL unsigned long long pf_[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_ = 0
 #define COOP_PROF_T0 (pt_ = __builtin_readcyclecounter())
 #define COOP_PROF_ADD(k, x) (pf_[k] += (unsigned long long)(x))
 #define COOP_PROF_DT(k) (pf_[k] += __builtin_readcyclecounter() - pt_)
 #define COOP_PROF_FLUSH                                                 \
   do {                                                                  \
     if (threadIdx.x == 0)                                               \
-      for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&coop_prof[7 + k_], pf_[k_]); \
+      for (int k_ = 0; k_ < 18; ++k_) atomicAdd(&coop_prof[7 + k_], pf_[k_]); \
   } while (0)
 #else
 #define COOP_WALK_END(first_lane, t_begin)
@@ -1499,6 +1499,10 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       bool overlap = false, pending = false;
       COOP_PROF_ADD(0, 1);
       COOP_PROF_ADD(2, __popcll(__ballot(act && tag == 0u)));
+      COOP_PROF_ADD(12, __popcll(__ballot(act)));                          // window entries
+      COOP_PROF_ADD(13, __popcll(__ballot(act && tag == COOP_DISJOINT)));  // ... boxes found disjoint, waiting for their visit
+      COOP_PROF_ADD(14, __popcll(__ballot(act && (tag == COOP_LEAF || tag == COOP_LEAF_EPA))));  // ... evaluated triangles, waiting
+      COOP_PROF_ADD(15, sp + w);                                           // stack depth
       COOP_PROF_T0;
       if (act && tag == 0u) {
         const DNode<T> n1 = *np;  // (the whole record at once: a leaf's box is read for nothing, an inner node's not a latency later)
@@ -1541,6 +1545,8 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       COOP_PROF_T0;
       const uint64_t block = gballot(overlap || pending);
       const int f = block ? __ffsll((unsigned long long)block) - 1 : W;
+      COOP_PROF_ADD(16, __popcll(gballot(pending)));  // unevaluated triangles left waiting for a batch
+      COOP_PROF_ADD(17, min(f, w));                   // entries visited
       bool visit = act && lig < f;
       const bool is_leaf = tag == COOP_LEAF || tag == COOP_LEAF_EPA;
       T bnd = big, recv = big;  // what this entry sets the bound to, and the recorded distance that goes with it

@@ -21,7 +21,7 @@ print("knobs:", {k: x for k, x in os.environ.items() if k.startswith("HFCL_") an
 for kind in kinds:
     b = wl.cfg4_mesh_mesh(n=n, seed=1) if kind == "mesh" else wl.mesh_vs_solid(kind, n=n, seg=50)
     lib = wl.make_library(pkg, b)
-    out = (C.c_ulonglong * 24)()
+    out = (C.c_ulonglong * 32)()
     lib.collide(b.s1, b.s2, b.tf1, b.tf2)
     dll.hfcl_debug_coop_prof(out, 1)
     lib.collide(b.s1, b.s2, b.tf1, b.tf2)
@@ -35,4 +35,6 @@ for kind in kinds:
                   v[7], v[7] / max(v[2], 1), v[9] / v[7], v[8] / v[7], v[10], v[10] / v[7], v[12] / max(v[10], 1), v[11] / max(v[10], 1),
                   v[8] / v[4], v[11] / v[4], v[13] / v[4], v[14] / v[4]))
         print("           scans %.2f, witness part %.2f, stack rewrite %.2f, the query's record %.2f" % (v[15] / v[4], v[16] / v[4], v[17] / v[4], v[18] / v[4]))
+        print("           per trip: window %.1f entries of a stack of %.1f: %.1f fresh boxes, %.1f disjoint boxes waiting, %.1f evaluated triangles waiting, %.1f triangles "
+              "waiting for a batch; %.1f entries visited" % (v[19] / v[7], v[22] / v[7], v[9] / v[7] - v[23] / v[7], v[20] / v[7], v[21] / v[7], v[23] / v[7], v[24] / v[7]))
     lib.close()
