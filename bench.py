@@ -380,33 +380,41 @@ def cpu_baseline(ctx, workload, batch, req, sample, budget_s, all_cores=True):
     return out
 
 
-def host_boundary(pkg, lib, batch, req, device_records):
-    """hfcl_collide_batch / hfcl_distance_batch on pageable host arrays: queries/s, and the time against what the link
-    admits (inputs in, records out, both directions at once)."""
+def host_boundary(pkg, lib, batch, req, device_records, f32=False):
+    """hfcl_collide_batch / hfcl_distance_batch (f32: hfcl_*_batch_f32, 7-float poses and 44-byte records) on pageable host arrays:
+    queries/s, and the time against what the link admits (inputs in, records out, both directions at once)."""
     import ctypes as C
     abi = pkg.abi
     n = len(batch)
     dll = pkg.engine.dll()
-    cfn = dll.hfcl_distance_batch if batch.kind == "distance" else dll.hfcl_collide_batch
     s1, s2 = batch.s1.astype(np.uint32), batch.s2.astype(np.uint32)
-    tf1, tf2 = np.ascontiguousarray(batch.tf1), np.ascontiguousarray(batch.tf2)
-    out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    if f32:
+        cfn = dll.hfcl_distance_batch_f32 if batch.kind == "distance" else dll.hfcl_collide_batch_f32
+        tf1, tf2 = np.ascontiguousarray(batch.pose1_f32), np.ascontiguousarray(batch.pose2_f32)
+        out = np.zeros(n, dtype=abi.RESULT_F32_DTYPE)
+    else:
+        cfn = dll.hfcl_distance_batch if batch.kind == "distance" else dll.hfcl_collide_batch
+        tf1, tf2 = np.ascontiguousarray(batch.tf1), np.ascontiguousarray(batch.tf2)
+        out = np.zeros(n, dtype=abi.RESULT_DTYPE)
     out[:] = out  # touched: first-touch page faults of a fresh array are the allocator's, not the link's
     ts = []
     for _ in range(5):
         t1 = time.perf_counter()
-        rc = cfn(lib._h, abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1), abi.ptr(tf2), C.c_size_t(n), C.byref(req), abi.ptr(out), None, None)
+        if f32:
+            rc = cfn(lib._h, abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1), abi.ptr(tf2), C.c_size_t(n), C.byref(req), abi.ptr(out))
+        else:
+            rc = cfn(lib._h, abi.ptr(s1), abi.ptr(s2), abi.ptr(tf1), abi.ptr(tf2), C.c_size_t(n), C.byref(req), abi.ptr(out), None, None)
         ts.append(time.perf_counter() - t1)
         assert rc == 0, pkg.engine.last_error()
     t_h = min(ts[1:])
-    b_in, b_out = 8 + 192, 96
+    b_in, b_out = (8 + 56, 44) if f32 else (8 + 192, 96)
     bound_s = max(n * b_in / (LINK_H2D_GBS * 1e9), n * b_out / (LINK_D2H_GBS * 1e9), n * (b_in + b_out) / (LINK_BOTH_GBS * 1e9))
     r = {"pairs": n, "value": n / t_h, "unit": "queries/s", "ms_per_call": 1e3 * t_h, "ms_first_call": 1e3 * ts[0],
          "bytes_in_per_pair": b_in, "bytes_out_per_pair": b_out,
          "link_GBps_measured": {"h2d": LINK_H2D_GBS, "d2h": LINK_D2H_GBS, "both_directions_total": LINK_BOTH_GBS},
          "link_bound_ms": 1e3 * bound_s, "frac_of_link_bound": bound_s / t_h,
-         "note": "hfcl_%s_batch on pageable host arrays: chunked H2D | kernels | D2H pipeline; PCIe inclusive; best of 4 calls on "
-                 "the same arrays (the first call on fresh arrays also pays the pinning of their pages: ms_first_call)" % batch.kind}
+         "note": "hfcl_%s_batch%s on pageable host arrays: chunked H2D | kernels | D2H pipeline; PCIe inclusive; best of 4 calls on "
+                 "the same arrays (the first call on fresh arrays also pays the pinning of their pages: ms_first_call)" % (batch.kind, "_f32" if f32 else "")}
     if device_records is not None:
         r["records_identical_to_device_path"] = bool(np.array_equal(out.view(np.int32), device_records.view(np.int32)))
     return r
@@ -653,10 +661,10 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
                        "lane_group_width": os.environ.get("HFCL_CVX_W", "auto (2; fp64 convex-convex 4)")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        if host_buffers and dtype == "f64" and ctx.world == 1:
+        if host_buffers and ctx.world == 1:
             # the same batch through the host-buffer boundary (what a hpp::fcl::collide()/distance() caller gets):
             # PCIe inclusive, never the headline value
-            result["host_buffers"] = host_boundary(pkg, lib, batch, req, res)
+            result["host_buffers"] = host_boundary(pkg, lib, batch, req, res, f32=(dtype == "f32"))
             if workload == "cfg2":  # ... and at a quarter / four times the size
                 result["host_buffers"]["other_sizes"] = [
                     host_boundary(pkg, lib, wl.cfg2_box_capsule(n=m, seed=1 + ctx.rank), req, None) for m in (250_000, 4_000_000)]
@@ -713,7 +721,7 @@ def main():
     headline_wl = args.workload or "cfg3"
     strong = args.scaling == "strong"
     head = run_workload(ctx, headline_wl, args.pairs, args.steps, args.warmup, strong=strong,
-                        cpu_budget_s=10.0, cpu_sample=args.cpu_sample, host_buffers=args.host_buffers,
+                        cpu_budget_s=10.0, cpu_sample=args.cpu_sample, host_buffers=args.host_buffers or args.workload is None,  # (the default line: the headline's PCIe-inclusive rate beside it, never `value`)
                         two_streams=bool(args.two_streams and args.workload and ctx.world == 1))
     secondary = []
     if args.workload is None and not args.no_secondary:

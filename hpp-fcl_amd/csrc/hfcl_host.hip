@@ -1936,7 +1936,9 @@ static int host_batch_small(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s
 // pipelined = false (contact lists: their pair ids are batch-wide) runs the batch as one chunk.
 static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, const double* tf1, const double* tf2,
                       size_t n, const hfcl_collision_request* creq, const hfcl_distance_request* dreq, hfcl_result* out,
-                      const hfcl_guess* gin, hfcl_guess* gout, bool pipelined = true, bool compact = false) {
+                      const hfcl_guess* gin, hfcl_guess* gout, bool pipelined = true, bool compact = false, bool f32 = false) {
+  // f32 (hfcl_*_batch_f32): tf1 / tf2 are 7-FLOAT poses and `out` hfcl_result_f32 records, both smaller than what the slots' buffers hold for the
+  // fp64 formats, so the same staging serves; the chunks go through the fp32 device path.  No guesses in that format.
   if (!lib) {
     set_error("null library");
     return HFCL_ERR_INVALID_ARGUMENT;
@@ -1947,7 +1949,7 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
     return HFCL_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(hipSetDevice(lib->device));
-  if (pipelined && n <= hfcl_lib::SMALL_MAX && !lib->pipe_chunk) return host_batch_small(lib, s1, s2, tf1, tf2, n, creq, dreq, out, gin, gout, compact);
+  if (pipelined && n <= hfcl_lib::SMALL_MAX && !lib->pipe_chunk && !f32) return host_batch_small(lib, s1, s2, tf1, tf2, n, creq, dreq, out, gin, gout, compact);
   // Chunks: large enough that a chunk's fixed costs (a dozen launches, ~0.1 ms) vanish, small enough that the pipeline
   // has several chunks to overlap.  The link is busy from the first byte to the last only if the first chunk is small
   // (nothing computes until it has arrived) and the last one too (nothing overlaps its way back): the sizes ramp up
@@ -1958,6 +1960,12 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
   if (pipelined && lib->pipe_chunk) {
     for (size_t lo = 0; lo < n; lo += lib->pipe_chunk) bounds.push_back(std::min(n, lo + lib->pipe_chunk));
     max_chunk = std::min(n, lib->pipe_chunk);
+  } else if (pipelined && f32 && n > (size_t(1) << 16)) {
+    // fp32: 108 B per pair cross the link -- a quarter of the time the kernels take -- and those kernels live on latency, so a chunk a quarter the
+    // size takes 0.44 of the time, not 0.25: few, large chunks (1M convex32 pairs: three chunks 3.7 ms, the fp64 policy's ten 6.4 ms, one chunk 4.1 ms)
+    const size_t c = std::min<size_t>(std::max<size_t>((n + 2) / 3, size_t(1) << 16), size_t(1) << 19);
+    for (size_t lo = 0; lo < n; lo += c) bounds.push_back(std::min(n, lo + c));
+    max_chunk = std::min(n, c);
   } else if (pipelined && n > (size_t(1) << 16)) {
     const size_t steady = std::min<size_t>(std::max<size_t>(n / 6, size_t(1) << 16), size_t(1) << 18);
     std::vector<size_t> up;    // 16k, 32k, ... below the steady size
@@ -2030,7 +2038,9 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
       const uint32_t* ids = h ? s2 : s1;
       const double* tf = h ? tf2 : tf1;
       hipError_t e = hipMemcpyAsync(h ? sg.d_s2 : sg.d_s1, ids + lo, m * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-      if (compact) {  // tf1 / tf2 are 7-double poses: expanded to Transform3f images by the first kernel of the chunk
+      if (f32) {
+        if (e == hipSuccess) e = hipMemcpyAsync(h ? sg.d_tf2 : sg.d_tf1, reinterpret_cast<const float*>(tf) + 7 * lo, m * 7 * sizeof(float), hipMemcpyHostToDevice, st);
+      } else if (compact) {  // tf1 / tf2 are 7-double poses: expanded to Transform3f images by the first kernel of the chunk
         if (e == hipSuccess) e = hipMemcpyAsync(h ? sg.d_qt2 : sg.d_qt1, tf + 7 * lo, m * 7 * sizeof(double), hipMemcpyHostToDevice, st);
       } else {
         if (e == hipSuccess) e = hipMemcpyAsync(h ? sg.d_tf2 : sg.d_tf1, tf + 12 * lo, m * 12 * sizeof(double), hipMemcpyHostToDevice, st);
@@ -2061,7 +2071,9 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
       hipError_t e = trace ? hipEventSynchronize(sg.ev_done) : hipSuccess;
       if (trace) tr[6 * k + 4] = ms_now();
       if (e == hipSuccess) e = hipStreamWaitEvent(lib->s_d2h, sg.ev_done, 0);
-      if (e == hipSuccess) e = hipMemcpyAsync(out + lo, sg.d_out, m * sizeof(hfcl_result), hipMemcpyDeviceToHost, lib->s_d2h);
+      if (e == hipSuccess)
+        e = f32 ? hipMemcpyAsync(reinterpret_cast<hfcl_result_f32*>(out) + lo, sg.d_out, m * sizeof(hfcl_result_f32), hipMemcpyDeviceToHost, lib->s_d2h)
+                : hipMemcpyAsync(out + lo, sg.d_out, m * sizeof(hfcl_result), hipMemcpyDeviceToHost, lib->s_d2h);
       if (e == hipSuccess && gout) e = hipMemcpyAsync(gout + lo, sg.d_gout, m * sizeof(hfcl_guess), hipMemcpyDeviceToHost, lib->s_d2h);
       if (e == hipSuccess) e = hipStreamSynchronize(lib->s_d2h);  // (ev_done has passed: the counters are on the host too)
       if (e == hipSuccess)
@@ -2144,7 +2156,13 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
       if (rc) return fail(rc);
       lib->helper->counts_dst = sg.h_counts2;
     }
-    if (creq)
+    if (f32 && creq)
+      rc = hfcl_collide_batch_device_f32(lib, sg.d_s1, sg.d_s2, reinterpret_cast<const float*>(sg.d_tf1), reinterpret_cast<const float*>(sg.d_tf2), m, creq,
+                                         reinterpret_cast<hfcl_result_f32*>(sg.d_out), lib->s_cmp);
+    else if (f32)
+      rc = hfcl_distance_batch_device_f32(lib, sg.d_s1, sg.d_s2, reinterpret_cast<const float*>(sg.d_tf1), reinterpret_cast<const float*>(sg.d_tf2), m, dreq,
+                                          reinterpret_cast<hfcl_result_f32*>(sg.d_out), lib->s_cmp);
+    else if (creq)
       rc = hfcl_collide_batch_device(lib, sg.d_s1, sg.d_s2, sg.d_tf1, sg.d_tf2, m, creq, sg.d_out, gin ? sg.d_gin : nullptr,
                                      gout ? sg.d_gout : nullptr, lib->s_cmp);
     else
@@ -2201,6 +2219,25 @@ int hfcl_distance_batch(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* s
     return HFCL_ERR_INVALID_ARGUMENT;
   }
   return host_batch(lib, shape1, shape2, tf1, tf2, n, nullptr, req, out, guess_in, guess_out);
+}
+
+int hfcl_collide_batch_f32(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2, const float* pose1, const float* pose2, size_t n,
+                           const hfcl_collision_request* req, hfcl_result_f32* out) {
+  if (!req) {
+    set_error("null request");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  return host_batch(lib, shape1, shape2, reinterpret_cast<const double*>(pose1), reinterpret_cast<const double*>(pose2), n, req, nullptr,
+                    reinterpret_cast<hfcl_result*>(out), nullptr, nullptr, true, false, true);
+}
+int hfcl_distance_batch_f32(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2, const float* pose1, const float* pose2, size_t n,
+                            const hfcl_distance_request* req, hfcl_result_f32* out) {
+  if (!req) {
+    set_error("null request");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  return host_batch(lib, shape1, shape2, reinterpret_cast<const double*>(pose1), reinterpret_cast<const double*>(pose2), n, nullptr, req,
+                    reinterpret_cast<hfcl_result*>(out), nullptr, nullptr, true, false, true);
 }
 
 int hfcl_collide_batch_qt(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2, const double* pose1,

@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "hfcl_abi_version", "hfcl_device_count", "hfcl_last_error", "hfcl_collision_request_init",
     "hfcl_distance_request_init", "hfcl_lib_create", "hfcl_lib_destroy", "hfcl_lib_num_shapes", "hfcl_lib_device", "hfcl_lib_climb_min",
     "hfcl_lib_add_bvh", "hfcl_collide_batch", "hfcl_distance_batch", "hfcl_collide_batch_device",
-    "hfcl_distance_batch_device", "hfcl_distance_batch_device_f32", "hfcl_collide_batch_device_f32",
+    "hfcl_distance_batch_device", "hfcl_distance_batch_device_f32", "hfcl_collide_batch_device_f32", "hfcl_collide_batch_f32", "hfcl_distance_batch_f32",
     "hfcl_collide_batch_contacts", "hfcl_last_kernel_ms", "hfcl_last_kernel_name", "hfcl_bvh_build",
     "hfcl_world_aabbs", "hfcl_broadphase_self_pairs", "hfcl_broadphase_pairs_between", "hfcl_pairlist_size",
     "hfcl_pairlist_data", "hfcl_pairlist_free", "hfcl_lib_set_kernel_timing", "hfcl_pair_supported", "hfcl_last_kernel_breakdown", "hfcl_last_bucket_counts", "hfcl_lib_set_split", "hfcl_lib_get_split", "hfcl_lib_last_split_parts",
@@ -226,6 +226,27 @@ class Library:
         """Batched hpp::fcl::distance (src/distance.cpp:60-109)."""
         return self._host(dll().hfcl_distance_batch, s1, s2, tf1, tf2, req or abi.default_distance_request(),
                           guess_in, want_guess)
+
+    def _host_f32(self, fn, s1, s2, pose1, pose2, req):
+        s1 = np.ascontiguousarray(s1, dtype=np.uint32)
+        s2 = np.ascontiguousarray(s2, dtype=np.uint32)
+        p1 = np.ascontiguousarray(pose1, dtype=np.float32).reshape(-1, 7)
+        p2 = np.ascontiguousarray(pose2, dtype=np.float32).reshape(-1, 7)
+        n = len(s1)
+        if not (len(s2) == len(p1) == len(p2) == n):
+            raise ValueError("array lengths differ")
+        out = np.zeros(n, dtype=abi.RESULT_F32_DTYPE)
+        _check(fn(self._h, C.c_void_p(s1.ctypes.data), C.c_void_p(s2.ctypes.data), C.c_void_p(p1.ctypes.data), C.c_void_p(p2.ctypes.data),
+                  C.c_size_t(n), C.byref(req), C.c_void_p(out.ctypes.data)))
+        return out
+
+    def collide_f32(self, s1, s2, pose1, pose2, req=None):
+        """collide() through the fp32 path from host arrays: (n, 7) float32 poses (quaternion w, x, y, z + translation), hfcl_result_f32 records."""
+        return self._host_f32(dll().hfcl_collide_batch_f32, s1, s2, pose1, pose2, req or abi.default_collision_request())
+
+    def distance_f32(self, s1, s2, pose1, pose2, req=None):
+        """distance() through the fp32 path from host arrays (see collide_f32)."""
+        return self._host_f32(dll().hfcl_distance_batch_f32, s1, s2, pose1, pose2, req or abi.default_distance_request())
 
     def collide_qt(self, s1, s2, pose1, pose2, req=None, guess_in=None, want_guess=False):
         """collide() with compact host poses: (n, 7) float64 = quaternion (w, x, y, z) + translation."""

@@ -366,7 +366,8 @@ int hfcl_distance_batch_device(hfcl_lib* lib, const uint32_t* d_shape1, const ui
 
 /* fp32 compute path (the reference has no fp32; parity = fp32 result vs fp64 oracle within
  * the tolerance stated in tests/).  Poses are 7-float (quat wxyz + translation) records,
- * results are 44-byte hfcl_result_f32 records (no primitive ids: see hfcl_result_f32).  Device-resident only.
+ * results are 44-byte hfcl_result_f32 records (no primitive ids: see hfcl_result_f32).  Device-resident arrays, or -- hfcl_*_batch_f32
+ * below -- host arrays that go through the same chunked copy / compute / copy pipeline as the fp64 host entry points.
  * EPA statuses and iteration counts of this path are not the reference's step for step: the fp32 convex x convex fast tier finds
  * an expansion's horizon without the reference's walk (every face the new vertex is above is removed, connected to the
  * closest face or not; csrc/hfcl_epa.hpp: silhouette_parallel), the depth converges to the same value
@@ -379,6 +380,14 @@ int hfcl_collide_batch_device_f32(hfcl_lib* lib, const uint32_t* d_shape1, const
                                   const float* d_pose1, const float* d_pose2, size_t n,
                                   const hfcl_collision_request* req, hfcl_result_f32* d_out,
                                   void* stream);
+/* The same path from HOST arrays (blocking; records identical to the device-resident calls'): what a caller that holds hpp::fcl objects in host
+ * memory and accepts the fp32 envelope uses -- 64 B in and 44 B out per pair over the link instead of 200 B and 96 B.  No cached guesses in this
+ * format (the fp32 records carry none).  Replaces the same loop as hfcl_collide_batch / hfcl_distance_batch
+ * (src/broadphase/default_broadphase_callbacks.cpp:43-91 over the pairs of a broadphase pass). */
+int hfcl_collide_batch_f32(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2, const float* pose1, const float* pose2, size_t n,
+                           const hfcl_collision_request* req, hfcl_result_f32* out);
+int hfcl_distance_batch_f32(hfcl_lib* lib, const uint32_t* shape1, const uint32_t* shape2, const float* pose1, const float* pose2, size_t n,
+                            const hfcl_distance_request* req, hfcl_result_f32* out);
 
 /* Device-resident full records -> compact records (see hfcl_result_compact); asynchronous on `stream`. */
 int hfcl_compact_results_device(hfcl_lib* lib, const hfcl_result* d_records, size_t n,

@@ -267,6 +267,33 @@ def test_fp32_device_path(pkg, oracle, torch_cuda, case):
     lib.close()
 
 
+@pytest.mark.parametrize("case,n", [("cfg3_convex_convex", 300001), ("cfg2_box_capsule", 70000), ("cfg5_mixed", 257), ("cfg3_convex_convex", 1)])
+def test_fp32_host_buffers_equal_device_path(pkg, torch_cuda, case, n):
+    """hfcl_collide_batch_f32 / hfcl_distance_batch_f32 (host arrays through the chunked pipeline; 300 001 pairs = several chunks of ramping
+    size, 257 and 1 = one chunk) against the device-resident fp32 call on the same batch: every record byte for byte."""
+    torch = torch_cuda
+    abi, wl = pkg.abi, pkg.workloads
+    b = getattr(wl, case)(n=n, seed=11)
+    req = wl.make_request(b, abi)
+    lib = pkg.Library(b.lib)
+    host = (lib.distance_f32 if b.kind == "distance" else lib.collide_f32)(b.s1, b.s2, b.pose1_f32, b.pose2_f32, req)
+    dev = torch.device("cuda:0")
+    d_s1 = torch.from_numpy(b.s1.astype(np.int32)).to(dev)
+    d_s2 = torch.from_numpy(b.s2.astype(np.int32)).to(dev)
+    d_p1 = torch.from_numpy(b.pose1_f32).to(dev)
+    d_p2 = torch.from_numpy(b.pose2_f32).to(dev)
+    d_out = torch.zeros(len(b) * 11, dtype=torch.int32, device=dev)
+    fn = lib.distance_device_f32 if b.kind == "distance" else lib.collide_device_f32
+    fn(d_s1, d_s2, d_p1, d_p2, len(b), req, d_out, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = d_out.cpu().numpy().reshape(len(b), 11)
+    got = host.view(np.int32).reshape(len(b), 11)
+    differ = np.flatnonzero((got != want).any(axis=1))
+    assert differ.size == 0, "%d records differ, first %s" % (differ.size, differ[:10])
+    assert lib.last_bucket_counts()  # (the host call's populations are those of the whole batch)
+    lib.close()
+
+
 @pytest.mark.parametrize("case,n", [("cfg3_convex_convex", 300000), ("cfg3_unique_hulls", 60000), ("cfg5_mixed", 120000)])
 def test_fp32_staged_epa_equals_one_kernel_form(pkg, torch_cuda, monkeypatch, case, n):
     """The convex x convex EPA fast tier in three stages (k_epa_prepare: one lane per polytope builds the first tetrahedron;
