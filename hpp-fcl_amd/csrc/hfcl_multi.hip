@@ -219,6 +219,18 @@ int hfcl_distance_batch_multi(hfcl_multi* m, const uint32_t* shape1, const uint3
                                guess_out ? guess_out + lo : nullptr);
   });
 }
+int hfcl_collide_batch_multi_f32(hfcl_multi* m, const uint32_t* shape1, const uint32_t* shape2, const float* pose1, const float* pose2, size_t n,
+                                 const hfcl_collision_request* req, hfcl_result_f32* out) {
+  return run_sharded(m, n, [&](hfcl_lib* lib, size_t lo, size_t hi) {
+    return hfcl_collide_batch_f32(lib, shape1 + lo, shape2 + lo, pose1 + 7 * lo, pose2 + 7 * lo, hi - lo, req, out + lo);
+  });
+}
+int hfcl_distance_batch_multi_f32(hfcl_multi* m, const uint32_t* shape1, const uint32_t* shape2, const float* pose1, const float* pose2, size_t n,
+                                  const hfcl_distance_request* req, hfcl_result_f32* out) {
+  return run_sharded(m, n, [&](hfcl_lib* lib, size_t lo, size_t hi) {
+    return hfcl_distance_batch_f32(lib, shape1 + lo, shape2 + lo, pose1 + 7 * lo, pose2 + 7 * lo, hi - lo, req, out + lo);
+  });
+}
 int hfcl_collide_batch_multi_device(hfcl_multi* m, const uint32_t* const* d_shape1, const uint32_t* const* d_shape2, const double* const* d_tf1,
                                     const double* const* d_tf2, size_t n, const hfcl_collision_request* req, hfcl_result* const* d_gathered,
                                     void* const* streams) {

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "hfcl_lib_set_convex_neighbors", "hfcl_compact_results_device", "hfcl_compact_results_device_f32",
  "hfcl_shard_range", "hfcl_multi_create", "hfcl_multi_destroy", "hfcl_multi_size", "hfcl_multi_replica",
     "hfcl_multi_set_shapes", "hfcl_multi_set_convex_neighbors", "hfcl_multi_add_bvh", "hfcl_collide_batch_multi", "hfcl_distance_batch_multi",
-    "hfcl_collide_batch_multi_device", "hfcl_distance_batch_multi_device",
+    "hfcl_collide_batch_multi_device", "hfcl_distance_batch_multi_device", "hfcl_collide_batch_multi_f32", "hfcl_distance_batch_multi_f32",
 ]
 
 
@@ -390,6 +390,12 @@ class MultiLibrary:
 
     def distance(self, s1, s2, tf1, tf2, req=None, guess_in=None, want_guess=False):
         return self._host(dll().hfcl_distance_batch_multi, s1, s2, tf1, tf2, req or abi.default_distance_request(), guess_in, want_guess)
+
+    def collide_f32(self, s1, s2, pose1, pose2, req=None):
+        return Library._host_f32(self, dll().hfcl_collide_batch_multi_f32, s1, s2, pose1, pose2, req or abi.default_collision_request())
+
+    def distance_f32(self, s1, s2, pose1, pose2, req=None):
+        return Library._host_f32(self, dll().hfcl_distance_batch_multi_f32, s1, s2, pose1, pose2, req or abi.default_distance_request())
 
     def _gathered(self, fn, d_s1, d_s2, d_tf1, d_tf2, n, req, d_gathered, streams=None):
         """Per-replica lists of device buffers (torch tensors or raw pointers); d_gathered[g]: len(self) * ceil(n / len(self)) records."""

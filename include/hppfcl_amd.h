@@ -458,6 +458,11 @@ int hfcl_collide_batch_multi(hfcl_multi* m, const uint32_t* shape1, const uint32
 int hfcl_distance_batch_multi(hfcl_multi* m, const uint32_t* shape1, const uint32_t* shape2, const double* tf1,
                               const double* tf2, size_t n, const hfcl_distance_request* req, hfcl_result* out,
                               const hfcl_guess* guess_in, hfcl_guess* guess_out);
+/* ... and through the fp32 path (hfcl_collide_batch_f32 / hfcl_distance_batch_f32 per shard) */
+int hfcl_collide_batch_multi_f32(hfcl_multi* m, const uint32_t* shape1, const uint32_t* shape2, const float* pose1, const float* pose2, size_t n,
+                                 const hfcl_collision_request* req, hfcl_result_f32* out);
+int hfcl_distance_batch_multi_f32(hfcl_multi* m, const uint32_t* shape1, const uint32_t* shape2, const float* pose1, const float* pose2, size_t n,
+                                  const hfcl_distance_request* req, hfcl_result_f32* out);
 /* Device-resident buffers: replica g finds the inputs of ITS shard on its device (d_shape1[g] ... : hi_g - lo_g entries)
  * and writes into d_gathered[g], a buffer of G * ceil(n / G) records on the same device: its own shard at slot g, then the
  * other replicas' shards arrive by an in-place all-gather of the fixed-size records (ncclAllGather of librccl.so -- RCCL

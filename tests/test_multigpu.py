@@ -202,6 +202,25 @@ def test_c_abi_multi_equals_single_library(pkg, case):
 
 
 @pytest.mark.gpu
+def test_c_abi_multi_f32_equals_single_library(pkg, torch_cuda):
+    """hfcl_{collide,distance}_batch_multi_f32 over two replicas on device 0 against hfcl_*_batch_f32 of one library on the same 100 001-pair
+    list (fp32 path, host arrays): byte for byte."""
+    abi, wl = pkg.abi, pkg.workloads
+    b = wl.cfg3_convex_convex(n=100001, seed=6)
+    single = wl.make_library(pkg, b)
+    multi = pkg.MultiLibrary(b.lib, devices=(0, 0))
+    try:
+        for kind in ("collide", "distance"):
+            req = abi.default_collision_request() if kind == "collide" else abi.default_distance_request()
+            ref = getattr(single, kind + "_f32")(b.s1, b.s2, b.pose1_f32, b.pose2_f32, req)
+            got = getattr(multi, kind + "_f32")(b.s1, b.s2, b.pose1_f32, b.pose2_f32, req)
+            assert got.tobytes() == ref.tobytes(), kind
+    finally:
+        single.close()
+        multi.close()
+
+
+@pytest.mark.gpu
 def test_c_abi_multi_device_resident(pkg, torch_cuda):
     """The device-resident form: one replica gathers nothing and equals hfcl_distance_batch_device; a device listed twice is refused
     (one communicator rank per device) with the reason in hfcl_last_error()."""
