@@ -622,6 +622,12 @@ def test_gpu_mesh_solid_collide_at_baseline_size(pkg, oracle):
     uncut = _device_collide(pkg, b, req, env=dict(HFCL_SHAPE_CUT_TICKS="0"))
     for f in got.dtype.names:
         assert _same(got[f], uncut[f], 0.0) if got[f].dtype.kind == "f" else np.array_equal(got[f], uncut[f]), f
+    # the EPA leaves (k_bvh_shape_finish): two tiers with the whole walks' items on the helper stream beside the chunk launches (default)
+    # against one launch at full capacity behind the last launch of the walk, and against each switch alone
+    for env in (dict(HFCL_SHAPE_FINISH_TIERS="0", HFCL_SHAPE_FINISH_ASIDE="0"), dict(HFCL_SHAPE_FINISH_TIERS="0"), dict(HFCL_SHAPE_FINISH_ASIDE="0")):
+        other = _device_collide(pkg, b, req, env=env)
+        for f in got.dtype.names:
+            assert _same(got[f], other[f], 0.0) if got[f].dtype.kind == "f" else np.array_equal(got[f], other[f]), (f, env)
 
 
 def test_mesh_vs_flats_headers_match_oracle(pkg, oracle, hostsim):
