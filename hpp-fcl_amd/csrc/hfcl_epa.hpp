@@ -1258,21 +1258,40 @@ struct Epa {
   // was prepared for hand-over (overflow && resumable, header written).
   template <class Sup>
   HFCL_HD int step(EpaLoop<T>& L, Sup& sup) {
-    if (!(L.iterations < max_iterations)) {
-      status = EPA_FAILED;
-      return 1;
-    }
-    if (L.iterations >= cap_iterations && cap_iterations < max_iterations) {
-      // capacity of this scratch block reached before the reference's limit: hand over
-      overflow = true;
-      resumable = true;
-      if (Grp::lane() == 0) m->hdr = EpaHeader{L.closest, L.iterations, L.pass, status, num_vertices, hull_count, stock_top, stamp, hw};
-      Grp::sync();
-      return 2;
-    }
-    if (num_vertices >= max_iterations + 4) {
-      status = EPA_OUT_OF_VERTICES;
-      return 1;
+    // The three ways a trip ends before it starts.  fp32: behind ONE test -- every way out of step() costs the lanes a copy of the loop's state into
+    // the registers the caller reads it from, made whether the way is taken or not (k_epa_loop<float,8,17>: 381 -> 347 static v_mov, cfg3 -0.7 %); the
+    // fp64 tiers keep the three tests (the same change costs them 1.3 % on cfg5: other live ranges, other copies; profiles/r05_h section 5).
+    constexpr bool ONE_TEST = sizeof(T) == 4;
+    if constexpr (ONE_TEST) {
+      const int early = !(L.iterations < max_iterations) ? 1 : ((L.iterations >= cap_iterations && cap_iterations < max_iterations) ? 2 : (num_vertices >= max_iterations + 4 ? 3 : 0));
+      if (early) {
+        if (early == 2) {
+          overflow = true;
+          resumable = true;
+          if (Grp::lane() == 0) m->hdr = EpaHeader{L.closest, L.iterations, L.pass, status, num_vertices, hull_count, stock_top, stamp, hw};
+          Grp::sync();
+          return 2;
+        }
+        status = early == 1 ? EPA_FAILED : EPA_OUT_OF_VERTICES;
+        return 1;
+      }
+    } else {
+      if (!(L.iterations < max_iterations)) {
+        status = EPA_FAILED;
+        return 1;
+      }
+      if (L.iterations >= cap_iterations && cap_iterations < max_iterations) {
+        // capacity of this scratch block reached before the reference's limit: hand over
+        overflow = true;
+        resumable = true;
+        if (Grp::lane() == 0) m->hdr = EpaHeader{L.closest, L.iterations, L.pass, status, num_vertices, hull_count, stock_top, stamp, hw};
+        Grp::sync();
+        return 2;
+      }
+      if (num_vertices >= max_iterations + 4) {
+        status = EPA_OUT_OF_VERTICES;
+        return 1;
+      }
     }
     const int closest = L.closest;
     const int iw = num_vertices++;
@@ -1298,13 +1317,20 @@ struct Epa {
     const T fdist = dot(cn, w - vf1);
     const T wnorm = norm(w);
     const T thr = tolerance + tolerance * wnorm;
-    if (fdist <= thr) {
-      status = EPA_ACCURACY_REACHED;
-      return 1;
-    }
-    if (norm(w - vf1) <= thr || norm(w - vf2) <= thr || norm(w - vf3) <= thr) {
-      status = EPA_ACCURACY_REACHED;
-      return 1;
+    if constexpr (ONE_TEST) {
+      if (fdist <= thr || norm(w - vf1) <= thr || norm(w - vf2) <= thr || norm(w - vf3) <= thr) {
+        status = EPA_ACCURACY_REACHED;
+        return 1;
+      }
+    } else {
+      if (fdist <= thr) {
+        status = EPA_ACCURACY_REACHED;
+        return 1;
+      }
+      if (norm(w - vf1) <= thr || norm(w - vf2) <= thr || norm(w - vf3) <= thr) {
+        status = EPA_ACCURACY_REACHED;
+        return 1;
+      }
     }
     if (!expand_iteration(L.pass, closest, iw)) {
       if (resumable) {  // hand over as of the start of this iteration (vertex iw is recomputed there)
