@@ -395,10 +395,10 @@ struct HullRegs {
       constexpr int M = decltype(stage)::value;
       const T od = group_exchange<W, M>(best);
       const int oi = group_exchange<W, M>(bi);
-      if (od > best || (od == best && oi < bi)) {
-        best = od;
-        bi = oi;
-      }
+      // (selects, not a short-circuit: as `if (a || (b && c))` every stage of every support was three exec-masked branches)
+      const bool take = (od > best) | ((od == best) & (oi < bi));
+      best = take ? od : best;
+      bi = take ? oi : bi;
     });
     // the winner's coordinates come from a run-time lane (ds_bpermute): carrying them through the stages,
     // or OR-reducing the owner's bits, costs the GJK kernels registers they do not have (spills; measured)

@@ -672,20 +672,20 @@ struct Epa {
     for (int j = 0; j < PER_LANE; ++j) {
       const int f = Grp::lane() + j * Grp::W;
       const int fl = t[j].flag();
-      const bool in_hull = f < nf && (fl & 1);
-      const bool release = in_hull && rel >= 0 && t[j].pass() == rel;
+      const bool in_hull = (f < nf) & ((fl & 1) != 0);
+      const bool release = in_hull & (rel >= 0) & (t[j].pass() == rel);
       int below, total;
       Grp::count(release, below, total);
       *(release ? topo_bytes(m->ft[f], 0) + 3 : dummy) = uint8_t(0);  // set_flag(f, 0)
       *(release ? &m->stock[stock_top + released + below] : dummy) = uint8_t(f);
       released += total;
-      const bool cand = in_hull && !release;
+      const bool cand = in_hull & !release;
       const int st = t[j].stamp();
-      const bool th = cand && st > head_stamp;
+      const bool th = cand & (st > head_stamp);
       head_stamp = th ? st : head_stamp;
       head_f = th ? f : head_f;
       const T sq = dist[j] * dist[j];
-      const bool take = cand && !(fl & 2) && (sq < best || (sq == best && st > best_stamp && best_f != EPA_NULL));
+      const bool take = cand & !(fl & 2) & ((sq < best) | ((sq == best) & (st > best_stamp) & (best_f != EPA_NULL)));  // (no short circuits: selects, not branches)
       best = take ? sq : best;
       best_stamp = take ? st : best_stamp;
       best_f = take ? f : best_f;
@@ -695,7 +695,7 @@ struct Epa {
       const T ob = Grp::template exchange<M>(best);
       const int os = Grp::template exchange<M>(best_stamp), of = Grp::template exchange<M>(best_f);
       const int ohs = Grp::template exchange<M>(head_stamp), ohf = Grp::template exchange<M>(head_f);
-      const bool take = (of != EPA_NULL) && (best_f == EPA_NULL || ob < best || (ob == best && os > best_stamp));
+      const bool take = (of != EPA_NULL) & ((best_f == EPA_NULL) | (ob < best) | ((ob == best) & (os > best_stamp)));
       best = take ? ob : best;
       best_stamp = take ? os : best_stamp;
       best_f = take ? of : best_f;
@@ -1318,7 +1318,9 @@ struct Epa {
     const T wnorm = norm(w);
     const T thr = tolerance + tolerance * wnorm;
     if constexpr (ONE_TEST) {
-      if (fdist <= thr || norm(w - vf1) <= thr || norm(w - vf2) <= thr || norm(w - vf3) <= thr) {
+      // (all four evaluated, no short circuit: three more norms cost less than the state copies in front of three more branches)
+      const bool reached = (fdist <= thr) | (norm(w - vf1) <= thr) | (norm(w - vf2) <= thr) | (norm(w - vf3) <= thr);
+      if (reached) {
         status = EPA_ACCURACY_REACHED;
         return 1;
       }
