@@ -242,22 +242,34 @@ HFCL_HD bool gjk_to_triangle(Gjk<T, P>& g, const SimplexV<T, P> X, const Simplex
   return false;
 }
 
+// The two small projections.  fp32: in SELECT form (round 5) -- every region's result is formed (the expressions are those of gjk_to_segment /
+// gjk_to_triangle, term for term) and the region picks among them: a wave steps 16-32 pairs that sit in different regions, so as branches all
+// regions ran anyway, one after the other under exec masks, each way out with its copy of the simplex (cfg3 -0.5 %).  fp64 keeps the branches: three
+// fp64 divisions where one is needed cost more than the branches (cfg5 +2.2 % with selects; profiles/r05_h section 6).
 template <typename T, class P>
 HFCL_HD bool gjk_project_line(Gjk<T, P>& g) {  // :543-569
   const V3<T> A = g.s0.w, B = g.s1.w;
   const V3<T> AB = B - A;
   const T d = dot(AB, -A);
-  if (d == T(0)) {
-    g.ray = A;
-    g.rank = 1;
-    return is_zero(A);
-  } else if (d < T(0)) {
-    g.ray = A;
-    g.rank = 1;
+  if constexpr (sizeof(T) == 4) {
+    const bool seg = !((d == T(0)) | (d < T(0)));  // else: the origin projects onto A (d == 0: A may be the origin itself)
+    const V3<T> r_seg = (dot(AB, B) * A + d * B) / sqnorm(AB);  // originToSegment(A, B)
+    g.ray = seg ? r_seg : A;
+    g.rank = seg ? 2 : 1;
+    return (d == T(0)) & is_zero(A);
   } else {
-    gjk_to_segment(g, g.s1, AB, d);
+    if (d == T(0)) {
+      g.ray = A;
+      g.rank = 1;
+      return is_zero(A);
+    } else if (d < T(0)) {
+      g.ray = A;
+      g.rank = 1;
+    } else {
+      gjk_to_segment(g, g.s1, AB, d);
+    }
+    return false;
   }
-  return false;
 }
 
 template <typename T, class P>
@@ -265,30 +277,54 @@ HFCL_HD bool gjk_project_triangle(Gjk<T, P>& g) {  // :571-611
   const V3<T> A = g.s0.w, B = g.s1.w, C = g.s2.w;
   const V3<T> AB = B - A, AC = C - A, ABC = cross(AB, AC);
   const T edgeAC2o = dot(cross(ABC, AC), -A);
-  bool region45 = false;
-  if (edgeAC2o >= T(0)) {
+  if constexpr (sizeof(T) == 4) {
     const T towardsC = dot(AC, -A);
-    if (towardsC >= T(0)) {
-      gjk_to_segment(g, g.s2, AC, towardsC);
-      return false;
-    }
-    region45 = true;
-  } else {
     const T edgeAB2o = dot(cross(AB, ABC), -A);
-    if (edgeAB2o >= T(0))
-      region45 = true;
-    else
-      return gjk_to_triangle(g, g.s1, g.s2, ABC, dot(ABC, -A));
-  }
-  if (region45) {
     const T towardsB = dot(AB, -A);
-    if (towardsB < T(0)) {
-      g.ray = A;
-      g.rank = 1;
-    } else
-      gjk_to_segment(g, g.s1, AB, towardsB);
+    const T NdotAO = dot(ABC, -A);
+    const bool e_ac = edgeAC2o >= T(0);
+    const bool segC = e_ac & (towardsC >= T(0));                      // originToSegment(A, C)
+    const bool r45 = (e_ac & !(towardsC >= T(0))) | (!e_ac & (edgeAB2o >= T(0)));
+    const bool vertA = r45 & (towardsB < T(0));                        // the vertex A
+    const bool segB = r45 & !(towardsB < T(0));                        // originToSegment(A, B)
+    const bool tri = !e_ac & !(edgeAB2o >= T(0));                      // originToTriangle(A, B, C)
+    const V3<T> r_c = (dot(AC, C) * A + towardsC * C) / sqnorm(AC);
+    const V3<T> r_b = (dot(AB, B) * A + towardsB * B) / sqnorm(AB);
+    const V3<T> r_t = (NdotAO == T(0)) ? mk<T>(T(0), T(0), T(0)) : ((-NdotAO / sqnorm(ABC)) * ABC);
+    const bool keep = NdotAO >= T(0);
+    const SimplexV<T, P> n1 = svsel(keep, g.s1, g.s2), n2 = svsel(keep, g.s2, g.s1);
+    g.ray = segC ? r_c : (vertA ? A : (segB ? r_b : r_t));
+    g.rank = (segC | segB) ? 2 : (vertA ? 1 : 3);
+    const SimplexV<T, P> s1 = svsel(segC, g.s2, svsel(tri, n1, g.s1));
+    g.s2 = svsel(tri, n2, g.s2);
+    g.s1 = s1;
+    return tri & (NdotAO == T(0));
+  } else {
+    bool region45 = false;
+    if (edgeAC2o >= T(0)) {
+      const T towardsC = dot(AC, -A);
+      if (towardsC >= T(0)) {
+        gjk_to_segment(g, g.s2, AC, towardsC);
+        return false;
+      }
+      region45 = true;
+    } else {
+      const T edgeAB2o = dot(cross(AB, ABC), -A);
+      if (edgeAB2o >= T(0))
+        region45 = true;
+      else
+        return gjk_to_triangle(g, g.s1, g.s2, ABC, dot(ABC, -A));
+    }
+    if (region45) {
+      const T towardsB = dot(AB, -A);
+      if (towardsB < T(0)) {
+        g.ray = A;
+        g.rank = 1;
+      } else
+        gjk_to_segment(g, g.s1, AB, towardsB);
+    }
+    return false;
   }
-  return false;
 }
 
 template <typename T, class P>
@@ -378,10 +414,10 @@ HFCL_HD void gjk_end(Gjk<T, P>& g, const GjkParams<T>& prm, const SimplexV<T, P>
     // then divide by |AB|^2 = 0.  A repeated support vertex means no progress is possible:
     // treat it as converged (the classical GJK termination test the reference notes as
     // "check removed", gjk.cpp:283-284).
-    const bool dup = (g.rank > 1 && g.w.x == g.s1.w.x && g.w.y == g.s1.w.y && g.w.z == g.s1.w.z) ||
-                     (g.rank > 2 && g.w.x == g.s2.w.x && g.w.y == g.s2.w.y && g.w.z == g.s2.w.z) ||
-                     (g.rank > 3 && g.w.x == g.s3.w.x && g.w.y == g.s3.w.y && g.w.z == g.s3.w.z);
-    cv = cv || dup;
+    const bool dup = ((g.rank > 1) & (g.w.x == g.s1.w.x) & (g.w.y == g.s1.w.y) & (g.w.z == g.s1.w.z)) |
+                     ((g.rank > 2) & (g.w.x == g.s2.w.x) & (g.w.y == g.s2.w.y) & (g.w.z == g.s2.w.z)) |
+                     ((g.rank > 3) & (g.w.x == g.s3.w.x) & (g.w.y == g.s3.w.y) & (g.w.z == g.s3.w.z));
+    cv = cv | dup;
   }
   if (g.iterations > 0 && cv) {
     gjk_pop(g);
