@@ -746,16 +746,13 @@ struct Epa {
       const T ob = Grp::template exchange<M>(best);
       const int os = Grp::template exchange<M>(best_stamp), of = Grp::template exchange<M>(best_f);
       const int ohs = Grp::template exchange<M>(head_stamp), ohf = Grp::template exchange<M>(head_f);
-      const bool take = (of != EPA_NULL) && (best_f == EPA_NULL || ob < best || (ob == best && os > best_stamp));
-      if (take) {
-        best = ob;
-        best_stamp = os;
-        best_f = of;
-      }
-      if (ohs > head_stamp) {
-        head_stamp = ohs;
-        head_f = ohf;
-      }
+      const bool take = (of != EPA_NULL) & ((best_f == EPA_NULL) | (ob < best) | ((ob == best) & (os > best_stamp)));  // (selects: see HullRegs::support)
+      best = take ? ob : best;
+      best_stamp = take ? os : best_stamp;
+      best_f = take ? of : best_f;
+      const bool th = ohs > head_stamp;
+      head_stamp = th ? ohs : head_stamp;
+      head_f = th ? ohf : head_f;
     });
     if (rel >= 0) {
       Grp::sync();
@@ -1070,11 +1067,10 @@ struct Epa {
       constexpr int M = decltype(stage)::value;
       const int ok = Grp::template exchange<M>(first_fail), oc = Grp::template exchange<M>(fail_code);
       const int ot = Grp::template exchange<M>(top_slot);
-      if (ok < first_fail) {
-        first_fail = ok;
-        fail_code = oc;
-      }
-      if (ot > top_slot) top_slot = ot;
+      const bool earlier = ok < first_fail;
+      first_fail = earlier ? ok : first_fail;
+      fail_code = earlier ? oc : fail_code;
+      top_slot = ot > top_slot ? ot : top_slot;
     });
     hw = top_slot;
     stock_top -= n_new;
