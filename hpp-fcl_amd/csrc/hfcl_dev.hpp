@@ -453,10 +453,9 @@ __device__ __forceinline__ V3<T> scan_support(const T* v, uint32_t n, const V3<T
     constexpr int M = decltype(stage)::value;
     const T od = group_exchange<W, M>(best);
     const uint32_t oi = group_exchange<W, M>(bi);
-    if (od > best || (od == best && oi < bi)) {
-      best = od;
-      bi = oi;
-    }
+    const bool take = (od > best) | ((od == best) & (oi < bi));
+    best = take ? od : best;
+    bi = take ? oi : bi;
   });
   if (idx_out) *idx_out = bi;
   return mk<T>(v[3 * bi], v[3 * bi + 1], v[3 * bi + 2]);
@@ -498,11 +497,10 @@ __device__ __forceinline__ V3<T> climb_support(const T* v, uint32_t n, const Hul
       const T od = group_exchange<W, M>(best);
       const uint32_t oc = group_exchange<W, M>(cur);
       const uint32_t ok = group_exchange<W, M>(bk);
-      if (od > best || (od == best && ok < bk)) {
-        best = od;
-        cur = oc;
-        bk = ok;
-      }
+      const bool take = (od > best) | ((od == best) & (ok < bk));
+      best = take ? od : best;
+      cur = take ? oc : cur;
+      bk = take ? ok : bk;
     });
   } else {
     cur = uint32_t(hint);
@@ -529,11 +527,10 @@ __device__ __forceinline__ V3<T> climb_support(const T* v, uint32_t n, const Hul
       const T od = group_exchange<W, M>(mb);
       const uint32_t oi = group_exchange<W, M>(mi);
       const uint32_t ok = group_exchange<W, M>(mpos);
-      if (od > mb || (od == mb && ok < mpos)) {
-        mb = od;
-        mi = oi;
-        mpos = ok;
-      }
+      const bool take = (od > mb) | ((od == mb) & (ok < mpos));
+      mb = take ? od : mb;
+      mi = take ? oi : mi;
+      mpos = take ? ok : mpos;
     });
     if (mi == 0xFFFFFFFFu) {  // no neighbour is strictly better (uniform over the group)
       if (!improved) {        // ... and none ever was: a neighbour that ties may hide a better vertex behind the plateau

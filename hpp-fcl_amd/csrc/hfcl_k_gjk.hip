@@ -290,10 +290,9 @@ struct HullLds {
       constexpr int M = decltype(stage)::value;
       const T od = group_exchange<W, M>(best);
       const int oi = group_exchange<W, M>(bi);
-      if (od > best || (od == best && oi < bi)) {
-        best = od;
-        bi = oi;
-      }
+      const bool take = (od > best) | ((od == best) & (oi < bi));  // (selects: see HullRegs::support)
+      best = take ? od : best;
+      bi = take ? oi : bi;
     });
     const int owner = bi / VPL, slot = bi % VPL;
     const T cx = lane[(3 * slot + 0) * NT], cy = lane[(3 * slot + 1) * NT], cz = lane[(3 * slot + 2) * NT];
