@@ -897,8 +897,11 @@ struct Epa {
       for (int j = 0; j < PER_LANE; ++j) {
         const int f = Grp::lane() + j * Grp::W;
         const V3<T> v = vw(t[j].vid(0));
-        const bool in_play = f < nf && (t[j].flag() & 1) && f != closest;
-        if (in_play && !(dot(mk<T>(pl[j].x, pl[j].y, pl[j].z), ww - v) < dummy_precision)) set_pass(f, pass);
+        const bool in_play = (f < nf) & ((t[j].flag() & 1) != 0) & (f != closest);
+        const bool mark = in_play & !(dot(mk<T>(pl[j].x, pl[j].y, pl[j].z), ww - v) < dummy_precision);
+        // set_pass(f, pass) where `mark`; elsewhere a store into the vertex tables, which are initialised just below (no branch per face)
+        // (the same lane initialises that byte of the tables right below)
+        *(mark ? topo_bytes(m->ft[f < nf ? f : 0], 1) + 3 : start_at + Grp::lane()) = uint8_t(pass);
       }
     }
     for (int v = Grp::lane(); v < 2 * Block::NV; v += Grp::W) start_at[v] = 255;

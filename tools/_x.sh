@@ -3,10 +3,9 @@ run() { python bench.py --workload $1 --steps 20 --warmup 4 --no-cpu-baseline 2>
 for rep in 1 2 3; do
 for v in before base; do
   if [ $v = base ]; then unset HFCL_LIB_PATH; else export HFCL_LIB_PATH=$PWD/build/ab/lib_$v.so; fi
-  echo "== $v cfg3: $(run cfg3)   cfg5: $(run cfg5)  cfg2: $(run cfg2)"
+  echo "== $v cfg3: $(run cfg3)   cfg2f: $(run cfg2f)"
 done
 done
 unset HFCL_LIB_PATH
-timeout 1400 python -m pytest tests -q -m gpu 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_epa_ground_truth.py -q -m gpu 2>&1 | tail -3
 for s in 21 22; do timeout 200 python tools/epa_staged_check.py 1000000 $s 2>&1 | tail -1; done
-python tools/fp64_exactness.py 2>&1 | tail -3 | cut -c1-200
