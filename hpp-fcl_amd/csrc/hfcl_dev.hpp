@@ -61,7 +61,9 @@ constexpr int CTR_SHAPE_DIST_TICKET = 2 * B_COUNT + 9;  // ticket of k_bvh_shape
 constexpr int CTR_EPA_CC_OVER = 2 * B_COUNT + 10;  // convex x convex polytopes k_epa_loop saved for k_epa_resume_cc
 constexpr int CTR_SHAPE_FINISH_OVER = 2 * B_COUNT + 11;  // [+0, +1] mesh x solid EPA leaves that outgrew k_bvh_shape_finish's fast block (the two halves of Work::shape_finish_over)
 constexpr int CTR_SHAPE_DEFER_MARK = 2 * B_COUNT + 13;   // CTR_SHAPE_DEFER as the first launch of k_bvh_shape_coop left it: the items of whole walks (k_bvh_level_mark)
-constexpr int N_COUNTERS = 2 * B_COUNT + 14;  // bucket populations + the four counters of Work::counts + curved populations + those
+// walks the pooled distance() continuations walked again in the reference's order (BvhSpill::rerun_count): mesh x mesh, mesh x solid
+constexpr int CTR_DIST_RERUN = 2 * B_COUNT + 14, CTR_SHAPE_DIST_RERUN = 2 * B_COUNT + 15;
+constexpr int N_COUNTERS = 2 * B_COUNT + 16;  // bucket populations + the four counters of Work::counts + curved populations + those
 
 // Classification-only kind code of a ConvexBase with more than 32 vertices (the reference switches
 // support algorithm there, minkowski_difference.cpp:136-151): GJK pairs with such a hull go to
@@ -736,6 +738,12 @@ struct BvhSpill {
   uint32_t pool;
   uint32_t* pool_ticket;
   uint32_t pool_leaf_min, pool_starve, pool_part_min;  // its scheduling knobs
+  // The pooled continuations evaluate a walk's entries out of the reference's order.  Their result is the sequential walk's unless a
+  // pair that set the minimum stands under a bound that exceeds its own distance (the rounding of two different computations: an ulp of
+  // the scene's size).  Such a walk is not written: its slot takes the suspended record again and walks it in the reference's order
+  // (the "ordered" mode of the pool kernels), bounded by what the pooled pass found.  Non-null = enabled; counts those walks.
+  uint32_t* rerun_count;
+  uint32_t rerun_all;  // (test knob) every pooled walk is walked again in order
 };
 constexpr int BVH_MAX_LEVELS = 12;  // most task levels a batch can be given (HFCL_BVH_LEVELS, the automatic choice)
 #ifndef HFCL_BVH_LEVELS
@@ -790,6 +798,11 @@ constexpr int BS_STACK = 128;
 // entries: models up to 19 levels deep (5 000 triangles: 16); deeper ones take the wide form with its global slabs.
 constexpr int BVHD_STACK = 40;
 constexpr int BVHD_BLOCK = 64;   // k_bvh_distance
+// The pooled distance() continuations keep, per stack entry, the largest bound among the entry's ancestors where it exceeds the entry's own
+// (0: none does) as a float rounded UP: an upper estimate, exact in the case that matters (an entry whose own bound is the largest of its
+// chain).  (In 16 bits -- 0.8 % above -- half of cfg4d's walks are flagged, profiles/r06_a.)
+__device__ __forceinline__ float chain_up(double d) { return __double2float_ru(d); }
+__device__ __forceinline__ float chain_up(float d) { return d; }
 template <typename T>
 struct ShapeDistSusp {  // a suspended mesh x solid distance() walk (the witness of the minimum is in the query's record)
   uint32_t pair, sp;

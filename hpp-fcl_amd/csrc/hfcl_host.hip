@@ -147,6 +147,7 @@ struct hfcl_lib {
   uint32_t bvhd_pool_leaf_min = 24, bvhd_pool_starve = 32, bvhd_pool_part_min = 48;  // HFCL_BVHD_LEAF_MIN / HFCL_BVHD_STARVE / HFCL_BVHD_PART_MIN
   void* d_dist_susp = nullptr;    // DistSusp<double>[dist_susp_capacity]
   size_t dist_susp_capacity = 0;
+  uint32_t pool_rerun = 1;          // HFCL_POOL_RERUN: pooled distance() walks whose result could hang on a rounding error are walked again in order (0: never -- the round-5 behaviour; 2: every walk, a test of the ordered mode)
   uint32_t shape_dist_pool = 1;     // HFCL_SHAPE_DIST_POOL: mesh x solid distance() walks past the budget continue in k_bvh_shape_distance_pool (0: k_bvh_shape_distance_coop)
   uint32_t shape_dist_leaf_min = 48, shape_dist_starve = 16;  // HFCL_SHAPE_DIST_LEAF_MIN / HFCL_SHAPE_DIST_STARVE (a GJK pass is worth waiting for: profiles/r04_i)
   uint32_t shape_dist_budget = 64;  // HFCL_SHAPE_DIST_BUDGET: the same for mesh x solid (a GJK leaf counts 16 steps; k_bvh_shape_distance_coop)
@@ -490,6 +491,7 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_BVHD_BUDGET")) lib->bvhd_budget = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_BVHD_POOL")) lib->bvhd_pool = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_DIST_POOL")) lib->shape_dist_pool = uint32_t(std::max(0, atoi(v)));
+  if (const char* v = getenv("HFCL_POOL_RERUN")) lib->pool_rerun = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_DIST_LEAF_MIN")) lib->shape_dist_leaf_min = uint32_t(std::max(1, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_DIST_STARVE")) lib->shape_dist_starve = uint32_t(std::max(1, atoi(v)));  // (>= 1: a window of triangles alone must always run)
   if (const char* v = getenv("HFCL_BVHD_LEAF_MIN")) lib->bvhd_pool_leaf_min = uint32_t(std::max(1, atoi(v)));
@@ -1330,6 +1332,8 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
             lib->shape_dist_susp_capacity = lib->ws_capacity;
           }
           ss.susp = lib->d_shape_dist_susp;
+          ss.rerun_count = lib->pool_rerun ? lib->d_counts + CTR_SHAPE_DIST_RERUN : nullptr;
+          ss.rerun_all = lib->pool_rerun >= 2 ? 1u : 0u;
           ss.susp_count = lib->d_counts + CTR_SHAPE_DIST_SUSP;
           ss.budget = lib->shape_dist_budget;
           ss.max_blocks = uint32_t(lib->n_cus) * 8u;
@@ -1353,6 +1357,8 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
           lib->dist_susp_capacity = lib->ws_capacity;
         }
         spill.susp = lib->d_dist_susp;
+        spill.rerun_count = lib->pool_rerun ? lib->d_counts + CTR_DIST_RERUN : nullptr;
+        spill.rerun_all = lib->pool_rerun >= 2 ? 1u : 0u;
         spill.susp_count = lib->d_counts + CTR_DIST_SUSP;
         spill.budget = lib->bvhd_budget;
         spill.max_blocks = uint32_t(lib->n_cus) * 8u;
@@ -2361,6 +2367,28 @@ void hfcl_last_bucket_counts(hfcl_lib* lib, uint32_t* out12) {  // B_COUNT bucke
     hipDeviceSynchronize();
   }
   for (int i = 0; i <= B_COUNT + 1; ++i) out12[i] = lib ? total_count(lib, i) : 0;
+}
+
+// Walks of the last distance() batch that the pooled continuations walked again in the reference's order (BvhSpill::rerun_count): out4 = mesh x mesh
+// walks continued by waves, of those re-run in order; the same two for mesh x solid.  Waits for the device like hfcl_last_bucket_counts.
+void hfcl_last_ordered_reruns(hfcl_lib* lib, uint32_t* out4) {
+  static const int idx[4] = {CTR_DIST_SUSP, CTR_DIST_RERUN, CTR_SHAPE_DIST_SUSP, CTR_SHAPE_DIST_RERUN};
+  if (lib) {
+    hipSetDevice(lib->device);
+    hipDeviceSynchronize();
+  }
+  for (int k = 0; k < 4; ++k) {
+    uint32_t c = 0;
+    if (lib) {
+      if (lib->last_host)
+        c = lib->acc_counts[idx[k]];
+      else {
+        c = lib->h_counts ? lib->h_counts[idx[k]] : 0u;
+        if (lib->last_split && lib->helper && lib->helper->h_counts) c += lib->helper->h_counts[idx[k]];
+      }
+    }
+    out4[k] = c;
+  }
 }
 
 }  // extern "C"

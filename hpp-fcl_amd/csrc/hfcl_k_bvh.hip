@@ -2383,13 +2383,15 @@ k_bvh_shape_distance_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
 // lane runs the leaf once more to queue the EPA item (k_bvh_shape_finish writes the record), as k_bvh_shape_distance_coop does.
 // Suspended walks never hand a cached guess on and their final guess is not read (the host does not suspend those).
 // ---------------------------------------------------------------------------------------
-constexpr int SDP_Q = 4, SDP_SEG = 64 / SDP_Q, SDP_CAPW = 160, SDP_CAP = SDP_CAPW + BVHD_STACK + 8;
+// (124 entries before the windows narrow -- it was 160 --: with the chain word per entry the fp64 block is 20 288 B, eight waves per CU)
+constexpr int SDP_Q = 4, SDP_SEG = 64 / SDP_Q, SDP_CAPW = 124, SDP_CAP = SDP_CAPW + BVHD_STACK + 8;
 template <typename T>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhSpill spill) {
   constexpr int Q = SDP_Q, SEG = SDP_SEG;
   __shared__ uint32_t st_x[Q][SDP_CAP];  // bit 31: a triangle (bits 0-30 its id); else a mesh node whose first child is bits 0-30
   __shared__ T st_d[Q][SDP_CAP];
+  __shared__ float st_c[Q][SDP_CAP];  // the largest bound among the entry's ancestors where it exceeds the entry's own, rounded up (0: none; k_bvh_distance_pool)
   __shared__ T q_tf[Q][12];    // pose of the mesh (R rows, t): the R0, T0 of the bound
   __shared__ T q_rss[Q][15];   // the solid's RSS in the mesh frame's terms (RssQuery): axes, Tr, l0, l1, r
   __shared__ uint32_t q_ids[Q][6];  // pair, solid id, swapped, vert_off, tri_off, node_off
@@ -2414,22 +2416,32 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
   // `ended`: a triangle that ENDS the sequential walk at its turn has been found (p marks it): it asks for EPA (ended_epa), or its
   // leaf reported a negative distance without EPA (a closed form) while its bound is a number -- bounds are clamped at 0, so behind
   // such a triangle every bounded entry is skipped: the walk's result is the FIRST such triangle in DFS order, not the smallest value
-  bool active = false, exhausted = false, ended = false, ended_epa = false, overflow = false;
+  // `ordered`: the slot walks a flagged record again, in the reference's order (k_bvh_distance_pool, hfcl_k_bvhd.hip; below); `redo`: it is
+  // about to take that record again; `touched`: the ordered walk has set a minimum or ended (else the record's witness, which the pooled
+  // pass has overwritten, is evaluated again at the end)
+  bool active = false, exhausted = false, ended = false, ended_epa = false, overflow = false, flagged = false, ordered = false, redo = false, touched = false;
   int sp = 0, p = 0, fb1 = -1, end_prim = -1;
-  T mind = big, end_val = T(0), margin = T(0);
-  uint32_t pair = 0;
+  T mind = big, end_val = T(0), margin = T(0), pooled = T(0), cut = big;
+  uint32_t pair = 0, susp_it = 0;
   for (;;) {
-    const uint64_t idle = __ballot(!active && j == 0);
-    if (idle && !exhausted) {
-      const int n_need = __popcll(idle);
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(spill.pool_ticket, uint32_t(n_need));
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (base + uint32_t(n_need) >= n_susp) exhausted = true;
-      const uint32_t it = base + uint32_t(__popcll(idle & ((uint64_t(1) << (qs * SEG)) - 1)));
-      if (!active && it < n_susp) {
+    const uint64_t idle = __ballot(!active && !redo && j == 0);
+    const bool any_redo = __ballot(redo) != 0;
+    if ((idle && !exhausted) || any_redo) {
+      uint32_t it = n_susp;
+      if (idle && !exhausted) {
+        const int n_need = __popcll(idle);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(spill.pool_ticket, uint32_t(n_need));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + uint32_t(n_need) >= n_susp) exhausted = true;
+        it = base + uint32_t(__popcll(idle & ((uint64_t(1) << (qs * SEG)) - 1)));
+      }
+      if (redo) it = susp_it;  // the slot's own record once more
+      if ((!active && it < n_susp) || redo) {
         const ShapeDistSusp<T>* const r = reinterpret_cast<const ShapeDistSusp<T>*>(spill.susp) + it;
         pair = r->pair;
+        ordered = redo;
+        redo = touched = false;
         const uint32_t id1 = wk.shape1[pair], id2 = wk.shape2[pair];
         const bool swapped = lib.kinds[id1] != uint8_t(K_BVH);
         const DMesh m1 = bv.meshes[lib.shapes[swapped ? id2 : id1].bvh_index];
@@ -2440,29 +2452,50 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
         ended = ended_epa = false;
         end_prim = -1;
         overflow = false;
+        susp_it = it;
+        flagged = false;  // (the lane's minimum is one the sequential walk holds)
+        const RssQuery<T> rq0 = table[pair];
+        const Pose<T> ltf = load_pose(swapped ? io.tf2 : io.tf1, pair);
+        DNodeD<T> lS;
+        lS.axes = rq0.axes;
+        lS.Tr = rq0.Tr;
+        lS.l0 = rq0.l0;
+        lS.l1 = rq0.l1;
+        lS.r = rq0.r;
         // (not vectorised: hipcc 7.2's instruction selection dies on the masked gather the loop vectoriser makes of this loop)
 #pragma clang loop vectorize(disable) interleave(disable)
         for (int k = j; k < sp; k += SEG) {
           const uint32_t b = r->entry[k];
-          const int32_t fc = bv.dnodes[m1.node_off + b].first_child;
+          const DNodeD<T>* const mn = bv.dnodes + m1.node_off + b;
+          const int32_t fc = mn->first_child;
           st_x[qs][k] = fc < 0 ? (0x80000000u | uint32_t(-(fc + 1))) : uint32_t(fc);
-          st_d[qs][k] = r->bound[k];
+          // fp64: the exact bounds again (the lane's stack carries them rounded down to 32 bits); the root's -1 stays
+          T bk = r->bound[k];
+          if constexpr (sizeof(T) == 8) {
+            if (bk >= T(0)) bk = rss_lower_bound(ltf.R, ltf.t, lS, *mn);
+          }
+          st_d[qs][k] = bk;
+          st_c[qs][k] = 0.0f;  // (its ancestors were decided by the lane, in the reference's order)
         }
         {
           // what a bound may exceed a distance beneath it by: a few ulps of the scene's size (the solid's volume in the mesh's frame and
           // the mesh's root volume), as in k_bvh_distance_pool -- an entry IN FRONT of the minimum is kept within that margin
-          const RssQuery<T> rq0 = table[pair];
           const DNodeD<T>* const root = bv.dnodes + m1.node_off;
           const T scale = habs(rq0.Tr.x) + habs(rq0.Tr.y) + habs(rq0.Tr.z) + rq0.l0 + rq0.l1 + T(2) * rq0.r + habs(root->Tr.x) + habs(root->Tr.y) +
                           habs(root->Tr.z) + root->l0 + root->l1 + T(2) * root->r;
-          margin = T(4) * Lim<T>::eps() * scale;
+          margin = T(16) * Lim<T>::eps() * scale;
+          // ... and what a leaf's distance may fall short of the true one by: the supports of Box, Cone and Cylinder are inflated by 1e-10
+          // (support_functions.cpp:146,229,281: hfcl_shapes.hpp), so GJK measures to a solid that much larger than the one the bound is
+          // taken to -- a triangle 0.89 from a box had its leaf bound 2.9e-11 ABOVE its distance
+          const DShape<T> sd = lib.shapes[swapped ? id1 : id2];
+          if (sd.kind == K_BOX || sd.kind == K_CONE || sd.kind == K_CYLINDER) margin += T(2e-10) * (habs(sd.p0) + habs(sd.p1) + habs(sd.p2));
         }
         if (j == 0) {
-          const Pose<T> tfm = load_pose(swapped ? io.tf2 : io.tf1, pair);
+          const Pose<T>& tfm = ltf;
           T* o = q_tf[qs];
           o[0] = tfm.R.r0.x; o[1] = tfm.R.r0.y; o[2] = tfm.R.r0.z; o[3] = tfm.R.r1.x; o[4] = tfm.R.r1.y; o[5] = tfm.R.r1.z;
           o[6] = tfm.R.r2.x; o[7] = tfm.R.r2.y; o[8] = tfm.R.r2.z; o[9] = tfm.t.x; o[10] = tfm.t.y; o[11] = tfm.t.z;
-          const RssQuery<T> rq = table[pair];
+          const RssQuery<T>& rq = rq0;
           T* g = q_rss[qs];
           g[0] = rq.axes.r0.x; g[1] = rq.axes.r0.y; g[2] = rq.axes.r0.z; g[3] = rq.axes.r1.x; g[4] = rq.axes.r1.y; g[5] = rq.axes.r1.z;
           g[6] = rq.axes.r2.x; g[7] = rq.axes.r2.y; g[8] = rq.axes.r2.z; g[9] = rq.Tr.x; g[10] = rq.Tr.y; g[11] = rq.Tr.z;
@@ -2482,14 +2515,42 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
     const int idx = sp - 1 - j;
     uint32_t x = 0u;
     T db = big;
+    float ch = 0.0f;
     if (act) {
       x = st_x[qs][idx];
       db = st_d[qs][idx];
+      ch = st_c[qs][idx];
     }
     // behind a triangle that ends the walk nothing is visited; else canStop(bound) with the slot's minimum: behind the triangle of
     // the minimum the sequential walk's test, in front of it a tie is kept (k_bvh_distance_pool; NaN bounds never skip)
-    const bool alive = act && !(ended && idx < p) && !(db >= T(0) && (idx < p && !ended ? db >= mind : db > mind + margin));
-    const bool is_leaf = alive && (x >> 31) != 0u, split = alive && (x >> 31) == 0u;
+    // (ordered mode: what lies above the cut is gone, everything else is decided below)
+    const bool alive = act && (ordered ? !(db > cut) : !(ended && idx < p) && !(db >= T(0) && (idx < p && !ended ? db >= mind : db > mind + margin)));
+    bool is_leaf = alive && (x >> 31) != 0u, split = alive && (x >> 31) == 0u, held = false;
+    // ---- Ordered mode (k_bvh_distance_pool): a node whose bound is below the pooled minimum -- or 0: the sequential walk's minimum is
+    // positive until the walk ends -- is split by that walk whatever its minimum, and so here, wherever it stands; a node of the band
+    // between that and the cut is decided at the top of the stack only; the triangles in front of the slot's first node are evaluated
+    // together and applied in stack order (the scan below does that in either mode); everything else waits for its turn.
+    if (__ballot(ordered) != 0) {
+      const uint64_t boxm = __ballot(split) & segm;
+      const int f = boxm ? __ffsll((unsigned long long)boxm) - 1 - qs * SEG : SEG;
+      if (ordered) {
+        if (split && !(db < pooled || db <= T(0))) {
+          if (j == 0) {
+            if (db >= mind) split = false;  // canStop at its turn
+          } else {
+            split = false;
+            held = true;
+          }
+        } else if (is_leaf) {
+          if (j > f) {
+            is_leaf = false;  // behind a node: not its turn yet
+            held = true;
+          } else if (db >= T(0) && db >= mind) {
+            is_leaf = false;  // canStop with a minimum that is not above the one of its turn
+          }
+        }
+      }
+    }
     // ---- the children's bounds of every split node of the wave in one list
     const uint64_t smask = __ballot(split);
     const int ns = __popcll(smask), k2 = 2 * __popcll(smask & lt_mask);
@@ -2560,6 +2621,10 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
       // records in 20 000 box queries, profiles/r05_c).  A triangle that ends the walk (asks for EPA, or a negative closed-form
       // distance behind a bound) is the result if the walk reaches it; against the standing result a tie wins only in front of it.
       const bool ends = is_leaf && (to_epa || (val < T(0) && db >= T(0)));
+      // a bound of the triangle's chain above its distance (an ending triangle: above 0 -- the sequential walk's minimum is positive until
+      // the walk ends, so bounds of 0 never turn it away): the sequential walk may not have come here, the walk is re-run in order
+      const T chain = ch != 0.0f ? T(ch) : db;
+      const bool viol = is_leaf && chain > (ends ? T(0) : val);
       T run = mind;
       bool upd = false, stop = false;
       int win_min = -1, win_end = -1;
@@ -2571,12 +2636,12 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
           upd_at = upd;
           stop_at = stop;
         }
-        const bool leaf_s = __shfl(int(is_leaf), src) != 0, ends_s = __shfl(int(ends), src) != 0;
+        const bool leaf_s = __shfl(int(is_leaf), src) != 0, ends_s = __shfl(int(ends), src) != 0, viol_s = __shfl(int(viol), src) != 0;
         const T db_s = __shfl(db, src), val_s = __shfl(val, src);
         const int idx_s = sp - 1 - s;
         const bool visited = leaf_s && !stop && !(upd && db_s >= T(0) && db_s >= run);
         const bool take_end = visited && ends_s && (!ended || idx_s >= p);
-        const bool take_min = visited && !ends_s && !ended && (val_s < run || (val_s == run && !upd && idx_s >= p));
+        const bool take_min = visited && !ends_s && !ended && (val_s < run || (val_s == run && !upd && idx_s >= p && !ordered));
         if (take_min) {
           run = val_s;
           win_min = s;
@@ -2586,6 +2651,7 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
           win_end = s;
           stop = true;
         }
+        flagged = flagged || ((take_min || take_end) && viol_s);
       }
       const bool swapped = q_ids[qs][2] != 0u;
       bool w_epa = false;
@@ -2593,11 +2659,13 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
         mind = run;
         fb1 = __shfl(int(prim), qs * SEG + win_min);
         jw = win_min;
+        touched = true;
       }
       if (win_end >= 0) {
         const int src = qs * SEG + win_end;
         w_epa = __shfl(int(to_epa), src) != 0;
         ended = true;
+        touched = true;
         ended_epa = w_epa;
         end_prim = __shfl(int(prim), src);
         if (!w_epa) end_val = __shfl(val, src);
@@ -2611,18 +2679,25 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
     // ---- the windows written back, in order (a node behind a minimum of this pass that its bound does not beat, or behind a triangle
     // that ended the walk in this pass, is not split: the sequential walk skips it at its turn)
     const bool unsplit = split && (stop_at || (upd_at && db >= T(0) && db >= run_at));
-    const int cnt = (split && !unsplit) ? 2 : ((is_leaf && !do_leaves) ? 1 : 0);
+    const int cnt = (split && !unsplit) ? 2 : (((is_leaf && !do_leaves) || held) ? 1 : 0);
     const uint64_t m2b = __ballot(cnt == 2), m1b = __ballot(cnt == 1);
     const int pos = base_i + 2 * __popcll(m2b & deeper) + __popcll(m1b & deeper);
     if (cnt == 2) {
       const bool c_first = d2 < d1;  // the nearer child is visited first
+      // the children's chains: the parent's largest bound (its own, or what it inherited) where the child's own is below it
+      const T pc = ch != 0.0f ? T(ch) : db;
+      const float pcw = ch != 0.0f ? ch : chain_up(db);
+      const float ca = d1 >= pc ? 0.0f : pcw, cc = d2 >= pc ? 0.0f : pcw;
       st_x[qs][pos] = c_first ? xa : xc;
       st_d[qs][pos] = c_first ? d1 : d2;
+      st_c[qs][pos] = c_first ? ca : cc;
       st_x[qs][pos + 1] = c_first ? xc : xa;
       st_d[qs][pos + 1] = c_first ? d2 : d1;
+      st_c[qs][pos + 1] = c_first ? cc : ca;
     } else if (cnt == 1) {
       st_x[qs][pos] = x;
       st_d[qs][pos] = db;
+      st_c[qs][pos] = ch;
     }
     const uint64_t later_m = __ballot(act && (jw >= 0 ? j > jw : idx < p)) & segm;
     p = (jw >= 0 ? base_i : min(p, base_i)) + 2 * __popcll(m2b & later_m) + __popcll(m1b & later_m);
@@ -2631,19 +2706,35 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
       overflow = true;
       sp = 0;
     }
+    // ordered mode: a triangle that ends the walk has everything that is left behind it; and a minimum that has come down to the pooled one
+    // is the first the reference meets at the final distance -- nothing behind it replaces it
+    if (ordered && (ended || mind <= pooled)) sp = 0;
     sync();
     if (active && sp == 0) {  // this walk is over
-      if (j == 0) {
-        if (ended && ended_epa && !overflow) {
+      if ((flagged || spill.rerun_all) && !ordered && !overflow && spill.rerun_count) {
+        // not written: the slot takes the record again and walks it in the reference's order.  What the pooled pass found bounds that walk:
+        // no entry whose bound exceeds it by a multiple of the arithmetic's slack can hold the reference's triangle
+        pooled = ended ? T(0) : mind;
+        cut = pooled + T(64) * margin;
+        redo = true;
+        if (j == 0) atomicAdd(spill.rerun_count, 1u);
+      } else if (j == 0) {
+        const bool epa_item = ended && ended_epa && !overflow;
+        // the ordered walk has kept the minimum its record came with: that triangle's witness once more (the pooled pass wrote its own)
+        const bool witness_again = ordered && !touched && !overflow && fb1 >= 0;
+        if (epa_item || witness_again) {
           // the triangle that ended the walk: its leaf once more, with the EPA item (k_bvh_shape_finish writes the record)
           const uint32_t* c = q_ids[qs];
           const bool swapped = c[2] != 0u;
-          SolidLeafIn<T> in{bv.verts + 3 * size_t(c[3]), bv.tris + 3 * size_t(c[4] + uint32_t(end_prim)), lib.shapes, lib.verts,
-                            swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer),
-                            &wk.counts[CTR_SHAPE_DEFER], wk.shape_defer_cap, pair, c[1], uint32_t(end_prim), 0xFFFFFFFFu, 0u, mind, fb1};
+          const uint32_t again = uint32_t(epa_item ? end_prim : fb1);
+          SolidLeafIn<T> in{bv.verts + 3 * size_t(c[3]), bv.tris + 3 * size_t(c[4] + again), lib.shapes, lib.verts,
+                            swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, epa_item ? reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer) : nullptr,
+                            epa_item ? &wk.counts[CTR_SHAPE_DEFER] : nullptr, epa_item ? wk.shape_defer_cap : 0u, pair, c[1], again, 0xFFFFFFFFu, 0u, epa_item ? mind : T(0), epa_item ? fb1 : -1};
           SolidLeafOut<T> lo;
-          solid_leaf_call<T>(in, &q, leaf_ps, initial_guess<T>(io, q, pair), &lo);
-        } else {
+          const bool deferred = solid_leaf_call<T>(in, &q, leaf_ps, initial_guess<T>(io, q, pair), &lo);
+          if (!epa_item && !deferred) store_witness(io, pair, swapped ? lo.p2 : lo.p1, swapped ? lo.p1 : lo.p2, swapped ? -lo.n : lo.n);
+        }
+        if (!epa_item) {
           // b1 = the triangle, b2 = NONE whatever the operand order (distance.cpp:84-88 swaps o1 / o2 only)
           const T dist = ended && !overflow ? end_val : mind;
           store_bvh_record_head(io, pair, dist, dist <= T(0) ? 0x80000000u : 0u, ended && !overflow ? end_prim : fb1, -1, overflow);
@@ -2651,6 +2742,7 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
         }
       }
       active = false;
+      ordered = false;
     }
   }
 }

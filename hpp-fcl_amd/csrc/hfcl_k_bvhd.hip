@@ -443,13 +443,21 @@ k_bvh_distance_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, BvhSpill s
 // by counting what the entries behind the marker became.  The lane phase hands a walk over with everything on its stack
 // behind its minimum (p = sp).  Measured (profiles/r04_c): the oracle's distance, triangle ids and witness points, bit for bit,
 // in 100 000 of 100 000 cfg4d queries; 95 % of the separated queries have several triangle pairs at exactly the minimal
-// distance (shared vertices), so the marker is what decides the reported ids.  What the rule cannot reproduce is a walk whose
-// choice hangs on a bound that exceeds a distance below it by an ulp AND on the minimum the sequential walk holds at that entry's
-// turn: an entry in front of the minimum is kept within a margin of 4 eps of the scene's size (the slack of the arithmetic), and
-// within that margin the sequential walk may have kept it (a larger minimum at its turn: one query in 20 000 without the margin) or
-// dropped it (a minimum an ulp below the bound: one in 450 000 with a margin 64x as wide); none in 2.1 M queries at present
-// (profiles/r04_c section 3b).  Which walks share a wave decides the order of the evaluations, so such a record can also differ
-// between two runs; the tests enumerate the class instead of asserting byte equality over it.
+// distance (shared vertices), so the marker is what decides the reported ids.
+//
+// Verification (round 6).  The rule stands on one premise: a bound never exceeds a distance beneath it.  In floating point it does, by
+// an ulp of the scene's size (rectDistance against sqrTriDistance), and then the sequential walk may DROP an entry -- its bound against
+// the minimum it holds at that entry's turn -- that the pool, which cannot know that minimum for entries in front of its own, keeps: the
+// pool then reports a pair the reference never visits (one query in 20 000 without the `margin` below, one in 450 000 with a wide one).
+// Any such case needs a triangle pair that sets the slot's minimum while standing under a bound -- its own or an ancestor's, the
+// hierarchy's bounds are not monotone -- ABOVE its distance (else every entry of its chain passes the sequential walk's test whatever
+// the minimum).  Every entry therefore carries the largest bound of its chain (`st_c`); a walk in which a pair with such a chain sets
+// the minimum is `flagged` and, instead of being written, walked AGAIN by its slot from the suspended record in "ordered" mode: the
+// pooled minimum tells which box pairs the sequential walk splits whatever its minimum (bound below it: split wherever they stand, in
+// parallel) and beyond which bound nothing matters (`cut`); the few entries between, and every triangle pair, are decided at their turn
+// with the minimum of that turn; the walk stops at the first pair that reaches the pooled minimum.  0.6 % of cfg4d's walks at 0.5 % of
+// the kernel's time; every byte of every record equal to the lanes' sequential walk (tools/distance_order_soak.py; HFCL_POOL_RERUN=2
+// sends every walk through the ordered mode, = 0 is the round-5 behaviour).
 // ---------------------------------------------------------------------------------------
 #ifndef HFCL_POOL_Q
 #define HFCL_POOL_Q 4
@@ -465,8 +473,14 @@ static_assert(POOL_E >= 1 && POOL_E <= 3, "per-lane counts travel as three ballo
 #ifndef HFCL_POOL_CAPW
 #define HFCL_POOL_CAPW (640 / HFCL_POOL_Q)
 #endif
+#ifndef HFCL_POOL_CAPW8
+#define HFCL_POOL_CAPW8 72
+#endif
 constexpr int POOL_CAPW = HFCL_POOL_CAPW;
-constexpr int POOL_BIG_BATCH = 400000;  // queries from which a wave takes 8 walks instead of POOL_Q
+#ifndef HFCL_POOL_BIG_BATCH
+#define HFCL_POOL_BIG_BATCH 400000
+#endif
+constexpr int POOL_BIG_BATCH = HFCL_POOL_BIG_BATCH;  // queries from which a wave takes 8 walks instead of POOL_Q
 #ifndef HFCL_POOL_ROUNDS
 #define HFCL_POOL_ROUNDS 2
 #endif
@@ -523,9 +537,18 @@ __device__ unsigned long long pool_prof[16];
 template <typename T, int PQ>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVHD_POOL, 8))) k_bvh_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, BvhSpill spill) {
   constexpr int Q = PQ, SEG = 64 / PQ;
-  constexpr int CAPW = PQ == POOL_Q ? POOL_CAPW : 832 / PQ, CAP = CAPW + BVHD_STACK + 8;
+  // (PQ = 8: 72 entries before the windows narrow -- it was 104 --: with the chain word per entry the block is 20 320 B, eight waves per CU.
+  // 1M queries 183 -> 198 ms; more entries at 7 or 6 waves per CU: 215 / 239 ms; the chain in 16 bits -- 90 entries -- flags half the walks:
+  // 228 ms; four walks per wave at this size: 201 ms.  profiles/r06_a)
+  constexpr int CAPW = PQ == POOL_Q ? POOL_CAPW : HFCL_POOL_CAPW8, CAP = CAPW + BVHD_STACK + 8;
   __shared__ uint32_t st_x[Q][CAP];
   __shared__ T st_d[Q][CAP];
+  // The largest bound among an entry's ancestors (since the walk came to the pool) where it exceeds the entry's own: 0 = none does, else that
+  // bound rounded UP to a float (bounds of a hierarchy are not monotone, and the sequential walk drops a subtree on its ROOT's bound).  Read
+  // when a triangle pair becomes the slot's minimum: if the chain's largest bound exceeds the pair's distance -- the roundings of
+  // rectDistance and sqrTriDistance, an ulp of the scene's size -- the sequential walk may never have come to this pair, and the walk is
+  // re-run in order (BvhSpill::flag_list).
+  __shared__ float st_c[Q][CAP];
   __shared__ T q_rt[Q][12];   // RT_R (row-major), RT_T of the slot's query
   __shared__ T q_wit[Q][6];   // witness points of the slot's minimum, model-1 frame
   __shared__ int q_fb[Q][2];
@@ -559,27 +582,37 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
   };
   auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
   // slot state, identical in the SEG lanes of a slot
-  bool active = false, exhausted = false;
+  // ordered: the slot walks a flagged record again, in the reference's order (below); redo: it is about to take that record again
+  bool active = false, exhausted = false, flagged = false, ordered = false, redo = false;
   int sp = 0, p = 0;
-  T mind = big, margin = T(0);
-  uint32_t pair = 0, off1 = 0, off2 = 0;
+  T mind = big, margin = T(0), pooled = T(0), cut = big;
+  uint32_t pair = 0, off1 = 0, off2 = 0, susp_it = 0;
   DMesh m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
 #ifdef HFCL_POOL_PROF
   unsigned long long tq_ = __builtin_readcyclecounter();
 #endif
   for (;;) {
     // ---- slots without a walk take the next suspended ones
-    const uint64_t idle = __ballot(!active && j == 0);
-    if (idle && !exhausted) {
-      const int n_need = __popcll(idle);
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(spill.pool_ticket, uint32_t(n_need));
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (base + uint32_t(n_need) >= n_susp) exhausted = true;
-      const uint32_t it = base + uint32_t(__popcll(idle & ((uint64_t(1) << (q * SEG)) - 1)));  // (bits of idle sit at the slots' first lanes)
-      if (!active && it < n_susp) {
+    const uint64_t idle = __ballot(!active && !redo && j == 0);
+    const bool any_redo = __ballot(redo) != 0;
+    if ((idle && !exhausted) || any_redo) {
+      uint32_t it = n_susp;
+      if (idle && !exhausted) {
+        const int n_need = __popcll(idle);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(spill.pool_ticket, uint32_t(n_need));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + uint32_t(n_need) >= n_susp) exhausted = true;
+        it = base + uint32_t(__popcll(idle & ((uint64_t(1) << (q * SEG)) - 1)));  // (bits of idle sit at the slots' first lanes)
+      }
+      if (redo) it = susp_it;  // the slot's own record once more
+      if ((!active && it < n_susp) || redo) {
         const DistSusp<T>* const r = reinterpret_cast<const DistSusp<T>*>(spill.susp) + it;
         pair = r->pair;
+        susp_it = it;
+        ordered = redo;
+        redo = false;
+        flagged = false;  // (the lane's minimum is one the sequential walk holds: the lane IS that walk up to here)
         m1 = bv.meshes[lib.shapes[wk.shape1[pair]].bvh_index];
         m2 = bv.meshes[lib.shapes[wk.shape2[pair]].bvh_index];
         off1 = m1.node_off;
@@ -587,33 +620,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
         sp = int(r->sp);
         p = sp;  // everything on the stack comes after what the lane has visited
         mind = r->mind;
+        const Pose<T> ltf1 = load_pose(io.tf1, pair), ltf2 = load_pose(io.tf2, pair);
+        const M3<T> lR = tmul(ltf1.R, ltf2.R);
+        const V3<T> lt = tmul(ltf1.R, ltf2.t - ltf1.t);
         {
           // what a bound may exceed a distance beneath it by: both are differences of coordinates of the size of the scene, so the
           // slack is a few ulps of THAT (the models' root volumes and their offset), not of the distance -- a pair 0.006 apart in a
           // scene of size 3 had its bound 81 eps of the distance above it (profiles/r04_c section 3)
           const DNodeD<T>* const a0 = bv.dnodes + off1;
           const DNodeD<T>* const b0 = bv.dnodes + off2;
-          const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
-          const V3<T> dt = tf2.t - tf1.t;
+          const V3<T> dt = ltf2.t - ltf1.t;
           const T scale = habs(dt.x) + habs(dt.y) + habs(dt.z) + a0->l0 + a0->l1 + T(2) * a0->r + habs(a0->Tr.x) + habs(a0->Tr.y) + habs(a0->Tr.z) +
                           b0->l0 + b0->l1 + T(2) * b0->r + habs(b0->Tr.x) + habs(b0->Tr.y) + habs(b0->Tr.z);
-          // (4 eps of the scene's size: ~80x the slack that was observed, 1.1e-16 in a scene of size ~10.  Not larger than needed:
-          // within the margin the rule can also go wrong the other way -- the sequential walk DROPS an entry in front whose bound
-          // exceeds the minimum it holds at that turn by an ulp, and with it a pair that ties the final minimum; seen once in 450 000
-          // queries with a margin 64x this one, profiles/r04_c section 3)
-          margin = T(4) * Lim<T>::eps() * scale;
+          // (16 eps of the scene's size: ~300x the slack that was observed, 1.1e-16 in a scene of size ~10.  Within the margin the rule
+          // can also go wrong the other way -- the sequential walk DROPS an entry in front whose bound exceeds the minimum it holds at
+          // that turn by an ulp, and with it a pair that ties the final minimum (seen once in 450 000 queries with a margin of 256 eps,
+          // profiles/r04_c section 3): those walks are the flagged ones, st_c)
+          margin = T(16) * Lim<T>::eps() * scale;
         }
         for (int k = j; k < sp; k += SEG) {
           const uint32_t e = r->entry[k];
           const DNodeD<T>* const a = bv.dnodes + off1 + (e & 0xFFFFu);
           const DNodeD<T>* const b = bv.dnodes + off2 + (e >> 16);
           st_x[q][k] = pool_entry_info(e & 0xFFFFu, a->first_child, a->rank, e >> 16, b->first_child, b->rank);
-          st_d[q][k] = r->bound[k];
+          // fp64: the lane's stack carries the bounds rounded down to 32 bits; here they are the exact values again (the same inputs, the
+          // same operations), which is what the chain test compares distances with (the root's -1 stays)
+          T bk = r->bound[k];
+          if constexpr (sizeof(T) == 8) {
+            if (bk >= T(0)) bk = rss_lower_bound(lR, lt, *a, *b);
+          }
+          st_d[q][k] = bk;
+          st_c[q][k] = 0.0f;  // (its ancestors were decided by the lane, in the reference's order)
         }
         if (j == 0) {
-          const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
-          const M3<T> R = tmul(tf1.R, tf2.R);
-          const V3<T> t = tmul(tf1.R, tf2.t - tf1.t);
+          const M3<T>& R = lR;
+          const V3<T>& t = lt;
           T* o = q_rt[q];
           o[0] = R.r0.x; o[1] = R.r0.y; o[2] = R.r0.z; o[3] = R.r1.x; o[4] = R.r1.y; o[5] = R.r1.z;
           o[6] = R.r2.x; o[7] = R.r2.y; o[8] = R.r2.z; o[9] = t.x; o[10] = t.y; o[11] = t.z;
@@ -635,6 +676,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
     const int base_i = sp - w;
     uint32_t x[E];
     T db[E];
+    float ch[E];
     int idx[E];
     bool is_leaf[E], split[E], held[E];
     int ns_l = 0, nl_l = 0;
@@ -645,19 +687,56 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
       idx[u] = sp - 1 - wj;
       x[u] = 0u;
       db[u] = big;
+      ch[u] = 0.0f;
       if (act) {
         x[u] = st_x[q][idx[u]];
         db[u] = st_d[q][idx[u]];
+        ch[u] = st_c[q][idx[u]];
       }
       // canStop(bound) with the slot's minimum.  Behind the pair that set the minimum (idx < p) this is the sequential walk's
       // test at the entry's turn.  In front of it the sequential walk held a larger minimum at the entry's turn, and a bound
       // can exceed a distance below it by an ulp (a leaf pair's rectangles against its triangles): such an entry may hold
       // the first pair at the minimal distance, so entries in front are only dropped when their bound is clear of the minimum
       // by `margin` (4 eps of the scene's size, set when the slot takes the walk)
-      const bool alive = act && !(db[u] >= T(0) && (idx[u] < p ? db[u] >= mind : db[u] > mind + margin));
+      // (ordered mode: what lies above the cut is gone, everything else is decided below)
+      const bool alive = act && (ordered ? !(db[u] > cut) : !(db[u] >= T(0) && (idx[u] < p ? db[u] >= mind : db[u] > mind + margin)));
       held[u] = false;
       is_leaf[u] = alive && (x[u] >> 31) != 0u;
       split[u] = alive && (x[u] >> 31) == 0u;
+    }
+    // ---- Ordered mode (a flagged walk, again from its record): the reference's decisions, each at its turn.  The pooled pass left two
+    // numbers: `pooled`, its minimum -- no triangle pair the sequential walk visits lies below it, so a box pair whose bound is below
+    // it is split by that walk whatever minimum it holds at its turn: those are split here wherever they stand --, and `cut` above it,
+    // beyond which nothing matters.  What lies between (a handful of entries) hangs on the minimum of ITS turn, and so does every
+    // triangle pair: a box pair of the band is decided only at the top of the stack, the triangle pairs in front of the first box pair
+    // of the window are evaluated together and applied in stack order (as k_bvh_distance_coop does), everything else waits.  The
+    // minimum is then the sequential walk's at every decision, and the walk is over as soon as it reaches `pooled`: that pair is the
+    // first the reference meets at the final distance.
+    if constexpr (E == 1) {
+      if (__ballot(ordered) != 0) {
+        const uint64_t boxm = __ballot(split[0]) & segm;
+        const int f = boxm ? __ffsll((unsigned long long)boxm) - 1 - q * SEG : SEG;  // the slot's first box pair from the top
+        if (ordered) {
+          if (split[0] && !(db[0] < pooled)) {  // a box pair of the band
+            if (j == 0) {
+              if (db[0] >= mind) split[0] = false;  // canStop at its turn: gone
+            } else {
+              split[0] = false;
+              held[0] = true;
+            }
+          } else if (is_leaf[0]) {
+            if (j > f) {
+              is_leaf[0] = false;  // behind a box pair: not its turn yet
+              held[0] = true;
+            } else if (db[0] >= T(0) && db[0] >= mind) {
+              is_leaf[0] = false;  // canStop with a minimum that is not above the one of its turn: gone
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
       ns_l += split[u] ? 1 : 0;
       nl_l += is_leaf[u] ? 1 : 0;
     }
@@ -823,6 +902,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
       // index 0 is the top of the stack), and against the standing minimum a tie wins only in front of it
       T bestv = big;
       int bw = 64 * E, bl = -1;  // window index and list index of the lane's / the slot's best candidate
+      int bviol = 0;             // ... and whether a bound of its chain exceeds its distance
 #pragma unroll
       for (int u = 0; u < E; ++u) {
         if (leaf_eval[u]) {
@@ -832,22 +912,53 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
             bestv = v;
             bw = j * E + u;
             bl = li[u];
+            bviol = (ch[u] != 0.0f ? T(ch[u]) > v : db[u] > v) ? 1 : 0;
           }
         }
       }
 #pragma unroll
       for (int m = 1; m < SEG; m <<= 1) {
         const T ov = __shfl_xor(bestv, m);
-        const int ow = __shfl_xor(bw, m), ol = __shfl_xor(bl, m);
+        const int ow = __shfl_xor(bw, m), ol = __shfl_xor(bl, m), oviol = __shfl_xor(bviol, m);
         if (ol >= 0 && (bl < 0 || ov < bestv || (ov == bestv && ow < bw))) {
           bestv = ov;
           bw = ow;
           bl = ol;
+          bviol = oviol;
+        }
+      }
+      if constexpr (E == 1) {
+        if (__ballot(ordered) != 0) {
+          // ordered mode: DistanceResult::update over the evaluated pairs in stack order -- a pair is visited if its bound is below the
+          // minimum of its turn, and lowers it only when strictly smaller
+          T run = mind;
+          int win = -1, winl = -1;
+          const T v0 = leaf_eval[0] ? l_val[li[0]] : big;
+          for (int s = 0; s < SEG; ++s) {
+            const int src = q * SEG + s;
+            const bool ev = __shfl(int(leaf_eval[0]), src) != 0;
+            const T vs = __shfl(v0, src), ds = __shfl(db[0], src);
+            const int ls = __shfl(li[0], src);
+            if (ev && !(ds >= T(0) && ds >= run) && vs < run) {
+              run = vs;
+              win = s;
+              winl = ls;
+            }
+          }
+          if (ordered) {
+            bestv = run;
+            bw = win;
+            bl = winl;
+            bviol = 0;
+          }
         }
       }
       if (bl >= 0) {
         jw = bw;
         mind = bestv;
+        // Every decision of the pool is the sequential walk's as long as the pair of the minimum is one that walk visits, or at least
+        // stands under no bound above its own distance (then the minimum the sequential walk holds behind it is not larger).  Otherwise:
+        flagged = flagged || bviol != 0;
         if (j == 0) q_win[q] = bl;
       }
       sync();
@@ -873,8 +984,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
       keep_a[u] = keep_c[u] = split[u];
 #if HFCL_POOL_DROP_DEAD
       if (split[u]) {
-        keep_a[u] = !(later ? d1[u] >= mind : d1[u] > mind + margin);
-        keep_c[u] = !(later ? d2[u] >= mind : d2[u] > mind + margin);
+        keep_a[u] = ordered ? !(d1[u] > cut) : !(later ? d1[u] >= mind : d1[u] > mind + margin);
+        keep_c[u] = ordered ? !(d2[u] > cut) : !(later ? d2[u] >= mind : d2[u] > mind + margin);
       }
 #endif
       cnt[u] = split[u] ? (keep_a[u] ? 1 : 0) + (keep_c[u] ? 1 : 0) : (((is_leaf[u] && !leaf_eval[u]) || held[u]) ? 1 : 0);
@@ -887,19 +998,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
       for (int u = E - 1; u >= 0; --u) {
         if (split[u]) {
           const bool c_first = d2[u] < d1[u];  // visit (c1, c2) first when it is strictly nearer: the other one lies deeper
+          // the children's chains: the parent's largest bound (its own, or what it inherited) where the child's own is below it
+          const T pc = ch[u] != 0.0f ? T(ch[u]) : db[u];
+          const float pcw = ch[u] != 0.0f ? ch[u] : chain_up(db[u]);
+          const float ca = d1[u] >= pc ? 0.0f : pcw, cc = d2[u] >= pc ? 0.0f : pcw;
           int at = pos;
           if (c_first ? keep_a[u] : keep_c[u]) {
             st_x[q][at] = c_first ? xa[u] : xc[u];
             st_d[q][at] = c_first ? d1[u] : d2[u];
+            st_c[q][at] = c_first ? ca : cc;
             ++at;
           }
           if (c_first ? keep_c[u] : keep_a[u]) {
             st_x[q][at] = c_first ? xc[u] : xa[u];
             st_d[q][at] = c_first ? d2[u] : d1[u];
+            st_c[q][at] = c_first ? cc : ca;
           }
         } else if (cnt[u] == 1) {
           st_x[q][pos] = x[u];
           st_d[q][pos] = db[u];
+          st_c[q][pos] = ch[u];
         }
         pos += cnt[u];
       }
@@ -907,10 +1025,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
     // the marker: what stands behind the pair of the minimum now
     p = (jw >= 0 ? base_i : min(p, base_i)) + lane_sum(later_l, segm);
     sp = base_i + lane_sum(cnt_l, segm);
+    if (ordered && mind <= pooled) sp = 0;  // the first pair at the final distance in the reference's order: nothing behind it replaces it
     sync();
     POOL_T(3);
     if (active && sp == 0) {  // this walk is over
-      if (j == 0) {
+      if (E == 1 && (flagged || spill.rerun_all) && !ordered && spill.rerun_count) {
+        // not written: the slot takes the record again and walks it in the reference's order.  What the pooled pass found bounds that
+        // walk: the sequential minimum is not below this one and within the arithmetic's slack of it, so no entry whose bound exceeds
+        // it by a multiple of that slack can hold the reference's pair.
+        pooled = mind;
+        cut = mind + T(64) * margin;
+        redo = true;
+        if (j == 0) atomicAdd(spill.rerun_count, 1u);
+      } else if (j == 0) {
 #ifdef HFCL_POOL_PROF
         atomicAdd(&pool_prof[13], 1ull);
 #endif
@@ -927,6 +1054,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WP
         store_bvh_record(io, pair, o, mind <= T(0) ? 0x80000000u : 0u, q_fb[q][0], q_fb[q][1], false);
       }
       active = false;
+      ordered = false;
     }
   }
 }

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "hfcl_distance_batch_device", "hfcl_distance_batch_device_f32", "hfcl_collide_batch_device_f32", "hfcl_collide_batch_f32", "hfcl_distance_batch_f32",
     "hfcl_collide_batch_contacts", "hfcl_last_kernel_ms", "hfcl_last_kernel_name", "hfcl_bvh_build",
     "hfcl_world_aabbs", "hfcl_broadphase_self_pairs", "hfcl_broadphase_pairs_between", "hfcl_pairlist_size",
-    "hfcl_pairlist_data", "hfcl_pairlist_free", "hfcl_lib_set_kernel_timing", "hfcl_pair_supported", "hfcl_last_kernel_breakdown", "hfcl_last_bucket_counts", "hfcl_lib_set_split", "hfcl_lib_get_split", "hfcl_lib_last_split_parts",
+    "hfcl_pairlist_data", "hfcl_pairlist_free", "hfcl_lib_set_kernel_timing", "hfcl_pair_supported", "hfcl_last_kernel_breakdown", "hfcl_last_bucket_counts", "hfcl_last_ordered_reruns", "hfcl_lib_set_split", "hfcl_lib_get_split", "hfcl_lib_last_split_parts",
     "hfcl_collide_batch_qt", "hfcl_distance_batch_qt", "hfcl_lib_set_host_chunk", "hfcl_lib_set_shapes",
     "hfcl_lib_set_convex_neighbors", "hfcl_compact_results_device", "hfcl_compact_results_device_f32",
  "hfcl_shard_range", "hfcl_multi_create", "hfcl_multi_destroy", "hfcl_multi_size", "hfcl_multi_replica",
@@ -333,6 +333,13 @@ class Library:
         dll().hfcl_last_bucket_counts(self._h, out)
         keys = ["closed", "prim", "cc", "pc", "cp", "bvh", "unsupported", "large", "bvh_shape", "tri", "epa_queue", "epa_overflow"]
         return dict(zip(keys, [int(v) for v in out]))
+
+
+    def last_ordered_reruns(self):
+        """distance() on meshes, last call: walks a wave continued / of those re-run in the reference's order, mesh x mesh then mesh x solid."""
+        out = (C.c_uint32 * 4)()
+        dll().hfcl_last_ordered_reruns(self._h, out)
+        return dict(zip(["mesh_continued", "mesh_rerun", "solid_continued", "solid_rerun"], [int(v) for v in out]))
 
 
 def shard_range(n, rank, world):

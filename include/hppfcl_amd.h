@@ -156,14 +156,14 @@ typedef struct hfcl_result {
   uint32_t status;          /* packed, see above                                       */
   int32_t  num_contacts;    /* collide only                                            */
 } hfcl_result;              /* 96 bytes                                                */
-/* b1 / b2 of a mesh distance() record and ties.  Triangles that share the closest vertex or edge are at the minimal distance
- * bit for bit, and DistanceResult::update (collision_data.h:1099-1125) keeps the first the reference's walk meets.  The default
- * continuation kernels of long walks (several walks per wave, their tests pooled) reproduce that choice through a marker rule;
- * where the choice hangs on a bound that exceeds a distance beneath it by an ulp, they may report ANOTHER triangle (pair) at exactly
- * the same distance -- measured: 0 records in 2.1 M mesh x mesh queries, 4 in 300 000 mesh x solid queries -- and, mesh x mesh, which
- * one can differ between two runs (which walks share a wave depends on the order they are drawn in).  distance, status and the
- * witness points of records with equal ids do not depend on it.  HFCL_BVHD_POOL=0 / HFCL_SHAPE_DIST_POOL=0 select the ordered
- * continuation kernels, which have no such records (1.5-2x slower on long walks). */
+/* Mesh distance(): which triangle pair is reported.  Triangles that share the closest vertex or edge are at the minimal distance bit
+ * for bit, and DistanceResult::update (collision_data.h:1099-1125) keeps the first one the reference's walk (distanceRecurse,
+ * traversal_recurse.cpp:153-203) meets.  b1 / b2 are that pair, in every record and in every run: the default continuation kernels of long
+ * walks (several walks per wave, their tests pooled, evaluated out of the reference's order) reproduce the choice through a marker rule and
+ * verify it -- a walk whose reported pair stands under a bound that exceeds its own distance (a rounding error of the two computations,
+ * where the choice could depend on the minimum the sequential walk held at that very entry) is walked again inside the same kernel in the
+ * reference's order, ~0.6 % of cfg4d's walks at ~0.5 % of its time (hfcl_last_ordered_reruns counts them).  Measured: every byte of every
+ * record equal to the lanes' sequential walk in 1.5 M mesh x mesh and mesh x solid queries (tools/distance_order_soak.py). */
 
 /* Compact fp32 record for the fp32 device-resident path: 44 bytes.  It has NO b1 / b2: a BVHModel pair run through the
  * fp32 entry points reports its contact flag, distance, witness points and normal, not the triangle ids (Contact::b1 / b2,
@@ -417,6 +417,11 @@ int hfcl_last_kernel_breakdown(hfcl_lib* lib, const char** names, double* ms, in
  * bvh_shape, tri) followed by the two EPA queue lengths.  Waits for the device (the counters come back with an
  * asynchronous copy into pinned memory at the end of the batch). */
 void hfcl_last_bucket_counts(hfcl_lib* lib, uint32_t* out12);
+/* distance() on meshes: the walks of the last call that a wave continued (several walks per wave, their tests pooled) and, of those,
+ * the ones walked again in the reference's order because the pooled result could have hung on a bound that exceeds a distance beneath it
+ * by a rounding error (see "Mesh distance(): which triangle pair is reported" below).  out4 = {mesh x mesh continued, re-run,
+ * mesh x solid continued, re-run}.  Diagnostic; waits for the device. */
+void hfcl_last_ordered_reruns(hfcl_lib* lib, uint32_t* out4);
 /* Batches of >= 128k pairs (library without meshes) can run as two halves on two streams -- the caller's and an
  * internal one, forked and joined with events, so the call stays asynchronous and ordered on the caller's stream.
  * Pays when the halves run different kernels side by side (mixed scenes: -6 % per batch) and costs ~3 % when the

@@ -36,6 +36,7 @@ int bvh_shape_collide_pair(const MeshView& m1, const Tf& tf1, const Shape& s2, c
                            bool swapped, hfcl_result& out, std::vector<hfcl_contact>* contacts, uint32_t pair_index,
                            hfcl_guess* guess_out, BvhStats* stats);
 double bvh_shape_leaf_distance(const MeshView& m1, const Tf& tf1, const Shape& s2, const Tf& tf2, const hfcl_distance_request& req, int pid);
+size_t bvh_shape_distance_trace(const MeshView& m1, const Tf& tf1, const Shape& s2, const Tf& tf2, const hfcl_distance_request& req, double* out, size_t cap);
 int bvh_shape_distance_pair(const MeshView& m1, const Tf& tf1, const Shape& s2, const Tf& tf2, const hfcl_distance_request& req,
                             bool swapped, hfcl_result& out, hfcl_guess* guess_out);
 // computeBV<OBBRSS,S>(shape, tf): fit of the shape's bound vertices (geometric_shapes_utility.h:73-82)

@@ -426,6 +426,9 @@ struct MeshShapeDistTraversal {
   int b1 = -1;
   V3 np1, np2, normal;
   bool ok = true;
+  // (diagnostic, bvh_shape_distance_trace) one record of four numbers per event: a child's canStop test {0, node, bound, minimum at the
+  // test} and a triangle's evaluation {1, triangle, distance, minimum before it}
+  std::vector<double>* trace = nullptr;
   MeshShapeDistTraversal(const MeshView& a, const Tf& t1, const Shape& b, const Tf& t2, const hfcl_distance_request& r)
       : m1(a), tf1(t1), tf2(t2), s2(b), signed_distance(r.enable_signed_distance != 0) {
     const double nanv = std::numeric_limits<double>::quiet_NaN();
@@ -452,6 +455,7 @@ struct MeshShapeDistTraversal {
     solver.cached_guess = solver.out_cached_guess;
     solver.support_func_cached_guess[0] = solver.out_support_guess[0];
     solver.support_func_cached_guess[1] = solver.out_support_guess[1];
+    if (trace) trace->insert(trace->end(), {1.0, double(pid), d, min_distance});
     if (min_distance > d) {  // DistanceResult::update (collision_data.h:1115-1160)
       min_distance = d;
       b1 = pid;
@@ -470,12 +474,16 @@ struct MeshShapeDistTraversal {
     }
     const unsigned a1 = unsigned(n1.first_child), c1 = a1 + 1;
     const double d1 = lower_bound(a1), d2 = lower_bound(c1);
+    auto visit = [&](unsigned c, double d) {
+      if (trace) trace->insert(trace->end(), {0.0, double(c), d, min_distance});
+      if (!can_stop(d)) recurse(c);
+    };
     if (d2 < d1) {
-      if (!can_stop(d2)) recurse(c1);
-      if (!can_stop(d1)) recurse(a1);
+      visit(c1, d2);
+      visit(a1, d1);
     } else {
-      if (!can_stop(d1)) recurse(a1);
-      if (!can_stop(d2)) recurse(c1);
+      visit(a1, d1);
+      visit(c1, d2);
     }
   }
 };
@@ -487,6 +495,19 @@ double bvh_shape_leaf_distance(const MeshView& m1, const Tf& tf1, const Shape& s
   MeshShapeDistTraversal t(m1, tf1, s2, tf2, req);
   t.leaf(pid);
   return t.ok ? t.min_distance : std::numeric_limits<double>::quiet_NaN();
+}
+
+// (diagnostic) the events of one query's walk, four numbers each (MeshShapeDistTraversal::trace); returns the number of events
+size_t bvh_shape_distance_trace(const MeshView& m1, const Tf& tf1, const Shape& s2, const Tf& tf2, const hfcl_distance_request& req, double* out, size_t cap) {
+  MeshShapeDistTraversal t(m1, tf1, s2, tf2, req);
+  if (shape_obbrss(s2, tf2, t.bv2)) return 0;
+  std::vector<double> ev;
+  t.trace = &ev;
+  t.leaf(0);
+  if (t.ok) t.recurse(0);
+  const size_t n = ev.size() / 4;
+  for (size_t k = 0; k < std::min(n, cap) * 4; ++k) out[k] = ev[k];
+  return n;
 }
 
 int bvh_shape_distance_pair(const MeshView& m1, const Tf& tf1, const Shape& s2, const Tf& tf2, const hfcl_distance_request& req,

@@ -360,6 +360,23 @@ double orc_mixed_leaf_distance(const hfcl_shape* shapes, size_t n_shapes, const 
   return ma ? bvh_shape_leaf_distance(mv, t1, solid, t2, *req, pid) : bvh_shape_leaf_distance(mv, t2, solid, t1, *req, pid);
 }
 
+// (diagnostic) the walk of ONE (mesh, solid) distance() query, event by event (bvh_shape_distance_trace)
+size_t orc_mixed_distance_trace(const hfcl_shape* shapes, const double* shape_verts, const hfcl_bvh_node* nodes, const double* mesh_verts,
+                                const uint32_t* tris, const uint64_t* mesh_table, uint32_t s1, uint32_t s2, const double* tf1, const double* tf2,
+                                const hfcl_distance_request* req, double* out, size_t cap) {
+  const hfcl_shape &a = shapes[s1], &c = shapes[s2];
+  const bool ma = a.type == HFCL_BV_OBBRSS;
+  const hfcl_shape& msh = ma ? a : c;
+  MeshView mv;
+  mv.nodes = nodes + mesh_table[4 * size_t(msh.bvh_index)];
+  mv.n_nodes = mesh_table[4 * size_t(msh.bvh_index) + 1];
+  mv.verts = mesh_verts + 3 * mesh_table[4 * size_t(msh.bvh_index) + 2];
+  mv.tris = tris + 3 * mesh_table[4 * size_t(msh.bvh_index) + 3];
+  const Shape solid = make_shape(ma ? c : a, shape_verts);
+  const Tf t1 = tf_from_abi(tf1), t2 = tf_from_abi(tf2);
+  return ma ? bvh_shape_distance_trace(mv, t1, solid, t2, *req, out, cap) : bvh_shape_distance_trace(mv, t2, solid, t1, *req, out, cap);
+}
+
 // BVHModel<OBBRSS> x BVHModel<OBBRSS> distance(); same mesh table as orc_bvh_collide_batch.
 int orc_bvh_distance_batch(const hfcl_bvh_node* nodes, const double* verts, const uint32_t* tris,
                            const uint64_t* mesh_table, size_t n_meshes, const uint32_t* m1, const uint32_t* m2,

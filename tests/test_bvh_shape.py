@@ -487,13 +487,14 @@ def test_device_headers_distance_match_oracle(pkg, oracle, hostsim, signed):
     assert _same(ggot["gjk_guess"], gref["gjk_guess"], 1e-11)
 
 
-def _check_shape_distance_records(pkg, oracle, ML, b, got, ref, what, req=None, max_ties=0.002):
+def _check_shape_distance_records(pkg, oracle, ML, b, got, ref, what, req=None, max_ties=0):
     """mesh x solid distance() records of the device against the oracle's.  The kernels are built without contraction
-    (hfcl_k_bvhs.o), i.e. with the reference's arithmetic: statuses and distances EQUAL in every record, the triangle id EQUAL --
-    except on records, enumerated here, whose reported triangle is at the oracle's distance bit for bit as well (triangles that share
-    the closest vertex or edge; DistanceResult::update keeps the first, /root/reference/include/hpp/fcl/collision_data.h:1099-1125,
-    and which one a walk meets first hangs on bounds an ulp apart) --, witness points and normal of records with equal ids to 1e-12
-    (their last step is summed in another order than the oracle's)."""
+    (hfcl_k_bvhs.o), i.e. with the reference's arithmetic: statuses and distances EQUAL in every record, the triangle id EQUAL
+    (max_ties = 0: the default kernels -- DistanceResult::update keeps the first triangle at the minimal distance,
+    /root/reference/include/hpp/fcl/collision_data.h:1099-1125, and the pooled continuation hands every walk whose choice could hang
+    on a rounding error back to the ordered walk), witness points and normal to 1e-12 (their last step is summed in another order
+    than the oracle's).  max_ties > 0 (the wave-per-walk continuation HFCL_SHAPE_DIST_POOL=0 and the 16-lane group kernel only)
+    allows that share of records, enumerated here, whose reported triangle is at the oracle's distance bit for bit as well."""
     abi = pkg.abi
     kinds = b.shapes["type"]
     mixed = (kinds[b.s1] == abi.BV_OBBRSS) != (kinds[b.s2] == abi.BV_OBBRSS)
@@ -504,7 +505,8 @@ def _check_shape_distance_records(pkg, oracle, ML, b, got, ref, what, req=None, 
     assert (got["b2"][mixed] == -1).all()
     same = got["b1"] == ref["b1"]
     ties = np.flatnonzero(mixed & ~same)
-    assert len(ties) <= max(1, int(max_ties * mixed.sum())), "%s: %d records with another triangle id" % (what, len(ties))
+    allowed = max(1, int(max_ties * mixed.sum())) if max_ties else 0
+    assert len(ties) <= allowed, "%s: %d records with another triangle id: %s" % (what, len(ties), ties[:8])
     for k in ties:  # enumerated: the reported triangle is at the oracle's distance, bit for bit
         d = oracle.mixed_leaf_distance(b.shapes, b.verts, ML, b.s1[k], b.s2[k], b.tf1[k], b.tf2[k], got["b1"][k], req)
         assert d == ref["distance"][k], "%s: record %d reports triangle %d at %.17g, the oracle triangle %d at %.17g" % (
@@ -571,7 +573,8 @@ def test_gpu_mesh_solid_distance_long_walks(pkg, oracle, kind):
              "ordered-16": dict(HFCL_SHAPE_DIST_POOL="0", HFCL_SHAPE_DIST_BUDGET="16"), "lanes-only": dict(HFCL_SHAPE_DIST_BUDGET="0"),
              "group": dict(HFCL_BVH_SHAPE_LANE="0")}
     res = {name: _device_distance(pkg, b, req, env) for name, env in forms.items()}
-    ties = {name: _check_shape_distance_records(pkg, oracle, ML, b, r, ref, "%s/%s" % (kind, name), req) for name, r in res.items()}
+    ties = {name: _check_shape_distance_records(pkg, oracle, ML, b, r, ref, "%s/%s" % (kind, name), req,
+                                                max_ties=0.002 if name in ("ordered", "ordered-16", "group") else 0) for name, r in res.items()}
     base = res["lanes-only"]  # the sequential walk of one lane: the oracle's order of visits
     assert ties["lanes-only"] == 0
     for name, r in res.items():

@@ -657,17 +657,19 @@ def test_bvh_security_margin_and_mixed_batch(pkg, oracle):
     assert (got["num_contacts"] > 0).sum() >= (got0["num_contacts"] > 0).sum()
 
 
-def _check_distance_records(oracle, ML, b, got, ref, what, max_ties=0.001):
+def _check_distance_records(oracle, ML, b, got, ref, what, max_ties=0):
     """mesh x mesh distance() records against the oracle's: the distance to 0 ulp (the device unit is built without
-    contraction, as the oracle and the reference's default build), the triangle ids EQUAL -- except on records, enumerated
-    here, where the pair the device reports has exactly the oracle's distance too (two triangle pairs at 0 ulp: which of
-    them a walk reports then hangs on a bound that exceeds a distance below it by an ulp) --,
-    the witness points of records with equal ids to 0 ulp as well."""
+    contraction, as the oracle and the reference's default build), the triangle ids EQUAL (max_ties = 0: the default kernels, whose
+    pooled continuation hands every walk whose reported pair could hang on a rounding error back to the ordered walk), the witness
+    points to 0 ulp as well.  max_ties > 0 -- the wave-per-walk continuation HFCL_BVHD_POOL=0 only, which splits box pairs ahead of
+    their turn -- allows that share of records, enumerated here, where the pair the device reports has exactly the oracle's distance
+    too (two triangle pairs at 0 ulp: which of them a walk reports then hangs on a bound that exceeds a distance below it by an ulp)."""
     assert not np.any((got["status"] >> 30) & 1), what + ": traversal stack overflow"
     assert np.array_equal(got["distance"], ref["distance"]), what + ": distances differ from the oracle's"
     same = (got["b1"] == ref["b1"]) & (got["b2"] == ref["b2"])
     ties = np.where(~same)[0]
-    assert len(ties) <= max(1, int(max_ties * len(ref))), "%s: %d records with other triangle ids" % (what, len(ties))
+    allowed = max(1, int(max_ties * len(ref))) if max_ties else 0
+    assert len(ties) <= allowed, "%s: %d records with other triangle ids: %s" % (what, len(ties), ties[:8])
     for k in ties:  # enumerated: the reported pair is at the oracle's minimal distance, bit for bit
         d = oracle.bvh_leaf_distance(ML, b.s1[k], b.s2[k], b.tf1[k], b.tf2[k], got["b1"][k], got["b2"][k])
         assert d == ref["distance"][k], "%s: record %d reports pair (%d, %d) at %.17g, the minimum is %.17g" % (
@@ -719,10 +721,9 @@ def test_bvh_distance_continuations(pkg, oracle, monkeypatch):
         finally:
             lib.close()
     n_ties = 0
-    for key, got in res.items():
-        n_ties += _check_distance_records(oracle, ML, b, got, ref, "continuation %s/%s" % key)
+    for key, got in res.items():  # the pooled continuation (the default) and the lanes alone: no exception at all
+        n_ties += _check_distance_records(oracle, ML, b, got, ref, "continuation %s/%s" % key, max_ties=0.001 if key[0] == "0" else 0)
     base = res[("1", "0")]  # the lanes' sequential walk
-    assert _check_distance_records(oracle, ML, b, base, ref, "lane walk") == 0  # ... is the oracle's walk: no exception at all
     for key, got in res.items():
         same = (got["b1"] == base["b1"]) & (got["b2"] == base["b2"])
         for f in ("distance", "p1", "p2", "status", "num_contacts"):
@@ -739,19 +740,17 @@ def test_bvh_distance_at_baseline_size(pkg, oracle, n):
     ML = bb.MeshLibrary(b.meshes)
     lib = wl.make_library(pkg, b)
     got = lib.distance(b.s1, b.s2, b.tf1, b.tf2)
+    reruns = lib.last_ordered_reruns()
     again = lib.distance(b.s1, b.s2, b.tf1, b.tf2)
     lib.close()
+    assert reruns["mesh_continued"] > 1000 and reruns["mesh_rerun"] <= reruns["mesh_continued"] // 20
     ref = oracle.bvh_distance_batch(ML, b.s1, b.s2, b.tf1, b.tf2, n_threads=os.cpu_count() or 8)
-    ties = _check_distance_records(oracle, ML, b, got, ref, "cfg4d", max_ties=0.00002)
-    ties2 = _check_distance_records(oracle, ML, b, again, ref, "cfg4d, second run", max_ties=0.00002)
-    # (which walks share a wave depends on the order the waves take their tickets, and with it the order in which a walk's pairs
-    # are evaluated: two runs agree byte for byte except where one of them falls into the enumerated class above)
-    differ = np.flatnonzero((got["b1"] != again["b1"]) | (got["b2"] != again["b2"]))
-    assert len(differ) <= ties + ties2
-    same = np.ones(n, dtype=bool)
-    same[differ] = False
-    assert np.array_equal(got[same].view(np.uint8), again[same].view(np.uint8)), "distance() is not deterministic"
-    print("cfg4d %d queries: %d / %d enumerated 0-ulp ties in two runs" % (n, ties, ties2))
+    _check_distance_records(oracle, ML, b, got, ref, "cfg4d")
+    _check_distance_records(oracle, ML, b, again, ref, "cfg4d, second run")
+    # which walks share a wave depends on the order the waves take their tickets, and with it the order in which a walk's pairs are
+    # evaluated -- the records do not: a walk whose reported pair could depend on it is re-run in the reference's order
+    assert np.array_equal(got.view(np.uint8), again.view(np.uint8)), "distance() is not deterministic"
+    print("cfg4d %d queries: walks continued by waves / re-run in order: %s" % (n, reruns))
 
 
 def _mesh_batch(pkg, meshes, n, seed, half_width):

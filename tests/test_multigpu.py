@@ -189,13 +189,9 @@ def test_c_abi_multi_equals_single_library(pkg, case):
             if want_guess:
                 assert ref[1].tobytes() == got[1].tobytes(), kind + ": cached guesses"
                 ref, got = ref[0], got[0]
-            if case == "meshes" and kind == "distance":
-                # mesh x mesh distance(): the pooled continuation is not run-to-run deterministic inside its enumerated 0-ulp tie class
-                # (include/hppfcl_amd.h); everything but the ids of such ties is
-                assert np.array_equal(got["distance"], ref["distance"]) and np.array_equal(got["status"], ref["status"])
-                assert (got["b1"] != ref["b1"]).mean() < 0.002
-            else:
-                assert got.tobytes() == ref.tobytes(), kind
+            # (mesh distance() included: which walks share a wave differs between the two calls, the records do not -- a walk whose
+            # reported pair could depend on it is walked again in the reference's order, include/hppfcl_amd.h)
+            assert got.tobytes() == ref.tobytes(), kind
     finally:
         single.close()
         multi.close()
