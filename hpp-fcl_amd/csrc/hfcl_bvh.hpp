@@ -7,7 +7,18 @@
 //                              triangles, centroid guess, no EPA), src/narrowphase/details.h:699-709
 //   triangle support           src/narrowphase/support_functions.cpp:110-134
 #pragma once
+// HFCL_LEAF_CONTRACT_OFF (the collide() part of the mesh unit, Makefile): the leaves' solvers -- GJK, EPA, the supports, everything of
+// hfcl_pair.hpp and the leaf functions of hfcl_bvh_shape.hpp -- are compiled without contraction of a*b+c, the box tests around them
+// with hipcc's default.  A leaf is called from several kernels (the lanes' walk, the waves' continuation, the task levels), each with
+// its own inlined copy; contracted, two copies may fuse differently and a GJK run that stops an iteration apart reports a normal
+// 1e-3 away (cylinder caps; profiles/r06_b) -- without, every copy is the same arithmetic, and the oracle's.
+#if defined(HFCL_LEAF_CONTRACT_OFF)
+#pragma clang fp contract(off)
+#endif
 #include "hfcl_pair.hpp"
+#if defined(HFCL_LEAF_CONTRACT_OFF)
+#pragma clang fp contract(fast)
+#endif
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <algorithm>
 #include <utility>

@@ -371,6 +371,9 @@ HFCL_HD bool shape_obb(const DShape<T>& s, const T* verts, const Pose<T>& tf, DN
   return shape_obbrss<T>(s, verts, tf, bv, nullptr);
 }
 
+#if defined(HFCL_LEAF_CONTRACT_OFF)
+#pragma clang fp contract(off)  // (the leaves' arithmetic: hfcl_bvh.hpp)
+#endif
 // details::segmentSqrDistance :235-255, projectInTriangle :258-279, sphereTriangleDistance :286-340
 template <typename T>
 HFCL_HD T segment_sqr_distance(const V3<T>& from, const V3<T>& to, const V3<T>& p, V3<T>& nearest) {
@@ -518,6 +521,9 @@ HFCL_HD void triangle_pair(const DShape<T>& a, const DShape<T>& b, const T* vert
   o.normal = t1 ? n : -n;
 }
 
+#if defined(HFCL_LEAF_CONTRACT_OFF)
+#pragma clang fp contract(fast)
+#endif
 template <typename T>
 struct MeshShapeState {  // the CollisionResult fields the traversal maintains
   T dlb, rec_dist;
@@ -682,6 +688,9 @@ struct ShapeDeferItem {  // a leaf whose GJK ended inside the solid (seed.pair =
   uint32_t parent, order;  // collide(): where the unit that met the leaf hangs in the task tree (0xFFFFFFFF: a whole query)
 };
 
+#if defined(HFCL_LEAF_CONTRACT_OFF)
+#pragma clang fp contract(off)  // (the leaves' arithmetic: hfcl_bvh.hpp)
+#endif
 // A leaf on one lane.  Returns true when the leaf must go through EPA (item.seed / a / b / c filled; nothing else
 // changed); otherwise distance / p1 (on the triangle) / p2 (on the solid) / n are the leaf's result and `guess` the
 // solver's cached guess after it.  tfm_of() / tfs_of(): the poses, produced where they are needed.
@@ -748,6 +757,9 @@ HFCL_HD T mesh_shape_leaf_finish(const ShapeDeferItem<T>& item, const Pose<T>& t
   return o.distance;
 }
 
+#if defined(HFCL_LEAF_CONTRACT_OFF)
+#pragma clang fp contract(fast)
+#endif
 // updateDistanceLowerBoundFromLeaf + the contact decision of leafCollides (traversal_node_bvh_shape.h:139-186).
 // lowered: the leaf's witness data replace the recorded ones.
 template <typename T>

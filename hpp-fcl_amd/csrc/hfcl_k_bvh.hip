@@ -4,7 +4,9 @@
 #include "hfcl_dev.hpp"
 #include "hfcl_launch.hpp"
 
-// This file is compiled twice (Makefile): hfcl_k_bvh.o, HFCL_BVH_PART = 1 -- the collide() kernels and their launchers -- and
+// This file is compiled three times (Makefile): hfcl_k_bvh.o, HFCL_BVH_PART = 1 -- mesh x mesh collide(), top-level triangle pairs and their
+// launchers --, hfcl_k_bvhc.o, HFCL_BVH_PART = 3 -- mesh x solid collide(), its leaves' solvers without contraction (HFCL_LEAF_CONTRACT_OFF,
+// hfcl_bvh.hpp: every inlined copy of a leaf is then the same arithmetic; the box tests keep hipcc's default) -- and
 // hfcl_k_bvhs.o, HFCL_BVH_PART = 2 -- mesh x solid distance() -- WITHOUT contraction of a*b+c: the reported triangle hangs on
 // comparisons of distances that are equal or an ulp apart (triangles that share the closest vertex or edge), and with the
 // reference's arithmetic the ids, distances and witness points are the oracle's (profiles/r05_c: ids 77-93 % -> 100 % equal,
@@ -13,8 +15,10 @@
 #ifndef HFCL_BVH_PART
 #define HFCL_BVH_PART 0
 #endif
-#define HFCL_BVH_COLLIDE_PART (HFCL_BVH_PART != 2)
-#define HFCL_BVH_DISTANCE_PART (HFCL_BVH_PART != 1)
+#define HFCL_BVH_COLLIDE_PART (HFCL_BVH_PART != 2)                          // either collide() part
+#define HFCL_BVH_MESH_PART (HFCL_BVH_PART == 0 || HFCL_BVH_PART == 1)      // mesh x mesh collide(), triangle pairs
+#define HFCL_BVH_SOLID_PART (HFCL_BVH_PART == 0 || HFCL_BVH_PART == 3)     // mesh x solid collide()
+#define HFCL_BVH_DISTANCE_PART (HFCL_BVH_PART == 0 || HFCL_BVH_PART == 2)  // mesh x solid distance()
 
 // ---------------------------------------------------------------------------------------
 // k_bvh_collide: BVHModel<OBBRSS> x BVHModel<OBBRSS> collide().
@@ -839,6 +843,7 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
 
 // Between two levels: the tasks made so far are the next level's units; the ticket counter starts over.
 #if HFCL_BVH_COLLIDE_PART
+template <int PART>
 __global__ void k_bvh_level_mark(Work wk, BvhSplit split, int ticket) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     split.ctr[BVH_CTR_LEVEL0 + split.level + 1] = split.ctr[BVH_CTR_TASKS];
@@ -849,7 +854,7 @@ __global__ void k_bvh_level_mark(Work wk, BvhSplit split, int ticket) {
 #endif
 
 // Fold the children of the suspended units of level `split.level` back (the children's own children are folded already).
-template <typename T>
+template <typename T, int PART>
 __global__ void __launch_bounds__(256) k_bvh_combine(Work wk, IO<T> io, BvhSplit split) {
   const uint32_t level = split.level;
   const uint32_t unit0 = level ? min(split.ctr[BVH_CTR_LEVEL0 + level - 1], split.cap) : 0u;
@@ -1364,6 +1369,83 @@ __device__ __forceinline__ bool coop_cut(const BvhSplit& split, uint32_t my_slot
 #ifndef HFCL_WPE_SHAPE_COOP
 #define HFCL_WPE_SHAPE_COOP 2
 #endif
+// What a walk of k_bvh_shape_coop and the leaf it calls share, in LDS (round 6).  The leaf's GJK takes 248 registers, so whatever the
+// walk holds across the call goes to scratch memory and back: as first built -- the walk's state in registers, the leaf's arguments a
+// by-value block, its result a block behind a pointer, the request's parameters behind another -- that was 608 B per lane, and 100 000
+// queries moved 6.4 GB through it (a read-only tree walk whose records are 9.6 MB; profiles/r05 traffic_cfg4s.json): more than the
+// XCD's L2 holds for its resident waves, so the kernel ran at half the chip's memory bandwidth.  Here the call passes two words per lane
+// (the triangle, a flag) and returns three; everything that is the same for the lanes of a walk -- where the model's arrays are, the
+// query, the solid, the request, the solid's OBB products, the witness of the walk's bound -- is in this block, and a leaf's witness
+// goes to a lane-minor slab beside it.
+template <typename T>
+struct ShapeCoopCtx {
+  const T* mesh_verts;      // of the walk's model
+  const uint32_t* tris;
+  const DShape<T>* shapes;
+  const T* lib_verts;
+  decltype(IO<T>::tf1) pose_m;  // pose arrays of the mesh / the solid
+  decltype(IO<T>::tf1) pose_s;
+  ShapeDeferItem<T>* defer;
+  uint32_t* defer_count;
+  T* wit;                   // [9][64]: p1, p2, n of the leaf each lane ran last
+  uint32_t defer_cap;
+  uint32_t pair, solid_id, parent, order;
+  V3<T> guess0;
+  QParams<T> q;
+  ObbQuery<T> oq;
+  V3<T> np1, np2, nn;       // witness of the walk's bound (record orientation)
+};
+template <typename T>
+struct CoopLeafRet {
+  T distance;
+  uint32_t to_epa, slot;
+};
+// (not_tail_called: LLVM marks a call that hands no pointer into the caller's frame as a possible tail call, and a function with such a call
+// site keeps the convention's callee-saved registers -- 50 of them here, saved and restored around every leaf, 200 B of scratch per lane;
+// without the mark the register allocation is interprocedural and the callee saves nothing the walk does not hold)
+template <typename T, class PS>
+__device__ __noinline__ __attribute__((not_tail_called)) CoopLeafRet<T> coop_solid_leaf(const ShapeCoopCtx<T>* c, const PS ps, uint32_t prim, uint32_t push) {
+  const QParams<T> q = c->q;
+  const T* const mv = c->mesh_verts;
+  const uint32_t* const tri = c->tris + 3 * size_t(prim);
+  auto vtx = [&](uint32_t i) { return mk<T>(mv[3 * size_t(i)], mv[3 * size_t(i) + 1], mv[3 * size_t(i) + 2]); };
+  const V3<T> ta = vtx(tri[0]), tb = vtx(tri[1]), tc = vtx(tri[2]);
+  LaneSolid<T> solid;
+  solid.s = c->shapes[c->solid_id];
+  solid.v = c->lib_verts + 3 * size_t(solid.s.vertex_offset);
+  const uint32_t pair = c->pair;
+  auto tfm_of = [&]() { return load_pose(c->pose_m, pair); };
+  auto tfs_of = [&]() { return load_pose(c->pose_s, pair); };
+  const MDiff<T> sMt = make_mdiff(tfs_of(), tfm_of());
+  V3<T> guess = c->guess0;
+  ShapeDeferItem<T> item;
+  CoopLeafRet<T> r;
+  r.distance = Lim<T>::max();
+  r.slot = 0u;
+  V3<T> p1 = mk<T>(T(0), T(0), T(0)), p2 = p1, n = p1;
+  const bool to_epa = mesh_shape_leaf_lane(ta, tb, tc, sMt, tfm_of, tfs_of, solid.s, solid, swept_radius(solid.s), q, guess, ps, r.distance, p1, p2, n, item);
+  r.to_epa = to_epa ? 1u : 0u;
+  if (to_epa) {
+    r.distance = Lim<T>::max();
+    if (push) {
+      item.seed.pair = pair;
+      item.prim = prim;
+      item.parent = c->parent;
+      item.order = c->order;
+      item.bound = T(0);
+      item.prev_prim = -1;
+      const uint32_t slot = atomicAdd(c->defer_count, 1u);
+      if (slot < c->defer_cap) c->defer[slot] = item;  // (the host sizes the queue for one item per unit of the batch; never past its end)
+      r.slot = slot;
+    }
+  } else {
+    T* const w = c->wit + (threadIdx.x & 63);
+    w[0 * 64] = p1.x; w[1 * 64] = p1.y; w[2 * 64] = p1.z;
+    w[3 * 64] = p2.x; w[4 * 64] = p2.y; w[5 * 64] = p2.z;
+    w[6 * 64] = n.x;  w[7 * 64] = n.y;  w[8 * 64] = n.z;
+  }
+  return r;
+}
 template <typename T>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_SHAPE_COOP, 8)))
 k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhParams bp, T break_distance2, BvhSplit split) {
@@ -1371,12 +1453,24 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
   __shared__ uint32_t stacks[G][COOP_CAP + COOP_SLACK];
   __shared__ T values[G][COOP_CAP + COOP_SLACK];
   __shared__ T w0_slab[W0Lds<T, 64>::WORDS];
+  __shared__ ShapeCoopCtx<T> ctxs[G];
+  __shared__ T wit_slab[9 * 64];
   const W0Lds<T, 64> leaf_ps{w0_slab + threadIdx.x};
   const int lane = threadIdx.x, grp = lane / W, lig = lane & (W - 1);
   uint32_t* const stack = stacks[grp];
   T* const value = values[grp];
+  ShapeCoopCtx<T>& ctx = ctxs[grp];
   const uint64_t gbits = W == 64 ? ~uint64_t(0) : ((uint64_t(1) << (W & 63)) - 1);
   auto gballot = [&](bool x) -> uint64_t { return (__ballot(x) >> (grp * W)) & gbits; };  // the group's lanes, bit 0 = its first lane
+  if (lig == 0) {  // what does not change from walk to walk
+    ctx.shapes = lib.shapes;
+    ctx.lib_verts = lib.verts;
+    ctx.defer = reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer);
+    ctx.defer_count = &wk.counts[CTR_SHAPE_DEFER];
+    ctx.defer_cap = wk.shape_defer_cap;
+    ctx.wit = wit_slab;
+    ctx.q = q;
+  }
   // the units of this launch: the suspended queries (level 0), or the chunks the launch before cut its long walks into
   const uint32_t level = split.level;
   const uint32_t unit0 = level ? min(split.ctr[BVH_CTR_LEVEL0 + level - 1], split.cap) : 0u;
@@ -1394,18 +1488,17 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
   (void)t_wave; (void)n_walks;
   bool swapped = false, overflow = false;
   COOP_PROF_DECL;  // [0] trips [1] box-test ticks [2] boxes tested [3] leaf batches [4] their ticks [5] their lanes [6] ticks from the scans to the end of a trip that ends in a contact [7] ticks drawing and loading units
-  DMesh m1 = {0, 0, 0, 0};
-  ObbQuery<T> oq;
-  oq.M.r0 = oq.M.r1 = oq.M.r2 = oq.V = oq.ext = mk<T>(T(0), T(0), T(0));
+  uint32_t node_off = 0;
   int sp = 0, fb = -1;
   T dlb = big, rec_dist = big, cand_val = big;
-  V3<T> np1 = oq.V, np2 = oq.V, nn = oq.V, guess0 = oq.V;
-  // a triangle's leaf; push: with the EPA item if it needs one
-  auto run_leaf = [&](uint32_t prim, bool push, SolidLeafOut<T>* lo, uint32_t* slot = nullptr) -> bool {
-    SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + prim), lib.shapes, lib.verts,
-                      swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2, push ? reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer) : nullptr,
-                      push ? &wk.counts[CTR_SHAPE_DEFER] : nullptr, wk.shape_defer_cap, pair, solid_id, prim, my_parent, my_order, T(0), -1};
-    return solid_leaf_call<T>(in, &q, leaf_ps, guess0, lo, slot);
+  // the witness of lane `l`'s last leaf, from the slab (record orientation)
+  auto slab_witness = [&](int l, V3<T>& a1, V3<T>& a2, V3<T>& an) {
+    const T* const w = wit_slab + l;
+    const int o1 = swapped ? 3 * 64 : 0, o2 = swapped ? 0 : 3 * 64;  // (rows, not a select between two structs: that one goes through an indexed stack slot)
+    const T sg = swapped ? T(-1) : T(1);
+    a1 = mk<T>(w[o1], w[o1 + 64], w[o1 + 128]);
+    a2 = mk<T>(w[o2], w[o2 + 64], w[o2 + 128]);
+    an = mk<T>(sg * w[6 * 64], sg * w[7 * 64], sg * w[8 * 64]);
   };
   for (;;) {
     if (!have && !exhausted) {
@@ -1432,16 +1525,22 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       solid_id = swapped ? id1 : id2;
       {
         const DMesh mm = bv.meshes[wave_uniform<W>(lib.shapes[swapped ? id2 : id1].bvh_index)];
-        m1.node_off = wave_uniform<W>(mm.node_off);
-        m1.vert_off = wave_uniform<W>(mm.vert_off);
-        m1.tri_off = wave_uniform<W>(mm.tri_off);
-        m1.n_nodes = wave_uniform<W>(mm.n_nodes);
-        const ObbQuery<T> o = reinterpret_cast<const ObbQuery<T>*>(wk.shape_oq)[pair];
-        oq.M.r0 = wave_uniform<W>(o.M.r0);
-        oq.M.r1 = wave_uniform<W>(o.M.r1);
-        oq.M.r2 = wave_uniform<W>(o.M.r2);
-        oq.V = wave_uniform<W>(o.V);
-        oq.ext = wave_uniform<W>(o.ext);
+        node_off = wave_uniform<W>(mm.node_off);
+        if (lig == 0) {
+          ctx.mesh_verts = bv.verts + 3 * size_t(mm.vert_off);
+          ctx.tris = bv.tris + 3 * size_t(mm.tri_off);
+          ctx.pose_m = swapped ? io.tf2 : io.tf1;
+          ctx.pose_s = swapped ? io.tf1 : io.tf2;
+          ctx.pair = pair;
+          ctx.solid_id = solid_id;
+          ctx.parent = u.parent;
+          ctx.order = u.order;
+          ctx.oq = reinterpret_cast<const ObbQuery<T>*>(wk.shape_oq)[pair];
+          ctx.np1 = s.np1;
+          ctx.np2 = s.np2;
+          ctx.nn = s.nn;
+          ctx.guess0 = initial_guess<T>(io, q, pair);  // (walks whose leaves hand a cached guess on are not split)
+        }
       }
       if (level) {  // the chunk's entries, with what is known about them
         for (uint32_t j = uint32_t(lig); j < s.n_child; j += uint32_t(W)) {
@@ -1457,14 +1556,10 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       cand_val = wave_uniform<W>(s.cand_val);
       t_begin = __builtin_readcyclecounter();
       ++n_walks;
-      np1 = wave_uniform<W>(s.np1);
-      np2 = wave_uniform<W>(s.np2);
-      nn = wave_uniform<W>(s.nn);
       fb = -1;
       ncontacts = 0;
       overflow = wave_uniform<W>(int((s.flags & BVH_SUM_OVERFLOW) != 0)) != 0 || sp > COOP_CAP;
       if (overflow) sp = 0;
-      guess0 = wave_uniform<W>(initial_guess<T>(io, q, pair));  // (walks whose leaves hand a cached guess on are not split)
       have = true;
       }
       COOP_PROF_DT(7);
@@ -1494,7 +1589,7 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       uint32_t tag = ew & ~COOP_NODE;
       // (1) entries nothing is known about yet: a box is tested -- an overlapping one only refines the stack (its children
       // take its place, at any position), a disjoint one keeps its bound; a triangle waits for the leaf batch
-      const DNode<T>* const np = bv.nodes + m1.node_off + e;
+      const DNode<T>* const np = bv.nodes + node_off + e;
       int32_t fc = 0;
       bool overlap = false, pending = false;
       COOP_PROF_ADD(0, 1);
@@ -1509,6 +1604,7 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
         fc = n1.first_child;
         if (fc >= 0) {
           T sq;
+          const ObbQuery<T> oq = ctx.oq;
           if (obb_disjoint_q(oq, n1, q.security_margin, break_distance2, sq)) {
             val = hsqrt(sq);
             tag = COOP_DISJOINT;
@@ -1521,9 +1617,7 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       }
       COOP_PROF_DT(1);
       // (2) the triangles, when enough of them wait or the window has nothing left to split
-      SolidLeafOut<T> lo;
-      lo.distance = big;
-      bool fresh = false;  // this lane ran its leaf in this trip (lo holds its witness)
+      bool fresh = false;  // this lane ran its leaf in this trip (the slab holds its witness)
       {
         const uint64_t pmask = gballot(pending);
         if (pmask && (__popcll(pmask) >= HFCL_COOP_LEAF_BATCH || !gballot(overlap))) {
@@ -1531,9 +1625,9 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
           COOP_PROF_ADD(5, __popcll(pmask));
           COOP_PROF_T0;
           if (pending) {
-            const bool to_epa = run_leaf(uint32_t(-(fc + 1)), false, &lo);
-            val = lo.distance;
-            tag = to_epa ? COOP_LEAF_EPA : COOP_LEAF;
+            const CoopLeafRet<T> r = coop_solid_leaf<T>(&ctx, leaf_ps, uint32_t(-(fc + 1)), 0u);
+            val = r.distance;
+            tag = r.to_epa ? COOP_LEAF_EPA : COOP_LEAF;
             pending = false;
             fresh = true;
           }
@@ -1586,20 +1680,11 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       COOP_PROF_T0;
       if (act && is_leaf && !fresh && ((lig == L) || (is_contact_lane && tag == COOP_LEAF && bp.contacts))) {
         fc = np->first_child;
-        run_leaf(uint32_t(-(fc + 1)), false, &lo);
+        coop_solid_leaf<T>(&ctx, leaf_ps, uint32_t(-(fc + 1)), 0u);  // (for its witness: the slab)
       }
-      {
-        const int Ls = L < 0 ? 0 : L;
-        const V3<T> a1 = swapped ? lo.p2 : lo.p1, a2 = swapped ? lo.p1 : lo.p2, an = swapped ? -lo.n : lo.n;
-        const V3<T> b1 = mk<T>(__shfl(a1.x, Ls, W), __shfl(a1.y, Ls, W), __shfl(a1.z, Ls, W));
-        const V3<T> b2 = mk<T>(__shfl(a2.x, Ls, W), __shfl(a2.y, Ls, W), __shfl(a2.z, Ls, W));
-        const V3<T> bn = mk<T>(__shfl(an.x, Ls, W), __shfl(an.y, Ls, W), __shfl(an.z, Ls, W));
-        if (L >= 0) {
-          np1 = wave_uniform<W>(b1);
-          np2 = wave_uniform<W>(b2);
-          nn = wave_uniform<W>(bn);
-        }
-      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (L >= 0 && lig == 0) slab_witness(grp * W + L, ctx.np1, ctx.np2, ctx.nn);
       if (c < W) {  // canStop()
         if (act && is_leaf && fc == 0) fc = np->first_child;
         const int prim_c = wave_uniform<W>(__shfl(int(-(fc + 1)), c, W));
@@ -1608,11 +1693,12 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
         bool lost = false;
         if (is_contact_lane) {
           if (tag == COOP_LEAF_EPA) {  // its leaf once more, this time with the EPA item (k_bvh_shape_finish patches the record)
-            uint32_t slot = 0u;
-            run_leaf(uint32_t(prim_c), true, &lo, &slot);
-            lost = slot >= wk.shape_defer_cap;
-          } else {
-            emit_shape_contact(bp, pair, swapped, prim_c, lo.distance, lo.p1, lo.p2, lo.n);
+            const CoopLeafRet<T> r = coop_solid_leaf<T>(&ctx, leaf_ps, uint32_t(prim_c), 1u);
+            lost = r.slot >= wk.shape_defer_cap;
+          } else if (bp.contacts) {
+            const T* const w = wit_slab + lane;  // (its leaf ran in this trip, above at the latest)
+            emit_shape_contact(bp, pair, swapped, prim_c, val, mk<T>(w[0 * 64], w[1 * 64], w[2 * 64]), mk<T>(w[3 * 64], w[4 * 64], w[5 * 64]),
+                               mk<T>(w[6 * 64], w[7 * 64], w[8 * 64]));
           }
         }
         // (the host sizes the queue of EPA items for the units it expects -- one and a half per query once walks are cut into chunks --;
@@ -1649,7 +1735,7 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
       if (cut_ticks && sp > COOP_CHUNK && __builtin_readcyclecounter() - t_begin > cut_ticks) {
         // ---- the walk has had its time: what is left of it becomes chunks for the next launch (coop_cut)
         if (coop_cut<T, W>(split, level ? split.n_queries + unit0 + unit : unit, pair, my_parent, my_order, stack, value, sp, lig, dlb, rec_dist, cand_val,
-                           np1, np2, nn, overflow)) {
+                           ctx.np1, ctx.np2, ctx.nn, overflow)) {
           COOP_CUT_COUNT(lig == 0);
           COOP_WALK_END(lig == 0, t_begin);
           have = false;
@@ -1662,7 +1748,7 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
     if (done && level) {
       // ---- a chunk's summary (k_bvh_combine folds it into the walk it was cut from)
       if (lig == 0) {
-        coop_write_sum<T>(split, split.n_queries + unit0 + unit, dlb, rec_dist, cand_val, np1, np2, nn, swapped ? -1 : fb, swapped ? fb : -1, ncontacts, 0u, 0u,
+        coop_write_sum<T>(split, split.n_queries + unit0 + unit, dlb, rec_dist, cand_val, ctx.np1, ctx.np2, ctx.nn, swapped ? -1 : fb, swapped ? fb : -1, ncontacts, 0u, 0u,
                           overflow ? BVH_SUM_OVERFLOW : 0u, my_parent, my_order);
         if (ncontacts) coop_report_contact<T>(split, my_parent, my_order);
       }
@@ -1675,9 +1761,9 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
         bvh_sum<T>(split, unit)->flags = 0u;  // (not cut: k_bvh_combine has nothing to fold for this query)
         PairOut<T> o;
         o.distance = rec_dist;
-        o.normal = nn;
-        o.p1 = np1;
-        o.p2 = np2;
+        o.normal = ctx.nn;
+        o.p1 = ctx.np1;
+        o.p2 = ctx.np2;
         o.gjk_status = GJK_DID_NOT_RUN;
         o.epa_status = EPA_DID_NOT_RUN;
         o.gjk_iters = o.epa_iters = 0;
@@ -2757,10 +2843,13 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
 #if HFCL_BVH_COLLIDE_PART
 template <typename T>
 static void launch_collide_kernel(bool wide, int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, const BvhSplit& split, const BvhSpill& spill, bool solid = false) {
+#if HFCL_BVH_SOLID_PART
   if (solid) {  // mesh x solid: the narrow form, 32-bit node ids in the entry
     hipLaunchKernelGGL((k_bvh_collide<T, false, false, true>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
     return;
   }
+#endif
+#if HFCL_BVH_MESH_PART
   if constexpr (sizeof(T) == 8) {
     if (bv.fnodes) {
       if (wide)
@@ -2774,6 +2863,9 @@ static void launch_collide_kernel(bool wide, int grid, hipStream_t st, const Wor
     hipLaunchKernelGGL((k_bvh_collide<T, true, false>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
   else
     hipLaunchKernelGGL((k_bvh_collide<T, false, false>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
+#else
+  (void)wide;
+#endif
 }
 // The continuation of the suspended queries by k_bvh_coop / k_bvh_shape_coop: one launch, or -- BvhSplit::cut_ticks -- three, the second and
 // third walking the chunks the launch before cut its long walks into (levels 2 and 3 of the task table: k_bvh_level_mark files the
@@ -2784,7 +2876,7 @@ static bool launch_coop_levels(int grid, hipStream_t st, const Work& wk, const I
   const bool cutting = s.cut_ticks != 0 && s.cut_words != nullptr;
   s.level = 0;
   for (uint32_t l = 0; l < (cutting ? 3u : 1u); ++l) {
-    hipLaunchKernelGGL(k_bvh_level_mark, dim3(1), dim3(64), 0, st, wk, s, ticket);
+    hipLaunchKernelGGL((k_bvh_level_mark<HFCL_BVH_PART>), dim3(1), dim3(64), 0, st, wk, s, ticket);
     if (l == 1) after_first();
     s.level = l ? l + 1 : 0u;  // launch 0: the suspended queries; launches 1, 2: the chunks of the launch before
     s.can_suspend = cutting && l < 2 ? 1u : 0u;
@@ -2793,9 +2885,9 @@ static bool launch_coop_levels(int grid, hipStream_t st, const Work& wk, const I
   }
   if (cutting) {
     s.level = 2;
-    hipLaunchKernelGGL((k_bvh_combine<T>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, io, s);
+    hipLaunchKernelGGL((k_bvh_combine<T, HFCL_BVH_PART>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, io, s);
     s.level = 0;
-    hipLaunchKernelGGL((k_bvh_combine<T>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, io, s);
+    hipLaunchKernelGGL((k_bvh_combine<T, HFCL_BVH_PART>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, io, s);
   }
   return cutting;
 }
@@ -2803,8 +2895,9 @@ template <typename T, class Launch>
 static void launch_coop_levels(int grid, hipStream_t st, const Work& wk, const IO<T>& io, BvhSplit s, int ticket, Launch&& launch) {
   launch_coop_levels<T>(grid, st, wk, io, s, ticket, launch, [] {});
 }
+// (static: each part of this unit has its own -- the mesh x solid part walks its task levels with it, solid = true)
 template <typename T>
-void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill, bool solid) {
+static void bvh_collide_levels(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill, bool solid) {
   if (spill.wide && !solid) {  // models with 32-bit node ids: single pass, global spill instead of tasks
     split.tasks = nullptr;
     split.budget = 0;
@@ -2823,6 +2916,7 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
     launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill, solid);
     return;
   }
+#if HFCL_BVH_MESH_PART
   if (split.coop && !solid) {
     // the queries for their step budget, one per lane; then the suspended ones, a lane group each (k_bvh_coop)
     BvhSplit s0 = split;
@@ -2838,6 +2932,7 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
     });
     return;
   }
+#endif
   const uint32_t budget = split.budget;
   for (uint32_t l = 0; l < split.n_levels; ++l) {
     split.level = l;
@@ -2845,13 +2940,21 @@ void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<
     BvhSplit s = split;
     s.can_suspend = l + 1 < split.n_levels;  // ... and cannot suspend (its stack overflows are flagged)
     launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s, spill, solid);
-    hipLaunchKernelGGL(k_bvh_level_mark, dim3(1), dim3(64), 0, st, wk, s, solid ? int(CTR_SHAPE_TICKET) : int(B_COUNT + 2));
+    hipLaunchKernelGGL((k_bvh_level_mark<HFCL_BVH_PART>), dim3(1), dim3(64), 0, st, wk, s, solid ? int(CTR_SHAPE_TICKET) : int(B_COUNT + 2));
   }
   for (int l = int(split.n_levels) - 2; l >= 0; --l) {
     split.level = uint32_t(l);
-    hipLaunchKernelGGL((k_bvh_combine<T>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, io, split);
+    hipLaunchKernelGGL((k_bvh_combine<T, HFCL_BVH_PART>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, io, split);
   }
 }
+#endif
+#if HFCL_BVH_MESH_PART
+template <typename T>
+void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill) {
+  bvh_collide_levels<T>(grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill, false);
+}
+#endif
+#if HFCL_BVH_SOLID_PART
 template <typename T>
 void launch_bvh_shape(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2) {
   hipLaunchKernelGGL((k_bvh_shape<T>), dim3(grid), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2);
@@ -2875,7 +2978,7 @@ void launch_bvh_shape_distance_fast(int grid, int grid_finish, hipStream_t st, c
   launch_shape_finish<T>(grid_finish, st, wk, lv, io, q, bp, none, 1);
 }
 #endif
-#if HFCL_BVH_COLLIDE_PART
+#if HFCL_BVH_SOLID_PART
 // mesh x solid collide(), one query per lane: the solids' OBBs, the walk (split as `split` says), the EPA leaves
 template <typename T>
 void launch_bvh_shape_fast(int grid, int grid_finish, int coop_grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill, const AsideStream* aside) {
@@ -2912,7 +3015,7 @@ void launch_bvh_shape_fast(int grid, int grid_finish, int coop_grid, hipStream_t
     if (forked) hipStreamWaitEvent(st, aside->join, 0);
     return;
   }
-  launch_bvh_collide<T>(grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill, true);
+  bvh_collide_levels<T>(grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill, true);
   split.level = 0;
   launch_shape_finish<T>(grid_finish, st, wk, lv, io, q, bp, split, 0);
 }
@@ -2923,18 +3026,24 @@ void launch_bvh_shape_distance(int grid, hipStream_t st, const Work& wk, const L
   hipLaunchKernelGGL((k_bvh_shape_distance<T>), dim3(grid), dim3(64), 0, st, wk, lv, bv, io, q);
 }
 #endif
-#if HFCL_BVH_COLLIDE_PART
+#if HFCL_BVH_MESH_PART
 template <typename T>
 void launch_triangle(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {
   hipLaunchKernelGGL((k_triangle<T>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
 }
 #endif
-#if HFCL_BVH_COLLIDE_PART
+#if HFCL_BVH_MESH_PART
 #define HFCL_INST(T)                                                                                                             \
-  template void launch_bvh_collide<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill, bool); \
-  template void launch_bvh_shape<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T);   \
-  template void launch_bvh_shape_fast<T>(int, int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill, const AsideStream*); \
+  template void launch_bvh_collide<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill); \
   template void launch_triangle<T>(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&);
+HFCL_INST(float)
+HFCL_INST(double)
+#undef HFCL_INST
+#endif
+#if HFCL_BVH_SOLID_PART
+#define HFCL_INST(T)                                                                                                             \
+  template void launch_bvh_shape<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T);   \
+  template void launch_bvh_shape_fast<T>(int, int, int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill, const AsideStream*);
 HFCL_INST(float)
 HFCL_INST(double)
 #undef HFCL_INST

@@ -8,13 +8,13 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-UNITS = ("gjk32", "gjk64", "epa32", "epa64", "bvh", "bvhs", "bvhd")  # as the Makefile builds them (gjk / epa: both precisions)
+UNITS = ("gjk32", "gjk64", "epa32", "epa64", "bvh", "bvhc", "bvhs", "bvhd")  # as the Makefile builds them (gjk / epa: both precisions)
 ALIAS = {"gjk": ["gjk32", "gjk64"], "epa": ["epa32", "epa64"]}
 units = [u for a in sys.argv[1:] for u in ALIAS.get(a, [a] if a in UNITS else [])] or list(UNITS)
 flags = [a for a in sys.argv[1:] if a not in UNITS and a not in ALIAS]
 procs = []
 for u in units:  # the translation units compile side by side
-    src = os.path.join(ROOT, "hpp-fcl_amd", "csrc", "hfcl_k_%s.hip" % ("bvh" if u == "bvhs" else u.rstrip("0123456789")))
+    src = os.path.join(ROOT, "hpp-fcl_amd", "csrc", "hfcl_k_%s.hip" % ("bvh" if u in ("bvhs", "bvhc") else u.rstrip("0123456789")))
     mk = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "hpp-fcl_amd", "csrc"), "-pn"], capture_output=True, text=True).stdout
     m = re.search(r"^FLAGS_k_%s = (.*)$" % u, mk, re.M)  # the Makefile's per-unit flags
     unit_flags = (m.group(1).split() if m else []) + (["-DHFCL_UNIT_PRECISION=" + u[-2:]] if u[-2:] in ("32", "64") else [])
