@@ -684,6 +684,42 @@ struct BvhSum {  // what a unit (query or task) knows when it ends or suspends
 };
 // counters of a split traversal (device words)
 enum { BVH_CTR_TASKS = 0, BVH_CTR_SUSPENDED = 1, BVH_CTR_LEVEL0 = 2 /* [2 + k] = number of tasks made before level k ended */, BVH_CTR_CUT = 15 /* words of BvhSplit::cut_words in use */, BVH_CTR_WORDS = 16 };
+// ---------------------------------------------------------------------------------------
+// Mesh x mesh collide() with the walk and the leaves in kernels of their own (round 6; hfcl_k_bvh.hip: k_bvh_walk, k_tri_leaves,
+// k_bvh_resolve).  collisionRecurse's box tests do not depend on anything a triangle pair reports -- only WHERE the walk ends does (the
+// first contact) -- so a lane can walk ahead of its triangle pairs: it lists the next `k` leaves it meets (with the smallest box bound
+// seen in front of each: the events between two leaves only ever form a minimum), a dense kernel evaluates every listed pair of the
+// batch, one per lane, and a third replays each query's events in the reference's order: bound, witness, first contact.  A query that
+// is not over after a round -- its `k` leaves listed without a contact -- walks on in the next; what is left after the last round, and
+// every walk that used up its step budget, goes to k_bvh_coop with its stack as before.
+// What it buys: the walk without the leaf's GJK fits 3-4 waves per SIMD instead of 2 and no lane waits for another's leaf (the probe
+// of round 3: 2.4x the steps per second); the leaves run 64 to a wave instead of the 5-10 a parked wave held.  What it costs: the
+// steps and leaves a walk takes beyond its first contact (at most k - 1 leaves of one round).
+// ---------------------------------------------------------------------------------------
+constexpr int BVH_STACK_WALK = 48;  // k_bvh_walk's LDS stack (entries per lane) and its image in WalkRec
+constexpr int WALK_K = 16;       // most leaves a walk lists per round
+constexpr int WALK_ROUNDS = 4;   // most rounds
+enum { WALK_OVER = 1u, WALK_BUDGET = 2u };
+template <typename T>
+struct WalkRec {  // one per query of the batch
+  uint32_t pair, sp, n_leaf, flags;  // flags: the stack ran empty (WALK_OVER) / the step budget or the stack's capacity ended the round (WALK_BUDGET)
+  uint32_t first_item, pad_[3];      // its leaves of this round are items first_item ... first_item + n_leaf - 1
+  T dlb, rec_dist, cand_val;         // the query's state after the rounds resolved so far (the witness lives in its record)
+  T pre[WALK_K + 1];                 // smallest bound of the disjoint boxes in front of leaf i (max(): none); [n_leaf]: behind the last leaf
+  uint32_t leaf1[WALK_K], leaf2[WALK_K];  // triangle ids
+  uint32_t stack[BVH_STACK_WALK];    // bottom first
+};
+struct WalkArgs {
+  void* recs;         // WalkRec<T>[n]
+  uint32_t* items;    // rec index | slot << 28, WALK_K per query at most
+  void* res;          // TriLeafOut<T> per item
+  uint32_t* ctr;      // per round r at ctr + 8 r: [0] ticket of the walk, [1] items listed, [2] queries that walk on in round r + 1,
+                      // [3] the suspended queries as round r left them (k_walk_snap), [4] the ticket of the launch that continues those round r added
+  uint32_t* list_in;  // rec indices of this round's queries (round 0: the B_BVH bucket, rec index = position in the bucket's list)
+  uint32_t* list_out;
+  uint32_t round, k, budget, last;
+  uint32_t item_cap, list_stride;  // entries of items / res; of one of the two lists list_in / list_out alternate between
+};
 struct BvhSplit {
   BvhTask* tasks;       // task table (cap entries)
   void* sums;           // BvhSum<T>[n_queries + cap]: suspended queries first, then one per task
@@ -707,8 +743,18 @@ struct BvhSplit {
                           // the host sized that queue for n queries + this many chunks; a walk that would exceed it is not cut)
   uint32_t* cut_words;  // stack entries of the cut walks
   void* cut_vals;       // T[cut_cap]: what is known about them (k_bvh_shape_coop's tagged entries: a box's bound, a triangle's distance)
+  // mesh x mesh: the queries' own phase as walk / leaves / resolve rounds (walk.recs != nullptr) instead of k_bvh_collide with its budget
+  WalkArgs walk;
+  uint32_t walk_rounds, walk_k[WALK_ROUNDS], walk_budget[WALK_ROUNDS];
+  // which of the suspended queries a launch of k_bvh_coop continues: all (0); those round r of the walk handed over (1 + r: beside the
+  // later rounds, on a stream of its own, with walk.ctr[8 r + 4] as its ticket); those added since the snapshot of round r (0x100 + r:
+  // what the last round added, on the caller's stream)
+  uint32_t coop_range;
 };
+enum { WALK_CTR_SNAP = 3, WALK_CTR_TICKET_EARLY = 4 };
 constexpr int COOP_CHUNK = 16;
+
+
 // Step budget per unit (the compile-time default; without HFCL_BVH_* in the environment the host chooses per batch, see
 // hfcl_lib::bvh_auto).  0: units only suspend when their LDS stack is full -- the task mechanism is then the overflow path
 // of deep traversals and costs nothing otherwise.  One budget for all levels does not pay (profiles/r02_k: cfg4 7.3 ms

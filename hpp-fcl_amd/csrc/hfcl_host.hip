@@ -97,6 +97,8 @@ struct hfcl_lib {
   void* d_epa_queue2 = nullptr;
   uint32_t* d_epa_cc_over = nullptr;  // Work::epa_cc_over (resume_cap entries)
   hipStream_t aux = nullptr;     // k_epa_records runs here, beside the tiers that continue the handed-over polytopes
+  hipStream_t walk_st[WALK_ROUNDS - 1] = {};  // mesh x mesh collide(): the continuation of what round r of the walk hands over runs on walk_st[r]
+  hipEvent_t walk_fork[WALK_ROUNDS - 1] = {}, walk_join[WALK_ROUNDS - 1] = {};
   hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr, ev_aux2 = nullptr, ev_aux3 = nullptr;  // fork / join of the EPA tail; of k_bvh_shape_finish's first half
   void* d_epa_ready = nullptr;   // EpaReady<float>[epa_ready_capacity]: the staged convex x convex fast tier (k_epa_prepare / k_epa_loop / k_epa_records)
   size_t epa_ready_capacity = 0;
@@ -234,6 +236,17 @@ struct hfcl_lib {
   void* d_bvh_sums = nullptr;
   uint32_t* d_bvh_susp = nullptr;
   uint32_t* d_bvh_ctr = nullptr;
+  // mesh x mesh collide() in walk / leaves / resolve rounds (hfcl_dev.hpp: WalkRec): records, item list, leaf results, the two query lists, counters
+  void* d_walk_recs = nullptr;
+  uint32_t* d_walk_items = nullptr;
+  void* d_walk_res = nullptr;
+  uint32_t* d_walk_lists = nullptr;
+  uint32_t* d_walk_ctr = nullptr;
+  size_t walk_n = 0;
+  bool walk_early_coop = true;                               // HFCL_BVH_WALK_EARLY_COOP: the queries round 0 hands over are continued beside the later rounds
+  uint32_t walk_rounds = 2;                                  // HFCL_BVH_WALK_ROUNDS (0: k_bvh_collide walks the queries, leaves inline)
+  uint32_t walk_k[WALK_ROUNDS] = {6, 16, 16, 16};           // HFCL_BVH_WALK_K: leaves a walk lists per round
+  uint32_t walk_budget[WALK_ROUNDS] = {224, 256, 512, 512};  // HFCL_BVH_WALK_BUDGET: box tests per round before the walk goes to k_bvh_coop
   size_t bvh_split_n = 0, bvh_split_cap = 0;
   uint32_t bvh_budget0 = HFCL_BVH_BUDGET0;  // HFCL_BVH_BUDGET0: step budget of the queries (level 0); bvh_budget: of the tasks
   // No budget given by the environment: chosen per batch.  A batch that does not fill the chip's lanes more than ~1.5
@@ -492,6 +505,24 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
   if (const char* v = getenv("HFCL_BVHD_POOL")) lib->bvhd_pool = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_DIST_POOL")) lib->shape_dist_pool = uint32_t(std::max(0, atoi(v)));
   if (const char* v = getenv("HFCL_POOL_RERUN")) lib->pool_rerun = uint32_t(std::max(0, atoi(v)));
+  if (const char* v = getenv("HFCL_BVH_WALK_ROUNDS")) lib->walk_rounds = uint32_t(std::min(std::max(0, atoi(v)), int(WALK_ROUNDS)));
+  if (const char* v = getenv("HFCL_BVH_WALK_EARLY_COOP")) lib->walk_early_coop = atoi(v) != 0;
+  if (const char* v = getenv("HFCL_BVH_WALK_K")) {  // "4,16": per round
+    int k = 0;
+    for (const char* p = v; *p && k < WALK_ROUNDS; ++k) {
+      lib->walk_k[k] = uint32_t(std::min(std::max(1, atoi(p)), int(WALK_K)));
+      while (*p && *p != ',') ++p;
+      if (*p == ',') ++p;
+    }
+  }
+  if (const char* v = getenv("HFCL_BVH_WALK_BUDGET")) {  // rounds 1 ...: box tests (round 0 takes HFCL_BVH_BUDGET0_COOP's)
+    int k = 1;
+    for (const char* p = v; *p && k < WALK_ROUNDS; ++k) {
+      lib->walk_budget[k] = uint32_t(std::max(0, atoi(p)));
+      while (*p && *p != ',') ++p;
+      if (*p == ',') ++p;
+    }
+  }
   if (const char* v = getenv("HFCL_SHAPE_DIST_LEAF_MIN")) lib->shape_dist_leaf_min = uint32_t(std::max(1, atoi(v)));
   if (const char* v = getenv("HFCL_SHAPE_DIST_STARVE")) lib->shape_dist_starve = uint32_t(std::max(1, atoi(v)));  // (>= 1: a window of triangles alone must always run)
   if (const char* v = getenv("HFCL_BVHD_LEAF_MIN")) lib->bvhd_pool_leaf_min = uint32_t(std::max(1, atoi(v)));
@@ -544,6 +575,11 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_epa_ready);
   hipFree(lib->d_epa_ready_g);
   hipFree(lib->d_epa_cc_over);
+  for (int k = 0; k < WALK_ROUNDS - 1; ++k) {
+    if (lib->walk_st[k]) hipStreamDestroy(lib->walk_st[k]);
+    if (lib->walk_fork[k]) hipEventDestroy(lib->walk_fork[k]);
+    if (lib->walk_join[k]) hipEventDestroy(lib->walk_join[k]);
+  }
   if (lib->aux) hipStreamDestroy(lib->aux);
   if (lib->ev_aux0) hipEventDestroy(lib->ev_aux0);
   if (lib->ev_aux1) hipEventDestroy(lib->ev_aux1);
@@ -598,6 +634,7 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_bvh_sums);
   hipFree(lib->d_bvh_susp);
   hipFree(lib->d_bvh_ctr);
+  hipFree(lib->d_walk_recs); hipFree(lib->d_walk_items); hipFree(lib->d_walk_res); hipFree(lib->d_walk_lists); hipFree(lib->d_walk_ctr);
   for (auto& t : lib->timers) {
     hipEventDestroy(t.e0);
     hipEventDestroy(t.e1);
@@ -780,6 +817,21 @@ static int ensure_bvh_split(hfcl_lib* lib, size_t n) {
   if (!lib->d_bvh_ctr) HIP_TRY(hipMalloc(&lib->d_bvh_ctr, BVH_CTR_WORDS * sizeof(uint32_t)));
   lib->bvh_split_n = nq;
   lib->bvh_split_cap = cap;
+  return HFCL_OK;
+}
+
+static int ensure_walk(hfcl_lib* lib, size_t n) {
+  if (n <= lib->walk_n) return HFCL_OK;
+  hipFree(lib->d_walk_recs); hipFree(lib->d_walk_items); hipFree(lib->d_walk_res); hipFree(lib->d_walk_lists);
+  lib->d_walk_recs = nullptr; lib->d_walk_items = nullptr; lib->d_walk_res = nullptr; lib->d_walk_lists = nullptr;
+  lib->walk_n = 0;
+  const size_t nq = n + n / 8 + 1024;
+  HIP_TRY(hipMalloc(&lib->d_walk_recs, nq * sizeof(WalkRec<double>)));
+  HIP_TRY(hipMalloc(&lib->d_walk_items, nq * WALK_K * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&lib->d_walk_res, nq * WALK_K * 10 * sizeof(double)));  // TriLeafOut<double>: distance, p1, p2, n
+  HIP_TRY(hipMalloc(&lib->d_walk_lists, 2 * nq * sizeof(uint32_t)));
+  if (!lib->d_walk_ctr) HIP_TRY(hipMalloc(&lib->d_walk_ctr, 8 * WALK_ROUNDS * sizeof(uint32_t)));
+  lib->walk_n = nq;
   return HFCL_OK;
 }
 
@@ -1043,11 +1095,43 @@ static int validate_query(const hfcl_query_request& q) {
 // the helper stream of a library (tail kernels beside the main ones) and its fork / join events, made on first use
 static int ensure_aux(hfcl_lib* lib) {
   if (lib->aux) return HFCL_OK;
-  HIP_TRY(hipStreamCreateWithFlags(&lib->aux, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux0, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux1, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux2, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&lib->ev_aux3, hipEventDisableTiming));
+  // created into locals and committed together: a failure half way leaves the library without a helper stream, not with null events
+  hipStream_t s = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+  if (e != hipSuccess) {
+    for (int k = 0; k < 4; ++k)
+      if (ev[k]) hipEventDestroy(ev[k]);
+    if (s) hipStreamDestroy(s);
+    HIP_TRY(e);
+  }
+  lib->ev_aux0 = ev[0];
+  lib->ev_aux1 = ev[1];
+  lib->ev_aux2 = ev[2];
+  lib->ev_aux3 = ev[3];
+  lib->aux = s;
+  return HFCL_OK;
+}
+static int ensure_walk_streams(hfcl_lib* lib) {
+  if (lib->walk_st[WALK_ROUNDS - 2]) return HFCL_OK;  // (committed last)
+  hipStream_t s[WALK_ROUNDS - 1] = {};
+  hipEvent_t ev[2 * (WALK_ROUNDS - 1)] = {};
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < WALK_ROUNDS - 1 && e == hipSuccess; ++k) e = hipStreamCreateWithFlags(&s[k], hipStreamNonBlocking);
+  for (int k = 0; k < 2 * (WALK_ROUNDS - 1) && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+  if (e != hipSuccess) {
+    for (auto x : ev)
+      if (x) hipEventDestroy(x);
+    for (auto x : s)
+      if (x) hipStreamDestroy(x);
+    HIP_TRY(e);
+  }
+  for (int k = 0; k < WALK_ROUNDS - 1; ++k) {
+    lib->walk_fork[k] = ev[2 * k];
+    lib->walk_join[k] = ev[2 * k + 1];
+  }
+  for (int k = 0; k < WALK_ROUNDS - 1; ++k) lib->walk_st[k] = s[k];
   return HFCL_OK;
 }
 template <typename T, int M>
@@ -1247,7 +1331,26 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       split.cut_vals = lib->d_bvh_cut_vals;
       if (!solid && lib->bvh_coop) {
         split.coop = 1u;
-        split.budget0 = lib->bvh_budget0_coop ? lib->bvh_budget0_coop : (n > 500000 ? 640u : 256u);
+        split.budget0 = lib->bvh_budget0_coop ? lib->bvh_budget0_coop : (n > 500000 ? 640u : (lib->walk_rounds ? (n > 150000 ? std::max(320u, lib->walk_budget[0]) : lib->walk_budget[0]) : 256u));
+        // the queries' own phase as walk / leaves / resolve rounds (narrow node ids; rec indices travel in 28 bits)
+        if (lib->walk_rounds && n < (size_t(1) << 28)) {
+          r = ensure_walk(lib, n);
+          if (r) return r;
+          HIP_TRY(hipMemsetAsync(lib->d_walk_ctr, 0, 8 * WALK_ROUNDS * sizeof(uint32_t), st));
+          split.walk.recs = lib->d_walk_recs;
+          split.walk.items = lib->d_walk_items;
+          split.walk.res = lib->d_walk_res;
+          split.walk.ctr = lib->d_walk_ctr;
+          split.walk.list_in = lib->d_walk_lists;
+          split.walk.list_out = lib->d_walk_lists;
+          split.walk.item_cap = uint32_t(std::min<size_t>(lib->walk_n * WALK_K, 0xFFFFFFFFu));
+          split.walk.list_stride = uint32_t(lib->walk_n);
+          split.walk_rounds = std::min<uint32_t>(lib->walk_rounds, WALK_ROUNDS);
+          for (int k = 0; k < WALK_ROUNDS; ++k) {
+            split.walk_k[k] = lib->walk_k[k];
+            split.walk_budget[k] = k == 0 ? split.budget0 : lib->walk_budget[k];
+          }
+        }
       }
       if (solid) {
         split.coop = lib->shape_coop ? 1u : 0u;
@@ -1315,7 +1418,15 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       BvhSplit split;
       rc = make_split(split, may(B_BVH) && !spill.wide && (n >= 256 || 2 * size_t(lib->bvh_max_depth) + 4 > size_t(std::min(BVH_STACK, BVH_STACK_FILT))), false);
       if (rc) return rc;
-      launch_bvh_collide<T>(blocks_for(n, BVH_BLOCK), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance), split, spill);
+      AsideStream beside[WALK_ROUNDS - 1];
+      memset(beside, 0, sizeof(beside));
+      const bool early = split.walk.recs && split.walk_rounds > 1 && lib->walk_early_coop;
+      if (early) {
+        rc = ensure_walk_streams(lib);
+        if (rc) return rc;
+        for (int k = 0; k < WALK_ROUNDS - 1; ++k) beside[k] = AsideStream{lib->walk_st[k], lib->walk_fork[k], lib->walk_join[k]};
+      }
+      launch_bvh_collide<T>(blocks_for(n, BVH_BLOCK), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance), split, spill, early ? beside : nullptr);
       tend();
     } else {
       tbeg("k_bvh_shape_distance");

@@ -1293,8 +1293,9 @@ __device__ __forceinline__ CoopUnit coop_draw(const BvhSplit& split, uint32_t* t
   u.index = qi;
   u.exhausted = qi >= n_units;
   if (u.exhausted) return u;
-  if (!level) {
-    u.pair = split.suspended[qi];
+  if (!level) {  // (unit0: where this launch's part of the suspended list starts, BvhSplit::coop_range)
+    u.index = unit0 + qi;
+    u.pair = split.suspended[u.index];
     u.take = true;
     return u;
   }
@@ -1799,10 +1800,23 @@ k_bvh_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhPa
   auto gballot = [&](bool x) -> uint64_t { return (__ballot(x) >> (grp * W)) & gbits; };
   // the units of this launch: the suspended queries (level 0), or the chunks the launch before cut its long walks into (see above)
   const uint32_t level = split.level;
-  const uint32_t unit0 = level ? min(split.ctr[BVH_CTR_LEVEL0 + level - 1], split.cap) : 0u;
-  const uint32_t n_units = level ? min(split.ctr[BVH_CTR_LEVEL0 + level], split.cap) - unit0 : min(split.ctr[BVH_CTR_SUSPENDED], split.n_queries);
+  uint32_t unit0 = level ? min(split.ctr[BVH_CTR_LEVEL0 + level - 1], split.cap) : 0u;
+  uint32_t n_units = level ? min(split.ctr[BVH_CTR_LEVEL0 + level], split.cap) - unit0 : 0u;
+  uint32_t* ticket = &wk.counts[B_COUNT + 2];  // (k_bvh_collide is through with it; k_bvh_level_mark has reset it)
+  if (!level) {
+    const uint32_t cr = split.coop_range;
+    if (cr && cr < 0x100u) {  // what round cr - 1 of the walk handed over; the later rounds append to the list meanwhile
+      const uint32_t r = cr - 1u;
+      unit0 = r ? min(split.walk.ctr[8u * (r - 1u) + WALK_CTR_SNAP], split.n_queries) : 0u;
+      n_units = min(split.walk.ctr[8u * r + WALK_CTR_SNAP], split.n_queries) - unit0;
+      ticket = &split.walk.ctr[8u * r + WALK_CTR_TICKET_EARLY];
+    } else {
+      const uint32_t tot = min(split.ctr[BVH_CTR_SUSPENDED], split.n_queries);
+      if (cr) unit0 = min(split.walk.ctr[8u * (cr - 0x100u) + WALK_CTR_SNAP], tot);
+      n_units = tot - unit0;
+    }
+  }
   const unsigned long long cut_ticks = split.can_suspend ? split.cut_ticks : 0u;
-  uint32_t* const ticket = &wk.counts[B_COUNT + 2];  // (k_bvh_collide is through with it; k_bvh_level_mark has reset it)
   const T big = Lim<T>::max();
   bool have = false, overflow = false, exhausted = false;
   uint32_t pair = 0, ncontacts = 0;
@@ -2833,6 +2847,334 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
   }
 }
 
+
+#if HFCL_BVH_MESH_PART
+// ---------------------------------------------------------------------------------------
+// Mesh x mesh collide() in rounds of three kernels (hfcl_dev.hpp: WalkRec): the walk without its leaves, the leaves without a walk, the
+// replay of each query's events in the reference's order.
+// ---------------------------------------------------------------------------------------
+// the lanes of `active` each need `count` consecutive slots behind *counter: one atomic per wave, the lane's first slot back
+__device__ __forceinline__ uint32_t wave_reserve(uint32_t* counter, uint32_t count, bool active) {
+  const int lane = threadIdx.x & 63;
+  uint32_t incl = active ? count : 0u;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = uint32_t(__shfl_up(int(incl), d));
+    if (lane >= d) incl += o;
+  }
+  const uint32_t total = uint32_t(__shfl(int(incl), 63));
+  uint32_t base = 0;
+  if (lane == 0 && total) base = atomicAdd(counter, total);
+  base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+  return base + incl - (active ? count : 0u);
+}
+#ifndef HFCL_WPE_BVH_WALK
+#define HFCL_WPE_BVH_WALK 2
+#endif
+#ifndef HFCL_WALK_NODE_CACHE
+#define HFCL_WALK_NODE_CACHE 1
+#endif
+// k_bvh_walk: collisionRecurse (src/traversal/traversal_recurse.cpp:44-85) with the triangle pairs LISTED instead of tested, one query
+// per lane, lanes refilled from a ticket as in k_bvh_collide.  A disjoint box pair only ever enters the walk's state through a
+// minimum (updateDistanceLowerBoundFromBV), so the boxes between two leaves leave one number: the smallest bound among them.
+template <typename T>
+__global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH_WALK, 8)))
+k_bvh_walk(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, T break_distance2, WalkArgs wa) {
+  typedef BvhEntry<false> EN;
+  constexpr int STACK = BVH_STACK_WALK;
+  __shared__ uint32_t stack[STACK][BVH_BLOCK];
+  WalkRec<T>* const recs = reinterpret_cast<WalkRec<T>*>(wa.recs);
+  uint32_t* const c = wa.ctr + 8 * wa.round;
+  const uint32_t cnt = wa.round ? wa.ctr[8 * (wa.round - 1) + 2] : wk.counts[B_BVH];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const T big = Lim<T>::max(), nanv = Lim<T>::nan();
+  bool live = false, pending = false, exhausted = false;  // exhausted is wave-uniform
+  uint32_t ri = 0, steps = 0, n_leaf = 0, flags = 0, noff1 = 0, noff2 = 0;
+  int sp = 0;
+  M3<T> RT_R;
+  V3<T> RT_T = mk<T>(T(0), T(0), T(0));
+  RT_R.r0 = RT_R.r1 = RT_R.r2 = RT_T;
+  T pre_cur = big;
+#if HFCL_WALK_NODE_CACHE
+  DNode<T> n1, n2;
+  n1.first_child = n2.first_child = 0;
+  n1.axes = n2.axes = RT_R;
+  n1.To = n2.To = n1.extent = n2.extent = RT_T;
+  uint32_t id1 = 0xFFFFFFFFu, id2 = 0xFFFFFFFFu;
+#endif
+  for (;;) {
+    if (live && (sp == 0 || n_leaf >= wa.k || flags != 0u)) {  // this round is over for the lane's query
+      if (sp == 0) flags |= WALK_OVER;
+      live = false;
+      pending = true;
+    }
+    const uint64_t live_mask = __ballot(live);
+    const int n_live = __popcll(live_mask);
+    if (exhausted ? n_live == 0 : 64 - n_live >= BVH_REFILL_MIN) {
+      // ---- the parked queries' records and their items (one reservation per wave), then new queries from the ticket
+      if (__ballot(pending)) {
+        WalkRec<T>* const r = recs + ri;
+        const uint32_t first = wave_reserve(&c[1], n_leaf, pending);
+        if (pending) {
+          const bool fits = first + n_leaf <= wa.item_cap;  // (the host sizes the list for WALK_K items per query: always)
+          r->sp = uint32_t(sp);
+          r->n_leaf = fits ? n_leaf : 0u;
+          r->flags = fits ? flags : (flags | 4u);
+          r->first_item = first;
+          r->pre[n_leaf] = pre_cur;
+          for (int k = 0; k < sp; ++k) r->stack[k] = stack[k][tid];
+          if (fits)
+            for (uint32_t s2 = 0; s2 < n_leaf; ++s2) wa.items[first + s2] = ri | (s2 << 28);
+          pending = false;
+        }
+      }
+      if (exhausted) break;
+      const int n_need = 64 - n_live;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&c[0], uint32_t(n_need));
+      base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+      if (!live) {
+        const uint32_t it = base + uint32_t(__popcll(~live_mask & ((uint64_t(1) << lane) - 1)));
+        if (it < cnt) {
+          uint32_t pair;
+          if (wa.round) {
+            ri = wa.list_in[it];
+            const WalkRec<T>* const r = recs + ri;
+            pair = r->pair;
+            sp = int(r->sp);
+            for (int k = 0; k < sp; ++k) stack[k][tid] = r->stack[k];
+          } else {
+            ri = it;
+            pair = wk.lists[size_t(B_BVH) * wk.n + it];
+            WalkRec<T>* const r = recs + ri;
+            r->pair = pair;
+            r->dlb = r->rec_dist = r->cand_val = big;
+            store_witness(io, pair, mk<T>(nanv, nanv, nanv), mk<T>(nanv, nanv, nanv), mk<T>(nanv, nanv, nanv));
+            stack[0][tid] = 0u;  // (b1 = 0, b2 = 0)
+            sp = 1;
+          }
+          noff1 = bv.meshes[lib.shapes[wk.shape1[pair]].bvh_index].node_off;
+          noff2 = bv.meshes[lib.shapes[wk.shape2[pair]].bvh_index].node_off;
+          const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
+          RT_R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
+          RT_T = tmul(tf1.R, tf2.t - tf1.t);
+          steps = 0;
+          n_leaf = 0;
+          flags = 0;
+          pre_cur = big;
+#if HFCL_WALK_NODE_CACHE
+          id1 = id2 = 0xFFFFFFFFu;
+#endif
+          live = true;
+        }
+      }
+      if (base + uint32_t(n_need) >= cnt) exhausted = true;
+      continue;
+    }
+    for (;;) {
+      const bool can = live && sp > 0 && n_leaf < wa.k && flags == 0u;
+      const uint64_t can_mask = __ballot(can);
+      if (!can_mask) break;
+      if (!exhausted && 64 - __popcll(can_mask) >= BVH_REFILL_MIN) break;
+      if (!can) continue;
+      if (wa.budget && steps >= wa.budget) {
+        flags = WALK_BUDGET;
+        continue;
+      }
+      ++steps;
+      const uint32_t e = stack[--sp][tid];
+      const uint32_t b1 = EN::first(e), b2 = EN::second(e);
+#if HFCL_WALK_NODE_CACHE
+      // the pair popped behind a box test shares a node with the pair tested (its child pair or its sibling): that record stays in registers
+      if (b1 != id1) {
+        n1 = bv.nodes[noff1 + b1];
+        id1 = b1;
+      }
+      if (b2 != id2) {
+        n2 = bv.nodes[noff2 + b2];
+        id2 = b2;
+      }
+#else
+      const DNode<T> n1 = bv.nodes[noff1 + b1];
+      const DNode<T> n2 = bv.nodes[noff2 + b2];
+#endif
+      const bool l1 = n1.first_child < 0, l2 = n2.first_child < 0;
+      if (l1 && l2) {
+        WalkRec<T>* const r = recs + ri;
+        r->leaf1[n_leaf] = uint32_t(-(n1.first_child + 1));
+        r->leaf2[n_leaf] = uint32_t(-(n2.first_child + 1));
+        r->pre[n_leaf] = pre_cur;
+        pre_cur = big;
+        ++n_leaf;
+        continue;
+      }
+      const T sz1 = sqnorm(n1.extent), sz2 = sqnorm(n2.extent);
+      const bool first = l2 || (!l1 && (sz1 > sz2));  // firstOverSecond
+#if HFCL_BVH_PREFETCH
+      const DNode<T>* const next = bv.nodes + (first ? noff1 + uint32_t(n1.first_child) : noff2 + uint32_t(n2.first_child));
+      const int32_t touched = next[0].first_child;  // (k_bvh_collide: the record of the pair popped next, on its way up the caches)
+#endif
+      T sq;
+      // argument order of the reference: overlap(RT.R, RT.T, model2.bv(b2), model1.bv(b1))
+      const bool disjoint = obb_disjoint(RT_R, RT_T, n2, n1, q.security_margin, break_distance2, sq);
+#if HFCL_BVH_PREFETCH
+      asm volatile("" ::"v"(touched));
+#endif
+      if (disjoint) {
+        const T nd = hsqrt(sq);
+        if (nd < pre_cur) pre_cur = nd;
+      } else if (sp + 2 > STACK) {
+        stack[sp++][tid] = e;  // no room for its children: the pair goes back, the rest of the walk is k_bvh_coop's
+        flags = WALK_BUDGET;
+      } else {
+        uint32_t ea, eb;
+        if (first) {
+          const uint32_t c1 = uint32_t(n1.first_child);
+          ea = EN::pack(c1, b2);
+          eb = EN::pack(c1 + 1, b2);
+        } else {
+          const uint32_t c1 = uint32_t(n2.first_child);
+          ea = EN::pack(b1, c1);
+          eb = EN::pack(b1, c1 + 1);
+        }
+        stack[sp++][tid] = eb;  // second child below
+        stack[sp++][tid] = ea;  // first child on top
+      }
+    }
+  }
+}
+
+// k_tri_leaves: every triangle pair the round's walks listed, one per lane (leafCollides' distance, traversal_node_bvhs.h:184-233,
+// through the same tri_leaf_call as k_bvh_coop: one machine code for the leaf, whoever asks).
+template <typename T>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
+k_tri_leaves(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, WalkArgs wa) {
+  __shared__ T w0_slab[W0Lds<T, 64>::WORDS];
+  const W0Lds<T, 64> leaf_ps{w0_slab + threadIdx.x};
+  const WalkRec<T>* const recs = reinterpret_cast<const WalkRec<T>*>(wa.recs);
+  TriLeafOut<T>* const res = reinterpret_cast<TriLeafOut<T>*>(wa.res);
+  const uint32_t n_items = min(wa.ctr[8 * wa.round + 1], wa.item_cap);
+  for (uint32_t base = blockIdx.x * 64u; base < n_items; base += gridDim.x * 64u) {
+    const uint32_t it = base + threadIdx.x;
+    if (it < n_items) {
+      const uint32_t item = wa.items[it];
+      const WalkRec<T>* const r = recs + (item & 0x0FFFFFFFu);
+      const uint32_t s2 = item >> 28, pair = r->pair;
+      const DMesh m1 = bv.meshes[lib.shapes[wk.shape1[pair]].bvh_index], m2 = bv.meshes[lib.shapes[wk.shape2[pair]].bvh_index];
+      TriLeafOut<T> tlo;
+      tri_leaf_call<T>(bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + r->leaf1[s2]), bv.verts + 3 * size_t(m2.vert_off),
+                       bv.tris + 3 * size_t(m2.tri_off + r->leaf2[s2]), io.tf1, io.tf2, pair, &q, leaf_ps, &tlo);
+      res[it] = tlo;
+    }
+  }
+}
+
+// the suspended queries as round `round` left them: the launch of k_bvh_coop that runs beside the later rounds continues those it added
+__global__ void k_walk_snap(BvhSplit split, uint32_t round) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) split.walk.ctr[8u * round + WALK_CTR_SNAP] = min(split.ctr[BVH_CTR_SUSPENDED], split.n_queries);
+}
+
+// k_bvh_resolve: a query's events of this round in the reference's order -- the boxes in front of a leaf (their smallest bound:
+// updateDistanceLowerBoundFromBV), the leaf (updateDistanceLowerBoundFromLeaf, the witness of the last one that lowered the bound, the
+// contact that ends the walk: whatever the walk listed behind it is void) -- and where the query goes from here: its record, the next
+// round, or k_bvh_coop (a suspended query with its stack as tasks, exactly what k_bvh_collide's suspension leaves).
+template <typename T>
+__global__ void __launch_bounds__(256) k_bvh_resolve(Work wk, IO<T> io, QParams<T> q, BvhSplit split, WalkArgs wa) {
+  WalkRec<T>* const recs = reinterpret_cast<WalkRec<T>*>(wa.recs);
+  const TriLeafOut<T>* const res = reinterpret_cast<const TriLeafOut<T>*>(wa.res);
+  uint32_t* const c = wa.ctr + 8 * wa.round;
+  const uint32_t cnt = wa.round ? wa.ctr[8 * (wa.round - 1) + 2] : wk.counts[B_BVH];
+  for (uint32_t base = blockIdx.x * blockDim.x; base < cnt; base += gridDim.x * blockDim.x) {
+    const uint32_t it = base + threadIdx.x;
+    const bool valid = it < cnt;
+    uint32_t ri = 0, pair = 0, sp = 0;
+    bool next = false, coop = false, lost = false;
+    WalkRec<T>* r = recs;
+    T dlb = T(0), rec_dist = T(0), cand_val = T(0);
+    if (valid) {
+      ri = wa.round ? wa.list_in[it] : it;
+      r = recs + ri;
+      pair = r->pair;
+      sp = r->sp;
+      const uint32_t n_leaf = r->n_leaf, flags = r->flags;
+      dlb = r->dlb;
+      rec_dist = r->rec_dist;
+      cand_val = r->cand_val;
+      int fb1 = -1, fb2 = -1, wit = -1;
+      bool contact = false;
+      auto boxes = [&](T pre) {  // updateDistanceLowerBoundFromBV over a run of disjoint boxes
+        if (!(dlb <= T(0)) && pre < dlb) {
+          dlb = pre;
+          rec_dist = pre + q.security_margin;
+        }
+      };
+      for (uint32_t s2 = 0; s2 < n_leaf; ++s2) {
+        boxes(r->pre[s2]);
+        const T distance = res[r->first_item + s2].distance;
+        const T dtc = distance - q.security_margin;
+        if (dtc < dlb) {  // updateDistanceLowerBoundFromLeaf
+          dlb = dtc;
+          cand_val = dtc;
+          rec_dist = distance;
+          wit = int(s2);
+        }
+        if (dtc <= q.collision_distance_threshold) {  // the first contact: canStop()
+          contact = true;
+          fb1 = int(r->leaf1[s2]);
+          fb2 = int(r->leaf2[s2]);
+          break;
+        }
+      }
+      if (!contact) boxes(r->pre[n_leaf]);
+      if (wit >= 0) {
+        const TriLeafOut<T> w = res[r->first_item + uint32_t(wit)];
+        store_witness(io, pair, w.p1, w.p2, w.n);
+      }
+      lost = (flags & 4u) != 0u;  // (its items did not fit the list)
+      if (contact || (flags & WALK_OVER) || lost) {
+        store_bvh_record_head(io, pair, rec_dist, contact ? 1u : 0u, fb1, fb2, lost);
+      } else if (!wa.last && !(flags & WALK_BUDGET)) {
+        next = true;
+      } else {
+        coop = true;
+      }
+      if (next || coop) {
+        r->dlb = dlb;
+        r->rec_dist = rec_dist;
+        r->cand_val = cand_val;
+      }
+    }
+    // ---- the queries that walk on: next round's list
+    {
+      const uint32_t slot = wave_reserve(&c[2], 1u, next);
+      if (next) wa.list_out[slot] = ri;
+    }
+    // ---- the queries k_bvh_coop continues: a suspended query (its state a summary) whose stack entries are its tasks, top first
+    if (__ballot(coop)) {
+      const uint32_t my_slot = wave_reserve(&split.ctr[BVH_CTR_SUSPENDED], 1u, coop);
+      const uint32_t first = wave_reserve(&split.ctr[BVH_CTR_TASKS], sp, coop);
+      if (coop) {
+        const bool fits = first + sp <= split.cap && my_slot < split.n_queries;
+        if (my_slot < split.n_queries) split.suspended[my_slot] = pair;
+        if (fits)
+          for (uint32_t j = 0; j < sp; ++j) split.tasks[first + j] = BvhTask{pair, my_slot, r->stack[sp - 1u - j], j};
+        else
+          for (uint32_t j = first; j < min(first + sp, split.cap); ++j) split.tasks[j] = BvhTask{0u, 0u, 0xFFFFFFFFu, 0u};
+        if (my_slot < split.n_queries) {
+          BvhSum<T>* const sm = bvh_sum<T>(split, my_slot);
+          sm->contact_order = 0xFFFFFFFFu; sm->parent = 0xFFFFFFFFu; sm->order = 0u; sm->pad_ = 0u;
+          sm->dlb = dlb; sm->rec_dist = rec_dist; sm->cand_val = cand_val;
+          sm->fb1 = sm->fb2 = -1;
+          sm->ncontacts = 0u; sm->first_child = first; sm->n_child = fits ? sp : 0u;
+          sm->flags = BVH_SUM_SUSPENDED | (fits ? 0u : BVH_SUM_OVERFLOW);  // (a full task table: flagged, as k_bvh_collide flags a stack it cannot hand on)
+          load_witness(io, pair, sm->np1, sm->np2, sm->nn);
+        }
+      }
+    }
+  }
+}
+#endif
+
 // =======================================================================================
 // launchers (hfcl_launch.hpp)
 // =======================================================================================
@@ -2897,7 +3239,7 @@ static void launch_coop_levels(int grid, hipStream_t st, const Work& wk, const I
 }
 // (static: each part of this unit has its own -- the mesh x solid part walks its task levels with it, solid = true)
 template <typename T>
-static void bvh_collide_levels(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill, bool solid) {
+static void bvh_collide_levels(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill, bool solid, const AsideStream* aside = nullptr) {
   if (spill.wide && !solid) {  // models with 32-bit node ids: single pass, global spill instead of tasks
     split.tasks = nullptr;
     split.budget = 0;
@@ -2923,13 +3265,50 @@ static void bvh_collide_levels(int grid, hipStream_t st, const Work& wk, const L
     s0.level = 0;
     s0.budget = split.budget0;
     s0.can_suspend = 1;
-    launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s0, spill, false);
+    uint32_t n_early = 0;  // helper streams with a continuation launch on them
+    if (split.walk.recs && split.walk_rounds) {
+      // the queries' own phase in rounds: walk (its leaves listed), leaves (one per lane), resolve (hfcl_dev.hpp: WalkRec)
+      WalkArgs wa = split.walk;
+      uint32_t* const lists = wa.list_in;
+      const int lgrid = std::max(1, std::min(grid * 2, int(split.coop_grid ? split.coop_grid : 2048u)));
+      // The queries a round hands over (step budget) are continued on a helper stream BESIDE the later rounds: at 100k queries neither
+      // fills the chip (1 500 waves of lanes, then a few thousand waves of one query each), both are chains of dependent steps.
+      const bool early = aside && split.walk_rounds > 1 && !(split.cut_ticks && split.cut_words);
+      const int coop_grid_w = std::max(1, std::min(grid * BVH_BLOCK, split.coop_grid ? int(split.coop_grid) : grid * 2));
+      for (uint32_t r = 0; r < split.walk_rounds; ++r) {
+        if (early && r >= 1 && aside[r - 1].stream) {
+          const AsideStream& as = aside[r - 1];
+          hipLaunchKernelGGL(k_walk_snap, dim3(1), dim3(64), 0, st, s0, r - 1u);
+          hipEventRecord(as.fork, st);
+          hipStreamWaitEvent(as.stream, as.fork, 0);
+          BvhSplit s1 = s0;
+          s1.coop_range = r;  // (1 + the round that just ended)
+          s1.can_suspend = 0u;
+          hipLaunchKernelGGL((k_bvh_coop<T>), dim3(coop_grid_w), dim3(64), 0, as.stream, wk, lv, bv, io, q, bp, break_distance2, s1);
+          hipEventRecord(as.join, as.stream);
+          s0.coop_range = 0x100u + (r - 1u);
+          n_early = r;
+        }
+        wa.round = r;
+        wa.k = std::min<uint32_t>(split.walk_k[r], uint32_t(WALK_K));
+        wa.budget = split.walk_budget[r];
+        wa.last = r + 1 == split.walk_rounds ? 1u : 0u;
+        wa.list_out = lists + size_t(r & 1u) * wa.list_stride;
+        wa.list_in = lists + size_t((r + 1u) & 1u) * wa.list_stride;  // (= the list_out of round r - 1; not read in round 0)
+        hipLaunchKernelGGL((k_bvh_walk<T>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, break_distance2, wa);
+        hipLaunchKernelGGL((k_tri_leaves<T>), dim3(lgrid), dim3(64), 0, st, wk, lv, bv, io, q, wa);
+        hipLaunchKernelGGL((k_bvh_resolve<T>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, io, q, s0, wa);
+      }
+    } else {
+      launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s0, spill, false);
+    }
     // a wave per suspended query, up to what the chip holds (`grid` blocks of BVH_BLOCK queries: `grid * 2` waves left a quarter of the
     // wave slots empty at 100k queries, profiles/r04_h)
     const int coop_grid = std::max(1, std::min(grid * BVH_BLOCK, split.coop_grid ? int(split.coop_grid) : grid * 2));
     launch_coop_levels<T>(grid, st, wk, io, s0, int(B_COUNT + 2), [&](const BvhSplit& s) {
       hipLaunchKernelGGL((k_bvh_coop<T>), dim3(coop_grid), dim3(64), 0, st, wk, lv, bv, io, q, bp, break_distance2, s);
     });
+    for (uint32_t r = 0; r < n_early; ++r) hipStreamWaitEvent(st, aside[r].join, 0);
     return;
   }
 #endif
@@ -2950,8 +3329,8 @@ static void bvh_collide_levels(int grid, hipStream_t st, const Work& wk, const L
 #endif
 #if HFCL_BVH_MESH_PART
 template <typename T>
-void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill) {
-  bvh_collide_levels<T>(grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill, false);
+void launch_bvh_collide(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const BvhView<T>& bv, const IO<T>& io, const QParams<T>& q, const BvhParams& bp, T break_distance2, BvhSplit split, BvhSpill spill, const AsideStream* aside) {
+  bvh_collide_levels<T>(grid, st, wk, lv, bv, io, q, bp, break_distance2, split, spill, false, aside);
 }
 #endif
 #if HFCL_BVH_SOLID_PART
@@ -3034,7 +3413,7 @@ void launch_triangle(int grid, hipStream_t st, const Work& wk, const LibView<T>&
 #endif
 #if HFCL_BVH_MESH_PART
 #define HFCL_INST(T)                                                                                                             \
-  template void launch_bvh_collide<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill); \
+  template void launch_bvh_collide<T>(int, hipStream_t, const Work&, const LibView<T>&, const BvhView<T>&, const IO<T>&, const QParams<T>&, const BvhParams&, T, BvhSplit, BvhSpill, const AsideStream*); \
   template void launch_triangle<T>(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&);
 HFCL_INST(float)
 HFCL_INST(double)
