@@ -243,6 +243,8 @@ struct hfcl_lib {
   uint32_t* d_walk_lists = nullptr;
   uint32_t* d_walk_ctr = nullptr;
   size_t walk_n = 0;
+  size_t epa_resume_slots = 0, bvh_task_slots = 0;  // options epa_resume_slots / bvh_task_slots (0: sized by the batch)
+  bool bvh_force_wide = false, pipe_trace = false;   // options bvh_force_wide / pipe_trace
   bool walk_early_coop = true;                               // HFCL_BVH_WALK_EARLY_COOP: the queries round 0 hands over are continued beside the later rounds
   uint32_t walk_rounds = 2;                                  // HFCL_BVH_WALK_ROUNDS (0: k_bvh_collide walks the queries, leaves inline)
   uint32_t walk_k[WALK_ROUNDS] = {6, 16, 16, 16};           // HFCL_BVH_WALK_K: leaves a walk lists per round
@@ -461,6 +463,90 @@ static bool upload_shapes(hfcl_lib* lib, const hfcl_shape* shapes, size_t n_shap
   return ok;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Tuning options (include/hppfcl_amd.h: hfcl_lib_set_option).  One table: the keys, and what each sets.  Every option is a field of
+// the library read when a batch is set up, so an option holds from the next call on; none changes a record (tests/ hold the forms
+// against each other), they choose between forms of the same computation and size their budgets.
+// ---------------------------------------------------------------------------------------
+static const char* const* option_keys() {
+  static const char* const keys[] = {
+      "closed_staged", "split", "epa_cc_staged", "epa_records_aside", "epa_general_staged", "shape_finish_tiers", "shape_finish_aside",
+      "epa_general_staged_min", "epa64_two_streams", "epa_cc_staged_min", "pipe_chunk", "bvh_filter", "bvh_shape_lane", "shape_coop",
+      "bvh_cut_ticks", "shape_cut_ticks", "bvh_coop", "bvhd_budget", "bvhd_pool", "shape_dist_pool", "pool_rerun", "bvh_walk_early_coop",
+      "bvh_walk_rounds", "bvh_walk_k", "bvh_walk_budget", "shape_dist_leaf_min", "shape_dist_starve", "bvhd_leaf_min", "bvhd_starve",
+      "bvhd_part_min", "shape_dist_budget", "bvh_budget0_coop", "shape_budget0", "shape_budget", "shape_leaf_cost", "shape_levels",
+      "climb_min", "bvh_budget", "bvh_budget0", "bvh_levels", "cvx_w", "epa_resume_slots", "bvh_task_slots", "bvh_force_wide",
+      "pipe_trace", nullptr};
+  return keys;
+}
+// "4,16,16": up to `cap` comma-separated unsigned values into out[first...]; returns how many were read
+static int parse_list(const char* v, uint32_t* out, int first, int cap, uint32_t lo, uint32_t hi) {
+  int k = first;
+  for (const char* p = v; *p && k < cap; ++k) {
+    const long long x = atoll(p);
+    out[k] = uint32_t(std::min<long long>(std::max<long long>(x, lo), hi));
+    while (*p && *p != ',') ++p;
+    if (*p == ',') ++p;
+  }
+  return k - first;
+}
+static int apply_option(hfcl_lib* lib, const std::string& key, const char* v) {
+  const long long i = atoll(v);
+  const bool on = i != 0;
+  auto u32 = [&](long long lo) { return uint32_t(std::min<long long>(std::max(i, lo), 0xFFFFFFFFll)); };
+  if (key == "closed_staged") lib->closed_staged = on;
+  else if (key == "split") lib->split = i >= 2 ? 2 : (i == 1 ? 1 : 0);
+  else if (key == "epa_cc_staged") lib->epa_cc_staged = on;
+  else if (key == "epa_records_aside") lib->records_aside = on;
+  else if (key == "epa_general_staged") lib->epa_general_staged = on;
+  else if (key == "shape_finish_tiers") lib->shape_finish_tiers = on;
+  else if (key == "shape_finish_aside") lib->shape_finish_aside = on;
+  else if (key == "epa_general_staged_min") lib->epa_general_staged_min = size_t(std::max(0ll, i));
+  else if (key == "epa64_two_streams") lib->epa64_two_streams = on;
+  else if (key == "epa_cc_staged_min") lib->epa_cc_staged_min = size_t(std::max(0ll, i));
+  else if (key == "pipe_chunk") lib->pipe_chunk = strtoull(v, nullptr, 10);
+  else if (key == "bvh_filter") lib->bvh_filter = on;
+  else if (key == "bvh_shape_lane") lib->bvh_shape_lane = on;
+  else if (key == "shape_coop") lib->shape_coop = on;
+  else if (key == "bvh_cut_ticks") lib->bvh_cut_ticks = uint32_t(strtoul(v, nullptr, 10));
+  else if (key == "shape_cut_ticks") lib->shape_cut_ticks = uint32_t(strtoul(v, nullptr, 10));
+  else if (key == "bvh_coop") lib->bvh_coop = on;
+  else if (key == "bvhd_budget") lib->bvhd_budget = u32(0);
+  else if (key == "bvhd_pool") lib->bvhd_pool = u32(0);
+  else if (key == "shape_dist_pool") lib->shape_dist_pool = u32(0);
+  else if (key == "pool_rerun") lib->pool_rerun = u32(0);
+  else if (key == "bvh_walk_early_coop") lib->walk_early_coop = on;
+  else if (key == "bvh_walk_rounds") lib->walk_rounds = uint32_t(std::min<long long>(std::max(0ll, i), WALK_ROUNDS));
+  else if (key == "bvh_walk_k") parse_list(v, lib->walk_k, 0, WALK_ROUNDS, 1u, uint32_t(WALK_K));  // "6,16": per round
+  else if (key == "bvh_walk_budget") parse_list(v, lib->walk_budget, 1, WALK_ROUNDS, 0u, 0xFFFFFFFFu);  // rounds 1 ...: box tests (round 0 takes bvh_budget0_coop's)
+  else if (key == "shape_dist_leaf_min") lib->shape_dist_leaf_min = u32(1);
+  else if (key == "shape_dist_starve") lib->shape_dist_starve = u32(1);  // (>= 1: a window of triangles alone must always run)
+  else if (key == "bvhd_leaf_min") lib->bvhd_pool_leaf_min = u32(1);
+  else if (key == "bvhd_starve") lib->bvhd_pool_starve = u32(1);
+  else if (key == "bvhd_part_min") lib->bvhd_pool_part_min = u32(0);
+  else if (key == "shape_dist_budget") lib->shape_dist_budget = u32(0);
+  else if (key == "bvh_budget0_coop") lib->bvh_budget0_coop = u32(1);
+  else if (key == "shape_budget0") lib->shape_budget0 = lib->shape_budget0_coop = uint32_t(i);
+  else if (key == "shape_budget") lib->shape_budget = uint32_t(i);
+  else if (key == "shape_leaf_cost") lib->shape_leaf_cost = u32(1);
+  else if (key == "shape_levels") lib->shape_levels = uint32_t(std::min<long long>(std::max(1ll, i), BVH_MAX_LEVELS));
+  else if (key == "climb_min") lib->climb_min = u32(0);
+  else if (key == "bvh_budget") { lib->bvh_budget = lib->bvh_budget0 = u32(0); lib->bvh_auto = false; }
+  else if (key == "bvh_budget0") { lib->bvh_budget0 = u32(0); lib->bvh_auto = false; }
+  else if (key == "bvh_levels") { lib->bvh_levels = uint32_t(std::min<long long>(BVH_MAX_LEVELS, std::max(1ll, i))); lib->bvh_auto = false; }
+  else if (key == "cvx_w") {
+    if (i == 0 || i == 2 || i == 4 || i == 8 || i == 16 || i == 32 || i == 64) lib->cvx_w = int(i);
+    else return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  else if (key == "epa_resume_slots") lib->epa_resume_slots = size_t(std::max(0ll, i));
+  else if (key == "bvh_task_slots") lib->bvh_task_slots = size_t(std::max(0ll, i));
+  else if (key == "bvh_force_wide") lib->bvh_force_wide = on;
+  else if (key == "pipe_trace") lib->pipe_trace = on;
+  else return HFCL_ERR_INVALID_ARGUMENT;
+  return HFCL_OK;
+}
+
 hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const double* vertices, size_t n_vertices,
                           int device) {
   if (ensure_device(device) != HFCL_OK) return nullptr;
@@ -484,64 +570,12 @@ hfcl_lib* hfcl_lib_create(const hfcl_shape* shapes, size_t n_shapes, const doubl
     hfcl_lib_destroy(lib);
     return nullptr;
   }
-  if (const char* v = getenv("HFCL_CLOSED_STAGED")) lib->closed_staged = atoi(v) != 0;
-  if (const char* v = getenv("HFCL_SPLIT")) lib->split = atoi(v) >= 2 ? 2 : (atoi(v) == 1 ? 1 : 0);
-  if (const char* v = getenv("HFCL_EPA_CC_STAGED")) lib->epa_cc_staged = atoi(v) != 0;
-  if (const char* v = getenv("HFCL_EPA_RECORDS_ASIDE")) lib->records_aside = atoi(v) != 0;
-  if (const char* v = getenv("HFCL_EPA_GENERAL_STAGED")) lib->epa_general_staged = atoi(v) != 0;
-  if (const char* v = getenv("HFCL_SHAPE_FINISH_TIERS")) lib->shape_finish_tiers = atoi(v) != 0;
-  if (const char* v = getenv("HFCL_SHAPE_FINISH_ASIDE")) lib->shape_finish_aside = atoi(v) != 0;
-  if (const char* v = getenv("HFCL_EPA_GENERAL_STAGED_MIN")) lib->epa_general_staged_min = size_t(std::max(0ll, atoll(v)));
-  if (const char* v = getenv("HFCL_EPA64_TWO_STREAMS")) lib->epa64_two_streams = atoi(v) != 0;
-  if (const char* v = getenv("HFCL_EPA_CC_STAGED_MIN")) lib->epa_cc_staged_min = size_t(std::max(0ll, atoll(v)));
-  if (const char* v = getenv("HFCL_PIPE_CHUNK")) lib->pipe_chunk = strtoull(v, nullptr, 10);
-  if (const char* v = getenv("HFCL_BVH_FILTER")) lib->bvh_filter = atoi(v) != 0;
-  if (const char* v = getenv("HFCL_BVH_SHAPE_LANE")) lib->bvh_shape_lane = atoi(v) != 0;
-  if (const char* v = getenv("HFCL_SHAPE_COOP")) lib->shape_coop = atoi(v) != 0;
-  if (const char* v = getenv("HFCL_BVH_CUT_TICKS")) lib->bvh_cut_ticks = uint32_t(strtoul(v, nullptr, 10));
-  if (const char* v = getenv("HFCL_SHAPE_CUT_TICKS")) lib->shape_cut_ticks = uint32_t(strtoul(v, nullptr, 10));
-  if (const char* v = getenv("HFCL_BVH_COOP")) lib->bvh_coop = atoi(v) != 0;
-  if (const char* v = getenv("HFCL_BVHD_BUDGET")) lib->bvhd_budget = uint32_t(std::max(0, atoi(v)));
-  if (const char* v = getenv("HFCL_BVHD_POOL")) lib->bvhd_pool = uint32_t(std::max(0, atoi(v)));
-  if (const char* v = getenv("HFCL_SHAPE_DIST_POOL")) lib->shape_dist_pool = uint32_t(std::max(0, atoi(v)));
-  if (const char* v = getenv("HFCL_POOL_RERUN")) lib->pool_rerun = uint32_t(std::max(0, atoi(v)));
-  if (const char* v = getenv("HFCL_BVH_WALK_ROUNDS")) lib->walk_rounds = uint32_t(std::min(std::max(0, atoi(v)), int(WALK_ROUNDS)));
-  if (const char* v = getenv("HFCL_BVH_WALK_EARLY_COOP")) lib->walk_early_coop = atoi(v) != 0;
-  if (const char* v = getenv("HFCL_BVH_WALK_K")) {  // "4,16": per round
-    int k = 0;
-    for (const char* p = v; *p && k < WALK_ROUNDS; ++k) {
-      lib->walk_k[k] = uint32_t(std::min(std::max(1, atoi(p)), int(WALK_K)));
-      while (*p && *p != ',') ++p;
-      if (*p == ',') ++p;
-    }
-  }
-  if (const char* v = getenv("HFCL_BVH_WALK_BUDGET")) {  // rounds 1 ...: box tests (round 0 takes HFCL_BVH_BUDGET0_COOP's)
-    int k = 1;
-    for (const char* p = v; *p && k < WALK_ROUNDS; ++k) {
-      lib->walk_budget[k] = uint32_t(std::max(0, atoi(p)));
-      while (*p && *p != ',') ++p;
-      if (*p == ',') ++p;
-    }
-  }
-  if (const char* v = getenv("HFCL_SHAPE_DIST_LEAF_MIN")) lib->shape_dist_leaf_min = uint32_t(std::max(1, atoi(v)));
-  if (const char* v = getenv("HFCL_SHAPE_DIST_STARVE")) lib->shape_dist_starve = uint32_t(std::max(1, atoi(v)));  // (>= 1: a window of triangles alone must always run)
-  if (const char* v = getenv("HFCL_BVHD_LEAF_MIN")) lib->bvhd_pool_leaf_min = uint32_t(std::max(1, atoi(v)));
-  if (const char* v = getenv("HFCL_BVHD_STARVE")) lib->bvhd_pool_starve = uint32_t(std::max(1, atoi(v)));
-  if (const char* v = getenv("HFCL_BVHD_PART_MIN")) lib->bvhd_pool_part_min = uint32_t(std::max(0, atoi(v)));
-  if (const char* v = getenv("HFCL_SHAPE_DIST_BUDGET")) lib->shape_dist_budget = uint32_t(std::max(0, atoi(v)));
-  if (const char* v = getenv("HFCL_BVH_BUDGET0_COOP")) lib->bvh_budget0_coop = uint32_t(std::max(1, atoi(v)));
-  if (const char* v = getenv("HFCL_SHAPE_BUDGET0")) lib->shape_budget0 = lib->shape_budget0_coop = uint32_t(atoi(v));
-  if (const char* v = getenv("HFCL_SHAPE_BUDGET")) lib->shape_budget = uint32_t(atoi(v));
-  if (const char* v = getenv("HFCL_SHAPE_LEAF_COST")) lib->shape_leaf_cost = uint32_t(std::max(1, atoi(v)));
-  if (const char* v = getenv("HFCL_SHAPE_LEVELS")) lib->shape_levels = uint32_t(std::min(std::max(1, atoi(v)), int(BVH_MAX_LEVELS)));
-  if (const char* v = getenv("HFCL_CLIMB_MIN")) lib->climb_min = uint32_t(std::max(0, atoi(v)));
-  if (const char* v = getenv("HFCL_BVH_BUDGET")) lib->bvh_budget = lib->bvh_budget0 = uint32_t(std::max(0, atoi(v)));
-  if (const char* v = getenv("HFCL_BVH_BUDGET0")) lib->bvh_budget0 = uint32_t(std::max(0, atoi(v)));
-  if (getenv("HFCL_BVH_BUDGET") || getenv("HFCL_BVH_BUDGET0") || getenv("HFCL_BVH_LEVELS")) lib->bvh_auto = false;
-  if (const char* v = getenv("HFCL_BVH_LEVELS")) lib->bvh_levels = uint32_t(std::min(BVH_MAX_LEVELS, std::max(1, atoi(v))));
-  if (const char* w = getenv("HFCL_CVX_W")) {
-    int v = atoi(w);
-    if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) lib->cvx_w = v;
+  // Tuning options: hfcl_lib_set_option is the interface; the environment (HFCL_<KEY>) is read ONCE, here, as a fallback for
+  // processes that cannot call it (A/B runs of an unchanged binary).
+  for (const char* const* k = option_keys(); *k; ++k) {
+    std::string name = "HFCL_";
+    for (const char* c = *k; *c; ++c) name.push_back(char(toupper(static_cast<unsigned char>(*c))));
+    if (const char* v = getenv(name.c_str())) apply_option(lib, *k, v);
   }
   return lib;
 }
@@ -790,7 +824,7 @@ static int ensure_workspace(hfcl_lib* lib, size_t n, bool need_epa) {
     // saved polytopes for the tier hand-over: room for an eighth of the batch (cfg5: 4 % of the pairs outgrow the fast
     // tier; beyond the area the full tier simply redoes the pair from its seed)
     size_t rcap = std::min(cap, std::max<size_t>(65536, cap / 8));
-    if (const char* e = getenv("HFCL_EPA_RESUME_SLOTS")) rcap = std::max<size_t>(1, std::min<size_t>(cap, strtoull(e, nullptr, 10)));  // test knob
+    if (lib->epa_resume_slots) rcap = std::max<size_t>(1, std::min<size_t>(cap, lib->epa_resume_slots));  // test knob (option epa_resume_slots)
     HIP_TRY(hipMalloc(&lib->d_epa_resume, rcap * std::max(epa_resume_stride<double>, epa_resume_stride<float>)));
     HIP_TRY(hipMalloc((void**)&lib->d_epa_cc_over, rcap * sizeof(uint32_t)));
     lib->resume_cap = rcap;
@@ -807,7 +841,7 @@ static int ensure_bvh_split(hfcl_lib* lib, size_t n) {
   lib->d_bvh_tasks = nullptr; lib->d_bvh_sums = nullptr; lib->d_bvh_susp = nullptr; lib->d_bvh_cut_words = nullptr; lib->d_bvh_cut_vals = nullptr;
   lib->bvh_split_n = 0;
   size_t per_query = 16;
-  if (const char* e = getenv("HFCL_BVH_TASK_SLOTS")) per_query = std::max<size_t>(1, strtoull(e, nullptr, 10));  // test / tuning knob
+  if (lib->bvh_task_slots) per_query = std::max<size_t>(1, lib->bvh_task_slots);  // test / tuning knob (option bvh_task_slots)
   const size_t nq = n + n / 8 + 1024, cap = per_query * nq + 65536;
   HIP_TRY(hipMalloc(&lib->d_bvh_tasks, cap * sizeof(BvhTask)));
   HIP_TRY(hipMalloc(&lib->d_bvh_sums, (nq + cap) * sizeof(BvhSum<double>)));
@@ -844,7 +878,7 @@ static int make_bvh_spill(hfcl_lib* lib, BvhSpill& sp, bool distance) {
   // no task form: anything deeper than its LDS stack takes the wide form with slabs
   const size_t narrow_holds = distance ? size_t(BVHD_STACK) : size_t(std::min(BVH_STACK, BVH_STACK_FILT)) * HFCL_BVH_LEVELS;
   sp.wide = (lib->bvh_max_nodes > 65535 || need > narrow_holds) ? 1u : 0u;
-  if (getenv("HFCL_BVH_FORCE_WIDE")) sp.wide = 1u;  // test knob: the wide form (and its slabs) on small models
+  if (lib->bvh_force_wide) sp.wide = 1u;  // test knob (option bvh_force_wide): the wide form (and its slabs) on small models
   if (!sp.wide || need <= size_t(std::min(BVH_STACK, BVH_STACK_FILT)) / 2) return HFCL_OK;  // the LDS stack of the wide form suffices
   const size_t cap = ((need + 63) / 64) * 64;                     // entries per lane
   const size_t per_block = size_t(BVH_BLOCK) * cap * 2 * sizeof(uint64_t);  // (entry, bound) records: k_bvh_distance
@@ -1636,6 +1670,7 @@ static hfcl_lib* make_helper(hfcl_lib* lib) {
   h->device = lib->device;
   share_tables(h, lib);
   h->cvx_w = lib->cvx_w;
+  h->epa_resume_slots = lib->epa_resume_slots;
   h->closed_staged = lib->closed_staged;
   h->epa_cc_staged = lib->epa_cc_staged;
   h->records_aside = lib->records_aside;
@@ -2134,8 +2169,8 @@ static int host_batch(hfcl_lib* lib, const uint32_t* s1, const uint32_t* s2, con
     cv.notify_all();
   };
 
-  // HFCL_PIPE_TRACE=1: per-chunk time line of the three threads on stderr (ms since the call started)
-  const bool trace = getenv("HFCL_PIPE_TRACE") != nullptr;
+  // option pipe_trace: per-chunk time line of the three threads on stderr (ms since the call started)
+  const bool trace = lib->pipe_trace;
   const auto t_call = std::chrono::steady_clock::now();
   auto ms_now = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
   std::vector<double> tr(trace ? 6 * n_chunks : 0);
@@ -2467,6 +2502,36 @@ int hfcl_lib_get_split(const hfcl_lib* lib) { return lib ? lib->split : 0; }
 // pairs per chunk of the host-buffer pipeline (0 = automatic: n/8 clamped to 32k .. 256k)
 void hfcl_lib_set_host_chunk(hfcl_lib* lib, size_t pairs) {
   if (lib) lib->pipe_chunk = pairs;
+}
+// Options by name (the list: option_keys above; INTEGRATION.md describes them).  Keys are case-insensitive, an "HFCL_" prefix -- the
+// spelling of the environment fallback -- is accepted.  Holds from the next batch on; the caller does not call it while a batch of this
+// library is being set up on another thread (the library has no lock of its own, like every other hfcl_lib_set_*).
+int hfcl_lib_set_option(hfcl_lib* lib, const char* key, const char* value) {
+  if (!lib || !key || !value) {
+    set_error("hfcl_lib_set_option: null argument");
+    return HFCL_ERR_INVALID_ARGUMENT;
+  }
+  std::string k;
+  for (const char* c = key; *c; ++c) k.push_back(char(tolower(static_cast<unsigned char>(*c))));
+  if (k.compare(0, 5, "hfcl_") == 0) k.erase(0, 5);
+  const int rc = apply_option(lib, k, value);
+  if (rc != HFCL_OK) {
+    set_error("hfcl_lib_set_option: unknown option or value out of range: " + std::string(key) + "=" + value);
+    return rc;
+  }
+  // buffers sized by an option are sized again by the next batch
+  if (k == "epa_resume_slots") lib->epa_capacity = 0;
+  if (k == "bvh_task_slots") lib->bvh_split_n = 0;
+  if (lib->helper) apply_option(lib->helper, k, value);
+  return HFCL_OK;
+}
+// The option names, one per call: index 0, 1, ... until nullptr.
+const char* hfcl_lib_option_key(int index) {
+  if (index < 0) return nullptr;
+  const char* const* k = option_keys();
+  for (int i = 0; k[i]; ++i)
+    if (i == index) return k[i];
+  return nullptr;
 }
 int hfcl_lib_last_split_parts(const hfcl_lib* lib) { return (lib && lib->last_split) ? 2 : 1; }
 

@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
  "hfcl_shard_range", "hfcl_multi_create", "hfcl_multi_destroy", "hfcl_multi_size", "hfcl_multi_replica",
     "hfcl_multi_set_shapes", "hfcl_multi_set_convex_neighbors", "hfcl_multi_add_bvh", "hfcl_collide_batch_multi", "hfcl_distance_batch_multi",
     "hfcl_collide_batch_multi_device", "hfcl_distance_batch_multi_device", "hfcl_collide_batch_multi_f32", "hfcl_distance_batch_multi_f32",
+    "hfcl_lib_set_option", "hfcl_lib_option_key", "hfcl_multi_set_option", "hfcl_multi_last_gather",
 ]
 
 
@@ -72,6 +73,7 @@ def dll():
         d.hfcl_broadphase_pairs_between.restype = C.c_void_p
         d.hfcl_pairlist_size.restype = C.c_size_t
         d.hfcl_pairlist_data.restype = C.c_void_p
+        d.hfcl_lib_option_key.restype = C.c_char_p
         _DLL = d
     return _DLL
 
@@ -82,6 +84,17 @@ def last_error():
 
 def device_count():
     return int(dll().hfcl_device_count())
+
+
+def option_keys():
+    """The names hfcl_lib_set_option accepts (hfcl_lib_option_key)."""
+    out, i = [], 0
+    while True:
+        k = dll().hfcl_lib_option_key(C.c_int(i))
+        if k is None:
+            return out
+        out.append(k.decode())
+        i += 1
 
 
 def bvh_build(vertices, triangles, n_threads=0):
@@ -151,7 +164,8 @@ def _dptr(x):
 class Library:
     """hfcl_lib: a shape library resident on one GPU."""
 
-    def __init__(self, shape_library, device=0):
+    def __init__(self, shape_library, device=0, options=None):
+        """options: {key: value} for hfcl_lib_set_option, applied before the first batch."""
         d = dll()
         self._shapes = np.ascontiguousarray(shape_library.shapes_array())
         self._verts = np.ascontiguousarray(shape_library.vertices_array(), dtype=np.float64)
@@ -161,6 +175,16 @@ class Library:
         if not h:
             raise EngineError(abi.ERR_NO_DEVICE, last_error())
         self._h = C.c_void_p(h)
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, key, value):
+        """hfcl_lib_set_option: a tuning option by name (the same names, upper-cased behind HFCL_, are the environment fallback)."""
+        if isinstance(value, bool):
+            value = int(value)
+        if isinstance(value, (list, tuple)):
+            value = ",".join(str(int(x)) for x in value)
+        _check(dll().hfcl_lib_set_option(self._h, str(key).encode(), str(value).encode()))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -353,7 +377,7 @@ class MultiLibrary:
     """hfcl_multi: replicas of a shape library on several devices of this process (include/hppfcl_amd.h); a batch is cut
     into contiguous shards, one per replica.  `devices` may list a device more than once (host-buffer entry points)."""
 
-    def __init__(self, shape_library, devices=(0,)):
+    def __init__(self, shape_library, devices=(0,), options=None):
         d = dll()
         self._shapes = np.ascontiguousarray(shape_library.shapes_array())
         self._verts = np.ascontiguousarray(shape_library.vertices_array(), dtype=np.float64)
@@ -365,6 +389,22 @@ class MultiLibrary:
         if not h:
             raise EngineError(abi.ERR_NO_DEVICE, last_error())
         self._h = C.c_void_p(h)
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, key, value):
+        """hfcl_multi_set_option: hfcl_lib_set_option on every replica."""
+        if isinstance(value, bool):
+            value = int(value)
+        if isinstance(value, (list, tuple)):
+            value = ",".join(str(int(x)) for x in value)
+        _check(dll().hfcl_multi_set_option(self._h, str(key).encode(), str(value).encode()))
+
+    def last_gather(self):
+        """hfcl_multi_last_gather: ranks the communicator reports, milliseconds of the all-gather (None: no collective), bytes per rank."""
+        ranks, ms, nbytes = C.c_int(0), C.c_double(-1.0), C.c_size_t(0)
+        _check(dll().hfcl_multi_last_gather(self._h, C.byref(ranks), C.byref(ms), C.byref(nbytes)))
+        return {"ranks": int(ranks.value), "ms": float(ms.value) if ms.value >= 0 else None, "bytes_per_rank": int(nbytes.value)}
 
     def close(self):
         if getattr(self, "_h", None):

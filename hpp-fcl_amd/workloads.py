@@ -494,9 +494,9 @@ def cfg4_mesh_mesh_distance(n=100_000, seed=1, n_variants=8, seg=50, ring=50, ha
     return b
 
 
-def make_library(pkg, batch, device=0):
-    """engine.Library for a batch (registers the batch's meshes, if any)."""
-    lib = pkg.Library(batch.lib, device=device)
+def make_library(pkg, batch, device=0, options=None):
+    """engine.Library for a batch (registers the batch's meshes, if any); options: {key: value} for hfcl_lib_set_option."""
+    lib = pkg.Library(batch.lib, device=device, options=options)
     for m in getattr(batch, "meshes", []) or []:
         lib.add_bvh(m)
     return lib

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HFCL_ABI_VERSION 4  /* 4: the hfcl_multi_* entry points (several devices in one process) */
+#define HFCL_ABI_VERSION 5  /* 4: the hfcl_multi_* entry points (several devices in one process); 5: hfcl_lib_set_option / hfcl_multi_set_option, hfcl_multi_last_gather */
 
 /* ---- geometry kinds: numeric values are hpp-fcl's NODE_TYPE
  *      (include/hpp/fcl/collision_object.h:65-89) so a caller can pass
@@ -430,6 +430,14 @@ void hfcl_last_ordered_reruns(hfcl_lib* lib, uint32_t* out4);
 void hfcl_lib_set_split(hfcl_lib* lib, int parts);
 int  hfcl_lib_get_split(const hfcl_lib* lib);
 int  hfcl_lib_last_split_parts(const hfcl_lib* lib);  /* 1 or 2: how the last batch ran */
+/* Tuning options by name.  Every option chooses between forms of the same computation or sizes a budget / a table; none changes a
+ * record (the forms are held against each other byte for byte in tests/).  Keys are case-insensitive; hfcl_lib_option_key(0), (1), ...
+ * enumerates them (NULL ends the list); INTEGRATION.md describes each.  An option holds from the next batch on.  Returns
+ * HFCL_ERR_INVALID_ARGUMENT for an unknown key or a value outside the option's range (nothing is changed then).
+ * The environment is a FALLBACK, read once by hfcl_lib_create: HFCL_<KEY IN UPPER CASE>=value sets the same option for a process that
+ * cannot be changed to call this function (A/B runs of a built binary); a later hfcl_lib_set_option wins. */
+int hfcl_lib_set_option(hfcl_lib* lib, const char* key, const char* value);
+const char* hfcl_lib_option_key(int index);
 /* Per-kernel HIP events are recorded by default; a caller that does not read them can switch
  * them off (on = 0) and save two stream markers per kernel launch. */
 void hfcl_lib_set_kernel_timing(hfcl_lib* lib, int on);
@@ -454,6 +462,12 @@ int hfcl_multi_set_shapes(hfcl_multi* m, const hfcl_shape* shapes, size_t n_shap
 int hfcl_multi_set_convex_neighbors(hfcl_multi* m, uint32_t shape_id, const uint32_t* offsets, const uint32_t* neighbors);
 int hfcl_multi_add_bvh(hfcl_multi* m, const hfcl_bvh_node* nodes, size_t n_nodes, const double* vertices, size_t n_vertices,
                        const uint32_t* triangles, size_t n_tris);
+/* A registration that succeeds on some replicas and fails on another (a device out of memory) leaves the replicas different for good:
+ * the call returns that replica's error and every later hfcl_multi_* call on this object fails with HFCL_ERR_INVALID_ARGUMENT and a
+ * message that says so -- destroy it and create it again.  The caller's current HIP device is the same after every hfcl_multi_* call
+ * as before it. */
+/* hfcl_lib_set_option on every replica. */
+int hfcl_multi_set_option(hfcl_multi* m, const char* key, const char* value);
 /* Host buffers: hfcl_collide_batch / hfcl_distance_batch with the pair list cut into the replicas' shards, every shard
  * through its replica's own pipeline (a host thread each), the records straight into the caller's `out` (the host form
  * needs no collective).  The records equal the single-library call's byte for byte. */
@@ -480,6 +494,11 @@ int hfcl_collide_batch_multi_device(hfcl_multi* m, const uint32_t* const* d_shap
 int hfcl_distance_batch_multi_device(hfcl_multi* m, const uint32_t* const* d_shape1, const uint32_t* const* d_shape2,
                                      const double* const* d_tf1, const double* const* d_tf2, size_t n,
                                      const hfcl_distance_request* req, hfcl_result* const* d_gathered, void* const* streams);
+/* The last device-resident batch, for a caller that wants to see what the exchange did: the ranks the communicator reports
+ * (ncclCommCount; 1 when there was no collective), the duration of the grouped all-gather on replica 0's stream in milliseconds (HIP
+ * events around it; waits for it; < 0: no collective), the bytes each rank contributed.  Bus bandwidth of the all-gather =
+ * (ranks - 1) * bytes_per_rank / ms (what each rank receives; DESIGN.md section 5 holds it against 153 GB/s per xGMI link). */
+int hfcl_multi_last_gather(hfcl_multi* m, int* ranks, double* ms, size_t* bytes_per_rank);
 
 #ifdef __cplusplus
 }

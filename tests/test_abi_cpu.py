@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(declared) >= 19
     for sym in sorted(declared):
         assert hasattr(lib, sym), "missing export: " + sym
-    assert lib.hfcl_abi_version() == 4
+    assert lib.hfcl_abi_version() == 5
     assert set(pkg.engine.EXPORTED_SYMBOLS) <= declared
 
 
@@ -37,6 +37,29 @@ def test_struct_layouts_match_header(pkg):
     c = abi.DistanceRequest()
     lib.hfcl_distance_request_init(C.byref(c))
     assert bytes(c) == bytes(abi.default_distance_request())
+
+
+def test_options_are_an_api_not_an_environment(pkg):
+    """hfcl_lib_set_option: the option names are enumerable without a device, a null library is refused, and the host code reads the
+    environment in ONE place (the fallback loop of hfcl_lib_create) -- no getenv("HFCL_...") scattered through the batch set-up."""
+    import ctypes as C
+    keys = pkg.engine.option_keys()
+    assert len(keys) >= 40 and len(set(keys)) == len(keys)
+    assert {"bvh_walk_rounds", "bvh_coop", "cvx_w", "epa_cc_staged", "bvhd_pool", "shape_dist_pool"} <= set(keys)
+    assert all(k == k.lower() and not k.startswith("hfcl_") for k in keys)
+    d = pkg.engine.dll()
+    assert d.hfcl_lib_set_option(None, b"bvh_coop", b"1") == pkg.abi.ERR_INVALID_ARGUMENT
+    assert d.hfcl_multi_set_option(None, b"bvh_coop", b"1") == pkg.abi.ERR_INVALID_ARGUMENT
+    n_getenv = 0
+    for f in ("hfcl_host.hip", "hfcl_multi.hip"):
+        txt = open(os.path.join(ROOT, "hpp-fcl_amd", "csrc", f)).read()
+        txt = re.sub(r"//[^\n]*", "", txt)
+        n_getenv += len(re.findall(r"\bgetenv\s*\(", txt))
+    assert n_getenv <= 1, n_getenv
+    # every option is described for integrators
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [k for k in keys if ("`%s`" % k) not in doc]
+    assert not missing, missing
 
 
 def test_no_gpu_means_loud_failure(pkg):

@@ -222,20 +222,10 @@ def test_gpu_mesh_vs_shapes(pkg, oracle, nmax, margin):
 
 
 def _device_collide(pkg, b, req, env=None, f32=False):
-    """Records of the device-resident entry point for batch b (library created under `env`)."""
-    import os
+    """Records of the device-resident entry point for batch b (library created with the options `env`)."""
     import torch
     abi, wl = pkg.abi, pkg.workloads
-    old = {k: os.environ.get(k) for k in (env or {})}
-    os.environ.update(env or {})
-    try:
-        lib = wl.make_library(pkg, b)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    lib = wl.make_library(pkg, b, options=env)  # (hfcl_lib_set_option takes the HFCL_ spelling of a key too)
     dev = torch.device("cuda:0")
     try:
         s1 = torch.from_numpy(b.s1.astype(np.int32)).to(dev)
@@ -289,15 +279,8 @@ def test_gpu_mesh_solid_ties_forms_agree(pkg, oracle):
     assert (cref["num_contacts"] == 0).all() and (dref["distance"] > 0.01).all()
     envs = (dict(HFCL_SHAPE_BUDGET0="2", HFCL_SHAPE_DIST_BUDGET="2"), dict(HFCL_SHAPE_COOP="0", HFCL_SHAPE_BUDGET0="2", HFCL_SHAPE_BUDGET="2"),
             dict(HFCL_SHAPE_LEVELS="1", HFCL_SHAPE_DIST_BUDGET="0"))
-    import os
     for env in envs:
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
-            lib = wl.make_library(pkg, big)
-        finally:
-            for k, v in old.items():
-                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        lib = wl.make_library(pkg, big, options=env)
         try:
             cg = lib.collide(big.s1, big.s2, big.tf1, big.tf2, creq)
             dg = lib.distance(big.s1, big.s2, big.tf1, big.tf2)
@@ -541,15 +524,7 @@ def test_gpu_mesh_vs_shapes_distance(pkg, oracle):
 
 
 def _device_distance(pkg, b, req, env=None):
-    import os
-    env = env or {}
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        lib = pkg.workloads.make_library(pkg, b)
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    lib = pkg.workloads.make_library(pkg, b, options=env)
     try:
         return lib.distance(b.s1, b.s2, b.tf1, b.tf2, req)
     finally:

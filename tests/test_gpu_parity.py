@@ -16,8 +16,8 @@ def _oracle(oracle, b, req, tf1=None, tf2=None):
               n_threads=min(64, max(8, os.cpu_count() or 8)))
 
 
-def _engine(pkg, b, req):
-    lib = pkg.Library(b.lib, device=0)
+def _engine(pkg, b, req, options=None):
+    lib = pkg.Library(b.lib, device=0, options=options)
     try:
         if b.kind == "distance":
             return lib.distance(b.s1, b.s2, b.tf1, b.tf2, req), lib.last_bucket_counts()
@@ -38,7 +38,7 @@ def _check_exact(abi, got, ref, name):
 
 def test_native_library_is_loaded(pkg):
     assert pkg.engine.device_count() >= 1
-    assert pkg.engine.dll().hfcl_abi_version() == 4
+    assert pkg.engine.dll().hfcl_abi_version() == 5
 
 
 @pytest.mark.parametrize("case,n", [("cfg1_sphere_sphere", 1000), ("cfg2_box_capsule", 100000),
@@ -59,7 +59,7 @@ def test_fp64_parity(pkg, oracle, case, n):
     assert buckets["unsupported"] == 0
 
 
-def test_epa_hand_over_equals_restart(pkg, monkeypatch):
+def test_epa_hand_over_equals_restart(pkg):
     """A polytope that outgrows the 20-iteration block is continued by the full-capacity kernel from the
     saved block; when the save area is full it is redone from its seed.  Both must give the same record
     bit for bit (the first iterations are the reference's in either tier)."""
@@ -68,8 +68,7 @@ def test_epa_hand_over_equals_restart(pkg, monkeypatch):
     req = wl.make_request(b, abi)
     got, buckets = _engine(pkg, b, req)
     assert buckets["epa_overflow"] > 500, buckets  # the workload does exercise the hand-over
-    monkeypatch.setenv("HFCL_EPA_RESUME_SLOTS", "64")  # nearly every hand-over now falls back to the seed
-    redo, buckets2 = _engine(pkg, b, req)
+    redo, buckets2 = _engine(pkg, b, req, options={"epa_resume_slots": 64})  # nearly every hand-over now falls back to the seed
     assert buckets2["epa_overflow"] == buckets["epa_overflow"]
     assert got.tobytes() == redo.tobytes()
 
@@ -295,7 +294,7 @@ def test_fp32_host_buffers_equal_device_path(pkg, torch_cuda, case, n):
 
 
 @pytest.mark.parametrize("case,n", [("cfg3_convex_convex", 300000), ("cfg3_unique_hulls", 60000), ("cfg5_mixed", 120000)])
-def test_fp32_staged_epa_equals_one_kernel_form(pkg, torch_cuda, monkeypatch, case, n):
+def test_fp32_staged_epa_equals_one_kernel_form(pkg, torch_cuda, case, n):
     """The convex x convex EPA fast tier in three stages (k_epa_prepare: one lane per polytope builds the first tetrahedron;
     k_epa_loop: the expansion loop; k_epa_records: one lane per polytope writes the record; k_epa_resume_cc continues the
     polytopes that outgrow the block) against the one-kernel streaming form on the same batch: every record byte for byte
@@ -310,10 +309,8 @@ def test_fp32_staged_epa_equals_one_kernel_form(pkg, torch_cuda, monkeypatch, ca
     d_p1 = torch.from_numpy(b.pose1_f32).to(dev)
     d_p2 = torch.from_numpy(b.pose2_f32).to(dev)
     recs, queues = {}, {}
-    monkeypatch.setenv("HFCL_EPA_CC_STAGED_MIN", "0")
     for staged in ("0", "1"):
-        monkeypatch.setenv("HFCL_EPA_CC_STAGED", staged)
-        lib = pkg.Library(b.lib)
+        lib = pkg.Library(b.lib, options={"epa_cc_staged_min": 0, "epa_cc_staged": staged})
         d_out = torch.zeros(len(b) * 11, dtype=torch.int32, device=dev)
         fn = lib.distance_device_f32 if b.kind == "distance" else lib.collide_device_f32
         for _ in range(2):  # (the second call runs on a warm workspace)
@@ -331,7 +328,7 @@ def test_fp32_staged_epa_equals_one_kernel_form(pkg, torch_cuda, monkeypatch, ca
 
 @pytest.mark.parametrize("case,n,precision", [("cfg5_mixed", 120000, "f64"), ("all_primitives", 60000, "f64"), ("cfg2_box_capsule", 120000, "f64"),
                                               ("cfg5_mixed", 120000, "f32"), ("cfg2_box_capsule", 120000, "f32")])
-def test_general_staged_epa_equals_one_kernel_form(pkg, torch_cuda, monkeypatch, case, n, precision):
+def test_general_staged_epa_equals_one_kernel_form(pkg, torch_cuda, case, n, precision):
     """HFCL_EPA_GENERAL_STAGED=1 (k_epa_prepare_general / k_epa_loop_general / k_epa_records_general for the general EPA queues; off by
     default, profiles/r05_e_general_staged.md) against the default one-kernel forms on the same batch: records and cached guesses byte for
     byte."""
@@ -347,10 +344,8 @@ def test_general_staged_epa_equals_one_kernel_form(pkg, torch_cuda, monkeypatch,
     d_p2 = torch.from_numpy(b.pose2_f32 if f32 else b.tf2).to(dev)
     words = 11 if f32 else 24
     recs = {}
-    monkeypatch.setenv("HFCL_EPA_GENERAL_STAGED_MIN", "0")
     for staged in ("0", "1"):
-        monkeypatch.setenv("HFCL_EPA_GENERAL_STAGED", staged)
-        lib = pkg.Library(b.lib)
+        lib = pkg.Library(b.lib, options={"epa_general_staged_min": 0, "epa_general_staged": staged})
         d_out = torch.zeros(len(b) * words, dtype=torch.int32, device=dev)
         name = ("distance" if b.kind == "distance" else "collide") + ("_device_f32" if f32 else "_device")
         for _ in range(2):
@@ -501,10 +496,10 @@ def test_host_pipeline_equals_device_path(pkg, torch_cuda, case):
 
 
 # ------------------------------------------------------------------------------------- BVH (cfg4)
-def _run_bvh(pkg, oracle, b, req, max_contacts=0):
+def _run_bvh(pkg, oracle, b, req, max_contacts=0, options=None):
     bb = pkg.bvh_builder
     ML = bb.MeshLibrary(b.meshes)
-    lib = pkg.workloads.make_library(pkg, b)
+    lib = pkg.workloads.make_library(pkg, b, options=options)
     try:
         if max_contacts:
             got, cgot, produced = lib.collide_contacts(b.s1, b.s2, b.tf1, b.tf2, req, max_contacts)
@@ -535,7 +530,7 @@ def _check_bvh_records(abi, got, ref, name):
 
 @pytest.mark.parametrize("form", ["default", "filter"])
 @pytest.mark.parametrize("seg,n", [(12, 20000), (50, 4000)])
-def test_bvh_collide_first_contact(pkg, oracle, seg, n, form, monkeypatch):
+def test_bvh_collide_first_contact(pkg, oracle, seg, n, form):
     """Default request (num_max_contacts = 1): collision flag and the first contact's (b1, b2) in the
     reference's DFS order are exact; depth / witness data to 1e-6.  filter: through the fp32 separating-axis filter in
     front of the fp64 test (HFCL_BVH_FILTER=1: the decisions of the default form, numbers to the last bits)."""
@@ -543,10 +538,9 @@ def test_bvh_collide_first_contact(pkg, oracle, seg, n, form, monkeypatch):
     if form == "filter":
         b0 = wl.cfg4_mesh_mesh(n=n, seg=seg, ring=seg, n_variants=4)
         plain, _, _ = _run_bvh(pkg, oracle, b0, wl.make_request(b0, abi))
-        monkeypatch.setenv("HFCL_BVH_FILTER", "1")
     b = wl.cfg4_mesh_mesh(n=n, seg=seg, ring=seg, n_variants=4)
     req = wl.make_request(b, abi)
-    got, ref, kt = _run_bvh(pkg, oracle, b, req)
+    got, ref, kt = _run_bvh(pkg, oracle, b, req, options={"bvh_filter": 1} if form == "filter" else None)
     _check_bvh_records(abi, got, ref, "bvh-first-%d" % seg)
     if form == "filter":
         # the same decisions as the plain fp64 kernel; the two are different instantiations, so their fp64 arithmetic may be
@@ -583,30 +577,27 @@ def test_bvh_collide_baseline_size(pkg, oracle, n):
     assert 0.2 < (ref["num_contacts"] > 0).mean() < 0.8
 
 
-@pytest.mark.parametrize("form", ["coop", "cut", "levels", "whole"])
-def test_bvh_collide_forms_agree(pkg, oracle, form, monkeypatch):
+@pytest.mark.parametrize("form", ["coop", "cut", "rounds", "inline", "levels", "whole"])
+def test_bvh_collide_forms_agree(pkg, oracle, form):
     """The forms of a long mesh x mesh walk -- continued 64 entries wide by a wave (with a budget of 24 steps, so that
     nearly every query is), the same with the waves' long walks cut into chunks that later launches walk and k_bvh_combine folds
     back (BvhSplit::cut_ticks, here after 15 000 clock ticks: thousands of cuts, chunks cut again, chunks behind a contact), cut into
-    task levels by the lanes, and walked in one piece by its lane -- give the oracle's records; and the fp32 device path (its own
+    task levels by the lanes, and walked in one piece by its lane -- give the oracle's records; so do the forms of the queries' own
+    phase in front of the continuation: walk / leaves / resolve rounds (the default: here four rounds of 24-48 box tests and 2-4 listed
+    leaves, every round's hand-overs continued on a stream of their own beside the next) and k_bvh_collide with its leaves inline
+    (bvh_walk_rounds = 0); and the fp32 device path (its own
     instantiations of the same kernels) the same decisions away from the decision boundary."""
     import torch
     abi, wl = pkg.abi, pkg.workloads
-    if form == "coop":
-        monkeypatch.setenv("HFCL_BVH_BUDGET0_COOP", "24")
-    elif form == "cut":
-        monkeypatch.setenv("HFCL_BVH_BUDGET0_COOP", "24")
-        monkeypatch.setenv("HFCL_BVH_CUT_TICKS", "15000")
-    elif form == "levels":
-        monkeypatch.setenv("HFCL_BVH_COOP", "0")
-    else:
-        monkeypatch.setenv("HFCL_BVH_COOP", "0")
-        monkeypatch.setenv("HFCL_BVH_LEVELS", "1")
+    options = {"coop": {"bvh_budget0_coop": 24}, "cut": {"bvh_budget0_coop": 24, "bvh_cut_ticks": 15000},
+               "rounds": {"bvh_budget0_coop": 24, "bvh_walk_rounds": 4, "bvh_walk_k": [2, 3, 4, 16], "bvh_walk_budget": [24, 24, 48]},
+               "inline": {"bvh_budget0_coop": 24, "bvh_walk_rounds": 0},
+               "levels": {"bvh_coop": 0}, "whole": {"bvh_coop": 0, "bvh_levels": 1}}[form]
     b = wl.cfg4_mesh_mesh(n=30_000, seed=21)
     req = wl.make_request(b, abi)
     ML = pkg.bvh_builder.MeshLibrary(b.meshes)
     ref = oracle.bvh_collide_batch(ML, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=32)
-    lib = wl.make_library(pkg, b)
+    lib = wl.make_library(pkg, b, options=options)
     try:
         got = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
         dev = torch.device("cuda:0")
@@ -695,7 +686,7 @@ def test_bvh_distance(pkg, oracle, seg, n, hw):
     assert np.abs(np.linalg.norm(got["p2"][pos] - got["p1"][pos], axis=1) - got["distance"][pos]).max() < 1e-7
 
 
-def test_bvh_distance_continuations(pkg, oracle, monkeypatch):
+def test_bvh_distance_continuations(pkg, oracle):
     """distance() walks past their step budget are continued by waves: k_bvh_distance_pool (default: several walks per wave,
     their box and triangle tests pooled, order kept by a marker) or k_bvh_distance_coop (HFCL_BVHD_POOL=0: a wave per walk, 64
     stack entries per trip, applied in order).  With a budget of 16 steps (every query continues there), the default, and
@@ -708,12 +699,10 @@ def test_bvh_distance_continuations(pkg, oracle, monkeypatch):
     assert 0.4 < (ref["distance"] > 1e-9).mean() < 0.95
     res = {}
     for pool, budget in (("1", "16"), ("1", ""), ("0", "16"), ("0", "1024"), ("1", "0")):
-        monkeypatch.setenv("HFCL_BVHD_POOL", pool)
+        options = {"bvhd_pool": pool}
         if budget:
-            monkeypatch.setenv("HFCL_BVHD_BUDGET", budget)
-        else:
-            monkeypatch.delenv("HFCL_BVHD_BUDGET", raising=False)
-        lib = wl.make_library(pkg, b)
+            options["bvhd_budget"] = budget
+        lib = wl.make_library(pkg, b, options=options)
         try:
             res[(pool, budget)] = lib.distance(b.s1, b.s2, b.tf1, b.tf2)
         finally:
@@ -816,16 +805,14 @@ def test_bvh_models_beyond_16_bit_node_ids(pkg, oracle):
 
 
 @pytest.mark.parametrize("force_wide", [False, True])
-def test_bvh_degenerate_deep_tree(pkg, oracle, force_wide, monkeypatch):
+def test_bvh_degenerate_deep_tree(pkg, oracle, force_wide):
     """A strip of triangles whose positions grow geometrically: the mean split (BV_splitter) peels a few triangles off
     per level and the tree gets deep (133 levels here; a mean split can only stay this lopsided while the coordinates
     grow faster than geometrically, so the range of a double bounds the depth of any BVHModel to a few hundred levels).
     The reference's traversal stack is a growable vector (traversal_recurse.cpp:95).  Here a full 96-entry LDS stack
     suspends into tasks (default form), or continues in a per-lane global slab (wide form: models beyond 65535 nodes or
-    deeper than the task levels hold; forced here with HFCL_BVH_FORCE_WIDE).  collide() and distance() vs the oracle."""
+    deeper than the task levels hold; forced here with the option bvh_force_wide).  collide() and distance() vs the oracle."""
     abi, bb = pkg.abi, pkg.bvh_builder
-    if force_wide:
-        monkeypatch.setenv("HFCL_BVH_FORCE_WIDE", "1")
     nt, r = 1200, 3.2
     x = r ** (np.arange(nt // 2 + 2) - float(nt // 2 + 1))  # largest coordinate 1
     v = np.zeros((2 * (nt // 2 + 2), 3))
@@ -838,7 +825,7 @@ def test_bvh_degenerate_deep_tree(pkg, oracle, force_wide, monkeypatch):
     assert depth > 100, depth
     b = _mesh_batch(pkg, [m], 256, 4, 0.05)
     ML = bb.MeshLibrary(b.meshes)
-    lib = pkg.workloads.make_library(pkg, b)
+    lib = pkg.workloads.make_library(pkg, b, options={"bvh_force_wide": 1} if force_wide else None)
     req = pkg.workloads.make_request(b, abi)
     got = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
     ref = oracle.bvh_collide_batch(ML, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=16)
@@ -891,7 +878,7 @@ def test_flat_rows_gpu(pkg, oracle, kind):
 
 @pytest.mark.parametrize("support", ["scan", "climb"])
 @pytest.mark.parametrize("kind", ["distance", "collide"])
-def test_large_hulls_gpu(pkg, oracle, kind, support, monkeypatch):
+def test_large_hulls_gpu(pkg, oracle, kind, support):
     """Hulls of 33..256 vertices (k_gjk_large + full-capacity EPA tier) vs the oracle's neighbour hill-climbing support
     (support_functions.cpp:323-397): with the vertices scanned from memory, and with the registered vertex adjacency
     climbed from the previous answer (hfcl_lib_set_convex_neighbors; HFCL_CLIMB_MIN lowered so that these hulls use it)."""
@@ -904,8 +891,7 @@ def test_large_hulls_gpu(pkg, oracle, kind, support, monkeypatch):
     finally:
         oracle.lib().orc_clear_neighbors()
     if support == "climb":
-        monkeypatch.setenv("HFCL_CLIMB_MIN", "33")
-        lib = pkg.Library(b.lib, device=0)
+        lib = pkg.Library(b.lib, device=0, options={"climb_min": 33})
         try:
             first = int(np.flatnonzero(b.shapes["num_points"] > 32)[0])
             n0 = int(b.shapes["num_points"][first])

@@ -250,3 +250,54 @@ def test_c_abi_multi_device_resident(pkg, torch_cuda):
         assert e.value.code == abi.ERR_INVALID_ARGUMENT and "listed twice" in str(e.value)
     finally:
         two.close()
+
+
+@pytest.mark.gpu
+def test_cpp_multi_device_all_gather(pkg):
+    """tests/cpp/test_multi_device.cpp: hfcl_{distance,collide}_batch_multi_device over every visible device -- the in-place ncclAllGather
+    of csrc/hfcl_multi.hip with more than one rank -- every device's gathered buffer against the single-library records, the ranks the
+    communicator reports, the caller's device restored.  SKIPS (does not pass) where fewer than two devices are visible."""
+    import os
+    import subprocess
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp")
+    subprocess.check_call(["make", "-s", "-C", d])
+    r = subprocess.run([os.path.join(d, "test_multi_device")], capture_output=True, text=True, timeout=600)
+    if r.returncode == 77:
+        pytest.skip(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_c_abi_multi_hardening(pkg, torch_cuda):
+    """hfcl_multi_*: null handles and null pointer arrays are refused with HFCL_ERR_INVALID_ARGUMENT (not dereferenced), the caller's
+    current device survives a call, an option reaches every replica, and the gather statistics of a one-replica batch say "no collective"."""
+    import ctypes as C
+    torch = torch_cuda
+    abi, wl = pkg.abi, pkg.workloads
+    d = pkg.engine.dll()
+    req = abi.default_distance_request()
+    for fn in (d.hfcl_distance_batch_multi, d.hfcl_collide_batch_multi):
+        assert fn(None, None, None, None, None, C.c_size_t(0), C.byref(req), None, None, None) == abi.ERR_INVALID_ARGUMENT
+    assert d.hfcl_distance_batch_multi_device(None, None, None, None, None, C.c_size_t(0), C.byref(req), None, None) == abi.ERR_INVALID_ARGUMENT
+    assert d.hfcl_multi_set_shapes(None, None, C.c_size_t(0), None, C.c_size_t(0)) == abi.ERR_INVALID_ARGUMENT
+    assert d.hfcl_multi_add_bvh(None, None, C.c_size_t(0), None, C.c_size_t(0), None, C.c_size_t(0)) < 0
+    b = wl.cfg5_mixed(n=5001, seed=3)
+    one = pkg.MultiLibrary(b.lib, devices=(0,), options={"split": 1})
+    try:
+        assert d.hfcl_distance_batch_multi_device(one._h, None, None, None, None, C.c_size_t(len(b)), C.byref(req), None, None) == abi.ERR_INVALID_ARGUMENT
+        assert "null pointer array" in pkg.engine.last_error()
+        one.set_option("HFCL_CVX_W", 4)
+        with pytest.raises(pkg.EngineError):
+            one.set_option("no_such_option", 1)
+        with pytest.raises(pkg.EngineError):
+            one.set_option("cvx_w", 3)
+        dev = torch.device("cuda:0")
+        t = [torch.from_numpy(x).to(dev) for x in (b.s1.astype(np.int32), b.s2.astype(np.int32), b.tf1, b.tf2)]
+        out = torch.zeros(len(b) * 24, dtype=torch.int32, device=dev)
+        one.distance_device_gathered([t[0]], [t[1]], [t[2]], [t[3]], len(b), req, [out])
+        torch.cuda.synchronize()
+        assert torch.cuda.current_device() == 0
+        g = one.last_gather()
+        assert g["ranks"] == 1 and g["ms"] is None and g["bytes_per_rank"] == len(b) * 96
+    finally:
+        one.close()
