@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_pkg  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+XGMI_IN_GBPS = 7 * 153.0  # what a rank can receive in an 8-GPU all-gather: 7 point-to-point xGMI links x ~153 GB/s (same guide)
 # Link rates of the GPU box between PAGEABLE host arrays and the device, measured with tools/link_probe.hip
 # (profiles/r03_c): one direction at a time / both at once from two host threads (46.5 - 50 GB/s per direction)
 LINK_H2D_GBS, LINK_D2H_GBS, LINK_BOTH_GBS = 57.4, 57.0, 2 * 47.0
@@ -145,32 +146,13 @@ def load_traffic(workload, dominant, n, want="traffic"):
     if t.get("source_sha") != kernel_source_sha():
         return None, "committed PMC pass (%s) was taken on other device code (source_sha %s, now %s): re-run tools/measure_traffic.py" % (
             os.path.relpath(path, ROOT), t.get("source_sha"), kernel_source_sha())
-    m = re.match(r"(k_\w+)(?:<(\w+)>)?", dominant)
-    base, tag = m.group(1), m.group(2)
-    # template arguments that tell the instantiations of one kernel apart: k_epa<T, WE, CAP, TIER, ...>, k_gjk_cvx<W, M, BVG>
-    sel = {"fast": r"k_epa<\w+, \d+, \d+, 1[,>]", "full": r"k_epa<\w+, \d+, \d+, 2[,>]", "cc": r"k_gjk_cvx(?:64)?<\d+, 0, ",
-           "pc": r"k_gjk_cvx(?:64)?<\d+, 1, ", "cp": r"k_gjk_cvx(?:64)?<\d+, 2, "}.get(tag, "")
-    # a timer label can stand for several instantiations launched back to back (the fp64 fast EPA tier is one kernel per
-    # class of pairs): their counters add up
+    # a timer label can stand for several kernels launched back to back (the fp64 fast EPA tier is one kernel per class of pairs; the
+    # mesh timers stand for a pass: the walk, its leaves, the continuation of the suspended queries ...): their counters add up
     tot_f = tot_w = tot_v = 0.0
     sq = {}
     found = False
     for name, v in t["kernels"].items():
-        hit = any(base + suffix in name for suffix in ("<", "64<", "(")) and re.search(sel, name) is not None
-        if tag == "fast" and ("k_epa_stream<" in name or "k_epa_loop<" in name):  # the fp32 fast tier: the streaming forms of the same kernel
-            hit = True
-        if base == "k_closed" and "k_closed_staged(" in name:  # the fp64 closed-form kernel (LDS-staged I/O)
-            hit = True
-        # the mesh timers stand for a pass of several kernels: the per-lane walk, the continuation of the suspended queries
-        # (k_bvh_coop / k_bvh_shape_coop) and, for mesh x solid, the solids' OBBs and the EPA leaves; the SOLID instantiation of
-        # k_bvh_collide belongs to the mesh x solid pass
-        solid_walk = re.search(r"k_bvh_collide<\w+, false, false, true>", name) is not None
-        if base == "k_bvh_collide":
-            hit = (hit and not solid_walk) or any(x in name for x in ("k_bvh_coop<", "k_bvh_combine<", "k_bvh_level_mark"))
-        if base == "k_bvh_shape":
-            hit = hit or solid_walk or any(x in name for x in ("k_shape_obb", "k_bvh_shape_coop<", "k_bvh_shape_finish<"))
-        if base == "k_bvh_distance":  # the lane walk and its continuation
-            hit = hit or any(x in name for x in ("k_bvh_distance_pool<", "k_bvh_distance_coop<"))
+        hit = _label_matches(dominant, name)
         if not hit:
             continue
         if want == "valu":
@@ -190,6 +172,81 @@ def load_traffic(workload, dominant, n, want="traffic"):
         return 2 * tot_f + tot_w, "PMC per launch: FETCH_SIZE raw %.3g B (x2 gfx950 correction applied), WRITE_SIZE %.3g B; %s" % (
             tot_f, tot_w, os.path.relpath(path, ROOT))
     return None, "kernel not found in " + os.path.relpath(path, ROOT)
+
+
+def _label_matches(label, name):
+    """Does the rocprofv3 kernel name `name` run under the library's timer label `label`?  (the rules of load_traffic, names only)"""
+    import re
+    m = re.match(r"(k_\w+)(?:<(\w+)>)?", label)
+    if not m:
+        return False
+    base, tag = m.group(1), m.group(2)
+    sel = {"fast": r"k_epa<\w+, \d+, \d+, 1[,>]", "full": r"k_epa<\w+, \d+, \d+, 2[,>]", "cc": r"k_gjk_cvx(?:64)?<\d+, 0, ",
+           "pc": r"k_gjk_cvx(?:64)?<\d+, 1, ", "cp": r"k_gjk_cvx(?:64)?<\d+, 2, "}.get(tag, "")
+    hit = any(base + suffix in name for suffix in ("<", "64<", "(")) and re.search(sel, name) is not None
+    if tag == "fast" and ("k_epa_stream<" in name or "k_epa_loop<" in name):
+        hit = True
+    if base == "k_closed" and "k_closed_staged(" in name:
+        hit = True
+    solid_walk = re.search(r"k_bvh_collide<\w+, false, false, true>", name) is not None
+    if base == "k_bvh_collide":
+        hit = (hit and not solid_walk) or any(x in name for x in ("k_bvh_coop<", "k_bvh_walk<", "k_tri_leaves<", "k_bvh_resolve<", "k_bvh_combine<"))
+    if base == "k_bvh_shape":
+        hit = hit or solid_walk or any(x in name for x in ("k_shape_obb", "k_bvh_shape_coop<", "k_bvh_shape_finish<"))
+    if base == "k_bvh_distance":
+        hit = hit or any(x in name for x in ("k_bvh_distance_pool<", "k_bvh_distance_coop<"))
+    return hit
+
+
+def rocprof_names(workload, label):
+    """The kernels rocprofv3 lists for a timer label of the library (the label of a pass of several kernels: all of them), longest-running
+    first as far as the committed kernel trace of the workload tells (profiles/r06_z_<workload>_kernel_trace_stats.txt, else the PMC
+    pass).  Names only -- they do not depend on the device code's fingerprint; [] when no committed file knows the label."""
+    import glob
+    import re
+    names = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_z_%s_kernel_trace_stats.txt" % workload)), reverse=True):
+        for ln in open(path):
+            m = re.match(r"((?:void )?k_\w+.*?\S)\s+\d+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s*$", ln)
+            if m and _label_matches(label, m.group(1)) and m.group(1) not in names:
+                names.append(m.group(1))  # (the file is sorted by total time)
+        if names:
+            return names
+    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    if os.path.exists(path):
+        names = [k for k in json.load(open(path)).get("kernels", {}) if _label_matches(label, k)]
+    return names
+
+
+def load_step_traffic(workload, n):
+    """HBM bytes of ONE STEP -- every kernel of the pipeline, 2 x FETCH_SIZE + WRITE_SIZE as in load_traffic -- from the committed PMC pass
+    of this device code and batch size; None otherwise."""
+    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    if (t.get("pairs") or DEFAULT_PAIRS.get(workload, 1_000_000)) != n or t.get("source_sha") != kernel_source_sha():
+        return None
+    tot, seen = 0.0, False
+    for v in t["kernels"].values():
+        if "FETCH_SIZE_KB_per_dispatch" in v and "WRITE_SIZE_KB_per_dispatch" in v:
+            tot += 2 * v["FETCH_SIZE_KB_per_dispatch"] * 1024 + v["WRITE_SIZE_KB_per_dispatch"] * 1024
+            seen = True
+    return tot if seen else None
+
+
+# "useful" floating-point work of a hull x hull query, for `roofline.useful_flop_frac`: a MODEL of what the reference's algorithm needs
+# per iteration (SURVEY.md 8d quotes 5-10 kflop per query for configs[2]) times the iteration counts the records of this run carry.
+#   GJK iteration (gjk.cpp:188-370): two support scans of 32 vertices (a dot product = 5 flop + the compare) = 2 x 32 x 6, the direction
+#     into both frames and the support point back (2 x 15 + 2 x 18), the simplex projection (line 20 / triangle 90 / tetrahedron 250:
+#     150 on average over a run), the convergence check and momentum update (40)              -> ~640 flop
+#   EPA iteration (gjk.cpp:1311-1466): the same two scans and transforms (450), the silhouette over ~40 faces (a dot + compare each:
+#     6 x 40), ~4 new faces (normal = cross 9 + normalise 8 + distance 5 + the degenerate test 6 each), the closest-face scan (2 x 40)
+#     -> ~880 flop;  set-up of a penetrating pair (encloseOrigin of the GJK simplex + the first tetrahedron's four faces) ~300 flop
+# The lanes execute 4-8 times as many instructions (VERDICT r5: both lanes of a pair run the serial simplex code, eight lanes share a
+# polytope): this figure prices that redundancy, `valu_frac` prices issue efficiency.
+FLOP_GJK_ITER, FLOP_EPA_ITER, FLOP_EPA_SETUP = 640.0, 880.0, 300.0
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X, /opt/skills/guides/MI355X_MICROARCH.md (non-matrix fp32)
 
 
 class Ctx:
@@ -223,12 +280,19 @@ def compact_line(full):
     cfg = full.get("config") or {}
     line["config"] = _pick(cfg, ("workload", "baseline_config", "pairs_per_gpu_per_step", "pairs_per_step_all_gpus",
                                  "contact_fraction", "request", "gather", "backend", "mean_bv_tests", "mean_leaf_tests"))
+    if cfg.get("exchange"):
+        line["config"]["exchange"] = _pick(cfg["exchange"], ("ranks_seen", "ms", "bus_GBps", "frac_of_link_budget", "bytes_received_per_rank"))
+    if cfg.get("per_rank_ms_no_exchange"):
+        line["config"]["per_rank_ms_no_exchange"] = _pick(cfg["per_rank_ms_no_exchange"], ("max", "min"))
     gc = cfg.get("gather_check")
     if gc:
         line["config"]["gather_check"] = {k: (all(v) if isinstance(v, (list, tuple)) else v) for k, v in gc.items()}
     rf = full.get("roofline") or {}
-    line["roofline"] = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_query",
-                                  "units_per_launch", "kernel_ms", "pipeline_ms", "pipeline_achieved", "hbm_side", "l2_side"))
+    line["roofline"] = _pick(rf, ("bound", "kernel", "timer_label", "achieved", "peak", "unit", "frac", "traffic", "traffic_ratio", "bytes_per_query",
+                                  "units_per_launch", "kernel_ms", "pipeline_ms", "pipeline_achieved", "step_traffic", "step_traffic_ratio",
+                                  "useful_flop_per_query", "useful_flop_frac", "hbm_side", "l2_side"))
+    if rf.get("traffic_source"):
+        line["roofline"]["traffic_source"] = rf["traffic_source"]
     if rf.get("valu_issue"):
         line["roofline"]["valu_frac"] = _r(rf["valu_issue"]["frac"])
     cb = full.get("cpu_baseline")
@@ -236,6 +300,8 @@ def compact_line(full):
         line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample"))
         if cb.get("all_cores"):
             line["cpu_baseline"]["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+        if cb.get("native"):
+            line["cpu_baseline"]["native"] = _pick(cb["native"], ("value", "cores", "build"))
     else:
         line["cpu_baseline"] = None
     hb = full.get("host_buffers")
@@ -334,7 +400,7 @@ def make_batch(ctx, workload, n, strong):
     return batch, dtype, extra, batch
 
 
-def cpu_baseline(ctx, workload, batch, req, sample, budget_s, all_cores=True):
+def cpu_baseline(ctx, workload, batch, req, sample, budget_s, all_cores=True, native=False):
     """The fp64 CPU oracle (oracle/, a restatement of the reference's algorithm: kind "port") on a bounded sample of
     the same workload: 1 thread (the reference is single-threaded) and, for scale, all host threads."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -377,6 +443,17 @@ def cpu_baseline(ctx, workload, batch, req, sample, budget_s, all_cores=True):
         t1 = time.perf_counter()
         run_cpu(0, ns, cores_all)
         out["all_cores"] = {"value": ns / (time.perf_counter() - t1), "cores": cores_all}
+    if native:
+        # BASELINE.md section 3 builds the CPU side with -march=native; the figure above is the reference's DEFAULT arithmetic (no FMA),
+        # which is what the parity tests hold the device to.  Both are stated: a second build of the same sources, made on this host.
+        try:
+            with ob.native_build():
+                run_cpu(0, min(1000, ns), 1)
+                t1 = time.perf_counter()
+                run_cpu(0, ns, 1)
+                out["native"] = {"value": ns / (time.perf_counter() - t1), "cores": 1, "build": "g++ -O3 -march=native (FMA contraction on)"}
+        except Exception as e:  # (no compiler on the box: the figure is absent, the line is not)
+            out["native"] = {"value": None, "cores": 1, "build": "failed: " + repr(e)[:60]}
     return out
 
 
@@ -561,6 +638,24 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
                 del f_s1, f_s2, f_p1, f_p2, f_out
             gather_check["equals_single_rank_run"] = ok
 
+    # N > 1: what the run can say about itself, outside the timed region -- the ranks the backend reached, the exchange alone, and every
+    # rank's steps WITHOUT the exchange (max / min over ranks: weak scaling's per-rank figure is the N = 1 bench's ms_per_step, so the
+    # driver can hold a SCALE line against its BENCH line)
+    exchange_probe = xch.probe(sent[last]) if (gather and steps > 0) else None
+    rank_ms = None
+    if ctx.dist_on and steps > 0:
+        sync_all()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            one_step(i, False, exchange=False)
+        torch.cuda.synchronize()
+        mine = 1e3 * (time.perf_counter() - t1) / steps
+        t = torch.tensor([mine, -mine], dtype=torch.float64, device=dev if ctx.backend != "gloo" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rank_ms = {"max": float(t[0].item()), "min": -float(t[1].item()), "rank0": mine,
+                   "note": "ms per step of a rank's own kernels with no exchange in flight (weak scaling: the N = 1 bench's ms_per_step)"}
+        sync_all()
+
     # per-kernel durations (HIP events inside the library, on the launch stream), separate pass so
     # the event reads do not serialise the timed region
     lib.set_kernel_timing(True)
@@ -620,11 +715,28 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
                     "frac": valu_insts / (dom_ms * 1e-3) / VALU_ISSUE_PEAK, "sq_counters_per_launch": sq,
                     "note": "wave-level VALU instructions / (kernel time x measured chip-wide issue peak, tools/valu_peak.hip); "
                             "fp64 arithmetic issues at 0.56 of that rate"}
+        names = rocprof_names(workload, dominant)
+        step_traffic = load_step_traffic(workload, n)
+        useful = None
+        if workload in ("cfg3", "cfg3u") and n:
+            g_it = float(abi.status_gjk_iters(status).mean())
+            e_it = float((abi.status_epa_iters(status) * (abi.status_epa(status) != 15)).mean())
+            ran_epa = float((abi.status_epa(status) != 15).mean())
+            useful = g_it * FLOP_GJK_ITER + e_it * FLOP_EPA_ITER + ran_epa * FLOP_EPA_SETUP
+            extra_cfg.update({"mean_gjk_iterations": g_it, "mean_epa_iterations_over_all_pairs": e_it})
         roofline = {
-            "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": (names[0].split("(")[0].replace("void ", "").strip() if names else dominant), "timer_label": dominant,
+            "kernels_under_label": names,
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_note": traffic_note,
+            "traffic_ratio": (traffic / (units * bpq)) if (traffic and units) else None,
+            "traffic_source": ("profiles/traffic_%s.json (PMC pass of this device code, source_sha %s; replayed, not collected in this run)" % (
+                workload, kernel_source_sha())) if traffic else None,
             "bytes_per_query": bpq, "units_per_launch": units, "kernel_ms": dom_ms,
             "pipeline_ms": pipeline_ms, "pipeline_achieved": (n * bpq) / (ms_per_step * 1e-3) / 1e9,
+            "step_traffic": step_traffic, "step_traffic_ratio": (step_traffic / (n * bpq)) if (step_traffic and n) else None,
+            "useful_flop_per_query": useful,
+            "useful_flop_frac": (useful * n / (ms_per_step * 1e-3) / (FP32_VECTOR_PEAK_TFLOPS * 1e12)) if useful else None,
             "kernels_ms": avg, "valu_issue": valu,
         }
         if workload in WALK_BYTES and achieved:
@@ -637,7 +749,7 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
                                      "note": "PMC bytes (2 x FETCH_SIZE + WRITE_SIZE) / kernel time"} if traffic else None)
         cpu = None
         if not args.no_cpu_baseline and ctx.world == 1 and cpu_budget_s > 0:  # reported on rank 0 at N=1 only
-            cpu = cpu_baseline(ctx, workload, batch, req, cpu_sample, cpu_budget_s)
+            cpu = cpu_baseline(ctx, workload, batch, req, cpu_sample, cpu_budget_s, native=cpu_budget_s >= 5.0)
         if two_streams:
             # a throughput-of-two-batches figure: the per-kernel durations above come from the one-stream event pass and do
             # not describe kernels that overlap another batch's, so this row carries no kernel / roofline figure of its own
@@ -657,6 +769,9 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
                        "request": batch.kind, "all_gather_results": bool(gather), "gather": gather_mode,
                        "gather_bytes_per_rank_per_step": dict(zip(("sent", "received"), xch.bytes_per_rank_per_step())),
                        "gather_check": gather_check, "backend": ctx.backend if ctx.dist_on else None,
+                       "exchange": ({**exchange_probe, "frac_of_link_budget": (exchange_probe["bus_GBps"] / XGMI_IN_GBPS) if exchange_probe.get("bus_GBps") else None,
+                                     "link_budget_GBps": XGMI_IN_GBPS} if exchange_probe else None),
+                       "per_rank_ms_no_exchange": rank_ms,
                        "split_parts": lib.last_split_parts(),
                        "lane_group_width": os.environ.get("HFCL_CVX_W", "auto (2; fp64 convex-convex 4)")},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -151,6 +151,45 @@ class RecordExchange:
                 self.inflight[buf] = self.dist.all_gather_into_tensor(self.gathered[buf], send, async_op=True)
         return send
 
+    def probe(self, send, reps=5):
+        """What the exchange does on its own, OUTSIDE the timed region of a run: the ranks the backend actually reaches (an all-reduce of
+        ones: `ranks_seen` must equal the world size or some rank sits in another communicator) and the duration of the all-gather of
+        one step's records alone (device events on the communication stream; host clock for the staged / CPU forms), best of `reps`.
+        Returns {"ranks_seen", "ms", "bus_GBps", "bytes_sent_per_rank", "bytes_received_per_rank"}; bus_GBps = bytes one rank RECEIVES
+        per second (what its incoming xGMI links carry: DESIGN.md section 5 holds it against 7 links x 153 GB/s)."""
+        if self.dist is None:
+            return None
+        import time
+        torch = self.torch
+        host = self.staged or self.on_cpu
+        one = torch.ones(1, dtype=torch.int32, device="cpu" if host else self.dev)
+        self.dist.all_reduce(one)
+        sent, received = self.bytes_per_rank_per_step()
+        best = None
+        for _ in range(reps):
+            if host:
+                t0 = time.perf_counter()
+                src = send.cpu()
+                out = torch.empty(self.world * src.numel(), dtype=torch.int32)
+                self.dist.all_gather_into_tensor(out, src)
+                ms = 1e3 * (time.perf_counter() - t0)
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                self.dist.barrier()
+                with torch.cuda.stream(self.comm_stream):
+                    e0.record(self.comm_stream)
+                    self.dist.all_gather_into_tensor(self.gathered[0], send)
+                    e1.record(self.comm_stream)
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+            best = ms if best is None else min(best, ms)
+        t = torch.tensor([best], dtype=torch.float64, device="cpu" if host else self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)  # the slowest rank's best
+        ms = float(t.item())
+        return {"ranks_seen": int(one.item()), "ms": ms, "bus_GBps": (received / (ms * 1e-3) / 1e9) if ms > 0 else None,
+                "bytes_sent_per_rank": sent, "bytes_received_per_rank": received}
+
     def drain(self):
         for h in self.inflight.values():
             h.wait()

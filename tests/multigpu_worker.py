@@ -35,6 +35,8 @@ def main():
         ok = ok and x.verify(buf, sent, rank)
         got = x.gathered[buf][:n_total * x.words].numpy().reshape(n_total, -1)
         ok = ok and np.array_equal(got, full + step)
+    pr = x.probe(sent, reps=2)  # what bench.py --gpus N reports about the exchange: the ranks reached and the gather alone
+    ok = ok and pr["ranks_seen"] == world and pr["ms"] > 0 and pr["bytes_received_per_rank"] == x.bytes_per_rank_per_step()[1]
     if rank == 0:
         np.save(out_path, np.array([int(ok), world, x.bytes_per_rank_per_step()[1]]))
     dist.barrier()

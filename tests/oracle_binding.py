@@ -28,6 +28,33 @@ def lib():
     return _LIB
 
 
+class native_build:
+    """with native_build(): ... -- the batch functions of this module run through a second build of the same sources, `-O3 -march=native`
+    (BASELINE.md section 3), made on THIS host under /tmp.  For bench.py's cpu_baseline.native figure only: never a checker (its
+    arithmetic contracts, the reference's default build does not)."""
+
+    def __enter__(self):
+        global _LIB
+        import tempfile
+        lib()  # (the default build is loaded first: it is what comes back)
+        out = os.path.join(tempfile.gettempdir(), "liboracle_native_%d.so" % os.getpid())
+        subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR, "native", "NATIVE_OUT=" + out])
+        self._old = _LIB
+        _LIB = C.CDLL(out)
+        _LIB.orc_project_origin.restype = C.c_uint
+        self._path = out
+        return self
+
+    def __exit__(self, *exc):
+        global _LIB
+        _LIB = self._old
+        try:
+            os.remove(self._path)
+        except OSError:
+            pass
+        return False
+
+
 def _pkg():
     import importlib.util
     import sys

@@ -77,3 +77,40 @@ def test_two_stream_rows_and_errors():
     d = json.loads(b.compact_line(full))
     assert len(d["secondary"][0]["error"]) <= 80
     assert d["secondary"][1]["l2_frac"] is None and d["secondary"][1]["hbm_frac"] is None and d["secondary"][1]["batches_in_flight"] == 2
+
+
+def test_line_explains_itself():
+    """The fields the round-5 review asked the line to carry: the dominant kernel under the name rocprofv3 lists it by (and the library's
+    timer label beside it), the step's HBM bytes against the algorithmic bytes, useful flop against the fp32 vector peak, where the counter
+    figures come from, the CPU figure of a -march=native build beside the reference's default arithmetic; N > 1: what the exchange did."""
+    b = _bench()
+    full = _full_record()
+    full["roofline"].update({"kernel": "k_epa_loop<float, 8, 17>", "timer_label": "k_epa<fast>", "traffic_ratio": 5.2, "step_traffic": 8.6e8,
+                             "step_traffic_ratio": 8.0, "useful_flop_per_query": 6400.0, "useful_flop_frac": 0.0241,
+                             "traffic_source": "profiles/traffic_cfg3.json (PMC pass of this device code, source_sha 0123456789abcdef; replayed, not collected in this run)"})
+    full["cpu_baseline"]["native"] = {"value": 612345.0, "cores": 1, "build": "g++ -O3 -march=native (FMA contraction on)"}
+    full["config"]["exchange"] = {"ranks_seen": 8, "ms": 0.41, "bus_GBps": 730.0, "frac_of_link_budget": 0.68, "bytes_received_per_rank": 7 * 44_000_000,
+                                  "bytes_sent_per_rank": 44_000_000, "link_budget_GBps": 1071.0}
+    full["config"]["per_rank_ms_no_exchange"] = {"max": 1.71, "min": 1.69, "rank0": 1.70, "note": "x"}
+    line = b.compact_line(full)
+    assert len(line) <= b.COMPACT_LIMIT
+    d = json.loads(line)
+    rf = d["roofline"]
+    assert rf["kernel"].startswith("k_epa_loop<") and rf["timer_label"] == "k_epa<fast>"
+    for k in ("traffic_ratio", "step_traffic", "step_traffic_ratio", "useful_flop_per_query", "useful_flop_frac", "traffic_source"):
+        assert rf[k] is not None, k
+    assert "replayed" in rf["traffic_source"]
+    assert d["cpu_baseline"]["native"]["value"] == 612350.0 or abs(d["cpu_baseline"]["native"]["value"] - 612345.0) < 10
+    assert d["config"]["exchange"]["ranks_seen"] == 8 and d["config"]["exchange"]["frac_of_link_budget"] == 0.68
+    assert d["config"]["per_rank_ms_no_exchange"] == {"max": 1.71, "min": 1.69}
+
+
+def test_timer_labels_resolve_to_profiler_names():
+    """bench.rocprof_names: the library's timer labels against the kernel names of the committed rocprofv3 traces."""
+    b = _bench()
+    assert any("k_epa_loop<float" in n for n in b.rocprof_names("cfg3", "k_epa<fast>"))
+    assert any("k_gjk_cvx<2, 0" in n for n in b.rocprof_names("cfg3", "k_gjk_cvx<cc>"))
+    names = b.rocprof_names("cfg4", "k_bvh_collide")
+    assert names and all(("k_bvh_" in n or "k_tri_leaves" in n) and "true>" not in n for n in names)
+    assert b._label_matches("k_bvh_collide", "void k_bvh_walk<double>(Work, ...)") and b._label_matches("k_bvh_collide", "void k_tri_leaves<double>(Work")
+    assert not b._label_matches("k_bvh_collide", "void k_bvh_collide<double, false, false, true>(Work")
