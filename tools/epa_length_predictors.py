@@ -49,3 +49,29 @@ for name, c in cols.items():
         order = np.argsort(-sign * c)
         res.append(" / ".join("%.2f" % (long_[order[:int(q * len(c))]].sum() / long_.sum()) for q in (0.1, 0.25, 0.5)))
     print("%-52s %6.3f   %s | %s" % (name, np.corrcoef(c, ei)[0, 1], res[0], res[1]))
+
+# What is left for a LAST continuation launch if the polytopes the predictor puts in front run (and are continued) first: the iteration counts
+# of the long polytopes the predictor misses.  (round 6: the tail of k_epa_resume_cc is as long as its longest chain beyond the 17-iteration block)
+c = np.nan_to_num(F[:, 1], nan=0, posinf=1e9, neginf=-1e9)  # largest face distance of the first tetrahedron
+order = np.argsort(-c)
+print("\nlongest chain beyond the block (iterations - 17) among the polytopes BEHIND the top q by 'largest face distance':")
+for qf in (0.0, 0.1, 0.25, 0.5):
+    rest = order[int(qf * len(c)):]
+    e = ei[rest]
+    over = np.sort(e[e >= 17] - 17)[::-1]
+    print("  q = %.2f: %6d handed over, longest %2d, 99th percentile of those %2d, 90th %2d" % (
+        qf, len(over), over[0] if len(over) else 0, over[int(0.01 * len(over))] if len(over) else 0, over[int(0.1 * len(over))] if len(over) else 0))
+
+# ... and with the rule k_epa_prepare can apply without a threshold: a polytope goes in front if its predictor ranks among the largest 16 / 24 / 32 of the
+# 64 polytopes of its wave (consecutive items of the queue)
+print("\nwave-local rule (rank among the 64 consecutive polytopes of a wave):")
+m = (len(c) // 64) * 64
+cw, ew = c[:m].reshape(-1, 64), ei[:m].reshape(-1, 64)
+rank = (cw[:, :, None] < cw[:, None, :]).sum(axis=2)  # how many of the wave's polytopes have a larger predictor
+for top in (8, 16, 24, 32):
+    front = rank < top
+    e = ew[~front]
+    over = np.sort(e[e >= 17] - 17)[::-1]
+    caught = (ew[front] >= 17).sum() / max((ew >= 17).sum(), 1)
+    print("  front = top %2d of 64 (%.0f %% of the polytopes, %.0f %% of their iterations): %.2f of the long ones in front; behind: %5d handed over, longest %2d, 99th percentile %2d" % (
+        top, 100 * front.mean(), 100 * ew[front].sum() / ew.sum(), caught, len(over), over[0] if len(over) else 0, over[int(0.01 * len(over))] if len(over) else 0))
