@@ -118,8 +118,8 @@ struct hfcl_lib {
   bool shape_finish_tiers = true;  // HFCL_SHAPE_FINISH_TIERS=0: k_bvh_shape_finish in one launch at full capacity
   bool shape_finish_aside = true;  // HFCL_SHAPE_FINISH_ASIDE=0: all of k_bvh_shape_finish behind the last launch of k_bvh_shape_coop
   void* d_shape_defer = nullptr;  // ShapeDeferItem<double>[shape_defer_capacity]: EPA queue of the one-query-per-lane mesh x solid form
-  void* d_shape_oq = nullptr;     // ObbQuery<double>[shape_defer_capacity]: the solids' OBBs against the mesh poses, by pair
-  size_t shape_defer_capacity = 0;
+  void* d_shape_oq = nullptr;     // ObbQuery<double>[shape_oq_capacity]: the solids' OBBs against the mesh poses, by pair
+  size_t shape_defer_capacity = 0, shape_oq_capacity = 0;
   bool bvh_shape_lane = true;     // HFCL_BVH_SHAPE_LANE=0: the group kernels for every request (A/B switch)
   // step budgets of the one-query-per-lane mesh x solid walk (a unit suspends into tasks when it has taken that many BV-test
   // equivalents; a GJK leaf counts shape_leaf_cost): the queries themselves / their tasks.  The steps per query have a heavy
@@ -1416,12 +1416,18 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       }
       if (need > lib->shape_defer_capacity) {
         hipFree(lib->d_shape_defer);
-        hipFree(lib->d_shape_oq);
-        lib->d_shape_defer = lib->d_shape_oq = nullptr;
+        lib->d_shape_defer = nullptr;
         lib->shape_defer_capacity = 0;
         HIP_TRY(hipMalloc(&lib->d_shape_defer, need * (sizeof(ShapeDeferItem<double>) + 2 * sizeof(uint32_t))));  // (+ the two lists of k_bvh_shape_finish's second tier)
-        HIP_TRY(hipMalloc(&lib->d_shape_oq, need * std::max(sizeof(ObbQuery<double>), sizeof(RssQuery<double>))));
         lib->shape_defer_capacity = need;
+      }
+      // (the solids' boxes are indexed by pair: one per pair of the workspace, not one per EPA item -- 1M pairs: 0.14 GB instead of 0.7)
+      if (lib->ws_capacity > lib->shape_oq_capacity) {
+        hipFree(lib->d_shape_oq);
+        lib->d_shape_oq = nullptr;
+        lib->shape_oq_capacity = 0;
+        HIP_TRY(hipMalloc(&lib->d_shape_oq, lib->ws_capacity * std::max(sizeof(ObbQuery<double>), sizeof(RssQuery<double>))));
+        lib->shape_oq_capacity = lib->ws_capacity;
       }
       wk.shape_defer = lib->d_shape_defer;
       wk.shape_defer_cap = uint32_t(std::min<size_t>(lib->shape_defer_capacity, 0xFFFFFFFFu));
