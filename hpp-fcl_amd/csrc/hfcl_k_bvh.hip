@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(
   const uint32_t level = split.level;
   const uint32_t unit0 = level ? split.ctr[BVH_CTR_LEVEL0 + level - 1] : 0u;  // first task of this level
   const uint32_t cnt = level ? min(split.ctr[BVH_CTR_LEVEL0 + level], split.cap) - min(unit0, split.cap) : wk.counts[SOLID ? B_BVHSHAPE : B_BVH];
+  if (cnt == 0u) return;  // (no unit of this kind in the batch / on this level: no wave draws a ticket)
   uint32_t* const ticket = &wk.counts[SOLID ? CTR_SHAPE_TICKET : B_COUNT + 2];
   auto ent_first = [](E e) -> uint32_t { return SOLID ? uint32_t(e) : EN::first(e); };  // SOLID: the entry is the mesh node
   const uint32_t budget = split.budget;  // steps a unit may take before it suspends (0: never)
@@ -1476,6 +1477,7 @@ k_bvh_shape_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q,
   const uint32_t level = split.level;
   const uint32_t unit0 = level ? min(split.ctr[BVH_CTR_LEVEL0 + level - 1], split.cap) : 0u;
   const uint32_t n_units = level ? min(split.ctr[BVH_CTR_LEVEL0 + level], split.cap) - unit0 : min(split.ctr[BVH_CTR_SUSPENDED], split.n_queries);
+  if (n_units == 0u) return;  // (nothing suspended / no chunk cut: no wave draws a ticket)
   const unsigned long long cut_ticks = split.can_suspend ? split.cut_ticks : 0u;
   uint32_t* const ticket = &wk.counts[CTR_SHAPE_TICKET];  // (k_bvh_collide<SOLID> is through with it; k_bvh_level_mark has reset it)
   T* const cut_vals = reinterpret_cast<T*>(split.cut_vals);
@@ -1816,6 +1818,7 @@ k_bvh_coop(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, BvhPa
       n_units = tot - unit0;
     }
   }
+  if (n_units == 0u) return;  // (nothing suspended: no wave draws a ticket)
   const unsigned long long cut_ticks = split.can_suspend ? split.cut_ticks : 0u;
   const T big = Lim<T>::max();
   bool have = false, overflow = false, exhausted = false;
@@ -2886,6 +2889,7 @@ k_bvh_walk(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, T bre
   WalkRec<T>* const recs = reinterpret_cast<WalkRec<T>*>(wa.recs);
   uint32_t* const c = wa.ctr + 8 * wa.round;
   const uint32_t cnt = wa.round ? wa.ctr[8 * (wa.round - 1) + 2] : wk.counts[B_BVH];
+  if (cnt == 0u) return;  // (a batch without mesh x mesh pairs: not one ticket drawn -- 1 500 same-address atomics are 30 us)
   const int tid = threadIdx.x, lane = tid & 63;
   const T big = Lim<T>::max(), nanv = Lim<T>::nan();
   bool live = false, pending = false, exhausted = false;  // exhausted is wave-uniform
