@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_pkg  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-XGMI_IN_GBPS = 7 * 153.0  # what a rank can receive in an 8-GPU all-gather: 7 point-to-point xGMI links x ~153 GB/s (same guide)
+XGMI_IN_GBPS = 7 * 76.8  # what a rank can receive in an 8-GPU all-gather: 7 point-to-point xGMI links x 153.6 GB/s both directions together = 76.8 GB/s inbound each
 # Link rates of the GPU box between PAGEABLE host arrays and the device, measured with tools/link_probe.hip
 # (profiles/r03_c): one direction at a time / both at once from two host threads (46.5 - 50 GB/s per direction)
 LINK_H2D_GBS, LINK_D2H_GBS, LINK_BOTH_GBS = 57.4, 57.0, 2 * 47.0
