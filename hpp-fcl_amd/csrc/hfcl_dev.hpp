@@ -682,6 +682,13 @@ struct BvhSum {  // what a unit (query or task) knows when it ends or suspends
   // ends there: children after it, and everything below them, are moot), and where the unit itself hangs
   uint32_t contact_order, parent, order, pad_;
 };
+// Forms that lost their A/B and stay only as identity references for the tests -- the fp32 filter in front of the fp64 box test
+// (k_bvh_collide<.., FILT>, profiles/r03_b), the general EPA queues in three stages (k_epa_*_general, profiles/r05_e) -- are compiled
+// only with -DHFCL_KEEP_AB_FORMS=1 (tools/build_variant.sh ab host,k_bvh,k_epa -DHFCL_KEEP_AB_FORMS=1 -> build/ab/lib_ab.so, selected with
+// HFCL_LIB_PATH): the product library does not carry them, their options are refused there (hfcl_has_ab_forms() says which build this is).
+#ifndef HFCL_KEEP_AB_FORMS
+#define HFCL_KEEP_AB_FORMS 0
+#endif
 // counters of a split traversal (device words)
 enum { BVH_CTR_TASKS = 0, BVH_CTR_SUSPENDED = 1, BVH_CTR_LEVEL0 = 2 /* [2 + k] = number of tasks made before level k ended */, BVH_CTR_CUT = 15 /* words of BvhSplit::cut_words in use */, BVH_CTR_WORDS = 16 };
 // ---------------------------------------------------------------------------------------

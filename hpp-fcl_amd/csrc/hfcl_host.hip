@@ -299,6 +299,7 @@ static int ensure_device(int device) {
 extern "C" {
 
 int hfcl_abi_version(void) { return HFCL_ABI_VERSION; }
+int hfcl_has_ab_forms(void) { return HFCL_KEEP_AB_FORMS ? 1 : 0; }
 int hfcl_pair_supported(int32_t t1, int32_t t2, int for_distance) {
   if (t1 < 0 || t1 > 255 || t2 < 0 || t2 > 255) return 0;
   return bucket_of(t1, t2, for_distance != 0) != B_UNSUPPORTED;
@@ -499,14 +500,20 @@ static int apply_option(hfcl_lib* lib, const std::string& key, const char* v) {
   else if (key == "split") lib->split = i >= 2 ? 2 : (i == 1 ? 1 : 0);
   else if (key == "epa_cc_staged") lib->epa_cc_staged = on;
   else if (key == "epa_records_aside") lib->records_aside = on;
-  else if (key == "epa_general_staged") lib->epa_general_staged = on;
+  else if (key == "epa_general_staged") {
+    if (on && !HFCL_KEEP_AB_FORMS) return HFCL_ERR_INVALID_ARGUMENT;  // (not in the product build: hfcl_dev.hpp)
+    lib->epa_general_staged = on;
+  }
   else if (key == "shape_finish_tiers") lib->shape_finish_tiers = on;
   else if (key == "shape_finish_aside") lib->shape_finish_aside = on;
   else if (key == "epa_general_staged_min") lib->epa_general_staged_min = size_t(std::max(0ll, i));
   else if (key == "epa64_two_streams") lib->epa64_two_streams = on;
   else if (key == "epa_cc_staged_min") lib->epa_cc_staged_min = size_t(std::max(0ll, i));
   else if (key == "pipe_chunk") lib->pipe_chunk = strtoull(v, nullptr, 10);
-  else if (key == "bvh_filter") lib->bvh_filter = on;
+  else if (key == "bvh_filter") {
+    if (on && !HFCL_KEEP_AB_FORMS) return HFCL_ERR_INVALID_ARGUMENT;
+    lib->bvh_filter = on;
+  }
   else if (key == "bvh_shape_lane") lib->bvh_shape_lane = on;
   else if (key == "shape_coop") lib->shape_coop = on;
   else if (key == "bvh_cut_ticks") lib->bvh_cut_ticks = uint32_t(strtoul(v, nullptr, 10));

@@ -3196,6 +3196,7 @@ static void launch_collide_kernel(bool wide, int grid, hipStream_t st, const Wor
   }
 #endif
 #if HFCL_BVH_MESH_PART
+#if HFCL_KEEP_AB_FORMS
   if constexpr (sizeof(T) == 8) {
     if (bv.fnodes) {
       if (wide)
@@ -3205,6 +3206,7 @@ static void launch_collide_kernel(bool wide, int grid, hipStream_t st, const Wor
       return;
     }
   }
+#endif
   if (wide)
     hipLaunchKernelGGL((k_bvh_collide<T, true, false>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, bp, break_distance2, split, spill);
   else

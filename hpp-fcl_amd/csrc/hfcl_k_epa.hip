@@ -856,6 +856,12 @@ void launch_epa_records(int grid, hipStream_t st, const Work& wk, const LibView<
 
 // the general three-stage fast tier (fp64: the polytope class from the bottom queue on st, the curved class from the top queue on st2 when
 // given; fp32: the bottom queue -- the top one is the convex x convex tier's)
+#if !HFCL_KEEP_AB_FORMS
+// (the product build does not carry the general staged kernels: the host refuses the option that would launch them)
+template <typename T> void launch_epa_prepare_general(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&, bool) {}
+template <typename T> void launch_epa_records_general(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&, bool) {}
+template <typename T> void launch_epa_loop_general(int, hipStream_t, hipStream_t, const Work&, const LibView<T>&, const QParams<T>&, int, bool) {}
+#else
 template <typename T>
 void launch_epa_prepare_general(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool skip_top) {
   hipLaunchKernelGGL((k_epa_prepare_general<T>), dim3(grid), dim3(256), 0, st, wk, lv, io, q, skip_top ? 1 : 0);
@@ -880,6 +886,7 @@ void launch_epa_loop_general(int grid, hipStream_t st, hipStream_t st2, const Wo
     hipLaunchKernelGGL((k_epa_loop_general<T, EPA_WE, epa_small_cap<T>, false>), dim3(std::min(grid, n_cus * per_cu_p * HFCL_EPA_LOOPG_ROUNDS)), dim3(64), 0, (curved_class && st2) ? st2 : st, wk, lv, q);
   }
 }
+#endif  // HFCL_KEEP_AB_FORMS
 #define HFCL_INST_G(T)                                                                                                                                     \
   template void launch_epa_prepare_general<T>(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&, bool);                   \
   template void launch_epa_records_general<T>(int, hipStream_t, const Work&, const LibView<T>&, const IO<T>&, const QParams<T>&, bool);                   \

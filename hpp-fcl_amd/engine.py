@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
  "hfcl_shard_range", "hfcl_multi_create", "hfcl_multi_destroy", "hfcl_multi_size", "hfcl_multi_replica",
     "hfcl_multi_set_shapes", "hfcl_multi_set_convex_neighbors", "hfcl_multi_add_bvh", "hfcl_collide_batch_multi", "hfcl_distance_batch_multi",
     "hfcl_collide_batch_multi_device", "hfcl_distance_batch_multi_device", "hfcl_collide_batch_multi_f32", "hfcl_distance_batch_multi_f32",
-    "hfcl_lib_set_option", "hfcl_lib_option_key", "hfcl_multi_set_option", "hfcl_multi_last_gather",
+    "hfcl_lib_set_option", "hfcl_lib_option_key", "hfcl_has_ab_forms", "hfcl_multi_set_option", "hfcl_multi_last_gather",
 ]
 
 
@@ -84,6 +84,11 @@ def last_error():
 
 def device_count():
     return int(dll().hfcl_device_count())
+
+
+def has_ab_forms():
+    """Does the loaded build carry the forms kept only as identity references (hfcl_has_ab_forms)?"""
+    return bool(dll().hfcl_has_ab_forms())
 
 
 def option_keys():

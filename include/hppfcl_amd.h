@@ -437,6 +437,9 @@ int  hfcl_lib_last_split_parts(const hfcl_lib* lib);  /* 1 or 2: how the last ba
  * The environment is a FALLBACK, read once by hfcl_lib_create: HFCL_<KEY IN UPPER CASE>=value sets the same option for a process that
  * cannot be changed to call this function (A/B runs of a built binary); a later hfcl_lib_set_option wins. */
 int hfcl_lib_set_option(hfcl_lib* lib, const char* key, const char* value);
+/* 1 when this build carries the forms that lost their A/B and are kept as identity references for the tests only (options `bvh_filter`,
+ * `epa_general_staged`: compiled with -DHFCL_KEEP_AB_FORMS=1, tools/build_variant.sh); the product build returns 0 and refuses those options. */
+int hfcl_has_ab_forms(void);
 const char* hfcl_lib_option_key(int index);
 /* Per-kernel HIP events are recorded by default; a caller that does not read them can switch
  * them off (on = 0) and save two stream markers per kernel launch. */

@@ -56,6 +56,8 @@ def test_options_are_an_api_not_an_environment(pkg):
         txt = re.sub(r"//[^\n]*", "", txt)
         n_getenv += len(re.findall(r"\bgetenv\s*\(", txt))
     assert n_getenv <= 1, n_getenv
+    # the forms kept only as identity references are refused by the product build (and say so through the API, not by crashing)
+    assert d.hfcl_has_ab_forms() in (0, 1)
     # every option is described for integrators
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     missing = [k for k in keys if ("`%s`" % k) not in doc]

@@ -332,6 +332,9 @@ def test_general_staged_epa_equals_one_kernel_form(pkg, torch_cuda, case, n, pre
     """HFCL_EPA_GENERAL_STAGED=1 (k_epa_prepare_general / k_epa_loop_general / k_epa_records_general for the general EPA queues; off by
     default, profiles/r05_e_general_staged.md) against the default one-kernel forms on the same batch: records and cached guesses byte for
     byte."""
+    if not pkg.engine.has_ab_forms():
+        pytest.skip("the general staged EPA lost its A/B (profiles/r05_e) and is not in the product build: tools/build_variant.sh ab host,k_bvh,k_epa "
+                    "-DHFCL_KEEP_AB_FORMS=1, then HFCL_LIB_PATH=build/ab/lib_ab.so")
     torch = torch_cuda
     abi, wl = pkg.abi, pkg.workloads
     b = getattr(wl, case)(n=n, seed=5)
@@ -535,6 +538,9 @@ def test_bvh_collide_first_contact(pkg, oracle, seg, n, form):
     reference's DFS order are exact; depth / witness data to 1e-6.  filter: through the fp32 separating-axis filter in
     front of the fp64 test (HFCL_BVH_FILTER=1: the decisions of the default form, numbers to the last bits)."""
     abi, wl = pkg.abi, pkg.workloads
+    if form == "filter" and not pkg.engine.has_ab_forms():
+        pytest.skip("the fp32 filter form lost its A/B (profiles/r03_b) and is not in the product build: tools/build_variant.sh ab host,k_bvh,k_epa "
+                    "-DHFCL_KEEP_AB_FORMS=1, then HFCL_LIB_PATH=build/ab/lib_ab.so")
     if form == "filter":
         b0 = wl.cfg4_mesh_mesh(n=n, seg=seg, ring=seg, n_variants=4)
         plain, _, _ = _run_bvh(pkg, oracle, b0, wl.make_request(b0, abi))
