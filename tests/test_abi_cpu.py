@@ -177,3 +177,13 @@ def test_request_defaults_equal_the_reference_headers(pkg):
     assert [a.DefaultGJK, a.PolyakAcceleration, a.NesterovAcceleration] == [en["GJKVariant"].index(n) for n in
                                                                            ("DefaultGJK", "PolyakAcceleration", "NesterovAcceleration")]
     assert [a.Default, a.DualityGap, a.Hybrid] == [en["GJKConvergenceCriterion"].index(n) for n in ("Default", "DualityGap", "Hybrid")]
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build() is what the driver runs on CPU every round: it must pass on the tree as it is (it checks the ABI version and the
+    exported symbols itself; the build is incremental, so this is seconds)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("graft_entry_under_test", os.path.join(ROOT, "__graft_entry__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build()
