@@ -100,6 +100,11 @@ def test_two_ranks_on_one_gpu_weak_cfg3(torch_cuda):
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and cfg["pairs_per_step_all_gpus"] == 2 * 65537
     assert cfg["gather_check"] == {"block_checksums": True, "equals_single_rank_run": True}
     assert cfg["gather_bytes_per_rank_per_step"]["received"] == 65537 * 44
+    # what the first run on several GPUs needs to be believed: the ranks the backend reached, the exchange timed alone, every rank's step
+    # without exchange (weak scaling: the N = 1 step)
+    ex, pr = cfg["exchange"], cfg["per_rank_ms_no_exchange"]
+    assert ex["ranks_seen"] == 2 and ex["ms"] > 0 and ex["bus_GBps"] > 0 and ex["bytes_received_per_rank"] == 65537 * 44
+    assert 0 < pr["min"] <= pr["max"] and pr["max"] < 50 * line["ms_per_step"]
 
 
 @pytest.mark.gpu
@@ -116,6 +121,7 @@ def test_rccl_exchange_branch_with_one_rank(torch_cuda, gather, monkeypatch):
     assert cfg["backend"] == "nccl" and cfg["all_gather_results"] is True and cfg["gather"] == gather
     assert cfg["gather_check"]["block_checksums"] is True
     assert cfg["gather_bytes_per_rank_per_step"]["sent"] == 65537 * (8 if gather == "compact" else 44)
+    assert cfg["exchange"]["ranks_seen"] == 1 and cfg["exchange"]["ms"] > 0  # (the all-gather alone, device events on the communication stream)
     assert line["value"] > 0
 
 
