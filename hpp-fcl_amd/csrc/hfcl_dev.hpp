@@ -757,6 +757,10 @@ struct BvhSplit {
   // later rounds, on a stream of its own, with walk.ctr[8 r + 4] as its ticket); those added since the snapshot of round r (0x100 + r:
   // what the last round added, on the caller's stream)
   uint32_t coop_range;
+  // ... and in which order its waves draw them: order[t] = the suspended slot of ticket t (k_walk_order: the queries with the most
+  // stack entries left first -- a wave draws its next walk when the last is over, so a long walk drawn last is the launch's tail);
+  // nullptr: in the order they were suspended
+  uint32_t* order;
 };
 enum { WALK_CTR_SNAP = 3, WALK_CTR_TICKET_EARLY = 4 };
 constexpr int COOP_CHUNK = 16;

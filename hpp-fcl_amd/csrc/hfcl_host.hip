@@ -241,14 +241,23 @@ struct hfcl_lib {
   uint32_t* d_walk_items = nullptr;
   void* d_walk_res = nullptr;
   uint32_t* d_walk_lists = nullptr;
+  uint32_t* d_walk_order = nullptr;  // BvhSplit::order (one entry per suspended slot)
+  bool walk_order = true;            // option bvh_walk_order: the continuation launches draw the queries with the most stack entries first
   uint32_t* d_walk_ctr = nullptr;
   size_t walk_n = 0;
   size_t epa_resume_slots = 0, bvh_task_slots = 0;  // options epa_resume_slots / bvh_task_slots (0: sized by the batch)
   bool bvh_force_wide = false, pipe_trace = false;   // options bvh_force_wide / pipe_trace
   bool walk_early_coop = true;                               // HFCL_BVH_WALK_EARLY_COOP: the queries round 0 hands over are continued beside the later rounds
-  uint32_t walk_rounds = 2;                                  // HFCL_BVH_WALK_ROUNDS (0: k_bvh_collide walks the queries, leaves inline)
-  uint32_t walk_k[WALK_ROUNDS] = {6, 16, 16, 16};           // HFCL_BVH_WALK_K: leaves a walk lists per round
-  uint32_t walk_budget[WALK_ROUNDS] = {224, 256, 512, 512};  // HFCL_BVH_WALK_BUDGET: box tests per round before the walk goes to k_bvh_coop
+  // Rounds of walk / leaves / resolve (option bvh_walk_rounds; 0: k_bvh_collide walks the queries, leaves inline).  Not set: chosen per
+  // batch -- ONE round of up to 16 listed leaves and 256 box tests (320 from 120k queries), then the continuation, up to 220k queries
+  // (100k: 1.86 against 1.94 ms with two rounds, 20k: 1.20 against 1.78, 50k: 1.46 against 1.74: a round is as long as its longest lane,
+  // and with the node records kept the lanes carry the walks far enough in one); TWO rounds (6 then 16 leaves; 320 / 640 then 256 box tests)
+  // with the first round's hand-overs continued beside the second above that (250k: 3.32 against 3.36-3.58 ms, 400k: 4.78 against 4.92,
+  // 1M: 9.2 against 10.0 with one round).  profiles/r06_a section 6
+  bool walk_auto = true;
+  uint32_t walk_rounds = 2;
+  uint32_t walk_k[WALK_ROUNDS] = {6, 16, 16, 16};           // option bvh_walk_k: leaves a walk lists per round (setting it switches the automatic choice off)
+  uint32_t walk_budget[WALK_ROUNDS] = {224, 256, 512, 512};  // option bvh_walk_budget: box tests per round from round 1 on before the walk goes to k_bvh_coop
   size_t bvh_split_n = 0, bvh_split_cap = 0;
   uint32_t bvh_budget0 = HFCL_BVH_BUDGET0;  // HFCL_BVH_BUDGET0: step budget of the queries (level 0); bvh_budget: of the tasks
   // No budget given by the environment: chosen per batch.  A batch that does not fill the chip's lanes more than ~1.5
@@ -475,7 +484,7 @@ static const char* const* option_keys() {
       "closed_staged", "split", "epa_cc_staged", "epa_records_aside", "epa_general_staged", "shape_finish_tiers", "shape_finish_aside",
       "epa_general_staged_min", "epa64_two_streams", "epa_cc_staged_min", "pipe_chunk", "bvh_filter", "bvh_shape_lane", "shape_coop",
       "bvh_cut_ticks", "shape_cut_ticks", "bvh_coop", "bvhd_budget", "bvhd_pool", "shape_dist_pool", "pool_rerun", "bvh_walk_early_coop",
-      "bvh_walk_rounds", "bvh_walk_k", "bvh_walk_budget", "shape_dist_leaf_min", "shape_dist_starve", "bvhd_leaf_min", "bvhd_starve",
+      "bvh_walk_rounds", "bvh_walk_order", "bvh_walk_k", "bvh_walk_budget", "shape_dist_leaf_min", "shape_dist_starve", "bvhd_leaf_min", "bvhd_starve",
       "bvhd_part_min", "shape_dist_budget", "bvh_budget0_coop", "shape_budget0", "shape_budget", "shape_leaf_cost", "shape_levels",
       "climb_min", "bvh_budget", "bvh_budget0", "bvh_levels", "cvx_w", "epa_resume_slots", "bvh_task_slots", "bvh_force_wide",
       "pipe_trace", nullptr};
@@ -524,8 +533,9 @@ static int apply_option(hfcl_lib* lib, const std::string& key, const char* v) {
   else if (key == "shape_dist_pool") lib->shape_dist_pool = u32(0);
   else if (key == "pool_rerun") lib->pool_rerun = u32(0);
   else if (key == "bvh_walk_early_coop") lib->walk_early_coop = on;
-  else if (key == "bvh_walk_rounds") lib->walk_rounds = uint32_t(std::min<long long>(std::max(0ll, i), WALK_ROUNDS));
-  else if (key == "bvh_walk_k") parse_list(v, lib->walk_k, 0, WALK_ROUNDS, 1u, uint32_t(WALK_K));  // "6,16": per round
+  else if (key == "bvh_walk_order") lib->walk_order = on;
+  else if (key == "bvh_walk_rounds") { lib->walk_rounds = uint32_t(std::min<long long>(std::max(0ll, i), WALK_ROUNDS)); lib->walk_auto = false; }
+  else if (key == "bvh_walk_k") { parse_list(v, lib->walk_k, 0, WALK_ROUNDS, 1u, uint32_t(WALK_K)); lib->walk_auto = false; }  // "6,16": per round
   else if (key == "bvh_walk_budget") parse_list(v, lib->walk_budget, 1, WALK_ROUNDS, 0u, 0xFFFFFFFFu);  // rounds 1 ...: box tests (round 0 takes bvh_budget0_coop's)
   else if (key == "shape_dist_leaf_min") lib->shape_dist_leaf_min = u32(1);
   else if (key == "shape_dist_starve") lib->shape_dist_starve = u32(1);  // (>= 1: a window of triangles alone must always run)
@@ -675,7 +685,7 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_bvh_sums);
   hipFree(lib->d_bvh_susp);
   hipFree(lib->d_bvh_ctr);
-  hipFree(lib->d_walk_recs); hipFree(lib->d_walk_items); hipFree(lib->d_walk_res); hipFree(lib->d_walk_lists); hipFree(lib->d_walk_ctr);
+  hipFree(lib->d_walk_recs); hipFree(lib->d_walk_items); hipFree(lib->d_walk_res); hipFree(lib->d_walk_lists); hipFree(lib->d_walk_ctr); hipFree(lib->d_walk_order);
   for (auto& t : lib->timers) {
     hipEventDestroy(t.e0);
     hipEventDestroy(t.e1);
@@ -863,7 +873,8 @@ static int ensure_bvh_split(hfcl_lib* lib, size_t n) {
 
 static int ensure_walk(hfcl_lib* lib, size_t n) {
   if (n <= lib->walk_n) return HFCL_OK;
-  hipFree(lib->d_walk_recs); hipFree(lib->d_walk_items); hipFree(lib->d_walk_res); hipFree(lib->d_walk_lists);
+  hipFree(lib->d_walk_recs); hipFree(lib->d_walk_items); hipFree(lib->d_walk_res); hipFree(lib->d_walk_lists); hipFree(lib->d_walk_order);
+  lib->d_walk_order = nullptr;
   lib->d_walk_recs = nullptr; lib->d_walk_items = nullptr; lib->d_walk_res = nullptr; lib->d_walk_lists = nullptr;
   lib->walk_n = 0;
   const size_t nq = n + n / 8 + 1024;
@@ -871,6 +882,7 @@ static int ensure_walk(hfcl_lib* lib, size_t n) {
   HIP_TRY(hipMalloc(&lib->d_walk_items, nq * WALK_K * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&lib->d_walk_res, nq * WALK_K * 10 * sizeof(double)));  // TriLeafOut<double>: distance, p1, p2, n
   HIP_TRY(hipMalloc(&lib->d_walk_lists, 2 * nq * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&lib->d_walk_order, nq * sizeof(uint32_t)));
   if (!lib->d_walk_ctr) HIP_TRY(hipMalloc(&lib->d_walk_ctr, 8 * WALK_ROUNDS * sizeof(uint32_t)));
   lib->walk_n = nq;
   return HFCL_OK;
@@ -1372,9 +1384,12 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       split.cut_vals = lib->d_bvh_cut_vals;
       if (!solid && lib->bvh_coop) {
         split.coop = 1u;
-        split.budget0 = lib->bvh_budget0_coop ? lib->bvh_budget0_coop : (n > 500000 ? 640u : (lib->walk_rounds ? (n > 150000 ? std::max(320u, lib->walk_budget[0]) : lib->walk_budget[0]) : 256u));
+        const bool one_round = lib->walk_auto && n <= 220000;
+        const uint32_t rounds = lib->walk_auto ? (one_round ? 1u : 2u) : lib->walk_rounds;
+        split.budget0 = lib->bvh_budget0_coop ? lib->bvh_budget0_coop
+                                              : (n > 500000 ? 640u : (one_round ? (n > 120000 ? 320u : 256u) : (rounds ? (n > 150000 ? std::max(320u, lib->walk_budget[0]) : lib->walk_budget[0]) : 256u)));
         // the queries' own phase as walk / leaves / resolve rounds (narrow node ids; rec indices travel in 28 bits)
-        if (lib->walk_rounds && n < (size_t(1) << 28)) {
+        if (rounds && n < (size_t(1) << 28)) {
           r = ensure_walk(lib, n);
           if (r) return r;
           HIP_TRY(hipMemsetAsync(lib->d_walk_ctr, 0, 8 * WALK_ROUNDS * sizeof(uint32_t), st));
@@ -1386,9 +1401,10 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
           split.walk.list_out = lib->d_walk_lists;
           split.walk.item_cap = uint32_t(std::min<size_t>(lib->walk_n * WALK_K, 0xFFFFFFFFu));
           split.walk.list_stride = uint32_t(lib->walk_n);
-          split.walk_rounds = std::min<uint32_t>(lib->walk_rounds, WALK_ROUNDS);
+          split.order = lib->walk_order ? lib->d_walk_order : nullptr;
+          split.walk_rounds = std::min<uint32_t>(rounds, WALK_ROUNDS);
           for (int k = 0; k < WALK_ROUNDS; ++k) {
-            split.walk_k[k] = lib->walk_k[k];
+            split.walk_k[k] = (one_round && k == 0) ? uint32_t(WALK_K) : lib->walk_k[k];
             split.walk_budget[k] = k == 0 ? split.budget0 : lib->walk_budget[k];
           }
         }
