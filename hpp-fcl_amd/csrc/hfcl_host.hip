@@ -97,6 +97,9 @@ struct hfcl_lib {
   void* d_epa_queue2 = nullptr;
   uint32_t* d_epa_cc_over = nullptr;  // Work::epa_cc_over (resume_cap entries)
   hipStream_t aux = nullptr;     // k_epa_records runs here, beside the tiers that continue the handed-over polytopes
+  hipStream_t mesh_st = nullptr;  // the mesh walks of a mixed library's batch run here, beside the solids' kernels (option mesh_beside)
+  hipEvent_t ev_mesh_fork = nullptr, ev_mesh_join = nullptr;
+  bool mesh_beside = true;
   hipStream_t walk_st[WALK_ROUNDS - 1] = {};  // mesh x mesh collide(): the continuation of what round r of the walk hands over runs on walk_st[r]
   hipEvent_t walk_fork[WALK_ROUNDS - 1] = {}, walk_join[WALK_ROUNDS - 1] = {};
   hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr, ev_aux2 = nullptr, ev_aux3 = nullptr;  // fork / join of the EPA tail; of k_bvh_shape_finish's first half
@@ -484,7 +487,7 @@ static const char* const* option_keys() {
       "closed_staged", "split", "epa_cc_staged", "epa_records_aside", "epa_general_staged", "shape_finish_tiers", "shape_finish_aside",
       "epa_general_staged_min", "epa64_two_streams", "epa_cc_staged_min", "pipe_chunk", "bvh_filter", "bvh_shape_lane", "shape_coop",
       "bvh_cut_ticks", "shape_cut_ticks", "bvh_coop", "bvhd_budget", "bvhd_pool", "shape_dist_pool", "pool_rerun", "bvh_walk_early_coop",
-      "bvh_walk_rounds", "bvh_walk_order", "bvh_walk_k", "bvh_walk_budget", "shape_dist_leaf_min", "shape_dist_starve", "bvhd_leaf_min", "bvhd_starve",
+      "bvh_walk_rounds", "bvh_walk_order", "mesh_beside", "bvh_walk_k", "bvh_walk_budget", "shape_dist_leaf_min", "shape_dist_starve", "bvhd_leaf_min", "bvhd_starve",
       "bvhd_part_min", "shape_dist_budget", "bvh_budget0_coop", "shape_budget0", "shape_budget", "shape_leaf_cost", "shape_levels",
       "climb_min", "bvh_budget", "bvh_budget0", "bvh_levels", "cvx_w", "epa_resume_slots", "bvh_task_slots", "bvh_force_wide",
       "pipe_trace", nullptr};
@@ -534,6 +537,7 @@ static int apply_option(hfcl_lib* lib, const std::string& key, const char* v) {
   else if (key == "pool_rerun") lib->pool_rerun = u32(0);
   else if (key == "bvh_walk_early_coop") lib->walk_early_coop = on;
   else if (key == "bvh_walk_order") lib->walk_order = on;
+  else if (key == "mesh_beside") lib->mesh_beside = on;
   else if (key == "bvh_walk_rounds") { lib->walk_rounds = uint32_t(std::min<long long>(std::max(0ll, i), WALK_ROUNDS)); lib->walk_auto = false; }
   else if (key == "bvh_walk_k") { parse_list(v, lib->walk_k, 0, WALK_ROUNDS, 1u, uint32_t(WALK_K)); lib->walk_auto = false; }  // "6,16": per round
   else if (key == "bvh_walk_budget") parse_list(v, lib->walk_budget, 1, WALK_ROUNDS, 0u, 0xFFFFFFFFu);  // rounds 1 ...: box tests (round 0 takes bvh_budget0_coop's)
@@ -626,6 +630,9 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_epa_ready);
   hipFree(lib->d_epa_ready_g);
   hipFree(lib->d_epa_cc_over);
+  if (lib->mesh_st) hipStreamDestroy(lib->mesh_st);
+  if (lib->ev_mesh_fork) hipEventDestroy(lib->ev_mesh_fork);
+  if (lib->ev_mesh_join) hipEventDestroy(lib->ev_mesh_join);
   for (int k = 0; k < WALK_ROUNDS - 1; ++k) {
     if (lib->walk_st[k]) hipStreamDestroy(lib->walk_st[k]);
     if (lib->walk_fork[k]) hipEventDestroy(lib->walk_fork[k]);
@@ -1166,6 +1173,24 @@ static int ensure_aux(hfcl_lib* lib) {
   lib->aux = s;
   return HFCL_OK;
 }
+static int ensure_mesh_stream(hfcl_lib* lib) {
+  if (lib->mesh_st) return HFCL_OK;
+  hipStream_t s = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&e0, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (s) hipStreamDestroy(s);
+    HIP_TRY(e);
+  }
+  lib->ev_mesh_fork = e0;
+  lib->ev_mesh_join = e1;
+  lib->mesh_st = s;
+  return HFCL_OK;
+}
 static int ensure_walk_streams(hfcl_lib* lib) {
   if (lib->walk_st[WALK_ROUNDS - 2]) return HFCL_OK;  // (committed last)
   hipStream_t s[WALK_ROUNDS - 1] = {};
@@ -1304,247 +1329,281 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
   launch_classify(blocks_for(n, CLS_BLOCK * 8), st, wk, lib->d_kinds, uint32_t(lib->n_shapes), q.mode != 1);
   tend();
 
-  if (may(B_CLOSED)) {
-    tbeg("k_closed");
-    launch_closed<T>(blocks_for(n, 256), st, wk, lv, io, q, lib->closed_staged);
-    tend();
-  }
-  if (may(B_PRIM)) {
-    tbeg("k_gjk_prim");
-    launch_gjk_prim<T>(blocks_for(n, 256), st, wk, lv, io, q, bvg);
-    tend();
-  }
-
-  launch_cvx<T>(lib, wk, lv, io, q, st, ti, n);
-
-  if (may(B_LARGE)) {
-    tbeg("k_gjk_large");
-    launch_gjk_large<T>(blocks_for(n, 256 / LARGE_W), st, wk, lv, io, q, bvg);
-    tend();
-  }
-
-  if (may(B_TRI)) {
-    tbeg("k_triangle");
-    launch_triangle<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, io, q);
-    tend();
-  }
-
-  if (!lib->h_meshes.empty() && (may(B_BVH) || may(B_BVHSHAPE))) {
-    // every BVH shape must name a registered model: checked on the host, the kernels index the mesh table with it
-    const hfcl_lib* owner = lib;  // (helpers never run mesh batches)
-    for (const hfcl_shape& sh : owner->h_shapes)
-      if (sh.type == HFCL_BV_OBBRSS && (sh.bvh_index < 0 || size_t(sh.bvh_index) >= owner->h_meshes.size())) {
-        set_error("BVH shape with bvh_index " + std::to_string(sh.bvh_index) + " but only " + std::to_string(owner->h_meshes.size()) +
-                  " BVHModel(s) registered (hfcl_lib_add_bvh)");
-        return HFCL_ERR_INVALID_ARGUMENT;
-      }
-    rc = upload_bvh(lib);
-    if (rc) return rc;
-    BvhView<T> bv;
-    bv.nodes = std::is_same<T, double>::value ? (const DNode<T>*)lib->d_nodes64 : (const DNode<T>*)lib->d_nodes32;
-    bv.fnodes = (std::is_same<T, double>::value && lib->bvh_filter) ? lib->d_fnodes : nullptr;
-    bv.rss = std::is_same<T, double>::value ? (const DRss<T>*)lib->d_rss64 : (const DRss<T>*)lib->d_rss32;
-    bv.dnodes = std::is_same<T, double>::value ? (const DNodeD<T>*)lib->d_dnodes64 : (const DNodeD<T>*)lib->d_dnodes32;
-    bv.verts = std::is_same<T, double>::value ? (const T*)lib->d_bverts64 : (const T*)lib->d_bverts32;
-    bv.tris = lib->d_btris;
-    bv.meshes = lib->d_meshes;
-    bv.n_meshes = uint32_t(lib->h_meshes.size());
-    BvhSpill spill;
-    rc = make_bvh_spill(lib, spill, q.mode != 1);
-    if (rc) return rc;
-    // long traversals are cut into tasks when the batch is large enough for the tail to matter and the request keeps no
-    // query-wide contact count (mesh x mesh and the one-query-per-lane form of mesh x solid alike)
-    auto make_split = [&](BvhSplit& split, bool want, bool solid) -> int {
-      memset(&split, 0, sizeof(split));
-      split.leaf_cost = lib->shape_leaf_cost;
-      if (!(want && (solid ? lib->shape_levels : lib->bvh_levels) > 1 && lib->bvh_params.num_max_contacts == 1 && !lib->bvh_params.contacts)) return HFCL_OK;
-      int r = ensure_bvh_split(lib, n);
-      if (r) return r;
-      HIP_TRY(hipMemsetAsync(lib->d_bvh_ctr, 0, BVH_CTR_WORDS * sizeof(uint32_t), st));
-      split.tasks = lib->d_bvh_tasks;
-      split.sums = lib->d_bvh_sums;
-      split.suspended = lib->d_bvh_susp;
-      split.ctr = lib->d_bvh_ctr;
-      split.cap = uint32_t(std::min<size_t>(lib->bvh_split_cap, 0x7FFFFFFFu));
-      split.n_queries = uint32_t(lib->bvh_split_n);
-      split.budget = lib->bvh_budget;
-      split.budget0 = lib->bvh_budget0;
-      split.n_levels = lib->bvh_levels;
-      if (lib->bvh_auto && 2 * n <= 3 * size_t(lib->n_cus) * 512) {  // (8 waves of 64 lanes per CU are resident)
-        split.budget0 = 512;
-        split.budget = 16;
-        split.n_levels = BVH_MAX_LEVELS;
-      }
-      split.coop_grid = uint32_t(lib->n_cus) * 8u;
-      split.cut_ticks = solid ? lib->shape_cut_ticks : lib->bvh_cut_ticks;
-      split.cut_cap = split.cap;
-      // (mesh x solid: the EPA queue has room for one item per query and per chunk -- shape_defer_cap entries, sized before the walk)
-      split.cut_task_cap = solid ? (wk.shape_defer_cap > n ? uint32_t(std::min<size_t>(wk.shape_defer_cap - n, split.cap)) : 0u) : split.cap;
-      split.cut_words = lib->d_bvh_cut_words;
-      split.cut_vals = lib->d_bvh_cut_vals;
-      if (!solid && lib->bvh_coop) {
-        split.coop = 1u;
-        const bool one_round = lib->walk_auto && n <= 220000;
-        const uint32_t rounds = lib->walk_auto ? (one_round ? 1u : 2u) : lib->walk_rounds;
-        split.budget0 = lib->bvh_budget0_coop ? lib->bvh_budget0_coop
-                                              : (n > 500000 ? 640u : (one_round ? (n > 120000 ? 320u : 256u) : (rounds ? (n > 150000 ? std::max(320u, lib->walk_budget[0]) : lib->walk_budget[0]) : 256u)));
-        // the queries' own phase as walk / leaves / resolve rounds (narrow node ids; rec indices travel in 28 bits)
-        if (rounds && n < (size_t(1) << 28)) {
-          r = ensure_walk(lib, n);
-          if (r) return r;
-          HIP_TRY(hipMemsetAsync(lib->d_walk_ctr, 0, 8 * WALK_ROUNDS * sizeof(uint32_t), st));
-          split.walk.recs = lib->d_walk_recs;
-          split.walk.items = lib->d_walk_items;
-          split.walk.res = lib->d_walk_res;
-          split.walk.ctr = lib->d_walk_ctr;
-          split.walk.list_in = lib->d_walk_lists;
-          split.walk.list_out = lib->d_walk_lists;
-          split.walk.item_cap = uint32_t(std::min<size_t>(lib->walk_n * WALK_K, 0xFFFFFFFFu));
-          split.walk.list_stride = uint32_t(lib->walk_n);
-          split.order = lib->walk_order ? lib->d_walk_order : nullptr;
-          split.walk_rounds = std::min<uint32_t>(rounds, WALK_ROUNDS);
-          for (int k = 0; k < WALK_ROUNDS; ++k) {
-            split.walk_k[k] = (one_round && k == 0) ? uint32_t(WALK_K) : lib->walk_k[k];
-            split.walk_budget[k] = k == 0 ? split.budget0 : lib->walk_budget[k];
-          }
-        }
-      }
-      if (solid) {
-        split.coop = lib->shape_coop ? 1u : 0u;
-        split.budget0 = lib->shape_coop ? lib->shape_budget0_coop : lib->shape_budget0;
-        split.budget = lib->shape_budget;
-        split.n_levels = lib->shape_levels;
-      }
-      return HFCL_OK;
-    };
-    // mesh x solid: one query per lane (k_bvh_collide's SOLID form) where the request lets a leaf that needs EPA end the
-    // walk (hfcl_bvh_shape.hpp: mesh_shape_lane_request) and the lanes' stacks hold the models; the 16-lane group kernel
-    // otherwise
-    const bool shape_fast = q.mode == 1 && may(B_BVHSHAPE) && lib->bvh_shape_lane && size_t(lib->bvh_max_depth) + 1 <= size_t(BVH_STACK) &&
-                            mesh_shape_lane_request(q, lib->bvh_params.num_max_contacts);
-    // distance(): a leaf that needs EPA always ends the walk; models deeper than the lanes' stacks take the group kernel
-    const bool shape_fast_d = q.mode != 1 && may(B_BVHSHAPE) && lib->bvh_shape_lane && size_t(lib->bvh_max_depth) + 1 <= size_t(BVHD_STACK);
-    if (shape_fast || shape_fast_d) {
-      // one EPA item per unit at most (a contact ends the unit): a query, or -- when suspended walks are cut into task levels
-      // instead of being continued by a wave (HFCL_SHAPE_COOP=0) -- every task of the split's table as well
-      size_t need = lib->ws_capacity;
-      // (the chunks of a cut walk are units too, and every unit can queue one item: room for four chunks per query -- 336 B each --; a walk
-      // whose chunks would not fit is not cut, BvhSplit::cut_task_cap.  cfg4s makes ~0.6 chunks per query; n / 2 was too tight: cuts refused,
-      // 3.5 -> 4.4 ms)
-      if (shape_fast && lib->shape_coop && lib->shape_cut_ticks) need = std::max(need, n + 4 * n + 4096);
-      if (shape_fast && !lib->shape_coop && n >= 256) {
-        rc = ensure_bvh_split(lib, n);
-        if (rc) return rc;
-        need = std::max(need, n + lib->bvh_split_cap);
-      }
-      if (need > lib->shape_defer_capacity) {
-        hipFree(lib->d_shape_defer);
-        lib->d_shape_defer = nullptr;
-        lib->shape_defer_capacity = 0;
-        HIP_TRY(hipMalloc(&lib->d_shape_defer, need * (sizeof(ShapeDeferItem<double>) + 2 * sizeof(uint32_t))));  // (+ the two lists of k_bvh_shape_finish's second tier)
-        lib->shape_defer_capacity = need;
-      }
-      // (the solids' boxes are indexed by pair: one per pair of the workspace, not one per EPA item -- 1M pairs: 0.14 GB instead of 0.7)
-      if (lib->ws_capacity > lib->shape_oq_capacity) {
-        hipFree(lib->d_shape_oq);
-        lib->d_shape_oq = nullptr;
-        lib->shape_oq_capacity = 0;
-        HIP_TRY(hipMalloc(&lib->d_shape_oq, lib->ws_capacity * std::max(sizeof(ObbQuery<double>), sizeof(RssQuery<double>))));
-        lib->shape_oq_capacity = lib->ws_capacity;
-      }
-      wk.shape_defer = lib->d_shape_defer;
-      wk.shape_defer_cap = uint32_t(std::min<size_t>(lib->shape_defer_capacity, 0xFFFFFFFFu));
-      wk.shape_finish_over = lib->shape_finish_tiers ? reinterpret_cast<uint32_t*>(static_cast<char*>(lib->d_shape_defer) + lib->shape_defer_capacity * sizeof(ShapeDeferItem<double>)) : nullptr;
-      wk.shape_oq = lib->d_shape_oq;
+  // the solids' kernels of the batch (closed forms, GJK; their EPA follows below, behind the mesh walks: a mesh x solid leaf can queue for it)
+  auto launch_solids = [&]() -> int {
+    if (may(B_CLOSED)) {
+      tbeg("k_closed");
+      launch_closed<T>(blocks_for(n, 256), st, wk, lv, io, q, lib->closed_staged);
+      tend();
     }
-    if (q.mode == 1) {
-      tbeg("k_bvh_shape");
-      if (shape_fast) {
-        // tasks re-start the leaf solver from the request's guess: a walk whose leaves hand the cached guess on, or whose
-        // final guess is read, stays in one piece
-        BvhSplit split;
-        rc = make_split(split, n >= 256 && q.guess_mode != HFCL_GUESS_CACHED && !io.gout, true);
-        if (rc) return rc;
-        AsideStream aside = {nullptr, nullptr, nullptr};
-        if (lib->shape_finish_aside && wk.shape_finish_over && split.tasks && split.coop && split.cut_ticks) {
-          rc = ensure_aux(lib);
-          if (rc) return rc;
-          aside = AsideStream{lib->aux, lib->ev_aux2, lib->ev_aux3};
-        }
-        launch_bvh_shape_fast<T>(blocks_for(n, BVH_BLOCK), blocks_for(n / 8 + 1, 64 / BS_W), int(std::min<size_t>(n / 4 + 1, size_t(lib->n_cus) * 8)), st, wk, lv, bv, io, q, lib->bvh_params,
-                                 T(lib->break_distance * lib->break_distance), split, spill, aside.stream ? &aside : nullptr);
-      } else {
-        launch_bvh_shape<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance));
-      }
+    if (may(B_PRIM)) {
+      tbeg("k_gjk_prim");
+      launch_gjk_prim<T>(blocks_for(n, 256), st, wk, lv, io, q, bvg);
       tend();
-      tbeg("k_bvh_collide");
-      BvhSplit split;
-      rc = make_split(split, may(B_BVH) && !spill.wide && (n >= 256 || 2 * size_t(lib->bvh_max_depth) + 4 > size_t(std::min(BVH_STACK, BVH_STACK_FILT))), false);
+    }
+
+    launch_cvx<T>(lib, wk, lv, io, q, st, ti, n);
+
+    if (may(B_LARGE)) {
+      tbeg("k_gjk_large");
+      launch_gjk_large<T>(blocks_for(n, 256 / LARGE_W), st, wk, lv, io, q, bvg);
+      tend();
+    }
+
+    if (may(B_TRI)) {
+      tbeg("k_triangle");
+      launch_triangle<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, io, q);
+      tend();
+    }
+    return HFCL_OK;
+  };
+  // the mesh walks of the batch
+  auto launch_meshes = [&]() -> int {
+    if (!lib->h_meshes.empty() && (may(B_BVH) || may(B_BVHSHAPE))) {
+      // every BVH shape must name a registered model: checked on the host, the kernels index the mesh table with it
+      const hfcl_lib* owner = lib;  // (helpers never run mesh batches)
+      for (const hfcl_shape& sh : owner->h_shapes)
+        if (sh.type == HFCL_BV_OBBRSS && (sh.bvh_index < 0 || size_t(sh.bvh_index) >= owner->h_meshes.size())) {
+          set_error("BVH shape with bvh_index " + std::to_string(sh.bvh_index) + " but only " + std::to_string(owner->h_meshes.size()) +
+                    " BVHModel(s) registered (hfcl_lib_add_bvh)");
+          return HFCL_ERR_INVALID_ARGUMENT;
+        }
+      rc = upload_bvh(lib);
       if (rc) return rc;
-      AsideStream beside[WALK_ROUNDS - 1];
-      memset(beside, 0, sizeof(beside));
-      const bool early = split.walk.recs && split.walk_rounds > 1 && lib->walk_early_coop;
-      if (early) {
-        rc = ensure_walk_streams(lib);
-        if (rc) return rc;
-        for (int k = 0; k < WALK_ROUNDS - 1; ++k) beside[k] = AsideStream{lib->walk_st[k], lib->walk_fork[k], lib->walk_join[k]};
-      }
-      launch_bvh_collide<T>(blocks_for(n, BVH_BLOCK), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance), split, spill, early ? beside : nullptr);
-      tend();
-    } else {
-      tbeg("k_bvh_shape_distance");
-      if (shape_fast_d) {
-        // long walks are handed to waves -- unless their leaves hand a cached guess on, or the final guess is read
-        BvhSpill ss;
-        memset(&ss, 0, sizeof(ss));
-        if (lib->shape_dist_budget && q.guess_mode != HFCL_GUESS_CACHED && !io.gout) {
-          if (lib->ws_capacity > lib->shape_dist_susp_capacity) {
-            hipFree(lib->d_shape_dist_susp);
-            lib->d_shape_dist_susp = nullptr;
-            lib->shape_dist_susp_capacity = 0;
-            HIP_TRY(hipMalloc(&lib->d_shape_dist_susp, lib->ws_capacity * sizeof(ShapeDistSusp<double>)));
-            lib->shape_dist_susp_capacity = lib->ws_capacity;
+      BvhView<T> bv;
+      bv.nodes = std::is_same<T, double>::value ? (const DNode<T>*)lib->d_nodes64 : (const DNode<T>*)lib->d_nodes32;
+      bv.fnodes = (std::is_same<T, double>::value && lib->bvh_filter) ? lib->d_fnodes : nullptr;
+      bv.rss = std::is_same<T, double>::value ? (const DRss<T>*)lib->d_rss64 : (const DRss<T>*)lib->d_rss32;
+      bv.dnodes = std::is_same<T, double>::value ? (const DNodeD<T>*)lib->d_dnodes64 : (const DNodeD<T>*)lib->d_dnodes32;
+      bv.verts = std::is_same<T, double>::value ? (const T*)lib->d_bverts64 : (const T*)lib->d_bverts32;
+      bv.tris = lib->d_btris;
+      bv.meshes = lib->d_meshes;
+      bv.n_meshes = uint32_t(lib->h_meshes.size());
+      BvhSpill spill;
+      rc = make_bvh_spill(lib, spill, q.mode != 1);
+      if (rc) return rc;
+      // long traversals are cut into tasks when the batch is large enough for the tail to matter and the request keeps no
+      // query-wide contact count (mesh x mesh and the one-query-per-lane form of mesh x solid alike)
+      auto make_split = [&](BvhSplit& split, bool want, bool solid) -> int {
+        memset(&split, 0, sizeof(split));
+        split.leaf_cost = lib->shape_leaf_cost;
+        if (!(want && (solid ? lib->shape_levels : lib->bvh_levels) > 1 && lib->bvh_params.num_max_contacts == 1 && !lib->bvh_params.contacts)) return HFCL_OK;
+        int r = ensure_bvh_split(lib, n);
+        if (r) return r;
+        HIP_TRY(hipMemsetAsync(lib->d_bvh_ctr, 0, BVH_CTR_WORDS * sizeof(uint32_t), st));
+        split.tasks = lib->d_bvh_tasks;
+        split.sums = lib->d_bvh_sums;
+        split.suspended = lib->d_bvh_susp;
+        split.ctr = lib->d_bvh_ctr;
+        split.cap = uint32_t(std::min<size_t>(lib->bvh_split_cap, 0x7FFFFFFFu));
+        split.n_queries = uint32_t(lib->bvh_split_n);
+        split.budget = lib->bvh_budget;
+        split.budget0 = lib->bvh_budget0;
+        split.n_levels = lib->bvh_levels;
+        if (lib->bvh_auto && 2 * n <= 3 * size_t(lib->n_cus) * 512) {  // (8 waves of 64 lanes per CU are resident)
+          split.budget0 = 512;
+          split.budget = 16;
+          split.n_levels = BVH_MAX_LEVELS;
+        }
+        split.coop_grid = uint32_t(lib->n_cus) * 8u;
+        split.cut_ticks = solid ? lib->shape_cut_ticks : lib->bvh_cut_ticks;
+        split.cut_cap = split.cap;
+        // (mesh x solid: the EPA queue has room for one item per query and per chunk -- shape_defer_cap entries, sized before the walk)
+        split.cut_task_cap = solid ? (wk.shape_defer_cap > n ? uint32_t(std::min<size_t>(wk.shape_defer_cap - n, split.cap)) : 0u) : split.cap;
+        split.cut_words = lib->d_bvh_cut_words;
+        split.cut_vals = lib->d_bvh_cut_vals;
+        if (!solid && lib->bvh_coop) {
+          split.coop = 1u;
+          const bool one_round = lib->walk_auto && n <= 220000;
+          const uint32_t rounds = lib->walk_auto ? (one_round ? 1u : 2u) : lib->walk_rounds;
+          split.budget0 = lib->bvh_budget0_coop ? lib->bvh_budget0_coop
+                                                : (n > 500000 ? 640u : (one_round ? (n > 120000 ? 320u : 256u) : (rounds ? (n > 150000 ? std::max(320u, lib->walk_budget[0]) : lib->walk_budget[0]) : 256u)));
+          // the queries' own phase as walk / leaves / resolve rounds (narrow node ids; rec indices travel in 28 bits)
+          if (rounds && n < (size_t(1) << 28)) {
+            r = ensure_walk(lib, n);
+            if (r) return r;
+            HIP_TRY(hipMemsetAsync(lib->d_walk_ctr, 0, 8 * WALK_ROUNDS * sizeof(uint32_t), st));
+            split.walk.recs = lib->d_walk_recs;
+            split.walk.items = lib->d_walk_items;
+            split.walk.res = lib->d_walk_res;
+            split.walk.ctr = lib->d_walk_ctr;
+            split.walk.list_in = lib->d_walk_lists;
+            split.walk.list_out = lib->d_walk_lists;
+            split.walk.item_cap = uint32_t(std::min<size_t>(lib->walk_n * WALK_K, 0xFFFFFFFFu));
+            split.walk.list_stride = uint32_t(lib->walk_n);
+            split.order = lib->walk_order ? lib->d_walk_order : nullptr;
+            split.walk_rounds = std::min<uint32_t>(rounds, WALK_ROUNDS);
+            for (int k = 0; k < WALK_ROUNDS; ++k) {
+              split.walk_k[k] = (one_round && k == 0) ? uint32_t(WALK_K) : lib->walk_k[k];
+              split.walk_budget[k] = k == 0 ? split.budget0 : lib->walk_budget[k];
+            }
           }
-          ss.susp = lib->d_shape_dist_susp;
-          ss.rerun_count = lib->pool_rerun ? lib->d_counts + CTR_SHAPE_DIST_RERUN : nullptr;
-          ss.rerun_all = lib->pool_rerun >= 2 ? 1u : 0u;
-          ss.susp_count = lib->d_counts + CTR_SHAPE_DIST_SUSP;
-          ss.budget = lib->shape_dist_budget;
-          ss.max_blocks = uint32_t(lib->n_cus) * 8u;
-          ss.pool = lib->has_flats ? 0u : lib->shape_dist_pool;
-          ss.pool_ticket = lib->d_counts + CTR_SHAPE_DIST_TICKET;
-          ss.pool_leaf_min = lib->shape_dist_leaf_min;
-          ss.pool_starve = lib->shape_dist_starve;
         }
-        launch_bvh_shape_distance_fast<T>(blocks_for(n, BVHD_BLOCK), blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, ss);
-      }
-      else
-        launch_bvh_shape_distance<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q);
-      tend();
-      tbeg("k_bvh_distance");
-      if (may(B_BVH) && !spill.wide && lib->bvhd_budget) {
-        if (lib->ws_capacity > lib->dist_susp_capacity) {
-          hipFree(lib->d_dist_susp);
-          lib->d_dist_susp = nullptr;
-          lib->dist_susp_capacity = 0;
-          HIP_TRY(hipMalloc(&lib->d_dist_susp, lib->ws_capacity * sizeof(DistSusp<double>)));
-          lib->dist_susp_capacity = lib->ws_capacity;
+        if (solid) {
+          split.coop = lib->shape_coop ? 1u : 0u;
+          split.budget0 = lib->shape_coop ? lib->shape_budget0_coop : lib->shape_budget0;
+          split.budget = lib->shape_budget;
+          split.n_levels = lib->shape_levels;
         }
-        spill.susp = lib->d_dist_susp;
-        spill.rerun_count = lib->pool_rerun ? lib->d_counts + CTR_DIST_RERUN : nullptr;
-        spill.rerun_all = lib->pool_rerun >= 2 ? 1u : 0u;
-        spill.susp_count = lib->d_counts + CTR_DIST_SUSP;
-        spill.budget = lib->bvhd_budget;
-        spill.max_blocks = uint32_t(lib->n_cus) * 8u;
-        spill.pool = lib->bvhd_pool;
-        spill.pool_ticket = lib->d_counts + CTR_DIST_TICKET;
-        spill.pool_leaf_min = lib->bvhd_pool_leaf_min;
-        spill.pool_starve = lib->bvhd_pool_starve;
-        spill.pool_part_min = lib->bvhd_pool_part_min;
-        if (lib->bvh_max_nodes > 32767) spill.pool = 0;  // 15-bit node ids in the pool's entry word (POOL_MAX_NODES)
+        return HFCL_OK;
+      };
+      // mesh x solid: one query per lane (k_bvh_collide's SOLID form) where the request lets a leaf that needs EPA end the
+      // walk (hfcl_bvh_shape.hpp: mesh_shape_lane_request) and the lanes' stacks hold the models; the 16-lane group kernel
+      // otherwise
+      const bool shape_fast = q.mode == 1 && may(B_BVHSHAPE) && lib->bvh_shape_lane && size_t(lib->bvh_max_depth) + 1 <= size_t(BVH_STACK) &&
+                              mesh_shape_lane_request(q, lib->bvh_params.num_max_contacts);
+      // distance(): a leaf that needs EPA always ends the walk; models deeper than the lanes' stacks take the group kernel
+      const bool shape_fast_d = q.mode != 1 && may(B_BVHSHAPE) && lib->bvh_shape_lane && size_t(lib->bvh_max_depth) + 1 <= size_t(BVHD_STACK);
+      if (shape_fast || shape_fast_d) {
+        // one EPA item per unit at most (a contact ends the unit): a query, or -- when suspended walks are cut into task levels
+        // instead of being continued by a wave (HFCL_SHAPE_COOP=0) -- every task of the split's table as well
+        size_t need = lib->ws_capacity;
+        // (the chunks of a cut walk are units too, and every unit can queue one item: room for four chunks per query -- 336 B each --; a walk
+        // whose chunks would not fit is not cut, BvhSplit::cut_task_cap.  cfg4s makes ~0.6 chunks per query; n / 2 was too tight: cuts refused,
+        // 3.5 -> 4.4 ms)
+        if (shape_fast && lib->shape_coop && lib->shape_cut_ticks) need = std::max(need, n + 4 * n + 4096);
+        if (shape_fast && !lib->shape_coop && n >= 256) {
+          rc = ensure_bvh_split(lib, n);
+          if (rc) return rc;
+          need = std::max(need, n + lib->bvh_split_cap);
+        }
+        if (need > lib->shape_defer_capacity) {
+          hipFree(lib->d_shape_defer);
+          lib->d_shape_defer = nullptr;
+          lib->shape_defer_capacity = 0;
+          HIP_TRY(hipMalloc(&lib->d_shape_defer, need * (sizeof(ShapeDeferItem<double>) + 2 * sizeof(uint32_t))));  // (+ the two lists of k_bvh_shape_finish's second tier)
+          lib->shape_defer_capacity = need;
+        }
+        // (the solids' boxes are indexed by pair: one per pair of the workspace, not one per EPA item -- 1M pairs: 0.14 GB instead of 0.7)
+        if (lib->ws_capacity > lib->shape_oq_capacity) {
+          hipFree(lib->d_shape_oq);
+          lib->d_shape_oq = nullptr;
+          lib->shape_oq_capacity = 0;
+          HIP_TRY(hipMalloc(&lib->d_shape_oq, lib->ws_capacity * std::max(sizeof(ObbQuery<double>), sizeof(RssQuery<double>))));
+          lib->shape_oq_capacity = lib->ws_capacity;
+        }
+        wk.shape_defer = lib->d_shape_defer;
+        wk.shape_defer_cap = uint32_t(std::min<size_t>(lib->shape_defer_capacity, 0xFFFFFFFFu));
+        wk.shape_finish_over = lib->shape_finish_tiers ? reinterpret_cast<uint32_t*>(static_cast<char*>(lib->d_shape_defer) + lib->shape_defer_capacity * sizeof(ShapeDeferItem<double>)) : nullptr;
+        wk.shape_oq = lib->d_shape_oq;
       }
-      launch_bvh_distance<T>(blocks_for(n, BVHD_BLOCK), st, wk, lv, bv, io, q, spill);
-      tend();
+      if (q.mode == 1) {
+        tbeg("k_bvh_shape");
+        if (shape_fast) {
+          // tasks re-start the leaf solver from the request's guess: a walk whose leaves hand the cached guess on, or whose
+          // final guess is read, stays in one piece
+          BvhSplit split;
+          rc = make_split(split, n >= 256 && q.guess_mode != HFCL_GUESS_CACHED && !io.gout, true);
+          if (rc) return rc;
+          AsideStream aside = {nullptr, nullptr, nullptr};
+          if (lib->shape_finish_aside && wk.shape_finish_over && split.tasks && split.coop && split.cut_ticks) {
+            rc = ensure_aux(lib);
+            if (rc) return rc;
+            aside = AsideStream{lib->aux, lib->ev_aux2, lib->ev_aux3};
+          }
+          launch_bvh_shape_fast<T>(blocks_for(n, BVH_BLOCK), blocks_for(n / 8 + 1, 64 / BS_W), int(std::min<size_t>(n / 4 + 1, size_t(lib->n_cus) * 8)), st, wk, lv, bv, io, q, lib->bvh_params,
+                                   T(lib->break_distance * lib->break_distance), split, spill, aside.stream ? &aside : nullptr);
+        } else {
+          launch_bvh_shape<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance));
+        }
+        tend();
+        tbeg("k_bvh_collide");
+        BvhSplit split;
+        rc = make_split(split, may(B_BVH) && !spill.wide && (n >= 256 || 2 * size_t(lib->bvh_max_depth) + 4 > size_t(std::min(BVH_STACK, BVH_STACK_FILT))), false);
+        if (rc) return rc;
+        AsideStream beside[WALK_ROUNDS - 1];
+        memset(beside, 0, sizeof(beside));
+        const bool early = split.walk.recs && split.walk_rounds > 1 && lib->walk_early_coop;
+        if (early) {
+          rc = ensure_walk_streams(lib);
+          if (rc) return rc;
+          for (int k = 0; k < WALK_ROUNDS - 1; ++k) beside[k] = AsideStream{lib->walk_st[k], lib->walk_fork[k], lib->walk_join[k]};
+        }
+        launch_bvh_collide<T>(blocks_for(n, BVH_BLOCK), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance), split, spill, early ? beside : nullptr);
+        tend();
+      } else {
+        tbeg("k_bvh_shape_distance");
+        if (shape_fast_d) {
+          // long walks are handed to waves -- unless their leaves hand a cached guess on, or the final guess is read
+          BvhSpill ss;
+          memset(&ss, 0, sizeof(ss));
+          if (lib->shape_dist_budget && q.guess_mode != HFCL_GUESS_CACHED && !io.gout) {
+            if (lib->ws_capacity > lib->shape_dist_susp_capacity) {
+              hipFree(lib->d_shape_dist_susp);
+              lib->d_shape_dist_susp = nullptr;
+              lib->shape_dist_susp_capacity = 0;
+              HIP_TRY(hipMalloc(&lib->d_shape_dist_susp, lib->ws_capacity * sizeof(ShapeDistSusp<double>)));
+              lib->shape_dist_susp_capacity = lib->ws_capacity;
+            }
+            ss.susp = lib->d_shape_dist_susp;
+            ss.rerun_count = lib->pool_rerun ? lib->d_counts + CTR_SHAPE_DIST_RERUN : nullptr;
+            ss.rerun_all = lib->pool_rerun >= 2 ? 1u : 0u;
+            ss.susp_count = lib->d_counts + CTR_SHAPE_DIST_SUSP;
+            ss.budget = lib->shape_dist_budget;
+            ss.max_blocks = uint32_t(lib->n_cus) * 8u;
+            ss.pool = lib->has_flats ? 0u : lib->shape_dist_pool;
+            ss.pool_ticket = lib->d_counts + CTR_SHAPE_DIST_TICKET;
+            ss.pool_leaf_min = lib->shape_dist_leaf_min;
+            ss.pool_starve = lib->shape_dist_starve;
+          }
+          launch_bvh_shape_distance_fast<T>(blocks_for(n, BVHD_BLOCK), blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, ss);
+        }
+        else
+          launch_bvh_shape_distance<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q);
+        tend();
+        tbeg("k_bvh_distance");
+        if (may(B_BVH) && !spill.wide && lib->bvhd_budget) {
+          if (lib->ws_capacity > lib->dist_susp_capacity) {
+            hipFree(lib->d_dist_susp);
+            lib->d_dist_susp = nullptr;
+            lib->dist_susp_capacity = 0;
+            HIP_TRY(hipMalloc(&lib->d_dist_susp, lib->ws_capacity * sizeof(DistSusp<double>)));
+            lib->dist_susp_capacity = lib->ws_capacity;
+          }
+          spill.susp = lib->d_dist_susp;
+          spill.rerun_count = lib->pool_rerun ? lib->d_counts + CTR_DIST_RERUN : nullptr;
+          spill.rerun_all = lib->pool_rerun >= 2 ? 1u : 0u;
+          spill.susp_count = lib->d_counts + CTR_DIST_SUSP;
+          spill.budget = lib->bvhd_budget;
+          spill.max_blocks = uint32_t(lib->n_cus) * 8u;
+          spill.pool = lib->bvhd_pool;
+          spill.pool_ticket = lib->d_counts + CTR_DIST_TICKET;
+          spill.pool_leaf_min = lib->bvhd_pool_leaf_min;
+          spill.pool_starve = lib->bvhd_pool_starve;
+          spill.pool_part_min = lib->bvhd_pool_part_min;
+          if (lib->bvh_max_nodes > 32767) spill.pool = 0;  // 15-bit node ids in the pool's entry word (POOL_MAX_NODES)
+        }
+        launch_bvh_distance<T>(blocks_for(n, BVHD_BLOCK), st, wk, lv, bv, io, q, spill);
+        tend();
+      }
+    }
+    return HFCL_OK;
+  };
+  // A library with meshes AND solids: the mesh walks on a stream of their own BESIDE the solids' kernels -- the walks are chains of dependent
+  // steps that leave the chip half empty (section 3 item 6f), and every kernel of a bucket the library COULD fill is launched whether or not
+  // this batch fills it (a mesh-only batch of a mixed library used to wait for ~0.08 ms of empty GJK launches in front of its walks).
+  {
+    const bool any_mesh = !lib->h_meshes.empty() && (may(B_BVH) || may(B_BVHSHAPE));
+    const bool any_solid = may(B_CLOSED) || any_gjk || may(B_TRI);
+    bool beside = any_mesh && any_solid && lib->mesh_beside;
+    if (beside && ensure_mesh_stream(lib) != HFCL_OK) beside = false;  // (no helper stream: one after the other, as before)
+    if (beside) {
+      hipStream_t const caller = st;
+      HIP_TRY(hipEventRecord(lib->ev_mesh_fork, caller));
+      HIP_TRY(hipStreamWaitEvent(lib->mesh_st, lib->ev_mesh_fork, 0));
+      st = lib->mesh_st;  // (the lambdas above launch on `st`)
+      rc = launch_meshes();
+      st = caller;
+      if (rc) return rc;
+      HIP_TRY(hipEventRecord(lib->ev_mesh_join, lib->mesh_st));
+      rc = launch_solids();
+      if (rc) return rc;
+      HIP_TRY(hipStreamWaitEvent(caller, lib->ev_mesh_join, 0));
+    } else {
+      rc = launch_solids();
+      if (rc) return rc;
+      rc = launch_meshes();
+      if (rc) return rc;
     }
   }
 
