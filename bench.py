@@ -11,6 +11,7 @@ its own timed region, roofline and (trimmed) CPU baseline --
   cfg2  1M Box-Capsule collide(), fp64 (+ the same batch through the host-buffer boundary, `host_buffers`)
   cfg4  100k BVHModel<OBBRSS> mesh-mesh collide(), fp64
   cfg5  1.25M (= 10M / 8) mixed pairs from the host broadphase, fp64, per GPU (weak)
+  cfgmix  200k pairs of a scene of meshes AND solids in one batch (solid x solid, mesh x solid, mesh x mesh), fp64
   cfg5_strong  ONE 10M-pair list from the host broadphase, sharded over the ranks with sharding.shard_range and its
         real records all-gathered (north_star's configs[4] as written; `--scaling strong --workload cfg5 --pairs 10000000`
         runs it as the headline)
@@ -66,18 +67,22 @@ BYTES_PER_QUERY = {
     # with the oracle on a sample as for cfg4
     "cfg4d": 8 + 2 * 96 + 96,
     "cfg4s": 8 + 2 * 96 + 96,
+    # a scene of meshes AND solids in one batch (40 % solid x solid, 40 % mesh x solid, 20 % mesh x mesh): ids + poses + record, plus the walk
+    # bytes of the mesh pairs averaged over all pairs (mixed_collide_batch's statistics count the mesh x solid walks)
+    "cfgmix": 8 + 2 * 96 + 96,
 }
 # per BV test / per leaf test of the reference's walk: cfg4 two 128-B OBB node records / two triangles (3 x 24 B vertices + 12 B
 # of indices each); cfg4d two 128-B RSS node records (DNodeD) / two triangles; cfg4s ONE mesh node record (the solid's box is
 # computed from its 56-B shape record, counted once in the 296 B) / one triangle
 CFG4_BYTES_PER_BV_TEST = 2 * 128
 CFG4_BYTES_PER_LEAF_TEST = 2 * (3 * 24 + 12)
-WALK_BYTES = {"cfg4": (CFG4_BYTES_PER_BV_TEST, CFG4_BYTES_PER_LEAF_TEST), "cfg4d": (2 * 128, 2 * (3 * 24 + 12)), "cfg4s": (128, 3 * 24 + 12)}
-DEFAULT_PAIRS = {"cfg4": 100_000, "cfg4d": 100_000, "cfg4s": 100_000, "cfg5": 1_250_000, "cfg1": 4_000_000}
+WALK_BYTES = {"cfg4": (CFG4_BYTES_PER_BV_TEST, CFG4_BYTES_PER_LEAF_TEST), "cfg4d": (2 * 128, 2 * (3 * 24 + 12)), "cfg4s": (128, 3 * 24 + 12), "cfgmix": (128, 3 * 24 + 12)}
+DEFAULT_PAIRS = {"cfg4": 100_000, "cfg4d": 100_000, "cfg4s": 100_000, "cfg5": 1_250_000, "cfg1": 4_000_000, "cfgmix": 200_000}
 BASELINE_CONFIG = {"cfg3": "configs[2]", "cfg2": "configs[1]", "cfg4": "configs[3]", "cfg5": "configs[4]",
                    "cfg1": "configs[0] (shape pair; GPU batch size)", "cfg3u": "configs[2], one hull pair per query",
                    "cfg2f": "configs[1] through the fp32 device path", "cfg4d": "configs[3], distance() instead of collide()",
-                   "cfg4s": "configs[3]'s models against convex solids (SURVEY.md 8 f3: BVH x primitive traversal), six solid kinds mixed"}
+                   "cfg4s": "configs[3]'s models against convex solids (SURVEY.md 8 f3: BVH x primitive traversal), six solid kinds mixed",
+                   "cfgmix": "a scene of configs[3]'s models and configs[4]'s solid kinds in ONE batch: solid x solid, mesh x solid, mesh x mesh"}
 
 # VALU issue peak, MEASURED on the box (tools/valu_peak.hip, profiles/r02_a_valu_issue_peak.txt): the select / compare /
 # fma mix these kernels are made of tops out at 1.00e12 wave64 instructions per second chip-wide with 8 waves per SIMD
@@ -91,7 +96,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=None, choices=["cfg3", "cfg2", "cfg4", "cfg5", "cfg1", "cfg3u", "cfg2f", "cfg4d", "cfg4s"],
+    ap.add_argument("--workload", default=None, choices=["cfg3", "cfg2", "cfg4", "cfg5", "cfg1", "cfg3u", "cfg2f", "cfg4d", "cfg4s", "cfgmix"],
                     help="run this workload alone as the headline (default: cfg3 + the secondary list)")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default 1M; cfg4: 100k; cfg5: 1.25M = 10M / 8); "
                     "with --scaling strong: pairs of the whole job")
@@ -388,6 +393,9 @@ def make_batch(ctx, workload, n, strong):
         batch, dtype = wl.cfg4_mesh_mesh_distance(n=n, seed=seed), "f64"
     elif workload == "cfg4s":
         batch, dtype = wl.mesh_vs_solid("mixed", n=n, seed=seed), "f64"
+    elif workload == "cfgmix":
+        batch, dtype = wl.mixed_scene(n=n, seed=seed), "f64"
+        extra = {"mix": batch.mix}
     else:
         batch, dtype = wl.cfg4_mesh_mesh(n=n, seed=seed), "f64"
     if strong:
@@ -418,7 +426,7 @@ def cpu_baseline(ctx, workload, batch, req, sample, budget_s, all_cores=True, na
 
         def run_cpu(lo, hi, threads):
             ob.bvh_distance_batch(MLc, sb.s1[lo:hi], sb.s2[lo:hi], tf1[lo:hi], tf2[lo:hi], n_threads=threads)
-    elif workload == "cfg4s":
+    elif workload in ("cfg4s", "cfgmix"):
         MLc = ctx.pkg.bvh_builder.MeshLibrary(batch.meshes)
 
         def run_cpu(lo, hi, threads):
@@ -847,13 +855,14 @@ def main():
             plan += [("cfg3", 0, False, dict(two_streams=True)), ("cfg4", 0, False, dict(two_streams=True))]
             plan.append(("cfg4d", 0, False, {}))  # configs[3]'s distance() variant: ~3 400 RSS tests + 215 triangle pairs per query
             plan.append(("cfg4s", 0, False, {}))  # configs[3]'s models against convex solids
+            plan.append(("cfgmix", 0, False, {}))  # meshes and solids in one batch: the mesh walks beside the solids' kernels
         if ctx.world > 1:  # the same list with the 24-B exchange format, and the headline without any exchange
             plan += [("cfg5", 10_000_000, True, dict(gather="compact")), ("cfg3", 0, False, dict(gather="none"))]
         for wl_name, pairs, st, kw in plan:
             try:
                 r = run_workload(ctx, wl_name, pairs, (sec_steps if not st else 5) if wl_name != "cfg4d" else 2, 2 if wl_name != "cfg4d" else 1,
                                  strong=st, cpu_budget_s=2.5,
-                                 cpu_sample=100_000 if wl_name not in ("cfg4", "cfg4d") else (20_000 if wl_name == "cfg4" else 2_000), **kw)
+                                 cpu_sample=100_000 if wl_name not in ("cfg4", "cfg4d", "cfgmix") else (20_000 if wl_name != "cfg4d" else 2_000), **kw)
             except Exception as e:  # a secondary must never take the headline down
                 r = {"workload": wl_name + ("/strong" if st else ""), "error": repr(e)} if ctx.rank == 0 else None
             if r is not None:

@@ -424,6 +424,28 @@ def mesh_vs_solid(kind, n=100_000, seed=1, seg=50, nper=64, half_width=1.6):
     return b
 
 
+def mixed_scene(n=200_000, seed=1, frac_solid=0.4, frac_mesh_solid=0.4):
+    """One batch with every kind of pair a scene of meshes and solids produces -- solid x solid (frac_solid; the six solid kinds of
+    mesh_vs_solid("mixed") among themselves), mesh x solid in both operand orders (frac_mesh_solid), mesh x mesh (the rest) -- on cfg4-size
+    models: bench.py's `cfgmix` row (what the mesh walks beside the solids' kernels are for; SURVEY.md 8 f3 + configs[3] + configs[4])."""
+    b = mesh_vs_solid("mixed", n=n, seed=seed)
+    rng = _rng(seed, 91)
+    n_lib = len(b.lib)
+    u = rng.uniform(size=n)
+    mesh_a, mesh_b = rng.integers(0, 8, n), rng.integers(0, 8, n)
+    sol_a, sol_b = rng.integers(8, n_lib, n), rng.integers(8, n_lib, n)
+    swap = rng.uniform(size=n) < 0.5
+    solid = u < frac_solid
+    ms = (~solid) & (u < frac_solid + frac_mesh_solid)
+    mm = ~(solid | ms)
+    s1 = np.where(solid, sol_a, np.where(ms, np.where(swap, sol_a, mesh_a), mesh_a))
+    s2 = np.where(solid, sol_b, np.where(ms, np.where(swap, mesh_b, sol_b), mesh_b))
+    b.s1, b.s2 = s1.astype(b.s1.dtype), s2.astype(b.s2.dtype)
+    b.name = "mixed_scene_collide"
+    b.mix = {"solid_x_solid": float(solid.mean()), "mesh_x_solid": float(ms.mean()), "mesh_x_mesh": float(mm.mean())}
+    return b
+
+
 def cfg5_mixed(n=100_000, seed=1, nper=256, half_width=0.8):
     """cfg5-style mixed primitive+convex pairs (type mix 20 % each of Box/Sphere/Capsule/
     Ellipsoid/Convex32), synthetic pair list (cfg5_broadphase_scene takes its pairs from the host broadphase)."""

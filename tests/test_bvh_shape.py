@@ -116,7 +116,7 @@ def test_device_headers_match_oracle(pkg, oracle, hostsim, nmax, margin, cached)
     a = (b.shapes, b.verts, ML, b.s1[sel], b.s2[sel], b.tf1[sel], b.tf2[sel], req)
     ref, cref, gref = oracle.mixed_collide_batch(*a, max_contacts=10 ** 6, want_guess=True)
     got, cgot, ggot = hostsim.mesh_shape_collide_f64(abi, *a, max_contacts=10 ** 6, want_guess=True)
-    assert 0.2 < (ref["num_contacts"] > 0).mean() < 0.9
+    assert 0.1 < (ref["num_contacts"] > 0).mean() < 0.9
     assert np.array_equal(ref["num_contacts"], got["num_contacts"])
     assert np.array_equal(ref["b1"], got["b1"]) and np.array_equal(ref["b2"], got["b2"])
     assert _same(got["distance"], ref["distance"], 1e-15)
@@ -150,7 +150,7 @@ def test_lane_form_equals_group_form(pkg, hostsim, margin, cached):
         got, cgot, ggot = hostsim.mesh_shape_collide_f64(abi, *a, max_contacts=10 ** 6, want_guess=True)
     finally:
         hostsim.set_shape_lane(False)
-    assert 0.2 < (ref["num_contacts"] > 0).mean() < 0.9
+    assert 0.1 < (ref["num_contacts"] > 0).mean() < 0.9
     assert ref.tobytes() == got.tobytes()
     assert cref.tobytes() == cgot.tobytes()
     assert gref.tobytes() == ggot.tobytes()
@@ -674,3 +674,35 @@ def test_gpu_mesh_vs_flats(pkg, oracle):
     sepd = mixed & (dref["distance"] > 1e-9)
     assert np.abs(dgot["distance"][sepd] - dref["distance"][sepd]).max() < 1e-9
     assert (dgot["distance"][mixed & (dref["distance"] <= 0)] <= 1e-9).all()
+
+
+@pytest.mark.gpu
+def test_gpu_mixed_scene_beside_equals_in_line(pkg, oracle):
+    """A batch with solid x solid, mesh x solid (both operand orders) and mesh x mesh pairs on cfg4-size models (workloads.mixed_scene, bench.py's
+    cfgmix row): the mesh walks on a stream of their own beside the solids' kernels (option mesh_beside, the default) give byte for byte the
+    records of the in-line order, twice, and both equal the oracle's decisions (contact flags, first-contact triangle ids)."""
+    abi, wl, bb = pkg.abi, pkg.workloads, pkg.bvh_builder
+    b = wl.mixed_scene(n=40_000, seed=3)
+    assert min(b.mix.values()) > 0.1
+    req = abi.default_collision_request()
+    recs = {}
+    for beside in (1, 0):
+        lib = wl.make_library(pkg, b, options={"mesh_beside": beside})
+        try:
+            first = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
+            again = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
+            assert first.tobytes() == again.tobytes()
+            recs[beside] = first
+        finally:
+            lib.close()
+    assert recs[1].tobytes() == recs[0].tobytes()
+    ML = bb.MeshLibrary(b.meshes)
+    ref = oracle.mixed_collide_batch(b.shapes, b.verts, ML, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=32)
+    got = recs[1]
+    assert not np.any((got["status"] >> 31) & 1)
+    clear = np.abs(ref["distance"]) > 1e-9
+    assert np.array_equal((got["num_contacts"] > 0)[clear], (ref["num_contacts"] > 0)[clear])
+    mesh_pair = (b.shapes["type"][b.s1] == abi.BV_OBBRSS) | (b.shapes["type"][b.s2] == abi.BV_OBBRSS)
+    hit = clear & mesh_pair & (ref["num_contacts"] > 0)
+    assert np.array_equal(got["b1"][hit], ref["b1"][hit]) and np.array_equal(got["b2"][hit], ref["b2"][hit])
+    assert 0.1 < (ref["num_contacts"] > 0).mean() < 0.9
