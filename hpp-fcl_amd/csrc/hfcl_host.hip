@@ -99,7 +99,18 @@ struct hfcl_lib {
   hipStream_t aux = nullptr;     // k_epa_records runs here, beside the tiers that continue the handed-over polytopes
   hipStream_t mesh_st = nullptr;  // the mesh walks of a mixed library's batch run here, beside the solids' kernels (option mesh_beside)
   hipEvent_t ev_mesh_fork = nullptr, ev_mesh_join = nullptr;
-  bool mesh_beside = true;
+  // ... the mesh x mesh walks of such a batch beside its mesh x solid walks (tables of their own: d_bvh2_*), and the helper stream the
+  // mesh x solid walks use instead of `aux` (which the solids' EPA section, now beside them, uses)
+  hipStream_t mesh_st2 = nullptr, mesh_aux = nullptr;
+  hipEvent_t ev_mesh_fork2 = nullptr, ev_mesh_join2 = nullptr;
+  BvhTask* d_bvh2_tasks = nullptr;
+  void* d_bvh2_sums = nullptr;
+  uint32_t* d_bvh2_susp = nullptr;
+  uint32_t* d_bvh2_ctr = nullptr;
+  size_t bvh2_split_n = 0, bvh2_split_cap = 0;
+  // 0 in line; 1 the mesh walks beside the solids' GJK kernels; 2 also mesh x mesh beside mesh x solid, the solids' EPA section beside both;
+  // 3 also the mesh x solid walks (the longest chain) launched in front of the mesh x mesh walks, their streams at high priority
+  uint32_t mesh_beside = 3;
   hipStream_t walk_st[WALK_ROUNDS - 1] = {};  // mesh x mesh collide(): the continuation of what round r of the walk hands over runs on walk_st[r]
   hipEvent_t walk_fork[WALK_ROUNDS - 1] = {}, walk_join[WALK_ROUNDS - 1] = {};
   hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr, ev_aux2 = nullptr, ev_aux3 = nullptr;  // fork / join of the EPA tail; of k_bvh_shape_finish's first half
@@ -537,7 +548,7 @@ static int apply_option(hfcl_lib* lib, const std::string& key, const char* v) {
   else if (key == "pool_rerun") lib->pool_rerun = u32(0);
   else if (key == "bvh_walk_early_coop") lib->walk_early_coop = on;
   else if (key == "bvh_walk_order") lib->walk_order = on;
-  else if (key == "mesh_beside") lib->mesh_beside = on;
+  else if (key == "mesh_beside") lib->mesh_beside = u32(0);
   else if (key == "bvh_walk_rounds") { lib->walk_rounds = uint32_t(std::min<long long>(std::max(0ll, i), WALK_ROUNDS)); lib->walk_auto = false; }
   else if (key == "bvh_walk_k") { parse_list(v, lib->walk_k, 0, WALK_ROUNDS, 1u, uint32_t(WALK_K)); lib->walk_auto = false; }  // "6,16": per round
   else if (key == "bvh_walk_budget") parse_list(v, lib->walk_budget, 1, WALK_ROUNDS, 0u, 0xFFFFFFFFu);  // rounds 1 ...: box tests (round 0 takes bvh_budget0_coop's)
@@ -631,8 +642,11 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_epa_ready_g);
   hipFree(lib->d_epa_cc_over);
   if (lib->mesh_st) hipStreamDestroy(lib->mesh_st);
-  if (lib->ev_mesh_fork) hipEventDestroy(lib->ev_mesh_fork);
-  if (lib->ev_mesh_join) hipEventDestroy(lib->ev_mesh_join);
+  if (lib->mesh_st2) hipStreamDestroy(lib->mesh_st2);
+  if (lib->mesh_aux) hipStreamDestroy(lib->mesh_aux);
+  for (hipEvent_t e : {lib->ev_mesh_fork, lib->ev_mesh_join, lib->ev_mesh_fork2, lib->ev_mesh_join2})
+    if (e) hipEventDestroy(e);
+  hipFree(lib->d_bvh2_tasks); hipFree(lib->d_bvh2_sums); hipFree(lib->d_bvh2_susp); hipFree(lib->d_bvh2_ctr);
   for (int k = 0; k < WALK_ROUNDS - 1; ++k) {
     if (lib->walk_st[k]) hipStreamDestroy(lib->walk_st[k]);
     if (lib->walk_fork[k]) hipEventDestroy(lib->walk_fork[k]);
@@ -1174,21 +1188,45 @@ static int ensure_aux(hfcl_lib* lib) {
   return HFCL_OK;
 }
 static int ensure_mesh_stream(hfcl_lib* lib) {
-  if (lib->mesh_st) return HFCL_OK;
-  hipStream_t s = nullptr;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&e0, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+  if (lib->mesh_st) return HFCL_OK;  // (committed last)
+  hipStream_t st[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  int prio_lo = 0, prio_hi = 0;
+  if (lib->mesh_beside >= 3) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  // (the mesh x solid walks are the longest chain of a mixed batch: their stream and its helper in front)
+  for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipStreamCreateWithPriority(&st[k], hipStreamNonBlocking, k == 1 ? 0 : prio_hi);
+  for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
   if (e != hipSuccess) {
-    if (e0) hipEventDestroy(e0);
-    if (e1) hipEventDestroy(e1);
-    if (s) hipStreamDestroy(s);
+    for (hipEvent_t x : ev)
+      if (x) hipEventDestroy(x);
+    for (hipStream_t x : st)
+      if (x) hipStreamDestroy(x);
     HIP_TRY(e);
   }
-  lib->ev_mesh_fork = e0;
-  lib->ev_mesh_join = e1;
-  lib->mesh_st = s;
+  lib->ev_mesh_fork = ev[0];
+  lib->ev_mesh_join = ev[1];
+  lib->ev_mesh_fork2 = ev[2];
+  lib->ev_mesh_join2 = ev[3];
+  lib->mesh_st2 = st[1];
+  lib->mesh_aux = st[2];
+  lib->mesh_st = st[0];
+  return HFCL_OK;
+}
+// the second set of split-traversal tables (what k_bvh_walk / k_bvh_resolve / k_bvh_coop use of them: tasks, summaries, suspended list,
+// counters): the mesh x mesh walks of a batch that also holds mesh x solid pairs run beside those on these
+static int ensure_bvh_split2(hfcl_lib* lib, size_t n) {
+  if (n <= lib->bvh2_split_n) return HFCL_OK;
+  hipFree(lib->d_bvh2_tasks); hipFree(lib->d_bvh2_sums); hipFree(lib->d_bvh2_susp);
+  lib->d_bvh2_tasks = nullptr; lib->d_bvh2_sums = nullptr; lib->d_bvh2_susp = nullptr;
+  lib->bvh2_split_n = 0;
+  const size_t nq = n + n / 8 + 1024, cap = 16 * nq + 65536;
+  HIP_TRY(hipMalloc(&lib->d_bvh2_tasks, cap * sizeof(BvhTask)));
+  HIP_TRY(hipMalloc(&lib->d_bvh2_sums, (nq + cap) * sizeof(BvhSum<double>)));
+  HIP_TRY(hipMalloc(&lib->d_bvh2_susp, nq * sizeof(uint32_t)));
+  if (!lib->d_bvh2_ctr) HIP_TRY(hipMalloc(&lib->d_bvh2_ctr, BVH_CTR_WORDS * sizeof(uint32_t)));
+  lib->bvh2_split_n = nq;
+  lib->bvh2_split_cap = cap;
   return HFCL_OK;
 }
 static int ensure_walk_streams(hfcl_lib* lib) {
@@ -1358,6 +1396,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     return HFCL_OK;
   };
   // the mesh walks of the batch
+  bool meshes_on_own_stream = false;
   auto launch_meshes = [&]() -> int {
     if (!lib->h_meshes.empty() && (may(B_BVH) || may(B_BVHSHAPE))) {
       // every BVH shape must name a registered model: checked on the host, the kernels index the mesh table with it
@@ -1384,19 +1423,19 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       if (rc) return rc;
       // long traversals are cut into tasks when the batch is large enough for the tail to matter and the request keeps no
       // query-wide contact count (mesh x mesh and the one-query-per-lane form of mesh x solid alike)
-      auto make_split = [&](BvhSplit& split, bool want, bool solid) -> int {
+      auto make_split = [&](BvhSplit& split, bool want, bool solid, bool own_tables = false) -> int {
         memset(&split, 0, sizeof(split));
         split.leaf_cost = lib->shape_leaf_cost;
         if (!(want && (solid ? lib->shape_levels : lib->bvh_levels) > 1 && lib->bvh_params.num_max_contacts == 1 && !lib->bvh_params.contacts)) return HFCL_OK;
-        int r = ensure_bvh_split(lib, n);
+        int r = own_tables ? ensure_bvh_split2(lib, n) : ensure_bvh_split(lib, n);
         if (r) return r;
-        HIP_TRY(hipMemsetAsync(lib->d_bvh_ctr, 0, BVH_CTR_WORDS * sizeof(uint32_t), st));
-        split.tasks = lib->d_bvh_tasks;
-        split.sums = lib->d_bvh_sums;
-        split.suspended = lib->d_bvh_susp;
-        split.ctr = lib->d_bvh_ctr;
-        split.cap = uint32_t(std::min<size_t>(lib->bvh_split_cap, 0x7FFFFFFFu));
-        split.n_queries = uint32_t(lib->bvh_split_n);
+        HIP_TRY(hipMemsetAsync(own_tables ? lib->d_bvh2_ctr : lib->d_bvh_ctr, 0, BVH_CTR_WORDS * sizeof(uint32_t), st));
+        split.tasks = own_tables ? lib->d_bvh2_tasks : lib->d_bvh_tasks;
+        split.sums = own_tables ? lib->d_bvh2_sums : lib->d_bvh_sums;
+        split.suspended = own_tables ? lib->d_bvh2_susp : lib->d_bvh_susp;
+        split.ctr = own_tables ? lib->d_bvh2_ctr : lib->d_bvh_ctr;
+        split.cap = uint32_t(std::min<size_t>(own_tables ? lib->bvh2_split_cap : lib->bvh_split_cap, 0x7FFFFFFFu));
+        split.n_queries = uint32_t(own_tables ? lib->bvh2_split_n : lib->bvh_split_n);
         split.budget = lib->bvh_budget;
         split.budget0 = lib->bvh_budget0;
         split.n_levels = lib->bvh_levels;
@@ -1406,7 +1445,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
           split.n_levels = BVH_MAX_LEVELS;
         }
         split.coop_grid = uint32_t(lib->n_cus) * 8u;
-        split.cut_ticks = solid ? lib->shape_cut_ticks : lib->bvh_cut_ticks;
+        split.cut_ticks = solid ? lib->shape_cut_ticks : (own_tables ? 0u : lib->bvh_cut_ticks);  // (the second set has no chunk tables)
         split.cut_cap = split.cap;
         // (mesh x solid: the EPA queue has room for one item per query and per chunk -- shape_defer_cap entries, sized before the walk)
         split.cut_task_cap = solid ? (wk.shape_defer_cap > n ? uint32_t(std::min<size_t>(wk.shape_defer_cap - n, split.cap)) : 0u) : split.cap;
@@ -1488,6 +1527,44 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         wk.shape_oq = lib->d_shape_oq;
       }
       if (q.mode == 1) {
+        // Both kinds of mesh pairs in the batch's library, and the mesh walks on streams of their own: the mesh x mesh walks (tables of
+        // their own) on a second one, beside the mesh x solid walks -- the two share nothing else, and each is a chain that leaves the chip
+        // half empty (cfgmix: 1.45 ms of mesh x mesh behind 2.3 ms of mesh x solid)
+        const bool mm_beside = meshes_on_own_stream && lib->mesh_beside >= 2 && may(B_BVH) && may(B_BVHSHAPE) && !spill.wide && !lib->bvh_cut_ticks && lib->bvh_coop && (lib->walk_auto || lib->walk_rounds != 0);
+        auto mesh_mesh = [&](bool own_tables) -> int {
+          tbeg("k_bvh_collide");
+          BvhSplit split;
+          rc = make_split(split, may(B_BVH) && !spill.wide && (n >= 256 || 2 * size_t(lib->bvh_max_depth) + 4 > size_t(std::min(BVH_STACK, BVH_STACK_FILT))), false, own_tables);
+          if (rc) return rc;
+          AsideStream beside[WALK_ROUNDS - 1];
+          memset(beside, 0, sizeof(beside));
+          const bool early = split.walk.recs && split.walk_rounds > 1 && lib->walk_early_coop;
+          if (early) {
+            rc = ensure_walk_streams(lib);
+            if (rc) return rc;
+            for (int k = 0; k < WALK_ROUNDS - 1; ++k) beside[k] = AsideStream{lib->walk_st[k], lib->walk_fork[k], lib->walk_join[k]};
+          }
+          launch_bvh_collide<T>(blocks_for(n, BVH_BLOCK), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance), split, spill, early ? beside : nullptr);
+          tend();
+          return HFCL_OK;
+        };
+        auto mesh_mesh_beside = [&]() -> int {
+          hipStream_t const ms = st;
+          st = lib->mesh_st2;
+          rc = mesh_mesh(true);
+          st = ms;
+          if (rc) return rc;
+          HIP_TRY(hipEventRecord(lib->ev_mesh_join2, lib->mesh_st2));
+          return HFCL_OK;
+        };
+        if (mm_beside) {
+          HIP_TRY(hipEventRecord(lib->ev_mesh_fork2, st));
+          HIP_TRY(hipStreamWaitEvent(lib->mesh_st2, lib->ev_mesh_fork2, 0));
+          if (lib->mesh_beside < 3) {
+            rc = mesh_mesh_beside();
+            if (rc) return rc;
+          }
+        }
         tbeg("k_bvh_shape");
         if (shape_fast) {
           // tasks re-start the leaf solver from the request's guess: a walk whose leaves hand the cached guess on, or whose
@@ -1499,7 +1576,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
           if (lib->shape_finish_aside && wk.shape_finish_over && split.tasks && split.coop && split.cut_ticks) {
             rc = ensure_aux(lib);
             if (rc) return rc;
-            aside = AsideStream{lib->aux, lib->ev_aux2, lib->ev_aux3};
+            aside = AsideStream{meshes_on_own_stream ? lib->mesh_aux : lib->aux, lib->ev_aux2, lib->ev_aux3};  // (`aux` is the solids' EPA section's, beside)
           }
           launch_bvh_shape_fast<T>(blocks_for(n, BVH_BLOCK), blocks_for(n / 8 + 1, 64 / BS_W), int(std::min<size_t>(n / 4 + 1, size_t(lib->n_cus) * 8)), st, wk, lv, bv, io, q, lib->bvh_params,
                                    T(lib->break_distance * lib->break_distance), split, spill, aside.stream ? &aside : nullptr);
@@ -1507,20 +1584,16 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
           launch_bvh_shape<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance));
         }
         tend();
-        tbeg("k_bvh_collide");
-        BvhSplit split;
-        rc = make_split(split, may(B_BVH) && !spill.wide && (n >= 256 || 2 * size_t(lib->bvh_max_depth) + 4 > size_t(std::min(BVH_STACK, BVH_STACK_FILT))), false);
-        if (rc) return rc;
-        AsideStream beside[WALK_ROUNDS - 1];
-        memset(beside, 0, sizeof(beside));
-        const bool early = split.walk.recs && split.walk_rounds > 1 && lib->walk_early_coop;
-        if (early) {
-          rc = ensure_walk_streams(lib);
+        if (mm_beside) {
+          if (lib->mesh_beside >= 3) {
+            rc = mesh_mesh_beside();
+            if (rc) return rc;
+          }
+          HIP_TRY(hipStreamWaitEvent(st, lib->ev_mesh_join2, 0));
+        } else {
+          rc = mesh_mesh(false);
           if (rc) return rc;
-          for (int k = 0; k < WALK_ROUNDS - 1; ++k) beside[k] = AsideStream{lib->walk_st[k], lib->walk_fork[k], lib->walk_join[k]};
         }
-        launch_bvh_collide<T>(blocks_for(n, BVH_BLOCK), st, wk, lv, bv, io, q, lib->bvh_params, T(lib->break_distance * lib->break_distance), split, spill, early ? beside : nullptr);
-        tend();
       } else {
         tbeg("k_bvh_shape_distance");
         if (shape_fast_d) {
@@ -1579,6 +1652,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     }
     return HFCL_OK;
   };
+  bool mesh_join_pending = false;
   // A library with meshes AND solids: the mesh walks on a stream of their own BESIDE the solids' kernels -- the walks are chains of dependent
   // steps that leave the chip half empty (section 3 item 6f), and every kernel of a bucket the library COULD fill is launched whether or not
   // this batch fills it (a mesh-only batch of a mixed library used to wait for ~0.08 ms of empty GJK launches in front of its walks).
@@ -1592,13 +1666,15 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       HIP_TRY(hipEventRecord(lib->ev_mesh_fork, caller));
       HIP_TRY(hipStreamWaitEvent(lib->mesh_st, lib->ev_mesh_fork, 0));
       st = lib->mesh_st;  // (the lambdas above launch on `st`)
+      meshes_on_own_stream = true;
       rc = launch_meshes();
       st = caller;
       if (rc) return rc;
       HIP_TRY(hipEventRecord(lib->ev_mesh_join, lib->mesh_st));
       rc = launch_solids();
       if (rc) return rc;
-      HIP_TRY(hipStreamWaitEvent(caller, lib->ev_mesh_join, 0));
+      if (lib->mesh_beside < 2) HIP_TRY(hipStreamWaitEvent(caller, lib->ev_mesh_join, 0));
+      else mesh_join_pending = true;  // (the solids' EPA section first: no mesh kernel feeds its queues; joined in front of the batch's last launches)
     } else {
       rc = launch_solids();
       if (rc) return rc;
@@ -1722,6 +1798,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
   }
   // last: a launch of a few waves that, between the GJK and the EPA kernels, only waited for a free CU while the other
   // half of a split batch had the chip (0.2 ms of this stream's timeline on cfg5)
+  if (mesh_join_pending) HIP_TRY(hipStreamWaitEvent(st, lib->ev_mesh_join, 0));
   tbeg("k_unsupported");
   if (may(B_UNSUPPORTED)) launch_unsupported<T>(blocks_for(n, 256 * 64), st, wk, io, int(B_UNSUPPORTED));
   if (lib->h_meshes.empty()) {  // BVH shapes without any registered mesh: flagged, never left unwritten
