@@ -706,7 +706,7 @@ enum { BVH_CTR_TASKS = 0, BVH_CTR_SUSPENDED = 1, BVH_CTR_LEVEL0 = 2 /* [2 + k] =
 constexpr int BVH_STACK_WALK = 48;  // k_bvh_walk's LDS stack (entries per lane) and its image in WalkRec
 constexpr int WALK_K = 16;       // most leaves a walk lists per round
 constexpr int WALK_ROUNDS = 4;   // most rounds
-enum { WALK_OVER = 1u, WALK_BUDGET = 2u };
+enum { WALK_OVER = 1u, WALK_BUDGET = 2u, WALK_LOST = 4u /* its items did not fit the list */, WALK_VOID = 8u /* mesh x solid: flagged unsupported by the walk, no record to write */ };
 template <typename T>
 struct WalkRec {  // one per query of the batch
   uint32_t pair, sp, n_leaf, flags;  // flags: the stack ran empty (WALK_OVER) / the step budget or the stack's capacity ended the round (WALK_BUDGET)
@@ -724,6 +724,9 @@ struct WalkArgs {
                       // [3] the suspended queries as round r left them (k_walk_snap), [4] the ticket of the launch that continues those round r added
   uint32_t* list_in;  // rec indices of this round's queries (round 0: the B_BVH bucket, rec index = position in the bucket's list)
   uint32_t* list_out;
+  uint32_t* redo;     // mesh x solid: the items (as in `items`) whose leaf ended its walk needing EPA; their number at ctr[8 r + 5], list_stride entries
+  uint32_t* perm;     // mesh x solid: the items ordered by the kind of their solid (item_cap entries, then list_stride for the redo list); nullptr: as listed
+  uint32_t* hist;     // ... [0..15] items per kind, [16..31] the scatter's cursors; [32..63] the same for the redo list (zeroed by the host)
   uint32_t round, k, budget, last;
   uint32_t item_cap, list_stride;  // entries of items / res; of one of the two lists list_in / list_out alternate between
 };

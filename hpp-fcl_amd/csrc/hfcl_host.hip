@@ -102,15 +102,17 @@ struct hfcl_lib {
   // ... the mesh x mesh walks of such a batch beside its mesh x solid walks (tables of their own: d_bvh2_*), and the helper stream the
   // mesh x solid walks use instead of `aux` (which the solids' EPA section, now beside them, uses)
   hipStream_t mesh_st2 = nullptr, mesh_aux = nullptr;
+  bool ran_batch = false;  // h_counts holds the bucket counts of this library's last batch (once its copy has landed)
   hipEvent_t ev_mesh_fork2 = nullptr, ev_mesh_join2 = nullptr;
   BvhTask* d_bvh2_tasks = nullptr;
   void* d_bvh2_sums = nullptr;
   uint32_t* d_bvh2_susp = nullptr;
   uint32_t* d_bvh2_ctr = nullptr;
   size_t bvh2_split_n = 0, bvh2_split_cap = 0;
-  // 0 in line; 1 the mesh walks beside the solids' GJK kernels; 2 also mesh x mesh beside mesh x solid, the solids' EPA section beside both;
-  // 3 also the mesh x solid walks (the longest chain) launched in front of the mesh x mesh walks, their streams at high priority
-  uint32_t mesh_beside = 3;
+  // 0 in line; 1 the mesh walks beside the solids' GJK kernels; 2 also mesh x mesh beside mesh x solid, the solids' EPA section beside both
+  // (1, 2: when the library's last batch held meshes and solids); 4: as 2 whatever the last batch held
+  uint32_t mesh_beside = 2;
+  bool mesh_prio = false;  // option mesh_prio = 1: the streams of the mesh x solid walks at the device's highest priority (read when they are created)
   hipStream_t walk_st[WALK_ROUNDS - 1] = {};  // mesh x mesh collide(): the continuation of what round r of the walk hands over runs on walk_st[r]
   hipEvent_t walk_fork[WALK_ROUNDS - 1] = {}, walk_join[WALK_ROUNDS - 1] = {};
   hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr, ev_aux2 = nullptr, ev_aux3 = nullptr;  // fork / join of the EPA tail; of k_bvh_shape_finish's first half
@@ -259,6 +261,17 @@ struct hfcl_lib {
   bool walk_order = true;            // option bvh_walk_order: the continuation launches draw the queries with the most stack entries first
   uint32_t* d_walk_ctr = nullptr;
   size_t walk_n = 0;
+  // ... of the mesh x solid walks (their own: the two kinds of walks of a mixed batch run beside each other); lists: [2 n] + the redo list [n]
+  void* d_swalk_recs = nullptr;
+  uint32_t* d_swalk_items = nullptr;
+  void* d_swalk_res = nullptr;
+  uint32_t* d_swalk_lists = nullptr;
+  uint32_t* d_swalk_ctr = nullptr;   // 8 words per round, then the 64 words of WalkArgs::hist
+  uint32_t* d_swalk_perm = nullptr;  // WalkArgs::perm
+  size_t swalk_n = 0;
+  bool shape_walk_sort = true;       // option shape_walk_sort = 0: the listed leaves evaluated in the order the walks listed them
+  bool shape_walk = true;            // option shape_walk = 0: the queries' own phase of mesh x solid collide() by k_bvh_collide's SOLID form (walk and leaves in one kernel)
+  uint32_t shape_walk_budget = 256;  // box tests a query's walk may take before k_bvh_shape_coop continues it
   size_t epa_resume_slots = 0, bvh_task_slots = 0;  // options epa_resume_slots / bvh_task_slots (0: sized by the batch)
   bool bvh_force_wide = false, pipe_trace = false;   // options bvh_force_wide / pipe_trace
   bool walk_early_coop = true;                               // HFCL_BVH_WALK_EARLY_COOP: the queries round 0 hands over are continued beside the later rounds
@@ -498,7 +511,7 @@ static const char* const* option_keys() {
       "closed_staged", "split", "epa_cc_staged", "epa_records_aside", "epa_general_staged", "shape_finish_tiers", "shape_finish_aside",
       "epa_general_staged_min", "epa64_two_streams", "epa_cc_staged_min", "pipe_chunk", "bvh_filter", "bvh_shape_lane", "shape_coop",
       "bvh_cut_ticks", "shape_cut_ticks", "bvh_coop", "bvhd_budget", "bvhd_pool", "shape_dist_pool", "pool_rerun", "bvh_walk_early_coop",
-      "bvh_walk_rounds", "bvh_walk_order", "mesh_beside", "bvh_walk_k", "bvh_walk_budget", "shape_dist_leaf_min", "shape_dist_starve", "bvhd_leaf_min", "bvhd_starve",
+      "bvh_walk_rounds", "bvh_walk_order", "mesh_beside", "mesh_prio", "shape_walk", "shape_walk_sort", "shape_walk_budget", "bvh_walk_k", "bvh_walk_budget", "shape_dist_leaf_min", "shape_dist_starve", "bvhd_leaf_min", "bvhd_starve",
       "bvhd_part_min", "shape_dist_budget", "bvh_budget0_coop", "shape_budget0", "shape_budget", "shape_leaf_cost", "shape_levels",
       "climb_min", "bvh_budget", "bvh_budget0", "bvh_levels", "cvx_w", "epa_resume_slots", "bvh_task_slots", "bvh_force_wide",
       "pipe_trace", nullptr};
@@ -549,6 +562,10 @@ static int apply_option(hfcl_lib* lib, const std::string& key, const char* v) {
   else if (key == "bvh_walk_early_coop") lib->walk_early_coop = on;
   else if (key == "bvh_walk_order") lib->walk_order = on;
   else if (key == "mesh_beside") lib->mesh_beside = u32(0);
+  else if (key == "shape_walk") lib->shape_walk = on;
+  else if (key == "mesh_prio") lib->mesh_prio = on;
+  else if (key == "shape_walk_sort") lib->shape_walk_sort = on;
+  else if (key == "shape_walk_budget") lib->shape_walk_budget = u32(0);
   else if (key == "bvh_walk_rounds") { lib->walk_rounds = uint32_t(std::min<long long>(std::max(0ll, i), WALK_ROUNDS)); lib->walk_auto = false; }
   else if (key == "bvh_walk_k") { parse_list(v, lib->walk_k, 0, WALK_ROUNDS, 1u, uint32_t(WALK_K)); lib->walk_auto = false; }  // "6,16": per round
   else if (key == "bvh_walk_budget") parse_list(v, lib->walk_budget, 1, WALK_ROUNDS, 0u, 0xFFFFFFFFu);  // rounds 1 ...: box tests (round 0 takes bvh_budget0_coop's)
@@ -707,6 +724,7 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   hipFree(lib->d_bvh_susp);
   hipFree(lib->d_bvh_ctr);
   hipFree(lib->d_walk_recs); hipFree(lib->d_walk_items); hipFree(lib->d_walk_res); hipFree(lib->d_walk_lists); hipFree(lib->d_walk_ctr); hipFree(lib->d_walk_order);
+  hipFree(lib->d_swalk_recs); hipFree(lib->d_swalk_items); hipFree(lib->d_swalk_res); hipFree(lib->d_swalk_lists); hipFree(lib->d_swalk_ctr); hipFree(lib->d_swalk_perm);
   for (auto& t : lib->timers) {
     hipEventDestroy(t.e0);
     hipEventDestroy(t.e1);
@@ -906,6 +924,22 @@ static int ensure_walk(hfcl_lib* lib, size_t n) {
   HIP_TRY(hipMalloc(&lib->d_walk_order, nq * sizeof(uint32_t)));
   if (!lib->d_walk_ctr) HIP_TRY(hipMalloc(&lib->d_walk_ctr, 8 * WALK_ROUNDS * sizeof(uint32_t)));
   lib->walk_n = nq;
+  return HFCL_OK;
+}
+
+static int ensure_swalk(hfcl_lib* lib, size_t n) {
+  if (n <= lib->swalk_n) return HFCL_OK;
+  hipFree(lib->d_swalk_recs); hipFree(lib->d_swalk_items); hipFree(lib->d_swalk_res); hipFree(lib->d_swalk_lists); hipFree(lib->d_swalk_perm);
+  lib->d_swalk_recs = nullptr; lib->d_swalk_items = nullptr; lib->d_swalk_res = nullptr; lib->d_swalk_lists = nullptr; lib->d_swalk_perm = nullptr;
+  lib->swalk_n = 0;
+  const size_t nq = n + n / 8 + 1024;
+  HIP_TRY(hipMalloc(&lib->d_swalk_recs, nq * sizeof(WalkRec<double>)));
+  HIP_TRY(hipMalloc(&lib->d_swalk_items, nq * WALK_K * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&lib->d_swalk_res, nq * WALK_K * 10 * sizeof(double)));  // TriLeafOut<double>: distance, p1, p2, n
+  HIP_TRY(hipMalloc(&lib->d_swalk_lists, 3 * nq * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&lib->d_swalk_perm, (nq * WALK_K + nq) * sizeof(uint32_t)));
+  if (!lib->d_swalk_ctr) HIP_TRY(hipMalloc(&lib->d_swalk_ctr, (8 * WALK_ROUNDS + 64) * sizeof(uint32_t)));
+  lib->swalk_n = nq;
   return HFCL_OK;
 }
 
@@ -1192,9 +1226,11 @@ static int ensure_mesh_stream(hfcl_lib* lib) {
   hipStream_t st[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipError_t e = hipSuccess;
+  // option mesh_prio: [0] the mesh x solid walks and [2] their helper at the device's highest priority -- hardware queues of their own (the runtime
+  // maps the streams of one priority onto four queues; two chains that share one run one after the other): cfgmix 2.90 -> 2.72 ms, but a process
+  // that has created them runs cfg4s's in-line batches 1 ms slower (3.7 against 2.65 ms; profiles/r06_g).  Off.
   int prio_lo = 0, prio_hi = 0;
-  if (lib->mesh_beside >= 3) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  // (the mesh x solid walks are the longest chain of a mixed batch: their stream and its helper in front)
+  if (lib->mesh_prio) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipStreamCreateWithPriority(&st[k], hipStreamNonBlocking, k == 1 ? 0 : prio_hi);
   for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -1483,6 +1519,26 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
           split.budget0 = lib->shape_coop ? lib->shape_budget0_coop : lib->shape_budget0;
           split.budget = lib->shape_budget;
           split.n_levels = lib->shape_levels;
+          // the queries' own phase as walk / leaves / resolve (one round; what is left of a walk is k_bvh_shape_coop's)
+          if (split.coop && lib->shape_walk && n < (size_t(1) << 28)) {
+            r = ensure_swalk(lib, n);
+            if (r) return r;
+            HIP_TRY(hipMemsetAsync(lib->d_swalk_ctr, 0, (8 * WALK_ROUNDS + 64) * sizeof(uint32_t), st));
+            split.walk.hist = lib->d_swalk_ctr + 8 * WALK_ROUNDS;
+            split.walk.perm = lib->shape_walk_sort ? lib->d_swalk_perm : nullptr;
+            split.walk.recs = lib->d_swalk_recs;
+            split.walk.items = lib->d_swalk_items;
+            split.walk.res = lib->d_swalk_res;
+            split.walk.ctr = lib->d_swalk_ctr;
+            split.walk.list_in = lib->d_swalk_lists;
+            split.walk.list_out = lib->d_swalk_lists;
+            split.walk.redo = lib->d_swalk_lists + 2 * lib->swalk_n;
+            split.walk.item_cap = uint32_t(std::min<size_t>(lib->swalk_n * WALK_K, 0xFFFFFFFFu));
+            split.walk.list_stride = uint32_t(lib->swalk_n);
+            split.walk_rounds = 1u;
+            split.walk_k[0] = uint32_t(WALK_K);
+            split.walk_budget[0] = lib->shape_walk_budget;
+          }
         }
         return HFCL_OK;
       };
@@ -1560,10 +1616,8 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         if (mm_beside) {
           HIP_TRY(hipEventRecord(lib->ev_mesh_fork2, st));
           HIP_TRY(hipStreamWaitEvent(lib->mesh_st2, lib->ev_mesh_fork2, 0));
-          if (lib->mesh_beside < 3) {
-            rc = mesh_mesh_beside();
-            if (rc) return rc;
-          }
+          rc = mesh_mesh_beside();
+          if (rc) return rc;
         }
         tbeg("k_bvh_shape");
         if (shape_fast) {
@@ -1585,10 +1639,6 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
         }
         tend();
         if (mm_beside) {
-          if (lib->mesh_beside >= 3) {
-            rc = mesh_mesh_beside();
-            if (rc) return rc;
-          }
           HIP_TRY(hipStreamWaitEvent(st, lib->ev_mesh_join2, 0));
         } else {
           rc = mesh_mesh(false);
@@ -1660,6 +1710,15 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     const bool any_mesh = !lib->h_meshes.empty() && (may(B_BVH) || may(B_BVHSHAPE));
     const bool any_solid = may(B_CLOSED) || any_gjk || may(B_TRI);
     bool beside = any_mesh && any_solid && lib->mesh_beside;
+    // ... when the batch holds both: a batch of mesh pairs alone pays for the solids' empty launches when they stand BESIDE its walks (grids sized
+    // for the batch, every block waiting for a wave slot of a full chip: cfg4s 2.67 -> 2.80 ms) and nothing when they stand in front of them
+    // (4 us each on an empty chip).  The witness is the library's batch before this one (its bucket counts, read without waiting for them:
+    // they only choose between two orders of the same launches); the first batch runs beside.
+    if (beside && lib->mesh_beside < 4 && lib->ran_batch && lib->h_counts) {
+      uint32_t solids_before = 0, meshes_before = one_count(lib->h_counts, int(B_BVH)) + one_count(lib->h_counts, int(B_BVHSHAPE));
+      for (int b : {int(B_CLOSED), int(B_PRIM), int(B_CC), int(B_PC), int(B_CP), int(B_LARGE), int(B_TRI)}) solids_before += one_count(lib->h_counts, b);
+      if (!solids_before || !meshes_before) beside = false;
+    }
     if (beside && ensure_mesh_stream(lib) != HFCL_OK) beside = false;  // (no helper stream: one after the other, as before)
     if (beside) {
       hipStream_t const caller = st;
@@ -1807,6 +1866,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
   }
   tend();
   HIP_TRY(hipMemcpyAsync(lib->counts_dst ? lib->counts_dst : lib->h_counts, lib->d_counts, N_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  lib->ran_batch = lib->counts_dst == nullptr;
   HIP_TRY(hipGetLastError());
   return HFCL_OK;
 }
@@ -2664,6 +2724,21 @@ void hfcl_lib_set_split(hfcl_lib* lib, int parts) {
   if (lib) lib->split = parts >= 2 ? 2 : (parts == 1 ? 1 : 0);
 }
 int hfcl_lib_get_split(const hfcl_lib* lib) { return lib ? lib->split : 0; }
+// (diagnostic, not part of the ABI: the counters of the last batch's walk rounds -- WalkArgs::ctr, 8 words per round -- of the mesh x mesh (solid = 0) or the
+// mesh x solid walks, and BVH_CTR_TASKS / BVH_CTR_SUSPENDED of their split tables behind them: tools/dbg/walk_counters.py)
+extern "C" int hfcl_debug_walk_counters(hfcl_lib* lib, int solid, uint32_t* out34) {
+  if (!lib || !out34) return HFCL_ERR_INVALID_ARGUMENT;
+  if (hipSetDevice(lib->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return HFCL_ERR_HIP;
+  memset(out34, 0, 34 * sizeof(uint32_t));
+  const uint32_t* src = solid ? lib->d_swalk_ctr : lib->d_walk_ctr;
+  if (src && hipMemcpy(out34, src, 8 * WALK_ROUNDS * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return HFCL_ERR_HIP;
+  uint32_t ctr[BVH_CTR_WORDS] = {0};
+  const uint32_t* bsrc = (!solid && lib->d_bvh2_ctr && lib->mesh_st2) ? lib->d_bvh_ctr : lib->d_bvh_ctr;
+  if (bsrc && hipMemcpy(ctr, bsrc, sizeof(ctr), hipMemcpyDeviceToHost) != hipSuccess) return HFCL_ERR_HIP;
+  out34[32] = ctr[BVH_CTR_TASKS];
+  out34[33] = ctr[BVH_CTR_SUSPENDED];
+  return HFCL_OK;
+}
 // pairs per chunk of the host-buffer pipeline (0 = automatic: n/8 clamped to 32k .. 256k)
 void hfcl_lib_set_host_chunk(hfcl_lib* lib, size_t pairs) {
   if (lib) lib->pipe_chunk = pairs;

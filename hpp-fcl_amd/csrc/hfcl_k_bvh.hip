@@ -2851,7 +2851,7 @@ k_bvh_shape_distance_pool(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QPar
 }
 
 
-#if HFCL_BVH_MESH_PART
+#if HFCL_BVH_MESH_PART || HFCL_BVH_SOLID_PART
 // ---------------------------------------------------------------------------------------
 // Mesh x mesh collide() in rounds of three kernels (hfcl_dev.hpp: WalkRec): the walk without its leaves, the leaves without a walk, the
 // replay of each query's events in the reference's order.
@@ -2871,6 +2871,8 @@ __device__ __forceinline__ uint32_t wave_reserve(uint32_t* counter, uint32_t cou
   base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
   return base + incl - (active ? count : 0u);
 }
+// the distance k_shape_leaves files for a leaf that needs EPA (no leaf is that far inside anything)
+template <typename T> __device__ __forceinline__ T walk_leaf_epa() { return -Lim<T>::max(); }
 #ifndef HFCL_WPE_BVH_WALK
 #define HFCL_WPE_BVH_WALK 2
 #endif
@@ -2880,7 +2882,9 @@ __device__ __forceinline__ uint32_t wave_reserve(uint32_t* counter, uint32_t cou
 // k_bvh_walk: collisionRecurse (src/traversal/traversal_recurse.cpp:44-85) with the triangle pairs LISTED instead of tested, one query
 // per lane, lanes refilled from a ticket as in k_bvh_collide.  A disjoint box pair only ever enters the walk's state through a
 // minimum (updateDistanceLowerBoundFromBV), so the boxes between two leaves leave one number: the smallest bound among them.
-template <typename T>
+// SOLID (mesh x solid, its own instantiation in its own part of this unit): one tree -- the entry is the mesh node, the other box is the
+// solid's (k_shape_obb's ObbQuery, kept where the mesh x mesh walk keeps the relative pose), a leaf is a triangle against the solid.
+template <typename T, bool SOLID = false>
 __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(HFCL_WPE_BVH_WALK, 8)))
 k_bvh_walk(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, T break_distance2, WalkArgs wa) {
   typedef BvhEntry<false> EN;
@@ -2888,9 +2892,10 @@ k_bvh_walk(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, T bre
   __shared__ uint32_t stack[STACK][BVH_BLOCK];
   WalkRec<T>* const recs = reinterpret_cast<WalkRec<T>*>(wa.recs);
   uint32_t* const c = wa.ctr + 8 * wa.round;
-  const uint32_t cnt = wa.round ? wa.ctr[8 * (wa.round - 1) + 2] : wk.counts[B_BVH];
+  const uint32_t cnt = wa.round ? wa.ctr[8 * (wa.round - 1) + 2] : wk.counts[SOLID ? B_BVHSHAPE : B_BVH];
   if (cnt == 0u) return;  // (a batch without mesh x mesh pairs: not one ticket drawn -- 1 500 same-address atomics are 30 us)
   const int tid = threadIdx.x, lane = tid & 63;
+  V3<T> q_ext = mk<T>(T(0), T(0), T(0));  // SOLID: RT_R / RT_T hold the ObbQuery's M / V, q_ext its extent
   const T big = Lim<T>::max(), nanv = Lim<T>::nan();
   bool live = false, pending = false, exhausted = false;  // exhausted is wave-uniform
   uint32_t ri = 0, steps = 0, n_leaf = 0, flags = 0, noff1 = 0, noff2 = 0;
@@ -2923,7 +2928,7 @@ k_bvh_walk(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, T bre
           const bool fits = first + n_leaf <= wa.item_cap;  // (the host sizes the list for WALK_K items per query: always)
           r->sp = uint32_t(sp);
           r->n_leaf = fits ? n_leaf : 0u;
-          r->flags = fits ? flags : (flags | 4u);
+          r->flags = fits ? flags : (flags | WALK_LOST);
           r->first_item = first;
           r->pre[n_leaf] = pre_cur;
           for (int k = 0; k < sp; ++k) r->stack[k] = stack[k][tid];
@@ -2949,7 +2954,7 @@ k_bvh_walk(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, T bre
             for (int k = 0; k < sp; ++k) stack[k][tid] = r->stack[k];
           } else {
             ri = it;
-            pair = wk.lists[size_t(B_BVH) * wk.n + it];
+            pair = wk.lists[size_t(SOLID ? B_BVHSHAPE : B_BVH) * wk.n + it];
             WalkRec<T>* const r = recs + ri;
             r->pair = pair;
             r->dlb = r->rec_dist = r->cand_val = big;
@@ -2957,11 +2962,32 @@ k_bvh_walk(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, T bre
             stack[0][tid] = 0u;  // (b1 = 0, b2 = 0)
             sp = 1;
           }
+          bool valid = true;
+          if constexpr (SOLID) {
+            const uint32_t sid1 = wk.shape1[pair], sid2 = wk.shape2[pair];
+            const bool swapped = lib.kinds[sid1] != uint8_t(K_BVH);  // (shape, BVH): collide(o2, o1) then swapObjects (collision.cpp:93-108)
+            noff1 = bv.meshes[lib.shapes[swapped ? sid2 : sid1].bvh_index].node_off;
+            const ObbQuery<T> oq = reinterpret_cast<const ObbQuery<T>*>(wk.shape_oq)[pair];
+            if (!(oq.ext.x == oq.ext.x)) {  // k_shape_obb: no OBB for this solid (k_bvh_collide's SOLID form flags the pair the same way)
+              valid = false;
+              store_unsupported(io, pair);
+              WalkRec<T>* const r = recs + ri;
+              r->sp = 0u;
+              r->n_leaf = 0u;
+              r->flags = WALK_VOID;
+              r->first_item = 0u;
+              sp = 0;
+            }
+            RT_R = oq.M;
+            RT_T = oq.V;
+            q_ext = oq.ext;
+          } else {
           noff1 = bv.meshes[lib.shapes[wk.shape1[pair]].bvh_index].node_off;
           noff2 = bv.meshes[lib.shapes[wk.shape2[pair]].bvh_index].node_off;
           const Pose<T> tf1 = load_pose(io.tf1, pair), tf2 = load_pose(io.tf2, pair);
           RT_R = tmul(tf1.R, tf2.R);  // traversal_node_setup.h:560-563
           RT_T = tmul(tf1.R, tf2.t - tf1.t);
+          }
           steps = 0;
           n_leaf = 0;
           flags = 0;
@@ -2969,7 +2995,7 @@ k_bvh_walk(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, T bre
 #if HFCL_WALK_NODE_CACHE
           id1 = id2 = 0xFFFFFFFFu;
 #endif
-          live = true;
+          live = valid;
         }
       }
       if (base + uint32_t(n_need) >= cnt) exhausted = true;
@@ -2987,6 +3013,42 @@ k_bvh_walk(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, T bre
       }
       ++steps;
       const uint32_t e = stack[--sp][tid];
+      if constexpr (SOLID) {
+        const DNode<T>* const np = bv.nodes + noff1 + e;
+        const int32_t fc = np->first_child;
+        if (fc < 0) {
+          WalkRec<T>* const r = recs + ri;
+          r->leaf1[n_leaf] = uint32_t(-(fc + 1));
+          r->pre[n_leaf] = pre_cur;
+          pre_cur = big;
+          ++n_leaf;
+          continue;
+        }
+        const DNode<T> nd1 = *np;
+#if HFCL_BVH_PREFETCH
+        const int32_t touched = np[fc - int32_t(e)].first_child;  // the node popped next if the boxes overlap
+#endif
+        ObbQuery<T> oq;
+        oq.M = RT_R;
+        oq.V = RT_T;
+        oq.ext = q_ext;
+        T sq;
+        const bool disjoint = obb_disjoint_q(oq, nd1, q.security_margin, break_distance2, sq);
+#if HFCL_BVH_PREFETCH
+        asm volatile("" ::"v"(touched));
+#endif
+        if (disjoint) {
+          const T nd = hsqrt(sq);
+          if (nd < pre_cur) pre_cur = nd;
+        } else if (sp + 2 > STACK) {
+          stack[sp++][tid] = e;  // (a tree deeper than the stack: the rest of the walk is k_bvh_shape_coop's)
+          flags = WALK_BUDGET;
+        } else {
+          stack[sp++][tid] = uint32_t(fc) + 1u;  // second child below
+          stack[sp++][tid] = uint32_t(fc);       // first child on top
+        }
+        continue;
+      }
       const uint32_t b1 = EN::first(e), b2 = EN::second(e);
 #if HFCL_WALK_NODE_CACHE
       // the pair popped behind a box test shares a node with the pair tested (its child pair or its sibling): that record stays in registers
@@ -3050,6 +3112,98 @@ k_bvh_walk(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, T bre
 
 // k_tri_leaves: every triangle pair the round's walks listed, one per lane (leafCollides' distance, traversal_node_bvhs.h:184-233,
 // through the same tri_leaf_call as k_bvh_coop: one machine code for the leaf, whoever asks).
+#if HFCL_BVH_SOLID_PART
+// k_shape_leaves: the same for mesh x solid -- every triangle the round's walks listed against its solid, one per lane, through the
+// solid_leaf_call of k_bvh_collide's SOLID form (internal/traversal_node_bvh_shape.h:139-188).  A leaf whose GJK ends inside the solid
+// (it needs EPA: a contact whatever EPA finds, mesh_shape_lane_request) is marked by its distance (WALK_LEAF_EPA) -- nothing else of it is
+// read --; redo = 1: the leaves k_bvh_resolve found to END their walks that way (wa.redo, their number at ctr[5]) once more, this time with
+// the EPA item queued for k_bvh_shape_finish (as k_bvh_shape_coop does with the leaf that ends a walk of its own).
+// The listed leaves ordered by the kind of their solid (WalkArgs::perm: position -> item), so that the 64 leaves of a wave of k_shape_leaves run ONE
+// support function: in the order the walks listed them a wave held all six kinds of cfg4s and ran their GJK loops one after the other (953 waves:
+// 440 us; profiles/r06_g).  Two launches: the kinds and their histogram (hist[16], zeroed by the host), then the scatter (cursor = hist + 16).
+template <typename T>
+__device__ __forceinline__ uint32_t item_kind(const Work& wk, const LibView<T>& lib, const WalkRec<T>* recs, uint32_t code) {
+  const uint32_t pair = recs[code & 0x0FFFFFFFu].pair;
+  const uint32_t id1 = wk.shape1[pair], id2 = wk.shape2[pair];
+  const uint32_t k1 = lib.kinds[id1];
+  return (k1 != uint32_t(K_BVH) ? k1 : uint32_t(lib.kinds[id2])) & 15u;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_item_kinds(Work wk, LibView<T> lib, WalkArgs wa, int redo) {
+  __shared__ uint32_t h[16];
+  const WalkRec<T>* const recs = reinterpret_cast<const WalkRec<T>*>(wa.recs);
+  const uint32_t n_items = redo ? min(wa.ctr[8 * wa.round + 5], wa.list_stride) : min(wa.ctr[8 * wa.round + 1], wa.item_cap);
+  uint32_t* const hist = wa.hist + (redo ? 32 : 0);
+  if (threadIdx.x < 16) h[threadIdx.x] = 0u;
+  __syncthreads();
+  for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < n_items; it += gridDim.x * 256u) atomicAdd(&h[item_kind(wk, lib, recs, redo ? wa.redo[it] : wa.items[it])], 1u);
+  __syncthreads();
+  if (threadIdx.x < 16 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_item_scatter(Work wk, LibView<T> lib, WalkArgs wa, int redo) {
+  __shared__ uint32_t h[16], base[16];
+  const WalkRec<T>* const recs = reinterpret_cast<const WalkRec<T>*>(wa.recs);
+  const uint32_t n_items = redo ? min(wa.ctr[8 * wa.round + 5], wa.list_stride) : min(wa.ctr[8 * wa.round + 1], wa.item_cap);
+  uint32_t* const hist = wa.hist + (redo ? 32 : 0);
+  uint32_t* const cursor = hist + 16;
+  uint32_t* const perm = redo ? wa.perm + wa.item_cap : wa.perm;
+  for (uint32_t it0 = blockIdx.x * 256u; it0 < n_items; it0 += gridDim.x * 256u) {
+    if (threadIdx.x < 16) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t it = it0 + threadIdx.x;
+    uint32_t kind = 0, rank = 0;
+    if (it < n_items) {
+      kind = item_kind(wk, lib, recs, redo ? wa.redo[it] : wa.items[it]);
+      rank = atomicAdd(&h[kind], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      uint32_t start = 0;
+      for (uint32_t k = 0; k < threadIdx.x; ++k) start += hist[k];
+      base[threadIdx.x] = start + (h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0u);
+    }
+    __syncthreads();
+    if (it < n_items) perm[base[kind] + rank] = it;
+    __syncthreads();
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
+k_shape_leaves(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, WalkArgs wa, int redo) {
+  __shared__ T w0_slab[W0Lds<T, 64>::WORDS];
+  const W0Lds<T, 64> leaf_ps{w0_slab + threadIdx.x};
+  const WalkRec<T>* const recs = reinterpret_cast<const WalkRec<T>*>(wa.recs);
+  TriLeafOut<T>* const res = reinterpret_cast<TriLeafOut<T>*>(wa.res);
+  const uint32_t n_items = redo ? min(wa.ctr[8 * wa.round + 5], wa.list_stride) : min(wa.ctr[8 * wa.round + 1], wa.item_cap);
+  for (uint32_t base = blockIdx.x * 64u; base < n_items; base += gridDim.x * 64u) {
+    if (base + threadIdx.x < n_items) {
+      const uint32_t it = wa.perm ? (redo ? wa.perm + wa.item_cap : wa.perm)[base + threadIdx.x] : base + threadIdx.x;
+      const uint32_t item = redo ? wa.redo[it] : wa.items[it];
+      const WalkRec<T>* const r = recs + (item & 0x0FFFFFFFu);
+      const uint32_t s2 = item >> 28, pair = r->pair, prim = r->leaf1[s2];
+      const uint32_t id1 = wk.shape1[pair], id2 = wk.shape2[pair];
+      const bool swapped = lib.kinds[id1] != uint8_t(K_BVH);
+      const uint32_t solid_id = swapped ? id1 : id2;
+      const DMesh m1 = bv.meshes[lib.shapes[swapped ? id2 : id1].bvh_index];
+      SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + prim), lib.shapes, lib.verts, swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2,
+                        redo ? reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer) : nullptr, &wk.counts[CTR_SHAPE_DEFER], wk.shape_defer_cap, pair, solid_id, prim, 0xFFFFFFFFu, 0u,
+                        T(0), -1};
+      SolidLeafOut<T> lo;
+      const bool to_epa = solid_leaf_call<T>(in, &q, leaf_ps, initial_guess<T>(io, q, pair), &lo);  // (split walks start every leaf from the request's guess)
+      if (!redo) {
+        TriLeafOut<T> tlo;
+        tlo.distance = to_epa ? walk_leaf_epa<T>() : lo.distance;
+        tlo.p1 = lo.p1;
+        tlo.p2 = lo.p2;
+        tlo.n = lo.n;
+        res[it] = tlo;
+      }
+    }
+  }
+}
+#endif
+#if HFCL_BVH_MESH_PART
 template <typename T>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 k_tri_leaves(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, WalkArgs wa) {
@@ -3072,6 +3226,7 @@ k_tri_leaves(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, Wal
     }
   }
 }
+#endif
 
 // The suspended queries as round `round` left them (the launch of k_bvh_coop that runs beside the later rounds continues those this round
 // added), and the order its waves draw them in: by the stack entries a query still holds, most first (BvhSplit::order; counting sort by
@@ -3106,25 +3261,29 @@ __global__ void __launch_bounds__(1024) k_walk_order(BvhSplit split, uint32_t ro
 // updateDistanceLowerBoundFromBV), the leaf (updateDistanceLowerBoundFromLeaf, the witness of the last one that lowered the bound, the
 // contact that ends the walk: whatever the walk listed behind it is void) -- and where the query goes from here: its record, the next
 // round, or k_bvh_coop (a suspended query with its stack as tasks, exactly what k_bvh_collide's suspension leaves).
-template <typename T>
-__global__ void __launch_bounds__(256) k_bvh_resolve(Work wk, IO<T> io, QParams<T> q, BvhSplit split, WalkArgs wa) {
+// SOLID: the leaf is a triangle against the solid (fb1 / fb2 and the witness in the caller's operand order: collision.cpp:93-108), a leaf that
+// needs EPA ends the walk as a contact whose numbers k_bvh_shape_finish writes: it goes on the redo list (k_shape_leaves, redo = 1).
+template <typename T, bool SOLID = false>
+__global__ void __launch_bounds__(256) k_bvh_resolve(Work wk, LibView<T> lib, IO<T> io, QParams<T> q, BvhSplit split, WalkArgs wa) {
   WalkRec<T>* const recs = reinterpret_cast<WalkRec<T>*>(wa.recs);
   const TriLeafOut<T>* const res = reinterpret_cast<const TriLeafOut<T>*>(wa.res);
   uint32_t* const c = wa.ctr + 8 * wa.round;
-  const uint32_t cnt = wa.round ? wa.ctr[8 * (wa.round - 1) + 2] : wk.counts[B_BVH];
+  const uint32_t cnt = wa.round ? wa.ctr[8 * (wa.round - 1) + 2] : wk.counts[SOLID ? B_BVHSHAPE : B_BVH];
   for (uint32_t base = blockIdx.x * blockDim.x; base < cnt; base += gridDim.x * blockDim.x) {
     const uint32_t it = base + threadIdx.x;
     const bool valid = it < cnt;
-    uint32_t ri = 0, pair = 0, sp = 0;
-    bool next = false, coop = false, lost = false;
+    uint32_t ri = 0, pair = 0, sp = 0, redo_item = 0;
+    bool next = false, coop = false, lost = false, redo = false;
     WalkRec<T>* r = recs;
     T dlb = T(0), rec_dist = T(0), cand_val = T(0);
-    if (valid) {
+    if (valid && !(SOLID && (recs[wa.round ? wa.list_in[it] : it].flags & WALK_VOID))) {
       ri = wa.round ? wa.list_in[it] : it;
       r = recs + ri;
       pair = r->pair;
       sp = r->sp;
       const uint32_t n_leaf = r->n_leaf, flags = r->flags;
+      bool swapped = false;
+      if constexpr (SOLID) swapped = lib.kinds[wk.shape1[pair]] != uint8_t(K_BVH);
       dlb = r->dlb;
       rec_dist = r->rec_dist;
       cand_val = r->cand_val;
@@ -3139,6 +3298,14 @@ __global__ void __launch_bounds__(256) k_bvh_resolve(Work wk, IO<T> io, QParams<
       for (uint32_t s2 = 0; s2 < n_leaf; ++s2) {
         boxes(r->pre[s2]);
         const T distance = res[r->first_item + s2].distance;
+        if (SOLID && distance == walk_leaf_epa<T>()) {  // canStop(): the bound and its witness stay as they are (k_bvh_collide's SOLID form)
+          contact = true;
+          redo = true;
+          redo_item = ri | (s2 << 28);
+          fb1 = swapped ? -1 : int(r->leaf1[s2]);
+          fb2 = swapped ? int(r->leaf1[s2]) : -1;
+          break;
+        }
         const T dtc = distance - q.security_margin;
         if (dtc < dlb) {  // updateDistanceLowerBoundFromLeaf
           dlb = dtc;
@@ -3148,17 +3315,20 @@ __global__ void __launch_bounds__(256) k_bvh_resolve(Work wk, IO<T> io, QParams<
         }
         if (dtc <= q.collision_distance_threshold) {  // the first contact: canStop()
           contact = true;
-          fb1 = int(r->leaf1[s2]);
-          fb2 = int(r->leaf2[s2]);
+          fb1 = SOLID ? (swapped ? -1 : int(r->leaf1[s2])) : int(r->leaf1[s2]);
+          fb2 = SOLID ? (swapped ? int(r->leaf1[s2]) : -1) : int(r->leaf2[s2]);
           break;
         }
       }
       if (!contact) boxes(r->pre[n_leaf]);
       if (wit >= 0) {
         const TriLeafOut<T> w = res[r->first_item + uint32_t(wit)];
-        store_witness(io, pair, w.p1, w.p2, w.n);
+        if (SOLID && swapped)
+          store_witness(io, pair, w.p2, w.p1, -w.n);
+        else
+          store_witness(io, pair, w.p1, w.p2, w.n);
       }
-      lost = (flags & 4u) != 0u;  // (its items did not fit the list)
+      lost = (flags & WALK_LOST) != 0u;  // (its items did not fit the list)
       if (contact || (flags & WALK_OVER) || lost) {
         store_bvh_record_head(io, pair, rec_dist, contact ? 1u : 0u, fb1, fb2, lost);
       } else if (!wa.last && !(flags & WALK_BUDGET)) {
@@ -3176,6 +3346,10 @@ __global__ void __launch_bounds__(256) k_bvh_resolve(Work wk, IO<T> io, QParams<
     {
       const uint32_t slot = wave_reserve(&c[2], 1u, next);
       if (next) wa.list_out[slot] = ri;
+    }
+    if constexpr (SOLID) {  // ---- the leaves that ended their walks needing EPA
+      const uint32_t slot = wave_reserve(&c[5], 1u, redo);
+      if (redo && slot < wa.list_stride) wa.redo[slot] = redo_item;
     }
     // ---- the queries k_bvh_coop continues: a suspended query (its state a summary) whose stack entries are its tasks, top first
     if (__ballot(coop)) {
@@ -3327,7 +3501,7 @@ static void bvh_collide_levels(int grid, hipStream_t st, const Work& wk, const L
         wa.list_in = lists + size_t((r + 1u) & 1u) * wa.list_stride;  // (= the list_out of round r - 1; not read in round 0)
         hipLaunchKernelGGL((k_bvh_walk<T>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, break_distance2, wa);
         hipLaunchKernelGGL((k_tri_leaves<T>), dim3(lgrid), dim3(64), 0, st, wk, lv, bv, io, q, wa);
-        hipLaunchKernelGGL((k_bvh_resolve<T>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, io, q, s0, wa);
+        hipLaunchKernelGGL((k_bvh_resolve<T>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, lv, io, q, s0, wa);
       }
     } else {
       launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s0, spill, false);
@@ -3408,7 +3582,32 @@ void launch_bvh_shape_fast(int grid, int grid_finish, int coop_grid, hipStream_t
     s0.level = 0;
     s0.budget = split.budget0;
     s0.can_suspend = 1;
-    launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s0, spill, true);
+    if (split.walk.recs && split.walk_rounds) {
+      // the queries' own phase as walk (its leaves listed) / leaves (one per lane, dense) / resolve (hfcl_dev.hpp: WalkRec), as mesh x mesh;
+      // then the leaves that ended a walk needing EPA once more, for their items
+      WalkArgs wa = split.walk;
+      wa.round = 0;
+      wa.k = std::min<uint32_t>(split.walk_k[0], uint32_t(WALK_K));
+      wa.budget = split.walk_budget[0];
+      wa.last = 1u;
+      wa.list_out = wa.list_in + wa.list_stride;
+      const int lgrid = std::max(1, std::min(grid * 2, 2048));
+      const int sgrid = std::max(1, std::min(grid, 512));
+      hipLaunchKernelGGL((k_bvh_walk<T, true>), dim3(grid), dim3(BVH_BLOCK), 0, st, wk, lv, bv, io, q, break_distance2, wa);
+      if (wa.perm) {
+        hipLaunchKernelGGL((k_item_kinds<T>), dim3(sgrid), dim3(256), 0, st, wk, lv, wa, 0);
+        hipLaunchKernelGGL((k_item_scatter<T>), dim3(sgrid), dim3(256), 0, st, wk, lv, wa, 0);
+      }
+      hipLaunchKernelGGL((k_shape_leaves<T>), dim3(lgrid), dim3(64), 0, st, wk, lv, bv, io, q, wa, 0);
+      hipLaunchKernelGGL((k_bvh_resolve<T, true>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, lv, io, q, s0, wa);
+      if (wa.perm) {
+        hipLaunchKernelGGL((k_item_kinds<T>), dim3(std::max(1, sgrid / 8)), dim3(256), 0, st, wk, lv, wa, 1);
+        hipLaunchKernelGGL((k_item_scatter<T>), dim3(std::max(1, sgrid / 8)), dim3(256), 0, st, wk, lv, wa, 1);
+      }
+      hipLaunchKernelGGL((k_shape_leaves<T>), dim3(lgrid), dim3(64), 0, st, wk, lv, bv, io, q, wa, 1);
+    } else {
+      launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s0, spill, true);
+    }
     // (the EPA item of a chunk that stands behind another chunk's contact is skipped: bvh_moot over the summaries; items of whole walks
     // hang under no summary)
     BvhSplit fin = s0;

@@ -679,9 +679,9 @@ def test_gpu_mesh_vs_flats(pkg, oracle):
 @pytest.mark.gpu
 def test_gpu_mixed_scene_beside_equals_in_line(pkg, oracle):
     """A batch with solid x solid, mesh x solid (both operand orders) and mesh x mesh pairs on cfg4-size models (workloads.mixed_scene, bench.py's
-    cfgmix row): the mesh walks on streams of their own beside the solids' kernels (option mesh_beside: 2 also runs the mesh x mesh walks
-    beside the mesh x solid walks on tables of their own and the solids' EPA section beside both; 3, the default, adds launch order and stream
-    priorities; 1 only forks the mesh walks) give byte for
+    cfgmix row): the mesh walks on streams of their own beside the solids' kernels (option mesh_beside: 2, the default, also runs the mesh x mesh
+    walks beside the mesh x solid walks on tables of their own and the solids' EPA section beside both -- when the library's batch before held
+    both kinds; 4 whatever it held; 1 only forks the mesh walks) give byte for
     byte the records of the in-line order, twice, and all equal the oracle's decisions (contact flags, first-contact triangle ids); distance()
     over the same batch likewise."""
     abi, wl, bb = pkg.abi, pkg.workloads, pkg.bvh_builder
@@ -690,7 +690,7 @@ def test_gpu_mixed_scene_beside_equals_in_line(pkg, oracle):
     req = abi.default_collision_request()
     dreq = abi.default_distance_request()
     recs, drecs = {}, {}
-    for beside in (3, 2, 1, 0):
+    for beside in (4, 2, 1, 0):
         lib = wl.make_library(pkg, b, options={"mesh_beside": beside})
         try:
             first = lib.collide(b.s1, b.s2, b.tf1, b.tf2, req)
@@ -700,11 +700,11 @@ def test_gpu_mixed_scene_beside_equals_in_line(pkg, oracle):
             drecs[beside] = lib.distance(b.s1[:8000], b.s2[:8000], b.tf1[:8000], b.tf2[:8000], dreq)
         finally:
             lib.close()
-    assert all(recs[k].tobytes() == recs[0].tobytes() for k in (3, 2, 1))
-    assert all(drecs[k].tobytes() == drecs[0].tobytes() for k in (3, 2, 1))
+    assert all(recs[k].tobytes() == recs[0].tobytes() for k in (4, 2, 1))
+    assert all(drecs[k].tobytes() == drecs[0].tobytes() for k in (4, 2, 1))
     ML = bb.MeshLibrary(b.meshes)
     ref = oracle.mixed_collide_batch(b.shapes, b.verts, ML, b.s1, b.s2, b.tf1, b.tf2, req, n_threads=32)
-    got = recs[3]
+    got = recs[2]
     assert not np.any((got["status"] >> 31) & 1)
     clear = np.abs(ref["distance"]) > 1e-9
     assert np.array_equal((got["num_contacts"] > 0)[clear], (ref["num_contacts"] > 0)[clear])
