@@ -151,7 +151,7 @@ struct hfcl_lib {
   // kinds within +-5 %; shorter budgets lose (200 000: 3.5 against 3.3 at 400 000, 100 000: 6.8 ms -- every cut walks the chunks
   // behind a contact for nothing and pays three launches).  mesh x mesh: off -- its waves are busy 79 % of the kernel's time already
   // and cfg4 went 2.97 -> 3.18 ms (profiles/r04_j)
-  uint32_t bvh_cut_ticks = 0, shape_cut_ticks = 600000;
+  uint32_t bvh_cut_ticks = 0, shape_cut_ticks = 350000;  // (600 000 until the queries' own phase became three kernels: profiles/r06_g section 5)
   uint32_t shape_budget0_coop = 16;
   // Mesh x mesh queries past their step budget are continued by k_bvh_coop (a wave per query, 64 stack entries per trip)
   // instead of task levels (HFCL_BVH_COOP=0: the levels).  cfg4, budgets 160 / 192 / 256 / 320 / 384: 100k queries 3.82 / 3.53 /
