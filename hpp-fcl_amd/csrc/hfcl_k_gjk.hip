@@ -259,6 +259,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFCL_W
 // (13 serialised scratch loads per trip in k_gjk_cvx<2,0>).  With the second hull in LDS the scan issues
 // its reads back to back, the winner's coordinates are one indexed LDS read instead of a select chain, and nothing
 // is spilled.
+#ifndef HFCL_HULL_LDS_BATCH
+#define HFCL_HULL_LDS_BATCH 4
+#endif
 template <typename T, int W, int NT>
 struct HullLds {
   static constexpr int VPL = (HULL_MAX + W - 1) / W;
@@ -276,6 +279,35 @@ struct HullLds {
     }
   }
   __device__ __forceinline__ V3<T> support(const V3<T>& dir, int lig) const {
+#if HFCL_HULL_LDS_BATCH
+    // the reads of HFCL_HULL_LDS_BATCH vertices in flight together, then their products: left to itself the scheduler reads two values, waits, multiplies
+    // (24 exposed LDS latencies per scan at two waves per SIMD, profiles/r06_f); the products and their order are the loop's
+    constexpr int B = HFCL_HULL_LDS_BATCH;
+    T best = T(0);
+    int bi = lig * VPL;
+#pragma unroll
+    for (int k0 = 0; k0 < VPL; k0 += B) {
+      T vx[B], vy[B], vz[B];
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        vx[j] = lane[(3 * (k0 + j) + 0) * NT];
+        vy[j] = lane[(3 * (k0 + j) + 1) * NT];
+        vz[j] = lane[(3 * (k0 + j) + 2) * NT];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const T d = vx[j] * dir.x + vy[j] * dir.y + vz[j] * dir.z;
+        if (k0 + j == 0) {
+          best = d;
+        } else if (d > best) {
+          best = d;
+          bi = lig * VPL + k0 + j;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
     T best = lane[0] * dir.x + lane[NT] * dir.y + lane[2 * NT] * dir.z;
     int bi = lig * VPL;
 #pragma unroll
@@ -286,6 +318,7 @@ struct HullLds {
         bi = lig * VPL + k;
       }
     }
+#endif
     butterfly_stages<W>([&](auto stage) {
       constexpr int M = decltype(stage)::value;
       const T od = group_exchange<W, M>(best);
