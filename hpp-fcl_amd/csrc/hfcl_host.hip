@@ -2733,7 +2733,8 @@ extern "C" int hfcl_debug_walk_counters(hfcl_lib* lib, int solid, uint32_t* out3
   const uint32_t* src = solid ? lib->d_swalk_ctr : lib->d_walk_ctr;
   if (src && hipMemcpy(out34, src, 8 * WALK_ROUNDS * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return HFCL_ERR_HIP;
   uint32_t ctr[BVH_CTR_WORDS] = {0};
-  const uint32_t* bsrc = (!solid && lib->d_bvh2_ctr && lib->mesh_st2) ? lib->d_bvh_ctr : lib->d_bvh_ctr;
+  // (a mixed batch run beside walks its mesh x mesh pairs on the second set of tables; otherwise the kind walked last owns the first)
+  const uint32_t* bsrc = (!solid && lib->d_bvh2_ctr) ? lib->d_bvh2_ctr : lib->d_bvh_ctr;
   if (bsrc && hipMemcpy(ctr, bsrc, sizeof(ctr), hipMemcpyDeviceToHost) != hipSuccess) return HFCL_ERR_HIP;
   out34[32] = ctr[BVH_CTR_TASKS];
   out34[33] = ctr[BVH_CTR_SUSPENDED];

@@ -6,7 +6,7 @@ set -e
 t1=$1; t2=$2; pre=$3
 sha=$(python -c "import json;print(json.load(open('gpurun_out/$t1/traffic_cfg3.json'))['source_sha'])")
 cp gpurun_out/$t1/traffic_cfg*.json profiles/
-for wl in cfg3 cfg5 cfg4 cfg4d cfg4s; do
+for wl in cfg3 cfg5 cfg4 cfg4d cfg4s cfgmix; do
   { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --workload $wl --no-cpu-baseline --no-secondary  (tools/measure_all.sh $t1, device code"
     echo "# source_sha $sha); the database is kept as gpurun_out/$t1/${wl}_results.db (scratch, not committed)"
     cat gpurun_out/$t1/${wl}_kernel_trace_stats.txt; } > profiles/${pre}_${wl}_kernel_trace_stats.txt

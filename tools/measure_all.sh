@@ -8,10 +8,10 @@ tag=${1:-final}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-for wl in cfg3 cfg2 cfg5 cfg4 cfg1 cfg4d cfg4s; do
+for wl in cfg3 cfg2 cfg5 cfg4 cfg1 cfg4d cfg4s cfg3u cfgmix; do
   timeout 900 python tools/measure_traffic.py --workload $wl --out $out/traffic_$wl.json > $out/traffic_$wl.log 2>&1 || echo "traffic $wl FAILED"
 done
-for wl in cfg3 cfg5 cfg4 cfg4d cfg4s; do
+for wl in cfg3 cfg5 cfg4 cfg4d cfg4s cfgmix; do
   rm -rf $out/prof_$wl
   timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof_$wl -o $wl -- python bench.py --workload $wl --no-cpu-baseline --no-secondary > $out/prof_$wl.log 2>&1
   db=$(find $out/prof_$wl -name "*.db" | head -1)
