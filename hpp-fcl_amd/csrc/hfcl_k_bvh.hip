@@ -46,6 +46,9 @@ __device__ __forceinline__ BvhSum<T>* bvh_sum(const BvhSplit& sp, uint32_t slot)
 // ---------------------------------------------------------------------------------------
 // Mesh x solid with one query per LANE: pieces of the SOLID form of k_bvh_collide (below) and of k_bvh_shape_finish.
 // ---------------------------------------------------------------------------------------
+#ifndef HFCL_LANE_SOLID_BATCH
+#define HFCL_LANE_SOLID_BATCH 4
+#endif
 template <typename T>
 struct LaneSolid {  // support of the solid in its own frame, by one lane (ConvexBase: serial scan, first maximum wins)
   DShape<T> s;
@@ -54,7 +57,27 @@ struct LaneSolid {  // support of the solid in its own frame, by one lane (Conve
     if (s.kind != K_CONVEX) return prim_support(s, d);
     uint32_t best = 0;
     T bd = v[0] * d.x + v[1] * d.y + v[2] * d.z;
-    for (uint32_t i = 1; i < s.num_points; ++i) {
+    uint32_t i = 1;
+#if HFCL_LANE_SOLID_BATCH
+    // HFCL_LANE_SOLID_BATCH vertices (four: 96 consecutive bytes in fp64) fetched together, then their products in the scan's order: one vertex per trip of a loop
+    // of unknown length was one exposed load latency per vertex, 32 per support call of a convex solid
+    constexpr uint32_t LB = HFCL_LANE_SOLID_BATCH;
+    for (; i + LB <= s.num_points; i += LB) {
+      T a[3 * LB];
+#pragma unroll
+      for (int j = 0; j < int(3 * LB); ++j) a[j] = v[3 * size_t(i) + size_t(j)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < int(LB); ++j) {
+        const T x = a[3 * j] * d.x + a[3 * j + 1] * d.y + a[3 * j + 2] * d.z;
+        if (x > bd) {
+          bd = x;
+          best = i + uint32_t(j);
+        }
+      }
+    }
+#endif
+    for (; i < s.num_points; ++i) {
       const T x = v[3 * size_t(i)] * d.x + v[3 * size_t(i) + 1] * d.y + v[3 * size_t(i) + 2] * d.z;
       if (x > bd) {
         bd = x;
