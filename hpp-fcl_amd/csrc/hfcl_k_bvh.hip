@@ -3191,35 +3191,53 @@ __global__ void __launch_bounds__(256) k_item_scatter(Work wk, LibView<T> lib, W
     __syncthreads();
   }
 }
-template <typename T>
+template <typename T, bool REDO>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
-k_shape_leaves(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, WalkArgs wa, int redo) {
+k_shape_leaves(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, WalkArgs wa) {
   __shared__ T w0_slab[W0Lds<T, 64>::WORDS];
   const W0Lds<T, 64> leaf_ps{w0_slab + threadIdx.x};
   const WalkRec<T>* const recs = reinterpret_cast<const WalkRec<T>*>(wa.recs);
   TriLeafOut<T>* const res = reinterpret_cast<TriLeafOut<T>*>(wa.res);
-  const uint32_t n_items = redo ? min(wa.ctr[8 * wa.round + 5], wa.list_stride) : min(wa.ctr[8 * wa.round + 1], wa.item_cap);
+  const uint32_t n_items = REDO ? min(wa.ctr[8 * wa.round + 5], wa.list_stride) : min(wa.ctr[8 * wa.round + 1], wa.item_cap);
   for (uint32_t base = blockIdx.x * 64u; base < n_items; base += gridDim.x * 64u) {
     if (base + threadIdx.x < n_items) {
-      const uint32_t it = wa.perm ? (redo ? wa.perm + wa.item_cap : wa.perm)[base + threadIdx.x] : base + threadIdx.x;
-      const uint32_t item = redo ? wa.redo[it] : wa.items[it];
-      const WalkRec<T>* const r = recs + (item & 0x0FFFFFFFu);
-      const uint32_t s2 = item >> 28, pair = r->pair, prim = r->leaf1[s2];
+      const uint32_t it = wa.perm ? (REDO ? wa.perm + wa.item_cap : wa.perm)[base + threadIdx.x] : base + threadIdx.x;
+      const uint32_t item_code = REDO ? wa.redo[it] : wa.items[it];
+      const WalkRec<T>* const r = recs + (item_code & 0x0FFFFFFFu);
+      const uint32_t s2 = item_code >> 28, pair = r->pair, prim = r->leaf1[s2];
       const uint32_t id1 = wk.shape1[pair], id2 = wk.shape2[pair];
       const bool swapped = lib.kinds[id1] != uint8_t(K_BVH);
       const uint32_t solid_id = swapped ? id1 : id2;
       const DMesh m1 = bv.meshes[lib.shapes[swapped ? id2 : id1].bvh_index];
-      SolidLeafIn<T> in{bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + prim), lib.shapes, lib.verts, swapped ? io.tf2 : io.tf1, swapped ? io.tf1 : io.tf2,
-                        redo ? reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer) : nullptr, &wk.counts[CTR_SHAPE_DEFER], wk.shape_defer_cap, pair, solid_id, prim, 0xFFFFFFFFu, 0u,
-                        T(0), -1};
-      SolidLeafOut<T> lo;
-      const bool to_epa = solid_leaf_call<T>(in, &q, leaf_ps, initial_guess<T>(io, q, pair), &lo);  // (split walks start every leaf from the request's guess)
-      if (!redo) {
-        TriLeafOut<T> tlo;
-        tlo.distance = to_epa ? walk_leaf_epa<T>() : lo.distance;
-        tlo.p1 = lo.p1;
-        tlo.p2 = lo.p2;
-        tlo.n = lo.n;
+      // the leaf INLINE (the same mesh_shape_leaf_lane as solid_leaf_call's: here no walk shares the lane's registers with it, and a call's
+      // argument block and saved registers were 320 B of scratch per lane -- 230 MB written per 100k cfg4s queries)
+      const uint32_t* const t3 = bv.tris + 3 * size_t(m1.tri_off + prim);
+      const T* const mv = bv.verts + 3 * size_t(m1.vert_off);
+      auto vtx = [&](uint32_t i) { return mk<T>(mv[3 * size_t(i)], mv[3 * size_t(i) + 1], mv[3 * size_t(i) + 2]); };
+      const V3<T> ta = vtx(t3[0]), tb = vtx(t3[1]), tc = vtx(t3[2]);
+      LaneSolid<T> solid;
+      solid.s = lib.shapes[solid_id];
+      solid.v = lib.verts + 3 * size_t(solid.s.vertex_offset);
+      auto tfm_of = [&]() { return load_pose(swapped ? io.tf2 : io.tf1, pair); };
+      auto tfs_of = [&]() { return load_pose(swapped ? io.tf1 : io.tf2, pair); };
+      const MDiff<T> sMt = make_mdiff(tfs_of(), tfm_of());  // Transform3f::inverseTimes: the mesh frame in the solid's frame
+      V3<T> guess = initial_guess<T>(io, q, pair);  // (split walks start every leaf from the request's guess)
+      ShapeDeferItem<T> item;
+      TriLeafOut<T> tlo;
+      const bool to_epa = mesh_shape_leaf_lane(ta, tb, tc, sMt, tfm_of, tfs_of, solid.s, solid, swept_radius(solid.s), q, guess, leaf_ps, tlo.distance, tlo.p1, tlo.p2, tlo.n, item);
+      if constexpr (REDO) {
+        if (to_epa) {  // (always: the resolve kernel listed the leaf because this run's twin said so)
+          item.seed.pair = pair;
+          item.prim = prim;
+          item.parent = 0xFFFFFFFFu;
+          item.order = 0u;
+          item.bound = T(0);
+          item.prev_prim = -1;
+          const uint32_t slot = atomicAdd(&wk.counts[CTR_SHAPE_DEFER], 1u);
+          if (slot < wk.shape_defer_cap) reinterpret_cast<ShapeDeferItem<T>*>(wk.shape_defer)[slot] = item;
+        }
+      } else {
+        if (to_epa) tlo.distance = walk_leaf_epa<T>();
         res[it] = tlo;
       }
     }
@@ -3621,13 +3639,13 @@ void launch_bvh_shape_fast(int grid, int grid_finish, int coop_grid, hipStream_t
         hipLaunchKernelGGL((k_item_kinds<T>), dim3(sgrid), dim3(256), 0, st, wk, lv, wa, 0);
         hipLaunchKernelGGL((k_item_scatter<T>), dim3(sgrid), dim3(256), 0, st, wk, lv, wa, 0);
       }
-      hipLaunchKernelGGL((k_shape_leaves<T>), dim3(lgrid), dim3(64), 0, st, wk, lv, bv, io, q, wa, 0);
+      hipLaunchKernelGGL((k_shape_leaves<T, false>), dim3(lgrid), dim3(64), 0, st, wk, lv, bv, io, q, wa);
       hipLaunchKernelGGL((k_bvh_resolve<T, true>), dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, wk, lv, io, q, s0, wa);
       if (wa.perm) {
         hipLaunchKernelGGL((k_item_kinds<T>), dim3(std::max(1, sgrid / 8)), dim3(256), 0, st, wk, lv, wa, 1);
         hipLaunchKernelGGL((k_item_scatter<T>), dim3(std::max(1, sgrid / 8)), dim3(256), 0, st, wk, lv, wa, 1);
       }
-      hipLaunchKernelGGL((k_shape_leaves<T>), dim3(lgrid), dim3(64), 0, st, wk, lv, bv, io, q, wa, 1);
+      hipLaunchKernelGGL((k_shape_leaves<T, true>), dim3(lgrid), dim3(64), 0, st, wk, lv, bv, io, q, wa);
     } else {
       launch_collide_kernel<T>(false, grid, st, wk, lv, bv, io, q, bp, break_distance2, s0, spill, true);
     }
