@@ -2899,6 +2899,9 @@ template <typename T> __device__ __forceinline__ T walk_leaf_epa() { return -Lim
 #ifndef HFCL_WPE_BVH_WALK
 #define HFCL_WPE_BVH_WALK 2
 #endif
+#ifndef HFCL_TRI_LEAVES_INLINE
+#define HFCL_TRI_LEAVES_INLINE 1
+#endif
 #ifndef HFCL_WALK_NODE_CACHE
 #define HFCL_WALK_NODE_CACHE 1
 #endif
@@ -3261,8 +3264,34 @@ k_tri_leaves(Work wk, LibView<T> lib, BvhView<T> bv, IO<T> io, QParams<T> q, Wal
       const uint32_t s2 = item >> 28, pair = r->pair;
       const DMesh m1 = bv.meshes[lib.shapes[wk.shape1[pair]].bvh_index], m2 = bv.meshes[lib.shapes[wk.shape2[pair]].bvh_index];
       TriLeafOut<T> tlo;
+#if HFCL_TRI_LEAVES_INLINE
+      {  // the leaf inline (k_bvh_collide's form of it): no walk shares the lane's registers here, and the call cost 192 B of scratch per lane
+        const T* const v1 = bv.verts + 3 * size_t(m1.vert_off);
+        const T* const v2 = bv.verts + 3 * size_t(m2.vert_off);
+        const uint32_t* const t1 = bv.tris + 3 * size_t(m1.tri_off + r->leaf1[s2]);
+        const uint32_t* const t2 = bv.tris + 3 * size_t(m2.tri_off + r->leaf2[s2]);
+        auto vtx = [](const T* v, uint32_t i) { return mk<T>(v[3 * size_t(i)], v[3 * size_t(i) + 1], v[3 * size_t(i) + 2]); };
+        TriSupport<T> tri;
+        {
+          const Pose<T> tf1 = load_pose(io.tf1, pair);
+          tri.p1 = xform(tf1, vtx(v1, t1[0]));
+          tri.p2 = xform(tf1, vtx(v1, t1[1]));
+          tri.p3 = xform(tf1, vtx(v1, t1[2]));
+        }
+        {
+          const Pose<T> tf2 = load_pose(io.tf2, pair);
+          tri.q1 = xform(tf2, vtx(v2, t2[0]));
+          tri.q2 = xform(tf2, vtx(v2, t2[1]));
+          tri.q3 = xform(tf2, vtx(v2, t2[2]));
+        }
+        int gst, git;
+        tlo.distance = tri_tri_distance(tri, q.gjk, q.guess_mode == HFCL_GUESS_CACHED, mk<T>(q.guess[0], q.guess[1], q.guess[2]), tlo.p1, tlo.p2, tlo.n, gst, git,
+                                        (V3<T>*)nullptr, leaf_ps);
+      }
+#else
       tri_leaf_call<T>(bv.verts + 3 * size_t(m1.vert_off), bv.tris + 3 * size_t(m1.tri_off + r->leaf1[s2]), bv.verts + 3 * size_t(m2.vert_off),
                        bv.tris + 3 * size_t(m2.tri_off + r->leaf2[s2]), io.tf1, io.tf2, pair, &q, leaf_ps, &tlo);
+#endif
       res[it] = tlo;
     }
   }
