@@ -272,6 +272,8 @@ struct hfcl_lib {
   bool shape_walk_sort = true;       // option shape_walk_sort = 0: the listed leaves evaluated in the order the walks listed them
   bool shape_walk = true;            // option shape_walk = 0: the queries' own phase of mesh x solid collide() by k_bvh_collide's SOLID form (walk and leaves in one kernel)
   uint32_t shape_walk_budget = 256;  // box tests a query's walk may take before k_bvh_shape_coop continues it
+  uint32_t shape_walk_min = 65536;   // batch size from which that phase is used (its eight launches are 0.2 ms of latency: 20k queries 1.63 against 1.42 ms,
+                                     // 50k 1.96 / 1.82, 100k 2.43 / 2.70, 200k 3.55 / 4.16)
   size_t epa_resume_slots = 0, bvh_task_slots = 0;  // options epa_resume_slots / bvh_task_slots (0: sized by the batch)
   bool bvh_force_wide = false, pipe_trace = false;   // options bvh_force_wide / pipe_trace
   bool walk_early_coop = true;                               // HFCL_BVH_WALK_EARLY_COOP: the queries round 0 hands over are continued beside the later rounds
@@ -511,7 +513,7 @@ static const char* const* option_keys() {
       "closed_staged", "split", "epa_cc_staged", "epa_records_aside", "epa_general_staged", "shape_finish_tiers", "shape_finish_aside",
       "epa_general_staged_min", "epa64_two_streams", "epa_cc_staged_min", "pipe_chunk", "bvh_filter", "bvh_shape_lane", "shape_coop",
       "bvh_cut_ticks", "shape_cut_ticks", "bvh_coop", "bvhd_budget", "bvhd_pool", "shape_dist_pool", "pool_rerun", "bvh_walk_early_coop",
-      "bvh_walk_rounds", "bvh_walk_order", "mesh_beside", "mesh_prio", "shape_walk", "shape_walk_sort", "shape_walk_budget", "bvh_walk_k", "bvh_walk_budget", "shape_dist_leaf_min", "shape_dist_starve", "bvhd_leaf_min", "bvhd_starve",
+      "bvh_walk_rounds", "bvh_walk_order", "mesh_beside", "mesh_prio", "shape_walk", "shape_walk_sort", "shape_walk_budget", "shape_walk_min", "bvh_walk_k", "bvh_walk_budget", "shape_dist_leaf_min", "shape_dist_starve", "bvhd_leaf_min", "bvhd_starve",
       "bvhd_part_min", "shape_dist_budget", "bvh_budget0_coop", "shape_budget0", "shape_budget", "shape_leaf_cost", "shape_levels",
       "climb_min", "bvh_budget", "bvh_budget0", "bvh_levels", "cvx_w", "epa_resume_slots", "bvh_task_slots", "bvh_force_wide",
       "pipe_trace", nullptr};
@@ -566,6 +568,7 @@ static int apply_option(hfcl_lib* lib, const std::string& key, const char* v) {
   else if (key == "mesh_prio") lib->mesh_prio = on;
   else if (key == "shape_walk_sort") lib->shape_walk_sort = on;
   else if (key == "shape_walk_budget") lib->shape_walk_budget = u32(0);
+  else if (key == "shape_walk_min") lib->shape_walk_min = u32(0);
   else if (key == "bvh_walk_rounds") { lib->walk_rounds = uint32_t(std::min<long long>(std::max(0ll, i), WALK_ROUNDS)); lib->walk_auto = false; }
   else if (key == "bvh_walk_k") { parse_list(v, lib->walk_k, 0, WALK_ROUNDS, 1u, uint32_t(WALK_K)); lib->walk_auto = false; }  // "6,16": per round
   else if (key == "bvh_walk_budget") parse_list(v, lib->walk_budget, 1, WALK_ROUNDS, 0u, 0xFFFFFFFFu);  // rounds 1 ...: box tests (round 0 takes bvh_budget0_coop's)
@@ -1520,7 +1523,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
           split.budget = lib->shape_budget;
           split.n_levels = lib->shape_levels;
           // the queries' own phase as walk / leaves / resolve (one round; what is left of a walk is k_bvh_shape_coop's)
-          if (split.coop && lib->shape_walk && n < (size_t(1) << 28)) {
+          if (split.coop && lib->shape_walk && n >= lib->shape_walk_min && n < (size_t(1) << 28)) {
             r = ensure_swalk(lib, n);
             if (r) return r;
             HIP_TRY(hipMemsetAsync(lib->d_swalk_ctr, 0, (8 * WALK_ROUNDS + 64) * sizeof(uint32_t), st));

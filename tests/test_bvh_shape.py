@@ -606,6 +606,13 @@ def test_gpu_mesh_solid_collide_at_baseline_size(pkg, oracle):
         other = _device_collide(pkg, b, req, env=env)
         for f in got.dtype.names:
             assert _same(got[f], other[f], 0.0) if got[f].dtype.kind == "f" else np.array_equal(got[f], other[f]), (f, env)
+    # the queries' own phase: walk / leaves / resolve (default from 65 536 queries per batch) against k_bvh_collide's SOLID form and against the
+    # listed leaves evaluated as listed; forced on a batch below its threshold as well
+    for env in (dict(HFCL_SHAPE_WALK="0"), dict(HFCL_SHAPE_WALK_SORT="0")):
+        other = _device_collide(pkg, b, req, env=env)
+        assert got.tobytes() == other.tobytes(), env
+    small = wl.mesh_vs_solid("mixed", n=3000, seed=5)
+    assert _device_collide(pkg, small, req, env=dict(HFCL_SHAPE_WALK_MIN="0")).tobytes() == _device_collide(pkg, small, req).tobytes()
 
 
 def test_mesh_vs_flats_headers_match_oracle(pkg, oracle, hostsim):
