@@ -113,6 +113,10 @@ struct hfcl_lib {
   // (1, 2: when the library's last batch held meshes and solids); 4: as 2 whatever the last batch held
   uint32_t mesh_beside = 2;
   bool mesh_prio = false;  // option mesh_prio = 1: the streams of the mesh x solid walks at the device's highest priority (read when they are created)
+  // the solids' GJK kernels of a small batch run beside each other on these (option gjk_beside_max): one bucket's kernel does not fill the chip
+  hipStream_t gjk_st[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t gjk_fork = nullptr, gjk_join[3] = {nullptr, nullptr, nullptr};
+  uint32_t gjk_beside_max = 120000;  // largest batch whose GJK kernels fan out (0: never; below the size from which batches run as two halves)
   hipStream_t walk_st[WALK_ROUNDS - 1] = {};  // mesh x mesh collide(): the continuation of what round r of the walk hands over runs on walk_st[r]
   hipEvent_t walk_fork[WALK_ROUNDS - 1] = {}, walk_join[WALK_ROUNDS - 1] = {};
   hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr, ev_aux2 = nullptr, ev_aux3 = nullptr;  // fork / join of the EPA tail; of k_bvh_shape_finish's first half
@@ -513,7 +517,7 @@ static const char* const* option_keys() {
       "closed_staged", "split", "epa_cc_staged", "epa_records_aside", "epa_general_staged", "shape_finish_tiers", "shape_finish_aside",
       "epa_general_staged_min", "epa64_two_streams", "epa_cc_staged_min", "pipe_chunk", "bvh_filter", "bvh_shape_lane", "shape_coop",
       "bvh_cut_ticks", "shape_cut_ticks", "bvh_coop", "bvhd_budget", "bvhd_pool", "shape_dist_pool", "pool_rerun", "bvh_walk_early_coop",
-      "bvh_walk_rounds", "bvh_walk_order", "mesh_beside", "mesh_prio", "shape_walk", "shape_walk_sort", "shape_walk_budget", "shape_walk_min", "bvh_walk_k", "bvh_walk_budget", "shape_dist_leaf_min", "shape_dist_starve", "bvhd_leaf_min", "bvhd_starve",
+      "bvh_walk_rounds", "bvh_walk_order", "mesh_beside", "mesh_prio", "shape_walk", "shape_walk_sort", "shape_walk_budget", "shape_walk_min", "gjk_beside_max", "bvh_walk_k", "bvh_walk_budget", "shape_dist_leaf_min", "shape_dist_starve", "bvhd_leaf_min", "bvhd_starve",
       "bvhd_part_min", "shape_dist_budget", "bvh_budget0_coop", "shape_budget0", "shape_budget", "shape_leaf_cost", "shape_levels",
       "climb_min", "bvh_budget", "bvh_budget0", "bvh_levels", "cvx_w", "epa_resume_slots", "bvh_task_slots", "bvh_force_wide",
       "pipe_trace", nullptr};
@@ -569,6 +573,7 @@ static int apply_option(hfcl_lib* lib, const std::string& key, const char* v) {
   else if (key == "shape_walk_sort") lib->shape_walk_sort = on;
   else if (key == "shape_walk_budget") lib->shape_walk_budget = u32(0);
   else if (key == "shape_walk_min") lib->shape_walk_min = u32(0);
+  else if (key == "gjk_beside_max") lib->gjk_beside_max = u32(0);
   else if (key == "bvh_walk_rounds") { lib->walk_rounds = uint32_t(std::min<long long>(std::max(0ll, i), WALK_ROUNDS)); lib->walk_auto = false; }
   else if (key == "bvh_walk_k") { parse_list(v, lib->walk_k, 0, WALK_ROUNDS, 1u, uint32_t(WALK_K)); lib->walk_auto = false; }  // "6,16": per round
   else if (key == "bvh_walk_budget") parse_list(v, lib->walk_budget, 1, WALK_ROUNDS, 0u, 0xFFFFFFFFu);  // rounds 1 ...: box tests (round 0 takes bvh_budget0_coop's)
@@ -667,6 +672,11 @@ void hfcl_lib_destroy(hfcl_lib* lib) {
   for (hipEvent_t e : {lib->ev_mesh_fork, lib->ev_mesh_join, lib->ev_mesh_fork2, lib->ev_mesh_join2})
     if (e) hipEventDestroy(e);
   hipFree(lib->d_bvh2_tasks); hipFree(lib->d_bvh2_sums); hipFree(lib->d_bvh2_susp); hipFree(lib->d_bvh2_ctr);
+  for (int k = 0; k < 3; ++k) {
+    if (lib->gjk_st[k]) hipStreamDestroy(lib->gjk_st[k]);
+    if (lib->gjk_join[k]) hipEventDestroy(lib->gjk_join[k]);
+  }
+  if (lib->gjk_fork) hipEventDestroy(lib->gjk_fork);
   for (int k = 0; k < WALK_ROUNDS - 1; ++k) {
     if (lib->walk_st[k]) hipStreamDestroy(lib->walk_st[k]);
     if (lib->walk_fork[k]) hipEventDestroy(lib->walk_fork[k]);
@@ -1289,6 +1299,27 @@ static int ensure_walk_streams(hfcl_lib* lib) {
   for (int k = 0; k < WALK_ROUNDS - 1; ++k) lib->walk_st[k] = s[k];
   return HFCL_OK;
 }
+static int ensure_gjk_streams(hfcl_lib* lib) {
+  if (lib->gjk_fork) return HFCL_OK;  // (committed last)
+  hipStream_t s[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipStreamCreateWithFlags(&s[k], hipStreamNonBlocking);
+  for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+  if (e != hipSuccess) {
+    for (auto x : ev)
+      if (x) hipEventDestroy(x);
+    for (auto x : s)
+      if (x) hipStreamDestroy(x);
+    HIP_TRY(e);
+  }
+  for (int k = 0; k < 3; ++k) {
+    lib->gjk_st[k] = s[k];
+    lib->gjk_join[k] = ev[k];
+  }
+  lib->gjk_fork = ev[3];
+  return HFCL_OK;
+}
 template <typename T, int M>
 static int auto_cvx_w() {
   return (sizeof(T) == 8 && M == 0) ? 4 : 2;
@@ -1302,9 +1333,10 @@ static void launch_cvx_m(hfcl_lib* lib, const Work& wk, const LibView<T>& lv, co
   if (b > size_t(lib->n_cus) * 16) b = size_t(lib->n_cus) * 16;
   launch_gjk_cvx<T>(M, w, q.guess_mode == HFCL_GUESS_BOUNDING_VOLUME, int(b), st, wk, lv, io, q);
 }
-template <typename T>
+// (next_stream, optional: called in front of every kernel, returns the stream it goes on -- the solids' kernels of a small batch fan out)
+template <typename T, class Next>
 static void launch_cvx(hfcl_lib* lib, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q,
-                       hipStream_t st, size_t& ti, size_t n) {
+                       hipStream_t st, size_t& ti, size_t n, Next&& next_stream) {
   KernelTime* t = nullptr;
   auto tbeg = [&](const char* name) {
     if (!lib->kernel_timing) return;
@@ -1315,16 +1347,19 @@ static void launch_cvx(hfcl_lib* lib, const Work& wk, const LibView<T>& lv, cons
     if (lib->kernel_timing) hipEventRecord(t->e1, st);
   };
   if ((lib->possible_buckets >> B_CC) & 1u) {
+    st = next_stream();
     tbeg("k_gjk_cvx<cc>");
     launch_cvx_m<T, 0>(lib, wk, lv, io, q, st, n);
     tend();
   }
   if ((lib->possible_buckets >> B_PC) & 1u) {
+    st = next_stream();
     tbeg("k_gjk_cvx<pc>");
     launch_cvx_m<T, 1>(lib, wk, lv, io, q, st, n);
     tend();
   }
   if ((lib->possible_buckets >> B_CP) & 1u) {
+    st = next_stream();
     tbeg("k_gjk_cvx<cp>");
     launch_cvx_m<T, 2>(lib, wk, lv, io, q, st, n);
     tend();
@@ -1408,30 +1443,62 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
 
   // the solids' kernels of the batch (closed forms, GJK; their EPA follows below, behind the mesh walks: a mesh x solid leaf can queue for it)
   auto launch_solids = [&]() -> int {
+    // A small batch (option gjk_beside_max) of a library without meshes: its buckets' kernels -- independent of each other, each a chain of
+    // GJK trips on a chip it does not fill -- fan out over the caller's stream and three helpers, joined in front of the EPA section
+    // (cfg5 at 20 000 pairs: four GJK kernels of 40-116 us in a row).
+    // From three iterative kernels on: a fork and a join cost ~0.08 ms themselves (cfg2, closed forms + one GJK kernel: 0.10 -> 0.20 ms with them).
+    int kernels = 0;
+    for (int b : {int(B_PRIM), int(B_CC), int(B_PC), int(B_CP), int(B_LARGE), int(B_TRI)}) kernels += may(b) ? 1 : 0;
+    bool fan = lib->gjk_beside_max && n <= lib->gjk_beside_max && lib->h_meshes.empty() && kernels >= 3;
+    if (fan && ensure_gjk_streams(lib) != HFCL_OK) fan = false;
+    hipStream_t const caller = st;
+    int fan_i = 0;
+    uint32_t used = 0;
+    if (fan) HIP_TRY(hipEventRecord(lib->gjk_fork, caller));
+    auto next_stream = [&]() -> hipStream_t {
+      if (!fan) return caller;
+      const int k = fan_i;
+      fan_i = (fan_i + 1) % 4;
+      if (k && !(used & (1u << (k - 1)))) {
+        used |= 1u << (k - 1);
+        (void)hipStreamWaitEvent(lib->gjk_st[k - 1], lib->gjk_fork, 0);
+      }
+      return k ? lib->gjk_st[k - 1] : caller;
+    };
     if (may(B_CLOSED)) {
+      st = next_stream();
       tbeg("k_closed");
       launch_closed<T>(blocks_for(n, 256), st, wk, lv, io, q, lib->closed_staged);
       tend();
     }
     if (may(B_PRIM)) {
+      st = next_stream();
       tbeg("k_gjk_prim");
       launch_gjk_prim<T>(blocks_for(n, 256), st, wk, lv, io, q, bvg);
       tend();
     }
 
-    launch_cvx<T>(lib, wk, lv, io, q, st, ti, n);
+    launch_cvx<T>(lib, wk, lv, io, q, caller, ti, n, next_stream);
 
     if (may(B_LARGE)) {
+      st = next_stream();
       tbeg("k_gjk_large");
       launch_gjk_large<T>(blocks_for(n, 256 / LARGE_W), st, wk, lv, io, q, bvg);
       tend();
     }
 
     if (may(B_TRI)) {
+      st = next_stream();
       tbeg("k_triangle");
       launch_triangle<T>(blocks_for(n / 8 + 1, 64 / BS_W), st, wk, lv, io, q);
       tend();
     }
+    st = caller;
+    for (int k = 0; k < 3; ++k)
+      if (used & (1u << k)) {
+        HIP_TRY(hipEventRecord(lib->gjk_join[k], lib->gjk_st[k]));
+        HIP_TRY(hipStreamWaitEvent(caller, lib->gjk_join[k], 0));
+      }
     return HFCL_OK;
   };
   // the mesh walks of the batch

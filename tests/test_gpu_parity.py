@@ -412,6 +412,28 @@ def test_full_size_properties(pkg, oracle, torch_cuda, case):
     lib.close()
 
 
+@pytest.mark.parametrize("case,kw", [("cfg5_mixed", {}), ("all_primitives", {"kind": "distance"}), ("triangle_pairs", {}), ("large_convex", {})])
+def test_small_batch_kernels_beside_each_other(pkg, case, kw):
+    """Option gjk_beside_max: the solids' kernels of a small batch (closed forms, k_gjk_prim, the three k_gjk_cvx, k_gjk_large, k_triangle) on four
+    streams beside each other, joined in front of the EPA section -- every record and cached guess of the in-line order, twice per library."""
+    abi, wl = pkg.abi, pkg.workloads
+    for n in (2_000, 50_000):
+        b = getattr(wl, case)(n=n, seed=9, **kw)
+        req = wl.make_request(b, abi)
+        out = {}
+        for fan in (120_000, 0):
+            lib = pkg.Library(b.lib, options={"gjk_beside_max": fan})
+            try:
+                fn = lib.distance if b.kind == "distance" else lib.collide
+                first, g1 = fn(b.s1, b.s2, b.tf1, b.tf2, req, want_guess=True)
+                again, g2 = fn(b.s1, b.s2, b.tf1, b.tf2, req, want_guess=True)
+                assert first.tobytes() == again.tobytes() and g1.tobytes() == g2.tobytes()
+                out[fan] = (first, g1)
+            finally:
+                lib.close()
+        assert out[120_000][0].tobytes() == out[0][0].tobytes() and out[120_000][1].tobytes() == out[0][1].tobytes()
+
+
 @pytest.mark.parametrize("case", ["cfg3_convex_convex", "cfg5_mixed"])
 def test_split_batches_are_bit_identical(pkg, torch_cuda, case):
     """hfcl_lib_set_split(2): the two halves of a batch run on two streams; every record (and cached guess) is the
