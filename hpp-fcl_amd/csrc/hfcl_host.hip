@@ -116,6 +116,7 @@ struct hfcl_lib {
   // the solids' GJK kernels of a small batch run beside each other on these (option gjk_beside_max): one bucket's kernel does not fill the chip
   hipStream_t gjk_st[3] = {nullptr, nullptr, nullptr};
   hipEvent_t gjk_fork = nullptr, gjk_join[3] = {nullptr, nullptr, nullptr};
+  uint32_t epa_direct_max = 4096;    // largest batch whose EPA seeds all go to the full-capacity tier, the fast tiers not launched (0: never)
   uint32_t gjk_beside_max = 120000;  // largest batch whose GJK kernels fan out (0: never; below the size from which batches run as two halves)
   hipStream_t walk_st[WALK_ROUNDS - 1] = {};  // mesh x mesh collide(): the continuation of what round r of the walk hands over runs on walk_st[r]
   hipEvent_t walk_fork[WALK_ROUNDS - 1] = {}, walk_join[WALK_ROUNDS - 1] = {};
@@ -517,7 +518,7 @@ static const char* const* option_keys() {
       "closed_staged", "split", "epa_cc_staged", "epa_records_aside", "epa_general_staged", "shape_finish_tiers", "shape_finish_aside",
       "epa_general_staged_min", "epa64_two_streams", "epa_cc_staged_min", "pipe_chunk", "bvh_filter", "bvh_shape_lane", "shape_coop",
       "bvh_cut_ticks", "shape_cut_ticks", "bvh_coop", "bvhd_budget", "bvhd_pool", "shape_dist_pool", "pool_rerun", "bvh_walk_early_coop",
-      "bvh_walk_rounds", "bvh_walk_order", "mesh_beside", "mesh_prio", "shape_walk", "shape_walk_sort", "shape_walk_budget", "shape_walk_min", "gjk_beside_max", "bvh_walk_k", "bvh_walk_budget", "shape_dist_leaf_min", "shape_dist_starve", "bvhd_leaf_min", "bvhd_starve",
+      "bvh_walk_rounds", "bvh_walk_order", "mesh_beside", "mesh_prio", "shape_walk", "shape_walk_sort", "shape_walk_budget", "shape_walk_min", "gjk_beside_max", "epa_direct_max", "bvh_walk_k", "bvh_walk_budget", "shape_dist_leaf_min", "shape_dist_starve", "bvhd_leaf_min", "bvhd_starve",
       "bvhd_part_min", "shape_dist_budget", "bvh_budget0_coop", "shape_budget0", "shape_budget", "shape_leaf_cost", "shape_levels",
       "climb_min", "bvh_budget", "bvh_budget0", "bvh_levels", "cvx_w", "epa_resume_slots", "bvh_task_slots", "bvh_force_wide",
       "pipe_trace", nullptr};
@@ -574,6 +575,7 @@ static int apply_option(hfcl_lib* lib, const std::string& key, const char* v) {
   else if (key == "shape_walk_budget") lib->shape_walk_budget = u32(0);
   else if (key == "shape_walk_min") lib->shape_walk_min = u32(0);
   else if (key == "gjk_beside_max") lib->gjk_beside_max = u32(0);
+  else if (key == "epa_direct_max") lib->epa_direct_max = u32(0);
   else if (key == "bvh_walk_rounds") { lib->walk_rounds = uint32_t(std::min<long long>(std::max(0ll, i), WALK_ROUNDS)); lib->walk_auto = false; }
   else if (key == "bvh_walk_k") { parse_list(v, lib->walk_k, 0, WALK_ROUNDS, 1u, uint32_t(WALK_K)); lib->walk_auto = false; }  // "6,16": per round
   else if (key == "bvh_walk_budget") parse_list(v, lib->walk_budget, 1, WALK_ROUNDS, 0u, 0xFFFFFFFFu);  // rounds 1 ...: box tests (round 0 takes bvh_budget0_coop's)
@@ -1822,7 +1824,11 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     const bool general_q = may(B_PRIM) || may(B_PC) || may(B_CP) || (!F32 && may(B_CC));
     bool cc_staged = false;
     if constexpr (F32) cc_staged = may(B_CC) && lib->epa_cc_staged && n >= lib->epa_cc_staged_min;
-    const bool gen_staged = general_q && lib->epa_general_staged && n >= lib->epa_general_staged_min;
+    bool gen_staged = general_q && lib->epa_general_staged && n >= lib->epa_general_staged_min;
+    // A very small batch: the full-capacity tier alone, over every seed (k_epa_requeue) -- the batch is as long as its longest polytope either way, and
+    // the fast tier in front of the full one is a second such chain (cfg5's mix at 2 000 pairs: 0.18 + 0.22 ms)
+    // (fp64 only: its tiers are compiled without contraction and agree bit for bit; the fp32 tiers are different instantiations of contracted code)
+    const bool direct = sizeof(T) == 8 && lib->epa_direct_max && n <= lib->epa_direct_max;
     auto need_aux = [&]() -> int { return ensure_aux(lib); };
     auto tbeg_on = [&](const char* name, hipStream_t s) {
       if (!lib->kernel_timing) return;
@@ -1832,6 +1838,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
     auto tend_on = [&](hipStream_t s) {
       if (lib->kernel_timing) hipEventRecord(t->e1, s);
     };
+    if (direct) cc_staged = gen_staged = false;
     if (cc_staged) {
       if (lib->ws_capacity > lib->epa_ready_capacity) {
         hipFree(lib->d_epa_ready);
@@ -1864,6 +1871,13 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       launch_epa_prepare_general<T>(blocks_for(n / 4 + 1, 256), st, wk, lv, io, q, F32);
       tend();
     }
+    if (direct) {
+      tbeg("k_epa<full>");
+      launch_epa_requeue<T>(st, wk);
+      // (the grid: a lane group per seed, up to what k_epa's shape-0 support point area holds -- n_cus * 16 blocks)
+      launch_epa_full<T>(int(std::min<size_t>(blocks_for(n / 2 + 1, 64 / epa_we2<T>), size_t(lib->n_cus) * 16)), st, wk, lv, io, q);
+      tend();
+    } else {
     const int epa_batches = int(std::min<size_t>((n + 64 / EPA_WE - 1) / (64 / EPA_WE), size_t(1) << 22));
     tbeg("k_epa<fast>");
     // fp64 with both classes of pairs: their fast-tier kernels on two streams (each one's tail under the other's body)
@@ -1923,6 +1937,7 @@ static int run_batch_one(hfcl_lib* lib, const uint32_t* d_s1, const uint32_t* d_
       tbeg("k_epa<full>");
       launch_epa_full<T>(blocks_for(n / 16 + 1, 64 / epa_we2<T>), st, wk, lv, io, q);
       tend();
+    }
     }
   }
   // last: a launch of a few waves that, between the GJK and the EPA kernels, only waited for a free CU while the other

@@ -903,9 +903,31 @@ template <typename T>
 void launch_epa_full(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q) {
   hipLaunchKernelGGL((k_epa<T, epa_we2<T>, EPA_MAX_ITER, 2>), dim3(grid), dim3(64), 0, st, wk, lv, io, q);
 }
+// A very small batch (option epa_direct_max): every seed of the two fast queues moves to the full-capacity tier's queue, which then runs alone -- one
+// kernel as long as the batch's longest polytope instead of the fast tier (as long as ITS longest) and the full tier behind it.  One block: the queues hold
+// a few thousand seeds at most.  The fast tiers are not launched for such a batch.
+template <typename T>
+__global__ void __launch_bounds__(1024) k_epa_requeue(Work wk) {
+  __shared__ uint32_t base_s;
+  const uint32_t n_bottom = min(wk.counts[B_COUNT], wk.n), n_top = min(wk.counts[B_COUNT + 3], wk.n - n_bottom);
+  if (threadIdx.x == 0) base_s = wk.counts[B_COUNT + 1];
+  __syncthreads();
+  const uint32_t base = base_s;
+  const EpaItem<T>* const src = reinterpret_cast<const EpaItem<T>*>(wk.epa_queue);
+  EpaItem<T>* const dst = reinterpret_cast<EpaItem<T>*>(wk.epa_queue2);
+  for (uint32_t i = threadIdx.x; i < n_bottom + n_top; i += blockDim.x) dst[base + i] = src[i < n_bottom ? i : wk.n - 1u - (i - n_bottom)];
+  __syncthreads();
+  if (threadIdx.x == 0) wk.counts[B_COUNT + 1] = base + n_bottom + n_top;  // (the fast queues' counters stay: what hfcl_last_bucket_counts reports as seeds)
+}
+template <typename T>
+void launch_epa_requeue(hipStream_t st, const Work& wk) {
+  hipLaunchKernelGGL((k_epa_requeue<T>), dim3(1), dim3(1024), 0, st, wk);
+}
 #if HFCL_UNIT_F32
+template void launch_epa_requeue<float>(hipStream_t, const Work&);
 template void launch_epa_full<float>(int, hipStream_t, const Work&, const LibView<float>&, const IO<float>&, const QParams<float>&);
 #endif
 #if HFCL_UNIT_F64
+template void launch_epa_requeue<double>(hipStream_t, const Work&);
 template void launch_epa_full<double>(int, hipStream_t, const Work&, const LibView<double>&, const IO<double>&, const QParams<double>&);
 #endif

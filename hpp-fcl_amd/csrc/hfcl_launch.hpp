@@ -63,6 +63,7 @@ void launch_epa_records(int grid, hipStream_t st, const Work& wk, const LibView<
 template <typename T> void launch_epa_prepare_general(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool skip_top);
 template <typename T> void launch_epa_loop_general(int grid, hipStream_t st, hipStream_t st2, const Work& wk, const LibView<T>& lv, const QParams<T>& q, int n_cus, bool curved_class);
 template <typename T> void launch_epa_records_general(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q, bool skip_top);
+template <typename T> void launch_epa_requeue(hipStream_t st, const Work& wk);
 template <typename T> void launch_epa_full(int grid, hipStream_t st, const Work& wk, const LibView<T>& lv, const IO<T>& io, const QParams<T>& q);
 
 // A helper stream with its fork / join events: k_bvh_shape_finish for the items of whole walks runs there, beside the launches that walk the

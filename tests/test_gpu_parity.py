@@ -412,6 +412,39 @@ def test_full_size_properties(pkg, oracle, torch_cuda, case):
     lib.close()
 
 
+@pytest.mark.parametrize("case,kw", [("cfg5_mixed", {}), ("all_primitives", {"kind": "distance"}), ("cfg3_convex_convex", {}), ("large_convex", {"kind": "collide"})])
+@pytest.mark.parametrize("f32", [False, True])
+def test_tiny_batch_epa_in_the_full_tier_alone(pkg, torch_cuda, case, kw, f32):
+    """Option epa_direct_max: every EPA seed of a very small batch moved to the full-capacity tier's queue (k_epa_requeue), the fast tiers not launched --
+    the records of the two-tier order byte for byte (fp64; the fp32 path keeps its two tiers, whose instantiations round differently)."""
+    torch = torch_cuda
+    abi, wl = pkg.abi, pkg.workloads
+    dev = torch.device("cuda:0")
+    for n in (300, 4000):
+        b = getattr(wl, case)(n=n, seed=13, **kw)
+        req = wl.make_request(b, abi)
+        d_s1, d_s2 = (torch.from_numpy(x.astype(np.int32)).to(dev) for x in (b.s1, b.s2))
+        d_p1, d_p2 = (torch.from_numpy(x).to(dev) for x in ((b.pose1_f32, b.pose2_f32) if f32 else (b.tf1, b.tf2)))
+        words = 11 if f32 else 24
+        name = ("distance" if b.kind == "distance" else "collide") + ("_device_f32" if f32 else "_device")
+        recs = {}
+        for direct in (4096, 0):
+            lib = pkg.Library(b.lib, options={"epa_direct_max": direct})
+            try:
+                d_out = torch.zeros(len(b) * words, dtype=torch.int32, device=dev)
+                for _ in range(2):
+                    getattr(lib, name)(d_s1, d_s2, d_p1, d_p2, len(b), req, d_out)
+                    torch.cuda.synchronize()
+                recs[direct] = d_out.cpu().numpy().copy()
+                names = [k for k, _ in lib.last_kernel_breakdown()]
+                assert ("k_epa<fast>" in names) == (direct == 0 or f32), names  # (fp64 only: the fp32 tiers do not agree to the bit)
+                c = lib.last_bucket_counts()
+                assert c["epa_queue"] + c["epa_overflow"] > 0, c  # (large hulls queue for the full tier themselves)
+            finally:
+                lib.close()
+        assert recs[4096].tobytes() == recs[0].tobytes(), (case, n, f32)
+
+
 @pytest.mark.parametrize("case,kw", [("cfg5_mixed", {}), ("all_primitives", {"kind": "distance"}), ("triangle_pairs", {}), ("large_convex", {})])
 def test_small_batch_kernels_beside_each_other(pkg, case, kw):
     """Option gjk_beside_max: the solids' kernels of a small batch (closed forms, k_gjk_prim, the three k_gjk_cvx, k_gjk_large, k_triangle) on four
