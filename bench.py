@@ -767,6 +767,7 @@ def run_workload(ctx, workload, n_arg, steps, warmup, strong=False, cpu_budget_s
         result = {
             "workload": batch.name + (" (two batches in flight: even / odd steps on two streams)" if two_streams else ""),
             "tag": workload + ("/strong" if strong else "") + ("/2streams" if two_streams else "") + (
+                "/%dk" % (n // 1000) if (n_arg and not strong and n != DEFAULT_PAIRS.get(workload, 1_000_000)) else "") + (
                 "/gather=" + gather_mode if ctx.dist_on else ""),
             "batches_in_flight": 2 if two_streams else 1,
             "value": qps, "unit": "queries/s", "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
@@ -856,6 +857,8 @@ def main():
             plan.append(("cfg4d", 0, False, {}))  # configs[3]'s distance() variant: ~3 400 RSS tests + 215 triangle pairs per query
             plan.append(("cfg4s", 0, False, {}))  # configs[3]'s models against convex solids
             plan.append(("cfgmix", 0, False, {}))  # meshes and solids in one batch: the mesh walks beside the solids' kernels
+            # what a planner sends: 20 000 pairs per batch -- every kernel a chain of dependent steps on a chip it does not fill, independent chains beside each other
+            plan.append(("cfg5", 20_000, False, {}))
         if ctx.world > 1:  # the same list with the 24-B exchange format, and the headline without any exchange
             plan += [("cfg5", 10_000_000, True, dict(gather="compact")), ("cfg3", 0, False, dict(gather="none"))]
         for wl_name, pairs, st, kw in plan:
